@@ -1,0 +1,211 @@
+"""ctypes binding of the CPU oracle (oracle/tkz_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under tokenizer_amd/ may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libtkz_oracle.so")
+
+P1, CL100K, O200K = 1, 2, 3
+E_FORMAT, E_DUP_RANK, E_KEY_NOT_FOUND, E_CAPACITY, E_UTF8, E_ARG = -1, -2, -3, -4, -5, -6
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "tkz_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        vp, i64, i32, u8p = C.c_void_p, C.c_int64, C.c_int32, C.c_void_p
+        L.tkzo_vocab_load.restype = vp
+        L.tkzo_vocab_load.argtypes = [u8p, C.c_size_t, C.POINTER(C.c_int)]
+        L.tkzo_vocab_free.argtypes = [vp]
+        L.tkzo_vocab_size.restype = i64
+        L.tkzo_vocab_size.argtypes = [vp]
+        L.tkzo_vocab_max_key_len.argtypes = [vp]
+        L.tkzo_vocab_rank.restype = i32
+        L.tkzo_vocab_rank.argtypes = [vp, u8p, C.c_int]
+        L.tkzo_vocab_entry.argtypes = [vp, i64, u8p, C.c_int, C.POINTER(i32)]
+        L.tkzo_encoder_create.restype = vp
+        L.tkzo_encoder_create.argtypes = [vp, C.c_int, C.c_int]
+        L.tkzo_encoder_free.argtypes = [vp]
+        L.tkzo_encoder_add_special.argtypes = [vp, u8p, C.c_int, i32]
+        L.tkzo_bpe.restype = i64
+        L.tkzo_bpe.argtypes = [vp, u8p, i64, vp, i64]
+        L.tkzo_split_utf8.restype = i64
+        L.tkzo_split_utf8.argtypes = [C.c_int, u8p, i64, vp, vp, i64]
+        L.tkzo_split_utf16.restype = i64
+        L.tkzo_split_utf16.argtypes = [C.c_int, vp, i64, vp, vp, i64]
+        L.tkzo_encode_utf8.restype = i64
+        L.tkzo_encode_utf8.argtypes = [vp, u8p, i64, vp, i64]
+        L.tkzo_encode_utf16.restype = i64
+        L.tkzo_encode_utf16.argtypes = [vp, vp, i64, vp, i64]
+        L.tkzo_encode_special_utf8.restype = i64
+        L.tkzo_encode_special_utf8.argtypes = [vp, u8p, i64, vp, C.c_int, vp, i64]
+        L.tkzo_encode_batch.restype = i64
+        L.tkzo_encode_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, i64, vp, vp, C.c_int]
+        _lib = L
+    return _lib
+
+
+class OracleError(Exception):
+    def __init__(self, code):
+        super().__init__("oracle error %d" % code)
+        self.code = code
+
+
+def _buf(b):
+    return (C.c_uint8 * max(1, len(b))).from_buffer_copy(bytes(b) + (b"\0" if len(b) == 0 else b""))
+
+
+class Vocab:
+    """LoadTikTokenBpe + Init's duplicate-rank check."""
+
+    def __init__(self, data: bytes):
+        err = C.c_int(0)
+        self._h = lib().tkzo_vocab_load(_buf(data), len(data), C.byref(err))
+        if not self._h:
+            raise OracleError(err.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().tkzo_vocab_free(self._h)
+            self._h = None
+
+    def __len__(self):
+        return lib().tkzo_vocab_size(self._h)
+
+    @property
+    def max_key_len(self):
+        return lib().tkzo_vocab_max_key_len(self._h)
+
+    def rank(self, key: bytes):
+        return lib().tkzo_vocab_rank(self._h, _buf(key), len(key))
+
+    def entries(self):
+        n = len(self)
+        buf = (C.c_uint8 * 4096)()
+        r = C.c_int32(0)
+        out = []
+        for i in range(n):
+            k = lib().tkzo_vocab_entry(self._h, i, buf, 4096, C.byref(r))
+            out.append((bytes(buf[:k]), r.value))
+        return out
+
+    def bpe(self, piece: bytes):
+        out = np.empty(max(1, len(piece)), dtype=np.int32)
+        k = lib().tkzo_bpe(self._h, _buf(piece), len(piece), out.ctypes.data, len(out))
+        if k < 0:
+            raise OracleError(int(k))
+        return out[:k].tolist()
+
+
+def split_utf8(pattern: int, text: bytes):
+    """Regex.Matches: list of (byte_start, byte_len)."""
+    cap = len(text) + 1
+    st = np.empty(cap, dtype=np.int64)
+    ln = np.empty(cap, dtype=np.int64)
+    k = lib().tkzo_split_utf8(pattern, _buf(text), len(text), st.ctypes.data, ln.ctypes.data, cap)
+    if k < 0:
+        raise OracleError(int(k))
+    return list(zip(st[:k].tolist(), ln[:k].tolist()))
+
+
+def split_utf16(pattern: int, units):
+    u = np.asarray(units, dtype=np.uint16)
+    cap = len(u) + 1
+    st = np.empty(cap, dtype=np.int64)
+    ln = np.empty(cap, dtype=np.int64)
+    uu = np.ascontiguousarray(np.concatenate([u, np.zeros(1, np.uint16)]))
+    k = lib().tkzo_split_utf16(pattern, uu.ctypes.data, len(u), st.ctypes.data, ln.ctypes.data, cap)
+    if k < 0:
+        raise OracleError(int(k))
+    return list(zip(st[:k].tolist(), ln[:k].tolist()))
+
+
+class Encoder:
+    """TikTokenizer restated: plain Encode, Encode with allowed specials, UTF-16 entry."""
+
+    def __init__(self, vocab: Vocab, pattern: int, cache_size: int = 8192, specials=None):
+        self.vocab = vocab
+        self._h = lib().tkzo_encoder_create(vocab._h, pattern, cache_size)
+        if not self._h:
+            raise OracleError(E_ARG)
+        self.specials = []
+        for lit, tid in (specials or {}).items():
+            b = lit.encode("utf-8")
+            lib().tkzo_encoder_add_special(self._h, _buf(b), len(b), tid)
+            self.specials.append(lit)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().tkzo_encoder_free(self._h)
+            self._h = None
+
+    def encode_bytes(self, text: bytes):
+        out = np.empty(max(1, len(text)), dtype=np.int32)
+        k = lib().tkzo_encode_utf8(self._h, _buf(text), len(text), out.ctypes.data, len(out))
+        if k < 0:
+            raise OracleError(int(k))
+        return out[:k].tolist()
+
+    def encode(self, text: str, allowed_special=None):
+        b = text.encode("utf-8")
+        if not allowed_special:
+            return self.encode_bytes(b)
+        idx = np.asarray([self.specials.index(s) for s in allowed_special if s in self.specials], dtype=np.int32)
+        out = np.empty(max(1, len(b)), dtype=np.int32)
+        k = lib().tkzo_encode_special_utf8(self._h, _buf(b), len(b), idx.ctypes.data, len(idx),
+                                           out.ctypes.data, len(out))
+        if k < 0:
+            raise OracleError(int(k))
+        return out[:k].tolist()
+
+    def encode_utf16(self, units):
+        u = np.ascontiguousarray(np.concatenate([np.asarray(units, dtype=np.uint16), np.zeros(1, np.uint16)]))
+        n = len(u) - 1
+        out = np.empty(max(1, 3 * n), dtype=np.int32)
+        k = lib().tkzo_encode_utf16(self._h, u.ctypes.data, n, out.ctypes.data, len(out))
+        if k < 0:
+            raise OracleError(int(k))
+        return out[:k].tolist()
+
+
+def encode_batch(vocab: Vocab, pattern: int, data: np.ndarray, offsets: np.ndarray, threads=1, cache_size=8192):
+    """CPU-baseline batch: returns (ids_flat, counts). data uint8[total], offsets int64[n+1]."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    out = np.empty(max(1, len(data)), dtype=np.int32)
+    counts = np.zeros(max(1, n), dtype=np.int32)
+    tot = lib().tkzo_encode_batch(vocab._h, pattern, cache_size, data.ctypes.data, offsets.ctypes.data, n,
+                                  out.ctypes.data, counts.ctypes.data, threads)
+    if tot < 0:
+        raise OracleError(int(tot))
+    counts = counts[:n]
+    if n == 0:
+        return np.empty(0, np.int32), counts
+    idx = np.concatenate([out[offsets[d]:offsets[d] + counts[d]] for d in range(n)]) if n < 100000 else _gather(out, offsets, counts)
+    return idx, counts
+
+
+def _gather(out, offsets, counts):
+    starts = offsets[:-1]
+    total = int(counts.sum())
+    pos = np.repeat(starts - np.concatenate([[0], np.cumsum(counts)[:-1]]), counts) + np.arange(total)
+    return out[pos]
