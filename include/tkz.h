@@ -1,0 +1,148 @@
+/*
+ * tkz.h -- C ABI of libtkz, the MI355X-native batch BPE encoder.
+ *
+ * Drop-in boundary for ONE path of microsoft/Tokenizer's TokenizerLib: the plain Encode path
+ *   TikTokenizer.Encode(string, List<int>, int, int)      Tokenizer_C#/TokenizerLib/TikTokenizer.cs:250-274
+ *   BytePairEncoder.BytePairEncode(byte[], ranks)         Tokenizer_C#/TokenizerLib/Utils/BytePairEncoder.cs:13-76
+ * reached through ITokenizer.Encode(text, allowedSpecial) / Encode(text, applySpecialTokens)
+ * (Tokenizer_C#/TokenizerLib/ITokenizer.cs:12,28; TikTokenizer.cs:178-207).
+ *
+ * The reference has no FFI of its own; these entry points are what a
+ * P/Invoke layer under `class GpuTikTokenizer : ITokenizer` binds (INTEGRATION.md shows the
+ * DllImport stubs).  Plain pointers and sizes only; no exceptions cross the boundary: every call
+ * returns a tkz_status and tkz_last_error() holds the message for the calling thread.
+ *
+ * Error mapping to the reference's exceptions:
+ *   TKZ_E_FORMAT        InvalidOperationException(FormatException)   TikTokenizer.cs:114-136
+ *   TKZ_E_DUP_RANK      ArgumentException                            TikTokenizer.cs:82-87
+ *   TKZ_E_KEY_NOT_FOUND KeyNotFoundException                         BytePairEncoder.cs:17,73
+ *   TKZ_E_UNSUPPORTED   NotImplementedException (unknown encoder)    TokenizerBuilder.cs:179
+ */
+#ifndef TKZ_H
+#define TKZ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum tkz_status {
+    TKZ_OK = 0,
+    TKZ_E_FORMAT = -1,
+    TKZ_E_DUP_RANK = -2,
+    TKZ_E_KEY_NOT_FOUND = -3,
+    TKZ_E_CAPACITY = -4,      /* out_cap too small; *needed holds the required id count */
+    TKZ_E_INVALID_UTF8 = -5,  /* the UTF-8 entry points require well-formed UTF-8 (a C# string always converts to it) */
+    TKZ_E_ARG = -6,
+    TKZ_E_UNSUPPORTED = -7,   /* pattern string that is not one of the three the reference defines; rank outside [0, 2^31-1024) */
+    TKZ_E_DEVICE = -8,        /* HIP runtime error */
+    TKZ_E_NO_DEVICE = -9      /* no gfx950 device / HIP runtime unusable: there is NO CPU fallback */
+} tkz_status;
+
+/* The three split regexes the reference defines.  A pattern is an enum, not a regex string:
+ * libtkz ships a hand-written scanner per pattern and refuses anything else.
+ *   TKZ_PATTERN_P1      gpt2 / r50k_base / p50k_base / p50k_edit   TokenizerBuilder.cs:128,140,155,167
+ *   TKZ_PATTERN_CL100K  cl100k_base                                TokenizerBuilder.cs:112
+ *   TKZ_PATTERN_O200K   o200k_base                                 tokenizer_ts/src/tokenizerBuilder.ts:79-89 */
+typedef enum tkz_pattern { TKZ_PATTERN_P1 = 1, TKZ_PATTERN_CL100K = 2, TKZ_PATTERN_O200K = 3 } tkz_pattern;
+
+typedef struct tkz_vocab tkz_vocab;
+typedef struct tkz_encoder tkz_encoder;
+
+/* Message for the last failing call on this thread ("" if none). */
+const char* tkz_last_error(void);
+
+/* Replaces TikTokenizer.LoadTikTokenBpe(Stream) + Init's rank-collision check
+ * (TikTokenizer.cs:99-139, :74-91).  `file` is the whole .tiktoken image (lines "base64 SP rank"). */
+tkz_status tkz_vocab_from_tiktoken(const uint8_t* file, size_t n, tkz_vocab** out);
+void tkz_vocab_destroy(tkz_vocab* v);
+int64_t tkz_vocab_size(const tkz_vocab* v);
+int32_t tkz_vocab_max_key_len(const tkz_vocab* v);
+/* Number of vocab keys whose own BPE does not reproduce [rank(key)] (informational; such keys are
+ * why the whole-piece lookup of TikTokenizer.cs:262 must run before the merge loop). */
+int64_t tkz_vocab_pair_table_entries(const tkz_vocab* v);
+
+/* Map one of the reference's regex strings (exact text) to a tkz_pattern; anything else is
+ * TKZ_E_UNSUPPORTED.  Replaces `new Regex(pattern, RegexOptions.Compiled)` (TikTokenizer.cs:77). */
+tkz_status tkz_pattern_from_regex(const char* regex_utf8, int32_t* pattern_out);
+
+/* Replaces TokenizerBuilder.CreateTokenizer(stream, specials, pattern, cacheSize)
+ * (TokenizerBuilder.cs:210-213) for the plain path: builds the device tables on HIP device
+ * `device` (>= 0).  The vocab may be destroyed afterwards. */
+tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t device, tkz_encoder** out);
+void tkz_encoder_destroy(tkz_encoder* e);
+int32_t tkz_encoder_device(const tkz_encoder* e);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+
+/* EncodeBatch over HOST buffers: n_docs documents, document d = bytes[doc_offsets[d] .. doc_offsets[d+1]).
+ * Each document is encoded exactly as ITokenizer.Encode(text, applySpecialTokens:false) would encode
+ * the string it is the UTF-8 form of.  out_ids receives all ids, document after document;
+ * out_offsets (n_docs+1 entries) the id range of each document.  Caller-allocated; out_cap >= total
+ * bytes is always sufficient (a token is at least one byte).  On TKZ_E_CAPACITY nothing useful is
+ * in out_ids and *needed (if non-NULL) holds the required capacity. */
+tkz_status tkz_encode_batch_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets,
+                                 int64_t n_docs, int32_t* out_ids, int64_t out_cap,
+                                 int64_t* out_offsets, int64_t* needed);
+
+/* Same with every buffer already resident in HBM on the encoder's device (16-byte aligned d_bytes).
+ * Work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream); the call returns after
+ * the stream has drained and *total_tokens is final. */
+tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets,
+                                   int64_t n_docs, int64_t total_bytes, int32_t* d_out_ids,
+                                   int64_t out_cap, int64_t* d_out_offsets, void* hip_stream,
+                                   int64_t* total_tokens);
+
+/* Single-string entries for `string` callers.  UTF-16: the split runs on the code units as .NET's
+ * Regex does; each piece is converted as Encoding.UTF8.GetBytes does (lone surrogate -> EF BF BD),
+ * TikTokenizer.cs:261. */
+tkz_status tkz_encode_utf8(tkz_encoder* e, const uint8_t* text, int64_t len, int32_t* out_ids,
+                           int64_t out_cap, int64_t* n_out);
+tkz_status tkz_encode_utf16(tkz_encoder* e, const uint16_t* text, int64_t len, int32_t* out_ids,
+                            int64_t out_cap, int64_t* n_out);
+
+/* ---- stage-level entry points (used by the parity tests; same kernels as the hot path) --- */
+
+/* Regex.Matches only: writes the piece-start bitmap (bit i of word i/64 set <=> a piece starts at
+ * byte i; ceil(total/64) words) for the batch.  Host buffers. */
+tkz_status tkz_pretokenize_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets,
+                                int64_t n_docs, uint64_t* out_bitmap_words);
+/* BytePairEncode + whole-piece lookup only: piece p = bytes[piece_offsets[p] .. piece_offsets[p+1])
+ * is encoded as ONE regex match (arbitrary bytes allowed).  Host buffers. */
+tkz_status tkz_encode_pieces(tkz_encoder* e, const uint8_t* bytes, const int64_t* piece_offsets,
+                             int64_t n_pieces, int32_t* out_ids, int64_t out_cap,
+                             int64_t* out_offsets, int64_t* needed);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+
+enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_ENCODE = 2, TKZ_K_LONG = 3, TKZ_K_SCAN = 4,
+       TKZ_K_COMPACT = 5, TKZ_K_DOCOFFS = 6, TKZ_K_COUNT = 7 };
+/* When enabled, every kernel launch of tkz_encode_batch_device is bracketed by HIP events on the
+ * launch stream; tkz_encoder_kernel_ms returns the accumulated milliseconds and launch counts per
+ * kernel since the last reset (arrays of TKZ_K_COUNT). */
+tkz_status tkz_encoder_set_profiling(tkz_encoder* e, int32_t enabled);
+tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, int32_t reset);
+/* Device bytes currently held by the encoder's workspace. */
+int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e);
+const char* tkz_kernel_name(int32_t k);
+
+/* Synthetic corpus of BASELINE.json's configs, generated ON DEVICE by a counter-based generator
+ * (see csrc/tkz_corpus.h); the same function compiled for the host regenerates any document for
+ * spot checks.  kind: 1 = ASCII English/code-like (configs 1,2,4), 2 = mixed UTF-8 CJK+emoji
+ * (config 3), 3 = long-context with long single-class runs (config 5).
+ * d_doc_offsets (n_docs+1) and d_bytes (capacity cap_bytes) are device buffers; *total_bytes is
+ * returned.  Document d's length depends only on (seed, kind, first_doc + d, min_len, max_len). */
+tkz_status tkz_corpus_generate_device(int32_t device, int32_t kind, uint64_t seed, int64_t first_doc,
+                                      int64_t n_docs, int32_t min_len, int32_t max_len,
+                                      int64_t* d_doc_offsets, uint8_t* d_bytes, int64_t cap_bytes,
+                                      void* hip_stream, int64_t* total_bytes);
+/* Host regeneration of ONE document (returns its byte length, or <0); buf may be NULL to query. */
+int64_t tkz_corpus_generate_doc_host(int32_t kind, uint64_t seed, int64_t doc_index, int32_t min_len,
+                                     int32_t max_len, uint8_t* buf, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TKZ_H */

@@ -1,0 +1,209 @@
+// tkz_vocab.cpp -- .tiktoken loader and device-table builder (host C++).
+//
+// Replaces TikTokenizer.LoadTikTokenBpe + the rank-collision check of Init
+// (Tokenizer_C#/TokenizerLib/TikTokenizer.cs:99-139, :74-91): same file format, same failure modes,
+// reported as status codes instead of exceptions.
+#include "tkz_vocab.h"
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+
+#include "../../include/tkz.h"
+
+namespace tkz {
+
+namespace {
+
+int b64val(int c) {
+    if (c >= 'A' && c <= 'Z') return c - 'A';
+    if (c >= 'a' && c <= 'z') return c - 'a' + 26;
+    if (c >= '0' && c <= '9') return c - '0' + 52;
+    if (c == '+') return 62;
+    if (c == '/') return 63;
+    return -1;
+}
+
+// Convert.FromBase64String semantics for a field without embedded white space.
+bool b64decode(const uint8_t* s, size_t n, std::string* out) {
+    out->clear();
+    if (n % 4) return false;
+    for (size_t i = 0; i < n; i += 4) {
+        int v[4], pad = 0;
+        for (int k = 0; k < 4; ++k) {
+            int c = s[i + k];
+            if (c == '=') {
+                if (i + 4 != n || k < 2) return false;
+                v[k] = 0; ++pad;
+            } else {
+                if (pad) return false;
+                v[k] = b64val(c);
+                if (v[k] < 0) return false;
+            }
+        }
+        uint32_t w = (uint32_t(v[0]) << 18) | (uint32_t(v[1]) << 12) | (uint32_t(v[2]) << 6) | uint32_t(v[3]);
+        out->push_back(char(w >> 16));
+        if (pad < 2) out->push_back(char(w >> 8));
+        if (pad < 1) out->push_back(char(w));
+    }
+    return true;
+}
+
+inline bool is_ws(int c) { return c == ' ' || (c >= 9 && c <= 13) || c == 0x85 || c == 0xA0; }
+
+const struct { uint16_t a, b; uint8_t c; } kRanges[] = {
+#include "unicode13_classes.inc"
+};
+
+inline uint32_t next_pow2(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return uint32_t(p); }
+
+inline uint32_t load_dword(const std::string& k, size_t off) {
+    uint32_t w = 0;
+    for (size_t j = 0; j < 4 && off + j < k.size(); ++j) w |= uint32_t(uint8_t(k[off + j])) << (8 * j);
+    return w;
+}
+
+}  // namespace
+
+const std::vector<uint8_t>& bmp_class_table() {
+    static const std::vector<uint8_t> table = [] {
+        std::vector<uint8_t> t(65536, UC_OTHER);
+        for (const auto& r : kRanges)
+            for (unsigned u = r.a; u <= r.b; ++u) t[u] = r.c;
+        return t;
+    }();
+    return table;
+}
+
+int parse_tiktoken(const uint8_t* file, size_t n, Vocab* out, std::string* msg) {
+    size_t pos = 0;
+    if (n >= 3 && file[0] == 0xEF && file[1] == 0xBB && file[2] == 0xBF) pos = 3;  // StreamReader eats a BOM
+    std::string key;
+    int64_t lineno = 0;
+    while (pos < n) {
+        ++lineno;
+        size_t ls = pos;
+        while (pos < n && file[pos] != '\n' && file[pos] != '\r') ++pos;     // ReadLine (:107)
+        size_t le = pos;
+        if (pos < n) pos += (file[pos] == '\r' && pos + 1 < n && file[pos + 1] == '\n') ? 2 : 1;
+        bool blank = true;                                                    // IsNullOrWhiteSpace (:109)
+        for (size_t i = ls; i < le; ++i) if (!is_ws(file[i])) { blank = false; break; }
+        if (blank) continue;
+        int nsp = 0; size_t sp = 0;                                           // Split(' ') -> 2 fields (:114-118)
+        for (size_t i = ls; i < le; ++i) if (file[i] == ' ') { if (!nsp) sp = i; ++nsp; }
+        if (nsp != 1) { *msg = "Failed to load from BPE encoder file stream: Invalid format in the BPE encoder file stream (line " + std::to_string(lineno) + ")"; return TKZ_E_FORMAT; }
+        if (!b64decode(file + ls, sp - ls, &key)) { *msg = "Failed to load from BPE encoder file stream: invalid base64 (line " + std::to_string(lineno) + ")"; return TKZ_E_FORMAT; }
+        size_t a = sp + 1, b = le;                                            // int.TryParse (:122)
+        while (a < b && is_ws(file[a])) ++a;
+        while (b > a && is_ws(file[b - 1])) --b;
+        bool neg = false;
+        if (a < b && (file[a] == '+' || file[a] == '-')) { neg = file[a] == '-'; ++a; }
+        bool ok = a < b;
+        int64_t val = 0;
+        for (size_t i = a; ok && i < b; ++i) {
+            if (file[i] < '0' || file[i] > '9') ok = false;
+            else { val = val * 10 + (file[i] - '0'); if (val > int64_t(INT_MAX) + 1) ok = false; }
+        }
+        if (neg) val = -val;
+        if (!ok || val > INT_MAX || val < INT_MIN) {
+            *msg = "Failed to load from BPE encoder file stream: Can't parse rank to integer (line " + std::to_string(lineno) + ")";
+            return TKZ_E_FORMAT;
+        }
+        if (val < 0 || val > TKZ_MAX_RANK) {
+            *msg = "rank " + std::to_string(val) + " outside the supported range [0, 2^27) (line " + std::to_string(lineno) + ")";
+            return TKZ_E_UNSUPPORTED;
+        }
+        auto it = out->index.find(key);
+        if (it != out->index.end()) out->ranks[it->second] = int32_t(val);     // bpeDict[key] = rank overwrites (:125)
+        else {
+            out->index.emplace(key, int32_t(out->keys.size()));
+            out->keys.push_back(key);
+            out->ranks.push_back(int32_t(val));
+            out->max_key_len = std::max<int32_t>(out->max_key_len, int32_t(key.size()));
+        }
+    }
+    // Decoder = Encoder.ToDictionary(rank -> key): a repeated rank throws ArgumentException (:82-87)
+    std::vector<int32_t> sorted(out->ranks);
+    std::sort(sorted.begin(), sorted.end());
+    for (size_t i = 1; i < sorted.size(); ++i)
+        if (sorted[i] == sorted[i - 1]) { *msg = "Encoder and decoder sizes don't match (rank " + std::to_string(sorted[i]) + " appears twice)"; return TKZ_E_DUP_RANK; }
+    return TKZ_OK;
+}
+
+int build_tables(Vocab* v, std::string* msg) {
+    (void)msg;
+    const size_t nk = v->keys.size();
+    // ---- single bytes ----
+    v->byte_rank.assign(256, 0);
+    for (int b = 0; b < 256; ++b) {
+        int32_t r;
+        std::string k(1, char(b));
+        v->byte_rank[b] = v->lookup(k, &r) ? r : int32_t(TKZ_PSEUDO_BASE + b);
+    }
+    // ---- SHORT / LONG whole-key tables ----
+    size_t n_short = 0, n_long = 0, blob = 0;
+    for (const auto& k : v->keys) {
+        if (k.empty()) continue;
+        if (k.size() <= TKZ_SHORT_KEY_MAX) ++n_short; else { ++n_long; blob += k.size(); }
+    }
+    const uint32_t short_cap = next_pow2(std::max<uint64_t>(16, uint64_t(n_short) * 2));
+    const uint32_t long_cap = next_pow2(std::max<uint64_t>(16, uint64_t(n_long) * 2));
+    v->short_slots.assign(short_cap, TkzShortSlot{0, 0, 0, 0});
+    v->long_slots.assign(long_cap, TkzLongSlot{0, 0, 0, 0});
+    v->long_blob.clear();
+    v->long_blob.reserve(blob + 16);
+    for (size_t i = 0; i < nk; ++i) {
+        const std::string& k = v->keys[i];
+        if (k.empty()) continue;   // an empty key can never equal a regex match or a merge slice
+        const uint32_t len = uint32_t(k.size());
+        if (len <= TKZ_SHORT_KEY_MAX) {
+            const uint32_t k0 = load_dword(k, 0), k1 = load_dword(k, 4), k2 = load_dword(k, 8);
+            uint32_t s = tkz_hash_short(k0, k1, k2, len) & (short_cap - 1);
+            while (v->short_slots[s].rank_len) s = (s + 1) & (short_cap - 1);
+            v->short_slots[s] = TkzShortSlot{k0, k1, k2, uint32_t(v->ranks[i]) | (len << TKZ_SHORT_RANK_BITS)};
+        } else {
+            uint32_t h = tkz_hash_long_init(len);
+            for (size_t off = 0; off < k.size(); off += 4) h = tkz_hash_long_step(h, load_dword(k, off));
+            uint32_t s = h & (long_cap - 1);
+            while (v->long_slots[s].len) s = (s + 1) & (long_cap - 1);
+            v->long_slots[s] = TkzLongSlot{h, v->ranks[i], uint32_t(v->long_blob.size()), len};
+            v->long_blob.insert(v->long_blob.end(), k.begin(), k.end());
+        }
+    }
+    v->long_blob.resize(v->long_blob.size() + 16, 0);   // kernels may read a few bytes past a key
+    // ---- PAIR table: every split of every key into two keys (or not-in-vocab single bytes) ----
+    struct P { uint32_t a, b; int32_t r; };
+    std::vector<P> pairs;
+    pairs.reserve(nk * 3);
+    auto id_of = [&](const std::string& s, int32_t* id) -> bool {
+        if (v->lookup(s, id)) return true;
+        if (s.size() == 1) { *id = int32_t(TKZ_PSEUDO_BASE + uint8_t(s[0])); return true; }
+        return false;
+    };
+    for (size_t i = 0; i < nk; ++i) {
+        const std::string& k = v->keys[i];
+        for (size_t p = 1; p < k.size(); ++p) {
+            int32_t a, b;
+            if (id_of(k.substr(0, p), &a) && id_of(k.substr(p), &b)) pairs.push_back(P{uint32_t(a), uint32_t(b), v->ranks[i]});
+        }
+    }
+    v->pair_entries = int64_t(pairs.size());
+    const uint32_t pair_cap = next_pow2(std::max<uint64_t>(16, uint64_t(pairs.size()) * 2));
+    v->pair_slots.assign(pair_cap, TkzPairSlot{0, 0, 0, 0});
+    v->bytepair_rank.assign(65536, TKZ_RANK_NONE);
+    for (const P& p : pairs) {
+        uint32_t s = tkz_hash_pair(p.a, p.b) & (pair_cap - 1);
+        while (v->pair_slots[s].valid) s = (s + 1) & (pair_cap - 1);
+        v->pair_slots[s] = TkzPairSlot{p.a, p.b, p.r, 1};
+    }
+    // two-single-byte pairs, directly indexed by the BYTES (not ranks): first-level lookups
+    for (int a = 0; a < 256; ++a)
+        for (int b = 0; b < 256; ++b) {
+            std::string k; k.push_back(char(a)); k.push_back(char(b));
+            int32_t r;
+            if (v->lookup(k, &r)) v->bytepair_rank[(a << 8) | b] = r;
+        }
+    return TKZ_OK;
+}
+
+}  // namespace tkz

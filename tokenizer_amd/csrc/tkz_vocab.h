@@ -1,0 +1,47 @@
+// tkz_vocab.h -- host side of the vocabulary: .tiktoken parsing and the builder of the device
+// table images (layouts in tkz_tables.h).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "tkz_tables.h"
+
+namespace tkz {
+
+// Unicode class codes stored in TkzTables::bmp_class (generated table, unicode13_classes.inc)
+enum : uint8_t { UC_OTHER = 0, UC_LU = 1, UC_LL = 2, UC_LT = 3, UC_LM = 4, UC_LO = 5, UC_M = 6, UC_N = 7, UC_WS = 8 };
+
+struct Vocab {
+    // insertion-ordered keys + ranks (a repeated key overwrites its rank, TikTokenizer.cs:125)
+    std::vector<std::string> keys;
+    std::vector<int32_t> ranks;
+    std::unordered_map<std::string, int32_t> index;   // key -> position in keys/ranks
+    int32_t max_key_len = 0;
+
+    // host images of the device tables
+    std::vector<TkzShortSlot> short_slots;
+    std::vector<TkzLongSlot> long_slots;
+    std::vector<uint8_t> long_blob;
+    std::vector<TkzPairSlot> pair_slots;
+    std::vector<int32_t> byte_rank;       // 256
+    std::vector<int32_t> bytepair_rank;   // 65536
+    int64_t pair_entries = 0;
+
+    bool lookup(const std::string& k, int32_t* rank) const {
+        auto it = index.find(k);
+        if (it == index.end()) return false;
+        *rank = ranks[it->second];
+        return true;
+    }
+};
+
+// Parses a .tiktoken image.  Returns 0 (TKZ_OK) or a negative tkz_status; msg receives a description.
+int parse_tiktoken(const uint8_t* file, size_t n, Vocab* out, std::string* msg);
+// Builds every table image (requires parse_tiktoken to have succeeded).
+int build_tables(Vocab* v, std::string* msg);
+// 65536-entry BMP class table (shared by all vocabularies)
+const std::vector<uint8_t>& bmp_class_table();
+
+}  // namespace tkz
