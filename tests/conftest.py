@@ -1,0 +1,56 @@
+import gzip
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpt2_tiktoken_bytes():
+    with open(os.path.join(GOLDEN, "gpt2.tiktoken.gz"), "rb") as f:
+        return gzip.decompress(f.read())
+
+
+@pytest.fixture(scope="session")
+def lib_rs_bytes():
+    with open(os.path.join(GOLDEN, "lib.rs.txt"), "rb") as f:
+        return f.read()
+
+
+def load_golden_json(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def find_vocab_file(name):
+    """cl100k_base / p50k_base / o200k_base are downloaded by the reference at run time
+    (TokenizerBuilder.cs:113,129,141,156,168) and are not in this repo; tests that need them look in
+    $TKZ_VOCAB_DIR and skip when absent."""
+    d = os.environ.get("TKZ_VOCAB_DIR")
+    if d:
+        p = os.path.join(d, name)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def oracle_gpt2(oracle_mod, gpt2_tiktoken_bytes):
+    return oracle_mod.Vocab(gpt2_tiktoken_bytes)
