@@ -9,8 +9,10 @@
  *
  * The reference has no FFI of its own; these entry points are what a
  * P/Invoke layer under `class GpuTikTokenizer : ITokenizer` binds (INTEGRATION.md shows the
- * DllImport stubs).  Plain pointers and sizes only; no exceptions cross the boundary: every call
- * returns a tkz_status and tkz_last_error() holds the message for the calling thread.
+ * DllImport stubs; bindings/csharp/ holds the class).  Plain pointers and sizes only; no exceptions
+ * cross the boundary: every call returns a tkz_status and tkz_last_error() holds the message for
+ * the calling thread.  There is NO CPU fallback: without a usable HIP device every encoder entry
+ * point fails with TKZ_E_NO_DEVICE.
  *
  * Error mapping to the reference's exceptions:
  *   TKZ_E_FORMAT        InvalidOperationException(FormatException)   TikTokenizer.cs:114-136
@@ -36,9 +38,9 @@ typedef enum tkz_status {
     TKZ_E_CAPACITY = -4,      /* out_cap too small; *needed holds the required id count */
     TKZ_E_INVALID_UTF8 = -5,  /* the UTF-8 entry points require well-formed UTF-8 (a C# string always converts to it) */
     TKZ_E_ARG = -6,
-    TKZ_E_UNSUPPORTED = -7,   /* pattern string that is not one of the three the reference defines; rank outside [0, 2^31-1024) */
+    TKZ_E_UNSUPPORTED = -7,   /* pattern string that is not one of the three the reference defines; rank outside [0, 2^27) */
     TKZ_E_DEVICE = -8,        /* HIP runtime error */
-    TKZ_E_NO_DEVICE = -9      /* no gfx950 device / HIP runtime unusable: there is NO CPU fallback */
+    TKZ_E_NO_DEVICE = -9      /* no HIP device / HIP runtime unusable: there is NO CPU fallback */
 } tkz_status;
 
 /* The three split regexes the reference defines.  A pattern is an enum, not a regex string:
@@ -60,9 +62,10 @@ tkz_status tkz_vocab_from_tiktoken(const uint8_t* file, size_t n, tkz_vocab** ou
 void tkz_vocab_destroy(tkz_vocab* v);
 int64_t tkz_vocab_size(const tkz_vocab* v);
 int32_t tkz_vocab_max_key_len(const tkz_vocab* v);
-/* Number of vocab keys whose own BPE does not reproduce [rank(key)] (informational; such keys are
- * why the whole-piece lookup of TikTokenizer.cs:262 must run before the merge loop). */
+/* Entries of the (id_left, id_right) -> rank table built for the merge loop (informational). */
 int64_t tkz_vocab_pair_table_entries(const tkz_vocab* v);
+/* Encoder[key] on the host copy: rank of an exact byte string, or -1. */
+int32_t tkz_vocab_rank(const tkz_vocab* v, const uint8_t* key, int32_t len);
 
 /* Map one of the reference's regex strings (exact text) to a tkz_pattern; anything else is
  * TKZ_E_UNSUPPORTED.  Replaces `new Regex(pattern, RegexOptions.Compiled)` (TikTokenizer.cs:77). */
@@ -87,17 +90,18 @@ tkz_status tkz_encode_batch_utf8(tkz_encoder* e, const uint8_t* bytes, const int
                                  int64_t n_docs, int32_t* out_ids, int64_t out_cap,
                                  int64_t* out_offsets, int64_t* needed);
 
-/* Same with every buffer already resident in HBM on the encoder's device (16-byte aligned d_bytes).
+/* Same with every buffer already resident in HBM on the encoder's device (d_bytes 16-byte aligned).
  * Work is enqueued on `hip_stream` (a hipStream_t, NULL = default stream); the call returns after
- * the stream has drained and *total_tokens is final. */
+ * the stream has drained and *total_tokens is final (it is also the required capacity when the call
+ * returns TKZ_E_CAPACITY). */
 tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets,
                                    int64_t n_docs, int64_t total_bytes, int32_t* d_out_ids,
                                    int64_t out_cap, int64_t* d_out_offsets, void* hip_stream,
                                    int64_t* total_tokens);
 
-/* Single-string entries for `string` callers.  UTF-16: the split runs on the code units as .NET's
- * Regex does; each piece is converted as Encoding.UTF8.GetBytes does (lone surrogate -> EF BF BD),
- * TikTokenizer.cs:261. */
+/* Single-string entries for `string` callers.  UTF-16: the split sees the code units as .NET's Regex
+ * does (a supplementary-plane char is two "other" units, a lone surrogate one); each piece is
+ * converted as Encoding.UTF8.GetBytes does (lone surrogate -> EF BF BD), TikTokenizer.cs:261. */
 tkz_status tkz_encode_utf8(tkz_encoder* e, const uint8_t* text, int64_t len, int32_t* out_ids,
                            int64_t out_cap, int64_t* n_out);
 tkz_status tkz_encode_utf16(tkz_encoder* e, const uint16_t* text, int64_t len, int32_t* out_ids,
@@ -106,7 +110,7 @@ tkz_status tkz_encode_utf16(tkz_encoder* e, const uint16_t* text, int64_t len, i
 /* ---- stage-level entry points (used by the parity tests; same kernels as the hot path) --- */
 
 /* Regex.Matches only: writes the piece-start bitmap (bit i of word i/64 set <=> a piece starts at
- * byte i; ceil(total/64) words) for the batch.  Host buffers. */
+ * byte i; total/64 + 1 words, the bit at `total` is a sentinel) for the batch.  Host buffers. */
 tkz_status tkz_pretokenize_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets,
                                 int64_t n_docs, uint64_t* out_bitmap_words);
 /* BytePairEncode + whole-piece lookup only: piece p = bytes[piece_offsets[p] .. piece_offsets[p+1])
@@ -115,30 +119,36 @@ tkz_status tkz_encode_pieces(tkz_encoder* e, const uint8_t* bytes, const int64_t
                              int64_t n_pieces, int32_t* out_ids, int64_t out_cap,
                              int64_t* out_offsets, int64_t* needed);
 
+/* Options.  TKZ_OPT_PRETOK_SEQUENTIAL: 1 = split with the one-lane-per-document scanner instead of
+ * the position-parallel one (always used for o200k); both must give identical bitmaps. */
+enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1 };
+tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value);
+
 /* ---- measurement ------------------------------------------------------------------------- */
 
-enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_ENCODE = 2, TKZ_K_LONG = 3, TKZ_K_SCAN = 4,
-       TKZ_K_COMPACT = 5, TKZ_K_DOCOFFS = 6, TKZ_K_COUNT = 7 };
+enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_ENCODE = 2, TKZ_K_SCAN = 3, TKZ_K_GATHER = 4,
+       TKZ_K_DOCOFFS = 5, TKZ_K_COUNT = 6 };
 /* When enabled, every kernel launch of tkz_encode_batch_device is bracketed by HIP events on the
  * launch stream; tkz_encoder_kernel_ms returns the accumulated milliseconds and launch counts per
  * kernel since the last reset (arrays of TKZ_K_COUNT). */
 tkz_status tkz_encoder_set_profiling(tkz_encoder* e, int32_t enabled);
 tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, int32_t reset);
-/* Device bytes currently held by the encoder's workspace. */
+/* Device bytes currently held by the encoder (tables + workspace). */
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e);
 const char* tkz_kernel_name(int32_t k);
 
 /* Synthetic corpus of BASELINE.json's configs, generated ON DEVICE by a counter-based generator
- * (see csrc/tkz_corpus.h); the same function compiled for the host regenerates any document for
- * spot checks.  kind: 1 = ASCII English/code-like (configs 1,2,4), 2 = mixed UTF-8 CJK+emoji
- * (config 3), 3 = long-context with long single-class runs (config 5).
- * d_doc_offsets (n_docs+1) and d_bytes (capacity cap_bytes) are device buffers; *total_bytes is
- * returned.  Document d's length depends only on (seed, kind, first_doc + d, min_len, max_len). */
+ * (csrc/tkz_corpus.h); the same function compiled for the host regenerates any document for spot
+ * checks.  kind: 1 = ASCII English/code-like (configs 1,2,4), 2 = mixed UTF-8 CJK+emoji (config 3),
+ * 3 = long-context with long single-class runs (config 5).
+ * d_doc_offsets (n_docs+1 entries, device) is always written; d_bytes (device, capacity cap_bytes) is
+ * filled when non-NULL and large enough; *total_bytes is returned either way, so a first call with
+ * d_bytes == NULL sizes the buffer.  Document d depends only on (kind, seed, first_doc + d, min_len, max_len). */
 tkz_status tkz_corpus_generate_device(int32_t device, int32_t kind, uint64_t seed, int64_t first_doc,
                                       int64_t n_docs, int32_t min_len, int32_t max_len,
                                       int64_t* d_doc_offsets, uint8_t* d_bytes, int64_t cap_bytes,
                                       void* hip_stream, int64_t* total_bytes);
-/* Host regeneration of ONE document (returns its byte length, or <0); buf may be NULL to query. */
+/* Host regeneration of ONE document (returns its byte length); buf may be NULL to query the length. */
 int64_t tkz_corpus_generate_doc_host(int32_t kind, uint64_t seed, int64_t doc_index, int32_t min_len,
                                      int32_t max_len, uint8_t* buf, int64_t cap);
 

@@ -1,0 +1,241 @@
+"""ctypes binding of libtkz (include/tkz.h).  The library is the in-tree HIP build
+(tokenizer_amd/lib/libtkz.so, produced by tokenizer_amd/csrc/Makefile or __graft_entry__.build()).
+There is no fallback: if the library or a HIP device is missing, construction raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libtkz.so")
+
+OK = 0
+E_FORMAT, E_DUP_RANK, E_KEY_NOT_FOUND, E_CAPACITY, E_INVALID_UTF8, E_ARG, E_UNSUPPORTED, E_DEVICE, E_NO_DEVICE = range(-1, -10, -1)
+P1, CL100K, O200K = 1, 2, 3
+OPT_PRETOK_SEQUENTIAL = 1
+K_NAMES = ["k_docmark", "k_pretok", "k_encode_tiles", "k_scan", "k_gather", "k_docoffs"]
+
+
+class TkzError(Exception):
+    """A non-OK tkz_status.  `.code` is the status; subclasses mirror the reference's exception types."""
+
+    def __init__(self, code, msg):
+        super().__init__("tkz status %d: %s" % (code, msg))
+        self.code = code
+
+
+class FormatError(TkzError):          # InvalidOperationException(FormatException)  TikTokenizer.cs:114-136
+    pass
+
+
+class DuplicateRankError(TkzError):   # ArgumentException                            TikTokenizer.cs:82-87
+    pass
+
+
+class KeyNotFoundError(TkzError, KeyError):   # KeyNotFoundException                 BytePairEncoder.cs:17,73
+    pass
+
+
+class UnsupportedError(TkzError, NotImplementedError):   # NotImplementedException   TokenizerBuilder.cs:179
+    pass
+
+
+_EXC = {E_FORMAT: FormatError, E_DUP_RANK: DuplicateRankError, E_KEY_NOT_FOUND: KeyNotFoundError, E_UNSUPPORTED: UnsupportedError}
+
+
+class Library:
+    def __init__(self, path=None):
+        path = path or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise RuntimeError("libtkz not built: %s is missing (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C tokenizer_amd/csrc`); there is no CPU fallback" % path)
+        self.path = path
+        L = self.L = C.CDLL(path)
+        vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
+        pv = C.POINTER(C.c_void_p)
+        pi64 = C.POINTER(C.c_int64)
+        L.tkz_last_error.restype = C.c_char_p
+        L.tkz_vocab_from_tiktoken.argtypes = [vp, sz, pv]
+        L.tkz_vocab_destroy.argtypes = [vp]
+        L.tkz_vocab_destroy.restype = None
+        L.tkz_vocab_size.argtypes = [vp]
+        L.tkz_vocab_size.restype = i64
+        L.tkz_vocab_max_key_len.argtypes = [vp]
+        L.tkz_vocab_pair_table_entries.argtypes = [vp]
+        L.tkz_vocab_pair_table_entries.restype = i64
+        L.tkz_vocab_rank.argtypes = [vp, vp, i32]
+        L.tkz_pattern_from_regex.argtypes = [C.c_char_p, C.POINTER(i32)]
+        L.tkz_encoder_create.argtypes = [vp, i32, i32, pv]
+        L.tkz_encoder_destroy.argtypes = [vp]
+        L.tkz_encoder_destroy.restype = None
+        L.tkz_encoder_device.argtypes = [vp]
+        L.tkz_encode_batch_utf8.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
+        L.tkz_encode_batch_device.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, pi64]
+        L.tkz_encode_utf8.argtypes = [vp, vp, i64, vp, i64, pi64]
+        L.tkz_encode_utf16.argtypes = [vp, vp, i64, vp, i64, pi64]
+        L.tkz_pretokenize_utf8.argtypes = [vp, vp, vp, i64, vp]
+        L.tkz_encode_pieces.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
+        L.tkz_encoder_set_option.argtypes = [vp, i32, i64]
+        L.tkz_encoder_set_profiling.argtypes = [vp, i32]
+        L.tkz_encoder_kernel_ms.argtypes = [vp, vp, vp, i32]
+        L.tkz_encoder_workspace_bytes.argtypes = [vp]
+        L.tkz_encoder_workspace_bytes.restype = i64
+        L.tkz_kernel_name.argtypes = [i32]
+        L.tkz_kernel_name.restype = C.c_char_p
+        L.tkz_corpus_generate_device.argtypes = [i32, i32, C.c_uint64, i64, i64, i32, i32, vp, vp, i64, vp, pi64]
+        L.tkz_corpus_generate_doc_host.argtypes = [i32, C.c_uint64, i64, i32, i32, vp, i64]
+        L.tkz_corpus_generate_doc_host.restype = i64
+
+    def check(self, status):
+        if status != OK:
+            msg = (self.L.tkz_last_error() or b"").decode("utf-8", "replace")
+            raise _EXC.get(status, TkzError)(status, msg)
+
+
+_default = None
+
+
+def default_library():
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Vocab:
+    """LoadTikTokenBpe + Init's duplicate-rank check (TikTokenizer.cs:99-139, :74-91)."""
+
+    def __init__(self, tiktoken_bytes: bytes, lib: Library = None):
+        self.lib = lib or default_library()
+        h = C.c_void_p()
+        buf = (C.c_uint8 * max(1, len(tiktoken_bytes))).from_buffer_copy(tiktoken_bytes or b"\0")
+        self.lib.check(self.lib.L.tkz_vocab_from_tiktoken(buf, len(tiktoken_bytes), C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.L.tkz_vocab_destroy(self._h)
+            self._h = None
+
+    def __len__(self):
+        return self.lib.L.tkz_vocab_size(self._h)
+
+    @property
+    def max_key_len(self):
+        return self.lib.L.tkz_vocab_max_key_len(self._h)
+
+    @property
+    def pair_table_entries(self):
+        return self.lib.L.tkz_vocab_pair_table_entries(self._h)
+
+    def rank(self, key: bytes):
+        buf = (C.c_uint8 * max(1, len(key))).from_buffer_copy(key or b"\0")
+        return self.lib.L.tkz_vocab_rank(self._h, buf, len(key))
+
+
+class Encoder:
+    """The device encoder (tables in HBM + workspace)."""
+
+    def __init__(self, vocab: Vocab, pattern: int, device: int = 0):
+        self.lib = vocab.lib
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.tkz_encoder_create(vocab._h, pattern, device, C.byref(h)))
+        self._h = h
+        self.pattern = pattern
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self.lib.L.tkz_encoder_destroy(self._h)
+            self._h = None
+
+    def set_option(self, opt, value):
+        self.lib.check(self.lib.L.tkz_encoder_set_option(self._h, opt, value))
+
+    def set_profiling(self, on):
+        self.lib.check(self.lib.L.tkz_encoder_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_ms(self, reset=False):
+        ms = np.zeros(len(K_NAMES), np.float64)
+        n = np.zeros(len(K_NAMES), np.int64)
+        self.lib.check(self.lib.L.tkz_encoder_kernel_ms(self._h, ms.ctypes.data, n.ctypes.data, 1 if reset else 0))
+        return {K_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(len(K_NAMES))}
+
+    @property
+    def workspace_bytes(self):
+        return self.lib.L.tkz_encoder_workspace_bytes(self._h)
+
+    # -- host buffers --
+    def encode_batch(self, data: np.ndarray, offsets: np.ndarray, out_cap=None):
+        """EncodeBatch: (ids int32[total_tokens], out_offsets int64[n+1])."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        cap = len(data) if out_cap is None else out_cap
+        ids = np.empty(max(1, cap), np.int32)
+        ooff = np.empty(n + 1, np.int64)
+        needed = C.c_int64(0)
+        self.lib.check(self.lib.L.tkz_encode_batch_utf8(self._h, _ptr(data), _ptr(offsets), n, _ptr(ids), cap, _ptr(ooff), C.byref(needed)))
+        return ids[:needed.value], ooff
+
+    def encode_pieces(self, data: np.ndarray, offsets: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        ids = np.empty(max(1, len(data)), np.int32)
+        ooff = np.empty(n + 1, np.int64)
+        needed = C.c_int64(0)
+        self.lib.check(self.lib.L.tkz_encode_pieces(self._h, _ptr(data), _ptr(offsets), n, _ptr(ids), len(data), _ptr(ooff), C.byref(needed)))
+        return ids[:needed.value], ooff
+
+    def pretokenize(self, data: np.ndarray, offsets: np.ndarray):
+        """Piece-start bitmap as a bool array of len(data) + 1 (the last entry is the sentinel)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        words = np.zeros(len(data) // 64 + 1, np.uint64)
+        self.lib.check(self.lib.L.tkz_pretokenize_utf8(self._h, _ptr(data), _ptr(offsets), n, _ptr(words)))
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")
+        return bits[:len(data) + 1].astype(bool)
+
+    def encode_utf8(self, text: bytes):
+        ids = np.empty(max(1, len(text)), np.int32)
+        n = C.c_int64(0)
+        buf = np.frombuffer(text, np.uint8) if text else np.zeros(1, np.uint8)
+        self.lib.check(self.lib.L.tkz_encode_utf8(self._h, _ptr(buf), len(text), _ptr(ids), len(text), C.byref(n)))
+        return ids[:n.value].tolist()
+
+    def encode_utf16(self, units):
+        u = np.ascontiguousarray(np.asarray(list(units) + [0], dtype=np.uint16))
+        n_units = len(u) - 1
+        ids = np.empty(max(1, 3 * n_units), np.int32)
+        n = C.c_int64(0)
+        self.lib.check(self.lib.L.tkz_encode_utf16(self._h, _ptr(u), n_units, _ptr(ids), 3 * n_units, C.byref(n)))
+        return ids[:n.value].tolist()
+
+    # -- device buffers (raw pointers, e.g. torch tensors' data_ptr()) --
+    def encode_batch_device(self, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, stream=0):
+        tot = C.c_int64(0)
+        self.lib.check(self.lib.L.tkz_encode_batch_device(self._h, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap,
+                                                          d_out_offsets, stream or None, C.byref(tot)))
+        return tot.value
+
+
+def corpus_doc_host(kind, seed, doc_index, min_len, max_len, lib: Library = None) -> bytes:
+    lib = lib or default_library()
+    n = lib.L.tkz_corpus_generate_doc_host(kind, seed, doc_index, min_len, max_len, None, 0)
+    buf = np.zeros(max(1, n), np.uint8)
+    lib.L.tkz_corpus_generate_doc_host(kind, seed, doc_index, min_len, max_len, buf.ctypes.data, n)
+    return buf[:n].tobytes()
+
+
+def corpus_generate_device(device, kind, seed, first_doc, n_docs, min_len, max_len, d_offsets, d_bytes, cap_bytes, stream=0,
+                           lib: Library = None):
+    lib = lib or default_library()
+    tot = C.c_int64(0)
+    lib.check(lib.L.tkz_corpus_generate_device(device, kind, seed, first_doc, n_docs, min_len, max_len, d_offsets, d_bytes or None,
+                                               cap_bytes, stream or None, C.byref(tot)))
+    return tot.value

@@ -1,0 +1,438 @@
+// tkz_api.cpp -- the C ABI of libtkz (include/tkz.h): vocabulary objects, device table upload,
+// workspace management and the launch sequence of one encode batch.  HIP only: there is no CPU path.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/tkz.h"
+#include "tkz_bpe.h"
+#include "tkz_corpus.h"
+#include "tkz_kernels.h"
+#include "tkz_pretok.h"
+#include "tkz_vocab.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+tkz_status fail(tkz_status s, const std::string& msg) { g_err = msg; return s; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(TKZ_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// a grow-only device buffer
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t n, int64_t* accounted) {
+        if (n <= cap) return hipSuccess;
+        size_t want = std::max(n, cap + cap / 2);
+        want = (want + 255) & ~size_t(255);
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, want);
+        if (e != hipSuccess && want > n) { want = (n + 255) & ~size_t(255); e = hipMalloc(&q, want); }
+        if (e != hipSuccess) return e;
+        if (p) (void)hipFree(p);
+        *accounted += (int64_t)want - (int64_t)cap;
+        p = q; cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct CounterBlock {          // mirrors the 64-byte device block
+    int32_t err; int32_t pad[3];
+    int64_t grand;
+    unsigned long long pool_head;
+    int64_t pad2[4];
+};
+
+}  // namespace
+
+struct tkz_vocab { tkz::Vocab v; };
+
+struct tkz_encoder {
+    int device = 0;
+    int pattern = 0;
+    int max_key_len = 0;
+    bool pretok_seq = false;
+    bool profiling = false;
+    std::mutex mu;
+    // device tables
+    DevBuf t_short, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp;
+    TkzTables T{};
+    // workspace
+    DevBuf w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doclocal, w_counters, w_pool;
+    // staging for the host-buffer entry points
+    DevBuf s_bytes, s_offs, s_out, s_outoffs;
+    CounterBlock* h_counters = nullptr;   // pinned
+    int64_t bytes_allocated = 0;
+    // profiling
+    hipEvent_t ev[tkz::K_COUNT][2] = {};
+    bool ev_used[tkz::K_COUNT] = {};
+    double ms[tkz::K_COUNT] = {};
+    int64_t launches[tkz::K_COUNT] = {};
+};
+
+namespace {
+
+void prof_hook(void* ctx, int id, int phase, hipStream_t s) {
+    tkz_encoder* e = static_cast<tkz_encoder*>(ctx);
+    if (!e->ev[id][phase]) (void)hipEventCreate(&e->ev[id][phase]);
+    (void)hipEventRecord(e->ev[id][phase], s);
+    if (phase == 1) e->ev_used[id] = true;
+}
+void prof_collect(tkz_encoder* e) {
+    for (int k = 0; k < tkz::K_COUNT; ++k) {
+        if (!e->ev_used[k]) continue;
+        float t = 0;
+        if (hipEventElapsedTime(&t, e->ev[k][0], e->ev[k][1]) == hipSuccess) { e->ms[k] += t; e->launches[k] += 1; }
+        e->ev_used[k] = false;
+    }
+}
+
+template <class T>
+hipError_t upload(DevBuf& b, const std::vector<T>& v, int64_t* acc) {
+    hipError_t e = b.ensure(std::max<size_t>(16, v.size() * sizeof(T)), acc);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+// the batch on the device; when pretok == false every "document" is taken as one piece
+tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
+                         int32_t* d_out, int64_t out_cap, int64_t* d_out_offs, hipStream_t stream, bool pretok,
+                         uint64_t* d_bitmap_only, int64_t* total_tokens) {
+    using namespace tkz;
+    if (n_docs < 0 || total < 0 || out_cap < 0) return fail(TKZ_E_ARG, "negative size");
+    if (total_tokens) *total_tokens = 0;
+    if (n_docs == 0 && total != 0) return fail(TKZ_E_ARG, "bytes without documents");
+    const int64_t nwords = total / 64 + 1;
+    if (total == 0) {
+        if (d_out_offs) HIP_TRY(hipMemsetAsync(d_out_offs, 0, (size_t)(n_docs + 1) * sizeof(int64_t), stream));
+        if (d_bitmap_only) { const uint64_t one = 1; HIP_TRY(hipMemcpyAsync(d_bitmap_only, &one, 8, hipMemcpyHostToDevice, stream)); }
+        HIP_TRY(hipStreamSynchronize(stream));
+        return TKZ_OK;
+    }
+    const int64_t ntiles = (total + kTile - 1) / kTile;
+    const int64_t nblk = (ntiles + kScanBlock - 1) / kScanBlock;
+    int64_t* acc = &e->bytes_allocated;
+    HIP_TRY(e->w_docbits.ensure((size_t)(nwords + 8) * 8, acc));
+    HIP_TRY(e->w_startbits.ensure((size_t)(nwords + 8) * 8, acc));
+    HIP_TRY(e->w_counters.ensure(sizeof(CounterBlock), acc));
+    if (!d_bitmap_only) {
+        HIP_TRY(e->w_tmp.ensure((size_t)(total + 64) * 4, acc));
+        HIP_TRY(e->w_tcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(e->w_tfirst.ensure((size_t)ntiles * 8, acc));
+        HIP_TRY(e->w_tbase.ensure((size_t)ntiles * 8, acc));
+        HIP_TRY(e->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
+        HIP_TRY(e->w_doclocal.ensure((size_t)(n_docs + 1) * 4, acc));
+        if (!e->w_pool.p) HIP_TRY(e->w_pool.ensure((size_t)std::min<int64_t>(16 * total + 4096, int64_t(64) << 20), acc));
+    }
+    if (!e->h_counters) HIP_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(CounterBlock), 0));
+
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        Launch L{stream, e->profiling ? prof_hook : nullptr, e};
+        int32_t* counters = e->w_counters.as<int32_t>();
+        int64_t* grand = reinterpret_cast<int64_t*>(e->w_counters.as<char>() + offsetof(CounterBlock, grand));
+        unsigned long long* pool_head = reinterpret_cast<unsigned long long*>(e->w_counters.as<char>() + offsetof(CounterBlock, pool_head));
+        uint64_t* docbits = e->w_docbits.as<uint64_t>();
+        uint64_t* startbits = e->w_startbits.as<uint64_t>();
+        HIP_TRY(hipMemsetAsync(counters, 0, sizeof(CounterBlock), stream));
+        HIP_TRY(hipMemsetAsync(docbits, 0, (size_t)nwords * 8, stream));
+        launch_docmark(L, d_offs, n_docs, total, docbits, counters);
+        if (!pretok) {
+            HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
+        } else if (e->pretok_seq || e->pattern == TKZ_PAT_O200K) {
+            HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
+            launch_pretok_seq(L, e->pattern, d_bytes, d_offs, n_docs, total, startbits, e->T.bmp_class, counters);
+        } else {
+            launch_pretok_rows(L, e->pattern, d_bytes, total, docbits, startbits, nwords, e->T.bmp_class, counters);
+        }
+        if (d_bitmap_only) {
+            HIP_TRY(hipMemcpyAsync(d_bitmap_only, startbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
+        } else {
+            EncodeParams P{};
+            P.bytes = d_bytes; P.total = total; P.startbits = startbits; P.docbits = docbits; P.nwords = nwords;
+            P.offs = d_offs; P.n_docs = n_docs;
+            P.tmp = e->w_tmp.as<int32_t>(); P.tile_count = e->w_tcount.as<int32_t>(); P.tile_first = e->w_tfirst.as<int64_t>();
+            P.doc_local = e->w_doclocal.as<int32_t>(); P.counters = counters;
+            P.pool = e->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(e->w_pool.cap / 4);
+            launch_encode(L, e->T, P, ntiles);
+            launch_scan(L, P.tile_count, ntiles, e->w_bsum.as<int64_t>(), e->w_tbase.as<int64_t>(), grand);
+            launch_gather(L, P.tmp, P.tile_count, P.tile_first, e->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
+            launch_docoffs(L, d_offs, n_docs, total, e->w_tbase.as<int64_t>(), P.doc_local, grand, d_out_offs);
+        }
+        HIP_TRY(hipMemcpyAsync(e->h_counters, counters, sizeof(CounterBlock), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipGetLastError());
+        if (e->profiling) prof_collect(e);
+        const int32_t err = e->h_counters->err;
+        if (err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the byte count");
+        if (err & kErrUtf8) return fail(TKZ_E_INVALID_UTF8, "input is not well-formed UTF-8 (or a document boundary falls inside a character)");
+        if (err & kErrTooLong) return fail(TKZ_E_UNSUPPORTED, "a single piece longer than 2^30 bytes");
+        if ((err & kErrPool) && attempt == 0) {      // scratch for very long pieces was too small: size it for the worst case, rerun
+            HIP_TRY(e->w_pool.ensure((size_t)(16 * total + 4096), acc));
+            continue;
+        }
+        if (err & kErrPool) return fail(TKZ_E_DEVICE, "long-piece scratch exhausted");
+        if (err & kErrKeyNotFound) return fail(TKZ_E_KEY_NOT_FOUND, "a byte of the input is not in the vocabulary (KeyNotFoundException in the reference)");
+        if (!d_bitmap_only) {
+            if (total_tokens) *total_tokens = e->h_counters->grand;
+            if (e->h_counters->grand > out_cap) return fail(TKZ_E_CAPACITY, "output capacity too small");
+        }
+        return TKZ_OK;
+    }
+    return fail(TKZ_E_DEVICE, "unreachable");
+}
+
+tkz_status check_encoder(tkz_encoder* e) {
+    if (!e) return fail(TKZ_E_ARG, "null encoder");
+    hipError_t r = hipSetDevice(e->device);
+    if (r != hipSuccess) return fail(TKZ_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(r));
+    return TKZ_OK;
+}
+
+// host buffers -> staging -> device path -> back
+tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const int64_t* offs, int64_t n_docs, int32_t* out_ids,
+                       int64_t out_cap, int64_t* out_offsets, int64_t* needed, bool pretok, uint64_t* bitmap) {
+    tkz_status st = check_encoder(e);
+    if (st != TKZ_OK) return st;
+    if (n_docs < 0 || !offs || (n_docs > 0 && !bytes && offs[n_docs] > 0)) return fail(TKZ_E_ARG, "null buffer");
+    if (offs[0] != 0) return fail(TKZ_E_ARG, "doc_offsets[0] must be 0");
+    const int64_t total = offs[n_docs];
+    if (total < 0) return fail(TKZ_E_ARG, "negative byte count");
+    std::lock_guard<std::mutex> lock(e->mu);
+    int64_t* acc = &e->bytes_allocated;
+    HIP_TRY(e->s_bytes.ensure((size_t)total + 64, acc));
+    HIP_TRY(e->s_offs.ensure((size_t)(n_docs + 1) * 8, acc));
+    const int64_t cap = bitmap ? 0 : std::min<int64_t>(out_cap, total);   // tokens <= bytes: more capacity is never used
+    if (!bitmap) {
+        HIP_TRY(e->s_out.ensure((size_t)std::max<int64_t>(cap, 1) * 4, acc));
+        HIP_TRY(e->s_outoffs.ensure((size_t)(n_docs + 1) * 8, acc));
+    } else {
+        HIP_TRY(e->s_out.ensure((size_t)(total / 64 + 1) * 8, acc));
+    }
+    if (total) HIP_TRY(hipMemcpy(e->s_bytes.p, bytes, (size_t)total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->s_offs.p, offs, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+    int64_t tokens = 0;
+    st = encode_device(e, e->s_bytes.as<uint8_t>(), e->s_offs.as<int64_t>(), n_docs, total, e->s_out.as<int32_t>(), cap,
+                       e->s_outoffs.as<int64_t>(), nullptr, pretok, bitmap ? e->s_out.as<uint64_t>() : nullptr, &tokens);
+    if (needed) *needed = tokens;
+    if (st != TKZ_OK) return st;
+    if (bitmap) {
+        HIP_TRY(hipMemcpy(bitmap, e->s_out.p, (size_t)(total / 64 + 1) * 8, hipMemcpyDeviceToHost));
+        return TKZ_OK;
+    }
+    if (tokens) HIP_TRY(hipMemcpy(out_ids, e->s_out.p, (size_t)tokens * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_offsets, e->s_outoffs.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    return TKZ_OK;
+}
+
+const char* const kRegexP1 = "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
+const char* const kRegexCl100k =
+    "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+#define TKZ_O2_SUFFIX "(?:'s|'S|'t|'T|'re|'RE|'Re|'eR|'ve|'VE|'vE|'Ve|'m|'M|'ll|'lL|'Ll|'LL|'d|'D)?"
+const char* const kRegexO200k =
+    "[^\r\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]*[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]+" TKZ_O2_SUFFIX
+    "|[^\r\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]+[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]*" TKZ_O2_SUFFIX
+    "|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n/]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+
+}  // namespace
+
+extern "C" {
+
+const char* tkz_last_error(void) { return g_err.c_str(); }
+
+tkz_status tkz_vocab_from_tiktoken(const uint8_t* file, size_t n, tkz_vocab** out) {
+    if (!out || (!file && n)) return fail(TKZ_E_ARG, "null argument");
+    *out = nullptr;
+    tkz_vocab* v = new tkz_vocab();
+    std::string msg;
+    int r = tkz::parse_tiktoken(file, n, &v->v, &msg);
+    if (r == TKZ_OK) r = tkz::build_tables(&v->v, &msg);
+    if (r != TKZ_OK) { delete v; return fail((tkz_status)r, msg); }
+    *out = v;
+    return TKZ_OK;
+}
+void tkz_vocab_destroy(tkz_vocab* v) { delete v; }
+int64_t tkz_vocab_size(const tkz_vocab* v) { return v ? (int64_t)v->v.keys.size() : 0; }
+int32_t tkz_vocab_max_key_len(const tkz_vocab* v) { return v ? v->v.max_key_len : 0; }
+int64_t tkz_vocab_pair_table_entries(const tkz_vocab* v) { return v ? v->v.pair_entries : 0; }
+int32_t tkz_vocab_rank(const tkz_vocab* v, const uint8_t* key, int32_t len) {
+    if (!v || len < 0 || (!key && len)) return -1;
+    int32_t r;
+    return v->v.lookup(std::string(reinterpret_cast<const char*>(key), (size_t)len), &r) ? r : -1;
+}
+
+tkz_status tkz_pattern_from_regex(const char* regex_utf8, int32_t* pattern_out) {
+    if (!regex_utf8 || !pattern_out) return fail(TKZ_E_ARG, "null argument");
+    if (!strcmp(regex_utf8, kRegexP1)) { *pattern_out = TKZ_PATTERN_P1; return TKZ_OK; }
+    if (!strcmp(regex_utf8, kRegexCl100k)) { *pattern_out = TKZ_PATTERN_CL100K; return TKZ_OK; }
+    if (!strcmp(regex_utf8, kRegexO200k)) { *pattern_out = TKZ_PATTERN_O200K; return TKZ_OK; }
+    return fail(TKZ_E_UNSUPPORTED, "only the three split patterns the reference defines are implemented (pattern 1, cl100k_base, o200k_base)");
+}
+
+tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t device, tkz_encoder** out) {
+    if (!out || !v) return fail(TKZ_E_ARG, "null argument");
+    *out = nullptr;
+    if (pattern < TKZ_PATTERN_P1 || pattern > TKZ_PATTERN_O200K) return fail(TKZ_E_UNSUPPORTED, "unknown pattern id");
+    int ndev = 0;
+    hipError_t r = hipGetDeviceCount(&ndev);
+    if (r != hipSuccess || ndev <= 0) return fail(TKZ_E_NO_DEVICE, "no HIP device available (libtkz has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(TKZ_E_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    tkz_encoder* e = new tkz_encoder();
+    e->device = device; e->pattern = pattern; e->max_key_len = v->v.max_key_len;
+    int64_t* acc = &e->bytes_allocated;
+    const tkz::Vocab& V = v->v;
+    hipError_t h = hipSuccess;
+    if (h == hipSuccess) h = upload(e->t_short, V.short_slots, acc);
+    if (h == hipSuccess) h = upload(e->t_long, V.long_slots, acc);
+    if (h == hipSuccess) h = upload(e->t_blob, V.long_blob, acc);
+    if (h == hipSuccess) h = upload(e->t_pair, V.pair_slots, acc);
+    if (h == hipSuccess) h = upload(e->t_byte, V.byte_rank, acc);
+    if (h == hipSuccess) h = upload(e->t_bpair, V.bytepair_rank, acc);
+    if (h == hipSuccess) h = upload(e->t_bmp, tkz::bmp_class_table(), acc);
+    if (h != hipSuccess) { tkz_encoder_destroy(e); return fail(TKZ_E_DEVICE, std::string("table upload: ") + hipGetErrorString(h)); }
+    e->T.short_slots = e->t_short.as<TkzShortSlot>(); e->T.short_mask = (uint32_t)V.short_slots.size() - 1;
+    e->T.long_slots = e->t_long.as<TkzLongSlot>();    e->T.long_mask = (uint32_t)V.long_slots.size() - 1;
+    e->T.long_blob = e->t_blob.as<uint8_t>();
+    e->T.pair_slots = e->t_pair.as<TkzPairSlot>();    e->T.pair_mask = (uint32_t)V.pair_slots.size() - 1;
+    e->T.byte_rank = e->t_byte.as<int32_t>();
+    e->T.bytepair_rank = e->t_bpair.as<int32_t>();
+    e->T.bmp_class = e->t_bmp.as<uint8_t>();
+    e->T.max_key_len = V.max_key_len;
+    e->T.pattern = pattern;
+    *out = e;
+    return TKZ_OK;
+}
+
+void tkz_encoder_destroy(tkz_encoder* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    DevBuf* bufs[] = {&e->t_short, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp,
+                      &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
+                      &e->w_doclocal, &e->w_counters, &e->w_pool, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs};
+    for (DevBuf* b : bufs) b->release();
+    if (e->h_counters) (void)hipHostFree(e->h_counters);
+    for (int k = 0; k < tkz::K_COUNT; ++k) for (int p = 0; p < 2; ++p) if (e->ev[k][p]) (void)hipEventDestroy(e->ev[k][p]);
+    delete e;
+}
+int32_t tkz_encoder_device(const tkz_encoder* e) { return e ? e->device : -1; }
+
+tkz_status tkz_encode_batch_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs,
+                                 int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed) {
+    if (!out_offsets || (out_cap > 0 && !out_ids)) return fail(TKZ_E_ARG, "null output buffer");
+    return encode_host(e, bytes, doc_offsets, n_docs, out_ids, out_cap, out_offsets, needed, true, nullptr);
+}
+
+tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets, int64_t n_docs,
+                                   int64_t total_bytes, int32_t* d_out_ids, int64_t out_cap, int64_t* d_out_offsets,
+                                   void* hip_stream, int64_t* total_tokens) {
+    tkz_status st = check_encoder(e);
+    if (st != TKZ_OK) return st;
+    if (!d_doc_offsets || !d_out_offsets || (total_bytes > 0 && (!d_bytes || !d_out_ids))) return fail(TKZ_E_ARG, "null device buffer");
+    if (reinterpret_cast<uintptr_t>(d_bytes) & 15) return fail(TKZ_E_ARG, "d_bytes must be 16-byte aligned");
+    std::lock_guard<std::mutex> lock(e->mu);
+    return encode_device(e, d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets,
+                         static_cast<hipStream_t>(hip_stream), true, nullptr, total_tokens);
+}
+
+tkz_status tkz_encode_utf8(tkz_encoder* e, const uint8_t* text, int64_t len, int32_t* out_ids, int64_t out_cap, int64_t* n_out) {
+    if (len < 0 || !n_out) return fail(TKZ_E_ARG, "bad argument");
+    const int64_t offs[2] = {0, len};
+    int64_t oo[2] = {0, 0}, needed = 0;
+    tkz_status st = encode_host(e, text, offs, 1, out_ids, out_cap, oo, &needed, true, nullptr);
+    *n_out = needed;
+    return st;
+}
+
+tkz_status tkz_encode_utf16(tkz_encoder* e, const uint16_t* text, int64_t len, int32_t* out_ids, int64_t out_cap, int64_t* n_out) {
+    if (len < 0 || (!text && len) || !n_out) return fail(TKZ_E_ARG, "bad argument");
+    // Encoding.UTF8.GetBytes semantics: a surrogate pair -> 4 bytes, a lone surrogate -> U+FFFD (EF BF BD).
+    // Splitting is unaffected: a lone surrogate (Cs) and U+FFFD (So) are both one "other" unit under every pattern.
+    std::vector<uint8_t> u8;
+    u8.reserve((size_t)len * 3);
+    for (int64_t i = 0; i < len; ++i) {
+        uint32_t c = text[i];
+        if (c >= 0xD800 && c <= 0xDBFF && i + 1 < len && text[i + 1] >= 0xDC00 && text[i + 1] <= 0xDFFF) {
+            c = 0x10000 + ((c - 0xD800) << 10) + (text[i + 1] - 0xDC00); ++i;
+        } else if (c >= 0xD800 && c <= 0xDFFF) c = 0xFFFD;
+        if (c < 0x80) u8.push_back((uint8_t)c);
+        else if (c < 0x800) { u8.push_back(0xC0 | (c >> 6)); u8.push_back(0x80 | (c & 0x3F)); }
+        else if (c < 0x10000) { u8.push_back(0xE0 | (c >> 12)); u8.push_back(0x80 | ((c >> 6) & 0x3F)); u8.push_back(0x80 | (c & 0x3F)); }
+        else { u8.push_back(0xF0 | (c >> 18)); u8.push_back(0x80 | ((c >> 12) & 0x3F)); u8.push_back(0x80 | ((c >> 6) & 0x3F)); u8.push_back(0x80 | (c & 0x3F)); }
+    }
+    return tkz_encode_utf8(e, u8.data(), (int64_t)u8.size(), out_ids, out_cap, n_out);
+}
+
+tkz_status tkz_pretokenize_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs, uint64_t* out_bitmap_words) {
+    if (!out_bitmap_words) return fail(TKZ_E_ARG, "null output buffer");
+    return encode_host(e, bytes, doc_offsets, n_docs, nullptr, 0, nullptr, nullptr, true, out_bitmap_words);
+}
+
+tkz_status tkz_encode_pieces(tkz_encoder* e, const uint8_t* bytes, const int64_t* piece_offsets, int64_t n_pieces,
+                             int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed) {
+    if (!out_offsets || (out_cap > 0 && !out_ids)) return fail(TKZ_E_ARG, "null output buffer");
+    return encode_host(e, bytes, piece_offsets, n_pieces, out_ids, out_cap, out_offsets, needed, false, nullptr);
+}
+
+tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value) {
+    if (!e) return fail(TKZ_E_ARG, "null encoder");
+    if (option == TKZ_OPT_PRETOK_SEQUENTIAL) { e->pretok_seq = value != 0; return TKZ_OK; }
+    return fail(TKZ_E_ARG, "unknown option");
+}
+
+tkz_status tkz_encoder_set_profiling(tkz_encoder* e, int32_t enabled) {
+    if (!e) return fail(TKZ_E_ARG, "null encoder");
+    e->profiling = enabled != 0;
+    return TKZ_OK;
+}
+tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, int32_t reset) {
+    if (!e) return fail(TKZ_E_ARG, "null encoder");
+    std::lock_guard<std::mutex> lock(e->mu);
+    for (int k = 0; k < tkz::K_COUNT; ++k) {
+        if (ms) ms[k] = e->ms[k];
+        if (launches) launches[k] = e->launches[k];
+        if (reset) { e->ms[k] = 0; e->launches[k] = 0; }
+    }
+    return TKZ_OK;
+}
+int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) { return e ? e->bytes_allocated : 0; }
+const char* tkz_kernel_name(int32_t k) {
+    static const char* const names[] = {"k_docmark", "k_pretok", "k_encode_tiles", "k_scan", "k_gather", "k_docoffs"};
+    return (k >= 0 && k < tkz::K_COUNT) ? names[k] : "?";
+}
+
+tkz_status tkz_corpus_generate_device(int32_t device, int32_t kind, uint64_t seed, int64_t first_doc, int64_t n_docs,
+                                      int32_t min_len, int32_t max_len, int64_t* d_doc_offsets, uint8_t* d_bytes,
+                                      int64_t cap_bytes, void* hip_stream, int64_t* total_bytes) {
+    if (kind < 1 || kind > 3 || n_docs < 0 || min_len < 0 || max_len < min_len || !d_doc_offsets || !total_bytes)
+        return fail(TKZ_E_ARG, "bad corpus arguments");
+    hipError_t r = hipSetDevice(device);
+    if (r != hipSuccess) return fail(TKZ_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(r));
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    int64_t* d_total = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_total, 8));
+    tkz::launch_corpus(s, kind, seed, first_doc, n_docs, min_len, max_len, d_doc_offsets, d_bytes, d_bytes ? cap_bytes : 0, d_total);
+    hipError_t c = hipMemcpyAsync(total_bytes, d_total, 8, hipMemcpyDeviceToHost, s);
+    if (c == hipSuccess) c = hipStreamSynchronize(s);
+    if (c == hipSuccess) c = hipGetLastError();
+    (void)hipFree(d_total);
+    if (c != hipSuccess) return fail(TKZ_E_DEVICE, std::string("corpus generation: ") + hipGetErrorString(c));
+    if (d_bytes && *total_bytes > cap_bytes) return fail(TKZ_E_CAPACITY, "corpus buffer too small");
+    return TKZ_OK;
+}
+
+int64_t tkz_corpus_generate_doc_host(int32_t kind, uint64_t seed, int64_t doc_index, int32_t min_len, int32_t max_len,
+                                     uint8_t* buf, int64_t cap) {
+    if (kind < 1 || kind > 3 || min_len < 0 || max_len < min_len) return -1;
+    return tkz_corpus_doc(kind, seed, doc_index, min_len, max_len, buf, cap);
+}
+
+}  // extern "C"

@@ -1,0 +1,395 @@
+// tkz_pretok.h -- Regex.Matches(text) of the three split patterns the reference defines
+// (Tokenizer_C#/TokenizerLib/TikTokenizer.cs:77,252; patterns TokenizerBuilder.cs:112,128 and
+// tokenizer_ts/src/tokenizerBuilder.ts:79-89), as scanners over UTF-8 bytes.
+//
+// Two formulations, which must agree bit for bit:
+//
+//  (1) tkz_match_*: the sequential matcher -- from a match start p, the end of the leftmost-first
+//      match.  Char-level restatement of each alternation with its backtracking resolved by hand.
+//      Used by the per-document fallback kernel (o200k today, and the cross-check of (2) in tests).
+//
+//  (2) TkzRowScan: the position-parallel formulation for pattern 1 and cl100k -- one wavefront
+//      takes 64 consecutive bytes ("a row"), every lane classifies its byte, class masks come from
+//      64-lane ballots, and "does a piece start here" is a function of the neighbouring chars plus
+//      three run scans (index in a digit run mod 3; CR/LF absorbed by the preceding
+//      `[^\s\p{L}\p{N}]+[\r\n]*`; a CR/LF further on in the same white-space run for `\s*[\r\n]+`).
+//      Rows are processed in order by a wave, carrying the scan state in scalars.
+//      Derivation of the local rules: DESIGN.md "K1".
+#pragma once
+#include <stdint.h>
+
+#include "tkz_classes.h"
+#include "tkz_simt.h"
+
+enum { TKZ_PAT_P1 = 1, TKZ_PAT_CL100K = 2, TKZ_PAT_O200K = 3 };
+
+// =================================================================================================
+// (1) sequential matcher
+// =================================================================================================
+struct TkzDoc { const uint8_t* b; int64_t n; const uint8_t* bmp; };
+
+TKZ_HD uint32_t tkz_doc_byte(const TkzDoc& d, int64_t p) { return p < d.n ? d.b[p] : 0u; }
+TKZ_HD TkzChar tkz_doc_char(const TkzDoc& d, int64_t p) {
+    return tkz_decode(d.b[p], tkz_doc_byte(d, p + 1), tkz_doc_byte(d, p + 2), tkz_doc_byte(d, p + 3), d.bmp);
+}
+TKZ_HD int64_t tkz_prev_char(const TkzDoc& d, int64_t p, int64_t lo) {   // start of the char that ends at p
+    int64_t s = p - 1;
+    int k = 0;
+    while (s > lo && k < 3 && (d.b[s] & 0xC0) == 0x80) { --s; ++k; }
+    // if that is not a lead covering p-1 (malformed input), fall back to the single byte
+    const TkzChar c = tkz_doc_char(d, s);
+    return (s + c.len == p) ? s : p - 1;
+}
+
+// white-space alternatives shared by the patterns.  crlf_alt: `\s*[\r\n]+` is present (cl100k, o200k).
+TKZ_HD int64_t tkz_match_ws(const TkzDoc& d, int64_t p, bool crlf_alt) {
+    int64_t k = p, last = p, after_crlf = -1;
+    while (k < d.n) {
+        const TkzChar c = tkz_doc_char(d, k);
+        if (c.uc != UC_WS || c.units == 2) break;
+        last = k; k += c.len;
+        if (c.cp == '\r' || c.cp == '\n') after_crlf = k;
+    }
+    if (crlf_alt && after_crlf >= 0) return after_crlf;   // \s*[\r\n]+ : backtracks to the LAST CR/LF of the run
+    if (k == d.n) return k;                               // \s+(?!\S) holds at the end of the text
+    if (last > p) return last;                            // \s+(?!\S) gives back one char
+    return k;                                             // \s+
+}
+
+TKZ_HD int64_t tkz_match_p1(const TkzDoc& d, int64_t p) {
+    const TkzChar c0 = tkz_doc_char(d, p);
+    if (c0.cp == '\'') {
+        const int k = tkz_contraction_len(tkz_doc_byte(d, p + 1), tkz_doc_byte(d, p + 2), false);
+        if (k) return p + k;
+    }
+    int64_t q = p;
+    int pc = tkz_pc_of(c0);
+    if (pc == PC_SP && p + 1 < d.n) {                     // ' ?' is greedy: try the space first
+        const int pc1 = tkz_pc_of(tkz_doc_char(d, p + 1));
+        if (pc1 == PC_L || pc1 == PC_N || tkz_pc_is_other(pc1)) { q = p + 1; pc = pc1; }
+    }
+    if (pc == PC_L || pc == PC_N || tkz_pc_is_other(pc)) {
+        const bool oth = tkz_pc_is_other(pc);
+        int64_t k = q;
+        while (k < d.n) {
+            const TkzChar c = tkz_doc_char(d, k);
+            const int x = tkz_pc_of(c);
+            if (oth ? !tkz_pc_is_other(x) : x != pc) break;
+            k += c.len;
+        }
+        return k;
+    }
+    return tkz_match_ws(d, p, false);
+}
+
+TKZ_HD int64_t tkz_match_cl100k(const TkzDoc& d, int64_t p) {
+    const TkzChar c0 = tkz_doc_char(d, p);
+    if (c0.cp == '\'') {
+        const int k = tkz_contraction_len(tkz_doc_byte(d, p + 1), tkz_doc_byte(d, p + 2), true);
+        if (k) return p + k;
+    }
+    const int pc0 = tkz_pc_of(c0);
+    {   // [^\r\n\p{L}\p{N}]?\p{L}+
+        int64_t q = -1;
+        if (pc0 == PC_L) q = p;
+        else if ((pc0 == PC_O1 || pc0 == PC_SP || pc0 == PC_WS) && p + c0.len < d.n &&
+                 tkz_pc_of(tkz_doc_char(d, p + c0.len)) == PC_L) q = p + c0.len;
+        if (q >= 0) {
+            int64_t k = q;
+            while (k < d.n) { const TkzChar c = tkz_doc_char(d, k); if (tkz_pc_of(c) != PC_L) break; k += c.len; }
+            return k;
+        }
+    }
+    if (pc0 == PC_N) {   // \p{N}{1,3}
+        int64_t k = p; int cnt = 0;
+        while (k < d.n && cnt < 3) { const TkzChar c = tkz_doc_char(d, k); if (tkz_pc_of(c) != PC_N) break; k += c.len; ++cnt; }
+        return k;
+    }
+    {   //  ?[^\s\p{L}\p{N}]+[\r\n]*
+        int64_t q = -1;
+        if (tkz_pc_is_other(pc0)) q = p;
+        else if (pc0 == PC_SP && p + 1 < d.n && tkz_pc_is_other(tkz_pc_of(tkz_doc_char(d, p + 1)))) q = p + 1;
+        if (q >= 0) {
+            int64_t k = q;
+            while (k < d.n) { const TkzChar c = tkz_doc_char(d, k); if (!tkz_pc_is_other(tkz_pc_of(c))) break; k += c.len; }
+            while (k < d.n && (d.b[k] == '\r' || d.b[k] == '\n')) ++k;
+            return k;
+        }
+    }
+    return tkz_match_ws(d, p, true);
+}
+
+// o200k: A = [\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}], B = [\p{Ll}\p{Lm}\p{Lo}\p{M}]
+TKZ_HD bool tkz_o2_A(const TkzChar& c) { return c.units == 1 && (c.uc == UC_LU || c.uc == UC_LT || c.uc == UC_LM || c.uc == UC_LO || c.uc == UC_M); }
+TKZ_HD bool tkz_o2_B(const TkzChar& c) { return c.units == 1 && (c.uc == UC_LL || c.uc == UC_LM || c.uc == UC_LO || c.uc == UC_M); }
+TKZ_HD int64_t tkz_o2_suffix(const TkzDoc& d, int64_t e) {   // (?:'s|'S|...)?
+    if (e < d.n && d.b[e] == '\'') e += tkz_contraction_len_o200k(tkz_doc_byte(d, e + 1), tkz_doc_byte(d, e + 2));
+    return e;
+}
+TKZ_HD int64_t tkz_match_o200k(const TkzDoc& d, int64_t p) {
+    const TkzChar c0 = tkz_doc_char(d, p);
+    const bool is_crlf = c0.cp == '\r' || c0.cp == '\n';
+    const bool prefixable = c0.units == 1 && !is_crlf && !tkz_uc_is_letter(c0.uc) && c0.uc != UC_N;
+    // alt 1: prefix? A* B+ suffix?
+    for (int pre = 1; pre >= 0; --pre) {
+        if (pre && !prefixable) continue;
+        const int64_t q = p + (pre ? c0.len : 0);
+        int64_t t = q;
+        while (t < d.n) { const TkzChar c = tkz_doc_char(d, t); if (!tkz_o2_A(c)) break; t += c.len; }
+        if (t < d.n && tkz_o2_B(tkz_doc_char(d, t))) {            // B+ continues after the A run
+            int64_t k = t;
+            while (k < d.n) { const TkzChar c = tkz_doc_char(d, k); if (!tkz_o2_B(c)) break; k += c.len; }
+            return tkz_o2_suffix(d, k);
+        }
+        // A* gives chars back until B+ can start: the last char of the A run that is also in B
+        int64_t s = t;
+        while (s > q) {
+            const int64_t s0 = tkz_prev_char(d, s, q);
+            const TkzChar c = tkz_doc_char(d, s0);
+            if (tkz_o2_B(c)) return tkz_o2_suffix(d, s0 + c.len);   // what follows (up to t) is in A only, so B+ stops here
+            s = s0;
+        }
+    }
+    // alt 2: prefix? A+ B* suffix?
+    for (int pre = 1; pre >= 0; --pre) {
+        if (pre && !prefixable) continue;
+        const int64_t q = p + (pre ? c0.len : 0);
+        int64_t t = q;
+        while (t < d.n) { const TkzChar c = tkz_doc_char(d, t); if (!tkz_o2_A(c)) break; t += c.len; }
+        if (t > q) {
+            while (t < d.n) { const TkzChar c = tkz_doc_char(d, t); if (!tkz_o2_B(c)) break; t += c.len; }
+            return tkz_o2_suffix(d, t);
+        }
+    }
+    if (c0.uc == UC_N && c0.units == 1) {   // \p{N}{1,3}
+        int64_t k = p; int cnt = 0;
+        while (k < d.n && cnt < 3) { const TkzChar c = tkz_doc_char(d, k); if (c.uc != UC_N || c.units != 1) break; k += c.len; ++cnt; }
+        return k;
+    }
+    {   //  ?[^\s\p{L}\p{N}]+[\r\n/]*   (the class contains \p{M})
+        auto oth = [](const TkzChar& c) { return c.units == 2 || c.uc == UC_OTHER || c.uc == UC_M; };
+        int64_t q = -1;
+        if (oth(c0)) q = p;
+        else if (c0.cp == ' ' && p + 1 < d.n && oth(tkz_doc_char(d, p + 1))) q = p + 1;
+        if (q >= 0) {
+            int64_t k = q;
+            while (k < d.n) { const TkzChar c = tkz_doc_char(d, k); if (!oth(c)) break; k += c.len; }
+            while (k < d.n && (d.b[k] == '\r' || d.b[k] == '\n' || d.b[k] == '/')) ++k;
+            return k;
+        }
+    }
+    return tkz_match_ws(d, p, true);
+}
+
+TKZ_HD int64_t tkz_match_at(int pattern, const TkzDoc& d, int64_t p) {
+    return pattern == TKZ_PAT_P1 ? tkz_match_p1(d, p) : pattern == TKZ_PAT_CL100K ? tkz_match_cl100k(d, p) : tkz_match_o200k(d, p);
+}
+
+// =================================================================================================
+// (2) position-parallel rows (pattern 1, cl100k)
+// =================================================================================================
+#ifndef TKZ_NO_SIMT
+
+struct TkzRowLane {      // what a lane knows about ITS byte of a row
+    int pc;              // PC_* of the char the byte belongs to (PC_NONE outside the corpus)
+    int len;             // byte length of that char
+    int off;             // distance back to its lead byte (0 for a lead)
+    uint32_t b, b1, b2;  // the byte and the two that follow
+    int bad;             // malformed UTF-8 seen by this lane
+};
+
+TKZ_DEV uint32_t tkz_gbyte(const uint8_t* bytes, int64_t total, int64_t pos) {
+    return (pos >= 0 && pos < total) ? bytes[pos] : 0u;
+}
+
+TKZ_DEV TkzRowLane tkz_classify_byte(const uint8_t* bytes, int64_t total, int64_t pos, const uint8_t* bmp) {
+    TkzRowLane r;
+    r.pc = PC_NONE; r.len = 1; r.off = 0; r.b = r.b1 = r.b2 = 0; r.bad = 0;
+    if (pos < 0 || pos >= total) return r;
+    uint32_t m3 = tkz_gbyte(bytes, total, pos - 3), m2 = tkz_gbyte(bytes, total, pos - 2), m1 = tkz_gbyte(bytes, total, pos - 1);
+    const uint32_t b0 = bytes[pos];
+    const uint32_t p1 = tkz_gbyte(bytes, total, pos + 1), p2 = tkz_gbyte(bytes, total, pos + 2), p3 = tkz_gbyte(bytes, total, pos + 3);
+    r.b = b0; r.b1 = p1; r.b2 = p2;
+    int off = 0;
+    if ((b0 & 0xC0) == 0x80) {   // continuation byte: find the lead within 3 bytes
+        if (m1 >= 0xC2 && pos >= 1) off = 1;
+        else if ((m1 & 0xC0) == 0x80 && m2 >= 0xE0 && pos >= 2) off = 2;
+        else if ((m1 & 0xC0) == 0x80 && (m2 & 0xC0) == 0x80 && m3 >= 0xF0 && pos >= 3) off = 3;
+        else r.bad = 1;
+    }
+    TkzChar c;
+    if (off == 0) c = tkz_decode(b0, p1, p2, p3, bmp);
+    else if (off == 1) c = tkz_decode(m1, b0, p1, p2, bmp);
+    else if (off == 2) c = tkz_decode(m2, m1, b0, p1, bmp);
+    else c = tkz_decode(m3, m2, m1, b0, bmp);
+    if (c.bad || off >= c.len) { r.bad = 1; c = tkz_decode(b0, 0, 0, 0, bmp); c.bad = 0; c.len = 1; c.units = 1; c.uc = UC_OTHER; off = 0; }
+    r.pc = tkz_pc_of(c); r.len = c.len; r.off = off;
+    return r;
+}
+
+struct TkzRowMasks { uint64_t nb, nl, cr, wsb; };   // N bytes, N leads, CR/LF bytes, \s bytes
+
+TKZ_DEV TkzRowMasks tkz_row_masks(const TkzRowLane& L) {
+    TkzRowMasks m;
+    m.nb = simt::ballot(L.pc == PC_N);
+    m.nl = simt::ballot(L.pc == PC_N && L.off == 0);
+    m.cr = simt::ballot(L.pc == PC_CRLF);
+    m.wsb = simt::ballot(tkz_pc_is_ws(L.pc));
+    return m;
+}
+
+// value of lane `rel` in the three-row window (rel in [-64, 128))
+TKZ_DEV int tkz_win3(int vP, int vC, int vN, int rel) {
+    const int a = simt::shfl(vP, rel & 63), b = simt::shfl(vC, rel & 63), c = simt::shfl(vN, rel & 63);
+    return rel < 0 ? a : (rel < 64 ? b : c);
+}
+TKZ_DEV int tkz_win2(int vP, int vC, int rel) {   // rel in [-64, 64)
+    const int a = simt::shfl(vP, rel & 63), b = simt::shfl(vC, rel & 63);
+    return rel < 0 ? a : b;
+}
+TKZ_DEV int tkz_bit3(uint64_t mP, uint64_t mC, uint64_t mN, int rel) {
+    const uint64_t m = rel < 0 ? mP : (rel < 64 ? mC : mN);
+    return (int)((m >> (rel & 63)) & 1ull);
+}
+
+// T = S | (R & (T << 1)) : propagate seeds S (subset of R) upward through runs of R.  64-bit.
+TKZ_HD uint64_t tkz_fill_up64(uint64_t S, uint64_t R) { return ((~(R + S)) & R) | S; }
+// the same over 128 bits (lo = bits 0..63)
+TKZ_HD void tkz_fill_up128(uint64_t Slo, uint64_t Shi, uint64_t Rlo, uint64_t Rhi, uint64_t* Tlo, uint64_t* Thi) {
+    const uint64_t lo = Rlo + Slo;
+    const uint64_t carry = lo < Rlo ? 1ull : 0ull;
+    const uint64_t hi = Rhi + Shi + carry;
+    *Tlo = ((~lo) & Rlo) | Slo;
+    *Thi = ((~hi) & Rhi) | Shi;
+}
+
+struct TkzScanCarry {        // wave-uniform state carried from row to row
+    int nb63;                // previous row: its last byte is an N byte
+    int carryN;              // N chars of the running digit run before this row, mod 3
+    int abs63;               // previous row: its last byte is an absorbed CR/LF
+    int64_t sa_from, sa_end, sa_lastcr;   // scan-ahead cache: a connected \s run covers [sa_from, sa_end), last CR/LF at sa_lastcr
+};
+
+// Does a connected white-space run that starts at absolute position `from` (a row boundary) contain a
+// CR/LF?  Only needed when a white-space run covers the whole look-ahead row.  Wave-uniform.
+TKZ_DEV bool tkz_scan_ahead_crlf(const uint8_t* bytes, int64_t total, const uint64_t* docbits, int64_t nrows,
+                                 const uint8_t* bmp, int64_t from, TkzScanCarry& cy) {
+    if (cy.sa_from >= 0 && from >= cy.sa_from && from < cy.sa_end) return cy.sa_lastcr >= from;
+    int64_t row = from >> 6;
+    int64_t lastcr = -1, end = from;
+    for (;; ++row) {
+        if (row >= nrows) { end = row << 6; break; }
+        const TkzRowLane L = tkz_classify_byte(bytes, total, (row << 6) + simt::lane(), bmp);
+        const uint64_t wsb = simt::ballot(tkz_pc_is_ws(L.pc));
+        const uint64_t cr = simt::ballot(L.pc == PC_CRLF);
+        const uint64_t conn = wsb & ~docbits[row];
+        const uint64_t brk = ~conn;
+        const int m = brk ? tkz_ctz64(brk) : 64;
+        const uint64_t c = cr & tkz_lowmask(m);
+        if (c) lastcr = (row << 6) + tkz_msb64(c);
+        if (m < 64) { end = (row << 6) + m; break; }
+    }
+    cy.sa_from = from; cy.sa_end = end; cy.sa_lastcr = lastcr;
+    return lastcr >= from;
+}
+
+// Evaluate one row.  P/C/N = lane values of the previous / current / next row; ds* = document-start
+// bits; mC/mN = class masks of the current / next row; fP = per-lane flags of the previous row
+// (clen, o1ms), fC receives the current row's.  Returns the piece-start mask of the current row.
+template <int PATTERN>
+TKZ_DEV uint64_t tkz_row_eval(const TkzRowLane& P, const TkzRowLane& C, const TkzRowLane& N,
+                              uint64_t dsP, uint64_t dsC, uint64_t dsN,
+                              const TkzRowMasks& mC, const TkzRowMasks& mN,
+                              int clenP, int o1msP, int* clenC_out, int* o1msC_out,
+                              TkzScanCarry& cy,
+                              const uint8_t* bytes, int64_t total, const uint64_t* docbits, int64_t nrows,
+                              const uint8_t* bmp, int64_t row) {
+    const int lane = simt::lane();
+    const int lead = lane - C.off;                       // >= -3
+    const int dsLead = tkz_bit3(dsP, dsC, dsN, lead);
+    int p = tkz_win3(P.pc, C.pc, N.pc, lead - 1);
+    if (dsLead) p = PC_NONE;
+    const int nx = lead + C.len;                         // <= 66
+    int n = tkz_win3(P.pc, C.pc, N.pc, nx);
+    if (tkz_bit3(dsP, dsC, dsN, nx)) n = PC_NONE;
+    const bool isLead = C.off == 0 && C.pc != PC_NONE;
+
+    // contraction at an apostrophe that is a match start
+    int clen = 0;
+    if (C.b == '\'' && C.pc == PC_O1 && !tkz_pc_is_other(p) && p != PC_SP) {
+        const int k = tkz_contraction_len(C.b1, C.b2, PATTERN == TKZ_PAT_CL100K);
+        if (k && !tkz_bit3(dsP, dsC, dsN, lane + 1) && (k == 2 || !tkz_bit3(dsP, dsC, dsN, lane + 2))) clen = k;
+    }
+    const int o1ms = (C.pc == PC_O1 && !tkz_pc_is_other(p) && p != PC_SP && !tkz_pc_is_other(n)) ? 1 : 0;
+    *clenC_out = clen; *o1msC_out = o1ms;
+    const int cback2 = tkz_win2(clenP, clen, lane - 2), cback3 = tkz_win2(clenP, clen, lane - 3);   // (collectives: evaluate both)
+    const bool contrEnd = cback2 == 2 || cback3 == 3;
+    const int clenPrev = tkz_win2(clenP, clen, lead - 1);
+    const int o1msPrev = tkz_win2(o1msP, o1ms, lead - 1);
+
+    bool start = false;
+    if (PATTERN == TKZ_PAT_P1) {
+        if (C.pc == PC_L) start = p != PC_L && p != PC_SP && clenPrev == 0;
+        else if (C.pc == PC_N) start = p != PC_N && p != PC_SP;
+        else if (tkz_pc_is_other(C.pc)) start = !tkz_pc_is_other(p) && p != PC_SP;
+        else if (tkz_pc_is_ws(C.pc)) start = !tkz_pc_is_ws(p) || (!tkz_pc_is_ws(n) && n != PC_NONE);
+    } else {
+        // ---- run scans (wave-uniform mask algebra) ----
+        // (a) index of an N char inside its digit run
+        const uint64_t startsN = mC.nb & (dsC | ~((mC.nb << 1) | (uint64_t)(cy.nb63 & 1)));
+        int idx = 0;
+        {
+            const uint64_t below = tkz_lowmask(lane);                 // bits < lane
+            const uint64_t m = startsN & (below | (1ull << lane));    // run starts at or below me
+            if (m) { const int rs = tkz_msb64(m); idx = tkz_popc64(mC.nl & below & ~tkz_lowmask(rs)); }
+            else idx = cy.carryN + tkz_popc64(mC.nl & below);
+        }
+        // (b) CR/LF absorbed by a preceding ` ?[^\s\p{L}\p{N}]+[\r\n]*`
+        const uint64_t R = mC.cr & ~dsC;
+        uint64_t seeds = simt::ballot(C.pc == PC_CRLF && tkz_pc_is_other(p));
+        if (cy.abs63) seeds |= R & 1ull;
+        const uint64_t ABS = tkz_fill_up64(seeds & R, R);
+        // (c) T(j) = CR(j) | (CONN(j+1) & T(j+1)): a CR/LF at or after j inside the same \s run
+        uint64_t Tcur;
+        {
+            const uint64_t connC = mC.wsb & ~dsC, connN = mN.wsb & ~dsN;
+            uint64_t crN = mN.cr;
+            if (connN == ~0ull && (mC.wsb >> 63)) {      // the run may continue past the look-ahead row
+                const int64_t from = (row + 2) << 6;
+                const bool conn128 = from < (nrows << 6) && !(docbits[row + 2] & 1ull) &&
+                                     tkz_pc_is_ws(tkz_classify_byte(bytes, total, from, bmp).pc);
+                if (conn128 && tkz_scan_ahead_crlf(bytes, total, docbits, nrows, bmp, from, cy)) crN |= 1ull << 63;
+            }
+            // reversed positions k = 127 - j : S'(k) = CR(127-k), G'(k) = CONN(128-k)
+            const uint64_t Slo = tkz_brev64(crN), Shi = tkz_brev64(mC.cr);
+            // CONN as a 128-bit value (lo = connC, hi = connN); G' = brev128(CONN) << 1
+            const uint64_t rlo = tkz_brev64(connN), rhi = tkz_brev64(connC);
+            const uint64_t Glo = rlo << 1, Ghi = (rhi << 1) | (rlo >> 63);
+            const uint64_t S2lo = (Slo << 1) & Glo, S2hi = ((Shi << 1) | (Slo >> 63)) & Ghi;
+            uint64_t Plo, Phi;
+            tkz_fill_up128(S2lo, S2hi, Glo, Ghi, &Plo, &Phi);
+            (void)Plo;
+            Tcur = tkz_brev64(Shi | Phi);
+        }
+        const bool absorbed = (ABS >> lane) & 1ull;
+        const bool absorbedPrev = lane == 0 ? (cy.abs63 != 0) : (((ABS >> ((lane - 1) & 63)) & 1ull) != 0);
+        const bool crlfAhead = (Tcur >> lane) & 1ull;
+
+        if (C.pc == PC_L) start = p != PC_L && p != PC_SP && p != PC_WS && !o1msPrev;
+        else if (C.pc == PC_N) start = (idx % 3) == 0;
+        else if (tkz_pc_is_other(C.pc)) start = !tkz_pc_is_other(p) && p != PC_SP;
+        else if (tkz_pc_is_ws(C.pc))
+            start = !absorbed && ((!tkz_pc_is_ws(p) || absorbedPrev) || (p == PC_CRLF && !crlfAhead) ||
+                                  (C.pc != PC_CRLF && !tkz_pc_is_ws(n) && n != PC_NONE));
+
+        // carries for the next row
+        int carryN = 0;
+        if (mC.nb >> 63) carryN = (startsN ? tkz_popc64(mC.nl & ~tkz_lowmask(tkz_msb64(startsN))) : cy.carryN + tkz_popc64(mC.nl)) % 3;
+        cy.carryN = carryN;
+        cy.nb63 = (int)(mC.nb >> 63);
+        cy.abs63 = (int)(ABS >> 63);
+    }
+    start = start || contrEnd;
+    return simt::ballot(start && isLead) | dsC;
+}
+#endif  // TKZ_NO_SIMT

@@ -1,0 +1,61 @@
+// tkz_simt.h -- the wave64 / workgroup primitives the kernels are written against.
+//
+// Product build (hipcc, gfx950): thin inline wrappers over the CDNA4 intrinsics (64-lane ballot,
+// ds_bpermute shuffles, s_barrier, bit ops).  Everything is written for wavefront = 64.
+//
+// Test build (-DTKZ_HOSTEMU, g++, tests/hostemu/): the same names are provided by a fiber-based
+// SIMT emulator so the *actual kernel sources* can be executed on a CPU by the `not gpu` tests
+// before GPU time is spent.  That build is test infrastructure only: it is never linked into
+// libtkz.so and nothing in tokenizer_amd/ loads it.
+#pragma once
+#include <stdint.h>
+
+#ifdef TKZ_HOSTEMU
+#include "hip_emu.h"   // tests/hostemu/hip_emu.h
+#else
+#include <hip/hip_runtime.h>
+
+#define TKZ_DEV __device__ __forceinline__
+#define TKZ_HD __host__ __device__ __forceinline__
+#define TKZ_KERNEL(bounds) __global__ __launch_bounds__(bounds)
+#define TKZ_SHARED __shared__
+#define TKZ_LAUNCH(kernel, grid, block, stream, ...) \
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, (stream), __VA_ARGS__)
+
+namespace simt {
+TKZ_DEV int tid() { return (int)threadIdx.x; }
+TKZ_DEV int lane() { return (int)(threadIdx.x & 63); }
+TKZ_DEV int wave() { return (int)(threadIdx.x >> 6); }
+TKZ_DEV int64_t bid() { return (int64_t)blockIdx.x; }
+TKZ_DEV int64_t nblocks() { return (int64_t)gridDim.x; }
+TKZ_DEV int nthreads() { return (int)blockDim.x; }
+TKZ_DEV void sync() { __syncthreads(); }
+TKZ_DEV uint64_t ballot(bool p) { return __ballot(p ? 1 : 0); }
+TKZ_DEV int shfl(int v, int src) { return __shfl(v, src, 64); }
+TKZ_DEV uint32_t shflu(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+TKZ_DEV int shfl_up(int v, int d) { return __shfl_up(v, (unsigned)d, 64); }
+TKZ_DEV int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
+TKZ_DEV int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
+TKZ_DEV int atomic_add(int* p, int v) { return atomicAdd(p, v); }
+TKZ_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
+TKZ_DEV unsigned long long atomic_or64(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
+TKZ_DEV unsigned long long atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
+TKZ_DEV unsigned long long atomic_min64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
+}  // namespace simt
+#endif
+
+// ---- bit helpers shared by host and device code ------------------------------------------------
+TKZ_HD int tkz_popc64(uint64_t x) { return __builtin_popcountll(x); }
+TKZ_HD int tkz_popc32(uint32_t x) { return __builtin_popcount(x); }
+TKZ_HD int tkz_ctz64(uint64_t x) { return __builtin_ctzll(x); }   // x != 0
+TKZ_HD int tkz_ctz32(uint32_t x) { return __builtin_ctz(x); }     // x != 0
+TKZ_HD int tkz_msb64(uint64_t x) { return 63 - __builtin_clzll(x); }   // x != 0
+TKZ_HD int tkz_msb32(uint32_t x) { return 31 - __builtin_clz(x); }     // x != 0
+TKZ_HD uint64_t tkz_brev64(uint64_t x) {
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+}
+// bits [0, n) set, n in [0, 64]
+TKZ_HD uint64_t tkz_lowmask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }

@@ -1,19 +1,19 @@
-// tkz_tables.h -- layouts of the device-resident vocabulary tables and the hash functions shared
-// by the host builder (tkz_vocab.cpp) and the HIP kernels (tkz_kernels.hip).
+// tkz_tables.h -- layouts of the device-resident vocabulary tables, the hash functions shared by the
+// host builder (tkz_vocab.cpp) and the HIP kernels (tkz_kernels.hip), and the probe functions.
 //
 // The reference keeps ONE structure, Dictionary<byte[],int> with an O(len) hash/compare
 // (Tokenizer_C#/TokenizerLib/TikTokenizer.cs:101, Utils/BytePairComparer.cs:8-43) and probes it with
 // freshly allocated byte slices (Utils/BytePairEncoder.cs:25-36).  Only its exact-match semantics are
-// observable.  On the device the same map is held as three open-addressed tables (all a few MB:
+// observable.  On the device the same map is held as three open-addressed tables (a few MB in total:
 // L2 / Infinity-Cache resident, never an HBM stream):
 //
-//   SHORT table  keys of 1..12 bytes, the key INLINE in a 16-byte slot: one 16 B gather resolves a
+//   SHORT table  keys of 1..12 bytes, the key INLINE in a 16-byte slot: one 16 B gather resolves the
 //                whole-piece lookup (TikTokenizer.cs:262) for ~95 % of pieces.
 //   LONG table   keys of 13..max_key_len bytes: {hash, rank, blob offset, len} + key bytes in a blob.
-//   PAIR table   (rank_left, rank_right) -> rank(left ++ right) for EVERY split of every key into two
+//   PAIR table   (id_left, id_right) -> rank(left ++ right) for EVERY split of every key into two
 //                keys.  Parts in the merge loop are always vocabulary keys (single bytes first, then
-//                merged tokens whose rank is by construction the rank of the concatenation), so
-//                `ranks.TryGetValue(bytes[a..c])` == PAIR[(rank(bytes[a..b]), rank(bytes[b..c]))]
+//                merged tokens whose id is by construction the rank of the concatenation), so
+//                `ranks.TryGetValue(bytes[a..c])` == PAIR[(id(bytes[a..b]), id(bytes[b..c]))]
 //                -- a fixed-width probe instead of hashing a variable-length slice.
 //                A single byte that is NOT a key gets the pseudo id TKZ_PSEUDO_BASE + byte; it can still
 //                take part in merges exactly as in the reference and raises KeyNotFound only if it
@@ -21,11 +21,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
-#define TKZ_HD __host__ __device__ __forceinline__
-#else
-#define TKZ_HD inline
-#endif
+#include "tkz_simt.h"
 
 #define TKZ_RANK_NONE 0x7FFFFFFF            /* int.MaxValue sentinel, BytePairEncoder.cs:23,35 */
 #define TKZ_PSEUDO_BASE 0x7FFFFC00          /* ids >= this are "single byte not in vocab" */
@@ -34,23 +30,23 @@
 #define TKZ_SHORT_KEY_MAX 12
 
 // 16 B; rank_len == 0 marks an empty slot (len is 1..12, so a used slot is never 0).
-// rank_len = rank | (len << 27): ranks must be < 2^27 (TKZ_MAX_RANK); the largest shipped vocabulary
-// (o200k_base) tops out below 2^18.  Larger ranks are rejected at load with TKZ_E_UNSUPPORTED.
-struct TkzShortSlot {
+// rank_len = rank | (len << 27): ranks must be < 2^27 (TKZ_MAX_RANK); the largest vocabulary the
+// reference names (o200k_base) tops out below 2^18.  Larger ranks are rejected at load (TKZ_E_UNSUPPORTED).
+struct alignas(16) TkzShortSlot {
     uint32_t k0, k1, k2;      // key bytes, little-endian packed, zero padded
     uint32_t rank_len;
 };
 #define TKZ_SHORT_RANK_BITS 27
 #define TKZ_SHORT_RANK_MASK ((1u << TKZ_SHORT_RANK_BITS) - 1u)
 
-struct TkzLongSlot {    // 16 B; len == 0 marks an empty slot
+struct alignas(16) TkzLongSlot {    // len == 0 marks an empty slot
     uint32_t hash;      // full 32-bit hash (cheap reject before touching the blob)
     int32_t rank;
     uint32_t off;       // byte offset of the key in the blob
     uint32_t len;
 };
 
-struct TkzPairSlot {    // 16 B; valid == 0 marks an empty slot
+struct alignas(16) TkzPairSlot {    // valid == 0 marks an empty slot
     uint32_t a, b;
     int32_t rank;
     uint32_t valid;
@@ -61,9 +57,9 @@ struct TkzTables {      // device pointers + masks, passed to kernels by value
     const TkzLongSlot* long_slots;   uint32_t long_mask;
     const uint8_t* long_blob;
     const TkzPairSlot* pair_slots;   uint32_t pair_mask;
-    const int32_t* byte_rank;        // [256] rank of the single byte, or TKZ_PSEUDO_BASE + b
-    const int32_t* bytepair_rank;    // [65536] PAIR restricted to two single bytes (direct index), TKZ_RANK_NONE if absent
-    const uint8_t* bmp_class;        // [65536] class of each BMP code unit (see tkz_classes.h)
+    const int32_t* byte_rank;        // [256] id of the single byte: its rank, or TKZ_PSEUDO_BASE + b
+    const int32_t* bytepair_rank;    // [65536] rank of the two-byte key (b0<<8|b1), TKZ_RANK_NONE if absent
+    const uint8_t* bmp_class;        // [65536] Unicode class of each BMP code unit (tkz_classes.h)
     int32_t max_key_len;
     int32_t pattern;
 };
@@ -84,4 +80,54 @@ TKZ_HD uint32_t tkz_hash_long_init(uint32_t len) { return 0x2545F491u ^ (len * 0
 TKZ_HD uint32_t tkz_hash_long_step(uint32_t h, uint32_t w) { return tkz_mix32(h ^ w) + 0x632BE5ABu; }
 TKZ_HD uint32_t tkz_hash_pair(uint32_t a, uint32_t b) {
     return tkz_mix32(a * 0x9E3779B9u ^ tkz_mix32(b + 0x7F4A7C15u));
+}
+
+// ---- probes (one 16 B gather per step; tables are built at load factor <= 0.5) -----------------
+TKZ_HD uint4 tkz_load16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// Encoder.TryGetValue(piece) for a piece of 1..12 bytes (TikTokenizer.cs:262)
+TKZ_HD int32_t tkz_lookup_short(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
+    uint32_t s = tkz_hash_short(k0, k1, k2, len) & T.short_mask;
+    for (;;) {
+        const uint4 v = tkz_load16(&T.short_slots[s]);
+        if (v.w == 0) return TKZ_RANK_NONE;
+        if (v.x == k0 && v.y == k1 && v.z == k2 && (v.w >> TKZ_SHORT_RANK_BITS) == len)
+            return (int32_t)(v.w & TKZ_SHORT_RANK_MASK);
+        s = (s + 1) & T.short_mask;
+    }
+}
+
+// ranks.TryGetValue(left ++ right) through the ids of the two parts (BytePairEncoder.cs:25-36)
+TKZ_HD int32_t tkz_lookup_pair(const TkzTables& T, uint32_t a, uint32_t b) {
+    uint32_t s = tkz_hash_pair(a, b) & T.pair_mask;
+    for (;;) {
+        const uint4 v = tkz_load16(&T.pair_slots[s]);
+        if (v.w == 0) return TKZ_RANK_NONE;
+        if (v.x == a && v.y == b) return (int32_t)v.z;
+        s = (s + 1) & T.pair_mask;
+    }
+}
+
+// Encoder.TryGetValue(piece) for a piece of 13..max_key_len bytes; `at(i)` yields byte i of the piece.
+template <class ByteAt>
+TKZ_HD int32_t tkz_lookup_long(const TkzTables& T, ByteAt at, uint32_t len) {
+    if ((int32_t)len > T.max_key_len) return TKZ_RANK_NONE;
+    uint32_t h = tkz_hash_long_init(len);
+    for (uint32_t off = 0; off < len; off += 4) {
+        uint32_t w = 0;
+        for (uint32_t j = 0; j < 4 && off + j < len; ++j) w |= (uint32_t)at(off + j) << (8 * j);
+        h = tkz_hash_long_step(h, w);
+    }
+    uint32_t s = h & T.long_mask;
+    for (;;) {
+        const uint4 v = tkz_load16(&T.long_slots[s]);   // {hash, rank, off, len}
+        if (v.w == 0) return TKZ_RANK_NONE;
+        if (v.x == h && v.w == len) {
+            const uint8_t* k = T.long_blob + v.z;
+            uint32_t i = 0;
+            while (i < len && k[i] == at(i)) ++i;
+            if (i == len) return (int32_t)v.y;
+        }
+        s = (s + 1) & T.long_mask;
+    }
 }
