@@ -1,0 +1,213 @@
+"""Parity checks shared by the emulated (CPU) and the real (GPU) test modules: every function takes
+the library under test (`lib`, a tokenizer_amd._native.Library) and the oracle, and compares the two on
+the same seeded inputs.  Integer work: the bar is bit-exact."""
+import random
+
+import numpy as np
+
+import regex_crosscheck as RC
+from tokenizer_amd import _native as N
+
+SMALL_ALPHAS = {
+    "ws": list(" \n\r\t") + ["　", "\x85", "\xa0"] + list("a.1"),
+    "dig": list("0123456789") + ["١", "１", " ", "a", ".", "\n"],
+    "apo": list("'''sStTrReEvVmMlLdD x.\n 1"),
+    "oth": list(".,;!\n\r  a1'") + ["\U0001F600", "⭐", "中"],
+    "case": list("aAbB") + ["中", "́", "ǅ", "ʰ", "'", "s", " ", ".", "1", "\n", "/"],
+}
+
+
+def gen_text(rng, kind, n, alpha):
+    if kind == "mix":
+        return RC.random_text(rng, alpha, n)
+    a = SMALL_ALPHAS[kind]
+    out = []
+    while len(out) < n:
+        ch = rng.choice(a)
+        rep = 1 if rng.random() < 0.5 else rng.choice([2, 3, 5, 70, 130, 300])
+        rep = min(rep, n - len(out))
+        if rng.random() < 0.5:
+            out.extend([ch] * rep)
+        else:
+            out.extend(rng.choice(a) for _ in range(rep))
+    return "".join(out[:n])
+
+
+def pack(docs):
+    data = np.frombuffer(b"".join(docs), np.uint8) if sum(map(len, docs)) else np.zeros(0, np.uint8)
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.int64)
+    return data, offs
+
+
+def oracle_bitmap(O, pattern, docs):
+    total = sum(len(d) for d in docs)
+    bm = np.zeros(total + 1, bool)
+    bm[total] = True
+    pos = 0
+    for d in docs:
+        for (a, _n) in O.split_utf8(pattern, d):
+            bm[pos + a] = True
+        bm[pos] = True
+        pos += len(d)
+    return bm
+
+
+def oracle_encode_docs(oenc, docs):
+    ids, offs = [], [0]
+    for d in docs:
+        ids += oenc.encode_bytes(d)
+        offs.append(len(ids))
+    return ids, offs
+
+
+def explain_bitmap_diff(got, exp, docs, offs):
+    bad = np.nonzero(got != exp)[0]
+    p = int(bad[0])
+    d = int(np.searchsorted(offs, p, side="right") - 1)
+    d = min(d, len(docs) - 1)
+    q = p - int(offs[d])
+    doc = docs[d]
+    return "first of %d differing bits at byte %d (doc %d + %d): got %s expected %s; context %r | %r" % (
+        len(bad), p, d, q, bool(got[p]), bool(exp[p]), doc[max(0, q - 16):q], doc[q:q + 16])
+
+
+def check_pretok(lib, O, vocab, pattern, sequential, seeds, kinds, doc_lens, n_docs_choices=(1, 3, 20)):
+    alpha = RC.alphabet()
+    enc = N.Encoder(vocab, pattern)
+    if sequential:
+        enc.set_option(N.OPT_PRETOK_SEQUENTIAL, 1)
+    for kind in kinds:
+        for seed in seeds:
+            rng = random.Random(seed * 7919 + sum(map(ord, kind)) + 31 * pattern)
+            docs = [gen_text(rng, kind, rng.choice(doc_lens), alpha).encode("utf-8") for _ in range(rng.choice(n_docs_choices))]
+            data, offs = pack(docs)
+            got = enc.pretokenize(data, offs)
+            exp = oracle_bitmap(O, pattern, docs)
+            assert np.array_equal(got, exp), "pattern %d seq=%d kind=%s seed=%d: %s" % (
+                pattern, sequential, kind, seed, explain_bitmap_diff(got, exp, docs, offs))
+
+
+def check_vocab_keys(lib, O, vocab, ovocab, pattern=N.CL100K):
+    """V1/K2: every vocabulary key, presented as one piece, must come back as exactly [rank]."""
+    enc = N.Encoder(vocab, pattern)
+    ents = ovocab.entries()
+    keys = [k for k, _ in ents]
+    data, offs = pack(keys)
+    ids, ooff = enc.encode_pieces(data, offs)
+    assert ids.tolist() == [r for _, r in ents]
+    assert np.array_equal(ooff, np.arange(len(keys) + 1))
+
+
+def random_piece(rng, keys, lens):
+    n = rng.choice(lens) if rng.random() < 0.5 else rng.randint(1, 24)
+    m = rng.random()
+    if m < 0.3:
+        return bytes(rng.randrange(256) for _ in range(n))
+    if m < 0.6:
+        return bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz ETAOIN") for _ in range(n))
+    if m < 0.7:
+        return bytes([rng.choice(b"a= 0x")]) * n
+    if m < 0.85:
+        out = b""
+        while len(out) < n:
+            out += rng.choice(keys)
+        return out[:n]
+    return (rng.choice(keys) * (n // 2 + 1))[:n]
+
+
+def check_pieces(lib, O, vocab, ovocab, seed, rounds, lens, counts):
+    """K3: BytePairEncode (+ whole-piece lookup) on arbitrary byte strings, vs the oracle's bpe()."""
+    enc = N.Encoder(vocab, N.CL100K)
+    keys = [k for k, _ in ovocab.entries()]
+    rng = random.Random(seed)
+    for it in range(rounds):
+        pcs = [random_piece(rng, keys, lens) for _ in range(rng.choice(counts))]
+        data, offs = pack(pcs)
+        ids, ooff = enc.encode_pieces(data, offs)
+        exp, eoff = [], [0]
+        for p in pcs:
+            r = ovocab.rank(p)
+            exp += [r] if r >= 0 else ovocab.bpe(p)
+            eoff.append(len(exp))
+        if ids.tolist() != exp or ooff.tolist() != eoff:
+            for i, p in enumerate(pcs):
+                g = ids[ooff[i]:ooff[i + 1]].tolist()
+                x = exp[eoff[i]:eoff[i + 1]]
+                assert g == x and ooff[i] == eoff[i], "round %d piece %d (len %d) %r: got %r expected %r" % (it, i, len(p), p[:40], g[:12], x[:12])
+            raise AssertionError("offset mismatch")
+
+
+def check_batch(lib, O, vocab, ovocab, pattern, seed, rounds, doc_lens, n_docs_choices, kinds=("mix",)):
+    """End to end: EncodeBatch vs TikTokenizer.Encode(text, false) restated by the oracle, ids and offsets."""
+    alpha = RC.alphabet()
+    enc = N.Encoder(vocab, pattern)
+    oenc = O.Encoder(ovocab, pattern)
+    rng = random.Random(seed)
+    for it in range(rounds):
+        kind = rng.choice(kinds)
+        docs = [gen_text(rng, kind, rng.choice(doc_lens), alpha).encode("utf-8") for _ in range(rng.choice(n_docs_choices))]
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        exp, eoff = oracle_encode_docs(oenc, docs)
+        if ids.tolist() != exp or ooff.tolist() != eoff:
+            for i in range(len(docs)):
+                g = ids[ooff[i]:ooff[i + 1]].tolist()
+                x = exp[eoff[i]:eoff[i + 1]]
+                assert g == x and ooff[i] == eoff[i], "pattern %d round %d doc %d (len %d): got %r... expected %r..." % (
+                    pattern, it, i, len(docs[i]), g[:12], x[:12])
+            raise AssertionError("trailing mismatch")
+
+
+def check_errors(lib, O, vocab):
+    enc = N.Encoder(vocab, N.CL100K)
+    import pytest
+    # malformed UTF-8 (the reference never sees it: a C# string always converts to well-formed UTF-8)
+    for bad in (b"abc\xff", b"\xe4\xb8", b"\x80abc", b"\xc0\xaf", b"\xed\xa0\x80", b"\xf4\x90\x80\x80"):
+        with pytest.raises(N.TkzError) as ei:
+            enc.encode_utf8(bad)
+        assert ei.value.code == N.E_INVALID_UTF8, bad
+    # a document boundary inside a character
+    data = np.frombuffer("a中b".encode("utf-8"), np.uint8)
+    with pytest.raises(N.TkzError) as ei:
+        enc.encode_batch(data, np.array([0, 2, len(data)]))
+    assert ei.value.code == N.E_INVALID_UTF8
+    # offsets
+    data = np.frombuffer(b"hello world", np.uint8)
+    for offs in ([0, 7, 5, 11], [0, 12, 3, 11]):
+        with pytest.raises(N.TkzError) as ei:
+            enc.encode_batch(data, np.array(offs))
+        assert ei.value.code == N.E_ARG, offs
+    # capacity: the needed count comes back
+    ids = np.empty(2, np.int32)
+    ooff = np.empty(2, np.int64)
+    import ctypes as C
+    needed = C.c_int64(0)
+    st = lib.L.tkz_encode_batch_utf8(enc._h, data.ctypes.data, np.array([0, 11], np.int64).ctypes.data, 1, ids.ctypes.data, 1, ooff.ctypes.data, C.byref(needed))
+    assert st == N.E_CAPACITY and needed.value == 2
+    # empty inputs (TikTokenizerUnitTest.cs:103-109)
+    assert enc.encode_utf8(b"") == []
+    ids, ooff = enc.encode_batch(np.zeros(0, np.uint8), np.array([0, 0, 0]))
+    assert len(ids) == 0 and ooff.tolist() == [0, 0, 0]
+    # a byte that is not in the vocabulary: KeyNotFoundException in the reference (BytePairEncoder.cs:17,73)
+    tiny = N.Vocab(b"YQ== 0\nYWI= 1\n", lib)          # 'a', 'ab'
+    te = N.Encoder(tiny, N.P1)
+    assert te.encode_utf8(b"ab") == [1]
+    assert te.encode_utf8(b"aab") == [0, 1]
+    with pytest.raises(N.KeyNotFoundError):
+        te.encode_utf8(b"b")
+    with pytest.raises(N.KeyNotFoundError):
+        te.encode_utf8(b"abb")
+
+
+def check_utf16(lib, O, vocab, ovocab):
+    """tkz_encode_utf16 vs the oracle's UTF-16 entry (lone surrogates -> U+FFFD per piece, TikTokenizer.cs:261)."""
+    rng = random.Random(77)
+    alpha = RC.alphabet()
+    for pattern in (N.P1, N.CL100K, N.O200K):
+        enc = N.Encoder(vocab, pattern)
+        oenc = O.Encoder(ovocab, pattern)
+        for it in range(12):
+            units = RC.to_units(RC.random_text(rng, alpha, rng.randint(0, 80)))
+            for _ in range(rng.choice([0, 0, 1, 3])):   # sprinkle lone surrogates
+                units.insert(rng.randint(0, len(units)), rng.choice([0xD800, 0xDBFF, 0xDC00, 0xDFFF]))
+            assert enc.encode_utf16(units) == oenc.encode_utf16(units), (pattern, units)

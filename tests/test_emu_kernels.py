@@ -1,0 +1,90 @@
+"""`not gpu` coverage of the DEVICE code: the real kernel sources (tokenizer_amd/csrc/tkz_kernels.hip and
+the C ABI above them) compiled against the fiber SIMT emulator of tests/hostemu/ and compared with the
+oracle.  Sizes are small (the emulator runs one workgroup at a time); the same checks run at full size
+on the GPU in test_gpu_parity.py."""
+import json
+
+import numpy as np
+import pytest
+
+import emu
+import parity
+from conftest import load_golden_json
+from tokenizer_amd import _native as N
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return emu.library()
+
+
+@pytest.fixture(scope="module")
+def vocab(lib, gpt2_tiktoken_bytes):
+    return N.Vocab(gpt2_tiktoken_bytes, lib)
+
+
+def test_golden_gpt2_ids(lib, vocab, lib_rs_bytes):
+    enc = N.Encoder(vocab, N.P1)
+    assert enc.encode_utf8(lib_rs_bytes) == load_golden_json("tokens_gpt2.json")
+    enc.set_option(N.OPT_PRETOK_SEQUENTIAL, 1)
+    assert enc.encode_utf8(lib_rs_bytes) == load_golden_json("tokens_gpt2.json")
+
+
+@pytest.mark.parametrize("pattern,sequential", [(1, 0), (2, 0), (1, 1), (2, 1), (3, 1)])
+def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
+    parity.check_pretok(lib, oracle_mod, vocab, pattern, sequential, seeds=range(6),
+                        kinds=["mix", "ws", "dig", "apo", "oth", "case"], doc_lens=[0, 1, 7, 64, 65, 200, 1000, 5000, 9000])
+
+
+def test_golden_splits(lib, vocab):
+    for rec in load_golden_json("splits.json"):
+        enc = N.Encoder(vocab, rec["pattern"])
+        b = rec["text"].encode("utf-8")
+        got = enc.pretokenize(np.frombuffer(b, np.uint8) if b else np.zeros(0, np.uint8), np.array([0, len(b)]))
+        assert [int(i) for i in np.nonzero(got[:len(b)])[0]] == [p[0] for p in rec["pieces"]], rec["text"]
+
+
+def test_every_vocab_key(lib, vocab, oracle_mod, oracle_gpt2):
+    parity.check_vocab_keys(lib, oracle_mod, vocab, oracle_gpt2)
+
+
+def test_pieces_vs_oracle_bpe(lib, vocab, oracle_mod, oracle_gpt2):
+    parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=5, rounds=6,
+                        lens=[1, 2, 3, 4, 5, 8, 12, 13, 16, 17, 20, 33, 64, 100, 300], counts=[1, 5, 300, 1200])
+
+
+def test_long_and_giant_pieces(lib, vocab, oracle_mod, oracle_gpt2):
+    # workgroup path in LDS (<= 2048 bytes) and in the global pool (> 2048), incl. the pool-grow retry
+    parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=9, rounds=2, lens=[700, 2048, 2049, 2600], counts=[3])
+
+
+@pytest.mark.parametrize("pattern", [1, 2, 3])
+def test_batch_vs_oracle(lib, vocab, oracle_mod, oracle_gpt2, pattern):
+    parity.check_batch(lib, oracle_mod, vocab, oracle_gpt2, pattern, seed=11 + pattern, rounds=5,
+                       doc_lens=[0, 1, 10, 100, 1000, 6000], n_docs_choices=[1, 4, 40], kinds=("mix", "ws", "oth"))
+
+
+def test_errors_and_edges(lib, vocab, oracle_mod):
+    parity.check_errors(lib, oracle_mod, vocab)
+
+
+def test_utf16_entry(lib, vocab, oracle_mod, oracle_gpt2):
+    parity.check_utf16(lib, oracle_mod, vocab, oracle_gpt2)
+
+
+def test_corpus_generator_host_device_agree(lib):
+    """The counter-based generator: the device kernel (emulated here) and the host function must produce
+    the same bytes, and a document must not depend on its position in the batch."""
+    import ctypes as C
+    for kind, lo, hi in ((1, 16, 128), (2, 100, 400), (3, 3000, 6000)):
+        n = 40
+        offs = np.zeros(n + 1, np.int64)
+        tot = N.corpus_generate_device(0, kind, 0x5EED0000 + kind, 7, n, lo, hi, offs.ctypes.data, None, 0, lib=lib)
+        assert tot == offs[-1] and np.all(np.diff(offs) >= lo) and np.all(np.diff(offs) <= hi)
+        buf = np.zeros(tot, np.uint8)
+        tot2 = N.corpus_generate_device(0, kind, 0x5EED0000 + kind, 7, n, lo, hi, offs.ctypes.data, buf.ctypes.data, tot, lib=lib)
+        assert tot2 == tot
+        for d in (0, 1, 17, n - 1):
+            host = N.corpus_doc_host(kind, 0x5EED0000 + kind, 7 + d, lo, hi, lib=lib)
+            assert host == buf[offs[d]:offs[d + 1]].tobytes()
+            host.decode("utf-8")          # well-formed

@@ -1,0 +1,166 @@
+"""`-m gpu`: the parity tests proper.  Everything goes through the C ABI of the hipcc-built
+tokenizer_amd/lib/libtkz.so on a real MI355X and is compared bit-exact with the CPU oracle, with the
+reference's golden ids, and -- at sizes the oracle cannot reach in seconds -- through size-independent
+properties (decode length = document length for every document, shard invariance, the two
+pre-tokenizer formulations agreeing on the whole bitmap)."""
+import os
+
+import numpy as np
+import pytest
+
+import parity
+from conftest import load_golden_json
+from tokenizer_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return N.default_library()       # raises if libtkz.so is missing: no fallback
+
+
+@pytest.fixture(scope="module")
+def vocab(lib, gpt2_tiktoken_bytes):
+    return N.Vocab(gpt2_tiktoken_bytes, lib)
+
+
+def test_native_library_is_the_hip_build(lib):
+    assert lib.path.endswith(os.path.join("tokenizer_amd", "lib", "libtkz.so"))
+    import subprocess
+    out = subprocess.run(["strings", "-n", "6", lib.path], capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_golden_gpt2_ids(lib, vocab, lib_rs_bytes):
+    exp = load_golden_json("tokens_gpt2.json")
+    enc = N.Encoder(vocab, N.P1)
+    assert enc.encode_utf8(lib_rs_bytes) == exp                    # TikTokenizerUnitTest.cs:227-245
+    enc.set_option(N.OPT_PRETOK_SEQUENTIAL, 1)
+    assert enc.encode_utf8(lib_rs_bytes) == exp
+    units = np.frombuffer(lib_rs_bytes.decode("utf-8").encode("utf-16-le"), np.uint16).tolist()
+    assert enc.encode_utf16(units) == exp
+
+
+@pytest.mark.parametrize("pattern,sequential", [(1, 0), (2, 0), (1, 1), (2, 1), (3, 1)])
+def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
+    parity.check_pretok(lib, oracle_mod, vocab, pattern, sequential, seeds=range(25),
+                        kinds=["mix", "ws", "dig", "apo", "oth", "case"],
+                        doc_lens=[0, 1, 7, 64, 65, 200, 1000, 5000, 9000, 40000], n_docs_choices=(1, 3, 20, 200))
+
+
+def test_golden_splits(lib, vocab):
+    for rec in load_golden_json("splits.json"):
+        enc = N.Encoder(vocab, rec["pattern"])
+        b = rec["text"].encode("utf-8")
+        got = enc.pretokenize(np.frombuffer(b, np.uint8) if b else np.zeros(0, np.uint8), np.array([0, len(b)]))
+        assert [int(i) for i in np.nonzero(got[:len(b)])[0]] == [p[0] for p in rec["pieces"]], rec["text"]
+
+
+def test_every_vocab_key(lib, vocab, oracle_mod, oracle_gpt2):
+    parity.check_vocab_keys(lib, oracle_mod, vocab, oracle_gpt2)
+
+
+def test_pieces_vs_oracle_bpe(lib, vocab, oracle_mod, oracle_gpt2):
+    parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=5, rounds=25,
+                        lens=[1, 2, 3, 4, 5, 8, 12, 13, 16, 17, 20, 33, 64, 100, 300, 1000, 2048, 2049, 3000], counts=[1, 5, 300, 3000])
+
+
+def test_giant_pieces(lib, vocab, oracle_mod, oracle_gpt2):
+    # the 4,000-byte single-letter piece of tokenizer_ts/test/tikTokenizer.test.ts:133, and longer ones
+    enc = N.Encoder(vocab, N.CL100K)
+    oenc = oracle_mod.Encoder(oracle_gpt2, oracle_mod.CL100K)
+    for text in (b"t" * 4000, b"=" * 9000, b" " * 5000 + b"x", b"ab" * 6000, bytes(range(97, 123)) * 400):
+        assert enc.encode_utf8(text) == oenc.encode_bytes(text)
+
+
+@pytest.mark.parametrize("pattern", [1, 2, 3])
+def test_batch_vs_oracle(lib, vocab, oracle_mod, oracle_gpt2, pattern):
+    parity.check_batch(lib, oracle_mod, vocab, oracle_gpt2, pattern, seed=11 + pattern, rounds=12,
+                       doc_lens=[0, 1, 10, 100, 1000, 6000, 30000], n_docs_choices=[1, 4, 40, 400], kinds=("mix", "ws", "oth", "dig", "apo", "case"))
+
+
+def test_errors_and_edges(lib, vocab, oracle_mod):
+    parity.check_errors(lib, oracle_mod, vocab)
+
+
+def test_utf16_entry(lib, vocab, oracle_mod, oracle_gpt2):
+    parity.check_utf16(lib, oracle_mod, vocab, oracle_gpt2)
+
+
+# ---- device-resident path at scale ------------------------------------------------------------------
+
+def _device_run(lib, vocab, kind, pattern, n_docs, lo, hi, seed, sequential=False, first_doc=0):
+    import torch
+    dev = torch.device("cuda", 0)
+    enc = N.Encoder(vocab, pattern)
+    if sequential:
+        enc.set_option(N.OPT_PRETOK_SEQUENTIAL, 1)
+    st = torch.cuda.current_stream().cuda_stream
+    d_offs = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
+    total = N.corpus_generate_device(0, kind, seed, first_doc, n_docs, lo, hi, d_offs.data_ptr(), None, 0, st, lib=lib)
+    d_bytes = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+    N.corpus_generate_device(0, kind, seed, first_doc, n_docs, lo, hi, d_offs.data_ptr(), d_bytes.data_ptr(), total, st, lib=lib)
+    d_ids = torch.empty(total, dtype=torch.int32, device=dev)
+    d_ooffs = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
+    ntok = enc.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total, d_ooffs.data_ptr(), st)
+    return dict(enc=enc, total=total, ntok=ntok, d_offs=d_offs, d_bytes=d_bytes, d_ids=d_ids[:ntok], d_ooffs=d_ooffs)
+
+
+def _token_lengths(oracle_gpt2):
+    ents = oracle_gpt2.entries()
+    tl = np.zeros(max(r for _, r in ents) + 1, np.int64)
+    for k, r in ents:
+        tl[r] = len(k)
+    return tl
+
+
+@pytest.mark.parametrize("kind,pattern,n_docs,lo,hi", [(1, 2, 400_000, 256, 768), (2, 2, 200_000, 256, 768), (3, 3, 1_500, 30_000, 34_000),
+                                                       (1, 1, 100_000, 16, 128), (3, 2, 1_500, 30_000, 34_000)])
+def test_device_corpus_properties_and_sample(lib, vocab, oracle_mod, oracle_gpt2, kind, pattern, n_docs, lo, hi):
+    import torch
+    r = _device_run(lib, vocab, kind, pattern, n_docs, lo, hi, 0x5EED0000 + kind)
+    ooffs = r["d_ooffs"]
+    assert int(ooffs[0]) == 0 and int(ooffs[-1]) == r["ntok"]
+    counts = ooffs[1:] - ooffs[:-1]
+    doc_len = r["d_offs"][1:] - r["d_offs"][:-1]
+    assert bool((counts >= 0).all()) and bool((counts <= doc_len).all())
+    # property over EVERY document: the byte lengths of a document's tokens add up to the document (decode length)
+    tl = torch.from_numpy(_token_lengths(oracle_gpt2)).to(ooffs.device)
+    ids = r["d_ids"].long()
+    assert int(ids.min()) >= 0 and int(ids.max()) < len(tl)
+    csum = torch.zeros(r["ntok"] + 1, dtype=torch.int64, device=ooffs.device)
+    csum[1:] = torch.cumsum(tl[ids], 0)
+    assert bool(((csum[ooffs[1:]] - csum[ooffs[:-1]]) == doc_len).all())
+    # bit-exact vs the oracle on a sample of documents (first, last, and a stride through the middle)
+    oenc = oracle_mod.Encoder(oracle_gpt2, pattern)
+    h_offs = r["d_offs"].cpu().numpy()
+    h_ooffs = ooffs.cpu().numpy()
+    pick = sorted(set(list(range(0, min(n_docs, 300))) + list(range(0, n_docs, max(1, n_docs // 300))) + [n_docs - 1]))
+    h_ids = r["d_ids"].cpu().numpy()
+    h_bytes = r["d_bytes"][:r["total"]].cpu().numpy()
+    for d in pick:
+        doc = h_bytes[h_offs[d]:h_offs[d + 1]].tobytes()
+        assert doc == N.corpus_doc_host(kind, 0x5EED0000 + kind, d, lo, hi, lib=lib)       # generator: device == host
+        assert h_ids[h_ooffs[d]:h_ooffs[d + 1]].tolist() == oenc.encode_bytes(doc), "doc %d" % d
+
+
+def test_shard_invariance(lib, vocab):
+    """ids of a batch == ids of its two halves encoded separately (documents are independent)."""
+    import torch
+    n, lo, hi, seed = 60_000, 256, 768, 0x5EED0002
+    whole = _device_run(lib, vocab, 1, 2, n, lo, hi, seed)
+    a = _device_run(lib, vocab, 1, 2, n // 2, lo, hi, seed, first_doc=0)
+    b = _device_run(lib, vocab, 1, 2, n - n // 2, lo, hi, seed, first_doc=n // 2)
+    assert whole["ntok"] == a["ntok"] + b["ntok"]
+    assert torch.equal(whole["d_ids"], torch.cat([a["d_ids"], b["d_ids"]]))
+    assert torch.equal(whole["d_ooffs"], torch.cat([a["d_ooffs"], b["d_ooffs"][1:] + a["ntok"]]))
+
+
+@pytest.mark.parametrize("kind,pattern", [(1, 2), (2, 2), (3, 2), (2, 1)])
+def test_parallel_and_sequential_pretok_agree_at_scale(lib, vocab, kind, pattern):
+    import torch
+    lo, hi, n = (30_000, 34_000, 600) if kind == 3 else (256, 768, 100_000)
+    p = _device_run(lib, vocab, kind, pattern, n, lo, hi, 0x5EED0000 + kind)
+    s = _device_run(lib, vocab, kind, pattern, n, lo, hi, 0x5EED0000 + kind, sequential=True)
+    assert p["ntok"] == s["ntok"] and torch.equal(p["d_ids"], s["d_ids"]) and torch.equal(p["d_ooffs"], s["d_ooffs"])

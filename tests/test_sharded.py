@@ -1,0 +1,70 @@
+"""`not gpu`: the N > 1 path (contiguous document shards + ONE all-gather of the per-rank counts) with
+world_size 2 over gloo.  Each rank encodes its shard with the emulated build of the kernels; rank 0
+checks that shards concatenated == the whole batch (shard invariance) and that the gathered bases are right."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import gzip
+    import torch.distributed as dist
+    import emu
+    from tokenizer_amd import _native as N
+    from tokenizer_amd import sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = emu.library()
+    raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "gpt2.tiktoken.gz"), "rb").read())
+    enc = N.Encoder(N.Vocab(raw, lib), N.CL100K)
+    n_total, lo_len, hi_len, seed = 301, 20, 300, 0x5EED0002
+    lo, hi = sharded.shard_range(n_total, rank, world)
+    docs = [N.corpus_doc_host(1, seed, d, lo_len, hi_len, lib=lib) for d in range(lo, hi)]
+    data = np.frombuffer(b"".join(docs), np.uint8)
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.int64)
+    ids, ooffs = enc.encode_batch(data, offs)
+    g = sharded.gather_counts(hi - lo, int(offs[-1]), len(ids))
+    q.put((rank, ids.tolist(), ooffs.tolist(), g["doc_base"], g["token_base"], g["docs"], g["bytes"], g["tokens"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shards_match_single_batch():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import gzip
+    import emu
+    from tokenizer_amd import _native as N
+    lib = emu.library()
+    raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "gpt2.tiktoken.gz"), "rb").read())
+    enc = N.Encoder(N.Vocab(raw, lib), N.CL100K)
+    docs = [N.corpus_doc_host(1, 0x5EED0002, d, 20, 300, lib=lib) for d in range(301)]
+    data = np.frombuffer(b"".join(docs), np.uint8)
+    offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.int64)
+    ids, ooffs = enc.encode_batch(data, offs)
+    (r0, ids0, oo0, db0, tb0, nd0, nb0, nt0), (r1, ids1, oo1, db1, tb1, nd1, nb1, nt1) = res
+    assert ids0 + ids1 == ids.tolist()
+    assert (db0, tb0) == (0, 0) and db1 == 150 and tb1 == len(ids0)
+    assert nd0 == nd1 == 301 and nb0 == nb1 == len(data) and nt0 == nt1 == len(ids)
+    assert oo0 + [x + tb1 for x in oo1[1:]] == ooffs.tolist()
