@@ -5,6 +5,13 @@ import sys
 
 import pytest
 
+try:                      # torch (bundled HIP runtime) must initialise before libtkz is loaded, see tokenizer_amd/_native.py
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -15,6 +15,7 @@
 #define TKZ_DEV inline
 #define TKZ_HD inline
 #define TKZ_KERNEL(bounds) static
+#define TKZ_KERNEL_OCC(bounds, waves_per_simd) static
 #define TKZ_SHARED static
 #define __host__
 #define __device__
@@ -94,5 +95,6 @@ inline int atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomic_or(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 inline unsigned long long atomic_or64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
 inline unsigned long long atomic_add64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+inline long long clock() { return 0; }
 inline unsigned long long atomic_min64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 }  // namespace simt

@@ -13,7 +13,7 @@ OK = 0
 E_FORMAT, E_DUP_RANK, E_KEY_NOT_FOUND, E_CAPACITY, E_INVALID_UTF8, E_ARG, E_UNSUPPORTED, E_DEVICE, E_NO_DEVICE = range(-1, -10, -1)
 P1, CL100K, O200K = 1, 2, 3
 OPT_PRETOK_SEQUENTIAL = 1
-K_NAMES = ["k_docmark", "k_pretok", "k_encode_tiles", "k_scan", "k_gather", "k_docoffs"]
+K_NAMES = ["k_docmark", "k_pretok", "k_encode_waves", "k_scan", "k_gather", "k_docoffs"]
 
 
 class TkzError(Exception):
@@ -50,6 +50,16 @@ class Library:
             raise RuntimeError("libtkz not built: %s is missing (run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "or `make -C tokenizer_amd/csrc`); there is no CPU fallback" % path)
         self.path = path
+        # PyTorch wheels bundle their own HIP runtime.  If torch is going to be used in this process (device
+        # buffers, streams, torch.distributed) it has to initialise first, so that libtkz binds to the same
+        # runtime instance; two runtimes in one process leave the second without a GPU.
+        if os.path.basename(path) == "libtkz.so":
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.init()
+            except ImportError:
+                pass
         L = self.L = C.CDLL(path)
         vp, i64, i32, sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
         pv = C.POINTER(C.c_void_p)

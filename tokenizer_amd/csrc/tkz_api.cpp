@@ -1,6 +1,8 @@
 // tkz_api.cpp -- the C ABI of libtkz (include/tkz.h): vocabulary objects, device table upload,
 // workspace management and the launch sequence of one encode batch.  HIP only: there is no CPU path.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -16,6 +18,7 @@
 namespace {
 
 thread_local std::string g_err;
+unsigned long long* g_devprof = nullptr;   // development only (TKZ_DEV_ABLATE bit 4)
 
 tkz_status fail(tkz_status s, const std::string& msg) { g_err = msg; return s; }
 
@@ -49,7 +52,8 @@ struct CounterBlock {          // mirrors the 64-byte device block
     int32_t err; int32_t pad[3];
     int64_t grand;
     unsigned long long pool_head;
-    int64_t pad2[4];
+    int64_t ndocstarts;
+    int64_t pad2[3];
 };
 
 }  // namespace
@@ -67,7 +71,7 @@ struct tkz_encoder {
     DevBuf t_short, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp;
     TkzTables T{};
     // workspace
-    DevBuf w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doclocal, w_counters, w_pool;
+    DevBuf w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
     // staging for the host-buffer entry points
     DevBuf s_bytes, s_offs, s_out, s_outoffs;
     CounterBlock* h_counters = nullptr;   // pinned
@@ -118,7 +122,7 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         HIP_TRY(hipStreamSynchronize(stream));
         return TKZ_OK;
     }
-    const int64_t ntiles = (total + kTile - 1) / kTile;
+    const int64_t ntiles = (total + kSub - 1) / kSub;       // sub-tiles: one wavefront each
     const int64_t nblk = (ntiles + kScanBlock - 1) / kScanBlock;
     int64_t* acc = &e->bytes_allocated;
     HIP_TRY(e->w_docbits.ensure((size_t)(nwords + 8) * 8, acc));
@@ -130,7 +134,9 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         HIP_TRY(e->w_tfirst.ensure((size_t)ntiles * 8, acc));
         HIP_TRY(e->w_tbase.ensure((size_t)ntiles * 8, acc));
         HIP_TRY(e->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
-        HIP_TRY(e->w_doclocal.ensure((size_t)(n_docs + 1) * 4, acc));
+        HIP_TRY(e->w_doctok.ensure((size_t)(n_docs + 2) * 4, acc));
+        HIP_TRY(e->w_dcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(e->w_dbase.ensure((size_t)ntiles * 8, acc));
         if (!e->w_pool.p) HIP_TRY(e->w_pool.ensure((size_t)std::min<int64_t>(16 * total + 4096, int64_t(64) << 20), acc));
     }
     if (!e->h_counters) HIP_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(CounterBlock), 0));
@@ -160,17 +166,33 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             P.bytes = d_bytes; P.total = total; P.startbits = startbits; P.docbits = docbits; P.nwords = nwords;
             P.offs = d_offs; P.n_docs = n_docs;
             P.tmp = e->w_tmp.as<int32_t>(); P.tile_count = e->w_tcount.as<int32_t>(); P.tile_first = e->w_tfirst.as<int64_t>();
-            P.doc_local = e->w_doclocal.as<int32_t>(); P.counters = counters;
+            P.docord_base = e->w_dbase.as<int64_t>(); P.doc_tok = e->w_doctok.as<int32_t>(); P.counters = counters;
             P.pool = e->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(e->w_pool.cap / 4);
+            { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
+            if (P.ablate & 16) {
+                if (!g_devprof) { HIP_TRY(hipMalloc((void**)&g_devprof, 16 * 8)); }
+                HIP_TRY(hipMemsetAsync(g_devprof, 0, 16 * 8, stream));
+            }
+            P.devprof = g_devprof;
+            int64_t* ndocstarts = reinterpret_cast<int64_t*>(e->w_counters.as<char>() + offsetof(CounterBlock, ndocstarts));
+            launch_doccount(L, docbits, nwords, ntiles, e->w_dcount.as<int32_t>());
+            launch_scan(L, e->w_dcount.as<int32_t>(), ntiles, e->w_bsum.as<int64_t>(), e->w_dbase.as<int64_t>(), ndocstarts, -1);
             launch_encode(L, e->T, P, ntiles);
-            launch_scan(L, P.tile_count, ntiles, e->w_bsum.as<int64_t>(), e->w_tbase.as<int64_t>(), grand);
+            launch_scan(L, P.tile_count, ntiles, e->w_bsum.as<int64_t>(), e->w_tbase.as<int64_t>(), grand, K_SCAN);
             launch_gather(L, P.tmp, P.tile_count, P.tile_first, e->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
-            launch_docoffs(L, d_offs, n_docs, total, e->w_tbase.as<int64_t>(), P.doc_local, grand, d_out_offs);
+            launch_docoffs(L, d_offs, n_docs, total, e->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs);
         }
         HIP_TRY(hipMemcpyAsync(e->h_counters, counters, sizeof(CounterBlock), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
         if (e->profiling) prof_collect(e);
+        if (g_devprof && getenv("TKZ_DEV_ABLATE") && (atoi(getenv("TKZ_DEV_ABLATE")) & 16) && !d_bitmap_only) {
+            unsigned long long h[16];
+            HIP_TRY(hipMemcpy(h, g_devprof, sizeof h, hipMemcpyDeviceToHost));
+            const double w = h[0] ? (double)h[0] : 1.0;
+            fprintf(stderr, "[tkz devprof] waves %llu  cycles/wave: total %.0f stage01 %.0f stageAB %.0f stageM %.0f stageC %.0f | rounds/wave %.2f misses/wave %.1f pieces/wave %.1f\n",
+                    h[0], h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w, h[8] / w);
+        }
         const int32_t err = e->h_counters->err;
         if (err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the byte count");
         if (err & kErrUtf8) return fail(TKZ_E_INVALID_UTF8, "input is not well-formed UTF-8 (or a document boundary falls inside a character)");
@@ -317,7 +339,7 @@ void tkz_encoder_destroy(tkz_encoder* e) {
     (void)hipSetDevice(e->device);
     DevBuf* bufs[] = {&e->t_short, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp,
                       &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
-                      &e->w_doclocal, &e->w_counters, &e->w_pool, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs};
+                      &e->w_doctok, &e->w_dcount, &e->w_dbase, &e->w_counters, &e->w_pool, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs};
     for (DevBuf* b : bufs) b->release();
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (int k = 0; k < tkz::K_COUNT; ++k) for (int p = 0; p < 2; ++p) if (e->ev[k][p]) (void)hipEventDestroy(e->ev[k][p]);
@@ -405,7 +427,7 @@ tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, 
 }
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) { return e ? e->bytes_allocated : 0; }
 const char* tkz_kernel_name(int32_t k) {
-    static const char* const names[] = {"k_docmark", "k_pretok", "k_encode_tiles", "k_scan", "k_gather", "k_docoffs"};
+    static const char* const names[] = {"k_docmark", "k_pretok", "k_encode_waves", "k_scan", "k_gather", "k_docoffs"};
     return (k >= 0 && k < tkz::K_COUNT) ? names[k] : "?";
 }
 

@@ -4,7 +4,7 @@
 //   tkz_bpe_short   one LANE per piece of <= 16 bytes.  The (Index, Rank) list of the reference
 //                   becomes: a 16-bit alive mask of part starts, ids[k] = token id of the part that
 //                   starts at byte k, pr[k] = packed (rank << 4 | k) of the pair (part at k, next
-//                   part) or NOKEY.  One u32 min over the pr slots is the reference's leftmost
+//                   part) or NOKEY.  One u32 min over the 16 pr slots is the reference's leftmost
 //                   strict-min scan (:47-54): equal ranks tie-break on the lower position.
 //   tkz_bpe_long    one WORKGROUP per piece of any length: the list is a doubly linked list in
 //                   LDS or global scratch, each round is a workgroup-wide min of (rank, position)
@@ -26,39 +26,75 @@ enum : int32_t { kErrUtf8 = 1, kErrKeyNotFound = 2, kErrOffsets = 4, kErrPool = 
 
 TKZ_HD uint32_t tkz_mkkey(int32_t rank, int k) { return rank == TKZ_RANK_NONE ? TKZ_NOKEY : (((uint32_t)rank << 4) | (uint32_t)k); }
 
-// Piece of n bytes, 1 <= n <= 16.  ids/pr: scratch of 16 entries each, entry k at [k * stride].
-// Returns the number of tokens; *alive_out has one bit per surviving part (token k is ids[k * stride]).
-template <class ByteAt>
-TKZ_HD int tkz_bpe_short(const TkzTables& T, ByteAt at, int n, uint32_t* ids, uint32_t* pr, int stride,
-                         uint32_t* alive_out, int* err) {
-    uint32_t prevb = at(0);
-    ids[0] = (uint32_t)T.byte_rank[prevb];
-    for (int k = 1; k < n; ++k) {                       // parts = single bytes; initial pair ranks (:37-44)
-        const uint32_t b = at(k);
-        ids[k * stride] = (uint32_t)T.byte_rank[b];
-        pr[(k - 1) * stride] = tkz_mkkey(T.bytepair_rank[(prevb << 8) | b], k - 1);
-        prevb = b;
+// Per-lane scratch of tkz_bpe_short: 16 ids + 16 pair keys, each array 16-byte aligned so that the
+// min scan is four 16-byte LDS reads.  kBpeLaneStride (in dwords) spaces the lanes of a wave so that
+// those reads are bank-conflict free (20 dwords: the 16 lanes of a read group land on 16 distinct
+// 4-bank slots of the 64-bank LDS).
+constexpr int kBpeLaneStride = 20;
+
+TKZ_HD uint32_t tkz_min3u(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
+
+// Piece of n bytes, 1 <= n <= 16, given as four little-endian dwords w0..w3 (bytes past n ignored).
+// ids/pr: this lane's 16-entry arrays (16-byte aligned).  brank: the 256-entry single-byte id table
+// (in LDS on the device).  Returns the number of tokens; *alive_out has one bit per surviving part
+// (token k is ids[k]).  Written for memory-level parallelism: all first-level gathers are issued
+// together, and each merge costs ONE round trip to the pair table (both re-ranked pairs probed at once).
+TKZ_HD int tkz_bpe_short(const TkzTables& T, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int n,
+                         uint32_t* ids, uint32_t* pr, const int32_t* brank, uint32_t* alive_out, int* err) {
+    uint32_t bk[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t w = k < 4 ? w0 : (k < 8 ? w1 : (k < 12 ? w2 : w3));
+        bk[k] = (w >> (8 * (k & 3))) & 0xFFu;
     }
-    pr[(n - 1) * stride] = TKZ_NOKEY;
-    uint32_t alive = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    // Unconditional, clamped gathers: a load inside a lane-divergent branch is waited for inside that
+    // branch, which would serialise these 31 independent loads (bytes past n index valid table entries).
+    uint32_t idv[16], prv[16];
+    int32_t r2[15];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) idv[k] = (uint32_t)brank[bk[k]];                             // parts = single bytes
+#pragma unroll
+    for (int k = 0; k < 15; ++k) r2[k] = T.bytepair_rank[(bk[k] << 8) | bk[k + 1]];           // initial pair ranks (:37-44)
+#pragma unroll
+    for (int k = 0; k < 15; ++k) prv[k] = (k + 1 < n) ? tkz_mkkey(r2[k], k) : TKZ_NOKEY;
+    prv[15] = TKZ_NOKEY;
+    uint4* ids4 = reinterpret_cast<uint4*>(ids);
+    uint4* pr4 = reinterpret_cast<uint4*>(pr);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint4 a, b;
+        a.x = idv[4 * q]; a.y = idv[4 * q + 1]; a.z = idv[4 * q + 2]; a.w = idv[4 * q + 3];
+        b.x = prv[4 * q]; b.y = prv[4 * q + 1]; b.z = prv[4 * q + 2]; b.w = prv[4 * q + 3];
+        ids4[q] = a; pr4[q] = b;
+    }
+    uint32_t alive = (1u << n) - 1u;                    // n <= 16
     for (;;) {                                          // while (byteIndicesAndRanks.Count > 1) (:45)
-        uint32_t key = TKZ_NOKEY;
-        for (int k = 0; k + 1 < n; ++k) { const uint32_t v = pr[k * stride]; key = v < key ? v : key; }
+        const uint4 p0 = pr4[0], p1 = pr4[1], p2 = pr4[2], p3 = pr4[3];
+        const uint32_t m0 = tkz_min3u(p0.x, p0.y, p0.z), m1 = tkz_min3u(p0.w, p1.x, p1.y), m2 = tkz_min3u(p1.z, p1.w, p2.x);
+        const uint32_t m3 = tkz_min3u(p2.y, p2.z, p2.w), m4 = tkz_min3u(p3.x, p3.y, p3.z);
+        const uint32_t key = tkz_min3u(tkz_min3u(m0, m1, m2), m3, m4 < p3.w ? m4 : p3.w);   // leftmost strict min (:47-54)
         if (key == TKZ_NOKEY) break;                    // minRank == int.MaxValue (:65-68)
         const int j = (int)(key & 15u);
         const uint32_t m = key >> 4;
         const int r = tkz_ctz32(alive >> (j + 1)) + j + 1;      // the part being swallowed
         alive &= ~(1u << r);                            // RemoveAt(j + 1) (:63)
-        ids[j * stride] = m;
-        pr[r * stride] = TKZ_NOKEY;
+        // the two re-ranked pairs (:58, :59-62): both first probes are issued before either is examined
         const uint32_t hi = alive & ~((2u << r) - 1u);
-        pr[j * stride] = hi ? tkz_mkkey(tkz_lookup_pair(T, m, ids[tkz_ctz32(hi) * stride]), j) : TKZ_NOKEY;       // (:58)
         const uint32_t lo = alive & ((1u << j) - 1u);
-        if (lo) { const int l = tkz_msb32(lo); pr[l * stride] = tkz_mkkey(tkz_lookup_pair(T, ids[l * stride], m), l); }   // (:59-62)
+        const int l = lo ? tkz_msb32(lo) : 0;
+        const int rr = hi ? tkz_ctz32(hi) : 0;
+        const uint32_t idr = ids[rr], idl = ids[l];     // (unconditional: see above)
+        const uint32_t s1 = tkz_hash_pair(m, idr) & T.pair_mask, s2 = tkz_hash_pair(idl, m) & T.pair_mask;
+        const uint4 v1 = tkz_load16(&T.pair_slots[s1]);
+        const uint4 v2 = tkz_load16(&T.pair_slots[s2]);
+        ids[j] = m;
+        pr[r] = TKZ_NOKEY;
+        pr[j] = hi ? tkz_mkkey(tkz_resolve_pair(T, m, idr, s1, v1), j) : TKZ_NOKEY;
+        if (lo) pr[l] = tkz_mkkey(tkz_resolve_pair(T, idl, m, s2, v2), l);
     }
     int cnt = 0;
     for (uint32_t a = alive; a; a &= a - 1) {
-        if (ids[tkz_ctz32(a) * stride] >= (uint32_t)TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;     // ranks[...] throws (:17,:73)
+        if (ids[tkz_ctz32(a)] >= (uint32_t)TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;     // ranks[...] throws (:17,:73)
         ++cnt;
     }
     *alive_out = alive;

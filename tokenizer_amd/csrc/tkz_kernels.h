@@ -9,10 +9,13 @@
 namespace tkz {
 
 constexpr int kThreads = 256;       // workgroup size of every kernel (4 wavefronts)
-constexpr int kTile = 4096;         // bytes of corpus per workgroup of k_encode_tiles
-constexpr int kHalo = 64;           // bytes staged past the tile (a short piece may straddle the edge)
+constexpr int kSub = 1024;          // bytes of corpus per wavefront of k_encode_waves (a "sub-tile")
+constexpr int kHalo = 64;           // bytes staged past the sub-tile (a short piece may straddle the edge)
 constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one-per-lane
-constexpr int kLdsLong = 2048;      // pieces up to this many bytes are merged by the workgroup in LDS
+constexpr int kLdsLong = 320;       // pieces up to this many bytes are merged by the wavefront in LDS
+constexpr int kPassBatches = 6;     // batches of 64 pieces whose lookups are in flight together (a 1 KiB sub-tile averages ~280 pieces)
+constexpr int kPassPieces = 64 * kPassBatches;
+constexpr int kMergeLanes = 32;     // misses merged per pass (one per lane); sets the LDS scratch of k_encode_waves
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 64;    // k_pretok_rows: 64-byte rows handled in sequence by one wavefront
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan
@@ -23,12 +26,15 @@ struct EncodeParams {
     const uint8_t* bytes; int64_t total;
     const uint64_t* startbits; const uint64_t* docbits; int64_t nwords;   // 1 bit / byte, nwords = total/64 + 1
     const int64_t* offs; int64_t n_docs;                                  // n_docs + 1 document offsets
-    int32_t* tmp;                 // [total + pad] tokens of a tile, dense from the tile's first piece start
-    int32_t* tile_count;          // tokens produced by each tile
-    int64_t* tile_first;          // absolute byte position of each tile's first piece (= its tmp origin)
-    int32_t* doc_local;           // per document: token index inside its tile
+    int32_t* tmp;                 // [total + pad] tokens of a sub-tile, dense from the sub-tile's first piece start
+    int32_t* tile_count;          // tokens produced by each sub-tile
+    int64_t* tile_first;          // absolute byte position of each sub-tile's first piece (= its tmp origin)
+    const int64_t* docord_base;   // per sub-tile: number of distinct document-start positions before it
+    int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
     int32_t* counters;            // [0] error bits
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kLdsLong (int32 units)
+    unsigned long long* devprof;  // development only: cycle counters (ablate bit 4)
+    int32_t ablate;               // development only: bit0 skip merges, bit1 skip table probes, bit2 skip stores, bit3 stage 0/1 only
 };
 
 typedef void (*KernelHook)(void* ctx, int kernel_id, int phase /*0 before, 1 after*/, hipStream_t s);
@@ -39,12 +45,14 @@ void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, in
                         uint64_t* startbits, int64_t nrows, const uint8_t* bmp, int32_t* counters);
 void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                        uint64_t* startbits, const uint8_t* bmp, int32_t* counters);
-void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t ntiles);
-void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand);
+void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub);
+void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t nsub, int32_t* cnt);
+// exclusive scan int32 -> int64 (+ grand total); kid = profiling id of the bracket, or -1
+void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid);
 void launch_gather(const Launch& L, const int32_t* tmp, const int32_t* tile_count, const int64_t* tile_first,
-                   const int64_t* tile_base, int64_t ntiles, int32_t* out, int64_t out_cap);
+                   const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap);
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
-                    const int32_t* doc_local, const int64_t* grand, int64_t* out_offs);
+                    const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs);
 void launch_corpus(hipStream_t s, int kind, uint64_t seed, int64_t first_doc, int64_t n_docs, int min_len, int max_len,
                    int64_t* d_offs, uint8_t* d_bytes, int64_t cap_bytes, int64_t* d_total);
 

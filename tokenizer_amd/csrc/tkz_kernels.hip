@@ -8,9 +8,10 @@
 //   k_pretok_rows    Regex.Matches for pattern 1 / cl100k, position-parallel (tkz_pretok.h (2))
 //   k_pretok_seq     Regex.Matches for any pattern, one lane per document (tkz_pretok.h (1))
 //                    -> 1 bit per byte "a piece starts here"
-//   k_encode_tiles   per 4 KiB tile: enumerate pieces from the bitmap, whole-piece lookup
-//                    (TikTokenizer.cs:262), BytePairEncode on a miss (BytePairEncoder.cs:13-76), tokens
-//                    written densely into the tile's own span of `tmp`; per-document token positions
+//   k_encode_waves   per 1 KiB sub-tile, one wavefront, no barriers: enumerate pieces from the bitmap,
+//                    whole-piece lookup (TikTokenizer.cs:262), BytePairEncode on a miss
+//                    (BytePairEncoder.cs:13-76), tokens written densely into the sub-tile's own span of
+//                    `tmp`; token position of every document that starts in the sub-tile
 //   k_scan_*         exclusive scan of the per-tile token counts
 //   k_gather         tmp -> out_ids at the tile's final offset (coalesced copy)
 //   k_docoffs        out_offsets[d] = tile base + position inside the tile
@@ -114,35 +115,56 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_encode_tiles
+// k_encode_waves : ONE WAVEFRONT per 1 KiB sub-tile, no workgroup barriers anywhere.
+//
+//   stage 0  the sub-tile (+ halo) goes to LDS, 16 B per lane; the 16 bitmap words are held one per lane
+//   stage 1  piece starts are compacted in order into s_pstart (ballot-free prefix: bit-sliced popcounts)
+//   then, in passes of up to 4 x 64 pieces (one piece per lane per batch, state in registers):
+//   stage A  key dwords from LDS, first probe of the whole-piece table issued for all 4 batches
+//   stage B  probes resolved; misses are compacted into s_missq
+//   stage M  BytePairEncode for the compacted misses, one per lane (a pass ends before a 65th miss);
+//            the tokens stay in the merging lane's ids[] until stage C copies them out
+//   stage C  prefix over the token counts, tokens stored densely into the sub-tile's span of `tmp`,
+//            token position recorded for every document that starts in the sub-tile
+//   A piece longer than 16 bytes ends the current pass and is merged by the whole wave (tkz_bpe_long).
 // -------------------------------------------------------------------------------------------------
-TKZ_DEV int64_t tkz_lower_bound(const int64_t* a, int64_t lo, int64_t hi, int64_t v) {   // first i in [lo,hi) with a[i] >= v
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
-    return lo;
-}
-// every document that starts at byte `pos` begins at token `val` of its tile
-TKZ_DEV void tkz_mark_docs(const int64_t* offs, int64_t d0, int64_t d1, int64_t pos, int32_t* doc_local, int32_t val) {
-    for (int64_t d = tkz_lower_bound(offs, d0, d1, pos); d < d1 && offs[d] == pos; ++d) doc_local[d] = val;
+// exclusive prefix over the wave of a small non-negative value (< 2^BITS), and the wave total;
+// bit-sliced: one ballot + mbcnt per bit, no LDS traffic
+template <int BITS>
+TKZ_DEV int tkz_wave_scan(int v, int* total) {
+    const uint64_t below = tkz_lowmask(simt::lane());
+    int pre = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < BITS; ++j) {
+        const uint64_t m = simt::ballot((v >> j) & 1);
+        pre += tkz_popc64(m & below) << j;
+        tot += tkz_popc64(m) << j;
+    }
+    *total = tot;
+    return pre;
 }
 
-TKZ_KERNEL(256) void k_encode_tiles(TkzTables T, EncodeParams P) {
-    TKZ_SHARED uint32_t s_bytes[(kTile + kHalo) / 4];
-    TKZ_SHARED uint64_t s_bits[kTile / 64];
-    TKZ_SHARED uint64_t s_docb[kTile / 64];
-    TKZ_SHARED uint16_t s_pstart[kTile + 2];
-    TKZ_SHARED uint32_t s_longmask[kTile / 32];
-    TKZ_SHARED uint32_t s_scr[32 * kThreads];            // short: ids[16][256] pr[16][256]; long: 4 arrays of kLdsLong
-    TKZ_SHARED int s_np, s_nlong, s_i0, s_i1;
-    TKZ_SHARED int64_t s_last_end, s_d0, s_d1, s_l0;
+TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
+    TKZ_SHARED uint32_t s_bytes[(kSub + kHalo) / 4];
+    TKZ_SHARED uint16_t s_pstart[kSub + 2];
+    TKZ_SHARED uint4 s_scr4[(2 * kBpeLaneStride * kMergeLanes) / 4];   // short: per lane ids[16] | pr[16] (stride kBpeLaneStride); long: 4 arrays of kLdsLong
+    TKZ_SHARED uint16_t s_missq[kPassPieces];             // start | (len - 1) << 11
+    TKZ_SHARED uint16_t s_minfo[kMergeLanes];                      // per merged miss: alive mask (its tokens stay in that lane's ids[])
+    TKZ_SHARED uint64_t s_longmask[kSub / 64];
+    TKZ_SHARED int s_i0;
+    TKZ_SHARED int64_t s_l0;
 
-    const int tid = simt::tid();
-    const int64_t tile = simt::bid();
-    const int64_t base = tile * kTile;
-    const int nb = (int)(P.total - base < kTile ? P.total - base : kTile);
+    const int lane = simt::lane();
+    const int64_t sub = simt::bid();
+    const int64_t base = sub * kSub;
+    const int nb = (int)(P.total - base < kSub ? P.total - base : kSub);
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_bytes);
+    uint32_t* s_scr = reinterpret_cast<uint32_t*>(s_scr4);
 
-    // ---- stage the tile (+ halo) in LDS: 16 B per lane, coalesced ----
-    for (int i = tid; i < (kTile + kHalo) / 16; i += kThreads) {
+    const bool prof = (P.ablate & 16) != 0;
+    long long t_start = prof ? simt::clock() : 0, t_a = 0, t_m = 0, t_c = 0, t_01 = 0, n_iter = 0, n_round = 0, n_miss = 0;
+    // ---- stage 0 ----
+    for (int i = lane; i < (kSub + kHalo) / 16; i += 64) {
         const int64_t pos = base + 16 * (int64_t)i;
         uint4 v;
         if (pos + 16 <= P.total) v = tkz_load16(P.bytes + pos);
@@ -153,130 +175,214 @@ TKZ_KERNEL(256) void k_encode_tiles(TkzTables T, EncodeParams P) {
         }
         s_bytes[4 * i + 0] = v.x; s_bytes[4 * i + 1] = v.y; s_bytes[4 * i + 2] = v.z; s_bytes[4 * i + 3] = v.w;
     }
-    if (tid < kTile / 64) {
-        const int64_t w = tile * (kTile / 64) + tid;
-        uint64_t sbit = w < P.nwords ? P.startbits[w] : 0, dbit = w < P.nwords ? P.docbits[w] : 0;
-        const int lim = nb - tid * 64;                       // bits at or beyond the end of the corpus are not pieces
-        if (lim <= 0) sbit = 0; else if (lim < 64) sbit &= tkz_lowmask(lim);
-        s_bits[tid] = sbit; s_docb[tid] = dbit;
+    uint64_t myword = 0, mydoc = 0;                        // lanes 0..15: bitmap word / doc word of the sub-tile
+    if (lane < kSub / 64) {
+        const int64_t w = sub * (kSub / 64) + lane;
+        if (w < P.nwords) { myword = P.startbits[w]; mydoc = P.docbits[w]; }
+        const int lim = nb - lane * 64;                    // bits at or beyond the end of the corpus are not pieces
+        if (lim <= 0) myword = 0; else if (lim < 64) myword &= tkz_lowmask(lim);
+        s_longmask[lane] = 0;
     }
-    if (tid < kTile / 32) s_longmask[tid] = 0;
-    if (tid == 0) { s_nlong = 0; s_d0 = tkz_lower_bound(P.offs, 0, P.n_docs + 1, base); }
-    if (tid == 64) s_d1 = tkz_lower_bound(P.offs, 0, P.n_docs + 1, base + nb);
-
-    // ---- end of the last piece that starts in this tile: first piece start at or after base+nb ----
+    // end of the last piece that starts here = first piece start at or after base+nb (the sentinel at `total` bounds it)
+    int64_t last_end;
     {
         const int64_t from = base + nb, w0 = from >> 6;
         int64_t found = -1;
         for (int64_t c = 0; found < 0; ++c) {
-            const int64_t w = w0 + c * kThreads + tid;
+            const int64_t w = w0 + c * 64 + lane;
             uint64_t v = w < P.nwords ? P.startbits[w] : 0;
             if (w == w0) v &= ~tkz_lowmask((int)(from & 63));
-            uint64_t cand = v ? (uint64_t)((w << 6) + tkz_ctz64(v)) : ~0ull;
-            cand = tkz_block_min64(cand);
-            if (cand != ~0ull) found = (int64_t)cand;
-            else if (w0 + (c + 1) * kThreads >= P.nwords) found = P.total;   // cannot happen: the sentinel bit sits at `total`
+            const uint64_t any = simt::ballot(v != 0);
+            if (any) {
+                const int src = tkz_ctz64(any);
+                const uint32_t lo = simt::shflu((uint32_t)v, src), hi = simt::shflu((uint32_t)(v >> 32), src);
+                found = ((w0 + c * 64 + src) << 6) + tkz_ctz64(((uint64_t)hi << 32) | lo);
+            } else if (w0 + (c + 1) * 64 >= P.nwords) found = P.total;
         }
-        if (tid == 0) s_last_end = found;
+        last_end = found;
     }
-    simt::sync();
+    const int64_t last_end_rel = last_end - base;
 
-    // ---- enumerate the piece starts of the tile (order-preserving compaction) ----
+    // ---- stage 1: ordered compaction of the piece starts ----
+    const uint32_t wlo = simt::shflu((uint32_t)myword, lane >> 2), whi = simt::shflu((uint32_t)(myword >> 32), lane >> 2);
+    const uint32_t bits16 = (uint32_t)(((((uint64_t)whi << 32) | wlo) >> (16 * (lane & 3))) & 0xFFFFull);
+    int np;
     {
-        const uint32_t bits16 = (uint32_t)(s_bits[tid >> 2] >> (16 * (tid & 3))) & 0xFFFFu;
-        int np;
-        int off = tkz_block_scan(tkz_popc32(bits16), &np);
-        for (uint32_t b = bits16; b; b &= b - 1) s_pstart[off++] = (uint16_t)(16 * tid + tkz_ctz32(b));
-        if (tid == 0) s_np = np;
+        int off = tkz_wave_scan<5>(tkz_popc32(bits16), &np);
+        for (uint32_t b = bits16; b; b &= b - 1) s_pstart[off++] = (uint16_t)(16 * lane + tkz_ctz32(b));
     }
+    // document ordinals: docs that start before word `lane` of this sub-tile
+    int docpre_tot;
+    const int docpre = tkz_wave_scan<7>(lane < kSub / 64 ? tkz_popc64(mydoc) : 0, &docpre_tot);
+    const int64_t docord0 = P.docord_base[sub];
     simt::sync();
-    const int np = s_np;
-    const int64_t last_end_rel = s_last_end - base;
     const int64_t first_abs = np ? base + s_pstart[0] : base;
-    for (int k = tid; k < np; k += kThreads) {
-        const int64_t e = k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel;
-        if (e - s_pstart[k] > kShortMax) { simt::atomic_or((unsigned*)&s_longmask[k >> 5], 1u << (k & 31)); simt::atomic_add(&s_nlong, 1); }
+    int nlong = 0;
+    for (int k0 = 0; k0 < np; k0 += 64) {
+        const int k = k0 + lane;
+        bool lg = false;
+        if (k < np) lg = (k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s_pstart[k] > kShortMax;
+        const uint64_t m = simt::ballot(lg);
+        if (m) { if (lane == 0) s_longmask[k0 >> 6] = m; nlong += tkz_popc64(m); }
     }
     simt::sync();
-    int nlong = s_nlong;
-    const int64_t d0 = s_d0, d1 = s_d1;
 
-    int running = 0;                                      // tokens of this tile so far (uniform)
+    if (prof) t_01 = simt::clock() - t_start;
+    int running = 0;                                      // tokens of this sub-tile so far (uniform)
     int err = 0;
     int k0 = 0;
+    if (P.ablate & 8) k0 = np;
+    uint32_t* ids = &s_scr[(lane & (kMergeLanes - 1)) * kBpeLaneStride];
+    uint32_t* pr = &s_scr[kBpeLaneStride * kMergeLanes + (lane & (kMergeLanes - 1)) * kBpeLaneStride];
     while (k0 < np) {
-        // next long piece at or after k0
         int next_long = np;
         if (nlong > 0) {
-            int w = k0 >> 5;
-            uint32_t m = s_longmask[w] & (0xFFFFFFFFu << (k0 & 31));
-            while (!m && ++w < (np + 31) / 32) m = s_longmask[w];
-            if (m) next_long = w * 32 + tkz_ctz32(m);
+            int w = k0 >> 6;
+            uint64_t m = s_longmask[w] & (~0ull << (k0 & 63));
+            while (!m && ++w < (np + 63) / 64) m = s_longmask[w];
+            if (m) next_long = w * 64 + tkz_ctz64(m);
         }
         if (next_long > k0) {
-            // ---------------- a batch of up to 256 short pieces, one per lane ----------------
-            const int kend = k0 + kThreads < next_long ? k0 + kThreads : next_long;
-            const int k = k0 + tid;
-            const bool active = k < kend;
-            int cnt = 0; int32_t tok0 = 0; uint32_t alive = 0; int s = 0;
-            uint32_t* ids = &s_scr[tid];
-            uint32_t* pr = &s_scr[16 * kThreads + tid];
-            if (active) {
-                s = s_pstart[k];
-                const int len = (int)((k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s);
-                auto at = [&](int i) -> uint32_t { return sb[s + i]; };
-                int32_t rank;
-                if (len <= TKZ_SHORT_KEY_MAX) {
-                    const int w = s >> 2, sh = (s & 3) * 8;
-                    const uint64_t a01 = ((uint64_t)s_bytes[w + 1] << 32) | s_bytes[w];
-                    const uint64_t a12 = ((uint64_t)s_bytes[w + 2] << 32) | s_bytes[w + 1];
-                    const uint64_t a23 = ((uint64_t)s_bytes[w + 3] << 32) | s_bytes[w + 2];
-                    uint32_t q0 = (uint32_t)(a01 >> sh), q1 = (uint32_t)(a12 >> sh), q2 = (uint32_t)(a23 >> sh);
-                    if (len < 4) { q0 &= (1u << (8 * len)) - 1u; q1 = 0; q2 = 0; }
-                    else if (len < 8) { q1 &= (len == 4) ? 0u : ((1u << (8 * (len - 4))) - 1u); q2 = 0; }
-                    else if (len < 12) { q2 &= (len == 8) ? 0u : ((1u << (8 * (len - 8))) - 1u); }
-                    rank = tkz_lookup_short(T, q0, q1, q2, (uint32_t)len);
-                } else {
-                    rank = tkz_lookup_long(T, at, (uint32_t)len);
+            const int kend = k0 + kPassPieces < next_long ? k0 + kPassPieces : next_long;
+            long long t0 = prof ? simt::clock() : 0;
+            // ---------------- stage A: fetch keys, issue the first probe of every batch ----------------
+            int ps[kPassBatches], plen[kPassBatches];
+            uint32_t q0[kPassBatches], q1[kPassBatches], q2[kPassBatches], slot[kPassBatches];
+            uint4 pv[kPassBatches];
+#pragma unroll
+            for (int b = 0; b < kPassBatches; ++b) {
+                const int k = k0 + 64 * b + lane;
+                ps[b] = 0; plen[b] = 0; q0[b] = q1[b] = q2[b] = 0; slot[b] = 0;
+                pv[b].x = pv[b].y = pv[b].z = pv[b].w = 0;
+                if (k < kend) {
+                    const int s = s_pstart[k];
+                    const int len = (int)((k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s);
+                    ps[b] = s; plen[b] = len;
+                    if (len <= TKZ_SHORT_KEY_MAX) {
+                        const int w = s >> 2, sh = (s & 3) * 8;
+                        const uint64_t a01 = ((uint64_t)s_bytes[w + 1] << 32) | s_bytes[w];
+                        const uint64_t a12 = ((uint64_t)s_bytes[w + 2] << 32) | s_bytes[w + 1];
+                        const uint64_t a23 = ((uint64_t)s_bytes[w + 3] << 32) | s_bytes[w + 2];
+                        uint32_t x0 = (uint32_t)(a01 >> sh), x1 = (uint32_t)(a12 >> sh), x2 = (uint32_t)(a23 >> sh);
+                        if (len < 4) { x0 &= (1u << (8 * len)) - 1u; x1 = 0; x2 = 0; }
+                        else if (len < 8) { x1 &= (len == 4) ? 0u : ((1u << (8 * (len - 4))) - 1u); x2 = 0; }
+                        else if (len < 12) { x2 &= (len == 8) ? 0u : ((1u << (8 * (len - 8))) - 1u); }
+                        q0[b] = x0; q1[b] = x1; q2[b] = x2;
+                        slot[b] = tkz_hash_short(x0, x1, x2, (uint32_t)len) & T.short_mask;
+                    }
                 }
-                if (rank != TKZ_RANK_NONE) { cnt = 1; tok0 = rank; }                       // TikTokenizer.cs:262-265
-                else cnt = tkz_bpe_short(T, at, len, ids, pr, kThreads, &alive, &err);     // TikTokenizer.cs:268
             }
-            int tot;
-            const int pre = tkz_block_scan(cnt, &tot);
-            if (active) {
-                int32_t* dst = P.tmp + first_abs + running + pre;
-                if (alive == 0) dst[0] = tok0;
-                else { int i = 0; for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)ids[tkz_ctz32(a) * kThreads]; }
-                if ((s_docb[s >> 6] >> (s & 63)) & 1ull) tkz_mark_docs(P.offs, d0, d1, base + s, P.doc_local, running + pre);
+            // (the probes are issued unconditionally, slot 0 for idle lanes: a load inside a divergent branch is
+            //  waited for inside it, and the four batches would not overlap)
+#pragma unroll
+            for (int b = 0; b < kPassBatches; ++b) pv[b] = tkz_load16(&T.short_slots[(P.ablate & 2) ? 0u : slot[b]]);
+            // ---------------- stage B: resolve, compact the misses ----------------
+            int cnt[kPassBatches], qidx[kPassBatches];
+            int32_t tok[kPassBatches];
+            int nmiss = 0;
+#pragma unroll
+            for (int b = 0; b < kPassBatches; ++b) {
+                cnt[b] = 0; tok[b] = 0; qidx[b] = -1;
+                bool miss = false;
+                if (plen[b] > 0) {
+                    int32_t rank;
+                    if (plen[b] <= TKZ_SHORT_KEY_MAX) rank = tkz_resolve_short(T, q0[b], q1[b], q2[b], (uint32_t)plen[b], slot[b], pv[b]);
+                    else { const int s = ps[b]; rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)plen[b]); }
+                    if (rank != TKZ_RANK_NONE) { cnt[b] = 1; tok[b] = rank; }      // TikTokenizer.cs:262-265
+                    else miss = true;
+                }
+                const uint64_t mm = simt::ballot(miss);
+                if (miss) { qidx[b] = nmiss + tkz_popc64(mm & tkz_lowmask(lane)); s_missq[qidx[b]] = (uint16_t)((uint32_t)ps[b] | ((uint32_t)(plen[b] - 1) << 11)); }
+                nmiss += tkz_popc64(mm);
             }
-            running += tot;
-            k0 = kend;
+            // one merge round per pass: if more than kMergeLanes pieces missed, the pass ends before the next one (it is redone next pass)
+            int kcut = kend;
+            if (nmiss > kMergeLanes) {
+#pragma unroll
+                for (int b = 0; b < kPassBatches; ++b) {
+                    const uint64_t m = simt::ballot(qidx[b] == kMergeLanes);
+                    if (m) kcut = k0 + 64 * b + tkz_ctz64(m);
+                }
+#pragma unroll
+                for (int b = 0; b < kPassBatches; ++b)
+                    if (k0 + 64 * b + lane >= kcut) { plen[b] = 0; cnt[b] = 0; qidx[b] = -1; }
+                nmiss = kMergeLanes;
+            }
+            simt::sync();
+            if (prof) { const long long t1 = simt::clock(); t_a += t1 - t0; t0 = t1; n_miss += nmiss; }
+            // ---------------- stage M: BytePairEncode of the misses (TikTokenizer.cs:268), one per lane ----------------
+            {
+                int err1 = 0;
+                if (lane < nmiss) {
+                    uint32_t alive = 1;
+                    if (P.ablate & 1) ids[0] = 0;
+                    else {
+                        const uint32_t e = s_missq[lane];
+                        const int s = (int)(e & 0x7FFu), len = (int)(e >> 11) + 1;
+                        const int w = s >> 2, sh = (s & 3) * 8;
+                        const uint32_t a0 = s_bytes[w], a1 = s_bytes[w + 1], a2 = s_bytes[w + 2], a3 = s_bytes[w + 3], a4 = s_bytes[w + 4];
+                        tkz_bpe_short(T, (uint32_t)((((uint64_t)a1 << 32) | a0) >> sh), (uint32_t)((((uint64_t)a2 << 32) | a1) >> sh),
+                                      (uint32_t)((((uint64_t)a3 << 32) | a2) >> sh), (uint32_t)((((uint64_t)a4 << 32) | a3) >> sh),
+                                      len, ids, pr, T.byte_rank, &alive, &err1);
+                    }
+                    s_minfo[lane] = (uint16_t)alive;
+                }
+                err |= err1;
+            }
+            simt::sync();
+            if (prof) { const long long t1 = simt::clock(); t_m += t1 - t0; t0 = t1; n_round += (nmiss + 63) / 64; }
+            // ---------------- stage C: positions, dense stores, document marks ----------------
+#pragma unroll
+            for (int b = 0; b < kPassBatches; ++b) {
+                uint32_t alive = 0;
+                if (qidx[b] >= 0) { alive = s_minfo[qidx[b]]; cnt[b] = tkz_popc32(alive); }
+                int tot;
+                const int pos = running + tkz_wave_scan<5>(cnt[b], &tot);
+                const int s = ps[b], w = (s >> 6) & 15;
+                const uint32_t dlo = simt::shflu((uint32_t)mydoc, w), dhi = simt::shflu((uint32_t)(mydoc >> 32), w);
+                const int dpre = simt::shfl(docpre, w);
+                if (plen[b] > 0) {
+                    int32_t* dst = P.tmp + first_abs + pos;
+                    if (P.ablate & 4) {}
+                    else if (qidx[b] < 0) dst[0] = tok[b];
+                    else { const uint32_t* src = &s_scr[qidx[b] * kBpeLaneStride]; int i = 0; for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)src[tkz_ctz32(a)]; }
+                    const uint64_t dw = ((uint64_t)dhi << 32) | dlo;
+                    if ((dw >> (s & 63)) & 1ull) P.doc_tok[docord0 + dpre + tkz_popc64(dw & tkz_lowmask(s & 63))] = pos;
+                }
+                running += tot;
+            }
+            simt::sync();
+            if (prof) { const long long t1 = simt::clock(); t_c += t1 - t0; }
+            k0 = kcut;
         } else {
-            // ---------------- one long piece, the whole workgroup ----------------
+            // ---------------- one long piece, the whole wave ----------------
             const int s = s_pstart[k0];
             const int64_t len64 = (k0 + 1 < np ? (int64_t)s_pstart[k0 + 1] : last_end_rel) - s;
             const int64_t abs0 = base + s;
             const uint8_t* gb = P.bytes + abs0;
             auto at = [&](int i) -> uint32_t { return gb[i]; };
             int32_t* dst = P.tmp + first_abs + running;
-            int cnt = 0;
+            int cnt1 = 0;
+            {
+                const int w = (s >> 6) & 15;
+                const uint32_t dlo = simt::shflu((uint32_t)mydoc, w), dhi = simt::shflu((uint32_t)(mydoc >> 32), w);
+                const int dpre = simt::shfl(docpre, w);
+                const uint64_t dw = ((uint64_t)dhi << 32) | dlo;
+                if (lane == 0 && ((dw >> (s & 63)) & 1ull)) P.doc_tok[docord0 + dpre + tkz_popc64(dw & tkz_lowmask(s & 63))] = running;
+            }
             if (len64 > kMaxPiece) { err |= kErrTooLong; }
             else {
                 const int len = (int)len64;
-                if (tid == 0) {
-                    s_i0 = tkz_lookup_long(T, at, (uint32_t)len);
-                    if ((s_docb[s >> 6] >> (s & 63)) & 1ull) tkz_mark_docs(P.offs, d0, d1, abs0, P.doc_local, running);
-                }
+                if (lane == 0) s_i0 = tkz_lookup_long(T, at, (uint32_t)len);
                 simt::sync();
                 const int32_t whole = s_i0;
-                if (whole != TKZ_RANK_NONE) { if (tid == 0) dst[0] = whole; cnt = 1; }
+                if (whole != TKZ_RANK_NONE) { if (lane == 0) dst[0] = whole; cnt1 = 1; }
                 else {
                     int32_t* arr = reinterpret_cast<int32_t*>(s_scr);
                     int stride = kLdsLong;
                     bool ok = true;
-                    if (len > kLdsLong) {                 // giant piece: arrays in the global pool
-                        if (tid == 0) {
+                    if (len > kLdsLong) {                 // arrays in the global pool
+                        if (lane == 0) {
                             const unsigned long long need = 4ull * (unsigned long long)len;
                             const unsigned long long o = simt::atomic_add64(P.pool_head, need);
                             s_l0 = (o + need <= (unsigned long long)P.pool_cap) ? (int64_t)o : -1;
@@ -285,17 +391,34 @@ TKZ_KERNEL(256) void k_encode_tiles(TkzTables T, EncodeParams P) {
                         if (s_l0 < 0) { ok = false; err |= kErrPool; }
                         else { arr = P.pool + s_l0; stride = len; }
                     }
-                    if (ok) cnt = tkz_bpe_long(T, at, len, arr, arr + stride, arr + 2 * stride, arr + 3 * stride, dst, &err);
+                    if (ok) cnt1 = tkz_bpe_long(T, at, len, arr, arr + stride, arr + 2 * stride, arr + 3 * stride, dst, &err);
                 }
                 simt::sync();
             }
-            running += cnt;
+            running += cnt1;
             k0 += 1;
             nlong -= 1;
         }
     }
-    if (tid == 0) { P.tile_count[tile] = running; P.tile_first[tile] = first_abs; }
+    if (prof && lane == 0) {
+        simt::atomic_add64(&P.devprof[0], 1); simt::atomic_add64(&P.devprof[1], (unsigned long long)(simt::clock() - t_start));
+        simt::atomic_add64(&P.devprof[2], (unsigned long long)t_01); simt::atomic_add64(&P.devprof[3], (unsigned long long)t_a);
+        simt::atomic_add64(&P.devprof[4], (unsigned long long)t_m); simt::atomic_add64(&P.devprof[5], (unsigned long long)t_c);
+        simt::atomic_add64(&P.devprof[6], (unsigned long long)n_round); simt::atomic_add64(&P.devprof[7], (unsigned long long)n_miss);
+        simt::atomic_add64(&P.devprof[8], (unsigned long long)np);
+    }
+    if (lane == 0) { P.tile_count[sub] = running; P.tile_first[sub] = first_abs; }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
+}
+
+// documents that start in each sub-tile (for the document ordinals)
+TKZ_KERNEL(256) void k_doccount(const uint64_t* docbits, int64_t nwords, int64_t nsub, int32_t* cnt) {
+    const int64_t stride = simt::nblocks() * simt::nthreads();
+    for (int64_t s = simt::bid() * simt::nthreads() + simt::tid(); s < nsub; s += stride) {
+        int c = 0;
+        for (int j = 0; j < kSub / 64; ++j) { const int64_t w = s * (kSub / 64) + j; if (w < nwords) c += tkz_popc64(docbits[w]); }
+        cnt[s] = c;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -340,19 +463,26 @@ TKZ_KERNEL(256) void k_scan_final(const int32_t* cnt, int64_t n, const int64_t* 
 // k_gather / k_docoffs
 // -------------------------------------------------------------------------------------------------
 TKZ_KERNEL(256) void k_gather(const int32_t* tmp, const int32_t* tile_count, const int64_t* tile_first, const int64_t* tile_base,
-                              int32_t* out, int64_t out_cap) {
-    const int64_t t = simt::bid();
+                              int64_t nsub, int32_t* out, int64_t out_cap) {
+    const int64_t t = simt::bid() * (kThreads / 64) + simt::wave();     // one wavefront per sub-tile
+    if (t >= nsub) return;
     const int cnt = tile_count[t];
     const int32_t* src = tmp + tile_first[t];
     const int64_t b = tile_base[t];
-    for (int i = simt::tid(); i < cnt; i += kThreads) if (b + i < out_cap) out[b + i] = src[i];
+    for (int i = simt::lane(); i < cnt; i += 64) if (b + i < out_cap) out[b + i] = src[i];
 }
-TKZ_KERNEL(256) void k_docoffs(const int64_t* offs, int64_t n_docs, int64_t total, const int64_t* tile_base, const int32_t* doc_local,
-                               const int64_t* grand, int64_t* out_offs) {
+TKZ_KERNEL(256) void k_docoffs(const int64_t* offs, int64_t n_docs, int64_t total, const int64_t* tile_base, const uint64_t* docbits,
+                               const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
     for (int64_t d = simt::bid() * simt::nthreads() + simt::tid(); d <= n_docs; d += stride) {
         const int64_t pos = offs[d];
-        out_offs[d] = pos >= total ? *grand : (pos < 0 ? 0 : tile_base[pos / kTile] + doc_local[d]);
+        if (pos >= total) { out_offs[d] = *grand; continue; }
+        if (pos < 0) { out_offs[d] = 0; continue; }
+        const int64_t sub = pos / kSub, wpos = pos >> 6;
+        int64_t ord = docord_base[sub];
+        for (int64_t w = sub * (kSub / 64); w < wpos; ++w) ord += tkz_popc64(docbits[w]);
+        ord += tkz_popc64(docbits[wpos] & tkz_lowmask((int)(pos & 63)));
+        out_offs[d] = tile_base[sub] + doc_tok[ord];
     }
 }
 
@@ -418,29 +548,32 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
     TKZ_LAUNCH(k_pretok_seq, grid_for(n_docs), kThreads, L.stream, d_bytes, d_offs, n_docs, total, startbits, pattern, bmp, counters);
     hook(L, K_PRETOK, 1);
 }
-void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t ntiles) {
+void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub) {
     hook(L, K_ENCODE, 0);
-    TKZ_LAUNCH(k_encode_tiles, ntiles, kThreads, L.stream, T, P);
+    TKZ_LAUNCH(k_encode_waves, nsub, 64, L.stream, T, P);
     hook(L, K_ENCODE, 1);
 }
-void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand) {
+void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t nsub, int32_t* cnt) {
+    TKZ_LAUNCH(k_doccount, grid_for(nsub), kThreads, L.stream, docbits, nwords, nsub, cnt);
+}
+void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid) {
     const int64_t nblk = cdiv(ntiles, kScanBlock);
-    hook(L, K_SCAN, 0);
+    if (kid >= 0) hook(L, kid, 0);
     TKZ_LAUNCH(k_scan_partials, nblk, kThreads, L.stream, tile_count, ntiles, bsum);
     TKZ_LAUNCH(k_scan_top, 1, kThreads, L.stream, bsum, nblk, grand);
     TKZ_LAUNCH(k_scan_final, nblk, kThreads, L.stream, tile_count, ntiles, (const int64_t*)bsum, tile_base);
-    hook(L, K_SCAN, 1);
+    if (kid >= 0) hook(L, kid, 1);
 }
 void launch_gather(const Launch& L, const int32_t* tmp, const int32_t* tile_count, const int64_t* tile_first,
-                   const int64_t* tile_base, int64_t ntiles, int32_t* out, int64_t out_cap) {
+                   const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
     hook(L, K_GATHER, 0);
-    TKZ_LAUNCH(k_gather, ntiles, kThreads, L.stream, tmp, tile_count, tile_first, tile_base, out, out_cap);
+    TKZ_LAUNCH(k_gather, cdiv(nsub, kThreads / 64), kThreads, L.stream, tmp, tile_count, tile_first, tile_base, nsub, out, out_cap);
     hook(L, K_GATHER, 1);
 }
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
-                    const int32_t* doc_local, const int64_t* grand, int64_t* out_offs) {
+                    const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs) {
     hook(L, K_DOCOFFS, 0);
-    TKZ_LAUNCH(k_docoffs, grid_for(n_docs + 1), kThreads, L.stream, d_offs, n_docs, total, tile_base, doc_local, grand, out_offs);
+    TKZ_LAUNCH(k_docoffs, grid_for(n_docs + 1), kThreads, L.stream, d_offs, n_docs, total, tile_base, docbits, docord_base, doc_tok, grand, out_offs);
     hook(L, K_DOCOFFS, 1);
 }
 void launch_corpus(hipStream_t s, int kind, uint64_t seed, int64_t first_doc, int64_t n_docs, int min_len, int max_len,

@@ -18,6 +18,7 @@
 #define TKZ_DEV __device__ __forceinline__
 #define TKZ_HD __host__ __device__ __forceinline__
 #define TKZ_KERNEL(bounds) __global__ __launch_bounds__(bounds)
+#define TKZ_KERNEL_OCC(bounds, waves_per_simd) __global__ __launch_bounds__(bounds, waves_per_simd)
 #define TKZ_SHARED __shared__
 #define TKZ_LAUNCH(kernel, grid, block, stream, ...) \
     hipLaunchKernelGGL(kernel, dim3((unsigned)(grid)), dim3((unsigned)(block)), 0, (stream), __VA_ARGS__)
@@ -41,6 +42,7 @@ TKZ_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
 TKZ_DEV unsigned long long atomic_or64(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
 TKZ_DEV unsigned long long atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 TKZ_DEV unsigned long long atomic_min64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
+TKZ_DEV long long clock() { return (long long)__builtin_readcyclecounter(); }
 }  // namespace simt
 #endif
 

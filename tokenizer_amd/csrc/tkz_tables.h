@@ -97,6 +97,18 @@ TKZ_HD int32_t tkz_lookup_short(const TkzTables& T, uint32_t k0, uint32_t k1, ui
     }
 }
 
+// The same when the caller has already fetched the first slot `v` (= short_slots[slot]) -- lets several
+// independent first probes be in flight before any of them is examined.
+TKZ_HD int32_t tkz_resolve_short(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t slot, uint4 v) {
+    for (;;) {
+        if (v.w == 0) return TKZ_RANK_NONE;
+        if (v.x == k0 && v.y == k1 && v.z == k2 && (v.w >> TKZ_SHORT_RANK_BITS) == len)
+            return (int32_t)(v.w & TKZ_SHORT_RANK_MASK);
+        slot = (slot + 1) & T.short_mask;
+        v = tkz_load16(&T.short_slots[slot]);
+    }
+}
+
 // ranks.TryGetValue(left ++ right) through the ids of the two parts (BytePairEncoder.cs:25-36)
 TKZ_HD int32_t tkz_lookup_pair(const TkzTables& T, uint32_t a, uint32_t b) {
     uint32_t s = tkz_hash_pair(a, b) & T.pair_mask;
@@ -105,6 +117,15 @@ TKZ_HD int32_t tkz_lookup_pair(const TkzTables& T, uint32_t a, uint32_t b) {
         if (v.w == 0) return TKZ_RANK_NONE;
         if (v.x == a && v.y == b) return (int32_t)v.z;
         s = (s + 1) & T.pair_mask;
+    }
+}
+
+TKZ_HD int32_t tkz_resolve_pair(const TkzTables& T, uint32_t a, uint32_t b, uint32_t slot, uint4 v) {
+    for (;;) {
+        if (v.w == 0) return TKZ_RANK_NONE;
+        if (v.x == a && v.y == b) return (int32_t)v.z;
+        slot = (slot + 1) & T.pair_mask;
+        v = tkz_load16(&T.pair_slots[slot]);
     }
 }
 
