@@ -68,6 +68,7 @@ namespace simt {
 inline int tid() { return hipemu::g_tid; }
 inline int lane() { return hipemu::g_tid & 63; }
 inline int wave() { return hipemu::g_tid >> 6; }
+inline uint64_t uniform64(uint64_t v) { return v; }
 inline int64_t bid() { return hipemu::g_bid; }
 inline int64_t nblocks() { return hipemu::g_nblocks; }
 inline int nthreads() { return hipemu::g_nthreads; }

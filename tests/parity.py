@@ -14,6 +14,14 @@ SMALL_ALPHAS = {
     "apo": list("'''sStTrReEvVmMlLdD x.\n 1"),
     "oth": list(".,;!\n\r  a1'") + ["\U0001F600", "⭐", "中"],
     "case": list("aAbB") + ["中", "́", "ǅ", "ʰ", "'", "s", " ", ".", "1", "\n", "/"],
+    # pure-ASCII variants: these rows take the mask-algebra fast path of k_pretok_rows
+    "a_ws": list(" \n\r\t\x0b\x0c") + list("a.1") + ["\x1c", "\x00"],
+    "a_dig": list("0123456789") + list(" a.\n"),
+    "a_apo": list("'''sStTrReEvVmMlLdD x.\n 1"),
+    "a_oth": list(".,;!\n\r  a1'/\\"),
+    "a_mix": list("abcdeflmrstvDELMRSTVxyzXYZ") * 2 + list("0123456789") + list("  \t\n\r") + list("''.,;:!?()[]{}<>=+-*/_#"),
+    # long ASCII stretches broken by the occasional multi-byte char: fast <-> general path hand-over
+    "a_brk": list("abc 12's.\n") * 6 + ["中", "\U0001F600", "é", "　"],
 }
 
 

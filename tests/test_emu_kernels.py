@@ -33,7 +33,8 @@ def test_golden_gpt2_ids(lib, vocab, lib_rs_bytes):
 @pytest.mark.parametrize("pattern,sequential", [(1, 0), (2, 0), (1, 1), (2, 1), (3, 1)])
 def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
     parity.check_pretok(lib, oracle_mod, vocab, pattern, sequential, seeds=range(6),
-                        kinds=["mix", "ws", "dig", "apo", "oth", "case"], doc_lens=[0, 1, 7, 64, 65, 200, 1000, 5000, 9000])
+                        kinds=["mix", "ws", "dig", "apo", "oth", "case", "a_ws", "a_dig", "a_apo", "a_oth", "a_mix", "a_brk"],
+                        doc_lens=[0, 1, 7, 63, 64, 65, 127, 128, 129, 200, 1000, 5000, 9000])
 
 
 def test_golden_splits(lib, vocab):

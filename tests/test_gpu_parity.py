@@ -45,8 +45,8 @@ def test_golden_gpt2_ids(lib, vocab, lib_rs_bytes):
 @pytest.mark.parametrize("pattern,sequential", [(1, 0), (2, 0), (1, 1), (2, 1), (3, 1)])
 def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
     parity.check_pretok(lib, oracle_mod, vocab, pattern, sequential, seeds=range(25),
-                        kinds=["mix", "ws", "dig", "apo", "oth", "case"],
-                        doc_lens=[0, 1, 7, 64, 65, 200, 1000, 5000, 9000, 40000], n_docs_choices=(1, 3, 20, 200))
+                        kinds=["mix", "ws", "dig", "apo", "oth", "case", "a_ws", "a_dig", "a_apo", "a_oth", "a_mix", "a_brk"],
+                        doc_lens=[0, 1, 7, 63, 64, 65, 127, 128, 129, 200, 1000, 5000, 9000, 40000], n_docs_choices=(1, 3, 20, 200))
 
 
 def test_golden_splits(lib, vocab):
@@ -77,7 +77,7 @@ def test_giant_pieces(lib, vocab, oracle_mod, oracle_gpt2):
 @pytest.mark.parametrize("pattern", [1, 2, 3])
 def test_batch_vs_oracle(lib, vocab, oracle_mod, oracle_gpt2, pattern):
     parity.check_batch(lib, oracle_mod, vocab, oracle_gpt2, pattern, seed=11 + pattern, rounds=12,
-                       doc_lens=[0, 1, 10, 100, 1000, 6000, 30000], n_docs_choices=[1, 4, 40, 400], kinds=("mix", "ws", "oth", "dig", "apo", "case"))
+                       doc_lens=[0, 1, 10, 100, 1000, 6000, 30000], n_docs_choices=[1, 4, 40, 400], kinds=("mix", "ws", "oth", "dig", "apo", "case", "a_mix", "a_brk", "a_ws", "a_dig"))
 
 
 def test_errors_and_edges(lib, vocab, oracle_mod):

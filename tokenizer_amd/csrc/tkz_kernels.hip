@@ -44,45 +44,111 @@ TKZ_KERNEL(256) void k_docmark(const int64_t* offs, int64_t n_items, int64_t tot
 // -------------------------------------------------------------------------------------------------
 // k_pretok_rows : one wave per kRowsPerWave rows of 64 bytes
 // -------------------------------------------------------------------------------------------------
+// classification of one row: general (any UTF-8) or, when its 64 bytes are all ASCII, from the flag table
+struct RowInfo { TkzRowLane L; TkzRowMasks m; bool simple; };
 template <int PATTERN>
-TKZ_KERNEL(256) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits,
-                                   int64_t nrows, const uint8_t* bmp, int32_t* counters) {
-    const int64_t wave_id = simt::bid() * (simt::nthreads() >> 6) + simt::wave();
-    const int64_t r0 = wave_id * kRowsPerWave;
-    if (r0 >= nrows) return;                               // whole wave leaves together
-    const int64_t r1 = r0 + kRowsPerWave < nrows ? r0 + kRowsPerWave : nrows;
+TKZ_DEV RowInfo tkz_load_row(const TkzSrc& S, int64_t row, const uint8_t* bmp, const uint16_t* aflags) {
+    RowInfo r;
+    const int64_t pos = (row << 6) + simt::lane();
+    const uint32_t b = tkz_gbyte(S, pos);
+    const bool full = row >= 0 && ((row + 1) << 6) <= S.total;
+    r.simple = full && simt::ballot(b >= 0x80u) == 0;
+    if (r.simple) {
+        const uint32_t f = aflags[b];
+        r.L.pc = tkz_pc_of_flags(f); r.L.len = 1; r.L.off = 0; r.L.b = b; r.L.bad = 0;
+        r.m = tkz_row_masks_ascii(f);
+    } else {
+        r.L = tkz_classify_byte(S, pos, bmp);
+        r.m = tkz_row_masks(r.L, PATTERN == TKZ_PAT_CL100K);
+    }
+    return r;
+}
+
+constexpr int kStageRows = kRowsPerWave + 3;               // rows r0-2 .. r0+kRowsPerWave of a wavefront's chunk
+
+template <int PATTERN>
+TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits,
+                                  int64_t nrows, const uint8_t* bmp, int32_t* counters) {
+    // One wavefront per workgroup: the chunk index is then blockIdx.x, which the compiler knows to be
+    // wave-uniform -- that keeps every row mask in scalar registers and the mask algebra on the scalar unit.
+    TKZ_SHARED uint16_t s_aflags[128];
+    TKZ_SHARED uint4 s_stage[kStageRows * 4];                  // the wavefront's rows, staged once
+    TKZ_SHARED uint64_t s_ds[kStageRows];                      // ... and their document-start words
+    for (int i = simt::tid(); i < 128; i += simt::nthreads()) s_aflags[i] = (uint16_t)tkz_ascii_flags((uint32_t)i, PATTERN == TKZ_PAT_CL100K);
+    const int64_t r0 = simt::bid() * kRowsPerWave;
     const int lane = simt::lane();
+    // ---- stage rows [r0-2, r0+kRowsPerWave+1) of the corpus: 16 B per lane per load, all loads in flight together ----
+    const int64_t srow0 = r0 - 2;
+    TkzSrc S;
+    S.bytes = bytes; S.total = total; S.stage = reinterpret_cast<const uint8_t*>(s_stage);
+    S.lo = srow0 > 0 ? srow0 << 6 : 0;
+    S.hi = ((srow0 + kStageRows) << 6) < total ? ((srow0 + kStageRows) << 6) : total;
+    if (r0 < nrows) {
+        for (int i = lane; i < kStageRows * 4; i += 64) {
+            const int64_t pos = (srow0 << 6) + 16 * (int64_t)i;   // LDS offset of byte `pos` is pos - (srow0 << 6); S.lo clips the window
+            uint4 v; v.x = v.y = v.z = v.w = 0;
+            if (pos >= 0 && pos + 16 <= total) v = tkz_load16(bytes + pos);
+            else if (pos >= 0 && pos < total) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int j = 0; j < 16; ++j) if (pos + j < total) w[j >> 2] |= (uint32_t)bytes[pos + j] << (8 * (j & 3));
+                v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+            }
+            s_stage[i] = v;
+        }
+        for (int i = lane; i < kStageRows; i += 64) {
+            const int64_t r = srow0 + i;
+            s_ds[i] = (r >= 0 && r < nrows) ? docbits[r] : 0;
+        }
+    }
+    simt::sync();
+    if (r0 >= nrows) return;                               // whole wave leaves together
+    if (srow0 < 0) S.stage += (-srow0) << 6;               // byte S.lo == 0 sits (-srow0) rows into the buffer
+    const uint64_t* dsw = s_ds;
+    auto ds_at = [&](int64_t r) -> uint64_t {
+        const int64_t i = r - srow0;
+        if (i >= 0 && i < kStageRows) return simt::uniform64(dsw[i]);
+        return (r >= 0 && r < nrows) ? docbits[r] : 0;
+    };
+    const int64_t r1 = r0 + kRowsPerWave < nrows ? r0 + kRowsPerWave : nrows;
 
     // warm-up start: the nearest row boundary at or before r0 across which no scan state flows
     // (the byte before it is neither a digit nor CR/LF, or a document starts exactly there)
     int64_t rw = r0;
     while (rw > 0) {
-        if (docbits[rw] & 1ull) break;
-        const int pc = tkz_classify_byte(bytes, total, (rw << 6) - 1, bmp).pc;
+        if (ds_at(rw) & 1ull) break;
+        // (first_lane: every lane looks at the same byte, but the compiler only knows that if told -- a lane-varying
+        //  `rw` would drag every mask of the row loop from the scalar unit onto the VALU)
+        const int pc = simt::first_lane(tkz_classify_byte(S, (rw << 6) - 1, bmp).pc);
         if (pc != PC_N && pc != PC_CRLF) break;
         --rw;
     }
     TkzScanCarry cy;
     cy.nb63 = 0; cy.carryN = 0; cy.abs63 = 0; cy.sa_from = -1; cy.sa_end = -1; cy.sa_lastcr = -1;
 
-    int64_t row = rw > 0 ? rw - 1 : 0;                     // one extra row so the per-lane flags of "previous" are real
-    TkzRowLane P = tkz_classify_byte(bytes, total, ((row - 1) << 6) + lane, bmp);
-    TkzRowLane C = tkz_classify_byte(bytes, total, (row << 6) + lane, bmp);
-    TkzRowMasks mC = tkz_row_masks(C);
-    uint64_t dsP = row >= 1 ? docbits[row - 1] : 0, dsC = docbits[row];
+    int64_t row = rw > 0 ? rw - 1 : 0;                     // one extra row so the flags carried from "previous" are real
+    RowInfo P = tkz_load_row<PATTERN>(S, row - 1, bmp, s_aflags);
+    RowInfo C = tkz_load_row<PATTERN>(S, row, bmp, s_aflags);
+    uint64_t dsP = ds_at(row - 1), dsC = ds_at(row);
     int clenP = 0, o1msP = 0, bad = 0;
+    uint64_t c2P = 0, c3P = 0, o1P = 0;
     for (; row < r1; ++row) {
-        const TkzRowLane N = tkz_classify_byte(bytes, total, ((row + 1) << 6) + lane, bmp);
-        const TkzRowMasks mN = tkz_row_masks(N);
-        const uint64_t dsN = row + 1 < nrows ? docbits[row + 1] : 0;
+        const RowInfo N = tkz_load_row<PATTERN>(S, row + 1, bmp, s_aflags);
+        const uint64_t dsN = ds_at(row + 1);
         int clenC, o1msC;
-        const uint64_t out = tkz_row_eval<PATTERN>(P, C, N, dsP, dsC, dsN, mC, mN, clenP, o1msP, &clenC, &o1msC, cy,
-                                                   bytes, total, docbits, nrows, bmp, row);
+        uint64_t c2C, c3C, o1C, out;
+        if (C.simple && N.simple) {
+            out = tkz_row_eval_ascii<PATTERN>(P.m, C.m, N.m, dsC, dsN, c2P, c3P, o1P, &c2C, &c3C, &o1C, cy, S, docbits, nrows, bmp, row);
+            clenC = (int)((c2C >> lane) & 1ull) * 2 + (int)((c3C >> lane) & 1ull) * 3;
+            o1msC = (int)((o1C >> lane) & 1ull);
+        } else {
+            out = tkz_row_eval<PATTERN>(P.L, C.L, N.L, dsP, dsC, dsN, C.m, N.m, clenP, o1msP, &clenC, &o1msC, &c2C, &c3C, &o1C, cy,
+                                        S, docbits, nrows, bmp, row);
+        }
         if (row >= r0) {
             if (lane == 0) startbits[row] = out;
-            bad |= C.bad | ((C.off != 0 && ((dsC >> lane) & 1ull)) ? 1 : 0);   // a document may not start inside a char
+            bad |= C.L.bad | ((C.L.off != 0 && ((dsC >> lane) & 1ull)) ? 1 : 0);   // a document may not start inside a char
         }
-        P = C; C = N; mC = mN; dsP = dsC; dsC = dsN; clenP = clenC; o1msP = o1msC;
+        P = C; C = N; dsP = dsC; dsC = dsN; clenP = clenC; o1msP = o1msC; c2P = c2C; c3P = c3C; o1P = o1C;
     }
     if (simt::ballot(bad != 0) && lane == 0) simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrUtf8);
 }
@@ -534,12 +600,12 @@ void launch_docmark(const Launch& L, const int64_t* d_offs, int64_t n_items, int
 }
 void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, int64_t total, const uint64_t* docbits,
                         uint64_t* startbits, int64_t nrows, const uint8_t* bmp, int32_t* counters) {
-    const int64_t waves = cdiv(nrows, kRowsPerWave), grid = cdiv(waves, kThreads / 64);
+    const int64_t grid = cdiv(nrows, kRowsPerWave);           // one 64-lane workgroup per chunk of rows
     hook(L, K_PRETOK, 0);
     if (pattern == TKZ_PAT_P1)
-        TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_P1>, grid, kThreads, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters);
+        TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_P1>, grid, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters);
     else
-        TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_CL100K>, grid, kThreads, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters);
+        TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_CL100K>, grid, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters);
     hook(L, K_PRETOK, 1);
 }
 void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,

@@ -194,22 +194,28 @@ struct TkzRowLane {      // what a lane knows about ITS byte of a row
     int pc;              // PC_* of the char the byte belongs to (PC_NONE outside the corpus)
     int len;             // byte length of that char
     int off;             // distance back to its lead byte (0 for a lead)
-    uint32_t b, b1, b2;  // the byte and the two that follow
+    uint32_t b;          // the byte
     int bad;             // malformed UTF-8 seen by this lane
 };
 
-TKZ_DEV uint32_t tkz_gbyte(const uint8_t* bytes, int64_t total, int64_t pos) {
-    return (pos >= 0 && pos < total) ? bytes[pos] : 0u;
+// Where the scanners read text from: the corpus in HBM, with an optional window [lo, hi) of it staged in
+// LDS (k_pretok_rows stages each wavefront's rows once, 16 B per lane, instead of paying an HBM round trip
+// per 64-byte row).  Positions outside [0, total) read as 0.
+struct TkzSrc { const uint8_t* bytes; int64_t total; const uint8_t* stage; int64_t lo, hi; };
+
+TKZ_DEV uint32_t tkz_gbyte(const TkzSrc& S, int64_t pos) {
+    if (pos >= S.lo && pos < S.hi) return S.stage[pos - S.lo];
+    return (pos >= 0 && pos < S.total) ? S.bytes[pos] : 0u;
 }
 
-TKZ_DEV TkzRowLane tkz_classify_byte(const uint8_t* bytes, int64_t total, int64_t pos, const uint8_t* bmp) {
+TKZ_DEV TkzRowLane tkz_classify_byte(const TkzSrc& S, int64_t pos, const uint8_t* bmp) {
     TkzRowLane r;
-    r.pc = PC_NONE; r.len = 1; r.off = 0; r.b = r.b1 = r.b2 = 0; r.bad = 0;
-    if (pos < 0 || pos >= total) return r;
-    uint32_t m3 = tkz_gbyte(bytes, total, pos - 3), m2 = tkz_gbyte(bytes, total, pos - 2), m1 = tkz_gbyte(bytes, total, pos - 1);
-    const uint32_t b0 = bytes[pos];
-    const uint32_t p1 = tkz_gbyte(bytes, total, pos + 1), p2 = tkz_gbyte(bytes, total, pos + 2), p3 = tkz_gbyte(bytes, total, pos + 3);
-    r.b = b0; r.b1 = p1; r.b2 = p2;
+    r.pc = PC_NONE; r.len = 1; r.off = 0; r.b = 0; r.bad = 0;
+    if (pos < 0 || pos >= S.total) return r;
+    uint32_t m3 = tkz_gbyte(S, pos - 3), m2 = tkz_gbyte(S, pos - 2), m1 = tkz_gbyte(S, pos - 1);
+    const uint32_t b0 = tkz_gbyte(S, pos);
+    const uint32_t p1 = tkz_gbyte(S, pos + 1), p2 = tkz_gbyte(S, pos + 2), p3 = tkz_gbyte(S, pos + 3);
+    r.b = b0;
     int off = 0;
     if ((b0 & 0xC0) == 0x80) {   // continuation byte: find the lead within 3 bytes
         if (m1 >= 0xC2 && pos >= 1) off = 1;
@@ -227,14 +233,56 @@ TKZ_DEV TkzRowLane tkz_classify_byte(const uint8_t* bytes, int64_t total, int64_
     return r;
 }
 
-struct TkzRowMasks { uint64_t nb, nl, cr, wsb; };   // N bytes, N leads, CR/LF bytes, \s bytes
+// Per-row class masks (one bit per byte; a multi-byte char marks all of its bytes):
+//   nb \p{N} bytes, nl \p{N} lead bytes, cr CR/LF, wsb \s, L \p{L}, O [^\s\p{L}\p{N}], sp ' ', ap '\'',
+//   s1 / rv / e / ll  the letters of the contraction literals (s|t|m|d, r|v, e, l; case-folded for cl100k)
+struct TkzRowMasks { uint64_t nb, nl, cr, wsb, L, O, sp, ap, s1, rv, e, ll; };
 
-TKZ_DEV TkzRowMasks tkz_row_masks(const TkzRowLane& L) {
+enum : uint32_t { AF_L = 1, AF_N = 2, AF_CRLF = 4, AF_SP = 8, AF_WSO = 16, AF_AP = 32, AF_S1 = 64, AF_RV = 128, AF_E = 256, AF_LL = 512 };
+// class + literal flags of an ASCII byte (b < 128)
+TKZ_HD uint32_t tkz_ascii_flags(uint32_t b, bool ignore_case) {
+    uint32_t f = 0;
+    const uint8_t uc = tkz_ascii_class(b);
+    if (tkz_uc_is_letter(uc)) f |= AF_L;
+    else if (uc == UC_N) f |= AF_N;
+    else if (uc == UC_WS) f |= (b == '\r' || b == '\n') ? AF_CRLF : (b == ' ' ? AF_SP : AF_WSO);
+    if (b == '\'') f |= AF_AP;
+    const uint32_t lc = (ignore_case && b - 'A' < 26u) ? (b | 0x20u) : b;
+    if (lc == 's' || lc == 't' || lc == 'm' || lc == 'd') f |= AF_S1;
+    if (lc == 'r' || lc == 'v') f |= AF_RV;
+    if (lc == 'e') f |= AF_E;
+    if (lc == 'l') f |= AF_LL;
+    return f;
+}
+TKZ_HD int tkz_pc_of_flags(uint32_t f) {
+    return (f & AF_L) ? PC_L : (f & AF_N) ? PC_N : (f & AF_CRLF) ? PC_CRLF : (f & AF_SP) ? PC_SP : (f & AF_WSO) ? PC_WS : PC_O1;
+}
+// masks of a row whose 64 bytes are all ASCII, from the per-lane flags
+TKZ_DEV TkzRowMasks tkz_row_masks_ascii(uint32_t f) {
+    TkzRowMasks m;
+    m.nb = simt::ballot(f & AF_N); m.nl = m.nb;
+    m.cr = simt::ballot(f & AF_CRLF);
+    m.wsb = simt::ballot(f & (AF_CRLF | AF_SP | AF_WSO));
+    m.L = simt::ballot(f & AF_L);
+    m.O = ~(m.nb | m.wsb | m.L);
+    m.sp = simt::ballot(f & AF_SP);
+    m.ap = simt::ballot(f & AF_AP);
+    m.s1 = simt::ballot(f & AF_S1); m.rv = simt::ballot(f & AF_RV); m.e = simt::ballot(f & AF_E); m.ll = simt::ballot(f & AF_LL);
+    return m;
+}
+// masks of any row, from the general per-byte classification
+TKZ_DEV TkzRowMasks tkz_row_masks(const TkzRowLane& L, bool ignore_case) {
     TkzRowMasks m;
     m.nb = simt::ballot(L.pc == PC_N);
     m.nl = simt::ballot(L.pc == PC_N && L.off == 0);
     m.cr = simt::ballot(L.pc == PC_CRLF);
     m.wsb = simt::ballot(tkz_pc_is_ws(L.pc));
+    m.L = simt::ballot(L.pc == PC_L);
+    m.O = simt::ballot(tkz_pc_is_other(L.pc));
+    m.sp = simt::ballot(L.pc == PC_SP);
+    const uint32_t f = (L.pc != PC_NONE && L.b < 128u) ? tkz_ascii_flags(L.b, ignore_case) : 0u;
+    m.ap = simt::ballot(f & AF_AP);
+    m.s1 = simt::ballot(f & AF_S1); m.rv = simt::ballot(f & AF_RV); m.e = simt::ballot(f & AF_E); m.ll = simt::ballot(f & AF_LL);
     return m;
 }
 
@@ -272,14 +320,14 @@ struct TkzScanCarry {        // wave-uniform state carried from row to row
 
 // Does a connected white-space run that starts at absolute position `from` (a row boundary) contain a
 // CR/LF?  Only needed when a white-space run covers the whole look-ahead row.  Wave-uniform.
-TKZ_DEV bool tkz_scan_ahead_crlf(const uint8_t* bytes, int64_t total, const uint64_t* docbits, int64_t nrows,
+TKZ_DEV bool tkz_scan_ahead_crlf(const TkzSrc& S, const uint64_t* docbits, int64_t nrows,
                                  const uint8_t* bmp, int64_t from, TkzScanCarry& cy) {
     if (cy.sa_from >= 0 && from >= cy.sa_from && from < cy.sa_end) return cy.sa_lastcr >= from;
     int64_t row = from >> 6;
     int64_t lastcr = -1, end = from;
     for (;; ++row) {
         if (row >= nrows) { end = row << 6; break; }
-        const TkzRowLane L = tkz_classify_byte(bytes, total, (row << 6) + simt::lane(), bmp);
+        const TkzRowLane L = tkz_classify_byte(S, (row << 6) + simt::lane(), bmp);
         const uint64_t wsb = simt::ballot(tkz_pc_is_ws(L.pc));
         const uint64_t cr = simt::ballot(L.pc == PC_CRLF);
         const uint64_t conn = wsb & ~docbits[row];
@@ -301,8 +349,9 @@ TKZ_DEV uint64_t tkz_row_eval(const TkzRowLane& P, const TkzRowLane& C, const Tk
                               uint64_t dsP, uint64_t dsC, uint64_t dsN,
                               const TkzRowMasks& mC, const TkzRowMasks& mN,
                               int clenP, int o1msP, int* clenC_out, int* o1msC_out,
+                              uint64_t* c2C, uint64_t* c3C, uint64_t* o1C,
                               TkzScanCarry& cy,
-                              const uint8_t* bytes, int64_t total, const uint64_t* docbits, int64_t nrows,
+                              const TkzSrc& S, const uint64_t* docbits, int64_t nrows,
                               const uint8_t* bmp, int64_t row) {
     const int lane = simt::lane();
     const int lead = lane - C.off;                       // >= -3
@@ -317,11 +366,13 @@ TKZ_DEV uint64_t tkz_row_eval(const TkzRowLane& P, const TkzRowLane& C, const Tk
     // contraction at an apostrophe that is a match start
     int clen = 0;
     if (C.b == '\'' && C.pc == PC_O1 && !tkz_pc_is_other(p) && p != PC_SP) {
-        const int k = tkz_contraction_len(C.b1, C.b2, PATTERN == TKZ_PAT_CL100K);
+        const int64_t pos = (row << 6) + lane;
+        const int k = tkz_contraction_len(tkz_gbyte(S, pos + 1), tkz_gbyte(S, pos + 2), PATTERN == TKZ_PAT_CL100K);
         if (k && !tkz_bit3(dsP, dsC, dsN, lane + 1) && (k == 2 || !tkz_bit3(dsP, dsC, dsN, lane + 2))) clen = k;
     }
     const int o1ms = (C.pc == PC_O1 && !tkz_pc_is_other(p) && p != PC_SP && !tkz_pc_is_other(n)) ? 1 : 0;
     *clenC_out = clen; *o1msC_out = o1ms;
+    *c2C = simt::ballot(clen == 2); *c3C = simt::ballot(clen == 3); *o1C = simt::ballot(o1ms != 0);
     const int cback2 = tkz_win2(clenP, clen, lane - 2), cback3 = tkz_win2(clenP, clen, lane - 3);   // (collectives: evaluate both)
     const bool contrEnd = cback2 == 2 || cback3 == 3;
     const int clenPrev = tkz_win2(clenP, clen, lead - 1);
@@ -357,8 +408,8 @@ TKZ_DEV uint64_t tkz_row_eval(const TkzRowLane& P, const TkzRowLane& C, const Tk
             if (connN == ~0ull && (mC.wsb >> 63)) {      // the run may continue past the look-ahead row
                 const int64_t from = (row + 2) << 6;
                 const bool conn128 = from < (nrows << 6) && !(docbits[row + 2] & 1ull) &&
-                                     tkz_pc_is_ws(tkz_classify_byte(bytes, total, from, bmp).pc);
-                if (conn128 && tkz_scan_ahead_crlf(bytes, total, docbits, nrows, bmp, from, cy)) crN |= 1ull << 63;
+                                     tkz_pc_is_ws(simt::first_lane(tkz_classify_byte(S, from, bmp).pc));
+                if (conn128 && tkz_scan_ahead_crlf(S, docbits, nrows, bmp, from, cy)) crN |= 1ull << 63;
             }
             // reversed positions k = 127 - j : S'(k) = CR(127-k), G'(k) = CONN(128-k)
             const uint64_t Slo = tkz_brev64(crN), Shi = tkz_brev64(mC.cr);
@@ -391,5 +442,114 @@ TKZ_DEV uint64_t tkz_row_eval(const TkzRowLane& P, const TkzRowLane& C, const Tk
     }
     start = start || contrEnd;
     return simt::ballot(start && isLead) | dsC;
+}
+
+// The same for a row whose own 64 bytes and whose successor row are pure ASCII: every quantity is a
+// 64-bit mask and the rules of tkz_row_eval become wave-uniform bit algebra (no per-lane work at all).
+// mP is only consulted for bit 63 of its masks (the char before this row).
+template <int PATTERN>
+TKZ_DEV uint64_t tkz_row_eval_ascii(const TkzRowMasks& mP, const TkzRowMasks& mC, const TkzRowMasks& mN,
+                                    uint64_t dsC, uint64_t dsN, uint64_t c2P, uint64_t c3P, uint64_t o1P,
+                                    uint64_t* c2C, uint64_t* c3C, uint64_t* o1C, TkzScanCarry& cy,
+                                    const TkzSrc& S, const uint64_t* docbits, int64_t nrows,
+                                    const uint8_t* bmp, int64_t row) {
+    const uint64_t nds = ~dsC;
+    const uint64_t KN = (dsC >> 1) | (dsN << 63);                 // the NEXT position starts a document
+    const uint64_t L = mC.L, N = mC.nb, O = mC.O, CR = mC.cr, SP = mC.sp, W = mC.wsb, AP = mC.ap;
+#define TKZ_PREV(xC, xP) ((((xC) << 1) | ((xP) >> 63)) & nds)
+#define TKZ_NEXT(xC, xN) ((((xC) >> 1) | ((xN) << 63)) & ~KN)
+    const uint64_t pL = TKZ_PREV(L, mP.L), pN = TKZ_PREV(N, mP.nb), pO = TKZ_PREV(O, mP.O), pSP = TKZ_PREV(SP, mP.sp);
+    const uint64_t pW = TKZ_PREV(W, mP.wsb), pCR = TKZ_PREV(CR, mP.cr);
+    const uint64_t nO = TKZ_NEXT(O, mN.O);
+    const uint64_t nReal = TKZ_NEXT(L | N | O, mN.L | mN.nb | mN.O);   // a next char exists in the document and is not \s
+    // contractions: an apostrophe that is a match start, followed by a literal inside the document
+    uint64_t c2 = 0, c3 = 0;
+    if (AP) {
+        const uint64_t KN2 = (dsC >> 2) | (dsN << 62);
+        const uint64_t n1S1 = (mC.s1 >> 1) | (mN.s1 << 63), n1RV = (mC.rv >> 1) | (mN.rv << 63), n1LL = (mC.ll >> 1) | (mN.ll << 63);
+        const uint64_t n2E = (mC.e >> 2) | (mN.e << 62), n2LL = (mC.ll >> 2) | (mN.ll << 62);
+        const uint64_t ms = AP & ~pO & ~pSP & ~KN;
+        c2 = ms & n1S1;
+        c3 = ms & ~KN2 & ((n1RV & n2E) | (n1LL & n2LL));
+    }
+    *c2C = c2; *c3C = c3;
+    const uint64_t contrEnd = (c2 << 2) | (c3 << 3) | (c2P >> 62) | (c3P >> 61);
+    uint64_t start;
+    if (PATTERN == TKZ_PAT_P1) {
+        const uint64_t clenPrev = ((c2 | c3) << 1) | ((c2P | c3P) >> 63);
+        *o1C = 0;
+        start = (L & ~pL & ~pSP & ~clenPrev) | (N & ~pN & ~pSP) | (O & ~pO & ~pSP) | (W & (~pW | nReal));
+    } else {
+        const uint64_t o1 = O & ~pO & ~pSP & ~nO;
+        *o1C = o1;
+        const uint64_t o1Prev = (o1 << 1) | (o1P >> 63);
+        const uint64_t pWSo = pW & ~pCR & ~pSP;
+        const uint64_t sL = L & ~pL & ~pSP & ~pWSo & ~o1Prev;
+        const uint64_t sO = O & ~pO & ~pSP;
+        // \p{N}{1,3}: every third digit of a run
+        uint64_t sN = 0;
+        int carryN = 0;
+        if (N) {
+            const uint64_t Q = N & pN;                            // continues the run of the previous byte
+            uint64_t S = N & ~pN;                                 // runs that start in this row
+            if (Q & 1ull) {                                       // a run entering from the previous row
+                const int d = (3 - cy.carryN) % 3, lead = (~Q) ? tkz_ctz64(~Q) : 64;
+                if (d < lead) S |= 1ull << d;
+            }
+            const uint64_t Q3 = Q & (Q << 1) & (Q << 2);
+            uint64_t T = S | ((S << 3) & Q3);
+            const uint64_t Q6 = Q3 & (Q3 << 3);
+            if (Q6) {
+                T |= (T << 6) & Q6;
+                const uint64_t Q12 = Q6 & (Q6 << 6);
+                if (Q12) {
+                    T |= (T << 12) & Q12;
+                    const uint64_t Q24 = Q12 & (Q12 << 12);
+                    if (Q24) { T |= (T << 24) & Q24; const uint64_t Q48 = Q24 & (Q24 << 24); T |= (T << 48) & Q48; }
+                }
+            }
+            sN = T;
+            if (N >> 63) carryN = (~Q) ? (64 - tkz_msb64(~Q)) % 3 : (cy.carryN + 64) % 3;
+        }
+        // white space
+        uint64_t ABS = 0;
+        if (CR) {
+            const uint64_t R = CR & nds;
+            uint64_t seeds = CR & pO;
+            if (cy.abs63) seeds |= R & 1ull;
+            ABS = tkz_fill_up64(seeds & R, R);
+        }
+        uint64_t Tcur = 0;
+        {
+            const uint64_t connC = W & nds, connN = mN.wsb & ~dsN;
+            const bool beyond = connN == ~0ull && (W >> 63);
+            if ((CR | mN.cr) || beyond) {
+                uint64_t crN = mN.cr;
+                if (beyond) {
+                    const int64_t from = (row + 2) << 6;
+                    const bool conn128 = from < (nrows << 6) && !(docbits[row + 2] & 1ull) &&
+                                         tkz_pc_is_ws(simt::first_lane(tkz_classify_byte(S, from, bmp).pc));
+                    if (conn128 && tkz_scan_ahead_crlf(S, docbits, nrows, bmp, from, cy)) crN |= 1ull << 63;
+                }
+                const uint64_t Slo = tkz_brev64(crN), Shi = tkz_brev64(CR);
+                const uint64_t rlo = tkz_brev64(connN), rhi = tkz_brev64(connC);
+                const uint64_t Glo = rlo << 1, Ghi = (rhi << 1) | (rlo >> 63);
+                const uint64_t S2lo = (Slo << 1) & Glo, S2hi = ((Shi << 1) | (Slo >> 63)) & Ghi;
+                uint64_t Plo, Phi;
+                tkz_fill_up128(S2lo, S2hi, Glo, Ghi, &Plo, &Phi);
+                (void)Plo;
+                Tcur = tkz_brev64(Shi | Phi);
+            }
+        }
+        const uint64_t pABS = (ABS << 1) | (uint64_t)(cy.abs63 & 1);
+        const uint64_t sW = W & ~ABS & ((~pW | pABS) | (pCR & ~Tcur) | (~CR & nReal));
+        start = sL | sN | sO | sW;
+        cy.carryN = carryN;
+        cy.nb63 = (int)(N >> 63);
+        cy.abs63 = (int)(ABS >> 63);
+    }
+#undef TKZ_PREV
+#undef TKZ_NEXT
+    return start | contrEnd | dsC;
 }
 #endif  // TKZ_NO_SIMT

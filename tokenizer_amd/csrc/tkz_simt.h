@@ -26,7 +26,12 @@
 namespace simt {
 TKZ_DEV int tid() { return (int)threadIdx.x; }
 TKZ_DEV int lane() { return (int)(threadIdx.x & 63); }
-TKZ_DEV int wave() { return (int)(threadIdx.x >> 6); }
+// (readfirstlane: the compiler cannot know that threadIdx.x >> 6 is the same in all 64 lanes; without it every
+//  value derived from the wave index -- row numbers, mask words -- is kept in VGPRs and computed on the VALU)
+TKZ_DEV int wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+TKZ_DEV uint64_t uniform64(uint64_t v) {   // v is known to be wave-uniform: move it to scalar registers
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 TKZ_DEV int64_t bid() { return (int64_t)blockIdx.x; }
 TKZ_DEV int64_t nblocks() { return (int64_t)gridDim.x; }
 TKZ_DEV int nthreads() { return (int)blockDim.x; }
