@@ -1,0 +1,141 @@
+// GpuTikTokenizer.cs -- ITokenizer over libtkz (MI355X).  SOURCE ONLY: the build image has no .NET toolchain
+// (no dotnet / mono / csc), so this file is not compiled or tested here; the same boundary is exercised through
+// ctypes (tokenizer_amd/_native.py) and C++ (include/tkz_tokenizer.hpp).  See INTEGRATION.md.
+//
+// Drop it into Tokenizer_C#/TokenizerLib next to TikTokenizer.cs.  It keeps the two Encode overloads of
+// ITokenizer (ITokenizer.cs:12,28) and adds EncodeBatch; special-token segmentation is the reference's own
+// EncodeInternal / FindNextSpecialToken (TikTokenizer.cs:141-170,230-241) with the plain segments sent to the
+// GPU in one batch.  Trim variants and Decode delegate to a CPU TikTokenizer (they are not on the hot path).
+using System;
+using System.Collections.Generic;
+using System.IO;
+using System.Linq;
+using System.Runtime.InteropServices;
+using System.Text;
+using System.Text.RegularExpressions;
+
+namespace Microsoft.DeepDev
+{
+    internal static class Tkz
+    {
+        private const string Lib = "tkz";   // libtkz.so
+
+        [DllImport(Lib)] internal static extern IntPtr tkz_last_error();
+        [DllImport(Lib)] internal static extern int tkz_vocab_from_tiktoken(byte[] file, UIntPtr n, out IntPtr vocab);
+        [DllImport(Lib)] internal static extern void tkz_vocab_destroy(IntPtr vocab);
+        [DllImport(Lib)] internal static extern int tkz_pattern_from_regex([MarshalAs(UnmanagedType.LPUTF8Str)] string regex, out int pattern);
+        [DllImport(Lib)] internal static extern int tkz_encoder_create(IntPtr vocab, int pattern, int device, out IntPtr encoder);
+        [DllImport(Lib)] internal static extern void tkz_encoder_destroy(IntPtr encoder);
+        [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_utf8(IntPtr encoder, byte* bytes, long* docOffsets, long nDocs,
+                                                                                  int* outIds, long outCap, long* outOffsets, out long needed);
+        [DllImport(Lib)] internal static extern unsafe int tkz_encode_utf16(IntPtr encoder, char* text, long len, int* outIds, long outCap, out long nOut);
+
+        internal static void Check(int status)
+        {
+            if (status == 0) return;
+            string msg = Marshal.PtrToStringUTF8(tkz_last_error()) ?? "";
+            switch (status)
+            {
+                case -1: throw new InvalidOperationException("Failed to load from BPE encoder file stream: " + msg, new FormatException(msg));  // TikTokenizer.cs:133-136
+                case -2: throw new ArgumentException(msg);                    // TikTokenizer.cs:84-87
+                case -3: throw new KeyNotFoundException(msg);                 // BytePairEncoder.cs:17,73
+                case -7: throw new NotImplementedException(msg);              // TokenizerBuilder.cs:179
+                case -9: throw new PlatformNotSupportedException(msg);        // no HIP device: there is no CPU fallback in libtkz
+                default: throw new InvalidOperationException("libtkz status " + status + ": " + msg);
+            }
+        }
+    }
+
+    public sealed class GpuTikTokenizer : ITokenizer, IDisposable
+    {
+        private readonly IntPtr encoder;
+        private readonly IReadOnlyDictionary<string, int> specialTokensEncoder;
+        private readonly HashSet<string> specialTokens;
+        private readonly Regex specialTokensRegex;
+        private readonly TikTokenizer cpu;       // Decode / trim variants
+
+        /// <summary>Same arguments as TokenizerBuilder.CreateTokenizer (TokenizerBuilder.cs:210-213) plus the HIP device index.</summary>
+        public GpuTikTokenizer(Stream tikTokenBpeFileStream, IReadOnlyDictionary<string, int> specialTokensEncoder, string pattern, int cacheSize = 8192, int device = 0)
+        {
+            byte[] file;
+            using (var ms = new MemoryStream()) { tikTokenBpeFileStream.CopyTo(ms); file = ms.ToArray(); }
+            Tkz.Check(Tkz.tkz_pattern_from_regex(pattern, out int pat));          // only the reference's own three patterns are implemented
+            Tkz.Check(Tkz.tkz_vocab_from_tiktoken(file, (UIntPtr)file.Length, out IntPtr vocab));
+            try { Tkz.Check(Tkz.tkz_encoder_create(vocab, pat, device, out encoder)); }
+            finally { Tkz.tkz_vocab_destroy(vocab); }
+            this.specialTokensEncoder = specialTokensEncoder;
+            specialTokens = new HashSet<string>(specialTokensEncoder.Keys);
+            specialTokensRegex = new Regex(string.Join("|", specialTokens.Select(s => Regex.Escape(s))), RegexOptions.Compiled);
+            cpu = new TikTokenizer(new MemoryStream(file), specialTokensEncoder, pattern, cacheSize);
+        }
+
+        public List<int> Encode(string text, IReadOnlyCollection<string> allowedSpecial)
+            => EncodeBatch(new[] { text }, allowedSpecial)[0];
+
+        public List<int> Encode(string text, bool applySpecialTokens = true)
+            => EncodeBatch(new[] { text }, applySpecialTokens && specialTokens.Count > 0 ? specialTokens : null)[0];
+
+        /// <summary>Encodes every text as Encode(text, allowedSpecial) would; all plain segments go to the GPU as one batch.</summary>
+        public unsafe List<List<int>> EncodeBatch(IReadOnlyList<string> texts, IReadOnlyCollection<string>? allowedSpecial = null)
+        {
+            // 1. segmentation on the host: (text index, plain segment) and literal special ids, in order
+            var plan = new List<(int text, int special, int segment)>();
+            var segments = new List<(string text, int start, int end)>();
+            for (int t = 0; t < texts.Count; ++t)
+            {
+                string text = texts[t];
+                if (allowedSpecial is null || allowedSpecial.Count == 0)
+                {
+                    if (text.Length > 0) { plan.Add((t, -1, segments.Count)); segments.Add((text, 0, text.Length)); }
+                    continue;
+                }
+                int start = 0;
+                while (true)
+                {
+                    Match next; int startFind = start;
+                    while (true)                                              // FindNextSpecialToken (TikTokenizer.cs:230-241)
+                    {
+                        next = specialTokensRegex.Match(text, startFind);
+                        if (!next.Success || allowedSpecial.Contains(next.Value)) break;
+                        startFind = next.Index + 1;
+                    }
+                    int end = next.Success ? next.Index : text.Length;
+                    if (end > start) { plan.Add((t, -1, segments.Count)); segments.Add((text, start, end)); }
+                    if (!next.Success) break;
+                    plan.Add((t, specialTokensEncoder[next.Value], -1));        // EncodeSpecialToken (:215-220)
+                    start = next.Index + next.Length;
+                    if (start >= text.Length) break;
+                }
+            }
+            // 2. the plain segments as one UTF-8 document batch (Encoding.UTF8.GetBytes, TikTokenizer.cs:261)
+            var offsets = new long[segments.Count + 1];
+            long total = 0;
+            for (int i = 0; i < segments.Count; ++i) { offsets[i] = total; total += Encoding.UTF8.GetByteCount(segments[i].text.AsSpan(segments[i].start, segments[i].end - segments[i].start)); }
+            offsets[segments.Count] = total;
+            var bytes = new byte[Math.Max(1, total)];
+            for (int i = 0; i < segments.Count; ++i)
+                Encoding.UTF8.GetBytes(segments[i].text.AsSpan(segments[i].start, segments[i].end - segments[i].start), bytes.AsSpan((int)offsets[i]));
+            var ids = new int[Math.Max(1, total)];                             // a token is at least one byte
+            var outOffsets = new long[segments.Count + 1];
+            fixed (byte* pb = bytes) fixed (long* po = offsets) fixed (int* pi = ids) fixed (long* poo = outOffsets)
+                Tkz.Check(Tkz.tkz_encode_batch_utf8(encoder, pb, po, segments.Count, pi, ids.Length, poo, out _));
+            // 3. stitch
+            var result = new List<List<int>>(texts.Count);
+            for (int t = 0; t < texts.Count; ++t) result.Add(new List<int>());
+            foreach (var (t, special, segment) in plan)
+            {
+                if (segment < 0) { result[t].Add(special); continue; }
+                for (long k = outOffsets[segment]; k < outOffsets[segment + 1]; ++k) result[t].Add(ids[k]);
+            }
+            return result;
+        }
+
+        public (List<int> TokenIds, string Text) EncodeTrimSuffix(string text, IReadOnlyCollection<string> allowedSpecial, int maxTokenCount) => cpu.EncodeTrimSuffix(text, allowedSpecial, maxTokenCount);
+        public (List<int> TokenIds, string Text) EncodeTrimSuffix(string text, int maxTokenCount, bool applySpecialTokens = true) => cpu.EncodeTrimSuffix(text, maxTokenCount, applySpecialTokens);
+        public (List<int> TokenIds, string Text) EncodeTrimPrefix(string text, IReadOnlyCollection<string> allowedSpecial, int maxTokenCount) => cpu.EncodeTrimPrefix(text, allowedSpecial, maxTokenCount);
+        public (List<int> TokenIds, string Text) EncodeTrimPrefix(string text, int maxTokenCount, bool applySpecialTokens = true) => cpu.EncodeTrimPrefix(text, maxTokenCount, applySpecialTokens);
+        public string Decode(int[] tokens) => cpu.Decode(tokens);
+
+        public void Dispose() { Tkz.tkz_encoder_destroy(encoder); }
+    }
+}

@@ -1,0 +1,152 @@
+// tkz_tokenizer.hpp -- C++ host mirror of the reference's tokenizer interface for the Encode path, over the
+// C ABI of include/tkz.h.  Header-only; link with libtkz.so.
+//
+//   tkz::TikTokenizer          ITokenizer.Encode x2 + EncodeBatch     Tokenizer_C#/TokenizerLib/ITokenizer.cs:12,28
+//   tkz::TokenizerBuilder      CreateTokenizer(stream, specials, pattern)   TokenizerBuilder.cs:210-213
+//
+// Text is UTF-8 (std::string); EncodeUtf16 takes the code units of a .NET string.  Special-token
+// segmentation (EncodeInternal / FindNextSpecialToken, TikTokenizer.cs:141-170,230-241) runs on the host and
+// every plain segment of a batch goes to the GPU in ONE tkz_encode_batch_utf8 call.  Errors are exceptions
+// named after the reference's: FormatException -> tkz::FormatError, ArgumentException -> tkz::DuplicateRankError,
+// KeyNotFoundException -> tkz::KeyNotFoundError, NotImplementedException -> tkz::NotImplementedError.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "tkz.h"
+
+namespace tkz {
+
+struct Error : std::runtime_error { int status; Error(int s, const std::string& m) : std::runtime_error(m), status(s) {} };
+struct FormatError : Error { using Error::Error; };
+struct DuplicateRankError : Error { using Error::Error; };
+struct KeyNotFoundError : Error { using Error::Error; };
+struct NotImplementedError : Error { using Error::Error; };
+
+inline void check(tkz_status s) {
+    if (s == TKZ_OK) return;
+    const std::string m = tkz_last_error();
+    switch (s) {
+        case TKZ_E_FORMAT: throw FormatError(s, m);
+        case TKZ_E_DUP_RANK: throw DuplicateRankError(s, m);
+        case TKZ_E_KEY_NOT_FOUND: throw KeyNotFoundError(s, m);
+        case TKZ_E_UNSUPPORTED: throw NotImplementedError(s, m);
+        default: throw Error(s, m);
+    }
+}
+
+using SpecialTokens = std::vector<std::pair<std::string, int32_t>>;   // registration order matters (alternation order)
+
+class TikTokenizer {
+public:
+    TikTokenizer(const std::string& tikTokenBpeFile, SpecialTokens specialTokensEncoder, const std::string& pattern, int device = 0)
+        : specials_(std::move(specialTokensEncoder)) {
+        int32_t pat = 0;
+        check(tkz_pattern_from_regex(pattern.c_str(), &pat));
+        tkz_vocab* v = nullptr;
+        check(tkz_vocab_from_tiktoken(reinterpret_cast<const uint8_t*>(tikTokenBpeFile.data()), tikTokenBpeFile.size(), &v));
+        const tkz_status s = tkz_encoder_create(v, pat, device, &enc_);
+        tkz_vocab_destroy(v);
+        check(s);
+    }
+    ~TikTokenizer() { tkz_encoder_destroy(enc_); }
+    TikTokenizer(const TikTokenizer&) = delete;
+    TikTokenizer& operator=(const TikTokenizer&) = delete;
+
+    // Encode(string text, IReadOnlyCollection<string> allowedSpecial)        TikTokenizer.cs:178-185
+    std::vector<int32_t> Encode(const std::string& text, const std::vector<std::string>& allowedSpecial) const {
+        return EncodeBatch({text}, allowedSpecial)[0];
+    }
+    // Encode(string text, bool applySpecialTokens = true)                     TikTokenizer.cs:193-207
+    std::vector<int32_t> Encode(const std::string& text, bool applySpecialTokens = true) const {
+        return EncodeBatch({text}, applySpecialTokens)[0];
+    }
+    std::vector<std::vector<int32_t>> EncodeBatch(const std::vector<std::string>& texts, bool applySpecialTokens = true) const {
+        std::vector<std::string> all;
+        if (applySpecialTokens) for (const auto& s : specials_) all.push_back(s.first);
+        return EncodeBatch(texts, all);
+    }
+    std::vector<std::vector<int32_t>> EncodeBatch(const std::vector<std::string>& texts, const std::vector<std::string>& allowedSpecial) const {
+        struct Item { size_t text; int32_t special; int64_t segment; };
+        std::vector<Item> plan;
+        std::vector<uint8_t> bytes;
+        std::vector<int64_t> offs{0};
+        for (size_t t = 0; t < texts.size(); ++t) {
+            const std::string& text = texts[t];
+            size_t start = 0;
+            for (;;) {
+                size_t hit_pos = std::string::npos; int hit = -1;
+                if (!allowedSpecial.empty()) {
+                    size_t find = start;
+                    for (;;) {                                          // FindNextSpecialToken (TikTokenizer.cs:230-241)
+                        hit = -1;
+                        size_t p = find;
+                        for (; p < text.size(); ++p) { hit = match_at(text, p); if (hit >= 0) break; }
+                        if (hit < 0) break;
+                        bool ok = false;
+                        for (const auto& a : allowedSpecial) if (a == specials_[hit].first) { ok = true; break; }
+                        if (ok) { hit_pos = p; break; }
+                        find = p + 1;                                   // startFind = nextSpecial.Index + 1 (one UTF-16 unit; literals are ASCII)
+                        while (find < text.size() && (static_cast<uint8_t>(text[find]) & 0xC0) == 0x80) ++find;
+                    }
+                }
+                const size_t end = hit >= 0 ? hit_pos : text.size();
+                if (end > start) {
+                    plan.push_back({t, 0, static_cast<int64_t>(offs.size()) - 1});
+                    bytes.insert(bytes.end(), text.begin() + start, text.begin() + end);
+                    offs.push_back(static_cast<int64_t>(bytes.size()));
+                }
+                if (hit < 0) break;
+                plan.push_back({t, specials_[hit].second, -1});         // EncodeSpecialToken (:215-220)
+                start = hit_pos + specials_[hit].first.size();
+                if (start >= text.size()) break;
+            }
+        }
+        const int64_t nseg = static_cast<int64_t>(offs.size()) - 1;
+        std::vector<int32_t> ids(bytes.size() ? bytes.size() : 1);
+        std::vector<int64_t> ooff(static_cast<size_t>(nseg) + 1, 0);
+        int64_t needed = 0;
+        if (bytes.empty()) bytes.push_back(0);
+        check(tkz_encode_batch_utf8(enc_, bytes.data(), offs.data(), nseg, ids.data(), static_cast<int64_t>(ids.size()), ooff.data(), &needed));
+        std::vector<std::vector<int32_t>> out(texts.size());
+        for (const Item& it : plan) {
+            if (it.segment < 0) { out[it.text].push_back(it.special); continue; }
+            out[it.text].insert(out[it.text].end(), ids.begin() + ooff[it.segment], ids.begin() + ooff[it.segment + 1]);
+        }
+        return out;
+    }
+    // the code units of a .NET string; plain path only (Encode(text, false))
+    std::vector<int32_t> EncodeUtf16(const std::u16string& text) const {
+        std::vector<int32_t> ids(text.size() * 3 + 1);
+        int64_t n = 0;
+        check(tkz_encode_utf16(enc_, reinterpret_cast<const uint16_t*>(text.data()), static_cast<int64_t>(text.size()), ids.data(),
+                               static_cast<int64_t>(ids.size()), &n));
+        ids.resize(static_cast<size_t>(n));
+        return ids;
+    }
+    tkz_encoder* native() const { return enc_; }
+
+private:
+    int match_at(const std::string& text, size_t p) const {       // first registered literal that matches at p
+        for (size_t i = 0; i < specials_.size(); ++i) {
+            const std::string& lit = specials_[i].first;
+            if (!lit.empty() && text.compare(p, lit.size(), lit) == 0) return static_cast<int>(i);
+        }
+        return -1;
+    }
+    SpecialTokens specials_;
+    tkz_encoder* enc_ = nullptr;
+};
+
+struct TokenizerBuilder {
+    // TokenizerBuilder.CreateTokenizer(Stream, IReadOnlyDictionary<string,int>, string pattern, int cacheSize)
+    static TikTokenizer* CreateTokenizer(const std::string& tikTokenBpeFile, SpecialTokens specialTokensEncoder, const std::string& pattern,
+                                         int /*cacheSize*/ = 8192, int device = 0) {
+        return new TikTokenizer(tikTokenBpeFile, std::move(specialTokensEncoder), pattern, device);
+    }
+};
+
+}  // namespace tkz

@@ -1,0 +1,46 @@
+// Drives the C++ host mirror (include/tkz_tokenizer.hpp) through the C ABI.  Built by tests/test_cpp_host.py against the
+// emulated library on CPU and against libtkz.so on the GPU box.  argv: gpt2.tiktoken lib.rs.txt tokens_gpt2.json
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+
+#include "tkz_tokenizer.hpp"
+
+static std::string slurp(const char* p) { std::ifstream f(p, std::ios::binary); std::stringstream ss; ss << f.rdbuf(); return ss.str(); }
+#define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "FAILED line %d: %s\n", __LINE__, #c); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 4) return 2;
+    const std::string vocab = slurp(argv[1]), text = slurp(argv[2]), golden_json = slurp(argv[3]);
+    std::vector<int32_t> golden;
+    for (size_t i = 0; i < golden_json.size();) {
+        if (golden_json[i] >= '0' && golden_json[i] <= '9') { size_t j = i; int v = 0; while (j < golden_json.size() && golden_json[j] >= '0' && golden_json[j] <= '9') v = v * 10 + (golden_json[j++] - '0'); golden.push_back(v); i = j; }
+        else ++i;
+    }
+    const std::string p1 = "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
+    tkz::SpecialTokens specials = {{"<|endoftext|>", 50256}, {"<|im_start|>", 50300}, {"<|im_end|>", 50301}};
+    tkz::TikTokenizer tok(vocab, specials, p1);
+    REQUIRE(tok.Encode(text, false) == golden);                                   // TikTokenizerUnitTest.cs:227-245
+    REQUIRE(tok.Encode(text, std::vector<std::string>{"<|im_start|>", "<|im_end|>"}) == golden);
+    REQUIRE(tok.Encode("", true).empty());
+    const auto hw = tok.Encode("Hello World", false);
+    const auto sp = tok.Encode("<|im_start|>Hello World<|im_end|>");
+    REQUIRE(sp.size() == hw.size() + 2 && sp.front() == 50300 && sp.back() == 50301);
+    REQUIRE(std::vector<int32_t>(sp.begin() + 1, sp.end() - 1) == hw);
+    const auto plain = tok.Encode("<|im_start|>Hello World<|im_end|>", false);
+    REQUIRE(plain.size() > sp.size() && plain.front() != 50300);
+    const auto only_end = tok.Encode("<|im_start|>x<|im_end|>", std::vector<std::string>{"<|im_end|>"});
+    REQUIRE(only_end.back() == 50301 && only_end.front() != 50300);
+    const auto batch = tok.EncodeBatch({"", "Hello World", "<|im_end|>", text.substr(0, 2000)});
+    REQUIRE(batch.size() == 4 && batch[0].empty() && batch[1] == hw && batch[2] == std::vector<int32_t>{50301});
+    REQUIRE(batch[3] == tok.Encode(text.substr(0, 2000)));
+    REQUIRE(tok.EncodeUtf16(u"Hello World") == hw);
+    bool threw = false;
+    try { tkz::TikTokenizer bad("YQ== 0\nYg== 0\n", {}, p1); } catch (const tkz::DuplicateRankError&) { threw = true; }
+    REQUIRE(threw);
+    threw = false;
+    try { tkz::TikTokenizer bad(vocab, {}, "\\w+"); } catch (const tkz::NotImplementedError&) { threw = true; }
+    REQUIRE(threw);
+    std::printf("cpp host mirror ok: %zu golden ids\n", golden.size());
+    return 0;
+}

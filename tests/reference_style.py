@@ -1,0 +1,69 @@
+"""The reference's own unit tests (Tokenizer_C#/TokenizerTest/TikTokenizerUnitTest.cs), restated against the
+host mirror tokenizer_amd.TikTokenizer.  The C# suite builds a cl100k tokenizer from a downloaded rank file;
+offline the same scenarios run with the gpt2 rank file (the vocabulary the reference ships), the expected ids
+coming from the golden gpt2 vector and from the oracle.  With $TKZ_VOCAB_DIR/cl100k_base.tiktoken present the
+literal cl100k assertions of the C# file run as written."""
+import os
+
+import numpy as np
+
+from conftest import find_vocab_file, load_golden_json
+from tokenizer_amd import REGEX_CL100K, REGEX_PATTERN_1, TokenizerBuilder
+
+IM_START, IM_END = "<|im_start|>", "<|im_end|>"
+
+
+def run_gpt2_suite(lib, gpt2_bytes, lib_rs_text, oracle_mod, oracle_vocab):
+    specials = {"<|endoftext|>": 50256, IM_START: 50300, IM_END: 50301}
+    tok = TokenizerBuilder.CreateTokenizer(gpt2_bytes, specials, REGEX_PATTERN_1, lib=lib)
+    oenc = oracle_mod.Encoder(oracle_vocab, oracle_mod.P1, specials=specials)
+    golden = load_golden_json("tokens_gpt2.json")
+    # TestEncode0 / TestEncode4-style: plain text, round trip
+    enc = tok.Encode("Hello World")
+    assert enc == oenc.encode("Hello World") and tok.Decode(enc) == "Hello World"
+    assert tok.Encode("") == []                                           # TikTokenizerUnitTest.cs:103-109
+    # TestEncode1 / TestEncode3: specials honoured by default and by an explicit allow-set (:52-64, :89-101)
+    text = IM_START + "Hello World" + IM_END
+    e1 = tok.Encode(text)
+    assert e1[0] == 50300 and e1[-1] == 50301 and e1[1:-1] == enc
+    assert tok.Encode(text, [IM_START, IM_END]) == e1
+    assert tok.Decode(e1) == text
+    # an allow-set that leaves a registered special out: that literal is plain text (FindNextSpecialToken skips it, :233-239)
+    only_end = tok.Encode(text, [IM_END])
+    assert only_end == oenc.encode(text, [IM_END]) and only_end[-1] == 50301 and only_end[0] != 50300
+    # applySpecialTokens = false: everything is plain text (:201-205)
+    assert tok.Encode(text, False) == oenc.encode(text) and 50300 not in tok.Encode(text, False)
+    # TestEncode2: the long document, through both overloads (:66-87)
+    assert tok.Encode(lib_rs_text, [IM_START, IM_END]) == golden
+    assert tok.Encode(lib_rs_text, False) == golden
+    assert tok.Decode(golden) == lib_rs_text
+    # TestEncode5: a multi-byte char between specials (:112-126)
+    t5 = IM_START + "Hello ⭐ World" + IM_END
+    e5 = tok.Encode(t5, [IM_START, IM_END])
+    assert e5 == oenc.encode(t5, [IM_START, IM_END]) and tok.Decode(e5) == t5
+    # overlapping / adjacent / trailing specials and a special as the whole text
+    for t in (IM_START, IM_START + IM_END, "a" + IM_START, IM_END + "b" + IM_END + IM_END, "<|im_start", "<|endoftext|><|endoftext|>x"):
+        assert tok.Encode(t) == oenc.encode(t, list(specials)), t
+    # EncodeBatch == [Encode(t) for t in texts], mixed empty / special / long inputs
+    texts = ["", "Hello World", text, lib_rs_text[:3000], t5, IM_END, " ", "x" * 300]
+    assert tok.EncodeBatch(texts) == [tok.Encode(t) for t in texts]
+    assert tok.EncodeBatch(texts, False) == [oenc.encode(t) for t in texts]
+    assert tok.EncodeBatch([]) == []
+    # lone surrogates: Encoding.UTF8.GetBytes semantics
+    s = "a\ud800b"
+    assert tok.Encode(s, False) == oenc.encode_bytes("a�b".encode("utf-8"))
+
+
+def run_cl100k_suite(lib):
+    p = find_vocab_file("cl100k_base.tiktoken")
+    if not p:
+        return False
+    specials = {"<|endoftext|>": 100257, "<|fim_prefix|>": 100258, "<|fim_middle|>": 100259, "<|fim_suffix|>": 100260,
+                "<|endofprompt|>": 100276, IM_START: 100264, IM_END: 100265}
+    tok = TokenizerBuilder.CreateTokenizer(open(p, "rb").read(), specials, REGEX_CL100K, lib=lib)
+    assert tok.Encode("Hello World") == [9906, 4435]                                              # :39-49
+    assert tok.Encode(IM_START + "Hello World" + IM_END) == [100264, 9906, 4435, 100265]          # :52-64
+    assert tok.Encode(IM_START + "Hello ⭐ World" + IM_END, [IM_START, IM_END]) == [100264, 9906, 2928, 99834, 4435, 100265]   # :112-126
+    lib_rs = open(os.path.join(os.path.dirname(__file__), "golden", "lib.rs.txt"), encoding="utf-8").read()
+    assert tok.Encode(lib_rs, False) == load_golden_json("tokens_cl100k.json")                    # :66-87
+    return True

@@ -89,3 +89,9 @@ def test_corpus_generator_host_device_agree(lib):
             host = N.corpus_doc_host(kind, 0x5EED0000 + kind, 7 + d, lo, hi, lib=lib)
             assert host == buf[offs[d]:offs[d + 1]].tobytes()
             host.decode("utf-8")          # well-formed
+
+
+def test_reference_unit_tests_restated(lib, gpt2_tiktoken_bytes, lib_rs_bytes, oracle_mod, oracle_gpt2):
+    import reference_style
+    reference_style.run_gpt2_suite(lib, gpt2_tiktoken_bytes, lib_rs_bytes.decode("utf-8"), oracle_mod, oracle_gpt2)
+    reference_style.run_cl100k_suite(lib)      # runs only when cl100k_base.tiktoken is supplied

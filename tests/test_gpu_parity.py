@@ -164,3 +164,9 @@ def test_parallel_and_sequential_pretok_agree_at_scale(lib, vocab, kind, pattern
     p = _device_run(lib, vocab, kind, pattern, n, lo, hi, 0x5EED0000 + kind)
     s = _device_run(lib, vocab, kind, pattern, n, lo, hi, 0x5EED0000 + kind, sequential=True)
     assert p["ntok"] == s["ntok"] and torch.equal(p["d_ids"], s["d_ids"]) and torch.equal(p["d_ooffs"], s["d_ooffs"])
+
+
+def test_reference_unit_tests_restated(lib, gpt2_tiktoken_bytes, lib_rs_bytes, oracle_mod, oracle_gpt2):
+    import reference_style
+    reference_style.run_gpt2_suite(lib, gpt2_tiktoken_bytes, lib_rs_bytes.decode("utf-8"), oracle_mod, oracle_gpt2)
+    reference_style.run_cl100k_suite(lib)      # runs only when cl100k_base.tiktoken is supplied

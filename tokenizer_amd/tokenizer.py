@@ -1,0 +1,231 @@
+"""Host-side mirror of the reference's tokenizer interface for the Encode path, over libtkz.
+
+Names, argument meaning and error behaviour follow
+  ITokenizer                     Tokenizer_C#/TokenizerLib/ITokenizer.cs:7-46
+  TikTokenizer                   Tokenizer_C#/TokenizerLib/TikTokenizer.cs:20-605
+  TokenizerBuilder               Tokenizer_C#/TokenizerLib/TokenizerBuilder.cs:14-214
+so that the parity tests read like the reference's own (TikTokenizerUnitTest.cs).  `EncodeBatch` is the
+one addition (the reference has no batch API).  What runs where:
+
+  * special-token segmentation (EncodeInternal / FindNextSpecialToken, TikTokenizer.cs:141-170,230-241)
+    is host work: every text is cut into plain segments + literal special ids, and ALL plain segments of
+    the batch go to the GPU as one document batch (a segment is matched in isolation by the reference
+    too: `Regex.Matches(text[start..end])`, TikTokenizer.cs:252);
+  * the plain path (TikTokenizer.cs:250-274 + BytePairEncoder.cs:13-76) is the HIP path of libtkz;
+  * Decode is a host-side table lookup (TikTokenizer.cs:586-604), kept for round-trip checks;
+  * EncodeTrimSuffix / EncodeTrimPrefix are not part of the accelerated path.
+"""
+import os
+import re
+from typing import Dict, Iterable, List, Optional, Sequence, Union
+
+import numpy as np
+
+from . import _native as N
+
+ENDOFTEXT = "<|endoftext|>"
+FIM_PREFIX = "<|fim_prefix|>"
+FIM_MIDDLE = "<|fim_middle|>"
+FIM_SUFFIX = "<|fim_suffix|>"
+ENDOFPROMPT = "<|endofprompt|>"
+
+# the split regexes, verbatim (TokenizerBuilder.cs:112,128; tokenizer_ts/src/tokenizerBuilder.ts:79-89)
+REGEX_PATTERN_1 = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
+REGEX_CL100K = (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*"
+                r"|\s*[\r\n]+|\s+(?!\S)|\s+")
+_O2_SUFFIX = r"(?:'s|'S|'t|'T|'re|'RE|'Re|'eR|'ve|'VE|'vE|'Ve|'m|'M|'ll|'lL|'Ll|'LL|'d|'D)?"
+REGEX_O200K = "|".join([
+    "[^\r\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]*[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]+" + _O2_SUFFIX,
+    "[^\r\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]+[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]*" + _O2_SUFFIX,
+    r"\p{N}{1,3}", r" ?[^\s\p{L}\p{N}]+[\r\n/]*", r"\s*[\r\n]+", r"\s+(?!\S)", r"\s+"])
+
+# TokenizerBuilder.cs:17-66 (and the o200k models of tokenizer_ts/src/tokenizerBuilder.ts)
+MODEL_PREFIX_TO_ENCODING = {"gpt-4-": "cl100k_base", "gpt-3.5-turbo-": "cl100k_base", "gpt-4o-": "o200k_base"}
+MODEL_TO_ENCODING = {
+    "gpt-4o": "o200k_base",
+    "gpt-4": "cl100k_base", "gpt-3.5-turbo": "cl100k_base",
+    "text-davinci-003": "p50k_base", "text-davinci-002": "p50k_base", "text-davinci-001": "r50k_base",
+    "text-curie-001": "r50k_base", "text-babbage-001": "r50k_base", "text-ada-001": "r50k_base",
+    "davinci": "r50k_base", "curie": "r50k_base", "babbage": "r50k_base", "ada": "r50k_base",
+    "code-davinci-002": "p50k_base", "code-davinci-001": "p50k_base", "code-cushman-002": "p50k_base",
+    "code-cushman-001": "p50k_base", "davinci-codex": "p50k_base", "cushman-codex": "p50k_base",
+    "text-davinci-edit-001": "p50k_edit", "code-davinci-edit-001": "p50k_edit",
+    "text-embedding-ada-002": "cl100k_base",
+    "text-similarity-davinci-001": "r50k_base", "text-similarity-curie-001": "r50k_base",
+    "text-similarity-babbage-001": "r50k_base", "text-similarity-ada-001": "r50k_base",
+    "text-search-davinci-doc-001": "r50k_base", "text-search-curie-doc-001": "r50k_base",
+    "text-search-babbage-doc-001": "r50k_base", "text-search-ada-doc-001": "r50k_base",
+    "code-search-babbage-code-001": "r50k_base", "code-search-ada-code-001": "r50k_base",
+    "gpt2": "gpt2",
+}
+# encoder -> (regex, rank file name, special tokens)          TokenizerBuilder.cs:109-181
+ENCODERS = {
+    "cl100k_base": (REGEX_CL100K, "cl100k_base.tiktoken",
+                    {ENDOFTEXT: 100257, FIM_PREFIX: 100258, FIM_MIDDLE: 100259, FIM_SUFFIX: 100260, ENDOFPROMPT: 100276}),
+    "p50k_base": (REGEX_PATTERN_1, "p50k_base.tiktoken", {ENDOFTEXT: 50256}),
+    "p50k_edit": (REGEX_PATTERN_1, "p50k_base.tiktoken", {ENDOFTEXT: 50256, FIM_PREFIX: 50281, FIM_MIDDLE: 50282, FIM_SUFFIX: 50283}),
+    "r50k_base": (REGEX_PATTERN_1, "r50k_base.tiktoken", {ENDOFTEXT: 50256}),
+    "gpt2": (REGEX_PATTERN_1, "gpt2.tiktoken", {ENDOFTEXT: 50256}),
+    "o200k_base": (REGEX_O200K, "o200k_base.tiktoken", {ENDOFTEXT: 199999, ENDOFPROMPT: 200018}),
+}
+
+
+def _utf8_like_dotnet(s: str) -> bytes:
+    """Encoding.UTF8.GetBytes: a lone surrogate becomes U+FFFD (TikTokenizer.cs:261)."""
+    try:
+        return s.encode("utf-8")
+    except UnicodeEncodeError:
+        return s.encode("utf-16-le", "surrogatepass").decode("utf-16-le", "replace").encode("utf-8")
+
+
+class TikTokenizer:
+    """ITokenizer over the MI355X encode path.  Construct through TokenizerBuilder, or directly with the
+    bytes of a .tiktoken rank file (the reference takes a Stream, TikTokenizer.cs:60-65)."""
+
+    def __init__(self, tikTokenBpeFile: bytes, specialTokensEncoder: Optional[Dict[str, int]], pattern: str,
+                 cacheSize: int = 8192, device: int = 0, lib: Optional[N.Library] = None):
+        del cacheSize  # the reference's LRU piece memo (LRUCache.cs) has no effect on results; the GPU path has no use for it
+        self._lib = lib or N.default_library()
+        pat = self._lib.L.tkz_pattern_from_regex  # maps the reference's regex text to a scanner, refuses anything else
+        import ctypes as C
+        out = C.c_int32(0)
+        self._lib.check(pat(pattern.encode("utf-8"), C.byref(out)))
+        self._vocab = N.Vocab(tikTokenBpeFile, self._lib)     # FormatError / DuplicateRankError as in LoadTikTokenBpe + Init
+        self._encoder = N.Encoder(self._vocab, out.value, device)
+        self.SpecialTokensEncoder: Dict[str, int] = dict(specialTokensEncoder or {})
+        self.SpecialTokens = set(self.SpecialTokensEncoder)
+        # alternation of the escaped literals in registration order (TikTokenizer.cs:78): leftmost match, first alternative wins
+        self._special_re = re.compile("|".join(re.escape(k) for k in self.SpecialTokensEncoder)) if self.SpecialTokensEncoder else None
+        self._decoder: Optional[Dict[int, bytes]] = None
+        self._tiktoken_bytes = tikTokenBpeFile
+
+    # ---- segmentation (host) ---------------------------------------------------------------------
+    def _segments(self, text: str, allowed: Optional[Iterable[str]]):
+        """EncodeInternal + FindNextSpecialToken: list of ('t', plain_text) / ('s', id)."""
+        allowed = set(allowed) if allowed else set()
+        if not allowed or self._special_re is None:
+            return [("t", text)] if text else []
+        out = []
+        start = 0
+        while True:
+            find = start
+            m = None
+            while True:                                       # FindNextSpecialToken (TikTokenizer.cs:230-241)
+                m = self._special_re.search(text, find)
+                if m is None or m.group(0) in allowed:
+                    break
+                find = m.start() + 1
+            end = m.start() if m else len(text)
+            if end > start:
+                out.append(("t", text[start:end]))
+            if m is None:
+                break
+            out.append(("s", self.SpecialTokensEncoder[m.group(0)]))   # EncodeSpecialToken (:215-220)
+            start = m.end()
+            if start >= len(text):
+                break
+        return out
+
+    def _resolve_allowed(self, allowedSpecialOrApply):
+        if isinstance(allowedSpecialOrApply, bool):           # Encode(string, bool applySpecialTokens = true)  (:193-207)
+            return self.SpecialTokens if (allowedSpecialOrApply and self.SpecialTokens) else None
+        return allowedSpecialOrApply                          # Encode(string, IReadOnlyCollection<string>)     (:178-185)
+
+    # ---- ITokenizer --------------------------------------------------------------------------------
+    def Encode(self, text: str, allowedSpecialOrApply: Union[bool, Sequence[str], None] = True) -> List[int]:
+        return self.EncodeBatch([text], allowedSpecialOrApply)[0]
+
+    def EncodeBatch(self, texts: Sequence[str], allowedSpecialOrApply: Union[bool, Sequence[str], None] = True) -> List[List[int]]:
+        allowed = self._resolve_allowed(allowedSpecialOrApply)
+        plans = [self._segments(t, allowed) for t in texts]
+        segs = [_utf8_like_dotnet(s) for plan in plans for kind, s in plan if kind == "t"]
+        if segs:
+            data = np.frombuffer(b"".join(segs), np.uint8) if sum(map(len, segs)) else np.zeros(0, np.uint8)
+            offs = np.cumsum([0] + [len(s) for s in segs]).astype(np.int64)
+            ids, ooff = self._encoder.encode_batch(data, offs)
+        else:
+            ids, ooff = np.zeros(0, np.int32), np.zeros(1, np.int64)
+        out, k = [], 0
+        for plan in plans:
+            cur: List[int] = []
+            for kind, v in plan:
+                if kind == "s":
+                    cur.append(v)
+                else:
+                    cur.extend(ids[ooff[k]:ooff[k + 1]].tolist())
+                    k += 1
+            out.append(cur)
+        return out
+
+    def EncodeTrimSuffix(self, *a, **k):
+        raise NotImplementedError("EncodeTrimSuffix is outside the accelerated Encode path (SURVEY.md 8f-3)")
+
+    def EncodeTrimPrefix(self, *a, **k):
+        raise NotImplementedError("EncodeTrimPrefix is outside the accelerated Encode path (SURVEY.md 8f-3)")
+
+    def Decode(self, tokens: Sequence[int]) -> str:
+        """TikTokenizer.cs:586-604: unknown ids are dropped; bytes are decoded as UTF-8."""
+        if self._decoder is None:
+            import base64
+            dec = {}
+            for line in self._tiktoken_bytes.splitlines():
+                if line.strip():
+                    k, r = line.split()
+                    dec[int(r)] = base64.b64decode(k)
+            self._decoder = dec
+            self._special_decoder = {v: k.encode("utf-8") for k, v in self.SpecialTokensEncoder.items()}
+        parts = []
+        for t in tokens:
+            b = self._decoder.get(t)
+            if b is None:
+                b = self._special_decoder.get(t)
+            if b is not None:
+                parts.append(b)
+        return b"".join(parts).decode("utf-8", "replace")
+
+    # the raw device encoder, for callers that hold documents in HBM (bench.py)
+    @property
+    def native(self) -> N.Encoder:
+        return self._encoder
+
+
+class TokenizerBuilder:
+    """TokenizerBuilder.cs:14-214 without the HTTP download: rank files are read from a directory
+    (`vocab_dir`, default $TKZ_VOCAB_DIR), because the build has no network."""
+
+    @staticmethod
+    def _encoder_for_model(modelName: str) -> str:
+        enc = MODEL_TO_ENCODING.get(modelName)
+        if enc is None:
+            for prefix, e in MODEL_PREFIX_TO_ENCODING.items():
+                if modelName.startswith(prefix):
+                    enc = e
+                    break
+        if enc is None:
+            raise NotImplementedError("Doesn't support this model [%s]" % modelName)       # TokenizerBuilder.cs:96
+        return enc
+
+    @staticmethod
+    def CreateByModelName(modelName: str, extraSpecialTokens: Optional[Dict[str, int]] = None, vocab_dir: Optional[str] = None, device: int = 0):
+        return TokenizerBuilder.CreateByEncoderName(TokenizerBuilder._encoder_for_model(modelName), extraSpecialTokens, vocab_dir, device)
+
+    @staticmethod
+    def CreateByEncoderName(encoderName: str, extraSpecialTokens: Optional[Dict[str, int]] = None, vocab_dir: Optional[str] = None, device: int = 0):
+        if encoderName not in ENCODERS:
+            raise NotImplementedError("Doesn't support this encoder [%s]" % encoderName)  # TokenizerBuilder.cs:179
+        regex, fname, specials = ENCODERS[encoderName]
+        specials = dict(specials)
+        if extraSpecialTokens:
+            specials.update(extraSpecialTokens)
+        d = vocab_dir or os.environ.get("TKZ_VOCAB_DIR") or "."
+        path = os.path.join(d, fname)
+        if not os.path.exists(path):
+            raise FileNotFoundError("%s not found: the reference downloads it at run time (TokenizerBuilder.cs:113,195); "
+                                    "place it in vocab_dir / $TKZ_VOCAB_DIR" % path)
+        with open(path, "rb") as f:
+            return TokenizerBuilder.CreateTokenizer(f.read(), specials, regex, device=device)
+
+    @staticmethod
+    def CreateTokenizer(tikTokenBpeFile: bytes, specialTokensEncoder: Optional[Dict[str, int]], pattern: str, cacheSize: int = 8192,
+                        device: int = 0, lib: Optional[N.Library] = None) -> TikTokenizer:
+        return TikTokenizer(tikTokenBpeFile, specialTokensEncoder, pattern, cacheSize, device, lib)
