@@ -17,7 +17,7 @@ constexpr int kPassBatches = 6;     // batches of 64 pieces whose lookups are in
 constexpr int kPassPieces = 64 * kPassBatches;
 constexpr int kMergeLanes = 32;     // misses merged per pass (one per lane); sets the LDS scratch of k_encode_waves
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
-constexpr int kRowsPerWave = 64;    // k_pretok_rows: 64-byte rows handled in sequence by one wavefront
+constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan
 
 enum { K_DOCMARK = 0, K_PRETOK = 1, K_ENCODE = 2, K_SCAN = 3, K_GATHER = 4, K_DOCOFFS = 5, K_COUNT = 6 };

@@ -64,53 +64,12 @@ TKZ_DEV RowInfo tkz_load_row(const TkzSrc& S, int64_t row, const uint8_t* bmp, c
     return r;
 }
 
-constexpr int kStageRows = kRowsPerWave + 3;               // rows r0-2 .. r0+kRowsPerWave of a wavefront's chunk
-
+// The sequential row loop over rows [r0, r1): rows one after the other, scan state carried in scalars.
 template <int PATTERN>
-TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits,
-                                  int64_t nrows, const uint8_t* bmp, int32_t* counters) {
-    // One wavefront per workgroup: the chunk index is then blockIdx.x, which the compiler knows to be
-    // wave-uniform -- that keeps every row mask in scalar registers and the mask algebra on the scalar unit.
-    TKZ_SHARED uint16_t s_aflags[128];
-    TKZ_SHARED uint4 s_stage[kStageRows * 4];                  // the wavefront's rows, staged once
-    TKZ_SHARED uint64_t s_ds[kStageRows];                      // ... and their document-start words
-    for (int i = simt::tid(); i < 128; i += simt::nthreads()) s_aflags[i] = (uint16_t)tkz_ascii_flags((uint32_t)i, PATTERN == TKZ_PAT_CL100K);
-    const int64_t r0 = simt::bid() * kRowsPerWave;
+TKZ_DEV void tkz_rows_sequential(const TkzSrc& S, const uint64_t* docbits, uint64_t* startbits, int64_t nrows, const uint8_t* bmp,
+                                 const uint16_t* aflags, int64_t r0, int64_t r1, int32_t* counters) {
     const int lane = simt::lane();
-    // ---- stage rows [r0-2, r0+kRowsPerWave+1) of the corpus: 16 B per lane per load, all loads in flight together ----
-    const int64_t srow0 = r0 - 2;
-    TkzSrc S;
-    S.bytes = bytes; S.total = total; S.stage = reinterpret_cast<const uint8_t*>(s_stage);
-    S.lo = srow0 > 0 ? srow0 << 6 : 0;
-    S.hi = ((srow0 + kStageRows) << 6) < total ? ((srow0 + kStageRows) << 6) : total;
-    if (r0 < nrows) {
-        for (int i = lane; i < kStageRows * 4; i += 64) {
-            const int64_t pos = (srow0 << 6) + 16 * (int64_t)i;   // LDS offset of byte `pos` is pos - (srow0 << 6); S.lo clips the window
-            uint4 v; v.x = v.y = v.z = v.w = 0;
-            if (pos >= 0 && pos + 16 <= total) v = tkz_load16(bytes + pos);
-            else if (pos >= 0 && pos < total) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (int j = 0; j < 16; ++j) if (pos + j < total) w[j >> 2] |= (uint32_t)bytes[pos + j] << (8 * (j & 3));
-                v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-            }
-            s_stage[i] = v;
-        }
-        for (int i = lane; i < kStageRows; i += 64) {
-            const int64_t r = srow0 + i;
-            s_ds[i] = (r >= 0 && r < nrows) ? docbits[r] : 0;
-        }
-    }
-    simt::sync();
-    if (r0 >= nrows) return;                               // whole wave leaves together
-    if (srow0 < 0) S.stage += (-srow0) << 6;               // byte S.lo == 0 sits (-srow0) rows into the buffer
-    const uint64_t* dsw = s_ds;
-    auto ds_at = [&](int64_t r) -> uint64_t {
-        const int64_t i = r - srow0;
-        if (i >= 0 && i < kStageRows) return simt::uniform64(dsw[i]);
-        return (r >= 0 && r < nrows) ? docbits[r] : 0;
-    };
-    const int64_t r1 = r0 + kRowsPerWave < nrows ? r0 + kRowsPerWave : nrows;
-
+    auto ds_at = [&](int64_t r) -> uint64_t { return (r >= 0 && r < nrows) ? docbits[r] : 0; };
     // warm-up start: the nearest row boundary at or before r0 across which no scan state flows
     // (the byte before it is neither a digit nor CR/LF, or a document starts exactly there)
     int64_t rw = r0;
@@ -124,15 +83,14 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
     }
     TkzScanCarry cy;
     cy.nb63 = 0; cy.carryN = 0; cy.abs63 = 0; cy.sa_from = -1; cy.sa_end = -1; cy.sa_lastcr = -1;
-
     int64_t row = rw > 0 ? rw - 1 : 0;                     // one extra row so the flags carried from "previous" are real
-    RowInfo P = tkz_load_row<PATTERN>(S, row - 1, bmp, s_aflags);
-    RowInfo C = tkz_load_row<PATTERN>(S, row, bmp, s_aflags);
+    RowInfo P = tkz_load_row<PATTERN>(S, row - 1, bmp, aflags);
+    RowInfo C = tkz_load_row<PATTERN>(S, row, bmp, aflags);
     uint64_t dsP = ds_at(row - 1), dsC = ds_at(row);
     int clenP = 0, o1msP = 0, bad = 0;
     uint64_t c2P = 0, c3P = 0, o1P = 0;
     for (; row < r1; ++row) {
-        const RowInfo N = tkz_load_row<PATTERN>(S, row + 1, bmp, s_aflags);
+        const RowInfo N = tkz_load_row<PATTERN>(S, row + 1, bmp, aflags);
         const uint64_t dsN = ds_at(row + 1);
         int clenC, o1msC;
         uint64_t c2C, c3C, o1C, out;
@@ -151,6 +109,45 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
         P = C; C = N; dsP = dsC; dsC = dsN; clenP = clenC; o1msP = o1msC; c2P = c2C; c3P = c3C; o1P = o1C;
     }
     if (simt::ballot(bad != 0) && lane == 0) simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrUtf8);
+}
+
+template <int PATTERN>
+TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits,
+                                  int64_t nrows, const uint8_t* bmp, int32_t* counters) {
+    // One wavefront per workgroup (the chunk index is then blockIdx.x, which the compiler knows to be wave-uniform).
+    // The wavefront owns output rows [r0, r0 + kRowsPerWave); it stages rows r0-1 .. r0+62 (one per lane) in LDS and
+    // evaluates them all at once (tkz_block_eval); blocks that scheme refuses go through the sequential row loop.
+    TKZ_SHARED uint16_t s_aflags[128];
+    TKZ_SHARED uint4 s_blk[(65 * kBlockRowStride) / 16];
+    for (int i = simt::tid(); i < 128; i += simt::nthreads()) s_aflags[i] = (uint16_t)tkz_ascii_flags((uint32_t)i, PATTERN == TKZ_PAT_CL100K);
+    const int lane = simt::lane();
+    const int64_t r0 = simt::bid() * kRowsPerWave;
+    const int64_t first = r0 - 1;                          // row of lane 0
+    const bool inside = ((first + 64) << 6) <= total;       // every staged row is a full row of the corpus
+    if (inside) {
+        for (int c = lane; c < 256; c += 64) {             // 16-byte chunk c of the 4 KiB block: row c/4, part c%4
+            const int64_t pos = (first << 6) + 16 * (int64_t)c;
+            uint4 v; v.x = v.y = v.z = v.w = 0;
+            if (pos >= 0) v = tkz_load16(bytes + pos);
+            s_blk[((c >> 2) * kBlockRowStride + (c & 3) * 16) / 16] = v;
+        }
+        if (lane < kBlockRowStride / 16) { uint4 z; z.x = z.y = z.z = z.w = 0; s_blk[(64 * kBlockRowStride) / 16 + lane] = z; }
+    }
+    simt::sync();
+    if (r0 >= nrows) return;
+    if (inside) {
+        const int64_t row = first + lane;
+        const uint64_t ds = (row >= 0 && row < nrows) ? docbits[row] : 0;
+        uint64_t out;
+        if (tkz_block_eval<PATTERN>(reinterpret_cast<const uint8_t*>(s_blk), ds, &out)) {
+            if (lane >= 1 && lane <= kRowsPerWave && row < nrows) startbits[row] = out;
+            return;
+        }
+    }
+    TkzSrc S;
+    S.bytes = bytes; S.total = total; S.stage = nullptr; S.lo = 0; S.hi = 0;
+    const int64_t r1 = r0 + kRowsPerWave < nrows ? r0 + kRowsPerWave : nrows;
+    tkz_rows_sequential<PATTERN>(S, docbits, startbits, nrows, bmp, s_aflags, r0, r1, counters);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -552,4 +552,166 @@ TKZ_DEV uint64_t tkz_row_eval_ascii(const TkzRowMasks& mP, const TkzRowMasks& mC
 #undef TKZ_NEXT
     return start | contrEnd | dsC;
 }
+
+// =================================================================================================
+// (2b) one ROW PER LANE: 64 consecutive ASCII rows evaluated at once.
+//
+// Lane j owns row (first_row + j): its 64 bytes are classified with SWAR arithmetic on 16 dwords (no
+// ballots, no per-byte work), giving the same 64-bit class masks as tkz_row_masks_ascii -- but in that
+// lane's VGPRs -- and the rules of tkz_row_eval_ascii are then ordinary per-lane 64-bit arithmetic, 64 rows
+// per instruction instead of one row per scalar instruction.  Every cross-row dependency is brought
+// down to the nearest neighbour (two lane-shift exchanges) by refusing blocks in which a digit run or a
+// white-space run covers a whole 64-byte row; those blocks, blocks with a non-ASCII byte and blocks that
+// are not entirely inside the corpus are left to the sequential row loop.  Lanes 0 and 63 are context:
+// only lanes 1..62 produce output rows.
+// =================================================================================================
+constexpr int kBlockRowStride = 80;       // bytes between rows in LDS: keeps 16-byte alignment, spreads the 4 x b128 row reads over all banks
+
+// bit 7 of every byte of x that lies in [lo, hi]; all bytes of x are < 0x80
+TKZ_HD uint32_t tkz_swar_range(uint32_t x, uint32_t lo, uint32_t hi) {
+    return (x + (0x80u - lo) * 0x01010101u) & ~(x + (0x7Fu - hi) * 0x01010101u) & 0x80808080u;
+}
+TKZ_HD uint32_t tkz_swar_eq(uint32_t x, uint32_t c) {
+    const uint32_t z = x ^ (c * 0x01010101u);
+    return ~(z + 0x7F7F7F7Fu) & 0x80808080u;
+}
+// the four bit-7 flags of r as a nibble (byte 0 -> bit 0)
+TKZ_HD uint32_t tkz_swar_nibble(uint32_t r) { return (((r >> 7) & 0x01010101u) * 0x01020408u) >> 24; }
+
+struct TkzBlockMasks { uint64_t L, N, O, W, CR, SP, AP; uint32_t hi; };
+
+// classify the 64 bytes of this lane's row (16 dwords at `row`, 16-byte aligned)
+TKZ_HD TkzBlockMasks tkz_block_classify(const uint4* row) {
+    uint32_t mL[2] = {0, 0}, mN[2] = {0, 0}, mW[2] = {0, 0}, mC[2] = {0, 0}, mS[2] = {0, 0}, mA[2] = {0, 0};
+    uint32_t hi = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint4 v = row[q];
+        const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int k = 4 * q + t;                       // dword index: bytes 4k .. 4k+3
+            const uint32_t x = xs[t];
+            hi |= x;
+            const uint32_t y = x | 0x20202020u;
+            const int h = k >> 3, sh = 4 * (k & 7);
+            mL[h] |= tkz_swar_nibble(tkz_swar_range(y, 'a', 'z')) << sh;
+            mN[h] |= tkz_swar_nibble(tkz_swar_range(x, '0', '9')) << sh;
+            mW[h] |= tkz_swar_nibble(tkz_swar_range(x, 9, 13) | tkz_swar_eq(x, ' ')) << sh;
+            mC[h] |= tkz_swar_nibble(tkz_swar_eq(x, '\n') | tkz_swar_eq(x, '\r')) << sh;
+            mS[h] |= tkz_swar_nibble(tkz_swar_eq(x, ' ')) << sh;
+            mA[h] |= tkz_swar_nibble(tkz_swar_eq(x, '\'')) << sh;
+        }
+    }
+    TkzBlockMasks m;
+    m.L = ((uint64_t)mL[1] << 32) | mL[0]; m.N = ((uint64_t)mN[1] << 32) | mN[0]; m.W = ((uint64_t)mW[1] << 32) | mW[0];
+    m.CR = ((uint64_t)mC[1] << 32) | mC[0]; m.SP = ((uint64_t)mS[1] << 32) | mS[0]; m.AP = ((uint64_t)mA[1] << 32) | mA[0];
+    m.O = ~(m.L | m.N | m.W);
+    m.hi = hi & 0x80808080u;
+    return m;
+}
+
+// Evaluates rows first_row .. first_row+63 (lane = row - first_row) staged at `stage` (kBlockRowStride bytes per
+// row, one extra row of zeros after the last).  Returns false -- and leaves `out` unset -- when the block has to be
+// done by the sequential row loop; otherwise *out is this lane's piece-start word (valid for lanes 1..62).
+template <int PATTERN>
+TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, uint64_t* out) {
+    const int lane = simt::lane();
+    const TkzBlockMasks m = tkz_block_classify(reinterpret_cast<const uint4*>(stage + lane * kBlockRowStride));
+    const uint64_t L = m.L, N = m.N, O = m.O, W = m.W, CR = m.CR, SP = m.SP, AP = m.AP;
+    const uint64_t nds = ~ds;
+    // ---- exchange 1: the class of the byte before my row (bit 63 of the previous lane's masks), the first bytes of the next row
+    const uint32_t up_bits = (uint32_t)(L >> 63) | ((uint32_t)(N >> 63) << 1) | ((uint32_t)(O >> 63) << 2) | ((uint32_t)(SP >> 63) << 3) |
+                             ((uint32_t)(W >> 63) << 4) | ((uint32_t)(CR >> 63) << 5);
+    // head: a CR/LF inside the leading connected white-space run of my row (what the row above needs for `\s*[\r\n]+`)
+    const uint64_t conn = W & nds;
+    const int lead_ws = (~conn) ? tkz_ctz64(~conn) : 64;
+    const uint32_t head = (CR & tkz_lowmask(lead_ws)) ? 1u : 0u;
+    const uint32_t dn_bits = (uint32_t)(L & 1) | ((uint32_t)(N & 1) << 1) | ((uint32_t)(O & 1) << 2) | ((uint32_t)(ds & 3) << 3) | (head << 5);
+    uint32_t pb = simt::shflu(up_bits, (lane + 63) & 63), nb = simt::shflu(dn_bits, (lane + 1) & 63);
+    if (lane == 0) pb = 0;
+    if (lane == 63) nb = 0;
+    // blocks the nearest-neighbour scheme cannot do: non-ASCII bytes, a digit run or a \s run covering a whole row
+    const uint64_t pN = ((N << 1) | ((pb >> 1) & 1)) & nds;
+    const uint64_t Q = N & pN;
+    // (lane 0 cannot see the row before it: an all-digit first row may be the continuation of a longer run)
+    if (simt::ballot(m.hi != 0 || Q == ~0ull || conn == ~0ull || (lane == 0 && N == ~0ull))) return false;
+    const uint64_t pL = ((L << 1) | (pb & 1)) & nds, pO = ((O << 1) | ((pb >> 2) & 1)) & nds, pSP = ((SP << 1) | ((pb >> 3) & 1)) & nds;
+    const uint64_t pW = ((W << 1) | ((pb >> 4) & 1)) & nds, pCR = ((CR << 1) | ((pb >> 5) & 1)) & nds;
+    const uint64_t dsn = (uint64_t)((nb >> 3) & 3);                   // document-start bits 0,1 of the next row
+    const uint64_t KN = (ds >> 1) | (dsn << 63), KN2 = (ds >> 2) | (dsn << 62);
+    const uint64_t nO = ((O >> 1) | ((uint64_t)((nb >> 2) & 1) << 63)) & ~KN;
+    const uint64_t nReal = (((L | N | O) >> 1) | ((uint64_t)((nb & 7) ? 1 : 0) << 63)) & ~KN;
+    // ---- contractions: per apostrophe that is a match start, look at the next two bytes (may sit in the next row)
+    uint64_t c2 = 0, c3 = 0;
+    {
+        uint64_t ap = AP & ~pO & ~pSP & ~KN;
+        while (simt::ballot(ap != 0)) {
+            if (ap) {
+                const int pos = tkz_ctz64(ap);
+                ap &= ap - 1;
+                const int p1 = pos + 1, p2 = pos + 2;
+                const uint32_t b1 = stage[(lane + (p1 >> 6)) * kBlockRowStride + (p1 & 63)];
+                const uint32_t b2 = stage[(lane + (p2 >> 6)) * kBlockRowStride + (p2 & 63)];
+                const int k = tkz_contraction_len(b1, b2, PATTERN == TKZ_PAT_CL100K);
+                if (k == 2) c2 |= 1ull << pos;
+                else if (k == 3 && !((KN2 >> pos) & 1ull)) c3 |= 1ull << pos;
+            }
+        }
+    }
+    const uint64_t o1 = (PATTERN == TKZ_PAT_P1) ? 0ull : (O & ~pO & ~pSP & ~nO);
+    // local carries out of my row (exact because no run covers a whole row)
+    uint32_t carryN_out = 0, abs_out = 0;
+    uint64_t ABS0 = 0, R = 0, seeds = 0;
+    if (PATTERN != TKZ_PAT_P1) {
+        if (N >> 63) carryN_out = (uint32_t)((64 - tkz_msb64(~Q)) % 3);   // Q != ~0 here
+        R = CR & nds; seeds = CR & pO;
+        ABS0 = tkz_fill_up64(seeds & R, R);
+        abs_out = (uint32_t)(ABS0 >> 63);
+    }
+    // ---- exchange 2: contraction ends, o1, absorbed state and digit phase flowing in from the previous row
+    const uint32_t up2 = (uint32_t)(c2 >> 62) | ((uint32_t)(c3 >> 61) << 2) | ((uint32_t)(o1 >> 63) << 5) | (abs_out << 6) | (carryN_out << 7) |
+                         ((uint32_t)((c2 | c3) >> 63) << 9);
+    uint32_t p2b = simt::shflu(up2, (lane + 63) & 63);
+    if (lane == 0) p2b = 0;
+    const uint64_t contrEnd = (c2 << 2) | (c3 << 3) | (uint64_t)(p2b & 3) | (uint64_t)((p2b >> 2) & 7);
+    uint64_t start;
+    if (PATTERN == TKZ_PAT_P1) {
+        const uint64_t clenPrev = ((c2 | c3) << 1) | (uint64_t)((p2b >> 9) & 1);
+        start = (L & ~pL & ~pSP & ~clenPrev) | (N & ~pN & ~pSP) | (O & ~pO & ~pSP) | (W & (~pW | nReal));
+    } else {
+        const uint64_t o1Prev = (o1 << 1) | (uint64_t)((p2b >> 5) & 1);
+        const uint64_t pWSo = pW & ~pCR & ~pSP;
+        const uint64_t sL = L & ~pL & ~pSP & ~pWSo & ~o1Prev;
+        const uint64_t sO = O & ~pO & ~pSP;
+        // \p{N}{1,3}
+        uint64_t S = N & ~pN;
+        if (Q & 1ull) {
+            const int d = (3 - (int)((p2b >> 7) & 3)) % 3, lead = tkz_ctz64(~Q);
+            if (d < lead) S |= 1ull << d;
+        }
+        const uint64_t Q3 = Q & (Q << 1) & (Q << 2);
+        uint64_t T = S | ((S << 3) & Q3);
+        const uint64_t Q6 = Q3 & (Q3 << 3);
+        T |= (T << 6) & Q6;
+        const uint64_t Q12 = Q6 & (Q6 << 6);
+        T |= (T << 12) & Q12;
+        const uint64_t Q24 = Q12 & (Q12 << 12);
+        T |= (T << 24) & Q24;
+        T |= (T << 48) & (Q24 & (Q24 << 24));
+        const uint64_t sN = T;
+        // white space
+        const uint32_t abs_in = (p2b >> 6) & 1;
+        const uint64_t ABS = abs_in ? tkz_fill_up64((seeds | (R & 1ull)) & R, R) : ABS0;
+        // T(i) = CR(i) | (CONN(i+1) & T(i+1)),  T(64) = head of the next row (which includes CONN(64))
+        const uint64_t Scr = CR | ((uint64_t)((nb >> 5) & 1) << 63);
+        const uint64_t Srev = tkz_brev64(Scr), Grev = tkz_brev64(conn) << 1;   // reversed positions k = 63 - i: G'(k) = CONN(64 - k)
+        const uint64_t Tcur = tkz_brev64(Srev | tkz_fill_up64((Srev << 1) & Grev, Grev));
+        const uint64_t pABS = (ABS << 1) | (uint64_t)abs_in;
+        const uint64_t sW = W & ~ABS & ((~pW | pABS) | (pCR & ~Tcur) | (~CR & nReal));
+        start = sL | sN | sO | sW;
+    }
+    *out = start | contrEnd | ds;
+    return true;
+}
 #endif  // TKZ_NO_SIMT
