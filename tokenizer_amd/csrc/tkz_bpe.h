@@ -38,7 +38,7 @@ TKZ_HD uint32_t tkz_min3u(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m
 // ids/pr: this lane's 16-entry arrays (16-byte aligned).  brank: the 256-entry single-byte id table
 // (in LDS on the device).  Returns the number of tokens; *alive_out has one bit per surviving part
 // (token k is ids[k]).  Written for memory-level parallelism: all first-level gathers are issued
-// together, and each merge costs ONE round trip to the pair table (both re-ranked pairs probed at once).
+// together, and each merge costs ONE round trip to the pair table (both re-ranked pairs, both cuckoo slots of each, in flight together).
 TKZ_HD int tkz_bpe_short(const TkzTables& T, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int n,
                          uint32_t* ids, uint32_t* pr, const int32_t* brank, uint32_t* alive_out, int* err) {
     uint32_t bk[16];
@@ -84,13 +84,15 @@ TKZ_HD int tkz_bpe_short(const TkzTables& T, uint32_t w0, uint32_t w1, uint32_t 
         const int l = lo ? tkz_msb32(lo) : 0;
         const int rr = hi ? tkz_ctz32(hi) : 0;
         const uint32_t idr = ids[rr], idl = ids[l];     // (unconditional: see above)
-        const uint32_t s1 = tkz_hash_pair(m, idr) & T.pair_mask, s2 = tkz_hash_pair(idl, m) & T.pair_mask;
-        const uint4 v1 = tkz_load16(&T.pair_slots[s1]);
-        const uint4 v2 = tkz_load16(&T.pair_slots[s2]);
+        uint32_t r1, r2, l1, l2;
+        tkz_pair_slots(T, m, idr, &r1, &r2);
+        tkz_pair_slots(T, idl, m, &l1, &l2);
+        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2]);
+        const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
         ids[j] = m;
         pr[r] = TKZ_NOKEY;
-        pr[j] = hi ? tkz_mkkey(tkz_resolve_pair(T, m, idr, s1, v1), j) : TKZ_NOKEY;
-        if (lo) pr[l] = tkz_mkkey(tkz_resolve_pair(T, idl, m, s2, v2), l);
+        pr[j] = hi ? tkz_mkkey(tkz_match_pair(m, idr, vr1, vr2), j) : TKZ_NOKEY;
+        if (lo) pr[l] = tkz_mkkey(tkz_match_pair(idl, m, vl1, vl2), l);
     }
     int cnt = 0;
     for (uint32_t a = alive; a; a &= a - 1) {

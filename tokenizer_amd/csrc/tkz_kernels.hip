@@ -310,13 +310,11 @@ TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
             long long t0 = prof ? simt::clock() : 0;
             // ---------------- stage A: fetch keys, issue the first probe of every batch ----------------
             int ps[kPassBatches], plen[kPassBatches];
-            uint32_t q0[kPassBatches], q1[kPassBatches], q2[kPassBatches], slot[kPassBatches];
-            uint4 pv[kPassBatches];
+            uint32_t q0[kPassBatches], q1[kPassBatches], q2[kPassBatches], slot1[kPassBatches], slot2[kPassBatches];
 #pragma unroll
             for (int b = 0; b < kPassBatches; ++b) {
                 const int k = k0 + 64 * b + lane;
-                ps[b] = 0; plen[b] = 0; q0[b] = q1[b] = q2[b] = 0; slot[b] = 0;
-                pv[b].x = pv[b].y = pv[b].z = pv[b].w = 0;
+                ps[b] = 0; plen[b] = 0; q0[b] = q1[b] = q2[b] = 0; slot1[b] = slot2[b] = 0;
                 if (k < kend) {
                     const int s = s_pstart[k];
                     const int len = (int)((k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s);
@@ -331,32 +329,40 @@ TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
                         else if (len < 8) { x1 &= (len == 4) ? 0u : ((1u << (8 * (len - 4))) - 1u); x2 = 0; }
                         else if (len < 12) { x2 &= (len == 8) ? 0u : ((1u << (8 * (len - 8))) - 1u); }
                         q0[b] = x0; q1[b] = x1; q2[b] = x2;
-                        slot[b] = tkz_hash_short(x0, x1, x2, (uint32_t)len) & T.short_mask;
+                        tkz_short_slots(T, x0, x1, x2, (uint32_t)len, &slot1[b], &slot2[b]);
                     }
                 }
             }
-            // (the probes are issued unconditionally, slot 0 for idle lanes: a load inside a divergent branch is
-            //  waited for inside it, and the four batches would not overlap)
-#pragma unroll
-            for (int b = 0; b < kPassBatches; ++b) pv[b] = tkz_load16(&T.short_slots[(P.ablate & 2) ? 0u : slot[b]]);
             // ---------------- stage B: resolve, compact the misses ----------------
             int cnt[kPassBatches], qidx[kPassBatches];
             int32_t tok[kPassBatches];
             int nmiss = 0;
 #pragma unroll
-            for (int b = 0; b < kPassBatches; ++b) {
-                cnt[b] = 0; tok[b] = 0; qidx[b] = -1;
-                bool miss = false;
-                if (plen[b] > 0) {
-                    int32_t rank;
-                    if (plen[b] <= TKZ_SHORT_KEY_MAX) rank = tkz_resolve_short(T, q0[b], q1[b], q2[b], (uint32_t)plen[b], slot[b], pv[b]);
-                    else { const int s = ps[b]; rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)plen[b]); }
-                    if (rank != TKZ_RANK_NONE) { cnt[b] = 1; tok[b] = rank; }      // TikTokenizer.cs:262-265
-                    else miss = true;
+            for (int g = 0; g < kPassBatches; g += 3) {
+                // both cuckoo slots of three batches in flight together; issued unconditionally (slot 0 for idle lanes): a load
+                // inside a divergent branch is waited for inside it, and the batches would not overlap
+                uint4 pv1[3], pv2[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    pv1[t] = tkz_load16(&T.short_slots[(P.ablate & 2) ? 0u : slot1[g + t]]);
+                    pv2[t] = tkz_load16(&T.short_slots[(P.ablate & 2) ? 0u : slot2[g + t]]);
                 }
-                const uint64_t mm = simt::ballot(miss);
-                if (miss) { qidx[b] = nmiss + tkz_popc64(mm & tkz_lowmask(lane)); s_missq[qidx[b]] = (uint16_t)((uint32_t)ps[b] | ((uint32_t)(plen[b] - 1) << 11)); }
-                nmiss += tkz_popc64(mm);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int b = g + t;
+                    cnt[b] = 0; tok[b] = 0; qidx[b] = -1;
+                    bool miss = false;
+                    if (plen[b] > 0) {
+                        int32_t rank;
+                        if (plen[b] <= TKZ_SHORT_KEY_MAX) rank = tkz_match_short(q0[b], q1[b], q2[b], (uint32_t)plen[b], pv1[t], pv2[t]);
+                        else { const int s = ps[b]; rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)plen[b]); }
+                        if (rank != TKZ_RANK_NONE) { cnt[b] = 1; tok[b] = rank; }      // TikTokenizer.cs:262-265
+                        else miss = true;
+                    }
+                    const uint64_t mm = simt::ballot(miss);
+                    if (miss) { qidx[b] = nmiss + tkz_popc64(mm & tkz_lowmask(lane)); s_missq[qidx[b]] = (uint16_t)((uint32_t)ps[b] | ((uint32_t)(plen[b] - 1) << 11)); }
+                    nmiss += tkz_popc64(mm);
+                }
             }
             // one merge round per pass: if more than kMergeLanes pieces missed, the pass ends before the next one (it is redone next pass)
             int kcut = kend;

@@ -4,8 +4,10 @@
 // The reference keeps ONE structure, Dictionary<byte[],int> with an O(len) hash/compare
 // (Tokenizer_C#/TokenizerLib/TikTokenizer.cs:101, Utils/BytePairComparer.cs:8-43) and probes it with
 // freshly allocated byte slices (Utils/BytePairEncoder.cs:25-36).  Only its exact-match semantics are
-// observable.  On the device the same map is held as three open-addressed tables (a few MB in total:
-// L2 / Infinity-Cache resident, never an HBM stream):
+// observable.  On the device the same map is held as three hash tables (a few MB in total: L2 /
+// Infinity-Cache resident, never an HBM stream).  SHORT and PAIR are CUCKOO tables (two hash functions, one
+// 16-byte slot each): a probe is exactly two independent 16-byte gathers, never a chain -- on a SIMT machine the
+// cost of a probe sequence is the MAXIMUM over the 64 lanes, so a bounded probe count matters more than the mean:
 //
 //   SHORT table  keys of 1..12 bytes, the key INLINE in a 16-byte slot: one 16 B gather resolves the
 //                whole-piece lookup (TikTokenizer.cs:262) for ~95 % of pieces.
@@ -53,10 +55,10 @@ struct alignas(16) TkzPairSlot {    // valid == 0 marks an empty slot
 };
 
 struct TkzTables {      // device pointers + masks, passed to kernels by value
-    const TkzShortSlot* short_slots; uint32_t short_mask;
+    const TkzShortSlot* short_slots; uint32_t short_mask; uint32_t short_seed;
     const TkzLongSlot* long_slots;   uint32_t long_mask;
     const uint8_t* long_blob;
-    const TkzPairSlot* pair_slots;   uint32_t pair_mask;
+    const TkzPairSlot* pair_slots;   uint32_t pair_mask; uint32_t pair_seed;
     const int32_t* byte_rank;        // [256] id of the single byte: its rank, or TKZ_PSEUDO_BASE + b
     const int32_t* bytepair_rank;    // [65536] rank of the two-byte key (b0<<8|b1), TKZ_RANK_NONE if absent
     const uint8_t* bmp_class;        // [65536] Unicode class of each BMP code unit (tkz_classes.h)
@@ -68,65 +70,56 @@ TKZ_HD uint32_t tkz_mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
     return h;
 }
-// hash of a key given as zero-padded little-endian dwords
-TKZ_HD uint32_t tkz_hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
-    uint32_t h = tkz_mix32(k0 + 0x9E3779B9u * len);
+// the two hashes of a short key given as zero-padded little-endian dwords
+TKZ_HD uint32_t tkz_hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t seed) {
+    uint32_t h = tkz_mix32(k0 + 0x9E3779B9u * len + seed);
     h = tkz_mix32(h ^ (k1 * 0x85EBCA6Bu));
     h = tkz_mix32(h + (k2 * 0xC2B2AE35u));
     return h;
 }
+TKZ_HD uint32_t tkz_hash_short2(uint32_t h1) { return tkz_mix32(h1 * 0x27D4EB2Fu + 0x165667B1u); }
 // streaming form for long keys: feed ceil(len/4) zero-padded dwords in order
 TKZ_HD uint32_t tkz_hash_long_init(uint32_t len) { return 0x2545F491u ^ (len * 0x9E3779B9u); }
 TKZ_HD uint32_t tkz_hash_long_step(uint32_t h, uint32_t w) { return tkz_mix32(h ^ w) + 0x632BE5ABu; }
-TKZ_HD uint32_t tkz_hash_pair(uint32_t a, uint32_t b) {
-    return tkz_mix32(a * 0x9E3779B9u ^ tkz_mix32(b + 0x7F4A7C15u));
+TKZ_HD uint32_t tkz_hash_pair(uint32_t a, uint32_t b, uint32_t seed) {
+    return tkz_mix32((a + seed) * 0x9E3779B9u ^ tkz_mix32(b + 0x7F4A7C15u));
 }
+TKZ_HD uint32_t tkz_hash_pair2(uint32_t h1) { return tkz_mix32(h1 * 0x27D4EB2Fu + 0x165667B1u); }
 
-// ---- probes (one 16 B gather per step; tables are built at load factor <= 0.5) -----------------
+// ---- probes ---------------------------------------------------------------------------------------
 TKZ_HD uint4 tkz_load16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 
-// Encoder.TryGetValue(piece) for a piece of 1..12 bytes (TikTokenizer.cs:262)
-TKZ_HD int32_t tkz_lookup_short(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
-    uint32_t s = tkz_hash_short(k0, k1, k2, len) & T.short_mask;
-    for (;;) {
-        const uint4 v = tkz_load16(&T.short_slots[s]);
-        if (v.w == 0) return TKZ_RANK_NONE;
-        if (v.x == k0 && v.y == k1 && v.z == k2 && (v.w >> TKZ_SHORT_RANK_BITS) == len)
-            return (int32_t)(v.w & TKZ_SHORT_RANK_MASK);
-        s = (s + 1) & T.short_mask;
-    }
+// the two candidate slots of a short key
+TKZ_HD void tkz_short_slots(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t* s1, uint32_t* s2) {
+    const uint32_t h = tkz_hash_short(k0, k1, k2, len, T.short_seed);
+    *s1 = h & T.short_mask; *s2 = tkz_hash_short2(h) & T.short_mask;
 }
-
-// The same when the caller has already fetched the first slot `v` (= short_slots[slot]) -- lets several
-// independent first probes be in flight before any of them is examined.
-TKZ_HD int32_t tkz_resolve_short(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t slot, uint4 v) {
-    for (;;) {
-        if (v.w == 0) return TKZ_RANK_NONE;
-        if (v.x == k0 && v.y == k1 && v.z == k2 && (v.w >> TKZ_SHORT_RANK_BITS) == len)
-            return (int32_t)(v.w & TKZ_SHORT_RANK_MASK);
-        slot = (slot + 1) & T.short_mask;
-        v = tkz_load16(&T.short_slots[slot]);
-    }
+// Encoder.TryGetValue(piece) for a piece of 1..12 bytes, given the contents of its two candidate slots (TikTokenizer.cs:262)
+TKZ_HD int32_t tkz_match_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint4 v1, uint4 v2) {
+    if (v1.x == k0 && v1.y == k1 && v1.z == k2 && (v1.w >> TKZ_SHORT_RANK_BITS) == len) return (int32_t)(v1.w & TKZ_SHORT_RANK_MASK);
+    if (v2.x == k0 && v2.y == k1 && v2.z == k2 && (v2.w >> TKZ_SHORT_RANK_BITS) == len) return (int32_t)(v2.w & TKZ_SHORT_RANK_MASK);
+    return TKZ_RANK_NONE;
+}
+TKZ_HD int32_t tkz_lookup_short(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
+    uint32_t s1, s2;
+    tkz_short_slots(T, k0, k1, k2, len, &s1, &s2);
+    return tkz_match_short(k0, k1, k2, len, tkz_load16(&T.short_slots[s1]), tkz_load16(&T.short_slots[s2]));
 }
 
 // ranks.TryGetValue(left ++ right) through the ids of the two parts (BytePairEncoder.cs:25-36)
-TKZ_HD int32_t tkz_lookup_pair(const TkzTables& T, uint32_t a, uint32_t b) {
-    uint32_t s = tkz_hash_pair(a, b) & T.pair_mask;
-    for (;;) {
-        const uint4 v = tkz_load16(&T.pair_slots[s]);
-        if (v.w == 0) return TKZ_RANK_NONE;
-        if (v.x == a && v.y == b) return (int32_t)v.z;
-        s = (s + 1) & T.pair_mask;
-    }
+TKZ_HD void tkz_pair_slots(const TkzTables& T, uint32_t a, uint32_t b, uint32_t* s1, uint32_t* s2) {
+    const uint32_t h = tkz_hash_pair(a, b, T.pair_seed);
+    *s1 = h & T.pair_mask; *s2 = tkz_hash_pair2(h) & T.pair_mask;
 }
-
-TKZ_HD int32_t tkz_resolve_pair(const TkzTables& T, uint32_t a, uint32_t b, uint32_t slot, uint4 v) {
-    for (;;) {
-        if (v.w == 0) return TKZ_RANK_NONE;
-        if (v.x == a && v.y == b) return (int32_t)v.z;
-        slot = (slot + 1) & T.pair_mask;
-        v = tkz_load16(&T.pair_slots[slot]);
-    }
+TKZ_HD int32_t tkz_match_pair(uint32_t a, uint32_t b, uint4 v1, uint4 v2) {
+    if (v1.w != 0 && v1.x == a && v1.y == b) return (int32_t)v1.z;
+    if (v2.w != 0 && v2.x == a && v2.y == b) return (int32_t)v2.z;
+    return TKZ_RANK_NONE;
+}
+TKZ_HD int32_t tkz_lookup_pair(const TkzTables& T, uint32_t a, uint32_t b) {
+    uint32_t s1, s2;
+    tkz_pair_slots(T, a, b, &s1, &s2);
+    return tkz_match_pair(a, b, tkz_load16(&T.pair_slots[s1]), tkz_load16(&T.pair_slots[s2]));
 }
 
 // Encoder.TryGetValue(piece) for a piece of 13..max_key_len bytes; `at(i)` yields byte i of the piece.

@@ -130,6 +130,24 @@ int parse_tiktoken(const uint8_t* file, size_t n, Vocab* out, std::string* msg) 
     return TKZ_OK;
 }
 
+namespace {
+// Cuckoo insertion (two hashes, one slot each): every key ends up in one of its two candidate slots, so a lookup
+// is two independent gathers.  Random-walk eviction; on failure the caller retries with another seed or a larger table.
+template <class Slot, class Occupied, class Slots2>
+bool cuckoo_insert(std::vector<Slot>& table, Slot item, Occupied occupied, Slots2 slots2) {
+    uint32_t s1, s2;
+    slots2(item, &s1, &s2);
+    uint32_t pos = s1;
+    for (int kick = 0; kick < 4000; ++kick) {
+        if (!occupied(table[pos])) { table[pos] = item; return true; }
+        std::swap(item, table[pos]);
+        slots2(item, &s1, &s2);
+        pos = (pos == s1) ? s2 : s1;                  // the evicted key moves to its other slot
+    }
+    return false;
+}
+}  // namespace
+
 int build_tables(Vocab* v, std::string* msg) {
     (void)msg;
     const size_t nk = v->keys.size();
@@ -146,29 +164,39 @@ int build_tables(Vocab* v, std::string* msg) {
         if (k.empty()) continue;
         if (k.size() <= TKZ_SHORT_KEY_MAX) ++n_short; else { ++n_long; blob += k.size(); }
     }
-    const uint32_t short_cap = next_pow2(std::max<uint64_t>(16, uint64_t(n_short) * 2));
+    uint32_t short_cap = next_pow2(std::max<uint64_t>(16, uint64_t(n_short) * 2));
     const uint32_t long_cap = next_pow2(std::max<uint64_t>(16, uint64_t(n_long) * 2));
-    v->short_slots.assign(short_cap, TkzShortSlot{0, 0, 0, 0});
     v->long_slots.assign(long_cap, TkzLongSlot{0, 0, 0, 0});
     v->long_blob.clear();
     v->long_blob.reserve(blob + 16);
     for (size_t i = 0; i < nk; ++i) {
         const std::string& k = v->keys[i];
-        if (k.empty()) continue;   // an empty key can never equal a regex match or a merge slice
+        if (k.size() <= TKZ_SHORT_KEY_MAX) continue;
         const uint32_t len = uint32_t(k.size());
-        if (len <= TKZ_SHORT_KEY_MAX) {
-            const uint32_t k0 = load_dword(k, 0), k1 = load_dword(k, 4), k2 = load_dword(k, 8);
-            uint32_t s = tkz_hash_short(k0, k1, k2, len) & (short_cap - 1);
-            while (v->short_slots[s].rank_len) s = (s + 1) & (short_cap - 1);
-            v->short_slots[s] = TkzShortSlot{k0, k1, k2, uint32_t(v->ranks[i]) | (len << TKZ_SHORT_RANK_BITS)};
-        } else {
-            uint32_t h = tkz_hash_long_init(len);
-            for (size_t off = 0; off < k.size(); off += 4) h = tkz_hash_long_step(h, load_dword(k, off));
-            uint32_t s = h & (long_cap - 1);
-            while (v->long_slots[s].len) s = (s + 1) & (long_cap - 1);
-            v->long_slots[s] = TkzLongSlot{h, v->ranks[i], uint32_t(v->long_blob.size()), len};
-            v->long_blob.insert(v->long_blob.end(), k.begin(), k.end());
+        uint32_t h = tkz_hash_long_init(len);
+        for (size_t off = 0; off < k.size(); off += 4) h = tkz_hash_long_step(h, load_dword(k, off));
+        uint32_t s = h & (long_cap - 1);
+        while (v->long_slots[s].len) s = (s + 1) & (long_cap - 1);
+        v->long_slots[s] = TkzLongSlot{h, v->ranks[i], uint32_t(v->long_blob.size()), len};
+        v->long_blob.insert(v->long_blob.end(), k.begin(), k.end());
+    }
+    // SHORT: cuckoo table of the keys of 1..12 bytes (an empty key can never equal a regex match or a merge slice)
+    for (bool done = false; !done; short_cap *= 2) {
+        for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
+            v->short_slots.assign(short_cap, TkzShortSlot{0, 0, 0, 0});
+            TkzTables T{}; T.short_mask = short_cap - 1; T.short_seed = seed;
+            bool ok = true;
+            for (size_t i = 0; i < nk && ok; ++i) {
+                const std::string& k = v->keys[i];
+                if (k.empty() || k.size() > TKZ_SHORT_KEY_MAX) continue;
+                const uint32_t len = uint32_t(k.size());
+                const TkzShortSlot item{load_dword(k, 0), load_dword(k, 4), load_dword(k, 8), uint32_t(v->ranks[i]) | (len << TKZ_SHORT_RANK_BITS)};
+                ok = cuckoo_insert(v->short_slots, item, [](const TkzShortSlot& s) { return s.rank_len != 0; },
+                                   [&](const TkzShortSlot& s, uint32_t* a, uint32_t* b) { tkz_short_slots(T, s.k0, s.k1, s.k2, s.rank_len >> TKZ_SHORT_RANK_BITS, a, b); });
+            }
+            if (ok) { v->short_seed = seed; done = true; }
         }
+        if (done) break;
     }
     v->long_blob.resize(v->long_blob.size() + 16, 0);   // kernels may read a few bytes past a key
     // ---- PAIR table: every split of every key into two keys (or not-in-vocab single bytes) ----
@@ -188,13 +216,20 @@ int build_tables(Vocab* v, std::string* msg) {
         }
     }
     v->pair_entries = int64_t(pairs.size());
-    const uint32_t pair_cap = next_pow2(std::max<uint64_t>(16, uint64_t(pairs.size()) * 2));
-    v->pair_slots.assign(pair_cap, TkzPairSlot{0, 0, 0, 0});
+    uint32_t pair_cap = next_pow2(std::max<uint64_t>(16, uint64_t(pairs.size()) * 2));
     v->bytepair_rank.assign(65536, TKZ_RANK_NONE);
-    for (const P& p : pairs) {
-        uint32_t s = tkz_hash_pair(p.a, p.b) & (pair_cap - 1);
-        while (v->pair_slots[s].valid) s = (s + 1) & (pair_cap - 1);
-        v->pair_slots[s] = TkzPairSlot{p.a, p.b, p.r, 1};
+    for (bool done = false; !done; pair_cap *= 2) {
+        for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
+            v->pair_slots.assign(pair_cap, TkzPairSlot{0, 0, 0, 0});
+            TkzTables T{}; T.pair_mask = pair_cap - 1; T.pair_seed = seed;
+            bool ok = true;
+            for (size_t i = 0; i < pairs.size() && ok; ++i)
+                ok = cuckoo_insert(v->pair_slots, TkzPairSlot{pairs[i].a, pairs[i].b, pairs[i].r, 1},
+                                   [](const TkzPairSlot& s) { return s.valid != 0; },
+                                   [&](const TkzPairSlot& s, uint32_t* a, uint32_t* b) { tkz_pair_slots(T, s.a, s.b, a, b); });
+            if (ok) { v->pair_seed = seed; done = true; }
+        }
+        if (done) break;
     }
     // two-single-byte pairs, directly indexed by the BYTES (not ranks): first-level lookups
     for (int a = 0; a < 256; ++a)

@@ -28,6 +28,7 @@ struct Vocab {
     std::vector<int32_t> byte_rank;       // 256
     std::vector<int32_t> bytepair_rank;   // 65536
     int64_t pair_entries = 0;
+    uint32_t short_seed = 0, pair_seed = 0;   // seeds under which the cuckoo insertion succeeded
 
     bool lookup(const std::string& k, int32_t* rank) const {
         auto it = index.find(k);
