@@ -219,3 +219,34 @@ def check_utf16(lib, O, vocab, ovocab):
             for _ in range(rng.choice([0, 0, 1, 3])):   # sprinkle lone surrogates
                 units.insert(rng.randint(0, len(units)), rng.choice([0xD800, 0xDBFF, 0xDC00, 0xDFFF]))
             assert enc.encode_utf16(units) == oenc.encode_utf16(units), (pattern, units)
+
+
+def random_vocab_bytes(rng, alphabet=b"abc", n_keys=300, max_len=6):
+    """A rank table that is NOT a trained BPE vocabulary: all 256 single bytes plus random strings over a tiny
+    alphabet, ranks in random order.  The reference's merge loop is still well defined on it, and new pairs
+    routinely rank BELOW the pair just merged -- the case the round-based merger has to cut its rounds for."""
+    import base64
+    keys = {bytes([b]) for b in range(256)}
+    n_keys = min(n_keys, sum(len(alphabet) ** k for k in range(2, max_len + 1)) // 2)
+    while len(keys) < 256 + n_keys:
+        keys.add(bytes(rng.choice(alphabet) for _ in range(rng.randint(2, max_len))))
+    keys = list(keys)
+    rng.shuffle(keys)
+    return b"".join(base64.b64encode(k) + b" " + str(i).encode() + b"\n" for i, k in enumerate(keys))
+
+
+def check_random_vocab(lib, O, seed, n_vocabs, lens, n_pieces):
+    """Every merge path (lane 16, lane 32, workgroup rounds in LDS and in the pool) on adversarial rank tables."""
+    rng = random.Random(seed)
+    for vi in range(n_vocabs):
+        raw = random_vocab_bytes(rng, alphabet=rng.choice([b"ab", b"abc", b"abcd"]), n_keys=rng.choice([20, 100, 400]))
+        vocab, ovocab = N.Vocab(raw, lib), O.Vocab(raw)
+        enc = N.Encoder(vocab, N.CL100K)
+        pcs = [bytes(rng.choice(b"abcd"[:rng.randint(1, 4)]) for _ in range(rng.choice(lens))) for _ in range(n_pieces)]
+        data, offs = pack(pcs)
+        ids, ooff = enc.encode_pieces(data, offs)
+        for i, p in enumerate(pcs):
+            r = ovocab.rank(p)
+            x = [r] if r >= 0 else ovocab.bpe(p)
+            g = ids[ooff[i]:ooff[i + 1]].tolist()
+            assert g == x, "vocab %d piece %d (len %d) %r: got %r expected %r" % (vi, i, len(p), p[:60], g[:16], x[:16])

@@ -51,7 +51,7 @@ def test_every_vocab_key(lib, vocab, oracle_mod, oracle_gpt2):
 
 def test_pieces_vs_oracle_bpe(lib, vocab, oracle_mod, oracle_gpt2):
     parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=5, rounds=6,
-                        lens=[1, 2, 3, 4, 5, 8, 12, 13, 16, 17, 20, 33, 64, 100, 300], counts=[1, 5, 300, 1200])
+                        lens=[1, 2, 3, 4, 5, 8, 12, 13, 15, 16, 17, 20, 31, 32, 33, 64, 100, 300], counts=[1, 5, 300, 1200])
 
 
 def test_long_and_giant_pieces(lib, vocab, oracle_mod, oracle_gpt2):
@@ -95,3 +95,7 @@ def test_reference_unit_tests_restated(lib, gpt2_tiktoken_bytes, lib_rs_bytes, o
     import reference_style
     reference_style.run_gpt2_suite(lib, gpt2_tiktoken_bytes, lib_rs_bytes.decode("utf-8"), oracle_mod, oracle_gpt2)
     reference_style.run_cl100k_suite(lib)      # runs only when cl100k_base.tiktoken is supplied
+
+
+def test_adversarial_rank_tables(lib, oracle_mod):
+    parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=12, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 321, 400], n_pieces=60)

@@ -53,7 +53,8 @@ struct CounterBlock {          // mirrors the 64-byte device block
     int64_t grand;
     unsigned long long pool_head;
     int64_t ndocstarts;
-    int64_t pad2[3];
+    unsigned long long heavy_count;
+    int64_t pad2[2];
 };
 
 }  // namespace
@@ -71,7 +72,7 @@ struct tkz_encoder {
     DevBuf t_short, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp;
     TkzTables T{};
     // workspace
-    DevBuf w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
+    DevBuf w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
     // staging for the host-buffer entry points
     DevBuf s_bytes, s_offs, s_out, s_outoffs;
     CounterBlock* h_counters = nullptr;   // pinned
@@ -137,7 +138,8 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         HIP_TRY(e->w_doctok.ensure((size_t)(n_docs + 2) * 4, acc));
         HIP_TRY(e->w_dcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(e->w_dbase.ensure((size_t)ntiles * 8, acc));
-        if (!e->w_pool.p) HIP_TRY(e->w_pool.ensure((size_t)std::min<int64_t>(16 * total + 4096, int64_t(64) << 20), acc));
+        HIP_TRY(e->w_heavyq.ensure((size_t)ntiles * 8, acc));
+        if (!e->w_pool.p) HIP_TRY(e->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
     }
     if (!e->h_counters) HIP_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(CounterBlock), 0));
 
@@ -167,6 +169,8 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             P.offs = d_offs; P.n_docs = n_docs;
             P.tmp = e->w_tmp.as<int32_t>(); P.tile_count = e->w_tcount.as<int32_t>(); P.tile_first = e->w_tfirst.as<int64_t>();
             P.docord_base = e->w_dbase.as<int64_t>(); P.doc_tok = e->w_doctok.as<int32_t>(); P.counters = counters;
+            P.heavy_q = e->w_heavyq.as<int64_t>();
+            P.heavy_count = reinterpret_cast<unsigned long long*>(e->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
             P.pool = e->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(e->w_pool.cap / 4);
             { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
             if (P.ablate & 16) {
@@ -198,7 +202,7 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         if (err & kErrUtf8) return fail(TKZ_E_INVALID_UTF8, "input is not well-formed UTF-8 (or a document boundary falls inside a character)");
         if (err & kErrTooLong) return fail(TKZ_E_UNSUPPORTED, "a single piece longer than 2^30 bytes");
         if ((err & kErrPool) && attempt == 0) {      // scratch for very long pieces was too small: size it for the worst case, rerun
-            HIP_TRY(e->w_pool.ensure((size_t)(16 * total + 4096), acc));
+            HIP_TRY(e->w_pool.ensure((size_t)(24 * total + 4096), acc));
             continue;
         }
         if (err & kErrPool) return fail(TKZ_E_DEVICE, "long-piece scratch exhausted");
@@ -338,7 +342,7 @@ void tkz_encoder_destroy(tkz_encoder* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     DevBuf* bufs[] = {&e->t_short, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp,
-                      &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
+                      &e->w_heavyq, &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
                       &e->w_doctok, &e->w_dcount, &e->w_dbase, &e->w_counters, &e->w_pool, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs};
     for (DevBuf* b : bufs) b->release();
     if (e->h_counters) (void)hipHostFree(e->h_counters);

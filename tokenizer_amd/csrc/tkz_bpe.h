@@ -1,9 +1,9 @@
 // tkz_bpe.h -- BytePairEncoder.BytePairEncode (Tokenizer_C#/TokenizerLib/Utils/BytePairEncoder.cs:13-76)
 // on the device, in two shapes that perform exactly the reference's merge sequence:
 //
-//   tkz_bpe_short   one LANE per piece of <= 16 bytes.  The (Index, Rank) list of the reference
+//   tkz_bpe_lane    one LANE per piece of <= 16 (or <= 32) bytes.  The (Index, Rank) list of the reference
 //                   becomes: a 16-bit alive mask of part starts, ids[k] = token id of the part that
-//                   starts at byte k, pr[k] = packed (rank << 4 | k) of the pair (part at k, next
+//                   starts at byte k, pr[k] = packed (rank << 4|5 | k) of the pair (part at k, next
 //                   part) or NOKEY.  One u32 min over the 16 pr slots is the reference's leftmost
 //                   strict-min scan (:47-54): equal ranks tie-break on the lower position.
 //   tkz_bpe_long    one WORKGROUP per piece of any length: the list is a doubly linked list in
@@ -24,75 +24,78 @@
 
 enum : int32_t { kErrUtf8 = 1, kErrKeyNotFound = 2, kErrOffsets = 4, kErrPool = 8, kErrTooLong = 16, kErrCapacity = 32 };
 
-TKZ_HD uint32_t tkz_mkkey(int32_t rank, int k) { return rank == TKZ_RANK_NONE ? TKZ_NOKEY : (((uint32_t)rank << 4) | (uint32_t)k); }
 
-// Per-lane scratch of tkz_bpe_short: 16 ids + 16 pair keys, each array 16-byte aligned so that the
-// min scan is four 16-byte LDS reads.  kBpeLaneStride (in dwords) spaces the lanes of a wave so that
-// those reads are bank-conflict free (20 dwords: the 16 lanes of a read group land on 16 distinct
-// 4-bank slots of the 64-bank LDS).
-constexpr int kBpeLaneStride = 20;
+// Per-lane scratch of tkz_bpe_lane<NMAX>: NMAX ids + NMAX pair keys, each array 16-byte aligned so that the
+// min scan is NMAX/4 16-byte LDS reads.  The lane stride (in dwords) is chosen so that those reads are
+// bank-conflict free: stride/4 odd puts the 16 lanes of a b128 read group on 16 distinct 4-bank slots.
+template <int NMAX> struct TkzBpeGeom;
+template <> struct TkzBpeGeom<16> { static constexpr int kStride = 20, kShift = 4; };
+template <> struct TkzBpeGeom<32> { static constexpr int kStride = 36, kShift = 5; };
+constexpr int kBpeLaneStride = TkzBpeGeom<16>::kStride;
 
 TKZ_HD uint32_t tkz_min3u(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
+TKZ_HD uint32_t tkz_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
 
-// Piece of n bytes, 1 <= n <= 16, given as four little-endian dwords w0..w3 (bytes past n ignored).
-// ids/pr: this lane's 16-entry arrays (16-byte aligned).  brank: the 256-entry single-byte id table
-// (in LDS on the device).  Returns the number of tokens; *alive_out has one bit per surviving part
-// (token k is ids[k]).  Written for memory-level parallelism: all first-level gathers are issued
-// together, and each merge costs ONE round trip to the pair table (both re-ranked pairs, both cuckoo slots of each, in flight together).
-TKZ_HD int tkz_bpe_short(const TkzTables& T, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int n,
-                         uint32_t* ids, uint32_t* pr, const int32_t* brank, uint32_t* alive_out, int* err) {
-    uint32_t bk[16];
+// One LANE merges one piece of n bytes, 1 <= n <= NMAX (16 or 32), given as little-endian dwords w[0 .. NMAX/4)
+// (bytes past n are ignored).  ids/pr: this lane's NMAX-entry arrays (16-byte aligned).  brank: the 256-entry
+// single-byte id table.  Returns the number of tokens; *alive_out has one bit per surviving part (token k is ids[k]).
+// Written for memory-level parallelism: all first-level gathers are issued together (unconditionally: a load inside
+// a lane-divergent branch is waited for inside that branch), and each merge costs ONE round trip to the pair table
+// (both re-ranked pairs, both cuckoo slots of each, in flight together).
+template <int NMAX>
+TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* ids, uint32_t* pr, const int32_t* brank,
+                        uint32_t* alive_out, int* err) {
+    constexpr int SH = TkzBpeGeom<NMAX>::kShift;
+    uint32_t bk[NMAX];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t w = k < 4 ? w0 : (k < 8 ? w1 : (k < 12 ? w2 : w3));
-        bk[k] = (w >> (8 * (k & 3))) & 0xFFu;
-    }
-    // Unconditional, clamped gathers: a load inside a lane-divergent branch is waited for inside that
-    // branch, which would serialise these 31 independent loads (bytes past n index valid table entries).
-    uint32_t idv[16], prv[16];
-    int32_t r2[15];
+    for (int k = 0; k < NMAX; ++k) bk[k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+    uint32_t idv[NMAX], prv[NMAX];
+    int32_t r2[NMAX - 1];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) idv[k] = (uint32_t)brank[bk[k]];                             // parts = single bytes
+    for (int k = 0; k < NMAX; ++k) idv[k] = (uint32_t)brank[bk[k]];                           // parts = single bytes
 #pragma unroll
-    for (int k = 0; k < 15; ++k) r2[k] = T.bytepair_rank[(bk[k] << 8) | bk[k + 1]];           // initial pair ranks (:37-44)
+    for (int k = 0; k < NMAX - 1; ++k) r2[k] = T.bytepair_rank[(bk[k] << 8) | bk[k + 1]];     // initial pair ranks (:37-44)
 #pragma unroll
-    for (int k = 0; k < 15; ++k) prv[k] = (k + 1 < n) ? tkz_mkkey(r2[k], k) : TKZ_NOKEY;
-    prv[15] = TKZ_NOKEY;
+    for (int k = 0; k < NMAX - 1; ++k) prv[k] = (k + 1 < n) ? (r2[k] == TKZ_RANK_NONE ? TKZ_NOKEY : (((uint32_t)r2[k] << SH) | (uint32_t)k)) : TKZ_NOKEY;
+    prv[NMAX - 1] = TKZ_NOKEY;
     uint4* ids4 = reinterpret_cast<uint4*>(ids);
     uint4* pr4 = reinterpret_cast<uint4*>(pr);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NMAX / 4; ++q) {
         uint4 a, b;
         a.x = idv[4 * q]; a.y = idv[4 * q + 1]; a.z = idv[4 * q + 2]; a.w = idv[4 * q + 3];
         b.x = prv[4 * q]; b.y = prv[4 * q + 1]; b.z = prv[4 * q + 2]; b.w = prv[4 * q + 3];
         ids4[q] = a; pr4[q] = b;
     }
-    uint32_t alive = (1u << n) - 1u;                    // n <= 16
+    uint32_t alive = tkz_lowmask32(n);
     for (;;) {                                          // while (byteIndicesAndRanks.Count > 1) (:45)
-        const uint4 p0 = pr4[0], p1 = pr4[1], p2 = pr4[2], p3 = pr4[3];
-        const uint32_t m0 = tkz_min3u(p0.x, p0.y, p0.z), m1 = tkz_min3u(p0.w, p1.x, p1.y), m2 = tkz_min3u(p1.z, p1.w, p2.x);
-        const uint32_t m3 = tkz_min3u(p2.y, p2.z, p2.w), m4 = tkz_min3u(p3.x, p3.y, p3.z);
-        const uint32_t key = tkz_min3u(tkz_min3u(m0, m1, m2), m3, m4 < p3.w ? m4 : p3.w);   // leftmost strict min (:47-54)
+        uint32_t key = TKZ_NOKEY;
+#pragma unroll
+        for (int q = 0; q < NMAX / 4; ++q) {            // leftmost strict min (:47-54): packed (rank, position), ties -> lower position
+            const uint4 p = pr4[q];
+            key = tkz_min3u(key, tkz_min3u(p.x, p.y, p.z), p.w);
+        }
         if (key == TKZ_NOKEY) break;                    // minRank == int.MaxValue (:65-68)
-        const int j = (int)(key & 15u);
-        const uint32_t m = key >> 4;
-        const int r = tkz_ctz32(alive >> (j + 1)) + j + 1;      // the part being swallowed
+        const int j = (int)(key & (uint32_t)(NMAX - 1));
+        const uint32_t m = key >> SH;
+        const int r = tkz_ctz32(alive & ~tkz_lowmask32(j + 1));   // the part being swallowed
         alive &= ~(1u << r);                            // RemoveAt(j + 1) (:63)
-        // the two re-ranked pairs (:58, :59-62): both first probes are issued before either is examined
-        const uint32_t hi = alive & ~((2u << r) - 1u);
-        const uint32_t lo = alive & ((1u << j) - 1u);
+        // the two re-ranked pairs (:58, :59-62)
+        const uint32_t hi = alive & ~tkz_lowmask32(r + 1);
+        const uint32_t lo = alive & tkz_lowmask32(j);
         const int l = lo ? tkz_msb32(lo) : 0;
         const int rr = hi ? tkz_ctz32(hi) : 0;
         const uint32_t idr = ids[rr], idl = ids[l];     // (unconditional: see above)
-        uint32_t r1, r2, l1, l2;
-        tkz_pair_slots(T, m, idr, &r1, &r2);
+        uint32_t r1, r2s, l1, l2;
+        tkz_pair_slots(T, m, idr, &r1, &r2s);
         tkz_pair_slots(T, idl, m, &l1, &l2);
-        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2]);
+        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2s]);
         const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
         ids[j] = m;
         pr[r] = TKZ_NOKEY;
-        pr[j] = hi ? tkz_mkkey(tkz_match_pair(m, idr, vr1, vr2), j) : TKZ_NOKEY;
-        if (lo) pr[l] = tkz_mkkey(tkz_match_pair(idl, m, vl1, vl2), l);
+        const int32_t rkr = tkz_match_pair(m, idr, vr1, vr2), rkl = tkz_match_pair(idl, m, vl1, vl2);
+        pr[j] = (hi && rkr != TKZ_RANK_NONE) ? (((uint32_t)rkr << SH) | (uint32_t)j) : TKZ_NOKEY;
+        if (lo) pr[l] = rkl != TKZ_RANK_NONE ? (((uint32_t)rkl << SH) | (uint32_t)l) : TKZ_NOKEY;
     }
     int cnt = 0;
     for (uint32_t a = alive; a; a &= a - 1) {
@@ -136,10 +139,141 @@ TKZ_DEV uint64_t tkz_block_min64(uint64_t key) {
     return m;
 }
 
-// Piece of n >= 2 bytes processed by the whole workgroup.  ids/pr/nxt/prv: n entries each (LDS or
-// global).  Tokens are written to dst in order; returns their number.
+// minimum of a 32-bit value over the workgroup
+TKZ_DEV uint32_t tkz_block_min32(uint32_t v) {
+    TKZ_SHARED uint32_t s_m[16];
+    const int lane = simt::lane(), wave = simt::wave(), nw = simt::nthreads() >> 6;
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = simt::shflu(v, lane ^ d); v = o < v ? o : v; }
+    if (lane == 0) s_m[wave] = v;
+    simt::sync();
+    uint32_t m = 0xFFFFFFFFu;
+    for (int w = 0; w < nw; ++w) { const uint32_t x = s_m[w]; m = x < m ? x : m; }
+    simt::sync();
+    return m;
+}
+// exclusive max-scan over the threads of the workgroup (identity -1)
+TKZ_DEV int tkz_block_exclusive_max(int v) {
+    TKZ_SHARED int s_w[16];
+    const int lane = simt::lane(), wave = simt::wave(), nw = simt::nthreads() >> 6;
+    int x = v;
+    for (int d = 1; d < 64; d <<= 1) { const int y = simt::shfl_up(x, d); if (lane >= d && y > x) x = y; }
+    if (lane == 63) s_w[wave] = x;
+    simt::sync();
+    int carry = -1;
+    for (int w = 0; w < wave && w < nw; ++w) carry = s_w[w] > carry ? s_w[w] : carry;
+    simt::sync();
+    const int prevx = simt::shfl_up(x, 1);
+    int ex = lane == 0 ? -1 : prevx;
+    return ex > carry ? ex : carry;
+}
+
+// A piece of n >= 2 bytes merged by the whole workgroup, in ROUNDS.  The parts are a dense array; one round merges
+// every pair whose rank equals the current minimum m, exactly as the reference would get to them one after the other:
+//   * leftmost first, so inside a chain of adjacent candidates (a a a a ...) every other one merges (:47-54, :63);
+//   * a merge re-ranks the pair to its left and the pair to its right (:58-62).  If one of those new ranks is BELOW m
+//     the reference would take that pair next, before the remaining rank-m pairs: the round therefore applies only
+//     the merges up to and including the leftmost one that creates such a pair; the rest wait for a later round.
+//     (The pair to the right is the "transient" one -- merged token + the still unmerged next part -- because the
+//     reference has not yet reached the candidates further right.)  With well-formed vocabularies the cut never
+//     triggers and a run of n equal bytes collapses in about log2(n) rounds; for arbitrary rank tables it keeps the
+//     result identical to the one-merge-at-a-time loop.
+// Arrays (n entries each, LDS or global): idsA/prA (state), s1/s2 (scratch), idsB/prB (next state).  pr[i] is the rank
+// of (part i, part i+1).  Tokens are written to dst in order; returns their number.
 template <class ByteAt>
-TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* ids, int32_t* pr, int32_t* nxt, int32_t* prv,
+TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, int32_t* prA, int32_t* s1, int32_t* s2,
+                         int32_t* idsB, int32_t* prB, int32_t* dst, int* err) {
+    const int tid = simt::tid(), G = simt::nthreads();
+    constexpr int32_t kNotMerge = 0x7FFFFFFE;
+    for (int k = tid; k < n; k += G) {
+        const uint32_t b = at(k);
+        idsA[k] = T.byte_rank[b];
+        prA[k] = (k + 1 < n) ? T.bytepair_rank[(b << 8) | at(k + 1)] : TKZ_RANK_NONE;
+    }
+    simt::sync();
+    int cnt = n;
+    int32_t* ids = idsA; int32_t* pr = prA; int32_t* idsN = idsB; int32_t* prN = prB;
+    for (;;) {
+        const int c = (cnt + G - 1) / G;                  // contiguous block of parts per thread
+        const int lo = tid * c < cnt ? tid * c : cnt, hi = lo + c < cnt ? lo + c : cnt;
+        // 1. the minimum rank
+        uint32_t mymin = (uint32_t)TKZ_RANK_NONE;
+        for (int i = lo; i < hi; ++i) { const uint32_t r = (uint32_t)pr[i]; mymin = r < mymin ? r : mymin; }
+        const int32_t m = (int32_t)tkz_block_min32(mymin);
+        if (m == TKZ_RANK_NONE) break;                    // (:65-68)
+        // 2. candidates, position in their chain -> merge flags (s1)
+        int lastNon = -1;                                 // last non-candidate index inside my block
+        for (int i = lo; i < hi; ++i) if (pr[i] != m) lastNon = i;
+        const int carry = tkz_block_exclusive_max(lastNon);   // last non-candidate before my block
+        {
+            int ln = carry;
+            for (int i = lo; i < hi; ++i) {
+                if (pr[i] != m) { ln = i; s1[i] = 0; }
+                else s1[i] = ((i - (ln + 1)) & 1) == 0 ? 1 : 0;   // even offset from the chain start
+            }
+        }
+        simt::sync();
+        // 3. the two re-ranked pairs of every merge: s2 = rank of (left part, merged), prN = rank of (merged, next part) (transient)
+        uint32_t firstViol = 0xFFFFFFFFu;
+        for (int i = lo; i < hi; ++i) {
+            int32_t L = kNotMerge, R = TKZ_RANK_NONE;
+            if (s1[i]) {
+                L = TKZ_RANK_NONE;
+                if (i >= 1) {
+                    const uint32_t left = (i >= 2 && s1[i - 2]) ? (uint32_t)m : (uint32_t)ids[i - 1];
+                    L = tkz_lookup_pair(T, left, (uint32_t)m);
+                }
+                if (i + 2 < cnt) R = tkz_lookup_pair(T, (uint32_t)m, (uint32_t)ids[i + 2]);
+                if ((L < m || R < m) && (uint32_t)i < firstViol) firstViol = (uint32_t)i;
+            }
+            s2[i] = L; prN[i] = R;
+        }
+        const uint32_t istar = tkz_block_min32(firstViol);   // merges beyond istar wait (includes a sync)
+        // 4. new state, compacted into idsN / prN' (prN holds R: read my own entries before overwriting -> two passes)
+        int alive = 0;
+        for (int i = lo; i < hi; ++i) alive += !(i >= 1 && s2[i - 1] != kNotMerge && (uint32_t)(i - 1) <= istar);
+        int tot;
+        int o = tkz_block_scan(alive, &tot);
+        // values are computed into registers per element and written to idsN / s1 (s1 is free again after the scan's sync)
+        for (int i = lo; i < hi; ++i) {
+            const bool swallowed = i >= 1 && s2[i - 1] != kNotMerge && (uint32_t)(i - 1) <= istar;
+            if (swallowed) continue;
+            const bool mg = s2[i] != kNotMerge && (uint32_t)i <= istar;
+            int32_t nid, npr;
+            if (mg) {
+                nid = m;
+                if (i + 2 < cnt) { const bool mg2 = s2[i + 2] != kNotMerge && (uint32_t)(i + 2) <= istar; npr = mg2 ? s2[i + 2] : prN[i]; }
+                else npr = TKZ_RANK_NONE;
+            } else {
+                nid = ids[i];
+                const bool mg1 = i + 1 < cnt && s2[i + 1] != kNotMerge && (uint32_t)(i + 1) <= istar;
+                npr = mg1 ? s2[i + 1] : pr[i];
+            }
+            idsN[o] = nid; s1[o] = npr; ++o;              // s1[o]: o <= i, and s1[<= i] is no longer read by anyone
+        }
+        simt::sync();
+        // s1 now holds the new pr; make it the pr array of the next round
+        { int32_t* t = pr; pr = s1; s1 = t; }
+        { int32_t* t = ids; ids = idsN; idsN = t; }
+        cnt = tot;
+        simt::sync();
+    }
+    // emit surviving parts in order (:70-75)
+    const int c = (cnt + G - 1) / G;
+    const int lo = tid * c < cnt ? tid * c : cnt, hi = lo + c < cnt ? lo + c : cnt;
+    for (int i = lo; i < hi; ++i) {
+        const int32_t id = ids[i];
+        if (id >= TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;
+        dst[i] = id;
+    }
+    simt::sync();
+    return cnt;
+}
+
+// A piece of n >= 2 bytes merged by the whole workgroup one merge at a time (doubly linked list, one workgroup-wide
+// min of (rank, position) per merge).  Used for pieces of a few dozen to a few hundred bytes, where almost every merge
+// has its own rank and rounds would not batch anything.  ids/pr/nxt/prv: n entries each.
+template <class ByteAt>
+TKZ_DEV int tkz_bpe_long_serial(const TkzTables& T, ByteAt at, int n, int32_t* ids, int32_t* pr, int32_t* nxt, int32_t* prv,
                          int32_t* dst, int* err) {
     const int tid = simt::tid(), G = simt::nthreads();
     for (int k = tid; k < n; k += G) {

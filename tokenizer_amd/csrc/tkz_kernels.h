@@ -11,8 +11,9 @@ namespace tkz {
 constexpr int kThreads = 256;       // workgroup size of every kernel (4 wavefronts)
 constexpr int kSub = 1024;          // bytes of corpus per wavefront of k_encode_waves (a "sub-tile")
 constexpr int kHalo = 64;           // bytes staged past the sub-tile (a short piece may straddle the edge)
-constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one-per-lane
-constexpr int kLdsLong = 320;       // pieces up to this many bytes are merged by the wavefront in LDS
+constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one-per-lane by k_encode_waves
+constexpr int kMedMax = 32;         // ... and up to this many by k_encode_waves_heavy (sub-tiles that have such a piece)
+constexpr int kLdsLong = 320;       // pieces up to this many bytes are merged by the wavefront in LDS (one merge at a time); longer: rounds, arrays in the pool
 constexpr int kPassBatches = 6;     // batches of 64 pieces whose lookups are in flight together (a 1 KiB sub-tile averages ~280 pieces)
 constexpr int kPassPieces = 64 * kPassBatches;
 constexpr int kMergeLanes = 32;     // misses merged per pass (one per lane); sets the LDS scratch of k_encode_waves
@@ -32,6 +33,7 @@ struct EncodeParams {
     const int64_t* docord_base;   // per sub-tile: number of distinct document-start positions before it
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
     int32_t* counters;            // [0] error bits
+    int64_t* heavy_q; unsigned long long* heavy_count;                    // sub-tiles deferred to k_encode_waves_heavy
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kLdsLong (int32 units)
     unsigned long long* devprof;  // development only: cycle counters (ablate bit 4)
     int32_t ablate;               // development only: bit0 skip merges, bit1 skip table probes, bit2 skip stores, bit3 stage 0/1 only

@@ -207,18 +207,35 @@ TKZ_DEV int tkz_wave_scan(int v, int* total) {
     return pre;
 }
 
-TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
+// HEAVY = false: the common case, sub-tiles whose pieces are all <= 16 bytes; a sub-tile with a longer piece is
+//                 appended to P.heavy_q and left to the second launch.
+// HEAVY = true:   the deferred sub-tiles: lanes merge pieces of up to 32 bytes (16 at a time, 32-entry state each:
+//                 CJK runs, emoji sequences, long identifiers), the whole wavefront merges anything longer.
+template <bool HEAVY>
+TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub);
+
+TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) { tkz_encode_subtile<false>(T, P, simt::bid()); }
+TKZ_KERNEL(64) void k_encode_waves_heavy(TkzTables T, EncodeParams P) {
+    const int64_t n = *P.heavy_count;
+    for (int64_t q = simt::bid(); q < n; q += simt::nblocks()) { tkz_encode_subtile<true>(T, P, P.heavy_q[q]); simt::sync(); }
+}
+
+template <bool HEAVY>
+TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub) {
+    constexpr int NMAX = HEAVY ? 32 : 16;                 // bytes a lane can merge
+    constexpr int LANE_MAX = HEAVY ? kMedMax : kShortMax; // pieces up to this many bytes are handled one per lane
+    constexpr int ML = HEAVY ? kMergeLanes / 2 : kMergeLanes;
+    constexpr int STRIDE = TkzBpeGeom<NMAX>::kStride;
     TKZ_SHARED uint32_t s_bytes[(kSub + kHalo) / 4];
     TKZ_SHARED uint16_t s_pstart[kSub + 2];
-    TKZ_SHARED uint4 s_scr4[(2 * kBpeLaneStride * kMergeLanes) / 4];   // short: per lane ids[16] | pr[16] (stride kBpeLaneStride); long: 4 arrays of kLdsLong
+    TKZ_SHARED uint4 s_scr4[(2 * STRIDE * ML) / 4 > (4 * kLdsLong) / 4 ? (2 * STRIDE * ML) / 4 : (4 * kLdsLong) / 4];   // short: per lane ids[16] | pr[16] (stride kBpeLaneStride); long: 4 arrays of kLdsLong
     TKZ_SHARED uint16_t s_missq[kPassPieces];             // start | (len - 1) << 11
-    TKZ_SHARED uint16_t s_minfo[kMergeLanes];                      // per merged miss: alive mask (its tokens stay in that lane's ids[])
+    TKZ_SHARED uint32_t s_minfo[kMergeLanes];                      // per merged miss: alive mask (its tokens stay in that lane's ids[])
     TKZ_SHARED uint64_t s_longmask[kSub / 64];
     TKZ_SHARED int s_i0;
     TKZ_SHARED int64_t s_l0;
 
     const int lane = simt::lane();
-    const int64_t sub = simt::bid();
     const int64_t base = sub * kSub;
     const int nb = (int)(P.total - base < kSub ? P.total - base : kSub);
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_bytes);
@@ -284,19 +301,23 @@ TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
     for (int k0 = 0; k0 < np; k0 += 64) {
         const int k = k0 + lane;
         bool lg = false;
-        if (k < np) lg = (k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s_pstart[k] > kShortMax;
+        if (k < np) lg = (k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s_pstart[k] > LANE_MAX;
         const uint64_t m = simt::ballot(lg);
         if (m) { if (lane == 0) s_longmask[k0 >> 6] = m; nlong += tkz_popc64(m); }
     }
     simt::sync();
+    if (!HEAVY && nlong > 0) {                            // a piece longer than a lean lane can merge: the heavy launch takes this sub-tile
+        if (lane == 0) P.heavy_q[simt::atomic_add64(P.heavy_count, 1ull)] = sub;
+        return;
+    }
 
     if (prof) t_01 = simt::clock() - t_start;
     int running = 0;                                      // tokens of this sub-tile so far (uniform)
     int err = 0;
     int k0 = 0;
     if (P.ablate & 8) k0 = np;
-    uint32_t* ids = &s_scr[(lane & (kMergeLanes - 1)) * kBpeLaneStride];
-    uint32_t* pr = &s_scr[kBpeLaneStride * kMergeLanes + (lane & (kMergeLanes - 1)) * kBpeLaneStride];
+    uint32_t* ids = &s_scr[(lane & (ML - 1)) * STRIDE];
+    uint32_t* pr = &s_scr[STRIDE * ML + (lane & (ML - 1)) * STRIDE];
     while (k0 < np) {
         int next_long = np;
         if (nlong > 0) {
@@ -366,16 +387,16 @@ TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
             }
             // one merge round per pass: if more than kMergeLanes pieces missed, the pass ends before the next one (it is redone next pass)
             int kcut = kend;
-            if (nmiss > kMergeLanes) {
+            if (nmiss > ML) {
 #pragma unroll
                 for (int b = 0; b < kPassBatches; ++b) {
-                    const uint64_t m = simt::ballot(qidx[b] == kMergeLanes);
+                    const uint64_t m = simt::ballot(qidx[b] == ML);
                     if (m) kcut = k0 + 64 * b + tkz_ctz64(m);
                 }
 #pragma unroll
                 for (int b = 0; b < kPassBatches; ++b)
                     if (k0 + 64 * b + lane >= kcut) { plen[b] = 0; cnt[b] = 0; qidx[b] = -1; }
-                nmiss = kMergeLanes;
+                nmiss = ML;
             }
             simt::sync();
             if (prof) { const long long t1 = simt::clock(); t_a += t1 - t0; t0 = t1; n_miss += nmiss; }
@@ -389,12 +410,12 @@ TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
                         const uint32_t e = s_missq[lane];
                         const int s = (int)(e & 0x7FFu), len = (int)(e >> 11) + 1;
                         const int w = s >> 2, sh = (s & 3) * 8;
-                        const uint32_t a0 = s_bytes[w], a1 = s_bytes[w + 1], a2 = s_bytes[w + 2], a3 = s_bytes[w + 3], a4 = s_bytes[w + 4];
-                        tkz_bpe_short(T, (uint32_t)((((uint64_t)a1 << 32) | a0) >> sh), (uint32_t)((((uint64_t)a2 << 32) | a1) >> sh),
-                                      (uint32_t)((((uint64_t)a3 << 32) | a2) >> sh), (uint32_t)((((uint64_t)a4 << 32) | a3) >> sh),
-                                      len, ids, pr, T.byte_rank, &alive, &err1);
+                        uint32_t pw[NMAX / 4];
+#pragma unroll
+                        for (int i = 0; i < NMAX / 4; ++i) pw[i] = (uint32_t)((((uint64_t)s_bytes[w + i + 1] << 32) | s_bytes[w + i]) >> sh);
+                        tkz_bpe_lane<NMAX>(T, pw, len, ids, pr, T.byte_rank, &alive, &err1);
                     }
-                    s_minfo[lane] = (uint16_t)alive;
+                    s_minfo[lane] = alive;
                 }
                 err |= err1;
             }
@@ -406,7 +427,7 @@ TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
                 uint32_t alive = 0;
                 if (qidx[b] >= 0) { alive = s_minfo[qidx[b]]; cnt[b] = tkz_popc32(alive); }
                 int tot;
-                const int pos = running + tkz_wave_scan<5>(cnt[b], &tot);
+                const int pos = running + tkz_wave_scan<HEAVY ? 6 : 5>(cnt[b], &tot);   // a lane holds up to NMAX tokens
                 const int s = ps[b], w = (s >> 6) & 15;
                 const uint32_t dlo = simt::shflu((uint32_t)mydoc, w), dhi = simt::shflu((uint32_t)(mydoc >> 32), w);
                 const int dpre = simt::shfl(docpre, w);
@@ -414,7 +435,7 @@ TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
                     int32_t* dst = P.tmp + first_abs + pos;
                     if (P.ablate & 4) {}
                     else if (qidx[b] < 0) dst[0] = tok[b];
-                    else { const uint32_t* src = &s_scr[qidx[b] * kBpeLaneStride]; int i = 0; for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)src[tkz_ctz32(a)]; }
+                    else { const uint32_t* src = &s_scr[qidx[b] * STRIDE]; int i = 0; for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)src[tkz_ctz32(a)]; }
                     const uint64_t dw = ((uint64_t)dhi << 32) | dlo;
                     if ((dw >> (s & 63)) & 1ull) P.doc_tok[docord0 + dpre + tkz_popc64(dw & tkz_lowmask(s & 63))] = pos;
                 }
@@ -452,7 +473,7 @@ TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
                     bool ok = true;
                     if (len > kLdsLong) {                 // arrays in the global pool
                         if (lane == 0) {
-                            const unsigned long long need = 4ull * (unsigned long long)len;
+                            const unsigned long long need = 6ull * (unsigned long long)len;
                             const unsigned long long o = simt::atomic_add64(P.pool_head, need);
                             s_l0 = (o + need <= (unsigned long long)P.pool_cap) ? (int64_t)o : -1;
                         }
@@ -460,7 +481,8 @@ TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) {
                         if (s_l0 < 0) { ok = false; err |= kErrPool; }
                         else { arr = P.pool + s_l0; stride = len; }
                     }
-                    if (ok) cnt1 = tkz_bpe_long(T, at, len, arr, arr + stride, arr + 2 * stride, arr + 3 * stride, dst, &err);
+                    if (ok && len <= kLdsLong) cnt1 = tkz_bpe_long_serial(T, at, len, arr, arr + stride, arr + 2 * stride, arr + 3 * stride, dst, &err);
+                    else if (ok) cnt1 = tkz_bpe_long(T, at, len, arr, arr + stride, arr + 2 * stride, arr + 3 * stride, arr + 4 * stride, arr + 5 * stride, dst, &err);
                 }
                 simt::sync();
             }
@@ -620,6 +642,7 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub) {
     hook(L, K_ENCODE, 0);
     TKZ_LAUNCH(k_encode_waves, nsub, 64, L.stream, T, P);
+    TKZ_LAUNCH(k_encode_waves_heavy, nsub < 16384 ? nsub : 16384, 64, L.stream, T, P);   // strides over the deferred sub-tiles
     hook(L, K_ENCODE, 1);
 }
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t nsub, int32_t* cnt) {

@@ -27,7 +27,7 @@
 
 #define TKZ_RANK_NONE 0x7FFFFFFF            /* int.MaxValue sentinel, BytePairEncoder.cs:23,35 */
 #define TKZ_PSEUDO_BASE 0x7FFFFC00          /* ids >= this are "single byte not in vocab" */
-#define TKZ_MAX_RANK ((1 << 27) - 1)        /* ranks must be in [0, TKZ_MAX_RANK] */
+#define TKZ_MAX_RANK ((1 << 27) - 2)        /* ranks must be in [0, TKZ_MAX_RANK]: (rank << 5 | 31) stays below the NOKEY sentinel */
 
 #define TKZ_SHORT_KEY_MAX 12
 
