@@ -46,26 +46,33 @@ template <int NMAX>
 TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* ids, uint32_t* pr, const int32_t* brank,
                         uint32_t* alive_out, int* err) {
     constexpr int SH = TkzBpeGeom<NMAX>::kShift;
-    uint32_t bk[NMAX];
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) bk[k] = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-    uint32_t idv[NMAX], prv[NMAX];
-    int32_t r2[NMAX - 1];
-#pragma unroll
-    for (int k = 0; k < NMAX; ++k) idv[k] = (uint32_t)brank[bk[k]];                           // parts = single bytes
-#pragma unroll
-    for (int k = 0; k < NMAX - 1; ++k) r2[k] = T.bytepair_rank[(bk[k] << 8) | bk[k + 1]];     // initial pair ranks (:37-44)
-#pragma unroll
-    for (int k = 0; k < NMAX - 1; ++k) prv[k] = (k + 1 < n) ? (r2[k] == TKZ_RANK_NONE ? TKZ_NOKEY : (((uint32_t)r2[k] << SH) | (uint32_t)k)) : TKZ_NOKEY;
-    prv[NMAX - 1] = TKZ_NOKEY;
     uint4* ids4 = reinterpret_cast<uint4*>(ids);
     uint4* pr4 = reinterpret_cast<uint4*>(pr);
+    // first-level state, 16 bytes at a time (keeps the register footprint of the 32-byte variant that of the 16-byte one)
+#pragma unroll 1
+    for (int c = 0; c < NMAX / 16; ++c) {
+        uint32_t bk[17];
 #pragma unroll
-    for (int q = 0; q < NMAX / 4; ++q) {
-        uint4 a, b;
-        a.x = idv[4 * q]; a.y = idv[4 * q + 1]; a.z = idv[4 * q + 2]; a.w = idv[4 * q + 3];
-        b.x = prv[4 * q]; b.y = prv[4 * q + 1]; b.z = prv[4 * q + 2]; b.w = prv[4 * q + 3];
-        ids4[q] = a; pr4[q] = b;
+        for (int k = 0; k < 16; ++k) bk[k] = (w[4 * c + (k >> 2)] >> (8 * (k & 3))) & 0xFFu;
+        bk[16] = (c + 1 < NMAX / 16) ? (w[4 * c + 4] & 0xFFu) : 0u;
+        uint32_t idv[16], prv[16];
+        int32_t r2[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) idv[k] = (uint32_t)brank[bk[k]];                         // parts = single bytes
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r2[k] = T.bytepair_rank[(bk[k] << 8) | bk[k + 1]];       // initial pair ranks (:37-44)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int g = 16 * c + k;
+            prv[k] = (g + 1 < n && r2[k] != TKZ_RANK_NONE) ? (((uint32_t)r2[k] << SH) | (uint32_t)g) : TKZ_NOKEY;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 a, b;
+            a.x = idv[4 * q]; a.y = idv[4 * q + 1]; a.z = idv[4 * q + 2]; a.w = idv[4 * q + 3];
+            b.x = prv[4 * q]; b.y = prv[4 * q + 1]; b.z = prv[4 * q + 2]; b.w = prv[4 * q + 3];
+            ids4[4 * c + q] = a; pr4[4 * c + q] = b;
+        }
     }
     uint32_t alive = tkz_lowmask32(n);
     for (;;) {                                          // while (byteIndicesAndRanks.Count > 1) (:45)

@@ -215,7 +215,7 @@ template <bool HEAVY>
 TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub);
 
 TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) { tkz_encode_subtile<false>(T, P, simt::bid()); }
-TKZ_KERNEL(64) void k_encode_waves_heavy(TkzTables T, EncodeParams P) {
+TKZ_KERNEL_OCC(64, 4) void k_encode_waves_heavy(TkzTables T, EncodeParams P) {
     const int64_t n = *P.heavy_count;
     for (int64_t q = simt::bid(); q < n; q += simt::nblocks()) { tkz_encode_subtile<true>(T, P, P.heavy_q[q]); simt::sync(); }
 }
