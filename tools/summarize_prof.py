@@ -9,8 +9,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k_encode_waves", "k_pretok_rows", "k_pretok_seq", "k_gather", "k_docmark", "k_docoffs", "k_scan_partials", "k_scan_top",
-              "k_scan_final", "k_corpus_fill", "k_corpus_lengths", "k_offsets_scan"):
+    for k in ("k_encode_waves_heavy", "k_encode_waves", "k_pretok_rows", "k_pretok_seq", "k_gather", "k_docmark", "k_docoffs", "k_scan_partials", "k_scan_top",
+              "k_scan_final", "k_corpus_fill", "k_corpus_lengths", "k_offsets_scan", "k_doccount"):
         if k in name:
             return k
     return name[:60]
