@@ -120,7 +120,7 @@ tkz_status tkz_encode_pieces(tkz_encoder* e, const uint8_t* bytes, const int64_t
                              int64_t* out_offsets, int64_t* needed);
 
 /* Options.  TKZ_OPT_PRETOK_SEQUENTIAL: 1 = split with the one-lane-per-document scanner instead of
- * the position-parallel one (always used for o200k); both must give identical bitmaps. */
+ * the position-parallel one; both must give identical bitmaps. */
 enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1 };
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value);
 

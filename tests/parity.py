@@ -22,6 +22,8 @@ SMALL_ALPHAS = {
     "a_mix": list("abcdeflmrstvDELMRSTVxyzXYZ") * 2 + list("0123456789") + list("  \t\n\r") + list("''.,;:!?()[]{}<>=+-*/_#"),
     # long ASCII stretches broken by the occasional multi-byte char: fast <-> general path hand-over
     "a_brk": list("abc 12's.\n") * 6 + ["中", "\U0001F600", "é", "　"],
+    # o200k: case transitions, contraction suffixes and their chains, '/' after CR/LF
+    "a_case": list("aAbBsStTlLrReEvVdDmM") + list("") + list(" .\n/1"),
 }
 
 

@@ -42,10 +42,10 @@ def test_golden_gpt2_ids(lib, vocab, lib_rs_bytes):
     assert enc.encode_utf16(units) == exp
 
 
-@pytest.mark.parametrize("pattern,sequential", [(1, 0), (2, 0), (1, 1), (2, 1), (3, 1)])
+@pytest.mark.parametrize("pattern,sequential", [(1, 0), (2, 0), (3, 0), (1, 1), (2, 1), (3, 1)])
 def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
     parity.check_pretok(lib, oracle_mod, vocab, pattern, sequential, seeds=range(25),
-                        kinds=["mix", "ws", "dig", "apo", "oth", "case", "a_ws", "a_dig", "a_apo", "a_oth", "a_mix", "a_brk"],
+                        kinds=["mix", "ws", "dig", "apo", "oth", "case", "a_ws", "a_dig", "a_apo", "a_oth", "a_mix", "a_brk", "a_case"],
                         doc_lens=[0, 1, 7, 63, 64, 65, 127, 128, 129, 200, 1000, 5000, 9000, 40000], n_docs_choices=(1, 3, 20, 200))
 
 

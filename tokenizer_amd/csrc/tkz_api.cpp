@@ -54,7 +54,8 @@ struct CounterBlock {          // mirrors the 64-byte device block
     unsigned long long pool_head;
     int64_t ndocstarts;
     unsigned long long heavy_count;
-    int64_t pad2[2];
+    unsigned long long xcount;
+    int64_t pad2[1];
 };
 
 }  // namespace
@@ -72,7 +73,7 @@ struct tkz_encoder {
     DevBuf t_short, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp;
     TkzTables T{};
     // workspace
-    DevBuf w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
+    DevBuf w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
     // staging for the host-buffer entry points
     DevBuf s_bytes, s_offs, s_out, s_outoffs;
     CounterBlock* h_counters = nullptr;   // pinned
@@ -155,11 +156,13 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         launch_docmark(L, d_offs, n_docs, total, docbits, counters);
         if (!pretok) {
             HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
-        } else if (e->pretok_seq || e->pattern == TKZ_PAT_O200K) {
+        } else if (e->pretok_seq) {
             HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
             launch_pretok_seq(L, e->pattern, d_bytes, d_offs, n_docs, total, startbits, e->T.bmp_class, counters);
         } else {
-            launch_pretok_rows(L, e->pattern, d_bytes, total, docbits, startbits, nwords, e->T.bmp_class, counters);
+            HIP_TRY(e->w_xq.ensure((size_t)(nwords / kRowsPerWave + 2) * 8, acc));
+            launch_pretok_rows(L, e->pattern, d_bytes, d_offs, n_docs, total, docbits, startbits, nwords, e->T.bmp_class, counters,
+                               e->w_xq.as<int64_t>(), reinterpret_cast<unsigned long long*>(e->w_counters.as<char>() + offsetof(CounterBlock, xcount)));
         }
         if (d_bitmap_only) {
             HIP_TRY(hipMemcpyAsync(d_bitmap_only, startbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
@@ -342,7 +345,7 @@ void tkz_encoder_destroy(tkz_encoder* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     DevBuf* bufs[] = {&e->t_short, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp,
-                      &e->w_heavyq, &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
+                      &e->w_xq, &e->w_heavyq, &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
                       &e->w_doctok, &e->w_dcount, &e->w_dbase, &e->w_counters, &e->w_pool, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs};
     for (DevBuf* b : bufs) b->release();
     if (e->h_counters) (void)hipHostFree(e->h_counters);

@@ -43,8 +43,10 @@ typedef void (*KernelHook)(void* ctx, int kernel_id, int phase /*0 before, 1 aft
 struct Launch { hipStream_t stream; KernelHook hook; void* hook_ctx; };
 
 void launch_docmark(const Launch& L, const int64_t* d_offs, int64_t n_items, int64_t total, uint64_t* bits, int32_t* counters);
-void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, int64_t total, const uint64_t* docbits,
-                        uint64_t* startbits, int64_t nrows, const uint8_t* bmp, int32_t* counters);
+// position-parallel Regex.Matches; xq / xcount: queue of row blocks left to the sequential matcher (o200k only)
+void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
+                        const uint64_t* docbits, uint64_t* startbits, int64_t nrows, const uint8_t* bmp, int32_t* counters,
+                        int64_t* xq, unsigned long long* xcount);
 void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                        uint64_t* startbits, const uint8_t* bmp, int32_t* counters);
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub);

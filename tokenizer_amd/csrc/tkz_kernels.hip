@@ -113,7 +113,7 @@ TKZ_DEV void tkz_rows_sequential(const TkzSrc& S, const uint64_t* docbits, uint6
 
 template <int PATTERN>
 TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits,
-                                  int64_t nrows, const uint8_t* bmp, int32_t* counters) {
+                                  int64_t nrows, const uint8_t* bmp, int32_t* counters, int64_t* xq, unsigned long long* xcount) {
     // One wavefront per workgroup (the chunk index is then blockIdx.x, which the compiler knows to be wave-uniform).
     // The wavefront owns output rows [r0, r0 + kRowsPerWave); it stages rows r0-1 .. r0+62 (one per lane) in LDS and
     // evaluates them all at once (tkz_block_eval); blocks that scheme refuses go through the sequential row loop.
@@ -139,15 +139,105 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
         const int64_t row = first + lane;
         const uint64_t ds = (row >= 0 && row < nrows) ? docbits[row] : 0;
         uint64_t out;
-        if (tkz_block_eval<PATTERN>(reinterpret_cast<const uint8_t*>(s_blk), ds, &out)) {
+        bool done;
+        if constexpr (PATTERN == TKZ_PAT_O200K) done = tkz_block_eval_o200k(reinterpret_cast<const uint8_t*>(s_blk), ds, &out);
+        else done = tkz_block_eval<PATTERN>(reinterpret_cast<const uint8_t*>(s_blk), ds, &out);
+        if (done) {
             if (lane >= 1 && lane <= kRowsPerWave && row < nrows) startbits[row] = out;
             return;
         }
     }
-    TkzSrc S;
-    S.bytes = bytes; S.total = total; S.stage = nullptr; S.lo = 0; S.hi = 0;
     const int64_t r1 = r0 + kRowsPerWave < nrows ? r0 + kRowsPerWave : nrows;
-    tkz_rows_sequential<PATTERN>(S, docbits, startbits, nrows, bmp, s_aflags, r0, r1, counters);
+    if constexpr (PATTERN == TKZ_PAT_O200K) {
+        // no row-sequential scanner for o200k: the block's rows start as the document-start bits and the block goes to
+        // k_pretok_seq_blocks (sequential matcher from the nearest guaranteed match start)
+        for (int64_t r = r0 + lane; r < r1; r += 64) startbits[r] = docbits[r];
+        if (lane == 0) xq[simt::atomic_add64(xcount, 1ull)] = simt::bid();
+    } else {
+        TkzSrc S;
+        S.bytes = bytes; S.total = total; S.stage = nullptr; S.lo = 0; S.hi = 0;
+        tkz_rows_sequential<PATTERN>(S, docbits, startbits, nrows, bmp, s_aflags, r0, r1, counters);
+    }
+}
+
+// one document through the sequential matcher from match start p0; piece starts inside [b0, b1) are OR-ed into startbits
+TKZ_DEV void tkz_seq_emit(int pattern, const TkzDoc& doc, int64_t a, int64_t p0, int64_t b0, int64_t b1, uint64_t* startbits) {
+    int64_t curw = -1; uint64_t acc = 0;
+    for (int64_t p = p0; p < doc.n && a + p < b1;) {
+        const int64_t g = a + p;
+        if (g >= b0) {
+            if ((g >> 6) != curw) {
+                if (acc) simt::atomic_or64((unsigned long long*)&startbits[curw], acc);
+                curw = g >> 6; acc = 0;
+            }
+            acc |= 1ull << (g & 63);
+        }
+        p = tkz_match_at(pattern, doc, p);
+    }
+    if (acc) simt::atomic_or64((unsigned long long*)&startbits[curw], acc);
+}
+
+// The blocks k_pretok_rows<O200K> left over.  For every document that overlaps the block's
+// bytes the sequential matcher runs from the nearest position at or before the block that is certainly a match start --
+// the document start; a letter/digit right after a CR/LF; an ASCII non-CR/LF white-space char after a non-white-space
+// ASCII char; an ASCII digit after a non-digit ASCII char (no alternative of the pattern can span any of these) -- and
+// the piece starts that fall inside the block are OR-ed in (one wavefront per block).  When more than a quarter of all blocks were left over
+// (text that is mostly non-ASCII) the kernel instead runs one lane per DOCUMENT over the whole batch: OR-ing the bits
+// of blocks that were already done is harmless.
+TKZ_KERNEL(256) void k_pretok_seq_blocks(const uint8_t* bytes, const int64_t* offs, int64_t n_docs, int64_t total, uint64_t* startbits,
+                                         int64_t nrows, int pattern, const uint8_t* bmp, const int64_t* xq, const unsigned long long* xcount,
+                                         int32_t* counters) {
+    const int64_t nx = (int64_t)*xcount;
+    const int64_t nblk = (nrows + kRowsPerWave - 1) / kRowsPerWave;
+    const int64_t stride = simt::nblocks() * simt::nthreads();
+    if (nx * 4 > nblk) {
+        for (int64_t d = simt::bid() * simt::nthreads() + simt::tid(); d < n_docs; d += stride) {
+            const int64_t a = offs[d], e = offs[d + 1];
+            if (e <= a || a < 0 || e > total) continue;
+            TkzDoc doc; doc.b = bytes + a; doc.n = e - a; doc.bmp = bmp;
+            int bad = 0;
+            for (int64_t v = 0; v < doc.n;) { const TkzChar ch = tkz_doc_char(doc, v); bad |= ch.bad; v += ch.len; }
+            if (bad) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrUtf8); continue; }
+            tkz_seq_emit(pattern, doc, a, 0, a, e, startbits);
+        }
+        return;
+    }
+    // one WAVEFRONT per block, lane 0 working: 64 lanes on 64 different blocks would each follow their own path through
+    // the matcher and the wavefront would serialise them
+    for (int64_t q = (simt::bid() * simt::nthreads() + simt::tid()) >> 6; q < nx; q += stride >> 6) {
+        if (simt::lane() != 0) continue;
+        const int64_t r0 = xq[q] * kRowsPerWave;
+        const int64_t r1 = r0 + kRowsPerWave < nrows ? r0 + kRowsPerWave : nrows;
+        const int64_t b0 = r0 << 6, b1 = (r1 << 6) < total ? (r1 << 6) : total;
+        if (b0 >= b1) continue;
+        // first document that ends after b0
+        int64_t lo = 0, hi = n_docs;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (offs[mid + 1] <= b0) lo = mid + 1; else hi = mid; }
+        for (int64_t d = lo; d < n_docs && offs[d] < b1; ++d) {
+            const int64_t a = offs[d], e = offs[d + 1];
+            if (e <= a || a < 0 || e > total) continue;
+            TkzDoc doc; doc.b = bytes + a; doc.n = e - a; doc.bmp = bmp;
+            int64_t p = 0;
+            if (a < b0) {                                 // the document starts before the block: look for a sync point
+                int64_t i = b0 - a;
+                for (; i > 0; --i) {
+                    const uint32_t c = doc.b[i], pc = doc.b[i - 1];
+                    if (pc >= 0x80u || c >= 0x80u) continue;
+                    const bool c_ws = c == ' ' || c - 9u < 5u, pc_ws = pc == ' ' || pc - 9u < 5u;
+                    if ((pc == '\n' || pc == '\r') && ((c | 0x20u) - 'a' < 26u || c - '0' < 10u)) break;
+                    if (c_ws && c != '\n' && c != '\r' && !pc_ws) break;
+                    if (c - '0' < 10u && !(pc - '0' < 10u)) break;
+                }
+                p = i;
+            }
+            int bad = 0;
+            int64_t v = a < b0 ? b0 - a : 0;                // validate from the start of the char that contains the block's first byte
+            for (int back = 0; v > 0 && back < 3 && (doc.b[v] & 0xC0) == 0x80; ++back) --v;
+            for (; v < doc.n && a + v < b1;) { const TkzChar ch = tkz_doc_char(doc, v); bad |= ch.bad; v += ch.len; }
+            if (bad) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrUtf8); continue; }
+            tkz_seq_emit(pattern, doc, a, p, b0, b1, startbits);
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -623,14 +713,20 @@ void launch_docmark(const Launch& L, const int64_t* d_offs, int64_t n_items, int
     TKZ_LAUNCH(k_docmark, grid_for(n_items + 1), kThreads, L.stream, d_offs, n_items, total, bits, counters);
     hook(L, K_DOCMARK, 1);
 }
-void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, int64_t total, const uint64_t* docbits,
-                        uint64_t* startbits, int64_t nrows, const uint8_t* bmp, int32_t* counters) {
+void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
+                        const uint64_t* docbits, uint64_t* startbits, int64_t nrows, const uint8_t* bmp, int32_t* counters,
+                        int64_t* xq, unsigned long long* xcount) {
     const int64_t grid = cdiv(nrows, kRowsPerWave);           // one 64-lane workgroup per chunk of rows
     hook(L, K_PRETOK, 0);
     if (pattern == TKZ_PAT_P1)
-        TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_P1>, grid, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters);
-    else
-        TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_CL100K>, grid, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters);
+        TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_P1>, grid, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters, xq, xcount);
+    else if (pattern == TKZ_PAT_CL100K)
+        TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_CL100K>, grid, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters, xq, xcount);
+    else {
+        TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_O200K>, grid, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters, xq, xcount);
+        TKZ_LAUNCH(k_pretok_seq_blocks, grid_for(n_docs > grid ? n_docs : grid), kThreads, L.stream, d_bytes, d_offs, n_docs, total, startbits, nrows,
+                   pattern, bmp, (const int64_t*)xq, (const unsigned long long*)xcount, counters);
+    }
     hook(L, K_PRETOK, 1);
 }
 void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,

@@ -578,11 +578,12 @@ TKZ_HD uint32_t tkz_swar_eq(uint32_t x, uint32_t c) {
 // the four bit-7 flags of r as a nibble (byte 0 -> bit 0)
 TKZ_HD uint32_t tkz_swar_nibble(uint32_t r) { return (((r >> 7) & 0x01010101u) * 0x01020408u) >> 24; }
 
-struct TkzBlockMasks { uint64_t L, N, O, W, CR, SP, AP; uint32_t hi; };
+struct TkzBlockMasks { uint64_t L, N, O, W, CR, SP, AP, UP, SL; uint32_t hi; };
 
-// classify the 64 bytes of this lane's row (16 dwords at `row`, 16-byte aligned)
+// classify the 64 bytes of this lane's row (16 dwords at `row`, 16-byte aligned); CASES: also upper-case letters and '/'
+template <bool CASES>
 TKZ_HD TkzBlockMasks tkz_block_classify(const uint4* row) {
-    uint32_t mL[2] = {0, 0}, mN[2] = {0, 0}, mW[2] = {0, 0}, mC[2] = {0, 0}, mS[2] = {0, 0}, mA[2] = {0, 0};
+    uint32_t mL[2] = {0, 0}, mN[2] = {0, 0}, mW[2] = {0, 0}, mC[2] = {0, 0}, mS[2] = {0, 0}, mA[2] = {0, 0}, mU[2] = {0, 0}, mX[2] = {0, 0};
     uint32_t hi = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -601,11 +602,16 @@ TKZ_HD TkzBlockMasks tkz_block_classify(const uint4* row) {
             mC[h] |= tkz_swar_nibble(tkz_swar_eq(x, '\n') | tkz_swar_eq(x, '\r')) << sh;
             mS[h] |= tkz_swar_nibble(tkz_swar_eq(x, ' ')) << sh;
             mA[h] |= tkz_swar_nibble(tkz_swar_eq(x, '\'')) << sh;
+            if (CASES) {
+                mU[h] |= tkz_swar_nibble(tkz_swar_range(x, 'A', 'Z')) << sh;
+                mX[h] |= tkz_swar_nibble(tkz_swar_eq(x, '/')) << sh;
+            }
         }
     }
     TkzBlockMasks m;
     m.L = ((uint64_t)mL[1] << 32) | mL[0]; m.N = ((uint64_t)mN[1] << 32) | mN[0]; m.W = ((uint64_t)mW[1] << 32) | mW[0];
     m.CR = ((uint64_t)mC[1] << 32) | mC[0]; m.SP = ((uint64_t)mS[1] << 32) | mS[0]; m.AP = ((uint64_t)mA[1] << 32) | mA[0];
+    m.UP = ((uint64_t)mU[1] << 32) | mU[0]; m.SL = ((uint64_t)mX[1] << 32) | mX[0];
     m.O = ~(m.L | m.N | m.W);
     m.hi = hi & 0x80808080u;
     return m;
@@ -617,7 +623,7 @@ TKZ_HD TkzBlockMasks tkz_block_classify(const uint4* row) {
 template <int PATTERN>
 TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, uint64_t* out) {
     const int lane = simt::lane();
-    const TkzBlockMasks m = tkz_block_classify(reinterpret_cast<const uint4*>(stage + lane * kBlockRowStride));
+    const TkzBlockMasks m = tkz_block_classify<false>(reinterpret_cast<const uint4*>(stage + lane * kBlockRowStride));
     const uint64_t L = m.L, N = m.N, O = m.O, W = m.W, CR = m.CR, SP = m.SP, AP = m.AP;
     const uint64_t nds = ~ds;
     // ---- exchange 1: the class of the byte before my row (bit 63 of the previous lane's masks), the first bytes of the next row
@@ -712,6 +718,122 @@ TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, uint64_t* out) {
         start = sL | sN | sO | sW;
     }
     *out = start | contrEnd | ds;
+    return true;
+}
+
+// The same for o200k (tokenizer_ts/src/tokenizerBuilder.ts:79-89) on ASCII rows.  Without \p{Lm}\p{Lo}\p{M} the two word
+// alternatives reduce to U*l* (upper-case run, then lower-case run): inside a letter run a piece starts exactly at a
+// lower->upper transition; the one-char prefix rule is cl100k's; a contraction is not an alternative of its own but an
+// optional SUFFIX of a word piece (the apostrophe is glued when the char before it ends a word piece -- not when that
+// char is itself the tail of a glued contraction: `it's's` = `it's` + `'s`, resolved by a short fixed-point iteration);
+// ` ?[^\s\p{L}\p{N}]+[\r\n/]*` also absorbs '/' after the CR/LF it absorbed.  Refuses (returns false) what the
+// nearest-neighbour scheme cannot do, as tkz_block_eval does.
+TKZ_DEV bool tkz_block_eval_o200k(const uint8_t* stage, uint64_t ds, uint64_t* out) {
+    const int lane = simt::lane();
+    const TkzBlockMasks m = tkz_block_classify<true>(reinterpret_cast<const uint4*>(stage + lane * kBlockRowStride));
+    const uint64_t L = m.L, N = m.N, O = m.O, W = m.W, CR = m.CR, SP = m.SP, AP = m.AP, UP = m.UP, LOW = m.L & ~m.UP;
+    const uint64_t nds = ~ds;
+    const uint32_t up_bits = (uint32_t)(L >> 63) | ((uint32_t)(N >> 63) << 1) | ((uint32_t)(O >> 63) << 2) | ((uint32_t)(SP >> 63) << 3) |
+                             ((uint32_t)(W >> 63) << 4) | ((uint32_t)(CR >> 63) << 5) | ((uint32_t)(LOW >> 63) << 6);
+    const uint64_t conn = W & nds;
+    const int lead_ws = (~conn) ? tkz_ctz64(~conn) : 64;
+    const uint32_t head = (CR & tkz_lowmask(lead_ws)) ? 1u : 0u;
+    const uint32_t dn_bits = (uint32_t)(L & 1) | ((uint32_t)(N & 1) << 1) | ((uint32_t)(O & 1) << 2) | ((uint32_t)(ds & 3) << 3) | (head << 5);
+    uint32_t pb = simt::shflu(up_bits, (lane + 63) & 63), nb = simt::shflu(dn_bits, (lane + 1) & 63);
+    if (lane == 0) pb = 0;
+    if (lane == 63) nb = 0;
+    const uint64_t pN = ((N << 1) | ((pb >> 1) & 1)) & nds;
+    const uint64_t Q = N & pN;
+    const uint64_t R = (CR | m.SL) & nds;                              // what `[\r\n/]*` can run through
+    const bool bad = m.hi != 0 || Q == ~0ull || conn == ~0ull || (lane == 0 && N == ~0ull) || (R & tkz_lowmask(60)) == tkz_lowmask(60);
+    if (simt::ballot(bad)) return false;
+    const uint64_t pL = ((L << 1) | (pb & 1)) & nds, pO = ((O << 1) | ((pb >> 2) & 1)) & nds, pSP = ((SP << 1) | ((pb >> 3) & 1)) & nds;
+    const uint64_t pW = ((W << 1) | ((pb >> 4) & 1)) & nds, pCR = ((CR << 1) | ((pb >> 5) & 1)) & nds;
+    const uint64_t pLOW = ((LOW << 1) | ((pb >> 6) & 1)) & nds;
+    const uint64_t dsn = (uint64_t)((nb >> 3) & 3);
+    const uint64_t KN = (ds >> 1) | (dsn << 63), KN2 = (ds >> 2) | (dsn << 62);
+    const uint64_t nO = ((O >> 1) | ((uint64_t)((nb >> 2) & 1) << 63)) & ~KN;
+    const uint64_t nReal = (((L | N | O) >> 1) | ((uint64_t)((nb & 7) ? 1 : 0) << 63)) & ~KN;
+    // ---- contraction candidates: an apostrophe right after a letter, followed by a literal inside the document
+    uint64_t k2 = 0, k3 = 0;
+    {
+        uint64_t ap = AP & pL & ~KN;
+        while (simt::ballot(ap != 0)) {
+            if (ap) {
+                const int pos = tkz_ctz64(ap);
+                ap &= ap - 1;
+                const int p1 = pos + 1, p2 = pos + 2;
+                const uint32_t b1 = stage[(lane + (p1 >> 6)) * kBlockRowStride + (p1 & 63)];
+                const uint32_t b2 = stage[(lane + (p2 >> 6)) * kBlockRowStride + (p2 & 63)];
+                const int k = tkz_contraction_len_o200k(b1, b2);
+                if (k == 2) k2 |= 1ull << pos;
+                else if (k == 3 && !((KN2 >> pos) & 1ull)) k3 |= 1ull << pos;
+            }
+        }
+    }
+    // glued = candidates whose preceding letter is not the tail of a glued contraction (fixed point, left to right)
+    auto resolve = [&](uint64_t blk_in, uint64_t* g2o, uint64_t* g3o) -> bool {
+        uint64_t g2 = k2, g3 = k3, blk = blk_in;
+        for (int it = 0; it < 6; ++it) {
+            g2 = k2 & ~blk; g3 = k3 & ~blk;
+            const uint64_t nblk = (g2 << 2) | (g3 << 3) | blk_in;
+            if (nblk == blk) { *g2o = g2; *g3o = g3; return true; }
+            blk = nblk;
+        }
+        *g2o = g2; *g3o = g3;
+        return false;
+    };
+    uint64_t g2, g3;
+    bool conv = resolve(0, &g2, &g3);
+    // local state that flows to the next row (computed with no inflow: exact unless a run covers the row, refused above)
+    uint32_t carryN_out = 0;
+    if (N >> 63) carryN_out = (uint32_t)((64 - tkz_msb64(~Q)) % 3);
+    const uint64_t seeds = CR & pO;
+    const uint64_t ABS0 = tkz_fill_up64(seeds & R, R);
+    const uint64_t o1_0 = O & ~ABS0 & (~pO | (ABS0 << 1)) & ~pSP & ~nO & ~(g2 | g3);
+    const uint32_t up2 = (uint32_t)(g2 >> 62) | ((uint32_t)(g3 >> 61) << 2) | ((uint32_t)(o1_0 >> 63) << 5) | ((uint32_t)(ABS0 >> 63) << 6) | (carryN_out << 7);
+    uint32_t p2b = simt::shflu(up2, (lane + 63) & 63);
+    if (lane == 0) p2b = 0;
+    // with the real inflow: positions 0..2 may be the fresh start after a contraction of the previous row
+    const uint64_t blk_in = (uint64_t)(p2b & 3) | (uint64_t)((p2b >> 2) & 7);
+    uint64_t h2, h3;
+    conv = resolve(blk_in, &h2, &h3) && conv;
+    // if the inflow changed what I told the next row, that row worked from wrong data: leave the block to the sequential path
+    if (simt::ballot(!conv || (h2 >> 62) != (g2 >> 62) || (h3 >> 61) != (g3 >> 61))) return false;
+    g2 = h2; g3 = h3;
+    const uint64_t glued = g2 | g3;
+    const uint64_t contrEnd = (g2 << 2) | (g3 << 3) | blk_in;
+    // letters covered by a glued literal (never piece starts): from this row and from the previous one
+    const uint32_t c2p = p2b & 3, c3p = (p2b >> 2) & 7;                 // previous row: g2 bits 62,63 ; g3 bits 61,62,63
+    const uint64_t cover = (g2 << 1) | (g3 << 1) | (g3 << 2) |
+                           (uint64_t)(((c2p >> 1) | (c3p >> 1) | (c3p >> 2)) & 1) | ((uint64_t)((c3p >> 2) & 1) << 1);
+    const uint32_t abs_in = (p2b >> 6) & 1;
+    const uint64_t ABS = abs_in ? tkz_fill_up64((seeds | (R & 1ull)) & R, R) : ABS0;
+    const uint64_t pABS = (ABS << 1) | (uint64_t)abs_in;
+    const uint64_t o1 = O & ~ABS & (~pO | pABS) & ~pSP & ~nO & ~glued;
+    const uint64_t o1Prev = (o1 << 1) | (uint64_t)((p2b >> 5) & 1);
+    const uint64_t pWSo = pW & ~pCR & ~pSP;
+    const uint64_t sL = (L & ~pL & ~pSP & ~pWSo & ~o1Prev) | (UP & pLOW);
+    const uint64_t sO = O & ~ABS & (~pO | pABS) & ~pSP;
+    uint64_t S = N & ~pN;
+    if (Q & 1ull) {
+        const int d = (3 - (int)((p2b >> 7) & 3)) % 3, lead = tkz_ctz64(~Q);
+        if (d < lead) S |= 1ull << d;
+    }
+    const uint64_t Q3 = Q & (Q << 1) & (Q << 2);
+    uint64_t T = S | ((S << 3) & Q3);
+    const uint64_t Q6 = Q3 & (Q3 << 3);
+    T |= (T << 6) & Q6;
+    const uint64_t Q12 = Q6 & (Q6 << 6);
+    T |= (T << 12) & Q12;
+    const uint64_t Q24 = Q12 & (Q12 << 12);
+    T |= (T << 24) & Q24;
+    T |= (T << 48) & (Q24 & (Q24 << 24));
+    const uint64_t Scr = CR | ((uint64_t)((nb >> 5) & 1) << 63);
+    const uint64_t Srev = tkz_brev64(Scr), Grev = tkz_brev64(conn) << 1;
+    const uint64_t Tcur = tkz_brev64(Srev | tkz_fill_up64((Srev << 1) & Grev, Grev));
+    const uint64_t sW = W & ~ABS & ((~pW | pABS) | (pCR & ~Tcur) | (~CR & nReal));
+    *out = ((sL | T | sO | sW) & ~cover & ~glued) | contrEnd | ds;
     return true;
 }
 #endif  // TKZ_NO_SIMT
