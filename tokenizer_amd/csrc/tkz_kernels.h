@@ -14,8 +14,9 @@ constexpr int kHalo = 64;           // bytes staged past the sub-tile (a short p
 constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one-per-lane by k_encode_waves
 constexpr int kMedMax = 32;         // ... and up to this many by k_encode_waves_heavy (sub-tiles that have such a piece)
 constexpr int kLdsLong = 320;       // pieces up to this many bytes are merged by the wavefront in LDS (one merge at a time); longer: rounds, arrays in the pool
-constexpr int kPassBatches = 6;     // batches of 64 pieces whose lookups are in flight together (a 1 KiB sub-tile averages ~280 pieces)
+constexpr int kPassBatches = 5;     // batches of 64 pieces whose lookups are in flight together (a 1 KiB sub-tile averages ~280 pieces)
 constexpr int kPassPieces = 64 * kPassBatches;
+constexpr int kLeanPieces = 512;    // k_encode_waves keeps this many piece positions; denser sub-tiles go to the heavy kernel
 constexpr int kMergeLanes = 32;     // misses merged per pass (one per lane); sets the LDS scratch of k_encode_waves
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)

@@ -304,7 +304,7 @@ TKZ_DEV int tkz_wave_scan(int v, int* total) {
 template <bool HEAVY>
 TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub);
 
-TKZ_KERNEL_OCC(64, 4) void k_encode_waves(TkzTables T, EncodeParams P) { tkz_encode_subtile<false>(T, P, simt::bid()); }
+TKZ_KERNEL_OCC(64, 5) void k_encode_waves(TkzTables T, EncodeParams P) { tkz_encode_subtile<false>(T, P, simt::bid()); }
 TKZ_KERNEL_OCC(64, 4) void k_encode_waves_heavy(TkzTables T, EncodeParams P) {
     const int64_t n = *P.heavy_count;
     for (int64_t q = simt::bid(); q < n; q += simt::nblocks()) { tkz_encode_subtile<true>(T, P, P.heavy_q[q]); simt::sync(); }
@@ -317,9 +317,9 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
     constexpr int ML = HEAVY ? kMergeLanes / 2 : kMergeLanes;
     constexpr int STRIDE = TkzBpeGeom<NMAX>::kStride;
     TKZ_SHARED uint32_t s_bytes[(kSub + kHalo) / 4];
-    TKZ_SHARED uint16_t s_pstart[kSub + 2];
+    TKZ_SHARED uint16_t s_pstart[(HEAVY ? kSub : kLeanPieces) + 2];
     TKZ_SHARED uint4 s_scr4[(2 * STRIDE * ML) / 4 > (4 * kLdsLong) / 4 ? (2 * STRIDE * ML) / 4 : (4 * kLdsLong) / 4];   // short: per lane ids[16] | pr[16] (stride kBpeLaneStride); long: 4 arrays of kLdsLong
-    TKZ_SHARED uint16_t s_missq[kPassPieces];             // start | (len - 1) << 11
+    TKZ_SHARED uint16_t s_missq[ML + 1];                  // start | (len - 1) << 11 (only the misses a pass can merge are kept)
     TKZ_SHARED uint32_t s_minfo[kMergeLanes];                      // per merged miss: alive mask (its tokens stay in that lane's ids[])
     TKZ_SHARED uint64_t s_longmask[kSub / 64];
     TKZ_SHARED int s_i0;
@@ -379,13 +379,18 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
     int np;
     {
         int off = tkz_wave_scan<5>(tkz_popc32(bits16), &np);
-        for (uint32_t b = bits16; b; b &= b - 1) s_pstart[off++] = (uint16_t)(16 * lane + tkz_ctz32(b));
+        if (HEAVY || np <= kLeanPieces)
+            for (uint32_t b = bits16; b; b &= b - 1) s_pstart[off++] = (uint16_t)(16 * lane + tkz_ctz32(b));
     }
     // document ordinals: docs that start before word `lane` of this sub-tile
     int docpre_tot;
     const int docpre = tkz_wave_scan<7>(lane < kSub / 64 ? tkz_popc64(mydoc) : 0, &docpre_tot);
     const int64_t docord0 = P.docord_base[sub];
     simt::sync();
+    if (!HEAVY && np > kLeanPieces) {                     // more pieces than the lean kernel keeps positions for
+        if (lane == 0) P.heavy_q[simt::atomic_add64(P.heavy_count, 1ull)] = sub;
+        return;
+    }
     const int64_t first_abs = np ? base + s_pstart[0] : base;
     int nlong = 0;
     for (int k0 = 0; k0 < np; k0 += 64) {
@@ -454,12 +459,12 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                 // inside a divergent branch is waited for inside it, and the batches would not overlap
                 uint4 pv1[3], pv2[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < 3 && g + t < kPassBatches; ++t) {
                     pv1[t] = tkz_load16(&T.short_slots[(P.ablate & 2) ? 0u : slot1[g + t]]);
                     pv2[t] = tkz_load16(&T.short_slots[(P.ablate & 2) ? 0u : slot2[g + t]]);
                 }
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
+                for (int t = 0; t < 3 && g + t < kPassBatches; ++t) {
                     const int b = g + t;
                     cnt[b] = 0; tok[b] = 0; qidx[b] = -1;
                     bool miss = false;
@@ -471,7 +476,7 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                         else miss = true;
                     }
                     const uint64_t mm = simt::ballot(miss);
-                    if (miss) { qidx[b] = nmiss + tkz_popc64(mm & tkz_lowmask(lane)); s_missq[qidx[b]] = (uint16_t)((uint32_t)ps[b] | ((uint32_t)(plen[b] - 1) << 11)); }
+                    if (miss) { qidx[b] = nmiss + tkz_popc64(mm & tkz_lowmask(lane)); if (qidx[b] < ML) s_missq[qidx[b]] = (uint16_t)((uint32_t)ps[b] | ((uint32_t)(plen[b] - 1) << 11)); }
                     nmiss += tkz_popc64(mm);
                 }
             }
