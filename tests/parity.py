@@ -108,8 +108,8 @@ def check_vocab_keys(lib, O, vocab, ovocab, pattern=N.CL100K):
     assert np.array_equal(ooff, np.arange(len(keys) + 1))
 
 
-def random_piece(rng, keys, lens):
-    n = rng.choice(lens) if rng.random() < 0.5 else rng.randint(1, 24)
+def random_piece(rng, keys, lens, p_listed=0.5):
+    n = rng.choice(lens) if rng.random() < p_listed else rng.randint(1, 24)
     m = rng.random()
     if m < 0.3:
         return bytes(rng.randrange(256) for _ in range(n))
@@ -125,13 +125,13 @@ def random_piece(rng, keys, lens):
     return (rng.choice(keys) * (n // 2 + 1))[:n]
 
 
-def check_pieces(lib, O, vocab, ovocab, seed, rounds, lens, counts):
+def check_pieces(lib, O, vocab, ovocab, seed, rounds, lens, counts, p_listed=0.5):
     """K3: BytePairEncode (+ whole-piece lookup) on arbitrary byte strings, vs the oracle's bpe()."""
     enc = N.Encoder(vocab, N.CL100K)
     keys = [k for k, _ in ovocab.entries()]
     rng = random.Random(seed)
     for it in range(rounds):
-        pcs = [random_piece(rng, keys, lens) for _ in range(rng.choice(counts))]
+        pcs = [random_piece(rng, keys, lens, p_listed) for _ in range(rng.choice(counts))]
         data, offs = pack(pcs)
         ids, ooff = enc.encode_pieces(data, offs)
         exp, eoff = [], [0]

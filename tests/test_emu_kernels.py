@@ -54,9 +54,14 @@ def test_pieces_vs_oracle_bpe(lib, vocab, oracle_mod, oracle_gpt2):
                         lens=[1, 2, 3, 4, 5, 8, 12, 13, 15, 16, 17, 20, 31, 32, 33, 64, 100, 300], counts=[1, 5, 300, 1200])
 
 
+def test_mid_pieces_share_the_arena(lib, vocab, oracle_mod, oracle_gpt2):
+    # sub-tiles full of 17..1024-byte misses: every pass of the heavy kernel ends on a full arena
+    parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=11, rounds=4, lens=[17, 24, 33, 40, 48, 64, 90, 128, 200, 400, 1023, 1024], counts=[40, 400], p_listed=1.0)
+
+
 def test_long_and_giant_pieces(lib, vocab, oracle_mod, oracle_gpt2):
-    # workgroup path in LDS (<= 2048 bytes) and in the global pool (> 2048), incl. the pool-grow retry
-    parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=9, rounds=2, lens=[300, 320, 321, 700, 2600], counts=[3])
+    # whole-wave path, arrays in the global pool (> kArenaPiece bytes), incl. the pool-grow retry
+    parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=9, rounds=2, lens=[300, 1024, 1025, 1500, 2600], counts=[3])
 
 
 @pytest.mark.parametrize("pattern", [1, 2, 3])
@@ -98,4 +103,4 @@ def test_reference_unit_tests_restated(lib, gpt2_tiktoken_bytes, lib_rs_bytes, o
 
 
 def test_adversarial_rank_tables(lib, oracle_mod):
-    parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=12, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 321, 400], n_pieces=60)
+    parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=12, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 1024, 1025], n_pieces=60)

@@ -63,7 +63,12 @@ def test_every_vocab_key(lib, vocab, oracle_mod, oracle_gpt2):
 
 def test_pieces_vs_oracle_bpe(lib, vocab, oracle_mod, oracle_gpt2):
     parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=5, rounds=25,
-                        lens=[1, 2, 3, 4, 5, 8, 12, 13, 15, 16, 17, 20, 31, 32, 33, 64, 100, 300, 320, 321, 1000, 2048, 3000], counts=[1, 5, 300, 3000])
+                        lens=[1, 2, 3, 4, 5, 8, 12, 13, 15, 16, 17, 20, 31, 32, 33, 64, 100, 300, 400, 1000, 1023, 1024, 1025, 2048, 3000], counts=[1, 5, 300, 3000])
+
+
+def test_mid_pieces_share_the_arena(lib, vocab, oracle_mod, oracle_gpt2):
+    # sub-tiles full of 17..1024-byte misses: every pass of the heavy kernel ends on a full arena
+    parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=11, rounds=12, lens=[17, 24, 33, 40, 48, 64, 90, 128, 200, 400, 1023, 1024], counts=[40, 400, 4000], p_listed=1.0)
 
 
 def test_giant_pieces(lib, vocab, oracle_mod, oracle_gpt2):
@@ -173,4 +178,4 @@ def test_reference_unit_tests_restated(lib, gpt2_tiktoken_bytes, lib_rs_bytes, o
 
 
 def test_adversarial_rank_tables(lib, oracle_mod):
-    parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=40, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 321, 400, 3000], n_pieces=200)
+    parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=40, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 1024, 1025, 3000], n_pieces=200)

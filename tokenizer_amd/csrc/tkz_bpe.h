@@ -113,6 +113,92 @@ TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* 
     return cnt;
 }
 
+// One LANE merges one piece of n >= 1 bytes with its state in a caller-provided span of tkz_bpe_var_dwords(n) dwords:
+//   ids[n4] | pr[n4] | alive[a4]      n4 = n rounded up to 4, a4 = ceil(n / 32) rounded up to 4 (one bit per part start)
+// The same loop as tkz_bpe_lane with the piece length a run-time value (the heavy kernel gives every missed piece of a
+// pass a span of its own size out of one LDS arena: CJK runs, emoji sequences and long identifiers are merged side by
+// side instead of one after the other).  pr holds plain ranks; the leftmost strict minimum (:47-54) is a first-wins
+// scan.  Returns the number of tokens: ids[k] for every set bit k of alive[], in order (tkz_bpe_var_emit).
+TKZ_HD int tkz_bpe_var_n4(int n) { return (n + 3) & ~3; }
+TKZ_HD int tkz_bpe_var_a4(int n) { return (((n + 31) >> 5) + 3) & ~3; }
+TKZ_HD int tkz_bpe_var_dwords(int n) { return 2 * tkz_bpe_var_n4(n) + tkz_bpe_var_a4(n); }
+
+template <class ByteAt>
+TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, int* err) {
+    const int n4 = tkz_bpe_var_n4(n), nw = (n + 31) >> 5;
+    uint32_t* ids = st; uint32_t* pr = st + n4; uint32_t* am = st + 2 * n4;
+    uint4* ids4 = reinterpret_cast<uint4*>(ids); uint4* pr4 = reinterpret_cast<uint4*>(pr);
+#pragma unroll 1
+    for (int c = 0; c < n4; c += 4) {
+        uint32_t b[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) b[k] = c + k < n ? at(c + k) : 0u;
+        uint32_t idv[4]; int32_t r2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) idv[k] = (uint32_t)T.byte_rank[b[k]];                       // parts = single bytes
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r2[k] = T.bytepair_rank[(b[k] << 8) | b[k + 1]];            // initial pair ranks (:37-44)
+        uint4 a, q;
+        a.x = idv[0]; a.y = idv[1]; a.z = idv[2]; a.w = idv[3];
+        q.x = c + 1 < n ? (uint32_t)r2[0] : (uint32_t)TKZ_RANK_NONE; q.y = c + 2 < n ? (uint32_t)r2[1] : (uint32_t)TKZ_RANK_NONE;
+        q.z = c + 3 < n ? (uint32_t)r2[2] : (uint32_t)TKZ_RANK_NONE; q.w = c + 4 < n ? (uint32_t)r2[3] : (uint32_t)TKZ_RANK_NONE;
+        ids4[c >> 2] = a; pr4[c >> 2] = q;
+    }
+    for (int w = 0; w < nw; ++w) am[w] = tkz_lowmask32(n - 32 * w);
+    int cnt = n;
+    for (;;) {                                          // while (byteIndicesAndRanks.Count > 1) (:45)
+        uint32_t m = (uint32_t)TKZ_RANK_NONE; int j = 0;
+#pragma unroll 2
+        for (int q = 0; q < (n4 >> 2); ++q) {           // leftmost strict min (:47-54)
+            const uint4 p = pr4[q];
+            if (p.x < m) { m = p.x; j = 4 * q; }
+            if (p.y < m) { m = p.y; j = 4 * q + 1; }
+            if (p.z < m) { m = p.z; j = 4 * q + 2; }
+            if (p.w < m) { m = p.w; j = 4 * q + 3; }
+        }
+        if (m == (uint32_t)TKZ_RANK_NONE) break;        // minRank == int.MaxValue (:65-68)
+        // r: the part being swallowed (next part after j), rr: the one after it, l: the part before j
+        int w = (j + 1) >> 5;
+        uint32_t bits = w < nw ? am[w] & (0xFFFFFFFFu << ((j + 1) & 31)) : 0u;
+        while (!bits && ++w < nw) bits = am[w];
+        const int r = 32 * w + tkz_ctz32(bits);         // exists: pr[j] was a rank
+        bits &= bits - 1;
+        am[w] &= ~(1u << (r & 31));                     // RemoveAt(j + 1) (:63)
+        while (!bits && ++w < nw) bits = am[w];
+        const bool hasr = bits != 0;
+        const int rr = hasr ? 32 * w + tkz_ctz32(bits) : 0;
+        w = j >> 5;
+        bits = am[w] & tkz_lowmask32(j & 31);
+        while (!bits && --w >= 0) bits = am[w];
+        const bool hasl = bits != 0;
+        const int l = hasl ? 32 * w + tkz_msb32(bits) : 0;
+        const uint32_t idr = ids[rr], idl = ids[l];     // (unconditional: see tkz_bpe_lane)
+        uint32_t r1, r2s, l1, l2;
+        tkz_pair_slots(T, m, idr, &r1, &r2s);
+        tkz_pair_slots(T, idl, m, &l1, &l2);
+        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2s]);
+        const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
+        ids[j] = m;                                     // the merged part carries the rank it was found under
+        pr[r] = (uint32_t)TKZ_RANK_NONE;
+        const int32_t rkr = tkz_match_pair(m, idr, vr1, vr2), rkl = tkz_match_pair(idl, m, vl1, vl2);
+        pr[j] = hasr ? (uint32_t)rkr : (uint32_t)TKZ_RANK_NONE;             // (:58)
+        if (hasl) pr[l] = (uint32_t)rkl;                                    // (:59-62)
+        --cnt;
+    }
+    for (int w = 0; w < nw; ++w)
+        for (uint32_t a = am[w]; a; a &= a - 1)
+            if (ids[32 * w + tkz_ctz32(a)] >= (uint32_t)TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;   // ranks[...] throws (:17,:73)
+    return cnt;
+}
+// the tokens of a piece merged by tkz_bpe_lane_var, in order
+TKZ_HD void tkz_bpe_var_emit(const uint32_t* st, int n, int32_t* dst) {
+    const int n4 = tkz_bpe_var_n4(n), nw = (n + 31) >> 5;
+    const uint32_t* am = st + 2 * n4;
+    int i = 0;
+    for (int w = 0; w < nw; ++w)
+        for (uint32_t a = am[w]; a; a &= a - 1) dst[i++] = (int32_t)st[32 * w + tkz_ctz32(a)];
+}
+
 #ifndef TKZ_NO_SIMT
 // ---- workgroup collectives (blockDim.x a multiple of 64, <= 1024) ---------------------------------
 // exclusive prefix sum of v over the workgroup; *total = sum over all threads
@@ -274,57 +360,5 @@ TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, in
     }
     simt::sync();
     return cnt;
-}
-
-// A piece of n >= 2 bytes merged by the whole workgroup one merge at a time (doubly linked list, one workgroup-wide
-// min of (rank, position) per merge).  Used for pieces of a few dozen to a few hundred bytes, where almost every merge
-// has its own rank and rounds would not batch anything.  ids/pr/nxt/prv: n entries each.
-template <class ByteAt>
-TKZ_DEV int tkz_bpe_long_serial(const TkzTables& T, ByteAt at, int n, int32_t* ids, int32_t* pr, int32_t* nxt, int32_t* prv,
-                         int32_t* dst, int* err) {
-    const int tid = simt::tid(), G = simt::nthreads();
-    for (int k = tid; k < n; k += G) {
-        const uint32_t b = at(k);
-        ids[k] = T.byte_rank[b];
-        pr[k] = (k + 1 < n) ? T.bytepair_rank[(b << 8) | at(k + 1)] : TKZ_RANK_NONE;
-        nxt[k] = k + 1; prv[k] = k - 1;
-    }
-    simt::sync();
-    for (;;) {
-        uint64_t key = ~0ull;
-        for (int k = tid; k < n; k += G) {
-            const int32_t r = pr[k];
-            if (r != TKZ_RANK_NONE) { const uint64_t c = ((uint64_t)(uint32_t)r << 32) | (uint32_t)k; key = c < key ? c : key; }
-        }
-        key = tkz_block_min64(key);                     // leftmost minimum (:47-54)
-        if (key == ~0ull) break;                        // (:65-68)
-        if (tid == 0) {
-            const int j = (int)(uint32_t)key;
-            const int32_t m = (int32_t)(key >> 32);
-            const int r = nxt[j], rr = nxt[r];
-            ids[j] = m; ids[r] = -1; pr[r] = TKZ_RANK_NONE;   // RemoveAt(j + 1) (:63)
-            nxt[j] = rr;
-            if (rr < n) prv[rr] = j;
-            pr[j] = rr < n ? tkz_lookup_pair(T, (uint32_t)m, (uint32_t)ids[rr]) : TKZ_RANK_NONE;    // (:58)
-            const int l = prv[j];
-            if (l >= 0) pr[l] = tkz_lookup_pair(T, (uint32_t)ids[l], (uint32_t)m);                  // (:59-62)
-        }
-        simt::sync();
-    }
-    // emit surviving parts in order (:70-75)
-    const int c = (n + G - 1) / G;
-    const int lo = tid * c < n ? tid * c : n, hi = lo + c < n ? lo + c : n;
-    int cnt = 0;
-    for (int k = lo; k < hi; ++k) cnt += ids[k] != -1;
-    int tot;
-    int i = tkz_block_scan(cnt, &tot);
-    for (int k = lo; k < hi; ++k) {
-        const int32_t id = ids[k];
-        if (id == -1) continue;
-        if (id >= TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;
-        dst[i++] = id;
-    }
-    simt::sync();
-    return tot;
 }
 #endif  // TKZ_NO_SIMT

@@ -12,8 +12,8 @@ constexpr int kThreads = 256;       // workgroup size of every kernel (4 wavefro
 constexpr int kSub = 1024;          // bytes of corpus per wavefront of k_encode_waves (a "sub-tile")
 constexpr int kHalo = 64;           // bytes staged past the sub-tile (a short piece may straddle the edge)
 constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one-per-lane by k_encode_waves
-constexpr int kMedMax = 32;         // ... and up to this many by k_encode_waves_heavy (sub-tiles that have such a piece)
-constexpr int kLdsLong = 320;       // pieces up to this many bytes are merged by the wavefront in LDS (one merge at a time); longer: rounds, arrays in the pool
+constexpr int kArenaDwords = 2560;  // LDS arena of k_encode_waves_heavy: the misses of a pass get 2 dwords + 1 bit per byte out of it
+constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (tkz_bpe_var_dwords(1024) <= kArenaDwords)
 constexpr int kPassBatches = 5;     // batches of 64 pieces whose lookups are in flight together (a 1 KiB sub-tile averages ~280 pieces)
 constexpr int kPassPieces = 64 * kPassBatches;
 constexpr int kLeanPieces = 512;    // k_encode_waves keeps this many piece positions; denser sub-tiles go to the heavy kernel
@@ -35,7 +35,7 @@ struct EncodeParams {
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
     int32_t* counters;            // [0] error bits
     int64_t* heavy_q; unsigned long long* heavy_count;                    // sub-tiles deferred to k_encode_waves_heavy
-    int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kLdsLong (int32 units)
+    int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)
     unsigned long long* devprof;  // development only: cycle counters (ablate bit 4)
     int32_t ablate;               // development only: bit0 skip merges, bit1 skip table probes, bit2 skip stores, bit3 stage 0/1 only
 };

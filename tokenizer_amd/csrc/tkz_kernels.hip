@@ -297,6 +297,15 @@ TKZ_DEV int tkz_wave_scan(int v, int* total) {
     return pre;
 }
 
+// exclusive prefix sum over the wave of any non-negative value
+TKZ_DEV int tkz_wave_scan_sum(int v, int* total) {
+    const int lane = simt::lane();
+    int x = v;
+    for (int d = 1; d < 64; d <<= 1) { const int y = simt::shfl_up(x, d); if (lane >= d) x += y; }
+    *total = simt::shfl(x, 63);
+    return x - v;
+}
+
 // HEAVY = false: the common case, sub-tiles whose pieces are all <= 16 bytes; a sub-tile with a longer piece is
 //                 appended to P.heavy_q and left to the second launch.
 // HEAVY = true:   the deferred sub-tiles: lanes merge pieces of up to 32 bytes (16 at a time, 32-entry state each:
@@ -305,22 +314,24 @@ template <bool HEAVY>
 TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub);
 
 TKZ_KERNEL_OCC(64, 5) void k_encode_waves(TkzTables T, EncodeParams P) { tkz_encode_subtile<false>(T, P, simt::bid()); }
-TKZ_KERNEL_OCC(64, 4) void k_encode_waves_heavy(TkzTables T, EncodeParams P) {
+TKZ_KERNEL_OCC(64, 3) void k_encode_waves_heavy(TkzTables T, EncodeParams P) {
     const int64_t n = *P.heavy_count;
     for (int64_t q = simt::bid(); q < n; q += simt::nblocks()) { tkz_encode_subtile<true>(T, P, P.heavy_q[q]); simt::sync(); }
 }
 
 template <bool HEAVY>
 TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub) {
-    constexpr int NMAX = HEAVY ? 32 : 16;                 // bytes a lane can merge
-    constexpr int LANE_MAX = HEAVY ? kMedMax : kShortMax; // pieces up to this many bytes are handled one per lane
-    constexpr int ML = HEAVY ? kMergeLanes / 2 : kMergeLanes;
+    constexpr int NMAX = 16;                              // bytes a lean lane can merge (state in a fixed 2 x 16 dword slot)
+    constexpr int LANE_MAX = HEAVY ? kArenaPiece : kShortMax;   // pieces up to this many bytes are handled one per lane
+    constexpr int ML = HEAVY ? 64 : kMergeLanes;          // misses merged per pass (heavy: as many as fit the arena)
     constexpr int STRIDE = TkzBpeGeom<NMAX>::kStride;
     TKZ_SHARED uint32_t s_bytes[(kSub + kHalo) / 4];
     TKZ_SHARED uint16_t s_pstart[(HEAVY ? kSub : kLeanPieces) + 2];
-    TKZ_SHARED uint4 s_scr4[(2 * STRIDE * ML) / 4 > (4 * kLdsLong) / 4 ? (2 * STRIDE * ML) / 4 : (4 * kLdsLong) / 4];   // short: per lane ids[16] | pr[16] (stride kBpeLaneStride); long: 4 arrays of kLdsLong
-    TKZ_SHARED uint16_t s_missq[ML + 1];                  // start | (len - 1) << 11 (only the misses a pass can merge are kept)
-    TKZ_SHARED uint32_t s_minfo[kMergeLanes];                      // per merged miss: alive mask (its tokens stay in that lane's ids[])
+    // lean: per merging lane ids[16] | pr[16] (lane stride kBpeLaneStride); heavy: the arena the misses of a pass share
+    TKZ_SHARED uint4 s_scr4[(HEAVY ? kArenaDwords : 2 * STRIDE * kMergeLanes) / 4];
+    TKZ_SHARED uint16_t s_missq[HEAVY ? 2 : ML + 1];      // lean: start | (len - 1) << 11 (only the misses a pass can merge are kept)
+    TKZ_SHARED uint32_t s_missq_h[HEAVY ? 64 : 1];        // heavy: start | (len - 1) << 11 | (arena offset / 4) << 21
+    TKZ_SHARED uint32_t s_minfo[ML];                      // per merged miss: lean alive mask / heavy token count (tokens stay in its state)
     TKZ_SHARED uint64_t s_longmask[kSub / 64];
     TKZ_SHARED int s_i0;
     TKZ_SHARED int64_t s_l0;
@@ -330,6 +341,7 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
     const int nb = (int)(P.total - base < kSub ? P.total - base : kSub);
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_bytes);
     uint32_t* s_scr = reinterpret_cast<uint32_t*>(s_scr4);
+    const uint8_t* gbase = P.bytes + base;                // bytes of a piece that runs past the halo come from memory
 
     const bool prof = (P.ablate & 16) != 0;
     long long t_start = prof ? simt::clock() : 0, t_a = 0, t_m = 0, t_c = 0, t_01 = 0, n_iter = 0, n_round = 0, n_miss = 0;
@@ -452,7 +464,7 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
             // ---------------- stage B: resolve, compact the misses ----------------
             int cnt[kPassBatches], qidx[kPassBatches];
             int32_t tok[kPassBatches];
-            int nmiss = 0;
+            int nmiss = 0, aused = 0, kcut = kend;
 #pragma unroll
             for (int g = 0; g < kPassBatches; g += 3) {
                 // both cuckoo slots of three batches in flight together; issued unconditionally (slot 0 for idle lanes): a load
@@ -471,34 +483,61 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                     if (plen[b] > 0) {
                         int32_t rank;
                         if (plen[b] <= TKZ_SHORT_KEY_MAX) rank = tkz_match_short(q0[b], q1[b], q2[b], (uint32_t)plen[b], pv1[t], pv2[t]);
-                        else { const int s = ps[b]; rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)plen[b]); }
+                        else {
+                            const int s = ps[b];
+                            if (HEAVY) rank = tkz_lookup_long(T, [&](int i) -> uint32_t { const int p = s + i; return p < kSub + kHalo ? sb[p] : gbase[p]; }, (uint32_t)plen[b]);
+                            else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)plen[b]);
+                        }
                         if (rank != TKZ_RANK_NONE) { cnt[b] = 1; tok[b] = rank; }      // TikTokenizer.cs:262-265
                         else miss = true;
                     }
                     const uint64_t mm = simt::ballot(miss);
-                    if (miss) { qidx[b] = nmiss + tkz_popc64(mm & tkz_lowmask(lane)); if (qidx[b] < ML) s_missq[qidx[b]] = (uint16_t)((uint32_t)ps[b] | ((uint32_t)(plen[b] - 1) << 11)); }
-                    nmiss += tkz_popc64(mm);
+                    if (HEAVY) {
+                        // every miss gets a span of the arena sized for it; the first one that does not fit ends the pass
+                        const int need = miss ? tkz_bpe_var_dwords(plen[b]) : 0;
+                        int btot;
+                        const int aoff = aused + tkz_wave_scan_sum(need, &btot);
+                        const int qi = nmiss + tkz_popc64(mm & tkz_lowmask(lane));
+                        const bool fits = miss && qi < ML && aoff + need <= kArenaDwords;
+                        const uint64_t bad = simt::ballot(miss && !fits);
+                        if (bad && kcut == kend) kcut = k0 + 64 * b + tkz_ctz64(bad);
+                        if (fits) { qidx[b] = qi; s_missq_h[qi] = (uint32_t)ps[b] | ((uint32_t)(plen[b] - 1) << 11) | ((uint32_t)(aoff >> 2) << 21); }
+                        nmiss += tkz_popc64(mm & ~bad);
+                        aused += btot;
+                    } else {
+                        if (miss) { qidx[b] = nmiss + tkz_popc64(mm & tkz_lowmask(lane)); if (qidx[b] < ML) s_missq[qidx[b]] = (uint16_t)((uint32_t)ps[b] | ((uint32_t)(plen[b] - 1) << 11)); }
+                        nmiss += tkz_popc64(mm);
+                    }
                 }
             }
-            // one merge round per pass: if more than kMergeLanes pieces missed, the pass ends before the next one (it is redone next pass)
-            int kcut = kend;
-            if (nmiss > ML) {
+            // one merge round per pass: if more pieces missed than it has room for, the pass ends before the first one left over
+            // (the pieces from there on are redone next pass)
+            if (!HEAVY && nmiss > ML) {
 #pragma unroll
                 for (int b = 0; b < kPassBatches; ++b) {
                     const uint64_t m = simt::ballot(qidx[b] == ML);
                     if (m) kcut = k0 + 64 * b + tkz_ctz64(m);
                 }
+                nmiss = ML;
+            }
+            if (kcut < kend) {
 #pragma unroll
                 for (int b = 0; b < kPassBatches; ++b)
                     if (k0 + 64 * b + lane >= kcut) { plen[b] = 0; cnt[b] = 0; qidx[b] = -1; }
-                nmiss = ML;
             }
             simt::sync();
             if (prof) { const long long t1 = simt::clock(); t_a += t1 - t0; t0 = t1; n_miss += nmiss; }
             // ---------------- stage M: BytePairEncode of the misses (TikTokenizer.cs:268), one per lane ----------------
             {
                 int err1 = 0;
-                if (lane < nmiss) {
+                if (HEAVY) {
+                    if (lane < nmiss) {
+                        const uint32_t e = s_missq_h[lane];
+                        const int s = (int)(e & 0x7FFu), len = (int)((e >> 11) & 0x3FFu) + 1;
+                        s_minfo[lane] = (uint32_t)tkz_bpe_lane_var(T, [&](int i) -> uint32_t { const int p = s + i; return p < kSub + kHalo ? sb[p] : gbase[p]; },
+                                                                   len, &s_scr[4 * (e >> 21)], &err1);
+                    }
+                } else if (lane < nmiss) {
                     uint32_t alive = 1;
                     if (P.ablate & 1) ids[0] = 0;
                     else {
@@ -520,9 +559,9 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
 #pragma unroll
             for (int b = 0; b < kPassBatches; ++b) {
                 uint32_t alive = 0;
-                if (qidx[b] >= 0) { alive = s_minfo[qidx[b]]; cnt[b] = tkz_popc32(alive); }
+                if (qidx[b] >= 0) { alive = s_minfo[qidx[b]]; cnt[b] = HEAVY ? (int)alive : tkz_popc32(alive); }
                 int tot;
-                const int pos = running + tkz_wave_scan<HEAVY ? 6 : 5>(cnt[b], &tot);   // a lane holds up to NMAX tokens
+                const int pos = running + tkz_wave_scan<HEAVY ? 11 : 5>(cnt[b], &tot);   // a lane holds up to 16 (heavy: kArenaPiece) tokens
                 const int s = ps[b], w = (s >> 6) & 15;
                 const uint32_t dlo = simt::shflu((uint32_t)mydoc, w), dhi = simt::shflu((uint32_t)(mydoc >> 32), w);
                 const int dpre = simt::shfl(docpre, w);
@@ -530,6 +569,10 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                     int32_t* dst = P.tmp + first_abs + pos;
                     if (P.ablate & 4) {}
                     else if (qidx[b] < 0) dst[0] = tok[b];
+                    else if (HEAVY) {
+                        const uint32_t e = s_missq_h[qidx[b]];
+                        tkz_bpe_var_emit(&s_scr[4 * (e >> 21)], (int)((e >> 11) & 0x3FFu) + 1, dst);
+                    }
                     else { const uint32_t* src = &s_scr[qidx[b] * STRIDE]; int i = 0; for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)src[tkz_ctz32(a)]; }
                     const uint64_t dw = ((uint64_t)dhi << 32) | dlo;
                     if ((dw >> (s & 63)) & 1ull) P.doc_tok[docord0 + dpre + tkz_popc64(dw & tkz_lowmask(s & 63))] = pos;
@@ -563,10 +606,10 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                 const int32_t whole = s_i0;
                 if (whole != TKZ_RANK_NONE) { if (lane == 0) dst[0] = whole; cnt1 = 1; }
                 else {
-                    int32_t* arr = reinterpret_cast<int32_t*>(s_scr);
-                    int stride = kLdsLong;
+                    int32_t* arr = nullptr;
+                    int stride = 0;
                     bool ok = true;
-                    if (len > kLdsLong) {                 // arrays in the global pool
+                    {                                     // arrays in the global pool
                         if (lane == 0) {
                             const unsigned long long need = 6ull * (unsigned long long)len;
                             const unsigned long long o = simt::atomic_add64(P.pool_head, need);
@@ -576,8 +619,7 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                         if (s_l0 < 0) { ok = false; err |= kErrPool; }
                         else { arr = P.pool + s_l0; stride = len; }
                     }
-                    if (ok && len <= kLdsLong) cnt1 = tkz_bpe_long_serial(T, at, len, arr, arr + stride, arr + 2 * stride, arr + 3 * stride, dst, &err);
-                    else if (ok) cnt1 = tkz_bpe_long(T, at, len, arr, arr + stride, arr + 2 * stride, arr + 3 * stride, arr + 4 * stride, arr + 5 * stride, dst, &err);
+                    if (ok) cnt1 = tkz_bpe_long(T, at, len, arr, arr + stride, arr + 2 * stride, arr + 3 * stride, arr + 4 * stride, arr + 5 * stride, dst, &err);
                 }
                 simt::sync();
             }
