@@ -18,7 +18,9 @@
 namespace {
 
 thread_local std::string g_err;
-unsigned long long* g_devprof = nullptr;   // development only (TKZ_DEV_ABLATE bit 4)
+#ifdef TKZ_DEVPROF
+unsigned long long* g_devprof = nullptr;   // development builds only (make DEVPROF=1, env TKZ_DEV_ABLATE bit 4)
+#endif
 
 tkz_status fail(tkz_status s, const std::string& msg) { g_err = msg; return s; }
 
@@ -175,12 +177,15 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             P.heavy_q = e->w_heavyq.as<int64_t>();
             P.heavy_count = reinterpret_cast<unsigned long long*>(e->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
             P.pool = e->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(e->w_pool.cap / 4);
+            P.ablate = 0; P.devprof = nullptr;
+#ifdef TKZ_DEVPROF
             { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
             if (P.ablate & 16) {
                 if (!g_devprof) { HIP_TRY(hipMalloc((void**)&g_devprof, 16 * 8)); }
                 HIP_TRY(hipMemsetAsync(g_devprof, 0, 16 * 8, stream));
             }
             P.devprof = g_devprof;
+#endif
             int64_t* ndocstarts = reinterpret_cast<int64_t*>(e->w_counters.as<char>() + offsetof(CounterBlock, ndocstarts));
             launch_doccount(L, docbits, nwords, ntiles, e->w_dcount.as<int32_t>());
             launch_scan(L, e->w_dcount.as<int32_t>(), ntiles, e->w_bsum.as<int64_t>(), e->w_dbase.as<int64_t>(), ndocstarts, -1);
@@ -193,6 +198,7 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
         if (e->profiling) prof_collect(e);
+#ifdef TKZ_DEVPROF
         if (g_devprof && getenv("TKZ_DEV_ABLATE") && (atoi(getenv("TKZ_DEV_ABLATE")) & 16) && !d_bitmap_only) {
             unsigned long long h[16];
             HIP_TRY(hipMemcpy(h, g_devprof, sizeof h, hipMemcpyDeviceToHost));
@@ -200,6 +206,7 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             fprintf(stderr, "[tkz devprof] waves %llu  cycles/wave: total %.0f stage01 %.0f stageAB %.0f stageM %.0f stageC %.0f | rounds/wave %.2f misses/wave %.1f pieces/wave %.1f\n",
                     h[0], h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w, h[8] / w);
         }
+#endif
         const int32_t err = e->h_counters->err;
         if (err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the byte count");
         if (err & kErrUtf8) return fail(TKZ_E_INVALID_UTF8, "input is not well-formed UTF-8 (or a document boundary falls inside a character)");

@@ -24,6 +24,12 @@ constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count sca
 
 enum { K_DOCMARK = 0, K_PRETOK = 1, K_ENCODE = 2, K_SCAN = 3, K_GATHER = 4, K_DOCOFFS = 5, K_COUNT = 6 };
 
+#ifdef TKZ_DEVPROF
+#define TKZ_DEV_FLAG(P, bit) (((P).ablate & (bit)) != 0)
+#else
+#define TKZ_DEV_FLAG(P, bit) false
+#endif
+
 struct EncodeParams {
     const uint8_t* bytes; int64_t total;
     const uint64_t* startbits; const uint64_t* docbits; int64_t nwords;   // 1 bit / byte, nwords = total/64 + 1
@@ -36,8 +42,10 @@ struct EncodeParams {
     int32_t* counters;            // [0] error bits
     int64_t* heavy_q; unsigned long long* heavy_count;                    // sub-tiles deferred to k_encode_waves_heavy
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)
-    unsigned long long* devprof;  // development only: cycle counters (ablate bit 4)
-    int32_t ablate;               // development only: bit0 skip merges, bit1 skip table probes, bit2 skip stores, bit3 stage 0/1 only
+    // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE): per-stage cycle counters (bit 4) and ablations
+    // (bit0 skip merges, bit1 skip table probes, bit2 skip stores, bit3 stage 0/1 only).  Compiled out of libtkz.so otherwise.
+    unsigned long long* devprof;
+    int32_t ablate;
 };
 
 typedef void (*KernelHook)(void* ctx, int kernel_id, int phase /*0 before, 1 after*/, hipStream_t s);

@@ -343,8 +343,8 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
     uint32_t* s_scr = reinterpret_cast<uint32_t*>(s_scr4);
     const uint8_t* gbase = P.bytes + base;                // bytes of a piece that runs past the halo come from memory
 
-    const bool prof = (P.ablate & 16) != 0;
-    long long t_start = prof ? simt::clock() : 0, t_a = 0, t_m = 0, t_c = 0, t_01 = 0, n_iter = 0, n_round = 0, n_miss = 0;
+    const bool prof = TKZ_DEV_FLAG(P, 16);
+    long long t_start = prof ? simt::clock() : 0, t_a = 0, t_m = 0, t_c = 0, t_01 = 0, n_round = 0, n_miss = 0;
     // ---- stage 0 ----
     for (int i = lane; i < (kSub + kHalo) / 16; i += 64) {
         const int64_t pos = base + 16 * (int64_t)i;
@@ -422,9 +422,9 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
     int running = 0;                                      // tokens of this sub-tile so far (uniform)
     int err = 0;
     int k0 = 0;
-    if (P.ablate & 8) k0 = np;
-    uint32_t* ids = &s_scr[(lane & (ML - 1)) * STRIDE];
-    uint32_t* pr = &s_scr[STRIDE * ML + (lane & (ML - 1)) * STRIDE];
+    if (TKZ_DEV_FLAG(P, 8)) k0 = np;
+    uint32_t* ids = &s_scr[(lane % ML) * STRIDE];
+    uint32_t* pr = &s_scr[STRIDE * ML + (lane % ML) * STRIDE];
     while (k0 < np) {
         int next_long = np;
         if (nlong > 0) {
@@ -472,8 +472,8 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                 uint4 pv1[3], pv2[3];
 #pragma unroll
                 for (int t = 0; t < 3 && g + t < kPassBatches; ++t) {
-                    pv1[t] = tkz_load16(&T.short_slots[(P.ablate & 2) ? 0u : slot1[g + t]]);
-                    pv2[t] = tkz_load16(&T.short_slots[(P.ablate & 2) ? 0u : slot2[g + t]]);
+                    pv1[t] = tkz_load16(&T.short_slots[TKZ_DEV_FLAG(P, 2) ? 0u : slot1[g + t]]);
+                    pv2[t] = tkz_load16(&T.short_slots[TKZ_DEV_FLAG(P, 2) ? 0u : slot2[g + t]]);
                 }
 #pragma unroll
                 for (int t = 0; t < 3 && g + t < kPassBatches; ++t) {
@@ -539,7 +539,7 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                     }
                 } else if (lane < nmiss) {
                     uint32_t alive = 1;
-                    if (P.ablate & 1) ids[0] = 0;
+                    if (TKZ_DEV_FLAG(P, 1)) ids[0] = 0;
                     else {
                         const uint32_t e = s_missq[lane];
                         const int s = (int)(e & 0x7FFu), len = (int)(e >> 11) + 1;
@@ -567,7 +567,7 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                 const int dpre = simt::shfl(docpre, w);
                 if (plen[b] > 0) {
                     int32_t* dst = P.tmp + first_abs + pos;
-                    if (P.ablate & 4) {}
+                    if (TKZ_DEV_FLAG(P, 4)) {}
                     else if (qidx[b] < 0) dst[0] = tok[b];
                     else if (HEAVY) {
                         const uint32_t e = s_missq_h[qidx[b]];
