@@ -159,7 +159,18 @@ def main():
             o_ids, o_counts = O.encode_batch(ov, args.pattern, h_bytes, h_offs, threads=threads)
             tcpu = time.perf_counter() - tc
             same = len(o_ids) == len(h_ids) and np.array_equal(o_ids, h_ids) and np.array_equal(np.diff(h_ooffs), o_counts)
-            parity_note = ("bit-exact vs oracle on %d docs / %d tokens" % (ns, len(o_ids))) if same else "MISMATCH vs oracle on the sample"
+            # (not timed) the LAST documents of the batch too, and the offsets of the whole batch: placement at large indices
+            nt = min(20_000, n_docs)
+            t_offs = d_offs[n_docs - nt:n_docs + 1].cpu().numpy()
+            t_bytes = d_bytes[int(t_offs[0]):int(t_offs[-1])].cpu().numpy()
+            t_ooffs = d_ooffs[n_docs - nt:n_docs + 1].cpu().numpy()
+            t_ids = d_ids[int(t_ooffs[0]):int(t_ooffs[-1])].cpu().numpy()
+            p_ids, p_counts = O.encode_batch(ov, args.pattern, t_bytes, t_offs - t_offs[0], threads=threads)
+            same = same and np.array_equal(p_ids, t_ids) and np.array_equal(np.diff(t_ooffs), p_counts)
+            same = same and int(d_ooffs[0].item()) == 0 and int(d_ooffs[n_docs].item()) == n_tokens_rank \
+                and bool((d_ooffs[1:n_docs + 1] >= d_ooffs[:n_docs]).all().item())
+            parity_note = ("bit-exact vs oracle on the first %d and the last %d docs (%d tokens); offsets of all %d docs monotone, ending at the token count"
+                           % (ns, nt, len(o_ids) + len(p_ids), n_docs)) if same else "MISMATCH vs oracle on the sample"
             cpu = {"value": round(nb / tcpu / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port",
                    "sample": "first %d documents (%.1f MB) of the same corpus, reference-algorithm CPU restatement (oracle/), "
                              "8192-entry LRU memo per thread, %d threads of %d host cores" % (ns, nb / 1e6, threads, os.cpu_count() or 1)}

@@ -641,11 +641,15 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
 
 // documents that start in each sub-tile (for the document ordinals)
 TKZ_KERNEL(256) void k_doccount(const uint64_t* docbits, int64_t nwords, int64_t nsub, int32_t* cnt) {
-    const int64_t stride = simt::nblocks() * simt::nthreads();
-    for (int64_t s = simt::bid() * simt::nthreads() + simt::tid(); s < nsub; s += stride) {
-        int c = 0;
-        for (int j = 0; j < kSub / 64; ++j) { const int64_t w = s * (kSub / 64) + j; if (w < nwords) c += tkz_popc64(docbits[w]); }
-        cnt[s] = c;
+    // one lane per bitmap word (coalesced), the kSub/64 = 16 words of a sub-tile summed across 16 lanes
+    static_assert(kSub / 64 == 16, "k_doccount sums 16 lanes per sub-tile");
+    const int lane = simt::lane();
+    const int64_t stride = simt::nblocks() * simt::nthreads(), nw = nsub * (kSub / 64);
+    for (int64_t w0 = simt::bid() * simt::nthreads() + (simt::tid() & ~63); w0 < nw; w0 += stride) {
+        const int64_t w = w0 + lane;
+        int c = (w < nw && w < nwords) ? tkz_popc64(docbits[w]) : 0;
+        c += simt::shfl_xor(c, 1); c += simt::shfl_xor(c, 2); c += simt::shfl_xor(c, 4); c += simt::shfl_xor(c, 8);
+        if ((lane & 15) == 0 && w < nw) cnt[w >> 4] = c;
     }
 }
 
@@ -665,14 +669,28 @@ TKZ_KERNEL(256) void k_scan_partials(const int32_t* cnt, int64_t n, int64_t* bsu
     simt::sync();
     if (simt::tid() == 0) bsum[simt::bid()] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
-TKZ_KERNEL(256) void k_scan_top(int64_t* bsum, int64_t nblk, int64_t* grand) {   // one workgroup, serial over chunks
-    TKZ_SHARED int64_t s_carry;
-    if (simt::tid() == 0) {
-        int64_t run = 0;
-        for (int64_t i = 0; i < nblk; ++i) { const int64_t v = bsum[i]; bsum[i] = run; run += v; }
-        *grand = run; s_carry = run;
+TKZ_KERNEL(256) void k_scan_top(int64_t* bsum, int64_t nblk, int64_t* grand) {   // one workgroup, kThreads partial sums per step
+    TKZ_SHARED int64_t s_w[kThreads / 64];
+    const int lane = simt::lane(), wave = simt::wave();
+    int64_t carry = 0;
+    for (int64_t i0 = 0; i0 < nblk; i0 += kThreads) {
+        const int64_t i = i0 + simt::tid();
+        const int64_t v = i < nblk ? bsum[i] : 0;
+        int64_t x = v;                                   // inclusive scan inside the wavefront
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t lo = simt::shflu((uint32_t)x, lane - d < 0 ? lane : lane - d);
+            const uint32_t hi = simt::shflu((uint32_t)((uint64_t)x >> 32), lane - d < 0 ? lane : lane - d);
+            if (lane >= d) x += (int64_t)(((uint64_t)hi << 32) | lo);
+        }
+        if (lane == 63) s_w[wave] = x;
+        simt::sync();
+        int64_t woff = 0, tot = 0;
+        for (int w = 0; w < kThreads / 64; ++w) { const int64_t t = s_w[w]; if (w < wave) woff += t; tot += t; }
+        simt::sync();
+        if (i < nblk) bsum[i] = carry + woff + x - v;
+        carry += tot;
     }
-    simt::sync();
+    if (simt::tid() == 0) *grand = carry;
 }
 TKZ_KERNEL(256) void k_scan_final(const int32_t* cnt, int64_t n, const int64_t* boff, int64_t* base) {
     const int64_t i0 = simt::bid() * kScanBlock;
@@ -789,7 +807,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     hook(L, K_ENCODE, 1);
 }
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t nsub, int32_t* cnt) {
-    TKZ_LAUNCH(k_doccount, grid_for(nsub), kThreads, L.stream, docbits, nwords, nsub, cnt);
+    TKZ_LAUNCH(k_doccount, grid_for(nsub * (kSub / 64)), kThreads, L.stream, docbits, nwords, nsub, cnt);
 }
 void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid) {
     const int64_t nblk = cdiv(ntiles, kScanBlock);
