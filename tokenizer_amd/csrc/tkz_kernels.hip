@@ -708,14 +708,44 @@ TKZ_KERNEL(256) void k_scan_final(const int32_t* cnt, int64_t n, const int64_t* 
 // -------------------------------------------------------------------------------------------------
 // k_gather / k_docoffs
 // -------------------------------------------------------------------------------------------------
+constexpr int kGatherTiles = 4;     // sub-tiles copied per wavefront of k_gather (their output spans are back to back)
 TKZ_KERNEL(256) void k_gather(const int32_t* tmp, const int32_t* tile_count, const int64_t* tile_first, const int64_t* tile_base,
                               int64_t nsub, int32_t* out, int64_t out_cap) {
-    const int64_t t = simt::bid() * (kThreads / 64) + simt::wave();     // one wavefront per sub-tile
-    if (t >= nsub) return;
-    const int cnt = tile_count[t];
-    const int32_t* src = tmp + tile_first[t];
-    const int64_t b = tile_base[t];
-    for (int i = simt::lane(); i < cnt; i += 64) if (b + i < out_cap) out[b + i] = src[i];
+    const int lane = simt::lane();
+    const int64_t t0 = (simt::bid() * (kThreads / 64) + simt::wave()) * kGatherTiles;
+    if (t0 >= nsub) return;
+    // the metadata of the group: one tile per lane, then broadcast
+    int cl = 0; int64_t fl = 0, bl = 0;
+    if (lane < kGatherTiles && t0 + lane < nsub) { cl = tile_count[t0 + lane]; fl = tile_first[t0 + lane]; bl = tile_base[t0 + lane]; }
+    int pre[kGatherTiles + 1]; int64_t first[kGatherTiles];
+    pre[0] = 0;
+#pragma unroll
+    for (int q = 0; q < kGatherTiles; ++q) {
+        pre[q + 1] = pre[q] + simt::shfl(cl, q);
+        first[q] = (int64_t)(((uint64_t)simt::shflu((uint32_t)((uint64_t)fl >> 32), q) << 32) | simt::shflu((uint32_t)fl, q));
+    }
+    const int64_t b0 = (int64_t)(((uint64_t)simt::shflu((uint32_t)((uint64_t)bl >> 32), 0) << 32) | simt::shflu((uint32_t)bl, 0));
+    const int total = pre[kGatherTiles];
+    constexpr int U = 4;                // loads in flight per lane
+    for (int i0 = 0; i0 < total; i0 += 64 * U) {
+        int32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 64 * u + lane;
+            int q = 0;
+#pragma unroll
+            for (int k = 1; k < kGatherTiles; ++k) q += i >= pre[k];
+            int64_t f = first[0]; int p = 0;
+#pragma unroll
+            for (int k = 1; k < kGatherTiles; ++k) if (q == k) { f = first[k]; p = pre[k]; }
+            v[u] = i < total ? tmp[f + (i - p)] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + 64 * u + lane;
+            if (i < total && b0 + i < out_cap) out[b0 + i] = v[u];
+        }
+    }
 }
 TKZ_KERNEL(256) void k_docoffs(const int64_t* offs, int64_t n_docs, int64_t total, const int64_t* tile_base, const uint64_t* docbits,
                                const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs) {
@@ -820,7 +850,7 @@ void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int
 void launch_gather(const Launch& L, const int32_t* tmp, const int32_t* tile_count, const int64_t* tile_first,
                    const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
     hook(L, K_GATHER, 0);
-    TKZ_LAUNCH(k_gather, cdiv(nsub, kThreads / 64), kThreads, L.stream, tmp, tile_count, tile_first, tile_base, nsub, out, out_cap);
+    TKZ_LAUNCH(k_gather, cdiv(nsub, (kThreads / 64) * kGatherTiles), kThreads, L.stream, tmp, tile_count, tile_first, tile_base, nsub, out, out_cap);
     hook(L, K_GATHER, 1);
 }
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
