@@ -128,21 +128,29 @@ TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, 
     const int n4 = tkz_bpe_var_n4(n), nw = (n + 31) >> 5;
     uint32_t* ids = st; uint32_t* pr = st + n4; uint32_t* am = st + 2 * n4;
     uint4* ids4 = reinterpret_cast<uint4*>(ids); uint4* pr4 = reinterpret_cast<uint4*>(pr);
+    // first-level state, 16 bytes per step: all 32 gathers of a step are in flight together
 #pragma unroll 1
-    for (int c = 0; c < n4; c += 4) {
-        uint32_t b[5];
+    for (int c = 0; c < n4; c += 16) {
+        uint32_t b[17];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) b[k] = c + k < n ? at(c + k) : 0u;
-        uint32_t idv[4]; int32_t r2[4];
+        for (int k = 0; k < 17; ++k) b[k] = c + k < n ? at(c + k) : 0u;
+        uint32_t idv[16]; int32_t r2[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) idv[k] = (uint32_t)T.byte_rank[b[k]];                       // parts = single bytes
+        for (int k = 0; k < 16; ++k) idv[k] = (uint32_t)T.byte_rank[b[k]];                      // parts = single bytes
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r2[k] = T.bytepair_rank[(b[k] << 8) | b[k + 1]];            // initial pair ranks (:37-44)
-        uint4 a, q;
-        a.x = idv[0]; a.y = idv[1]; a.z = idv[2]; a.w = idv[3];
-        q.x = c + 1 < n ? (uint32_t)r2[0] : (uint32_t)TKZ_RANK_NONE; q.y = c + 2 < n ? (uint32_t)r2[1] : (uint32_t)TKZ_RANK_NONE;
-        q.z = c + 3 < n ? (uint32_t)r2[2] : (uint32_t)TKZ_RANK_NONE; q.w = c + 4 < n ? (uint32_t)r2[3] : (uint32_t)TKZ_RANK_NONE;
-        ids4[c >> 2] = a; pr4[c >> 2] = q;
+        for (int k = 0; k < 16; ++k) r2[k] = T.bytepair_rank[(b[k] << 8) | b[k + 1]];           // initial pair ranks (:37-44)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (c + 4 * q < n4) {
+                uint4 a, p;
+                a.x = idv[4 * q]; a.y = idv[4 * q + 1]; a.z = idv[4 * q + 2]; a.w = idv[4 * q + 3];
+                p.x = c + 4 * q + 1 < n ? (uint32_t)r2[4 * q] : (uint32_t)TKZ_RANK_NONE;
+                p.y = c + 4 * q + 2 < n ? (uint32_t)r2[4 * q + 1] : (uint32_t)TKZ_RANK_NONE;
+                p.z = c + 4 * q + 3 < n ? (uint32_t)r2[4 * q + 2] : (uint32_t)TKZ_RANK_NONE;
+                p.w = c + 4 * q + 4 < n ? (uint32_t)r2[4 * q + 3] : (uint32_t)TKZ_RANK_NONE;
+                ids4[(c >> 2) + q] = a; pr4[(c >> 2) + q] = p;
+            }
+        }
     }
     for (int w = 0; w < nw; ++w) am[w] = tkz_lowmask32(n - 32 * w);
     int cnt = n;
