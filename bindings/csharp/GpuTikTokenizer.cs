@@ -5,7 +5,8 @@
 // Drop it into Tokenizer_C#/TokenizerLib next to TikTokenizer.cs.  It keeps the two Encode overloads of
 // ITokenizer (ITokenizer.cs:12,28) and adds EncodeBatch; special-token segmentation is the reference's own
 // EncodeInternal / FindNextSpecialToken (TikTokenizer.cs:141-170,230-241) with the plain segments sent to the
-// GPU in one batch.  Trim variants and Decode delegate to a CPU TikTokenizer (they are not on the hot path).
+// GPU in one batch.  The trim variants (TikTokenizer.cs:288-579) get the token count and length of every regex piece
+// from tkz_encode_batch_pieces_utf8 and decide the cut on the host; Decode delegates to a CPU TikTokenizer.
 using System;
 using System.Collections.Generic;
 using System.IO;
@@ -29,6 +30,9 @@ namespace Microsoft.DeepDev
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_utf8(IntPtr encoder, byte* bytes, long* docOffsets, long nDocs,
                                                                                   int* outIds, long outCap, long* outOffsets, out long needed);
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_utf16(IntPtr encoder, char* text, long len, int* outIds, long outCap, out long nOut);
+        [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_pieces_utf8(IntPtr encoder, byte* bytes, long* docOffsets, long nDocs, int* outIds, long outCap,
+                                                                                         long* docPieceOffsets, long* pieceByteOffsets, long* pieceTokenOffsets,
+                                                                                         long pieceCap, out long nPieces, out long neededIds);
 
         internal static void Check(int status)
         {
@@ -52,7 +56,7 @@ namespace Microsoft.DeepDev
         private readonly IReadOnlyDictionary<string, int> specialTokensEncoder;
         private readonly HashSet<string> specialTokens;
         private readonly Regex specialTokensRegex;
-        private readonly TikTokenizer cpu;       // Decode / trim variants
+        private readonly TikTokenizer cpu;       // Decode
 
         /// <summary>Same arguments as TokenizerBuilder.CreateTokenizer (TokenizerBuilder.cs:210-213) plus the HIP device index.</summary>
         public GpuTikTokenizer(Stream tikTokenBpeFileStream, IReadOnlyDictionary<string, int> specialTokensEncoder, string pattern, int cacheSize = 8192, int device = 0)
@@ -130,10 +134,98 @@ namespace Microsoft.DeepDev
             return result;
         }
 
-        public (List<int> TokenIds, string Text) EncodeTrimSuffix(string text, IReadOnlyCollection<string> allowedSpecial, int maxTokenCount) => cpu.EncodeTrimSuffix(text, allowedSpecial, maxTokenCount);
-        public (List<int> TokenIds, string Text) EncodeTrimSuffix(string text, int maxTokenCount, bool applySpecialTokens = true) => cpu.EncodeTrimSuffix(text, maxTokenCount, applySpecialTokens);
-        public (List<int> TokenIds, string Text) EncodeTrimPrefix(string text, IReadOnlyCollection<string> allowedSpecial, int maxTokenCount) => cpu.EncodeTrimPrefix(text, allowedSpecial, maxTokenCount);
-        public (List<int> TokenIds, string Text) EncodeTrimPrefix(string text, int maxTokenCount, bool applySpecialTokens = true) => cpu.EncodeTrimPrefix(text, maxTokenCount, applySpecialTokens);
+        // One item per regex piece of every plain segment and one per special token, in order: its ids and its length in
+        // UTF-16 units (piece.Length / nextSpecial.Value.Length of TikTokenizer.cs:295,367).
+        private unsafe List<(int[] Ids, int Length)> PieceItems(string text, IReadOnlyCollection<string>? allowedSpecial)
+        {
+            var plan = new List<(int special, int start, int end)>();          // special < 0: plain segment text[start..end]
+            int start = 0;
+            while (text.Length > 0)
+            {
+                Match? next = null; int end = text.Length;
+                if (allowedSpecial != null && allowedSpecial.Count > 0)
+                {
+                    int startFind = start;
+                    while (true)                                              // FindNextSpecialToken (TikTokenizer.cs:230-241)
+                    {
+                        next = specialTokensRegex.Match(text, startFind);
+                        if (!next.Success || allowedSpecial.Contains(next.Value)) break;
+                        startFind = next.Index + 1;
+                    }
+                    if (next.Success) end = next.Index;
+                }
+                if (end > start) plan.Add((-1, start, end));
+                if (next is null || !next.Success) break;
+                plan.Add((specialTokensEncoder[next.Value], next.Index, next.Index + next.Length));
+                start = next.Index + next.Length;
+                if (start >= text.Length) break;
+            }
+            var segs = plan.Where(p => p.special < 0).ToList();
+            var offsets = new long[segs.Count + 1];
+            long total = 0;
+            for (int i = 0; i < segs.Count; ++i) { offsets[i] = total; total += Encoding.UTF8.GetByteCount(text.AsSpan(segs[i].start, segs[i].end - segs[i].start)); }
+            offsets[segs.Count] = total;
+            var bytes = new byte[Math.Max(1, total)];
+            for (int i = 0; i < segs.Count; ++i) Encoding.UTF8.GetBytes(text.AsSpan(segs[i].start, segs[i].end - segs[i].start), bytes.AsSpan((int)offsets[i]));
+            int cap = (int)Math.Max(1, total);
+            var ids = new int[cap]; var dpo = new long[segs.Count + 1]; var pbo = new long[cap + 1]; var pto = new long[cap + 1];
+            fixed (byte* pb = bytes) fixed (long* po = offsets) fixed (int* pi = ids) fixed (long* pd = dpo) fixed (long* pp = pbo) fixed (long* pt = pto)
+                Tkz.Check(Tkz.tkz_encode_batch_pieces_utf8(encoder, pb, po, segs.Count, pi, cap, pd, pp, pt, cap, out _, out _));
+            var items = new List<(int[] Ids, int Length)>();
+            int k = 0;
+            foreach (var (special, s0, e0) in plan)
+            {
+                if (special >= 0) { items.Add((new[] { special }, e0 - s0)); continue; }
+                for (long p = dpo[k]; p < dpo[k + 1]; ++p)
+                {
+                    var tok = new int[pto[p + 1] - pto[p]];
+                    Array.Copy(ids, pto[p], tok, 0, tok.Length);
+                    // UTF-16 length of the piece: chars + supplementary-plane chars (lead bytes, 0xF0.. counted twice)
+                    int len = 0;
+                    for (long b = pbo[p]; b < pbo[p + 1]; ++b) { if ((bytes[b] & 0xC0) != 0x80) ++len; if (bytes[b] >= 0xF0) ++len; }
+                    items.Add((tok, len));
+                }
+                ++k;
+            }
+            return items;
+        }
+
+        public (List<int> TokenIds, string Text) EncodeTrimSuffix(string text, IReadOnlyCollection<string> allowedSpecial, int maxTokenCount)
+        {
+            var tokenIds = new List<int>();
+            int tokenCount = 0, encodeLength = 0;
+            foreach (var (ids, length) in PieceItems(text, allowedSpecial))           // the walk of TikTokenizer.cs:288-341 / :343-392
+            {
+                tokenCount += ids.Length;
+                if (tokenCount > maxTokenCount) break;                            // the piece that overflows is dropped, with everything after it
+                tokenIds.AddRange(ids);
+                encodeLength += length;
+                if (tokenCount >= maxTokenCount) break;
+            }
+            return (tokenIds, encodeLength == text.Length ? text : text[..encodeLength]);
+        }
+        public (List<int> TokenIds, string Text) EncodeTrimSuffix(string text, int maxTokenCount, bool applySpecialTokens = true)
+            => EncodeTrimSuffix(text, applySpecialTokens && specialTokens.Count > 0 ? specialTokens : null!, maxTokenCount);
+
+        public (List<int> TokenIds, string Text) EncodeTrimPrefix(string text, IReadOnlyCollection<string> allowedSpecial, int maxTokenCount)
+        {
+            var tokenIds = new List<int>();
+            int tokenCount = 0, encodeLength = 0;
+            var tokenCountMap = new SortedDictionary<int, int> { { 0, 0 } };          // TikTokenizer.cs:438-441
+            foreach (var (ids, length) in PieceItems(text, allowedSpecial))
+            {
+                tokenCount += ids.Length; encodeLength += length;
+                tokenIds.AddRange(ids);
+                tokenCountMap[tokenCount] = encodeLength;
+            }
+            if (tokenCount <= maxTokenCount) return (tokenIds, text);                  // TrimPrefix (:470-483)
+            int prefixTokenCount = tokenCount - maxTokenCount, cutTokens = 0, cutLength = 0;
+            foreach (var pair in tokenCountMap) if (pair.Key >= prefixTokenCount) { cutTokens = pair.Key; cutLength = pair.Value; break; }
+            return (tokenIds.Skip(cutTokens).ToList(), text[cutLength..]);
+        }
+        public (List<int> TokenIds, string Text) EncodeTrimPrefix(string text, int maxTokenCount, bool applySpecialTokens = true)
+            => EncodeTrimPrefix(text, applySpecialTokens && specialTokens.Count > 0 ? specialTokens : null!, maxTokenCount);
+
         public string Decode(int[] tokens) => cpu.Decode(tokens);
 
         public void Dispose() { Tkz.tkz_encoder_destroy(encoder); }

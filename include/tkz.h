@@ -107,6 +107,20 @@ tkz_status tkz_encode_utf8(tkz_encoder* e, const uint8_t* text, int64_t len, int
 tkz_status tkz_encode_utf16(tkz_encoder* e, const uint16_t* text, int64_t len, int32_t* out_ids,
                             int64_t out_cap, int64_t* n_out);
 
+/* EncodeBatch with PIECE granularity -- what EncodeTrimSuffix / EncodeTrimPrefix consume
+ * (TikTokenizer.cs:288-341 and :483-519 walk the regex matches of a text and need the token count and
+ * the length of each).  Every document is split into its pieces and each piece is encoded:
+ * piece k = bytes[piece_byte_offsets[k] .. piece_byte_offsets[k+1]), its ids are
+ * out_ids[piece_token_offsets[k] .. piece_token_offsets[k+1]); the pieces of document d are
+ * [doc_piece_offsets[d], doc_piece_offsets[d+1]).  piece_cap is the capacity of the two piece arrays
+ * minus one (piece_cap >= total bytes is always enough); TKZ_E_CAPACITY with *n_pieces / *needed_ids
+ * holding the required sizes otherwise.  Host buffers. */
+tkz_status tkz_encode_batch_pieces_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets,
+                                        int64_t n_docs, int32_t* out_ids, int64_t out_cap,
+                                        int64_t* doc_piece_offsets, int64_t* piece_byte_offsets,
+                                        int64_t* piece_token_offsets, int64_t piece_cap,
+                                        int64_t* n_pieces, int64_t* needed_ids);
+
 /* ---- stage-level entry points (used by the parity tests; same kernels as the hot path) --- */
 
 /* Regex.Matches only: writes the piece-start bitmap (bit i of word i/64 set <=> a piece starts at

@@ -2,6 +2,7 @@
 // C ABI of include/tkz.h.  Header-only; link with libtkz.so.
 //
 //   tkz::TikTokenizer          ITokenizer.Encode x2 + EncodeBatch     Tokenizer_C#/TokenizerLib/ITokenizer.cs:12,28
+//                              EncodeTrimSuffix / EncodeTrimPrefix x2   ITokenizer.cs:30-44, TikTokenizer.cs:288-579
 //   tkz::TokenizerBuilder      CreateTokenizer(stream, specials, pattern)   TokenizerBuilder.cs:210-213
 //
 // Text is UTF-8 (std::string); EncodeUtf16 takes the code units of a .NET string.  Special-token
@@ -75,34 +76,11 @@ public:
         std::vector<uint8_t> bytes;
         std::vector<int64_t> offs{0};
         for (size_t t = 0; t < texts.size(); ++t) {
-            const std::string& text = texts[t];
-            size_t start = 0;
-            for (;;) {
-                size_t hit_pos = std::string::npos; int hit = -1;
-                if (!allowedSpecial.empty()) {
-                    size_t find = start;
-                    for (;;) {                                          // FindNextSpecialToken (TikTokenizer.cs:230-241)
-                        hit = -1;
-                        size_t p = find;
-                        for (; p < text.size(); ++p) { hit = match_at(text, p); if (hit >= 0) break; }
-                        if (hit < 0) break;
-                        bool ok = false;
-                        for (const auto& a : allowedSpecial) if (a == specials_[hit].first) { ok = true; break; }
-                        if (ok) { hit_pos = p; break; }
-                        find = p + 1;                                   // startFind = nextSpecial.Index + 1 (one UTF-16 unit; literals are ASCII)
-                        while (find < text.size() && (static_cast<uint8_t>(text[find]) & 0xC0) == 0x80) ++find;
-                    }
-                }
-                const size_t end = hit >= 0 ? hit_pos : text.size();
-                if (end > start) {
-                    plan.push_back({t, 0, static_cast<int64_t>(offs.size()) - 1});
-                    bytes.insert(bytes.end(), text.begin() + start, text.begin() + end);
-                    offs.push_back(static_cast<int64_t>(bytes.size()));
-                }
-                if (hit < 0) break;
-                plan.push_back({t, specials_[hit].second, -1});         // EncodeSpecialToken (:215-220)
-                start = hit_pos + specials_[hit].first.size();
-                if (start >= text.size()) break;
+            for (const Segment& g : segments(texts[t], allowedSpecial)) {
+                if (g.special) { plan.push_back({t, g.id, -1}); continue; }
+                plan.push_back({t, 0, static_cast<int64_t>(offs.size()) - 1});
+                bytes.insert(bytes.end(), texts[t].begin() + g.begin, texts[t].begin() + g.end);
+                offs.push_back(static_cast<int64_t>(bytes.size()));
             }
         }
         const int64_t nseg = static_cast<int64_t>(offs.size()) - 1;
@@ -118,6 +96,45 @@ public:
         }
         return out;
     }
+
+    using Trimmed = std::pair<std::vector<int32_t>, std::string>;   // (List<int> TokenIds, string Text)
+    // EncodeTrimSuffix(string, IReadOnlyCollection<string> allowedSpecial, int maxTokenCount)     TikTokenizer.cs:394-403
+    Trimmed EncodeTrimSuffix(const std::string& text, const std::vector<std::string>& allowedSpecial, int maxTokenCount) const {
+        std::vector<int32_t> ids;
+        int64_t tokenCount = 0; size_t encodeLength = 0;
+        for (const PieceItem& it : piece_items(text, allowedSpecial)) {            // the walk of :288-341 / :343-392
+            tokenCount += static_cast<int64_t>(it.ids.size());
+            if (tokenCount > maxTokenCount) break;                                // the piece that overflows is dropped, with all after it
+            ids.insert(ids.end(), it.ids.begin(), it.ids.end());
+            encodeLength = it.end;
+            if (tokenCount >= maxTokenCount) break;
+        }
+        return {ids, text.substr(0, encodeLength)};
+    }
+    // EncodeTrimSuffix(string, int maxTokenCount, bool applySpecialTokens = true)                  TikTokenizer.cs:412-429
+    Trimmed EncodeTrimSuffix(const std::string& text, int maxTokenCount, bool applySpecialTokens = true) const {
+        return EncodeTrimSuffix(text, applySpecialTokens ? all_specials() : std::vector<std::string>{}, maxTokenCount);
+    }
+    // EncodeTrimPrefix(string, IReadOnlyCollection<string> allowedSpecial, int maxTokenCount)     TikTokenizer.cs:529-536
+    Trimmed EncodeTrimPrefix(const std::string& text, const std::vector<std::string>& allowedSpecial, int maxTokenCount) const {
+        std::vector<int32_t> ids;
+        std::vector<std::pair<int64_t, size_t>> boundaries{{0, 0}};               // tokenCountMap (:438-441)
+        int64_t tokenCount = 0;
+        for (const PieceItem& it : piece_items(text, allowedSpecial)) {
+            tokenCount += static_cast<int64_t>(it.ids.size());
+            ids.insert(ids.end(), it.ids.begin(), it.ids.end());
+            boundaries.push_back({tokenCount, it.end});
+        }
+        if (tokenCount <= maxTokenCount) return {ids, text};                      // TrimPrefix (:470-483)
+        const int64_t prefix = tokenCount - maxTokenCount;
+        int64_t cutTokens = 0; size_t cutLen = 0;
+        for (const auto& b : boundaries) if (b.first >= prefix) { cutTokens = b.first; cutLen = b.second; break; }
+        return {std::vector<int32_t>(ids.begin() + cutTokens, ids.end()), text.substr(cutLen)};
+    }
+    // EncodeTrimPrefix(string, int maxTokenCount, bool applySpecialTokens = true)                  TikTokenizer.cs:545-564
+    Trimmed EncodeTrimPrefix(const std::string& text, int maxTokenCount, bool applySpecialTokens = true) const {
+        return EncodeTrimPrefix(text, applySpecialTokens ? all_specials() : std::vector<std::string>{}, maxTokenCount);
+    }
     // the code units of a .NET string; plain path only (Encode(text, false))
     std::vector<int32_t> EncodeUtf16(const std::u16string& text) const {
         std::vector<int32_t> ids(text.size() * 3 + 1);
@@ -130,6 +147,68 @@ public:
     tkz_encoder* native() const { return enc_; }
 
 private:
+    struct Segment { bool special; int32_t id; size_t begin, end; };          // bytes [begin, end) of the text
+    // EncodeInternal + FindNextSpecialToken (TikTokenizer.cs:141-170,230-241): plain segments and special literals in order
+    std::vector<Segment> segments(const std::string& text, const std::vector<std::string>& allowedSpecial) const {
+        std::vector<Segment> out;
+        size_t start = 0;
+        for (;;) {
+            size_t hit_pos = std::string::npos; int hit = -1;
+            if (!allowedSpecial.empty()) {
+                size_t find = start;
+                for (;;) {
+                    hit = -1;
+                    size_t p = find;
+                    for (; p < text.size(); ++p) { hit = match_at(text, p); if (hit >= 0) break; }
+                    if (hit < 0) break;
+                    bool ok = false;
+                    for (const auto& a : allowedSpecial) if (a == specials_[hit].first) { ok = true; break; }
+                    if (ok) { hit_pos = p; break; }
+                    find = p + 1;                                       // startFind = nextSpecial.Index + 1 (one UTF-16 unit; literals are ASCII)
+                    while (find < text.size() && (static_cast<uint8_t>(text[find]) & 0xC0) == 0x80) ++find;
+                }
+            }
+            const size_t end = hit >= 0 ? hit_pos : text.size();
+            if (end > start) out.push_back({false, 0, start, end});
+            if (hit < 0) break;
+            out.push_back({true, specials_[hit].second, hit_pos, hit_pos + specials_[hit].first.size()});   // EncodeSpecialToken (:215-220)
+            start = hit_pos + specials_[hit].first.size();
+            if (start >= text.size()) break;
+        }
+        return out;
+    }
+    std::vector<std::string> all_specials() const {
+        std::vector<std::string> all;
+        for (const auto& s : specials_) all.push_back(s.first);
+        return all;
+    }
+    // one item per regex piece of every plain segment and one per special token: its ids and the byte position where it ends
+    struct PieceItem { std::vector<int32_t> ids; size_t end; };
+    std::vector<PieceItem> piece_items(const std::string& text, const std::vector<std::string>& allowedSpecial) const {
+        const std::vector<Segment> segs = segments(text, allowedSpecial);
+        std::vector<uint8_t> bytes;
+        std::vector<int64_t> offs{0};
+        for (const Segment& g : segs)
+            if (!g.special) { bytes.insert(bytes.end(), text.begin() + g.begin, text.begin() + g.end); offs.push_back(static_cast<int64_t>(bytes.size())); }
+        const int64_t nseg = static_cast<int64_t>(offs.size()) - 1;
+        const size_t cap = bytes.size() ? bytes.size() : 1;
+        std::vector<int32_t> ids(cap);
+        std::vector<int64_t> dpo(static_cast<size_t>(nseg) + 1, 0), pbo(cap + 1, 0), pto(cap + 1, 0);
+        int64_t npieces = 0, needed = 0;
+        if (bytes.empty()) bytes.push_back(0);
+        check(tkz_encode_batch_pieces_utf8(enc_, bytes.data(), offs.data(), nseg, ids.data(), static_cast<int64_t>(cap), dpo.data(), pbo.data(),
+                                           pto.data(), static_cast<int64_t>(cap), &npieces, &needed));
+        std::vector<PieceItem> out;
+        int64_t k = 0;
+        for (const Segment& g : segs) {
+            if (g.special) { out.push_back({{g.id}, g.end}); continue; }
+            for (int64_t p = dpo[k]; p < dpo[k + 1]; ++p)
+                out.push_back({std::vector<int32_t>(ids.begin() + pto[p], ids.begin() + pto[p + 1]),
+                               g.begin + static_cast<size_t>(pbo[p + 1] - offs[k])});
+            ++k;
+        }
+        return out;
+    }
     int match_at(const std::string& text, size_t p) const {       // first registered literal that matches at p
         for (size_t i = 0; i < specials_.size(); ++i) {
             const std::string& lit = specials_[i].first;

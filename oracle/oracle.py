@@ -209,3 +209,154 @@ def _gather(out, offsets, counts):
     total = int(counts.sum())
     pos = np.repeat(starts - np.concatenate([[0], np.cumsum(counts)[:-1]]), counts) + np.arange(total)
     return out[pos]
+
+
+# ---- EncodeTrimSuffix / EncodeTrimPrefix restated -------------------------------------------------
+# Pure Python over the C primitives above (split on UTF-16 units, whole-piece rank, bpe); small inputs only.
+# Follows Tokenizer_C#/TokenizerLib/TikTokenizer.cs function by function; all indices are UTF-16 code units.
+class TrimOracle:
+    def __init__(self, vocab: Vocab, pattern: int, specials=None):
+        import re
+        self.vocab, self.pattern = vocab, pattern
+        self.specials = dict(specials or {})
+        # new Regex(string.Join("|", specials.Keys.Select(Regex.Escape)))          TikTokenizer.cs:78
+        self._re = re.compile("|".join(re.escape(k) for k in self.specials)) if self.specials else None
+
+    @staticmethod
+    def _units(text: str):
+        return np.frombuffer(text.encode("utf-16-le", "surrogatepass"), dtype=np.uint16)
+
+    @staticmethod
+    def _str(units) -> str:
+        return np.asarray(units, dtype=np.uint16).tobytes().decode("utf-16-le", "surrogatepass")
+
+    def _piece_tokens(self, units):
+        # Encoding.UTF8.GetBytes(piece) (:261 -- a lone surrogate becomes U+FFFD), Encoder.TryGetValue (:262), BytePairEncode (:268)
+        b = self._str(units).encode("utf-16-le", "surrogatepass").decode("utf-16-le", "replace").encode("utf-8")
+        r = self.vocab.rank(b)
+        return [r] if r >= 0 else self.vocab.bpe(b)
+
+    def _find_next_special(self, text: str, allowed, start: int):
+        """FindNextSpecialToken (:230-241) on a Python str whose indices we keep in UTF-16 units through `u2s`."""
+        # special literals are ASCII, so search on the str and convert the index
+        find = start
+        while True:
+            m = self._re.search(self._s, self._u2s(find)) if self._re else None
+            if m is None:
+                return None, len(self._u)
+            if m.group(0) in allowed:
+                return m, self._s2u(m.start())
+            find = self._s2u(m.start()) + 1                    # startFind = nextSpecial.Index + 1 (:238)
+
+    def _bind(self, text: str):
+        self._s = text
+        self._u = self._units(text)
+        # maps between str indices (code points) and UTF-16 unit indices
+        s2u = [0]
+        for ch in text:
+            s2u.append(s2u[-1] + (2 if ord(ch) >= 0x10000 else 1))
+        self._s2u_tab = s2u
+        u2s = {}
+        for si, ui in enumerate(s2u):
+            u2s[ui] = si
+        self._u2s_tab = u2s
+
+    def _s2u(self, si):
+        return self._s2u_tab[si]
+
+    def _u2s(self, ui):
+        while ui not in self._u2s_tab:                         # inside a surrogate pair: the search cannot match there anyway
+            ui += 1
+        return self._u2s_tab[ui]
+
+    # private (int, int) EncodeTrimSuffix(text, tokenIds, start, end, maxTokenCount, tokenCount, encodeLength)   (:288-341)
+    def _trim_suffix_segment(self, token_ids, start, end, max_tokens, token_count, encode_length):
+        seg = self._u[start:end]
+        for st, ln in split_utf16(self.pattern, seg):
+            toks = self._piece_tokens(seg[st:st + ln])
+            token_count += len(toks)
+            if token_count <= max_tokens:
+                encode_length += ln
+                token_ids.extend(toks)
+            else:
+                break
+            if token_count >= max_tokens:
+                break
+        return token_count, encode_length
+
+    # EncodeTrimSuffixInternal (:343-392) and the public overloads (:394-429)
+    def encode_trim_suffix(self, text: str, allowed, max_tokens: int):
+        self._bind(text)
+        n = len(self._u)
+        token_ids = []
+        if not allowed or self._re is None:
+            _, enc_len = self._trim_suffix_segment(token_ids, 0, n, max_tokens, 0, 0)
+            return token_ids, (text if enc_len == n else self._str(self._u[:enc_len]))
+        allowed = set(allowed)
+        start = token_count = enc_len = 0
+        while True:
+            m, end = self._find_next_special(text, allowed, start)
+            if end > start:
+                token_count, enc_len = self._trim_suffix_segment(token_ids, start, end, max_tokens, token_count, enc_len)
+                if token_count >= max_tokens:
+                    break
+            if m is not None:
+                token_count += 1
+                if token_count <= max_tokens:
+                    token_ids.append(self.specials[m.group(0)])             # EncodeSpecialToken (:215-220)
+                    start = end + len(m.group(0))
+                    enc_len += len(m.group(0))
+                    if start >= n:
+                        break
+                if token_count >= max_tokens:
+                    break
+            else:
+                break
+        return token_ids, (text if enc_len == n else self._str(self._u[:enc_len]))
+
+    # private void Encode(text, tokenIds, start, ref tokenCount, ref encodeLength, tokenCountMap, end)   (:485-519)
+    def _encode_segment_mapped(self, token_ids, start, end, state, count_map):
+        seg = self._u[start:end]
+        for st, ln in split_utf16(self.pattern, seg):
+            toks = self._piece_tokens(seg[st:st + ln])
+            state[0] += len(toks)
+            state[1] += ln
+            token_ids.extend(toks)
+            count_map[state[0]] = state[1]
+
+    # EncodeTrimPrefixInternal (:431-468), TrimPrefix (:470-483) and the public overloads (:529-564)
+    def encode_trim_prefix(self, text: str, allowed, max_tokens: int):
+        self._bind(text)
+        n = len(self._u)
+        token_ids = []
+        state = [0, 0]
+        count_map = {0: 0}
+        if not allowed or self._re is None:
+            self._encode_segment_mapped(token_ids, 0, n, state, count_map)
+        else:
+            allowed = set(allowed)
+            start = 0
+            while True:
+                m, end = self._find_next_special(text, allowed, start)
+                if end > start:
+                    self._encode_segment_mapped(token_ids, start, end, state, count_map)
+                if m is not None:
+                    token_ids.append(self.specials[m.group(0)])
+                    start = end + len(m.group(0))
+                    state[0] += 1
+                    state[1] += len(m.group(0))
+                    count_map[state[0]] = state[1]
+                    if start >= n:
+                        break
+                else:
+                    break
+        token_count = state[0]
+        if token_count <= max_tokens:
+            return token_ids, text
+        prefix = token_count - max_tokens
+        cut_tokens = cut_len = 0
+        for key in sorted(count_map):                          # SortedDictionary enumeration
+            if key >= prefix:
+                cut_tokens, cut_len = key, count_map[key]
+                break
+        return token_ids[cut_tokens:], self._str(self._u[cut_len:])

@@ -35,6 +35,35 @@ int main(int argc, char** argv) {
     REQUIRE(batch.size() == 4 && batch[0].empty() && batch[1] == hw && batch[2] == std::vector<int32_t>{50301});
     REQUIRE(batch[3] == tok.Encode(text.substr(0, 2000)));
     REQUIRE(tok.EncodeUtf16(u"Hello World") == hw);
+    // EncodeTrimSuffix / EncodeTrimPrefix (TikTokenizerUnitTest.cs:128-225 restated; expected values from the oracle's TrimOracle)
+    {
+        const std::string t = "<|im_start|>Hello TempWorld \xF0\x9F\x98\x80 \xE6\xBC\xA2\xE5\xAD\x97<|im_end|>";
+        const std::vector<std::string> allow = {"<|endoftext|>", "<|im_start|>", "<|im_end|>"};
+        const std::vector<int32_t> full = {50300, 15496, 24189, 10603, 30325, 222, 10545, 120, 95, 27764, 245, 50301};
+        REQUIRE(tok.Encode(t) == full);
+        auto r = tok.EncodeTrimSuffix(t, allow, 0);
+        REQUIRE(r.first.empty() && r.second.empty());
+        r = tok.EncodeTrimSuffix(t, allow, 2);
+        REQUIRE((r.first == std::vector<int32_t>{50300, 15496}) && r.second == "<|im_start|>Hello");
+        r = tok.EncodeTrimSuffix(t, allow, 5);                                     // " 😀" (2 tokens) would make 6: dropped
+        REQUIRE((r.first == std::vector<int32_t>{50300, 15496, 24189, 10603}) && r.second == "<|im_start|>Hello TempWorld");
+        r = tok.EncodeTrimSuffix(t, 7);                                            // applySpecialTokens = true
+        REQUIRE(r.first == std::vector<int32_t>(full.begin(), full.begin() + 6) && r.second == "<|im_start|>Hello TempWorld \xF0\x9F\x98\x80");
+        r = tok.EncodeTrimSuffix(t, allow, 12);
+        REQUIRE(r.first == full && r.second == t);
+        r = tok.EncodeTrimSuffix(t, 5, false);                                     // specials as plain text
+        REQUIRE(r.second == "<|im_start" && r.first.size() <= 5);
+        r = tok.EncodeTrimPrefix(t, allow, 5);
+        REQUIRE((r.first == std::vector<int32_t>{50301}) && r.second == "<|im_end|>");
+        r = tok.EncodeTrimPrefix(t, allow, 7);
+        REQUIRE(r.first == std::vector<int32_t>(full.begin() + 6, full.end()) && r.second == " \xE6\xBC\xA2\xE5\xAD\x97<|im_end|>");
+        r = tok.EncodeTrimPrefix(t, 12);
+        REQUIRE(r.first == full && r.second == t);
+        r = tok.EncodeTrimPrefix(t, 5, false);
+        REQUIRE(r.second == "im_end|>" && r.first.size() <= 5);
+        r = tok.EncodeTrimPrefix(t, allow, 0);
+        REQUIRE(r.first.empty() && r.second.empty());
+    }
     bool threw = false;
     try { tkz::TikTokenizer bad("YQ== 0\nYg== 0\n", {}, p1); } catch (const tkz::DuplicateRankError&) { threw = true; }
     REQUIRE(threw);

@@ -52,6 +52,40 @@ def run_gpt2_suite(lib, gpt2_bytes, lib_rs_text, oracle_mod, oracle_vocab):
     # lone surrogates: Encoding.UTF8.GetBytes semantics
     s = "a\ud800b"
     assert tok.Encode(s, False) == oenc.encode_bytes("a�b".encode("utf-8"))
+    run_trim_suite(tok, oracle_mod.TrimOracle(oracle_vocab, oracle_mod.P1, specials), specials, lib_rs_text)
+
+
+def run_trim_suite(tok, trim_oracle, specials, long_text):
+    """TestEncodeTrimSuffix/2, TestEncodeTrimPrefix/2 (TikTokenizerUnitTest.cs:128-225): the same scenarios, every
+    maxTokenCount from 0 past the full length, all three overload shapes, against the oracle's restatement of
+    TikTokenizer.cs:288-579; then seeded random texts with specials, CJK, emoji and lone-surrogate-free BMP symbols."""
+    import random
+    allow = list(specials)
+    cases = [IM_START + "Hello World" + IM_END, IM_START + "Hello TempWorld" + IM_END, IM_START + "HelloTemp World" + IM_END,
+             "", "a", IM_END, "Hello ⭐ World 😀😀 done" + IM_END + " tail", long_text[:700]]
+    rng = random.Random(77)
+    frag = ["Hello", " World", " the", "ing", " 1234567", "\n\n", "  ", "'s", " don't", IM_START, IM_END, "<|endoftext|>", "<|im_",
+            "漢字かな", "😀", "⭐", " tokenization", "!!!", "\t", "x" * 40]
+    for _ in range(25):
+        cases.append("".join(rng.choice(frag) for _ in range(rng.randint(1, 14))))
+    for text in cases:
+        full = len(tok.Encode(text, allow))
+        for mx in sorted(set([0, 1, 2, 3, 4, 5, 6, 7, full - 1, full, full + 1, 1000])):
+            if mx < 0:
+                continue
+            for fn, ofn in ((tok.EncodeTrimSuffix, trim_oracle.encode_trim_suffix), (tok.EncodeTrimPrefix, trim_oracle.encode_trim_prefix)):
+                assert fn(text, allow, mx) == ofn(text, allow, mx), (fn.__name__, text, mx, "allowed")
+                assert fn(text, mx) == ofn(text, allow, mx), (fn.__name__, text, mx, "apply=True")
+                assert fn(text, mx, False) == ofn(text, None, mx), (fn.__name__, text, mx, "apply=False")
+                assert fn(text, [IM_END], mx) == ofn(text, [IM_END], mx), (fn.__name__, text, mx, "subset")
+    # the properties the C# tests assert: the ids decode to the returned text, and never exceed maxTokenCount
+    text = IM_START + "Hello World" + IM_END
+    ids, cut = tok.EncodeTrimSuffix(text, allow, 3)
+    assert cut == IM_START + "Hello World" and tok.Decode(ids) == cut and len(ids) == 3          # :148-152
+    ids, cut = tok.EncodeTrimPrefix(text, allow, 3)
+    assert cut == "Hello World" + IM_END and tok.Decode(ids) == cut and len(ids) == 3            # :196-200
+    assert tok.EncodeTrimSuffix(text, allow, 4) == (tok.Encode(text, allow), text)                # :132-134
+    assert tok.EncodeTrimPrefix(text, allow, 5) == (tok.Encode(text, allow), text)                # :192-194
 
 
 def run_cl100k_suite(lib):
@@ -66,4 +100,26 @@ def run_cl100k_suite(lib):
     assert tok.Encode(IM_START + "Hello ⭐ World" + IM_END, [IM_START, IM_END]) == [100264, 9906, 2928, 99834, 4435, 100265]   # :112-126
     lib_rs = open(os.path.join(os.path.dirname(__file__), "golden", "lib.rs.txt"), encoding="utf-8").read()
     assert tok.Encode(lib_rs, False) == load_golden_json("tokens_cl100k.json")                    # :66-87
+    # TestEncodeTrimSuffix / 2 (:128-173) and TestEncodeTrimPrefix / 2 (:177-225), as written
+    allow = list(specials)
+    text = IM_START + "Hello World" + IM_END
+    for mx, n, cut in ((4, 4, text), (5, 4, text), (3, 3, IM_START + "Hello World")):
+        ids, t = tok.EncodeTrimSuffix(text, allow, mx)
+        assert (len(ids), t) == (n, cut)
+    ids, t = tok.EncodeTrimSuffix(text, 4, False)
+    assert (len(ids), t) == (4, "<|im_start")
+    assert tok.EncodeTrimSuffix(text, 4)[1] == text
+    text2 = IM_START + "Hello TempWorld" + IM_END
+    for mx, n, cut in ((5, 5, text2), (6, 5, text2), (3, 2, IM_START + "Hello")):
+        ids, t = tok.EncodeTrimSuffix(text2, allow, mx)
+        assert (len(ids), t) == (n, cut) and (mx != 3 or tok.Decode(ids) == cut)
+    for mx, n, cut in ((4, 4, text), (5, 4, text), (3, 3, "Hello World" + IM_END)):
+        ids, t = tok.EncodeTrimPrefix(text, allow, mx)
+        assert (len(ids), t) == (n, cut)
+    ids, t = tok.EncodeTrimPrefix(text, 4, False)
+    assert (len(ids), t) == (4, "im_end|>")
+    text3 = IM_START + "HelloTemp World" + IM_END
+    for mx, n, cut in ((5, 5, text3), (6, 5, text3), (3, 2, " World" + IM_END)):
+        ids, t = tok.EncodeTrimPrefix(text3, allow, mx)
+        assert (len(ids), t) == (n, cut) and (mx != 3 or tok.Decode(ids) == cut)
     return True

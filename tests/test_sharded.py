@@ -11,7 +11,7 @@ import pytest
 from conftest import ROOT
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, outdir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -20,7 +20,7 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     import emu
     from tokenizer_amd import _native as N
-    from tokenizer_amd import sharded
+    from tokenizer_amd import sharded, write_shard
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lib = emu.library()
     raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "gpt2.tiktoken.gz"), "rb").read())
@@ -32,12 +32,13 @@ def _worker(rank, world, port, q):
     offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.int64)
     ids, ooffs = enc.encode_batch(data, offs)
     g = sharded.gather_counts(hi - lo, int(offs[-1]), len(ids))
+    write_shard(os.path.join(outdir, "tokens.%05d.tkzs" % rank), ids, ooffs, g["doc_base"], g["token_base"])
     q.put((rank, ids.tolist(), ooffs.tolist(), g["doc_base"], g["token_base"], g["docs"], g["bytes"], g["tokens"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_shards_match_single_batch():
+def test_two_rank_shards_match_single_batch(tmp_path):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -45,7 +46,7 @@ def test_two_rank_shards_match_single_batch():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in procs)
@@ -68,3 +69,33 @@ def test_two_rank_shards_match_single_batch():
     assert (db0, tb0) == (0, 0) and db1 == 150 and tb1 == len(ids0)
     assert nd0 == nd1 == 301 and nb0 == nb1 == len(data) and nt0 == nt1 == len(ids)
     assert oo0 + [x + tb1 for x in oo1[1:]] == ooffs.tolist()
+    # the shard files the two ranks wrote concatenate into the whole-batch result without any further exchange
+    from tokenizer_amd import Shard
+    shards = [Shard(str(tmp_path / ("tokens.%05d.tkzs" % r))) for r in range(2)]
+    assert [sh.doc_base for sh in shards] == [0, 150] and [sh.token_base for sh in shards] == [0, len(ids0)]
+    assert sum(len(sh) for sh in shards) == 301
+    for sh in shards:
+        for d in (0, len(sh) // 2, len(sh) - 1):
+            g = sh.doc_base + d
+            assert sh[d].tolist() == ids[ooffs[g]:ooffs[g + 1]].tolist()
+    assert np.concatenate([np.asarray(sh.ids) for sh in shards]).tolist() == ids.tolist()
+
+
+def test_shard_file_round_trip_and_errors(tmp_path):
+    from tokenizer_amd import Shard, write_shard
+    ids = np.arange(17, dtype=np.int32) * 3
+    offs = np.array([0, 0, 5, 5, 16, 17], dtype=np.int64)          # empty documents at both ends of a run
+    p = str(tmp_path / "a.tkzs")
+    write_shard(p, ids, offs, doc_base=1000, token_base=12345)
+    sh = Shard(p)
+    assert (len(sh), sh.n_tokens, sh.doc_base, sh.token_base) == (5, 17, 1000, 12345)
+    assert [sh[d].tolist() for d in range(5)] == [[], [0, 3, 6, 9, 12], [], list(range(15, 48, 3)), [48]]
+    write_shard(p, np.zeros(0, np.int32), np.zeros(1, np.int64))   # an empty shard is a valid file
+    assert len(Shard(p)) == 0 and Shard(p).n_tokens == 0
+    with pytest.raises(ValueError):
+        write_shard(p, ids, np.array([0, 5, 3, 17], dtype=np.int64))
+    with pytest.raises(ValueError):
+        write_shard(p, ids, np.array([0, 16], dtype=np.int64))
+    open(p, "wb").write(b"not a shard")
+    with pytest.raises(ValueError):
+        Shard(p)

@@ -85,6 +85,7 @@ class Library:
         L.tkz_encode_utf16.argtypes = [vp, vp, i64, vp, i64, pi64]
         L.tkz_pretokenize_utf8.argtypes = [vp, vp, vp, i64, vp]
         L.tkz_encode_pieces.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
+        L.tkz_encode_batch_pieces_utf8.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, pi64, pi64]
         L.tkz_encoder_set_option.argtypes = [vp, i32, i64]
         L.tkz_encoder_set_profiling.argtypes = [vp, i32]
         L.tkz_encoder_kernel_ms.argtypes = [vp, vp, vp, i32]
@@ -200,6 +201,22 @@ class Encoder:
         needed = C.c_int64(0)
         self.lib.check(self.lib.L.tkz_encode_pieces(self._h, _ptr(data), _ptr(offsets), n, _ptr(ids), len(data), _ptr(ooff), C.byref(needed)))
         return ids[:needed.value], ooff
+
+    def encode_batch_pieces(self, data: np.ndarray, offsets: np.ndarray):
+        """EncodeBatch with piece granularity: (ids, doc_piece_offsets[n+1], piece_byte_offsets[np+1], piece_token_offsets[np+1])."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        cap = max(1, len(data))
+        ids = np.empty(cap, np.int32)
+        dpo = np.empty(n + 1, np.int64)
+        pbo = np.empty(cap + 1, np.int64)
+        pto = np.empty(cap + 1, np.int64)
+        npieces, needed = C.c_int64(0), C.c_int64(0)
+        self.lib.check(self.lib.L.tkz_encode_batch_pieces_utf8(self._h, _ptr(data), _ptr(offsets), n, _ptr(ids), cap, _ptr(dpo), _ptr(pbo),
+                                                               _ptr(pto), cap, C.byref(npieces), C.byref(needed)))
+        k = npieces.value
+        return ids[:needed.value], dpo, pbo[:k + 1], pto[:k + 1]
 
     def pretokenize(self, data: np.ndarray, offsets: np.ndarray):
         """Piece-start bitmap as a bool array of len(data) + 1 (the last entry is the sentinel)."""

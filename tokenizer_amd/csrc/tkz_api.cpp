@@ -418,6 +418,44 @@ tkz_status tkz_encode_pieces(tkz_encoder* e, const uint8_t* bytes, const int64_t
     return encode_host(e, bytes, piece_offsets, n_pieces, out_ids, out_cap, out_offsets, needed, false, nullptr);
 }
 
+tkz_status tkz_encode_batch_pieces_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs,
+                                        int32_t* out_ids, int64_t out_cap, int64_t* doc_piece_offsets, int64_t* piece_byte_offsets,
+                                        int64_t* piece_token_offsets, int64_t piece_cap, int64_t* n_pieces, int64_t* needed_ids) {
+    if (!doc_piece_offsets || !piece_byte_offsets || !piece_token_offsets || !n_pieces || (out_cap > 0 && !out_ids))
+        return fail(TKZ_E_ARG, "null output buffer");
+    if (n_docs < 0 || !doc_offsets) return fail(TKZ_E_ARG, "null buffer");
+    // 1. Regex.Matches on the device: the piece-start bitmap of the whole batch
+    const int64_t total = doc_offsets[n_docs];
+    if (total < 0) return fail(TKZ_E_ARG, "negative byte count");
+    std::vector<uint64_t> bitmap((size_t)(total / 64 + 1), 0);
+    tkz_status st = encode_host(e, bytes, doc_offsets, n_docs, nullptr, 0, nullptr, nullptr, true, bitmap.data());
+    if (st != TKZ_OK) return st;
+    // 2. the pieces in order (a document start is always a piece start; empty documents have no piece)
+    int64_t np = 0;
+    for (size_t w = 0; w < bitmap.size(); ++w) {
+        uint64_t m = bitmap[w];
+        if (w == bitmap.size() - 1) m &= (total & 63) ? ((1ull << (total & 63)) - 1ull) : 0ull;   // drop the sentinel at `total`
+        np += __builtin_popcountll(m);
+    }
+    *n_pieces = np;
+    if (np > piece_cap) return fail(TKZ_E_CAPACITY, "piece arrays too small");
+    int64_t k = 0, d = 0;
+    for (size_t w = 0; w < bitmap.size(); ++w) {
+        uint64_t m = bitmap[w];
+        if (w == bitmap.size() - 1) m &= (total & 63) ? ((1ull << (total & 63)) - 1ull) : 0ull;
+        for (; m; m &= m - 1) {
+            const int64_t pos = (int64_t)w * 64 + __builtin_ctzll(m);
+            while (d < n_docs && doc_offsets[d] <= pos) doc_piece_offsets[d++] = k;      // documents that start at or before this piece
+            piece_byte_offsets[k++] = pos;
+        }
+    }
+    while (d <= n_docs) doc_piece_offsets[d++] = k;
+    piece_byte_offsets[np] = total;
+    // 3. BytePairEncode + whole-piece lookup of every piece
+    if (np == 0) { piece_token_offsets[0] = 0; if (needed_ids) *needed_ids = 0; return TKZ_OK; }
+    return encode_host(e, bytes, piece_byte_offsets, np, out_ids, out_cap, piece_token_offsets, needed_ids, false, nullptr);
+}
+
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value) {
     if (!e) return fail(TKZ_E_ARG, "null encoder");
     if (option == TKZ_OPT_PRETOK_SEQUENTIAL) { e->pretok_seq = value != 0; return TKZ_OK; }

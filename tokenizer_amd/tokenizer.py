@@ -13,7 +13,9 @@ one addition (the reference has no batch API).  What runs where:
     too: `Regex.Matches(text[start..end])`, TikTokenizer.cs:252);
   * the plain path (TikTokenizer.cs:250-274 + BytePairEncoder.cs:13-76) is the HIP path of libtkz;
   * Decode is a host-side table lookup (TikTokenizer.cs:586-604), kept for round-trip checks;
-  * EncodeTrimSuffix / EncodeTrimPrefix are not part of the accelerated path.
+  * EncodeTrimSuffix / EncodeTrimPrefix (TikTokenizer.cs:288-579) cut at piece granularity: the GPU
+    encodes every plain segment with piece granularity (tkz_encode_batch_pieces_utf8: token count and byte span of each
+    regex match), the walk over pieces / special tokens that decides where to cut is host work.
 """
 import os
 import re
@@ -101,10 +103,10 @@ class TikTokenizer:
 
     # ---- segmentation (host) ---------------------------------------------------------------------
     def _segments(self, text: str, allowed: Optional[Iterable[str]]):
-        """EncodeInternal + FindNextSpecialToken: list of ('t', plain_text) / ('s', id)."""
+        """EncodeInternal + FindNextSpecialToken: list of ('t', plain_text, None) / ('s', id, literal)."""
         allowed = set(allowed) if allowed else set()
         if not allowed or self._special_re is None:
-            return [("t", text)] if text else []
+            return [("t", text, None)] if text else []
         out = []
         start = 0
         while True:
@@ -117,10 +119,10 @@ class TikTokenizer:
                 find = m.start() + 1
             end = m.start() if m else len(text)
             if end > start:
-                out.append(("t", text[start:end]))
+                out.append(("t", text[start:end], None))
             if m is None:
                 break
-            out.append(("s", self.SpecialTokensEncoder[m.group(0)]))   # EncodeSpecialToken (:215-220)
+            out.append(("s", self.SpecialTokensEncoder[m.group(0)], m.group(0)))   # EncodeSpecialToken (:215-220)
             start = m.end()
             if start >= len(text):
                 break
@@ -138,7 +140,7 @@ class TikTokenizer:
     def EncodeBatch(self, texts: Sequence[str], allowedSpecialOrApply: Union[bool, Sequence[str], None] = True) -> List[List[int]]:
         allowed = self._resolve_allowed(allowedSpecialOrApply)
         plans = [self._segments(t, allowed) for t in texts]
-        segs = [_utf8_like_dotnet(s) for plan in plans for kind, s in plan if kind == "t"]
+        segs = [_utf8_like_dotnet(s) for plan in plans for kind, s, _ in plan if kind == "t"]
         if segs:
             data = np.frombuffer(b"".join(segs), np.uint8) if sum(map(len, segs)) else np.zeros(0, np.uint8)
             offs = np.cumsum([0] + [len(s) for s in segs]).astype(np.int64)
@@ -148,7 +150,7 @@ class TikTokenizer:
         out, k = [], 0
         for plan in plans:
             cur: List[int] = []
-            for kind, v in plan:
+            for kind, v, _ in plan:
                 if kind == "s":
                     cur.append(v)
                 else:
@@ -157,11 +159,89 @@ class TikTokenizer:
             out.append(cur)
         return out
 
-    def EncodeTrimSuffix(self, *a, **k):
-        raise NotImplementedError("EncodeTrimSuffix is outside the accelerated Encode path (SURVEY.md 8f-3)")
+    # ---- trim variants (TikTokenizer.cs:288-579) --------------------------------------------------
+    def _piece_items(self, text: str, allowed):
+        """The walk both trim variants share: the text as a list of (n_tokens, ids, utf16_length) items in order --
+        one item per regex piece of every plain segment (Regex.Matches(text[start..end]), :290,:485) and one per special
+        token (:215-220).  All plain segments go to the GPU in one piece-granular call."""
+        plan = self._segments(text, allowed)
+        segs = [_utf8_like_dotnet(s) for kind, s, _ in plan if kind == "t"]
+        items = []
+        if segs:
+            data = np.frombuffer(b"".join(segs), np.uint8)
+            offs = np.cumsum([0] + [len(s) for s in segs]).astype(np.int64)
+            ids, dpo, pbo, pto = self._encoder.encode_batch_pieces(data, offs)
+            # UTF-16 length of a piece = chars + 4-byte chars (piece.Length, :295): count lead bytes, 0xF0.. twice
+            lead = ((data & 0xC0) != 0x80).astype(np.int64) + (data >= 0xF0).astype(np.int64)
+            cum = np.concatenate([[0], np.cumsum(lead)])
+            u16 = cum[pbo[1:]] - cum[pbo[:-1]]
+        k = 0
+        for kind, v, lit in plan:
+            if kind == "s":
+                items.append((1, [v], len(lit.encode("utf-16-le")) // 2, True))
+            else:
+                for p in range(int(dpo[k]), int(dpo[k + 1])):
+                    items.append((int(pto[p + 1] - pto[p]), ids[pto[p]:pto[p + 1]].tolist(), int(u16[p]), False))
+                k += 1
+        return items
 
-    def EncodeTrimPrefix(self, *a, **k):
-        raise NotImplementedError("EncodeTrimPrefix is outside the accelerated Encode path (SURVEY.md 8f-3)")
+    @staticmethod
+    def _utf16_prefix(text: str, n_units: int, drop: bool = False) -> str:
+        """text[..n] / text[n..] with n in UTF-16 code units, as the reference slices a .NET string."""
+        raw = text.encode("utf-16-le", "surrogatepass")
+        if n_units * 2 >= len(raw):
+            return "" if drop else text
+        part = raw[2 * n_units:] if drop else raw[:2 * n_units]
+        return part.decode("utf-16-le", "surrogatepass")
+
+    def _trim_args(self, a, b):
+        # EncodeTrimX(string, IReadOnlyCollection<string> allowedSpecial, int maxTokenCount)       (:394-403, :529-536)
+        # EncodeTrimX(string, int maxTokenCount, bool applySpecialTokens = true)                   (:412-429, :545-564)
+        if isinstance(a, int) and not isinstance(a, bool):
+            apply = True if b is None else bool(b)
+            return (self.SpecialTokens if (apply and self.SpecialTokens) else None), int(a)
+        if b is None:
+            raise TypeError("maxTokenCount is required")
+        return (a if a else None), int(b)
+
+    def EncodeTrimSuffix(self, text: str, a, b=None):
+        """Token ids and the text they cover, cut after the last piece / special token that still fits maxTokenCount."""
+        allowed, max_tokens = self._trim_args(a, b)
+        token_ids: List[int] = []
+        token_count = 0
+        encode_length = 0
+        for n, ids, ulen, is_special in self._piece_items(text, allowed):
+            token_count += n                                   # (:298,:313,:328; special: :364)
+            if token_count <= max_tokens:
+                token_ids.extend(ids)
+                encode_length += ulen
+            else:
+                break                                          # the piece that overflows is dropped with everything after it
+            if token_count >= max_tokens:
+                break                                          # (:340, :356-359, :375-378)
+        return token_ids, self._utf16_prefix(text, encode_length)
+
+    def EncodeTrimPrefix(self, text: str, a, b=None):
+        """Token ids and the text they cover, cut before the first piece boundary that leaves at most maxTokenCount tokens."""
+        allowed, max_tokens = self._trim_args(a, b)
+        token_ids: List[int] = []
+        token_count = 0
+        encode_length = 0
+        boundaries = [(0, 0)]                                  # tokenCountMap: cumulative tokens -> cumulative UTF-16 length (:438-441)
+        for n, ids, ulen, is_special in self._piece_items(text, allowed):
+            token_count += n
+            encode_length += ulen
+            token_ids.extend(ids)
+            boundaries.append((token_count, encode_length))
+        if token_count <= max_tokens:                          # TrimPrefix (:463-483)
+            return token_ids, text
+        prefix_tokens = token_count - max_tokens
+        cut_tokens, cut_len = 0, 0
+        for tc, el in boundaries:
+            if tc >= prefix_tokens:
+                cut_tokens, cut_len = tc, el
+                break
+        return token_ids[cut_tokens:], self._utf16_prefix(text, cut_len, drop=True)
 
     def Decode(self, tokens: Sequence[int]) -> str:
         """TikTokenizer.cs:586-604: unknown ids are dropped; bytes are decoded as UTF-8."""
