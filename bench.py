@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--min-len", type=int, default=256)
     ap.add_argument("--max-len", type=int, default=768)
     ap.add_argument("--pattern", type=int, default=2, help="1 pattern-1, 2 cl100k, 3 o200k")
-    ap.add_argument("--cpu-sample-docs", type=int, default=200_000)
+    ap.add_argument("--cpu-sample-docs", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -144,6 +144,7 @@ def main():
                     "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kms.items()}}
         # ---- CPU baseline (the oracle = reference-algorithm restatement, "port") + parity on the sample ----
         cpu = None
+        host_path = None
         parity_note = "unchecked"
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle as O
@@ -155,9 +156,9 @@ def main():
             h_ids = d_ids[:int(h_ooffs[-1])].cpu().numpy()
             ov = O.Vocab(raw)
             threads = max(1, min(os.cpu_count() or 1, 64))
-            tc = time.perf_counter()
-            o_ids, o_counts = O.encode_batch(ov, args.pattern, h_bytes, h_offs, threads=threads)
-            tcpu = time.perf_counter() - tc
+            tm = {}
+            o_ids, o_counts = O.encode_batch(ov, args.pattern, h_bytes, h_offs, threads=threads, timing=tm)
+            tcpu = tm["seconds"]
             same = len(o_ids) == len(h_ids) and np.array_equal(o_ids, h_ids) and np.array_equal(np.diff(h_ooffs), o_counts)
             # (not timed) the LAST documents of the batch too, and the offsets of the whole batch: placement at large indices
             nt = min(20_000, n_docs)
@@ -171,7 +172,24 @@ def main():
                 and bool((d_ooffs[1:n_docs + 1] >= d_ooffs[:n_docs]).all().item())
             parity_note = ("bit-exact vs oracle on the first %d and the last %d docs (%d tokens); offsets of all %d docs monotone, ending at the token count"
                            % (ns, nt, len(o_ids) + len(p_ids), n_docs)) if same else "MISMATCH vs oracle on the sample"
-            cpu = {"value": round(nb / tcpu / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port",
+            # one thread, on a tenth of the sample (SURVEY.md 8d asks for both figures)
+            n1 = max(1, ns // 20)
+            O.encode_batch(ov, args.pattern, h_bytes[:int(h_offs[n1])], h_offs[:n1 + 1], threads=1, timing=tm)
+            t1 = tm["seconds"]
+            cpu_1t = round(int(h_offs[n1]) / t1 / 1e6, 2)
+            # PCIe-inclusive rate through the host-buffer entry point (tkz_encode_batch_utf8: pageable H2D of the text,
+            # D2H of ids + offsets).  Reported beside the number, never as `value`.
+            nh = min(1_000_000, n_docs)
+            hh_offs = d_offs[:nh + 1].cpu().numpy()
+            hh_bytes = d_bytes[:int(hh_offs[-1])].cpu().numpy()
+            enc.encode_batch(hh_bytes[:int(hh_offs[min(nh, 1000)])], hh_offs[:min(nh, 1000) + 1])      # warm the staging buffers
+            tc = time.perf_counter()
+            hh_ids, hh_ooffs = enc.encode_batch(hh_bytes, hh_offs)
+            th = time.perf_counter() - tc
+            host_same = int(hh_ooffs[-1]) == int(d_ooffs[nh].item()) and np.array_equal(hh_ids[:len(h_ids)], h_ids[:len(hh_ids)])
+            host_path = {"value": round(len(hh_bytes) / th / 1e6, 1), "unit": "MB/s", "docs": nh, "same_ids_as_device_path": bool(host_same),
+                         "note": "tkz_encode_batch_utf8 on host numpy buffers: pageable H2D of the text + kernels + D2H of ids and offsets"}
+            cpu = {"value": round(nb / tcpu / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port", "value_1_thread": cpu_1t,
                    "sample": "first %d documents (%.1f MB) of the same corpus, reference-algorithm CPU restatement (oracle/), "
                              "8192-entry LRU memo per thread, %d threads of %d host cores" % (ns, nb / 1e6, threads, os.cpu_count() or 1)}
         line = {
@@ -188,6 +206,7 @@ def main():
             "parity": parity_note,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "pcie_inclusive": host_path,
         }
         print(json.dumps(line))
     if world > 1:

@@ -186,15 +186,21 @@ class Encoder:
         return out[:k].tolist()
 
 
-def encode_batch(vocab: Vocab, pattern: int, data: np.ndarray, offsets: np.ndarray, threads=1, cache_size=8192):
-    """CPU-baseline batch: returns (ids_flat, counts). data uint8[total], offsets int64[n+1]."""
+def encode_batch(vocab: Vocab, pattern: int, data: np.ndarray, offsets: np.ndarray, threads=1, cache_size=8192, timing=None):
+    """CPU-baseline batch: returns (ids_flat, counts). data uint8[total], offsets int64[n+1].
+    timing (a dict), if given, receives "seconds": the wall time of the C call alone (the threads' encode work, without
+    the numpy packing of the result below)."""
     data = np.ascontiguousarray(data, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     n = len(offsets) - 1
     out = np.empty(max(1, len(data)), dtype=np.int32)
     counts = np.zeros(max(1, n), dtype=np.int32)
+    import time
+    t0 = time.perf_counter()
     tot = lib().tkzo_encode_batch(vocab._h, pattern, cache_size, data.ctypes.data, offsets.ctypes.data, n,
                                   out.ctypes.data, counts.ctypes.data, threads)
+    if timing is not None:
+        timing["seconds"] = time.perf_counter() - t0
     if tot < 0:
         raise OracleError(int(tot))
     counts = counts[:n]
