@@ -223,7 +223,7 @@ def check_utf16(lib, O, vocab, ovocab):
             assert enc.encode_utf16(units) == oenc.encode_utf16(units), (pattern, units)
 
 
-def random_vocab_bytes(rng, alphabet=b"abc", n_keys=300, max_len=6):
+def random_vocab_bytes(rng, alphabet=b"abc", n_keys=300, max_len=6, rank_step=1, rank_base=0):
     """A rank table that is NOT a trained BPE vocabulary: all 256 single bytes plus random strings over a tiny
     alphabet, ranks in random order.  The reference's merge loop is still well defined on it, and new pairs
     routinely rank BELOW the pair just merged -- the case the round-based merger has to cut its rounds for."""
@@ -234,14 +234,17 @@ def random_vocab_bytes(rng, alphabet=b"abc", n_keys=300, max_len=6):
         keys.add(bytes(rng.choice(alphabet) for _ in range(rng.randint(2, max_len))))
     keys = list(keys)
     rng.shuffle(keys)
-    return b"".join(base64.b64encode(k) + b" " + str(i).encode() + b"\n" for i, k in enumerate(keys))
+    # (sparse / large ranks are legal in a .tiktoken file; ranks >= 2^22 switch the lane mergers to their unpacked form)
+    return b"".join(base64.b64encode(k) + b" " + str(rank_base + rank_step * i).encode() + b"\n" for i, k in enumerate(keys))
 
 
 def check_random_vocab(lib, O, seed, n_vocabs, lens, n_pieces):
-    """Every merge path (lane 16, lane 32, workgroup rounds in LDS and in the pool) on adversarial rank tables."""
+    """Every merge path (lean lane, arena lane packed and unpacked, whole-wave rounds in the pool) on adversarial rank tables."""
     rng = random.Random(seed)
     for vi in range(n_vocabs):
-        raw = random_vocab_bytes(rng, alphabet=rng.choice([b"ab", b"abc", b"abcd"]), n_keys=rng.choice([20, 100, 400]))
+        big = vi % 3 == 2                                        # every third vocabulary: sparse ranks up to ~2^26
+        raw = random_vocab_bytes(rng, alphabet=rng.choice([b"ab", b"abc", b"abcd"]), n_keys=rng.choice([20, 100, 400]),
+                                 rank_step=97_003 if big else 1, rank_base=4_200_000 if big else 0)
         vocab, ovocab = N.Vocab(raw, lib), O.Vocab(raw)
         enc = N.Encoder(vocab, N.CL100K)
         pcs = [bytes(rng.choice(b"abcd"[:rng.randint(1, 4)]) for _ in range(rng.choice(lens))) for _ in range(n_pieces)]

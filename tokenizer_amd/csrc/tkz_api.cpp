@@ -344,6 +344,8 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     e->T.bmp_class = e->t_bmp.as<uint8_t>();
     e->T.max_key_len = V.max_key_len;
     e->T.pattern = pattern;
+    e->T.max_rank = 0;
+    for (int32_t r : V.ranks) e->T.max_rank = std::max(e->T.max_rank, r);
     *out = e;
     return TKZ_OK;
 }

@@ -117,14 +117,23 @@ TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* 
 //   ids[n4] | pr[n4] | alive[a4]      n4 = n rounded up to 4, a4 = ceil(n / 32) rounded up to 4 (one bit per part start)
 // The same loop as tkz_bpe_lane with the piece length a run-time value (the heavy kernel gives every missed piece of a
 // pass a span of its own size out of one LDS arena: CJK runs, emoji sequences and long identifiers are merged side by
-// side instead of one after the other).  pr holds plain ranks; the leftmost strict minimum (:47-54) is a first-wins
-// scan.  Returns the number of tokens: ids[k] for every set bit k of alive[], in order (tkz_bpe_var_emit).
+// side instead of one after the other).  PACKED (vocabularies whose ranks stay below 2^22, i.e. every published one):
+// pr holds rank << 10 | position and the leftmost strict minimum (:47-54) is a v_min3 tree over 16-byte LDS reads, as
+// in tkz_bpe_lane; otherwise pr holds plain ranks and the minimum is a first-wins scan (6x the VALU work per entry).
+// Returns the number of tokens: ids[k] for every set bit k of alive[], in order (tkz_bpe_var_emit).
+constexpr int kVarPosBits = 10;                         // positions < 1024 (kArenaPiece)
+constexpr int32_t kVarPackedMaxRank = (1 << (32 - kVarPosBits)) - 2;
 TKZ_HD int tkz_bpe_var_n4(int n) { return (n + 3) & ~3; }
 TKZ_HD int tkz_bpe_var_a4(int n) { return (((n + 31) >> 5) + 3) & ~3; }
 TKZ_HD int tkz_bpe_var_dwords(int n) { return 2 * tkz_bpe_var_n4(n) + tkz_bpe_var_a4(n); }
 
-template <class ByteAt>
+template <bool PACKED, class ByteAt>
 TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, int* err) {
+    constexpr uint32_t NONE = PACKED ? TKZ_NOKEY : (uint32_t)TKZ_RANK_NONE;
+    auto entry = [](int32_t rank, int pos) -> uint32_t {
+        if (rank == TKZ_RANK_NONE) return NONE;
+        return PACKED ? (((uint32_t)rank << kVarPosBits) | (uint32_t)pos) : (uint32_t)rank;
+    };
     const int n4 = tkz_bpe_var_n4(n), nw = (n + 31) >> 5;
     uint32_t* ids = st; uint32_t* pr = st + n4; uint32_t* am = st + 2 * n4;
     uint4* ids4 = reinterpret_cast<uint4*>(ids); uint4* pr4 = reinterpret_cast<uint4*>(pr);
@@ -144,10 +153,10 @@ TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, 
             if (c + 4 * q < n4) {
                 uint4 a, p;
                 a.x = idv[4 * q]; a.y = idv[4 * q + 1]; a.z = idv[4 * q + 2]; a.w = idv[4 * q + 3];
-                p.x = c + 4 * q + 1 < n ? (uint32_t)r2[4 * q] : (uint32_t)TKZ_RANK_NONE;
-                p.y = c + 4 * q + 2 < n ? (uint32_t)r2[4 * q + 1] : (uint32_t)TKZ_RANK_NONE;
-                p.z = c + 4 * q + 3 < n ? (uint32_t)r2[4 * q + 2] : (uint32_t)TKZ_RANK_NONE;
-                p.w = c + 4 * q + 4 < n ? (uint32_t)r2[4 * q + 3] : (uint32_t)TKZ_RANK_NONE;
+                p.x = c + 4 * q + 1 < n ? entry(r2[4 * q], c + 4 * q) : NONE;
+                p.y = c + 4 * q + 2 < n ? entry(r2[4 * q + 1], c + 4 * q + 1) : NONE;
+                p.z = c + 4 * q + 3 < n ? entry(r2[4 * q + 2], c + 4 * q + 2) : NONE;
+                p.w = c + 4 * q + 4 < n ? entry(r2[4 * q + 3], c + 4 * q + 3) : NONE;
                 ids4[(c >> 2) + q] = a; pr4[(c >> 2) + q] = p;
             }
         }
@@ -155,16 +164,27 @@ TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, 
     for (int w = 0; w < nw; ++w) am[w] = tkz_lowmask32(n - 32 * w);
     int cnt = n;
     for (;;) {                                          // while (byteIndicesAndRanks.Count > 1) (:45)
-        uint32_t m = (uint32_t)TKZ_RANK_NONE; int j = 0;
+        uint32_t m = NONE; int j = 0;
+        if (PACKED) {
+#pragma unroll 4
+            for (int q = 0; q < (n4 >> 2); ++q) {       // leftmost strict min (:47-54): packed (rank, position), ties -> lower position
+                const uint4 p = pr4[q];
+                m = tkz_min3u(m, tkz_min3u(p.x, p.y, p.z), p.w);
+            }
+            if (m == NONE) break;                       // minRank == int.MaxValue (:65-68)
+            j = (int)(m & ((1u << kVarPosBits) - 1u));
+            m >>= kVarPosBits;
+        } else {
 #pragma unroll 2
-        for (int q = 0; q < (n4 >> 2); ++q) {           // leftmost strict min (:47-54)
-            const uint4 p = pr4[q];
-            if (p.x < m) { m = p.x; j = 4 * q; }
-            if (p.y < m) { m = p.y; j = 4 * q + 1; }
-            if (p.z < m) { m = p.z; j = 4 * q + 2; }
-            if (p.w < m) { m = p.w; j = 4 * q + 3; }
+            for (int q = 0; q < (n4 >> 2); ++q) {       // leftmost strict min (:47-54), first wins
+                const uint4 p = pr4[q];
+                if (p.x < m) { m = p.x; j = 4 * q; }
+                if (p.y < m) { m = p.y; j = 4 * q + 1; }
+                if (p.z < m) { m = p.z; j = 4 * q + 2; }
+                if (p.w < m) { m = p.w; j = 4 * q + 3; }
+            }
+            if (m == NONE) break;                       // minRank == int.MaxValue (:65-68)
         }
-        if (m == (uint32_t)TKZ_RANK_NONE) break;        // minRank == int.MaxValue (:65-68)
         // r: the part being swallowed (next part after j), rr: the one after it, l: the part before j
         int w = (j + 1) >> 5;
         uint32_t bits = w < nw ? am[w] & (0xFFFFFFFFu << ((j + 1) & 31)) : 0u;
@@ -187,10 +207,10 @@ TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, 
         const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2s]);
         const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
         ids[j] = m;                                     // the merged part carries the rank it was found under
-        pr[r] = (uint32_t)TKZ_RANK_NONE;
+        pr[r] = NONE;
         const int32_t rkr = tkz_match_pair(m, idr, vr1, vr2), rkl = tkz_match_pair(idl, m, vl1, vl2);
-        pr[j] = hasr ? (uint32_t)rkr : (uint32_t)TKZ_RANK_NONE;             // (:58)
-        if (hasl) pr[l] = (uint32_t)rkl;                                    // (:59-62)
+        pr[j] = hasr ? entry(rkr, j) : NONE;                                // (:58)
+        if (hasl) pr[l] = entry(rkl, l);                                    // (:59-62)
         --cnt;
     }
     for (int w = 0; w < nw; ++w)

@@ -534,8 +534,9 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                     if (lane < nmiss) {
                         const uint32_t e = s_missq_h[lane];
                         const int s = (int)(e & 0x7FFu), len = (int)((e >> 11) & 0x3FFu) + 1;
-                        s_minfo[lane] = (uint32_t)tkz_bpe_lane_var(T, [&](int i) -> uint32_t { const int p = s + i; return p < kSub + kHalo ? sb[p] : gbase[p]; },
-                                                                   len, &s_scr[4 * (e >> 21)], &err1);
+                        auto at = [&](int i) -> uint32_t { const int p = s + i; return p < kSub + kHalo ? sb[p] : gbase[p]; };
+                        s_minfo[lane] = (uint32_t)(T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, &s_scr[4 * (e >> 21)], &err1)
+                                                                                   : tkz_bpe_lane_var<false>(T, at, len, &s_scr[4 * (e >> 21)], &err1));
                     }
                 } else if (lane < nmiss) {
                     uint32_t alive = 1;

@@ -64,6 +64,7 @@ struct TkzTables {      // device pointers + masks, passed to kernels by value
     const uint8_t* bmp_class;        // [65536] Unicode class of each BMP code unit (tkz_classes.h)
     int32_t max_key_len;
     int32_t pattern;
+    int32_t max_rank;                // largest rank in the vocabulary (kernels pack rank and position into one word when it is small)
 };
 
 TKZ_HD uint32_t tkz_mix32(uint32_t h) {
