@@ -177,18 +177,33 @@ def main():
             O.encode_batch(ov, args.pattern, h_bytes[:int(h_offs[n1])], h_offs[:n1 + 1], threads=1, timing=tm)
             t1 = tm["seconds"]
             cpu_1t = round(int(h_offs[n1]) / t1 / 1e6, 2)
-            # PCIe-inclusive rate through the host-buffer entry point (tkz_encode_batch_utf8: pageable H2D of the text,
-            # D2H of ids + offsets).  Reported beside the number, never as `value`.
+            # PCIe-inclusive rate through the host-buffer entry point (tkz_encode_batch_utf8: H2D of the text, the kernels,
+            # D2H of ids + offsets), on ordinary (pageable) numpy buffers and on page-locked ones.  Output buffers are
+            # allocated and touched beforehand: a fresh np.empty would add its first-touch page faults to the figure.
+            # Reported beside the number, never as `value`.
             nh = min(1_000_000, n_docs)
             hh_offs = d_offs[:nh + 1].cpu().numpy()
             hh_bytes = d_bytes[:int(hh_offs[-1])].cpu().numpy()
-            enc.encode_batch(hh_bytes[:int(hh_offs[min(nh, 1000)])], hh_offs[:min(nh, 1000) + 1])      # warm the staging buffers
-            tc = time.perf_counter()
-            hh_ids, hh_ooffs = enc.encode_batch(hh_bytes, hh_offs)
-            th = time.perf_counter() - tc
-            host_same = int(hh_ooffs[-1]) == int(d_ooffs[nh].item()) and np.array_equal(hh_ids[:len(h_ids)], h_ids[:len(hh_ids)])
-            host_path = {"value": round(len(hh_bytes) / th / 1e6, 1), "unit": "MB/s", "docs": nh, "same_ids_as_device_path": bool(host_same),
-                         "note": "tkz_encode_batch_utf8 on host numpy buffers: pageable H2D of the text + kernels + D2H of ids and offsets"}
+            o_ids_buf = np.zeros(len(hh_bytes), np.int32)
+            o_off_buf = np.zeros(nh + 1, np.int64)
+            rates = []
+            for pinned in (False, True):
+                if pinned:
+                    tb = torch.empty(len(hh_bytes), dtype=torch.uint8).pin_memory(); tb.numpy()[:] = hh_bytes
+                    to = torch.empty(nh + 1, dtype=torch.int64).pin_memory(); to.numpy()[:] = hh_offs
+                    ti = torch.zeros(len(hh_bytes), dtype=torch.int32).pin_memory()
+                    too = torch.zeros(nh + 1, dtype=torch.int64).pin_memory()
+                    bufs = (tb.numpy(), to.numpy(), (ti.numpy(), too.numpy()))
+                else:
+                    bufs = (hh_bytes, hh_offs, (o_ids_buf, o_off_buf))
+                enc.encode_batch(bufs[0], bufs[1], out=bufs[2])                   # sizes the encoder's staging buffers
+                tc = time.perf_counter()
+                r_ids, r_ooffs = enc.encode_batch(bufs[0], bufs[1], out=bufs[2])
+                rates.append(round(len(hh_bytes) / (time.perf_counter() - tc) / 1e6, 1))
+                host_same = (pinned is False or host_same) and int(r_ooffs[-1]) == int(d_ooffs[nh].item()) \
+                    and np.array_equal(r_ids[:len(h_ids)], h_ids[:len(r_ids)])
+            host_path = {"value": rates[0], "value_pinned_buffers": rates[1], "unit": "MB/s", "docs": nh, "same_ids_as_device_path": bool(host_same),
+                         "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text + kernels + D2H of ids and offsets, one after the other"}
             cpu = {"value": round(nb / tcpu / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port", "value_1_thread": cpu_1t,
                    "sample": "first %d documents (%.1f MB) of the same corpus, reference-algorithm CPU restatement (oracle/), "
                              "8192-entry LRU memo per thread, %d threads of %d host cores" % (ns, nb / 1e6, threads, os.cpu_count() or 1)}

@@ -180,17 +180,24 @@ class Encoder:
         return self.lib.L.tkz_encoder_workspace_bytes(self._h)
 
     # -- host buffers --
-    def encode_batch(self, data: np.ndarray, offsets: np.ndarray, out_cap=None):
-        """EncodeBatch: (ids int32[total_tokens], out_offsets int64[n+1])."""
+    def encode_batch(self, data: np.ndarray, offsets: np.ndarray, out_cap=None, out=None):
+        """EncodeBatch: (ids int32[total_tokens], out_offsets int64[n+1]).  `out` = (ids, out_offsets) arrays to fill
+        (e.g. views of page-locked memory: the copies over PCIe then run at link speed instead of through a bounce buffer)."""
         data = np.ascontiguousarray(data, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         n = len(offsets) - 1
         cap = len(data) if out_cap is None else out_cap
-        ids = np.empty(max(1, cap), np.int32)
-        ooff = np.empty(n + 1, np.int64)
+        if out is not None:
+            ids, ooff = out
+            assert ids.dtype == np.int32 and ooff.dtype == np.int64 and ids.flags.c_contiguous and ooff.flags.c_contiguous
+            assert len(ooff) >= n + 1
+            cap = len(ids)
+        else:
+            ids = np.empty(max(1, cap), np.int32)
+            ooff = np.empty(n + 1, np.int64)
         needed = C.c_int64(0)
         self.lib.check(self.lib.L.tkz_encode_batch_utf8(self._h, _ptr(data), _ptr(offsets), n, _ptr(ids), cap, _ptr(ooff), C.byref(needed)))
-        return ids[:needed.value], ooff
+        return ids[:needed.value], ooff[:n + 1]
 
     def encode_pieces(self, data: np.ndarray, offsets: np.ndarray):
         data = np.ascontiguousarray(data, dtype=np.uint8)

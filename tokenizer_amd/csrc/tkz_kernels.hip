@@ -485,7 +485,8 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                         if (plen[b] <= TKZ_SHORT_KEY_MAX) rank = tkz_match_short(q0[b], q1[b], q2[b], (uint32_t)plen[b], pv1[t], pv2[t]);
                         else {
                             const int s = ps[b];
-                            if (HEAVY) rank = tkz_lookup_long(T, [&](int i) -> uint32_t { const int p = s + i; return p < kSub + kHalo ? sb[p] : gbase[p]; }, (uint32_t)plen[b]);
+                            if (HEAVY && s + plen[b] > kSub + kHalo)      // runs past the staged bytes: read the piece from memory
+                                rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return gbase[s + i]; }, (uint32_t)plen[b]);
                             else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)plen[b]);
                         }
                         if (rank != TKZ_RANK_NONE) { cnt[b] = 1; tok[b] = rank; }      // TikTokenizer.cs:262-265
@@ -534,9 +535,13 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                     if (lane < nmiss) {
                         const uint32_t e = s_missq_h[lane];
                         const int s = (int)(e & 0x7FFu), len = (int)((e >> 11) & 0x3FFu) + 1;
-                        auto at = [&](int i) -> uint32_t { const int p = s + i; return p < kSub + kHalo ? sb[p] : gbase[p]; };
-                        s_minfo[lane] = (uint32_t)(T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, &s_scr[4 * (e >> 21)], &err1)
-                                                                                   : tkz_bpe_lane_var<false>(T, at, len, &s_scr[4 * (e >> 21)], &err1));
+                        // (a piece that runs past the staged bytes is read from memory; the choice is per piece, not per byte)
+                        uint32_t* st = &s_scr[4 * (e >> 21)];
+                        auto merge = [&](auto at) -> int {
+                            return T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &err1) : tkz_bpe_lane_var<false>(T, at, len, st, &err1);
+                        };
+                        s_minfo[lane] = (uint32_t)(s + len <= kSub + kHalo ? merge([&](int i) -> uint32_t { return sb[s + i]; })
+                                                                           : merge([&](int i) -> uint32_t { return gbase[s + i]; }));
                     }
                 } else if (lane < nmiss) {
                     uint32_t alive = 1;
