@@ -121,7 +121,9 @@ def _token_lengths(oracle_gpt2):
 
 
 @pytest.mark.parametrize("kind,pattern,n_docs,lo,hi", [(1, 2, 400_000, 256, 768), (2, 2, 200_000, 256, 768), (3, 3, 1_500, 30_000, 34_000),
-                                                       (1, 1, 100_000, 16, 128), (3, 2, 1_500, 30_000, 34_000)])
+                                                       (1, 1, 100_000, 16, 128), (3, 2, 1_500, 30_000, 34_000),
+                                                       # BASELINE.json configs[1], [2] and one GPU's share of [4] at full size
+                                                       (1, 2, 10_000_000, 256, 768), (2, 2, 2_000_000, 256, 768), (3, 3, 32_768, 30_000, 34_000)])
 def test_device_corpus_properties_and_sample(lib, vocab, oracle_mod, oracle_gpt2, kind, pattern, n_docs, lo, hi):
     import torch
     r = _device_run(lib, vocab, kind, pattern, n_docs, lo, hi, 0x5EED0000 + kind)
