@@ -306,8 +306,9 @@ TKZ_DEV int tkz_wave_scan_sum(int v, int* total) {
     return x - v;
 }
 
-// HEAVY = false: the common case, sub-tiles whose pieces are all <= 16 bytes; a sub-tile with a longer piece is
-//                 appended to P.heavy_q and left to the second launch.
+// HEAVY = false: the common case, sub-tiles whose pieces are all <= 16 bytes or vocabulary keys; a sub-tile with a longer
+//                 piece that has to be merged (or more than kLeanPieces pieces) is appended to P.heavy_q and left to the
+//                 second launch.
 // HEAVY = true:   the deferred sub-tiles: lanes merge pieces of up to 32 bytes (16 at a time, 32-entry state each:
 //                 CJK runs, emoji sequences, long identifiers), the whole wavefront merges anything longer.
 template <bool HEAVY>
@@ -408,7 +409,16 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
     for (int k0 = 0; k0 < np; k0 += 64) {
         const int k = k0 + lane;
         bool lg = false;
-        if (k < np) lg = (k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s_pstart[k] > LANE_MAX;
+        if (k < np) {
+            const int64_t len = (k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s_pstart[k];
+            lg = len > LANE_MAX;
+            // lean: a piece of 17+ bytes may still be a vocabulary key (runs of spaces, long common words): stage B will find it, as it
+            // finds the keys of 13..16 bytes; the sub-tile is refused only if the piece has to be merged
+            if (!HEAVY && lg && len <= T.max_key_len && s_pstart[k] + len <= kSub + kHalo) {
+                const int s = s_pstart[k];
+                lg = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)len) == TKZ_RANK_NONE;
+            }
+        }
         const uint64_t m = simt::ballot(lg);
         if (m) { if (lane == 0) s_longmask[k0 >> 6] = m; nlong += tkz_popc64(m); }
     }
