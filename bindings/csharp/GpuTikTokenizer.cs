@@ -30,6 +30,8 @@ namespace Microsoft.DeepDev
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_utf8(IntPtr encoder, byte* bytes, long* docOffsets, long nDocs,
                                                                                   int* outIds, long outCap, long* outOffsets, out long needed);
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_utf16(IntPtr encoder, char* text, long len, int* outIds, long outCap, out long nOut);
+        [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_utf16(IntPtr encoder, char* units, long* unitOffsets, long nDocs,
+                                                                                   int* outIds, long outCap, long* outOffsets, out long needed);
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_pieces_utf8(IntPtr encoder, byte* bytes, long* docOffsets, long nDocs, int* outIds, long outCap,
                                                                                          long* docPieceOffsets, long* pieceByteOffsets, long* pieceTokenOffsets,
                                                                                          long pieceCap, out long nPieces, out long neededIds);
@@ -111,18 +113,19 @@ namespace Microsoft.DeepDev
                     if (start >= text.Length) break;
                 }
             }
-            // 2. the plain segments as one UTF-8 document batch (Encoding.UTF8.GetBytes, TikTokenizer.cs:261)
+            // 2. the plain segments as one batch of UTF-16 code units: a memcpy per string; Encoding.UTF8.GetBytes
+            //    (TikTokenizer.cs:261) is done for the whole batch on the device by tkz_encode_batch_utf16
             var offsets = new long[segments.Count + 1];
             long total = 0;
-            for (int i = 0; i < segments.Count; ++i) { offsets[i] = total; total += Encoding.UTF8.GetByteCount(segments[i].text.AsSpan(segments[i].start, segments[i].end - segments[i].start)); }
+            for (int i = 0; i < segments.Count; ++i) { offsets[i] = total; total += segments[i].end - segments[i].start; }
             offsets[segments.Count] = total;
-            var bytes = new byte[Math.Max(1, total)];
+            var units = new char[Math.Max(1, total)];
             for (int i = 0; i < segments.Count; ++i)
-                Encoding.UTF8.GetBytes(segments[i].text.AsSpan(segments[i].start, segments[i].end - segments[i].start), bytes.AsSpan((int)offsets[i]));
-            var ids = new int[Math.Max(1, total)];                             // a token is at least one byte
+                segments[i].text.CopyTo(segments[i].start, units, (int)offsets[i], segments[i].end - segments[i].start);
+            var ids = new int[Math.Max(1, 3 * total)];                         // a code unit is at most three UTF-8 bytes, a token at least one byte
             var outOffsets = new long[segments.Count + 1];
-            fixed (byte* pb = bytes) fixed (long* po = offsets) fixed (int* pi = ids) fixed (long* poo = outOffsets)
-                Tkz.Check(Tkz.tkz_encode_batch_utf8(encoder, pb, po, segments.Count, pi, ids.Length, poo, out _));
+            fixed (char* pu = units) fixed (long* po = offsets) fixed (int* pi = ids) fixed (long* poo = outOffsets)
+                Tkz.Check(Tkz.tkz_encode_batch_utf16(encoder, pu, po, segments.Count, pi, ids.Length, poo, out _));
             // 3. stitch
             var result = new List<List<int>>(texts.Count);
             for (int t = 0; t < texts.Count; ++t) result.Add(new List<int>());

@@ -99,6 +99,16 @@ tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const
                                    int64_t out_cap, int64_t* d_out_offsets, void* hip_stream,
                                    int64_t* total_tokens);
 
+/* EncodeBatch for hosts whose strings are UTF-16 (.NET `string`, Java, JavaScript): document d is the code units
+ * units[unit_offsets[d] .. unit_offsets[d+1]).  The units are uploaded as they are and converted to UTF-8 ON THE
+ * DEVICE exactly as Encoding.UTF8.GetBytes does (TikTokenizer.cs:261: a surrogate pair becomes one 4-byte char, a lone
+ * surrogate -- also a pair cut by a document boundary -- becomes EF BF BD); the host is spared the transcode, which
+ * is the slow half of feeding `string`s to the UTF-8 entry point.  Results as tkz_encode_batch_utf8;
+ * out_cap >= 3 * total units is always sufficient.  Host buffers. */
+tkz_status tkz_encode_batch_utf16(tkz_encoder* e, const uint16_t* units, const int64_t* unit_offsets,
+                                  int64_t n_docs, int32_t* out_ids, int64_t out_cap,
+                                  int64_t* out_offsets, int64_t* needed);
+
 /* Single-string entries for `string` callers.  UTF-16: the split sees the code units as .NET's Regex
  * does (a supplementary-plane char is two "other" units, a lone surrogate one); each piece is
  * converted as Encoding.UTF8.GetBytes does (lone surrogate -> EF BF BD), TikTokenizer.cs:261. */

@@ -135,6 +135,21 @@ public:
     Trimmed EncodeTrimPrefix(const std::string& text, int maxTokenCount, bool applySpecialTokens = true) const {
         return EncodeTrimPrefix(text, applySpecialTokens ? all_specials() : std::vector<std::string>{}, maxTokenCount);
     }
+    // a batch of UTF-16 strings (plain path): the code units go to the device as they are (tkz_encode_batch_utf16)
+    std::vector<std::vector<int32_t>> EncodeBatchUtf16(const std::vector<std::u16string>& texts) const {
+        std::vector<uint16_t> units;
+        std::vector<int64_t> offs{0};
+        for (const auto& t : texts) { units.insert(units.end(), t.begin(), t.end()); offs.push_back(static_cast<int64_t>(units.size())); }
+        const size_t cap = units.size() * 3 + 1;
+        std::vector<int32_t> ids(cap);
+        std::vector<int64_t> ooff(texts.size() + 1, 0);
+        int64_t needed = 0;
+        if (units.empty()) units.push_back(0);
+        check(tkz_encode_batch_utf16(enc_, units.data(), offs.data(), static_cast<int64_t>(texts.size()), ids.data(), static_cast<int64_t>(cap), ooff.data(), &needed));
+        std::vector<std::vector<int32_t>> out(texts.size());
+        for (size_t t = 0; t < texts.size(); ++t) out[t].assign(ids.begin() + ooff[t], ids.begin() + ooff[t + 1]);
+        return out;
+    }
     // the code units of a .NET string; plain path only (Encode(text, false))
     std::vector<int32_t> EncodeUtf16(const std::u16string& text) const {
         std::vector<int32_t> ids(text.size() * 3 + 1);

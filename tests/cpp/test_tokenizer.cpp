@@ -35,6 +35,14 @@ int main(int argc, char** argv) {
     REQUIRE(batch.size() == 4 && batch[0].empty() && batch[1] == hw && batch[2] == std::vector<int32_t>{50301});
     REQUIRE(batch[3] == tok.Encode(text.substr(0, 2000)));
     REQUIRE(tok.EncodeUtf16(u"Hello World") == hw);
+    {
+        const std::u16string lone = {u'a', char16_t(0xD83D)}, pair = {char16_t(0xD83D), char16_t(0xDE00), u'b'}, half = {char16_t(0xDE00), u'c'};
+        const auto b16 = tok.EncodeBatchUtf16({u"Hello World", u"", lone, half, pair});
+        REQUIRE(b16.size() == 5 && b16[0] == hw && b16[1].empty());
+        REQUIRE(b16[2] == tok.Encode("a\xEF\xBF\xBD", false));                    // a lone high half at the end of a document -> U+FFFD
+        REQUIRE(b16[3] == tok.Encode("\xEF\xBF\xBD" "c", false));                 // ... and the low half that starts the next one
+        REQUIRE(b16[4] == tok.Encode("\xF0\x9F\x98\x80" "b", false));            // a pair inside one document is one 4-byte char
+    }
     // EncodeTrimSuffix / EncodeTrimPrefix (TikTokenizerUnitTest.cs:128-225 restated; expected values from the oracle's TrimOracle)
     {
         const std::string t = "<|im_start|>Hello TempWorld \xF0\x9F\x98\x80 \xE6\xBC\xA2\xE5\xAD\x97<|im_end|>";

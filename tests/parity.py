@@ -3,6 +3,8 @@ the library under test (`lib`, a tokenizer_amd._native.Library) and the oracle, 
 the same seeded inputs.  Integer work: the bar is bit-exact."""
 import random
 
+import pytest
+
 import numpy as np
 
 import regex_crosscheck as RC
@@ -221,6 +223,48 @@ def check_utf16(lib, O, vocab, ovocab):
             for _ in range(rng.choice([0, 0, 1, 3])):   # sprinkle lone surrogates
                 units.insert(rng.randint(0, len(units)), rng.choice([0xD800, 0xDBFF, 0xDC00, 0xDFFF]))
             assert enc.encode_utf16(units) == oenc.encode_utf16(units), (pattern, units)
+
+
+def check_utf16_batch(lib, O, vocab, ovocab, seed=91, rounds=10, doc_counts=(1, 7, 60), max_units=400):
+    """tkz_encode_batch_utf16 (code units transcoded ON THE DEVICE) vs the oracle's UTF-16 entry per document, and vs the UTF-8
+    batch entry fed with the bytes Encoding.UTF8.GetBytes would produce.  Surrogate pairs, lone halves, halves that face each
+    other across a document boundary, pairs straddling the 16-unit lane groups and the 1024-unit tiles, empty documents."""
+    rng = random.Random(seed)
+    alpha = RC.alphabet()
+    for pattern in (N.P1, N.CL100K, N.O200K):
+        enc = N.Encoder(vocab, pattern)
+        oenc = O.Encoder(ovocab, pattern)
+        for it in range(rounds):
+            docs = []
+            for _ in range(rng.choice(doc_counts)):
+                k = rng.random()
+                if k < 0.1:
+                    units = []
+                elif k < 0.3:                                   # dense surrogate soup
+                    units = [rng.choice([0xD800, 0xDBFF, 0xDC00, 0xDFFF, 0xD83D, 0xDE00, 0x41, 0x4E2D, 0xE9]) for _ in range(rng.randint(1, max_units))]
+                else:
+                    units = RC.to_units(RC.random_text(rng, alpha, rng.randint(0, max_units)))
+                    for _ in range(rng.choice([0, 0, 1, 3])):
+                        units.insert(rng.randint(0, len(units)), rng.choice([0xD800, 0xDBFF, 0xDC00, 0xDFFF]))
+                docs.append(units)
+            if len(docs) >= 2 and rng.random() < 0.5:           # a high half ending one document, a low half starting the next
+                i = rng.randrange(len(docs) - 1)
+                docs[i] = docs[i] + [0xD83D]
+                docs[i + 1] = [0xDE00] + docs[i + 1]
+            flat = np.asarray([u for d in docs for u in d], dtype=np.uint16)
+            offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.int64)
+            ids, ooff = enc.encode_batch_utf16(flat, offs)
+            for d, units in enumerate(docs):
+                assert ids[ooff[d]:ooff[d + 1]].tolist() == oenc.encode_utf16(units), (pattern, it, d, units[:40])
+            u8 = [np.asarray(d, dtype=np.uint16).tobytes().decode("utf-16-le", "replace").encode("utf-8") for d in docs]
+            data, boffs = pack(u8)
+            ids8, ooff8 = enc.encode_batch(data, boffs)
+            assert ids.tolist() == ids8.tolist() and ooff.tolist() == ooff8.tolist()
+    enc = N.Encoder(vocab, N.CL100K)
+    ids, ooff = enc.encode_batch_utf16(np.zeros(0, np.uint16), np.zeros(4, np.int64))       # three empty documents
+    assert len(ids) == 0 and ooff.tolist() == [0, 0, 0, 0]
+    with pytest.raises(N.TkzError):
+        enc.encode_batch_utf16(np.zeros(8, np.uint16) + 65, np.array([0, 5, 3, 8], dtype=np.int64))
 
 
 def random_vocab_bytes(rng, alphabet=b"abc", n_keys=300, max_len=6, rank_step=1, rank_base=0):

@@ -78,6 +78,10 @@ def test_utf16_entry(lib, vocab, oracle_mod, oracle_gpt2):
     parity.check_utf16(lib, oracle_mod, vocab, oracle_gpt2)
 
 
+def test_utf16_batch_entry(lib, vocab, oracle_mod, oracle_gpt2):
+    parity.check_utf16_batch(lib, oracle_mod, vocab, oracle_gpt2, **dict(rounds=4, doc_counts=(1, 7, 40), max_units=300))
+
+
 def test_corpus_generator_host_device_agree(lib):
     """The counter-based generator: the device kernel (emulated here) and the host function must produce
     the same bytes, and a document must not depend on its position in the batch."""

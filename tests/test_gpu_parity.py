@@ -93,6 +93,10 @@ def test_utf16_entry(lib, vocab, oracle_mod, oracle_gpt2):
     parity.check_utf16(lib, oracle_mod, vocab, oracle_gpt2)
 
 
+def test_utf16_batch_entry(lib, vocab, oracle_mod, oracle_gpt2):
+    parity.check_utf16_batch(lib, oracle_mod, vocab, oracle_gpt2, **dict(rounds=12, doc_counts=(1, 7, 60, 600), max_units=2500))
+
+
 # ---- device-resident path at scale ------------------------------------------------------------------
 
 def _device_run(lib, vocab, kind, pattern, n_docs, lo, hi, seed, sequential=False, first_doc=0):

@@ -81,6 +81,7 @@ class Library:
         L.tkz_encoder_device.argtypes = [vp]
         L.tkz_encode_batch_utf8.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
         L.tkz_encode_batch_device.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, pi64]
+        L.tkz_encode_batch_utf16.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
         L.tkz_encode_utf8.argtypes = [vp, vp, i64, vp, i64, pi64]
         L.tkz_encode_utf16.argtypes = [vp, vp, i64, vp, i64, pi64]
         L.tkz_pretokenize_utf8.argtypes = [vp, vp, vp, i64, vp]
@@ -197,6 +198,25 @@ class Encoder:
             ooff = np.empty(n + 1, np.int64)
         needed = C.c_int64(0)
         self.lib.check(self.lib.L.tkz_encode_batch_utf8(self._h, _ptr(data), _ptr(offsets), n, _ptr(ids), cap, _ptr(ooff), C.byref(needed)))
+        return ids[:needed.value], ooff[:n + 1]
+
+    def encode_batch_utf16(self, units: np.ndarray, offsets: np.ndarray, out=None):
+        """EncodeBatch on UTF-16 code units (uint16[total], offsets int64[n+1] in units); transcoded on the device.
+        `out` = (ids, out_offsets) arrays to fill, as in encode_batch."""
+        units = np.ascontiguousarray(units, dtype=np.uint16)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        if out is not None:
+            ids, ooff = out
+            assert ids.dtype == np.int32 and ooff.dtype == np.int64 and ids.flags.c_contiguous and ooff.flags.c_contiguous and len(ooff) >= n + 1
+            cap = len(ids)
+        else:
+            cap = max(1, 3 * len(units))
+            ids = np.empty(cap, np.int32)
+            ooff = np.empty(n + 1, np.int64)
+        needed = C.c_int64(0)
+        buf = units if len(units) else np.zeros(1, np.uint16)
+        self.lib.check(self.lib.L.tkz_encode_batch_utf16(self._h, _ptr(buf), _ptr(offsets), n, _ptr(ids), cap, _ptr(ooff), C.byref(needed)))
         return ids[:needed.value], ooff[:n + 1]
 
     def encode_pieces(self, data: np.ndarray, offsets: np.ndarray):

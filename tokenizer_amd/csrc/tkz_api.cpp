@@ -78,6 +78,8 @@ struct tkz_encoder {
     DevBuf w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
     // staging for the host-buffer entry points
     DevBuf s_bytes, s_offs, s_out, s_outoffs;
+    // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
+    DevBuf u_units, u_offs, u_docbits, u_grp, u_tsum, u_tbase, u_bsum, u_counters, u_bytes, u_boffs;
     CounterBlock* h_counters = nullptr;   // pinned
     int64_t bytes_allocated = 0;
     // profiling
@@ -355,7 +357,8 @@ void tkz_encoder_destroy(tkz_encoder* e) {
     (void)hipSetDevice(e->device);
     DevBuf* bufs[] = {&e->t_short, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp,
                       &e->w_xq, &e->w_heavyq, &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
-                      &e->w_doctok, &e->w_dcount, &e->w_dbase, &e->w_counters, &e->w_pool, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs};
+                      &e->w_doctok, &e->w_dcount, &e->w_dbase, &e->w_counters, &e->w_pool, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs,
+                      &e->u_units, &e->u_offs, &e->u_docbits, &e->u_grp, &e->u_tsum, &e->u_tbase, &e->u_bsum, &e->u_counters, &e->u_bytes, &e->u_boffs};
     for (DevBuf* b : bufs) b->release();
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (int k = 0; k < tkz::K_COUNT; ++k) for (int p = 0; p < 2; ++p) if (e->ev[k][p]) (void)hipEventDestroy(e->ev[k][p]);
@@ -407,6 +410,67 @@ tkz_status tkz_encode_utf16(tkz_encoder* e, const uint16_t* text, int64_t len, i
         else { u8.push_back(0xF0 | (c >> 18)); u8.push_back(0x80 | ((c >> 12) & 0x3F)); u8.push_back(0x80 | ((c >> 6) & 0x3F)); u8.push_back(0x80 | (c & 0x3F)); }
     }
     return tkz_encode_utf8(e, u8.data(), (int64_t)u8.size(), out_ids, out_cap, n_out);
+}
+
+tkz_status tkz_encode_batch_utf16(tkz_encoder* e, const uint16_t* units, const int64_t* unit_offsets, int64_t n_docs,
+                                  int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed) {
+    using namespace tkz;
+    tkz_status st = check_encoder(e);
+    if (st != TKZ_OK) return st;
+    if (!out_offsets || (out_cap > 0 && !out_ids)) return fail(TKZ_E_ARG, "null output buffer");
+    if (n_docs < 0 || !unit_offsets || (n_docs > 0 && !units && unit_offsets[n_docs] > 0)) return fail(TKZ_E_ARG, "null buffer");
+    if (unit_offsets[0] != 0) return fail(TKZ_E_ARG, "doc_offsets[0] must be 0");
+    const int64_t total_units = unit_offsets[n_docs];
+    if (total_units < 0) return fail(TKZ_E_ARG, "negative unit count");
+    if (needed) *needed = 0;
+    if (total_units == 0) {
+        for (int64_t d = 0; d <= n_docs; ++d) { if (unit_offsets[d] != 0) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count"); out_offsets[d] = 0; }
+        return TKZ_OK;
+    }
+    std::lock_guard<std::mutex> lock(e->mu);
+    int64_t* acc = &e->bytes_allocated;
+    hipStream_t stream = nullptr;
+    const int64_t nwords = total_units / 64 + 1, ntiles = u16_tiles(total_units), nblk = (ntiles + kScanBlock - 1) / kScanBlock;
+    HIP_TRY(e->u_units.ensure((size_t)(total_units + 64) * 2, acc));
+    HIP_TRY(e->u_offs.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(e->u_docbits.ensure((size_t)(nwords + 8) * 8, acc));
+    HIP_TRY(e->u_grp.ensure((size_t)ntiles * 64 * 4, acc));
+    HIP_TRY(e->u_tsum.ensure((size_t)ntiles * 4, acc));
+    HIP_TRY(e->u_tbase.ensure((size_t)ntiles * 8, acc));
+    HIP_TRY(e->u_bsum.ensure((size_t)(nblk + 1) * 8, acc));
+    HIP_TRY(e->u_counters.ensure(64, acc));
+    HIP_TRY(e->u_boffs.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(hipMemcpy(e->u_units.p, units, (size_t)total_units * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->u_offs.p, unit_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+    // 1. document marks over the code units, UTF-8 length of every unit, scan
+    Launch L{stream, nullptr, e};
+    int32_t* counters = e->u_counters.as<int32_t>();
+    int64_t* grand = reinterpret_cast<int64_t*>(e->u_counters.as<char>() + 8);
+    HIP_TRY(hipMemsetAsync(counters, 0, 64, stream));
+    HIP_TRY(hipMemsetAsync(e->u_docbits.p, 0, (size_t)(nwords + 8) * 8, stream));
+    launch_docmark(L, e->u_offs.as<int64_t>(), n_docs, total_units, e->u_docbits.as<uint64_t>(), counters);
+    launch_u16_len(L, e->u_units.as<uint16_t>(), total_units, e->u_docbits.as<uint64_t>(), ntiles, e->u_grp.as<int32_t>(), e->u_tsum.as<int32_t>());
+    launch_scan(L, e->u_tsum.as<int32_t>(), ntiles, e->u_bsum.as<int64_t>(), e->u_tbase.as<int64_t>(), grand, -1);
+    struct { int32_t err; int32_t pad; int64_t grand; } h{};
+    HIP_TRY(hipMemcpy(&h, counters, sizeof h, hipMemcpyDeviceToHost));
+    HIP_TRY(hipGetLastError());
+    if (h.err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count");
+    const int64_t total = h.grand;                       // UTF-8 bytes of the batch
+    // 2. the UTF-8 batch, in HBM; 3. the same path as every other entry point
+    HIP_TRY(e->u_bytes.ensure((size_t)total + 64, acc));
+    launch_u16_write(L, e->u_units.as<uint16_t>(), total_units, e->u_docbits.as<uint64_t>(), ntiles, e->u_tbase.as<int64_t>(), e->u_bytes.as<uint8_t>(),
+                     e->u_offs.as<int64_t>(), n_docs, e->u_grp.as<int32_t>(), grand, e->u_boffs.as<int64_t>());
+    const int64_t cap = std::min<int64_t>(out_cap, total);
+    HIP_TRY(e->s_out.ensure((size_t)std::max<int64_t>(cap, 1) * 4, acc));
+    HIP_TRY(e->s_outoffs.ensure((size_t)(n_docs + 1) * 8, acc));
+    int64_t tokens = 0;
+    st = encode_device(e, e->u_bytes.as<uint8_t>(), e->u_boffs.as<int64_t>(), n_docs, total, e->s_out.as<int32_t>(), cap,
+                       e->s_outoffs.as<int64_t>(), stream, true, nullptr, &tokens);
+    if (needed) *needed = tokens;
+    if (st != TKZ_OK) return st;
+    if (tokens) HIP_TRY(hipMemcpy(out_ids, e->s_out.p, (size_t)tokens * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_offsets, e->s_outoffs.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    return TKZ_OK;
 }
 
 tkz_status tkz_pretokenize_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs, uint64_t* out_bitmap_words) {

@@ -66,6 +66,12 @@ void launch_gather(const Launch& L, const int32_t* tmp, const int32_t* tile_coun
                    const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap);
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
                     const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs);
+// UTF-16 documents -> UTF-8 documents (Encoding.UTF8.GetBytes for a batch): lengths + group prefixes, then (after the scan of
+// the tile sums) the bytes and the byte offset of every document
+int64_t u16_tiles(int64_t total_units);
+void launch_u16_len(const Launch& L, const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum);
+void launch_u16_write(const Launch& L, const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, const int64_t* tile_base,
+                      uint8_t* out, const int64_t* unit_offs, int64_t n_docs, const int32_t* grp_prefix, const int64_t* grand, int64_t* byte_offs);
 void launch_corpus(hipStream_t s, int kind, uint64_t seed, int64_t first_doc, int64_t n_docs, int min_len, int max_len,
                    int64_t* d_offs, uint8_t* d_bytes, int64_t cap_bytes, int64_t* d_total);
 

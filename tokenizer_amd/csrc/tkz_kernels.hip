@@ -779,6 +779,123 @@ TKZ_KERNEL(256) void k_docoffs(const int64_t* offs, int64_t n_docs, int64_t tota
 }
 
 // -------------------------------------------------------------------------------------------------
+// UTF-16 documents -> UTF-8 documents on the device (the batch form of Encoding.UTF8.GetBytes, TikTokenizer.cs:261):
+// a host whose strings are UTF-16 (.NET, Java, JS) uploads the code units as they are.  A surrogate pair becomes one
+// 4-byte char, a lone surrogate (also: a pair cut by a document boundary) becomes EF BF BD, as GetBytes does.
+//   k_u16_len     per 1024-unit tile (one wavefront, 16 units per lane): UTF-8 length of every unit -> tile sum and the
+//                 exclusive prefix of every 16-unit group inside the tile
+//   (scan of the tile sums: k_scan_*)
+//   k_u16_write   the bytes, staged per tile in LDS and copied out coalesced
+//   k_u16_docoffs byte offset of every document = tile base + group prefix + the units of the group before it
+// -------------------------------------------------------------------------------------------------
+constexpr int kU16Tile = 1024;      // code units per wavefront
+constexpr int kU16Lane = 16;        // ... per lane
+// UTF-8 length of unit u at a position whose neighbours are prev/next (0 when there is none inside the document):
+// 0 for the low half of a pair (its bytes belong to the high half)
+TKZ_HD int tkz_u16_len(uint32_t u, uint32_t prev, bool has_prev, uint32_t next, bool has_next) {
+    if (u < 0x80u) return 1;
+    if (u < 0x800u) return 2;
+    if (u - 0xD800u < 0x400u) return (has_next && next - 0xDC00u < 0x400u) ? 4 : 3;      // high surrogate: pair, or alone -> U+FFFD
+    if (u - 0xDC00u < 0x400u) return (has_prev && prev - 0xD800u < 0x400u) ? 0 : 3;      // low surrogate: second half, or alone -> U+FFFD
+    return 3;
+}
+TKZ_HD int tkz_u16_put(uint32_t u, uint32_t next, int len, uint8_t* o) {
+    if (len == 1) { o[0] = (uint8_t)u; }
+    else if (len == 2) { o[0] = (uint8_t)(0xC0u | (u >> 6)); o[1] = (uint8_t)(0x80u | (u & 0x3Fu)); }
+    else if (len == 4) {
+        const uint32_t c = 0x10000u + ((u - 0xD800u) << 10) + (next - 0xDC00u);
+        o[0] = (uint8_t)(0xF0u | (c >> 18)); o[1] = (uint8_t)(0x80u | ((c >> 12) & 0x3Fu)); o[2] = (uint8_t)(0x80u | ((c >> 6) & 0x3Fu)); o[3] = (uint8_t)(0x80u | (c & 0x3Fu));
+    } else if (len == 3) {
+        const uint32_t c = (u - 0xD800u < 0x800u) ? 0xFFFDu : u;
+        o[0] = (uint8_t)(0xE0u | (c >> 12)); o[1] = (uint8_t)(0x80u | ((c >> 6) & 0x3Fu)); o[2] = (uint8_t)(0x80u | (c & 0x3Fu));
+    }
+    return len;
+}
+// the units of this lane's group (and the one after it), its document-start bits, the lengths; returns the lane sum
+struct TkzU16Lane { uint32_t u[kU16Lane + 1]; uint8_t len[kU16Lane]; };
+TKZ_DEV int tkz_u16_lane(const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t tile, TkzU16Lane* L) {
+    const int lane = simt::lane();
+    const int64_t p0 = tile * kU16Tile + (int64_t)lane * kU16Lane;
+    uint32_t w[8];
+    if (p0 + kU16Lane <= total) {
+        const uint4 a = tkz_load16(units + p0), b = tkz_load16(units + p0 + 8);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    } else {
+        for (int k = 0; k < 8; ++k) {
+            const int64_t q = p0 + 2 * k;
+            w[k] = (q < total ? (uint32_t)units[q] : 0u) | ((q + 1 < total ? (uint32_t)units[q + 1] : 0u) << 16);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kU16Lane; ++k) L->u[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+    // neighbours across the lane edge: the last unit of the lane below, the first unit of the lane above
+    uint32_t prev = simt::shflu(L->u[kU16Lane - 1], (lane + 63) & 63), next = simt::shflu(L->u[0], (lane + 1) & 63);
+    if (lane == 0) prev = p0 > 0 ? (uint32_t)units[p0 - 1] : 0u;
+    if (lane == 63) next = p0 + kU16Lane < total ? (uint32_t)units[p0 + kU16Lane] : 0u;
+    L->u[kU16Lane] = next;
+    // document-start bits of positions p0 .. p0 + 16 (17 bits)
+    const int64_t wd = p0 >> 6; const int sh = (int)(p0 & 63);
+    uint64_t ds = p0 < total ? docbits[wd] >> sh : 0ull;                       // (docbits has total/64 + 1 words)
+    if (sh == 48 && p0 + kU16Lane <= total) ds |= (docbits[wd + 1] & 1ull) << 16;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kU16Lane; ++k) {
+        const int64_t q = p0 + k;
+        int len = 0;
+        if (q < total) {
+            const bool has_prev = q > 0 && !((ds >> k) & 1ull);                 // not the first unit of its document
+            const bool has_next = q + 1 < total && !((ds >> (k + 1)) & 1ull);   // not the last one
+            len = tkz_u16_len(L->u[k], k ? L->u[k - 1] : prev, has_prev, L->u[k + 1], has_next);
+        }
+        L->len[k] = (uint8_t)len; sum += len;
+    }
+    return sum;
+}
+TKZ_KERNEL(256) void k_u16_len(const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum) {
+    const int64_t tile = simt::bid() * (kThreads / 64) + simt::wave();
+    if (tile >= ntiles) return;
+    TkzU16Lane L;
+    const int sum = tkz_u16_lane(units, total, docbits, tile, &L);
+    int tot;
+    const int pre = tkz_wave_scan_sum(sum, &tot);
+    grp_prefix[tile * 64 + simt::lane()] = pre;
+    if (simt::lane() == 0) tile_sum[tile] = tot;
+}
+TKZ_KERNEL(256) void k_u16_write(const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, const int64_t* tile_base,
+                                 uint8_t* out) {
+    TKZ_SHARED uint8_t s_stage[kThreads / 64][3 * kU16Tile + 16];            // (a unit yields at most 3 bytes: a pair is 4 for 2 units)
+    const int64_t tile = simt::bid() * (kThreads / 64) + simt::wave();
+    if (tile >= ntiles) return;
+    TkzU16Lane L;
+    const int sum = tkz_u16_lane(units, total, docbits, tile, &L);
+    int tot;
+    int pos = tkz_wave_scan_sum(sum, &tot);
+    uint8_t* st = s_stage[simt::wave()];
+#pragma unroll
+    for (int k = 0; k < kU16Lane; ++k) pos += tkz_u16_put(L.u[k], L.u[k + 1], L.len[k], st + pos);
+    (void)simt::ballot(true);          // (the staging area is private to the wavefront: its LDS accesses are ordered, no barrier)
+    uint8_t* dst = out + tile_base[tile];
+    for (int i = simt::lane(); i < tot; i += 64) dst[i] = st[i];
+}
+TKZ_KERNEL(256) void k_u16_docoffs(const uint16_t* units, int64_t total, const uint64_t* docbits, const int64_t* unit_offs, int64_t n_docs,
+                                   const int64_t* tile_base, const int32_t* grp_prefix, const int64_t* grand, int64_t* byte_offs) {
+    const int64_t stride = simt::nblocks() * simt::nthreads();
+    for (int64_t d = simt::bid() * simt::nthreads() + simt::tid(); d <= n_docs; d += stride) {
+        const int64_t p = unit_offs[d];
+        if (p >= total) { byte_offs[d] = *grand; continue; }
+        if (p < 0) { byte_offs[d] = 0; continue; }
+        const int64_t g0 = p & ~(int64_t)(kU16Lane - 1);
+        int64_t v = tile_base[p / kU16Tile] + grp_prefix[p / kU16Lane];
+        for (int64_t q = g0; q < p; ++q) {                                 // the units of the group that belong to the document before
+            const bool has_prev = q > 0 && !((docbits[q >> 6] >> (q & 63)) & 1ull);
+            const bool has_next = q + 1 < total && !((docbits[(q + 1) >> 6] >> ((q + 1) & 63)) & 1ull);
+            v += tkz_u16_len(units[q], q > 0 ? units[q - 1] : 0u, has_prev, q + 1 < total ? units[q + 1] : 0u, has_next);
+        }
+        byte_offs[d] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // synthetic corpus (tkz_corpus.h): lengths, then bytes
 // -------------------------------------------------------------------------------------------------
 TKZ_KERNEL(256) void k_corpus_lengths(int kind, uint64_t seed, int64_t first_doc, int64_t n_docs, int min_len, int max_len, int64_t* offs) {
@@ -875,6 +992,15 @@ void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int6
     TKZ_LAUNCH(k_docoffs, grid_for(n_docs + 1), kThreads, L.stream, d_offs, n_docs, total, tile_base, docbits, docord_base, doc_tok, grand, out_offs);
     hook(L, K_DOCOFFS, 1);
 }
+void launch_u16_len(const Launch& L, const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum) {
+    TKZ_LAUNCH(k_u16_len, cdiv(ntiles, kThreads / 64), kThreads, L.stream, units, total, docbits, ntiles, grp_prefix, tile_sum);
+}
+void launch_u16_write(const Launch& L, const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, const int64_t* tile_base,
+                      uint8_t* out, const int64_t* unit_offs, int64_t n_docs, const int32_t* grp_prefix, const int64_t* grand, int64_t* byte_offs) {
+    TKZ_LAUNCH(k_u16_write, cdiv(ntiles, kThreads / 64), kThreads, L.stream, units, total, docbits, ntiles, tile_base, out);
+    TKZ_LAUNCH(k_u16_docoffs, grid_for(n_docs + 1), kThreads, L.stream, units, total, docbits, unit_offs, n_docs, tile_base, grp_prefix, grand, byte_offs);
+}
+int64_t u16_tiles(int64_t total_units) { return cdiv(total_units, kU16Tile); }
 void launch_corpus(hipStream_t s, int kind, uint64_t seed, int64_t first_doc, int64_t n_docs, int min_len, int max_len,
                    int64_t* d_offs, uint8_t* d_bytes, int64_t cap_bytes, int64_t* d_total) {
     TKZ_LAUNCH(k_corpus_lengths, grid_for(n_docs), kThreads, s, kind, seed, first_doc, n_docs, min_len, max_len, d_offs);
