@@ -143,7 +143,7 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         HIP_TRY(e->w_doctok.ensure((size_t)(n_docs + 2) * 4, acc));
         HIP_TRY(e->w_dcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(e->w_dbase.ensure((size_t)ntiles * 8, acc));
-        HIP_TRY(e->w_heavyq.ensure((size_t)ntiles * 8, acc));
+        HIP_TRY(e->w_heavyq.ensure((size_t)ntiles + 64, acc));
         if (!e->w_pool.p) HIP_TRY(e->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
     }
     if (!e->h_counters) HIP_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(CounterBlock), 0));
@@ -176,8 +176,8 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             P.offs = d_offs; P.n_docs = n_docs;
             P.tmp = e->w_tmp.as<int32_t>(); P.tile_count = e->w_tcount.as<int32_t>(); P.tile_first = e->w_tfirst.as<int64_t>();
             P.docord_base = e->w_dbase.as<int64_t>(); P.doc_tok = e->w_doctok.as<int32_t>(); P.counters = counters;
-            P.heavy_q = e->w_heavyq.as<int64_t>();
-            P.heavy_count = reinterpret_cast<unsigned long long*>(e->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
+            P.heavy_flag = e->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
+            HIP_TRY(hipMemsetAsync(P.heavy_flag, 0, (size_t)ntiles, stream));
             P.pool = e->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(e->w_pool.cap / 4);
             P.ablate = 0; P.devprof = nullptr;
 #ifdef TKZ_DEVPROF

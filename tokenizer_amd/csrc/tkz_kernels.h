@@ -40,7 +40,8 @@ struct EncodeParams {
     const int64_t* docord_base;   // per sub-tile: number of distinct document-start positions before it
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
     int32_t* counters;            // [0] error bits
-    int64_t* heavy_q; unsigned long long* heavy_count;                    // sub-tiles deferred to k_encode_waves_heavy
+    uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_encode_waves for the ones it leaves to k_encode_waves_heavy
+                                                                          // (a flag, not a queue: a queue's one counter serialises a million atomics on mixed text)
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)
     // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE): per-stage cycle counters (bit 4) and ablations
     // (bit0 skip merges, bit1 skip table probes, bit2 skip stores, bit3 stage 0/1 only).  Compiled out of libtkz.so otherwise.

@@ -307,7 +307,7 @@ TKZ_DEV int tkz_wave_scan_sum(int v, int* total) {
 }
 
 // HEAVY = false: the common case, sub-tiles whose pieces are all <= 16 bytes or vocabulary keys; a sub-tile with a longer
-//                 piece that has to be merged (or more than kLeanPieces pieces) is appended to P.heavy_q and left to the
+//                 piece that has to be merged (or more than kLeanPieces pieces) is flagged in P.heavy_flag and left to the
 //                 second launch.
 // HEAVY = true:   the deferred sub-tiles: lanes merge pieces of up to 32 bytes (16 at a time, 32-entry state each:
 //                 CJK runs, emoji sequences, long identifiers), the whole wavefront merges anything longer.
@@ -316,8 +316,13 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
 
 TKZ_KERNEL_OCC(64, 5) void k_encode_waves(TkzTables T, EncodeParams P) { tkz_encode_subtile<false>(T, P, simt::bid()); }
 TKZ_KERNEL_OCC(64, 3) void k_encode_waves_heavy(TkzTables T, EncodeParams P) {
-    const int64_t n = *P.heavy_count;
-    for (int64_t q = simt::bid(); q < n; q += simt::nblocks()) { tkz_encode_subtile<true>(T, P, P.heavy_q[q]); simt::sync(); }
+    // chunks of 64 consecutive sub-tiles per wavefront: one flag per lane, then the flagged ones in turn
+    const int lane = simt::lane();
+    for (int64_t c = simt::bid(); c * 64 < P.nsub; c += simt::nblocks()) {
+        const int64_t t = c * 64 + lane;
+        uint64_t m = simt::ballot(t < P.nsub && P.heavy_flag[t] != 0);
+        for (; m; m &= m - 1) { tkz_encode_subtile<true>(T, P, c * 64 + tkz_ctz64(m)); simt::sync(); }
+    }
 }
 
 template <bool HEAVY>
@@ -401,7 +406,7 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
     const int64_t docord0 = P.docord_base[sub];
     simt::sync();
     if (!HEAVY && np > kLeanPieces) {                     // more pieces than the lean kernel keeps positions for
-        if (lane == 0) P.heavy_q[simt::atomic_add64(P.heavy_count, 1ull)] = sub;
+        if (lane == 0) P.heavy_flag[sub] = 1;
         return;
     }
     const int64_t first_abs = np ? base + s_pstart[0] : base;
@@ -424,7 +429,7 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
     }
     simt::sync();
     if (!HEAVY && nlong > 0) {                            // a piece longer than a lean lane can merge: the heavy launch takes this sub-tile
-        if (lane == 0) P.heavy_q[simt::atomic_add64(P.heavy_count, 1ull)] = sub;
+        if (lane == 0) P.heavy_flag[sub] = 1;
         return;
     }
 
@@ -966,7 +971,7 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub) {
     hook(L, K_ENCODE, 0);
     TKZ_LAUNCH(k_encode_waves, nsub, 64, L.stream, T, P);
-    TKZ_LAUNCH(k_encode_waves_heavy, nsub < 16384 ? nsub : 16384, 64, L.stream, T, P);   // strides over the deferred sub-tiles
+    { const int64_t chunks = cdiv(nsub, 64); TKZ_LAUNCH(k_encode_waves_heavy, chunks < 16384 ? chunks : 16384, 64, L.stream, T, P); }   // strides over 64-sub-tile chunks
     hook(L, K_ENCODE, 1);
 }
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t nsub, int32_t* cnt) {

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Kernel-trace summary + PMC passes (separate runs, never combined with tracing domains) for bench.py.
-# usage: tools/gpu_profile.sh <tag> [docs]
+# usage: tools/gpu_profile.sh <tag> [docs] [extra bench.py arguments, e.g. "--kind 2"]
 set -u
-TAG=${1:-r01}; DOCS=${2:-2000000}
+TAG=${1:-r01}; DOCS=${2:-2000000}; EXTRA=${3:-}
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$REPO"; mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --docs $DOCS --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python $REPO/bench.py --docs $DOCS --steps 3 --warmup 1 --no-cpu-baseline $EXTRA"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG/trace -o trace -- $BENCH > $REPO/gpurun_out/prof_$TAG/trace.log 2>&1; echo "trace rc=$?"
 i=0
