@@ -450,6 +450,9 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
         }
         if (next_long > k0) {
             const int kend = k0 + kPassPieces < next_long ? k0 + kPassPieces : next_long;
+            // (heavy sub-tiles are usually sparse in pieces: the batches a pass does not need are skipped as a whole; the lean kernel
+            //  nearly always fills all of them and keeps its straight-line code)
+            const int nbatch = HEAVY ? (kend - k0 + 63) >> 6 : kPassBatches;
             long long t0 = prof ? simt::clock() : 0;
             // ---------------- stage A: fetch keys, issue the first probe of every batch ----------------
             int ps[kPassBatches], plen[kPassBatches];
@@ -458,7 +461,7 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
             for (int b = 0; b < kPassBatches; ++b) {
                 const int k = k0 + 64 * b + lane;
                 ps[b] = 0; plen[b] = 0; q0[b] = q1[b] = q2[b] = 0; slot1[b] = slot2[b] = 0;
-                if (k < kend) {
+                if (b < nbatch && k < kend) {
                     const int s = s_pstart[k];
                     const int len = (int)((k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s);
                     ps[b] = s; plen[b] = len;
@@ -487,13 +490,17 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
                 uint4 pv1[3], pv2[3];
 #pragma unroll
                 for (int t = 0; t < 3 && g + t < kPassBatches; ++t) {
-                    pv1[t] = tkz_load16(&T.short_slots[TKZ_DEV_FLAG(P, 2) ? 0u : slot1[g + t]]);
-                    pv2[t] = tkz_load16(&T.short_slots[TKZ_DEV_FLAG(P, 2) ? 0u : slot2[g + t]]);
+                    pv1[t].x = pv1[t].y = pv1[t].z = pv1[t].w = 0; pv2[t] = pv1[t];
+                    if (g + t < nbatch) {
+                        pv1[t] = tkz_load16(&T.short_slots[TKZ_DEV_FLAG(P, 2) ? 0u : slot1[g + t]]);
+                        pv2[t] = tkz_load16(&T.short_slots[TKZ_DEV_FLAG(P, 2) ? 0u : slot2[g + t]]);
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < 3 && g + t < kPassBatches; ++t) {
                     const int b = g + t;
                     cnt[b] = 0; tok[b] = 0; qidx[b] = -1;
+                    if (b >= nbatch) continue;
                     bool miss = false;
                     if (plen[b] > 0) {
                         int32_t rank;
@@ -579,6 +586,7 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
             // ---------------- stage C: positions, dense stores, document marks ----------------
 #pragma unroll
             for (int b = 0; b < kPassBatches; ++b) {
+                if (b >= nbatch) continue;
                 uint32_t alive = 0;
                 if (qidx[b] >= 0) { alive = s_minfo[qidx[b]]; cnt[b] = HEAVY ? (int)alive : tkz_popc32(alive); }
                 int tot;
