@@ -131,7 +131,12 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
             if (pos >= 0) v = tkz_load16(bytes + pos);
             s_blk[((c >> 2) * kBlockRowStride + (c & 3) * 16) / 16] = v;
         }
-        if (lane < kBlockRowStride / 16) { uint4 z; z.x = z.y = z.z = z.w = 0; s_blk[(64 * kBlockRowStride) / 16 + lane] = z; }
+        if (lane < kBlockRowStride / 16) {                 // the row after the block: its first 16 bytes (a char of the last row may end there), zeros beyond
+            uint4 z; z.x = z.y = z.z = z.w = 0;
+            const int64_t pos = (first + 64) << 6;
+            if (lane == 0 && pos + 16 <= total) z = tkz_load16(bytes + pos);
+            s_blk[(64 * kBlockRowStride) / 16 + lane] = z;
+        }
     }
     simt::sync();
     if (r0 >= nrows) return;
@@ -141,7 +146,7 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
         uint64_t out;
         bool done;
         if constexpr (PATTERN == TKZ_PAT_O200K) done = tkz_block_eval_o200k(reinterpret_cast<const uint8_t*>(s_blk), ds, &out);
-        else done = tkz_block_eval<PATTERN>(reinterpret_cast<const uint8_t*>(s_blk), ds, &out);
+        else done = tkz_block_eval<PATTERN>(reinterpret_cast<const uint8_t*>(s_blk), ds, bmp, &out);
         if (done) {
             if (lane >= 1 && lane <= kRowsPerWave && row < nrows) startbits[row] = out;
             return;

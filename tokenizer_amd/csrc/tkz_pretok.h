@@ -578,12 +578,13 @@ TKZ_HD uint32_t tkz_swar_eq(uint32_t x, uint32_t c) {
 // the four bit-7 flags of r as a nibble (byte 0 -> bit 0)
 TKZ_HD uint32_t tkz_swar_nibble(uint32_t r) { return (((r >> 7) & 0x01010101u) * 0x01020408u) >> 24; }
 
-struct TkzBlockMasks { uint64_t L, N, O, W, CR, SP, AP, UP, SL; uint32_t hi; };
+struct TkzBlockMasks { uint64_t L, N, O, W, CR, SP, AP, UP, SL, HI, CONT; uint32_t hi; };   // HI: bytes >= 0x80, CONT: 10xxxxxx
 
 // classify the 64 bytes of this lane's row (16 dwords at `row`, 16-byte aligned); CASES: also upper-case letters and '/'
 template <bool CASES>
 TKZ_HD TkzBlockMasks tkz_block_classify(const uint4* row) {
     uint32_t mL[2] = {0, 0}, mN[2] = {0, 0}, mW[2] = {0, 0}, mC[2] = {0, 0}, mS[2] = {0, 0}, mA[2] = {0, 0}, mU[2] = {0, 0}, mX[2] = {0, 0};
+    uint32_t mH[2] = {0, 0}, mT[2] = {0, 0};
     uint32_t hi = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -592,8 +593,11 @@ TKZ_HD TkzBlockMasks tkz_block_classify(const uint4* row) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int k = 4 * q + t;                       // dword index: bytes 4k .. 4k+3
-            const uint32_t x = xs[t];
-            hi |= x;
+            const uint32_t xr = xs[t];
+            hi |= xr;
+            // (the range tests add per byte and must not carry into the next one: they run on the low 7 bits; what they say
+            //  about a byte >= 0x80 is meaningless and masked by the caller with HI)
+            const uint32_t x = xr & 0x7F7F7F7Fu;
             const uint32_t y = x | 0x20202020u;
             const int h = k >> 3, sh = 4 * (k & 7);
             mL[h] |= tkz_swar_nibble(tkz_swar_range(y, 'a', 'z')) << sh;
@@ -602,6 +606,8 @@ TKZ_HD TkzBlockMasks tkz_block_classify(const uint4* row) {
             mC[h] |= tkz_swar_nibble(tkz_swar_eq(x, '\n') | tkz_swar_eq(x, '\r')) << sh;
             mS[h] |= tkz_swar_nibble(tkz_swar_eq(x, ' ')) << sh;
             mA[h] |= tkz_swar_nibble(tkz_swar_eq(x, '\'')) << sh;
+            mH[h] |= tkz_swar_nibble(xr & 0x80808080u) << sh;
+            mT[h] |= tkz_swar_nibble(xr & ~(xr << 1) & 0x80808080u) << sh;
             if (CASES) {
                 mU[h] |= tkz_swar_nibble(tkz_swar_range(x, 'A', 'Z')) << sh;
                 mX[h] |= tkz_swar_nibble(tkz_swar_eq(x, '/')) << sh;
@@ -612,23 +618,61 @@ TKZ_HD TkzBlockMasks tkz_block_classify(const uint4* row) {
     m.L = ((uint64_t)mL[1] << 32) | mL[0]; m.N = ((uint64_t)mN[1] << 32) | mN[0]; m.W = ((uint64_t)mW[1] << 32) | mW[0];
     m.CR = ((uint64_t)mC[1] << 32) | mC[0]; m.SP = ((uint64_t)mS[1] << 32) | mS[0]; m.AP = ((uint64_t)mA[1] << 32) | mA[0];
     m.UP = ((uint64_t)mU[1] << 32) | mU[0]; m.SL = ((uint64_t)mX[1] << 32) | mX[0];
+    m.HI = ((uint64_t)mH[1] << 32) | mH[0]; m.CONT = ((uint64_t)mT[1] << 32) | mT[0];
     m.O = ~(m.L | m.N | m.W);
     m.hi = hi & 0x80808080u;
     return m;
 }
 
-// Evaluates rows first_row .. first_row+63 (lane = row - first_row) staged at `stage` (kBlockRowStride bytes per
-// row, one extra row of zeros after the last).  Returns false -- and leaves `out` unset -- when the block has to be
-// done by the sequential row loop; otherwise *out is this lane's piece-start word (valid for lanes 1..62).
+// ---- rows with multi-byte chars: the same algebra on CHARS -------------------------------------------
+// The rules are stated on chars.  On an ASCII row a char is a byte and the masks above are already char masks; on
+// a row with multi-byte chars every lane packs its masks down to one bit per char (the continuation bytes are
+// squeezed out: compress / expand of Hacker's Delight 7-4, 7-5), evaluates the same algebra on n <= 64 chars
+// instead of 64, and spreads the piece starts back onto the lead bytes.  A char belongs to the row its lead
+// byte is in.
+struct TkzPext { uint64_t mv[6]; };
+TKZ_HD TkzPext tkz_pext_prepare(uint64_t m) {
+    TkzPext p;
+    uint64_t mk = ~m << 1;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        uint64_t mp = mk ^ (mk << 1);
+        mp ^= mp << 2; mp ^= mp << 4; mp ^= mp << 8; mp ^= mp << 16; mp ^= mp << 32;
+        const uint64_t mv = mp & m;
+        p.mv[i] = mv;
+        m = (m ^ mv) | (mv >> (1 << i));
+        mk &= ~mp;
+    }
+    return p;
+}
+TKZ_HD uint64_t tkz_pext(uint64_t x, uint64_t m, const TkzPext& p) {      // the bits of x under m, packed to the low end
+    x &= m;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { const uint64_t t = x & p.mv[i]; x = (x ^ t) | (t >> (1 << i)); }
+    return x;
+}
+TKZ_HD uint64_t tkz_pdep(uint64_t x, uint64_t m, const TkzPext& p) {      // bit k of x to the k-th set bit of m
+#pragma unroll
+    for (int i = 5; i >= 0; --i) { const uint64_t t = x << (1 << i); x = (x & ~p.mv[i]) | (t & p.mv[i]); }
+    return x & m;
+}
+
+// one bit per CHAR of the lane's row (n chars, bits >= n clear): classes, raw contraction candidates ('x followed by a
+// literal of 2 / 3 chars, conditions not yet applied), document starts
+struct TkzCharMasks { uint64_t L, N, O, O2, W, CR, SP, k2, k3, ds; int n; };
+
+// The rules on char masks; every lane of the wavefront calls it (two lane-shift exchanges inside).  Returns false when
+// the nearest-neighbour scheme cannot do the block: a digit run or a white-space run covering a whole row.
 template <int PATTERN>
-TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, uint64_t* out) {
+TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, uint64_t* start_out) {
     const int lane = simt::lane();
-    const TkzBlockMasks m = tkz_block_classify<false>(reinterpret_cast<const uint4*>(stage + lane * kBlockRowStride));
-    const uint64_t L = m.L, N = m.N, O = m.O, W = m.W, CR = m.CR, SP = m.SP, AP = m.AP;
+    const int n = c.n, top = n - 1;
+    const uint64_t all = tkz_lowmask(n);
+    const uint64_t L = c.L, N = c.N, O = c.O, W = c.W, CR = c.CR, SP = c.SP, ds = c.ds;
     const uint64_t nds = ~ds;
-    // ---- exchange 1: the class of the byte before my row (bit 63 of the previous lane's masks), the first bytes of the next row
-    const uint32_t up_bits = (uint32_t)(L >> 63) | ((uint32_t)(N >> 63) << 1) | ((uint32_t)(O >> 63) << 2) | ((uint32_t)(SP >> 63) << 3) |
-                             ((uint32_t)(W >> 63) << 4) | ((uint32_t)(CR >> 63) << 5);
+    // ---- exchange 1: the class of the char before my row (the last char of the previous lane's row), the first chars of the next row
+    const uint32_t up_bits = (uint32_t)((L >> top) & 1) | ((uint32_t)((N >> top) & 1) << 1) | ((uint32_t)((O >> top) & 1) << 2) |
+                             ((uint32_t)((SP >> top) & 1) << 3) | ((uint32_t)((W >> top) & 1) << 4) | ((uint32_t)((CR >> top) & 1) << 5);
     // head: a CR/LF inside the leading connected white-space run of my row (what the row above needs for `\s*[\r\n]+`)
     const uint64_t conn = W & nds;
     const int lead_ws = (~conn) ? tkz_ctz64(~conn) : 64;
@@ -637,47 +681,35 @@ TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, uint64_t* out) {
     uint32_t pb = simt::shflu(up_bits, (lane + 63) & 63), nb = simt::shflu(dn_bits, (lane + 1) & 63);
     if (lane == 0) pb = 0;
     if (lane == 63) nb = 0;
-    // blocks the nearest-neighbour scheme cannot do: non-ASCII bytes, a digit run or a \s run covering a whole row
-    const uint64_t pN = ((N << 1) | ((pb >> 1) & 1)) & nds;
+    // blocks the nearest-neighbour scheme cannot do: a digit run or a \s run covering a whole row
+    const uint64_t pN = ((N << 1) | ((pb >> 1) & 1)) & nds & all;
     const uint64_t Q = N & pN;
     // (lane 0 cannot see the row before it: an all-digit first row may be the continuation of a longer run)
-    if (simt::ballot(m.hi != 0 || Q == ~0ull || conn == ~0ull || (lane == 0 && N == ~0ull))) return false;
+    if (simt::ballot(Q == all || conn == all || (lane == 0 && N == all))) return false;
     const uint64_t pL = ((L << 1) | (pb & 1)) & nds, pO = ((O << 1) | ((pb >> 2) & 1)) & nds, pSP = ((SP << 1) | ((pb >> 3) & 1)) & nds;
     const uint64_t pW = ((W << 1) | ((pb >> 4) & 1)) & nds, pCR = ((CR << 1) | ((pb >> 5) & 1)) & nds;
-    const uint64_t dsn = (uint64_t)((nb >> 3) & 3);                   // document-start bits 0,1 of the next row
-    const uint64_t KN = (ds >> 1) | (dsn << 63), KN2 = (ds >> 2) | (dsn << 62);
-    const uint64_t nO = ((O >> 1) | ((uint64_t)((nb >> 2) & 1) << 63)) & ~KN;
-    const uint64_t nReal = (((L | N | O) >> 1) | ((uint64_t)((nb & 7) ? 1 : 0) << 63)) & ~KN;
-    // ---- contractions: per apostrophe that is a match start, look at the next two bytes (may sit in the next row)
-    uint64_t c2 = 0, c3 = 0;
-    {
-        uint64_t ap = AP & ~pO & ~pSP & ~KN;
-        while (simt::ballot(ap != 0)) {
-            if (ap) {
-                const int pos = tkz_ctz64(ap);
-                ap &= ap - 1;
-                const int p1 = pos + 1, p2 = pos + 2;
-                const uint32_t b1 = stage[(lane + (p1 >> 6)) * kBlockRowStride + (p1 & 63)];
-                const uint32_t b2 = stage[(lane + (p2 >> 6)) * kBlockRowStride + (p2 & 63)];
-                const int k = tkz_contraction_len(b1, b2, PATTERN == TKZ_PAT_CL100K);
-                if (k == 2) c2 |= 1ull << pos;
-                else if (k == 3 && !((KN2 >> pos) & 1ull)) c3 |= 1ull << pos;
-            }
-        }
-    }
-    const uint64_t o1 = (PATTERN == TKZ_PAT_P1) ? 0ull : (O & ~pO & ~pSP & ~nO);
+    const uint64_t dsn = (uint64_t)((nb >> 3) & 3);                   // document-start bits of chars 0,1 of the next row
+    const uint64_t KN = (ds >> 1) | (dsn << top), KN2 = (ds >> 2) | (dsn << (top - 1));
+    const uint64_t nO = ((O >> 1) | ((uint64_t)((nb >> 2) & 1) << top)) & ~KN;
+    const uint64_t nReal = (((L | N | O) >> 1) | ((uint64_t)((nb & 7) ? 1 : 0) << top)) & ~KN;
+    // ---- contractions: an apostrophe that is a match start, followed by a literal inside the document
+    const uint64_t apOk = ~pO & ~pSP & ~KN;
+    const uint64_t c2 = c.k2 & apOk, c3 = c.k3 & apOk & ~KN2;
+    const uint64_t o1 = (PATTERN == TKZ_PAT_P1) ? 0ull : (O & ~c.O2 & ~pO & ~pSP & ~nO);     // (a two-unit char is never the one-unit prefix)
     // local carries out of my row (exact because no run covers a whole row)
     uint32_t carryN_out = 0, abs_out = 0;
     uint64_t ABS0 = 0, R = 0, seeds = 0;
     if (PATTERN != TKZ_PAT_P1) {
-        if (N >> 63) carryN_out = (uint32_t)((64 - tkz_msb64(~Q)) % 3);   // Q != ~0 here
+        if ((N >> top) & 1) carryN_out = (uint32_t)((n - tkz_msb64(~Q & all)) % 3);   // (~Q & all) != 0 here
         R = CR & nds; seeds = CR & pO;
         ABS0 = tkz_fill_up64(seeds & R, R);
-        abs_out = (uint32_t)(ABS0 >> 63);
+        abs_out = (uint32_t)((ABS0 >> top) & 1);
     }
     // ---- exchange 2: contraction ends, o1, absorbed state and digit phase flowing in from the previous row
-    const uint32_t up2 = (uint32_t)(c2 >> 62) | ((uint32_t)(c3 >> 61) << 2) | ((uint32_t)(o1 >> 63) << 5) | (abs_out << 6) | (carryN_out << 7) |
-                         ((uint32_t)((c2 | c3) >> 63) << 9);
+    // (a literal that ends k chars past my last char ends at char k - 1 of the next row)
+    const uint32_t c2out = (uint32_t)((c2 >> (n - 2)) & 3), c3out = (uint32_t)((c3 >> (n - 3)) & 7);      // (n >= 16: a char is at most 4 bytes)
+    const uint32_t up2 = c2out | (c3out << 2) | ((uint32_t)((o1 >> top) & 1) << 5) | (abs_out << 6) | (carryN_out << 7) |
+                         ((uint32_t)(((c2 | c3) >> top) & 1) << 9);
     uint32_t p2b = simt::shflu(up2, (lane + 63) & 63);
     if (lane == 0) p2b = 0;
     const uint64_t contrEnd = (c2 << 2) | (c3 << 3) | (uint64_t)(p2b & 3) | (uint64_t)((p2b >> 2) & 7);
@@ -709,15 +741,91 @@ TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, uint64_t* out) {
         // white space
         const uint32_t abs_in = (p2b >> 6) & 1;
         const uint64_t ABS = abs_in ? tkz_fill_up64((seeds | (R & 1ull)) & R, R) : ABS0;
-        // T(i) = CR(i) | (CONN(i+1) & T(i+1)),  T(64) = head of the next row (which includes CONN(64))
-        const uint64_t Scr = CR | ((uint64_t)((nb >> 5) & 1) << 63);
+        // T(i) = CR(i) | (CONN(i+1) & T(i+1)),  T(n) = head of the next row (which includes CONN(n))
+        const uint64_t Scr = CR | ((uint64_t)((nb >> 5) & 1) << top);
         const uint64_t Srev = tkz_brev64(Scr), Grev = tkz_brev64(conn) << 1;   // reversed positions k = 63 - i: G'(k) = CONN(64 - k)
         const uint64_t Tcur = tkz_brev64(Srev | tkz_fill_up64((Srev << 1) & Grev, Grev));
         const uint64_t pABS = (ABS << 1) | (uint64_t)abs_in;
         const uint64_t sW = W & ~ABS & ((~pW | pABS) | (pCR & ~Tcur) | (~CR & nReal));
         start = sL | sN | sO | sW;
     }
-    *out = start | contrEnd | ds;
+    *start_out = (start | contrEnd | ds) & all;
+    return true;
+}
+
+// raw contraction candidates at BYTE positions: an apostrophe followed by a literal (the bytes may sit in the next row)
+template <int PATTERN>
+TKZ_DEV void tkz_block_contractions(const uint8_t* stage, uint64_t AP, uint64_t* k2, uint64_t* k3) {
+    const int lane = simt::lane();
+    uint64_t c2 = 0, c3 = 0;
+    for (uint64_t ap = AP; ap; ap &= ap - 1) {
+        const int pos = tkz_ctz64(ap);
+        const int p1 = pos + 1, p2 = pos + 2;
+        const uint32_t b1 = stage[(lane + (p1 >> 6)) * kBlockRowStride + (p1 & 63)];
+        const uint32_t b2 = stage[(lane + (p2 >> 6)) * kBlockRowStride + (p2 & 63)];
+        const int k = tkz_contraction_len(b1, b2, PATTERN == TKZ_PAT_CL100K);
+        if (k == 2) c2 |= 1ull << pos;
+        else if (k == 3) c3 |= 1ull << pos;
+    }
+    *k2 = c2; *k3 = c3;
+}
+
+// Evaluates rows first_row .. first_row+63 (lane = row - first_row) staged at `stage` (kBlockRowStride bytes per
+// row, one extra row of zeros after the last).  Returns false -- and leaves `out` unset -- when the block has to be
+// done by the sequential row loop (a run covering a whole row, malformed UTF-8, a document that starts inside a char);
+// otherwise *out is this lane's piece-start word (valid for lanes 1..62).
+template <int PATTERN>
+TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, const uint8_t* bmp, uint64_t* out) {
+    const int lane = simt::lane();
+    const uint8_t* myrow = stage + lane * kBlockRowStride;
+    const TkzBlockMasks m = tkz_block_classify<false>(reinterpret_cast<const uint4*>(myrow));
+    TkzCharMasks c;
+    if (simt::ballot(m.hi != 0) == 0) {                    // ---- an ASCII block: bytes are chars ----
+        c.L = m.L; c.N = m.N; c.O = m.O; c.O2 = 0; c.W = m.W; c.CR = m.CR; c.SP = m.SP; c.ds = ds; c.n = 64;
+        tkz_block_contractions<PATTERN>(stage, m.AP, &c.k2, &c.k3);
+        uint64_t start;
+        if (!tkz_block_core<PATTERN>(c, &start)) return false;
+        *out = start;
+        return true;
+    }
+    // ---- multi-byte chars: the ASCII classes are valid on the ASCII bytes only; lead / continuation structure ----
+    const uint64_t HI = m.HI, CONT = m.CONT;
+    const uint64_t A = ~HI;                                // ASCII bytes
+    uint64_t L = m.L & A, N = m.N & A, W = m.W & A, O1 = ~(m.L | m.N | m.W) & A, O2 = 0;
+    const uint64_t CR = m.CR & A, SP = m.SP & A;
+    int bad = 0;
+    uint64_t E = 0;                                        // where continuation bytes are expected, from the leads of my row
+    uint32_t spill = 0;                                    // ... and in the first three bytes of the next row
+    for (uint64_t t = HI & ~CONT; t; t &= t - 1) {         // every non-ASCII lead of my row: decode, class from the table
+        const int pos = tkz_ctz64(t);
+        uint32_t b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int q = pos + k; b[k] = stage[(lane + (q >> 6)) * kBlockRowStride + (q & 63)]; }
+        const TkzChar ch = tkz_decode(b[0], b[1], b[2], b[3], bmp);
+        bad |= ch.bad;
+        const int pc = tkz_pc_of(ch);
+        const uint64_t bit = 1ull << pos;
+        if (pc == PC_L) L |= bit; else if (pc == PC_N) N |= bit; else if (pc == PC_WS) W |= bit; else if (pc == PC_O2) O2 |= bit; else O1 |= bit;
+        for (int k = 1; k < ch.len; ++k) { const int q = pos + k; if (q < 64) E |= 1ull << q; else spill |= 1u << (q - 64); }
+    }
+    uint32_t spill_in = simt::shflu(spill, (lane + 63) & 63);
+    if (lane == 0) { const int lc = (~CONT) ? tkz_ctz64(~CONT) : 64; spill_in = lc <= 3 ? (uint32_t)tkz_lowmask(lc) : 0u; }   // lane 0 is context: its leading continuation bytes belong to a char of the row before
+    E |= spill_in;
+    // malformed text and a document that starts inside a char are reported by the sequential row loop
+    if (simt::ballot(bad != 0 || E != CONT || (ds & CONT) != 0)) return false;
+    const uint64_t LEAD = ~CONT;
+    const TkzPext px = tkz_pext_prepare(LEAD);
+    uint64_t k2b, k3b;
+    tkz_block_contractions<PATTERN>(stage, m.AP & A, &k2b, &k3b);
+    c.n = tkz_popc64(LEAD);
+    c.L = tkz_pext(L, LEAD, px); c.N = tkz_pext(N, LEAD, px); c.W = tkz_pext(W, LEAD, px);
+    c.O2 = tkz_pext(O2, LEAD, px); c.O = tkz_pext(O1, LEAD, px) | c.O2;
+    c.CR = tkz_pext(CR, LEAD, px); c.SP = tkz_pext(SP, LEAD, px);
+    c.k2 = tkz_pext(k2b, LEAD, px); c.k3 = tkz_pext(k3b, LEAD, px);
+    c.ds = tkz_pext(ds, LEAD, px);
+    uint64_t start;
+    if (!tkz_block_core<PATTERN>(c, &start)) return false;
+    *out = tkz_pdep(start, LEAD, px) | ds;
     return true;
 }
 
