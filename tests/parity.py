@@ -29,9 +29,46 @@ SMALL_ALPHAS = {
 }
 
 
+def gen_runs(rng, n):
+    """Single-class runs of a few bytes up to several 4 KiB blocks (digits, spaces, mixed white space with and without
+    CR/LF, newlines, letters, punctuation), glued together: what makes the digit phase and the CR/LF look-ahead of the
+    position-parallel scanners cross rows and whole blocks."""
+    out = []
+    total = 0
+    while total < n:
+        k = rng.randrange(10)
+        ln = rng.choice([1, 2, 3, 5, 63, 64, 65, 130, 700, 4096, 4100, 9000, 20000])
+        ln = min(ln, n - total)
+        if k == 0:
+            seg = "".join(rng.choice("0123456789") for _ in range(ln))
+        elif k == 1:
+            seg = " " * ln
+        elif k == 2:
+            seg = "".join(rng.choice(" \t") for _ in range(ln))
+        elif k == 3:
+            seg = " " * (ln - 1) + rng.choice("\n\r")                 # a CR/LF at the very end of a long run
+        elif k == 4:
+            seg = "".join(rng.choice(" \n") if rng.random() < 0.02 else " " for _ in range(ln))
+        elif k == 5:
+            seg = "\n" * min(ln, 200)
+        elif k == 6:
+            seg = rng.choice("aZ") * ln
+        elif k == 7:
+            seg = rng.choice(["=", "/", ";"]) * ln
+        elif k == 8:
+            seg = rng.choice(["x", ".", "'s", "\u3000", "\uff11", "9"]) * min(ln, 100)
+        else:
+            seg = "".join(rng.choice("ab 12.\n") for _ in range(min(ln, 50)))
+        out.append(seg)
+        total += len(seg)
+    return "".join(out)[:n]
+
+
 def gen_text(rng, kind, n, alpha):
     if kind == "mix":
         return RC.random_text(rng, alpha, n)
+    if kind == "runs":
+        return gen_runs(rng, n)
     a = SMALL_ALPHAS[kind]
     out = []
     while len(out) < n:

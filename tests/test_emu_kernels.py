@@ -45,6 +45,12 @@ def test_golden_splits(lib, vocab):
         assert [int(i) for i in np.nonzero(got[:len(b)])[0]] == [p[0] for p in rec["pieces"]], rec["text"]
 
 
+@pytest.mark.parametrize("pattern", [1, 2, 3])
+def test_pretok_long_runs(lib, vocab, oracle_mod, pattern):
+    # runs that cross rows and whole 4 KiB blocks: the lane scans and the beyond-the-block searches of the block scanners
+    parity.check_pretok(lib, oracle_mod, vocab, pattern, 0, seeds=range(5), kinds=("runs",), doc_lens=[3000, 30000, 70000], n_docs_choices=(1, 3))
+
+
 def test_every_vocab_key(lib, vocab, oracle_mod, oracle_gpt2):
     parity.check_vocab_keys(lib, oracle_mod, vocab, oracle_gpt2)
 

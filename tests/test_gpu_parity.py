@@ -49,6 +49,12 @@ def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
                         doc_lens=[0, 1, 7, 63, 64, 65, 127, 128, 129, 200, 1000, 5000, 9000, 40000], n_docs_choices=(1, 3, 20, 200))
 
 
+@pytest.mark.parametrize("pattern", [1, 2, 3])
+def test_pretok_long_runs(lib, vocab, oracle_mod, pattern):
+    # runs that cross rows and whole 4 KiB blocks: the lane scans and the beyond-the-block searches of the block scanners
+    parity.check_pretok(lib, oracle_mod, vocab, pattern, 0, seeds=range(12), kinds=("runs",), doc_lens=[3000, 30000, 70000, 300000], n_docs_choices=(1, 3, 9))
+
+
 def test_golden_splits(lib, vocab):
     for rec in load_golden_json("splits.json"):
         enc = N.Encoder(vocab, rec["pattern"])

@@ -657,14 +657,119 @@ TKZ_HD uint64_t tkz_pdep(uint64_t x, uint64_t m, const TkzPext& p) {      // bit
     return x & m;
 }
 
+// ---- states that can cross a whole row ----------------------------------------------------------------
+// Two of the run states are not nearest-neighbour matters: the phase of a digit run (`\p{N}{1,3}` counts from the run's
+// first digit) flows through rows that are all digits, and "is there a CR/LF further on in this white-space run"
+// (`\s*[\r\n]+`) flows backwards through rows that are all white space.  Inside the block both are resolved by a scan over
+// the lanes of (propagate | generate) functions; what flows in from beyond the block -- only when the block's first row is
+// all digits or its last row all white space -- is found by a wavefront-wide search over the rows outside (64 rows per step).
+struct TkzBlockCtx { const uint8_t* bytes; const uint64_t* docbits; int64_t total, nrows, row0; };   // row0 = row of lane 0
+
+// class masks of corpus row `row` (any row index; bytes outside the corpus read as 0 = "other")
+TKZ_DEV TkzBlockMasks tkz_corpus_row_masks(const TkzBlockCtx& X, int64_t row) {
+    uint4 v[4];
+    const int64_t pos = row << 6;
+    if (row >= 0 && pos + 64 <= X.total) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = tkz_load16(X.bytes + pos + 16 * q);
+    } else {
+        uint32_t w[16];
+        for (int k = 0; k < 16; ++k) {
+            w[k] = 0;
+            for (int j = 0; j < 4; ++j) { const int64_t q = pos + 4 * k + j; if (row >= 0 && q < X.total) w[k] |= (uint32_t)X.bytes[q] << (8 * j); }
+        }
+        for (int q = 0; q < 4; ++q) { v[q].x = w[4 * q]; v[q].y = w[4 * q + 1]; v[q].z = w[4 * q + 2]; v[q].w = w[4 * q + 3]; }
+    }
+    return tkz_block_classify<false>(v);
+}
+// digits of the run that ends right before row X.row0, mod 3 (0 when the char before is not a digit); -1 when the run is
+// preceded by a multi-byte char (which may itself be a digit: the caller leaves the block to the sequential path).  Wave-uniform.
+TKZ_DEV int tkz_digits_before(const TkzBlockCtx& X) {
+    const int lane = simt::lane();
+    int64_t count = 0;
+    for (int64_t base = X.row0 - 1;; base -= 64) {
+        const int64_t row = base - lane;
+        int tail = 0, unknown = 0;
+        bool full = false;
+        if (row >= 0) {
+            const TkzBlockMasks m = tkz_corpus_row_masks(X, row);
+            const uint64_t ds = X.docbits[row];
+            const uint64_t notN = ~(m.N & ~m.HI);
+            tail = notN ? 63 - tkz_msb64(notN) : 64;                          // ASCII digits at the end of the row
+            const bool capped = ds != 0 && tail >= 64 - tkz_msb64(ds);         // a document start begins a new run
+            if (capped) tail = 64 - tkz_msb64(ds);
+            else if (tail < 64 && ((m.HI >> (63 - tail)) & 1ull)) unknown = 1;   // stopped by a multi-byte char
+            full = tail == 64 && ds == 0;
+        }
+        const uint64_t f = simt::ballot(full);
+        const int idx = (~f) ? tkz_ctz64(~f) : 64;
+        const int t = simt::shfl(tail, idx & 63), u = simt::shfl(unknown, idx & 63);
+        if (idx < 64 && u) return -1;
+        if (idx < 64) { count += 64 * (int64_t)idx + t; break; }
+        count += 64 * 64;
+    }
+    return (int)(count % 3);
+}
+// does the connected white-space run that continues past the block's last row contain a CR/LF?  1 / 0; -1 when multi-byte
+// text is met before the run ends (the caller leaves the block to the sequential path).  Wave-uniform.
+TKZ_DEV int tkz_crlf_ahead(const TkzBlockCtx& X) {
+    const int lane = simt::lane();
+    for (int64_t base = X.row0 + 64;; base += 64) {
+        const int64_t row = base + lane;
+        bool full = false, hi = false, crlead = false, crany = false;
+        if (row < X.nrows) {
+            const TkzBlockMasks m = tkz_corpus_row_masks(X, row);
+            const uint64_t conn = m.W & ~X.docbits[row];
+            hi = m.hi != 0;
+            full = !hi && conn == ~0ull;
+            const int lead = (~conn) ? tkz_ctz64(~conn) : 64;
+            crlead = (m.CR & tkz_lowmask(lead)) != 0;
+            crany = m.CR != 0;
+        }
+        const uint64_t f = simt::ballot(full);
+        const int idx = (~f) ? tkz_ctz64(~f) : 64;
+        const uint64_t crs = simt::ballot(full && crany) & tkz_lowmask(idx);
+        const int hi_at = simt::shfl(hi ? 1 : 0, idx & 63), cr_at = simt::shfl(crlead ? 1 : 0, idx & 63);
+        if (crs) return 1;
+        if (idx < 64) return hi_at ? -1 : cr_at;
+    }
+}
+// digit phase: every lane contributes f(x) = prop ? (x + v) % 3 : v; returns the phase flowing INTO this lane's row (lane 0: in0)
+TKZ_DEV int tkz_scan_phase(bool prop, int v, int in0) {
+    const int lane = simt::lane();
+    int p = prop ? 1 : 0, val = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int pl = simt::shfl(p, (lane - d) & 63), vl = simt::shfl(val, (lane - d) & 63);
+        if (lane >= d && p) { val = (vl + val) % 3; p = pl; }
+    }
+    const int out = p ? (in0 + val) % 3 : val;
+    const int prev = simt::shfl(out, (lane + 63) & 63);
+    return lane == 0 ? in0 : prev;
+}
+// CR/LF ahead: every lane contributes f(x) = prop ? (v | x) : v, composed from the top lane down; returns the value of the
+// row AFTER this lane's (lane 63: in64)
+TKZ_DEV uint32_t tkz_scan_head(bool prop, uint32_t v, uint32_t in64) {
+    const int lane = simt::lane();
+    int p = prop ? 1 : 0;
+    uint32_t val = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int pr = simt::shfl(p, (lane + d) & 63);
+        const uint32_t vr = simt::shflu(val, (lane + d) & 63);
+        if (lane + d < 64 && p) { val |= vr; p = pr; }
+    }
+    const uint32_t out = p ? (val | in64) : val;
+    const uint32_t next = simt::shflu(out, (lane + 1) & 63);
+    return lane == 63 ? in64 : next;
+}
+
 // one bit per CHAR of the lane's row (n chars, bits >= n clear): classes, raw contraction candidates ('x followed by a
 // literal of 2 / 3 chars, conditions not yet applied), document starts
-struct TkzCharMasks { uint64_t L, N, O, O2, W, CR, SP, k2, k3, ds; int n; };
+struct TkzCharMasks { uint64_t L, N, O, O2, W, CR, SP, k2, k3, ds; int n; bool ascii; };   // ascii: the row has no multi-byte char
 
 // The rules on char masks; every lane of the wavefront calls it (two lane-shift exchanges inside).  Returns false when
 // the nearest-neighbour scheme cannot do the block: a digit run or a white-space run covering a whole row.
 template <int PATTERN>
-TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, uint64_t* start_out) {
+TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, const TkzBlockCtx& X, uint64_t* start_out) {
     const int lane = simt::lane();
     const int n = c.n, top = n - 1;
     const uint64_t all = tkz_lowmask(n);
@@ -681,11 +786,41 @@ TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, uint64_t* start_out) {
     uint32_t pb = simt::shflu(up_bits, (lane + 63) & 63), nb = simt::shflu(dn_bits, (lane + 1) & 63);
     if (lane == 0) pb = 0;
     if (lane == 63) nb = 0;
-    // blocks the nearest-neighbour scheme cannot do: a digit run or a \s run covering a whole row
     const uint64_t pN = ((N << 1) | ((pb >> 1) & 1)) & nds & all;
     const uint64_t Q = N & pN;
-    // (lane 0 cannot see the row before it: an all-digit first row may be the continuation of a longer run)
-    if (simt::ballot(Q == all || conn == all || (lane == 0 && N == all))) return false;
+    // ---- the two states that can cross whole rows (pattern 1 has neither) ----
+    int carry_in = 0;                                      // digits of the open run before my row, mod 3
+    uint32_t head_next = (nb >> 5) & 1;                    // a CR/LF inside the leading connected white-space run of the next row
+    if (PATTERN != TKZ_PAT_P1) {
+        // a row of CR/LF only: the absorbed state would cross it -- left to the sequential path
+        if (simt::ballot((CR & nds & all) == all)) return false;
+        // (lane 0 is context and cannot see the row before it: only an all-digit row needs to know what came before)
+        const bool first_all = lane == 0 && N == all && ds == 0;
+        const bool propN = Q == all || first_all, propW = conn == all;
+        int gen = 0;
+        if (!propN && ((N >> top) & 1)) gen = (n - tkz_msb64(~Q & all)) % 3;     // the open run started inside my row
+        if (simt::ballot(propN)) {
+            int in0 = 0;
+            if (simt::ballot(first_all)) {
+                if (simt::ballot(first_all && !c.ascii)) return false;
+                in0 = tkz_digits_before(X);
+                if (in0 < 0) return false;
+            }
+            carry_in = tkz_scan_phase(propN, propN ? n % 3 : gen, in0);
+        } else {
+            carry_in = simt::shfl(gen, (lane + 63) & 63);
+            if (lane == 0) carry_in = 0;
+        }
+        if (simt::ballot(propW)) {
+            uint32_t in64 = 0;
+            if (simt::ballot(lane == 63 && propW)) {
+                const int a = tkz_crlf_ahead(X);
+                if (a < 0) return false;
+                in64 = (uint32_t)a;
+            }
+            head_next = tkz_scan_head(propW, propW ? ((CR & all) ? 1u : 0u) : head, in64);
+        }
+    }
     const uint64_t pL = ((L << 1) | (pb & 1)) & nds, pO = ((O << 1) | ((pb >> 2) & 1)) & nds, pSP = ((SP << 1) | ((pb >> 3) & 1)) & nds;
     const uint64_t pW = ((W << 1) | ((pb >> 4) & 1)) & nds, pCR = ((CR << 1) | ((pb >> 5) & 1)) & nds;
     const uint64_t dsn = (uint64_t)((nb >> 3) & 3);                   // document-start bits of chars 0,1 of the next row
@@ -697,10 +832,9 @@ TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, uint64_t* start_out) {
     const uint64_t c2 = c.k2 & apOk, c3 = c.k3 & apOk & ~KN2;
     const uint64_t o1 = (PATTERN == TKZ_PAT_P1) ? 0ull : (O & ~c.O2 & ~pO & ~pSP & ~nO);     // (a two-unit char is never the one-unit prefix)
     // local carries out of my row (exact because no run covers a whole row)
-    uint32_t carryN_out = 0, abs_out = 0;
+    uint32_t abs_out = 0;
     uint64_t ABS0 = 0, R = 0, seeds = 0;
     if (PATTERN != TKZ_PAT_P1) {
-        if ((N >> top) & 1) carryN_out = (uint32_t)((n - tkz_msb64(~Q & all)) % 3);   // (~Q & all) != 0 here
         R = CR & nds; seeds = CR & pO;
         ABS0 = tkz_fill_up64(seeds & R, R);
         abs_out = (uint32_t)((ABS0 >> top) & 1);
@@ -708,7 +842,7 @@ TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, uint64_t* start_out) {
     // ---- exchange 2: contraction ends, o1, absorbed state and digit phase flowing in from the previous row
     // (a literal that ends k chars past my last char ends at char k - 1 of the next row)
     const uint32_t c2out = (uint32_t)((c2 >> (n - 2)) & 3), c3out = (uint32_t)((c3 >> (n - 3)) & 7);      // (n >= 16: a char is at most 4 bytes)
-    const uint32_t up2 = c2out | (c3out << 2) | ((uint32_t)((o1 >> top) & 1) << 5) | (abs_out << 6) | (carryN_out << 7) |
+    const uint32_t up2 = c2out | (c3out << 2) | ((uint32_t)((o1 >> top) & 1) << 5) | (abs_out << 6) |
                          ((uint32_t)(((c2 | c3) >> top) & 1) << 9);
     uint32_t p2b = simt::shflu(up2, (lane + 63) & 63);
     if (lane == 0) p2b = 0;
@@ -725,7 +859,7 @@ TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, uint64_t* start_out) {
         // \p{N}{1,3}
         uint64_t S = N & ~pN;
         if (Q & 1ull) {
-            const int d = (3 - (int)((p2b >> 7) & 3)) % 3, lead = tkz_ctz64(~Q);
+            const int d = (3 - carry_in) % 3, lead = (~Q) ? tkz_ctz64(~Q) : 64;
             if (d < lead) S |= 1ull << d;
         }
         const uint64_t Q3 = Q & (Q << 1) & (Q << 2);
@@ -742,7 +876,7 @@ TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, uint64_t* start_out) {
         const uint32_t abs_in = (p2b >> 6) & 1;
         const uint64_t ABS = abs_in ? tkz_fill_up64((seeds | (R & 1ull)) & R, R) : ABS0;
         // T(i) = CR(i) | (CONN(i+1) & T(i+1)),  T(n) = head of the next row (which includes CONN(n))
-        const uint64_t Scr = CR | ((uint64_t)((nb >> 5) & 1) << top);
+        const uint64_t Scr = CR | ((uint64_t)head_next << top);
         const uint64_t Srev = tkz_brev64(Scr), Grev = tkz_brev64(conn) << 1;   // reversed positions k = 63 - i: G'(k) = CONN(64 - k)
         const uint64_t Tcur = tkz_brev64(Srev | tkz_fill_up64((Srev << 1) & Grev, Grev));
         const uint64_t pABS = (ABS << 1) | (uint64_t)abs_in;
@@ -775,16 +909,16 @@ TKZ_DEV void tkz_block_contractions(const uint8_t* stage, uint64_t AP, uint64_t*
 // done by the sequential row loop (a run covering a whole row, malformed UTF-8, a document that starts inside a char);
 // otherwise *out is this lane's piece-start word (valid for lanes 1..62).
 template <int PATTERN>
-TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, const uint8_t* bmp, uint64_t* out) {
+TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, const uint8_t* bmp, const TkzBlockCtx& X, uint64_t* out) {
     const int lane = simt::lane();
     const uint8_t* myrow = stage + lane * kBlockRowStride;
     const TkzBlockMasks m = tkz_block_classify<false>(reinterpret_cast<const uint4*>(myrow));
     TkzCharMasks c;
     if (simt::ballot(m.hi != 0) == 0) {                    // ---- an ASCII block: bytes are chars ----
-        c.L = m.L; c.N = m.N; c.O = m.O; c.O2 = 0; c.W = m.W; c.CR = m.CR; c.SP = m.SP; c.ds = ds; c.n = 64;
+        c.L = m.L; c.N = m.N; c.O = m.O; c.O2 = 0; c.W = m.W; c.CR = m.CR; c.SP = m.SP; c.ds = ds; c.n = 64; c.ascii = true;
         tkz_block_contractions<PATTERN>(stage, m.AP, &c.k2, &c.k3);
         uint64_t start;
-        if (!tkz_block_core<PATTERN>(c, &start)) return false;
+        if (!tkz_block_core<PATTERN>(c, X, &start)) return false;
         *out = start;
         return true;
     }
@@ -823,8 +957,9 @@ TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, const uint8_t* bm
     c.CR = tkz_pext(CR, LEAD, px); c.SP = tkz_pext(SP, LEAD, px);
     c.k2 = tkz_pext(k2b, LEAD, px); c.k3 = tkz_pext(k3b, LEAD, px);
     c.ds = tkz_pext(ds, LEAD, px);
+    c.ascii = HI == 0;
     uint64_t start;
-    if (!tkz_block_core<PATTERN>(c, &start)) return false;
+    if (!tkz_block_core<PATTERN>(c, X, &start)) return false;
     *out = tkz_pdep(start, LEAD, px) | ds;
     return true;
 }
@@ -836,7 +971,7 @@ TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, const uint8_t* bm
 // char is itself the tail of a glued contraction: `it's's` = `it's` + `'s`, resolved by a short fixed-point iteration);
 // ` ?[^\s\p{L}\p{N}]+[\r\n/]*` also absorbs '/' after the CR/LF it absorbed.  Refuses (returns false) what the
 // nearest-neighbour scheme cannot do, as tkz_block_eval does.
-TKZ_DEV bool tkz_block_eval_o200k(const uint8_t* stage, uint64_t ds, uint64_t* out) {
+TKZ_DEV bool tkz_block_eval_o200k(const uint8_t* stage, uint64_t ds, const TkzBlockCtx& X, uint64_t* out) {
     const int lane = simt::lane();
     const TkzBlockMasks m = tkz_block_classify<true>(reinterpret_cast<const uint4*>(stage + lane * kBlockRowStride));
     const uint64_t L = m.L, N = m.N, O = m.O, W = m.W, CR = m.CR, SP = m.SP, AP = m.AP, UP = m.UP, LOW = m.L & ~m.UP;
@@ -853,8 +988,30 @@ TKZ_DEV bool tkz_block_eval_o200k(const uint8_t* stage, uint64_t ds, uint64_t* o
     const uint64_t pN = ((N << 1) | ((pb >> 1) & 1)) & nds;
     const uint64_t Q = N & pN;
     const uint64_t R = (CR | m.SL) & nds;                              // what `[\r\n/]*` can run through
-    const bool bad = m.hi != 0 || Q == ~0ull || conn == ~0ull || (lane == 0 && N == ~0ull) || (R & tkz_lowmask(60)) == tkz_lowmask(60);
+    const bool bad = m.hi != 0 || (R & tkz_lowmask(60)) == tkz_lowmask(60);
     if (simt::ballot(bad)) return false;
+    // the two states that can cross whole rows: digit phase, CR/LF further on in the white-space run (see tkz_block_core)
+    int carry_in;
+    uint32_t head_next = (nb >> 5) & 1;
+    {
+        const bool first_all = lane == 0 && N == ~0ull && ds == 0;
+        const bool propN = Q == ~0ull || first_all, propW = conn == ~0ull;
+        int gen = 0;
+        if (!propN && (N >> 63)) gen = (64 - tkz_msb64(~Q)) % 3;
+        if (simt::ballot(propN)) {
+            int in0 = 0;
+            if (simt::ballot(first_all)) { in0 = tkz_digits_before(X); if (in0 < 0) return false; }
+            carry_in = tkz_scan_phase(propN, propN ? 64 % 3 : gen, in0);
+        } else {
+            carry_in = simt::shfl(gen, (lane + 63) & 63);
+            if (lane == 0) carry_in = 0;
+        }
+        if (simt::ballot(propW)) {
+            uint32_t in64 = 0;
+            if (simt::ballot(lane == 63 && propW)) { const int a = tkz_crlf_ahead(X); if (a < 0) return false; in64 = (uint32_t)a; }
+            head_next = tkz_scan_head(propW, propW ? (CR ? 1u : 0u) : head, in64);
+        }
+    }
     const uint64_t pL = ((L << 1) | (pb & 1)) & nds, pO = ((O << 1) | ((pb >> 2) & 1)) & nds, pSP = ((SP << 1) | ((pb >> 3) & 1)) & nds;
     const uint64_t pW = ((W << 1) | ((pb >> 4) & 1)) & nds, pCR = ((CR << 1) | ((pb >> 5) & 1)) & nds;
     const uint64_t pLOW = ((LOW << 1) | ((pb >> 6) & 1)) & nds;
@@ -894,12 +1051,10 @@ TKZ_DEV bool tkz_block_eval_o200k(const uint8_t* stage, uint64_t ds, uint64_t* o
     uint64_t g2, g3;
     bool conv = resolve(0, &g2, &g3);
     // local state that flows to the next row (computed with no inflow: exact unless a run covers the row, refused above)
-    uint32_t carryN_out = 0;
-    if (N >> 63) carryN_out = (uint32_t)((64 - tkz_msb64(~Q)) % 3);
     const uint64_t seeds = CR & pO;
     const uint64_t ABS0 = tkz_fill_up64(seeds & R, R);
     const uint64_t o1_0 = O & ~ABS0 & (~pO | (ABS0 << 1)) & ~pSP & ~nO & ~(g2 | g3);
-    const uint32_t up2 = (uint32_t)(g2 >> 62) | ((uint32_t)(g3 >> 61) << 2) | ((uint32_t)(o1_0 >> 63) << 5) | ((uint32_t)(ABS0 >> 63) << 6) | (carryN_out << 7);
+    const uint32_t up2 = (uint32_t)(g2 >> 62) | ((uint32_t)(g3 >> 61) << 2) | ((uint32_t)(o1_0 >> 63) << 5) | ((uint32_t)(ABS0 >> 63) << 6);
     uint32_t p2b = simt::shflu(up2, (lane + 63) & 63);
     if (lane == 0) p2b = 0;
     // with the real inflow: positions 0..2 may be the fresh start after a contraction of the previous row
@@ -925,7 +1080,7 @@ TKZ_DEV bool tkz_block_eval_o200k(const uint8_t* stage, uint64_t ds, uint64_t* o
     const uint64_t sO = O & ~ABS & (~pO | pABS) & ~pSP;
     uint64_t S = N & ~pN;
     if (Q & 1ull) {
-        const int d = (3 - (int)((p2b >> 7) & 3)) % 3, lead = tkz_ctz64(~Q);
+        const int d = (3 - carry_in) % 3, lead = (~Q) ? tkz_ctz64(~Q) : 64;
         if (d < lead) S |= 1ull << d;
     }
     const uint64_t Q3 = Q & (Q << 1) & (Q << 2);
@@ -937,7 +1092,7 @@ TKZ_DEV bool tkz_block_eval_o200k(const uint8_t* stage, uint64_t ds, uint64_t* o
     const uint64_t Q24 = Q12 & (Q12 << 12);
     T |= (T << 24) & Q24;
     T |= (T << 48) & (Q24 & (Q24 << 24));
-    const uint64_t Scr = CR | ((uint64_t)((nb >> 5) & 1) << 63);
+    const uint64_t Scr = CR | ((uint64_t)head_next << 63);
     const uint64_t Srev = tkz_brev64(Scr), Grev = tkz_brev64(conn) << 1;
     const uint64_t Tcur = tkz_brev64(Srev | tkz_fill_up64((Srev << 1) & Grev, Grev));
     const uint64_t sW = W & ~ABS & ((~pW | pABS) | (pCR & ~Tcur) | (~CR & nReal));
