@@ -145,9 +145,10 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
         const uint64_t ds = (row >= 0 && row < nrows) ? docbits[row] : 0;
         uint64_t out;
         bool done;
-        TkzBlockCtx X; X.bytes = bytes; X.docbits = docbits; X.total = total; X.nrows = nrows; X.row0 = first;
-        if constexpr (PATTERN == TKZ_PAT_O200K) done = tkz_block_eval_o200k(reinterpret_cast<const uint8_t*>(s_blk), ds, X, &out);
-        else done = tkz_block_eval<PATTERN>(reinterpret_cast<const uint8_t*>(s_blk), ds, bmp, X, &out);
+        if constexpr (PATTERN == TKZ_PAT_O200K) {
+            TkzBlockCtx X; X.bytes = bytes; X.docbits = docbits; X.total = total; X.nrows = nrows; X.row0 = first;
+            done = tkz_block_eval_o200k(reinterpret_cast<const uint8_t*>(s_blk), ds, X, &out);
+        } else done = tkz_block_eval<PATTERN>(reinterpret_cast<const uint8_t*>(s_blk), ds, bmp, &out);
         if (done) {
             if (lane >= 1 && lane <= kRowsPerWave && row < nrows) startbits[row] = out;
             return;

@@ -769,7 +769,7 @@ struct TkzCharMasks { uint64_t L, N, O, O2, W, CR, SP, k2, k3, ds; int n; bool a
 // The rules on char masks; every lane of the wavefront calls it (two lane-shift exchanges inside).  Returns false when
 // the nearest-neighbour scheme cannot do the block: a digit run or a white-space run covering a whole row.
 template <int PATTERN>
-TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, const TkzBlockCtx& X, uint64_t* start_out) {
+TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, uint64_t* start_out) {
     const int lane = simt::lane();
     const int n = c.n, top = n - 1;
     const uint64_t all = tkz_lowmask(n);
@@ -801,11 +801,9 @@ TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, const TkzBlockCtx& X, uint64_
         if (!propN && ((N >> top) & 1)) gen = (n - tkz_msb64(~Q & all)) % 3;     // the open run started inside my row
         if (simt::ballot(propN)) {
             int in0 = 0;
-            if (simt::ballot(first_all)) {
-                if (simt::ballot(first_all && !c.ascii)) return false;
-                in0 = tkz_digits_before(X);
-                if (in0 < 0) return false;
-            }
+            // (what flows in from beyond the block is looked up only by the o200k scanner, which has no other fast path; here
+            //  the row-sequential evaluator takes such a block, and the searches' registers stay out of this kernel)
+            if (simt::ballot(first_all)) return false;
             carry_in = tkz_scan_phase(propN, propN ? n % 3 : gen, in0);
         } else {
             carry_in = simt::shfl(gen, (lane + 63) & 63);
@@ -813,11 +811,7 @@ TKZ_DEV bool tkz_block_core(const TkzCharMasks& c, const TkzBlockCtx& X, uint64_
         }
         if (simt::ballot(propW)) {
             uint32_t in64 = 0;
-            if (simt::ballot(lane == 63 && propW)) {
-                const int a = tkz_crlf_ahead(X);
-                if (a < 0) return false;
-                in64 = (uint32_t)a;
-            }
+            if (simt::ballot(lane == 63 && propW)) return false;
             head_next = tkz_scan_head(propW, propW ? ((CR & all) ? 1u : 0u) : head, in64);
         }
     }
@@ -909,7 +903,7 @@ TKZ_DEV void tkz_block_contractions(const uint8_t* stage, uint64_t AP, uint64_t*
 // done by the sequential row loop (a run covering a whole row, malformed UTF-8, a document that starts inside a char);
 // otherwise *out is this lane's piece-start word (valid for lanes 1..62).
 template <int PATTERN>
-TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, const uint8_t* bmp, const TkzBlockCtx& X, uint64_t* out) {
+TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, const uint8_t* bmp, uint64_t* out) {
     const int lane = simt::lane();
     const uint8_t* myrow = stage + lane * kBlockRowStride;
     const TkzBlockMasks m = tkz_block_classify<false>(reinterpret_cast<const uint4*>(myrow));
@@ -918,7 +912,7 @@ TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, const uint8_t* bm
         c.L = m.L; c.N = m.N; c.O = m.O; c.O2 = 0; c.W = m.W; c.CR = m.CR; c.SP = m.SP; c.ds = ds; c.n = 64; c.ascii = true;
         tkz_block_contractions<PATTERN>(stage, m.AP, &c.k2, &c.k3);
         uint64_t start;
-        if (!tkz_block_core<PATTERN>(c, X, &start)) return false;
+        if (!tkz_block_core<PATTERN>(c, &start)) return false;
         *out = start;
         return true;
     }
@@ -959,7 +953,7 @@ TKZ_DEV bool tkz_block_eval(const uint8_t* stage, uint64_t ds, const uint8_t* bm
     c.ds = tkz_pext(ds, LEAD, px);
     c.ascii = HI == 0;
     uint64_t start;
-    if (!tkz_block_core<PATTERN>(c, X, &start)) return false;
+    if (!tkz_block_core<PATTERN>(c, &start)) return false;
     *out = tkz_pdep(start, LEAD, px) | ds;
     return true;
 }
