@@ -75,7 +75,7 @@ struct tkz_encoder {
     DevBuf t_short, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp;
     TkzTables T{};
     // workspace
-    DevBuf w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
+    DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
     // staging for the host-buffer entry points
     DevBuf s_bytes, s_offs, s_out, s_outoffs;
     // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
@@ -144,6 +144,8 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         HIP_TRY(e->w_dcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(e->w_dbase.ensure((size_t)ntiles * 8, acc));
         HIP_TRY(e->w_heavyq.ensure((size_t)ntiles + 64, acc));
+        HIP_TRY(e->w_gq.ensure((size_t)(total / kArenaPiece + 2) * 16, acc));
+        HIP_TRY(e->w_gcnt.ensure((size_t)ntiles * 4, acc));
         if (!e->w_pool.p) HIP_TRY(e->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
     }
     if (!e->h_counters) HIP_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(CounterBlock), 0));
@@ -176,6 +178,8 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             P.offs = d_offs; P.n_docs = n_docs;
             P.tmp = e->w_tmp.as<int32_t>(); P.tile_count = e->w_tcount.as<int32_t>(); P.tile_first = e->w_tfirst.as<int64_t>();
             P.docord_base = e->w_dbase.as<int64_t>(); P.doc_tok = e->w_doctok.as<int32_t>(); P.counters = counters;
+            P.giant_q = e->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = e->w_gcnt.as<int32_t>();
+            P.giant_count = reinterpret_cast<unsigned long long*>(e->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
             P.heavy_flag = e->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
             HIP_TRY(hipMemsetAsync(P.heavy_flag, 0, (size_t)ntiles, stream));
             P.pool = e->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(e->w_pool.cap / 4);
@@ -356,7 +360,7 @@ void tkz_encoder_destroy(tkz_encoder* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     DevBuf* bufs[] = {&e->t_short, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp,
-                      &e->w_xq, &e->w_heavyq, &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
+                      &e->w_gq, &e->w_gcnt, &e->w_xq, &e->w_heavyq, &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
                       &e->w_doctok, &e->w_dcount, &e->w_dbase, &e->w_counters, &e->w_pool, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs,
                       &e->u_units, &e->u_offs, &e->u_docbits, &e->u_grp, &e->u_tsum, &e->u_tbase, &e->u_bsum, &e->u_counters, &e->u_bytes, &e->u_boffs};
     for (DevBuf* b : bufs) b->release();

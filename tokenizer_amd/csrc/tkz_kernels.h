@@ -43,6 +43,9 @@ struct EncodeParams {
     uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_encode_waves for the ones it leaves to k_encode_waves_heavy
                                                                           // (a flag, not a queue: a queue's one counter serialises a million atomics on mixed text)
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)
+    // pieces > kArenaPiece bytes ("giant"): found by k_giant_find, merged by k_giant_merge (one 1024-thread workgroup each) BEFORE the
+    // encode kernels; their tokens wait in tmp at the piece's own byte position, their count in giant_cnt[sub-tile of the piece start]
+    int64_t* giant_q; unsigned long long* giant_count; int64_t giant_cap; int32_t* giant_cnt;
     // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE): per-stage cycle counters (bit 4) and ablations
     // (bit0 skip merges, bit1 skip table probes, bit2 skip stores, bit3 stage 0/1 only).  Compiled out of libtkz.so otherwise.
     unsigned long long* devprof;

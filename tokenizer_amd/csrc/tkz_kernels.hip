@@ -346,8 +346,6 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
     TKZ_SHARED uint32_t s_missq_h[HEAVY ? 64 : 1];        // heavy: start | (len - 1) << 11 | (arena offset / 4) << 21
     TKZ_SHARED uint32_t s_minfo[ML];                      // per merged miss: lean alive mask / heavy token count (tokens stay in its state)
     TKZ_SHARED uint64_t s_longmask[kSub / 64];
-    TKZ_SHARED int s_i0;
-    TKZ_SHARED int64_t s_l0;
 
     const int lane = simt::lane();
     const int64_t base = sub * kSub;
@@ -623,8 +621,6 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
             const int s = s_pstart[k0];
             const int64_t len64 = (k0 + 1 < np ? (int64_t)s_pstart[k0 + 1] : last_end_rel) - s;
             const int64_t abs0 = base + s;
-            const uint8_t* gb = P.bytes + abs0;
-            auto at = [&](int i) -> uint32_t { return gb[i]; };
             int32_t* dst = P.tmp + first_abs + running;
             int cnt1 = 0;
             {
@@ -636,28 +632,18 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
             }
             if (len64 > kMaxPiece) { err |= kErrTooLong; }
             else {
-                const int len = (int)len64;
-                if (lane == 0) s_i0 = tkz_lookup_long(T, at, (uint32_t)len);
-                simt::sync();
-                const int32_t whole = s_i0;
-                if (whole != TKZ_RANK_NONE) { if (lane == 0) dst[0] = whole; cnt1 = 1; }
-                else {
-                    int32_t* arr = nullptr;
-                    int stride = 0;
-                    bool ok = true;
-                    {                                     // arrays in the global pool
-                        if (lane == 0) {
-                            const unsigned long long need = 6ull * (unsigned long long)len;
-                            const unsigned long long o = simt::atomic_add64(P.pool_head, need);
-                            s_l0 = (o + need <= (unsigned long long)P.pool_cap) ? (int64_t)o : -1;
-                        }
-                        simt::sync();
-                        if (s_l0 < 0) { ok = false; err |= kErrPool; }
-                        else { arr = P.pool + s_l0; stride = len; }
+                // merged already (k_giant_merge): its tokens wait at the piece's own position in tmp; move them down to where the
+                // sub-tile's tokens are dense (a forward copy: the destination is never above the source)
+                cnt1 = P.giant_cnt[sub];
+                const int32_t* src = P.tmp + abs0;
+                if (cnt1 < 0) cnt1 = 0;                                        // (no room in the pool: the call is being retried)
+                if (src != dst)
+                    for (int i0 = 0; i0 < cnt1; i0 += 64) {
+                        const int i = i0 + lane;
+                        const int32_t v = i < cnt1 ? src[i] : 0;
+                        (void)simt::ballot(true);                              // (every lane has read its element of the chunk before any is overwritten)
+                        if (i < cnt1) dst[i] = v;
                     }
-                    if (ok) cnt1 = tkz_bpe_long(T, at, len, arr, arr + stride, arr + 2 * stride, arr + 3 * stride, arr + 4 * stride, arr + 5 * stride, dst, &err);
-                }
-                simt::sync();
             }
             running += cnt1;
             k0 += 1;
@@ -672,6 +658,66 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
         simt::atomic_add64(&P.devprof[8], (unsigned long long)np);
     }
     if (lane == 0) { P.tile_count[sub] = running; P.tile_first[sub] = first_abs; }
+    if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
+}
+
+// -------------------------------------------------------------------------------------------------
+// giant pieces (> kArenaPiece bytes: a run of thousands of letters, of '=' ...): found on the bitmap, merged by a whole
+// 1024-thread workgroup each (tkz_bpe_long, rounds) before the encode kernels run
+// -------------------------------------------------------------------------------------------------
+TKZ_KERNEL(256) void k_giant_find(const uint64_t* startbits, int64_t nwords, int64_t total, int64_t* gq, unsigned long long* gcount, int64_t gcap) {
+    const int64_t stride = simt::nblocks() * simt::nthreads();
+    for (int64_t w = simt::bid() * simt::nthreads() + simt::tid(); w < nwords; w += stride) {
+        const uint64_t m = startbits[w];
+        if (!m) continue;
+        const int64_t p = (w << 6) + tkz_msb64(m);          // the last piece start of the word: the only one that can reach past it
+        if (p >= total) continue;                            // (the sentinel)
+        int64_t next = -1;
+        for (int64_t v = w + 1; v < nwords; ++v) {
+            const uint64_t x = startbits[v];
+            if (x) { next = (v << 6) + tkz_ctz64(x); break; }
+        }
+        if (next < 0) next = total;
+        if (next - p > kArenaPiece) {
+            const unsigned long long q = simt::atomic_add64(gcount, 1ull);
+            if ((int64_t)q < gcap) { gq[2 * q] = p; gq[2 * q + 1] = next - p; }
+        }
+    }
+}
+TKZ_KERNEL(1024) void k_giant_merge(TkzTables T, EncodeParams P) {
+    TKZ_SHARED int64_t s_off;
+    TKZ_SHARED int32_t s_whole;
+    const int64_t n = (int64_t)*P.giant_count < P.giant_cap ? (int64_t)*P.giant_count : P.giant_cap;
+    int err = 0;
+    for (int64_t q = simt::bid(); q < n; q += simt::nblocks()) {
+        const int64_t p = P.giant_q[2 * q], len64 = P.giant_q[2 * q + 1];
+        int cnt = 0;
+        if (len64 > kMaxPiece) err |= kErrTooLong;
+        else {
+            const int len = (int)len64;
+            const uint8_t* gb = P.bytes + p;
+            auto at = [&](int i) -> uint32_t { return gb[i]; };
+            int32_t* dst = P.tmp + p;
+            if (simt::tid() == 0) {
+                s_whole = tkz_lookup_long(T, at, (uint32_t)len);                 // TikTokenizer.cs:262 (a key this long is unusual, not impossible)
+                const unsigned long long need = 6ull * (unsigned long long)len;
+                const unsigned long long o = simt::atomic_add64(P.pool_head, need);
+                s_off = (o + need <= (unsigned long long)P.pool_cap) ? (int64_t)o : -1;
+            }
+            simt::sync();
+            const int32_t whole = s_whole;
+            const int64_t off = s_off;
+            simt::sync();
+            if (whole != TKZ_RANK_NONE) { if (simt::tid() == 0) dst[0] = whole; cnt = 1; }
+            else if (off < 0) { err |= kErrPool; cnt = -1; }
+            else {
+                int32_t* arr = P.pool + off;
+                cnt = tkz_bpe_long(T, at, len, arr, arr + len, arr + 2 * (int64_t)len, arr + 3 * (int64_t)len, arr + 4 * (int64_t)len, arr + 5 * (int64_t)len, dst, &err);
+            }
+        }
+        if (simt::tid() == 0) P.giant_cnt[p / kSub] = cnt;
+        simt::sync();
+    }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
 
@@ -985,6 +1031,13 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
 }
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub) {
     hook(L, K_ENCODE, 0);
+    TKZ_LAUNCH(k_giant_find, grid_for(P.nwords), kThreads, L.stream, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap);
+#ifdef TKZ_HOSTEMU
+    constexpr int kGiantGrid = 2;       // (the CPU emulator pays for every thread of an idle workgroup)
+#else
+    constexpr int kGiantGrid = 256;
+#endif
+    TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // strides over the queue; exits at once when it is empty
     TKZ_LAUNCH(k_encode_waves, nsub, 64, L.stream, T, P);
     { const int64_t chunks = cdiv(nsub, 64); TKZ_LAUNCH(k_encode_waves_heavy, chunks < 16384 ? chunks : 16384, 64, L.stream, T, P); }   // strides over 64-sub-tile chunks
     hook(L, K_ENCODE, 1);
