@@ -344,7 +344,7 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     e->T.short_slots = e->t_short.as<TkzShortSlot>(); e->T.short_mask = (uint32_t)V.short_slots.size() - 1; e->T.short_seed = V.short_seed;
     e->T.long_slots = e->t_long.as<TkzLongSlot>();    e->T.long_mask = (uint32_t)V.long_slots.size() - 1;
     e->T.long_blob = e->t_blob.as<uint8_t>();
-    e->T.pair_slots = e->t_pair.as<TkzPairSlot>();    e->T.pair_mask = (uint32_t)V.pair_slots.size() - 1; e->T.pair_seed = V.pair_seed;
+    e->T.pair_slots = e->t_pair.as<TkzPairSlot>();    e->T.pair_mask = (uint32_t)V.pair_slots.size() - 1; e->T.pair_seed = V.pair_seed; e->T.pair_compact = V.pair_compact ? 1u : 0u;
     e->T.byte_rank = e->t_byte.as<int32_t>();
     e->T.bytepair_rank = e->t_bpair.as<int32_t>();
     e->T.bmp_class = e->t_bmp.as<uint8_t>();

@@ -100,7 +100,7 @@ TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* 
         const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
         ids[j] = m;
         pr[r] = TKZ_NOKEY;
-        const int32_t rkr = tkz_match_pair(m, idr, vr1, vr2), rkl = tkz_match_pair(idl, m, vl1, vl2);
+        const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);
         pr[j] = (hi && rkr != TKZ_RANK_NONE) ? (((uint32_t)rkr << SH) | (uint32_t)j) : TKZ_NOKEY;
         if (lo) pr[l] = rkl != TKZ_RANK_NONE ? (((uint32_t)rkl << SH) | (uint32_t)l) : TKZ_NOKEY;
     }
@@ -208,7 +208,7 @@ TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, 
         const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
         ids[j] = m;                                     // the merged part carries the rank it was found under
         pr[r] = NONE;
-        const int32_t rkr = tkz_match_pair(m, idr, vr1, vr2), rkl = tkz_match_pair(idl, m, vl1, vl2);
+        const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);
         pr[j] = hasr ? entry(rkr, j) : NONE;                                // (:58)
         if (hasl) pr[l] = entry(rkl, l);                                    // (:59-62)
         --cnt;

@@ -216,9 +216,53 @@ int build_tables(Vocab* v, std::string* msg) {
         }
     }
     v->pair_entries = int64_t(pairs.size());
-    uint32_t pair_cap = next_pow2(std::max<uint64_t>(16, uint64_t(pairs.size()) * 2));
     v->bytepair_rank.assign(65536, TKZ_RANK_NONE);
-    for (bool done = false; !done; pair_cap *= 2) {
+    // compact form: every id fits 21 bits -> 8-byte entries, two per 16-byte bucket, (2,2)-cuckoo at a load of <= 0.85
+    bool compact = true;
+    for (const P& q : pairs) if (tkz_pair_cid(q.a) >= (1u << 21) || tkz_pair_cid(q.b) >= (1u << 21) || uint32_t(q.r) >= TKZ_PAIR_CID_LIMIT) { compact = false; break; }
+    for (int32_t r : v->ranks) if (uint32_t(r) >= TKZ_PAIR_CID_LIMIT) { compact = false; break; }
+    v->pair_compact = false;
+    if (compact) {
+        uint32_t buckets = next_pow2(std::max<uint64_t>(16, (uint64_t(pairs.size()) * 10 + 16) / 17));      // entries / 1.7
+        for (int grow = 0; grow < 3 && !v->pair_compact; ++grow, buckets *= 2) {
+            for (uint32_t seed = 1; seed <= 16 && !v->pair_compact; ++seed) {
+                std::vector<uint64_t> ent(size_t(buckets) * 2, 0);
+                TkzTables T{}; T.pair_mask = buckets - 1; T.pair_seed = seed;
+                bool ok = true;
+                uint32_t rng = 0x9E3779B9u * seed;
+                for (size_t i = 0; i < pairs.size() && ok; ++i) {
+                    uint32_t a = pairs[i].a, b = pairs[i].b; int32_t r = pairs[i].r;
+                    ok = false;
+                    for (int kick = 0; kick < 2000; ++kick) {
+                        uint32_t s1, s2;
+                        tkz_pair_slots(T, a, b, &s1, &s2);
+                        const uint64_t e = tkz_pair_key42(a, b) | (uint64_t(uint32_t(r)) << 42) | (1ull << 63);
+                        uint64_t* cand[4] = {&ent[2 * size_t(s1)], &ent[2 * size_t(s1) + 1], &ent[2 * size_t(s2)], &ent[2 * size_t(s2) + 1]};
+                        bool placed = false;
+                        for (uint64_t* c : cand) if (*c == 0) { *c = e; placed = true; break; }
+                        if (placed) { ok = true; break; }
+                        rng = rng * 1664525u + 1013904223u;
+                        uint64_t* victim = cand[(rng >> 16) & 3];
+                        const uint64_t old = *victim;
+                        *victim = e;
+                        // the evicted entry goes on: recover its ids (compact ids map back to ids)
+                        auto uncid = [](uint32_t c) { return c >= TKZ_PAIR_CID_LIMIT ? c - TKZ_PAIR_CID_LIMIT + uint32_t(TKZ_PSEUDO_BASE) : c; };
+                        a = uncid(uint32_t(old & 0x1FFFFFu)); b = uncid(uint32_t((old >> 21) & 0x1FFFFFu)); r = int32_t((old >> 42) & 0x1FFFFFu);
+                    }
+                }
+                if (ok) {
+                    v->pair_slots.assign(buckets, TkzPairSlot{0, 0, 0, 0});
+                    for (uint32_t k = 0; k < buckets; ++k) {
+                        const uint64_t e0 = ent[2 * size_t(k)], e1 = ent[2 * size_t(k) + 1];
+                        v->pair_slots[k] = TkzPairSlot{uint32_t(e0), uint32_t(e0 >> 32), int32_t(uint32_t(e1)), uint32_t(e1 >> 32)};
+                    }
+                    v->pair_seed = seed; v->pair_compact = true;
+                }
+            }
+        }
+    }
+    uint32_t pair_cap = next_pow2(std::max<uint64_t>(16, uint64_t(pairs.size()) * 2));
+    for (bool done = v->pair_compact; !done; pair_cap *= 2) {
         for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
             v->pair_slots.assign(pair_cap, TkzPairSlot{0, 0, 0, 0});
             TkzTables T{}; T.pair_mask = pair_cap - 1; T.pair_seed = seed;

@@ -29,6 +29,7 @@ struct Vocab {
     std::vector<int32_t> bytepair_rank;   // 65536
     int64_t pair_entries = 0;
     uint32_t short_seed = 0, pair_seed = 0;   // seeds under which the cuckoo insertion succeeded
+    bool pair_compact = false;                // pair_slots are two-entry buckets of 8-byte entries (tkz_tables.h)
 
     bool lookup(const std::string& k, int32_t* rank) const {
         auto it = index.find(k);
