@@ -665,19 +665,25 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
 // giant pieces (> kArenaPiece bytes: a run of thousands of letters, of '=' ...): found on the bitmap, merged by a whole
 // 1024-thread workgroup each (tkz_bpe_long, rounds) before the encode kernels run
 // -------------------------------------------------------------------------------------------------
-TKZ_KERNEL(256) void k_giant_find(const uint64_t* startbits, int64_t nwords, int64_t total, int64_t* gq, unsigned long long* gcount, int64_t gcap) {
+TKZ_KERNEL(256) void k_giant_find(const uint8_t* heavy_flag, int64_t nsub, const uint64_t* startbits, int64_t nwords, int64_t total,
+                                  int64_t* gq, unsigned long long* gcount, int64_t gcap) {
+    // only a sub-tile the lean kernel flagged can hold the start of a giant piece, and only its LAST piece start can be one
+    // (a giant piece reaches past the end of its sub-tile)
     const int64_t stride = simt::nblocks() * simt::nthreads();
-    for (int64_t w = simt::bid() * simt::nthreads() + simt::tid(); w < nwords; w += stride) {
-        const uint64_t m = startbits[w];
-        if (!m) continue;
-        const int64_t p = (w << 6) + tkz_msb64(m);          // the last piece start of the word: the only one that can reach past it
-        if (p >= total) continue;                            // (the sentinel)
-        int64_t next = -1;
-        for (int64_t v = w + 1; v < nwords; ++v) {
+    for (int64_t t = simt::bid() * simt::nthreads() + simt::tid(); t < nsub; t += stride) {
+        if (!heavy_flag[t]) continue;
+        int64_t p = -1;
+        for (int k = kSub / 64 - 1; k >= 0 && p < 0; --k) {
+            const int64_t w = t * (kSub / 64) + k;
+            const uint64_t m = w < nwords ? startbits[w] : 0;
+            if (m) p = (w << 6) + tkz_msb64(m);
+        }
+        if (p < 0 || p >= total) continue;                   // (no piece starts here / the sentinel)
+        int64_t next = total;
+        for (int64_t v = (t + 1) * (kSub / 64); v < nwords; ++v) {
             const uint64_t x = startbits[v];
             if (x) { next = (v << 6) + tkz_ctz64(x); break; }
         }
-        if (next < 0) next = total;
         if (next - p > kArenaPiece) {
             const unsigned long long q = simt::atomic_add64(gcount, 1ull);
             if ((int64_t)q < gcap) { gq[2 * q] = p; gq[2 * q + 1] = next - p; }
@@ -1031,14 +1037,15 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
 }
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub) {
     hook(L, K_ENCODE, 0);
-    TKZ_LAUNCH(k_giant_find, grid_for(P.nwords), kThreads, L.stream, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap);
+    TKZ_LAUNCH(k_encode_waves, nsub, 64, L.stream, T, P);
+    // giant pieces start in sub-tiles the lean kernel has just flagged: find them, merge them, then the heavy kernel
+    TKZ_LAUNCH(k_giant_find, grid_for(nsub), kThreads, L.stream, (const uint8_t*)P.heavy_flag, nsub, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap);
 #ifdef TKZ_HOSTEMU
     constexpr int kGiantGrid = 2;       // (the CPU emulator pays for every thread of an idle workgroup)
 #else
     constexpr int kGiantGrid = 256;
 #endif
     TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // strides over the queue; exits at once when it is empty
-    TKZ_LAUNCH(k_encode_waves, nsub, 64, L.stream, T, P);
     { const int64_t chunks = cdiv(nsub, 64); TKZ_LAUNCH(k_encode_waves_heavy, chunks < 16384 ? chunks : 16384, 64, L.stream, T, P); }   // strides over 64-sub-tile chunks
     hook(L, K_ENCODE, 1);
 }
