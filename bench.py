@@ -147,66 +147,72 @@ def main():
         host_path = None
         parity_note = "unchecked"
         if world == 1 and not args.no_cpu_baseline:
-            from oracle import oracle as O
-            ns = min(args.cpu_sample_docs, n_docs)
-            h_offs = d_offs[:ns + 1].cpu().numpy()
-            nb = int(h_offs[-1])
-            h_bytes = d_bytes[:nb].cpu().numpy()
-            h_ooffs = d_ooffs[:ns + 1].cpu().numpy()
-            h_ids = d_ids[:int(h_ooffs[-1])].cpu().numpy()
-            ov = O.Vocab(raw)
-            threads = max(1, min(os.cpu_count() or 1, 64))
-            tm = {}
-            o_ids, o_counts = O.encode_batch(ov, args.pattern, h_bytes, h_offs, threads=threads, timing=tm)
-            tcpu = tm["seconds"]
-            same = len(o_ids) == len(h_ids) and np.array_equal(o_ids, h_ids) and np.array_equal(np.diff(h_ooffs), o_counts)
-            # (not timed) the LAST documents of the batch too, and the offsets of the whole batch: placement at large indices
-            nt = min(20_000, n_docs)
-            t_offs = d_offs[n_docs - nt:n_docs + 1].cpu().numpy()
-            t_bytes = d_bytes[int(t_offs[0]):int(t_offs[-1])].cpu().numpy()
-            t_ooffs = d_ooffs[n_docs - nt:n_docs + 1].cpu().numpy()
-            t_ids = d_ids[int(t_ooffs[0]):int(t_ooffs[-1])].cpu().numpy()
-            p_ids, p_counts = O.encode_batch(ov, args.pattern, t_bytes, t_offs - t_offs[0], threads=threads)
-            same = same and np.array_equal(p_ids, t_ids) and np.array_equal(np.diff(t_ooffs), p_counts)
-            same = same and int(d_ooffs[0].item()) == 0 and int(d_ooffs[n_docs].item()) == n_tokens_rank \
-                and bool((d_ooffs[1:n_docs + 1] >= d_ooffs[:n_docs]).all().item())
-            parity_note = ("bit-exact vs oracle on the first %d and the last %d docs (%d tokens); offsets of all %d docs monotone, ending at the token count"
-                           % (ns, nt, len(o_ids) + len(p_ids), n_docs)) if same else "MISMATCH vs oracle on the sample"
-            # one thread, on a tenth of the sample (SURVEY.md 8d asks for both figures)
-            n1 = max(1, ns // 20)
-            O.encode_batch(ov, args.pattern, h_bytes[:int(h_offs[n1])], h_offs[:n1 + 1], threads=1, timing=tm)
-            t1 = tm["seconds"]
-            cpu_1t = round(int(h_offs[n1]) / t1 / 1e6, 2)
-            # PCIe-inclusive rate through the host-buffer entry point (tkz_encode_batch_utf8: H2D of the text, the kernels,
-            # D2H of ids + offsets), on ordinary (pageable) numpy buffers and on page-locked ones.  Output buffers are
-            # allocated and touched beforehand: a fresh np.empty would add its first-touch page faults to the figure.
-            # Reported beside the number, never as `value`.
-            nh = min(1_000_000, n_docs)
-            hh_offs = d_offs[:nh + 1].cpu().numpy()
-            hh_bytes = d_bytes[:int(hh_offs[-1])].cpu().numpy()
-            o_ids_buf = np.zeros(len(hh_bytes), np.int32)
-            o_off_buf = np.zeros(nh + 1, np.int64)
-            rates = []
-            for pinned in (False, True):
-                if pinned:
-                    tb = torch.empty(len(hh_bytes), dtype=torch.uint8).pin_memory(); tb.numpy()[:] = hh_bytes
-                    to = torch.empty(nh + 1, dtype=torch.int64).pin_memory(); to.numpy()[:] = hh_offs
-                    ti = torch.zeros(len(hh_bytes), dtype=torch.int32).pin_memory()
-                    too = torch.zeros(nh + 1, dtype=torch.int64).pin_memory()
-                    bufs = (tb.numpy(), to.numpy(), (ti.numpy(), too.numpy()))
-                else:
-                    bufs = (hh_bytes, hh_offs, (o_ids_buf, o_off_buf))
-                enc.encode_batch(bufs[0], bufs[1], out=bufs[2])                   # sizes the encoder's staging buffers
-                tc = time.perf_counter()
-                r_ids, r_ooffs = enc.encode_batch(bufs[0], bufs[1], out=bufs[2])
-                rates.append(round(len(hh_bytes) / (time.perf_counter() - tc) / 1e6, 1))
-                host_same = (pinned is False or host_same) and int(r_ooffs[-1]) == int(d_ooffs[nh].item()) \
-                    and np.array_equal(r_ids[:len(h_ids)], h_ids[:len(r_ids)])
-            host_path = {"value": rates[0], "value_pinned_buffers": rates[1], "unit": "MB/s", "docs": nh, "same_ids_as_device_path": bool(host_same),
-                         "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text + kernels + D2H of ids and offsets, one after the other"}
-            cpu = {"value": round(nb / tcpu / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port", "value_1_thread": cpu_1t,
-                   "sample": "first %d documents (%.1f MB) of the same corpus, reference-algorithm CPU restatement (oracle/), "
-                             "8192-entry LRU memo per thread, %d threads of %d host cores" % (ns, nb / 1e6, threads, os.cpu_count() or 1)}
+            try:
+                from oracle import oracle as O
+                ns = min(args.cpu_sample_docs, n_docs)
+                h_offs = d_offs[:ns + 1].cpu().numpy()
+                nb = int(h_offs[-1])
+                h_bytes = d_bytes[:nb].cpu().numpy()
+                h_ooffs = d_ooffs[:ns + 1].cpu().numpy()
+                h_ids = d_ids[:int(h_ooffs[-1])].cpu().numpy()
+                ov = O.Vocab(raw)
+                threads = max(1, min(os.cpu_count() or 1, 64))
+                tm = {}
+                o_ids, o_counts = O.encode_batch(ov, args.pattern, h_bytes, h_offs, threads=threads, timing=tm)
+                tcpu = tm["seconds"]
+                same = len(o_ids) == len(h_ids) and np.array_equal(o_ids, h_ids) and np.array_equal(np.diff(h_ooffs), o_counts)
+                # (not timed) the LAST documents of the batch too, and the offsets of the whole batch: placement at large indices
+                nt = min(20_000, n_docs)
+                t_offs = d_offs[n_docs - nt:n_docs + 1].cpu().numpy()
+                t_bytes = d_bytes[int(t_offs[0]):int(t_offs[-1])].cpu().numpy()
+                t_ooffs = d_ooffs[n_docs - nt:n_docs + 1].cpu().numpy()
+                t_ids = d_ids[int(t_ooffs[0]):int(t_ooffs[-1])].cpu().numpy()
+                p_ids, p_counts = O.encode_batch(ov, args.pattern, t_bytes, t_offs - t_offs[0], threads=threads)
+                same = same and np.array_equal(p_ids, t_ids) and np.array_equal(np.diff(t_ooffs), p_counts)
+                same = same and int(d_ooffs[0].item()) == 0 and int(d_ooffs[n_docs].item()) == n_tokens_rank \
+                    and bool((d_ooffs[1:n_docs + 1] >= d_ooffs[:n_docs]).all().item())
+                parity_note = ("bit-exact vs oracle on the first %d and the last %d docs (%d tokens); offsets of all %d docs monotone, ending at the token count"
+                               % (ns, nt, len(o_ids) + len(p_ids), n_docs)) if same else "MISMATCH vs oracle on the sample"
+                # one thread, on a tenth of the sample (SURVEY.md 8d asks for both figures)
+                n1 = max(1, ns // 20)
+                O.encode_batch(ov, args.pattern, h_bytes[:int(h_offs[n1])], h_offs[:n1 + 1], threads=1, timing=tm)
+                t1 = tm["seconds"]
+                cpu_1t = round(int(h_offs[n1]) / t1 / 1e6, 2)
+                # PCIe-inclusive rate through the host-buffer entry point (tkz_encode_batch_utf8: H2D of the text, the kernels,
+                # D2H of ids + offsets), on ordinary (pageable) numpy buffers and on page-locked ones.  Output buffers are
+                # allocated and touched beforehand: a fresh np.empty would add its first-touch page faults to the figure.
+                # Reported beside the number, never as `value`.
+                try:
+                    nh = min(1_000_000, n_docs)
+                    hh_offs = d_offs[:nh + 1].cpu().numpy()
+                    hh_bytes = d_bytes[:int(hh_offs[-1])].cpu().numpy()
+                    o_ids_buf = np.zeros(len(hh_bytes), np.int32)
+                    o_off_buf = np.zeros(nh + 1, np.int64)
+                    rates = []
+                    for pinned in (False, True):
+                        if pinned:
+                            tb = torch.empty(len(hh_bytes), dtype=torch.uint8).pin_memory(); tb.numpy()[:] = hh_bytes
+                            to = torch.empty(nh + 1, dtype=torch.int64).pin_memory(); to.numpy()[:] = hh_offs
+                            ti = torch.zeros(len(hh_bytes), dtype=torch.int32).pin_memory()
+                            too = torch.zeros(nh + 1, dtype=torch.int64).pin_memory()
+                            bufs = (tb.numpy(), to.numpy(), (ti.numpy(), too.numpy()))
+                        else:
+                            bufs = (hh_bytes, hh_offs, (o_ids_buf, o_off_buf))
+                        enc.encode_batch(bufs[0], bufs[1], out=bufs[2])                   # sizes the encoder's staging buffers
+                        tc = time.perf_counter()
+                        r_ids, r_ooffs = enc.encode_batch(bufs[0], bufs[1], out=bufs[2])
+                        rates.append(round(len(hh_bytes) / (time.perf_counter() - tc) / 1e6, 1))
+                        host_same = (pinned is False or host_same) and int(r_ooffs[-1]) == int(d_ooffs[nh].item()) \
+                            and np.array_equal(r_ids[:len(h_ids)], h_ids[:len(r_ids)])
+                    host_path = {"value": rates[0], "value_pinned_buffers": rates[1], "unit": "MB/s", "docs": nh, "same_ids_as_device_path": bool(host_same),
+                                 "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text + kernels + D2H of ids and offsets, one after the other"}
+                except Exception as ex:                      # an auxiliary figure must never cost the bench line
+                    host_path = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                cpu = {"value": round(nb / tcpu / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port", "value_1_thread": cpu_1t,
+                       "sample": "first %d documents (%.1f MB) of the same corpus, reference-algorithm CPU restatement (oracle/), "
+                                 "8192-entry LRU memo per thread, %d threads of %d host cores" % (ns, nb / 1e6, threads, os.cpu_count() or 1)}
+            except Exception as ex:                          # (e.g. no C compiler for the oracle on this host)
+                parity_note = "unchecked: CPU oracle unavailable (%s: %s)" % (type(ex).__name__, ex)
         line = {
             "metric": "input MB/s encoded (cl100k_base)", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
