@@ -83,7 +83,7 @@ class Vocab:
             raise OracleError(err.value)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # (module globals may be gone at interpreter shutdown)
             lib().tkzo_vocab_free(self._h)
             self._h = None
 
@@ -153,7 +153,7 @@ class Encoder:
             self.specials.append(lit)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:
             lib().tkzo_encoder_free(self._h)
             self._h = None
 
