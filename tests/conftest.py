@@ -28,6 +28,24 @@ def gpt2_tiktoken_bytes():
         return gzip.decompress(f.read())
 
 
+# Rank files in tests/golden/: gpt2 is the one vocabulary the reference ships (model/gpt2.tiktoken); synth100k / synth200k are
+# stand-ins of the SIZE of cl100k_base / o200k_base (which the reference downloads at run time and which exist nowhere offline),
+# trained by tools/train_bpe.py with the cl100k / o200k split pattern: 100,256 and 199,998 keys, keys up to 128 bytes, ids > 2^17.
+VOCAB_FILES = {"gpt2": "gpt2.tiktoken.gz", "synth100k": "synth100k.tiktoken.gz", "synth200k": "synth200k.tiktoken.gz"}
+
+
+@pytest.fixture(scope="session")
+def vocab_bytes():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            with open(os.path.join(GOLDEN, VOCAB_FILES[name]), "rb") as f:
+                cache[name] = gzip.decompress(f.read())
+        return cache[name]
+    return get
+
+
 @pytest.fixture(scope="session")
 def lib_rs_bytes():
     with open(os.path.join(GOLDEN, "lib.rs.txt"), "rb") as f:

@@ -23,6 +23,19 @@ def vocab(lib, gpt2_tiktoken_bytes):
     return N.Vocab(gpt2_tiktoken_bytes, lib)
 
 
+@pytest.fixture(scope="module")
+def vocabs(lib, vocab_bytes, oracle_mod):
+    """name -> (device-table vocabulary, oracle vocabulary) for gpt2 / synth100k / synth200k (tests/conftest.py)."""
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            raw = vocab_bytes(name)
+            cache[name] = (N.Vocab(raw, lib), oracle_mod.Vocab(raw))
+        return cache[name]
+    return get
+
+
 def test_golden_gpt2_ids(lib, vocab, lib_rs_bytes):
     enc = N.Encoder(vocab, N.P1)
     assert enc.encode_utf8(lib_rs_bytes) == load_golden_json("tokens_gpt2.json")
@@ -51,12 +64,16 @@ def test_pretok_long_runs(lib, vocab, oracle_mod, pattern):
     parity.check_pretok(lib, oracle_mod, vocab, pattern, 0, seeds=range(5), kinds=("runs",), doc_lens=[3000, 30000, 70000], n_docs_choices=(1, 3))
 
 
-def test_every_vocab_key(lib, vocab, oracle_mod, oracle_gpt2):
-    parity.check_vocab_keys(lib, oracle_mod, vocab, oracle_gpt2)
+@pytest.mark.parametrize("vname", ["gpt2", "synth100k", "synth200k"])
+def test_every_vocab_key(lib, vocabs, oracle_mod, vname):
+    v, ov = vocabs(vname)
+    parity.check_vocab_keys(lib, oracle_mod, v, ov)
 
 
-def test_pieces_vs_oracle_bpe(lib, vocab, oracle_mod, oracle_gpt2):
-    parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=5, rounds=6,
+@pytest.mark.parametrize("vname", ["gpt2", "synth100k", "synth200k"])
+def test_pieces_vs_oracle_bpe(lib, vocabs, oracle_mod, vname):
+    vocab, oracle_gpt2 = vocabs(vname)
+    parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=5, rounds=6 if vname == "gpt2" else 3,
                         lens=[1, 2, 3, 4, 5, 8, 12, 13, 15, 16, 17, 20, 31, 32, 33, 64, 100, 300], counts=[1, 5, 300, 1200])
 
 
@@ -70,9 +87,10 @@ def test_long_and_giant_pieces(lib, vocab, oracle_mod, oracle_gpt2):
     parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=9, rounds=2, lens=[300, 1024, 1025, 1500, 2600], counts=[3])
 
 
-@pytest.mark.parametrize("pattern", [1, 2, 3])
-def test_batch_vs_oracle(lib, vocab, oracle_mod, oracle_gpt2, pattern):
-    parity.check_batch(lib, oracle_mod, vocab, oracle_gpt2, pattern, seed=11 + pattern, rounds=5,
+@pytest.mark.parametrize("pattern,vname", [(1, "gpt2"), (2, "gpt2"), (3, "gpt2"), (2, "synth100k"), (3, "synth200k")])
+def test_batch_vs_oracle(lib, vocabs, oracle_mod, pattern, vname):
+    vocab, oracle_gpt2 = vocabs(vname)
+    parity.check_batch(lib, oracle_mod, vocab, oracle_gpt2, pattern, seed=11 + pattern, rounds=5 if vname == "gpt2" else 3,
                        doc_lens=[0, 1, 10, 100, 1000, 6000], n_docs_choices=[1, 4, 40], kinds=("mix", "ws", "oth"))
 
 

@@ -25,6 +25,19 @@ def vocab(lib, gpt2_tiktoken_bytes):
     return N.Vocab(gpt2_tiktoken_bytes, lib)
 
 
+@pytest.fixture(scope="module")
+def vocabs(lib, vocab_bytes, oracle_mod):
+    """name -> (device-table vocabulary, oracle vocabulary) for gpt2 / synth100k / synth200k (tests/conftest.py)."""
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            raw = vocab_bytes(name)
+            cache[name] = (N.Vocab(raw, lib), oracle_mod.Vocab(raw))
+        return cache[name]
+    return get
+
+
 def test_native_library_is_the_hip_build(lib):
     assert lib.path.endswith(os.path.join("tokenizer_amd", "lib", "libtkz.so"))
     import subprocess
@@ -63,12 +76,20 @@ def test_golden_splits(lib, vocab):
         assert [int(i) for i in np.nonzero(got[:len(b)])[0]] == [p[0] for p in rec["pieces"]], rec["text"]
 
 
-def test_every_vocab_key(lib, vocab, oracle_mod, oracle_gpt2):
-    parity.check_vocab_keys(lib, oracle_mod, vocab, oracle_gpt2)
+VOCABS = ["gpt2", "synth100k", "synth200k"]
 
 
-def test_pieces_vs_oracle_bpe(lib, vocab, oracle_mod, oracle_gpt2):
-    parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=5, rounds=25,
+@pytest.mark.parametrize("vname", VOCABS)
+def test_every_vocab_key(lib, vocabs, oracle_mod, vname):
+    v, ov = vocabs(vname)
+    assert len(v) == len(ov) == {"gpt2": 50256, "synth100k": 100256, "synth200k": 199998}[vname]
+    parity.check_vocab_keys(lib, oracle_mod, v, ov)
+
+
+@pytest.mark.parametrize("vname", VOCABS)
+def test_pieces_vs_oracle_bpe(lib, vocabs, oracle_mod, vname):
+    v, ov = vocabs(vname)
+    parity.check_pieces(lib, oracle_mod, v, ov, seed=5, rounds=25 if vname == "gpt2" else 12,
                         lens=[1, 2, 3, 4, 5, 8, 12, 13, 15, 16, 17, 20, 31, 32, 33, 64, 100, 300, 400, 1000, 1023, 1024, 1025, 2048, 3000], counts=[1, 5, 300, 3000])
 
 
@@ -77,17 +98,20 @@ def test_mid_pieces_share_the_arena(lib, vocab, oracle_mod, oracle_gpt2):
     parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=11, rounds=12, lens=[17, 24, 33, 40, 48, 64, 90, 128, 200, 400, 1023, 1024], counts=[40, 400, 4000], p_listed=1.0)
 
 
-def test_giant_pieces(lib, vocab, oracle_mod, oracle_gpt2):
+@pytest.mark.parametrize("vname", ["gpt2", "synth100k"])
+def test_giant_pieces(lib, vocabs, oracle_mod, vname):
     # the 4,000-byte single-letter piece of tokenizer_ts/test/tikTokenizer.test.ts:133, and longer ones
+    vocab, oracle_gpt2 = vocabs(vname)
     enc = N.Encoder(vocab, N.CL100K)
     oenc = oracle_mod.Encoder(oracle_gpt2, oracle_mod.CL100K)
     for text in (b"t" * 4000, b"=" * 9000, b" " * 5000 + b"x", b"ab" * 6000, bytes(range(97, 123)) * 400):
         assert enc.encode_utf8(text) == oenc.encode_bytes(text)
 
 
-@pytest.mark.parametrize("pattern", [1, 2, 3])
-def test_batch_vs_oracle(lib, vocab, oracle_mod, oracle_gpt2, pattern):
-    parity.check_batch(lib, oracle_mod, vocab, oracle_gpt2, pattern, seed=11 + pattern, rounds=12,
+@pytest.mark.parametrize("pattern,vname", [(1, "gpt2"), (2, "gpt2"), (3, "gpt2"), (2, "synth100k"), (3, "synth200k"), (1, "synth200k")])
+def test_batch_vs_oracle(lib, vocabs, oracle_mod, pattern, vname):
+    v, ov = vocabs(vname)
+    parity.check_batch(lib, oracle_mod, v, ov, pattern, seed=11 + pattern, rounds=12 if vname == "gpt2" else 8,
                        doc_lens=[0, 1, 10, 100, 1000, 6000, 30000], n_docs_choices=[1, 4, 40, 400], kinds=("mix", "ws", "oth", "dig", "apo", "case", "a_mix", "a_brk", "a_ws", "a_dig"))
 
 
@@ -122,20 +146,23 @@ def _device_run(lib, vocab, kind, pattern, n_docs, lo, hi, seed, sequential=Fals
     return dict(enc=enc, total=total, ntok=ntok, d_offs=d_offs, d_bytes=d_bytes, d_ids=d_ids[:ntok], d_ooffs=d_ooffs)
 
 
-def _token_lengths(oracle_gpt2):
-    ents = oracle_gpt2.entries()
+def _token_lengths(ovocab):
+    ents = ovocab.entries()
     tl = np.zeros(max(r for _, r in ents) + 1, np.int64)
     for k, r in ents:
         tl[r] = len(k)
     return tl
 
 
-@pytest.mark.parametrize("kind,pattern,n_docs,lo,hi", [(1, 2, 400_000, 256, 768), (2, 2, 200_000, 256, 768), (3, 3, 1_500, 30_000, 34_000),
-                                                       (1, 1, 100_000, 16, 128), (3, 2, 1_500, 30_000, 34_000),
-                                                       # BASELINE.json configs[1], [2] and one GPU's share of [4] at full size
-                                                       (1, 2, 10_000_000, 256, 768), (2, 2, 2_000_000, 256, 768), (3, 3, 32_768, 30_000, 34_000)])
-def test_device_corpus_properties_and_sample(lib, vocab, oracle_mod, oracle_gpt2, kind, pattern, n_docs, lo, hi):
+@pytest.mark.parametrize("vname,kind,pattern,n_docs,lo,hi", [
+    ("gpt2", 1, 2, 400_000, 256, 768), ("synth100k", 1, 2, 400_000, 256, 768), ("synth100k", 2, 2, 200_000, 256, 768),
+    ("synth200k", 3, 3, 1_500, 30_000, 34_000), ("gpt2", 1, 1, 100_000, 16, 128), ("synth100k", 3, 2, 1_500, 30_000, 34_000),
+    ("synth200k", 2, 3, 100_000, 256, 768),
+    # BASELINE.json configs[1], [2] and one GPU's share of [4] at full size, on the stand-ins of the vocabularies they name
+    ("synth100k", 1, 2, 10_000_000, 256, 768), ("synth100k", 2, 2, 2_000_000, 256, 768), ("synth200k", 3, 3, 32_768, 30_000, 34_000)])
+def test_device_corpus_properties_and_sample(lib, vocabs, oracle_mod, vname, kind, pattern, n_docs, lo, hi):
     import torch
+    vocab, oracle_gpt2 = vocabs(vname)
     r = _device_run(lib, vocab, kind, pattern, n_docs, lo, hi, 0x5EED0000 + kind)
     ooffs = r["d_ooffs"]
     assert int(ooffs[0]) == 0 and int(ooffs[-1]) == r["ntok"]

@@ -3,9 +3,11 @@
 // generate a 10 M-document batch in place and the host can regenerate any single document for a spot
 // check with the same function.  Integer arithmetic only (bit-identical on host and device).
 //
-//   kind 1  ASCII English/code-like: Zipf-ranked words from a fixed 1024-word table joined by single
-//           spaces, sentence punctuation, newlines, double spaces, 1..6-digit numbers, contractions
-//           ('s 're 'll and upper-case 'S), code-like punctuation runs            (configs 1, 2, 4)
+//   kind 1  ASCII English/code-like: Zipf-ranked (s = 1) words from a fixed 4096-word table (4 % of it longer than
+//           16 bytes, all in the rarest octave) joined by single spaces, sentence punctuation, newlines, double
+//           spaces, 1..6-digit numbers, contractions ('s 're 'll and upper-case 'S), code-like punctuation
+//           runs, identifiers (snake_case, camelCase, PascalCase, dotted.paths, calls), URLs and hex blobs
+//                                                                                  (configs 1, 2, 4)
 //   kind 2  mixed UTF-8: ASCII words, BMP CJK / kana / hangul runs, emoji incl. supplementary-plane
 //           ZWJ / VS-16 / skin-tone sequences placed directly against letters and CJK, and
 //           U+3000 / NBSP / NEL white space                                        (config 3)
@@ -18,7 +20,8 @@
 
 #include "tkz_simt.h"
 
-static constexpr char kTkzCorpusWords[1024 * 12 + 1] =
+constexpr int kTkzCorpusWordCount = 4096, kTkzCorpusWordWidth = 24;
+static constexpr char kTkzCorpusWords[kTkzCorpusWordCount * kTkzCorpusWordWidth + 1] =
 #include "tkz_corpus_words.inc"
     ;
 
@@ -47,14 +50,16 @@ struct TkzEmit {
     }
 };
 
-// log-uniform rank in [0, 1024): octave k (uniform), then uniform inside [2^k - 1, 2^(k+1) - 1)
+// log-uniform rank in [0, 4095) (Zipf s = 1): octave k (uniform), then uniform inside [2^k - 1, 2^(k+1) - 1)
 TKZ_HD uint32_t tkz_zipf_rank(TkzRng& r) {
-    const uint32_t k = r.below(10);
+    const uint32_t k = r.below(12);
     return ((1u << k) - 1u) + r.below(1u << k);
 }
-TKZ_HD void tkz_emit_word(TkzEmit& e, TkzRng& r, int casing) {   // casing: 0 lower, 1 Capitalised, 2 UPPER
-    const char* w = &kTkzCorpusWords[tkz_zipf_rank(r) * 12];
-    for (int i = 0; i < 12 && w[i]; ++i) {
+TKZ_HD void tkz_emit_word_rank(TkzEmit& e, uint32_t rank, int casing);
+TKZ_HD void tkz_emit_word(TkzEmit& e, TkzRng& r, int casing) { tkz_emit_word_rank(e, tkz_zipf_rank(r), casing); }   // casing: 0 lower, 1 Capitalised, 2 UPPER
+TKZ_HD void tkz_emit_word_rank(TkzEmit& e, uint32_t rank, int casing) {
+    const char* w = &kTkzCorpusWords[rank * kTkzCorpusWordWidth];
+    for (int i = 0; i < kTkzCorpusWordWidth && w[i]; ++i) {
         uint32_t c = (uint8_t)w[i];
         if (casing == 2 || (casing == 1 && i == 0)) c -= 32;
         e.put(c);
@@ -70,6 +75,34 @@ TKZ_HD void tkz_emit_punct_run(TkzEmit& e, TkzRng& r) {
     for (int i = 0; s[i]; ++i) e.put((uint8_t)s[i]);
 }
 
+// identifiers as source code has them: snake_case, camelCase, PascalCase, a dotted path, a call -- two or three of the
+// 511 commonest (short) words
+TKZ_HD void tkz_emit_identifier(TkzEmit& e, TkzRng& r) {
+    const uint32_t style = r.below(5);
+    const int n = 2 + (int)r.below(2);
+    for (int i = 0; i < n; ++i) {
+        if (i && style == 0) e.put('_');
+        if (i && style == 3) e.put('.');
+        const uint32_t k = r.below(9);
+        tkz_emit_word_rank(e, ((1u << k) - 1u) + r.below(1u << k), (style == 1 && i > 0) || style == 2 ? 1 : 0);
+    }
+    if (style == 4) { e.put('('); if (r.below(2)) e.put(')'); }
+}
+TKZ_HD void tkz_emit_hex(TkzEmit& e, TkzRng& r, int n) {
+    for (int i = 0; i < n; ++i) { const uint32_t d = r.below(16); e.put(d < 10 ? '0' + d : 'a' + d - 10); }
+}
+TKZ_HD void tkz_emit_url(TkzEmit& e, TkzRng& r) {
+    const char* const head = r.below(4) ? "https://www." : "http://";
+    for (int i = 0; head[i]; ++i) e.put((uint8_t)head[i]);
+    tkz_emit_word(e, r, 0);
+    const char* const tld[] = {".com/", ".org/", ".net/", ".io/"};
+    const char* t = tld[r.below(4)];
+    for (int i = 0; t[i]; ++i) e.put((uint8_t)t[i]);
+    const int n = 1 + (int)r.below(3);
+    for (int i = 0; i < n; ++i) { if (i) e.put('/'); tkz_emit_word(e, r, 0); }
+    if (r.below(3) == 0) { const char* q = "?id="; for (int i = 0; q[i]; ++i) e.put((uint8_t)q[i]); tkz_emit_number(e, r); }
+}
+
 TKZ_HD void tkz_corpus_ascii_item(TkzEmit& e, TkzRng& r, bool first) {
     const uint32_t u = r.below(1000);
     if (!first) {
@@ -82,6 +115,9 @@ TKZ_HD void tkz_corpus_ascii_item(TkzEmit& e, TkzRng& r, bool first) {
     const uint32_t v = r.below(1000);
     if (v < 60) tkz_emit_number(e, r);
     else if (v < 110) tkz_emit_punct_run(e, r);
+    else if (v < 130) tkz_emit_identifier(e, r);
+    else if (v < 134) tkz_emit_url(e, r);
+    else if (v < 137) { if (r.below(2)) { e.put('0'); e.put('x'); tkz_emit_hex(e, r, r.below(2) ? 8 : 16); } else tkz_emit_hex(e, r, r.below(2) ? 32 : 40); }
     else {
         const uint32_t c = r.below(100);
         tkz_emit_word(e, r, c < 86 ? 0 : (c < 97 ? 1 : 2));

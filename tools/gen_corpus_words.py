@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Emit tokenizer_amd/csrc/tkz_corpus_words.inc: the fixed word table of the synthetic corpus
-generator (tkz_corpus.h).  1024 entries of up to 11 ASCII letters, most frequent first; the
-generator draws ranks log-uniformly (Zipf-like).  The list is hand-written common English plus a
-programmatic long tail (stem + suffix) so that a realistic share of pieces misses the whole-piece
-lookup and goes through the merge loop."""
+generator (tkz_corpus.h).  4096 entries of up to 23 ASCII letters, most frequent first; the generator
+draws ranks log-uniformly (Zipf s = 1).  The head is hand-written common English, the tail
+is derivational morphology (prefix + stem + suffix) sorted by length, so that the tail is made of long,
+rare words: about 5 % of the table is longer than 16 bytes (`internationalizations`, ...), which is what
+sends a piece to the general merge path of the encode kernel, and a realistic share of all pieces misses
+the whole-piece lookup."""
 import sys
 
 COMMON = """
@@ -69,28 +71,70 @@ original share station dad bread charge proper bar offer segment slave duck inst
 populate chick dear enemy reply drink occur support speech nature range steam motion path liquid
 log meant quotient teeth shell neck
 """.split()
-STEMS = ["token", "encod", "comput", "network", "memor", "kernel", "vector", "matri", "parallel", "schedul",
-         "compil", "optim", "gradient", "tensor", "buffer", "thread", "latenc", "bandwid", "quantiz", "normaliz"]
-SUFF = ["er", "ing", "ation", "ized", "s", "ize", "al", "ity", "able", "ly", "ment", "ed"]
+
+# stems the tail is derived from (technical + general); a stem ending in a vowel-dropping form is spelt as it combines
+STEMS = """token encod comput network memor kernel vector matri parallel schedul compil optim gradient tensor buffer
+thread latenc bandwidth quantiz normaliz national character organiz general special standard local global central
+industrial commercial material natural formal legal social critical practical technical political historical
+physical chemical logical mechanical electrical numerical statistical theoretical experimental environmental
+professional institutional constitutional conventional functional operational educational international
+sequenc structur configur architectur infrastructur represent implement document instrument environ govern
+develop manag establish accomplish acknowledg understand communicat demonstrat investigat administrat
+concentrat illustrat incorporat differentiat discriminat authenticat synchroniz initializ serializ virtualiz
+visualiz categoriz characteriz internationaliz institutionaliz compartmentaliz conceptualiz
+respons product construct instruct destruct abstract interact transact distribut contribut attribut
+""".split()
+SUFF = ["", "s", "ed", "er", "ers", "ing", "ings", "ation", "ations", "ized", "izing", "ize", "izes", "al", "ally", "ity", "ities",
+        "able", "ability", "ly", "ment", "ments", "ness", "ism", "ist", "ists", "ive", "ively", "iveness", "or", "ors", "ional", "ionally"]
+PREF = ["", "re", "un", "pre", "de", "non", "mis", "dis", "over", "under", "inter", "multi", "micro", "macro", "anti", "counter",
+        "super", "trans", "hyper", "pseudo", "meta", "cross", "auto", "self", "semi", "sub", "post", "co", "out", "up"]
+WIDTH = 24
+N_WORDS = 4096
 
 
 def main():
-    seen, words = set(), []
+    seen, head = set(), []
     for w in COMMON:
-        if w not in seen and w.isalpha() and len(w) <= 11:
-            seen.add(w); words.append(w)
-    i = 0
-    while len(words) < 1024:
-        w = (STEMS[i % len(STEMS)] + SUFF[(i // len(STEMS)) % len(SUFF)])[:11]
-        i += 1
-        if w not in seen:
-            seen.add(w); words.append(w)
-    words = words[:1024]
-    out = ["/* GENERATED by tools/gen_corpus_words.py -- 1024 words, 12 bytes each, NUL padded */\n"]
-    for j in range(0, 1024, 4):
-        out.append(" ".join('"%s"' % (w + "\\0" * (12 - len(w))) for w in words[j:j + 4]) + "\n")
+        if w not in seen and w.isalpha() and len(w) < WIDTH:
+            seen.add(w); head.append(w)
+    # the tail: every prefix + stem + suffix, deterministically thinned, shortest first (rank grows with length, as in text)
+    tail = []
+    k = 0
+    for pi, p in enumerate(PREF):
+        for si, s in enumerate(STEMS):
+            for ui, u in enumerate(SUFF):
+                k += 1
+                if (pi * 7 + si * 13 + ui * 29 + (k * 2654435761 >> 7)) % 11 >= 4:      # keep ~4 of 11 combinations
+                    continue
+                stem = s
+                if u and u[0] in "aei" and stem.endswith("e"):
+                    stem = stem[:-1]
+                w = p + stem + u
+                if w not in seen and len(w) < WIDTH and w.isalpha():
+                    seen.add(w); tail.append(w)
+    tail.sort(key=lambda w: (len(w), w))
+    need = N_WORDS - len(head)
+    # quotas by length class, so that the table's tail looks like a real lexicon's: mostly 5..12 letters, some 13..16, and
+    # ~4 % of the table longer than 16 bytes -- all of those in the last Zipf octave (the rarest ranks)
+    short = [w for w in tail if len(w) <= 12]
+    mid = [w for w in tail if 13 <= len(w) <= 16]
+    long_ = [w for w in tail if len(w) > 16]
+    n_long, n_mid = 160, 640
+    n_short = need - n_long - n_mid
+    assert len(short) >= n_short and len(mid) >= n_mid and len(long_) >= n_long, (len(short), len(mid), len(long_))
+
+    def spread(lst, n):
+        step = len(lst) / float(n)
+        return [lst[int(i * step)] for i in range(n)]
+    picked = spread(short, n_short) + spread(mid, n_mid) + spread(long_, n_long)
+    words = head + picked
+    assert len(words) == N_WORDS and len(set(words)) == N_WORDS
+    out = ["/* GENERATED by tools/gen_corpus_words.py -- %d words, %d bytes each, NUL padded */\n" % (N_WORDS, WIDTH)]
+    for j in range(0, N_WORDS, 4):
+        out.append(" ".join('"%s"' % (w + "\\0" * (WIDTH - len(w))) for w in words[j:j + 4]) + "\n")
     open(sys.argv[1], "w").write("".join(out))
-    print(len(words), "words")
+    n_long = sum(len(w) > 16 for w in words)
+    print(len(words), "words; longer than 16 bytes:", n_long, "; longest:", max(words, key=len), "; mean length %.2f" % (sum(map(len, words)) / len(words)))
 
 
 if __name__ == "__main__":
