@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- input MB/s of the batch BPE encode path on MI355X (BASELINE.json's metric).
 
-One "step" = one pass of the whole hot path (document marks, pre-tokenizer, piece lookup + byte-pair
-merge, compaction, per-document offsets; plus, at N > 1, the all-gather of the per-rank counts) over
-one batch of synthetic documents that is already resident in HBM.
+One "step" = one pass of the whole hot path (document marks, pre-tokenizer, piece lookup + byte-pair merge, compaction,
+per-document offsets, and the all-gather of the per-rank counts on the C ABI's RCCL communicator) over one batch of synthetic
+documents that is already resident in HBM.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): BASELINE.json configs[1] -- cl100k_base split pattern, 10 M synthetic ASCII
-documents of 256..768 bytes (mean 512) per GPU, generated on the device by the counter-based generator
-of tokenizer_amd/csrc/tkz_corpus.h (seed 0x5EED0002).  The cl100k_base rank file is downloaded by the
-reference at run time and is not available offline: unless $TKZ_VOCAB_DIR/cl100k_base.tiktoken exists the
-run uses the gpt2 rank file (the one vocabulary the reference ships) with the cl100k pattern and says so
-(config.vocab = "gpt2 (VOCAB-SUBSTITUTED)").
+With N > 1 and no WORLD_SIZE in the environment the script re-launches itself under torch.distributed.run (one process per
+GPU, rendezvous on 127.0.0.1); launched by the driver under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM bandwidth using the
-algorithmic bytes of SURVEY.md 8(d); `cpu_baseline` times the reference-algorithm CPU restatement
-(oracle/, "port") on a bounded sample of the same documents and is also the parity check of the run.
+Workload (config.workload): BASELINE.json configs[1] -- cl100k_base split pattern, 10 M synthetic ASCII documents of 256..768
+bytes (mean 512) per GPU, generated on the device by the counter-based generator of tokenizer_amd/csrc/tkz_corpus.h (seed
+0x5EED0002; 4096-word Zipf table, identifiers, URLs, hex blobs, numbers, contractions).  The cl100k_base rank file is
+downloaded by the reference at run time and exists nowhere offline: unless $TKZ_VOCAB_DIR/cl100k_base.tiktoken is supplied the
+run uses tests/golden/synth100k.tiktoken.gz, a trained stand-in of cl100k_base's size (100,256 keys, tools/train_bpe.py), and
+says so in config.vocab.
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM bandwidth with the algorithmic bytes of
+SURVEY.md 8(d); `cpu_baseline` times the reference-algorithm CPU restatement (oracle/, kind "port") on a bounded sample of the
+same documents on ALL host cores and is also the parity check of the run.
 """
 import argparse
+import glob
 import gzip
+import hashlib
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,14 +38,61 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
+VOCAB_OF_PATTERN = {1: ("gpt2", None), 2: ("synth100k", "cl100k_base"), 3: ("synth200k", "o200k_base")}
 
 
-def load_vocab_bytes():
+def load_vocab_bytes(pattern, want=None):
+    """(bytes, label).  The real rank file from $TKZ_VOCAB_DIR when present; otherwise the stand-in of the same size."""
+    stand_in, real = VOCAB_OF_PATTERN[pattern]
+    if want:
+        stand_in, real = want, None
     d = os.environ.get("TKZ_VOCAB_DIR")
-    if d and os.path.exists(os.path.join(d, "cl100k_base.tiktoken")):
-        return open(os.path.join(d, "cl100k_base.tiktoken"), "rb").read(), "cl100k_base"
-    raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "gpt2.tiktoken.gz"), "rb").read())
-    return raw, "gpt2 (VOCAB-SUBSTITUTED: cl100k_base.tiktoken is not available offline)"
+    if real and d and os.path.exists(os.path.join(d, real + ".tiktoken")):
+        return open(os.path.join(d, real + ".tiktoken"), "rb").read(), real
+    raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", stand_in + ".tiktoken.gz"), "rb").read())
+    if stand_in == "gpt2":
+        return raw, "gpt2" + ("" if pattern == 1 else " (VOCAB-SUBSTITUTED)")
+    return raw, "%s (VOCAB-SUBSTITUTED: trained stand-in with the key count of %s, which is not available offline)" % (stand_in, real or "the named vocabulary")
+
+
+def kernel_sources_sha():
+    """Identity of the kernels a PMC traffic figure was collected on: sha256 over tokenizer_amd/csrc (there is no .git on the GPU box)."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "tokenizer_amd", "csrc", "*"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def relaunch_under_torchrun(n):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def reference_dotnet_baseline(sample_path):
+    """when a .NET SDK and a checkout of the reference are present on this host, time the REAL TokenizerLib
+    through tools/dotnet_baseline (a console driver).  Neither exists in this image; the probe is the hook."""
+    ref = os.environ.get("TKZ_REFERENCE_DIR")
+    if not shutil.which("dotnet") or not ref or not os.path.isdir(os.path.join(ref, "Tokenizer_C#", "TokenizerLib")):
+        return None
+    try:
+        proj = os.path.join(ROOT, "tools", "dotnet_baseline")
+        out = subprocess.run(["dotnet", "run", "-c", "Release", "--project", proj, "--", sample_path], capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, TKZ_REFERENCE_DIR=ref))
+        for line in out.stdout.splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": (out.stderr or out.stdout)[-400:]}
+    except Exception as ex:
+        return {"error": "%s: %s" % (type(ex).__name__, ex)}
 
 
 def main():
@@ -47,13 +101,19 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--docs", type=int, default=10_000_000, help="documents per GPU")
-    ap.add_argument("--kind", type=int, default=1, help="corpus kind: 1 ASCII (config 2), 2 mixed UTF-8 (config 3), 3 long-context (config 5)")
+    ap.add_argument("--kind", type=int, default=1, help="corpus: 1 ASCII (config 2), 2 mixed UTF-8 (config 3), 3 long-context (config 5), "
+                                                        "4 the reference's test text lib.rs.txt tiled (real source code)")
     ap.add_argument("--min-len", type=int, default=256)
     ap.add_argument("--max-len", type=int, default=768)
     ap.add_argument("--pattern", type=int, default=2, help="1 pattern-1, 2 cl100k, 3 o200k")
+    ap.add_argument("--vocab", default=None, help="gpt2 | synth100k | synth200k (default: the stand-in of the pattern's vocabulary)")
     ap.add_argument("--cpu-sample-docs", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--write-shards", default=None, metavar="DIR", help="after the timed loop every rank writes its token shard file (SURVEY 8f-2)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)
 
     import numpy as np
     import torch
@@ -66,7 +126,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)" % (args.gpus, world), file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if torch.cuda.device_count() <= local_rank:
+        print("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()), file=sys.stderr)
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -74,28 +137,60 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    raw, vocab_name = load_vocab_bytes()
+    raw, vocab_name = load_vocab_bytes(args.pattern, args.vocab)
     vocab = N.Vocab(raw)
     enc = N.Encoder(vocab, args.pattern, device=local_rank)
 
+    # ---- the count exchange: the C ABI's own RCCL communicator (also at N = 1: RCCL is initialised and used on every run) ----
+    def exchange(idbytes):
+        if world == 1:
+            return idbytes
+        box = [idbytes]
+        dist.broadcast_object_list(box, src=0, device=dev)
+        return box[0]
+    comm, comm_info = None, None
+    try:
+        comm = sharded.RcclCounts(rank, world, local_rank, exchange)
+        comm_info = comm.info()
+    except Exception as ex:
+        if world > 1:
+            raise
+        comm_info = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
     # ---- synthetic corpus, generated on the device; rank r owns documents [r*docs, (r+1)*docs) ----
-    seed = 0x5EED0000 + {1: 2, 2: 3, 3: 5}[args.kind]
     n_docs = args.docs
     first_doc = rank * n_docs
-    d_offs = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    total = N.corpus_generate_device(local_rank, args.kind, seed, first_doc, n_docs, args.min_len, args.max_len,
-                                     d_offs.data_ptr(), None, 0, stream)
-    d_bytes = torch.empty(total + 64, dtype=torch.uint8, device=dev)
-    N.corpus_generate_device(local_rank, args.kind, seed, first_doc, n_docs, args.min_len, args.max_len,
-                             d_offs.data_ptr(), d_bytes.data_ptr(), total, stream)
+    if args.kind == 4:
+        # the reference's own test input (Tokenizer_C#/TokenizerTest/testData/lib.rs.txt, real Rust source) tiled; document lengths
+        # drawn like the synthetic kinds.  A document is a slice of the tiled text, so pieces are cut at document edges as anywhere.
+        text = torch.from_numpy(np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "lib.rs.txt"), "rb").read(), np.uint8).copy()).to(dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(0x5EED0004 + first_doc)
+        lens = torch.randint(args.min_len, args.max_len + 1, (n_docs,), generator=g, device=dev, dtype=torch.int64)
+        d_offs = torch.zeros(n_docs + 1, dtype=torch.int64, device=dev)
+        d_offs[1:] = torch.cumsum(lens, 0)
+        total = int(d_offs[-1].item())
+        reps = (total + 64 + len(text) - 1) // len(text)
+        d_bytes = text.repeat(reps)[:total + 64].contiguous()
+        seed = None
+    else:
+        seed = 0x5EED0000 + {1: 2, 2: 3, 3: 5}[args.kind]
+        d_offs = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
+        total = N.corpus_generate_device(local_rank, args.kind, seed, first_doc, n_docs, args.min_len, args.max_len,
+                                         d_offs.data_ptr(), None, 0, stream)
+        d_bytes = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+        N.corpus_generate_device(local_rank, args.kind, seed, first_doc, n_docs, args.min_len, args.max_len,
+                                 d_offs.data_ptr(), d_bytes.data_ptr(), total, stream)
     d_ids = torch.empty(total, dtype=torch.int32, device=dev)          # tokens <= bytes: always enough
     d_ooffs = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
 
     def step():
         ntok = enc.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total,
                                        d_ooffs.data_ptr(), stream)
-        return sharded.gather_counts(n_docs, total, ntok, device=dev)
+        if comm is not None:
+            comm.gather_async(enc, stream)      # ncclAllGather of {docs, bytes, tokens}, enqueued on the encode stream; the table stays in HBM
+        return ntok
 
     def fence():
         if world > 1:
@@ -103,13 +198,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        g = step()
+        ntok = step()
     enc.set_profiling(True)
     enc.kernel_ms(reset=True)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        g = step()
+        ntok = step()
     fence()
     dt = time.perf_counter() - t0
     enc.set_profiling(False)
@@ -118,7 +213,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kms = enc.kernel_ms()
+    g = comm.result() if comm is not None else sharded.gather_counts(n_docs, total, ntok)
     n_tokens_rank = int(g["table"][rank][2])
+    assert n_tokens_rank == ntok and int(g["table"][rank][0]) == n_docs and int(g["table"][rank][1]) == total
+
+    shard_note = None
+    if args.write_shards:
+        os.makedirs(args.write_shards, exist_ok=True)
+        path = os.path.join(args.write_shards, "tokens.%05d.tkzs" % rank)
+        ts = time.perf_counter()
+        N.shard_write_device(path, d_ids.data_ptr(), ntok, d_ooffs.data_ptr(), n_docs, g["doc_base"], g["token_base"], device=local_rank)
+        shard_note = {"file": path, "bytes": os.path.getsize(path), "seconds": round(time.perf_counter() - ts, 3)}
 
     if rank == 0:
         job_bytes, job_tokens, job_docs = g["bytes"], g["tokens"], g["docs"]
@@ -129,19 +234,24 @@ def main():
         dom_ms = kms[dom][0] / max(1, kms[dom][1])
         alg_bytes = total + 4 * n_tokens_rank + 16 * n_docs      # read text + write int32 ids + 8 B offset in + 8 B offset out
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_note = None, "no PMC summary for this build"
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("docs_per_gpu") == n_docs and tj.get("kind") == args.kind:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                if tj.get("src_sha") != kernel_sources_sha():
+                    traffic_note = "profiles/traffic_latest.json was collected on other kernel sources (src_sha differs): not reported"
+                elif tj.get("docs_per_gpu") != n_docs or tj.get("kind") != args.kind or tj.get("kernel") != dom:
+                    traffic_note = "profiles/traffic_latest.json is for another workload / kernel: not reported"
+                else:
+                    traffic, traffic_note = tj.get("hbm_bytes_per_launch"), "rocprofv3 PMC passes of this build (profiles/traffic_latest.json)"
             except Exception:
                 traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
-                    "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kms.items()}}
+                    "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kms.items()},
+                    "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
         # ---- CPU baseline (the oracle = reference-algorithm restatement, "port") + parity on the sample ----
         cpu = None
         host_path = None
@@ -156,7 +266,7 @@ def main():
                 h_ooffs = d_ooffs[:ns + 1].cpu().numpy()
                 h_ids = d_ids[:int(h_ooffs[-1])].cpu().numpy()
                 ov = O.Vocab(raw)
-                threads = max(1, min(os.cpu_count() or 1, 64))
+                threads = max(1, os.cpu_count() or 1)          # ALL host cores
                 tm = {}
                 o_ids, o_counts = O.encode_batch(ov, args.pattern, h_bytes, h_offs, threads=threads, timing=tm)
                 tcpu = tm["seconds"]
@@ -173,11 +283,20 @@ def main():
                     and bool((d_ooffs[1:n_docs + 1] >= d_ooffs[:n_docs]).all().item())
                 parity_note = ("bit-exact vs oracle on the first %d and the last %d docs (%d tokens); offsets of all %d docs monotone, ending at the token count"
                                % (ns, nt, len(o_ids) + len(p_ids), n_docs)) if same else "MISMATCH vs oracle on the sample"
-                # one thread, on a tenth of the sample (SURVEY.md 8d asks for both figures)
-                n1 = max(1, ns // 20)
+                # one thread, on a fifth of the sample (SURVEY.md 8d asks for both figures)
+                n1 = max(1, ns // 5)
                 O.encode_batch(ov, args.pattern, h_bytes[:int(h_offs[n1])], h_offs[:n1 + 1], threads=1, timing=tm)
                 t1 = tm["seconds"]
                 cpu_1t = round(int(h_offs[n1]) / t1 / 1e6, 2)
+                cpu = {"value": round(nb / tcpu / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port", "value_1_thread": cpu_1t,
+                       "sample": "first %d documents (%.1f MB) of the same corpus on all %d host cores (one thread: the first %d documents), "
+                                 "reference-algorithm CPU restatement (oracle/), 8192-entry LRU memo per thread" % (ns, nb / 1e6, threads, n1)}
+                # the real C# TokenizerLib beside it, when this host has a .NET SDK and a reference checkout (never in this image)
+                if shutil.which("dotnet") and os.environ.get("TKZ_REFERENCE_DIR"):
+                    sp = "/tmp/tkz_bench_sample.bin"
+                    with open(sp, "wb") as f:
+                        f.write(np.int64(ns).tobytes()); f.write(h_offs.tobytes()); f.write(h_bytes.tobytes())
+                    cpu["reference_dotnet"] = reference_dotnet_baseline(sp)
                 # PCIe-inclusive rate through the host-buffer entry point (tkz_encode_batch_utf8: H2D of the text, the kernels,
                 # D2H of ids + offsets), on ordinary (pageable) numpy buffers and on page-locked ones.  Output buffers are
                 # allocated and touched beforehand: a fresh np.empty would add its first-touch page faults to the figure.
@@ -189,6 +308,7 @@ def main():
                     o_ids_buf = np.zeros(len(hh_bytes), np.int32)
                     o_off_buf = np.zeros(nh + 1, np.int64)
                     rates = []
+                    host_same = True
                     for pinned in (False, True):
                         if pinned:
                             tb = torch.empty(len(hh_bytes), dtype=torch.uint8).pin_memory(); tb.numpy()[:] = hh_bytes
@@ -202,34 +322,38 @@ def main():
                         tc = time.perf_counter()
                         r_ids, r_ooffs = enc.encode_batch(bufs[0], bufs[1], out=bufs[2])
                         rates.append(round(len(hh_bytes) / (time.perf_counter() - tc) / 1e6, 1))
-                        host_same = (pinned is False or host_same) and int(r_ooffs[-1]) == int(d_ooffs[nh].item()) \
-                            and np.array_equal(r_ids[:len(h_ids)], h_ids[:len(r_ids)])
+                        host_same = host_same and int(r_ooffs[-1]) == int(d_ooffs[nh].item()) and np.array_equal(r_ids[:len(h_ids)], h_ids[:len(r_ids)])
                     host_path = {"value": rates[0], "value_pinned_buffers": rates[1], "unit": "MB/s", "docs": nh, "same_ids_as_device_path": bool(host_same),
-                                 "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text + kernels + D2H of ids and offsets, one after the other"}
+                                 "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text, kernels and D2H of ids and offsets, chunked and overlapped on two streams"}
                 except Exception as ex:                      # an auxiliary figure must never cost the bench line
                     host_path = {"error": "%s: %s" % (type(ex).__name__, ex)}
-                cpu = {"value": round(nb / tcpu / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port", "value_1_thread": cpu_1t,
-                       "sample": "first %d documents (%.1f MB) of the same corpus, reference-algorithm CPU restatement (oracle/), "
-                                 "8192-entry LRU memo per thread, %d threads of %d host cores" % (ns, nb / 1e6, threads, os.cpu_count() or 1)}
             except Exception as ex:                          # (e.g. no C compiler for the oracle on this host)
                 parity_note = "unchecked: CPU oracle unavailable (%s: %s)" % (type(ex).__name__, ex)
+        workloads = {1: "BASELINE.json configs[1]: cl100k_base pattern, %d synthetic ASCII docs/GPU, %d..%d B (mean %.0f), device-resident",
+                     2: "BASELINE.json configs[2] shape: mixed UTF-8 (CJK + emoji) corpus, %d docs/GPU, %d..%d B (mean %.0f), device-resident",
+                     3: "BASELINE.json configs[4] shape: long-context docs with long single-class runs, %d docs/GPU, %d..%d B (mean %.0f), device-resident",
+                     4: "real source text: the reference's lib.rs.txt tiled, %d docs/GPU, %d..%d B (mean %.0f), device-resident"}
         line = {
             "metric": "input MB/s encoded (cl100k_base)", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: cl100k_base pattern, %d synthetic ASCII docs/GPU, %d..%d B (mean %.0f), device-resident"
-                                   % (n_docs, args.min_len, args.max_len, job_bytes / max(1, job_docs)) if args.kind == 1 and args.pattern == 2 else
-                                   "kind %d corpus, pattern %d, %d docs/GPU, %d..%d B" % (args.kind, args.pattern, n_docs, args.min_len, args.max_len),
-                       "vocab": vocab_name, "docs_per_gpu": n_docs, "bytes_per_gpu": total, "tokens_per_gpu": n_tokens_rank,
+            "config": {"workload": workloads[args.kind] % (n_docs, args.min_len, args.max_len, job_bytes / max(1, job_docs)),
+                       "pattern": {1: "pattern 1 (gpt2 / r50k / p50k)", 2: "cl100k_base", 3: "o200k_base"}[args.pattern],
+                       "vocab": vocab_name, "vocab_keys": len(vocab), "docs_per_gpu": n_docs, "bytes_per_gpu": total, "tokens_per_gpu": n_tokens_rank,
                        "job_docs": job_docs, "job_bytes": job_bytes, "job_tokens": job_tokens,
-                       "partitioning": "contiguous document ranges, one process per GPU; all-gather of 3 int64 counts per rank"},
+                       "partitioning": "contiguous document ranges, one process per GPU; one all-gather of 3 int64 counts per rank per step"},
+            "comm": comm_info,
             "tokens_per_s": round(job_tokens * args.steps / dt, 1),
             "parity": parity_note,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "pcie_inclusive": host_path,
         }
+        if shard_note:
+            line["shard_file"] = shard_note
         print(json.dumps(line))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -40,7 +40,8 @@ typedef enum tkz_status {
     TKZ_E_ARG = -6,
     TKZ_E_UNSUPPORTED = -7,   /* pattern string that is not one of the three the reference defines; rank outside [0, 2^27) */
     TKZ_E_DEVICE = -8,        /* HIP runtime error */
-    TKZ_E_NO_DEVICE = -9      /* no HIP device / HIP runtime unusable: there is NO CPU fallback */
+    TKZ_E_NO_DEVICE = -9,     /* no HIP device / HIP runtime unusable: there is NO CPU fallback */
+    TKZ_E_OUT_OF_MEMORY = -10 /* device memory for the workspace could not be allocated (OutOfMemoryException) */
 } tkz_status;
 
 /* The three split regexes the reference defines.  A pattern is an enum, not a regex string:
@@ -124,12 +125,69 @@ tkz_status tkz_encode_utf16(tkz_encoder* e, const uint16_t* text, int64_t len, i
  * out_ids[piece_token_offsets[k] .. piece_token_offsets[k+1]); the pieces of document d are
  * [doc_piece_offsets[d], doc_piece_offsets[d+1]).  piece_cap is the capacity of the two piece arrays
  * minus one (piece_cap >= total bytes is always enough); TKZ_E_CAPACITY with *n_pieces / *needed_ids
- * holding the required sizes otherwise.  Host buffers. */
+ * holding the required sizes otherwise.  Host buffers.  One launch sequence: the piece offsets are built on the device from
+ * the piece-start bitmap and the encode kernels mark the token position of every piece start. */
 tkz_status tkz_encode_batch_pieces_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets,
                                         int64_t n_docs, int32_t* out_ids, int64_t out_cap,
                                         int64_t* doc_piece_offsets, int64_t* piece_byte_offsets,
                                         int64_t* piece_token_offsets, int64_t piece_cap,
                                         int64_t* n_pieces, int64_t* needed_ids);
+
+/* ---- Decode (TikTokenizer.cs:586-604) for a batch ---------------------------------------------
+ * Document d of the result is the concatenation of the byte strings of ids[id_offsets[d] .. id_offsets[d+1]): a vocabulary id
+ * yields its key, a registered special token its UTF-8 literal, any other id nothing (the reference drops unknown ids silently,
+ * :591-599).  The bytes are what the reference hands to Encoding.UTF8.GetString; the string conversion is the host's.
+ * tkz_encoder_set_special_tokens registers SpecialTokensDecoder (TikTokenizer.cs:79): literal i = literals_utf8[literal_offsets[i]
+ * .. literal_offsets[i+1]) for id ids[i] (a vocabulary id is never shadowed, :591-598).  out_cap too small: TKZ_E_CAPACITY and
+ * the required byte count in *total_bytes / *needed. */
+tkz_status tkz_encoder_set_special_tokens(tkz_encoder* e, const int32_t* ids, const uint8_t* literals_utf8, const int64_t* literal_offsets, int32_t n);
+tkz_status tkz_decode_batch_device(tkz_encoder* e, const int32_t* d_ids, const int64_t* d_id_offsets, int64_t n_docs, int64_t total_ids,
+                                   uint8_t* d_out_bytes, int64_t out_cap, int64_t* d_out_offsets, void* hip_stream, int64_t* total_bytes);
+tkz_status tkz_decode_batch(tkz_encoder* e, const int32_t* ids, const int64_t* id_offsets, int64_t n_docs, uint8_t* out_bytes, int64_t out_cap,
+                            int64_t* out_offsets, int64_t* needed);
+
+/* ---- token shard files -------------------------------------------------------
+ * The on-disk form of one rank's EncodeBatch result: a 64-byte header ("TKZSHRD1", version, n_docs, n_tokens, doc_base,
+ * token_base), then offsets int64[n_docs + 1] (relative to the shard), then ids int32[n_tokens]; little-endian.  The
+ * reference has no batch or file format (it returns List<int>), so there is nothing to be compatible with.  doc_base /
+ * token_base are this rank's bases from tkz_shard_bases: the files of all ranks concatenate into the global result.
+ * The device form streams straight from HBM through page-locked chunks (copy of chunk k+1 overlaps the write of chunk k). */
+tkz_status tkz_shard_write(const char* path, const int32_t* ids, int64_t n_tokens, const int64_t* offsets, int64_t n_docs,
+                           int64_t doc_base, int64_t token_base);
+tkz_status tkz_shard_write_device(const char* path, int32_t device, const int32_t* d_ids, int64_t n_tokens, const int64_t* d_offsets,
+                                  int64_t n_docs, int64_t doc_base, int64_t token_base);
+tkz_status tkz_shard_read_header(const char* path, int64_t* n_docs, int64_t* n_tokens, int64_t* doc_base, int64_t* token_base);
+
+/* ---- multi-GPU ------------------------------------------------------------------------------
+ * The reference is single-process; the batch path shards by CONTIGUOUS DOCUMENT RANGES, one process per GPU,
+ * vocabulary tables replicated, token ids never leave the GPU that produced them.  The only exchange is ONE all-gather of
+ * {n_docs, n_bytes, n_tokens} (3 x int64 per rank) per batch, issued directly on RCCL (ncclAllGather over xGMI) -- no torch,
+ * no Python needed in the host.  RCCL is bound at run time (dlopen of librccl.so.1): without it tkz_comm_unique_id /
+ * tkz_comm_create fail with TKZ_E_UNSUPPORTED, everything else works.
+ *
+ *   rank 0:      tkz_comm_unique_id(id)        -> distribute the 128 bytes to the other ranks by any means (file, socket, env)
+ *   every rank:  tkz_comm_create(id, rank, world, device, &comm)            (ncclCommInitRank; collective)
+ *   per batch:   tkz_shard_range(n_docs_total, rank, world, &lo, &hi); encode documents [lo, hi) on this rank's encoder;
+ *                tkz_comm_allgather_counts_device(comm, tkz_encoder_counts_device(enc), d_table, stream)   (asynchronous)
+ *             or tkz_comm_allgather_counts(comm, n_docs, n_bytes, n_tokens, table)                          (host, blocking)
+ *                tkz_shard_bases(table, world, rank, bases, totals): global index of this shard's first document / byte / token */
+typedef struct tkz_comm tkz_comm;
+enum { TKZ_COMM_ID_BYTES = 128 };
+tkz_status tkz_comm_unique_id(uint8_t* id128);
+tkz_status tkz_comm_create(const uint8_t* id128, int32_t rank, int32_t world, int32_t device, tkz_comm** out);
+void tkz_comm_destroy(tkz_comm* c);
+int32_t tkz_comm_world(const tkz_comm* c);     /* as reported by the communicator (ncclCommCount) */
+int32_t tkz_comm_rank(const tkz_comm* c);
+const char* tkz_comm_backend(const tkz_comm* c);   /* "rccl <major>.<minor>.<patch>" */
+/* d_mine: 3 int64 on the device; d_table: world * 3 int64 on the device (row r = rank r's counts); enqueued on hip_stream */
+tkz_status tkz_comm_allgather_counts_device(tkz_comm* c, const int64_t* d_mine, int64_t* d_table, void* hip_stream);
+tkz_status tkz_comm_allgather_counts(tkz_comm* c, int64_t n_docs, int64_t n_bytes, int64_t n_tokens, int64_t* table);
+/* {n_docs, n_bytes, n_tokens} of the encoder's last batch, resident on its device (valid once that batch's stream work is done) */
+const int64_t* tkz_encoder_counts_device(const tkz_encoder* e);
+/* documents [*lo, *hi) of a job of n_docs_total belong to `rank` */
+void tkz_shard_range(int64_t n_docs_total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi);
+/* from a gathered table: bases3 = {doc, byte, token} index of this rank's first unit, totals3 = the job totals */
+tkz_status tkz_shard_bases(const int64_t* table, int32_t world, int32_t rank, int64_t* bases3, int64_t* totals3);
 
 /* ---- stage-level entry points (used by the parity tests; same kernels as the hot path) --- */
 
@@ -150,8 +208,8 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
 
 /* ---- measurement ------------------------------------------------------------------------- */
 
-enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_ENCODE = 2, TKZ_K_SCAN = 3, TKZ_K_GATHER = 4,
-       TKZ_K_DOCOFFS = 5, TKZ_K_COUNT = 6 };
+enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_ENCODE = 2 /* k_encode_waves alone */, TKZ_K_SCAN = 3, TKZ_K_GATHER = 4,
+       TKZ_K_DOCOFFS = 5, TKZ_K_HEAVY = 6 /* k_giant_find + k_giant_merge + k_encode_waves_heavy */, TKZ_K_COUNT = 7 };
 /* When enabled, every kernel launch of tkz_encode_batch_device is bracketed by HIP events on the
  * launch stream; tkz_encoder_kernel_ms returns the accumulated milliseconds and launch counts per
  * kernel since the last reset (arrays of TKZ_K_COUNT). */

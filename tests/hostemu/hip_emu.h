@@ -41,6 +41,9 @@ hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hip
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
 hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipStreamSynchronize(hipStream_t st);
+hipError_t hipStreamCreate(hipStream_t* st);
+hipError_t hipStreamDestroy(hipStream_t st);
+hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned flags = 0);
 hipError_t hipDeviceSynchronize();
 hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t e);

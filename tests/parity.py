@@ -336,3 +336,68 @@ def check_random_vocab(lib, O, seed, n_vocabs, lens, n_pieces):
             x = [r] if r >= 0 else ovocab.bpe(p)
             g = ids[ooff[i]:ooff[i + 1]].tolist()
             assert g == x, "vocab %d piece %d (len %d) %r: got %r expected %r" % (vi, i, len(p), p[:60], g[:16], x[:16])
+
+
+def check_decode(lib, O, vocab, ovocab, raw_vocab=None, seed=5, rounds=6):
+    """Batch Decode on the device (TikTokenizer.cs:586-604) vs the vocabulary's own keys: decode(encode(x)) == x for every
+    document (the round trip every reference test asserts, TikTokenizerUnitTest.cs:47-48), unknown ids dropped, special
+    tokens decoded from their literals, capacity and offset errors."""
+    alpha = RC.alphabet()
+    rng = random.Random(seed)
+    enc = N.Encoder(vocab, N.CL100K)
+    ents = ovocab.entries()
+    key_of = {r: k for k, r in ents}
+    max_id = max(key_of)
+    for it in range(rounds):
+        docs = [gen_text(rng, rng.choice(["mix", "a_mix", "oth", "ws"]), rng.choice([0, 1, 9, 200, 3000]), alpha).encode("utf-8") for _ in range(rng.choice([1, 5, 60]))]
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        out, boffs = enc.decode_batch(ids, ooff)
+        assert out.tobytes() == data.tobytes() and boffs.tolist() == offs.tolist(), "round %d" % it
+    # ids in no table contribute nothing; specials decode to their literal; a vocabulary id is never shadowed by a special
+    known = sorted(key_of)
+    a, b, c = known[5], known[0], known[17]
+    enc.set_special_tokens({"<|endoftext|>": max_id + 1, "<|x|>": max_id + 20, "shadow": a})
+    seq = [a, max_id + 1, max_id + 7, -3, b, max_id + 20, 2**31 - 1, c]
+    exp = key_of[a] + b"<|endoftext|>" + key_of[b] + b"<|x|>" + key_of[c]
+    out, boffs = enc.decode_batch(np.asarray(seq, np.int32), np.array([0, 3, 3, len(seq)]))
+    assert out.tobytes() == exp and boffs.tolist() == [0, len(key_of[a]) + 13, len(key_of[a]) + 13, len(exp)]
+    out, boffs = enc.decode_batch(np.zeros(0, np.int32), np.array([0, 0, 0]))
+    assert len(out) == 0 and boffs.tolist() == [0, 0, 0]
+    # a long tile: 1024 ids of the longest key exceed the LDS stage of k_dec_write (direct copies)
+    longest = max(ents, key=lambda e: len(e[0]))
+    many = np.full(2500, longest[1], np.int32)
+    out, boffs = enc.decode_batch(many, np.array([0, 1000, 2500]))
+    assert out.tobytes() == longest[0] * 2500 and boffs.tolist() == [0, 1000 * len(longest[0]), 2500 * len(longest[0])]
+    with pytest.raises(N.TkzError) as ei:
+        enc.decode_batch(np.asarray([1, 2, 3], np.int32), np.array([0, 2, 1, 3]))
+    assert ei.value.code == N.E_ARG
+    with pytest.raises(N.TkzError) as ei:
+        enc.decode_batch(many, np.array([0, 2500]), out_cap=10)
+    assert ei.value.code == N.E_CAPACITY
+
+
+def check_piece_granular(lib, O, vocab, ovocab, pattern, seed=3, rounds=6):
+    """tkz_encode_batch_pieces_utf8 (piece offsets built on the device from the bitmap, token marks per piece) vs the oracle's
+    split + per-piece encode: the pieces of every document, their byte spans and their token ranges."""
+    alpha = RC.alphabet()
+    rng = random.Random(seed + pattern)
+    enc = N.Encoder(vocab, pattern)
+    for it in range(rounds):
+        docs = [gen_text(rng, rng.choice(["mix", "a_mix", "a_ws", "oth", "a_dig"]), rng.choice([0, 0, 1, 30, 700, 5000]), alpha).encode("utf-8")
+                for _ in range(rng.choice([1, 4, 50]))]
+        data, offs = pack(docs)
+        ids, dpo, pbo, pto = enc.encode_batch_pieces(data, offs)
+        e_dpo, e_pbo, e_pto, e_ids = [0], [], [0], []
+        pos = 0
+        for d in docs:
+            for (a, n) in O.split_utf8(pattern, d):
+                p = d[a:a + n]
+                r = ovocab.rank(p)
+                e_ids += [r] if r >= 0 else ovocab.bpe(p)
+                e_pbo.append(pos + a)
+                e_pto.append(len(e_ids))
+            e_dpo.append(len(e_pbo))
+            pos += len(d)
+        e_pbo.append(pos)
+        assert dpo.tolist() == e_dpo and pbo.tolist() == e_pbo and pto.tolist() == e_pto and ids.tolist() == e_ids, "pattern %d round %d" % (pattern, it)

@@ -94,6 +94,44 @@ def test_batch_vs_oracle(lib, vocabs, oracle_mod, pattern, vname):
                        doc_lens=[0, 1, 10, 100, 1000, 6000], n_docs_choices=[1, 4, 40], kinds=("mix", "ws", "oth"))
 
 
+@pytest.mark.parametrize("vname", ["gpt2", "synth100k"])
+def test_decode_round_trip(lib, vocabs, oracle_mod, vname):
+    v, ov = vocabs(vname)
+    parity.check_decode(lib, oracle_mod, v, ov, rounds=3)
+
+
+def test_decode_sparse_rank_table(lib, oracle_mod):
+    # ranks up to ~2^26: the decoder table takes its sorted (binary-search) form
+    import random
+    raw = parity.random_vocab_bytes(random.Random(4), alphabet=b"abc", n_keys=200, rank_step=97_003, rank_base=4_200_000)
+    parity.check_decode(lib, oracle_mod, N.Vocab(raw, lib), oracle_mod.Vocab(raw), rounds=2)
+
+
+@pytest.mark.parametrize("pattern", [1, 2, 3])
+def test_piece_granular_batch(lib, vocab, oracle_mod, oracle_gpt2, pattern):
+    parity.check_piece_granular(lib, oracle_mod, vocab, oracle_gpt2, pattern, rounds=6)
+
+
+def test_shard_writer_c_abi(lib, tmp_path):
+    """tkz_shard_write / tkz_shard_write_device / tkz_shard_read_header against the memory-mapping reader."""
+    from tokenizer_amd import Shard
+    rng = np.random.default_rng(5)
+    n_docs = 3000
+    counts = rng.integers(0, 40, n_docs)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ids = rng.integers(0, 200_000, int(offs[-1])).astype(np.int32)
+    p = str(tmp_path / "h.tkzs")
+    N.shard_write(p, ids, offs, 77, 1234, lib=lib)
+    assert N.shard_read_header(p, lib=lib) == (n_docs, len(ids), 77, 1234)
+    sh = Shard(p)
+    assert np.array_equal(np.asarray(sh.ids), ids) and np.array_equal(np.asarray(sh.offsets), offs) and (sh.doc_base, sh.token_base) == (77, 1234)
+    with pytest.raises(N.TkzError):
+        N.shard_write(p, ids, offs[::-1].copy(), lib=lib)
+    p2 = str(tmp_path / "d.tkzs")      # (emulated device: device pointers are host pointers)
+    N.shard_write_device(p2, ids.ctypes.data, len(ids), offs.ctypes.data, n_docs, 77, 1234, device=0, lib=lib)
+    assert open(p2, "rb").read() == open(p, "rb").read()
+
+
 def test_errors_and_edges(lib, vocab, oracle_mod):
     parity.check_errors(lib, oracle_mod, vocab)
 

@@ -115,6 +115,46 @@ def test_batch_vs_oracle(lib, vocabs, oracle_mod, pattern, vname):
                        doc_lens=[0, 1, 10, 100, 1000, 6000, 30000], n_docs_choices=[1, 4, 40, 400], kinds=("mix", "ws", "oth", "dig", "apo", "case", "a_mix", "a_brk", "a_ws", "a_dig"))
 
 
+@pytest.mark.parametrize("vname", ["gpt2", "synth100k"])
+def test_decode_round_trip(lib, vocabs, oracle_mod, vname):
+    v, ov = vocabs(vname)
+    parity.check_decode(lib, oracle_mod, v, ov, rounds=10)
+
+
+def test_decode_sparse_rank_table(lib, oracle_mod):
+    # ranks up to ~2^26: the decoder table takes its sorted (binary-search) form
+    import random
+    raw = parity.random_vocab_bytes(random.Random(4), alphabet=b"abc", n_keys=200, rank_step=97_003, rank_base=4_200_000)
+    parity.check_decode(lib, oracle_mod, N.Vocab(raw, lib), oracle_mod.Vocab(raw), rounds=2)
+
+
+@pytest.mark.parametrize("pattern", [1, 2, 3])
+def test_piece_granular_batch(lib, vocab, oracle_mod, oracle_gpt2, pattern):
+    parity.check_piece_granular(lib, oracle_mod, vocab, oracle_gpt2, pattern, rounds=20)
+
+
+def test_shard_writer_c_abi(lib, tmp_path):
+    """tkz_shard_write / tkz_shard_write_device / tkz_shard_read_header against the memory-mapping reader."""
+    from tokenizer_amd import Shard
+    rng = np.random.default_rng(5)
+    n_docs = 3_000_000                                     # 24 MB of offsets + ~230 MB of ids: several 32 MiB chunks
+    counts = rng.integers(0, 40, n_docs)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    ids = rng.integers(0, 200_000, int(offs[-1])).astype(np.int32)
+    p = str(tmp_path / "h.tkzs")
+    N.shard_write(p, ids, offs, 77, 1234, lib=lib)
+    assert N.shard_read_header(p, lib=lib) == (n_docs, len(ids), 77, 1234)
+    sh = Shard(p)
+    assert np.array_equal(np.asarray(sh.ids), ids) and np.array_equal(np.asarray(sh.offsets), offs) and (sh.doc_base, sh.token_base) == (77, 1234)
+    with pytest.raises(N.TkzError):
+        N.shard_write(p, ids, offs[::-1].copy(), lib=lib)
+    import torch
+    d_ids, d_offs = torch.from_numpy(ids).cuda(), torch.from_numpy(offs).cuda()
+    p2 = str(tmp_path / "d.tkzs")
+    N.shard_write_device(p2, d_ids.data_ptr(), len(ids), d_offs.data_ptr(), n_docs, 77, 1234, device=0, lib=lib)
+    assert open(p2, "rb").read() == open(p, "rb").read()
+
+
 def test_errors_and_edges(lib, vocab, oracle_mod):
     parity.check_errors(lib, oracle_mod, vocab)
 
@@ -176,6 +216,14 @@ def test_device_corpus_properties_and_sample(lib, vocabs, oracle_mod, vname, kin
     csum = torch.zeros(r["ntok"] + 1, dtype=torch.int64, device=ooffs.device)
     csum[1:] = torch.cumsum(tl[ids], 0)
     assert bool(((csum[ooffs[1:]] - csum[ooffs[:-1]]) == doc_len).all())
+    # decode(encode(x)) == x for the WHOLE batch, on the device (TikTokenizer.Decode, TikTokenizer.cs:586-604; the round trip
+    # every reference test asserts, TikTokenizerUnitTest.cs:47-48): bytes and document offsets
+    d_back = torch.empty(r["total"] + 64, dtype=torch.uint8, device=ooffs.device)
+    d_boffs = torch.empty(n_docs + 1, dtype=torch.int64, device=ooffs.device)
+    nb = r["enc"].decode_batch_device(r["d_ids"].data_ptr(), ooffs.data_ptr(), n_docs, r["ntok"], d_back.data_ptr(), r["total"], d_boffs.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+    assert nb == r["total"] and torch.equal(d_back[:nb], r["d_bytes"][:nb]) and torch.equal(d_boffs, r["d_offs"])
+    del d_back, d_boffs
     # bit-exact vs the oracle on a sample of documents (first, last, and a stride through the middle)
     oenc = oracle_mod.Encoder(oracle_gpt2, pattern)
     h_offs = r["d_offs"].cpu().numpy()
@@ -187,6 +235,51 @@ def test_device_corpus_properties_and_sample(lib, vocabs, oracle_mod, vname, kin
         doc = h_bytes[h_offs[d]:h_offs[d + 1]].tobytes()
         assert doc == N.corpus_doc_host(kind, 0x5EED0000 + kind, d, lo, hi, lib=lib)       # generator: device == host
         assert h_ids[h_ooffs[d]:h_ooffs[d + 1]].tolist() == oenc.encode_bytes(doc), "doc %d" % d
+
+
+def test_rccl_communicator_counts(lib, vocab):
+    """The C ABI's direct-RCCL communicator (tkz_comm_*): RCCL is initialised through libtkz and the count all-gather runs both
+    asynchronously on the encode stream (table kept in HBM) and in its blocking host form.  world = 1 on a one-GPU box (RCCL
+    admits one rank per device); the N-rank arithmetic is covered by test_eight_shards_on_one_device."""
+    import torch
+    from tokenizer_amd import sharded
+    c = sharded.RcclCounts(0, 1, 0, lambda b: b, lib=lib)
+    info = c.info()
+    assert info["world_size"] == 1 and info["rank"] == 0 and info["backend"].startswith("rccl ")
+    r = _device_run(lib, vocab, 1, 2, 50_000, 256, 768, 0x5EED0002)
+    st = torch.cuda.current_stream().cuda_stream
+    c.gather_async(r["enc"], st)
+    g = c.result()
+    assert g["table"].tolist() == [[50_000, r["total"], r["ntok"]]] and (g["doc_base"], g["token_base"]) == (0, 0)
+    assert (g["docs"], g["bytes"], g["tokens"]) == (50_000, r["total"], r["ntok"])
+    g2 = c.gather(7, 8, 9)
+    assert g2["table"].tolist() == [[7, 8, 9]]
+    c.close()
+
+
+def test_eight_shards_on_one_device(lib, vocabs):
+    """BASELINE configs[3]'s partitioning with the 8 ranks faked on one device: rank r encodes documents tkz_shard_range(r) of the
+    job; the per-rank counts form the table the all-gather would deliver; tkz_shard_bases gives every rank its global bases; the
+    shards laid out at those bases reproduce the single-batch result exactly (ids and document offsets)."""
+    import torch
+    vocab, _ = vocabs("synth100k")
+    n, lo, hi, seed, world = 400_000, 256, 768, 0x5EED0002, 8
+    whole = _device_run(lib, vocab, 1, 2, n, lo, hi, seed)
+    parts, table = [], []
+    for r in range(world):
+        a, b = N.shard_range(n, r, world, lib=lib)
+        assert (a, b) == ((n * r) // world, (n * (r + 1)) // world)
+        p = _device_run(lib, vocab, 1, 2, b - a, lo, hi, seed, first_doc=a)
+        parts.append(p)
+        table.append([b - a, p["total"], p["ntok"]])
+    ids = torch.empty_like(whole["d_ids"])
+    ooffs = torch.empty_like(whole["d_ooffs"])
+    for r, p in enumerate(parts):
+        bases, totals = N.shard_bases(table, r, lib=lib)
+        assert totals == [n, whole["total"], whole["ntok"]]
+        ids[bases[2]:bases[2] + p["ntok"]] = p["d_ids"]
+        ooffs[bases[0]:bases[0] + table[r][0] + 1] = p["d_ooffs"] + bases[2]
+    assert torch.equal(ids, whole["d_ids"]) and torch.equal(ooffs, whole["d_ooffs"])
 
 
 def test_shard_invariance(lib, vocab):

@@ -26,12 +26,12 @@ def _worker(rank, world, port, q, outdir):
     raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "gpt2.tiktoken.gz"), "rb").read())
     enc = N.Encoder(N.Vocab(raw, lib), N.CL100K)
     n_total, lo_len, hi_len, seed = 301, 20, 300, 0x5EED0002
-    lo, hi = sharded.shard_range(n_total, rank, world)
+    lo, hi = sharded.shard_range(n_total, rank, world, lib=lib)
     docs = [N.corpus_doc_host(1, seed, d, lo_len, hi_len, lib=lib) for d in range(lo, hi)]
     data = np.frombuffer(b"".join(docs), np.uint8)
     offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.int64)
     ids, ooffs = enc.encode_batch(data, offs)
-    g = sharded.gather_counts(hi - lo, int(offs[-1]), len(ids))
+    g = sharded.gather_counts(hi - lo, int(offs[-1]), len(ids), lib=lib)
     write_shard(os.path.join(outdir, "tokens.%05d.tkzs" % rank), ids, ooffs, g["doc_base"], g["token_base"])
     q.put((rank, ids.tolist(), ooffs.tolist(), g["doc_base"], g["token_base"], g["docs"], g["bytes"], g["tokens"]))
     dist.barrier()

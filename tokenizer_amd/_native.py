@@ -10,10 +10,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "lib", "libtkz.so")
 
 OK = 0
-E_FORMAT, E_DUP_RANK, E_KEY_NOT_FOUND, E_CAPACITY, E_INVALID_UTF8, E_ARG, E_UNSUPPORTED, E_DEVICE, E_NO_DEVICE = range(-1, -10, -1)
+E_FORMAT, E_DUP_RANK, E_KEY_NOT_FOUND, E_CAPACITY, E_INVALID_UTF8, E_ARG, E_UNSUPPORTED, E_DEVICE, E_NO_DEVICE, E_OUT_OF_MEMORY = range(-1, -11, -1)
 P1, CL100K, O200K = 1, 2, 3
 OPT_PRETOK_SEQUENTIAL = 1
-K_NAMES = ["k_docmark", "k_pretok", "k_encode_waves", "k_scan", "k_gather", "k_docoffs"]
+K_NAMES = ["k_docmark", "k_pretok", "k_encode_waves", "k_scan", "k_gather", "k_docoffs", "k_encode_heavy_group"]
 
 
 class TkzError(Exception):
@@ -97,6 +97,29 @@ class Library:
         L.tkz_corpus_generate_device.argtypes = [i32, i32, C.c_uint64, i64, i64, i32, i32, vp, vp, i64, vp, pi64]
         L.tkz_corpus_generate_doc_host.argtypes = [i32, C.c_uint64, i64, i32, i32, vp, i64]
         L.tkz_corpus_generate_doc_host.restype = i64
+        L.tkz_shard_range.argtypes = [i64, i32, i32, pi64, pi64]
+        L.tkz_shard_range.restype = None
+        L.tkz_shard_bases.argtypes = [vp, i32, i32, vp, vp]
+        L.tkz_encoder_counts_device.argtypes = [vp]
+        L.tkz_encoder_counts_device.restype = vp
+        L.tkz_encoder_set_special_tokens.argtypes = [vp, vp, vp, vp, i32]
+        L.tkz_decode_batch_device.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, pi64]
+        L.tkz_decode_batch.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
+        L.tkz_shard_write.argtypes = [C.c_char_p, vp, i64, vp, i64, i64, i64]
+        L.tkz_shard_write_device.argtypes = [C.c_char_p, i32, vp, i64, vp, i64, i64, i64]
+        L.tkz_shard_read_header.argtypes = [C.c_char_p, pi64, pi64, pi64, pi64]
+        self.has_comm = hasattr(L, "tkz_comm_create")      # (the CPU emulator build of the tests has no communicator)
+        if self.has_comm:
+            L.tkz_comm_unique_id.argtypes = [vp]
+            L.tkz_comm_create.argtypes = [vp, i32, i32, i32, pv]
+            L.tkz_comm_destroy.argtypes = [vp]
+            L.tkz_comm_destroy.restype = None
+            L.tkz_comm_world.argtypes = [vp]
+            L.tkz_comm_rank.argtypes = [vp]
+            L.tkz_comm_backend.argtypes = [vp]
+            L.tkz_comm_backend.restype = C.c_char_p
+            L.tkz_comm_allgather_counts_device.argtypes = [vp, vp, vp, vp]
+            L.tkz_comm_allgather_counts.argtypes = [vp, i64, i64, i64, vp]
 
     def check(self, status):
         if status != OK:
@@ -270,12 +293,137 @@ class Encoder:
         self.lib.check(self.lib.L.tkz_encode_utf16(self._h, _ptr(u), n_units, _ptr(ids), 3 * n_units, C.byref(n)))
         return ids[:n.value].tolist()
 
+    # -- Decode --
+    def set_special_tokens(self, specials):
+        """specials: {literal str: id}.  Registers SpecialTokensDecoder for Decode (TikTokenizer.cs:79)."""
+        items = list(specials.items())
+        lits = [k.encode("utf-8") for k, _ in items]
+        ids = np.asarray([v for _, v in items], dtype=np.int32)
+        blob = np.frombuffer(b"".join(lits), np.uint8) if sum(map(len, lits)) else np.zeros(1, np.uint8)
+        offs = np.cumsum([0] + [len(x) for x in lits]).astype(np.int64)
+        self.lib.check(self.lib.L.tkz_encoder_set_special_tokens(self._h, _ptr(ids) if len(ids) else None, _ptr(blob), _ptr(offs), len(ids)))
+
+    def decode_batch(self, ids: np.ndarray, id_offsets: np.ndarray, out_cap=None):
+        """Batch Decode on the device: (bytes uint8[total], byte_offsets int64[n+1])."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        id_offsets = np.ascontiguousarray(id_offsets, dtype=np.int64)
+        n = len(id_offsets) - 1
+        cap = out_cap if out_cap is not None else max(16, 8 * len(ids))
+        while True:
+            out = np.empty(max(1, cap), np.uint8)
+            ooff = np.empty(n + 1, np.int64)
+            needed = C.c_int64(0)
+            st = self.lib.L.tkz_decode_batch(self._h, _ptr(ids) if len(ids) else None, _ptr(id_offsets), n, _ptr(out), cap, _ptr(ooff), C.byref(needed))
+            if st == E_CAPACITY and out_cap is None:
+                cap = needed.value
+                continue
+            self.lib.check(st)
+            return out[:needed.value], ooff
+
+    def decode_batch_device(self, d_ids, d_id_offsets, n_docs, total_ids, d_out, out_cap, d_out_offsets, stream=0):
+        tot = C.c_int64(0)
+        self.lib.check(self.lib.L.tkz_decode_batch_device(self._h, d_ids, d_id_offsets, n_docs, total_ids, d_out, out_cap, d_out_offsets,
+                                                          stream or None, C.byref(tot)))
+        return tot.value
+
+    @property
+    def counts_device(self):
+        """Device pointer to {n_docs, n_bytes, n_tokens} (3 int64) of the last batch."""
+        return self.lib.L.tkz_encoder_counts_device(self._h)
+
     # -- device buffers (raw pointers, e.g. torch tensors' data_ptr()) --
     def encode_batch_device(self, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, stream=0):
         tot = C.c_int64(0)
         self.lib.check(self.lib.L.tkz_encode_batch_device(self._h, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap,
                                                           d_out_offsets, stream or None, C.byref(tot)))
         return tot.value
+
+
+class Comm:
+    """The direct-RCCL communicator of the C ABI (tkz_comm_*): one all-gather of {n_docs, n_bytes, n_tokens} per batch.
+    `exchange(id_or_None) -> id`: how the 128-byte id travels from rank 0 to the others (any broadcast the host has)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, rank: int, world: int, device: int, exchange, lib: Library = None):
+        self.lib = lib or default_library()
+        if not self.lib.has_comm:
+            raise RuntimeError("this build of libtkz has no communicator")
+        idbuf = (C.c_uint8 * self.ID_BYTES)()
+        if rank == 0:
+            self.lib.check(self.lib.L.tkz_comm_unique_id(idbuf))
+        got = exchange(bytes(idbuf) if rank == 0 else None)
+        assert len(got) == self.ID_BYTES
+        idbuf = (C.c_uint8 * self.ID_BYTES).from_buffer_copy(got)
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.tkz_comm_create(idbuf, rank, world, device, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.L.tkz_comm_destroy(self._h)
+            self._h = None
+
+    @property
+    def world(self):
+        return self.lib.L.tkz_comm_world(self._h)
+
+    @property
+    def rank(self):
+        return self.lib.L.tkz_comm_rank(self._h)
+
+    @property
+    def backend(self):
+        return self.lib.L.tkz_comm_backend(self._h).decode()
+
+    def allgather_counts_device(self, d_mine, d_table, stream=0):
+        """d_mine: device pointer to 3 int64 (Encoder.counts_device); d_table: device pointer to world*3 int64.  Asynchronous."""
+        self.lib.check(self.lib.L.tkz_comm_allgather_counts_device(self._h, d_mine, d_table, stream or None))
+
+    def allgather_counts(self, n_docs, n_bytes, n_tokens):
+        table = np.zeros(self.world * 3, np.int64)
+        self.lib.check(self.lib.L.tkz_comm_allgather_counts(self._h, n_docs, n_bytes, n_tokens, table.ctypes.data))
+        return table.reshape(self.world, 3)
+
+
+def shard_range(n_docs_total, rank, world, lib: Library = None):
+    lib = lib or default_library()
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    lib.L.tkz_shard_range(n_docs_total, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def shard_bases(table, rank, lib: Library = None):
+    """table: int64[world, 3] as gathered.  Returns (bases3, totals3) as lists {docs, bytes, tokens}."""
+    lib = lib or default_library()
+    t = np.ascontiguousarray(table, dtype=np.int64).reshape(-1, 3)
+    b, tot = np.zeros(3, np.int64), np.zeros(3, np.int64)
+    lib.check(lib.L.tkz_shard_bases(t.ctypes.data, len(t), rank, b.ctypes.data, tot.ctypes.data))
+    return b.tolist(), tot.tolist()
+
+
+def shard_write(path, ids, offsets, doc_base=0, token_base=0, lib: Library = None):
+    """tkz_shard_write on host arrays."""
+    lib = lib or default_library()
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    lib.check(lib.L.tkz_shard_write(os.fsencode(path), _ptr(ids) if len(ids) else None, len(ids), _ptr(offsets), len(offsets) - 1, doc_base, token_base))
+
+
+def shard_write_device(path, d_ids, n_tokens, d_offsets, n_docs, doc_base=0, token_base=0, device=0, lib: Library = None):
+    """tkz_shard_write_device: straight from HBM (raw device pointers)."""
+    lib = lib or default_library()
+    lib.check(lib.L.tkz_shard_write_device(os.fsencode(path), device, d_ids, n_tokens, d_offsets, n_docs, doc_base, token_base))
+
+
+def shard_read_header(path, lib: Library = None):
+    lib = lib or default_library()
+    v = [C.c_int64(0) for _ in range(4)]
+    lib.check(lib.L.tkz_shard_read_header(os.fsencode(path), *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)      # n_docs, n_tokens, doc_base, token_base
 
 
 def corpus_doc_host(kind, seed, doc_index, min_len, max_len, lib: Library = None) -> bytes:

@@ -24,6 +24,20 @@ unsigned long long* g_devprof = nullptr;   // development builds only (make DEVP
 
 tkz_status fail(tkz_status s, const std::string& msg) { g_err = msg; return s; }
 
+// The caller's current HIP device is left as it was found: every entry point that needs the encoder's device switches to it
+// for the duration of the call only (a host may drive several GPUs, or run torch with another current device).
+struct DeviceScope {
+    int prev = -1;
+    hipError_t enter(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur == dev) return hipSuccess;
+        const hipError_t r = hipSetDevice(dev);
+        if (r == hipSuccess) prev = cur;
+        return r;
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
@@ -62,6 +76,8 @@ struct CounterBlock {          // mirrors the 64-byte device block
 
 }  // namespace
 
+namespace tkz { tkz_status set_error(tkz_status s, const std::string& msg) { return fail(s, msg); } }   // (tkz_comm.cpp, tkz_decode.cpp)
+
 struct tkz_vocab { tkz::Vocab v; };
 
 struct tkz_encoder {
@@ -75,11 +91,18 @@ struct tkz_encoder {
     DevBuf t_short, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp;
     TkzTables T{};
     // workspace
-    DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
+    DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool, w_counts3;
     // staging for the host-buffer entry points
     DevBuf s_bytes, s_offs, s_out, s_outoffs;
     // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
     DevBuf u_units, u_offs, u_docbits, u_grp, u_tsum, u_tbase, u_bsum, u_counters, u_bytes, u_boffs;
+    // Decode: id -> bytes (vocabulary keys + registered special tokens), rebuilt when the special tokens change
+    DevBuf t_decoff, t_decblob, t_decids;
+    TkzDecodeTable D{};
+    std::vector<std::pair<int32_t, std::string>> dec_vocab, dec_special;   // host copies (id, bytes)
+    DevBuf d_grp, d_tsum, d_tbase, d_bsum, d_counters, d_ids, d_idoffs, d_out, d_outoffs;
+    // piece-granular entry point: piece byte offsets, token offsets, first piece of every document
+    DevBuf p_boffs, p_toffs, p_docp;
     CounterBlock* h_counters = nullptr;   // pinned
     int64_t bytes_allocated = 0;
     // profiling
@@ -113,16 +136,71 @@ hipError_t upload(DevBuf& b, const std::vector<T>& v, int64_t* acc) {
     return hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
+// (re)builds the device decoder table from the vocabulary keys and the registered special tokens.  The reference looks an id
+// up in Decoder first, then in SpecialTokensDecoder (TikTokenizer.cs:591-598): a special token never shadows a vocabulary id.
+tkz_status build_decode_table(tkz_encoder* e) {
+    std::vector<std::pair<int32_t, const std::string*>> ent;
+    ent.reserve(e->dec_vocab.size() + e->dec_special.size());
+    for (const auto& kv : e->dec_vocab) ent.emplace_back(kv.first, &kv.second);
+    const size_t nv = ent.size();
+    for (const auto& kv : e->dec_special) ent.emplace_back(kv.first, &kv.second);
+    // stable by id: of two entries with one id the vocabulary's (first) wins
+    std::vector<size_t> order(ent.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return ent[a].first < ent[b].first; });
+    (void)nv;
+    int64_t max_id = -1;
+    for (const auto& kv : ent) max_id = std::max<int64_t>(max_id, kv.first);
+    const bool dense = max_id < (int64_t(1) << 22);
+    std::vector<uint32_t> off;
+    std::vector<int32_t> ids;
+    std::vector<uint8_t> blob;
+    if (dense) {
+        off.assign((size_t)(max_id + 2), 0);
+        std::vector<const std::string*> by_id((size_t)(max_id + 1), nullptr);
+        for (size_t k : order) if (ent[k].first >= 0 && !by_id[(size_t)ent[k].first]) by_id[(size_t)ent[k].first] = ent[k].second;
+        for (int64_t i = 0; i <= max_id; ++i) {
+            off[(size_t)i] = (uint32_t)blob.size();
+            if (by_id[(size_t)i]) blob.insert(blob.end(), by_id[(size_t)i]->begin(), by_id[(size_t)i]->end());
+        }
+        off[(size_t)(max_id + 1)] = (uint32_t)blob.size();
+    } else {
+        int64_t last = INT64_MIN;
+        for (size_t k : order) {
+            if (ent[k].first == last) continue;
+            last = ent[k].first;
+            ids.push_back(ent[k].first);
+            off.push_back((uint32_t)blob.size());
+            blob.insert(blob.end(), ent[k].second->begin(), ent[k].second->end());
+        }
+        off.push_back((uint32_t)blob.size());
+    }
+    blob.resize(blob.size() + 16, 0);
+    int64_t* acc = &e->bytes_allocated;
+    hipError_t h = upload(e->t_decoff, off, acc);
+    if (h == hipSuccess) h = upload(e->t_decblob, blob, acc);
+    if (h == hipSuccess && !dense) h = upload(e->t_decids, ids, acc);
+    if (h != hipSuccess) return fail(TKZ_E_DEVICE, std::string("decoder table upload: ") + hipGetErrorString(h));
+    e->D.off = e->t_decoff.as<uint32_t>(); e->D.blob = e->t_decblob.as<uint8_t>(); e->D.ids = dense ? nullptr : e->t_decids.as<int32_t>();
+    e->D.n = dense ? max_id + 1 : (int64_t)ids.size(); e->D.dense = dense ? 1 : 0;
+    return TKZ_OK;
+}
+
+// where the piece-granular entry point wants its arrays (all on the device)
+struct PiecesOut { int64_t* piece_boffs; int64_t* piece_toffs; int64_t* doc_piece; int64_t piece_cap; int64_t n_pieces; };
+
 // the batch on the device; when pretok == false every "document" is taken as one piece
 tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                          int32_t* d_out, int64_t out_cap, int64_t* d_out_offs, hipStream_t stream, bool pretok,
-                         uint64_t* d_bitmap_only, int64_t* total_tokens) {
+                         uint64_t* d_bitmap_only, int64_t* total_tokens, PiecesOut* po = nullptr) {
     using namespace tkz;
     if (n_docs < 0 || total < 0 || out_cap < 0) return fail(TKZ_E_ARG, "negative size");
     if (total_tokens) *total_tokens = 0;
     if (n_docs == 0 && total != 0) return fail(TKZ_E_ARG, "bytes without documents");
     const int64_t nwords = total / 64 + 1;
+    HIP_TRY(e->w_counts3.ensure(32, &e->bytes_allocated));
     if (total == 0) {
+        { tkz::Launch L0{stream, nullptr, e}; tkz::launch_counts3(L0, n_docs, 0, nullptr, e->w_counts3.as<int64_t>()); }
         if (d_out_offs) HIP_TRY(hipMemsetAsync(d_out_offs, 0, (size_t)(n_docs + 1) * sizeof(int64_t), stream));
         if (d_bitmap_only) { const uint64_t one = 1; HIP_TRY(hipMemcpyAsync(d_bitmap_only, &one, 8, hipMemcpyHostToDevice, stream)); }
         HIP_TRY(hipStreamSynchronize(stream));
@@ -140,7 +218,7 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         HIP_TRY(e->w_tfirst.ensure((size_t)ntiles * 8, acc));
         HIP_TRY(e->w_tbase.ensure((size_t)ntiles * 8, acc));
         HIP_TRY(e->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
-        HIP_TRY(e->w_doctok.ensure((size_t)(n_docs + 2) * 4, acc));
+        HIP_TRY(e->w_doctok.ensure((size_t)((po ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
         HIP_TRY(e->w_dcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(e->w_dbase.ensure((size_t)ntiles * 8, acc));
         HIP_TRY(e->w_heavyq.ensure((size_t)ntiles + 64, acc));
@@ -193,12 +271,27 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             P.devprof = g_devprof;
 #endif
             int64_t* ndocstarts = reinterpret_cast<int64_t*>(e->w_counters.as<char>() + offsetof(CounterBlock, ndocstarts));
-            launch_doccount(L, docbits, nwords, ntiles, e->w_dcount.as<int32_t>());
+            // piece granularity: the piece-start bitmap takes the place of the document bitmap from here on, so that the encode
+            // kernels record the token position of every PIECE start and k_docoffs yields the token range of every piece
+            const uint64_t* markbits = po ? startbits : docbits;
+            P.docbits = markbits;
+            launch_doccount(L, markbits, nwords, total, ntiles, e->w_dcount.as<int32_t>());
             launch_scan(L, e->w_dcount.as<int32_t>(), ntiles, e->w_bsum.as<int64_t>(), e->w_dbase.as<int64_t>(), ndocstarts, -1);
+            if (po) {
+                int64_t np = 0;
+                HIP_TRY(hipMemcpyAsync(&e->h_counters->ndocstarts, ndocstarts, 8, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                np = e->h_counters->ndocstarts;                  // piece starts below `total` (a document start is one)
+                po->n_pieces = np;
+                if (np > po->piece_cap) return fail(TKZ_E_CAPACITY, "piece arrays too small");
+                launch_piece_index(L, startbits, nwords, total, ntiles, e->w_dbase.as<int64_t>(), np, po->piece_boffs, d_offs, n_docs, po->doc_piece);
+            }
             launch_encode(L, e->T, P, ntiles);
             launch_scan(L, P.tile_count, ntiles, e->w_bsum.as<int64_t>(), e->w_tbase.as<int64_t>(), grand, K_SCAN);
             launch_gather(L, P.tmp, P.tile_count, P.tile_first, e->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
-            launch_docoffs(L, d_offs, n_docs, total, e->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs);
+            if (po) launch_docoffs(L, po->piece_boffs, po->n_pieces, total, e->w_tbase.as<int64_t>(), markbits, P.docord_base, P.doc_tok, grand, po->piece_toffs);
+            else launch_docoffs(L, d_offs, n_docs, total, e->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs);
+            launch_counts3(L, n_docs, total, grand, e->w_counts3.as<int64_t>());
         }
         HIP_TRY(hipMemcpyAsync(e->h_counters, counters, sizeof(CounterBlock), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
@@ -217,11 +310,15 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         if (err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the byte count");
         if (err & kErrUtf8) return fail(TKZ_E_INVALID_UTF8, "input is not well-formed UTF-8 (or a document boundary falls inside a character)");
         if (err & kErrTooLong) return fail(TKZ_E_UNSUPPORTED, "a single piece longer than 2^30 bytes");
-        if ((err & kErrPool) && attempt == 0) {      // scratch for very long pieces was too small: size it for the worst case, rerun
-            HIP_TRY(e->w_pool.ensure((size_t)(24 * total + 4096), acc));
+        if ((err & kErrPool) && attempt == 0) {
+            // scratch for the giant pieces was too small.  pool_head keeps counting past the capacity, so it holds the exact need
+            // (6 int32 per byte of every giant piece of the batch): size the pool for that -- not for the whole batch -- and rerun
+            const size_t need = (size_t)e->h_counters->pool_head * 4 + 4096;
+            if (e->w_pool.ensure(need, acc) != hipSuccess)
+                return fail(TKZ_E_OUT_OF_MEMORY, "scratch for the pieces longer than 1024 bytes: " + std::to_string(need) + " bytes could not be allocated");
             continue;
         }
-        if (err & kErrPool) return fail(TKZ_E_DEVICE, "long-piece scratch exhausted");
+        if (err & kErrPool) return fail(TKZ_E_OUT_OF_MEMORY, "long-piece scratch exhausted");
         if (err & kErrKeyNotFound) return fail(TKZ_E_KEY_NOT_FOUND, "a byte of the input is not in the vocabulary (KeyNotFoundException in the reference)");
         if (!d_bitmap_only) {
             if (total_tokens) *total_tokens = e->h_counters->grand;
@@ -232,9 +329,9 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
     return fail(TKZ_E_DEVICE, "unreachable");
 }
 
-tkz_status check_encoder(tkz_encoder* e) {
+tkz_status check_encoder(tkz_encoder* e, DeviceScope& scope) {
     if (!e) return fail(TKZ_E_ARG, "null encoder");
-    hipError_t r = hipSetDevice(e->device);
+    hipError_t r = scope.enter(e->device);
     if (r != hipSuccess) return fail(TKZ_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(r));
     return TKZ_OK;
 }
@@ -242,7 +339,8 @@ tkz_status check_encoder(tkz_encoder* e) {
 // host buffers -> staging -> device path -> back
 tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const int64_t* offs, int64_t n_docs, int32_t* out_ids,
                        int64_t out_cap, int64_t* out_offsets, int64_t* needed, bool pretok, uint64_t* bitmap) {
-    tkz_status st = check_encoder(e);
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
     if (st != TKZ_OK) return st;
     if (n_docs < 0 || !offs || (n_docs > 0 && !bytes && offs[n_docs] > 0)) return fail(TKZ_E_ARG, "null buffer");
     if (offs[0] != 0) return fail(TKZ_E_ARG, "doc_offsets[0] must be 0");
@@ -327,7 +425,8 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     hipError_t r = hipGetDeviceCount(&ndev);
     if (r != hipSuccess || ndev <= 0) return fail(TKZ_E_NO_DEVICE, "no HIP device available (libtkz has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(TKZ_E_ARG, "device index out of range");
-    HIP_TRY(hipSetDevice(device));
+    DeviceScope scope;
+    HIP_TRY(scope.enter(device));
     tkz_encoder* e = new tkz_encoder();
     e->device = device; e->pattern = pattern; e->max_key_len = v->v.max_key_len;
     int64_t* acc = &e->bytes_allocated;
@@ -352,16 +451,22 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     e->T.pattern = pattern;
     e->T.max_rank = 0;
     for (int32_t r : V.ranks) e->T.max_rank = std::max(e->T.max_rank, r);
+    e->dec_vocab.reserve(V.keys.size());
+    for (size_t i = 0; i < V.keys.size(); ++i) e->dec_vocab.emplace_back(V.ranks[i], V.keys[i]);
+    { const tkz_status ds = build_decode_table(e); if (ds != TKZ_OK) { tkz_encoder_destroy(e); return ds; } }
     *out = e;
     return TKZ_OK;
 }
 
 void tkz_encoder_destroy(tkz_encoder* e) {
     if (!e) return;
-    (void)hipSetDevice(e->device);
+    DeviceScope scope;
+    (void)scope.enter(e->device);
     DevBuf* bufs[] = {&e->t_short, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp,
                       &e->w_gq, &e->w_gcnt, &e->w_xq, &e->w_heavyq, &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
-                      &e->w_doctok, &e->w_dcount, &e->w_dbase, &e->w_counters, &e->w_pool, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs,
+                      &e->w_doctok, &e->w_dcount, &e->w_dbase, &e->w_counters, &e->w_pool, &e->w_counts3, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs,
+                      &e->t_decoff, &e->t_decblob, &e->t_decids, &e->d_grp, &e->d_tsum, &e->d_tbase, &e->d_bsum, &e->d_counters, &e->d_ids, &e->d_idoffs, &e->d_out, &e->d_outoffs,
+                      &e->p_boffs, &e->p_toffs, &e->p_docp,
                       &e->u_units, &e->u_offs, &e->u_docbits, &e->u_grp, &e->u_tsum, &e->u_tbase, &e->u_bsum, &e->u_counters, &e->u_bytes, &e->u_boffs};
     for (DevBuf* b : bufs) b->release();
     if (e->h_counters) (void)hipHostFree(e->h_counters);
@@ -369,6 +474,7 @@ void tkz_encoder_destroy(tkz_encoder* e) {
     delete e;
 }
 int32_t tkz_encoder_device(const tkz_encoder* e) { return e ? e->device : -1; }
+const int64_t* tkz_encoder_counts_device(const tkz_encoder* e) { return e ? e->w_counts3.as<int64_t>() : nullptr; }
 
 tkz_status tkz_encode_batch_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs,
                                  int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed) {
@@ -379,7 +485,8 @@ tkz_status tkz_encode_batch_utf8(tkz_encoder* e, const uint8_t* bytes, const int
 tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets, int64_t n_docs,
                                    int64_t total_bytes, int32_t* d_out_ids, int64_t out_cap, int64_t* d_out_offsets,
                                    void* hip_stream, int64_t* total_tokens) {
-    tkz_status st = check_encoder(e);
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
     if (st != TKZ_OK) return st;
     if (!d_doc_offsets || !d_out_offsets || (total_bytes > 0 && (!d_bytes || !d_out_ids))) return fail(TKZ_E_ARG, "null device buffer");
     if (reinterpret_cast<uintptr_t>(d_bytes) & 15) return fail(TKZ_E_ARG, "d_bytes must be 16-byte aligned");
@@ -419,7 +526,8 @@ tkz_status tkz_encode_utf16(tkz_encoder* e, const uint16_t* text, int64_t len, i
 tkz_status tkz_encode_batch_utf16(tkz_encoder* e, const uint16_t* units, const int64_t* unit_offsets, int64_t n_docs,
                                   int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed) {
     using namespace tkz;
-    tkz_status st = check_encoder(e);
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
     if (st != TKZ_OK) return st;
     if (!out_offsets || (out_cap > 0 && !out_ids)) return fail(TKZ_E_ARG, "null output buffer");
     if (n_docs < 0 || !unit_offsets || (n_docs > 0 && !units && unit_offsets[n_docs] > 0)) return fail(TKZ_E_ARG, "null buffer");
@@ -493,37 +601,136 @@ tkz_status tkz_encode_batch_pieces_utf8(tkz_encoder* e, const uint8_t* bytes, co
                                         int64_t* piece_token_offsets, int64_t piece_cap, int64_t* n_pieces, int64_t* needed_ids) {
     if (!doc_piece_offsets || !piece_byte_offsets || !piece_token_offsets || !n_pieces || (out_cap > 0 && !out_ids))
         return fail(TKZ_E_ARG, "null output buffer");
-    if (n_docs < 0 || !doc_offsets) return fail(TKZ_E_ARG, "null buffer");
-    // 1. Regex.Matches on the device: the piece-start bitmap of the whole batch
-    const int64_t total = doc_offsets[n_docs];
-    if (total < 0) return fail(TKZ_E_ARG, "negative byte count");
-    std::vector<uint64_t> bitmap((size_t)(total / 64 + 1), 0);
-    tkz_status st = encode_host(e, bytes, doc_offsets, n_docs, nullptr, 0, nullptr, nullptr, true, bitmap.data());
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
     if (st != TKZ_OK) return st;
-    // 2. the pieces in order (a document start is always a piece start; empty documents have no piece)
-    int64_t np = 0;
-    for (size_t w = 0; w < bitmap.size(); ++w) {
-        uint64_t m = bitmap[w];
-        if (w == bitmap.size() - 1) m &= (total & 63) ? ((1ull << (total & 63)) - 1ull) : 0ull;   // drop the sentinel at `total`
-        np += __builtin_popcountll(m);
+    if (n_docs < 0 || !doc_offsets || (n_docs > 0 && !bytes && doc_offsets[n_docs] > 0)) return fail(TKZ_E_ARG, "null buffer");
+    if (doc_offsets[0] != 0) return fail(TKZ_E_ARG, "doc_offsets[0] must be 0");
+    const int64_t total = doc_offsets[n_docs];
+    if (total < 0 || piece_cap < 0) return fail(TKZ_E_ARG, "negative size");
+    *n_pieces = 0;
+    if (needed_ids) *needed_ids = 0;
+    if (total == 0) {                                        // no bytes: no pieces (empty documents have none)
+        for (int64_t d = 0; d <= n_docs; ++d) { if (doc_offsets[d] != 0) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the byte count"); doc_piece_offsets[d] = 0; }
+        piece_byte_offsets[0] = 0; piece_token_offsets[0] = 0;
+        return TKZ_OK;
     }
-    *n_pieces = np;
-    if (np > piece_cap) return fail(TKZ_E_CAPACITY, "piece arrays too small");
-    int64_t k = 0, d = 0;
-    for (size_t w = 0; w < bitmap.size(); ++w) {
-        uint64_t m = bitmap[w];
-        if (w == bitmap.size() - 1) m &= (total & 63) ? ((1ull << (total & 63)) - 1ull) : 0ull;
-        for (; m; m &= m - 1) {
-            const int64_t pos = (int64_t)w * 64 + __builtin_ctzll(m);
-            while (d < n_docs && doc_offsets[d] <= pos) doc_piece_offsets[d++] = k;      // documents that start at or before this piece
-            piece_byte_offsets[k++] = pos;
-        }
+    // ONE launch sequence on the device: Regex.Matches -> piece offsets from the bitmap -> encode with a token mark per piece
+    std::lock_guard<std::mutex> lock(e->mu);
+    int64_t* acc = &e->bytes_allocated;
+    const int64_t pcap = std::min<int64_t>(piece_cap, total);           // pieces <= bytes
+    const int64_t cap = std::min<int64_t>(out_cap, total);
+    HIP_TRY(e->s_bytes.ensure((size_t)total + 64, acc));
+    HIP_TRY(e->s_offs.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(e->s_out.ensure((size_t)std::max<int64_t>(cap, 1) * 4, acc));
+    HIP_TRY(e->p_boffs.ensure((size_t)(pcap + 1) * 8, acc));
+    HIP_TRY(e->p_toffs.ensure((size_t)(pcap + 1) * 8, acc));
+    HIP_TRY(e->p_docp.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(hipMemcpy(e->s_bytes.p, bytes, (size_t)total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->s_offs.p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+    PiecesOut po{e->p_boffs.as<int64_t>(), e->p_toffs.as<int64_t>(), e->p_docp.as<int64_t>(), pcap, 0};
+    int64_t tokens = 0;
+    st = encode_device(e, e->s_bytes.as<uint8_t>(), e->s_offs.as<int64_t>(), n_docs, total, e->s_out.as<int32_t>(), cap, nullptr, nullptr, true,
+                       nullptr, &tokens, &po);
+    *n_pieces = po.n_pieces;
+    if (needed_ids) *needed_ids = tokens;
+    if (st != TKZ_OK) return st;
+    const int64_t np = po.n_pieces;
+    if (tokens) HIP_TRY(hipMemcpy(out_ids, e->s_out.p, (size_t)tokens * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(piece_byte_offsets, e->p_boffs.p, (size_t)(np + 1) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(piece_token_offsets, e->p_toffs.p, (size_t)(np + 1) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(doc_piece_offsets, e->p_docp.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    return TKZ_OK;
+}
+
+// ---- Decode (TikTokenizer.cs:586-604) ----------------------------------------------------------------
+
+tkz_status tkz_encoder_set_special_tokens(tkz_encoder* e, const int32_t* ids, const uint8_t* literals_utf8, const int64_t* literal_offsets, int32_t n) {
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
+    if (st != TKZ_OK) return st;
+    if (n < 0 || (n > 0 && (!ids || !literal_offsets || (!literals_utf8 && literal_offsets[n] > 0)))) return fail(TKZ_E_ARG, "bad special-token arguments");
+    std::lock_guard<std::mutex> lock(e->mu);
+    std::vector<std::pair<int32_t, std::string>> sp;
+    for (int32_t i = 0; i < n; ++i) {
+        if (literal_offsets[i + 1] < literal_offsets[i] || literal_offsets[i] < 0) return fail(TKZ_E_ARG, "literal offsets must be non-decreasing");
+        sp.emplace_back(ids[i], std::string(reinterpret_cast<const char*>(literals_utf8) + literal_offsets[i], (size_t)(literal_offsets[i + 1] - literal_offsets[i])));
     }
-    while (d <= n_docs) doc_piece_offsets[d++] = k;
-    piece_byte_offsets[np] = total;
-    // 3. BytePairEncode + whole-piece lookup of every piece
-    if (np == 0) { piece_token_offsets[0] = 0; if (needed_ids) *needed_ids = 0; return TKZ_OK; }
-    return encode_host(e, bytes, piece_byte_offsets, np, out_ids, out_cap, piece_token_offsets, needed_ids, false, nullptr);
+    e->dec_special.swap(sp);
+    return build_decode_table(e);
+}
+
+namespace {
+// lengths -> scan -> bytes + document offsets, all on `stream`; d_out may be null when only the size is wanted
+tkz_status decode_device(tkz_encoder* e, const int32_t* d_ids, const int64_t* d_id_offs, int64_t n_docs, int64_t total_ids, uint8_t* d_out, int64_t out_cap,
+                         int64_t* d_out_offs, hipStream_t stream, int64_t* total_bytes) {
+    using namespace tkz;
+    if (total_bytes) *total_bytes = 0;
+    if (n_docs < 0 || total_ids < 0 || out_cap < 0) return fail(TKZ_E_ARG, "negative size");
+    if (n_docs == 0 && total_ids != 0) return fail(TKZ_E_ARG, "ids without documents");
+    int64_t* acc = &e->bytes_allocated;
+    const int64_t ntiles = std::max<int64_t>(1, dec_tiles(total_ids)), nblk = (ntiles + kScanBlock - 1) / kScanBlock;
+    HIP_TRY(e->d_grp.ensure((size_t)ntiles * 64 * 4, acc));
+    HIP_TRY(e->d_tsum.ensure((size_t)ntiles * 4, acc));
+    HIP_TRY(e->d_tbase.ensure((size_t)ntiles * 8, acc));
+    HIP_TRY(e->d_bsum.ensure((size_t)(nblk + 1) * 8, acc));
+    HIP_TRY(e->d_counters.ensure(64, acc));
+    if (!e->h_counters) HIP_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(CounterBlock), 0));
+    Launch L{stream, nullptr, e};
+    int32_t* counters = e->d_counters.as<int32_t>();
+    int64_t* grand = reinterpret_cast<int64_t*>(e->d_counters.as<char>() + 8);
+    HIP_TRY(hipMemsetAsync(counters, 0, 64, stream));
+    launch_dec_len(L, e->D, d_ids, total_ids, ntiles, e->d_grp.as<int32_t>(), e->d_tsum.as<int32_t>());
+    launch_scan(L, e->d_tsum.as<int32_t>(), ntiles, e->d_bsum.as<int64_t>(), e->d_tbase.as<int64_t>(), grand, -1);
+    launch_dec_write(L, e->D, d_ids, total_ids, ntiles, e->d_tbase.as<int64_t>(), d_out, d_out ? out_cap : 0, d_id_offs, n_docs, e->d_grp.as<int32_t>(), grand,
+                     d_out_offs, counters);
+    struct { int32_t err; int32_t pad; int64_t grand; } h{};
+    HIP_TRY(hipMemcpyAsync(e->h_counters, counters, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipGetLastError());
+    memcpy(&h, e->h_counters, 16);
+    if (h.err & kErrOffsets) return fail(TKZ_E_ARG, "id offsets must start at 0, be non-decreasing and end at the id count");
+    if (total_bytes) *total_bytes = h.grand;
+    if (h.grand > out_cap) return fail(TKZ_E_CAPACITY, "output capacity too small");
+    return TKZ_OK;
+}
+}  // namespace
+
+tkz_status tkz_decode_batch_device(tkz_encoder* e, const int32_t* d_ids, const int64_t* d_id_offsets, int64_t n_docs, int64_t total_ids,
+                                   uint8_t* d_out_bytes, int64_t out_cap, int64_t* d_out_offsets, void* hip_stream, int64_t* total_bytes) {
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
+    if (st != TKZ_OK) return st;
+    if (!d_id_offsets || !d_out_offsets || (total_ids > 0 && !d_ids) || (out_cap > 0 && !d_out_bytes)) return fail(TKZ_E_ARG, "null device buffer");
+    std::lock_guard<std::mutex> lock(e->mu);
+    return decode_device(e, d_ids, d_id_offsets, n_docs, total_ids, d_out_bytes, out_cap, d_out_offsets, static_cast<hipStream_t>(hip_stream), total_bytes);
+}
+
+tkz_status tkz_decode_batch(tkz_encoder* e, const int32_t* ids, const int64_t* id_offsets, int64_t n_docs, uint8_t* out_bytes, int64_t out_cap,
+                            int64_t* out_offsets, int64_t* needed) {
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
+    if (st != TKZ_OK) return st;
+    if (n_docs < 0 || !id_offsets || !out_offsets || (out_cap > 0 && !out_bytes)) return fail(TKZ_E_ARG, "null buffer");
+    if (id_offsets[0] != 0) return fail(TKZ_E_ARG, "id_offsets[0] must be 0");
+    const int64_t total = id_offsets[n_docs];
+    if (total < 0 || (total > 0 && !ids)) return fail(TKZ_E_ARG, "bad id count");
+    if (needed) *needed = 0;
+    std::lock_guard<std::mutex> lock(e->mu);
+    int64_t* acc = &e->bytes_allocated;
+    HIP_TRY(e->d_ids.ensure((size_t)std::max<int64_t>(total, 1) * 4, acc));
+    HIP_TRY(e->d_idoffs.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(e->d_outoffs.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(e->d_out.ensure((size_t)std::max<int64_t>(out_cap, 1), acc));
+    if (total) HIP_TRY(hipMemcpy(e->d_ids.p, ids, (size_t)total * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->d_idoffs.p, id_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+    int64_t nbytes = 0;
+    st = decode_device(e, e->d_ids.as<int32_t>(), e->d_idoffs.as<int64_t>(), n_docs, total, e->d_out.as<uint8_t>(), out_cap, e->d_outoffs.as<int64_t>(), nullptr, &nbytes);
+    if (needed) *needed = nbytes;
+    if (st != TKZ_OK) return st;
+    if (nbytes) HIP_TRY(hipMemcpy(out_bytes, e->d_out.p, (size_t)nbytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_offsets, e->d_outoffs.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    return TKZ_OK;
 }
 
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value) {
@@ -549,7 +756,7 @@ tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, 
 }
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) { return e ? e->bytes_allocated : 0; }
 const char* tkz_kernel_name(int32_t k) {
-    static const char* const names[] = {"k_docmark", "k_pretok", "k_encode_waves", "k_scan", "k_gather", "k_docoffs"};
+    static const char* const names[] = {"k_docmark", "k_pretok", "k_encode_waves", "k_scan", "k_gather", "k_docoffs", "k_encode_heavy_group"};
     return (k >= 0 && k < tkz::K_COUNT) ? names[k] : "?";
 }
 
@@ -558,7 +765,8 @@ tkz_status tkz_corpus_generate_device(int32_t device, int32_t kind, uint64_t see
                                       int64_t cap_bytes, void* hip_stream, int64_t* total_bytes) {
     if (kind < 1 || kind > 3 || n_docs < 0 || min_len < 0 || max_len < min_len || !d_doc_offsets || !total_bytes)
         return fail(TKZ_E_ARG, "bad corpus arguments");
-    hipError_t r = hipSetDevice(device);
+    DeviceScope scope;
+    hipError_t r = scope.enter(device);
     if (r != hipSuccess) return fail(TKZ_E_NO_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(r));
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     int64_t* d_total = nullptr;
@@ -570,6 +778,29 @@ tkz_status tkz_corpus_generate_device(int32_t device, int32_t kind, uint64_t see
     (void)hipFree(d_total);
     if (c != hipSuccess) return fail(TKZ_E_DEVICE, std::string("corpus generation: ") + hipGetErrorString(c));
     if (d_bytes && *total_bytes > cap_bytes) return fail(TKZ_E_CAPACITY, "corpus buffer too small");
+    return TKZ_OK;
+}
+
+// ---- shard arithmetic of the multi-GPU partitioning (the communicator itself is tkz_comm.cpp) ----
+void tkz_shard_range(int64_t n_docs_total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi) {
+    if (world < 1) world = 1;
+    // (128-bit product: n_docs_total * world may exceed 2^63 only for absurd inputs, but costs nothing to get right)
+    if (lo) *lo = (int64_t)(((__int128)n_docs_total * rank) / world);
+    if (hi) *hi = (int64_t)(((__int128)n_docs_total * (rank + 1)) / world);
+}
+
+tkz_status tkz_shard_bases(const int64_t* table, int32_t world, int32_t rank, int64_t* bases3, int64_t* totals3) {
+    if (!table || world < 1 || rank < 0 || rank >= world) return fail(TKZ_E_ARG, "bad table / rank");
+    int64_t b[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+    for (int r = 0; r < world; ++r)
+        for (int k = 0; k < 3; ++k) {
+            const int64_t v = table[3 * r + k];
+            if (v < 0) return fail(TKZ_E_ARG, "negative count in the gathered table");
+            if (r < rank) b[k] += v;
+            t[k] += v;
+        }
+    if (bases3) memcpy(bases3, b, sizeof b);
+    if (totals3) memcpy(totals3, t, sizeof t);
     return TKZ_OK;
 }
 

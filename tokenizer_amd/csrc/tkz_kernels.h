@@ -22,7 +22,7 @@ constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrToo
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan
 
-enum { K_DOCMARK = 0, K_PRETOK = 1, K_ENCODE = 2, K_SCAN = 3, K_GATHER = 4, K_DOCOFFS = 5, K_COUNT = 6 };
+enum { K_DOCMARK = 0, K_PRETOK = 1, K_ENCODE = 2, K_SCAN = 3, K_GATHER = 4, K_DOCOFFS = 5, K_HEAVY = 6, K_COUNT = 7 };
 
 #ifdef TKZ_DEVPROF
 #define TKZ_DEV_FLAG(P, bit) (((P).ablate & (bit)) != 0)
@@ -63,19 +63,28 @@ void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, co
 void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                        uint64_t* startbits, const uint8_t* bmp, int32_t* counters);
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub);
-void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t nsub, int32_t* cnt);
+void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt);
 // exclusive scan int32 -> int64 (+ grand total); kid = profiling id of the bracket, or -1
 void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid);
 void launch_gather(const Launch& L, const int32_t* tmp, const int32_t* tile_count, const int64_t* tile_first,
                    const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap);
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
                     const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs);
+void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3);
 // UTF-16 documents -> UTF-8 documents (Encoding.UTF8.GetBytes for a batch): lengths + group prefixes, then (after the scan of
 // the tile sums) the bytes and the byte offset of every document
 int64_t u16_tiles(int64_t total_units);
 void launch_u16_len(const Launch& L, const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum);
 void launch_u16_write(const Launch& L, const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, const int64_t* tile_base,
                       uint8_t* out, const int64_t* unit_offs, int64_t n_docs, const int32_t* grp_prefix, const int64_t* grand, int64_t* byte_offs);
+// piece granularity: byte offset of every piece (n_pieces + 1 entries) and first piece of every document, from the bitmap
+void launch_piece_index(const Launch& L, const uint64_t* startbits, int64_t nwords, int64_t total, int64_t nsub, const int64_t* ord_base,
+                        int64_t n_pieces, int64_t* piece_offs, const int64_t* d_offs, int64_t n_docs, int64_t* doc_piece);
+// batch Decode
+int64_t dec_tiles(int64_t total_ids);
+void launch_dec_len(const Launch& L, const TkzDecodeTable& D, const int32_t* ids, int64_t total, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum);
+void launch_dec_write(const Launch& L, const TkzDecodeTable& D, const int32_t* ids, int64_t total, int64_t ntiles, const int64_t* tile_base, uint8_t* out,
+                      int64_t out_cap, const int64_t* id_offs, int64_t n_docs, const int32_t* grp_prefix, const int64_t* grand, int64_t* byte_offs, int32_t* counters);
 void launch_corpus(hipStream_t s, int kind, uint64_t seed, int64_t first_doc, int64_t n_docs, int min_len, int max_len,
                    int64_t* d_offs, uint8_t* d_bytes, int64_t cap_bytes, int64_t* d_total);
 

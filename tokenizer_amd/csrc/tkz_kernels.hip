@@ -728,14 +728,17 @@ TKZ_KERNEL(1024) void k_giant_merge(TkzTables T, EncodeParams P) {
 }
 
 // documents that start in each sub-tile (for the document ordinals)
-TKZ_KERNEL(256) void k_doccount(const uint64_t* docbits, int64_t nwords, int64_t nsub, int32_t* cnt) {
+TKZ_KERNEL(256) void k_doccount(const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt) {
     // one lane per bitmap word (coalesced), the kSub/64 = 16 words of a sub-tile summed across 16 lanes
     static_assert(kSub / 64 == 16, "k_doccount sums 16 lanes per sub-tile");
     const int lane = simt::lane();
     const int64_t stride = simt::nblocks() * simt::nthreads(), nw = nsub * (kSub / 64);
     for (int64_t w0 = simt::bid() * simt::nthreads() + (simt::tid() & ~63); w0 < nw; w0 += stride) {
         const int64_t w = w0 + lane;
-        int c = (w < nw && w < nwords) ? tkz_popc64(docbits[w]) : 0;
+        uint64_t m = (w < nw && w < nwords) ? docbits[w] : 0ull;
+        const int64_t lim = total - (w << 6);              // (the sentinel bit at `total` is not a start)
+        if (lim <= 0) m = 0; else if (lim < 64) m &= tkz_lowmask((int)lim);
+        int c = tkz_popc64(m);
         c += simt::shfl_xor(c, 1); c += simt::shfl_xor(c, 2); c += simt::shfl_xor(c, 4); c += simt::shfl_xor(c, 8);
         if ((lane & 15) == 0 && w < nw) cnt[w >> 4] = c;
     }
@@ -848,6 +851,11 @@ TKZ_KERNEL(256) void k_docoffs(const int64_t* offs, int64_t n_docs, int64_t tota
         ord += tkz_popc64(docbits[wpos] & tkz_lowmask((int)(pos & 63)));
         out_offs[d] = tile_base[sub] + doc_tok[ord];
     }
+}
+
+// {n_docs, n_bytes, n_tokens} of the batch, on the device: what tkz_comm_allgather_counts_device sends (no host round trip)
+TKZ_KERNEL(64) void k_counts3(int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3) {
+    if (simt::tid() == 0) { out3[0] = n_docs; out3[1] = total; out3[2] = grand ? *grand : 0; }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -968,6 +976,128 @@ TKZ_KERNEL(256) void k_u16_docoffs(const uint16_t* units, int64_t total, const u
 }
 
 // -------------------------------------------------------------------------------------------------
+// piece granularity (EncodeTrimSuffix / EncodeTrimPrefix walk the regex matches, TikTokenizer.cs:288-341, :483-519): the byte
+// offset of every piece and the first piece of every document, straight from the piece-start bitmap -- no host round trip
+//   (k_doccount + scan over STARTBITS give every sub-tile its first piece ordinal)
+//   k_piece_index   one wavefront per sub-tile: positions of the set bits below `total`, in order
+//   k_doc_piece     first piece of document d = number of piece starts before its first byte
+// The encode kernels then run with the piece-start bitmap AS the document bitmap: they record the token position of every
+// piece start, and k_docoffs over the piece offsets yields the token range of every piece in the same pass as the ids.
+// -------------------------------------------------------------------------------------------------
+TKZ_KERNEL(256) void k_piece_index(const uint64_t* startbits, int64_t nwords, int64_t total, int64_t nsub, const int64_t* ord_base,
+                                   int64_t n_pieces, int64_t* piece_offs) {
+    static_assert(kSub / 64 == 16, "one bitmap word per lane 0..15");
+    const int lane = simt::lane();
+    const int64_t sub = simt::bid() * (kThreads / 64) + simt::wave();
+    if (sub == 0 && lane == 0) piece_offs[n_pieces] = total;
+    if (sub >= nsub) return;
+    const int64_t w = sub * (kSub / 64) + lane;
+    uint64_t m = (lane < kSub / 64 && w < nwords) ? startbits[w] : 0ull;
+    const int64_t lim = total - (w << 6);                 // bits at or beyond `total` (the sentinel) are not pieces
+    if (lim <= 0) m = 0; else if (lim < 64) m &= tkz_lowmask((int)lim);
+    int tot;
+    const int pre = tkz_wave_scan<7>(tkz_popc64(m), &tot);
+    int64_t o = ord_base[sub] + pre;
+    for (; m; m &= m - 1) piece_offs[o++] = (w << 6) + tkz_ctz64(m);
+}
+TKZ_KERNEL(256) void k_doc_piece(const int64_t* offs, int64_t n_docs, int64_t total, const uint64_t* startbits, const int64_t* ord_base,
+                                 int64_t n_pieces, int64_t* doc_piece) {
+    const int64_t stride = simt::nblocks() * simt::nthreads();
+    for (int64_t d = simt::bid() * simt::nthreads() + simt::tid(); d <= n_docs; d += stride) {
+        const int64_t pos = offs[d];
+        if (pos >= total) { doc_piece[d] = n_pieces; continue; }
+        if (pos < 0) { doc_piece[d] = 0; continue; }
+        const int64_t sub = pos / kSub, wpos = pos >> 6;
+        int64_t ord = ord_base[sub];
+        for (int64_t w = sub * (kSub / 64); w < wpos; ++w) ord += tkz_popc64(startbits[w]);
+        ord += tkz_popc64(startbits[wpos] & tkz_lowmask((int)(pos & 63)));
+        doc_piece[d] = ord;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Decode for a batch (TikTokenizer.Decode, TikTokenizer.cs:586-604): id -> bytes through the decoder table, ids that are in
+// neither the vocabulary nor the registered special tokens contribute nothing (:591-599), documents concatenated.
+//   k_dec_len      per 1024-id tile (one wavefront, 16 ids per lane): byte length of every id -> tile sum and the exclusive
+//                  prefix of every 16-id group inside the tile
+//   (scan of the tile sums: k_scan_*)
+//   k_dec_write    the bytes, staged per tile in LDS and copied out coalesced (direct copies when a tile exceeds the stage)
+//   k_dec_docoffs  byte offset of every document = tile base + group prefix + the ids of the group before it
+// -------------------------------------------------------------------------------------------------
+constexpr int kDecTile = 1024, kDecLane = 16, kDecStage = 12288;
+TKZ_DEV bool tkz_dec_find(const TkzDecodeTable& D, int32_t id, uint32_t* off, uint32_t* len) {
+    int64_t k;
+    if (D.dense) { if (id < 0 || (int64_t)id >= D.n) return false; k = id; }
+    else {
+        int64_t lo = 0, hi = D.n;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (D.ids[mid] < id) lo = mid + 1; else hi = mid; }
+        if (lo >= D.n || D.ids[lo] != id) return false;
+        k = lo;
+    }
+    *off = D.off[k]; *len = D.off[k + 1] - D.off[k];
+    return *len != 0;
+}
+struct TkzDecLane { uint32_t off[kDecLane]; uint32_t len[kDecLane]; };
+TKZ_DEV int tkz_dec_lane(const TkzDecodeTable& D, const int32_t* ids, int64_t total, int64_t tile, TkzDecLane* L) {
+    const int64_t p0 = tile * kDecTile + (int64_t)simt::lane() * kDecLane;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kDecLane; ++k) {
+        L->off[k] = 0; L->len[k] = 0;
+        if (p0 + k < total) { uint32_t o, n; if (tkz_dec_find(D, ids[p0 + k], &o, &n)) { L->off[k] = o; L->len[k] = n; } }
+        sum += (int)L->len[k];
+    }
+    return sum;
+}
+TKZ_KERNEL(256) void k_dec_len(TkzDecodeTable D, const int32_t* ids, int64_t total, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum) {
+    const int64_t tile = simt::bid() * (kThreads / 64) + simt::wave();
+    if (tile >= ntiles) return;
+    TkzDecLane L;
+    const int sum = tkz_dec_lane(D, ids, total, tile, &L);
+    int tot;
+    const int pre = tkz_wave_scan_sum(sum, &tot);
+    grp_prefix[tile * 64 + simt::lane()] = pre;
+    if (simt::lane() == 0) tile_sum[tile] = tot;
+}
+TKZ_KERNEL(256) void k_dec_write(TkzDecodeTable D, const int32_t* ids, int64_t total, int64_t ntiles, const int64_t* tile_base, uint8_t* out, int64_t out_cap) {
+    TKZ_SHARED uint8_t s_stage[kThreads / 64][kDecStage];
+    const int64_t tile = simt::bid() * (kThreads / 64) + simt::wave();
+    if (tile >= ntiles) return;
+    TkzDecLane L;
+    const int sum = tkz_dec_lane(D, ids, total, tile, &L);
+    int tot;
+    int pos = tkz_wave_scan_sum(sum, &tot);
+    const int64_t base = tile_base[tile];
+    if (base + tot > out_cap) return;                       // (the host reports TKZ_E_CAPACITY from the grand total)
+    uint8_t* dst = out + base;
+    if (tot <= kDecStage) {
+        uint8_t* st = s_stage[simt::wave()];
+#pragma unroll 1
+        for (int k = 0; k < kDecLane; ++k) { const uint8_t* src = D.blob + L.off[k]; for (uint32_t j = 0; j < L.len[k]; ++j) st[pos + (int)j] = src[j]; pos += (int)L.len[k]; }
+        (void)simt::ballot(true);      // (the staging area is private to the wavefront: its LDS accesses are ordered, no barrier)
+        for (int i = simt::lane(); i < tot; i += 64) dst[i] = st[i];
+    } else {
+#pragma unroll 1
+        for (int k = 0; k < kDecLane; ++k) { const uint8_t* src = D.blob + L.off[k]; for (uint32_t j = 0; j < L.len[k]; ++j) dst[pos + (int)j] = src[j]; pos += (int)L.len[k]; }
+    }
+}
+TKZ_KERNEL(256) void k_dec_docoffs(TkzDecodeTable D, const int32_t* ids, int64_t total, const int64_t* id_offs, int64_t n_docs, const int64_t* tile_base,
+                                   const int32_t* grp_prefix, const int64_t* grand, int64_t* byte_offs, int32_t* counters) {
+    const int64_t stride = simt::nblocks() * simt::nthreads();
+    for (int64_t d = simt::bid() * simt::nthreads() + simt::tid(); d <= n_docs; d += stride) {
+        const int64_t p = id_offs[d];
+        bool ok = p >= 0 && p <= total;
+        if (d == 0) ok = ok && p == 0;
+        if (d == n_docs) ok = ok && p == total; else ok = ok && p <= id_offs[d + 1];
+        if (!ok) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrOffsets); byte_offs[d] = 0; continue; }
+        if (p >= total) { byte_offs[d] = *grand; continue; }
+        int64_t v = tile_base[p / kDecTile] + grp_prefix[p / kDecLane];
+        for (int64_t q = p & ~(int64_t)(kDecLane - 1); q < p; ++q) { uint32_t o, n; if (tkz_dec_find(D, ids[q], &o, &n)) v += n; }
+        byte_offs[d] = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // synthetic corpus (tkz_corpus.h): lengths, then bytes
 // -------------------------------------------------------------------------------------------------
 TKZ_KERNEL(256) void k_corpus_lengths(int kind, uint64_t seed, int64_t first_doc, int64_t n_docs, int min_len, int max_len, int64_t* offs) {
@@ -1038,6 +1168,8 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub) {
     hook(L, K_ENCODE, 0);
     TKZ_LAUNCH(k_encode_waves, nsub, 64, L.stream, T, P);
+    hook(L, K_ENCODE, 1);
+    hook(L, K_HEAVY, 0);
     // giant pieces start in sub-tiles the lean kernel has just flagged: find them, merge them, then the heavy kernel
     TKZ_LAUNCH(k_giant_find, grid_for(nsub), kThreads, L.stream, (const uint8_t*)P.heavy_flag, nsub, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap);
 #ifdef TKZ_HOSTEMU
@@ -1047,10 +1179,10 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
 #endif
     TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // strides over the queue; exits at once when it is empty
     { const int64_t chunks = cdiv(nsub, 64); TKZ_LAUNCH(k_encode_waves_heavy, chunks < 16384 ? chunks : 16384, 64, L.stream, T, P); }   // strides over 64-sub-tile chunks
-    hook(L, K_ENCODE, 1);
+    hook(L, K_HEAVY, 1);
 }
-void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t nsub, int32_t* cnt) {
-    TKZ_LAUNCH(k_doccount, grid_for(nsub * (kSub / 64)), kThreads, L.stream, docbits, nwords, nsub, cnt);
+void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt) {
+    TKZ_LAUNCH(k_doccount, grid_for(nsub * (kSub / 64)), kThreads, L.stream, docbits, nwords, total, nsub, cnt);
 }
 void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid) {
     const int64_t nblk = cdiv(ntiles, kScanBlock);
@@ -1072,6 +1204,9 @@ void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int6
     TKZ_LAUNCH(k_docoffs, grid_for(n_docs + 1), kThreads, L.stream, d_offs, n_docs, total, tile_base, docbits, docord_base, doc_tok, grand, out_offs);
     hook(L, K_DOCOFFS, 1);
 }
+void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3) {
+    TKZ_LAUNCH(k_counts3, 1, 64, L.stream, n_docs, total, grand, out3);
+}
 void launch_u16_len(const Launch& L, const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum) {
     TKZ_LAUNCH(k_u16_len, cdiv(ntiles, kThreads / 64), kThreads, L.stream, units, total, docbits, ntiles, grp_prefix, tile_sum);
 }
@@ -1081,6 +1216,20 @@ void launch_u16_write(const Launch& L, const uint16_t* units, int64_t total, con
     TKZ_LAUNCH(k_u16_docoffs, grid_for(n_docs + 1), kThreads, L.stream, units, total, docbits, unit_offs, n_docs, tile_base, grp_prefix, grand, byte_offs);
 }
 int64_t u16_tiles(int64_t total_units) { return cdiv(total_units, kU16Tile); }
+void launch_piece_index(const Launch& L, const uint64_t* startbits, int64_t nwords, int64_t total, int64_t nsub, const int64_t* ord_base,
+                        int64_t n_pieces, int64_t* piece_offs, const int64_t* d_offs, int64_t n_docs, int64_t* doc_piece) {
+    TKZ_LAUNCH(k_piece_index, cdiv(nsub, kThreads / 64), kThreads, L.stream, startbits, nwords, total, nsub, ord_base, n_pieces, piece_offs);
+    TKZ_LAUNCH(k_doc_piece, grid_for(n_docs + 1), kThreads, L.stream, d_offs, n_docs, total, startbits, ord_base, n_pieces, doc_piece);
+}
+int64_t dec_tiles(int64_t total_ids) { return cdiv(total_ids, kDecTile); }
+void launch_dec_len(const Launch& L, const TkzDecodeTable& D, const int32_t* ids, int64_t total, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum) {
+    TKZ_LAUNCH(k_dec_len, cdiv(ntiles, kThreads / 64), kThreads, L.stream, D, ids, total, ntiles, grp_prefix, tile_sum);
+}
+void launch_dec_write(const Launch& L, const TkzDecodeTable& D, const int32_t* ids, int64_t total, int64_t ntiles, const int64_t* tile_base, uint8_t* out,
+                      int64_t out_cap, const int64_t* id_offs, int64_t n_docs, const int32_t* grp_prefix, const int64_t* grand, int64_t* byte_offs, int32_t* counters) {
+    TKZ_LAUNCH(k_dec_write, cdiv(ntiles, kThreads / 64), kThreads, L.stream, D, ids, total, ntiles, tile_base, out, out_cap);
+    TKZ_LAUNCH(k_dec_docoffs, grid_for(n_docs + 1), kThreads, L.stream, D, ids, total, id_offs, n_docs, tile_base, grp_prefix, grand, byte_offs, counters);
+}
 void launch_corpus(hipStream_t s, int kind, uint64_t seed, int64_t first_doc, int64_t n_docs, int min_len, int max_len,
                    int64_t* d_offs, uint8_t* d_bytes, int64_t cap_bytes, int64_t* d_total) {
     TKZ_LAUNCH(k_corpus_lengths, grid_for(n_docs), kThreads, s, kind, seed, first_doc, n_docs, min_len, max_len, d_offs);

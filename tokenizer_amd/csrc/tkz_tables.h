@@ -75,6 +75,16 @@ struct TkzTables {      // device pointers + masks, passed to kernels by value
     int32_t max_rank;                // largest rank in the vocabulary (kernels pack rank and position into one word when it is small)
 };
 
+// Decoder (TikTokenizer.cs:81 `Decoder = Encoder.ToDictionary(kvp => kvp.Value, kvp => kvp.Key)` + SpecialTokensDecoder): id -> bytes.
+// dense: entry k IS id k (every published vocabulary: ids are dense from 0); otherwise `ids` is sorted and searched.
+struct TkzDecodeTable {
+    const uint32_t* off;      // [n + 1] byte offsets into blob; an id without bytes has off[k] == off[k + 1]
+    const uint8_t* blob;
+    const int32_t* ids;       // [n] sorted ids (sparse form only)
+    int64_t n;
+    int32_t dense;
+};
+
 TKZ_HD uint32_t tkz_mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
     return h;

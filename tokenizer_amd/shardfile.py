@@ -10,8 +10,9 @@ compatible with; this is the packed (ids int32[], offsets int64[]) layout of the
     then          offsets  int64[n_docs + 1]   (token range of document d, relative to this shard: offsets[0] = 0)
     then          ids      int32[n_tokens]
 
-`doc_base` / `token_base` come from the one all-gather of sharded.gather_counts, so shard files of different ranks
-concatenate into the global result without any further exchange.
+`doc_base` / `token_base` come from the one all-gather of counts (tkz_shard_bases), so shard files of different ranks
+concatenate into the global result without any further exchange.  The writer is the C ABI's (tkz_shard_write /
+tkz_shard_write_device in include/tkz.h -- a C# or C++ host produces the same files); this module is the memory-mapping reader.
 """
 import struct
 
@@ -22,7 +23,7 @@ _HEADER = struct.Struct("<8sIIqqqq16x")
 assert _HEADER.size == 64
 
 
-def write_shard(path, ids, offsets, doc_base=0, token_base=0):
+def write_shard(path, ids, offsets, doc_base=0, token_base=0, lib=None):
     """ids: int32[n_tokens]; offsets: int64[n_docs + 1] with offsets[0] == 0 and offsets[-1] == n_tokens.
     Accepts numpy arrays or torch tensors (device tensors are copied to the host)."""
     if hasattr(ids, "detach"):
@@ -31,12 +32,13 @@ def write_shard(path, ids, offsets, doc_base=0, token_base=0):
         offsets = offsets.detach().cpu().numpy()
     ids = np.ascontiguousarray(ids, dtype=np.int32)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
-    if len(offsets) < 1 or offsets[0] != 0 or offsets[-1] != len(ids) or (len(offsets) > 1 and (np.diff(offsets) < 0).any()):
+    if len(offsets) < 1:
         raise ValueError("offsets must start at 0, be non-decreasing and end at the number of ids")
-    with open(path, "wb") as f:
-        f.write(_HEADER.pack(MAGIC, 1, 4, len(offsets) - 1, len(ids), int(doc_base), int(token_base)))
-        f.write(offsets.tobytes())
-        f.write(ids.tobytes())
+    from . import _native as N
+    try:
+        N.shard_write(str(path), ids, offsets, int(doc_base), int(token_base), lib=lib)       # the C ABI's writer (tkz_shard_write)
+    except N.TkzError as ex:
+        raise ValueError(str(ex))
 
 
 class Shard:

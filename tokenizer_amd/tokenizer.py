@@ -12,7 +12,7 @@ one addition (the reference has no batch API).  What runs where:
     the batch go to the GPU as one document batch (a segment is matched in isolation by the reference
     too: `Regex.Matches(text[start..end])`, TikTokenizer.cs:252);
   * the plain path (TikTokenizer.cs:250-274 + BytePairEncoder.cs:13-76) is the HIP path of libtkz;
-  * Decode is a host-side table lookup (TikTokenizer.cs:586-604), kept for round-trip checks;
+  * Decode / DecodeBatch (TikTokenizer.cs:586-604) run on the device too: an id -> bytes gather through the decoder table + a scan;
   * EncodeTrimSuffix / EncodeTrimPrefix (TikTokenizer.cs:288-579) cut at piece granularity: the GPU
     encodes every plain segment with piece granularity (tkz_encode_batch_pieces_utf8: token count and byte span of each
     regex match), the walk over pieces / special tokens that decides where to cut is host work.
@@ -98,8 +98,8 @@ class TikTokenizer:
         self.SpecialTokens = set(self.SpecialTokensEncoder)
         # alternation of the escaped literals in registration order (TikTokenizer.cs:78): leftmost match, first alternative wins
         self._special_re = re.compile("|".join(re.escape(k) for k in self.SpecialTokensEncoder)) if self.SpecialTokensEncoder else None
-        self._decoder: Optional[Dict[int, bytes]] = None
-        self._tiktoken_bytes = tikTokenBpeFile
+        if self.SpecialTokensEncoder:
+            self._encoder.set_special_tokens(self.SpecialTokensEncoder)      # SpecialTokensDecoder (TikTokenizer.cs:79), for Decode
 
     # ---- segmentation (host) ---------------------------------------------------------------------
     def _segments(self, text: str, allowed: Optional[Iterable[str]]):
@@ -244,24 +244,18 @@ class TikTokenizer:
         return token_ids[cut_tokens:], self._utf16_prefix(text, cut_len, drop=True)
 
     def Decode(self, tokens: Sequence[int]) -> str:
-        """TikTokenizer.cs:586-604: unknown ids are dropped; bytes are decoded as UTF-8."""
-        if self._decoder is None:
-            import base64
-            dec = {}
-            for line in self._tiktoken_bytes.splitlines():
-                if line.strip():
-                    k, r = line.split()
-                    dec[int(r)] = base64.b64decode(k)
-            self._decoder = dec
-            self._special_decoder = {v: k.encode("utf-8") for k, v in self.SpecialTokensEncoder.items()}
-        parts = []
-        for t in tokens:
-            b = self._decoder.get(t)
-            if b is None:
-                b = self._special_decoder.get(t)
-            if b is not None:
-                parts.append(b)
-        return b"".join(parts).decode("utf-8", "replace")
+        """TikTokenizer.cs:586-604: ids that are neither in the vocabulary nor special tokens are dropped; the bytes are decoded as
+        UTF-8 (Encoding.UTF8.GetString: malformed sequences become U+FFFD)."""
+        return self.DecodeBatch([tokens])[0]
+
+    def DecodeBatch(self, batches: Sequence[Sequence[int]]) -> List[str]:
+        """Decode for a batch, on the device (tkz_decode_batch: id -> bytes gather through the decoder table + scan)."""
+        flat = np.asarray([t for b in batches for t in b], dtype=np.int64)
+        flat = np.where((flat < -2**31) | (flat >= 2**31), -1, flat).astype(np.int32)      # (an id outside int is in no table)
+        offs = np.cumsum([0] + [len(b) for b in batches]).astype(np.int64)
+        data, boffs = self._encoder.decode_batch(flat, offs)
+        raw = data.tobytes()
+        return [raw[boffs[d]:boffs[d + 1]].decode("utf-8", "replace") for d in range(len(batches))]
 
     # the raw device encoder, for callers that hold documents in HBM (bench.py)
     @property
