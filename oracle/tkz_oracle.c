@@ -28,6 +28,25 @@ static void cls_init(void) {
     for (size_t i = 0; i < sizeof k_ranges / sizeof k_ranges[0]; ++i)
         for (unsigned u = k_ranges[i].a; u <= k_ranges[i].b; ++u) g_cls[u] = k_ranges[i].c;
 }
+/* Supplementary planes, by code point: used ONLY for o200k, the one pattern that exists only in the TypeScript reference and is
+ * compiled there with `new RegExp(pattern, "gu")` (tokenizer_ts/src/tikTokenizer.ts:100): code-point matching, one class test per
+ * CHARACTER.  The two patterns the C# reference defines keep .NET's code-unit matching (a supplementary char = two OTHER units). */
+static const struct { uint32_t a, b; uint8_t c; } k_supp[] = {
+#include "unicode13_supp.inc"
+};
+static uint8_t supp_class(uint32_t cp) {
+    size_t lo = 0, hi = sizeof k_supp / sizeof k_supp[0];
+    while (lo < hi) { size_t mid = (lo + hi) / 2; if (k_supp[mid].b < cp) lo = mid + 1; else hi = mid; }
+    return (lo < sizeof k_supp / sizeof k_supp[0] && k_supp[lo].a <= cp) ? k_supp[lo].c : C_OTHER;
+}
+/* class of a code point under the ECMAScript `u`-flag semantics of the o200k pattern: Unicode categories as above, but \s is
+ * ECMAScript's WhiteSpace + LineTerminator = [\t\n\v\f\r \u00a0\ufeff\p{Zs}\u2028\u2029]: U+FEFF IS white space, U+0085 is NOT
+ * (it is Cc, hence [^\s\p{L}\p{N}]).  A lone surrogate (possible only through the UTF-16 entry) is Cs: OTHER. */
+static uint8_t js_class(uint32_t cp) {
+    if (cp == 0xFEFF) return C_WS;
+    if (cp == 0x85) return C_OTHER;
+    return cp < 0x10000 ? g_cls[cp] : supp_class(cp);
+}
 static inline int isL(uint8_t c) { return c >= C_LU && c <= C_LO; }
 static inline int isN(uint8_t c) { return c == C_N; }
 static inline int isWS(uint8_t c) { return c == C_WS; }
@@ -297,8 +316,8 @@ int64_t tkzo_bpe(const tkzo_vocab* v, const uint8_t* bytes, int64_t n, int32_t* 
 /* The split regexes, as a leftmost-first backtracking matcher over UTF-16 code units.         */
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
-    const uint16_t* u;   /* code units */
-    const uint8_t* c;    /* class per unit */
+    const uint32_t* u;   /* the text as the regex engine sees it: UTF-16 code units (pattern 1, cl100k: .NET) or code points (o200k: JS /u) */
+    const uint8_t* c;    /* class per unit / code point */
     int64_t n;
 } utext;
 
@@ -321,7 +340,7 @@ static int64_t m_contraction(const utext* t, int64_t p, int mode) {
     if (p >= t->n || U(p) != '\'') return -1;
     int64_t r = t->n - p - 1;
     if (r < 1) return -1;
-    int a = U(p + 1), b = r >= 2 ? U(p + 2) : -1;
+    int a = (int)U(p + 1), b = r >= 2 ? (int)U(p + 2) : -1;
     if (a > 127) return -1;
     if (mode == 0) {
         if (a == 's' || a == 't') return p + 2;
@@ -486,9 +505,9 @@ static void split_units(int pattern, const utext* t, piece_fn fn, void* ctx) {
 
 /* UTF-8 (valid) -> UTF-16 units + classes + byte offset of each unit (the low half of a pair maps
  * to the same byte offset as the high half; no shipped pattern can split a pair). */
-typedef struct { uint16_t* u; uint8_t* c; int64_t* off; int64_t n; } u16buf;
-static int utf8_to_units(const uint8_t* s, int64_t n, u16buf* b) {
-    b->u = (uint16_t*)malloc((size_t)(n + 1) * sizeof(uint16_t));
+typedef struct { uint32_t* u; uint8_t* c; int64_t* off; int64_t n; } u16buf;
+static int utf8_to_units(const uint8_t* s, int64_t n, u16buf* b, int by_code_point) {
+    b->u = (uint32_t*)malloc((size_t)(n + 1) * sizeof(uint32_t));
     b->c = (uint8_t*)malloc((size_t)(n + 1));
     b->off = (int64_t*)malloc((size_t)(n + 2) * sizeof(int64_t));
     int64_t i = 0, k = 0;
@@ -511,12 +530,14 @@ static int utf8_to_units(const uint8_t* s, int64_t n, u16buf* b) {
             if ((len == 3 && (cp < 0x800 || (cp >= 0xD800 && cp <= 0xDFFF))) ||
                 (len == 4 && (cp < 0x10000 || cp > 0x10FFFF))) return TKZO_E_UTF8;
         }
-        if (cp < 0x10000) {
-            b->u[k] = (uint16_t)cp; b->c[k] = g_cls[cp]; b->off[k] = i; ++k;
+        if (by_code_point) {
+            b->u[k] = cp; b->c[k] = js_class(cp); b->off[k] = i; ++k;
+        } else if (cp < 0x10000) {
+            b->u[k] = cp; b->c[k] = g_cls[cp]; b->off[k] = i; ++k;
         } else {
             cp -= 0x10000;
-            b->u[k] = (uint16_t)(0xD800 + (cp >> 10)); b->c[k] = C_OTHER; b->off[k] = i; ++k;
-            b->u[k] = (uint16_t)(0xDC00 + (cp & 0x3FF)); b->c[k] = C_OTHER; b->off[k] = i; ++k;
+            b->u[k] = 0xD800 + (cp >> 10); b->c[k] = C_OTHER; b->off[k] = i; ++k;
+            b->u[k] = 0xDC00 + (cp & 0x3FF); b->c[k] = C_OTHER; b->off[k] = i; ++k;
         }
         i += len;
     }
@@ -524,6 +545,26 @@ static int utf8_to_units(const uint8_t* s, int64_t n, u16buf* b) {
     return TKZO_OK;
 }
 static void u16buf_free(u16buf* b) { free(b->u); free(b->c); free(b->off); }
+
+/* UTF-16 units -> what the engine sees + the unit offset of each entry: the units themselves (.NET), or -- by code point -- a
+ * well-formed surrogate pair as ONE entry and a lone surrogate as one entry of class OTHER (Cs). */
+static void units_to_text(const uint16_t* text, int64_t n, u16buf* b, int by_code_point) {
+    b->u = (uint32_t*)malloc((size_t)(n + 1) * sizeof(uint32_t));
+    b->c = (uint8_t*)malloc((size_t)(n + 1));
+    b->off = (int64_t*)malloc((size_t)(n + 2) * sizeof(int64_t));
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t x = text[i];
+        b->off[k] = i;
+        if (by_code_point && x >= 0xD800 && x <= 0xDBFF && i + 1 < n && text[i + 1] >= 0xDC00 && text[i + 1] <= 0xDFFF) {
+            x = 0x10000 + ((x - 0xD800) << 10) + (text[i + 1] - 0xDC00); ++i;
+            b->u[k] = x; b->c[k] = js_class(x);
+        } else if (x >= 0xD800 && x <= 0xDFFF) { b->u[k] = x; b->c[k] = C_OTHER; }
+        else { b->u[k] = x; b->c[k] = by_code_point ? js_class(x) : g_cls[x]; }
+        ++k;
+    }
+    b->off[k] = n; b->n = k;
+}
 
 typedef struct { int64_t* starts; int64_t* lens; int64_t cap, count; const int64_t* off; } collect_ctx;
 static void collect_piece(void* vc, int64_t us, int64_t ul) {
@@ -537,7 +578,7 @@ static void collect_piece(void* vc, int64_t us, int64_t ul) {
 int64_t tkzo_split_utf8(int pattern, const uint8_t* text, int64_t n, int64_t* starts,
                         int64_t* lens, int64_t cap) {
     pthread_once(&g_cls_once, cls_init);
-    u16buf b; int r = utf8_to_units(text, n, &b);
+    u16buf b; int r = utf8_to_units(text, n, &b, pattern == TKZO_PATTERN_O200K);
     if (r) { u16buf_free(&b); return r; }
     utext t = { b.u, b.c, b.n };
     collect_ctx c = { starts, lens, cap, 0, b.off };
@@ -548,12 +589,11 @@ int64_t tkzo_split_utf8(int pattern, const uint8_t* text, int64_t n, int64_t* st
 int64_t tkzo_split_utf16(int pattern, const uint16_t* text, int64_t n, int64_t* starts,
                          int64_t* lens, int64_t cap) {
     pthread_once(&g_cls_once, cls_init);
-    uint8_t* cls = (uint8_t*)malloc((size_t)n + 1);
-    for (int64_t i = 0; i < n; ++i) cls[i] = g_cls[text[i]];
-    utext t = { text, cls, n };
-    collect_ctx c = { starts, lens, cap, 0, NULL };
+    u16buf b; units_to_text(text, n, &b, pattern == TKZO_PATTERN_O200K);
+    utext t = { b.u, b.c, b.n };
+    collect_ctx c = { starts, lens, cap, 0, b.off };
     split_units(pattern, &t, collect_piece, &c);
-    free(cls);
+    u16buf_free(&b);
     return c.count;
 }
 
@@ -682,7 +722,7 @@ static void encode_piece_u8(void* vc, int64_t us, int64_t ul) {
 /* Encode(text, tokenIds, start, end) over a UTF-8 segment */
 static int64_t encode_segment_utf8(tkzo_encoder* e, const uint8_t* text, int64_t n, int32_t* out, int64_t cap) {
     if (n == 0) return 0;
-    u16buf b; int r = utf8_to_units(text, n, &b);
+    u16buf b; int r = utf8_to_units(text, n, &b, e->pattern == TKZO_PATTERN_O200K);
     if (r) { u16buf_free(&b); return r; }
     utext t = { b.u, b.c, b.n };
     enc_ctx c = { e, text, b.off, out, cap, 0, 0 };
@@ -697,8 +737,9 @@ int64_t tkzo_encode_utf8(tkzo_encoder* e, const uint8_t* text, int64_t n, int32_
 /* UTF-16 entry: the regex sees the units as they are; each piece goes through
  * Encoding.UTF8.GetBytes (TikTokenizer.cs:261), which writes EF BF BD for a lone surrogate. */
 typedef struct { enc_ctx base; const uint16_t* u; uint8_t* tmp; int64_t tmpcap; } enc16_ctx;
-static void encode_piece_u16(void* vc, int64_t us, int64_t ul) {
+static void encode_piece_u16(void* vc, int64_t es, int64_t el) {
     enc16_ctx* c = (enc16_ctx*)vc;
+    const int64_t us = c->base.off[es], ul = c->base.off[es + el] - us;      /* entries -> code units */
     if (c->tmpcap < ul * 3 + 4) { c->tmpcap = ul * 6 + 64; c->tmp = (uint8_t*)realloc(c->tmp, (size_t)c->tmpcap); }
     int64_t o = 0;
     for (int64_t i = us; i < us + ul; ++i) {
@@ -715,13 +756,12 @@ static void encode_piece_u16(void* vc, int64_t us, int64_t ul) {
 }
 int64_t tkzo_encode_utf16(tkzo_encoder* e, const uint16_t* text, int64_t n, int32_t* out, int64_t cap) {
     if (n == 0) return 0;
-    uint8_t* cls = (uint8_t*)malloc((size_t)n + 1);
-    for (int64_t i = 0; i < n; ++i) cls[i] = g_cls[text[i]];
-    utext t = { text, cls, n };
+    u16buf b; units_to_text(text, n, &b, e->pattern == TKZO_PATTERN_O200K);
+    utext t = { b.u, b.c, b.n };
     enc16_ctx c; memset(&c, 0, sizeof c);
-    c.base.e = e; c.base.out = out; c.base.cap = cap; c.u = text;
+    c.base.e = e; c.base.out = out; c.base.cap = cap; c.base.off = b.off; c.u = text;
     split_units(e->pattern, &t, encode_piece_u16, &c);
-    free(cls); free(c.tmp);
+    u16buf_free(&b); free(c.tmp);
     return c.base.err ? c.base.err : c.base.n;
 }
 

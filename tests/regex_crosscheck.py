@@ -30,15 +30,21 @@ O2_SRC = "|".join([
 ])
 
 
-def _compile(src):
-    # write \s inside and outside classes as the explicit .NET whitespace set
+# o200k is matched by CODE POINT with ECMAScript's \s (tokenizer_ts/src/tikTokenizer.ts:100: `new RegExp(pattern, "gu")`):
+# WhiteSpace + LineTerminator = TAB VT FF SP NBSP ZWNBSP(U+FEFF) \p{Zs} LF CR LS PS.  U+0085 is not in it.
+JS_WS_IN = r"\t-\r \xa0\ufeff\p{Zs}\u2028\u2029"
+
+
+def _compile(src, ws_in=r"\t-\r \x85\p{Z}"):
+    # write \s inside and outside classes as an explicit set (.NET's by default)
+    WS, NWS = "[" + ws_in + "]", "[^" + ws_in + "]"
     out, i, depth = [], 0, 0
     while i < len(src):
         ch = src[i]
         if ch == "\\" and i + 1 < len(src):
             nx = src[i + 1]
             if nx == "s":
-                out.append(r"\t-\r \x85\p{Z}" if depth else WS)
+                out.append(ws_in if depth else WS)
                 i += 2
                 continue
             if nx == "S":
@@ -58,7 +64,7 @@ def _compile(src):
     return regex.compile("".join(out), regex.V0)
 
 
-PATTERNS = {1: _compile(P1_SRC), 2: _compile(CL_SRC), 3: _compile(O2_SRC)}
+PATTERNS = {1: _compile(P1_SRC), 2: _compile(CL_SRC), 3: _compile(O2_SRC, JS_WS_IN)}
 
 
 def to_units(s: str):
@@ -68,8 +74,24 @@ def to_units(s: str):
 
 
 def split_units_regex(pattern_id: int, units):
-    s = "".join(map(chr, units))
-    return [(m.start(), m.end() - m.start()) for m in PATTERNS[pattern_id].finditer(s)]
+    """(start, length) in UTF-16 units of every match.  Patterns 1 / cl100k: the engine is fed the code units themselves (.NET);
+    o200k: code points -- a well-formed surrogate pair is one character, a lone surrogate stays a lone (Cs) code point."""
+    if pattern_id != 3:
+        s = "".join(map(chr, units))
+        return [(m.start(), m.end() - m.start()) for m in PATTERNS[pattern_id].finditer(s)]
+    chars, at = [], []
+    i = 0
+    while i < len(units):
+        u = units[i]
+        at.append(i)
+        if 0xD800 <= u <= 0xDBFF and i + 1 < len(units) and 0xDC00 <= units[i + 1] <= 0xDFFF:
+            chars.append(chr(0x10000 + ((u - 0xD800) << 10) + (units[i + 1] - 0xDC00)))
+            i += 2
+        else:
+            chars.append(chr(u))
+            i += 1
+    at.append(len(units))
+    return [(at[m.start()], at[m.end()] - at[m.start()]) for m in PATTERNS[3].finditer("".join(chars))]
 
 
 def _agree(cp):
@@ -95,8 +117,10 @@ def alphabet():
              0x2B50, 0x2764, 0xFE0F, 0x200D, 0x0301, 0x0300, 0x093F, 0x01C5, 0x02B0, 0x00AA, 0x00B2, 0x2160, 0x3007,
              0x00DF, 0x0130, 0x0131, 0xFF21, 0xFF41, 0xFF10, 0x1F600, 0x1F468, 0x1F3FD, 0x20000, 0x1D7D8, 0x10400,
              0xFFFD, 0x00B7, 0x2019, 0x201C, 0x00AD, 0x0E01, 0x0E31]
+    # supplementary-plane letters / digits / marks (o200k sees their classes; .NET sees two OTHER units) and ECMAScript's \s edge cases
+    extra += [0x1D400, 0x1D7CE, 0x1D7CF, 0x10428, 0x1E900, 0x1E922, 0x16F93, 0x2A700, 0x1F1E6, 0x101FD, 0x1D165, 0x10107, 0xFEFF, 0x2028, 0x1680]
     for cp in extra:
-        if cp >= 0x10000 or _agree(cp):
+        if _agree(cp):
             base.append(chr(cp))
     return base
 

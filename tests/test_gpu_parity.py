@@ -62,6 +62,30 @@ def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
                         doc_lens=[0, 1, 7, 63, 64, 65, 127, 128, 129, 200, 1000, 5000, 9000, 40000], n_docs_choices=(1, 3, 20, 200))
 
 
+@pytest.mark.parametrize("sequential", [0, 1])
+def test_hand_derived_splits(lib, vocab, sequential):
+    """The device pre-tokenizers against expected pieces written by hand from the regex semantics (tests/hand_splits.py)."""
+    from hand_splits import HAND_SPLITS
+    encs = {}
+    for pat, text, exp in HAND_SPLITS:
+        if pat not in encs:
+            encs[pat] = N.Encoder(vocab, pat)
+            encs[pat].set_option(N.OPT_PRETOK_SEQUENTIAL, sequential)
+        b = text.encode("utf-8")
+        # once alone, once embedded in a longer ASCII document (the block scanners need full rows to engage)
+        # (the separator before the case must not join its first piece: a digit before white space, a newline before anything else)
+        sep = b"7" if (text[0].isspace() or text[0] in "\x85\ufeff") else b"\n"
+        for pre, post in ((b"", b""), (b"lorem ipsum dolor sit amet " * 12 + sep, b"\n" + b"consectetur adipiscing elit " * 12)):
+            doc = pre + b + post
+            got = encs[pat].pretokenize(np.frombuffer(doc, np.uint8), np.array([0, len(doc)]))
+            starts = [int(i) - len(pre) for i in np.nonzero(got[:len(doc)])[0] if len(pre) <= i < len(pre) + len(b)]
+            exp_starts, pos = [], 0
+            for piece in exp:
+                exp_starts.append(pos)
+                pos += len(piece.encode("utf-8"))
+            assert starts == exp_starts, (pat, text, bool(pre))
+
+
 @pytest.mark.parametrize("pattern", [1, 2, 3])
 def test_pretok_long_runs(lib, vocab, oracle_mod, pattern):
     # runs that cross rows and whole 4 KiB blocks: the lane scans and the beyond-the-block searches of the block scanners

@@ -80,3 +80,16 @@ def test_downloaded_vocab_vectors(oracle_mod, lib_rs_bytes, vocab, pattern, fixt
     v = oracle_mod.Vocab(open(p, "rb").read())
     enc = oracle_mod.Encoder(v, pattern)
     assert enc.encode_bytes(lib_rs_bytes) == load_golden_json(fixture)
+
+
+def test_hand_derived_splits(oracle_mod):
+    """Expected pieces written by hand from the regex semantics (tests/hand_splits.py), not produced by any implementation."""
+    from hand_splits import HAND_SPLITS
+    for pat, text, exp in HAND_SPLITS:
+        b = text.encode("utf-8")
+        got = [b[a:a + n].decode("utf-8") for a, n in oracle_mod.split_utf8(pat, b)]
+        assert got == exp, (pat, text)
+        units = list(text.encode("utf-16-le"))
+        units = [units[i] | (units[i + 1] << 8) for i in range(0, len(units), 2)]
+        got16 = [bytes(x for u in units[a:a + n] for x in (u & 255, u >> 8)).decode("utf-16-le") for a, n in oracle_mod.split_utf16(pat, units)]
+        assert got16 == exp, (pat, text, "utf16")

@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "lib", "libtkz.so")
+# ($TKZ_LIBTKZ: development only -- e.g. the `make DEVPROF=1 OUT=../lib_dev` build with per-stage cycle counters)
+DEFAULT_LIB = os.environ.get("TKZ_LIBTKZ") or os.path.join(_HERE, "lib", "libtkz.so")
 
 OK = 0
 E_FORMAT, E_DUP_RANK, E_KEY_NOT_FOUND, E_CAPACITY, E_INVALID_UTF8, E_ARG, E_UNSUPPORTED, E_DEVICE, E_NO_DEVICE, E_OUT_OF_MEMORY = range(-1, -11, -1)

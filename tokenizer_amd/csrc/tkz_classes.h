@@ -1,6 +1,6 @@
 // tkz_classes.h -- character classes of the split regexes, evaluated on UTF-8 bytes.
 //
-// The reference matches with System.Text.RegularExpressions over UTF-16 code units
+// Pattern 1 and cl100k: the reference matches with System.Text.RegularExpressions over UTF-16 code units
 // (Tokenizer_C#/TokenizerLib/TikTokenizer.cs:77,252): every class test looks at ONE unit, a surrogate
 // half is category Cs.  A code point >= 0x10000 is therefore two "other" units; on UTF-8 data that
 // is a 4-byte sequence whose char is class OTHER and which can never be the one-unit optional
@@ -58,6 +58,27 @@ TKZ_HD TkzChar tkz_decode(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, co
 }
 
 TKZ_HD bool tkz_uc_is_letter(uint8_t uc) { return uc >= UC_LU && uc <= UC_LO; }
+
+// ---- o200k: CODE-POINT semantics ---------------------------------------------------------------
+// o200k exists only in the TypeScript reference, which compiles the pattern with `new RegExp(pattern, "gu")`
+// (tokenizer_ts/src/tikTokenizer.ts:100; the C# builder does not know the encoding, TokenizerBuilder.cs:109-181): one class test
+// per CHARACTER -- a supplementary-plane char has its own Unicode class, can be the optional one-char prefix and counts once
+// toward \p{N}{1,3} -- and \s is ECMAScript's WhiteSpace + LineTerminator: U+FEFF is white space, U+0085 is not.
+// The class table in HBM is bmp_class[65536] followed by {uint32 n, uint32 0, n x {first, last | class << 24}} for the code points
+// above the BMP (sorted; Unicode 13.0 like the BMP table).
+TKZ_HD uint8_t tkz_supp_class(const uint8_t* ucd, uint32_t cp) {
+    const uint32_t* t = reinterpret_cast<const uint32_t*>(ucd + 65536);
+    uint32_t lo = 0, hi = t[0];
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((t[3 + 2 * mid] & 0xFFFFFFu) < cp) lo = mid + 1; else hi = mid; }
+    return (lo < t[0] && t[2 + 2 * lo] <= cp) ? (uint8_t)(t[3 + 2 * lo] >> 24) : (uint8_t)UC_OTHER;
+}
+// what the o200k matcher sees: `units` becomes 1 for every well-formed char ("one class test per char")
+TKZ_HD void tkz_char_to_code_point_semantics(TkzChar& c, const uint8_t* ucd) {
+    if (c.bad) return;
+    if (c.units == 2) { c.uc = tkz_supp_class(ucd, c.cp); c.units = 1; }
+    else if (c.cp == 0xFEFFu) c.uc = UC_WS;
+    else if (c.cp == 0x85u) c.uc = UC_OTHER;
+}
 
 // ---- classes of pattern 1 / cl100k (TokenizerBuilder.cs:112,128): one small code per char --------
 //   PC_O1   [^\s\p{L}\p{N}], one UTF-16 unit          PC_O2  the same, two units (supplementary plane)

@@ -201,7 +201,7 @@ TKZ_KERNEL(256) void k_pretok_seq_blocks(const uint8_t* bytes, const int64_t* of
         for (int64_t d = simt::bid() * simt::nthreads() + simt::tid(); d < n_docs; d += stride) {
             const int64_t a = offs[d], e = offs[d + 1];
             if (e <= a || a < 0 || e > total) continue;
-            TkzDoc doc; doc.b = bytes + a; doc.n = e - a; doc.bmp = bmp;
+            TkzDoc doc; doc.b = bytes + a; doc.n = e - a; doc.bmp = bmp; doc.by_code_point = pattern == TKZ_PAT_O200K;
             int bad = 0;
             for (int64_t v = 0; v < doc.n;) { const TkzChar ch = tkz_doc_char(doc, v); bad |= ch.bad; v += ch.len; }
             if (bad) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrUtf8); continue; }
@@ -223,7 +223,7 @@ TKZ_KERNEL(256) void k_pretok_seq_blocks(const uint8_t* bytes, const int64_t* of
         for (int64_t d = lo; d < n_docs && offs[d] < b1; ++d) {
             const int64_t a = offs[d], e = offs[d + 1];
             if (e <= a || a < 0 || e > total) continue;
-            TkzDoc doc; doc.b = bytes + a; doc.n = e - a; doc.bmp = bmp;
+            TkzDoc doc; doc.b = bytes + a; doc.n = e - a; doc.bmp = bmp; doc.by_code_point = pattern == TKZ_PAT_O200K;
             int64_t p = 0;
             if (a < b0) {                                 // the document starts before the block: look for a sync point
                 int64_t i = b0 - a;
@@ -256,7 +256,7 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
     for (int64_t d = simt::bid() * simt::nthreads() + simt::tid(); d < n_docs; d += stride) {
         const int64_t a = offs[d], b = offs[d + 1];
         if (b <= a || a < 0 || b > total) continue;       // (bad offsets are reported by k_docmark)
-        TkzDoc doc; doc.b = bytes + a; doc.n = b - a; doc.bmp = bmp;
+        TkzDoc doc; doc.b = bytes + a; doc.n = b - a; doc.bmp = bmp; doc.by_code_point = pattern == TKZ_PAT_O200K;
         int bad = 0;
         for (int64_t p = 0; p < doc.n;) { const TkzChar c = tkz_doc_char(doc, p); bad |= c.bad; p += c.len; }
         if (bad) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrUtf8); continue; }

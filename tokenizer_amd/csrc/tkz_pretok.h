@@ -26,11 +26,13 @@ enum { TKZ_PAT_P1 = 1, TKZ_PAT_CL100K = 2, TKZ_PAT_O200K = 3 };
 // =================================================================================================
 // (1) sequential matcher
 // =================================================================================================
-struct TkzDoc { const uint8_t* b; int64_t n; const uint8_t* bmp; };
+struct TkzDoc { const uint8_t* b; int64_t n; const uint8_t* bmp; int by_code_point; };   // by_code_point: o200k (tkz_classes.h)
 
 TKZ_HD uint32_t tkz_doc_byte(const TkzDoc& d, int64_t p) { return p < d.n ? d.b[p] : 0u; }
 TKZ_HD TkzChar tkz_doc_char(const TkzDoc& d, int64_t p) {
-    return tkz_decode(d.b[p], tkz_doc_byte(d, p + 1), tkz_doc_byte(d, p + 2), tkz_doc_byte(d, p + 3), d.bmp);
+    TkzChar c = tkz_decode(d.b[p], tkz_doc_byte(d, p + 1), tkz_doc_byte(d, p + 2), tkz_doc_byte(d, p + 3), d.bmp);
+    if (d.by_code_point) tkz_char_to_code_point_semantics(c, d.bmp);
+    return c;
 }
 TKZ_HD int64_t tkz_prev_char(const TkzDoc& d, int64_t p, int64_t lo) {   // start of the char that ends at p
     int64_t s = p - 1;

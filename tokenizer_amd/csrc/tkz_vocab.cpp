@@ -65,11 +65,21 @@ inline uint32_t load_dword(const std::string& k, size_t off) {
 
 }  // namespace
 
+const struct { uint32_t a, b; uint8_t c; } kSuppRanges[] = {
+#include "unicode13_supp.inc"
+};
+
+// bmp_class[65536], then the supplementary-plane ranges the o200k (code-point) matcher searches: {n, 0, n x {first, last | class << 24}}
 const std::vector<uint8_t>& bmp_class_table() {
     static const std::vector<uint8_t> table = [] {
-        std::vector<uint8_t> t(65536, UC_OTHER);
+        const size_t ns = sizeof kSuppRanges / sizeof kSuppRanges[0];
+        std::vector<uint8_t> t(65536 + 8 + 8 * ns, UC_OTHER);
         for (const auto& r : kRanges)
             for (unsigned u = r.a; u <= r.b; ++u) t[u] = r.c;
+        std::vector<uint32_t> w;
+        w.push_back(uint32_t(ns)); w.push_back(0);
+        for (const auto& r : kSuppRanges) { w.push_back(r.a); w.push_back(r.b | (uint32_t(r.c) << 24)); }
+        memcpy(t.data() + 65536, w.data(), w.size() * 4);
         return t;
     }();
     return table;
