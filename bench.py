@@ -150,7 +150,15 @@ def main():
         return box[0]
     comm, comm_info = None, None
     try:
-        comm = sharded.RcclCounts(rank, world, local_rank, exchange)
+        # (RCCL prints a version banner on file descriptor 1 when a communicator is created: keep stdout for the ONE JSON line)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = sharded.RcclCounts(rank, world, local_rank, exchange)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         comm_info = comm.info()
     except Exception as ex:
         if world > 1:

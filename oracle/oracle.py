@@ -193,7 +193,9 @@ def encode_batch(vocab: Vocab, pattern: int, data: np.ndarray, offsets: np.ndarr
     data = np.ascontiguousarray(data, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     n = len(offsets) - 1
-    out = np.empty(max(1, len(data)), dtype=np.int32)
+    # zeros, not empty: the pages are touched here, outside the timed call (256 threads first-touching 4 bytes per input byte
+    # serialise on the kernel's mm lock and the figure would measure page faults)
+    out = np.zeros(max(1, len(data)), dtype=np.int32)
     counts = np.zeros(max(1, n), dtype=np.int32)
     import time
     t0 = time.perf_counter()

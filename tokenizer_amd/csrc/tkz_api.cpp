@@ -71,7 +71,7 @@ struct CounterBlock {          // mirrors the 64-byte device block
     int64_t ndocstarts;
     unsigned long long heavy_count;
     unsigned long long xcount;
-    int64_t pad2[1];
+    int64_t npieces;
 };
 
 }  // namespace
@@ -88,10 +88,10 @@ struct tkz_encoder {
     bool profiling = false;
     std::mutex mu;
     // device tables
-    DevBuf t_short, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp;
+    DevBuf t_short, t_mid, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp;
     TkzTables T{};
     // workspace
-    DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_tfirst, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool, w_counts3;
+    DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool, w_counts3;
     // staging for the host-buffer entry points
     DevBuf s_bytes, s_offs, s_out, s_outoffs;
     // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
@@ -215,7 +215,12 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
     if (!d_bitmap_only) {
         HIP_TRY(e->w_tmp.ensure((size_t)(total + 64) * 4, acc));
         HIP_TRY(e->w_tcount.ensure((size_t)ntiles * 4, acc));
-        HIP_TRY(e->w_tfirst.ensure((size_t)ntiles * 8, acc));
+        HIP_TRY(e->w_pcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(e->w_pbase.ensure((size_t)ntiles * 8, acc));
+        // one 4-byte record per piece.  The number of pieces is known only after the pre-tokenizer has run (English/code text: a
+        // piece per ~4.5 bytes; the bound is a piece per byte): the buffer starts at a piece per 3 bytes, k_probe refuses to write
+        // past it, and the batch is redone once with the exact size if that was not enough
+        HIP_TRY(e->w_prank.ensure((size_t)(total / 3 + 4096) * 4, acc));
         HIP_TRY(e->w_tbase.ensure((size_t)ntiles * 8, acc));
         HIP_TRY(e->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
         HIP_TRY(e->w_doctok.ensure((size_t)((po ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
@@ -228,7 +233,7 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
     }
     if (!e->h_counters) HIP_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(CounterBlock), 0));
 
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 3; ++attempt) {
         Launch L{stream, e->profiling ? prof_hook : nullptr, e};
         int32_t* counters = e->w_counters.as<int32_t>();
         int64_t* grand = reinterpret_cast<int64_t*>(e->w_counters.as<char>() + offsetof(CounterBlock, grand));
@@ -254,7 +259,8 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             EncodeParams P{};
             P.bytes = d_bytes; P.total = total; P.startbits = startbits; P.docbits = docbits; P.nwords = nwords;
             P.offs = d_offs; P.n_docs = n_docs;
-            P.tmp = e->w_tmp.as<int32_t>(); P.tile_count = e->w_tcount.as<int32_t>(); P.tile_first = e->w_tfirst.as<int64_t>();
+            P.tmp = e->w_tmp.as<int32_t>(); P.tile_count = e->w_tcount.as<int32_t>();
+            P.prank = e->w_prank.as<int32_t>(); P.prank_cap = (int64_t)(e->w_prank.cap / 4); P.pcount = e->w_pcount.as<int32_t>(); P.pbase = e->w_pbase.as<int64_t>();
             P.docord_base = e->w_dbase.as<int64_t>(); P.doc_tok = e->w_doctok.as<int32_t>(); P.counters = counters;
             P.giant_q = e->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = e->w_gcnt.as<int32_t>();
             P.giant_count = reinterpret_cast<unsigned long long*>(e->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
@@ -286,9 +292,13 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
                 if (np > po->piece_cap) return fail(TKZ_E_CAPACITY, "piece arrays too small");
                 launch_piece_index(L, startbits, nwords, total, ntiles, e->w_dbase.as<int64_t>(), np, po->piece_boffs, d_offs, n_docs, po->doc_piece);
             }
+            // pieces that start in each sub-tile and their scan: where a sub-tile's records live in `prank`
+            int64_t* npieces = reinterpret_cast<int64_t*>(e->w_counters.as<char>() + offsetof(CounterBlock, npieces));
+            launch_doccount(L, startbits, nwords, total, ntiles, e->w_pcount.as<int32_t>());
+            launch_scan(L, e->w_pcount.as<int32_t>(), ntiles, e->w_bsum.as<int64_t>(), e->w_pbase.as<int64_t>(), npieces, -1);
             launch_encode(L, e->T, P, ntiles);
             launch_scan(L, P.tile_count, ntiles, e->w_bsum.as<int64_t>(), e->w_tbase.as<int64_t>(), grand, K_SCAN);
-            launch_gather(L, P.tmp, P.tile_count, P.tile_first, e->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
+            launch_place(L, P, e->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
             if (po) launch_docoffs(L, po->piece_boffs, po->n_pieces, total, e->w_tbase.as<int64_t>(), markbits, P.docord_base, P.doc_tok, grand, po->piece_toffs);
             else launch_docoffs(L, d_offs, n_docs, total, e->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs);
             launch_counts3(L, n_docs, total, grand, e->w_counts3.as<int64_t>());
@@ -310,7 +320,7 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
         if (err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the byte count");
         if (err & kErrUtf8) return fail(TKZ_E_INVALID_UTF8, "input is not well-formed UTF-8 (or a document boundary falls inside a character)");
         if (err & kErrTooLong) return fail(TKZ_E_UNSUPPORTED, "a single piece longer than 2^30 bytes");
-        if ((err & kErrPool) && attempt == 0) {
+        if ((err & kErrPool) && attempt < 2) {
             // scratch for the giant pieces was too small.  pool_head keeps counting past the capacity, so it holds the exact need
             // (6 int32 per byte of every giant piece of the batch): size the pool for that -- not for the whole batch -- and rerun
             const size_t need = (size_t)e->h_counters->pool_head * 4 + 4096;
@@ -319,6 +329,13 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             continue;
         }
         if (err & kErrPool) return fail(TKZ_E_OUT_OF_MEMORY, "long-piece scratch exhausted");
+        if ((err & kErrCapacity) && attempt < 2) {          // more pieces than the record buffer was sized for: the exact count is known now
+            const size_t need = ((size_t)e->h_counters->npieces + 4096) * 4;
+            if (e->w_prank.ensure(need, acc) != hipSuccess)
+                return fail(TKZ_E_OUT_OF_MEMORY, "piece records: " + std::to_string(need) + " bytes could not be allocated");
+            continue;
+        }
+        if (err & kErrCapacity) return fail(TKZ_E_DEVICE, "piece record buffer overflow");
         if (err & kErrKeyNotFound) return fail(TKZ_E_KEY_NOT_FOUND, "a byte of the input is not in the vocabulary (KeyNotFoundException in the reference)");
         if (!d_bitmap_only) {
             if (total_tokens) *total_tokens = e->h_counters->grand;
@@ -433,6 +450,7 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     const tkz::Vocab& V = v->v;
     hipError_t h = hipSuccess;
     if (h == hipSuccess) h = upload(e->t_short, V.short_slots, acc);
+    if (h == hipSuccess) h = upload(e->t_mid, V.mid_slots, acc);
     if (h == hipSuccess) h = upload(e->t_long, V.long_slots, acc);
     if (h == hipSuccess) h = upload(e->t_blob, V.long_blob, acc);
     if (h == hipSuccess) h = upload(e->t_pair, V.pair_slots, acc);
@@ -440,10 +458,11 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     if (h == hipSuccess) h = upload(e->t_bpair, V.bytepair_rank, acc);
     if (h == hipSuccess) h = upload(e->t_bmp, tkz::bmp_class_table(), acc);
     if (h != hipSuccess) { tkz_encoder_destroy(e); return fail(TKZ_E_DEVICE, std::string("table upload: ") + hipGetErrorString(h)); }
-    e->T.short_slots = e->t_short.as<TkzShortSlot>(); e->T.short_mask = (uint32_t)V.short_slots.size() - 1; e->T.short_seed = V.short_seed;
+    e->T.short_slots = e->t_short.as<TkzShortSlot>(); e->T.short_nb = (uint32_t)(V.short_slots.size() / 2); e->T.short_seed = V.short_seed;
+    e->T.mid_slots = e->t_mid.as<TkzMidSlot>();       e->T.mid_ns = (uint32_t)V.mid_slots.size(); e->T.mid_seed = V.mid_seed;
     e->T.long_slots = e->t_long.as<TkzLongSlot>();    e->T.long_mask = (uint32_t)V.long_slots.size() - 1;
     e->T.long_blob = e->t_blob.as<uint8_t>();
-    e->T.pair_slots = e->t_pair.as<TkzPairSlot>();    e->T.pair_mask = (uint32_t)V.pair_slots.size() - 1; e->T.pair_seed = V.pair_seed; e->T.pair_compact = V.pair_compact ? 1u : 0u;
+    e->T.pair_slots = e->t_pair.as<TkzPairSlot>();    e->T.pair_n = (uint32_t)V.pair_slots.size(); e->T.pair_seed = V.pair_seed; e->T.pair_compact = V.pair_compact ? 1u : 0u;
     e->T.byte_rank = e->t_byte.as<int32_t>();
     e->T.bytepair_rank = e->t_bpair.as<int32_t>();
     e->T.bmp_class = e->t_bmp.as<uint8_t>();
@@ -462,8 +481,8 @@ void tkz_encoder_destroy(tkz_encoder* e) {
     if (!e) return;
     DeviceScope scope;
     (void)scope.enter(e->device);
-    DevBuf* bufs[] = {&e->t_short, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp,
-                      &e->w_gq, &e->w_gcnt, &e->w_xq, &e->w_heavyq, &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_tfirst, &e->w_tbase, &e->w_bsum,
+    DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp,
+                      &e->w_gq, &e->w_gcnt, &e->w_xq, &e->w_heavyq, &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_prank, &e->w_pcount, &e->w_pbase, &e->w_tbase, &e->w_bsum,
                       &e->w_doctok, &e->w_dcount, &e->w_dbase, &e->w_counters, &e->w_pool, &e->w_counts3, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs,
                       &e->t_decoff, &e->t_decblob, &e->t_decids, &e->d_grp, &e->d_tsum, &e->d_tbase, &e->d_bsum, &e->d_counters, &e->d_ids, &e->d_idoffs, &e->d_out, &e->d_outoffs,
                       &e->p_boffs, &e->p_toffs, &e->p_docp,

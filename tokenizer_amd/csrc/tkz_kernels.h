@@ -11,13 +11,9 @@ namespace tkz {
 constexpr int kThreads = 256;       // workgroup size of every kernel (4 wavefronts)
 constexpr int kSub = 1024;          // bytes of corpus per wavefront of k_encode_waves (a "sub-tile")
 constexpr int kHalo = 64;           // bytes staged past the sub-tile (a short piece may straddle the edge)
-constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one-per-lane by k_encode_waves
-constexpr int kArenaDwords = 2560;  // LDS arena of k_encode_waves_heavy: the misses of a pass get 2 dwords + 1 bit per byte out of it
+constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one per lane, 64 to a wavefront, by k_merge_short
+constexpr int kArenaDwords = 2560;  // LDS arena of k_merge_long: the misses of a pass get 2 dwords + 1 bit per byte out of it
 constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (tkz_bpe_var_dwords(1024) <= kArenaDwords)
-constexpr int kPassBatches = 5;     // batches of 64 pieces whose lookups are in flight together (a 1 KiB sub-tile averages ~280 pieces)
-constexpr int kPassPieces = 64 * kPassBatches;
-constexpr int kLeanPieces = 512;    // k_encode_waves keeps this many piece positions; denser sub-tiles go to the heavy kernel
-constexpr int kMergeLanes = 32;     // misses merged per pass (one per lane); sets the LDS scratch of k_encode_waves
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan
@@ -34,9 +30,11 @@ struct EncodeParams {
     const uint8_t* bytes; int64_t total;
     const uint64_t* startbits; const uint64_t* docbits; int64_t nwords;   // 1 bit / byte, nwords = total/64 + 1
     const int64_t* offs; int64_t n_docs;                                  // n_docs + 1 document offsets
-    int32_t* tmp;                 // [total + pad] tokens of a sub-tile, dense from the sub-tile's first piece start
+    int32_t* tmp;                 // [total + pad] tokens of a MISSED piece wait at the piece's own byte position (tokens <= bytes)
     int32_t* tile_count;          // tokens produced by each sub-tile
-    int64_t* tile_first;          // absolute byte position of each sub-tile's first piece (= its tmp origin)
+    int32_t* prank; int64_t prank_cap;   // one record per piece, in piece order (tkz_kernels.hip, "the encode stage")
+    const int32_t* pcount;        // pieces that start in each sub-tile
+    const int64_t* pbase;         // ... and their exclusive scan: first piece ordinal of each sub-tile
     const int64_t* docord_base;   // per sub-tile: number of distinct document-start positions before it
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
     int32_t* counters;            // [0] error bits
@@ -66,8 +64,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt);
 // exclusive scan int32 -> int64 (+ grand total); kid = profiling id of the bracket, or -1
 void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid);
-void launch_gather(const Launch& L, const int32_t* tmp, const int32_t* tile_count, const int64_t* tile_first,
-                   const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap);
+void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap);
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
                     const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs);
 void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3);

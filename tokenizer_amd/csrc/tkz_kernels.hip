@@ -8,12 +8,13 @@
 //   k_pretok_rows    Regex.Matches for pattern 1 / cl100k, position-parallel (tkz_pretok.h (2))
 //   k_pretok_seq     Regex.Matches for any pattern, one lane per document (tkz_pretok.h (1))
 //                    -> 1 bit per byte "a piece starts here"
-//   k_encode_waves   per 1 KiB sub-tile, one wavefront, no barriers: enumerate pieces from the bitmap,
-//                    whole-piece lookup (TikTokenizer.cs:262), BytePairEncode on a miss
-//                    (BytePairEncoder.cs:13-76), tokens written densely into the sub-tile's own span of
-//                    `tmp`; token position of every document that starts in the sub-tile
-//   k_scan_*         exclusive scan of the per-tile token counts
-//   k_gather         tmp -> out_ids at the tile's final offset (coalesced copy)
+//   k_doccount/scan  documents and pieces that start in each 1 KiB sub-tile -> ordinal bases
+//   k_probe          per sub-tile, one wavefront: enumerate pieces from the bitmap, whole-piece lookup
+//                    (TikTokenizer.cs:262) -> one 32-bit record per piece
+//   k_merge_short    BytePairEncode (BytePairEncoder.cs:13-76) of the missed pieces of <= 16 bytes, 64 per wavefront
+//   k_giant_* / k_merge_long   the missed pieces of > 1024 / 17..1024 bytes
+//   k_scan_*         exclusive scan of the per-sub-tile token counts
+//   k_place          ids stored at their final position
 //   k_docoffs        out_offsets[d] = tile base + position inside the tile
 #include "tkz_kernels.h"
 
@@ -275,19 +276,39 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_encode_waves : ONE WAVEFRONT per 1 KiB sub-tile, no workgroup barriers anywhere.
+// The encode stage: PROBE -> MERGE -> PLACE, three kernels over one array of per-piece records.
 //
-//   stage 0  the sub-tile (+ halo) goes to LDS, 16 B per lane; the 16 bitmap words are held one per lane
-//   stage 1  piece starts are compacted in order into s_pstart (ballot-free prefix: bit-sliced popcounts)
-//   then, in passes of up to 4 x 64 pieces (one piece per lane per batch, state in registers):
-//   stage A  key dwords from LDS, first probe of the whole-piece table issued for all 4 batches
-//   stage B  probes resolved; misses are compacted into s_missq
-//   stage M  BytePairEncode for the compacted misses, one per lane (a pass ends before a 65th miss);
-//            the tokens stay in the merging lane's ids[] until stage C copies them out
-//   stage C  prefix over the token counts, tokens stored densely into the sub-tile's span of `tmp`,
-//            token position recorded for every document that starts in the sub-tile
-//   A piece longer than 16 bytes ends the current pass and is merged by the whole wave (tkz_bpe_long).
+// The per-piece driver of the reference (TikTokenizer.cs:250-274) does, for every regex match: whole-piece lookup (:262), else
+// BytePairEncode (:268), then appends the ids (:256,264,269).  On the device those three steps have very different shapes --
+// 94 % of the pieces of English/code text end at the lookup, a merge is a chain of ~10 dependent table gathers, and the append
+// needs a prefix sum over everything before it -- so they are three kernels, each shaped for its own bottleneck, joined by
+//
+//   prank[p]   one 32-bit record per piece, in piece order (p = piece ordinal of the batch; sub-tile s owns [pbase[s], pbase[s+1])):
+//              hit : rank | MARK                                  (MARK: a document -- or, at piece granularity, a piece -- starts here)
+//              miss: MISS | MARK | (len-1) << 10 | relpos         (relpos: byte offset inside the 1 KiB sub-tile), GIANT if len > 1024;
+//                    after its merge: MISS | MARK | DONE | (count-1) << 10 | relpos, the tokens waiting in tmp[abs .. abs + count)
+//   tmp[b]     4 B per input byte, touched only under missed pieces: a piece's tokens fit inside its own byte span (tokens <= bytes)
+//
+//   k_probe        one wavefront per 1 KiB sub-tile, 32 wavefronts per CU (64 VGPRs, 3 KB LDS): piece enumeration from the bitmap,
+//                  SHORT / MID probes (four 16-byte gathers per piece, two batches of 64 pieces in flight), records stored coalesced
+//   k_merge_short  one wavefront per 4 sub-tiles: the misses of up to 16 bytes are packed 64 to a wavefront -- every lane merges
+//                  (tkz_bpe_lane<16>) -- instead of the ~14 of 64 a sub-tile has on its own: the wave still waits for its slowest
+//                  chain, but it waits once per 64 pieces.  Also the per-sub-tile token counts.
+//   k_giant_find / k_giant_merge, k_merge_long   the rare long ones: > 1024 bytes by a whole workgroup in rounds (tkz_bpe_long),
+//                  17..1024 bytes one per lane in an LDS arena (tkz_bpe_lane_var), only in the sub-tiles k_probe flagged
+//   (scan of the token counts)
+//   k_place        one wavefront per sub-tile: count per record -> prefix -> ids stored at their final position, token index
+//                  of every marked piece for the document offsets
+// Round 1 did all of this in one kernel per sub-tile: 96 VGPRs + 7.6 KB LDS (20 waves/CU), a merge stage with 15 of 64 lanes
+// busy, and a second, 3x slower kernel for every sub-tile that held one piece of 17+ bytes to merge -- half of all sub-tiles
+// on text with identifiers or long words.
 // -------------------------------------------------------------------------------------------------
+constexpr uint32_t kPrMiss = 1u << 31, kPrMark = 1u << 30, kPrDone = 1u << 29, kPrGiant = 1u << 28;
+constexpr uint32_t kPrRankMask = (1u << 28) - 1u;       // ranks are < 2^27 (TKZ_MAX_RANK)
+constexpr int kPrLenShift = 10;
+constexpr uint32_t kPrLenMask = 0x7FFu;                 // len - 1 / count - 1 (< 1024), in bits 10..20
+constexpr int kGroup = 4;                               // sub-tiles per wavefront of k_merge_short
+
 // exclusive prefix over the wave of a small non-negative value (< 2^BITS), and the wave total;
 // bit-sliced: one ballot + mbcnt per bit, no LDS traffic
 template <int BITS>
@@ -313,50 +334,27 @@ TKZ_DEV int tkz_wave_scan_sum(int v, int* total) {
     return x - v;
 }
 
-// HEAVY = false: the common case, sub-tiles whose pieces are all <= 16 bytes or vocabulary keys; a sub-tile with a longer
-//                 piece that has to be merged (or more than kLeanPieces pieces) is flagged in P.heavy_flag and left to the
-//                 second launch.
-// HEAVY = true:   the deferred sub-tiles: lanes merge pieces of up to 32 bytes (16 at a time, 32-entry state each:
-//                 CJK runs, emoji sequences, long identifiers), the whole wavefront merges anything longer.
-template <bool HEAVY>
-TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub);
-
-TKZ_KERNEL_OCC(64, 5) void k_encode_waves(TkzTables T, EncodeParams P) { tkz_encode_subtile<false>(T, P, simt::bid()); }
-TKZ_KERNEL_OCC(64, 3) void k_encode_waves_heavy(TkzTables T, EncodeParams P) {
-    // chunks of 64 consecutive sub-tiles per wavefront: one flag per lane, then the flagged ones in turn
-    const int lane = simt::lane();
-    for (int64_t c = simt::bid(); c * 64 < P.nsub; c += simt::nblocks()) {
-        const int64_t t = c * 64 + lane;
-        uint64_t m = simt::ballot(t < P.nsub && P.heavy_flag[t] != 0);
-        for (; m; m &= m - 1) { tkz_encode_subtile<true>(T, P, c * 64 + tkz_ctz64(m)); simt::sync(); }
-    }
+// dword i of the key that starts at byte s of the LDS-staged sub-tile, zero-padded past len
+TKZ_DEV uint32_t tkz_key_dword(const uint32_t* s_bytes, int s, int len, int i) {
+    const int w = (s >> 2) + i, sh = (s & 3) * 8;
+    const uint32_t x = (uint32_t)((((uint64_t)s_bytes[w + 1] << 32) | s_bytes[w]) >> sh);
+    const int nb = len - 4 * i;
+    return nb >= 4 ? x : (nb <= 0 ? 0u : (x & ((1u << (8 * nb)) - 1u)));
 }
 
-template <bool HEAVY>
-TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub) {
-    constexpr int NMAX = 16;                              // bytes a lean lane can merge (state in a fixed 2 x 16 dword slot)
-    constexpr int LANE_MAX = HEAVY ? kArenaPiece : kShortMax;   // pieces up to this many bytes are handled one per lane
-    constexpr int ML = HEAVY ? 64 : kMergeLanes;          // misses merged per pass (heavy: as many as fit the arena)
-    constexpr int STRIDE = TkzBpeGeom<NMAX>::kStride;
-    TKZ_SHARED uint32_t s_bytes[(kSub + kHalo) / 4];
-    TKZ_SHARED uint16_t s_pstart[(HEAVY ? kSub : kLeanPieces) + 2];
-    // lean: per merging lane ids[16] | pr[16] (lane stride kBpeLaneStride); heavy: the arena the misses of a pass share
-    TKZ_SHARED uint4 s_scr4[(HEAVY ? kArenaDwords : 2 * STRIDE * kMergeLanes) / 4];
-    TKZ_SHARED uint16_t s_missq[HEAVY ? 2 : ML + 1];      // lean: start | (len - 1) << 11 (only the misses a pass can merge are kept)
-    TKZ_SHARED uint32_t s_missq_h[HEAVY ? 64 : 1];        // heavy: start | (len - 1) << 11 | (arena offset / 4) << 21
-    TKZ_SHARED uint32_t s_minfo[ML];                      // per merged miss: lean alive mask / heavy token count (tokens stay in its state)
-    TKZ_SHARED uint64_t s_longmask[kSub / 64];
-
+TKZ_KERNEL_OCC(256, 8) void k_probe(TkzTables T, EncodeParams P) {
+    TKZ_SHARED uint32_t s_bytes_all[kThreads / 64][(kSub + kHalo) / 4];
+    TKZ_SHARED uint16_t s_pstart_all[kThreads / 64][kSub + 2];
     const int lane = simt::lane();
+    const int64_t sub = simt::bid() * (kThreads / 64) + simt::wave();
+    if (sub >= P.nsub) return;                            // (no workgroup barrier anywhere: every wavefront is on its own)
+    uint32_t* s_bytes = s_bytes_all[simt::wave()];
+    uint16_t* s_pstart = s_pstart_all[simt::wave()];
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_bytes);
     const int64_t base = sub * kSub;
     const int nb = (int)(P.total - base < kSub ? P.total - base : kSub);
-    const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_bytes);
-    uint32_t* s_scr = reinterpret_cast<uint32_t*>(s_scr4);
-    const uint8_t* gbase = P.bytes + base;                // bytes of a piece that runs past the halo come from memory
-
-    const bool prof = TKZ_DEV_FLAG(P, 16);
-    long long t_start = prof ? simt::clock() : 0, t_a = 0, t_m = 0, t_c = 0, t_01 = 0, n_round = 0, n_miss = 0;
-    // ---- stage 0 ----
+    const uint8_t* gbase = P.bytes + base;
+    // ---- the sub-tile (+ halo) goes to LDS, 16 B per lane; the bitmap words one per lane ----
     for (int i = lane; i < (kSub + kHalo) / 16; i += 64) {
         const int64_t pos = base + 16 * (int64_t)i;
         uint4 v;
@@ -368,13 +366,12 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
         }
         s_bytes[4 * i + 0] = v.x; s_bytes[4 * i + 1] = v.y; s_bytes[4 * i + 2] = v.z; s_bytes[4 * i + 3] = v.w;
     }
-    uint64_t myword = 0, mydoc = 0;                        // lanes 0..15: bitmap word / doc word of the sub-tile
+    uint64_t myword = 0, mymark = 0;                      // lanes 0..15: piece-start word / mark word of the sub-tile
     if (lane < kSub / 64) {
         const int64_t w = sub * (kSub / 64) + lane;
-        if (w < P.nwords) { myword = P.startbits[w]; mydoc = P.docbits[w]; }
+        if (w < P.nwords) { myword = P.startbits[w]; mymark = P.docbits[w]; }
         const int lim = nb - lane * 64;                    // bits at or beyond the end of the corpus are not pieces
         if (lim <= 0) myword = 0; else if (lim < 64) myword &= tkz_lowmask(lim);
-        s_longmask[lane] = 0;
     }
     // end of the last piece that starts here = first piece start at or after base+nb (the sentinel at `total` bounds it)
     int64_t last_end;
@@ -395,270 +392,285 @@ TKZ_DEV void tkz_encode_subtile(const TkzTables& T, const EncodeParams& P, int64
         last_end = found;
     }
     const int64_t last_end_rel = last_end - base;
-
-    // ---- stage 1: ordered compaction of the piece starts ----
+    // ---- ordered compaction of the piece starts (bit-sliced ballot prefix, no LDS scan) ----
     const uint32_t wlo = simt::shflu((uint32_t)myword, lane >> 2), whi = simt::shflu((uint32_t)(myword >> 32), lane >> 2);
     const uint32_t bits16 = (uint32_t)(((((uint64_t)whi << 32) | wlo) >> (16 * (lane & 3))) & 0xFFFFull);
     int np;
     {
         int off = tkz_wave_scan<5>(tkz_popc32(bits16), &np);
-        if (HEAVY || np <= kLeanPieces)
-            for (uint32_t b = bits16; b; b &= b - 1) s_pstart[off++] = (uint16_t)(16 * lane + tkz_ctz32(b));
+        for (uint32_t b = bits16; b; b &= b - 1) s_pstart[off++] = (uint16_t)(16 * lane + tkz_ctz32(b));
     }
-    // document ordinals: docs that start before word `lane` of this sub-tile
-    int docpre_tot;
-    const int docpre = tkz_wave_scan<7>(lane < kSub / 64 ? tkz_popc64(mydoc) : 0, &docpre_tot);
-    const int64_t docord0 = P.docord_base[sub];
-    simt::sync();
-    if (!HEAVY && np > kLeanPieces) {                     // more pieces than the lean kernel keeps positions for
-        if (lane == 0) P.heavy_flag[sub] = 1;
-        return;
-    }
-    const int64_t first_abs = np ? base + s_pstart[0] : base;
-    int nlong = 0;
-    for (int k0 = 0; k0 < np; k0 += 64) {
-        const int k = k0 + lane;
-        bool lg = false;
-        if (k < np) {
-            const int64_t len = (k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s_pstart[k];
-            lg = len > LANE_MAX;
-            // lean: a piece of 17+ bytes may still be a vocabulary key (runs of spaces, long common words): stage B will find it, as it
-            // finds the keys of 13..16 bytes; the sub-tile is refused only if the piece has to be merged
-            if (!HEAVY && lg && len <= T.max_key_len && s_pstart[k] + len <= kSub + kHalo) {
+    (void)simt::ballot(true);                              // (LDS written by other lanes of this wavefront is read below)
+    const int64_t pb = P.pbase[sub];
+    uint32_t flags = 0;
+    constexpr int U = 2;                                   // batches of 64 pieces whose gathers are in flight together
+    for (int k0 = 0; k0 < np; k0 += 64 * U) {
+        int ps[U], plen[U];
+        uint4 a0[U], a1[U], b0[U], b1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 64 * u + lane;
+            ps[u] = 0; plen[u] = 0;
+            const uint4* pa = reinterpret_cast<const uint4*>(T.short_slots);     // (idle lanes and long pieces gather slot 0: a load inside a
+            const uint4* pbk = pa;                                               //  divergent branch is waited for inside it)
+            if (k < np) {
                 const int s = s_pstart[k];
-                lg = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)len) == TKZ_RANK_NONE;
+                const int64_t len64 = (k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s;
+                const int len = len64 > kArenaPiece ? kArenaPiece + 1 : (int)len64;
+                ps[u] = s; plen[u] = len;
+                if (len <= TKZ_SHORT_KEY_MAX) {
+                    uint32_t s1, s2;
+                    tkz_short_slots(T, tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len, &s1, &s2);
+                    pa = reinterpret_cast<const uint4*>(T.short_slots) + s1; pbk = reinterpret_cast<const uint4*>(T.short_slots) + s2;
+                } else if (len <= TKZ_MID_KEY_MAX) {
+                    uint32_t kk[7], s1, s2;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) kk[i] = tkz_key_dword(s_bytes, s, len, i);
+                    tkz_mid_slots(T, kk, (uint32_t)len, &s1, &s2);
+                    pa = reinterpret_cast<const uint4*>(T.mid_slots) + 2 * (size_t)s1; pbk = reinterpret_cast<const uint4*>(T.mid_slots) + 2 * (size_t)s2;
+                }
             }
+            a0[u] = tkz_load16(pa); a1[u] = tkz_load16(pa + 1); b0[u] = tkz_load16(pbk); b1[u] = tkz_load16(pbk + 1);
         }
-        const uint64_t m = simt::ballot(lg);
-        if (m) { if (lane == 0) s_longmask[k0 >> 6] = m; nlong += tkz_popc64(m); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 64 * u + lane;
+            const int s = ps[u], len = plen[u];
+            // (the mark word of the piece's position: a wave-wide exchange, so every lane takes part -- idle ones with s = 0)
+            const uint64_t mw = ((uint64_t)simt::shflu((uint32_t)(mymark >> 32), (s >> 6) & 15) << 32) | simt::shflu((uint32_t)mymark, (s >> 6) & 15);
+            if (k >= np) continue;
+            int32_t rank;                                                        // Encoder.TryGetValue(piece) (TikTokenizer.cs:262)
+            if (len <= TKZ_SHORT_KEY_MAX)
+                rank = tkz_match_short(tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len,
+                                       a0[u], a1[u], b0[u], b1[u]);
+            else if (len <= TKZ_MID_KEY_MAX) {
+                uint32_t kk[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) kk[i] = tkz_key_dword(s_bytes, s, len, i);
+                rank = tkz_match_mid(kk, (uint32_t)len, a0[u], a1[u], b0[u], b1[u]);
+            } else if (len > kArenaPiece) rank = TKZ_RANK_NONE;                  // (k_giant_merge looks a giant piece up itself)
+            else if (s + len <= kSub + kHalo) rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)len);
+            else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return gbase[s + i]; }, (uint32_t)len);
+            uint32_t rec = ((mw >> (s & 63)) & 1ull) ? kPrMark : 0u;
+            if (rank != TKZ_RANK_NONE) rec |= (uint32_t)rank;
+            else if (len > kArenaPiece) { rec |= kPrMiss | kPrGiant | (uint32_t)s; flags |= 2u; }
+            else { rec |= kPrMiss | ((uint32_t)(len - 1) << kPrLenShift) | (uint32_t)s; if (len > kShortMax) flags |= 1u; }
+            if (pb + k < P.prank_cap) P.prank[pb + k] = rec;
+        }
     }
-    simt::sync();
-    if (!HEAVY && nlong > 0) {                            // a piece longer than a lean lane can merge: the heavy launch takes this sub-tile
-        if (lane == 0) P.heavy_flag[sub] = 1;
-        return;
-    }
+    // sub-tiles with a piece of 17+ bytes to merge (bit 0) or a giant piece (bit 1) are visited by k_merge_long / k_giant_find
+    const uint32_t f = (simt::ballot(flags & 1u) ? 1u : 0u) | (simt::ballot(flags & 2u) ? 2u : 0u);
+    if (lane == 0) P.heavy_flag[sub] = (uint8_t)f;
+    if (pb + np > P.prank_cap && lane == 0) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
+}
 
-    if (prof) t_01 = simt::clock() - t_start;
-    int running = 0;                                      // tokens of this sub-tile so far (uniform)
-    int err = 0;
-    int k0 = 0;
-    if (TKZ_DEV_FLAG(P, 8)) k0 = np;
-    uint32_t* ids = &s_scr[(lane % ML) * STRIDE];
-    uint32_t* pr = &s_scr[STRIDE * ML + (lane % ML) * STRIDE];
-    while (k0 < np) {
-        int next_long = np;
-        if (nlong > 0) {
-            int w = k0 >> 6;
-            uint64_t m = s_longmask[w] & (~0ull << (k0 & 63));
-            while (!m && ++w < (np + 63) / 64) m = s_longmask[w];
-            if (m) next_long = w * 64 + tkz_ctz64(m);
+// five aligned dwords around byte position `abs` of the corpus -> the 16 bytes that start there, as four little-endian dwords
+TKZ_DEV void tkz_load_piece16(const uint8_t* bytes, int64_t total, int64_t abs, uint32_t* pw) {
+    const int64_t a0 = abs & ~(int64_t)3;
+    const int sh = (int)(abs & 3) * 8;
+    uint32_t w[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int64_t p = a0 + 4 * i;
+        if (p + 4 <= total) w[i] = *reinterpret_cast<const uint32_t*>(bytes + p);
+        else { w[i] = 0; for (int j = 0; j < 4; ++j) if (p + j < total) w[i] |= (uint32_t)bytes[p + j] << (8 * j); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pw[i] = (uint32_t)((((uint64_t)w[i + 1] << 32) | w[i]) >> sh);
+}
+
+TKZ_KERNEL_OCC(256, 3) void k_merge_short(TkzTables T, EncodeParams P) {
+    constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride;
+    TKZ_SHARED uint4 s_scr_all[kThreads / 64][(2 * STRIDE * 64) / 4];   // per lane ids[16] | pr[16] at a conflict-free stride
+    TKZ_SHARED uint32_t s_rec_all[kThreads / 64][64];                   // the batch: record, and (sub-tile of the group) << 10 | piece index
+    TKZ_SHARED uint32_t s_idx_all[kThreads / 64][64];
+    const int lane = simt::lane(), wv = simt::wave();
+    const int64_t sub0 = (simt::bid() * (kThreads / 64) + wv) * kGroup;
+    if (sub0 >= P.nsub) return;
+    uint32_t* s_scr = reinterpret_cast<uint32_t*>(s_scr_all[wv]);
+    uint32_t* s_rec = s_rec_all[wv];
+    uint32_t* s_idx = s_idx_all[wv];
+    uint32_t* ids = &s_scr[lane * STRIDE];
+    uint32_t* pr = &s_scr[STRIDE * 64 + lane * STRIDE];
+    int64_t pbs[kGroup]; int nps[kGroup]; int extra[kGroup];
+#pragma unroll
+    for (int si = 0; si < kGroup; ++si) {
+        const int64_t sub = sub0 + si;
+        pbs[si] = 0; nps[si] = 0; extra[si] = 0;
+        if (sub < P.nsub) { pbs[si] = P.pbase[sub]; nps[si] = P.pcount[sub]; }
+    }
+    int err = 0, nlist = 0;
+    // one batch: lane i < n merges the piece of list entry i (BytePairEncode, TikTokenizer.cs:268), its tokens go to tmp at the
+    // piece's own byte position, its record gets the token count
+    auto run_batch = [&](int n) {
+        (void)simt::ballot(true);
+        int cnt1 = 0, si = 0;
+        if (lane < n) {
+            const uint32_t rec = s_rec[lane], ix = s_idx[lane];
+            si = (int)(ix >> 10);
+            const int k = (int)(ix & 1023u), rel = (int)(rec & 1023u), len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+            const int64_t abs = (sub0 + si) * kSub + rel;
+            uint32_t pw[NMAX / 4], alive = 1;
+            tkz_load_piece16(P.bytes, P.total, abs, pw);
+            int e1 = 0;
+            const int cnt = tkz_bpe_lane<NMAX>(T, pw, len, ids, pr, T.byte_rank, &alive, &e1);
+            err |= e1;
+            int32_t* dst = P.tmp + abs;
+            int i = 0;
+            for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)ids[tkz_ctz32(a)];
+            int64_t pbk = pbs[0];
+#pragma unroll
+            for (int q = 1; q < kGroup; ++q) if (si == q) pbk = pbs[q];
+            P.prank[pbk + k] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (uint32_t)rel;
+            cnt1 = cnt - 1;
         }
-        if (next_long > k0) {
-            const int kend = k0 + kPassPieces < next_long ? k0 + kPassPieces : next_long;
-            // (heavy sub-tiles are usually sparse in pieces: the batches a pass does not need are skipped as a whole; the lean kernel
-            //  nearly always fills all of them and keeps its straight-line code)
-            const int nbatch = HEAVY ? (kend - k0 + 63) >> 6 : kPassBatches;
-            long long t0 = prof ? simt::clock() : 0;
-            // ---------------- stage A: fetch keys, issue the first probe of every batch ----------------
-            int ps[kPassBatches], plen[kPassBatches];
-            uint32_t q0[kPassBatches], q1[kPassBatches], q2[kPassBatches], slot1[kPassBatches], slot2[kPassBatches];
 #pragma unroll
-            for (int b = 0; b < kPassBatches; ++b) {
-                const int k = k0 + 64 * b + lane;
-                ps[b] = 0; plen[b] = 0; q0[b] = q1[b] = q2[b] = 0; slot1[b] = slot2[b] = 0;
-                if (b < nbatch && k < kend) {
-                    const int s = s_pstart[k];
-                    const int len = (int)((k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s);
-                    ps[b] = s; plen[b] = len;
-                    if (len <= TKZ_SHORT_KEY_MAX) {
-                        const int w = s >> 2, sh = (s & 3) * 8;
-                        const uint64_t a01 = ((uint64_t)s_bytes[w + 1] << 32) | s_bytes[w];
-                        const uint64_t a12 = ((uint64_t)s_bytes[w + 2] << 32) | s_bytes[w + 1];
-                        const uint64_t a23 = ((uint64_t)s_bytes[w + 3] << 32) | s_bytes[w + 2];
-                        uint32_t x0 = (uint32_t)(a01 >> sh), x1 = (uint32_t)(a12 >> sh), x2 = (uint32_t)(a23 >> sh);
-                        if (len < 4) { x0 &= (1u << (8 * len)) - 1u; x1 = 0; x2 = 0; }
-                        else if (len < 8) { x1 &= (len == 4) ? 0u : ((1u << (8 * (len - 4))) - 1u); x2 = 0; }
-                        else if (len < 12) { x2 &= (len == 8) ? 0u : ((1u << (8 * (len - 8))) - 1u); }
-                        q0[b] = x0; q1[b] = x1; q2[b] = x2;
-                        tkz_short_slots(T, x0, x1, x2, (uint32_t)len, &slot1[b], &slot2[b]);
-                    }
-                }
-            }
-            // ---------------- stage B: resolve, compact the misses ----------------
-            int cnt[kPassBatches], qidx[kPassBatches];
-            int32_t tok[kPassBatches];
-            int nmiss = 0, aused = 0, kcut = kend;
+        for (int q = 0; q < kGroup; ++q) { int tot; (void)tkz_wave_scan<4>((lane < n && si == q) ? cnt1 : 0, &tot); extra[q] += tot; }
+        (void)simt::ballot(true);
+    };
+#pragma unroll 1
+    for (int si = 0; si < kGroup; ++si) {
+#pragma unroll 1
+        for (int k0 = 0; k0 < nps[si]; k0 += 64) {
+            const int k = k0 + lane;
+            uint32_t rec = 0;
+            if (k < nps[si] && pbs[si] + k < P.prank_cap) rec = P.prank[pbs[si] + k];
+            const bool is = (rec & kPrMiss) && !(rec & kPrGiant) && (int)((rec >> kPrLenShift) & kPrLenMask) < kShortMax;
+            const uint64_t m = simt::ballot(is);
+            const int c = tkz_popc64(m);
+            if (c == 0) continue;
+            if (nlist + c > 64) { run_batch(nlist); nlist = 0; }
+            if (is) { const int o = nlist + tkz_popc64(m & tkz_lowmask(lane)); s_rec[o] = rec; s_idx[o] = ((uint32_t)si << 10) | (uint32_t)k; }
+            nlist += c;
+        }
+    }
+    if (nlist > 0) run_batch(nlist);
+    // tokens of every sub-tile of the group: one per piece, plus what the merges added (k_merge_long adds its own later)
+    if (lane < kGroup && sub0 + lane < P.nsub) {
+        int np = nps[0], ex = extra[0];
 #pragma unroll
-            for (int g = 0; g < kPassBatches; g += 3) {
-                // both cuckoo slots of three batches in flight together; issued unconditionally (slot 0 for idle lanes): a load
-                // inside a divergent branch is waited for inside it, and the batches would not overlap
-                uint4 pv1[3], pv2[3];
-#pragma unroll
-                for (int t = 0; t < 3 && g + t < kPassBatches; ++t) {
-                    pv1[t].x = pv1[t].y = pv1[t].z = pv1[t].w = 0; pv2[t] = pv1[t];
-                    if (g + t < nbatch) {
-                        pv1[t] = tkz_load16(&T.short_slots[TKZ_DEV_FLAG(P, 2) ? 0u : slot1[g + t]]);
-                        pv2[t] = tkz_load16(&T.short_slots[TKZ_DEV_FLAG(P, 2) ? 0u : slot2[g + t]]);
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < 3 && g + t < kPassBatches; ++t) {
-                    const int b = g + t;
-                    cnt[b] = 0; tok[b] = 0; qidx[b] = -1;
-                    if (b >= nbatch) continue;
-                    bool miss = false;
-                    if (plen[b] > 0) {
-                        int32_t rank;
-                        if (plen[b] <= TKZ_SHORT_KEY_MAX) rank = tkz_match_short(q0[b], q1[b], q2[b], (uint32_t)plen[b], pv1[t], pv2[t]);
-                        else {
-                            const int s = ps[b];
-                            if (HEAVY && s + plen[b] > kSub + kHalo)      // runs past the staged bytes: read the piece from memory
-                                rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return gbase[s + i]; }, (uint32_t)plen[b]);
-                            else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)plen[b]);
-                        }
-                        if (rank != TKZ_RANK_NONE) { cnt[b] = 1; tok[b] = rank; }      // TikTokenizer.cs:262-265
-                        else miss = true;
-                    }
-                    const uint64_t mm = simt::ballot(miss);
-                    if (HEAVY) {
-                        // every miss gets a span of the arena sized for it; the first one that does not fit ends the pass
-                        const int need = miss ? tkz_bpe_var_dwords(plen[b]) : 0;
+        for (int q = 1; q < kGroup; ++q) if (lane == q) { np = nps[q]; ex = extra[q]; }
+        P.tile_count[sub0 + lane] = np + ex;
+    }
+    if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
+}
+
+// The pieces of 17..1024 bytes that have to be merged, and the token counts of the giant ones: only in the sub-tiles k_probe
+// flagged.  One lane per piece with its state in an LDS arena sized for it (tkz_bpe_lane_var), as many pieces per pass as fit.
+TKZ_KERNEL_OCC(64, 3) void k_merge_long(TkzTables T, EncodeParams P) {
+    TKZ_SHARED uint4 s_arena4[kArenaDwords / 4];
+    TKZ_SHARED uint32_t s_rec[64], s_idx[64], s_aoff[64];
+    uint32_t* s_arena = reinterpret_cast<uint32_t*>(s_arena4);
+    const int lane = simt::lane();
+    int err = 0;
+    for (int64_t c = simt::bid(); c * 64 < P.nsub; c += simt::nblocks()) {
+        const int64_t t = c * 64 + lane;
+        uint64_t fm = simt::ballot(t < P.nsub && P.heavy_flag[t] != 0);
+        for (; fm; fm &= fm - 1) {
+            const int64_t sub = c * 64 + tkz_ctz64(fm);
+            const int64_t pb = P.pbase[sub];
+            const int np = P.pcount[sub];
+            int added = 0;
+            int k0 = 0;
+            while (k0 < np) {
+                // collect the next long misses of this sub-tile, as many as the arena and the 64 lanes take
+                int nlist = 0, aused = 0, knext = np;
+                for (; k0 < np && knext == np; k0 += 64) {
+                    const int k = k0 + lane;
+                    uint32_t rec = 0;
+                    if (k < np && pb + k < P.prank_cap) rec = P.prank[pb + k];
+                    const int len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+                    const bool giant = (rec & kPrMiss) && (rec & kPrGiant);
+                    const bool is = (rec & kPrMiss) && !(rec & (kPrGiant | kPrDone)) && len > kShortMax;
+                    const uint64_t gm = simt::ballot(giant);
+                    const uint64_t m = simt::ballot(is);
+                    int limit = 64;                              // lanes of this chunk at or beyond `limit` wait for the next pass
+                    if (m) {
+                        const int need = is ? tkz_bpe_var_dwords(len) : 0;
                         int btot;
                         const int aoff = aused + tkz_wave_scan_sum(need, &btot);
-                        const int qi = nmiss + tkz_popc64(mm & tkz_lowmask(lane));
-                        const bool fits = miss && qi < ML && aoff + need <= kArenaDwords;
-                        const uint64_t bad = simt::ballot(miss && !fits);
-                        if (bad && kcut == kend) kcut = k0 + 64 * b + tkz_ctz64(bad);
-                        if (fits) { qidx[b] = qi; s_missq_h[qi] = (uint32_t)ps[b] | ((uint32_t)(plen[b] - 1) << 11) | ((uint32_t)(aoff >> 2) << 21); }
-                        nmiss += tkz_popc64(mm & ~bad);
-                        aused += btot;
-                    } else {
-                        if (miss) { qidx[b] = nmiss + tkz_popc64(mm & tkz_lowmask(lane)); if (qidx[b] < ML) s_missq[qidx[b]] = (uint16_t)((uint32_t)ps[b] | ((uint32_t)(plen[b] - 1) << 11)); }
-                        nmiss += tkz_popc64(mm);
+                        const int qi = nlist + tkz_popc64(m & tkz_lowmask(lane));
+                        const bool fits = is && qi < 64 && aoff + need <= kArenaDwords;
+                        const uint64_t bad = simt::ballot(is && !fits);
+                        if (bad) limit = tkz_ctz64(bad);         // the first piece left over starts the next pass
+                        if (fits && lane < limit) { s_rec[qi] = rec; s_idx[qi] = (uint32_t)k; s_aoff[qi] = (uint32_t)aoff; }
+                        if (bad) { knext = k0 + limit; nlist += tkz_popc64(m & tkz_lowmask(limit)); aused = simt::shfl(aoff, limit); }
+                        else { nlist += tkz_popc64(m); aused += btot; }
                     }
+                    // the giant piece of the sub-tile (its last piece): merged by k_giant_merge, its token count is added here -- once
+                    if (gm && tkz_ctz64(gm) < limit && lane == 0) { const int g = P.giant_cnt[sub]; added += g > 0 ? g - 1 : 0; }   // (< 0: no pool, the call is retried)
                 }
-            }
-            // one merge round per pass: if more pieces missed than it has room for, the pass ends before the first one left over
-            // (the pieces from there on are redone next pass)
-            if (!HEAVY && nmiss > ML) {
-#pragma unroll
-                for (int b = 0; b < kPassBatches; ++b) {
-                    const uint64_t m = simt::ballot(qidx[b] == ML);
-                    if (m) kcut = k0 + 64 * b + tkz_ctz64(m);
+                (void)simt::ballot(true);
+                int cnt1 = 0;
+                if (lane < nlist) {
+                    const uint32_t rec = s_rec[lane];
+                    const int rel = (int)(rec & 1023u), len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+                    const int64_t abs = sub * kSub + rel;
+                    const uint8_t* gb = P.bytes + abs;
+                    uint32_t* st = &s_arena[s_aoff[lane]];
+                    auto at = [&](int i) -> uint32_t { return gb[i]; };
+                    int e1 = 0;
+                    const int cnt = T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &e1) : tkz_bpe_lane_var<false>(T, at, len, st, &e1);
+                    err |= e1;
+                    tkz_bpe_var_emit(st, len, P.tmp + abs);
+                    P.prank[pb + s_idx[lane]] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (uint32_t)rel;
+                    cnt1 = cnt - 1;
                 }
-                nmiss = ML;
-            }
-            if (kcut < kend) {
-#pragma unroll
-                for (int b = 0; b < kPassBatches; ++b)
-                    if (k0 + 64 * b + lane >= kcut) { plen[b] = 0; cnt[b] = 0; qidx[b] = -1; }
-            }
-            simt::sync();
-            if (prof) { const long long t1 = simt::clock(); t_a += t1 - t0; t0 = t1; n_miss += nmiss; }
-            // ---------------- stage M: BytePairEncode of the misses (TikTokenizer.cs:268), one per lane ----------------
-            {
-                int err1 = 0;
-                if (HEAVY) {
-                    if (lane < nmiss) {
-                        const uint32_t e = s_missq_h[lane];
-                        const int s = (int)(e & 0x7FFu), len = (int)((e >> 11) & 0x3FFu) + 1;
-                        // (a piece that runs past the staged bytes is read from memory; the choice is per piece, not per byte)
-                        uint32_t* st = &s_scr[4 * (e >> 21)];
-                        auto merge = [&](auto at) -> int {
-                            return T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &err1) : tkz_bpe_lane_var<false>(T, at, len, st, &err1);
-                        };
-                        s_minfo[lane] = (uint32_t)(s + len <= kSub + kHalo ? merge([&](int i) -> uint32_t { return sb[s + i]; })
-                                                                           : merge([&](int i) -> uint32_t { return gbase[s + i]; }));
-                    }
-                } else if (lane < nmiss) {
-                    uint32_t alive = 1;
-                    if (TKZ_DEV_FLAG(P, 1)) ids[0] = 0;
-                    else {
-                        const uint32_t e = s_missq[lane];
-                        const int s = (int)(e & 0x7FFu), len = (int)(e >> 11) + 1;
-                        const int w = s >> 2, sh = (s & 3) * 8;
-                        uint32_t pw[NMAX / 4];
-#pragma unroll
-                        for (int i = 0; i < NMAX / 4; ++i) pw[i] = (uint32_t)((((uint64_t)s_bytes[w + i + 1] << 32) | s_bytes[w + i]) >> sh);
-                        tkz_bpe_lane<NMAX>(T, pw, len, ids, pr, T.byte_rank, &alive, &err1);
-                    }
-                    s_minfo[lane] = alive;
-                }
-                err |= err1;
-            }
-            simt::sync();
-            if (prof) { const long long t1 = simt::clock(); t_m += t1 - t0; t0 = t1; n_round += (nmiss + 63) / 64; }
-            // ---------------- stage C: positions, dense stores, document marks ----------------
-#pragma unroll
-            for (int b = 0; b < kPassBatches; ++b) {
-                if (b >= nbatch) continue;
-                uint32_t alive = 0;
-                if (qidx[b] >= 0) { alive = s_minfo[qidx[b]]; cnt[b] = HEAVY ? (int)alive : tkz_popc32(alive); }
                 int tot;
-                const int pos = running + tkz_wave_scan<HEAVY ? 11 : 5>(cnt[b], &tot);   // a lane holds up to 16 (heavy: kArenaPiece) tokens
-                const int s = ps[b], w = (s >> 6) & 15;
-                const uint32_t dlo = simt::shflu((uint32_t)mydoc, w), dhi = simt::shflu((uint32_t)(mydoc >> 32), w);
-                const int dpre = simt::shfl(docpre, w);
-                if (plen[b] > 0) {
-                    int32_t* dst = P.tmp + first_abs + pos;
-                    if (TKZ_DEV_FLAG(P, 4)) {}
-                    else if (qidx[b] < 0) dst[0] = tok[b];
-                    else if (HEAVY) {
-                        const uint32_t e = s_missq_h[qidx[b]];
-                        tkz_bpe_var_emit(&s_scr[4 * (e >> 21)], (int)((e >> 11) & 0x3FFu) + 1, dst);
-                    }
-                    else { const uint32_t* src = &s_scr[qidx[b] * STRIDE]; int i = 0; for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)src[tkz_ctz32(a)]; }
-                    const uint64_t dw = ((uint64_t)dhi << 32) | dlo;
-                    if ((dw >> (s & 63)) & 1ull) P.doc_tok[docord0 + dpre + tkz_popc64(dw & tkz_lowmask(s & 63))] = pos;
-                }
-                running += tot;
+                (void)tkz_wave_scan_sum(cnt1, &tot);
+                added += tot;                                    // (lane 0's copy also holds the giant pieces' share)
+                (void)simt::ballot(true);
+                if (knext < np) k0 = knext;                      // redo from the first piece that did not fit (done pieces are skipped)
             }
-            simt::sync();
-            if (prof) { const long long t1 = simt::clock(); t_c += t1 - t0; }
-            k0 = kcut;
-        } else {
-            // ---------------- one long piece, the whole wave ----------------
-            const int s = s_pstart[k0];
-            const int64_t len64 = (k0 + 1 < np ? (int64_t)s_pstart[k0 + 1] : last_end_rel) - s;
-            const int64_t abs0 = base + s;
-            int32_t* dst = P.tmp + first_abs + running;
-            int cnt1 = 0;
-            {
-                const int w = (s >> 6) & 15;
-                const uint32_t dlo = simt::shflu((uint32_t)mydoc, w), dhi = simt::shflu((uint32_t)(mydoc >> 32), w);
-                const int dpre = simt::shfl(docpre, w);
-                const uint64_t dw = ((uint64_t)dhi << 32) | dlo;
-                if (lane == 0 && ((dw >> (s & 63)) & 1ull)) P.doc_tok[docord0 + dpre + tkz_popc64(dw & tkz_lowmask(s & 63))] = running;
-            }
-            if (len64 > kMaxPiece) { err |= kErrTooLong; }
-            else {
-                // merged already (k_giant_merge): its tokens wait at the piece's own position in tmp; move them down to where the
-                // sub-tile's tokens are dense (a forward copy: the destination is never above the source)
-                cnt1 = P.giant_cnt[sub];
-                const int32_t* src = P.tmp + abs0;
-                if (cnt1 < 0) cnt1 = 0;                                        // (no room in the pool: the call is being retried)
-                if (src != dst)
-                    for (int i0 = 0; i0 < cnt1; i0 += 64) {
-                        const int i = i0 + lane;
-                        const int32_t v = i < cnt1 ? src[i] : 0;
-                        (void)simt::ballot(true);                              // (every lane has read its element of the chunk before any is overwritten)
-                        if (i < cnt1) dst[i] = v;
-                    }
-            }
-            running += cnt1;
-            k0 += 1;
-            nlong -= 1;
+            const int mine = simt::shfl(added, 0);              // lane 0: merges + giants; other lanes: merges only -- take lane 0's
+            if (lane == 0 && mine) simt::atomic_add(&P.tile_count[sub], mine);
         }
     }
-    if (prof && lane == 0) {
-        simt::atomic_add64(&P.devprof[0], 1); simt::atomic_add64(&P.devprof[1], (unsigned long long)(simt::clock() - t_start));
-        simt::atomic_add64(&P.devprof[2], (unsigned long long)t_01); simt::atomic_add64(&P.devprof[3], (unsigned long long)t_a);
-        simt::atomic_add64(&P.devprof[4], (unsigned long long)t_m); simt::atomic_add64(&P.devprof[5], (unsigned long long)t_c);
-        simt::atomic_add64(&P.devprof[6], (unsigned long long)n_round); simt::atomic_add64(&P.devprof[7], (unsigned long long)n_miss);
-        simt::atomic_add64(&P.devprof[8], (unsigned long long)np);
-    }
-    if (lane == 0) { P.tile_count[sub] = running; P.tile_first[sub] = first_abs; }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
+}
+
+// ids at their final position: count per record -> prefix -> stores; the token index (inside the sub-tile) of every marked piece
+TKZ_KERNEL_OCC(256, 8) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
+    const int lane = simt::lane();
+    const int64_t sub = simt::bid() * (kThreads / 64) + simt::wave();
+    if (sub >= P.nsub) return;
+    const int64_t pb = P.pbase[sub], tb = tile_base[sub], base = sub * kSub, ord0 = P.docord_base[sub];
+    const int np = P.pcount[sub];
+    const bool has_giant = (P.heavy_flag[sub] & 2u) != 0;
+    int gcnt = has_giant ? P.giant_cnt[sub] : 0;
+    if (gcnt < 0) gcnt = 0;
+    int running = 0, marks = 0;
+#pragma unroll 1
+    for (int k0 = 0; k0 < np; k0 += 64) {
+        const int k = k0 + lane;
+        const bool valid = k < np && pb + k < P.prank_cap;
+        const uint32_t rec = valid ? (uint32_t)P.prank[pb + k] : 0u;
+        const bool miss = (rec & kPrMiss) != 0;
+        int cnt = !valid ? 0 : !miss ? 1 : (rec & kPrGiant) ? gcnt : (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+        int tot;
+        const int pos = running + ((has_giant && simt::ballot(cnt > 1024)) ? tkz_wave_scan_sum(cnt, &tot) : tkz_wave_scan<11>(cnt, &tot));
+        const uint64_t mm = simt::ballot(valid && (rec & kPrMark));
+        if (valid) {
+            if (rec & kPrMark) P.doc_tok[ord0 + marks + tkz_popc64(mm & tkz_lowmask(lane))] = pos;
+            int32_t* dst = out + tb + pos;
+            if (!miss) { if (tb + pos < out_cap) dst[0] = (int32_t)(rec & kPrRankMask); }
+            else if (cnt <= 16) {
+                const int32_t* src = P.tmp + base + (rec & 1023u);
+                for (int i = 0; i < cnt; ++i) if (tb + pos + i < out_cap) dst[i] = src[i];
+            }
+        }
+        // long token runs (a merged piece of many bytes, a giant piece): copied by the whole wavefront, one after the other
+        for (uint64_t big = simt::ballot(valid && miss && cnt > 16); big; big &= big - 1) {
+            const int src_lane = tkz_ctz64(big);
+            const int c = simt::shfl(cnt, src_lane), p0 = simt::shfl(pos, src_lane);
+            const int rel = (int)(simt::shflu(rec, src_lane) & 1023u);
+            const int32_t* src = P.tmp + base + rel;
+            int32_t* dst = out + tb + p0;
+            for (int i = lane; i < c; i += 64) if (tb + p0 + i < out_cap) dst[i] = src[i];
+        }
+        running += tot;
+        marks += tkz_popc64(mm);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -797,47 +809,8 @@ TKZ_KERNEL(256) void k_scan_final(const int32_t* cnt, int64_t n, const int64_t* 
 }
 
 // -------------------------------------------------------------------------------------------------
-// k_gather / k_docoffs
+// k_docoffs
 // -------------------------------------------------------------------------------------------------
-constexpr int kGatherTiles = 4;     // sub-tiles copied per wavefront of k_gather (their output spans are back to back)
-TKZ_KERNEL(256) void k_gather(const int32_t* tmp, const int32_t* tile_count, const int64_t* tile_first, const int64_t* tile_base,
-                              int64_t nsub, int32_t* out, int64_t out_cap) {
-    const int lane = simt::lane();
-    const int64_t t0 = (simt::bid() * (kThreads / 64) + simt::wave()) * kGatherTiles;
-    if (t0 >= nsub) return;
-    // the metadata of the group: one tile per lane, then broadcast
-    int cl = 0; int64_t fl = 0, bl = 0;
-    if (lane < kGatherTiles && t0 + lane < nsub) { cl = tile_count[t0 + lane]; fl = tile_first[t0 + lane]; bl = tile_base[t0 + lane]; }
-    int pre[kGatherTiles + 1]; int64_t first[kGatherTiles];
-    pre[0] = 0;
-#pragma unroll
-    for (int q = 0; q < kGatherTiles; ++q) {
-        pre[q + 1] = pre[q] + simt::shfl(cl, q);
-        first[q] = (int64_t)(((uint64_t)simt::shflu((uint32_t)((uint64_t)fl >> 32), q) << 32) | simt::shflu((uint32_t)fl, q));
-    }
-    const int64_t b0 = (int64_t)(((uint64_t)simt::shflu((uint32_t)((uint64_t)bl >> 32), 0) << 32) | simt::shflu((uint32_t)bl, 0));
-    const int total = pre[kGatherTiles];
-    constexpr int U = 4;                // loads in flight per lane
-    for (int i0 = 0; i0 < total; i0 += 64 * U) {
-        int32_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + 64 * u + lane;
-            int q = 0;
-#pragma unroll
-            for (int k = 1; k < kGatherTiles; ++k) q += i >= pre[k];
-            int64_t f = first[0]; int p = 0;
-#pragma unroll
-            for (int k = 1; k < kGatherTiles; ++k) if (q == k) { f = first[k]; p = pre[k]; }
-            v[u] = i < total ? tmp[f + (i - p)] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = i0 + 64 * u + lane;
-            if (i < total && b0 + i < out_cap) out[b0 + i] = v[u];
-        }
-    }
-}
 TKZ_KERNEL(256) void k_docoffs(const int64_t* offs, int64_t n_docs, int64_t total, const int64_t* tile_base, const uint64_t* docbits,
                                const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
@@ -1167,10 +1140,11 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
 }
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub) {
     hook(L, K_ENCODE, 0);
-    TKZ_LAUNCH(k_encode_waves, nsub, 64, L.stream, T, P);
+    TKZ_LAUNCH(k_probe, cdiv(nsub, kThreads / 64), kThreads, L.stream, T, P);
     hook(L, K_ENCODE, 1);
     hook(L, K_HEAVY, 0);
-    // giant pieces start in sub-tiles the lean kernel has just flagged: find them, merge them, then the heavy kernel
+    TKZ_LAUNCH(k_merge_short, cdiv(nsub, (kThreads / 64) * kGroup), kThreads, L.stream, T, P);
+    // giant pieces start in sub-tiles k_probe has flagged: find them, merge them; then the pieces of 17..1024 bytes and the giants' token counts
     TKZ_LAUNCH(k_giant_find, grid_for(nsub), kThreads, L.stream, (const uint8_t*)P.heavy_flag, nsub, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap);
 #ifdef TKZ_HOSTEMU
     constexpr int kGiantGrid = 2;       // (the CPU emulator pays for every thread of an idle workgroup)
@@ -1178,8 +1152,13 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     constexpr int kGiantGrid = 256;
 #endif
     TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // strides over the queue; exits at once when it is empty
-    { const int64_t chunks = cdiv(nsub, 64); TKZ_LAUNCH(k_encode_waves_heavy, chunks < 16384 ? chunks : 16384, 64, L.stream, T, P); }   // strides over 64-sub-tile chunks
+    { const int64_t chunks = cdiv(nsub, 64); TKZ_LAUNCH(k_merge_long, chunks < 16384 ? chunks : 16384, 64, L.stream, T, P); }   // strides over 64-sub-tile chunks
     hook(L, K_HEAVY, 1);
+}
+void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
+    hook(L, K_GATHER, 0);
+    TKZ_LAUNCH(k_place, cdiv(nsub, kThreads / 64), kThreads, L.stream, P, tile_base, out, out_cap);
+    hook(L, K_GATHER, 1);
 }
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt) {
     TKZ_LAUNCH(k_doccount, grid_for(nsub * (kSub / 64)), kThreads, L.stream, docbits, nwords, total, nsub, cnt);
@@ -1191,12 +1170,6 @@ void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int
     TKZ_LAUNCH(k_scan_top, 1, kThreads, L.stream, bsum, nblk, grand);
     TKZ_LAUNCH(k_scan_final, nblk, kThreads, L.stream, tile_count, ntiles, (const int64_t*)bsum, tile_base);
     if (kid >= 0) hook(L, kid, 1);
-}
-void launch_gather(const Launch& L, const int32_t* tmp, const int32_t* tile_count, const int64_t* tile_first,
-                   const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
-    hook(L, K_GATHER, 0);
-    TKZ_LAUNCH(k_gather, cdiv(nsub, (kThreads / 64) * kGatherTiles), kThreads, L.stream, tmp, tile_count, tile_first, tile_base, nsub, out, out_cap);
-    hook(L, K_GATHER, 1);
 }
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
                     const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs) {

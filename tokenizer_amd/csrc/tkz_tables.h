@@ -4,14 +4,22 @@
 // The reference keeps ONE structure, Dictionary<byte[],int> with an O(len) hash/compare
 // (Tokenizer_C#/TokenizerLib/TikTokenizer.cs:101, Utils/BytePairComparer.cs:8-43) and probes it with
 // freshly allocated byte slices (Utils/BytePairEncoder.cs:25-36).  Only its exact-match semantics are
-// observable.  On the device the same map is held as three hash tables (a few MB in total: L2 /
-// Infinity-Cache resident, never an HBM stream).  SHORT and PAIR are CUCKOO tables (two hash functions, one
-// 16-byte slot each): a probe is exactly two independent 16-byte gathers, never a chain -- on a SIMT machine the
-// cost of a probe sequence is the MAXIMUM over the 64 lanes, so a bounded probe count matters more than the mean:
+// observable.  On the device the same map is held as four hash tables, a few MB in total.  They are sized for the 4 MiB L2
+// of ONE XCD (every XCD keeps its own copy of the hot lines): with cl100k-sized vocabularies the tables of round 1
+// (power-of-two sizes at a load of 0.3-0.4: 9 MB) missed L2 on most gathers and the encode kernel fetched 4x its input
+// from the fabric.  Every table is a CUCKOO table with an arbitrary (not power-of-two) size -- slot = mulhi(hash, size) --
+// so a probe is a fixed number of independent 16-byte gathers issued together, never a chain: on a SIMT machine a probe
+// sequence costs the MAXIMUM over the 64 lanes, so a bounded probe count matters more than the mean.
 //
-//   SHORT table  keys of 1..12 bytes, the key INLINE in a 16-byte slot: one 16 B gather resolves the
-//                whole-piece lookup (TikTokenizer.cs:262) for ~95 % of pieces.
-//   LONG table   keys of 13..max_key_len bytes: {hash, rank, blob offset, len} + key bytes in a blob.
+//   SHORT table  keys of 1..12 bytes, the key INLINE in a 16-byte slot {k0,k1,k2, rank|len<<27}; buckets of two slots,
+//                two candidate buckets per key ((2,2) cuckoo, load 0.8): four 16-byte gathers resolve the whole-piece
+//                lookup (TikTokenizer.cs:262) for ~90 % of pieces.
+//   MID table    keys of 13..28 bytes inline in a 32-byte slot {k0..k6, rank|(len-12)<<27}; two candidate slots ((2,1)
+//                cuckoo, load 0.45): the same four 16-byte gathers.  (Round 1 kept these keys behind a linear-probing
+//                table with a byte-by-byte compare against a blob: with a 100 k-key vocabulary a third of all pieces
+//                are longer than 12 bytes and that lookup was 55 % of the encode kernel.)
+//   LONG table   keys of 29..max_key_len bytes (runs of white space / punctuation: a few hundred keys):
+//                {hash, rank, blob offset, len} + key bytes in a blob, linear probing.
 //   PAIR table   (id_left, id_right) -> rank(left ++ right) for EVERY split of every key into two
 //                keys.  Parts in the merge loop are always vocabulary keys (single bytes first, then
 //                merged tokens whose id is by construction the rank of the concatenation), so
@@ -30,6 +38,7 @@
 #define TKZ_MAX_RANK ((1 << 27) - 2)        /* ranks must be in [0, TKZ_MAX_RANK]: (rank << 5 | 31) stays below the NOKEY sentinel */
 
 #define TKZ_SHORT_KEY_MAX 12
+#define TKZ_MID_KEY_MAX 28
 
 // 16 B; rank_len == 0 marks an empty slot (len is 1..12, so a used slot is never 0).
 // rank_len = rank | (len << 27): ranks must be < 2^27 (TKZ_MAX_RANK); the largest vocabulary the
@@ -40,6 +49,12 @@ struct alignas(16) TkzShortSlot {
 };
 #define TKZ_SHORT_RANK_BITS 27
 #define TKZ_SHORT_RANK_MASK ((1u << TKZ_SHORT_RANK_BITS) - 1u)
+
+// 32 B: keys of 13..28 bytes; rank_len = rank | (len - 12) << 27, never 0 for a used slot
+struct alignas(16) TkzMidSlot {
+    uint32_t k[7];
+    uint32_t rank_len;
+};
 
 struct alignas(16) TkzLongSlot {    // len == 0 marks an empty slot
     uint32_t hash;      // full 32-bit hash (cheap reject before touching the blob)
@@ -62,11 +77,12 @@ struct alignas(16) TkzPairSlot {
 TKZ_HD uint32_t tkz_pair_cid(uint32_t id) { return id >= (uint32_t)TKZ_PSEUDO_BASE ? id - (uint32_t)TKZ_PSEUDO_BASE + TKZ_PAIR_CID_LIMIT : id; }
 TKZ_HD uint64_t tkz_pair_key42(uint32_t a, uint32_t b) { return (uint64_t)tkz_pair_cid(a) | ((uint64_t)tkz_pair_cid(b) << 21); }
 
-struct TkzTables {      // device pointers + masks, passed to kernels by value
-    const TkzShortSlot* short_slots; uint32_t short_mask; uint32_t short_seed;
+struct TkzTables {      // device pointers + sizes, passed to kernels by value
+    const TkzShortSlot* short_slots; uint32_t short_nb; uint32_t short_seed;    // short_nb buckets of two slots
+    const TkzMidSlot* mid_slots;     uint32_t mid_ns;   uint32_t mid_seed;      // mid_ns slots
     const TkzLongSlot* long_slots;   uint32_t long_mask;
     const uint8_t* long_blob;
-    const TkzPairSlot* pair_slots;   uint32_t pair_mask; uint32_t pair_seed; uint32_t pair_compact;   // compact: slots are two-entry buckets
+    const TkzPairSlot* pair_slots;   uint32_t pair_n; uint32_t pair_seed; uint32_t pair_compact;   // pair_n slots; compact: a slot is a two-entry bucket
     const int32_t* byte_rank;        // [256] id of the single byte: its rank, or TKZ_PSEUDO_BASE + b
     const int32_t* bytepair_rank;    // [65536] rank of the two-byte key (b0<<8|b1), TKZ_RANK_NONE if absent
     const uint8_t* bmp_class;        // [65536] Unicode class of each BMP code unit (tkz_classes.h)
@@ -97,6 +113,16 @@ TKZ_HD uint32_t tkz_hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t l
     return h;
 }
 TKZ_HD uint32_t tkz_hash_short2(uint32_t h1) { return tkz_mix32(h1 * 0x27D4EB2Fu + 0x165667B1u); }
+// slot of a hash in a table of n slots (n arbitrary, h uniform over 32 bits): one v_mul_hi_u32
+TKZ_HD uint32_t tkz_mulhi(uint32_t h, uint32_t n) { return (uint32_t)(((uint64_t)h * (uint64_t)n) >> 32); }
+// a key of 13..28 bytes given as seven zero-padded little-endian dwords
+TKZ_HD uint32_t tkz_hash_mid(const uint32_t* k, uint32_t len, uint32_t seed) {
+    uint32_t h = tkz_mix32(k[0] + 0x9E3779B9u * len + seed);
+    h = tkz_mix32(h ^ (k[1] * 0x85EBCA6Bu)) + k[2] * 0xC2B2AE35u;
+    h = tkz_mix32(h ^ (k[3] * 0x27D4EB2Fu)) + k[4] * 0x165667B1u;
+    h = tkz_mix32(h ^ (k[5] * 0x9E3779B1u)) + k[6] * 0x85EBCA77u;
+    return tkz_mix32(h);
+}
 // streaming form for long keys: feed ceil(len/4) zero-padded dwords in order
 TKZ_HD uint32_t tkz_hash_long_init(uint32_t len) { return 0x2545F491u ^ (len * 0x9E3779B9u); }
 TKZ_HD uint32_t tkz_hash_long_step(uint32_t h, uint32_t w) { return tkz_mix32(h ^ w) + 0x632BE5ABu; }
@@ -108,27 +134,53 @@ TKZ_HD uint32_t tkz_hash_pair2(uint32_t h1) { return tkz_mix32(h1 * 0x27D4EB2Fu 
 // ---- probes ---------------------------------------------------------------------------------------
 TKZ_HD uint4 tkz_load16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 
-// the two candidate slots of a short key
+// the two candidate BUCKETS of a short key (slot index of the first of the bucket's two slots)
 TKZ_HD void tkz_short_slots(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t* s1, uint32_t* s2) {
     const uint32_t h = tkz_hash_short(k0, k1, k2, len, T.short_seed);
-    *s1 = h & T.short_mask; *s2 = tkz_hash_short2(h) & T.short_mask;
+    *s1 = 2u * tkz_mulhi(h, T.short_nb); *s2 = 2u * tkz_mulhi(tkz_hash_short2(h), T.short_nb);
 }
-// Encoder.TryGetValue(piece) for a piece of 1..12 bytes, given the contents of its two candidate slots (TikTokenizer.cs:262)
-TKZ_HD int32_t tkz_match_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint4 v1, uint4 v2) {
-    if (v1.x == k0 && v1.y == k1 && v1.z == k2 && (v1.w >> TKZ_SHORT_RANK_BITS) == len) return (int32_t)(v1.w & TKZ_SHORT_RANK_MASK);
-    if (v2.x == k0 && v2.y == k1 && v2.z == k2 && (v2.w >> TKZ_SHORT_RANK_BITS) == len) return (int32_t)(v2.w & TKZ_SHORT_RANK_MASK);
+TKZ_HD bool tkz_short_slot_is(uint4 v, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
+    return v.x == k0 && v.y == k1 && v.z == k2 && (v.w >> TKZ_SHORT_RANK_BITS) == len;
+}
+// Encoder.TryGetValue(piece) for a piece of 1..12 bytes, given the contents of its two candidate buckets (TikTokenizer.cs:262)
+TKZ_HD int32_t tkz_match_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint4 a0, uint4 a1, uint4 b0, uint4 b1) {
+    if (tkz_short_slot_is(a0, k0, k1, k2, len)) return (int32_t)(a0.w & TKZ_SHORT_RANK_MASK);
+    if (tkz_short_slot_is(a1, k0, k1, k2, len)) return (int32_t)(a1.w & TKZ_SHORT_RANK_MASK);
+    if (tkz_short_slot_is(b0, k0, k1, k2, len)) return (int32_t)(b0.w & TKZ_SHORT_RANK_MASK);
+    if (tkz_short_slot_is(b1, k0, k1, k2, len)) return (int32_t)(b1.w & TKZ_SHORT_RANK_MASK);
     return TKZ_RANK_NONE;
 }
 TKZ_HD int32_t tkz_lookup_short(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
     uint32_t s1, s2;
     tkz_short_slots(T, k0, k1, k2, len, &s1, &s2);
-    return tkz_match_short(k0, k1, k2, len, tkz_load16(&T.short_slots[s1]), tkz_load16(&T.short_slots[s2]));
+    return tkz_match_short(k0, k1, k2, len, tkz_load16(&T.short_slots[s1]), tkz_load16(&T.short_slots[s1 + 1]),
+                           tkz_load16(&T.short_slots[s2]), tkz_load16(&T.short_slots[s2 + 1]));
+}
+// the two candidate slots of a 13..28-byte key, and the match given both halves of both
+TKZ_HD void tkz_mid_slots(const TkzTables& T, const uint32_t* k, uint32_t len, uint32_t* s1, uint32_t* s2) {
+    const uint32_t h = tkz_hash_mid(k, len, T.mid_seed);
+    *s1 = tkz_mulhi(h, T.mid_ns); *s2 = tkz_mulhi(tkz_hash_short2(h), T.mid_ns);
+}
+TKZ_HD bool tkz_mid_slot_is(uint4 lo, uint4 hi, const uint32_t* k, uint32_t len) {
+    return lo.x == k[0] && lo.y == k[1] && lo.z == k[2] && lo.w == k[3] && hi.x == k[4] && hi.y == k[5] && hi.z == k[6] &&
+           (hi.w >> TKZ_SHORT_RANK_BITS) == len - 12u;
+}
+TKZ_HD int32_t tkz_match_mid(const uint32_t* k, uint32_t len, uint4 a0, uint4 a1, uint4 b0, uint4 b1) {
+    if (tkz_mid_slot_is(a0, a1, k, len)) return (int32_t)(a1.w & TKZ_SHORT_RANK_MASK);
+    if (tkz_mid_slot_is(b0, b1, k, len)) return (int32_t)(b1.w & TKZ_SHORT_RANK_MASK);
+    return TKZ_RANK_NONE;
+}
+TKZ_HD int32_t tkz_lookup_mid(const TkzTables& T, const uint32_t* k, uint32_t len) {
+    uint32_t s1, s2;
+    tkz_mid_slots(T, k, len, &s1, &s2);
+    const uint4* m = reinterpret_cast<const uint4*>(T.mid_slots);
+    return tkz_match_mid(k, len, tkz_load16(&m[2 * s1]), tkz_load16(&m[2 * s1 + 1]), tkz_load16(&m[2 * s2]), tkz_load16(&m[2 * s2 + 1]));
 }
 
 // ranks.TryGetValue(left ++ right) through the ids of the two parts (BytePairEncoder.cs:25-36)
 TKZ_HD void tkz_pair_slots(const TkzTables& T, uint32_t a, uint32_t b, uint32_t* s1, uint32_t* s2) {
     const uint32_t h = tkz_hash_pair(a, b, T.pair_seed);
-    *s1 = h & T.pair_mask; *s2 = tkz_hash_pair2(h) & T.pair_mask;
+    *s1 = tkz_mulhi(h, T.pair_n); *s2 = tkz_mulhi(tkz_hash_pair2(h), T.pair_n);
 }
 TKZ_HD int32_t tkz_match_pair(const TkzTables& T, uint32_t a, uint32_t b, uint4 v1, uint4 v2) {
     if (T.pair_compact) {
@@ -151,10 +203,10 @@ TKZ_HD int32_t tkz_lookup_pair(const TkzTables& T, uint32_t a, uint32_t b) {
     return tkz_match_pair(T, a, b, tkz_load16(&T.pair_slots[s1]), tkz_load16(&T.pair_slots[s2]));
 }
 
-// Encoder.TryGetValue(piece) for a piece of 13..max_key_len bytes; `at(i)` yields byte i of the piece.
+// Encoder.TryGetValue(piece) for a piece of 29..max_key_len bytes; `at(i)` yields byte i of the piece.
 template <class ByteAt>
 TKZ_HD int32_t tkz_lookup_long(const TkzTables& T, ByteAt at, uint32_t len) {
-    if ((int32_t)len > T.max_key_len) return TKZ_RANK_NONE;
+    if ((int32_t)len > T.max_key_len || len <= TKZ_MID_KEY_MAX) return TKZ_RANK_NONE;
     uint32_t h = tkz_hash_long_init(len);
     for (uint32_t off = 0; off < len; off += 4) {
         uint32_t w = 0;
@@ -173,4 +225,16 @@ TKZ_HD int32_t tkz_lookup_long(const TkzTables& T, ByteAt at, uint32_t len) {
         }
         s = (s + 1) & T.long_mask;
     }
+}
+
+// Encoder.TryGetValue(piece) for a piece of any length (TikTokenizer.cs:262), one lane, no batching: the slow general form
+template <class ByteAt>
+TKZ_HD int32_t tkz_lookup_any(const TkzTables& T, ByteAt at, uint32_t len) {
+    if (len == 0) return TKZ_RANK_NONE;
+    if (len <= TKZ_MID_KEY_MAX) {
+        uint32_t k[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t i = 0; i < len; ++i) k[i >> 2] |= (uint32_t)at(i) << (8 * (i & 3));
+        return len <= TKZ_SHORT_KEY_MAX ? tkz_lookup_short(T, k[0], k[1], k[2], len) : tkz_lookup_mid(T, k, len);
+    }
+    return tkz_lookup_long(T, at, len);
 }

@@ -168,20 +168,19 @@ int build_tables(Vocab* v, std::string* msg) {
         std::string k(1, char(b));
         v->byte_rank[b] = v->lookup(k, &r) ? r : int32_t(TKZ_PSEUDO_BASE + b);
     }
-    // ---- SHORT / LONG whole-key tables ----
-    size_t n_short = 0, n_long = 0, blob = 0;
+    // ---- SHORT / MID / LONG whole-key tables ----
+    size_t n_short = 0, n_mid = 0, n_long = 0, blob = 0;
     for (const auto& k : v->keys) {
-        if (k.empty()) continue;
-        if (k.size() <= TKZ_SHORT_KEY_MAX) ++n_short; else { ++n_long; blob += k.size(); }
+        if (k.empty()) continue;                       // (an empty key can never equal a regex match or a merge slice)
+        if (k.size() <= TKZ_SHORT_KEY_MAX) ++n_short; else if (k.size() <= TKZ_MID_KEY_MAX) ++n_mid; else { ++n_long; blob += k.size(); }
     }
-    uint32_t short_cap = next_pow2(std::max<uint64_t>(16, uint64_t(n_short) * 2));
     const uint32_t long_cap = next_pow2(std::max<uint64_t>(16, uint64_t(n_long) * 2));
     v->long_slots.assign(long_cap, TkzLongSlot{0, 0, 0, 0});
     v->long_blob.clear();
     v->long_blob.reserve(blob + 16);
     for (size_t i = 0; i < nk; ++i) {
         const std::string& k = v->keys[i];
-        if (k.size() <= TKZ_SHORT_KEY_MAX) continue;
+        if (k.size() <= TKZ_MID_KEY_MAX) continue;
         const uint32_t len = uint32_t(k.size());
         uint32_t h = tkz_hash_long_init(len);
         for (size_t off = 0; off < k.size(); off += 4) h = tkz_hash_long_step(h, load_dword(k, off));
@@ -190,25 +189,60 @@ int build_tables(Vocab* v, std::string* msg) {
         v->long_slots[s] = TkzLongSlot{h, v->ranks[i], uint32_t(v->long_blob.size()), len};
         v->long_blob.insert(v->long_blob.end(), k.begin(), k.end());
     }
-    // SHORT: cuckoo table of the keys of 1..12 bytes (an empty key can never equal a regex match or a merge slice)
-    for (bool done = false; !done; short_cap *= 2) {
-        for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
-            v->short_slots.assign(short_cap, TkzShortSlot{0, 0, 0, 0});
-            TkzTables T{}; T.short_mask = short_cap - 1; T.short_seed = seed;
-            bool ok = true;
-            for (size_t i = 0; i < nk && ok; ++i) {
-                const std::string& k = v->keys[i];
-                if (k.empty() || k.size() > TKZ_SHORT_KEY_MAX) continue;
-                const uint32_t len = uint32_t(k.size());
-                const TkzShortSlot item{load_dword(k, 0), load_dword(k, 4), load_dword(k, 8), uint32_t(v->ranks[i]) | (len << TKZ_SHORT_RANK_BITS)};
-                ok = cuckoo_insert(v->short_slots, item, [](const TkzShortSlot& s) { return s.rank_len != 0; },
-                                   [&](const TkzShortSlot& s, uint32_t* a, uint32_t* b) { tkz_short_slots(T, s.k0, s.k1, s.k2, s.rank_len >> TKZ_SHORT_RANK_BITS, a, b); });
-            }
-            if (ok) { v->short_seed = seed; done = true; }
-        }
-        if (done) break;
-    }
     v->long_blob.resize(v->long_blob.size() + 16, 0);   // kernels may read a few bytes past a key
+    // SHORT: (2,2) cuckoo -- buckets of two 16-byte slots, two candidate buckets per key -- at a load of 0.8 (the threshold
+    // of that scheme is ~0.89); sizes are arbitrary (slot = mulhi(hash, size)), grown 4 % at a time when 16 seeds fail
+    {
+        uint32_t nb = uint32_t(std::max<uint64_t>(8, (uint64_t(n_short) * 10 + 15) / 16));          // n / (2 * 0.8)
+        for (bool done = false; !done; nb += nb / 25 + 1) {
+            for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
+                v->short_slots.assign(size_t(nb) * 2, TkzShortSlot{0, 0, 0, 0});
+                TkzTables T{}; T.short_nb = nb; T.short_seed = seed;
+                bool ok = true;
+                uint32_t rng = 0x9E3779B9u * seed;
+                for (size_t i = 0; i < nk && ok; ++i) {
+                    const std::string& k = v->keys[i];
+                    if (k.empty() || k.size() > TKZ_SHORT_KEY_MAX) continue;
+                    TkzShortSlot item{load_dword(k, 0), load_dword(k, 4), load_dword(k, 8), uint32_t(v->ranks[i]) | (uint32_t(k.size()) << TKZ_SHORT_RANK_BITS)};
+                    ok = false;
+                    for (int kick = 0; kick < 2000; ++kick) {
+                        uint32_t s1, s2;
+                        tkz_short_slots(T, item.k0, item.k1, item.k2, item.rank_len >> TKZ_SHORT_RANK_BITS, &s1, &s2);
+                        TkzShortSlot* cand[4] = {&v->short_slots[s1], &v->short_slots[s1 + 1], &v->short_slots[s2], &v->short_slots[s2 + 1]};
+                        bool placed = false;
+                        for (TkzShortSlot* c : cand) if (c->rank_len == 0) { *c = item; placed = true; break; }
+                        if (placed) { ok = true; break; }
+                        rng = rng * 1664525u + 1013904223u;
+                        std::swap(item, *cand[(rng >> 16) & 3]);          // random-walk eviction
+                    }
+                }
+                if (ok) { v->short_seed = seed; done = true; }
+            }
+            if (done) break;
+        }
+    }
+    // MID: (2,1) cuckoo of 32-byte slots at a load of 0.45
+    {
+        uint32_t ns = uint32_t(std::max<uint64_t>(8, (uint64_t(n_mid) * 20 + 8) / 9));
+        for (bool done = false; !done; ns += ns / 25 + 1) {
+            for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
+                v->mid_slots.assign(ns, TkzMidSlot{{0, 0, 0, 0, 0, 0, 0}, 0});
+                TkzTables T{}; T.mid_ns = ns; T.mid_seed = seed;
+                bool ok = true;
+                for (size_t i = 0; i < nk && ok; ++i) {
+                    const std::string& k = v->keys[i];
+                    if (k.size() <= TKZ_SHORT_KEY_MAX || k.size() > TKZ_MID_KEY_MAX) continue;
+                    TkzMidSlot item;
+                    for (int d = 0; d < 7; ++d) item.k[d] = load_dword(k, 4 * size_t(d));
+                    item.rank_len = uint32_t(v->ranks[i]) | (uint32_t(k.size() - 12) << TKZ_SHORT_RANK_BITS);
+                    ok = cuckoo_insert(v->mid_slots, item, [](const TkzMidSlot& s) { return s.rank_len != 0; },
+                                       [&](const TkzMidSlot& s, uint32_t* a, uint32_t* b) { tkz_mid_slots(T, s.k, (s.rank_len >> TKZ_SHORT_RANK_BITS) + 12u, a, b); });
+                }
+                if (ok) { v->mid_seed = seed; done = true; }
+            }
+            if (done) break;
+        }
+    }
     // ---- PAIR table: every split of every key into two keys (or not-in-vocab single bytes) ----
     struct P { uint32_t a, b; int32_t r; };
     std::vector<P> pairs;
@@ -233,11 +267,11 @@ int build_tables(Vocab* v, std::string* msg) {
     for (int32_t r : v->ranks) if (uint32_t(r) >= TKZ_PAIR_CID_LIMIT) { compact = false; break; }
     v->pair_compact = false;
     if (compact) {
-        uint32_t buckets = next_pow2(std::max<uint64_t>(16, (uint64_t(pairs.size()) * 10 + 16) / 17));      // entries / 1.7
-        for (int grow = 0; grow < 3 && !v->pair_compact; ++grow, buckets *= 2) {
+        uint32_t buckets = uint32_t(std::max<uint64_t>(16, (uint64_t(pairs.size()) * 10 + 16) / 17));      // entries / 1.7: a load of 0.85
+        for (int grow = 0; grow < 40 && !v->pair_compact; ++grow, buckets += buckets / 25 + 1) {
             for (uint32_t seed = 1; seed <= 16 && !v->pair_compact; ++seed) {
                 std::vector<uint64_t> ent(size_t(buckets) * 2, 0);
-                TkzTables T{}; T.pair_mask = buckets - 1; T.pair_seed = seed;
+                TkzTables T{}; T.pair_n = buckets; T.pair_seed = seed;
                 bool ok = true;
                 uint32_t rng = 0x9E3779B9u * seed;
                 for (size_t i = 0; i < pairs.size() && ok; ++i) {
@@ -271,11 +305,11 @@ int build_tables(Vocab* v, std::string* msg) {
             }
         }
     }
-    uint32_t pair_cap = next_pow2(std::max<uint64_t>(16, uint64_t(pairs.size()) * 2));
-    for (bool done = v->pair_compact; !done; pair_cap *= 2) {
+    uint32_t pair_cap = uint32_t(std::max<uint64_t>(16, (uint64_t(pairs.size()) * 20 + 8) / 9));          // a load of 0.45
+    for (bool done = v->pair_compact; !done; pair_cap += pair_cap / 25 + 1) {
         for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
             v->pair_slots.assign(pair_cap, TkzPairSlot{0, 0, 0, 0});
-            TkzTables T{}; T.pair_mask = pair_cap - 1; T.pair_seed = seed;
+            TkzTables T{}; T.pair_n = pair_cap; T.pair_seed = seed;
             bool ok = true;
             for (size_t i = 0; i < pairs.size() && ok; ++i)
                 ok = cuckoo_insert(v->pair_slots, TkzPairSlot{pairs[i].a, pairs[i].b, pairs[i].r, 1},

@@ -21,14 +21,15 @@ struct Vocab {
     int32_t max_key_len = 0;
 
     // host images of the device tables
-    std::vector<TkzShortSlot> short_slots;
+    std::vector<TkzShortSlot> short_slots;    // two per bucket
+    std::vector<TkzMidSlot> mid_slots;
     std::vector<TkzLongSlot> long_slots;
     std::vector<uint8_t> long_blob;
     std::vector<TkzPairSlot> pair_slots;
     std::vector<int32_t> byte_rank;       // 256
     std::vector<int32_t> bytepair_rank;   // 65536
     int64_t pair_entries = 0;
-    uint32_t short_seed = 0, pair_seed = 0;   // seeds under which the cuckoo insertion succeeded
+    uint32_t short_seed = 0, mid_seed = 0, pair_seed = 0;   // seeds under which the cuckoo insertion succeeded
     bool pair_compact = false;                // pair_slots are two-entry buckets of 8-byte entries (tkz_tables.h)
 
     bool lookup(const std::string& k, int32_t* rank) const {

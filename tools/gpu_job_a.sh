@@ -1,7 +1,7 @@
 #!/bin/bash
 # first GPU job of round 2: parity suite, bench line, other shapes, stage breakdown (dev build), rocprof passes
 set -u
-REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; O=gpurun_out/r02a; mkdir -p $O
+REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; O=gpurun_out/r02b; mkdir -p $O
 rocm-smi --showproductname 2>/dev/null | head -8 > $O/gpu.txt; nproc >> $O/gpu.txt
 ( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"; cut -c1-1500 $O/bench_n1.json
@@ -10,9 +10,7 @@ for spec in "--kind 4 --docs 4000000" "--kind 2 --docs 2000000" "--kind 3 --patt
 done
 python - <<'PY'
 import json
-for l in open('gpurun_out/r02a/bench_shapes.jsonl'):
+for l in open('gpurun_out/r02b/bench_shapes.jsonl'):
     j=json.loads(l); print(j['config']['workload'][:60], j['config']['pattern'], j['value'], j['ms_per_step'], j['roofline']['kernels_ms'])
 PY
-TKZ_LIBTKZ=$REPO/tokenizer_amd/lib_dev/libtkz.so TKZ_DEV_ABLATE=16 timeout 600 python bench.py --docs 2000000 --steps 2 --warmup 1 --no-cpu-baseline > $O/devprof.json 2> $O/devprof.err; grep devprof $O/devprof.err | tail -3
-TKZ_LIBTKZ=$REPO/tokenizer_amd/lib_dev/libtkz.so TKZ_DEV_ABLATE=16 timeout 600 python bench.py --docs 2000000 --kind 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/devprof4.json 2> $O/devprof4.err; grep devprof $O/devprof4.err | tail -3
-bash tools/gpu_profile.sh r02a 10000000 > $O/profile.log 2>&1; tail -60 $O/profile.log | head -80
+bash tools/gpu_profile.sh r02b 10000000 > $O/profile.log 2>&1; tail -60 $O/profile.log | head -80
