@@ -67,6 +67,11 @@ extern int64_t g_bid, g_nblocks;
 #define TKZ_LAUNCH(kernel, grid, block, stream, ...) \
     hipemu::launch((int64_t)(grid), (int)(block), [=]() { kernel(__VA_ARGS__); })
 
+inline uint4 tkz_load16_nt(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+inline uint32_t tkz_load_nt(const uint32_t* p) { return *p; }
+inline int32_t tkz_load_nt(const int32_t* p) { return *p; }
+inline void tkz_store_nt(int32_t* p, int32_t v) { *p = v; }
+
 namespace simt {
 inline int tid() { return hipemu::g_tid; }
 inline int lane() { return hipemu::g_tid & 63; }
@@ -95,6 +100,14 @@ inline int first_lane(int v) {   // value of the lowest live lane
     for (int l = 0; l < 64; ++l) if (a[l] >> 32) return (int)(uint32_t)a[l];
     return v;
 }
+inline int scan_inclusive(int v) {
+    const int l = lane();
+    uint64_t* a = hipemu::wave_exchange((uint32_t)v);
+    int x = 0;
+    for (int i = 0; i <= l; ++i) x += (int)(uint32_t)a[i];
+    return x;
+}
+inline int last_lane(int v) { return (int)(uint32_t)hipemu::wave_exchange((uint32_t)v)[63]; }
 inline int atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomic_or(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 inline unsigned long long atomic_or64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }

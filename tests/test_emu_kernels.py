@@ -106,9 +106,18 @@ def test_mid_pieces_share_the_arena(lib, vocab, oracle_mod, oracle_gpt2):
     parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=11, rounds=4, lens=[17, 24, 33, 40, 48, 64, 90, 128, 200, 400, 1023, 1024], counts=[40, 400], p_listed=1.0)
 
 
-def test_long_and_giant_pieces(lib, vocab, oracle_mod, oracle_gpt2):
+def test_long_and_giant_pieces(lib, vocab, vocabs, oracle_mod, oracle_gpt2):
     # whole-wave path, arrays in the global pool (> kArenaPiece bytes), incl. the pool-grow retry
     parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=9, rounds=2, lens=[300, 1024, 1025, 1500, 2600], counts=[3])
+    # giant pieces that collapse to a handful of tokens (runs of one byte under a vocabulary with long run keys): the in-lane copy of k_place
+    v, ov = vocabs("synth100k")
+    enc = N.Encoder(v, N.CL100K)
+    pcs = [b" " * 1025, b"ab", b"=" * 2000, b"\n" * 1100, b"-" * 1024, b"x", b" " * 1040]
+    data, offs = parity.pack(pcs)
+    ids, ooff = enc.encode_pieces(data, offs)
+    for i, p in enumerate(pcs):
+        r = ov.rank(p)
+        assert ids[ooff[i]:ooff[i + 1]].tolist() == ([r] if r >= 0 else ov.bpe(p)), (i, len(p))
 
 
 @pytest.mark.parametrize("pattern,vname", [(1, "gpt2"), (2, "gpt2"), (3, "gpt2"), (2, "synth100k"), (3, "synth200k")])

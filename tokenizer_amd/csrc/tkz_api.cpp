@@ -312,8 +312,8 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             unsigned long long h[16];
             HIP_TRY(hipMemcpy(h, g_devprof, sizeof h, hipMemcpyDeviceToHost));
             const double w = h[0] ? (double)h[0] : 1.0;
-            fprintf(stderr, "[tkz devprof] waves %llu  cycles/wave: total %.0f stage01 %.0f stageAB %.0f stageM %.0f stageC %.0f | rounds/wave %.2f misses/wave %.1f pieces/wave %.1f\n",
-                    h[0], h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w, h[7] / w, h[8] / w);
+            fprintf(stderr, "[tkz devprof] k_probe waves %llu  clock ticks/wave: total %.0f  load+compact %.0f  short batches %.0f  mid batches %.0f | mid pieces/wave %.1f pieces/wave %.1f\n",
+                    h[0], h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w);
         }
 #endif
         const int32_t err = e->h_counters->err;
@@ -449,8 +449,11 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     int64_t* acc = &e->bytes_allocated;
     const tkz::Vocab& V = v->v;
     hipError_t h = hipSuccess;
-    if (h == hipSuccess) h = upload(e->t_short, V.short_slots, acc);
-    if (h == hipSuccess) h = upload(e->t_mid, V.mid_slots, acc);
+    // SHORT and MID in ONE allocation (k_probe addresses both from one uniform base with 32-bit offsets)
+    const size_t short_bytes = V.short_slots.size() * sizeof(TkzShortSlot), mid_bytes = V.mid_slots.size() * sizeof(TkzMidSlot);
+    if (h == hipSuccess) h = e->t_short.ensure(std::max<size_t>(64, short_bytes + mid_bytes), acc);
+    if (h == hipSuccess && short_bytes) h = hipMemcpy(e->t_short.p, V.short_slots.data(), short_bytes, hipMemcpyHostToDevice);
+    if (h == hipSuccess && mid_bytes) h = hipMemcpy(e->t_short.as<char>() + short_bytes, V.mid_slots.data(), mid_bytes, hipMemcpyHostToDevice);
     if (h == hipSuccess) h = upload(e->t_long, V.long_slots, acc);
     if (h == hipSuccess) h = upload(e->t_blob, V.long_blob, acc);
     if (h == hipSuccess) h = upload(e->t_pair, V.pair_slots, acc);
@@ -459,7 +462,7 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     if (h == hipSuccess) h = upload(e->t_bmp, tkz::bmp_class_table(), acc);
     if (h != hipSuccess) { tkz_encoder_destroy(e); return fail(TKZ_E_DEVICE, std::string("table upload: ") + hipGetErrorString(h)); }
     e->T.short_slots = e->t_short.as<TkzShortSlot>(); e->T.short_nb = (uint32_t)(V.short_slots.size() / 2); e->T.short_seed = V.short_seed;
-    e->T.mid_slots = e->t_mid.as<TkzMidSlot>();       e->T.mid_ns = (uint32_t)V.mid_slots.size(); e->T.mid_seed = V.mid_seed;
+    e->T.mid_slots = reinterpret_cast<const TkzMidSlot*>(e->t_short.as<char>() + short_bytes); e->T.mid_ns = (uint32_t)V.mid_slots.size(); e->T.mid_seed = V.mid_seed;
     e->T.long_slots = e->t_long.as<TkzLongSlot>();    e->T.long_mask = (uint32_t)V.long_slots.size() - 1;
     e->T.long_blob = e->t_blob.as<uint8_t>();
     e->T.pair_slots = e->t_pair.as<TkzPairSlot>();    e->T.pair_n = (uint32_t)V.pair_slots.size(); e->T.pair_seed = V.pair_seed; e->T.pair_compact = V.pair_compact ? 1u : 0u;

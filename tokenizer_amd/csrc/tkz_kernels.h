@@ -12,8 +12,8 @@ constexpr int kThreads = 256;       // workgroup size of every kernel (4 wavefro
 constexpr int kSub = 1024;          // bytes of corpus per wavefront of k_encode_waves (a "sub-tile")
 constexpr int kHalo = 64;           // bytes staged past the sub-tile (a short piece may straddle the edge)
 constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one per lane, 64 to a wavefront, by k_merge_short
-constexpr int kArenaDwords = 2560;  // LDS arena of k_merge_long: the misses of a pass get 2 dwords + 1 bit per byte out of it
-constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (tkz_bpe_var_dwords(1024) <= kArenaDwords)
+constexpr int kArenaDwords = 3584;  // LDS arena of k_merge_long: the long misses of a batch get 2 dwords + 1 byte + 1 bit per byte out of it
+constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (256 + tkz_bpe_var_dwords(1024) <= kArenaDwords)
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan

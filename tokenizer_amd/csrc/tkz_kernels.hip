@@ -307,7 +307,16 @@ constexpr uint32_t kPrMiss = 1u << 31, kPrMark = 1u << 30, kPrDone = 1u << 29, k
 constexpr uint32_t kPrRankMask = (1u << 28) - 1u;       // ranks are < 2^27 (TKZ_MAX_RANK)
 constexpr int kPrLenShift = 10;
 constexpr uint32_t kPrLenMask = 0x7FFu;                 // len - 1 / count - 1 (< 1024), in bits 10..20
-constexpr int kGroup = 4;                               // sub-tiles per wavefront of k_merge_short
+#ifndef TKZ_GROUP
+#define TKZ_GROUP 4
+#endif
+#ifndef TKZ_PROBE_U
+#define TKZ_PROBE_U 2
+#endif
+#ifndef TKZ_PROBE_OCC
+#define TKZ_PROBE_OCC 8
+#endif
+constexpr int kGroup = TKZ_GROUP;                       // sub-tiles per wavefront of k_merge_short
 
 // exclusive prefix over the wave of a small non-negative value (< 2^BITS), and the wave total;
 // bit-sliced: one ballot + mbcnt per bit, no LDS traffic
@@ -325,12 +334,10 @@ TKZ_DEV int tkz_wave_scan(int v, int* total) {
     return pre;
 }
 
-// exclusive prefix sum over the wave of any non-negative value
+// exclusive prefix sum over the wave of any non-negative value (idle lanes contribute 0: every lane of the wave must be active)
 TKZ_DEV int tkz_wave_scan_sum(int v, int* total) {
-    const int lane = simt::lane();
-    int x = v;
-    for (int d = 1; d < 64; d <<= 1) { const int y = simt::shfl_up(x, d); if (lane >= d) x += y; }
-    *total = simt::shfl(x, 63);
+    const int x = simt::scan_inclusive(v);
+    *total = simt::last_lane(x);
     return x - v;
 }
 
@@ -342,45 +349,67 @@ TKZ_DEV uint32_t tkz_key_dword(const uint32_t* s_bytes, int s, int len, int i) {
     return nb >= 4 ? x : (nb <= 0 ? 0u : (x & ((1u << (8 * nb)) - 1u)));
 }
 
-TKZ_KERNEL_OCC(256, 8) void k_probe(TkzTables T, EncodeParams P) {
+TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
     TKZ_SHARED uint32_t s_bytes_all[kThreads / 64][(kSub + kHalo) / 4];
     TKZ_SHARED uint16_t s_pstart_all[kThreads / 64][kSub + 2];
+    TKZ_SHARED uint16_t s_mid_all[kThreads / 64][kSub / (TKZ_SHORT_KEY_MAX + 1) + 2];   // pieces of 13..28 bytes of the sub-tile (<= 78 of them)
     const int lane = simt::lane();
     const int64_t sub = simt::bid() * (kThreads / 64) + simt::wave();
     if (sub >= P.nsub) return;                            // (no workgroup barrier anywhere: every wavefront is on its own)
     uint32_t* s_bytes = s_bytes_all[simt::wave()];
     uint16_t* s_pstart = s_pstart_all[simt::wave()];
+    uint16_t* s_mid = s_mid_all[simt::wave()];
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_bytes);
     const int64_t base = sub * kSub;
     const int nb = (int)(P.total - base < kSub ? P.total - base : kSub);
     const uint8_t* gbase = P.bytes + base;
-    // ---- the sub-tile (+ halo) goes to LDS, 16 B per lane; the bitmap words one per lane ----
-    for (int i = lane; i < (kSub + kHalo) / 16; i += 64) {
-        const int64_t pos = base + 16 * (int64_t)i;
-        uint4 v;
-        if (pos + 16 <= P.total) v = tkz_load16(P.bytes + pos);
+    const bool prof = TKZ_DEV_FLAG(P, 16);
+    long long t_0 = prof ? simt::clock() : 0, t_1 = 0, t_2 = 0, t_3 = 0;
+    // ---- everything the wavefront needs from memory is requested first, in ONE round trip: the sub-tile (+ halo), 16 B per lane
+    // (the halo by lanes 0..3), the bitmap words one per lane, and the 64 bitmap words after the sub-tile in which the end of
+    // its last piece is looked for -- and only then consumed ----
+    static_assert((kSub + kHalo) / 16 <= 128, "two 16-byte loads per lane cover the sub-tile and its halo");
+    uint4 v0, v1;
+    v0.x = v0.y = v0.z = v0.w = 0; v1 = v0;
+    {
+        const int64_t p0 = base + 16 * (int64_t)lane, p1 = base + 16 * (int64_t)(lane + 64);
+        if (p0 + 16 <= P.total) v0 = tkz_load16_nt(P.bytes + p0);
         else {
             uint32_t w[4] = {0, 0, 0, 0};
-            for (int j = 0; j < 16; ++j) if (pos + j < P.total) w[j >> 2] |= (uint32_t)P.bytes[pos + j] << (8 * (j & 3));
-            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+            for (int j = 0; j < 16; ++j) if (p0 + j < P.total) w[j >> 2] |= (uint32_t)P.bytes[p0 + j] << (8 * (j & 3));
+            v0.x = w[0]; v0.y = w[1]; v0.z = w[2]; v0.w = w[3];
         }
-        s_bytes[4 * i + 0] = v.x; s_bytes[4 * i + 1] = v.y; s_bytes[4 * i + 2] = v.z; s_bytes[4 * i + 3] = v.w;
+        if (lane + 64 < (kSub + kHalo) / 16) {
+            if (p1 + 16 <= P.total) v1 = tkz_load16_nt(P.bytes + p1);
+            else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int j = 0; j < 16; ++j) if (p1 + j < P.total) w[j >> 2] |= (uint32_t)P.bytes[p1 + j] << (8 * (j & 3));
+                v1.x = w[0]; v1.y = w[1]; v1.z = w[2]; v1.w = w[3];
+            }
+        }
     }
     uint64_t myword = 0, mymark = 0;                      // lanes 0..15: piece-start word / mark word of the sub-tile
     if (lane < kSub / 64) {
         const int64_t w = sub * (kSub / 64) + lane;
         if (w < P.nwords) { myword = P.startbits[w]; mymark = P.docbits[w]; }
+    }
+    const int64_t from = base + nb, w0 = from >> 6;        // the search for the end of the last piece starts here
+    uint64_t ahead = (w0 + lane < P.nwords) ? P.startbits[w0 + lane] : 0ull;
+    const int64_t pb = P.pbase[sub];
+    // ---- consume ----
+    s_bytes[4 * lane + 0] = v0.x; s_bytes[4 * lane + 1] = v0.y; s_bytes[4 * lane + 2] = v0.z; s_bytes[4 * lane + 3] = v0.w;
+    if (lane + 64 < (kSub + kHalo) / 16) { const int i = lane + 64; s_bytes[4 * i + 0] = v1.x; s_bytes[4 * i + 1] = v1.y; s_bytes[4 * i + 2] = v1.z; s_bytes[4 * i + 3] = v1.w; }
+    if (lane < kSub / 64) {
         const int lim = nb - lane * 64;                    // bits at or beyond the end of the corpus are not pieces
         if (lim <= 0) myword = 0; else if (lim < 64) myword &= tkz_lowmask(lim);
     }
     // end of the last piece that starts here = first piece start at or after base+nb (the sentinel at `total` bounds it)
     int64_t last_end;
     {
-        const int64_t from = base + nb, w0 = from >> 6;
         int64_t found = -1;
         for (int64_t c = 0; found < 0; ++c) {
             const int64_t w = w0 + c * 64 + lane;
-            uint64_t v = w < P.nwords ? P.startbits[w] : 0;
+            uint64_t v = c == 0 ? ahead : (w < P.nwords ? P.startbits[w] : 0);
             if (w == w0) v &= ~tkz_lowmask((int)(from & 63));
             const uint64_t any = simt::ballot(v != 0);
             if (any) {
@@ -401,9 +430,16 @@ TKZ_KERNEL_OCC(256, 8) void k_probe(TkzTables T, EncodeParams P) {
         for (uint32_t b = bits16; b; b &= b - 1) s_pstart[off++] = (uint16_t)(16 * lane + tkz_ctz32(b));
     }
     (void)simt::ballot(true);                              // (LDS written by other lanes of this wavefront is read below)
-    const int64_t pb = P.pbase[sub];
+    if (prof) t_1 = simt::clock();
+    const char* tb0 = reinterpret_cast<const char*>(T.short_slots);
+    const uint32_t mid_off = (uint32_t)(reinterpret_cast<const char*>(T.mid_slots) - tb0);   // (SHORT and MID share one allocation)
     uint32_t flags = 0;
-    constexpr int U = 2;                                   // batches of 64 pieces whose gathers are in flight together
+    int nmid = 0;
+    // Two batches of 64 pieces per iteration, their gathers in flight together (what a sub-tile costs is its count of dependent
+    // round trips to the tables); the pieces of 13..28 bytes -- a few per cent of all pieces, whose lookup costs twice the
+    // instructions of a short one -- are only noted here and looked up together after the loop.
+    constexpr int U = TKZ_PROBE_U;                         // batches of 64 pieces whose gathers are in flight together
+#pragma unroll 1
     for (int k0 = 0; k0 < np; k0 += 64 * U) {
         int ps[U], plen[U];
         uint4 a0[U], a1[U], b0[U], b1[U];
@@ -411,8 +447,7 @@ TKZ_KERNEL_OCC(256, 8) void k_probe(TkzTables T, EncodeParams P) {
         for (int u = 0; u < U; ++u) {
             const int k = k0 + 64 * u + lane;
             ps[u] = 0; plen[u] = 0;
-            const uint4* pa = reinterpret_cast<const uint4*>(T.short_slots);     // (idle lanes and long pieces gather slot 0: a load inside a
-            const uint4* pbk = pa;                                               //  divergent branch is waited for inside it)
+            uint32_t oa = 0, ob = 0;
             if (k < np) {
                 const int s = s_pstart[k];
                 const int64_t len64 = (k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s;
@@ -421,42 +456,78 @@ TKZ_KERNEL_OCC(256, 8) void k_probe(TkzTables T, EncodeParams P) {
                 if (len <= TKZ_SHORT_KEY_MAX) {
                     uint32_t s1, s2;
                     tkz_short_slots(T, tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len, &s1, &s2);
-                    pa = reinterpret_cast<const uint4*>(T.short_slots) + s1; pbk = reinterpret_cast<const uint4*>(T.short_slots) + s2;
-                } else if (len <= TKZ_MID_KEY_MAX) {
-                    uint32_t kk[7], s1, s2;
-#pragma unroll
-                    for (int i = 0; i < 7; ++i) kk[i] = tkz_key_dword(s_bytes, s, len, i);
-                    tkz_mid_slots(T, kk, (uint32_t)len, &s1, &s2);
-                    pa = reinterpret_cast<const uint4*>(T.mid_slots) + 2 * (size_t)s1; pbk = reinterpret_cast<const uint4*>(T.mid_slots) + 2 * (size_t)s2;
+                    oa = 16u * s1; ob = 16u * s2;
                 }
             }
-            a0[u] = tkz_load16(pa); a1[u] = tkz_load16(pa + 1); b0[u] = tkz_load16(pbk); b1[u] = tkz_load16(pbk + 1);
+            // (idle lanes and longer pieces gather slot 0: a load inside a divergent branch is waited for inside it)
+#if defined(TKZ_EXP_LOADS) && TKZ_EXP_LOADS == 2
+            a0[u] = tkz_load16(tb0 + oa); a1[u] = tkz_load16(tb0 + oa + 16u); b0[u] = a0[u]; b1[u] = a1[u];
+#elif defined(TKZ_EXP_LOADS) && TKZ_EXP_LOADS == 1
+            a0[u] = tkz_load16(tb0 + oa); a1[u] = a0[u]; b0[u] = a0[u]; b1[u] = a0[u];
+#else
+            a0[u] = tkz_load16(tb0 + oa); a1[u] = tkz_load16(tb0 + oa + 16u); b0[u] = tkz_load16(tb0 + ob); b1[u] = tkz_load16(tb0 + ob + 16u);
+#endif
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + 64 * u + lane;
+            const bool valid = k < np;
             const int s = ps[u], len = plen[u];
-            // (the mark word of the piece's position: a wave-wide exchange, so every lane takes part -- idle ones with s = 0)
             const uint64_t mw = ((uint64_t)simt::shflu((uint32_t)(mymark >> 32), (s >> 6) & 15) << 32) | simt::shflu((uint32_t)mymark, (s >> 6) & 15);
-            if (k >= np) continue;
-            int32_t rank;                                                        // Encoder.TryGetValue(piece) (TikTokenizer.cs:262)
-            if (len <= TKZ_SHORT_KEY_MAX)
-                rank = tkz_match_short(tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len,
-                                       a0[u], a1[u], b0[u], b1[u]);
-            else if (len <= TKZ_MID_KEY_MAX) {
-                uint32_t kk[7];
+            const bool is_mid = valid && len > TKZ_SHORT_KEY_MAX && len <= TKZ_MID_KEY_MAX;
+            const uint64_t midm = simt::ballot(is_mid);
+            if (is_mid) s_mid[nmid + tkz_popc64(midm & tkz_lowmask(lane))] = (uint16_t)k;
+            nmid += tkz_popc64(midm);
+            if (valid && !is_mid) {
+                int32_t rank;                                                    // Encoder.TryGetValue(piece) (TikTokenizer.cs:262)
+                if (len <= TKZ_SHORT_KEY_MAX)
+                    rank = tkz_match_short(tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len,
+                                           a0[u], a1[u], b0[u], b1[u]);
+                else if (len > kArenaPiece) rank = TKZ_RANK_NONE;                // (k_giant_merge looks a giant piece up itself)
+                else if (s + len <= kSub + kHalo) rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)len);
+                else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return gbase[s + i]; }, (uint32_t)len);
+                uint32_t rec = ((mw >> (s & 63)) & 1ull) ? kPrMark : 0u;
+                if (rank != TKZ_RANK_NONE) rec |= (uint32_t)rank;
+                else if (len > kArenaPiece) { rec |= kPrMiss | kPrGiant | (uint32_t)s; flags |= 2u; }
+                else { rec |= kPrMiss | ((uint32_t)(len - 1) << kPrLenShift) | (uint32_t)s; if (len > kShortMax) flags |= 1u; }
+                if (pb + k < P.prank_cap) tkz_store_nt(&P.prank[pb + k], (int32_t)rec);
+            }
+        }
+    }
+    (void)simt::ballot(true);
+    if (prof) t_2 = simt::clock();
+    // ---- the pieces of 13..28 bytes: MID table, 64 per batch ----
+#pragma unroll 1
+    for (int m0 = 0; m0 < nmid; m0 += 64) {
+        const bool valid = m0 + lane < nmid;
+        int k = 0, s = 0, len = 13;
+        uint32_t kk[7] = {0, 0, 0, 0, 0, 0, 0}, oa = 0, ob = 0;
+        if (valid) {
+            k = s_mid[m0 + lane];
+            s = s_pstart[k];
+            len = (int)((k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s);
 #pragma unroll
-                for (int i = 0; i < 7; ++i) kk[i] = tkz_key_dword(s_bytes, s, len, i);
-                rank = tkz_match_mid(kk, (uint32_t)len, a0[u], a1[u], b0[u], b1[u]);
-            } else if (len > kArenaPiece) rank = TKZ_RANK_NONE;                  // (k_giant_merge looks a giant piece up itself)
-            else if (s + len <= kSub + kHalo) rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)len);
-            else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return gbase[s + i]; }, (uint32_t)len);
+            for (int i = 0; i < 7; ++i) kk[i] = tkz_key_dword(s_bytes, s, len, i);
+            uint32_t s1, s2;
+            tkz_mid_slots(T, kk, (uint32_t)len, &s1, &s2);
+            oa = mid_off + 32u * s1; ob = mid_off + 32u * s2;
+        }
+        const uint4 a0 = tkz_load16(tb0 + oa), a1 = tkz_load16(tb0 + oa + 16u), b0 = tkz_load16(tb0 + ob), b1 = tkz_load16(tb0 + ob + 16u);
+        const uint64_t mw = ((uint64_t)simt::shflu((uint32_t)(mymark >> 32), (s >> 6) & 15) << 32) | simt::shflu((uint32_t)mymark, (s >> 6) & 15);
+        if (valid) {
+            const int32_t rank = tkz_match_mid(kk, (uint32_t)len, a0, a1, b0, b1);
             uint32_t rec = ((mw >> (s & 63)) & 1ull) ? kPrMark : 0u;
             if (rank != TKZ_RANK_NONE) rec |= (uint32_t)rank;
-            else if (len > kArenaPiece) { rec |= kPrMiss | kPrGiant | (uint32_t)s; flags |= 2u; }
             else { rec |= kPrMiss | ((uint32_t)(len - 1) << kPrLenShift) | (uint32_t)s; if (len > kShortMax) flags |= 1u; }
-            if (pb + k < P.prank_cap) P.prank[pb + k] = rec;
+            if (pb + k < P.prank_cap) tkz_store_nt(&P.prank[pb + k], (int32_t)rec);
         }
+    }
+    if (prof && lane == 0) {
+        t_3 = simt::clock();
+        simt::atomic_add64(&P.devprof[0], 1); simt::atomic_add64(&P.devprof[1], (unsigned long long)(t_3 - t_0));
+        simt::atomic_add64(&P.devprof[2], (unsigned long long)(t_1 - t_0)); simt::atomic_add64(&P.devprof[3], (unsigned long long)(t_2 - t_1));
+        simt::atomic_add64(&P.devprof[4], (unsigned long long)(t_3 - t_2)); simt::atomic_add64(&P.devprof[5], (unsigned long long)nmid);
+        simt::atomic_add64(&P.devprof[6], (unsigned long long)np);
     }
     // sub-tiles with a piece of 17+ bytes to merge (bit 0) or a giant piece (bit 1) are visited by k_merge_long / k_giant_find
     const uint32_t f = (simt::ballot(flags & 1u) ? 1u : 0u) | (simt::ballot(flags & 2u) ? 2u : 0u);
@@ -531,17 +602,24 @@ TKZ_KERNEL_OCC(256, 3) void k_merge_short(TkzTables T, EncodeParams P) {
 #pragma unroll 1
     for (int si = 0; si < kGroup; ++si) {
 #pragma unroll 1
-        for (int k0 = 0; k0 < nps[si]; k0 += 64) {
-            const int k = k0 + lane;
-            uint32_t rec = 0;
-            if (k < nps[si] && pbs[si] + k < P.prank_cap) rec = P.prank[pbs[si] + k];
-            const bool is = (rec & kPrMiss) && !(rec & kPrGiant) && (int)((rec >> kPrLenShift) & kPrLenMask) < kShortMax;
-            const uint64_t m = simt::ballot(is);
-            const int c = tkz_popc64(m);
-            if (c == 0) continue;
-            if (nlist + c > 64) { run_batch(nlist); nlist = 0; }
-            if (is) { const int o = nlist + tkz_popc64(m & tkz_lowmask(lane)); s_rec[o] = rec; s_idx[o] = ((uint32_t)si << 10) | (uint32_t)k; }
-            nlist += c;
+        for (int k0 = 0; k0 < nps[si]; k0 += 256) {          // four record loads in flight per lane (a sub-tile averages ~230 pieces)
+            uint32_t r4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + 64 * j + lane;
+                r4[j] = (k < nps[si] && pbs[si] + k < P.prank_cap) ? (uint32_t)tkz_load_nt(&P.prank[pbs[si] + k]) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t rec = r4[j];
+                const bool is = (rec & kPrMiss) && !(rec & kPrGiant) && (int)((rec >> kPrLenShift) & kPrLenMask) < kShortMax;
+                const uint64_t m = simt::ballot(is);
+                const int c = tkz_popc64(m);
+                if (c == 0) continue;
+                if (nlist + c > 64) { run_batch(nlist); nlist = 0; }
+                if (is) { const int o = nlist + tkz_popc64(m & tkz_lowmask(lane)); s_rec[o] = rec; s_idx[o] = ((uint32_t)si << 10) | (uint32_t)(k0 + 64 * j + lane); }
+                nlist += c;
+            }
         }
     }
     if (nlist > 0) run_batch(nlist);
@@ -556,8 +634,10 @@ TKZ_KERNEL_OCC(256, 3) void k_merge_short(TkzTables T, EncodeParams P) {
 }
 
 // The pieces of 17..1024 bytes that have to be merged, and the token counts of the giant ones: only in the sub-tiles k_probe
-// flagged.  One lane per piece with its state in an LDS arena sized for it (tkz_bpe_lane_var), as many pieces per pass as fit.
-TKZ_KERNEL_OCC(64, 3) void k_merge_long(TkzTables T, EncodeParams P) {
+// flagged.  One lane per piece with its state in a span of an LDS arena sized for it (tkz_bpe_lane_var: ids | pair ranks | alive
+// bits, preceded by the piece's bytes); the long misses of the 64 sub-tiles of a chunk are packed into one wavefront's lanes -- as
+// many per batch as the arena and the 64 lanes take -- because a sub-tile on its own has one or two of them.
+TKZ_KERNEL_OCC(64, 2) void k_merge_long(TkzTables T, EncodeParams P) {
     TKZ_SHARED uint4 s_arena4[kArenaDwords / 4];
     TKZ_SHARED uint32_t s_rec[64], s_idx[64], s_aoff[64];
     uint32_t* s_arena = reinterpret_cast<uint32_t*>(s_arena4);
@@ -565,66 +645,89 @@ TKZ_KERNEL_OCC(64, 3) void k_merge_long(TkzTables T, EncodeParams P) {
     int err = 0;
     for (int64_t c = simt::bid(); c * 64 < P.nsub; c += simt::nblocks()) {
         const int64_t t = c * 64 + lane;
-        uint64_t fm = simt::ballot(t < P.nsub && P.heavy_flag[t] != 0);
+        const uint32_t myflag = t < P.nsub ? P.heavy_flag[t] : 0u;
+        uint64_t fm = simt::ballot(myflag != 0);
+        if (!fm) continue;
+        int nlist = 0, aused = 0;
+        // one batch: lane i < nlist stages the bytes of its piece, merges it, leaves the tokens in tmp at the piece's own position
+        auto run_batch = [&]() {
+            (void)simt::ballot(true);
+            if (lane < nlist) {
+                const uint32_t rec = s_rec[lane], ix = s_idx[lane];
+                const int64_t sub = c * 64 + (int64_t)(ix >> 10);
+                const int rel = (int)(rec & 1023u), len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+                const int64_t abs = sub * kSub + rel;
+                uint32_t* bw = &s_arena[s_aoff[lane]];           // (len + 3) / 4 dwords of bytes, then the merge state
+                const int nbw = (len + 3) >> 2;
+                {
+                    const int64_t a0 = abs & ~(int64_t)3;
+                    const int sh = (int)(abs & 3) * 8;
+                    uint32_t prev = 0;
+                    if (a0 + 4 <= P.total) prev = *reinterpret_cast<const uint32_t*>(P.bytes + a0);
+                    else for (int b = 0; b < 4; ++b) if (a0 + b < P.total) prev |= (uint32_t)P.bytes[a0 + b] << (8 * b);
+                    for (int q = 0; q < nbw; ++q) {
+                        const int64_t p = a0 + 4 * (q + 1);
+                        uint32_t nx = 0;
+                        if (p + 4 <= P.total) nx = *reinterpret_cast<const uint32_t*>(P.bytes + p);
+                        else for (int b = 0; b < 4; ++b) if (p + b < P.total) nx |= (uint32_t)P.bytes[p + b] << (8 * b);
+                        bw[q] = (uint32_t)((((uint64_t)nx << 32) | prev) >> sh);
+                        prev = nx;
+                    }
+                }
+                const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(bw);
+                uint32_t* st = bw + ((nbw + 3) & ~3);             // (the state arrays are read 16 bytes at a time)
+                auto at = [&](int i) -> uint32_t { return pbytes[i]; };
+                int e1 = 0;
+                const int cnt = T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &e1) : tkz_bpe_lane_var<false>(T, at, len, st, &e1);
+                err |= e1;
+                tkz_bpe_var_emit(st, len, P.tmp + abs);
+                P.prank[P.pbase[sub] + (ix & 1023u)] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (uint32_t)rel;
+                if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
+            }
+            (void)simt::ballot(true);
+            nlist = 0; aused = 0;
+        };
         for (; fm; fm &= fm - 1) {
-            const int64_t sub = c * 64 + tkz_ctz64(fm);
+            const int sidx = tkz_ctz64(fm);
+            const int64_t sub = c * 64 + sidx;
             const int64_t pb = P.pbase[sub];
             const int np = P.pcount[sub];
-            int added = 0;
-            int k0 = 0;
-            while (k0 < np) {
-                // collect the next long misses of this sub-tile, as many as the arena and the 64 lanes take
-                int nlist = 0, aused = 0, knext = np;
-                for (; k0 < np && knext == np; k0 += 64) {
-                    const int k = k0 + lane;
-                    uint32_t rec = 0;
-                    if (k < np && pb + k < P.prank_cap) rec = P.prank[pb + k];
+#pragma unroll 1
+            for (int k0 = 0; k0 < np; k0 += 256) {               // four record loads in flight per lane
+                uint32_t r4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = k0 + 64 * j + lane;
+                    r4[j] = (k < np && pb + k < P.prank_cap) ? (uint32_t)tkz_load_nt(&P.prank[pb + k]) : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t rec = r4[j];
                     const int len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
-                    const bool giant = (rec & kPrMiss) && (rec & kPrGiant);
                     const bool is = (rec & kPrMiss) && !(rec & (kPrGiant | kPrDone)) && len > kShortMax;
-                    const uint64_t gm = simt::ballot(giant);
-                    const uint64_t m = simt::ballot(is);
-                    int limit = 64;                              // lanes of this chunk at or beyond `limit` wait for the next pass
-                    if (m) {
-                        const int need = is ? tkz_bpe_var_dwords(len) : 0;
+                    // the giant piece of the sub-tile (its last piece): merged by k_giant_merge, its token count is added here
+                    if ((rec & kPrMiss) && (rec & kPrGiant)) { const int g = P.giant_cnt[sub]; if (g > 1) simt::atomic_add(&P.tile_count[sub], g - 1); }   // (< 0: no pool, the call is retried)
+                    uint64_t pending = simt::ballot(is);
+                    while (pending) {
+                        const bool mine = is && ((pending >> lane) & 1ull);
+                        const int need = mine ? ((((len + 3) >> 2) + 3) & ~3) + tkz_bpe_var_dwords(len) : 0;
                         int btot;
                         const int aoff = aused + tkz_wave_scan_sum(need, &btot);
-                        const int qi = nlist + tkz_popc64(m & tkz_lowmask(lane));
-                        const bool fits = is && qi < 64 && aoff + need <= kArenaDwords;
-                        const uint64_t bad = simt::ballot(is && !fits);
-                        if (bad) limit = tkz_ctz64(bad);         // the first piece left over starts the next pass
-                        if (fits && lane < limit) { s_rec[qi] = rec; s_idx[qi] = (uint32_t)k; s_aoff[qi] = (uint32_t)aoff; }
-                        if (bad) { knext = k0 + limit; nlist += tkz_popc64(m & tkz_lowmask(limit)); aused = simt::shfl(aoff, limit); }
-                        else { nlist += tkz_popc64(m); aused += btot; }
+                        const int qi = nlist + tkz_popc64(pending & tkz_lowmask(lane));
+                        const bool fits = mine && qi < 64 && aoff + need <= kArenaDwords;
+                        const uint64_t bad = simt::ballot(mine && !fits);
+                        const int limit = bad ? tkz_ctz64(bad) : 64;       // lanes at or beyond `limit` wait for the next batch
+                        if (fits && lane < limit) { s_rec[qi] = rec; s_idx[qi] = ((uint32_t)sidx << 10) | (uint32_t)(k0 + 64 * j + lane); s_aoff[qi] = (uint32_t)aoff; }
+                        const uint64_t took = pending & tkz_lowmask(limit);
+                        nlist += tkz_popc64(took);
+                        aused = bad ? simt::shfl(aoff, limit) : aused + btot;
+                        pending &= ~took;
+                        if (pending) run_batch();
                     }
-                    // the giant piece of the sub-tile (its last piece): merged by k_giant_merge, its token count is added here -- once
-                    if (gm && tkz_ctz64(gm) < limit && lane == 0) { const int g = P.giant_cnt[sub]; added += g > 0 ? g - 1 : 0; }   // (< 0: no pool, the call is retried)
                 }
-                (void)simt::ballot(true);
-                int cnt1 = 0;
-                if (lane < nlist) {
-                    const uint32_t rec = s_rec[lane];
-                    const int rel = (int)(rec & 1023u), len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
-                    const int64_t abs = sub * kSub + rel;
-                    const uint8_t* gb = P.bytes + abs;
-                    uint32_t* st = &s_arena[s_aoff[lane]];
-                    auto at = [&](int i) -> uint32_t { return gb[i]; };
-                    int e1 = 0;
-                    const int cnt = T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &e1) : tkz_bpe_lane_var<false>(T, at, len, st, &e1);
-                    err |= e1;
-                    tkz_bpe_var_emit(st, len, P.tmp + abs);
-                    P.prank[pb + s_idx[lane]] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (uint32_t)rel;
-                    cnt1 = cnt - 1;
-                }
-                int tot;
-                (void)tkz_wave_scan_sum(cnt1, &tot);
-                added += tot;                                    // (lane 0's copy also holds the giant pieces' share)
-                (void)simt::ballot(true);
-                if (knext < np) k0 = knext;                      // redo from the first piece that did not fit (done pieces are skipped)
             }
-            const int mine = simt::shfl(added, 0);              // lane 0: merges + giants; other lanes: merges only -- take lane 0's
-            if (lane == 0 && mine) simt::atomic_add(&P.tile_count[sub], mine);
         }
+        if (nlist > 0) run_batch();
     }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
@@ -641,22 +744,45 @@ TKZ_KERNEL_OCC(256, 8) void k_place(EncodeParams P, const int64_t* tile_base, in
     if (gcnt < 0) gcnt = 0;
     int running = 0, marks = 0;
 #pragma unroll 1
-    for (int k0 = 0; k0 < np; k0 += 64) {
+    for (int kk = 0; kk < np; kk += 256) {                     // four record loads in flight per lane
+      uint32_t r4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+          const int k = kk + 64 * j + lane;
+          r4[j] = (k < np && pb + k < P.prank_cap) ? (uint32_t)tkz_load_nt(&P.prank[pb + k]) : 0u;
+      }
+      // the first four tokens of every missed piece of the four chunks: all those gathers in flight together, before any store
+      int32_t t4[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+          const uint32_t rec = r4[j];
+          const int32_t* src = P.tmp + base + (rec & 1023u);
+          const bool ld = (rec & kPrMiss) != 0;
+          const int cnt = (rec & kPrGiant) ? gcnt : (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t4[j][i] = (ld && i < cnt) ? src[i] : 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k0 = kk + 64 * j;
+        if (k0 >= np) break;
         const int k = k0 + lane;
         const bool valid = k < np && pb + k < P.prank_cap;
-        const uint32_t rec = valid ? (uint32_t)P.prank[pb + k] : 0u;
+        const uint32_t rec = r4[j];
         const bool miss = (rec & kPrMiss) != 0;
         int cnt = !valid ? 0 : !miss ? 1 : (rec & kPrGiant) ? gcnt : (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
         int tot;
-        const int pos = running + ((has_giant && simt::ballot(cnt > 1024)) ? tkz_wave_scan_sum(cnt, &tot) : tkz_wave_scan<11>(cnt, &tot));
+        const int pos = running + tkz_wave_scan_sum(cnt, &tot);
         const uint64_t mm = simt::ballot(valid && (rec & kPrMark));
         if (valid) {
             if (rec & kPrMark) P.doc_tok[ord0 + marks + tkz_popc64(mm & tkz_lowmask(lane))] = pos;
             int32_t* dst = out + tb + pos;
-            if (!miss) { if (tb + pos < out_cap) dst[0] = (int32_t)(rec & kPrRankMask); }
+            if (!miss) { if (tb + pos < out_cap) tkz_store_nt(&dst[0], (int32_t)(rec & kPrRankMask)); }
             else if (cnt <= 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i < cnt && tb + pos + i < out_cap) dst[i] = t4[j][i];
                 const int32_t* src = P.tmp + base + (rec & 1023u);
-                for (int i = 0; i < cnt; ++i) if (tb + pos + i < out_cap) dst[i] = src[i];
+                for (int i = 4; i < cnt; ++i) if (tb + pos + i < out_cap) dst[i] = src[i];
             }
         }
         // long token runs (a merged piece of many bytes, a giant piece): copied by the whole wavefront, one after the other
@@ -670,6 +796,7 @@ TKZ_KERNEL_OCC(256, 8) void k_place(EncodeParams P, const int64_t* tile_base, in
         }
         running += tot;
         marks += tkz_popc64(mm);
+      }
     }
 }
 

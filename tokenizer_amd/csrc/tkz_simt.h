@@ -48,7 +48,32 @@ TKZ_DEV unsigned long long atomic_or64(unsigned long long* p, unsigned long long
 TKZ_DEV unsigned long long atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 TKZ_DEV unsigned long long atomic_min64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
 TKZ_DEV long long clock() { return (long long)__builtin_readcyclecounter(); }
+// inclusive prefix sum over the 64 lanes on the DPP crossbar (row shifts inside the rows of 16, then the two row broadcasts): six
+// data-parallel moves, no LDS, no ballots
+template <int CTRL> TKZ_DEV int dpp_mov(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false); }
+TKZ_DEV int scan_inclusive(int v) {
+    const int l = lane();
+    int x = v, t;
+    t = dpp_mov<0x111>(x); if ((l & 15) >= 1) x += t;      // row_shr:1
+    t = dpp_mov<0x112>(x); if ((l & 15) >= 2) x += t;      // row_shr:2
+    t = dpp_mov<0x114>(x); if ((l & 15) >= 4) x += t;      // row_shr:4
+    t = dpp_mov<0x118>(x); if ((l & 15) >= 8) x += t;      // row_shr:8
+    t = dpp_mov<0x142>(x); if ((l & 31) >= 16) x += t;     // row_bcast:15
+    t = dpp_mov<0x143>(x); if (l >= 32) x += t;            // row_bcast:31
+    return x;
+}
+TKZ_DEV int last_lane(int v) { return __builtin_amdgcn_readlane(v, 63); }
 }  // namespace simt
+// Streaming accesses (touched once: the corpus, the per-piece records, the ids): non-temporal, so that they do not evict the
+// vocabulary tables every gather of the encode kernels wants to find in L2.
+typedef uint32_t tkz_u32x4 __attribute__((ext_vector_type(4)));
+TKZ_DEV uint4 tkz_load16_nt(const void* p) {
+    const tkz_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const tkz_u32x4*>(p));
+    uint4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
+}
+TKZ_DEV uint32_t tkz_load_nt(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+TKZ_DEV int32_t tkz_load_nt(const int32_t* p) { return __builtin_nontemporal_load(p); }
+TKZ_DEV void tkz_store_nt(int32_t* p, int32_t v) { __builtin_nontemporal_store(v, p); }
 #endif
 
 // ---- bit helpers shared by host and device code ------------------------------------------------

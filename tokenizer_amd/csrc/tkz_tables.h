@@ -105,31 +105,39 @@ TKZ_HD uint32_t tkz_mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
     return h;
 }
-// the two hashes of a short key given as zero-padded little-endian dwords
-TKZ_HD uint32_t tkz_hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t seed) {
-    uint32_t h = tkz_mix32(k0 + 0x9E3779B9u * len + seed);
-    h = tkz_mix32(h ^ (k1 * 0x85EBCA6Bu));
-    h = tkz_mix32(h + (k2 * 0xC2B2AE35u));
-    return h;
-}
-TKZ_HD uint32_t tkz_hash_short2(uint32_t h1) { return tkz_mix32(h1 * 0x27D4EB2Fu + 0x165667B1u); }
+// The table hashes are deliberately CHEAP (one multiply per key dword + one finishing multiply): k_probe issues them for every
+// piece of the corpus and is bound by VALU issue, not by memory; the builder verifies every insertion and retries with another
+// seed, so a weak hash can cost build time but never correctness.  Slots are taken from the HIGH bits (tkz_mulhi).
+TKZ_HD uint32_t tkz_rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+TKZ_HD uint32_t tkz_fmix(uint32_t h) { h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; return h; }
 // slot of a hash in a table of n slots (n arbitrary, h uniform over 32 bits): one v_mul_hi_u32
 TKZ_HD uint32_t tkz_mulhi(uint32_t h, uint32_t n) { return (uint32_t)(((uint64_t)h * (uint64_t)n) >> 32); }
+// the second hash of every cuckoo table, derived from the first
+TKZ_HD uint32_t tkz_hash_second(uint32_t h1) { const uint32_t h = h1 * 0x846ca68bU + 0x165667B1u; return h ^ (h >> 15); }
+// a short key given as zero-padded little-endian dwords
+TKZ_HD uint32_t tkz_hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t seed) {
+    uint32_t h = (k0 ^ tkz_rotl(k1, 13) ^ tkz_rotl(k2, 23) ^ (len << 27) ^ seed) * 0x9E3779B1u;     // (32-bit multiplies run at a quarter of the VALU rate)
+    return tkz_fmix(h ^ (h >> 15) ^ k1);
+}
+TKZ_HD uint32_t tkz_hash_short2(uint32_t h1) { return tkz_hash_second(h1); }
 // a key of 13..28 bytes given as seven zero-padded little-endian dwords
 TKZ_HD uint32_t tkz_hash_mid(const uint32_t* k, uint32_t len, uint32_t seed) {
-    uint32_t h = tkz_mix32(k[0] + 0x9E3779B9u * len + seed);
-    h = tkz_mix32(h ^ (k[1] * 0x85EBCA6Bu)) + k[2] * 0xC2B2AE35u;
-    h = tkz_mix32(h ^ (k[3] * 0x27D4EB2Fu)) + k[4] * 0x165667B1u;
-    h = tkz_mix32(h ^ (k[5] * 0x9E3779B1u)) + k[6] * 0x85EBCA77u;
-    return tkz_mix32(h);
+    uint32_t h = (k[0] + seed) * 0x9E3779B1u;
+    h ^= tkz_rotl(k[1] * 0x85EBCA77u, 15);
+    h ^= tkz_rotl(k[2] * 0xC2B2AE3Du, 7);
+    h += tkz_rotl(k[3] * 0x27D4EB2Fu, 11);
+    h ^= tkz_rotl(k[4] * 0x165667B1u, 19);
+    h += tkz_rotl(k[5] * 0x9E3779B9u, 3);
+    h ^= tkz_rotl(k[6] * 0x85EBCA6Bu, 23);
+    return tkz_fmix(h + len * 0x27D4EB2Fu);
 }
 // streaming form for long keys: feed ceil(len/4) zero-padded dwords in order
 TKZ_HD uint32_t tkz_hash_long_init(uint32_t len) { return 0x2545F491u ^ (len * 0x9E3779B9u); }
 TKZ_HD uint32_t tkz_hash_long_step(uint32_t h, uint32_t w) { return tkz_mix32(h ^ w) + 0x632BE5ABu; }
 TKZ_HD uint32_t tkz_hash_pair(uint32_t a, uint32_t b, uint32_t seed) {
-    return tkz_mix32((a + seed) * 0x9E3779B9u ^ tkz_mix32(b + 0x7F4A7C15u));
+    return tkz_fmix(((a + seed) * 0x9E3779B1u) ^ tkz_rotl(b * 0x85EBCA77u, 13));
 }
-TKZ_HD uint32_t tkz_hash_pair2(uint32_t h1) { return tkz_mix32(h1 * 0x27D4EB2Fu + 0x165667B1u); }
+TKZ_HD uint32_t tkz_hash_pair2(uint32_t h1) { return tkz_hash_second(h1); }
 
 // ---- probes ---------------------------------------------------------------------------------------
 TKZ_HD uint4 tkz_load16(const void* p) { return *reinterpret_cast<const uint4*>(p); }

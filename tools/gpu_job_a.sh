@@ -1,7 +1,7 @@
 #!/bin/bash
 # first GPU job of round 2: parity suite, bench line, other shapes, stage breakdown (dev build), rocprof passes
 set -u
-REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; O=gpurun_out/r02b; mkdir -p $O
+REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; O=gpurun_out/r02f; mkdir -p $O
 rocm-smi --showproductname 2>/dev/null | head -8 > $O/gpu.txt; nproc >> $O/gpu.txt
 ( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
 timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"; cut -c1-1500 $O/bench_n1.json
@@ -10,7 +10,7 @@ for spec in "--kind 4 --docs 4000000" "--kind 2 --docs 2000000" "--kind 3 --patt
 done
 python - <<'PY'
 import json
-for l in open('gpurun_out/r02b/bench_shapes.jsonl'):
+for l in open('gpurun_out/r02f/bench_shapes.jsonl'):
     j=json.loads(l); print(j['config']['workload'][:60], j['config']['pattern'], j['value'], j['ms_per_step'], j['roofline']['kernels_ms'])
 PY
-bash tools/gpu_profile.sh r02b 10000000 > $O/profile.log 2>&1; tail -60 $O/profile.log | head -80
+bash tools/gpu_profile.sh r02f 10000000 > $O/profile.log 2>&1; tail -60 $O/profile.log | head -80
