@@ -157,6 +157,8 @@ def main():
         try:
             comm = sharded.RcclCounts(rank, world, local_rank, exchange)
         finally:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)          # (the banner sits in C stdio's buffer: flush it while fd 1 still points at stderr)
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
         comm_info = comm.info()

@@ -815,12 +815,14 @@ typedef struct {
 static void* batch_worker(void* vj) {
     batch_job* j = (batch_job*)vj;
     tkzo_encoder* e = tkzo_encoder_create(j->v, j->pattern, j->cache);
+    int64_t total = 0;                     /* (kept local: the jobs of neighbouring threads share cache lines) */
     for (int64_t d = j->d0; d < j->d1; ++d) {
         int64_t a = j->offs[d], b = j->offs[d + 1];
         int64_t k = encode_segment_utf8(e, j->bytes + a, b - a, j->out + a, b - a);
         if (k < 0) { j->err = k; break; }
-        j->counts[d] = (int32_t)k; j->total += k;
+        j->counts[d] = (int32_t)k; total += k;
     }
+    j->total = total;
     tkzo_encoder_free(e);
     return NULL;
 }

@@ -1,6 +1,7 @@
 """Parity checks shared by the emulated (CPU) and the real (GPU) test modules: every function takes
 the library under test (`lib`, a tokenizer_amd._native.Library) and the oracle, and compares the two on
 the same seeded inputs.  Integer work: the bar is bit-exact."""
+import os
 import random
 
 import pytest
@@ -401,3 +402,33 @@ def check_piece_granular(lib, O, vocab, ovocab, pattern, seed=3, rounds=6):
             pos += len(d)
         e_pbo.append(pos)
         assert dpo.tolist() == e_dpo and pbo.tolist() == e_pbo and pto.tolist() == e_pto and ids.tolist() == e_ids, "pattern %d round %d" % (pattern, it)
+
+
+def check_host_chunks(lib, O, vocab, ovocab, pattern=N.CL100K, seed=21):
+    """The chunked, overlapped host path of tkz_encode_batch_utf8 (document ranges on three streams, two staging sets) gives the
+    ids and offsets of the one-piece path: empty documents on chunk edges, a chunk that is one long document, the capacity error
+    with the total requirement, bad offsets.  ($TKZ_HOST_CHUNK_BYTES must be small for the batch to be cut at all.)"""
+    alpha = RC.alphabet()
+    rng = random.Random(seed)
+    enc = N.Encoder(vocab, pattern)
+    oenc = O.Encoder(ovocab, pattern)
+    for it in range(4):
+        docs = []
+        for _ in range(rng.choice([30, 120])):
+            k = rng.random()
+            docs.append(b"" if k < 0.15 else gen_text(rng, rng.choice(["mix", "a_mix", "ws"]), rng.choice([1, 50, 700, 3000, 9000]), alpha).encode("utf-8"))
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        exp, eoff = oracle_encode_docs(oenc, docs)
+        assert ids.tolist() == exp and ooff.tolist() == eoff, "round %d" % it
+        # capacity: one id short -> TKZ_E_CAPACITY and the whole batch's requirement
+        import ctypes as C
+        small = np.empty(max(1, len(exp) - 1), np.int32)
+        oo = np.empty(len(docs) + 1, np.int64)
+        needed = C.c_int64(0)
+        st = lib.L.tkz_encode_batch_utf8(enc._h, data.ctypes.data, offs.ctypes.data, len(docs), small.ctypes.data, len(exp) - 1, oo.ctypes.data, C.byref(needed))
+        if len(exp) > 0:
+            assert st == N.E_CAPACITY and needed.value == len(exp), (st, needed.value, len(exp))
+    with pytest.raises(N.TkzError) as ei:
+        enc.encode_batch(np.frombuffer(b"x" * 40000, np.uint8), np.array([0, 30000, 20000, 40000]))
+    assert ei.value.code == N.E_ARG

@@ -165,6 +165,22 @@ def test_shard_writer_c_abi(lib, tmp_path):
     assert open(p2, "rb").read() == open(p, "rb").read()
 
 
+def test_host_path_chunks(vocab_bytes, oracle_mod):
+    # the chunk size is read once per process: this test runs in its own interpreter with a 4 KiB chunk
+    import subprocess, sys, os
+    code = ("import os, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import gzip, emu, parity\n"
+            "from tokenizer_amd import _native as N\n"
+            "from oracle import oracle as O\n"
+            "raw = gzip.decompress(open(%r, 'rb').read())\n"
+            "lib = emu.library()\n"
+            "parity.check_host_chunks(lib, O, N.Vocab(raw, lib), O.Vocab(raw))\n"
+            "print('CHUNKS_OK')\n") % (parity.os.path.dirname(parity.os.path.dirname(parity.__file__)), parity.os.path.dirname(parity.__file__),
+                                       parity.os.path.join(parity.os.path.dirname(parity.__file__), "golden", "gpt2.tiktoken.gz"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKZ_HOST_CHUNK_BYTES="4096"), capture_output=True, text=True, timeout=600)
+    assert "CHUNKS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_errors_and_edges(lib, vocab, oracle_mod):
     parity.check_errors(lib, oracle_mod, vocab)
 

@@ -261,6 +261,49 @@ def test_device_corpus_properties_and_sample(lib, vocabs, oracle_mod, vname, kin
         assert h_ids[h_ooffs[d]:h_ooffs[d + 1]].tolist() == oenc.encode_bytes(doc), "doc %d" % d
 
 
+def test_host_path_chunked_and_threads(lib, vocabs, oracle_mod):
+    """tkz_encode_batch_utf8 on host buffers at a size that is cut into chunks (upload k+1 / kernels k / download k-1 overlapped),
+    pageable and page-locked, against the device-resident path; then two host threads on ONE encoder at the same time (each call
+    leases its own workspace and streams): both get the right answer."""
+    import threading
+    import time
+    import torch
+    vocab, ov = vocabs("synth100k")
+    n, lo, hi, seed = 600_000, 256, 768, 0x5EED0002
+    r = _device_run(lib, vocab, 1, 2, n, lo, hi, seed)
+    h_bytes = r["d_bytes"][:r["total"]].cpu().numpy()
+    h_offs = r["d_offs"].cpu().numpy()
+    want_ids, want_offs = r["d_ids"].cpu().numpy(), r["d_ooffs"].cpu().numpy()
+    enc = r["enc"]
+    ids, ooff = enc.encode_batch(h_bytes, h_offs)                                  # pageable buffers
+    assert np.array_equal(ids, want_ids) and np.array_equal(ooff, want_offs)
+    pb = torch.from_numpy(h_bytes).pin_memory()
+    po = torch.from_numpy(h_offs).pin_memory()
+    out = (torch.zeros(len(h_bytes), dtype=torch.int32).pin_memory().numpy(), torch.zeros(n + 1, dtype=torch.int64).pin_memory().numpy())
+    t0 = time.perf_counter()
+    ids, ooff = enc.encode_batch(pb.numpy(), po.numpy(), out=out)                  # page-locked buffers: fully asynchronous copies
+    dt = time.perf_counter() - t0
+    assert np.array_equal(ids, want_ids) and np.array_equal(ooff, want_offs)
+    print("host path, page-locked buffers: %.1f GB/s" % (len(h_bytes) / dt / 1e9))
+    # two threads, two different batches, one encoder
+    half = n // 2
+    cutb = int(h_offs[half])
+    parts = [(h_bytes[:cutb], h_offs[:half + 1]), (h_bytes[cutb:], h_offs[half:] - cutb)]
+    res = [None, None]
+
+    def work(i):
+        for _ in range(3):
+            res[i] = enc.encode_batch(parts[i][0], parts[i][1])
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    ntok0 = int(want_offs[half])
+    assert np.array_equal(res[0][0], want_ids[:ntok0]) and np.array_equal(res[0][1], want_offs[:half + 1])
+    assert np.array_equal(res[1][0], want_ids[ntok0:]) and np.array_equal(res[1][1], want_offs[half:] - ntok0)
+
+
 def test_rccl_communicator_counts(lib, vocab):
     """The C ABI's direct-RCCL communicator (tkz_comm_*): RCCL is initialised through libtkz and the count all-gather runs both
     asynchronously on the encode stream (table kept in HBM) and in its blocking host form.  world = 1 on a one-GPU box (RCCL

@@ -80,47 +80,88 @@ namespace tkz { tkz_status set_error(tkz_status s, const std::string& msg) { ret
 
 struct tkz_vocab { tkz::Vocab v; };
 
+// Everything one in-flight call needs besides the (read-only) tables: kernel workspace, staging for the host-buffer entry
+// points, streams and profiling events.  An encoder keeps a pool of these; every entry point leases one for the duration of the
+// call, so host threads sharing one encoder run concurrently, each on its own workspace and streams ("one encoder
+// usable from many host threads") -- the reference's instance is likewise safe to share (its only shared mutable state, the LRU
+// memo, is locked: LRUCache.cs:61,99).
+struct Workspace {
+    // kernel workspace
+    DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
+    // staging for the host-buffer entry points (two sets: chunk k+1 is uploaded while chunk k is encoded and chunk k-1 downloaded)
+    DevBuf s_bytes[2], s_offs[2], s_out[2], s_outoffs[2];
+    // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
+    DevBuf u_units, u_offs, u_docbits, u_grp, u_tsum, u_tbase, u_bsum, u_counters, u_bytes, u_boffs;
+    // Decode
+    DevBuf d_grp, d_tsum, d_tbase, d_bsum, d_counters, d_ids, d_idoffs, d_out, d_outoffs;
+    // piece-granular entry point: piece byte offsets, token offsets, first piece of every document
+    DevBuf p_boffs, p_toffs, p_docp;
+    CounterBlock* h_counters = nullptr;   // pinned
+    hipStream_t st_compute = nullptr, st_in = nullptr, st_out = nullptr;   // the host-buffer entry points: kernels / uploads / downloads
+    hipEvent_t ev_in[2] = {}, ev_done[2] = {}, ev_out[2] = {};
+    int64_t bytes_allocated = 0;
+    bool busy = false;
+    // profiling
+    hipEvent_t ev[tkz::K_COUNT][2] = {};
+    bool ev_used[tkz::K_COUNT] = {};
+    double ms[tkz::K_COUNT] = {};
+    int64_t launches[tkz::K_COUNT] = {};
+    void release_all() {
+        DevBuf* bufs[] = {&w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
+                          &w_doctok, &w_dcount, &w_dbase, &w_counters, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
+                          &s_outoffs[0], &s_outoffs[1], &u_units, &u_offs, &u_docbits, &u_grp, &u_tsum, &u_tbase, &u_bsum, &u_counters, &u_bytes, &u_boffs,
+                          &d_grp, &d_tsum, &d_tbase, &d_bsum, &d_counters, &d_ids, &d_idoffs, &d_out, &d_outoffs, &p_boffs, &p_toffs, &p_docp};
+        for (DevBuf* b : bufs) b->release();
+        if (h_counters) (void)hipHostFree(h_counters);
+        for (int k = 0; k < tkz::K_COUNT; ++k) for (int q = 0; q < 2; ++q) if (ev[k][q]) (void)hipEventDestroy(ev[k][q]);
+        for (int q = 0; q < 2; ++q) { if (ev_in[q]) (void)hipEventDestroy(ev_in[q]); if (ev_done[q]) (void)hipEventDestroy(ev_done[q]); if (ev_out[q]) (void)hipEventDestroy(ev_out[q]); }
+        if (st_compute) (void)hipStreamDestroy(st_compute);
+        if (st_in) (void)hipStreamDestroy(st_in);
+        if (st_out) (void)hipStreamDestroy(st_out);
+    }
+};
+
 struct tkz_encoder {
     int device = 0;
     int pattern = 0;
     int max_key_len = 0;
     bool pretok_seq = false;
     bool profiling = false;
-    std::mutex mu;
-    // device tables
-    DevBuf t_short, t_mid, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp;
+    std::mutex mu;                         // the workspace pool, the decoder table
+    std::vector<Workspace*> pool;
+    // device tables (read-only once built)
+    DevBuf t_short, t_mid, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp, t_counts3;
     TkzTables T{};
-    // workspace
-    DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool, w_counts3;
-    // staging for the host-buffer entry points
-    DevBuf s_bytes, s_offs, s_out, s_outoffs;
-    // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
-    DevBuf u_units, u_offs, u_docbits, u_grp, u_tsum, u_tbase, u_bsum, u_counters, u_bytes, u_boffs;
     // Decode: id -> bytes (vocabulary keys + registered special tokens), rebuilt when the special tokens change
     DevBuf t_decoff, t_decblob, t_decids;
     TkzDecodeTable D{};
     std::vector<std::pair<int32_t, std::string>> dec_vocab, dec_special;   // host copies (id, bytes)
-    DevBuf d_grp, d_tsum, d_tbase, d_bsum, d_counters, d_ids, d_idoffs, d_out, d_outoffs;
-    // piece-granular entry point: piece byte offsets, token offsets, first piece of every document
-    DevBuf p_boffs, p_toffs, p_docp;
-    CounterBlock* h_counters = nullptr;   // pinned
-    int64_t bytes_allocated = 0;
-    // profiling
-    hipEvent_t ev[tkz::K_COUNT][2] = {};
-    bool ev_used[tkz::K_COUNT] = {};
-    double ms[tkz::K_COUNT] = {};
-    int64_t launches[tkz::K_COUNT] = {};
+    int64_t bytes_allocated = 0;           // tables
 };
 
 namespace {
 
+// a workspace of the encoder's pool for the duration of one call
+struct Lease {
+    tkz_encoder* e; Workspace* ws = nullptr;
+    explicit Lease(tkz_encoder* enc) : e(enc) {
+        std::lock_guard<std::mutex> lock(e->mu);
+        for (Workspace* w : e->pool) if (!w->busy) { ws = w; break; }
+        if (!ws) { ws = new Workspace(); e->pool.push_back(ws); }
+        ws->busy = true;
+    }
+    ~Lease() { std::lock_guard<std::mutex> lock(e->mu); ws->busy = false; }
+    Lease(const Lease&) = delete;
+    Lease& operator=(const Lease&) = delete;
+};
+
 void prof_hook(void* ctx, int id, int phase, hipStream_t s) {
-    tkz_encoder* e = static_cast<tkz_encoder*>(ctx);
+    Workspace* e = static_cast<Workspace*>(ctx);
     if (!e->ev[id][phase]) (void)hipEventCreate(&e->ev[id][phase]);
     (void)hipEventRecord(e->ev[id][phase], s);
     if (phase == 1) e->ev_used[id] = true;
 }
-void prof_collect(tkz_encoder* e) {
+void prof_collect(Workspace* e) {
     for (int k = 0; k < tkz::K_COUNT; ++k) {
         if (!e->ev_used[k]) continue;
         float t = 0;
@@ -190,7 +231,7 @@ tkz_status build_decode_table(tkz_encoder* e) {
 struct PiecesOut { int64_t* piece_boffs; int64_t* piece_toffs; int64_t* doc_piece; int64_t piece_cap; int64_t n_pieces; };
 
 // the batch on the device; when pretok == false every "document" is taken as one piece
-tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
+tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                          int32_t* d_out, int64_t out_cap, int64_t* d_out_offs, hipStream_t stream, bool pretok,
                          uint64_t* d_bitmap_only, int64_t* total_tokens, PiecesOut* po = nullptr) {
     using namespace tkz;
@@ -198,9 +239,9 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
     if (total_tokens) *total_tokens = 0;
     if (n_docs == 0 && total != 0) return fail(TKZ_E_ARG, "bytes without documents");
     const int64_t nwords = total / 64 + 1;
-    HIP_TRY(e->w_counts3.ensure(32, &e->bytes_allocated));
+    HIP_TRY(e->t_counts3.ensure(32, &e->bytes_allocated));
     if (total == 0) {
-        { tkz::Launch L0{stream, nullptr, e}; tkz::launch_counts3(L0, n_docs, 0, nullptr, e->w_counts3.as<int64_t>()); }
+        { tkz::Launch L0{stream, nullptr, ws}; tkz::launch_counts3(L0, n_docs, 0, nullptr, e->t_counts3.as<int64_t>()); }
         if (d_out_offs) HIP_TRY(hipMemsetAsync(d_out_offs, 0, (size_t)(n_docs + 1) * sizeof(int64_t), stream));
         if (d_bitmap_only) { const uint64_t one = 1; HIP_TRY(hipMemcpyAsync(d_bitmap_only, &one, 8, hipMemcpyHostToDevice, stream)); }
         HIP_TRY(hipStreamSynchronize(stream));
@@ -208,38 +249,38 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
     }
     const int64_t ntiles = (total + kSub - 1) / kSub;       // sub-tiles: one wavefront each
     const int64_t nblk = (ntiles + kScanBlock - 1) / kScanBlock;
-    int64_t* acc = &e->bytes_allocated;
-    HIP_TRY(e->w_docbits.ensure((size_t)(nwords + 8) * 8, acc));
-    HIP_TRY(e->w_startbits.ensure((size_t)(nwords + 8) * 8, acc));
-    HIP_TRY(e->w_counters.ensure(sizeof(CounterBlock), acc));
+    int64_t* acc = &ws->bytes_allocated;
+    HIP_TRY(ws->w_docbits.ensure((size_t)(nwords + 8) * 8, acc));
+    HIP_TRY(ws->w_startbits.ensure((size_t)(nwords + 8) * 8, acc));
+    HIP_TRY(ws->w_counters.ensure(sizeof(CounterBlock), acc));
     if (!d_bitmap_only) {
-        HIP_TRY(e->w_tmp.ensure((size_t)(total + 64) * 4, acc));
-        HIP_TRY(e->w_tcount.ensure((size_t)ntiles * 4, acc));
-        HIP_TRY(e->w_pcount.ensure((size_t)ntiles * 4, acc));
-        HIP_TRY(e->w_pbase.ensure((size_t)ntiles * 8, acc));
+        HIP_TRY(ws->w_tmp.ensure((size_t)(total + 64) * 4, acc));
+        HIP_TRY(ws->w_tcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(ws->w_pcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(ws->w_pbase.ensure((size_t)ntiles * 8, acc));
         // one 4-byte record per piece.  The number of pieces is known only after the pre-tokenizer has run (English/code text: a
         // piece per ~4.5 bytes; the bound is a piece per byte): the buffer starts at a piece per 3 bytes, k_probe refuses to write
         // past it, and the batch is redone once with the exact size if that was not enough
-        HIP_TRY(e->w_prank.ensure((size_t)(total / 3 + 4096) * 4, acc));
-        HIP_TRY(e->w_tbase.ensure((size_t)ntiles * 8, acc));
-        HIP_TRY(e->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
-        HIP_TRY(e->w_doctok.ensure((size_t)((po ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
-        HIP_TRY(e->w_dcount.ensure((size_t)ntiles * 4, acc));
-        HIP_TRY(e->w_dbase.ensure((size_t)ntiles * 8, acc));
-        HIP_TRY(e->w_heavyq.ensure((size_t)ntiles + 64, acc));
-        HIP_TRY(e->w_gq.ensure((size_t)(total / kArenaPiece + 2) * 16, acc));
-        HIP_TRY(e->w_gcnt.ensure((size_t)ntiles * 4, acc));
-        if (!e->w_pool.p) HIP_TRY(e->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
+        HIP_TRY(ws->w_prank.ensure((size_t)(total / 3 + 4096) * 4, acc));
+        HIP_TRY(ws->w_tbase.ensure((size_t)ntiles * 8, acc));
+        HIP_TRY(ws->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
+        HIP_TRY(ws->w_doctok.ensure((size_t)((po ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
+        HIP_TRY(ws->w_dcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(ws->w_dbase.ensure((size_t)ntiles * 8, acc));
+        HIP_TRY(ws->w_heavyq.ensure((size_t)ntiles + 64, acc));
+        HIP_TRY(ws->w_gq.ensure((size_t)(total / kArenaPiece + 2) * 16, acc));
+        HIP_TRY(ws->w_gcnt.ensure((size_t)ntiles * 4, acc));
+        if (!ws->w_pool.p) HIP_TRY(ws->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
     }
-    if (!e->h_counters) HIP_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(CounterBlock), 0));
+    if (!ws->h_counters) HIP_TRY(hipHostMalloc((void**)&ws->h_counters, sizeof(CounterBlock), 0));
 
     for (int attempt = 0; attempt < 3; ++attempt) {
-        Launch L{stream, e->profiling ? prof_hook : nullptr, e};
-        int32_t* counters = e->w_counters.as<int32_t>();
-        int64_t* grand = reinterpret_cast<int64_t*>(e->w_counters.as<char>() + offsetof(CounterBlock, grand));
-        unsigned long long* pool_head = reinterpret_cast<unsigned long long*>(e->w_counters.as<char>() + offsetof(CounterBlock, pool_head));
-        uint64_t* docbits = e->w_docbits.as<uint64_t>();
-        uint64_t* startbits = e->w_startbits.as<uint64_t>();
+        Launch L{stream, e->profiling ? prof_hook : nullptr, ws};
+        int32_t* counters = ws->w_counters.as<int32_t>();
+        int64_t* grand = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, grand));
+        unsigned long long* pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head));
+        uint64_t* docbits = ws->w_docbits.as<uint64_t>();
+        uint64_t* startbits = ws->w_startbits.as<uint64_t>();
         HIP_TRY(hipMemsetAsync(counters, 0, sizeof(CounterBlock), stream));
         HIP_TRY(hipMemsetAsync(docbits, 0, (size_t)nwords * 8, stream));
         launch_docmark(L, d_offs, n_docs, total, docbits, counters);
@@ -249,9 +290,9 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
             launch_pretok_seq(L, e->pattern, d_bytes, d_offs, n_docs, total, startbits, e->T.bmp_class, counters);
         } else {
-            HIP_TRY(e->w_xq.ensure((size_t)(nwords / kRowsPerWave + 2) * 8, acc));
+            HIP_TRY(ws->w_xq.ensure((size_t)(nwords / kRowsPerWave + 2) * 8, acc));
             launch_pretok_rows(L, e->pattern, d_bytes, d_offs, n_docs, total, docbits, startbits, nwords, e->T.bmp_class, counters,
-                               e->w_xq.as<int64_t>(), reinterpret_cast<unsigned long long*>(e->w_counters.as<char>() + offsetof(CounterBlock, xcount)));
+                               ws->w_xq.as<int64_t>(), reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, xcount)));
         }
         if (d_bitmap_only) {
             HIP_TRY(hipMemcpyAsync(d_bitmap_only, startbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
@@ -259,14 +300,14 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             EncodeParams P{};
             P.bytes = d_bytes; P.total = total; P.startbits = startbits; P.docbits = docbits; P.nwords = nwords;
             P.offs = d_offs; P.n_docs = n_docs;
-            P.tmp = e->w_tmp.as<int32_t>(); P.tile_count = e->w_tcount.as<int32_t>();
-            P.prank = e->w_prank.as<int32_t>(); P.prank_cap = (int64_t)(e->w_prank.cap / 4); P.pcount = e->w_pcount.as<int32_t>(); P.pbase = e->w_pbase.as<int64_t>();
-            P.docord_base = e->w_dbase.as<int64_t>(); P.doc_tok = e->w_doctok.as<int32_t>(); P.counters = counters;
-            P.giant_q = e->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = e->w_gcnt.as<int32_t>();
-            P.giant_count = reinterpret_cast<unsigned long long*>(e->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
-            P.heavy_flag = e->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
+            P.tmp = ws->w_tmp.as<int32_t>(); P.tile_count = ws->w_tcount.as<int32_t>();
+            P.prank = ws->w_prank.as<int32_t>(); P.prank_cap = (int64_t)(ws->w_prank.cap / 4); P.pcount = ws->w_pcount.as<int32_t>(); P.pbase = ws->w_pbase.as<int64_t>();
+            P.docord_base = ws->w_dbase.as<int64_t>(); P.doc_tok = ws->w_doctok.as<int32_t>(); P.counters = counters;
+            P.giant_q = ws->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = ws->w_gcnt.as<int32_t>();
+            P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
+            P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
             HIP_TRY(hipMemsetAsync(P.heavy_flag, 0, (size_t)ntiles, stream));
-            P.pool = e->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(e->w_pool.cap / 4);
+            P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
             P.ablate = 0; P.devprof = nullptr;
 #ifdef TKZ_DEVPROF
             { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
@@ -276,37 +317,37 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
             }
             P.devprof = g_devprof;
 #endif
-            int64_t* ndocstarts = reinterpret_cast<int64_t*>(e->w_counters.as<char>() + offsetof(CounterBlock, ndocstarts));
+            int64_t* ndocstarts = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, ndocstarts));
             // piece granularity: the piece-start bitmap takes the place of the document bitmap from here on, so that the encode
             // kernels record the token position of every PIECE start and k_docoffs yields the token range of every piece
             const uint64_t* markbits = po ? startbits : docbits;
             P.docbits = markbits;
-            launch_doccount(L, markbits, nwords, total, ntiles, e->w_dcount.as<int32_t>());
-            launch_scan(L, e->w_dcount.as<int32_t>(), ntiles, e->w_bsum.as<int64_t>(), e->w_dbase.as<int64_t>(), ndocstarts, -1);
+            launch_doccount(L, markbits, nwords, total, ntiles, ws->w_dcount.as<int32_t>());
+            launch_scan(L, ws->w_dcount.as<int32_t>(), ntiles, ws->w_bsum.as<int64_t>(), ws->w_dbase.as<int64_t>(), ndocstarts, -1);
             if (po) {
                 int64_t np = 0;
-                HIP_TRY(hipMemcpyAsync(&e->h_counters->ndocstarts, ndocstarts, 8, hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipMemcpyAsync(&ws->h_counters->ndocstarts, ndocstarts, 8, hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
-                np = e->h_counters->ndocstarts;                  // piece starts below `total` (a document start is one)
+                np = ws->h_counters->ndocstarts;                  // piece starts below `total` (a document start is one)
                 po->n_pieces = np;
                 if (np > po->piece_cap) return fail(TKZ_E_CAPACITY, "piece arrays too small");
-                launch_piece_index(L, startbits, nwords, total, ntiles, e->w_dbase.as<int64_t>(), np, po->piece_boffs, d_offs, n_docs, po->doc_piece);
+                launch_piece_index(L, startbits, nwords, total, ntiles, ws->w_dbase.as<int64_t>(), np, po->piece_boffs, d_offs, n_docs, po->doc_piece);
             }
             // pieces that start in each sub-tile and their scan: where a sub-tile's records live in `prank`
-            int64_t* npieces = reinterpret_cast<int64_t*>(e->w_counters.as<char>() + offsetof(CounterBlock, npieces));
-            launch_doccount(L, startbits, nwords, total, ntiles, e->w_pcount.as<int32_t>());
-            launch_scan(L, e->w_pcount.as<int32_t>(), ntiles, e->w_bsum.as<int64_t>(), e->w_pbase.as<int64_t>(), npieces, -1);
+            int64_t* npieces = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, npieces));
+            launch_doccount(L, startbits, nwords, total, ntiles, ws->w_pcount.as<int32_t>());
+            launch_scan(L, ws->w_pcount.as<int32_t>(), ntiles, ws->w_bsum.as<int64_t>(), ws->w_pbase.as<int64_t>(), npieces, -1);
             launch_encode(L, e->T, P, ntiles);
-            launch_scan(L, P.tile_count, ntiles, e->w_bsum.as<int64_t>(), e->w_tbase.as<int64_t>(), grand, K_SCAN);
-            launch_place(L, P, e->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
-            if (po) launch_docoffs(L, po->piece_boffs, po->n_pieces, total, e->w_tbase.as<int64_t>(), markbits, P.docord_base, P.doc_tok, grand, po->piece_toffs);
-            else launch_docoffs(L, d_offs, n_docs, total, e->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs);
-            launch_counts3(L, n_docs, total, grand, e->w_counts3.as<int64_t>());
+            launch_scan(L, P.tile_count, ntiles, ws->w_bsum.as<int64_t>(), ws->w_tbase.as<int64_t>(), grand, K_SCAN);
+            launch_place(L, P, ws->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
+            if (po) launch_docoffs(L, po->piece_boffs, po->n_pieces, total, ws->w_tbase.as<int64_t>(), markbits, P.docord_base, P.doc_tok, grand, po->piece_toffs);
+            else launch_docoffs(L, d_offs, n_docs, total, ws->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs);
+            launch_counts3(L, n_docs, total, grand, e->t_counts3.as<int64_t>());
         }
-        HIP_TRY(hipMemcpyAsync(e->h_counters, counters, sizeof(CounterBlock), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(ws->h_counters, counters, sizeof(CounterBlock), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
-        if (e->profiling) prof_collect(e);
+        if (e->profiling) prof_collect(ws);
 #ifdef TKZ_DEVPROF
         if (g_devprof && getenv("TKZ_DEV_ABLATE") && (atoi(getenv("TKZ_DEV_ABLATE")) & 16) && !d_bitmap_only) {
             unsigned long long h[16];
@@ -316,30 +357,30 @@ tkz_status encode_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* 
                     h[0], h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w);
         }
 #endif
-        const int32_t err = e->h_counters->err;
+        const int32_t err = ws->h_counters->err;
         if (err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the byte count");
         if (err & kErrUtf8) return fail(TKZ_E_INVALID_UTF8, "input is not well-formed UTF-8 (or a document boundary falls inside a character)");
         if (err & kErrTooLong) return fail(TKZ_E_UNSUPPORTED, "a single piece longer than 2^30 bytes");
         if ((err & kErrPool) && attempt < 2) {
             // scratch for the giant pieces was too small.  pool_head keeps counting past the capacity, so it holds the exact need
             // (6 int32 per byte of every giant piece of the batch): size the pool for that -- not for the whole batch -- and rerun
-            const size_t need = (size_t)e->h_counters->pool_head * 4 + 4096;
-            if (e->w_pool.ensure(need, acc) != hipSuccess)
+            const size_t need = (size_t)ws->h_counters->pool_head * 4 + 4096;
+            if (ws->w_pool.ensure(need, acc) != hipSuccess)
                 return fail(TKZ_E_OUT_OF_MEMORY, "scratch for the pieces longer than 1024 bytes: " + std::to_string(need) + " bytes could not be allocated");
             continue;
         }
         if (err & kErrPool) return fail(TKZ_E_OUT_OF_MEMORY, "long-piece scratch exhausted");
         if ((err & kErrCapacity) && attempt < 2) {          // more pieces than the record buffer was sized for: the exact count is known now
-            const size_t need = ((size_t)e->h_counters->npieces + 4096) * 4;
-            if (e->w_prank.ensure(need, acc) != hipSuccess)
+            const size_t need = ((size_t)ws->h_counters->npieces + 4096) * 4;
+            if (ws->w_prank.ensure(need, acc) != hipSuccess)
                 return fail(TKZ_E_OUT_OF_MEMORY, "piece records: " + std::to_string(need) + " bytes could not be allocated");
             continue;
         }
         if (err & kErrCapacity) return fail(TKZ_E_DEVICE, "piece record buffer overflow");
         if (err & kErrKeyNotFound) return fail(TKZ_E_KEY_NOT_FOUND, "a byte of the input is not in the vocabulary (KeyNotFoundException in the reference)");
         if (!d_bitmap_only) {
-            if (total_tokens) *total_tokens = e->h_counters->grand;
-            if (e->h_counters->grand > out_cap) return fail(TKZ_E_CAPACITY, "output capacity too small");
+            if (total_tokens) *total_tokens = ws->h_counters->grand;
+            if (ws->h_counters->grand > out_cap) return fail(TKZ_E_CAPACITY, "output capacity too small");
         }
         return TKZ_OK;
     }
@@ -353,7 +394,22 @@ tkz_status check_encoder(tkz_encoder* e, DeviceScope& scope) {
     return TKZ_OK;
 }
 
-// host buffers -> staging -> device path -> back
+hipError_t ensure_streams(Workspace* ws) {
+    hipError_t r = hipSuccess;
+    if (!ws->st_compute) r = hipStreamCreate(&ws->st_compute);
+    if (r == hipSuccess && !ws->st_in) r = hipStreamCreate(&ws->st_in);
+    if (r == hipSuccess && !ws->st_out) r = hipStreamCreate(&ws->st_out);
+    for (int q = 0; q < 2 && r == hipSuccess; ++q) {
+        if (!ws->ev_in[q]) r = hipEventCreate(&ws->ev_in[q]);
+        if (r == hipSuccess && !ws->ev_out[q]) r = hipEventCreate(&ws->ev_out[q]);
+    }
+    return r;
+}
+
+// host buffers -> staging -> device path -> back.  A large batch is cut into document ranges (chunks): the upload of chunk k+1
+// (stream st_in), the kernels of chunk k (st_compute) and the download of chunk k-1 (st_out) run at the same time -- PCIe is full
+// duplex and the kernels need a fifth of a transfer's time -- on two sets of staging buffers.  (The copies are asynchronous for
+// page-locked caller buffers; for pageable ones the HIP runtime stages them itself and overlaps what it can.)
 tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const int64_t* offs, int64_t n_docs, int32_t* out_ids,
                        int64_t out_cap, int64_t* out_offsets, int64_t* needed, bool pretok, uint64_t* bitmap) {
     DeviceScope scope;
@@ -363,30 +419,106 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const int64_t* offs
     if (offs[0] != 0) return fail(TKZ_E_ARG, "doc_offsets[0] must be 0");
     const int64_t total = offs[n_docs];
     if (total < 0) return fail(TKZ_E_ARG, "negative byte count");
-    std::lock_guard<std::mutex> lock(e->mu);
-    int64_t* acc = &e->bytes_allocated;
-    HIP_TRY(e->s_bytes.ensure((size_t)total + 64, acc));
-    HIP_TRY(e->s_offs.ensure((size_t)(n_docs + 1) * 8, acc));
-    const int64_t cap = bitmap ? 0 : std::min<int64_t>(out_cap, total);   // tokens <= bytes: more capacity is never used
-    if (!bitmap) {
-        HIP_TRY(e->s_out.ensure((size_t)std::max<int64_t>(cap, 1) * 4, acc));
-        HIP_TRY(e->s_outoffs.ensure((size_t)(n_docs + 1) * 8, acc));
-    } else {
-        HIP_TRY(e->s_out.ensure((size_t)(total / 64 + 1) * 8, acc));
+    Lease lease(e);
+    Workspace* ws = lease.ws;
+    int64_t* acc = &ws->bytes_allocated;
+    // ($TKZ_HOST_CHUNK_BYTES: test knob, so that the CPU-emulated tests can exercise the pipeline on kilobytes)
+    static const int64_t kChunkBytes = [] { const char* v = getenv("TKZ_HOST_CHUNK_BYTES"); const long long n = v ? atoll(v) : 0; return n > 0 ? (int64_t)n : (int64_t(48) << 20); }();
+    int64_t nchunks = (bitmap || !pretok || total < 2 * kChunkBytes) ? 1 : std::min<int64_t>(64, (total + kChunkBytes - 1) / kChunkBytes);
+    // chunk boundaries on documents: chunk k = documents [cut[k], cut[k+1]).  Offsets that are not monotone cannot be cut: the
+    // whole batch then goes as one chunk and the device reports them (k_docmark)
+    std::vector<int64_t> cut((size_t)nchunks + 1, 0);
+    cut[(size_t)nchunks] = n_docs;
+    for (int64_t k = 1; k < nchunks; ++k) {
+        const int64_t want = total / nchunks * k;
+        cut[(size_t)k] = std::lower_bound(offs, offs + n_docs, want) - offs;
+        if (cut[(size_t)k] < cut[(size_t)k - 1] || offs[cut[(size_t)k]] < offs[cut[(size_t)k - 1]]) { nchunks = 1; break; }
     }
-    if (total) HIP_TRY(hipMemcpy(e->s_bytes.p, bytes, (size_t)total, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->s_offs.p, offs, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
-    int64_t tokens = 0;
-    st = encode_device(e, e->s_bytes.as<uint8_t>(), e->s_offs.as<int64_t>(), n_docs, total, e->s_out.as<int32_t>(), cap,
-                       e->s_outoffs.as<int64_t>(), nullptr, pretok, bitmap ? e->s_out.as<uint64_t>() : nullptr, &tokens);
-    if (needed) *needed = tokens;
-    if (st != TKZ_OK) return st;
-    if (bitmap) {
-        HIP_TRY(hipMemcpy(bitmap, e->s_out.p, (size_t)(total / 64 + 1) * 8, hipMemcpyDeviceToHost));
+    if (nchunks == 1) { cut.assign(2, 0); cut[1] = n_docs; }
+    if (nchunks == 1) {
+        HIP_TRY(ws->s_bytes[0].ensure((size_t)total + 64, acc));
+        HIP_TRY(ws->s_offs[0].ensure((size_t)(n_docs + 1) * 8, acc));
+        const int64_t cap = bitmap ? 0 : std::min<int64_t>(out_cap, total);   // tokens <= bytes: more capacity is never used
+        if (!bitmap) {
+            HIP_TRY(ws->s_out[0].ensure((size_t)std::max<int64_t>(cap, 1) * 4, acc));
+            HIP_TRY(ws->s_outoffs[0].ensure((size_t)(n_docs + 1) * 8, acc));
+        } else {
+            HIP_TRY(ws->s_out[0].ensure((size_t)(total / 64 + 1) * 8, acc));
+        }
+        if (total) HIP_TRY(hipMemcpy(ws->s_bytes[0].p, bytes, (size_t)total, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ws->s_offs[0].p, offs, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+        int64_t tokens = 0;
+        st = encode_device(e, ws, ws->s_bytes[0].as<uint8_t>(), ws->s_offs[0].as<int64_t>(), n_docs, total, ws->s_out[0].as<int32_t>(), cap,
+                           ws->s_outoffs[0].as<int64_t>(), nullptr, pretok, bitmap ? ws->s_out[0].as<uint64_t>() : nullptr, &tokens);
+        if (needed) *needed = tokens;
+        if (st != TKZ_OK) return st;
+        if (bitmap) {
+            HIP_TRY(hipMemcpy(bitmap, ws->s_out[0].p, (size_t)(total / 64 + 1) * 8, hipMemcpyDeviceToHost));
+            return TKZ_OK;
+        }
+        if (tokens) HIP_TRY(hipMemcpy(out_ids, ws->s_out[0].p, (size_t)tokens * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out_offsets, ws->s_outoffs[0].p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
         return TKZ_OK;
     }
-    if (tokens) HIP_TRY(hipMemcpy(out_ids, e->s_out.p, (size_t)tokens * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_offsets, e->s_outoffs.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    // ---- pipelined chunks ----
+    HIP_TRY(ensure_streams(ws));
+    int64_t max_bytes = 0, max_docs = 0;
+    for (int64_t k = 0; k < nchunks; ++k) {
+        max_bytes = std::max(max_bytes, offs[cut[(size_t)k + 1]] - offs[cut[(size_t)k]]);
+        max_docs = std::max(max_docs, cut[(size_t)k + 1] - cut[(size_t)k]);
+    }
+    for (int q = 0; q < 2; ++q) {
+        HIP_TRY(ws->s_bytes[q].ensure((size_t)max_bytes + 64, acc));
+        HIP_TRY(ws->s_offs[q].ensure((size_t)(max_docs + 1) * 8, acc));
+        HIP_TRY(ws->s_out[q].ensure((size_t)std::max<int64_t>(max_bytes, 1) * 4, acc));
+        HIP_TRY(ws->s_outoffs[q].ensure((size_t)(max_docs + 1) * 8, acc));
+    }
+    auto upload_chunk = [&](int64_t k) -> hipError_t {
+        const int q = (int)(k & 1);
+        const int64_t d0 = cut[(size_t)k], d1 = cut[(size_t)k + 1], b0 = offs[d0], nb = offs[d1] - b0;
+        hipError_t r = hipSuccess;
+        if (nb) r = hipMemcpyAsync(ws->s_bytes[q].p, bytes + b0, (size_t)nb, hipMemcpyHostToDevice, ws->st_in);
+        if (r == hipSuccess) r = hipMemcpyAsync(ws->s_offs[q].p, offs + d0, (size_t)(d1 - d0 + 1) * 8, hipMemcpyHostToDevice, ws->st_in);
+        if (r == hipSuccess) r = hipEventRecord(ws->ev_in[q], ws->st_in);
+        return r;
+    };
+    std::vector<int64_t> tok_base((size_t)nchunks + 1, 0);
+    bool over = false;                                       // out_cap exceeded: the remaining chunks are only counted
+    tkz_status first_err = TKZ_OK;
+    std::string first_msg;
+    HIP_TRY(upload_chunk(0));
+    for (int64_t k = 0; k < nchunks; ++k) {
+        const int q = (int)(k & 1);
+        const int64_t d0 = cut[(size_t)k], d1 = cut[(size_t)k + 1], b0 = offs[d0], nb = offs[d1] - b0, nd = d1 - d0;
+        if (k + 1 < nchunks) HIP_TRY(upload_chunk(k + 1));                      // (its staging set was last read by the kernels of chunk k-1: done)
+        HIP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_in[q], 0));
+        if (k >= 2) HIP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_out[q], 0));   // the download of chunk k-2 has left this set's output buffers
+        { tkz::Launch L{ws->st_compute, nullptr, ws}; tkz::launch_rebase(L, ws->s_offs[q].as<int64_t>(), nd + 1, b0); }
+        const int64_t cap = over ? 0 : std::min<int64_t>(out_cap - tok_base[(size_t)k], nb);
+        int64_t tokens = 0;
+        st = encode_device(e, ws, ws->s_bytes[q].as<uint8_t>(), ws->s_offs[q].as<int64_t>(), nd, nb, ws->s_out[q].as<int32_t>(), cap,
+                           ws->s_outoffs[q].as<int64_t>(), ws->st_compute, true, nullptr, &tokens);      // (returns when st_compute has drained)
+        tok_base[(size_t)k + 1] = tok_base[(size_t)k] + tokens;
+        if (st == TKZ_E_CAPACITY) { over = true; continue; }
+        if (st != TKZ_OK) { first_err = st; first_msg = g_err; break; }
+        if (!over) {
+            if (tokens) HIP_TRY(hipMemcpyAsync(out_ids + tok_base[(size_t)k], ws->s_out[q].p, (size_t)tokens * 4, hipMemcpyDeviceToHost, ws->st_out));
+            HIP_TRY(hipMemcpyAsync(out_offsets + d0, ws->s_outoffs[q].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, ws->st_out));
+            HIP_TRY(hipEventRecord(ws->ev_out[q], ws->st_out));
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(ws->st_in));
+    HIP_TRY(hipStreamSynchronize(ws->st_out));
+    if (first_err != TKZ_OK) return fail(first_err, first_msg);
+    if (needed) *needed = tok_base[(size_t)nchunks];
+    if (over) return fail(TKZ_E_CAPACITY, "output capacity too small");
+    // the offsets came back relative to their chunk: add the chunk's token base (chunk 0 needs nothing; the shared boundary entry
+    // of two chunks was written by the later one as 0 and gets that chunk's base, which is what the earlier chunk's last entry was)
+    for (int64_t k = 1; k < nchunks; ++k) {
+        const int64_t tb = tok_base[(size_t)k];
+        for (int64_t d = cut[(size_t)k]; d < cut[(size_t)k + 1]; ++d) out_offsets[d] += tb;
+    }
+    out_offsets[n_docs] = tok_base[(size_t)nchunks];
     return TKZ_OK;
 }
 
@@ -484,19 +616,13 @@ void tkz_encoder_destroy(tkz_encoder* e) {
     if (!e) return;
     DeviceScope scope;
     (void)scope.enter(e->device);
-    DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp,
-                      &e->w_gq, &e->w_gcnt, &e->w_xq, &e->w_heavyq, &e->w_docbits, &e->w_startbits, &e->w_tmp, &e->w_tcount, &e->w_prank, &e->w_pcount, &e->w_pbase, &e->w_tbase, &e->w_bsum,
-                      &e->w_doctok, &e->w_dcount, &e->w_dbase, &e->w_counters, &e->w_pool, &e->w_counts3, &e->s_bytes, &e->s_offs, &e->s_out, &e->s_outoffs,
-                      &e->t_decoff, &e->t_decblob, &e->t_decids, &e->d_grp, &e->d_tsum, &e->d_tbase, &e->d_bsum, &e->d_counters, &e->d_ids, &e->d_idoffs, &e->d_out, &e->d_outoffs,
-                      &e->p_boffs, &e->p_toffs, &e->p_docp,
-                      &e->u_units, &e->u_offs, &e->u_docbits, &e->u_grp, &e->u_tsum, &e->u_tbase, &e->u_bsum, &e->u_counters, &e->u_bytes, &e->u_boffs};
+    DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp, &e->t_counts3, &e->t_decoff, &e->t_decblob, &e->t_decids};
     for (DevBuf* b : bufs) b->release();
-    if (e->h_counters) (void)hipHostFree(e->h_counters);
-    for (int k = 0; k < tkz::K_COUNT; ++k) for (int p = 0; p < 2; ++p) if (e->ev[k][p]) (void)hipEventDestroy(e->ev[k][p]);
+    for (Workspace* w : e->pool) { w->release_all(); delete w; }
     delete e;
 }
 int32_t tkz_encoder_device(const tkz_encoder* e) { return e ? e->device : -1; }
-const int64_t* tkz_encoder_counts_device(const tkz_encoder* e) { return e ? e->w_counts3.as<int64_t>() : nullptr; }
+const int64_t* tkz_encoder_counts_device(const tkz_encoder* e) { return e ? e->t_counts3.as<int64_t>() : nullptr; }
 
 tkz_status tkz_encode_batch_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs,
                                  int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed) {
@@ -512,8 +638,9 @@ tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const
     if (st != TKZ_OK) return st;
     if (!d_doc_offsets || !d_out_offsets || (total_bytes > 0 && (!d_bytes || !d_out_ids))) return fail(TKZ_E_ARG, "null device buffer");
     if (reinterpret_cast<uintptr_t>(d_bytes) & 15) return fail(TKZ_E_ARG, "d_bytes must be 16-byte aligned");
-    std::lock_guard<std::mutex> lock(e->mu);
-    return encode_device(e, d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets,
+    Lease lease(e);
+    Workspace* ws = lease.ws;
+    return encode_device(e, ws, d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets,
                          static_cast<hipStream_t>(hip_stream), true, nullptr, total_tokens);
 }
 
@@ -561,49 +688,50 @@ tkz_status tkz_encode_batch_utf16(tkz_encoder* e, const uint16_t* units, const i
         for (int64_t d = 0; d <= n_docs; ++d) { if (unit_offsets[d] != 0) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count"); out_offsets[d] = 0; }
         return TKZ_OK;
     }
-    std::lock_guard<std::mutex> lock(e->mu);
-    int64_t* acc = &e->bytes_allocated;
+    Lease lease(e);
+    Workspace* ws = lease.ws;
+    int64_t* acc = &ws->bytes_allocated;
     hipStream_t stream = nullptr;
     const int64_t nwords = total_units / 64 + 1, ntiles = u16_tiles(total_units), nblk = (ntiles + kScanBlock - 1) / kScanBlock;
-    HIP_TRY(e->u_units.ensure((size_t)(total_units + 64) * 2, acc));
-    HIP_TRY(e->u_offs.ensure((size_t)(n_docs + 1) * 8, acc));
-    HIP_TRY(e->u_docbits.ensure((size_t)(nwords + 8) * 8, acc));
-    HIP_TRY(e->u_grp.ensure((size_t)ntiles * 64 * 4, acc));
-    HIP_TRY(e->u_tsum.ensure((size_t)ntiles * 4, acc));
-    HIP_TRY(e->u_tbase.ensure((size_t)ntiles * 8, acc));
-    HIP_TRY(e->u_bsum.ensure((size_t)(nblk + 1) * 8, acc));
-    HIP_TRY(e->u_counters.ensure(64, acc));
-    HIP_TRY(e->u_boffs.ensure((size_t)(n_docs + 1) * 8, acc));
-    HIP_TRY(hipMemcpy(e->u_units.p, units, (size_t)total_units * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->u_offs.p, unit_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+    HIP_TRY(ws->u_units.ensure((size_t)(total_units + 64) * 2, acc));
+    HIP_TRY(ws->u_offs.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(ws->u_docbits.ensure((size_t)(nwords + 8) * 8, acc));
+    HIP_TRY(ws->u_grp.ensure((size_t)ntiles * 64 * 4, acc));
+    HIP_TRY(ws->u_tsum.ensure((size_t)ntiles * 4, acc));
+    HIP_TRY(ws->u_tbase.ensure((size_t)ntiles * 8, acc));
+    HIP_TRY(ws->u_bsum.ensure((size_t)(nblk + 1) * 8, acc));
+    HIP_TRY(ws->u_counters.ensure(64, acc));
+    HIP_TRY(ws->u_boffs.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(hipMemcpy(ws->u_units.p, units, (size_t)total_units * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ws->u_offs.p, unit_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
     // 1. document marks over the code units, UTF-8 length of every unit, scan
-    Launch L{stream, nullptr, e};
-    int32_t* counters = e->u_counters.as<int32_t>();
-    int64_t* grand = reinterpret_cast<int64_t*>(e->u_counters.as<char>() + 8);
+    Launch L{stream, nullptr, ws};
+    int32_t* counters = ws->u_counters.as<int32_t>();
+    int64_t* grand = reinterpret_cast<int64_t*>(ws->u_counters.as<char>() + 8);
     HIP_TRY(hipMemsetAsync(counters, 0, 64, stream));
-    HIP_TRY(hipMemsetAsync(e->u_docbits.p, 0, (size_t)(nwords + 8) * 8, stream));
-    launch_docmark(L, e->u_offs.as<int64_t>(), n_docs, total_units, e->u_docbits.as<uint64_t>(), counters);
-    launch_u16_len(L, e->u_units.as<uint16_t>(), total_units, e->u_docbits.as<uint64_t>(), ntiles, e->u_grp.as<int32_t>(), e->u_tsum.as<int32_t>());
-    launch_scan(L, e->u_tsum.as<int32_t>(), ntiles, e->u_bsum.as<int64_t>(), e->u_tbase.as<int64_t>(), grand, -1);
+    HIP_TRY(hipMemsetAsync(ws->u_docbits.p, 0, (size_t)(nwords + 8) * 8, stream));
+    launch_docmark(L, ws->u_offs.as<int64_t>(), n_docs, total_units, ws->u_docbits.as<uint64_t>(), counters);
+    launch_u16_len(L, ws->u_units.as<uint16_t>(), total_units, ws->u_docbits.as<uint64_t>(), ntiles, ws->u_grp.as<int32_t>(), ws->u_tsum.as<int32_t>());
+    launch_scan(L, ws->u_tsum.as<int32_t>(), ntiles, ws->u_bsum.as<int64_t>(), ws->u_tbase.as<int64_t>(), grand, -1);
     struct { int32_t err; int32_t pad; int64_t grand; } h{};
     HIP_TRY(hipMemcpy(&h, counters, sizeof h, hipMemcpyDeviceToHost));
     HIP_TRY(hipGetLastError());
     if (h.err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count");
     const int64_t total = h.grand;                       // UTF-8 bytes of the batch
     // 2. the UTF-8 batch, in HBM; 3. the same path as every other entry point
-    HIP_TRY(e->u_bytes.ensure((size_t)total + 64, acc));
-    launch_u16_write(L, e->u_units.as<uint16_t>(), total_units, e->u_docbits.as<uint64_t>(), ntiles, e->u_tbase.as<int64_t>(), e->u_bytes.as<uint8_t>(),
-                     e->u_offs.as<int64_t>(), n_docs, e->u_grp.as<int32_t>(), grand, e->u_boffs.as<int64_t>());
+    HIP_TRY(ws->u_bytes.ensure((size_t)total + 64, acc));
+    launch_u16_write(L, ws->u_units.as<uint16_t>(), total_units, ws->u_docbits.as<uint64_t>(), ntiles, ws->u_tbase.as<int64_t>(), ws->u_bytes.as<uint8_t>(),
+                     ws->u_offs.as<int64_t>(), n_docs, ws->u_grp.as<int32_t>(), grand, ws->u_boffs.as<int64_t>());
     const int64_t cap = std::min<int64_t>(out_cap, total);
-    HIP_TRY(e->s_out.ensure((size_t)std::max<int64_t>(cap, 1) * 4, acc));
-    HIP_TRY(e->s_outoffs.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(ws->s_out[0].ensure((size_t)std::max<int64_t>(cap, 1) * 4, acc));
+    HIP_TRY(ws->s_outoffs[0].ensure((size_t)(n_docs + 1) * 8, acc));
     int64_t tokens = 0;
-    st = encode_device(e, e->u_bytes.as<uint8_t>(), e->u_boffs.as<int64_t>(), n_docs, total, e->s_out.as<int32_t>(), cap,
-                       e->s_outoffs.as<int64_t>(), stream, true, nullptr, &tokens);
+    st = encode_device(e, ws, ws->u_bytes.as<uint8_t>(), ws->u_boffs.as<int64_t>(), n_docs, total, ws->s_out[0].as<int32_t>(), cap,
+                       ws->s_outoffs[0].as<int64_t>(), stream, true, nullptr, &tokens);
     if (needed) *needed = tokens;
     if (st != TKZ_OK) return st;
-    if (tokens) HIP_TRY(hipMemcpy(out_ids, e->s_out.p, (size_t)tokens * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_offsets, e->s_outoffs.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    if (tokens) HIP_TRY(hipMemcpy(out_ids, ws->s_out[0].p, (size_t)tokens * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_offsets, ws->s_outoffs[0].p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
     return TKZ_OK;
 }
 
@@ -638,30 +766,31 @@ tkz_status tkz_encode_batch_pieces_utf8(tkz_encoder* e, const uint8_t* bytes, co
         return TKZ_OK;
     }
     // ONE launch sequence on the device: Regex.Matches -> piece offsets from the bitmap -> encode with a token mark per piece
-    std::lock_guard<std::mutex> lock(e->mu);
-    int64_t* acc = &e->bytes_allocated;
+    Lease lease(e);
+    Workspace* ws = lease.ws;
+    int64_t* acc = &ws->bytes_allocated;
     const int64_t pcap = std::min<int64_t>(piece_cap, total);           // pieces <= bytes
     const int64_t cap = std::min<int64_t>(out_cap, total);
-    HIP_TRY(e->s_bytes.ensure((size_t)total + 64, acc));
-    HIP_TRY(e->s_offs.ensure((size_t)(n_docs + 1) * 8, acc));
-    HIP_TRY(e->s_out.ensure((size_t)std::max<int64_t>(cap, 1) * 4, acc));
-    HIP_TRY(e->p_boffs.ensure((size_t)(pcap + 1) * 8, acc));
-    HIP_TRY(e->p_toffs.ensure((size_t)(pcap + 1) * 8, acc));
-    HIP_TRY(e->p_docp.ensure((size_t)(n_docs + 1) * 8, acc));
-    HIP_TRY(hipMemcpy(e->s_bytes.p, bytes, (size_t)total, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->s_offs.p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
-    PiecesOut po{e->p_boffs.as<int64_t>(), e->p_toffs.as<int64_t>(), e->p_docp.as<int64_t>(), pcap, 0};
+    HIP_TRY(ws->s_bytes[0].ensure((size_t)total + 64, acc));
+    HIP_TRY(ws->s_offs[0].ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(ws->s_out[0].ensure((size_t)std::max<int64_t>(cap, 1) * 4, acc));
+    HIP_TRY(ws->p_boffs.ensure((size_t)(pcap + 1) * 8, acc));
+    HIP_TRY(ws->p_toffs.ensure((size_t)(pcap + 1) * 8, acc));
+    HIP_TRY(ws->p_docp.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(hipMemcpy(ws->s_bytes[0].p, bytes, (size_t)total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ws->s_offs[0].p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+    PiecesOut po{ws->p_boffs.as<int64_t>(), ws->p_toffs.as<int64_t>(), ws->p_docp.as<int64_t>(), pcap, 0};
     int64_t tokens = 0;
-    st = encode_device(e, e->s_bytes.as<uint8_t>(), e->s_offs.as<int64_t>(), n_docs, total, e->s_out.as<int32_t>(), cap, nullptr, nullptr, true,
+    st = encode_device(e, ws, ws->s_bytes[0].as<uint8_t>(), ws->s_offs[0].as<int64_t>(), n_docs, total, ws->s_out[0].as<int32_t>(), cap, nullptr, nullptr, true,
                        nullptr, &tokens, &po);
     *n_pieces = po.n_pieces;
     if (needed_ids) *needed_ids = tokens;
     if (st != TKZ_OK) return st;
     const int64_t np = po.n_pieces;
-    if (tokens) HIP_TRY(hipMemcpy(out_ids, e->s_out.p, (size_t)tokens * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(piece_byte_offsets, e->p_boffs.p, (size_t)(np + 1) * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(piece_token_offsets, e->p_toffs.p, (size_t)(np + 1) * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(doc_piece_offsets, e->p_docp.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    if (tokens) HIP_TRY(hipMemcpy(out_ids, ws->s_out[0].p, (size_t)tokens * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(piece_byte_offsets, ws->p_boffs.p, (size_t)(np + 1) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(piece_token_offsets, ws->p_toffs.p, (size_t)(np + 1) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(doc_piece_offsets, ws->p_docp.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
     return TKZ_OK;
 }
 
@@ -684,33 +813,33 @@ tkz_status tkz_encoder_set_special_tokens(tkz_encoder* e, const int32_t* ids, co
 
 namespace {
 // lengths -> scan -> bytes + document offsets, all on `stream`; d_out may be null when only the size is wanted
-tkz_status decode_device(tkz_encoder* e, const int32_t* d_ids, const int64_t* d_id_offs, int64_t n_docs, int64_t total_ids, uint8_t* d_out, int64_t out_cap,
+tkz_status decode_device(tkz_encoder* e, Workspace* ws, const int32_t* d_ids, const int64_t* d_id_offs, int64_t n_docs, int64_t total_ids, uint8_t* d_out, int64_t out_cap,
                          int64_t* d_out_offs, hipStream_t stream, int64_t* total_bytes) {
     using namespace tkz;
     if (total_bytes) *total_bytes = 0;
     if (n_docs < 0 || total_ids < 0 || out_cap < 0) return fail(TKZ_E_ARG, "negative size");
     if (n_docs == 0 && total_ids != 0) return fail(TKZ_E_ARG, "ids without documents");
-    int64_t* acc = &e->bytes_allocated;
+    int64_t* acc = &ws->bytes_allocated;
     const int64_t ntiles = std::max<int64_t>(1, dec_tiles(total_ids)), nblk = (ntiles + kScanBlock - 1) / kScanBlock;
-    HIP_TRY(e->d_grp.ensure((size_t)ntiles * 64 * 4, acc));
-    HIP_TRY(e->d_tsum.ensure((size_t)ntiles * 4, acc));
-    HIP_TRY(e->d_tbase.ensure((size_t)ntiles * 8, acc));
-    HIP_TRY(e->d_bsum.ensure((size_t)(nblk + 1) * 8, acc));
-    HIP_TRY(e->d_counters.ensure(64, acc));
-    if (!e->h_counters) HIP_TRY(hipHostMalloc((void**)&e->h_counters, sizeof(CounterBlock), 0));
-    Launch L{stream, nullptr, e};
-    int32_t* counters = e->d_counters.as<int32_t>();
-    int64_t* grand = reinterpret_cast<int64_t*>(e->d_counters.as<char>() + 8);
+    HIP_TRY(ws->d_grp.ensure((size_t)ntiles * 64 * 4, acc));
+    HIP_TRY(ws->d_tsum.ensure((size_t)ntiles * 4, acc));
+    HIP_TRY(ws->d_tbase.ensure((size_t)ntiles * 8, acc));
+    HIP_TRY(ws->d_bsum.ensure((size_t)(nblk + 1) * 8, acc));
+    HIP_TRY(ws->d_counters.ensure(64, acc));
+    if (!ws->h_counters) HIP_TRY(hipHostMalloc((void**)&ws->h_counters, sizeof(CounterBlock), 0));
+    Launch L{stream, nullptr, ws};
+    int32_t* counters = ws->d_counters.as<int32_t>();
+    int64_t* grand = reinterpret_cast<int64_t*>(ws->d_counters.as<char>() + 8);
     HIP_TRY(hipMemsetAsync(counters, 0, 64, stream));
-    launch_dec_len(L, e->D, d_ids, total_ids, ntiles, e->d_grp.as<int32_t>(), e->d_tsum.as<int32_t>());
-    launch_scan(L, e->d_tsum.as<int32_t>(), ntiles, e->d_bsum.as<int64_t>(), e->d_tbase.as<int64_t>(), grand, -1);
-    launch_dec_write(L, e->D, d_ids, total_ids, ntiles, e->d_tbase.as<int64_t>(), d_out, d_out ? out_cap : 0, d_id_offs, n_docs, e->d_grp.as<int32_t>(), grand,
+    launch_dec_len(L, e->D, d_ids, total_ids, ntiles, ws->d_grp.as<int32_t>(), ws->d_tsum.as<int32_t>());
+    launch_scan(L, ws->d_tsum.as<int32_t>(), ntiles, ws->d_bsum.as<int64_t>(), ws->d_tbase.as<int64_t>(), grand, -1);
+    launch_dec_write(L, e->D, d_ids, total_ids, ntiles, ws->d_tbase.as<int64_t>(), d_out, d_out ? out_cap : 0, d_id_offs, n_docs, ws->d_grp.as<int32_t>(), grand,
                      d_out_offs, counters);
     struct { int32_t err; int32_t pad; int64_t grand; } h{};
-    HIP_TRY(hipMemcpyAsync(e->h_counters, counters, 16, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(ws->h_counters, counters, 16, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipGetLastError());
-    memcpy(&h, e->h_counters, 16);
+    memcpy(&h, ws->h_counters, 16);
     if (h.err & kErrOffsets) return fail(TKZ_E_ARG, "id offsets must start at 0, be non-decreasing and end at the id count");
     if (total_bytes) *total_bytes = h.grand;
     if (h.grand > out_cap) return fail(TKZ_E_CAPACITY, "output capacity too small");
@@ -724,8 +853,9 @@ tkz_status tkz_decode_batch_device(tkz_encoder* e, const int32_t* d_ids, const i
     tkz_status st = check_encoder(e, scope);
     if (st != TKZ_OK) return st;
     if (!d_id_offsets || !d_out_offsets || (total_ids > 0 && !d_ids) || (out_cap > 0 && !d_out_bytes)) return fail(TKZ_E_ARG, "null device buffer");
-    std::lock_guard<std::mutex> lock(e->mu);
-    return decode_device(e, d_ids, d_id_offsets, n_docs, total_ids, d_out_bytes, out_cap, d_out_offsets, static_cast<hipStream_t>(hip_stream), total_bytes);
+    Lease lease(e);
+    Workspace* ws = lease.ws;
+    return decode_device(e, ws, d_ids, d_id_offsets, n_docs, total_ids, d_out_bytes, out_cap, d_out_offsets, static_cast<hipStream_t>(hip_stream), total_bytes);
 }
 
 tkz_status tkz_decode_batch(tkz_encoder* e, const int32_t* ids, const int64_t* id_offsets, int64_t n_docs, uint8_t* out_bytes, int64_t out_cap,
@@ -738,20 +868,21 @@ tkz_status tkz_decode_batch(tkz_encoder* e, const int32_t* ids, const int64_t* i
     const int64_t total = id_offsets[n_docs];
     if (total < 0 || (total > 0 && !ids)) return fail(TKZ_E_ARG, "bad id count");
     if (needed) *needed = 0;
-    std::lock_guard<std::mutex> lock(e->mu);
-    int64_t* acc = &e->bytes_allocated;
-    HIP_TRY(e->d_ids.ensure((size_t)std::max<int64_t>(total, 1) * 4, acc));
-    HIP_TRY(e->d_idoffs.ensure((size_t)(n_docs + 1) * 8, acc));
-    HIP_TRY(e->d_outoffs.ensure((size_t)(n_docs + 1) * 8, acc));
-    HIP_TRY(e->d_out.ensure((size_t)std::max<int64_t>(out_cap, 1), acc));
-    if (total) HIP_TRY(hipMemcpy(e->d_ids.p, ids, (size_t)total * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(e->d_idoffs.p, id_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
+    Lease lease(e);
+    Workspace* ws = lease.ws;
+    int64_t* acc = &ws->bytes_allocated;
+    HIP_TRY(ws->d_ids.ensure((size_t)std::max<int64_t>(total, 1) * 4, acc));
+    HIP_TRY(ws->d_idoffs.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(ws->d_outoffs.ensure((size_t)(n_docs + 1) * 8, acc));
+    HIP_TRY(ws->d_out.ensure((size_t)std::max<int64_t>(out_cap, 1), acc));
+    if (total) HIP_TRY(hipMemcpy(ws->d_ids.p, ids, (size_t)total * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ws->d_idoffs.p, id_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
     int64_t nbytes = 0;
-    st = decode_device(e, e->d_ids.as<int32_t>(), e->d_idoffs.as<int64_t>(), n_docs, total, e->d_out.as<uint8_t>(), out_cap, e->d_outoffs.as<int64_t>(), nullptr, &nbytes);
+    st = decode_device(e, ws, ws->d_ids.as<int32_t>(), ws->d_idoffs.as<int64_t>(), n_docs, total, ws->d_out.as<uint8_t>(), out_cap, ws->d_outoffs.as<int64_t>(), nullptr, &nbytes);
     if (needed) *needed = nbytes;
     if (st != TKZ_OK) return st;
-    if (nbytes) HIP_TRY(hipMemcpy(out_bytes, e->d_out.p, (size_t)nbytes, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_offsets, e->d_outoffs.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    if (nbytes) HIP_TRY(hipMemcpy(out_bytes, ws->d_out.p, (size_t)nbytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out_offsets, ws->d_outoffs.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
     return TKZ_OK;
 }
 
@@ -770,13 +901,21 @@ tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, 
     if (!e) return fail(TKZ_E_ARG, "null encoder");
     std::lock_guard<std::mutex> lock(e->mu);
     for (int k = 0; k < tkz::K_COUNT; ++k) {
-        if (ms) ms[k] = e->ms[k];
-        if (launches) launches[k] = e->launches[k];
-        if (reset) { e->ms[k] = 0; e->launches[k] = 0; }
+        double m = 0; int64_t n = 0;
+        for (Workspace* w : e->pool) { m += w->ms[k]; n += w->launches[k]; if (reset) { w->ms[k] = 0; w->launches[k] = 0; } }
+        if (ms) ms[k] = m;
+        if (launches) launches[k] = n;
     }
     return TKZ_OK;
 }
-int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) { return e ? e->bytes_allocated : 0; }
+int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) {
+    if (!e) return 0;
+    tkz_encoder* m = const_cast<tkz_encoder*>(e);
+    std::lock_guard<std::mutex> lock(m->mu);
+    int64_t n = e->bytes_allocated;
+    for (Workspace* w : e->pool) n += w->bytes_allocated;
+    return n;
+}
 const char* tkz_kernel_name(int32_t k) {
     static const char* const names[] = {"k_docmark", "k_pretok", "k_encode_waves", "k_scan", "k_gather", "k_docoffs", "k_encode_heavy_group"};
     return (k >= 0 && k < tkz::K_COUNT) ? names[k] : "?";

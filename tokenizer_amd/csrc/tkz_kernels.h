@@ -67,6 +67,7 @@ void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap);
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
                     const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs);
+void launch_rebase(const Launch& L, int64_t* offs, int64_t n, int64_t base);
 void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3);
 // UTF-16 documents -> UTF-8 documents (Encoding.UTF8.GetBytes for a batch): lengths + group prefixes, then (after the scan of
 // the tile sums) the bytes and the byte offset of every document

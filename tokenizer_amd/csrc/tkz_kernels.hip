@@ -953,6 +953,12 @@ TKZ_KERNEL(256) void k_docoffs(const int64_t* offs, int64_t n_docs, int64_t tota
     }
 }
 
+// document offsets of a chunk cut out of a larger batch: made relative to the chunk's first byte
+TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
+    const int64_t stride = simt::nblocks() * simt::nthreads();
+    for (int64_t i = simt::bid() * simt::nthreads() + simt::tid(); i < n; i += stride) offs[i] -= base;
+}
+
 // {n_docs, n_bytes, n_tokens} of the batch, on the device: what tkz_comm_allgather_counts_device sends (no host round trip)
 TKZ_KERNEL(64) void k_counts3(int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3) {
     if (simt::tid() == 0) { out3[0] = n_docs; out3[1] = total; out3[2] = grand ? *grand : 0; }
@@ -1303,6 +1309,9 @@ void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int6
     hook(L, K_DOCOFFS, 0);
     TKZ_LAUNCH(k_docoffs, grid_for(n_docs + 1), kThreads, L.stream, d_offs, n_docs, total, tile_base, docbits, docord_base, doc_tok, grand, out_offs);
     hook(L, K_DOCOFFS, 1);
+}
+void launch_rebase(const Launch& L, int64_t* offs, int64_t n, int64_t base) {
+    TKZ_LAUNCH(k_rebase, grid_for(n), kThreads, L.stream, offs, n, base);
 }
 void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3) {
     TKZ_LAUNCH(k_counts3, 1, 64, L.stream, n_docs, total, grand, out3);
