@@ -115,6 +115,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)
 
+    # stdout carries ONE JSON line and nothing else: libraries that print on file descriptor 1 (RCCL writes a version banner
+    # through C stdio when its first communicator is created) are pointed at stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -150,17 +156,7 @@ def main():
         return box[0]
     comm, comm_info = None, None
     try:
-        # (RCCL prints a version banner on file descriptor 1 when a communicator is created: keep stdout for the ONE JSON line)
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            comm = sharded.RcclCounts(rank, world, local_rank, exchange)
-        finally:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)          # (the banner sits in C stdio's buffer: flush it while fd 1 still points at stderr)
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
+        comm = sharded.RcclCounts(rank, world, local_rank, exchange)
         comm_info = comm.info()
     except Exception as ex:
         if world > 1:
@@ -361,7 +357,7 @@ def main():
         }
         if shard_note:
             line["shard_file"] = shard_note
-        print(json.dumps(line))
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if comm is not None:
         comm.close()
     if world > 1:
