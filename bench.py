@@ -300,8 +300,13 @@ def main():
                 # the real C# TokenizerLib beside it, when this host has a .NET SDK and a reference checkout (never in this image)
                 if shutil.which("dotnet") and os.environ.get("TKZ_REFERENCE_DIR"):
                     sp = "/tmp/tkz_bench_sample.bin"
+                    nd = min(ns, 200_000)
                     with open(sp, "wb") as f:
-                        f.write(np.int64(ns).tobytes()); f.write(h_offs.tobytes()); f.write(h_bytes.tobytes())
+                        f.write(np.int64(nd).tobytes()); f.write(h_offs[:nd + 1].tobytes()); f.write(h_bytes[:int(h_offs[nd])].tobytes())
+                    open("/tmp/tkz_bench_vocab.tiktoken", "wb").write(raw)
+                    from tokenizer_amd import tokenizer as TK
+                    os.environ["TKZ_BENCH_VOCAB"] = "/tmp/tkz_bench_vocab.tiktoken"
+                    os.environ["TKZ_BENCH_PATTERN"] = {1: TK.REGEX_PATTERN_1, 2: TK.REGEX_CL100K, 3: TK.REGEX_O200K}[args.pattern]
                     cpu["reference_dotnet"] = reference_dotnet_baseline(sp)
                 # PCIe-inclusive rate through the host-buffer entry point (tkz_encode_batch_utf8: H2D of the text, the kernels,
                 # D2H of ids + offsets), on ordinary (pageable) numpy buffers and on page-locked ones.  Output buffers are

@@ -6,7 +6,9 @@
 // ITokenizer (ITokenizer.cs:12,28) and adds EncodeBatch; special-token segmentation is the reference's own
 // EncodeInternal / FindNextSpecialToken (TikTokenizer.cs:141-170,230-241) with the plain segments sent to the
 // GPU in one batch.  The trim variants (TikTokenizer.cs:288-579) get the token count and length of every regex piece
-// from tkz_encode_batch_pieces_utf8 and decide the cut on the host; Decode delegates to a CPU TikTokenizer.
+// from tkz_encode_batch_pieces_utf8 and decide the cut on the host; Decode / DecodeBatch run on the device too
+// (tkz_decode_batch).  ShardedEncoder at the end is the multi-GPU form: one process per GPU, contiguous document
+// ranges, ONE RCCL all-gather of the per-rank counts through libtkz's own communicator (tkz_comm_*), token shard files.
 using System;
 using System.Collections.Generic;
 using System.IO;
@@ -32,6 +34,17 @@ namespace Microsoft.DeepDev
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_utf16(IntPtr encoder, char* text, long len, int* outIds, long outCap, out long nOut);
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_utf16(IntPtr encoder, char* units, long* unitOffsets, long nDocs,
                                                                                    int* outIds, long outCap, long* outOffsets, out long needed);
+        [DllImport(Lib)] internal static extern unsafe int tkz_encoder_set_special_tokens(IntPtr encoder, int* ids, byte* literalsUtf8, long* literalOffsets, int n);
+        [DllImport(Lib)] internal static extern unsafe int tkz_decode_batch(IntPtr encoder, int* ids, long* idOffsets, long nDocs, byte* outBytes, long outCap, long* outOffsets, out long needed);
+        // multi-GPU: the count exchange and the shard arithmetic (include/tkz.h, "multi-GPU"), token shard files
+        [DllImport(Lib)] internal static extern int tkz_comm_unique_id(byte[] id128);
+        [DllImport(Lib)] internal static extern int tkz_comm_create(byte[] id128, int rank, int world, int device, out IntPtr comm);
+        [DllImport(Lib)] internal static extern void tkz_comm_destroy(IntPtr comm);
+        [DllImport(Lib)] internal static extern int tkz_comm_world(IntPtr comm);
+        [DllImport(Lib)] internal static extern int tkz_comm_allgather_counts(IntPtr comm, long nDocs, long nBytes, long nTokens, long[] table);
+        [DllImport(Lib)] internal static extern void tkz_shard_range(long nDocsTotal, int rank, int world, out long lo, out long hi);
+        [DllImport(Lib)] internal static extern int tkz_shard_bases(long[] table, int world, int rank, long[] bases3, long[] totals3);
+        [DllImport(Lib)] internal static extern int tkz_shard_write([MarshalAs(UnmanagedType.LPUTF8Str)] string path, int[] ids, long nTokens, long[] offsets, long nDocs, long docBase, long tokenBase);
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_pieces_utf8(IntPtr encoder, byte* bytes, long* docOffsets, long nDocs, int* outIds, long outCap,
                                                                                          long* docPieceOffsets, long* pieceByteOffsets, long* pieceTokenOffsets,
                                                                                          long pieceCap, out long nPieces, out long neededIds);
@@ -47,18 +60,27 @@ namespace Microsoft.DeepDev
                 case -3: throw new KeyNotFoundException(msg);                 // BytePairEncoder.cs:17,73
                 case -7: throw new NotImplementedException(msg);              // TokenizerBuilder.cs:179
                 case -9: throw new PlatformNotSupportedException(msg);        // no HIP device: there is no CPU fallback in libtkz
+                case -10: throw new OutOfMemoryException(msg);                // device memory for the workspace
                 default: throw new InvalidOperationException("libtkz status " + status + ": " + msg);
             }
         }
     }
 
+    /// <summary>The native encoder (device tables + workspaces): released exactly once, also when Dispose is never called.</summary>
+    internal sealed class EncoderHandle : SafeHandle
+    {
+        public EncoderHandle(IntPtr h) : base(IntPtr.Zero, true) { SetHandle(h); }
+        public override bool IsInvalid => handle == IntPtr.Zero;
+        protected override bool ReleaseHandle() { Tkz.tkz_encoder_destroy(handle); return true; }
+    }
+
     public sealed class GpuTikTokenizer : ITokenizer, IDisposable
     {
-        private readonly IntPtr encoder;
+        private readonly EncoderHandle handle;
+        private IntPtr encoder => handle.DangerousGetHandle();
         private readonly IReadOnlyDictionary<string, int> specialTokensEncoder;
-        private readonly HashSet<string> specialTokens;
+        private readonly HashSet<string> specialTokens;         // Contains() only: the alternation below keeps the dictionary's order
         private readonly Regex specialTokensRegex;
-        private readonly TikTokenizer cpu;       // Decode
 
         /// <summary>Same arguments as TokenizerBuilder.CreateTokenizer (TokenizerBuilder.cs:210-213) plus the HIP device index.</summary>
         public GpuTikTokenizer(Stream tikTokenBpeFileStream, IReadOnlyDictionary<string, int> specialTokensEncoder, string pattern, int cacheSize = 8192, int device = 0)
@@ -67,12 +89,31 @@ namespace Microsoft.DeepDev
             using (var ms = new MemoryStream()) { tikTokenBpeFileStream.CopyTo(ms); file = ms.ToArray(); }
             Tkz.Check(Tkz.tkz_pattern_from_regex(pattern, out int pat));          // only the reference's own three patterns are implemented
             Tkz.Check(Tkz.tkz_vocab_from_tiktoken(file, (UIntPtr)file.Length, out IntPtr vocab));
-            try { Tkz.Check(Tkz.tkz_encoder_create(vocab, pat, device, out encoder)); }
+            IntPtr enc;
+            try { Tkz.Check(Tkz.tkz_encoder_create(vocab, pat, device, out enc)); }
             finally { Tkz.tkz_vocab_destroy(vocab); }
+            handle = new EncoderHandle(enc);
             this.specialTokensEncoder = specialTokensEncoder;
             specialTokens = new HashSet<string>(specialTokensEncoder.Keys);
-            specialTokensRegex = new Regex(string.Join("|", specialTokens.Select(s => Regex.Escape(s))), RegexOptions.Compiled);
-            cpu = new TikTokenizer(new MemoryStream(file), specialTokensEncoder, pattern, cacheSize);
+            // the alternation in the order of specialTokensEncoder.Keys, as the reference builds it (TikTokenizer.cs:78): when one
+            // special token is a prefix of another, the order of the alternatives decides the match
+            specialTokensRegex = new Regex(string.Join("|", specialTokensEncoder.Keys.Select(s => Regex.Escape(s))), RegexOptions.Compiled);
+            RegisterSpecialTokensForDecode();
+            _ = cacheSize;                                                     // the LRU piece memo has no effect on results (LRUCache.cs)
+        }
+
+        // SpecialTokensDecoder (TikTokenizer.cs:79) for the device Decode
+        private unsafe void RegisterSpecialTokensForDecode()
+        {
+            if (specialTokensEncoder.Count == 0) return;
+            var ids = specialTokensEncoder.Values.ToArray();
+            var lits = specialTokensEncoder.Keys.Select(k => Encoding.UTF8.GetBytes(k)).ToArray();
+            var offs = new long[lits.Length + 1];
+            for (int i = 0; i < lits.Length; ++i) offs[i + 1] = offs[i] + lits[i].Length;
+            var blob = new byte[Math.Max(1, offs[lits.Length])];
+            for (int i = 0; i < lits.Length; ++i) lits[i].CopyTo(blob, offs[i]);
+            fixed (int* pi = ids) fixed (byte* pb = blob) fixed (long* po = offs)
+                Tkz.Check(Tkz.tkz_encoder_set_special_tokens(encoder, pi, pb, po, ids.Length));
         }
 
         public List<int> Encode(string text, IReadOnlyCollection<string> allowedSpecial)
@@ -229,8 +270,60 @@ namespace Microsoft.DeepDev
         public (List<int> TokenIds, string Text) EncodeTrimPrefix(string text, int maxTokenCount, bool applySpecialTokens = true)
             => EncodeTrimPrefix(text, applySpecialTokens && specialTokens.Count > 0 ? specialTokens : null!, maxTokenCount);
 
-        public string Decode(int[] tokens) => cpu.Decode(tokens);
+        /// <summary>TikTokenizer.Decode (TikTokenizer.cs:586-604): ids in neither table are dropped; on the device.</summary>
+        public string Decode(int[] tokens) => DecodeBatch(new[] { tokens })[0];
 
-        public void Dispose() { Tkz.tkz_encoder_destroy(encoder); }
+        public unsafe List<string> DecodeBatch(IReadOnlyList<int[]> batches)
+        {
+            var offs = new long[batches.Count + 1];
+            for (int i = 0; i < batches.Count; ++i) offs[i + 1] = offs[i] + batches[i].Length;
+            var flat = new int[Math.Max(1, offs[batches.Count])];
+            for (int i = 0; i < batches.Count; ++i) batches[i].CopyTo(flat, offs[i]);
+            var outOffs = new long[batches.Count + 1];
+            var bytes = new byte[Math.Max(16, 8 * flat.Length)];
+            while (true)
+            {
+                int st; long needed;
+                fixed (int* pi = flat) fixed (long* po = offs) fixed (byte* pb = bytes) fixed (long* poo = outOffs)
+                    st = Tkz.tkz_decode_batch(encoder, pi, po, batches.Count, pb, bytes.Length, poo, out needed);
+                if (st == -4) { bytes = new byte[needed]; continue; }              // TKZ_E_CAPACITY: `needed` is the exact size
+                Tkz.Check(st);
+                break;
+            }
+            var result = new List<string>(batches.Count);
+            for (int i = 0; i < batches.Count; ++i) result.Add(Encoding.UTF8.GetString(bytes, (int)outOffs[i], (int)(outOffs[i + 1] - outOffs[i])));
+            return result;
+        }
+
+        public void Dispose() { handle.Dispose(); }                              // idempotent (SafeHandle)
+    }
+
+    /// <summary>One rank of a sharded job (BASELINE configs[3]): rank r of `world` encodes documents tkz_shard_range(r) on its own GPU;
+    /// the only exchange is one RCCL all-gather of {docs, bytes, tokens} per batch (tkz_comm_allgather_counts), from which every rank
+    /// gets the global index of its first document and token; results go to one token shard file per rank (tkz_shard_write).
+    /// The 128-byte communicator id travels from rank 0 to the others by whatever the host has (a file, a socket, MPI).</summary>
+    public sealed class ShardedEncoder : IDisposable
+    {
+        private readonly IntPtr comm;
+        public int Rank { get; }
+        public int World { get; }
+        public static byte[] NewCommunicatorId() { var id = new byte[128]; Tkz.Check(Tkz.tkz_comm_unique_id(id)); return id; }
+        public ShardedEncoder(byte[] communicatorId, int rank, int world, int device)
+        {
+            Tkz.Check(Tkz.tkz_comm_create(communicatorId, rank, world, device, out comm));
+            Rank = rank; World = world;
+        }
+        public (long Lo, long Hi) MyDocuments(long nDocsTotal) { Tkz.tkz_shard_range(nDocsTotal, Rank, World, out long lo, out long hi); return (lo, hi); }
+        /// <summary>After encoding this rank's documents: exchange the counts, write the shard.  Returns the job totals {docs, bytes, tokens}.</summary>
+        public long[] Publish(string shardPath, int[] ids, long nTokens, long[] offsets, long nDocs, long nBytes)
+        {
+            var table = new long[3 * World];
+            Tkz.Check(Tkz.tkz_comm_allgather_counts(comm, nDocs, nBytes, nTokens, table));
+            var bases = new long[3]; var totals = new long[3];
+            Tkz.Check(Tkz.tkz_shard_bases(table, World, Rank, bases, totals));
+            Tkz.Check(Tkz.tkz_shard_write(shardPath, ids, nTokens, offsets, nDocs, bases[0], bases[2]));
+            return totals;
+        }
+        public void Dispose() { Tkz.tkz_comm_destroy(comm); }
     }
 }

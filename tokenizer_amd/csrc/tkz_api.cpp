@@ -917,7 +917,7 @@ int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) {
     return n;
 }
 const char* tkz_kernel_name(int32_t k) {
-    static const char* const names[] = {"k_docmark", "k_pretok", "k_encode_waves", "k_scan", "k_gather", "k_docoffs", "k_encode_heavy_group"};
+    static const char* const names[] = {"k_docmark", "k_pretok", "k_probe", "k_scan", "k_place", "k_docoffs", "k_merge_group"};
     return (k >= 0 && k < tkz::K_COUNT) ? names[k] : "?";
 }
 

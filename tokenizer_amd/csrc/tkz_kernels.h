@@ -9,7 +9,7 @@
 namespace tkz {
 
 constexpr int kThreads = 256;       // workgroup size of every kernel (4 wavefronts)
-constexpr int kSub = 1024;          // bytes of corpus per wavefront of k_encode_waves (a "sub-tile")
+constexpr int kSub = 1024;          // bytes of corpus per wavefront of k_probe / k_place (a "sub-tile")
 constexpr int kHalo = 64;           // bytes staged past the sub-tile (a short piece may straddle the edge)
 constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one per lane, 64 to a wavefront, by k_merge_short
 constexpr int kArenaDwords = 3584;  // LDS arena of k_merge_long: the long misses of a batch get 2 dwords + 1 byte + 1 bit per byte out of it
@@ -38,14 +38,13 @@ struct EncodeParams {
     const int64_t* docord_base;   // per sub-tile: number of distinct document-start positions before it
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
     int32_t* counters;            // [0] error bits
-    uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_encode_waves for the ones it leaves to k_encode_waves_heavy
+    uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_probe: bit 0 = a piece of 17..1024 bytes to merge, bit 1 = a giant piece
                                                                           // (a flag, not a queue: a queue's one counter serialises a million atomics on mixed text)
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)
-    // pieces > kArenaPiece bytes ("giant"): found by k_giant_find, merged by k_giant_merge (one 1024-thread workgroup each) BEFORE the
-    // encode kernels; their tokens wait in tmp at the piece's own byte position, their count in giant_cnt[sub-tile of the piece start]
+    // pieces > kArenaPiece bytes ("giant"): found by k_giant_find, merged by k_giant_merge (one 1024-thread workgroup each); their
+    // tokens wait in tmp at the piece's own byte position, their count in giant_cnt[sub-tile of the piece start]
     int64_t* giant_q; unsigned long long* giant_count; int64_t giant_cap; int32_t* giant_cnt;
-    // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE): per-stage cycle counters (bit 4) and ablations
-    // (bit0 skip merges, bit1 skip table probes, bit2 skip stores, bit3 stage 0/1 only).  Compiled out of libtkz.so otherwise.
+    // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE bit 4): per-phase clock counters of k_probe.  Compiled out of libtkz.so otherwise.
     unsigned long long* devprof;
     int32_t ablate;
 };
