@@ -113,5 +113,6 @@ inline unsigned atomic_or(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v
 inline unsigned long long atomic_or64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
 inline unsigned long long atomic_add64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline long long clock() { return 0; }
+inline unsigned long long atomic_max64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 inline unsigned long long atomic_min64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 }  // namespace simt

@@ -109,6 +109,12 @@ def test_mid_pieces_share_the_arena(lib, vocab, oracle_mod, oracle_gpt2):
 def test_long_and_giant_pieces(lib, vocab, vocabs, oracle_mod, oracle_gpt2):
     # whole-wave path, arrays in the global pool (> kArenaPiece bytes), incl. the pool-grow retry
     parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=9, rounds=2, lens=[300, 1024, 1025, 1500, 2600], counts=[3])
+    # longer than the LDS state of k_giant_merge (6144 parts): starts in the global pool, moves into LDS when it has shrunk
+    enc0 = N.Encoder(vocab, N.CL100K)
+    for p in (b"ab" * 3500, (b"hello world, " * 600)[:7100].replace(b" ", b"_").replace(b",", b"x")):
+        r = oracle_gpt2.rank(p)
+        got = enc0.encode_pieces(np.frombuffer(p, np.uint8), np.array([0, len(p)]))[0].tolist()
+        assert got == ([r] if r >= 0 else oracle_gpt2.bpe(p)), len(p)
     # giant pieces that collapse to a handful of tokens (runs of one byte under a vocabulary with long run keys): the in-lane copy of k_place
     v, ov = vocabs("synth100k")
     enc = N.Encoder(v, N.CL100K)

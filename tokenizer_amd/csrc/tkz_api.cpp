@@ -355,6 +355,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             const double w = h[0] ? (double)h[0] : 1.0;
             fprintf(stderr, "[tkz devprof] k_probe waves %llu  clock ticks/wave: total %.0f  load+compact %.0f  short batches %.0f  mid batches %.0f | mid pieces/wave %.1f pieces/wave %.1f\n",
                     h[0], h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w);
+            if (h[8]) fprintf(stderr, "[tkz devprof] k_giant_merge pieces %llu  clock ticks/piece: global-memory rounds %.0f  LDS rounds %.0f | bytes/piece %.0f tokens/piece %.0f | slowest piece %llu ticks | rounds/piece: global %.0f LDS %.0f\n",
+                              h[8], (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[12] / h[8], h[13], (double)h[14] / h[8], (double)h[15] / h[8]);
         }
 #endif
         const int32_t err = ws->h_counters->err;

@@ -59,8 +59,10 @@ TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* 
         int32_t r2[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) idv[k] = (uint32_t)brank[bk[k]];                         // parts = single bytes
+        // initial pair ranks (:37-44): only the pairs the piece has (every gather is a request to the memory pipeline, and those
+        // requests -- not bytes, not flops -- are what the merge kernels are made of)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) r2[k] = T.bytepair_rank[(bk[k] << 8) | bk[k + 1]];       // initial pair ranks (:37-44)
+        for (int k = 0; k < 16; ++k) r2[k] = (16 * c + k + 1 < n) ? T.bytepair_rank[(bk[k] << 8) | bk[k + 1]] : TKZ_RANK_NONE;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int g = 16 * c + k;
@@ -128,7 +130,8 @@ TKZ_HD int tkz_bpe_var_a4(int n) { return (((n + 31) >> 5) + 3) & ~3; }
 TKZ_HD int tkz_bpe_var_dwords(int n) { return 2 * tkz_bpe_var_n4(n) + tkz_bpe_var_a4(n); }
 
 template <bool PACKED, class ByteAt>
-TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, int* err) {
+TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, int* err, const int32_t* brank = nullptr) {
+    if (!brank) brank = T.byte_rank;
     constexpr uint32_t NONE = PACKED ? TKZ_NOKEY : (uint32_t)TKZ_RANK_NONE;
     auto entry = [](int32_t rank, int pos) -> uint32_t {
         if (rank == TKZ_RANK_NONE) return NONE;
@@ -145,9 +148,9 @@ TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, 
         for (int k = 0; k < 17; ++k) b[k] = c + k < n ? at(c + k) : 0u;
         uint32_t idv[16]; int32_t r2[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) idv[k] = (uint32_t)T.byte_rank[b[k]];                      // parts = single bytes
+        for (int k = 0; k < 16; ++k) idv[k] = c + k < n ? (uint32_t)brank[b[k]] : 0u;           // parts = single bytes
 #pragma unroll
-        for (int k = 0; k < 16; ++k) r2[k] = T.bytepair_rank[(b[k] << 8) | b[k + 1]];           // initial pair ranks (:37-44)
+        for (int k = 0; k < 16; ++k) r2[k] = c + k + 1 < n ? T.bytepair_rank[(b[k] << 8) | b[k + 1]] : TKZ_RANK_NONE;   // initial pair ranks (:37-44), only the pairs there are
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (c + 4 * q < n4) {
@@ -300,27 +303,22 @@ TKZ_DEV int tkz_block_exclusive_max(int v) {
 //     result identical to the one-merge-at-a-time loop.
 // Arrays (n entries each, LDS or global): idsA/prA (state), s1/s2 (scratch), idsB/prB (next state).  pr[i] is the rank
 // of (part i, part i+1).  Tokens are written to dst in order; returns their number.
-template <class ByteAt>
-TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, int32_t* prA, int32_t* s1, int32_t* s2,
-                         int32_t* idsB, int32_t* prB, int32_t* dst, int* err) {
+// The rounds, on whatever arrays the state is in.  Runs until no pair has a rank (returns true) or, when stop_at > 0, until the
+// state has shrunk to stop_at parts or fewer (returns false: the caller moves the state to faster memory and calls again).
+// ids / pr are left pointing at the current state, cnt at its length.
+TKZ_DEV bool tkz_bpe_long_rounds(const TkzTables& T, int& cnt, int32_t*& ids, int32_t*& pr, int32_t*& s1, int32_t* s2, int32_t*& idsN, int32_t* prN, int stop_at, int* rounds = nullptr) {
     const int tid = simt::tid(), G = simt::nthreads();
     constexpr int32_t kNotMerge = 0x7FFFFFFE;
-    for (int k = tid; k < n; k += G) {
-        const uint32_t b = at(k);
-        idsA[k] = T.byte_rank[b];
-        prA[k] = (k + 1 < n) ? T.bytepair_rank[(b << 8) | at(k + 1)] : TKZ_RANK_NONE;
-    }
-    simt::sync();
-    int cnt = n;
-    int32_t* ids = idsA; int32_t* pr = prA; int32_t* idsN = idsB; int32_t* prN = prB;
     for (;;) {
+        if (rounds) ++*rounds;
+        if (stop_at > 0 && cnt <= stop_at) return false;
         const int c = (cnt + G - 1) / G;                  // contiguous block of parts per thread
         const int lo = tid * c < cnt ? tid * c : cnt, hi = lo + c < cnt ? lo + c : cnt;
         // 1. the minimum rank
         uint32_t mymin = (uint32_t)TKZ_RANK_NONE;
         for (int i = lo; i < hi; ++i) { const uint32_t r = (uint32_t)pr[i]; mymin = r < mymin ? r : mymin; }
         const int32_t m = (int32_t)tkz_block_min32(mymin);
-        if (m == TKZ_RANK_NONE) break;                    // (:65-68)
+        if (m == TKZ_RANK_NONE) return true;              // (:65-68)
         // 2. candidates, position in their chain -> merge flags (s1)
         int lastNon = -1;                                 // last non-candidate index inside my block
         for (int i = lo; i < hi; ++i) if (pr[i] != m) lastNon = i;
@@ -377,6 +375,137 @@ TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, in
         { int32_t* t = ids; ids = idsN; idsN = t; }
         cnt = tot;
         simt::sync();
+    }
+}
+
+// The same rounds with the state in LDS in its COMPACT form -- ids[cap] | pr[cap] | one flag byte per part (9 bytes per part, so
+// 16 Ki parts fit a CU's LDS) -- for a workgroup of exactly 1024 threads, each owning C = cap / 1024 consecutive parts in a fully
+// unrolled loop (what it computes for its parts stays in registers between the phases).  What a round needs from a merge's
+// neighbours is recomputed by the thread that needs it instead of being passed through scratch arrays:
+//   merge at i (flag[i], i <= istar):  id' = m;  pr' = rank(m, id[i+2])   or rank(m, m) when i+2 merges too      (:58)
+//   part j left of a merge (flag[j+1]): id' = id[j];  pr' = rank(id[j], m)                                      (:59-62)
+//   part right of a merge (flag[j-1]): swallowed                                                               (:63)
+// and the round is cut after the leftmost merge that creates a pair ranked below m, exactly as in tkz_bpe_long_rounds.
+template <int C>
+TKZ_DEV void tkz_bpe_long_rounds_lds(const TkzTables& T, int& cnt, int32_t* ids, int32_t* pr, uint8_t* flag, int* rounds = nullptr) {
+    const int tid = simt::tid();
+    for (;;) {
+        if (rounds) ++*rounds;
+        const int c = (cnt + 1023) >> 10;                 // parts per thread this round (<= C)
+        const int lo = tid * c < cnt ? tid * c : cnt;
+        // 1. the minimum rank
+        int32_t mypr[C], myid[C];
+        uint32_t mymin = (uint32_t)TKZ_RANK_NONE;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int i = lo + q;
+            const bool in = q < c && i < cnt;
+            mypr[q] = in ? pr[i] : TKZ_RANK_NONE; myid[q] = in ? ids[i] : 0;
+            mymin = (uint32_t)mypr[q] < mymin ? (uint32_t)mypr[q] : mymin;
+        }
+        const int32_t m = (int32_t)tkz_block_min32(mymin);
+        if (m == TKZ_RANK_NONE) return;                   // (:65-68)
+        // 2. candidates; leftmost first inside a chain of adjacent candidates: every other one, counted from the chain's start
+        int lastNon = -1;
+#pragma unroll
+        for (int q = 0; q < C; ++q) if (q < c && lo + q < cnt && mypr[q] != m) lastNon = lo + q;
+        int ln = tkz_block_exclusive_max(lastNon);
+        uint32_t myflags = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int i = lo + q;
+            if (q < c && i < cnt) {
+                if (mypr[q] != m) { ln = i; flag[i] = 0; }
+                else { const bool mg = ((i - (ln + 1)) & 1) == 0; flag[i] = mg ? 1 : 0; myflags |= mg ? (1u << q) : 0u; }
+            }
+        }
+        simt::sync();
+        // 3. the leftmost merge that creates a pair ranked below m: merges beyond it wait for a later round
+        uint32_t firstViol = 0xFFFFFFFFu;
+        int32_t Rv[C];                                    // rank(m, next part) of my merges (the transient pair)
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            Rv[q] = TKZ_RANK_NONE;
+            if ((myflags >> q) & 1u) {
+                const int i = lo + q;
+                int32_t L = TKZ_RANK_NONE;
+                if (i >= 1) L = tkz_lookup_pair(T, (i >= 2 && flag[i - 2]) ? (uint32_t)m : (uint32_t)ids[i - 1], (uint32_t)m);
+                if (i + 2 < cnt) Rv[q] = tkz_lookup_pair(T, (uint32_t)m, (uint32_t)ids[i + 2]);
+                if ((L < m || Rv[q] < m) && (uint32_t)i < firstViol) firstViol = (uint32_t)i;
+                // a merging part's own pair rank is m (known): its slot carries rank(left part, m) to whoever needs it in step 4 -- the
+                // part on its left, or a merge two to the left -- instead of a second table round trip there
+                pr[i] = L;
+            }
+        }
+        const uint32_t istar = tkz_block_min32(firstViol);   // (its barriers publish the slots written above)
+        // 4. the new state of my parts, in registers; then compaction in place (everything is read before anything is written)
+        int32_t nid[C], npr[C];
+        int alive = 0;
+        uint32_t keep = 0;
+#pragma unroll
+        for (int q = 0; q < C; ++q) {
+            const int i = lo + q;
+            nid[q] = 0; npr[q] = TKZ_RANK_NONE;
+            if (!(q < c && i < cnt)) continue;
+            if (i >= 1 && flag[i - 1] && (uint32_t)(i - 1) <= istar) continue;                       // swallowed (:63)
+            keep |= 1u << q; ++alive;
+            if (((myflags >> q) & 1u) && (uint32_t)i <= istar) {
+                nid[q] = m;
+                if (i + 2 < cnt) npr[q] = (flag[i + 2] && (uint32_t)(i + 2) <= istar) ? pr[i + 2] : Rv[q];      // rank(m, m) left there by the merge at i + 2
+            } else {
+                nid[q] = myid[q];
+                npr[q] = (i + 1 < cnt && flag[i + 1] && (uint32_t)(i + 1) <= istar) ? pr[i + 1] : mypr[q];          // rank(id, m) left there by the merge at i + 1
+            }
+        }
+        int tot;
+        int o = tkz_block_scan(alive, &tot);              // (its barriers also separate the reads above from the writes below)
+#pragma unroll
+        for (int q = 0; q < C; ++q) if ((keep >> q) & 1u) { ids[o] = nid[q]; pr[o] = npr[q]; ++o; }
+        cnt = tot;
+        simt::sync();
+    }
+}
+
+// lds: 9 * kBpeLongLds bytes of LDS (workgroups of 1024 threads) or null.  The state starts in the global arrays when the piece is
+// longer than kBpeLongLds parts and MOVES INTO LDS as soon as it has shrunk to that: a round is ten passes over the state and as
+// many workgroup barriers, and most rounds of a long diverse piece (one per distinct rank) happen when a few thousand parts are
+// left -- in L2 / Infinity Cache a round costs ~25 us, in LDS ~5.
+constexpr int kBpeLongLds = 16384;
+template <class ByteAt>
+TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, int32_t* prA, int32_t* s1g, int32_t* s2g,
+                         int32_t* idsB, int32_t* prB, int32_t* dst, int* err, int32_t* lds = nullptr, unsigned long long* prof = nullptr) {
+    const int tid = simt::tid(), G = simt::nthreads();
+    const bool use_lds = lds != nullptr && G == 1024;
+    const bool start_in_lds = use_lds && n <= kBpeLongLds;
+    int32_t* ids = start_in_lds ? lds : idsA;
+    int32_t* pr = start_in_lds ? lds + kBpeLongLds : prA;
+    for (int k = tid; k < n; k += G) {
+        const uint32_t b = at(k);
+        ids[k] = T.byte_rank[b];
+        pr[k] = (k + 1 < n) ? T.bytepair_rank[(b << 8) | at(k + 1)] : TKZ_RANK_NONE;
+    }
+    simt::sync();
+    int cnt = n;
+    bool done = false;
+    long long t0 = prof ? simt::clock() : 0, t1 = t0;
+    int rg = 0, rl = 0;
+    if (!start_in_lds) {
+        int32_t* s1 = s1g; int32_t* idsN = idsB;
+        done = tkz_bpe_long_rounds(T, cnt, ids, pr, s1, s2g, idsN, prB, use_lds ? kBpeLongLds : 0, prof ? &rg : nullptr);
+        if (prof) t1 = simt::clock();
+        if (!done) {                                     // the state fits LDS now: move it
+            for (int k = tid; k < cnt; k += G) { lds[k] = ids[k]; lds[kBpeLongLds + k] = pr[k]; }
+            simt::sync();
+            ids = lds; pr = lds + kBpeLongLds;
+        }
+    }
+    if (!done) tkz_bpe_long_rounds_lds<kBpeLongLds / 1024>(T, cnt, ids, pr, reinterpret_cast<uint8_t*>(lds + 2 * kBpeLongLds), prof ? &rl : nullptr);
+    if (prof && tid == 0) {
+        const long long t2 = simt::clock();
+        simt::atomic_add64(&prof[8], 1ull); simt::atomic_add64(&prof[9], (unsigned long long)(t1 - t0)); simt::atomic_add64(&prof[10], (unsigned long long)(t2 - t1));
+        simt::atomic_add64(&prof[11], (unsigned long long)n); simt::atomic_add64(&prof[12], (unsigned long long)cnt);
+        simt::atomic_max64(&prof[13], (unsigned long long)(t2 - t0));
+        simt::atomic_add64(&prof[14], (unsigned long long)rg); simt::atomic_add64(&prof[15], (unsigned long long)rl);
     }
     // emit surviving parts in order (:70-75)
     const int c = (cnt + G - 1) / G;

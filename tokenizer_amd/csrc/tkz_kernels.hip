@@ -313,10 +313,14 @@ constexpr uint32_t kPrLenMask = 0x7FFu;                 // len - 1 / count - 1 (
 #ifndef TKZ_PROBE_U
 #define TKZ_PROBE_U 2
 #endif
+#ifndef TKZ_MS_THREADS
+#define TKZ_MS_THREADS 256
+#endif
 #ifndef TKZ_PROBE_OCC
 #define TKZ_PROBE_OCC 8
 #endif
 constexpr int kGroup = TKZ_GROUP;                       // sub-tiles per wavefront of k_merge_short
+constexpr int kMsThreads = TKZ_MS_THREADS;              // ... and the workgroup size of that kernel
 
 // exclusive prefix over the wave of a small non-negative value (< 2^BITS), and the wave total;
 // bit-sliced: one ballot + mbcnt per bit, no LDS traffic
@@ -550,13 +554,16 @@ TKZ_DEV void tkz_load_piece16(const uint8_t* bytes, int64_t total, int64_t abs, 
     for (int i = 0; i < 4; ++i) pw[i] = (uint32_t)((((uint64_t)w[i + 1] << 32) | w[i]) >> sh);
 }
 
-TKZ_KERNEL_OCC(256, 3) void k_merge_short(TkzTables T, EncodeParams P) {
+TKZ_KERNEL_OCC(kMsThreads, 3) void k_merge_short(TkzTables T, EncodeParams P) {
     constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride;
-    TKZ_SHARED uint4 s_scr_all[kThreads / 64][(2 * STRIDE * 64) / 4];   // per lane ids[16] | pr[16] at a conflict-free stride
-    TKZ_SHARED uint32_t s_rec_all[kThreads / 64][64];                   // the batch: record, and (sub-tile of the group) << 10 | piece index
-    TKZ_SHARED uint32_t s_idx_all[kThreads / 64][64];
+    TKZ_SHARED uint4 s_scr_all[kMsThreads / 64][(2 * STRIDE * 64) / 4];   // per lane ids[16] | pr[16] at a conflict-free stride
+    TKZ_SHARED uint32_t s_rec_all[kMsThreads / 64][64];                   // the batch: record, and (sub-tile of the group) << 10 | piece index
+    TKZ_SHARED uint32_t s_idx_all[kMsThreads / 64][64];
+    TKZ_SHARED int32_t s_brank[256];                                     // id of every single byte: in LDS, not 16 gathers per piece
     const int lane = simt::lane(), wv = simt::wave();
-    const int64_t sub0 = (simt::bid() * (kThreads / 64) + wv) * kGroup;
+    for (int i = simt::tid(); i < 256; i += simt::nthreads()) s_brank[i] = T.byte_rank[i];
+    simt::sync();
+    const int64_t sub0 = (simt::bid() * (kMsThreads / 64) + wv) * kGroup;
     if (sub0 >= P.nsub) return;
     uint32_t* s_scr = reinterpret_cast<uint32_t*>(s_scr_all[wv]);
     uint32_t* s_rec = s_rec_all[wv];
@@ -584,7 +591,7 @@ TKZ_KERNEL_OCC(256, 3) void k_merge_short(TkzTables T, EncodeParams P) {
             uint32_t pw[NMAX / 4], alive = 1;
             tkz_load_piece16(P.bytes, P.total, abs, pw);
             int e1 = 0;
-            const int cnt = tkz_bpe_lane<NMAX>(T, pw, len, ids, pr, T.byte_rank, &alive, &e1);
+            const int cnt = tkz_bpe_lane<NMAX>(T, pw, len, ids, pr, s_brank, &alive, &e1);
             err |= e1;
             int32_t* dst = P.tmp + abs;
             int i = 0;
@@ -640,8 +647,11 @@ TKZ_KERNEL_OCC(256, 3) void k_merge_short(TkzTables T, EncodeParams P) {
 TKZ_KERNEL_OCC(64, 2) void k_merge_long(TkzTables T, EncodeParams P) {
     TKZ_SHARED uint4 s_arena4[kArenaDwords / 4];
     TKZ_SHARED uint32_t s_rec[64], s_idx[64], s_aoff[64];
+    TKZ_SHARED int32_t s_brank[256];                                     // id of every single byte: in LDS, not a gather per byte
     uint32_t* s_arena = reinterpret_cast<uint32_t*>(s_arena4);
     const int lane = simt::lane();
+    for (int i = lane; i < 256; i += 64) s_brank[i] = T.byte_rank[i];
+    (void)simt::ballot(true);
     int err = 0;
     for (int64_t c = simt::bid(); c * 64 < P.nsub; c += simt::nblocks()) {
         const int64_t t = c * 64 + lane;
@@ -678,7 +688,7 @@ TKZ_KERNEL_OCC(64, 2) void k_merge_long(TkzTables T, EncodeParams P) {
                 uint32_t* st = bw + ((nbw + 3) & ~3);             // (the state arrays are read 16 bytes at a time)
                 auto at = [&](int i) -> uint32_t { return pbytes[i]; };
                 int e1 = 0;
-                const int cnt = T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &e1) : tkz_bpe_lane_var<false>(T, at, len, st, &e1);
+                const int cnt = T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &e1, s_brank) : tkz_bpe_lane_var<false>(T, at, len, st, &e1, s_brank);
                 err |= e1;
                 tkz_bpe_var_emit(st, len, P.tmp + abs);
                 P.prank[P.pbase[sub] + (ix & 1023u)] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (uint32_t)rel;
@@ -830,11 +840,16 @@ TKZ_KERNEL(256) void k_giant_find(const uint8_t* heavy_flag, int64_t nsub, const
     }
 }
 TKZ_KERNEL(1024) void k_giant_merge(TkzTables T, EncodeParams P) {
+    TKZ_SHARED int32_t s_state[(9 * kBpeLongLds + 3) / 4];        // ids | pair ranks | flag bytes of up to 16 Ki parts: 144 KB of the CU's 160
     TKZ_SHARED int64_t s_off;
     TKZ_SHARED int32_t s_whole;
     const int64_t n = (int64_t)*P.giant_count < P.giant_cap ? (int64_t)*P.giant_count : P.giant_cap;
     int err = 0;
-    for (int64_t q = simt::bid(); q < n; q += simt::nblocks()) {
+    // longest first: a diverse piece of tens of KiB is merged in thousands of rounds and sets the kernel's duration by itself, so
+    // those are started before the short ones (two passes over the queue: pieces longer than 12 KiB, then the rest)
+    for (int64_t qq = simt::bid(); qq < 2 * n; qq += simt::nblocks()) {
+        const int64_t q = qq < n ? qq : qq - n;
+        { const bool big = P.giant_q[2 * q + 1] > 12288; if (big != (qq < n)) continue; }
         const int64_t p = P.giant_q[2 * q], len64 = P.giant_q[2 * q + 1];
         int cnt = 0;
         if (len64 > kMaxPiece) err |= kErrTooLong;
@@ -857,7 +872,7 @@ TKZ_KERNEL(1024) void k_giant_merge(TkzTables T, EncodeParams P) {
             else if (off < 0) { err |= kErrPool; cnt = -1; }
             else {
                 int32_t* arr = P.pool + off;
-                cnt = tkz_bpe_long(T, at, len, arr, arr + len, arr + 2 * (int64_t)len, arr + 3 * (int64_t)len, arr + 4 * (int64_t)len, arr + 5 * (int64_t)len, dst, &err);
+                cnt = tkz_bpe_long(T, at, len, arr, arr + len, arr + 2 * (int64_t)len, arr + 3 * (int64_t)len, arr + 4 * (int64_t)len, arr + 5 * (int64_t)len, dst, &err, s_state, TKZ_DEV_FLAG(P, 16) ? P.devprof : nullptr);
             }
         }
         if (simt::tid() == 0) P.giant_cnt[p / kSub] = cnt;
@@ -1276,7 +1291,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     TKZ_LAUNCH(k_probe, cdiv(nsub, kThreads / 64), kThreads, L.stream, T, P);
     hook(L, K_ENCODE, 1);
     hook(L, K_HEAVY, 0);
-    TKZ_LAUNCH(k_merge_short, cdiv(nsub, (kThreads / 64) * kGroup), kThreads, L.stream, T, P);
+    TKZ_LAUNCH(k_merge_short, cdiv(nsub, (kMsThreads / 64) * kGroup), kMsThreads, L.stream, T, P);
     // giant pieces start in sub-tiles k_probe has flagged: find them, merge them; then the pieces of 17..1024 bytes and the giants' token counts
     TKZ_LAUNCH(k_giant_find, grid_for(nsub), kThreads, L.stream, (const uint8_t*)P.heavy_flag, nsub, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap);
 #ifdef TKZ_HOSTEMU

@@ -47,6 +47,7 @@ TKZ_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
 TKZ_DEV unsigned long long atomic_or64(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
 TKZ_DEV unsigned long long atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 TKZ_DEV unsigned long long atomic_min64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
+TKZ_DEV unsigned long long atomic_max64(unsigned long long* p, unsigned long long v) { return atomicMax(p, v); }
 TKZ_DEV long long clock() { return (long long)__builtin_readcyclecounter(); }
 // inclusive prefix sum over the 64 lanes on the DPP crossbar (row shifts inside the rows of 16, then the two row broadcasts): six
 // data-parallel moves, no LDS, no ballots
