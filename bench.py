@@ -247,10 +247,10 @@ def main():
                 tj = json.load(open(tpath))
                 if tj.get("src_sha") != kernel_sources_sha():
                     traffic_note = "profiles/traffic_latest.json was collected on other kernel sources (src_sha differs): not reported"
-                elif tj.get("docs_per_gpu") != n_docs or tj.get("kind") != args.kind or tj.get("kernel") != dom:
+                elif tj.get("docs_per_gpu") != n_docs or tj.get("kind") != args.kind or dom not in tj.get("by_kernel", {}):
                     traffic_note = "profiles/traffic_latest.json is for another workload / kernel: not reported"
                 else:
-                    traffic, traffic_note = tj.get("hbm_bytes_per_launch"), "rocprofv3 PMC passes of this build (profiles/traffic_latest.json)"
+                    traffic, traffic_note = tj["by_kernel"][dom]["hbm_bytes_per_launch"], "rocprofv3 PMC passes of this build (profiles/traffic_latest.json)"
             except Exception:
                 traffic = None
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -209,7 +209,8 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
 /* ---- measurement ------------------------------------------------------------------------- */
 
 enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_PROBE = 2 /* k_probe alone */, TKZ_K_SCAN = 3, TKZ_K_PLACE = 4,
-       TKZ_K_DOCOFFS = 5, TKZ_K_MERGE = 6 /* k_merge_short + k_giant_find + k_giant_merge + k_merge_long */, TKZ_K_COUNT = 7 };
+       TKZ_K_DOCOFFS = 5, TKZ_K_MERGE_LONG = 6 /* k_giant_find + k_giant_merge + k_merge_long */, TKZ_K_MERGE_SHORT = 7 /* k_merge_short alone */,
+       TKZ_K_COUNT = 8 };
 /* When enabled, every kernel launch of tkz_encode_batch_device is bracketed by HIP events on the
  * launch stream; tkz_encoder_kernel_ms returns the accumulated milliseconds and launch counts per
  * kernel since the last reset (arrays of TKZ_K_COUNT). */

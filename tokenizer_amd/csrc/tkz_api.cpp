@@ -919,7 +919,7 @@ int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) {
     return n;
 }
 const char* tkz_kernel_name(int32_t k) {
-    static const char* const names[] = {"k_docmark", "k_pretok", "k_probe", "k_scan", "k_place", "k_docoffs", "k_merge_group"};
+    static const char* const names[] = {"k_docmark", "k_pretok", "k_probe", "k_scan", "k_place", "k_docoffs", "k_merge_long_group", "k_merge_short"};
     return (k >= 0 && k < tkz::K_COUNT) ? names[k] : "?";
 }
 

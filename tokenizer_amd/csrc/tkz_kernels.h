@@ -18,7 +18,7 @@ constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrToo
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan
 
-enum { K_DOCMARK = 0, K_PRETOK = 1, K_ENCODE = 2, K_SCAN = 3, K_GATHER = 4, K_DOCOFFS = 5, K_HEAVY = 6, K_COUNT = 7 };
+enum { K_DOCMARK = 0, K_PRETOK = 1, K_ENCODE = 2, K_SCAN = 3, K_GATHER = 4, K_DOCOFFS = 5, K_HEAVY = 6, K_MERGE_SHORT = 7, K_COUNT = 8 };
 
 #ifdef TKZ_DEVPROF
 #define TKZ_DEV_FLAG(P, bit) (((P).ablate & (bit)) != 0)

@@ -1290,8 +1290,10 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     hook(L, K_ENCODE, 0);
     TKZ_LAUNCH(k_probe, cdiv(nsub, kThreads / 64), kThreads, L.stream, T, P);
     hook(L, K_ENCODE, 1);
-    hook(L, K_HEAVY, 0);
+    hook(L, K_MERGE_SHORT, 0);
     TKZ_LAUNCH(k_merge_short, cdiv(nsub, (kMsThreads / 64) * kGroup), kMsThreads, L.stream, T, P);
+    hook(L, K_MERGE_SHORT, 1);
+    hook(L, K_HEAVY, 0);
     // giant pieces start in sub-tiles k_probe has flagged: find them, merge them; then the pieces of 17..1024 bytes and the giants' token counts
     TKZ_LAUNCH(k_giant_find, grid_for(nsub), kThreads, L.stream, (const uint8_t*)P.heavy_flag, nsub, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap);
 #ifdef TKZ_HOSTEMU

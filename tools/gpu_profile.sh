@@ -19,7 +19,7 @@ done
 cd $REPO
 python tools/summarize_prof.py gpurun_out/prof_$TAG > gpurun_out/prof_$TAG/summary.txt 2>&1
 KIND=1; case "$EXTRA" in *"--kind 2"*) KIND=2;; *"--kind 3"*) KIND=3;; *"--kind 4"*) KIND=4;; esac
-python tools/make_traffic_json.py gpurun_out/prof_$TAG/summary.txt $DOCS $KIND k_probe gpurun_out/prof_$TAG/traffic.json > /dev/null 2>&1
+python tools/make_traffic_json.py gpurun_out/prof_$TAG/summary.txt $DOCS $KIND gpurun_out/prof_$TAG/traffic.json > /dev/null 2>&1
 cat gpurun_out/prof_$TAG/summary.txt
 # keep only the summaries small enough to merge back
 find gpurun_out/prof_$TAG -name "*.db" -delete
