@@ -65,6 +65,9 @@ int64_t tkz_vocab_size(const tkz_vocab* v);
 int32_t tkz_vocab_max_key_len(const tkz_vocab* v);
 /* Entries of the (id_left, id_right) -> rank table built for the merge loop (informational). */
 int64_t tkz_vocab_pair_table_entries(const tkz_vocab* v);
+/* Bytes of one device table image (informational): 0 SHORT, 1 MID, 2 LONG (slots + blob), 3 PAIR,
+ * 4 the direct-index tables (byte ids + byte-pair ranks); -1 = all of them.  0 for an unknown table. */
+int64_t tkz_vocab_table_bytes(const tkz_vocab* v, int32_t which);
 /* Encoder[key] on the host copy: rank of an exact byte string, or -1. */
 int32_t tkz_vocab_rank(const tkz_vocab* v, const uint8_t* key, int32_t len);
 

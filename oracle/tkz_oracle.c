@@ -182,7 +182,18 @@ static int b64decode(const uint8_t* s, int n, uint8_t* out, int cap) {
     }
     return o;
 }
-static int is_dotnet_ws_ascii(int c) { return c == ' ' || (c >= 9 && c <= 13) || c == 0x85 || c == 0xA0; }
+/* the file is read through a StreamReader (UTF-8): white space is decided on the decoded chars.  A lone byte 0x85 / 0xA0 decodes to
+ * U+FFFD (not white space); C2 85, C2 A0 and the other char.IsWhiteSpace code points are. */
+static int is_dotnet_ws_ascii(int c) { return c == ' ' || (c >= 9 && c <= 13); }
+static size_t dotnet_ws_at(const uint8_t* p, size_t n) {   /* bytes of the white-space char that starts at p, 0 if none */
+    if (n >= 1 && is_dotnet_ws_ascii(p[0])) return 1;
+    if (n >= 2 && p[0] == 0xC2 && (p[1] == 0x85 || p[1] == 0xA0)) return 2;
+    if (n >= 3 && p[0] == 0xE1 && p[1] == 0x9A && p[2] == 0x80) return 3;                                   /* U+1680 */
+    if (n >= 3 && p[0] == 0xE2 && p[1] == 0x80 && ((p[2] >= 0x80 && p[2] <= 0x8A) || p[2] == 0xA8 || p[2] == 0xA9 || p[2] == 0xAF)) return 3;
+    if (n >= 3 && p[0] == 0xE2 && p[1] == 0x81 && p[2] == 0x9F) return 3;                                   /* U+205F */
+    if (n >= 3 && p[0] == 0xE3 && p[1] == 0x80 && p[2] == 0x80) return 3;                                   /* U+3000 */
+    return 0;
+}
 
 static int cmp_i32(const void* a, const void* b) {
     int32_t x = *(const int32_t*)a, y = *(const int32_t*)b; return (x > y) - (x < y);
@@ -203,7 +214,7 @@ tkzo_vocab* tkzo_vocab_load(const uint8_t* file, size_t n, int* err) {
         if (pos < n) { if (file[pos] == '\r' && pos + 1 < n && file[pos + 1] == '\n') pos += 2; else ++pos; }
         /* string.IsNullOrWhiteSpace(line) -> continue  (:109-112) */
         int blank = 1;
-        for (size_t i = ls; i < le; ++i) if (!is_dotnet_ws_ascii(file[i])) { blank = 0; break; }
+        for (size_t i = ls; i < le;) { const size_t w = dotnet_ws_at(file + i, le - i); if (!w) { blank = 0; break; } i += w; }
         if (blank) continue;
         /* line.Split(' ') must give exactly two fields  (:114-118) */
         int nsp = 0; size_t sp = 0;

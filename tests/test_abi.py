@@ -43,6 +43,8 @@ def test_vocab_loader_host_side(lib, gpt2_tiktoken_bytes):
     v = N.Vocab(gpt2_tiktoken_bytes, lib)
     assert len(v) == 50256 and v.max_key_len == 128 and v.pair_table_entries == 108299
     assert v.rank(b"!") == 0 and v.rank(b" the") == 262 and v.rank(b"\xff\xfe") == -1
+    tb = v.table_bytes()                           # the whole table set is sized for one XCD's 4 MiB L2
+    assert tb["total"] == tb["short"] + tb["mid"] + tb["long"] + tb["pair"] + tb["direct"] and 1 << 20 < tb["total"] < 4 << 20
     with pytest.raises(N.DuplicateRankError):      # ArgumentException, TikTokenizer.cs:84-87
         N.Vocab(b"YQ== 0\nYg== 0\n", lib)
     with pytest.raises(N.FormatError):             # TikTokenizer.cs:114-118
@@ -53,6 +55,10 @@ def test_vocab_loader_host_side(lib, gpt2_tiktoken_bytes):
         N.Vocab(b"Y!== 1\n", lib)
     v2 = N.Vocab(b"\nYQ== 0\n\r\n  \nYg== 1\n", lib)     # blank lines skipped, TikTokenizer.cs:109-112
     assert len(v2) == 2 and v2.rank(b"b") == 1
+    # the reference reads through a UTF-8 StreamReader: a line of U+0085 / U+00A0 / U+3000 is blank, a lone byte 0x85 is U+FFFD
+    assert len(N.Vocab(b"YQ== 0\n\xc2\x85\xc2\xa0 \xe3\x80\x80\nYg== 1\n", lib)) == 2
+    with pytest.raises(N.FormatError):
+        N.Vocab(b"YQ== 0\n\x85\nYg== 1\n", lib)
 
 
 def test_pattern_from_regex(lib):

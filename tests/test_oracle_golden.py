@@ -50,6 +50,10 @@ def test_vocab_loader_errors(oracle_mod):
     assert e.value.code == O.E_FORMAT
     v = O.Vocab(b"\nYQ== 0\n\r\n  \nYg== 1\n")   # blank lines skipped (:109-112)
     assert len(v) == 2 and v.rank(b"a") == 0 and v.rank(b"b") == 1
+    assert len(O.Vocab(b"YQ== 0\n\xc2\x85\xc2\xa0 \xe3\x80\x80\nYg== 1\n")) == 2   # UTF-8 StreamReader: these chars are white space
+    with pytest.raises(O.OracleError) as e:
+        O.Vocab(b"YQ== 0\n\x85\nYg== 1\n")     # ... a lone byte 0x85 is U+FFFD, which is not
+    assert e.value.code == O.E_FORMAT
 
 
 def test_missing_single_byte_is_key_not_found(oracle_mod):

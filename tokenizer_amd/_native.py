@@ -74,6 +74,8 @@ class Library:
         L.tkz_vocab_max_key_len.argtypes = [vp]
         L.tkz_vocab_pair_table_entries.argtypes = [vp]
         L.tkz_vocab_pair_table_entries.restype = i64
+        L.tkz_vocab_table_bytes.argtypes = [vp, C.c_int32]
+        L.tkz_vocab_table_bytes.restype = i64
         L.tkz_vocab_rank.argtypes = [vp, vp, i32]
         L.tkz_pattern_from_regex.argtypes = [C.c_char_p, C.POINTER(i32)]
         L.tkz_encoder_create.argtypes = [vp, i32, i32, pv]
@@ -167,6 +169,13 @@ class Vocab:
     @property
     def pair_table_entries(self):
         return self.lib.L.tkz_vocab_pair_table_entries(self._h)
+
+    def table_bytes(self):
+        """Bytes of every device table image: {"short", "mid", "long", "pair", "direct", "total"}."""
+        f = self.lib.L.tkz_vocab_table_bytes
+        d = {k: int(f(self._h, i)) for i, k in enumerate(("short", "mid", "long", "pair", "direct"))}
+        d["total"] = int(f(self._h, -1))
+        return d
 
     def rank(self, key: bytes):
         buf = (C.c_uint8 * max(1, len(key))).from_buffer_copy(key or b"\0")

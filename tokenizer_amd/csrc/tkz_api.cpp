@@ -554,6 +554,15 @@ void tkz_vocab_destroy(tkz_vocab* v) { delete v; }
 int64_t tkz_vocab_size(const tkz_vocab* v) { return v ? (int64_t)v->v.keys.size() : 0; }
 int32_t tkz_vocab_max_key_len(const tkz_vocab* v) { return v ? v->v.max_key_len : 0; }
 int64_t tkz_vocab_pair_table_entries(const tkz_vocab* v) { return v ? v->v.pair_entries : 0; }
+int64_t tkz_vocab_table_bytes(const tkz_vocab* v, int32_t which) {
+    if (!v) return 0;
+    const tkz::Vocab& V = v->v;
+    const int64_t b[5] = {(int64_t)(V.short_slots.size() * sizeof(TkzShortSlot)), (int64_t)(V.mid_slots.size() * sizeof(TkzMidSlot)),
+                          (int64_t)(V.long_slots.size() * sizeof(TkzLongSlot) + V.long_blob.size()), (int64_t)(V.pair_slots.size() * sizeof(TkzPairSlot)),
+                          (int64_t)((V.byte_rank.size() + V.bytepair_rank.size()) * sizeof(int32_t))};
+    if (which == -1) return b[0] + b[1] + b[2] + b[3] + b[4];
+    return which >= 0 && which < 5 ? b[which] : 0;
+}
 int32_t tkz_vocab_rank(const tkz_vocab* v, const uint8_t* key, int32_t len) {
     if (!v || len < 0 || (!key && len)) return -1;
     int32_t r;

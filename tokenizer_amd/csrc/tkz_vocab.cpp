@@ -49,7 +49,18 @@ bool b64decode(const uint8_t* s, size_t n, std::string* out) {
     return true;
 }
 
-inline bool is_ws(int c) { return c == ' ' || (c >= 9 && c <= 13) || c == 0x85 || c == 0xA0; }
+// The reference reads the file through a StreamReader (UTF-8), so white space is a property of decoded chars: a lone byte 0x85 or
+// 0xA0 is U+FFFD (not white space), the sequences C2 85 / C2 A0 / ... are.  int.TryParse trims only the ASCII set.
+inline bool is_ws(int c) { return c == ' ' || (c >= 9 && c <= 13); }
+inline size_t ws_char_at(const uint8_t* p, size_t n) {      // bytes of the char.IsWhiteSpace char that starts at p, 0 if none
+    if (n >= 1 && is_ws(p[0])) return 1;
+    if (n >= 2 && p[0] == 0xC2 && (p[1] == 0x85 || p[1] == 0xA0)) return 2;
+    if (n >= 3 && p[0] == 0xE1 && p[1] == 0x9A && p[2] == 0x80) return 3;
+    if (n >= 3 && p[0] == 0xE2 && p[1] == 0x80 && ((p[2] >= 0x80 && p[2] <= 0x8A) || p[2] == 0xA8 || p[2] == 0xA9 || p[2] == 0xAF)) return 3;
+    if (n >= 3 && p[0] == 0xE2 && p[1] == 0x81 && p[2] == 0x9F) return 3;
+    if (n >= 3 && p[0] == 0xE3 && p[1] == 0x80 && p[2] == 0x80) return 3;
+    return 0;
+}
 
 const struct { uint16_t a, b; uint8_t c; } kRanges[] = {
 #include "unicode13_classes.inc"
@@ -97,7 +108,7 @@ int parse_tiktoken(const uint8_t* file, size_t n, Vocab* out, std::string* msg) 
         size_t le = pos;
         if (pos < n) pos += (file[pos] == '\r' && pos + 1 < n && file[pos + 1] == '\n') ? 2 : 1;
         bool blank = true;                                                    // IsNullOrWhiteSpace (:109)
-        for (size_t i = ls; i < le; ++i) if (!is_ws(file[i])) { blank = false; break; }
+        for (size_t i = ls; i < le;) { const size_t w = ws_char_at(file + i, le - i); if (!w) { blank = false; break; } i += w; }
         if (blank) continue;
         int nsp = 0; size_t sp = 0;                                           // Split(' ') -> 2 fields (:114-118)
         for (size_t i = ls; i < le; ++i) if (file[i] == ' ') { if (!nsp) sp = i; ++nsp; }
