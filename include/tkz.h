@@ -219,6 +219,9 @@ enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_PROBE = 2 /* k_probe alone */,
  * kernel since the last reset (arrays of TKZ_K_COUNT). */
 tkz_status tkz_encoder_set_profiling(tkz_encoder* e, int32_t enabled);
 tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, int32_t reset);
+/* o200k only, informational: of the 4 KiB blocks of the last batch, how many the ASCII block scanner handed on (blocks with multi-byte
+ * chars or a state it cannot carry), and how many of those the multi-byte block scanner handed on to the sequential matcher. */
+void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_scanner, int64_t* after_multibyte_scanner);
 /* Device bytes currently held by the encoder (tables + workspace). */
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e);
 const char* tkz_kernel_name(int32_t k);

@@ -156,3 +156,6 @@ hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess;
 }
+
+// development aid: which rule of the o200k multi-byte block scanner refused a block (tkz_pretok.h)
+extern "C" { long long tkz_o2_refusals[32] = {0}; }

@@ -137,6 +137,54 @@ def check_pretok(lib, O, vocab, pattern, sequential, seeds, kinds, doc_lens, n_d
                 pattern, sequential, kind, seed, explain_bitmap_diff(got, exp, docs, offs))
 
 
+# ---- o200k: alphabets that exercise every flow of the multi-byte block scanner (tkz_block_core_o200k): case transitions through
+# runs of Lo/Lm/M chars, marks after punctuation, swallowed '/' runs, contraction suffixes, supplementary-plane letters / digits /
+# symbols, ECMAScript white space
+O200K_ALPHAS = {
+    "cjk": list("\u4e2d\u6587\u65e5\u672c\u8a9e\u304b\u306a\u30ab\u30ca\ud55c\uae00abcXYZ  .,!'s\n"),
+    "case": list("aAbB\u4e2d\u02b0\u0301\u00e9 \u00c9's'S ."),
+    "mark": list("a\u0301\u0301!!/ \n\u4e2dA'sx"),
+    "emoji": ["\U0001F600", "\u200d", "\ufe0f", "\u2764", "a", "A", " ", "\u4e2d", "!", "\U0001D400", "\U00020000", "1", "\uff11"],
+    "slash": list("/\n!\u0301a A;*"),
+    "upper": list("AB\u4e2d\u0301. a"),
+    "all": list("aAzZ\u4e2d\u6587\u304b\u02b0\u0301\u0300\u00e9 \u00c9's'S'll'LL .,!/\n\r\t 12\uff13\u3000\u00a0\ufeff\u0085\u2028") +
+           ["\U0001F600", "\u200d", "\ufe0f", "\U0001D400", "\U00020000", "\U0001D7D8"],
+}
+
+
+def o200k_gen(rng, a, n):
+    out = []
+    while len(out) < n:
+        ch = rng.choice(a)
+        r = rng.random()
+        rep = 1 if r < 0.6 else (rng.choice([2, 3, 5, 8]) if r < 0.97 else rng.choice([20, 70, 130]))
+        if rng.random() < 0.5:
+            out.extend([ch] * rep)
+        else:
+            out.extend(rng.choice(a) for _ in range(rep))
+    return "".join(out[:n])
+
+
+def check_o200k_blocks(lib, O, vocab, kinds, seeds, doc_lens=(3000, 9000, 20000), min_handled=None):
+    """Block scanners of o200k vs the oracle's sequential matcher on documents long enough to hold whole 4 KiB blocks.
+    Returns (blocks, left over by the ASCII scanner, left over by the multi-byte scanner)."""
+    enc = N.Encoder(vocab, N.O200K)
+    tblk = ta = tb = 0
+    for kind in kinds:
+        for seed in seeds:
+            rng = random.Random(seed * 1000 + len(kind))
+            docs = [o200k_gen(rng, O200K_ALPHAS[kind], rng.choice(doc_lens)).encode("utf-8") for _ in range(rng.choice([1, 2, 5]))]
+            data, offs = pack(docs)
+            got = enc.pretokenize(data, offs)
+            exp = oracle_bitmap(O, N.O200K, docs)
+            assert np.array_equal(got, exp), "o200k kind=%s seed=%d: %s" % (kind, seed, explain_bitmap_diff(got, exp, docs, offs))
+            a, b = enc.pretok_leftovers()
+            ta += a
+            tb += b
+            tblk += (len(data) + 3967) // 3968
+    return tblk, ta, tb
+
+
 def check_vocab_keys(lib, O, vocab, ovocab, pattern=N.CL100K):
     """V1/K2: every vocabulary key, presented as one piece, must come back as exactly [rank]."""
     enc = N.Encoder(vocab, pattern)

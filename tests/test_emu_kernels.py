@@ -88,6 +88,19 @@ def test_pretok_long_runs(lib, vocab, oracle_mod, pattern):
     parity.check_pretok(lib, oracle_mod, vocab, pattern, 0, seeds=range(5), kinds=("runs",), doc_lens=[3000, 30000, 70000], n_docs_choices=(1, 3))
 
 
+def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod):
+    # CJK / kana / hangul / emoji / combining-mark text under o200k goes through the char-level block scanner, not the sequential matcher
+    blocks, after_ascii, after_mb = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["cjk", "case", "emoji", "upper", "all", "mark", "slash"], range(2))
+    assert after_ascii > 0 and after_mb < after_ascii // 2, (blocks, after_ascii, after_mb)
+    # the bench's mixed corpus: every block holds multi-byte chars, all but the ragged last one are done by the block scanner
+    docs = [N.corpus_doc_host(2, 0x5EED0001, d, 256, 768, lib=lib) for d in range(120)]
+    data, offs = parity.pack(docs)
+    enc = N.Encoder(vocab, N.O200K)
+    assert np.array_equal(enc.pretokenize(data, offs), parity.oracle_bitmap(oracle_mod, N.O200K, docs))
+    a, b = enc.pretok_leftovers()
+    assert a >= 10 and b <= 1, (a, b)
+
+
 @pytest.mark.parametrize("vname", ["gpt2", "synth100k", "synth200k"])
 def test_every_vocab_key(lib, vocabs, oracle_mod, vname):
     v, ov = vocabs(vname)

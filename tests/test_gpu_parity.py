@@ -92,6 +92,12 @@ def test_pretok_long_runs(lib, vocab, oracle_mod, pattern):
     parity.check_pretok(lib, oracle_mod, vocab, pattern, 0, seeds=range(12), kinds=("runs",), doc_lens=[3000, 30000, 70000, 300000], n_docs_choices=(1, 3, 9))
 
 
+def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod):
+    blocks, after_ascii, after_mb = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["cjk", "case", "emoji", "upper", "all", "mark", "slash"], range(12),
+                                                              doc_lens=(3000, 9000, 20000, 100000))
+    assert after_ascii > 0 and after_mb < after_ascii // 2, (blocks, after_ascii, after_mb)
+
+
 def test_golden_splits(lib, vocab):
     for rec in load_golden_json("splits.json"):
         enc = N.Encoder(vocab, rec["pattern"])

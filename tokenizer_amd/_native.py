@@ -74,6 +74,8 @@ class Library:
         L.tkz_vocab_max_key_len.argtypes = [vp]
         L.tkz_vocab_pair_table_entries.argtypes = [vp]
         L.tkz_vocab_pair_table_entries.restype = i64
+        L.tkz_encoder_pretok_leftovers.argtypes = [vp, pi64, pi64]
+        L.tkz_encoder_pretok_leftovers.restype = None
         L.tkz_vocab_table_bytes.argtypes = [vp, C.c_int32]
         L.tkz_vocab_table_bytes.restype = i64
         L.tkz_vocab_rank.argtypes = [vp, vp, i32]
@@ -208,6 +210,12 @@ class Encoder:
         n = np.zeros(len(K_NAMES), np.int64)
         self.lib.check(self.lib.L.tkz_encoder_kernel_ms(self._h, ms.ctypes.data, n.ctypes.data, 1 if reset else 0))
         return {K_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(len(K_NAMES))}
+
+    def pretok_leftovers(self):
+        """(blocks the o200k ASCII block scanner handed on, blocks the multi-byte block scanner handed on to the sequential matcher) of the last batch."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.lib.L.tkz_encoder_pretok_leftovers(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     @property
     def workspace_bytes(self):

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -64,14 +65,14 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-struct CounterBlock {          // mirrors the 64-byte device block
+struct CounterBlock {          // mirrors the device block
     int32_t err; int32_t pad[3];
     int64_t grand;
     unsigned long long pool_head;
     int64_t ndocstarts;
     unsigned long long heavy_count;
-    unsigned long long xcount;
     int64_t npieces;
+    unsigned long long xcount, xcount2;    // (adjacent: launch_pretok_rows) blocks the o200k ASCII scanner left over, blocks the multi-byte one left over as well
 };
 
 }  // namespace
@@ -137,6 +138,7 @@ struct tkz_encoder {
     TkzDecodeTable D{};
     std::vector<std::pair<int32_t, std::string>> dec_vocab, dec_special;   // host copies (id, bytes)
     int64_t bytes_allocated = 0;           // tables
+    std::atomic<int64_t> last_xcount{0}, last_xcount2{0};   // tkz_encoder_pretok_leftovers
 };
 
 namespace {
@@ -290,7 +292,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
             launch_pretok_seq(L, e->pattern, d_bytes, d_offs, n_docs, total, startbits, e->T.bmp_class, counters);
         } else {
-            HIP_TRY(ws->w_xq.ensure((size_t)(nwords / kRowsPerWave + 2) * 8, acc));
+            HIP_TRY(ws->w_xq.ensure((size_t)(nwords / kRowsPerWave + 4) * 16, acc));     // two queues (launch_pretok_rows)
             launch_pretok_rows(L, e->pattern, d_bytes, d_offs, n_docs, total, docbits, startbits, nwords, e->T.bmp_class, counters,
                                ws->w_xq.as<int64_t>(), reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, xcount)));
         }
@@ -359,6 +361,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                               h[8], (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[12] / h[8], h[13], (double)h[14] / h[8], (double)h[15] / h[8]);
         }
 #endif
+        e->last_xcount = (int64_t)ws->h_counters->xcount; e->last_xcount2 = (int64_t)ws->h_counters->xcount2;
         const int32_t err = ws->h_counters->err;
         if (err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the byte count");
         if (err & kErrUtf8) return fail(TKZ_E_INVALID_UTF8, "input is not well-formed UTF-8 (or a document boundary falls inside a character)");
@@ -918,6 +921,10 @@ tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, 
         if (launches) launches[k] = n;
     }
     return TKZ_OK;
+}
+void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_scanner, int64_t* after_multibyte_scanner) {
+    if (after_ascii_scanner) *after_ascii_scanner = e ? e->last_xcount.load() : 0;
+    if (after_multibyte_scanner) *after_multibyte_scanner = e ? e->last_xcount2.load() : 0;
 }
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) {
     if (!e) return 0;

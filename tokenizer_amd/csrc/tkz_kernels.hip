@@ -168,6 +168,47 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
     }
 }
 
+// o200k, second pass: the blocks k_pretok_rows<O200K> left over because they hold multi-byte chars, through the char-level block
+// evaluator (tkz_block_eval_o200k_mb).  A kernel of its own so that its registers stay out of the ASCII scanner's.  What it
+// refuses as well goes into the second queue, for k_pretok_seq_blocks.
+TKZ_KERNEL(64) void k_pretok_mb_blocks(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits, int64_t nrows,
+                                       const uint8_t* bmp, const int64_t* xq, const unsigned long long* xcount, int64_t* xq2, unsigned long long* xcount2) {
+    TKZ_SHARED uint4 s_blk[(65 * kBlockRowStride) / 16];
+    const int lane = simt::lane();
+    const int64_t nx = (int64_t)*xcount;
+    for (int64_t q = simt::bid(); q < nx; q += simt::nblocks()) {
+        const int64_t blk = xq[q];
+        const int64_t r0 = blk * kRowsPerWave, first = r0 - 1;
+        const bool inside = ((first + 64) << 6) <= total;
+        bool done = false;
+        uint64_t out = 0;
+        simt::sync();                                          // (the previous block's rows are no longer read)
+        if (inside) {
+            for (int c = lane; c < 256; c += 64) {
+                const int64_t pos = (first << 6) + 16 * (int64_t)c;
+                uint4 v; v.x = v.y = v.z = v.w = 0;
+                if (pos >= 0) v = tkz_load16(bytes + pos);
+                s_blk[((c >> 2) * kBlockRowStride + (c & 3) * 16) / 16] = v;
+            }
+            if (lane < kBlockRowStride / 16) {
+                uint4 z; z.x = z.y = z.z = z.w = 0;
+                const int64_t pos = (first + 64) << 6;
+                if (lane == 0 && pos + 16 <= total) z = tkz_load16(bytes + pos);
+                s_blk[(64 * kBlockRowStride) / 16 + lane] = z;
+            }
+        }
+        simt::sync();
+        if (inside) {
+            const int64_t row = first + lane;
+            const uint64_t ds = (row >= 0 && row < nrows) ? docbits[row] : 0;
+            TkzBlockCtx X; X.bytes = bytes; X.docbits = docbits; X.total = total; X.nrows = nrows; X.row0 = first;
+            done = tkz_block_eval_o200k_mb(reinterpret_cast<const uint8_t*>(s_blk), ds, X, bmp, &out);
+            if (done && lane >= 1 && lane <= kRowsPerWave && row < nrows) startbits[row] = out;
+        }
+        if (!done && lane == 0) xq2[simt::atomic_add64(xcount2, 1ull)] = blk;
+    }
+}
+
 // one document through the sequential matcher from match start p0; piece starts inside [b0, b1) are OR-ed into startbits
 TKZ_DEV void tkz_seq_emit(int pattern, const TkzDoc& doc, int64_t a, int64_t p0, int64_t b0, int64_t b1, uint64_t* startbits) {
     int64_t curw = -1; uint64_t acc = 0;
@@ -1275,8 +1316,13 @@ void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, co
         TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_CL100K>, grid, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters, xq, xcount);
     else {
         TKZ_LAUNCH(k_pretok_rows<TKZ_PAT_O200K>, grid, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, counters, xq, xcount);
+        // blocks with multi-byte chars: the char-level block evaluator; what that refuses as well: the sequential matcher
+        int64_t* xq2 = xq + grid + 1;
+        unsigned long long* xcount2 = xcount + 1;
+        TKZ_LAUNCH(k_pretok_mb_blocks, grid < 8192 ? grid : 8192, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, (const int64_t*)xq,
+                   (const unsigned long long*)xcount, xq2, xcount2);
         TKZ_LAUNCH(k_pretok_seq_blocks, grid_for(n_docs > grid ? n_docs : grid), kThreads, L.stream, d_bytes, d_offs, n_docs, total, startbits, nrows,
-                   pattern, bmp, (const int64_t*)xq, (const unsigned long long*)xcount, counters);
+                   pattern, bmp, (const int64_t*)xq2, (const unsigned long long*)xcount2, counters);
     }
     hook(L, K_PRETOK, 1);
 }

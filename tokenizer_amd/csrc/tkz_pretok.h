@@ -1095,4 +1095,306 @@ TKZ_DEV bool tkz_block_eval_o200k(const uint8_t* stage, uint64_t ds, const TkzBl
     *out = ((sL | T | sO | sW) & ~cover & ~glued) | contrEnd | ds;
     return true;
 }
+
+// =================================================================================================
+// (2c) o200k on rows WITH multi-byte chars (CJK, kana, hangul, emoji, combining marks ...).
+//
+// Char-level form of tkz_block_eval_o200k.  With \p{Lm}\p{Lo}\p{M} in BOTH word alternatives
+//     alt 1  [^\r\n\p{L}\p{N}]? A* B+ suffix?      A = [\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]
+//     alt 2  [^\r\n\p{L}\p{N}]? A+ B* suffix?      B = [\p{Ll}\p{Lm}\p{Lo}\p{M}]
+// a run of word chars (letters and marks) is cut by a two-state automaton.  Classes: U = Lu|Lt (A only), l = Ll (B only),
+// Y = Lm|Lo|M (both).  State S0 = inside A*, S1 = inside B+.  S0: U,Y stay, l -> S1.  S1: l,Y stay, U -> a new piece.  So
+//   (a) an U starts a piece when the nearest preceding non-Y char of its run is an l  -- a forward flow through runs of Y;
+//   (b) when the A run is NOT followed by an l, A* has to give chars back until B+ can match: the piece ends right after the
+//       LAST Y of the run and the U's behind it are a piece of their own (alt 2): an U whose predecessor is a Y in state S0
+//       starts a piece when only U's follow up to the end of the word run -- a backward flow through runs of U.
+// \p{M} is also in the class of ` ?[^\s\p{L}\p{N}]+[\r\n/]*` ("R4" below): a mark is part of such a piece when the char before
+// it is, of a word otherwise.  An O char (other, not a mark) opens an R4 piece when it follows a blank or is not followed by a
+// word char (then it would be the one-char prefix of the word), and every O / mark behind one that is in R4 is in R4: a
+// forward flow through runs of O|M.  The tail `[\r\n/]*` (ABS) follows an R4 char; a '/' swallowed by it is NOT an R4 char
+// for what follows, which the flow above ignores: a block where a swallowed '/' is followed by another O / mark is refused.
+// Everything else (digits, white space, contraction suffixes) is tkz_block_eval_o200k's algebra on n <= 64 chars.
+// Refused blocks (return false) are matched sequentially; that is the definition, so refusing is always safe.
+// =================================================================================================
+// forward flow over the lanes: every lane contributes f(x) = prop ? x : gen; returns the value flowing INTO this lane (lane 0: in0)
+TKZ_DEV uint32_t tkz_scan_flow(bool prop, uint32_t gen, uint32_t in0) {
+    const int lane = simt::lane();
+    int p = prop ? 1 : 0;
+    uint32_t val = prop ? 0u : gen;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int pl = simt::shfl(p, (lane - d) & 63);
+        const uint32_t vl = simt::shflu(val, (lane - d) & 63);
+        if (lane >= d && p) { val = vl; p = pl; }
+    }
+    const uint32_t outv = p ? in0 : val;
+    const uint32_t prev = simt::shflu(outv, (lane + 63) & 63);
+    return lane == 0 ? in0 : prev;
+}
+
+struct TkzO2Chars { uint64_t U, l, X, M, N, W, O, CR, SP, SL, AP, k2, k3, ds; int n; };   // one bit per CHAR of the lane's row (O excludes marks)
+
+// (development aid of the CPU-emulated build: which rule refused a block, counted in tkz_o2_refusals[])
+#ifdef TKZ_HOSTEMU
+extern "C" long long tkz_o2_refusals[32];
+inline bool tkz_o2_refuse(int why) { if (simt::lane() == 0) ++tkz_o2_refusals[why & 31]; return false; }
+#else
+TKZ_DEV bool tkz_o2_refuse(int) { return false; }
+#endif
+TKZ_DEV bool tkz_block_core_o200k(const TkzO2Chars& c, const TkzBlockCtx& X, uint64_t* start_out) {
+    const int lane = simt::lane();
+    const int n = c.n, top = n - 1;
+    const uint64_t all = tkz_lowmask(n);
+    const uint64_t U = c.U, l = c.l, Xl = c.X, M = c.M, N = c.N, W = c.W, O = c.O, CR = c.CR, SP = c.SP, SL = c.SL, AP = c.AP, ds = c.ds;
+    const uint64_t nds = ~ds;
+    const uint64_t Lw = U | l | Xl, Wd = Lw | M, Oc = O | M;
+    auto bit = [](uint64_t x, int i) -> uint32_t { return (uint32_t)((x >> i) & 1ull); };
+    // ---- exchange 1: class of the last char of the previous row, of the first char of the next row ----
+    const uint32_t up_bits = bit(U, top) | (bit(l, top) << 1) | (bit(Xl, top) << 2) | (bit(M, top) << 3) | (bit(N, top) << 4) | (bit(O, top) << 5) |
+                             (bit(SP, top) << 6) | (bit(W, top) << 7) | (bit(CR, top) << 8) | (bit(SL, top) << 9);
+    const uint64_t conn = W & nds;
+    const int lead_ws = tkz_ctz64(~conn);                      // (bit n of ~conn is set)
+    const uint32_t head = (CR & tkz_lowmask(lead_ws)) ? 1u : 0u;
+    const uint32_t dn_bits = bit(U, 0) | (bit(l, 0) << 1) | (bit(Xl, 0) << 2) | (bit(M, 0) << 3) | (bit(N, 0) << 4) | (bit(O, 0) << 5) | (bit(W, 0) << 6) |
+                             ((uint32_t)(ds & 3) << 7) | (head << 9) | (bit(SL, 0) << 10);
+    uint32_t pb = simt::shflu(up_bits, (lane + 63) & 63), nb = simt::shflu(dn_bits, (lane + 1) & 63);
+    if (lane == 0) pb = 0;
+    if (lane == 63) nb = 0;
+    const uint64_t dsn = (uint64_t)((nb >> 7) & 3);
+    const uint64_t KN = ((ds >> 1) | (dsn << top)) & all, KN2 = ((ds >> 2) | (dsn << (top - 1))) & all;
+    const uint64_t pSP = ((SP << 1) | ((pb >> 6) & 1)) & nds & all;
+    const uint64_t pW = ((W << 1) | ((pb >> 7) & 1)) & nds & all, pCR = ((CR << 1) | ((pb >> 8) & 1)) & nds & all;
+    const uint64_t pN = ((N << 1) | ((pb >> 4) & 1)) & nds & all;
+    const uint64_t nWd = ((Wd >> 1) | ((uint64_t)((nb & 15) ? 1 : 0) << top)) & ~KN & all;
+    // ---- R4: which O / mark chars belong to a ` ?[^\s\p{L}\p{N}]+` piece ----
+    const uint64_t gR4 = O & (pSP | ~nWd) & all;
+    const uint64_t PR = Oc & nds & all;
+    const bool propR = PR == all && gR4 == 0;
+    const uint32_t genR = bit(tkz_fill_up64(gR4, PR | gR4), top);
+    uint32_t cinR;
+    {
+        const uint64_t pm = simt::ballot(propR);
+        if (pm) {
+            if (pm & 1ull) {                                   // lane 0 is context: what flows out of it is unknown
+                const int lp = tkz_ctz64(~pm);
+                if (lp >= 2) return tkz_o2_refuse(1);
+                if (simt::ballot(lane == 1 && (PR & ~gR4 & 1ull))) return tkz_o2_refuse(2);
+            }
+            cinR = tkz_scan_flow(propR, genR, 0u);
+        } else {
+            cinR = simt::shflu(genR, (lane + 63) & 63);
+            if (lane == 0) cinR = 0;
+        }
+    }
+    const uint64_t T = tkz_fill_up64(gR4 | (cinR ? (PR & 1ull) : 0ull), PR | gR4);     // chars in R4
+    const uint64_t pR4 = ((T << 1) | cinR) & nds & all;
+    // ---- ABS: the tail `[\r\n/]*` of an R4 piece ----
+    const uint64_t Rabs = (CR | SL) & nds & all;
+    if (simt::ballot(Rabs == all)) return tkz_o2_refuse(3);               // a row of nothing but CR / LF / '/': the absorbed state would cross it
+    const uint64_t seeds = CR & pR4;
+    const uint64_t ABS0 = tkz_fill_up64(seeds & Rabs, Rabs);
+    // ---- the two states that can cross whole rows: digit phase, CR/LF further on in the white-space run (tkz_block_core) ----
+    const uint64_t Q = N & pN;
+    int carry_in;
+    uint32_t head_next = (nb >> 9) & 1;
+    {
+        const bool first_all = lane == 0 && N == all && ds == 0;
+        const bool propN = Q == all || first_all, propW = conn == all;
+        int gen = 0;
+        if (!propN && bit(N, top)) gen = (n - tkz_msb64(~Q & all)) % 3;
+        if (simt::ballot(propN)) {
+            int in0 = 0;
+            if (simt::ballot(first_all)) { in0 = tkz_digits_before(X); if (in0 < 0) return tkz_o2_refuse(4); }
+            carry_in = tkz_scan_phase(propN, propN ? n % 3 : gen, in0);
+        } else {
+            carry_in = simt::shfl(gen, (lane + 63) & 63);
+            if (lane == 0) carry_in = 0;
+        }
+        if (simt::ballot(propW)) {
+            uint32_t in64 = 0;
+            if (simt::ballot(lane == 63 && propW)) { const int a = tkz_crlf_ahead(X); if (a < 0) return tkz_o2_refuse(5); in64 = (uint32_t)a; }
+            head_next = tkz_scan_head(propW, propW ? ((CR & all) ? 1u : 0u) : head, in64);
+        }
+    }
+    // ---- contraction suffixes: an apostrophe right after the last char of a word piece, followed by a literal inside the document ----
+    const uint32_t pbLw = (pb & 7) ? 1u : 0u, pbMw = (((pb >> 3) & 1) && !cinR) ? 1u : 0u;
+    const uint64_t pLw = ((Lw << 1) | pbLw) & nds & all, pMw = (((M & ~T) << 1) | pbMw) & nds & all;
+    const uint64_t cand = AP & (pLw | pMw) & ~KN;
+    const uint64_t k2 = c.k2 & cand, k3 = c.k3 & cand & ~KN2;
+    auto resolve = [&](uint64_t blk_in, uint64_t* g2o, uint64_t* g3o) -> bool {
+        uint64_t g2 = k2, g3 = k3, blk = blk_in;
+        for (int it = 0; it < 6; ++it) {
+            g2 = k2 & ~blk; g3 = k3 & ~blk;
+            const uint64_t nblk = (g2 << 2) | (g3 << 3) | blk_in;
+            if (nblk == blk) { *g2o = g2; *g3o = g3; return true; }
+            blk = nblk;
+        }
+        *g2o = g2; *g3o = g3;
+        return false;
+    };
+    uint64_t g2, g3;
+    bool conv = resolve(0, &g2, &g3);
+    // ---- exchange 2: what flows into the next row (computed with no inflow: exact unless a run covers the row, refused above) ----
+    const uint64_t o1_0 = O & ~T & ~(g2 | g3) & ~ABS0 & all;
+    const uint32_t up2 = (uint32_t)((g2 >> (n - 2)) & 3) | ((uint32_t)((g3 >> (n - 3)) & 7) << 2) | (bit(o1_0, top) << 5) | (bit(ABS0, top) << 6);
+    uint32_t p2b = simt::shflu(up2, (lane + 63) & 63);
+    if (lane == 0) p2b = 0;
+    const uint64_t blk_in = (uint64_t)(p2b & 3) | (uint64_t)((p2b >> 2) & 7);
+    uint64_t h2, h3;
+    conv = resolve(blk_in, &h2, &h3) && conv;
+    if (simt::ballot(!conv || ((h2 >> (n - 2)) & 3) != ((g2 >> (n - 2)) & 3) || ((h3 >> (n - 3)) & 7) != ((g3 >> (n - 3)) & 7))) return tkz_o2_refuse(7);
+    g2 = h2; g3 = h3;
+    const uint64_t glued = g2 | g3;
+    const uint64_t contrEnd = ((g2 << 2) | (g3 << 3) | blk_in) & all;
+    const uint32_t c2p = p2b & 3, c3p = (p2b >> 2) & 7;
+    const uint64_t cover = ((g2 << 1) | (g3 << 1) | (g3 << 2) |
+                            (uint64_t)(((c2p >> 1) | (c3p >> 1) | (c3p >> 2)) & 1) | ((uint64_t)((c3p >> 2) & 1) << 1)) & all;
+    const uint32_t abs_in = (p2b >> 6) & 1;
+    const uint64_t ABS = abs_in ? tkz_fill_up64((seeds | (Rabs & 1ull)) & Rabs, Rabs) : ABS0;
+    const uint64_t pABS = ((ABS << 1) | (uint64_t)abs_in) & all;
+    {   // a swallowed '/' followed by an O / mark that is not a '/': the R4 flow above would run through it
+        const uint64_t nOcNS = (((Oc & ~SL) >> 1) | ((uint64_t)((((nb >> 3) & 1) | ((nb >> 5) & 1)) & (((nb >> 10) & 1) ^ 1)) << top)) & ~KN & all;
+        if (simt::ballot((SL & ABS & nOcNS) != 0)) return tkz_o2_refuse(8);
+    }
+    // ---- word runs: chars, run starts, the S1 flow (rule a) and the trailing-U flow (rule b) ----
+    const uint64_t rs = (ds | contrEnd) & all;
+    const uint64_t Up = U & ~cover, lp = l & ~cover, Yp = (Xl | (M & ~T)) & all, Wdp = Up | lp | Yp;
+    const uint64_t Yc = Yp & ~rs;                               // a Y char that continues its run
+    const uint64_t Rst = Yc | lp;
+    const bool propS = Yc == all;
+    const uint32_t genS = bit(tkz_fill_up64(lp, Rst), top);
+    uint32_t cinS;
+    {
+        const uint64_t pm = simt::ballot(propS);
+        if (pm) {
+            if (pm & 1ull) {                                   // lane 0's state is unknown: it matters to the first U behind the Y run that carries it
+                const int lp0 = tkz_ctz64(~pm);                // first row that is not all Y
+                const int leadY = tkz_ctz64(~Yc);              // (<= n)
+                const bool hit = lane == lp0 && leadY < n && bit(Up, leadY) && !bit(rs, leadY);
+                if (simt::ballot(hit)) return tkz_o2_refuse(9);
+            }
+            cinS = tkz_scan_flow(propS, genS, 0u);
+        } else {
+            cinS = simt::shflu(genS, (lane + 63) & 63);
+            if (lane == 0) cinS = 0;
+        }
+    }
+    const uint64_t st1 = tkz_fill_up64(lp | (cinS ? (Yc & 1ull) : 0ull), Rst);
+    const uint64_t p_st1 = ((st1 << 1) | cinS) & ~rs & all;
+    // backward: E(i) = U(i) & (the next char ends the word run | (the next char is an U of the same run & E(i+1)))
+    const uint64_t Uc = Up & ~(rs & ~1ull);                     // leading-run test: U chars with no run start behind position 0
+    const int leadU = tkz_ctz64(~Uc);
+    const bool propE = leadU >= n && !bit(rs, 0);               // nothing but upper-case letters of one run: the flow crosses the row
+    uint32_t e_head;                                            // E of the virtual char behind the previous row's last one
+    if (bit(rs, 0) || !bit(Wdp, 0)) e_head = 1;
+    else if (propE) e_head = 0;                                 // (placeholder: the lane scan below passes the inflow through)
+    else if (bit(Up, 0)) e_head = (!bit(Wdp, leadU) || bit(rs, leadU)) ? 1u : 0u;
+    else e_head = 0;
+    uint32_t et;
+    if (simt::ballot(propE)) {
+        if (simt::ballot(lane == 63 && propE)) return tkz_o2_refuse(10);   // lane 63 is context: what flows into it is unknown
+        et = tkz_scan_head(propE, propE ? 0u : e_head, 1u);
+    } else {
+        et = simt::shflu(e_head, (lane + 1) & 63);
+        if (lane == 63) et = 1;
+    }
+    const uint64_t below = tkz_lowmask(top);
+    const uint64_t stopm = ((~Wdp | rs) >> 1) & below, contm = ((Up & ~rs) >> 1) & below;
+    const uint64_t Sfull = (Up & stopm) | ((et || bit(KN, top)) ? (Up & (1ull << top)) : 0ull);
+    const uint64_t Rfull = (Up & contm) | Sfull;
+    const int rsh = 64 - n;
+    const uint64_t Erev = tkz_fill_up64(tkz_brev64(Sfull) >> rsh, tkz_brev64(Rfull) >> rsh);
+    const uint64_t E = (tkz_brev64(Erev) >> rsh) & all;
+    const uint32_t pbYp = (((pb >> 2) & 1) || (((pb >> 3) & 1) && !cinR)) ? 1u : 0u;
+    const uint64_t pYp = ((Yp << 1) | pbYp) & ~rs & all;
+    const uint32_t pbWdp = ((pb & 7) || (((pb >> 3) & 1) && !cinR)) ? 1u : 0u;
+    const uint64_t pWdp = ((Wdp << 1) | pbWdp) & ~rs & all;
+    // ---- piece starts ----
+    const uint64_t o1 = O & ~T & ~glued & ~ABS & all;
+    const uint64_t o1Prev = ((o1 << 1) | (uint64_t)((p2b >> 5) & 1)) & all;
+    const uint64_t pWSo = pW & ~pCR & ~pSP;
+    const uint64_t sWd = Wdp & ~pWdp & ~pSP & ~pWSo & ~o1Prev;
+    const uint64_t sa = Up & p_st1;
+    const uint64_t sb = Up & E & pYp & ~p_st1 & ~rs;
+    const uint64_t sO = O & ~ABS & ~pSP & ~pR4;
+    uint64_t S = N & ~pN;
+    if (Q & 1ull) {
+        const int d = (3 - carry_in) % 3, lead = tkz_ctz64(~Q);
+        if (d < lead) S |= 1ull << d;
+    }
+    const uint64_t Q3 = Q & (Q << 1) & (Q << 2);
+    uint64_t Tn = S | ((S << 3) & Q3);
+    const uint64_t Q6 = Q3 & (Q3 << 3);
+    Tn |= (Tn << 6) & Q6;
+    const uint64_t Q12 = Q6 & (Q6 << 6);
+    Tn |= (Tn << 12) & Q12;
+    const uint64_t Q24 = Q12 & (Q12 << 12);
+    Tn |= (Tn << 24) & Q24;
+    Tn |= (Tn << 48) & (Q24 & (Q24 << 24));
+    const uint64_t nReal = ((((~W) & all) >> 1) | ((uint64_t)((nb & 0x3F) ? 1 : 0) << top)) & ~KN & all;
+    const uint64_t Scr = CR | ((uint64_t)head_next << top);
+    const uint64_t Srev = tkz_brev64(Scr), Grev = tkz_brev64(conn) << 1;
+    const uint64_t Tcur = tkz_brev64(Srev | tkz_fill_up64((Srev << 1) & Grev, Grev));
+    const uint64_t sW = W & ~ABS & ((~pW | pABS) | (pCR & ~Tcur) | (~CR & nReal));
+    *start_out = ((((sWd | sa | sb | Tn | sO | sW) & ~cover & ~glued) | contrEnd | ds)) & all;
+    return true;
+}
+
+// Evaluates rows first_row .. first_row+63 (lane = row - first_row) staged at `stage` as tkz_block_eval does, for o200k, any UTF-8.
+TKZ_DEV bool tkz_block_eval_o200k_mb(const uint8_t* stage, uint64_t dsb, const TkzBlockCtx& X, const uint8_t* ucd, uint64_t* out) {
+    const int lane = simt::lane();
+    const TkzBlockMasks m = tkz_block_classify<true>(reinterpret_cast<const uint4*>(stage + lane * kBlockRowStride));
+    const uint64_t HI = m.HI, CONT = m.CONT, A = ~HI;
+    uint64_t U = m.UP & A, l = m.L & ~m.UP & A, Xl = 0, M = 0, N = m.N & A, W = m.W & A, O = ~(m.L | m.N | m.W) & A;
+    const uint64_t CR = m.CR & A, SP = m.SP & A, SL = m.SL & A, AP = m.AP & A;
+    int bad = 0;
+    uint64_t E = 0;                                        // where continuation bytes are expected, from the leads of my row
+    uint32_t spill = 0;                                    // ... and in the first three bytes of the next row
+    for (uint64_t t = HI & ~CONT; t; t &= t - 1) {         // every non-ASCII lead of my row: decode, class by code point
+        const int pos = tkz_ctz64(t);
+        uint32_t b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int q = pos + k; b[k] = stage[(lane + (q >> 6)) * kBlockRowStride + (q & 63)]; }
+        TkzChar ch = tkz_decode(b[0], b[1], b[2], b[3], ucd);
+        bad |= ch.bad;
+        tkz_char_to_code_point_semantics(ch, ucd);
+        const uint64_t bitp = 1ull << pos;
+        const uint8_t uc = ch.uc;
+        if (uc == UC_LU || uc == UC_LT) U |= bitp;
+        else if (uc == UC_LL) l |= bitp;
+        else if (uc == UC_LM || uc == UC_LO) Xl |= bitp;
+        else if (uc == UC_M) M |= bitp;
+        else if (uc == UC_N) N |= bitp;
+        else if (uc == UC_WS) W |= bitp;
+        else O |= bitp;
+        for (int k = 1; k < ch.len; ++k) { const int q = pos + k; if (q < 64) E |= 1ull << q; else spill |= 1u << (q - 64); }
+    }
+    uint32_t spill_in = simt::shflu(spill, (lane + 63) & 63);
+    if (lane == 0) { const int lc = (~CONT) ? tkz_ctz64(~CONT) : 64; spill_in = lc <= 3 ? (uint32_t)tkz_lowmask(lc) : 0u; }
+    E |= spill_in;
+    if (simt::ballot(bad != 0 || E != CONT || (dsb & CONT) != 0)) return tkz_o2_refuse(11);   // (reported by the sequential path)
+    // raw contraction candidates at BYTE positions: an apostrophe followed by a literal of the o200k list
+    uint64_t k2b = 0, k3b = 0;
+    for (uint64_t ap = AP; ap; ap &= ap - 1) {
+        const int pos = tkz_ctz64(ap);
+        const int p1 = pos + 1, p2 = pos + 2;
+        const uint32_t b1 = stage[(lane + (p1 >> 6)) * kBlockRowStride + (p1 & 63)];
+        const uint32_t b2 = stage[(lane + (p2 >> 6)) * kBlockRowStride + (p2 & 63)];
+        const int k = tkz_contraction_len_o200k(b1, b2);
+        if (k == 2) k2b |= 1ull << pos;
+        else if (k == 3) k3b |= 1ull << pos;
+    }
+    const uint64_t LEAD = ~CONT;
+    const TkzPext px = tkz_pext_prepare(LEAD);
+    TkzO2Chars c;
+    c.n = tkz_popc64(LEAD);
+    c.U = tkz_pext(U, LEAD, px); c.l = tkz_pext(l, LEAD, px); c.X = tkz_pext(Xl, LEAD, px); c.M = tkz_pext(M, LEAD, px);
+    c.N = tkz_pext(N, LEAD, px); c.W = tkz_pext(W, LEAD, px); c.O = tkz_pext(O, LEAD, px);
+    c.CR = tkz_pext(CR, LEAD, px); c.SP = tkz_pext(SP, LEAD, px); c.SL = tkz_pext(SL, LEAD, px); c.AP = tkz_pext(AP, LEAD, px);
+    c.k2 = tkz_pext(k2b, LEAD, px); c.k3 = tkz_pext(k3b, LEAD, px);
+    c.ds = tkz_pext(dsb, LEAD, px);
+    uint64_t start;
+    if (!tkz_block_core_o200k(c, X, &start)) return false;
+    *out = tkz_pdep(start, LEAD, px) | dsb;
+    return true;
+}
 #endif  // TKZ_NO_SIMT
