@@ -71,6 +71,11 @@ int64_t tkz_vocab_table_bytes(const tkz_vocab* v, int32_t which);
 /* Encoder[key] on the host copy: rank of an exact byte string, or -1. */
 int32_t tkz_vocab_rank(const tkz_vocab* v, const uint8_t* key, int32_t len);
 
+/* The Unicode class the split scanners assign to code points first .. first + n - 1 (0 other, 1 Lu, 2 Ll, 3 Lt, 4 Lm, 5 Lo, 6 M, 7 N,
+ * 8 white space: .NET's \s), from the table the device holds (Unicode 13.0, the data of the reference's net6.0 target).  Pattern 1 and
+ * cl100k look only code UNITS up (the entries below 0x10000); o200k looks code points up.  Informational: lets a host verify the table. */
+void tkz_unicode_classes(uint32_t first, int32_t n, uint8_t* out);
+
 /* Map one of the reference's regex strings (exact text) to a tkz_pattern; anything else is
  * TKZ_E_UNSUPPORTED.  Replaces `new Regex(pattern, RegexOptions.Compiled)` (TikTokenizer.cs:77). */
 tkz_status tkz_pattern_from_regex(const char* regex_utf8, int32_t* pattern_out);

@@ -256,6 +256,37 @@ def check_batch(lib, O, vocab, ovocab, pattern, seed, rounds, doc_lens, n_docs_c
             raise AssertionError("trailing mismatch")
 
 
+def check_dense_region(lib, O, vocab, ovocab, pattern=N.CL100K, seed=17):
+    """The packed region for the tokens of merged short pieces (1024 per group of four sub-tiles): groups that fill it exactly, overflow it
+    (the rest waits in tmp) and stay far below it, next to each other, with long misses in between."""
+    rng = random.Random(seed)
+    enc = N.Encoder(vocab, pattern)
+    oenc = O.Encoder(ovocab, pattern)
+    cons = "bcdfghjklmnpqrstvwxz"
+
+    def gibberish(n):                      # 2..9-letter words that no vocabulary holds: every piece is merged, ~1 token per 1.5 bytes
+        out = []
+        while sum(map(len, out)) < n:
+            out.append(" " + "".join(rng.choice(cons) for _ in range(rng.randint(2, 9))))
+        return "".join(out)[:n]
+
+    def english(n):
+        return ("the quick brown fox jumps over the lazy dog and runs away " * (n // 50 + 1))[:n]
+
+    docs = []
+    for it in range(6):
+        parts = []
+        for _ in range(rng.randint(2, 10)):
+            k = rng.random()
+            parts.append(gibberish(rng.choice([300, 1500, 4096, 6000])) if k < 0.5 else english(rng.choice([200, 3000, 5000])) if k < 0.85
+                         else " " + "".join(rng.choice(cons) for _ in range(rng.choice([17, 40, 200]))))
+        docs.append("".join(parts).encode("utf-8"))
+    data, offs = pack(docs)
+    ids, ooff = enc.encode_batch(data, offs)
+    exp, eoff = oracle_encode_docs(oenc, docs)
+    assert ooff.tolist() == eoff and ids.tolist() == exp
+
+
 def check_errors(lib, O, vocab):
     enc = N.Encoder(vocab, N.CL100K)
     import pytest

@@ -123,6 +123,13 @@ def test_pieces_vs_oracle_bpe(lib, vocabs, oracle_mod, vname):
                         lens=[1, 2, 3, 4, 5, 8, 12, 13, 15, 16, 17, 20, 31, 32, 33, 64, 100, 300, 400, 1000, 1023, 1024, 1025, 2048, 3000], counts=[1, 5, 300, 3000])
 
 
+@pytest.mark.parametrize("vname", ["gpt2", "synth100k"])
+def test_dense_token_region(lib, vocabs, oracle_mod, vname):
+    v, ov = vocabs(vname)
+    for seed in (17, 18):
+        parity.check_dense_region(lib, oracle_mod, v, ov, seed=seed)
+
+
 def test_mid_pieces_share_the_arena(lib, vocab, oracle_mod, oracle_gpt2):
     # sub-tiles full of 17..1024-byte misses: every pass of the heavy kernel ends on a full arena
     parity.check_pieces(lib, oracle_mod, vocab, oracle_gpt2, seed=11, rounds=12, lens=[17, 24, 33, 40, 48, 64, 90, 128, 200, 400, 1023, 1024], counts=[40, 400, 4000], p_listed=1.0)

@@ -72,3 +72,19 @@ def test_supplementary_classes_match_unicodedata(copy):
 def test_the_two_copies_are_identical():
     for name in ("unicode13_classes.inc", "unicode13_supp.inc"):
         assert open(os.path.join(COPIES["oracle"], name)).read() == open(os.path.join(COPIES["product"], name)).read()
+
+
+def test_device_table_image_matches_unicodedata():
+    """The table the product uploads (one byte per code point below 0x40000 + the ranges above), read back through the C ABI:
+    all 1,114,112 code points against unicodedata, so the folding of the ranges into the direct table is checked too."""
+    import ctypes as C
+
+    import numpy as np
+
+    from tokenizer_amd import _native as N
+    L = N.default_library().L
+    got = np.zeros(0x110000, np.uint8)
+    L.tkz_unicode_classes(0, 0x110000, got.ctypes.data_as(C.c_void_p))
+    exp = np.fromiter((expected_class(u) for u in range(0x110000)), np.uint8, 0x110000)
+    bad = np.nonzero(got != exp)[0]
+    assert len(bad) == 0, [(hex(int(u)), int(got[u]), int(exp[u])) for u in bad[:10]]

@@ -74,6 +74,8 @@ class Library:
         L.tkz_vocab_max_key_len.argtypes = [vp]
         L.tkz_vocab_pair_table_entries.argtypes = [vp]
         L.tkz_vocab_pair_table_entries.restype = i64
+        L.tkz_unicode_classes.argtypes = [C.c_uint32, C.c_int32, vp]
+        L.tkz_unicode_classes.restype = None
         L.tkz_encoder_pretok_leftovers.argtypes = [vp, pi64, pi64]
         L.tkz_encoder_pretok_leftovers.restype = None
         L.tkz_vocab_table_bytes.argtypes = [vp, C.c_int32]

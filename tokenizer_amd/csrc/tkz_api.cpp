@@ -88,7 +88,7 @@ struct tkz_vocab { tkz::Vocab v; };
 // memo, is locked: LRUCache.cs:61,99).
 struct Workspace {
     // kernel workspace
-    DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
+    DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_dense, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
     // staging for the host-buffer entry points (two sets: chunk k+1 is uploaded while chunk k is encoded and chunk k-1 downloaded)
     DevBuf s_bytes[2], s_offs[2], s_out[2], s_outoffs[2];
     // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
@@ -108,7 +108,7 @@ struct Workspace {
     double ms[tkz::K_COUNT] = {};
     int64_t launches[tkz::K_COUNT] = {};
     void release_all() {
-        DevBuf* bufs[] = {&w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
+        DevBuf* bufs[] = {&w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
                           &w_doctok, &w_dcount, &w_dbase, &w_counters, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
                           &s_outoffs[0], &s_outoffs[1], &u_units, &u_offs, &u_docbits, &u_grp, &u_tsum, &u_tbase, &u_bsum, &u_counters, &u_bytes, &u_boffs,
                           &d_grp, &d_tsum, &d_tbase, &d_bsum, &d_counters, &d_ids, &d_idoffs, &d_out, &d_outoffs, &p_boffs, &p_toffs, &p_docp};
@@ -257,6 +257,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
     HIP_TRY(ws->w_counters.ensure(sizeof(CounterBlock), acc));
     if (!d_bitmap_only) {
         HIP_TRY(ws->w_tmp.ensure((size_t)(total + 64) * 4, acc));
+        HIP_TRY(ws->w_dense.ensure((size_t)(ntiles / kMergeGroup + 1) * kDenseCap * 4, acc));
         HIP_TRY(ws->w_tcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_pcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_pbase.ensure((size_t)ntiles * 8, acc));
@@ -302,7 +303,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             EncodeParams P{};
             P.bytes = d_bytes; P.total = total; P.startbits = startbits; P.docbits = docbits; P.nwords = nwords;
             P.offs = d_offs; P.n_docs = n_docs;
-            P.tmp = ws->w_tmp.as<int32_t>(); P.tile_count = ws->w_tcount.as<int32_t>();
+            P.tmp = ws->w_tmp.as<int32_t>(); P.dense = ws->w_dense.as<int32_t>(); P.tile_count = ws->w_tcount.as<int32_t>();
             P.prank = ws->w_prank.as<int32_t>(); P.prank_cap = (int64_t)(ws->w_prank.cap / 4); P.pcount = ws->w_pcount.as<int32_t>(); P.pbase = ws->w_pbase.as<int64_t>();
             P.docord_base = ws->w_dbase.as<int64_t>(); P.doc_tok = ws->w_doctok.as<int32_t>(); P.counters = counters;
             P.giant_q = ws->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = ws->w_gcnt.as<int32_t>();
@@ -570,6 +571,11 @@ int32_t tkz_vocab_rank(const tkz_vocab* v, const uint8_t* key, int32_t len) {
     if (!v || len < 0 || (!key && len)) return -1;
     int32_t r;
     return v->v.lookup(std::string(reinterpret_cast<const char*>(key), (size_t)len), &r) ? r : -1;
+}
+
+void tkz_unicode_classes(uint32_t first, int32_t n, uint8_t* out) {
+    const uint8_t* ucd = tkz::bmp_class_table().data();
+    for (int32_t i = 0; out && i < n; ++i) out[i] = tkz_supp_class(ucd, first + (uint32_t)i);
 }
 
 tkz_status tkz_pattern_from_regex(const char* regex_utf8, int32_t* pattern_out) {

@@ -33,10 +33,11 @@ TKZ_HD uint8_t tkz_ascii_class(uint32_t c) {
 }
 
 // Decode the char whose LEAD byte is b0; b1..b3 are the following bytes (0 when past the end of the
-// document: 0 is never a continuation byte, so truncation shows up as malformed).
-TKZ_HD TkzChar tkz_decode(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, const uint8_t* bmp_class) {
+// document: 0 is never a continuation byte, so truncation shows up as malformed).  tkz_decode_raw leaves the class of a
+// non-ASCII char to the caller (uc = UC_OTHER), so that several table lookups can be in flight together.
+TKZ_HD TkzChar tkz_decode_raw(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3) {
     TkzChar c;
-    c.bad = 0; c.units = 1;
+    c.bad = 0; c.units = 1; c.uc = UC_OTHER;
     if (b0 < 0x80) { c.cp = b0; c.len = 1; c.uc = tkz_ascii_class(b0); return c; }
     const bool c1 = (b1 & 0xC0) == 0x80, c2 = (b2 & 0xC0) == 0x80, c3 = (b3 & 0xC0) == 0x80;
     if (b0 >= 0xC2 && b0 <= 0xDF && c1) {
@@ -47,13 +48,15 @@ TKZ_HD TkzChar tkz_decode(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, co
     } else if (b0 >= 0xF0 && b0 <= 0xF4 && c1 && c2 && c3) {
         c.cp = ((b0 & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F); c.len = 4;
         if (c.cp < 0x10000 || c.cp > 0x10FFFF) c.bad = 1;
-        c.units = 2; c.uc = UC_OTHER;
-        return c;
+        c.units = 2;
     } else {
-        c.cp = 0xFFFFFFFFu; c.len = 1; c.uc = UC_OTHER; c.bad = 1;
-        return c;
+        c.cp = 0xFFFFFFFFu; c.len = 1; c.bad = 1;
     }
-    c.uc = c.bad ? (uint8_t)UC_OTHER : bmp_class[c.cp];
+    return c;
+}
+TKZ_HD TkzChar tkz_decode(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, const uint8_t* bmp_class) {
+    TkzChar c = tkz_decode_raw(b0, b1, b2, b3);
+    if (b0 >= 0x80 && c.units == 1 && !c.bad) c.uc = bmp_class[c.cp];
     return c;
 }
 
@@ -64,13 +67,15 @@ TKZ_HD bool tkz_uc_is_letter(uint8_t uc) { return uc >= UC_LU && uc <= UC_LO; }
 // (tokenizer_ts/src/tikTokenizer.ts:100; the C# builder does not know the encoding, TokenizerBuilder.cs:109-181): one class test
 // per CHARACTER -- a supplementary-plane char has its own Unicode class, can be the optional one-char prefix and counts once
 // toward \p{N}{1,3} -- and \s is ECMAScript's WhiteSpace + LineTerminator: U+FEFF is white space, U+0085 is not.
-// The class table in HBM is bmp_class[65536] followed by {uint32 n, uint32 0, n x {first, last | class << 24}} for the code points
-// above the BMP (sorted; Unicode 13.0 like the BMP table).
+// The class table in HBM holds one byte per code point below TKZ_UCD_DIRECT (BMP + planes 1-3, Unicode 13.0: one gather per char),
+// followed by {uint32 n, n x {first, last | class << 24}} for the few assigned ranges above (plane 14's variation selectors).
+#define TKZ_UCD_DIRECT 0x40000u
 TKZ_HD uint8_t tkz_supp_class(const uint8_t* ucd, uint32_t cp) {
-    const uint32_t* t = reinterpret_cast<const uint32_t*>(ucd + 65536);
-    uint32_t lo = 0, hi = t[0];
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((t[3 + 2 * mid] & 0xFFFFFFu) < cp) lo = mid + 1; else hi = mid; }
-    return (lo < t[0] && t[2 + 2 * lo] <= cp) ? (uint8_t)(t[3 + 2 * lo] >> 24) : (uint8_t)UC_OTHER;
+    if (cp < TKZ_UCD_DIRECT) return ucd[cp];
+    const uint32_t* t = reinterpret_cast<const uint32_t*>(ucd + TKZ_UCD_DIRECT);
+    for (uint32_t i = 0; i < t[0]; ++i)
+        if (cp >= t[1 + 2 * i] && cp <= (t[2 + 2 * i] & 0xFFFFFFu)) return (uint8_t)(t[2 + 2 * i] >> 24);
+    return (uint8_t)UC_OTHER;
 }
 // what the o200k matcher sees: `units` becomes 1 for every well-formed char ("one class test per char")
 TKZ_HD void tkz_char_to_code_point_semantics(TkzChar& c, const uint8_t* ucd) {

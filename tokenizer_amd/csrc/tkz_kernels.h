@@ -12,6 +12,8 @@ constexpr int kThreads = 256;       // workgroup size of every kernel (4 wavefro
 constexpr int kSub = 1024;          // bytes of corpus per wavefront of k_probe / k_place (a "sub-tile")
 constexpr int kHalo = 64;           // bytes staged past the sub-tile (a short piece may straddle the edge)
 constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one per lane, 64 to a wavefront, by k_merge_short
+constexpr int kMergeGroup = 4;      // sub-tiles per wavefront of k_merge_short ("group")
+constexpr int kDenseCap = 1024;     // tokens of merged short pieces a group keeps packed (what does not fit waits in tmp, like the long pieces' tokens)
 constexpr int kArenaDwords = 3584;  // LDS arena of k_merge_long: the long misses of a batch get 2 dwords + 1 byte + 1 bit per byte out of it
 constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (256 + tkz_bpe_var_dwords(1024) <= kArenaDwords)
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
@@ -30,7 +32,8 @@ struct EncodeParams {
     const uint8_t* bytes; int64_t total;
     const uint64_t* startbits; const uint64_t* docbits; int64_t nwords;   // 1 bit / byte, nwords = total/64 + 1
     const int64_t* offs; int64_t n_docs;                                  // n_docs + 1 document offsets
-    int32_t* tmp;                 // [total + pad] tokens of a MISSED piece wait at the piece's own byte position (tokens <= bytes)
+    int32_t* tmp;                 // [total + pad] tokens of a LONG missed piece wait at the piece's own byte position (tokens <= bytes)
+    int32_t* dense;               // [groups x kDenseCap] tokens of the short missed pieces of a group of sub-tiles, packed in piece order
     int32_t* tile_count;          // tokens produced by each sub-tile
     int32_t* prank; int64_t prank_cap;   // one record per piece, in piece order (tkz_kernels.hip, "the encode stage")
     const int32_t* pcount;        // pieces that start in each sub-tile

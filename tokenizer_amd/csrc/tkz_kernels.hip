@@ -171,7 +171,7 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
 // o200k, second pass: the blocks k_pretok_rows<O200K> left over because they hold multi-byte chars, through the char-level block
 // evaluator (tkz_block_eval_o200k_mb).  A kernel of its own so that its registers stay out of the ASCII scanner's.  What it
 // refuses as well goes into the second queue, for k_pretok_seq_blocks.
-TKZ_KERNEL(64) void k_pretok_mb_blocks(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits, int64_t nrows,
+TKZ_KERNEL_OCC(64, 3) void k_pretok_mb_blocks(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits, int64_t nrows,
                                        const uint8_t* bmp, const int64_t* xq, const unsigned long long* xcount, int64_t* xq2, unsigned long long* xcount2) {
     TKZ_SHARED uint4 s_blk[(65 * kBlockRowStride) / 16];
     const int lane = simt::lane();
@@ -327,8 +327,12 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
 //   prank[p]   one 32-bit record per piece, in piece order (p = piece ordinal of the batch; sub-tile s owns [pbase[s], pbase[s+1])):
 //              hit : rank | MARK                                  (MARK: a document -- or, at piece granularity, a piece -- starts here)
 //              miss: MISS | MARK | (len-1) << 10 | relpos         (relpos: byte offset inside the 1 KiB sub-tile), GIANT if len > 1024;
-//                    after its merge: MISS | MARK | DONE | (count-1) << 10 | relpos, the tokens waiting in tmp[abs .. abs + count)
-//   tmp[b]     4 B per input byte, touched only under missed pieces: a piece's tokens fit inside its own byte span (tokens <= bytes)
+//                    after its merge: MISS | MARK | DONE | (count-1) << 10 | relpos, the tokens waiting in tmp[abs .. abs + count),
+//                    or ... | DENSE | (count-1) << 10 | offset, the tokens waiting in dense[group * kDenseCap + offset ..)
+//   dense[]    the tokens of the merged SHORT pieces of a group of 4 sub-tiles, packed in piece order (1024 per group; a miss costs
+//              ~4 tokens = one 16-byte store next to its neighbour's, not a 64-byte line of its own in k_merge_short and again in k_place)
+//   tmp[b]     4 B per input byte, touched only under LONG missed pieces (and what overflows dense[]): a piece's tokens fit inside
+//              its own byte span (tokens <= bytes)
 //
 //   k_probe        one wavefront per 1 KiB sub-tile, 32 wavefronts per CU (64 VGPRs, 3 KB LDS): piece enumeration from the bitmap,
 //                  SHORT / MID probes (four 16-byte gathers per piece, two batches of 64 pieces in flight), records stored coalesced
@@ -344,13 +348,10 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
 // busy, and a second, 3x slower kernel for every sub-tile that held one piece of 17+ bytes to merge -- half of all sub-tiles
 // on text with identifiers or long words.
 // -------------------------------------------------------------------------------------------------
-constexpr uint32_t kPrMiss = 1u << 31, kPrMark = 1u << 30, kPrDone = 1u << 29, kPrGiant = 1u << 28;
+constexpr uint32_t kPrMiss = 1u << 31, kPrMark = 1u << 30, kPrDone = 1u << 29, kPrGiant = 1u << 28, kPrDense = 1u << 27;
 constexpr uint32_t kPrRankMask = (1u << 28) - 1u;       // ranks are < 2^27 (TKZ_MAX_RANK)
 constexpr int kPrLenShift = 10;
 constexpr uint32_t kPrLenMask = 0x7FFu;                 // len - 1 / count - 1 (< 1024), in bits 10..20
-#ifndef TKZ_GROUP
-#define TKZ_GROUP 4
-#endif
 #ifndef TKZ_PROBE_U
 #define TKZ_PROBE_U 2
 #endif
@@ -360,7 +361,7 @@ constexpr uint32_t kPrLenMask = 0x7FFu;                 // len - 1 / count - 1 (
 #ifndef TKZ_PROBE_OCC
 #define TKZ_PROBE_OCC 8
 #endif
-constexpr int kGroup = TKZ_GROUP;                       // sub-tiles per wavefront of k_merge_short
+constexpr int kGroup = kMergeGroup;                     // sub-tiles per wavefront of k_merge_short
 constexpr int kMsThreads = TKZ_MS_THREADS;              // ... and the workgroup size of that kernel
 
 // exclusive prefix over the wave of a small non-negative value (< 2^BITS), and the wave total;
@@ -618,31 +619,39 @@ TKZ_KERNEL_OCC(kMsThreads, 3) void k_merge_short(TkzTables T, EncodeParams P) {
         pbs[si] = 0; nps[si] = 0; extra[si] = 0;
         if (sub < P.nsub) { pbs[si] = P.pbase[sub]; nps[si] = P.pcount[sub]; }
     }
-    int err = 0, nlist = 0;
-    // one batch: lane i < n merges the piece of list entry i (BytePairEncode, TikTokenizer.cs:268), its tokens go to tmp at the
-    // piece's own byte position, its record gets the token count
+    int err = 0, nlist = 0, dused = 0;
+    int32_t* const dense = P.dense + (sub0 / kGroup) * kDenseCap;
+    // one batch: lane i < n merges the piece of list entry i (BytePairEncode, TikTokenizer.cs:268); its tokens are packed behind those
+    // of the pieces before it in the group's dense region (in tmp, at the piece's own byte position, once that is full), its record
+    // gets the token count and where they are
     auto run_batch = [&](int n) {
         (void)simt::ballot(true);
-        int cnt1 = 0, si = 0;
+        int cnt = 0, si = 0, k = 0, rel = 0, e1 = 0;
+        uint32_t rec = 0, alive = 1;
         if (lane < n) {
-            const uint32_t rec = s_rec[lane], ix = s_idx[lane];
-            si = (int)(ix >> 10);
-            const int k = (int)(ix & 1023u), rel = (int)(rec & 1023u), len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
-            const int64_t abs = (sub0 + si) * kSub + rel;
-            uint32_t pw[NMAX / 4], alive = 1;
-            tkz_load_piece16(P.bytes, P.total, abs, pw);
-            int e1 = 0;
-            const int cnt = tkz_bpe_lane<NMAX>(T, pw, len, ids, pr, s_brank, &alive, &e1);
+            rec = s_rec[lane];
+            const uint32_t ix = s_idx[lane];
+            si = (int)(ix >> 10); k = (int)(ix & 1023u); rel = (int)(rec & 1023u);
+            const int len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+            uint32_t pw[NMAX / 4];
+            tkz_load_piece16(P.bytes, P.total, (sub0 + si) * kSub + rel, pw);
+            cnt = tkz_bpe_lane<NMAX>(T, pw, len, ids, pr, s_brank, &alive, &e1);
             err |= e1;
-            int32_t* dst = P.tmp + abs;
+        }
+        int btot;
+        const int doff = dused + tkz_wave_scan_sum(cnt, &btot);
+        if (lane < n) {
+            const bool packed = doff + cnt <= kDenseCap;
+            int32_t* dst = packed ? dense + doff : P.tmp + ((sub0 + si) * kSub + rel);
             int i = 0;
             for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)ids[tkz_ctz32(a)];
             int64_t pbk = pbs[0];
 #pragma unroll
             for (int q = 1; q < kGroup; ++q) if (si == q) pbk = pbs[q];
-            P.prank[pbk + k] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (uint32_t)rel;
-            cnt1 = cnt - 1;
+            P.prank[pbk + k] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (packed ? (kPrDense | (uint32_t)doff) : (uint32_t)rel);
         }
+        dused += btot;
+        const int cnt1 = lane < n ? cnt - 1 : 0;
 #pragma unroll
         for (int q = 0; q < kGroup; ++q) { int tot; (void)tkz_wave_scan<4>((lane < n && si == q) ? cnt1 : 0, &tot); extra[q] += tot; }
         (void)simt::ballot(true);
@@ -784,12 +793,13 @@ TKZ_KERNEL_OCC(64, 2) void k_merge_long(TkzTables T, EncodeParams P) {
 }
 
 // ids at their final position: count per record -> prefix -> stores; the token index (inside the sub-tile) of every marked piece
-TKZ_KERNEL_OCC(256, 8) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
+TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
     const int lane = simt::lane();
     const int64_t sub = simt::bid() * (kThreads / 64) + simt::wave();
     if (sub >= P.nsub) return;
     const int64_t pb = P.pbase[sub], tb = tile_base[sub], base = sub * kSub, ord0 = P.docord_base[sub];
     const int np = P.pcount[sub];
+    const int32_t* const dense = P.dense + (sub / kGroup) * kDenseCap;
     const bool has_giant = (P.heavy_flag[sub] & 2u) != 0;
     int gcnt = has_giant ? P.giant_cnt[sub] : 0;
     if (gcnt < 0) gcnt = 0;
@@ -807,7 +817,7 @@ TKZ_KERNEL_OCC(256, 8) void k_place(EncodeParams P, const int64_t* tile_base, in
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
           const uint32_t rec = r4[j];
-          const int32_t* src = P.tmp + base + (rec & 1023u);
+          const int32_t* src = (rec & kPrDense) ? dense + (rec & 1023u) : P.tmp + base + (rec & 1023u);
           const bool ld = (rec & kPrMiss) != 0;
           const int cnt = (rec & kPrGiant) ? gcnt : (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
 #pragma unroll
@@ -832,7 +842,7 @@ TKZ_KERNEL_OCC(256, 8) void k_place(EncodeParams P, const int64_t* tile_base, in
             else if (cnt <= 16) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (i < cnt && tb + pos + i < out_cap) dst[i] = t4[j][i];
-                const int32_t* src = P.tmp + base + (rec & 1023u);
+                const int32_t* src = (rec & kPrDense) ? dense + (rec & 1023u) : P.tmp + base + (rec & 1023u);
                 for (int i = 4; i < cnt; ++i) if (tb + pos + i < out_cap) dst[i] = src[i];
             }
         }

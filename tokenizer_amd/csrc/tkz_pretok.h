@@ -1152,7 +1152,7 @@ TKZ_DEV bool tkz_block_core_o200k(const TkzO2Chars& c, const TkzBlockCtx& X, uin
     const uint32_t up_bits = bit(U, top) | (bit(l, top) << 1) | (bit(Xl, top) << 2) | (bit(M, top) << 3) | (bit(N, top) << 4) | (bit(O, top) << 5) |
                              (bit(SP, top) << 6) | (bit(W, top) << 7) | (bit(CR, top) << 8) | (bit(SL, top) << 9);
     const uint64_t conn = W & nds;
-    const int lead_ws = tkz_ctz64(~conn);                      // (bit n of ~conn is set)
+    const int lead_ws = tkz_ctz64z(~conn);
     const uint32_t head = (CR & tkz_lowmask(lead_ws)) ? 1u : 0u;
     const uint32_t dn_bits = bit(U, 0) | (bit(l, 0) << 1) | (bit(Xl, 0) << 2) | (bit(M, 0) << 3) | (bit(N, 0) << 4) | (bit(O, 0) << 5) | (bit(W, 0) << 6) |
                              ((uint32_t)(ds & 3) << 7) | (head << 9) | (bit(SL, 0) << 10);
@@ -1175,7 +1175,7 @@ TKZ_DEV bool tkz_block_core_o200k(const TkzO2Chars& c, const TkzBlockCtx& X, uin
         const uint64_t pm = simt::ballot(propR);
         if (pm) {
             if (pm & 1ull) {                                   // lane 0 is context: what flows out of it is unknown
-                const int lp = tkz_ctz64(~pm);
+                const int lp = tkz_ctz64z(~pm);
                 if (lp >= 2) return tkz_o2_refuse(1);
                 if (simt::ballot(lane == 1 && (PR & ~gR4 & 1ull))) return tkz_o2_refuse(2);
             }
@@ -1267,8 +1267,8 @@ TKZ_DEV bool tkz_block_core_o200k(const TkzO2Chars& c, const TkzBlockCtx& X, uin
         const uint64_t pm = simt::ballot(propS);
         if (pm) {
             if (pm & 1ull) {                                   // lane 0's state is unknown: it matters to the first U behind the Y run that carries it
-                const int lp0 = tkz_ctz64(~pm);                // first row that is not all Y
-                const int leadY = tkz_ctz64(~Yc);              // (<= n)
+                const int lp0 = tkz_ctz64z(~pm);               // first row that is not all Y
+                const int leadY = tkz_ctz64z(~Yc);
                 const bool hit = lane == lp0 && leadY < n && bit(Up, leadY) && !bit(rs, leadY);
                 if (simt::ballot(hit)) return tkz_o2_refuse(9);
             }
@@ -1282,7 +1282,7 @@ TKZ_DEV bool tkz_block_core_o200k(const TkzO2Chars& c, const TkzBlockCtx& X, uin
     const uint64_t p_st1 = ((st1 << 1) | cinS) & ~rs & all;
     // backward: E(i) = U(i) & (the next char ends the word run | (the next char is an U of the same run & E(i+1)))
     const uint64_t Uc = Up & ~(rs & ~1ull);                     // leading-run test: U chars with no run start behind position 0
-    const int leadU = tkz_ctz64(~Uc);
+    const int leadU = tkz_ctz64z(~Uc);
     const bool propE = leadU >= n && !bit(rs, 0);               // nothing but upper-case letters of one run: the flow crosses the row
     uint32_t e_head;                                            // E of the virtual char behind the previous row's last one
     if (bit(rs, 0) || !bit(Wdp, 0)) e_head = 1;
@@ -1318,7 +1318,7 @@ TKZ_DEV bool tkz_block_core_o200k(const TkzO2Chars& c, const TkzBlockCtx& X, uin
     const uint64_t sO = O & ~ABS & ~pSP & ~pR4;
     uint64_t S = N & ~pN;
     if (Q & 1ull) {
-        const int d = (3 - carry_in) % 3, lead = tkz_ctz64(~Q);
+        const int d = (3 - carry_in) % 3, lead = tkz_ctz64z(~Q);
         if (d < lead) S |= 1ull << d;
     }
     const uint64_t Q3 = Q & (Q << 1) & (Q << 2);
@@ -1349,24 +1349,47 @@ TKZ_DEV bool tkz_block_eval_o200k_mb(const uint8_t* stage, uint64_t dsb, const T
     int bad = 0;
     uint64_t E = 0;                                        // where continuation bytes are expected, from the leads of my row
     uint32_t spill = 0;                                    // ... and in the first three bytes of the next row
-    for (uint64_t t = HI & ~CONT; t; t &= t - 1) {         // every non-ASCII lead of my row: decode, class by code point
-        const int pos = tkz_ctz64(t);
-        uint32_t b[4];
+    // every non-ASCII lead of my row: decode, class by code point from the table -- four chars per step, their gathers in flight
+    // together (a row of CJK text has ~21 leads: the loop is a chain of table round trips otherwise)
+    const uint32_t* srow = reinterpret_cast<const uint32_t*>(stage);
+    for (uint64_t t = HI & ~CONT; t;) {
+        int pos[4];
+        uint32_t cp[4], cls[4];
+        int len[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int q = pos + k; b[k] = stage[(lane + (q >> 6)) * kBlockRowStride + (q & 63)]; }
-        TkzChar ch = tkz_decode(b[0], b[1], b[2], b[3], ucd);
-        bad |= ch.bad;
-        tkz_char_to_code_point_semantics(ch, ucd);
-        const uint64_t bitp = 1ull << pos;
-        const uint8_t uc = ch.uc;
-        if (uc == UC_LU || uc == UC_LT) U |= bitp;
-        else if (uc == UC_LL) l |= bitp;
-        else if (uc == UC_LM || uc == UC_LO) Xl |= bitp;
-        else if (uc == UC_M) M |= bitp;
-        else if (uc == UC_N) N |= bitp;
-        else if (uc == UC_WS) W |= bitp;
-        else O |= bitp;
-        for (int k = 1; k < ch.len; ++k) { const int q = pos + k; if (q < 64) E |= 1ull << q; else spill |= 1u << (q - 64); }
+        for (int j = 0; j < 4; ++j) {
+            pos[j] = -1; cp[j] = 0; len[j] = 1;
+            if (t) {
+                pos[j] = tkz_ctz64(t);
+                t &= t - 1;
+                // the four bytes at `pos` (they may run into the next row): two aligned dwords of the staged block
+                const int q = pos[j], r = lane + (q >> 6), o = q & 63;
+                const int w0 = (r * kBlockRowStride + (o & ~3)) >> 2;
+                const int q4 = q + 4 - (q & 3), r1 = lane + (q4 >> 6), o1 = q4 & 63;
+                const int w1 = (r1 * kBlockRowStride + o1) >> 2;
+                const uint32_t x = (uint32_t)((((uint64_t)srow[w1] << 32) | srow[w0]) >> (8 * (o & 3)));
+                const TkzChar ch = tkz_decode_raw(x & 0xFFu, (x >> 8) & 0xFFu, (x >> 16) & 0xFFu, x >> 24);
+                bad |= ch.bad;
+                cp[j] = ch.bad ? 0u : ch.cp; len[j] = ch.len;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cls[j] = cp[j] < TKZ_UCD_DIRECT ? (uint32_t)ucd[cp[j]] : (uint32_t)tkz_supp_class(ucd, cp[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (pos[j] < 0) continue;
+            uint32_t uc = cls[j];
+            if (cp[j] == 0xFEFFu) uc = UC_WS; else if (cp[j] == 0x85u) uc = UC_OTHER;      // ECMAScript \s (tkz_char_to_code_point_semantics)
+            const uint64_t bitp = 1ull << pos[j];
+            if (uc == UC_LU || uc == UC_LT) U |= bitp;
+            else if (uc == UC_LL) l |= bitp;
+            else if (uc == UC_LM || uc == UC_LO) Xl |= bitp;
+            else if (uc == UC_M) M |= bitp;
+            else if (uc == UC_N) N |= bitp;
+            else if (uc == UC_WS) W |= bitp;
+            else O |= bitp;
+            for (int k = 1; k < len[j]; ++k) { const int q = pos[j] + k; if (q < 64) E |= 1ull << q; else spill |= 1u << (q - 64); }
+        }
     }
     uint32_t spill_in = simt::shflu(spill, (lane + 63) & 63);
     if (lane == 0) { const int lc = (~CONT) ? tkz_ctz64(~CONT) : 64; spill_in = lc <= 3 ? (uint32_t)tkz_lowmask(lc) : 0u; }

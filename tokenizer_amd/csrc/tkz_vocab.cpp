@@ -4,6 +4,7 @@
 // (Tokenizer_C#/TokenizerLib/TikTokenizer.cs:99-139, :74-91): same file format, same failure modes,
 // reported as status codes instead of exceptions.
 #include "tkz_vocab.h"
+#include "tkz_classes.h"
 
 #include <algorithm>
 #include <climits>
@@ -80,17 +81,23 @@ const struct { uint32_t a, b; uint8_t c; } kSuppRanges[] = {
 #include "unicode13_supp.inc"
 };
 
-// bmp_class[65536], then the supplementary-plane ranges the o200k (code-point) matcher searches: {n, 0, n x {first, last | class << 24}}
+// Class of every code point below 0x40000 (the BMP and planes 1-3: everything Unicode 13.0 assigns apart from the two ranges of plane 14),
+// one byte each, then {uint32 n, n x {first, last | class << 24}} for the ranges above (tkz_supp_class searches those few linearly).
+// The scanners of pattern 1 / cl100k only index the first 65,536 entries (UTF-16 code units); o200k matches by code point.
 const std::vector<uint8_t>& bmp_class_table() {
     static const std::vector<uint8_t> table = [] {
-        const size_t ns = sizeof kSuppRanges / sizeof kSuppRanges[0];
-        std::vector<uint8_t> t(65536 + 8 + 8 * ns, UC_OTHER);
+        std::vector<uint8_t> t(TKZ_UCD_DIRECT, UC_OTHER);
         for (const auto& r : kRanges)
             for (unsigned u = r.a; u <= r.b; ++u) t[u] = r.c;
-        std::vector<uint32_t> w;
-        w.push_back(uint32_t(ns)); w.push_back(0);
-        for (const auto& r : kSuppRanges) { w.push_back(r.a); w.push_back(r.b | (uint32_t(r.c) << 24)); }
-        memcpy(t.data() + 65536, w.data(), w.size() * 4);
+        std::vector<uint32_t> hi;
+        for (const auto& r : kSuppRanges) {
+            if (r.b < TKZ_UCD_DIRECT) { for (uint32_t u = r.a; u <= r.b; ++u) t[u] = r.c; }
+            else { hi.push_back(r.a); hi.push_back(r.b | (uint32_t(r.c) << 24)); }     // (no range straddles the limit: planes 4-13 are unassigned)
+        }
+        const uint32_t n = uint32_t(hi.size() / 2);
+        hi.insert(hi.begin(), n);
+        t.resize(TKZ_UCD_DIRECT + hi.size() * 4);
+        memcpy(t.data() + TKZ_UCD_DIRECT, hi.data(), hi.size() * 4);
         return t;
     }();
     return table;
