@@ -25,19 +25,20 @@
 enum : int32_t { kErrUtf8 = 1, kErrKeyNotFound = 2, kErrOffsets = 4, kErrPool = 8, kErrTooLong = 16, kErrCapacity = 32 };
 
 
-// Per-lane scratch of tkz_bpe_lane<NMAX>: NMAX ids + NMAX pair keys, each array 16-byte aligned so that the
-// min scan is NMAX/4 16-byte LDS reads.  The lane stride (in dwords) is chosen so that those reads are
-// bank-conflict free: stride/4 odd puts the 16 lanes of a b128 read group on 16 distinct 4-bank slots.
+// Per-lane scratch of tkz_bpe_lane<NMAX>: NMAX pair keys, 16-byte aligned so that the min scan is NMAX/4 16-byte LDS reads -- the
+// lane stride kStride (in dwords) is chosen so that those reads are bank-conflict free: stride/4 odd puts the 16 lanes of a b128
+// read group on 16 distinct 4-bank slots -- and NMAX ids, read and written one dword at a time, at the odd lane stride kIdStride
+// (every dword of LDS the merge state does not take is occupancy: k_merge_short is a chain of dependent gathers).
 template <int NMAX> struct TkzBpeGeom;
-template <> struct TkzBpeGeom<16> { static constexpr int kStride = 20, kShift = 4; };
-template <> struct TkzBpeGeom<32> { static constexpr int kStride = 36, kShift = 5; };
+template <> struct TkzBpeGeom<16> { static constexpr int kStride = 20, kIdStride = 17, kShift = 4; };
+template <> struct TkzBpeGeom<32> { static constexpr int kStride = 36, kIdStride = 33, kShift = 5; };
 constexpr int kBpeLaneStride = TkzBpeGeom<16>::kStride;
 
 TKZ_HD uint32_t tkz_min3u(uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; }
 TKZ_HD uint32_t tkz_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u); }
 
 // One LANE merges one piece of n bytes, 1 <= n <= NMAX (16 or 32), given as little-endian dwords w[0 .. NMAX/4)
-// (bytes past n are ignored).  ids/pr: this lane's NMAX-entry arrays (16-byte aligned).  brank: the 256-entry
+// (bytes past n are ignored).  ids/pr: this lane's NMAX-entry arrays (pr 16-byte aligned).  brank: the 256-entry
 // single-byte id table.  Returns the number of tokens; *alive_out has one bit per surviving part (token k is ids[k]).
 // Written for memory-level parallelism: all first-level gathers are issued together (unconditionally: a load inside
 // a lane-divergent branch is waited for inside that branch), and each merge costs ONE round trip to the pair table
@@ -46,7 +47,6 @@ template <int NMAX>
 TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* ids, uint32_t* pr, const int32_t* brank,
                         uint32_t* alive_out, int* err) {
     constexpr int SH = TkzBpeGeom<NMAX>::kShift;
-    uint4* ids4 = reinterpret_cast<uint4*>(ids);
     uint4* pr4 = reinterpret_cast<uint4*>(pr);
     // first-level state, 16 bytes at a time (keeps the register footprint of the 32-byte variant that of the 16-byte one)
 #pragma unroll 1
@@ -69,11 +69,12 @@ TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* 
             prv[k] = (g + 1 < n && r2[k] != TKZ_RANK_NONE) ? (((uint32_t)r2[k] << SH) | (uint32_t)g) : TKZ_NOKEY;
         }
 #pragma unroll
+        for (int k = 0; k < 16; ++k) ids[16 * c + k] = idv[k];
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
-            uint4 a, b;
-            a.x = idv[4 * q]; a.y = idv[4 * q + 1]; a.z = idv[4 * q + 2]; a.w = idv[4 * q + 3];
+            uint4 b;
             b.x = prv[4 * q]; b.y = prv[4 * q + 1]; b.z = prv[4 * q + 2]; b.w = prv[4 * q + 3];
-            ids4[4 * c + q] = a; pr4[4 * c + q] = b;
+            pr4[4 * c + q] = b;
         }
     }
     uint32_t alive = tkz_lowmask32(n);

@@ -152,6 +152,7 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
         } else done = tkz_block_eval<PATTERN>(reinterpret_cast<const uint8_t*>(s_blk), ds, bmp, &out);
         if (done) {
             if (lane >= 1 && lane <= kRowsPerWave && row < nrows) startbits[row] = out;
+            if (PATTERN == TKZ_PAT_O200K && lane == 0) reinterpret_cast<uint8_t*>(xq)[simt::bid()] = 0;
             return;
         }
     }
@@ -159,8 +160,9 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
     if constexpr (PATTERN == TKZ_PAT_O200K) {
         // no row-sequential scanner for o200k: the block's rows start as the document-start bits and the block goes to
         // k_pretok_seq_blocks (sequential matcher from the nearest guaranteed match start)
+        // (a flag per block, not a queue: one queue counter serialises a quarter of a million atomics per GB of non-ASCII text)
         for (int64_t r = r0 + lane; r < r1; r += 64) startbits[r] = docbits[r];
-        if (lane == 0) xq[simt::atomic_add64(xcount, 1ull)] = simt::bid();
+        if (lane == 0) reinterpret_cast<uint8_t*>(xq)[simt::bid()] = 1;
     } else {
         TkzSrc S;
         S.bytes = bytes; S.total = total; S.stage = nullptr; S.lo = 0; S.hi = 0;
@@ -172,12 +174,13 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
 // evaluator (tkz_block_eval_o200k_mb).  A kernel of its own so that its registers stay out of the ASCII scanner's.  What it
 // refuses as well goes into the second queue, for k_pretok_seq_blocks.
 TKZ_KERNEL_OCC(64, 3) void k_pretok_mb_blocks(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits, int64_t nrows,
-                                       const uint8_t* bmp, const int64_t* xq, const unsigned long long* xcount, int64_t* xq2, unsigned long long* xcount2) {
+                                       const uint8_t* bmp, const uint8_t* xflag, int64_t nblk, unsigned long long* xcount, int64_t* xq2, unsigned long long* xcount2) {
     TKZ_SHARED uint4 s_blk[(65 * kBlockRowStride) / 16];
     const int lane = simt::lane();
-    const int64_t nx = (int64_t)*xcount;
-    for (int64_t q = simt::bid(); q < nx; q += simt::nblocks()) {
-        const int64_t blk = xq[q];
+    unsigned long long mine = 0;
+    for (int64_t blk = simt::bid(); blk < nblk; blk += simt::nblocks()) {
+        if (xflag[blk] != 1) continue;                         // (one wavefront per workgroup: the branch is uniform)
+        ++mine;
         const int64_t r0 = blk * kRowsPerWave, first = r0 - 1;
         const bool inside = ((first + 64) << 6) <= total;
         bool done = false;
@@ -207,6 +210,7 @@ TKZ_KERNEL_OCC(64, 3) void k_pretok_mb_blocks(const uint8_t* bytes, int64_t tota
         }
         if (!done && lane == 0) xq2[simt::atomic_add64(xcount2, 1ull)] = blk;
     }
+    if (mine && lane == 0) simt::atomic_add64(xcount, mine);    // (statistics: tkz_encoder_pretok_leftovers)
 }
 
 // one document through the sequential matcher from match start p0; piece starts inside [b0, b1) are OR-ed into startbits
@@ -596,29 +600,28 @@ TKZ_DEV void tkz_load_piece16(const uint8_t* bytes, int64_t total, int64_t abs, 
     for (int i = 0; i < 4; ++i) pw[i] = (uint32_t)((((uint64_t)w[i + 1] << 32) | w[i]) >> sh);
 }
 
-TKZ_KERNEL_OCC(kMsThreads, 3) void k_merge_short(TkzTables T, EncodeParams P) {
-    constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride;
-    TKZ_SHARED uint4 s_scr_all[kMsThreads / 64][(2 * STRIDE * 64) / 4];   // per lane ids[16] | pr[16] at a conflict-free stride
+// (LDS: 4 x 9.25 KB of merge state + 2.5 KB = 39.5 KB per workgroup, and 128 VGPRs: four workgroups = 16 wavefronts per CU)
+TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
+    constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride, IDSTRIDE = TkzBpeGeom<NMAX>::kIdStride;
+    TKZ_SHARED uint4 s_pr_all[kMsThreads / 64][(STRIDE * 64) / 4];        // per lane pr[16] at a conflict-free stride for 16-byte reads
+    TKZ_SHARED uint32_t s_ids_all[kMsThreads / 64][IDSTRIDE * 64];        // per lane ids[16]
     TKZ_SHARED uint32_t s_rec_all[kMsThreads / 64][64];                   // the batch: record, and (sub-tile of the group) << 10 | piece index
-    TKZ_SHARED uint32_t s_idx_all[kMsThreads / 64][64];
+    TKZ_SHARED uint16_t s_idx_all[kMsThreads / 64][64];
     TKZ_SHARED int32_t s_brank[256];                                     // id of every single byte: in LDS, not 16 gathers per piece
     const int lane = simt::lane(), wv = simt::wave();
     for (int i = simt::tid(); i < 256; i += simt::nthreads()) s_brank[i] = T.byte_rank[i];
     simt::sync();
     const int64_t sub0 = (simt::bid() * (kMsThreads / 64) + wv) * kGroup;
     if (sub0 >= P.nsub) return;
-    uint32_t* s_scr = reinterpret_cast<uint32_t*>(s_scr_all[wv]);
     uint32_t* s_rec = s_rec_all[wv];
-    uint32_t* s_idx = s_idx_all[wv];
-    uint32_t* ids = &s_scr[lane * STRIDE];
-    uint32_t* pr = &s_scr[STRIDE * 64 + lane * STRIDE];
-    int64_t pbs[kGroup]; int nps[kGroup]; int extra[kGroup];
-#pragma unroll
-    for (int si = 0; si < kGroup; ++si) {
-        const int64_t sub = sub0 + si;
-        pbs[si] = 0; nps[si] = 0; extra[si] = 0;
-        if (sub < P.nsub) { pbs[si] = P.pbase[sub]; nps[si] = P.pcount[sub]; }
-    }
+    uint16_t* s_idx = s_idx_all[wv];
+    uint32_t* ids = &s_ids_all[wv][lane * IDSTRIDE];
+    uint32_t* pr = reinterpret_cast<uint32_t*>(s_pr_all[wv]) + lane * STRIDE;
+    // lane q < kGroup keeps what belongs to sub-tile q of the group: where its records start, how many there are, tokens added by merges
+    static_assert(kGroup <= 64, "one lane per sub-tile of the group");
+    int64_t my_pb = 0; int my_np = 0, my_extra = 0;
+    if (lane < kGroup && sub0 + lane < P.nsub) { my_pb = P.pbase[sub0 + lane]; my_np = P.pcount[sub0 + lane]; }
+    auto pb_of = [&](int q) -> int64_t { return ((int64_t)simt::shfl((int)(my_pb >> 32), q) << 32) | (uint32_t)simt::shfl((int)my_pb, q); };
     int err = 0, nlist = 0, dused = 0;
     int32_t* const dense = P.dense + (sub0 / kGroup) * kDenseCap;
     // one batch: lane i < n merges the piece of list entry i (BytePairEncode, TikTokenizer.cs:268); its tokens are packed behind those
@@ -640,31 +643,31 @@ TKZ_KERNEL_OCC(kMsThreads, 3) void k_merge_short(TkzTables T, EncodeParams P) {
         }
         int btot;
         const int doff = dused + tkz_wave_scan_sum(cnt, &btot);
+        const int64_t pbk = pb_of(si);                         // (a shuffle: every lane takes part)
         if (lane < n) {
             const bool packed = doff + cnt <= kDenseCap;
             int32_t* dst = packed ? dense + doff : P.tmp + ((sub0 + si) * kSub + rel);
             int i = 0;
             for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)ids[tkz_ctz32(a)];
-            int64_t pbk = pbs[0];
-#pragma unroll
-            for (int q = 1; q < kGroup; ++q) if (si == q) pbk = pbs[q];
             P.prank[pbk + k] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (packed ? (kPrDense | (uint32_t)doff) : (uint32_t)rel);
         }
         dused += btot;
         const int cnt1 = lane < n ? cnt - 1 : 0;
 #pragma unroll
-        for (int q = 0; q < kGroup; ++q) { int tot; (void)tkz_wave_scan<4>((lane < n && si == q) ? cnt1 : 0, &tot); extra[q] += tot; }
+        for (int q = 0; q < kGroup; ++q) { int tot; (void)tkz_wave_scan<4>((lane < n && si == q) ? cnt1 : 0, &tot); if (lane == q) my_extra += tot; }
         (void)simt::ballot(true);
     };
 #pragma unroll 1
     for (int si = 0; si < kGroup; ++si) {
+        const int64_t pb = pb_of(si);
+        const int np = simt::shfl(my_np, si);
 #pragma unroll 1
-        for (int k0 = 0; k0 < nps[si]; k0 += 256) {          // four record loads in flight per lane (a sub-tile averages ~230 pieces)
+        for (int k0 = 0; k0 < np; k0 += 256) {               // four record loads in flight per lane (a sub-tile averages ~230 pieces)
             uint32_t r4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = k0 + 64 * j + lane;
-                r4[j] = (k < nps[si] && pbs[si] + k < P.prank_cap) ? (uint32_t)tkz_load_nt(&P.prank[pbs[si] + k]) : 0u;
+                r4[j] = (k < np && pb + k < P.prank_cap) ? (uint32_t)tkz_load_nt(&P.prank[pb + k]) : 0u;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -674,19 +677,14 @@ TKZ_KERNEL_OCC(kMsThreads, 3) void k_merge_short(TkzTables T, EncodeParams P) {
                 const int c = tkz_popc64(m);
                 if (c == 0) continue;
                 if (nlist + c > 64) { run_batch(nlist); nlist = 0; }
-                if (is) { const int o = nlist + tkz_popc64(m & tkz_lowmask(lane)); s_rec[o] = rec; s_idx[o] = ((uint32_t)si << 10) | (uint32_t)(k0 + 64 * j + lane); }
+                if (is) { const int o = nlist + tkz_popc64(m & tkz_lowmask(lane)); s_rec[o] = rec; s_idx[o] = (uint16_t)((si << 10) | (k0 + 64 * j + lane)); }
                 nlist += c;
             }
         }
     }
     if (nlist > 0) run_batch(nlist);
     // tokens of every sub-tile of the group: one per piece, plus what the merges added (k_merge_long adds its own later)
-    if (lane < kGroup && sub0 + lane < P.nsub) {
-        int np = nps[0], ex = extra[0];
-#pragma unroll
-        for (int q = 1; q < kGroup; ++q) if (lane == q) { np = nps[q]; ex = extra[q]; }
-        P.tile_count[sub0 + lane] = np + ex;
-    }
+    if (lane < kGroup && sub0 + lane < P.nsub) P.tile_count[sub0 + lane] = my_np + my_extra;
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
 
@@ -1329,8 +1327,8 @@ void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, co
         // blocks with multi-byte chars: the char-level block evaluator; what that refuses as well: the sequential matcher
         int64_t* xq2 = xq + grid + 1;
         unsigned long long* xcount2 = xcount + 1;
-        TKZ_LAUNCH(k_pretok_mb_blocks, grid < 8192 ? grid : 8192, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, (const int64_t*)xq,
-                   (const unsigned long long*)xcount, xq2, xcount2);
+        TKZ_LAUNCH(k_pretok_mb_blocks, grid < 8192 ? grid : 8192, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, (const uint8_t*)xq, grid,
+                   xcount, xq2, xcount2);
         TKZ_LAUNCH(k_pretok_seq_blocks, grid_for(n_docs > grid ? n_docs : grid), kThreads, L.stream, d_bytes, d_offs, n_docs, total, startbits, nrows,
                    pattern, bmp, (const int64_t*)xq2, (const unsigned long long*)xcount2, counters);
     }
