@@ -99,9 +99,6 @@ struct Workspace {
     DevBuf p_boffs, p_toffs, p_docp;
     CounterBlock* h_counters = nullptr;   // pinned
     hipStream_t st_compute = nullptr, st_in = nullptr, st_out = nullptr;   // the host-buffer entry points: kernels / uploads / downloads
-    hipStream_t st_aux = nullptr;                                          // launch_encode: k_merge_short beside k_probe
-    hipEvent_t ev_rng[tkz::kMaxRanges + 1] = {};
-    int last_ranges = 1;
     hipEvent_t ev_in[2] = {}, ev_done[2] = {}, ev_out[2] = {};
     int64_t bytes_allocated = 0;
     bool busy = false;
@@ -120,8 +117,6 @@ struct Workspace {
         for (int k = 0; k < tkz::K_COUNT; ++k) for (int q = 0; q < 2; ++q) if (ev[k][q]) (void)hipEventDestroy(ev[k][q]);
         for (int q = 0; q < 2; ++q) { if (ev_in[q]) (void)hipEventDestroy(ev_in[q]); if (ev_done[q]) (void)hipEventDestroy(ev_done[q]); if (ev_out[q]) (void)hipEventDestroy(ev_out[q]); }
         if (st_compute) (void)hipStreamDestroy(st_compute);
-        if (st_aux) (void)hipStreamDestroy(st_aux);
-        for (hipEvent_t& ev1 : ev_rng) if (ev1) (void)hipEventDestroy(ev1);
         if (st_in) (void)hipStreamDestroy(st_in);
         if (st_out) (void)hipStreamDestroy(st_out);
     }
@@ -172,9 +167,7 @@ void prof_collect(Workspace* e) {
     for (int k = 0; k < tkz::K_COUNT; ++k) {
         if (!e->ev_used[k]) continue;
         float t = 0;
-        // (the k_probe / k_merge_short brackets span all the ranges launch_encode cut the batch into: that many launches each)
-        const int nl = (k == tkz::K_ENCODE || k == tkz::K_MERGE_SHORT) ? e->last_ranges : 1;
-        if (hipEventElapsedTime(&t, e->ev[k][0], e->ev[k][1]) == hipSuccess) { e->ms[k] += t; e->launches[k] += nl; }
+        if (hipEventElapsedTime(&t, e->ev[k][0], e->ev[k][1]) == hipSuccess) { e->ms[k] += t; e->launches[k] += 1; }
         e->ev_used[k] = false;
     }
 }
@@ -284,12 +277,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
     }
     if (!ws->h_counters) HIP_TRY(hipHostMalloc((void**)&ws->h_counters, sizeof(CounterBlock), 0));
 
-    if (!d_bitmap_only && !ws->st_aux) {
-        HIP_TRY(hipStreamCreateWithFlags(&ws->st_aux, hipStreamNonBlocking));
-        for (hipEvent_t& ev1 : ws->ev_rng) HIP_TRY(hipEventCreateWithFlags(&ev1, hipEventDisableTiming));
-    }
     for (int attempt = 0; attempt < 3; ++attempt) {
-        Launch L{stream, e->profiling ? prof_hook : nullptr, ws, ws->st_aux, ws->ev_rng, &ws->last_ranges};
+        Launch L{stream, e->profiling ? prof_hook : nullptr, ws};
         int32_t* counters = ws->w_counters.as<int32_t>();
         int64_t* grand = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, grand));
         unsigned long long* pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head));

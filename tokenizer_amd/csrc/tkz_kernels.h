@@ -41,7 +41,6 @@ struct EncodeParams {
     const int64_t* docord_base;   // per sub-tile: number of distinct document-start positions before it
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
     int32_t* counters;            // [0] error bits
-    int64_t sub_begin, sub_end;   // k_probe / k_merge_short: the range of sub-tiles of this launch (launch_encode cuts the batch into ranges)
     uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_probe: bit 0 = a piece of 17..1024 bytes to merge, bit 1 = a giant piece
                                                                           // (a flag, not a queue: a queue's one counter serialises a million atomics on mixed text)
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)
@@ -54,10 +53,7 @@ struct EncodeParams {
 };
 
 typedef void (*KernelHook)(void* ctx, int kernel_id, int phase /*0 before, 1 after*/, hipStream_t s);
-// aux / ev: a second stream and kMaxRanges + 1 events for launch_encode's overlap of k_probe (range i+1) with k_merge_short (range i);
-// null = everything on `stream`, one launch each.  launches[k]: kernel launches one profiled bracket of kernel k stood for.
-constexpr int kMaxRanges = 16;
-struct Launch { hipStream_t stream; KernelHook hook; void* hook_ctx; hipStream_t aux = nullptr; hipEvent_t* ev = nullptr; int* ranges_out = nullptr; };
+struct Launch { hipStream_t stream; KernelHook hook; void* hook_ctx; };
 
 void launch_docmark(const Launch& L, const int64_t* d_offs, int64_t n_items, int64_t total, uint64_t* bits, int32_t* counters);
 // position-parallel Regex.Matches; xq / xcount: queue of row blocks left to the sequential matcher (o200k only)

@@ -407,8 +407,8 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
     TKZ_SHARED uint16_t s_pstart_all[kThreads / 64][kSub + 2];
     TKZ_SHARED uint16_t s_mid_all[kThreads / 64][kSub / (TKZ_SHORT_KEY_MAX + 1) + 2];   // pieces of 13..28 bytes of the sub-tile (<= 78 of them)
     const int lane = simt::lane();
-    const int64_t sub = P.sub_begin + simt::bid() * (kThreads / 64) + simt::wave();
-    if (sub >= P.sub_end) return;                         // (no workgroup barrier anywhere: every wavefront is on its own)
+    const int64_t sub = simt::bid() * (kThreads / 64) + simt::wave();
+    if (sub >= P.nsub) return;                            // (no workgroup barrier anywhere: every wavefront is on its own)
     uint32_t* s_bytes = s_bytes_all[simt::wave()];
     uint16_t* s_pstart = s_pstart_all[simt::wave()];
     uint16_t* s_mid = s_mid_all[simt::wave()];
@@ -614,8 +614,8 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     const int lane = simt::lane(), wv = simt::wave();
     for (int i = simt::tid(); i < 256; i += simt::nthreads()) s_brank[i] = T.byte_rank[i];
     simt::sync();
-    const int64_t sub0 = P.sub_begin + (simt::bid() * (kMsThreads / 64) + wv) * kGroup;      // (sub_begin is a multiple of kGroup)
-    if (sub0 >= P.sub_end) return;
+    const int64_t sub0 = (simt::bid() * (kMsThreads / 64) + wv) * kGroup;
+    if (sub0 >= P.nsub) return;
     uint32_t* s_rec = s_rec_all[wv];
     uint16_t* s_idx = s_idx_all[wv];
     uint32_t* ids = &s_ids_all[wv][lane * IDSTRIDE];
@@ -623,7 +623,7 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     // lane q < kGroup keeps what belongs to sub-tile q of the group: where its records start, how many there are, tokens added by merges
     static_assert(kGroup <= 64, "one lane per sub-tile of the group");
     int64_t my_pb = 0; int my_np = 0, my_extra = 0;
-    if (lane < kGroup && sub0 + lane < P.sub_end) { my_pb = P.pbase[sub0 + lane]; my_np = P.pcount[sub0 + lane]; }
+    if (lane < kGroup && sub0 + lane < P.nsub) { my_pb = P.pbase[sub0 + lane]; my_np = P.pcount[sub0 + lane]; }
     auto pb_of = [&](int q) -> int64_t { return ((int64_t)simt::shfl((int)(my_pb >> 32), q) << 32) | (uint32_t)simt::shfl((int)my_pb, q); };
     int err = 0, nlist = 0, dused = 0;
     int32_t* const dense = P.dense + (sub0 / kGroup) * kDenseCap;
@@ -687,7 +687,7 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     }
     if (nlist > 0) run_batch(nlist);
     // tokens of every sub-tile of the group: one per piece, plus what the merges added (k_merge_long adds its own later)
-    if (lane < kGroup && sub0 + lane < P.sub_end) P.tile_count[sub0 + lane] = my_np + my_extra;
+    if (lane < kGroup && sub0 + lane < P.nsub) P.tile_count[sub0 + lane] = my_np + my_extra;
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
 
@@ -1343,32 +1343,13 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
     TKZ_LAUNCH(k_pretok_seq, grid_for(n_docs), kThreads, L.stream, d_bytes, d_offs, n_docs, total, startbits, pattern, bmp, counters);
     hook(L, K_PRETOK, 1);
 }
-// k_probe is bound by VALU issue and k_merge_short by the latency of dependent gathers with the VALU half idle: run side by side they
-// fill each other's gaps.  The batch is cut into ranges of sub-tiles; k_probe of range i+1 (main stream) runs while k_merge_short of
-// range i does (second stream, released by an event after k_probe of range i); the main stream waits for the last k_merge_short.
-void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P0, int64_t nsub) {
-    EncodeParams P = P0;
-    int nr = 1;
-    if (L.aux && L.ev && nsub >= 65536) nr = 8;
-    static const int forced = [] { const char* v = getenv("TKZ_ENCODE_RANGES"); return v ? atoi(v) : 0; }();      // (development: 1 = no overlap)
-    if (forced > 0 && L.aux && L.ev) nr = forced > kMaxRanges ? kMaxRanges : forced;
-    if (L.ranges_out) *L.ranges_out = nr;
-    const int64_t per = cdiv(cdiv(nsub, nr), 64) * 64;                 // sub-tiles per range (a multiple of kGroup)
-    hipStream_t ms = nr > 1 ? L.aux : L.stream;
-    for (int i = 0; i < nr; ++i) {
-        P.sub_begin = i * per; P.sub_end = (i + 1) * per < nsub ? (i + 1) * per : nsub;
-        if (P.sub_begin >= P.sub_end) { P.sub_begin = P.sub_end = nsub; }
-        const int64_t n = P.sub_end - P.sub_begin;
-        if (i == 0) hook(L, K_ENCODE, 0);
-        if (n > 0) TKZ_LAUNCH(k_probe, cdiv(n, kThreads / 64), kThreads, L.stream, T, P);
-        if (i == nr - 1) hook(L, K_ENCODE, 1);
-        if (nr > 1) { (void)hipEventRecord(L.ev[i], L.stream); (void)hipStreamWaitEvent(ms, L.ev[i], 0); }
-        if (i == 0 && L.hook) L.hook(L.hook_ctx, K_MERGE_SHORT, 0, ms);
-        if (n > 0) TKZ_LAUNCH(k_merge_short, cdiv(n, (kMsThreads / 64) * kGroup), kMsThreads, ms, T, P);
-        if (i == nr - 1 && L.hook) L.hook(L.hook_ctx, K_MERGE_SHORT, 1, ms);
-    }
-    if (nr > 1) { (void)hipEventRecord(L.ev[kMaxRanges], ms); (void)hipStreamWaitEvent(L.stream, L.ev[kMaxRanges], 0); }
-    P = P0;
+void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub) {
+    hook(L, K_ENCODE, 0);
+    TKZ_LAUNCH(k_probe, cdiv(nsub, kThreads / 64), kThreads, L.stream, T, P);
+    hook(L, K_ENCODE, 1);
+    hook(L, K_MERGE_SHORT, 0);
+    TKZ_LAUNCH(k_merge_short, cdiv(nsub, (kMsThreads / 64) * kGroup), kMsThreads, L.stream, T, P);
+    hook(L, K_MERGE_SHORT, 1);
     hook(L, K_HEAVY, 0);
     // giant pieces start in sub-tiles k_probe has flagged: find them, merge them; then the pieces of 17..1024 bytes and the giants' token counts
     TKZ_LAUNCH(k_giant_find, grid_for(nsub), kThreads, L.stream, (const uint8_t*)P.heavy_flag, nsub, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap);
