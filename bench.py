@@ -253,11 +253,14 @@ def main():
                     traffic, traffic_note = tj["by_kernel"][dom]["hbm_bytes_per_launch"], "rocprofv3 PMC passes of this build (profiles/traffic_latest.json)"
             except Exception:
                 traffic = None
+        leftovers = enc.pretok_leftovers() if hasattr(enc, "pretok_leftovers") else (0, 0)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
                     "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kms.items()},
                     "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
+        if args.pattern == 3:     # of the 4 KiB blocks: handed on by the ASCII block scanner / by the multi-byte one as well (to the sequential matcher)
+            roofline["o200k_blocks"] = {"total": (total + 3967) // 3968, "after_ascii_scanner": leftovers[0], "after_multibyte_scanner": leftovers[1]}
         # ---- CPU baseline (the oracle = reference-algorithm restatement, "port") + parity on the sample ----
         cpu = None
         host_path = None

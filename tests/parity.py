@@ -165,6 +165,20 @@ def o200k_gen(rng, a, n):
     return "".join(out[:n])
 
 
+def check_o200k_no_sync_points(lib, O, vocab):
+    """Blocks the o200k block scanners hand on (a row of nothing but '/') inside text without blanks, digits or line breaks: the sequential
+    kernel finds no sync point within its window and takes the block from HBM; next to a document where it does find them."""
+    rng = random.Random(5)
+    cjk = "".join(chr(0x4E00 + rng.randrange(2000)) for _ in range(7000))
+    docs = [(cjk[:3000] + "/" * 200 + cjk[3000:]).encode("utf-8"), ("A" + cjk[:2500] + "/" * 130 + "x y 1" + cjk[100:2000]).encode("utf-8")]
+    data, offs = pack(docs)
+    enc = N.Encoder(vocab, N.O200K)
+    got = enc.pretokenize(data, offs)
+    exp = oracle_bitmap(O, N.O200K, docs)
+    assert np.array_equal(got, exp), explain_bitmap_diff(got, exp, docs, offs)
+    assert enc.pretok_leftovers()[1] >= 2
+
+
 def check_o200k_blocks(lib, O, vocab, kinds, seeds, doc_lens=(3000, 9000, 20000), min_handled=None):
     """Block scanners of o200k vs the oracle's sequential matcher on documents long enough to hold whole 4 KiB blocks.
     Returns (blocks, left over by the ASCII scanner, left over by the multi-byte scanner)."""

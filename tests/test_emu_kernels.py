@@ -92,13 +92,14 @@ def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod):
     # CJK / kana / hangul / emoji / combining-mark text under o200k goes through the char-level block scanner, not the sequential matcher
     blocks, after_ascii, after_mb = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["cjk", "case", "emoji", "upper", "all", "mark", "slash"], range(2))
     assert after_ascii > 0 and after_mb < after_ascii // 2, (blocks, after_ascii, after_mb)
+    parity.check_o200k_no_sync_points(lib, oracle_mod, vocab)
     # the bench's mixed corpus: every block holds multi-byte chars, all but the ragged last one are done by the block scanner
     docs = [N.corpus_doc_host(2, 0x5EED0001, d, 256, 768, lib=lib) for d in range(120)]
     data, offs = parity.pack(docs)
     enc = N.Encoder(vocab, N.O200K)
     assert np.array_equal(enc.pretokenize(data, offs), parity.oracle_bitmap(oracle_mod, N.O200K, docs))
     a, b = enc.pretok_leftovers()
-    assert a >= 10 and b <= 1, (a, b)
+    assert a >= 10 and b == 0, (a, b)
 
 
 @pytest.mark.parametrize("vname", ["gpt2", "synth100k", "synth200k"])

@@ -96,6 +96,7 @@ def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod):
     blocks, after_ascii, after_mb = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["cjk", "case", "emoji", "upper", "all", "mark", "slash"], range(12),
                                                               doc_lens=(3000, 9000, 20000, 100000))
     assert after_ascii > 0 and after_mb < after_ascii // 2, (blocks, after_ascii, after_mb)
+    parity.check_o200k_no_sync_points(lib, oracle_mod, vocab)
 
 
 def test_golden_splits(lib, vocab):

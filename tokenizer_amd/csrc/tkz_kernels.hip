@@ -233,6 +233,42 @@ TKZ_DEV void tkz_seq_emit(int pattern, const TkzDoc& doc, int64_t a, int64_t p0,
     if (acc) simt::atomic_or64((unsigned long long*)&startbits[curw], acc);
 }
 
+constexpr int kSeqBack = 768, kSeqFwd = 384, kSeqSeg = 62, kSeqWin = kSeqBack + kRowsPerWave * 64 + kSeqFwd;
+static_assert(kSeqSeg * 64 == kRowsPerWave * 64 && kSeqWin % 16 == 0, "64 segments tile a block");
+// byte i is certainly a match start when (byte i-1, byte i) are: CR/LF then an ASCII letter or digit; a non-white-space ASCII char then an
+// ASCII white-space char that is not CR/LF; a non-digit ASCII char then an ASCII digit (no alternative of the patterns spans any of these)
+TKZ_HD bool tkz_sync_rule(uint32_t pc, uint32_t c) {
+    if (pc >= 0x80u || c >= 0x80u) return false;
+    const bool c_ws = c == ' ' || c - 9u < 5u, pc_ws = pc == ' ' || pc - 9u < 5u;
+    if ((pc == '\n' || pc == '\r') && ((c | 0x20u) - 'a' < 26u || c - '0' < 10u)) return true;
+    if (c_ws && c != '\n' && c != '\r' && !pc_ws) return true;
+    return c - '0' < 10u && !(pc - '0' < 10u);
+}
+// one block through the sequential matcher straight from HBM, by ONE lane: every document that overlaps [b0, b1) from the nearest sync
+// point at or before b0
+TKZ_DEV void tkz_seq_block_global(const uint8_t* bytes, const int64_t* offs, int64_t n_docs, int64_t total, uint64_t* startbits, int pattern,
+                                  const uint8_t* bmp, int64_t b0, int64_t b1, int32_t* counters) {
+    int64_t lo = 0, hi = n_docs;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (offs[mid + 1] <= b0) lo = mid + 1; else hi = mid; }
+    for (int64_t d = lo; d < n_docs && offs[d] < b1; ++d) {
+        const int64_t a = offs[d], e = offs[d + 1];
+        if (e <= a || a < 0 || e > total) continue;
+        TkzDoc doc; doc.b = bytes + a; doc.n = e - a; doc.bmp = bmp; doc.by_code_point = pattern == TKZ_PAT_O200K;
+        int64_t p = 0;
+        if (a < b0) {
+            int64_t i = b0 - a;
+            for (; i > 0; --i) if (tkz_sync_rule(doc.b[i - 1], doc.b[i])) break;
+            p = i;
+        }
+        int bad = 0;
+        int64_t v = a < b0 ? b0 - a : 0;                    // validate from the start of the char that contains the block's first byte
+        for (int back = 0; v > 0 && back < 3 && (doc.b[v] & 0xC0) == 0x80; ++back) --v;
+        for (; v < doc.n && a + v < b1;) { const TkzChar ch = tkz_doc_char(doc, v); bad |= ch.bad; v += ch.len; }
+        if (bad) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrUtf8); continue; }
+        tkz_seq_emit(pattern, doc, a, p, b0, b1, startbits);
+    }
+}
+
 // The blocks k_pretok_rows<O200K> left over.  For every document that overlaps the block's
 // bytes the sequential matcher runs from the nearest position at or before the block that is certainly a match start --
 // the document start; a letter/digit right after a CR/LF; an ASCII non-CR/LF white-space char after a non-white-space
@@ -258,40 +294,125 @@ TKZ_KERNEL(256) void k_pretok_seq_blocks(const uint8_t* bytes, const int64_t* of
         }
         return;
     }
-    // one WAVEFRONT per block, lane 0 working: 64 lanes on 64 different blocks would each follow their own path through
-    // the matcher and the wavefront would serialise them
+    // One WAVEFRONT per block.  The block (+ 768 bytes before it, 384 after) is staged in LDS -- the matcher reads a char at a time,
+    // every read a dependent round trip when it goes to HBM: a lane took ~1 us per byte that way -- and cut into 64 segments of 62
+    // bytes at sync points: lane l matches from the first sync point at or after the start of its segment up to the one lane l+1
+    // starts from (lane 0: from the nearest sync point before the block).  When the window holds no sync point where one is needed
+    // (text without blanks, digits or line breaks for hundreds of bytes) lane 0 does the block from HBM, as before.
+    TKZ_SHARED uint4 s_win_all[kThreads / 64][kSeqWin / 16];
+    uint8_t* const win = reinterpret_cast<uint8_t*>(s_win_all[simt::wave()]);
+    const int lane = simt::lane();
     for (int64_t q = (simt::bid() * simt::nthreads() + simt::tid()) >> 6; q < nx; q += stride >> 6) {
-        if (simt::lane() != 0) continue;
         const int64_t r0 = xq[q] * kRowsPerWave;
         const int64_t r1 = r0 + kRowsPerWave < nrows ? r0 + kRowsPerWave : nrows;
         const int64_t b0 = r0 << 6, b1 = (r1 << 6) < total ? (r1 << 6) : total;
         if (b0 >= b1) continue;
-        // first document that ends after b0
-        int64_t lo = 0, hi = n_docs;
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (offs[mid + 1] <= b0) lo = mid + 1; else hi = mid; }
-        for (int64_t d = lo; d < n_docs && offs[d] < b1; ++d) {
-            const int64_t a = offs[d], e = offs[d + 1];
-            if (e <= a || a < 0 || e > total) continue;
-            TkzDoc doc; doc.b = bytes + a; doc.n = e - a; doc.bmp = bmp; doc.by_code_point = pattern == TKZ_PAT_O200K;
-            int64_t p = 0;
-            if (a < b0) {                                 // the document starts before the block: look for a sync point
-                int64_t i = b0 - a;
-                for (; i > 0; --i) {
-                    const uint32_t c = doc.b[i], pc = doc.b[i - 1];
-                    if (pc >= 0x80u || c >= 0x80u) continue;
-                    const bool c_ws = c == ' ' || c - 9u < 5u, pc_ws = pc == ' ' || pc - 9u < 5u;
-                    if ((pc == '\n' || pc == '\r') && ((c | 0x20u) - 'a' < 26u || c - '0' < 10u)) break;
-                    if (c_ws && c != '\n' && c != '\r' && !pc_ws) break;
-                    if (c - '0' < 10u && !(pc - '0' < 10u)) break;
-                }
-                p = i;
+        const int64_t wlo = b0 > kSeqBack ? b0 - kSeqBack : 0;             // (multiples of 64)
+        const int64_t whi = b1 + kSeqFwd < total ? b1 + kSeqFwd : total;
+        (void)simt::ballot(true);                                           // (the previous block's window is no longer read)
+        for (int64_t p = wlo + 16 * lane; p < whi; p += 16 * 64) {
+            uint4 v; v.x = v.y = v.z = v.w = 0;
+            if (p + 16 <= total) v = tkz_load16(bytes + p);
+            else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 16; ++k) if (p + k < total) w[k >> 2] |= (uint32_t)bytes[p + k] << (8 * (k & 3));
+                v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
             }
-            int bad = 0;
-            int64_t v = a < b0 ? b0 - a : 0;                // validate from the start of the char that contains the block's first byte
-            for (int back = 0; v > 0 && back < 3 && (doc.b[v] & 0xC0) == 0x80; ++back) --v;
-            for (; v < doc.n && a + v < b1;) { const TkzChar ch = tkz_doc_char(doc, v); bad |= ch.bad; v += ch.len; }
-            if (bad) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrUtf8); continue; }
-            tkz_seq_emit(pattern, doc, a, p, b0, b1, startbits);
+            *reinterpret_cast<uint4*>(win + (p - wlo)) = v;
+        }
+        (void)simt::ballot(true);
+        auto wb = [&](int64_t abs) -> uint32_t { return win[abs - wlo]; };
+        auto doc_of = [&](int64_t pos) -> int64_t {                         // the document that holds byte `pos` (documents tile [0, total))
+            int64_t lo = 0, hi = n_docs;
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (offs[mid + 1] <= pos) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        // where the matcher may stop reading: the end of the text, or 8 bytes behind the first sync point at or after the block's end
+        int64_t cut = -1;
+        if (whi == total) cut = total;
+        else {
+            int64_t f = -1;
+            for (int64_t base = b1; base + 8 < whi && f < 0; base += 64) {
+                const int64_t i = base + lane;
+                const bool ok = i + 8 < whi && tkz_sync_rule(wb(i - 1), wb(i));
+                const uint64_t m = simt::ballot(ok);
+                if (m) f = base + tkz_ctz64(m);
+            }
+            const int64_t dn = doc_of(b1);                                  // a document start at or after b1 is a sync point too
+            const int64_t ds1 = offs[dn] >= b1 ? offs[dn] : offs[dn + 1];
+            if (ds1 + 8 < whi && (f < 0 || ds1 < f)) f = ds1;
+            if (f >= 0) cut = f + 8;
+        }
+        // lane 0 starts from the nearest sync point at or before the block's first byte
+        const int64_t d0 = doc_of(b0), a0 = offs[d0];
+        int64_t start0 = -1;
+        if (a0 == b0) start0 = b0;
+        else {
+            const int64_t lower = a0 > wlo ? a0 : wlo;                       // candidates i need byte i-1 of the same document inside the window
+            for (int64_t base = b0; base > lower && start0 < 0; base -= 64) {
+                const int64_t i = base - lane;
+                const bool ok = i > lower && tkz_sync_rule(wb(i - 1), wb(i));
+                const uint64_t m = simt::ballot(ok);
+                if (m) start0 = base - tkz_ctz64(m);
+            }
+            if (start0 < 0 && a0 >= wlo) start0 = a0;
+        }
+        if (cut < 0 || start0 < 0) {                                        // no sync point in reach: the block from HBM, one lane
+            if (lane == 0) tkz_seq_block_global(bytes, offs, n_docs, total, startbits, pattern, bmp, b0, b1, counters);
+            continue;
+        }
+        // first sync point of every segment, then the first one at or after every segment's start (suffix minimum over the lanes)
+        const int64_t t0 = b0 + (int64_t)kSeqSeg * lane, t1 = t0 + kSeqSeg < b1 ? t0 + kSeqSeg : b1;
+        int64_t own = b1;
+        if (lane > 0 && t0 < b1) {
+            for (int64_t i = t0; i < t1; ++i) if (tkz_sync_rule(wb(i - 1), wb(i))) { own = i; break; }
+            const int64_t dn = doc_of(t0);
+            const int64_t ds1 = offs[dn] >= t0 ? offs[dn] : offs[dn + 1];
+            if (ds1 < t1 && ds1 < own) own = ds1;
+        }
+        int64_t st = own;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t o = ((int64_t)simt::shfl((int)(st >> 32), (lane + d) & 63) << 32) | (uint32_t)simt::shfl((int)st, (lane + d) & 63);
+            if (lane + d < 64 && o < st) st = o;
+        }
+        int64_t lim = ((int64_t)simt::shfl((int)(st >> 32), (lane + 1) & 63) << 32) | (uint32_t)simt::shfl((int)st, (lane + 1) & 63);
+        if (lane == 63) lim = b1;
+        if (lane == 0) st = start0;
+        // UTF-8 validation of the chars whose lead byte lies in my segment (lane 0: from the start of the char that holds the block's first byte)
+        int bad = 0;
+        if (t0 < b1) {
+            int64_t v = t0;
+            int64_t d = doc_of(v);
+            if (lane == 0) { for (int back = 0; v > offs[d] && v > wlo && back < 3 && (wb(v) & 0xC0) == 0x80; ++back) --v; }
+            else { for (int k = 0; k < 3 && v < t1 && v > offs[d] && v < offs[d + 1] && (wb(v) & 0xC0) == 0x80; ++k) ++v; }
+            while (v < t1) {
+                while (offs[d + 1] <= v) ++d;
+                const int64_t a = offs[d], e = offs[d + 1];
+                TkzDoc doc; doc.b = win + (a - wlo); doc.n = (e < cut ? e : cut) - a; doc.bmp = bmp; doc.by_code_point = pattern == TKZ_PAT_O200K;
+                const TkzChar ch = tkz_doc_char(doc, v - a);
+                bad |= ch.bad;
+                v += ch.len;
+            }
+        }
+        if (simt::ballot(bad != 0)) { if (lane == 0) simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrUtf8); continue; }
+        // the matches that start in [st, lim)
+        if (st < lim) {
+            int64_t pos = st, d = doc_of(st), curw = -1;
+            uint64_t acc = 0;
+            while (pos < lim) {
+                while (offs[d + 1] <= pos) ++d;
+                const int64_t a = offs[d], e = offs[d + 1];
+                TkzDoc doc; doc.b = win + (a - wlo); doc.n = (e < cut ? e : cut) - a; doc.bmp = bmp; doc.by_code_point = pattern == TKZ_PAT_O200K;
+                if (pos >= b0) {
+                    if ((pos >> 6) != curw) {
+                        if (acc) simt::atomic_or64((unsigned long long*)&startbits[curw], acc);
+                        curw = pos >> 6; acc = 0;
+                    }
+                    acc |= 1ull << (pos & 63);
+                }
+                pos = a + tkz_match_at(pattern, doc, pos - a);
+            }
+            if (acc) simt::atomic_or64((unsigned long long*)&startbits[curw], acc);
         }
     }
 }
