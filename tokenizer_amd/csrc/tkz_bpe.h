@@ -222,6 +222,107 @@ TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, 
             if (ids[32 * w + tkz_ctz32(a)] >= (uint32_t)TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;   // ranks[...] throws (:17,:73)
     return cnt;
 }
+// ---- the same loop WITHOUT an ids[] array (vocabularies whose ranks stay below 2^21: every published one) -----------------
+// What limits k_merge_long is how many pieces fit into a CU's LDS at once (a merge is a dependent round trip to the pair table,
+// so throughput = pieces in flight / latency), and ids[] is 40 % of a piece's state.  It is redundant:
+//   * a part that has never merged is a single byte and its id is brank[byte] (the bytes are staged in LDS anyway);
+//   * a part j that HAS merged swallowed the part that began at j+1, so slot j+1 of pr[] is dead for good: it holds the id.
+// Dead slots have the top bit set (DEAD | id, or NONE): a live key (rank << 10 | position, rank < 2^21) is always smaller, so the
+// v_min3 scan needs no mask, and "no pair left" reads as min >= DEAD.   Layout: pr[n4] | alive[a4].
+constexpr int32_t kVarCompactMaxRank = (1 << 21) - 2;
+constexpr uint32_t kVarDead = 0x80000000u;
+TKZ_HD int tkz_bpe_varc_dwords(int n) { return tkz_bpe_var_n4(n) + tkz_bpe_var_a4(n); }
+
+template <class ByteAt>
+TKZ_HD uint32_t tkz_bpe_varc_id(ByteAt at, int n, const uint32_t* pr, const uint32_t* am, const int32_t* brank, int x) {
+    const int y = x + 1 < n ? x + 1 : x;                 // (x = n-1 never merges to its right: am bit of x itself is set)
+    const bool merged = x + 1 < n && !((am[y >> 5] >> (y & 31)) & 1u);
+    const uint32_t a = pr[y] & ~kVarDead, b = (uint32_t)brank[at(x)];     // (both loads unconditional)
+    return merged ? a : b;
+}
+
+template <class ByteAt>
+TKZ_HD int tkz_bpe_lane_varc(const TkzTables& T, ByteAt at, int n, uint32_t* st, int* err, const int32_t* brank) {
+    auto entry = [](int32_t rank, int pos) -> uint32_t {
+        return rank == TKZ_RANK_NONE ? TKZ_NOKEY : (((uint32_t)rank << kVarPosBits) | (uint32_t)pos);
+    };
+    const int n4 = tkz_bpe_var_n4(n), nw = (n + 31) >> 5;
+    uint32_t* pr = st; uint32_t* am = st + n4;
+    uint4* pr4 = reinterpret_cast<uint4*>(pr);
+#pragma unroll 1
+    for (int c = 0; c < n4; c += 16) {                   // first-level pair ranks (:37-44), 16 bytes per step, their gathers in flight together
+        uint32_t b[17];
+#pragma unroll
+        for (int k = 0; k < 17; ++k) b[k] = c + k < n ? at(c + k) : 0u;
+        int32_t r2[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r2[k] = c + k + 1 < n ? T.bytepair_rank[(b[k] << 8) | b[k + 1]] : TKZ_RANK_NONE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (c + 4 * q < n4) {
+                uint4 p;
+                p.x = c + 4 * q + 1 < n ? entry(r2[4 * q], c + 4 * q) : TKZ_NOKEY;
+                p.y = c + 4 * q + 2 < n ? entry(r2[4 * q + 1], c + 4 * q + 1) : TKZ_NOKEY;
+                p.z = c + 4 * q + 3 < n ? entry(r2[4 * q + 2], c + 4 * q + 2) : TKZ_NOKEY;
+                p.w = c + 4 * q + 4 < n ? entry(r2[4 * q + 3], c + 4 * q + 3) : TKZ_NOKEY;
+                pr4[(c >> 2) + q] = p;
+            }
+        }
+    }
+    for (int w = 0; w < nw; ++w) am[w] = tkz_lowmask32(n - 32 * w);
+    int cnt = n;
+    for (;;) {                                          // while (byteIndicesAndRanks.Count > 1) (:45)
+        uint32_t m = TKZ_NOKEY;
+#pragma unroll 4
+        for (int q = 0; q < (n4 >> 2); ++q) {           // leftmost strict min (:47-54): packed (rank, position), ties -> lower position
+            const uint4 p = pr4[q];
+            m = tkz_min3u(m, tkz_min3u(p.x, p.y, p.z), p.w);
+        }
+        if (m >= kVarDead) break;                       // minRank == int.MaxValue (:65-68)
+        const int j = (int)(m & ((1u << kVarPosBits) - 1u));
+        m >>= kVarPosBits;
+        // r: the part being swallowed (next part after j), rr: the one after it, l: the part before j
+        int w = (j + 1) >> 5;
+        uint32_t bits = w < nw ? am[w] & (0xFFFFFFFFu << ((j + 1) & 31)) : 0u;
+        while (!bits && ++w < nw) bits = am[w];
+        const int r = 32 * w + tkz_ctz32(bits);         // exists: pr[j] was a rank
+        bits &= bits - 1;
+        am[w] &= ~(1u << (r & 31));                     // RemoveAt(j + 1) (:63)
+        while (!bits && ++w < nw) bits = am[w];
+        const bool hasr = bits != 0;
+        const int rr = hasr ? 32 * w + tkz_ctz32(bits) : 0;
+        w = j >> 5;
+        bits = am[w] & tkz_lowmask32(j & 31);
+        while (!bits && --w >= 0) bits = am[w];
+        const bool hasl = bits != 0;
+        const int l = hasl ? 32 * w + tkz_msb32(bits) : 0;
+        const uint32_t idr = tkz_bpe_varc_id(at, n, pr, am, brank, rr), idl = tkz_bpe_varc_id(at, n, pr, am, brank, l);
+        uint32_t r1, r2s, l1, l2;
+        tkz_pair_slots(T, m, idr, &r1, &r2s);
+        tkz_pair_slots(T, idl, m, &l1, &l2);
+        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2s]);
+        const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
+        pr[r] = TKZ_NOKEY;                              // dead for good
+        pr[j + 1] = kVarDead | m;                       // ... and the slot behind j carries the id of the merged part (= the rank it was found under)
+        const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);
+        pr[j] = hasr ? entry(rkr, j) : TKZ_NOKEY;                           // (:58)
+        if (hasl) pr[l] = entry(rkl, l);                                    // (:59-62)
+        --cnt;
+    }
+    for (int w = 0; w < nw; ++w)
+        for (uint32_t a = am[w]; a; a &= a - 1)
+            if (tkz_bpe_varc_id(at, n, pr, am, brank, 32 * w + tkz_ctz32(a)) >= (uint32_t)TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;   // ranks[...] throws (:17,:73)
+    return cnt;
+}
+template <class ByteAt>
+TKZ_HD void tkz_bpe_varc_emit(ByteAt at, const uint32_t* st, int n, const int32_t* brank, int32_t* dst) {
+    const int n4 = tkz_bpe_var_n4(n), nw = (n + 31) >> 5;
+    const uint32_t* pr = st; const uint32_t* am = st + n4;
+    int i = 0;
+    for (int w = 0; w < nw; ++w)
+        for (uint32_t a = am[w]; a; a &= a - 1) dst[i++] = (int32_t)tkz_bpe_varc_id(at, n, pr, am, brank, 32 * w + tkz_ctz32(a));
+}
+
 // the tokens of a piece merged by tkz_bpe_lane_var, in order
 TKZ_HD void tkz_bpe_var_emit(const uint32_t* st, int n, int32_t* dst) {
     const int n4 = tkz_bpe_var_n4(n), nw = (n + 31) >> 5;

@@ -14,8 +14,9 @@ constexpr int kHalo = 64;           // bytes staged past the sub-tile (a short p
 constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one per lane, 64 to a wavefront, by k_merge_short
 constexpr int kMergeGroup = 4;      // sub-tiles per wavefront of k_merge_short ("group")
 constexpr int kDenseCap = 1024;     // tokens of merged short pieces a group keeps packed (what does not fit waits in tmp, like the long pieces' tokens)
-constexpr int kArenaDwords = 3584;  // LDS arena of k_merge_long: the long misses of a batch get 2 dwords + 1 byte + 1 bit per byte out of it
-constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (256 + tkz_bpe_var_dwords(1024) <= kArenaDwords)
+constexpr int kArenaDwords = 2560;  // LDS arena of k_merge_long: a long miss of a batch gets its bytes + 1 dword + 1 bit per byte out of it (2 dwords per byte for
+                                    // vocabularies with ranks of 2^21 and more, which keep an ids[] array: tkz_bpe.h)
+constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (256 + tkz_bpe_var_dwords(1024) = 2336 <= kArenaDwords)
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan
