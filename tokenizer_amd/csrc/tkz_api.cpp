@@ -72,6 +72,7 @@ struct CounterBlock {          // mirrors the device block
     int64_t ndocstarts;
     unsigned long long heavy_count;
     int64_t npieces;
+    unsigned long long giant_ticket;       // k_giant_merge's work counter
     unsigned long long xcount, xcount2;    // (adjacent: launch_pretok_rows) blocks the o200k ASCII scanner left over, blocks the multi-byte one left over as well
 };
 
@@ -271,7 +272,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         HIP_TRY(ws->w_dcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_dbase.ensure((size_t)ntiles * 8, acc));
         HIP_TRY(ws->w_heavyq.ensure((size_t)ntiles + 64, acc));
-        HIP_TRY(ws->w_gq.ensure((size_t)(total / kArenaPiece + 2) * 16, acc));
+        HIP_TRY(ws->w_gq.ensure((size_t)(total / kArenaPiece + 2) * 24, acc));     // {position, length} per giant piece + the order they are taken in
         HIP_TRY(ws->w_gcnt.ensure((size_t)ntiles * 4, acc));
         if (!ws->w_pool.p) HIP_TRY(ws->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
     }
@@ -308,6 +309,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.docord_base = ws->w_dbase.as<int64_t>(); P.doc_tok = ws->w_doctok.as<int32_t>(); P.counters = counters;
             P.giant_q = ws->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = ws->w_gcnt.as<int32_t>();
             P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
+            P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
             P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
             HIP_TRY(hipMemsetAsync(P.heavy_flag, 0, (size_t)ntiles, stream));
             P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);

@@ -48,6 +48,7 @@ struct EncodeParams {
     // pieces > kArenaPiece bytes ("giant"): found by k_giant_find, merged by k_giant_merge (one 1024-thread workgroup each); their
     // tokens wait in tmp at the piece's own byte position, their count in giant_cnt[sub-tile of the piece start]
     int64_t* giant_q; unsigned long long* giant_count; int64_t giant_cap; int32_t* giant_cnt;
+    unsigned long long* giant_ticket;       // k_giant_merge: next entry of the (longest first) order, giant_q[2 * giant_cap + t], to be taken
     // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE bit 4): per-phase clock counters of k_probe.  Compiled out of libtkz.so otherwise.
     unsigned long long* devprof;
     int32_t ablate;

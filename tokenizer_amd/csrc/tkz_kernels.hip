@@ -724,11 +724,10 @@ TKZ_DEV void tkz_load_piece16(const uint8_t* bytes, int64_t total, int64_t abs, 
     for (int i = 0; i < 4; ++i) pw[i] = (uint32_t)((((uint64_t)w[i + 1] << 32) | w[i]) >> sh);
 }
 
-// (LDS: 4 x 9.25 KB of merge state + 2.5 KB = 39.5 KB per workgroup, and 128 VGPRs: four workgroups = 16 wavefronts per CU)
-TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
-    constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride, IDSTRIDE = TkzBpeGeom<NMAX>::kIdStride;
+// (LDS: 4 x 5 KB of merge state + 2.5 KB = 22.5 KB per workgroup and 80 VGPRs: six workgroups = 24 wavefronts per CU)
+TKZ_KERNEL_OCC(kMsThreads, 6) void k_merge_short(TkzTables T, EncodeParams P) {
+    constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride;
     TKZ_SHARED uint4 s_pr_all[kMsThreads / 64][(STRIDE * 64) / 4];        // per lane pr[16] at a conflict-free stride for 16-byte reads
-    TKZ_SHARED uint32_t s_ids_all[kMsThreads / 64][IDSTRIDE * 64];        // per lane ids[16]
     TKZ_SHARED uint32_t s_rec_all[kMsThreads / 64][64];                   // the batch: record, and (sub-tile of the group) << 10 | piece index
     TKZ_SHARED uint16_t s_idx_all[kMsThreads / 64][64];
     TKZ_SHARED int32_t s_brank[256];                                     // id of every single byte: in LDS, not 16 gathers per piece
@@ -739,7 +738,6 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     if (sub0 >= P.nsub) return;
     uint32_t* s_rec = s_rec_all[wv];
     uint16_t* s_idx = s_idx_all[wv];
-    uint32_t* ids = &s_ids_all[wv][lane * IDSTRIDE];
     uint32_t* pr = reinterpret_cast<uint32_t*>(s_pr_all[wv]) + lane * STRIDE;
     // lane q < kGroup keeps what belongs to sub-tile q of the group: where its records start, how many there are, tokens added by merges
     static_assert(kGroup <= 64, "one lane per sub-tile of the group");
@@ -753,16 +751,16 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     // gets the token count and where they are
     auto run_batch = [&](int n) {
         (void)simt::ballot(true);
-        int cnt = 0, si = 0, k = 0, rel = 0, e1 = 0;
+        int cnt = 0, si = 0, k = 0, rel = 0, e1 = 0, len = 1;
         uint32_t rec = 0, alive = 1;
+        uint32_t pw[NMAX / 4] = {0, 0, 0, 0};
         if (lane < n) {
             rec = s_rec[lane];
             const uint32_t ix = s_idx[lane];
             si = (int)(ix >> 10); k = (int)(ix & 1023u); rel = (int)(rec & 1023u);
-            const int len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
-            uint32_t pw[NMAX / 4];
+            len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
             tkz_load_piece16(P.bytes, P.total, (sub0 + si) * kSub + rel, pw);
-            cnt = tkz_bpe_lane<NMAX>(T, pw, len, ids, pr, s_brank, &alive, &e1);
+            cnt = tkz_bpe_lane_c<NMAX>(T, pw, len, pr, s_brank, &alive, &e1);
             err |= e1;
         }
         int btot;
@@ -772,7 +770,7 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
             const bool packed = doff + cnt <= kDenseCap;
             int32_t* dst = packed ? dense + doff : P.tmp + ((sub0 + si) * kSub + rel);
             int i = 0;
-            for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)ids[tkz_ctz32(a)];
+            for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)tkz_bpe_lane_c_id<NMAX>(pw, len, pr, s_brank, alive, tkz_ctz32(a));
             P.prank[pbk + k] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (packed ? (kPrDense | (uint32_t)doff) : (uint32_t)rel);
         }
         dused += btot;
@@ -1016,17 +1014,41 @@ TKZ_KERNEL(256) void k_giant_find(const uint8_t* heavy_flag, int64_t nsub, const
         }
     }
 }
+// The order the giant pieces are taken in: longest first (a diverse piece of tens of KiB is merged in thousands of rounds and sets the
+// kernel's duration, so those must start first), by rank counting in one workgroup; identity beyond 8192 pieces.
+constexpr int kGiantSort = 8192;
+TKZ_KERNEL(1024) void k_giant_order(EncodeParams P) {
+    TKZ_SHARED int32_t s_len[kGiantSort];
+    const int64_t n = (int64_t)*P.giant_count < P.giant_cap ? (int64_t)*P.giant_count : P.giant_cap;
+    int64_t* order = P.giant_q + 2 * P.giant_cap;
+    if (n > kGiantSort) { for (int64_t i = simt::tid(); i < n; i += simt::nthreads()) order[i] = i; return; }
+    for (int i = simt::tid(); i < (int)n; i += simt::nthreads()) { const int64_t l = P.giant_q[2 * i + 1]; s_len[i] = l > 0x7FFFFFFF ? 0x7FFFFFFF : (int32_t)l; }
+    simt::sync();
+    for (int i = simt::tid(); i < (int)n; i += simt::nthreads()) {
+        const int32_t li = s_len[i];
+        int rank = 0;
+        for (int j = 0; j < (int)n; ++j) { const int32_t lj = s_len[j]; rank += (lj > li || (lj == li && j < i)) ? 1 : 0; }
+        order[rank] = i;
+    }
+}
+
 TKZ_KERNEL(1024) void k_giant_merge(TkzTables T, EncodeParams P) {
     TKZ_SHARED int32_t s_state[(9 * kBpeLongLds + 3) / 4];        // ids | pair ranks | flag bytes of up to 16 Ki parts: 144 KB of the CU's 160
     TKZ_SHARED int64_t s_off;
     TKZ_SHARED int32_t s_whole;
+    TKZ_SHARED unsigned long long s_ticket;
     const int64_t n = (int64_t)*P.giant_count < P.giant_cap ? (int64_t)*P.giant_count : P.giant_cap;
+    const int64_t* order = P.giant_q + 2 * P.giant_cap;
     int err = 0;
-    // longest first: a diverse piece of tens of KiB is merged in thousands of rounds and sets the kernel's duration by itself, so
-    // those are started before the short ones (two passes over the queue: pieces longer than 12 KiB, then the rest)
-    for (int64_t qq = simt::bid(); qq < 2 * n; qq += simt::nblocks()) {
-        const int64_t q = qq < n ? qq : qq - n;
-        { const bool big = P.giant_q[2 * q + 1] > 12288; if (big != (qq < n)) continue; }
+    // every workgroup keeps taking the next piece of the longest-first order until none is left (a fixed share per workgroup left the
+    // ones with two long pieces working twice as long as the others)
+    for (;;) {
+        if (simt::tid() == 0) s_ticket = simt::atomic_add64(P.giant_ticket, 1ull);
+        simt::sync();
+        const int64_t t = (int64_t)s_ticket;
+        simt::sync();
+        if (t >= n) break;
+        const int64_t q = order[t];
         const int64_t p = P.giant_q[2 * q], len64 = P.giant_q[2 * q + 1];
         int cnt = 0;
         if (len64 > kMaxPiece) err |= kErrTooLong;
@@ -1483,7 +1505,8 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
 #else
     constexpr int kGiantGrid = 256;
 #endif
-    TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // strides over the queue; exits at once when it is empty
+    TKZ_LAUNCH(k_giant_order, 1, 1024, L.stream, P);
+    TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // takes pieces off the ordered queue; exits at once when it is empty
     { const int64_t chunks = cdiv(nsub, 64); TKZ_LAUNCH(k_merge_long, chunks < 16384 ? chunks : 16384, 64, L.stream, T, P); }   // strides over 64-sub-tile chunks
     hook(L, K_HEAVY, 1);
 }
