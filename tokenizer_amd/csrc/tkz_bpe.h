@@ -116,85 +116,6 @@ TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* 
     return cnt;
 }
 
-// tkz_bpe_lane without the ids[] array (see tkz_bpe_lane_varc below for why it is redundant): the id of a part that has merged lives
-// in the dead pr[] slot behind it (top bit set: keys are rank << SH | position < 2^31 for every rank the loader accepts), a part that
-// has not is a single byte of w[].  LDS per piece: NMAX dwords instead of 2 x NMAX.
-template <int NMAX>
-TKZ_HD uint32_t tkz_bpe_lane_c_id(const uint32_t* w, int n, const uint32_t* pr, const int32_t* brank, uint32_t alive, int x) {
-    const int y = x + 1 < n ? x + 1 : x;
-    const bool merged = x + 1 < n && !((alive >> y) & 1u);
-    // (byte x of the piece out of registers: two selects and a 64-bit shift -- written on scalars, an indexed array would go to scratch)
-    static_assert(NMAX == 16, "the piece is four dwords");
-    const uint64_t lo = ((uint64_t)w[1] << 32) | w[0], hi = ((uint64_t)w[3] << 32) | w[2];
-    const uint32_t byte = (uint32_t)(((x & 8) ? hi : lo) >> (8 * (x & 7))) & 0xFFu;
-    const uint32_t a = pr[y] & 0x7FFFFFFFu, b = (uint32_t)brank[byte];     // (both loads unconditional)
-    return merged ? a : b;
-}
-template <int NMAX>
-TKZ_HD int tkz_bpe_lane_c(const TkzTables& T, const uint32_t* w, int n, uint32_t* pr, const int32_t* brank, uint32_t* alive_out, int* err) {
-    constexpr int SH = TkzBpeGeom<NMAX>::kShift;
-    constexpr uint32_t DEAD = 0x80000000u;
-    uint4* pr4 = reinterpret_cast<uint4*>(pr);
-#pragma unroll 1
-    for (int c = 0; c < NMAX / 16; ++c) {
-        uint32_t bk[17];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) bk[k] = (w[4 * c + (k >> 2)] >> (8 * (k & 3))) & 0xFFu;
-        bk[16] = (c + 1 < NMAX / 16) ? (w[4 * c + 4] & 0xFFu) : 0u;
-        uint32_t prv[16];
-        int32_t r2[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) r2[k] = (16 * c + k + 1 < n) ? T.bytepair_rank[(bk[k] << 8) | bk[k + 1]] : TKZ_RANK_NONE;   // (:37-44)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int g = 16 * c + k;
-            prv[k] = (g + 1 < n && r2[k] != TKZ_RANK_NONE) ? (((uint32_t)r2[k] << SH) | (uint32_t)g) : TKZ_NOKEY;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint4 b;
-            b.x = prv[4 * q]; b.y = prv[4 * q + 1]; b.z = prv[4 * q + 2]; b.w = prv[4 * q + 3];
-            pr4[4 * c + q] = b;
-        }
-    }
-    uint32_t alive = tkz_lowmask32(n);
-    for (;;) {                                          // while (byteIndicesAndRanks.Count > 1) (:45)
-        uint32_t key = TKZ_NOKEY;
-#pragma unroll
-        for (int q = 0; q < NMAX / 4; ++q) {            // leftmost strict min (:47-54): packed (rank, position), ties -> lower position
-            const uint4 p = pr4[q];
-            key = tkz_min3u(key, tkz_min3u(p.x, p.y, p.z), p.w);
-        }
-        if (key >= DEAD) break;                         // minRank == int.MaxValue (:65-68)
-        const int j = (int)(key & (uint32_t)(NMAX - 1));
-        const uint32_t m = key >> SH;
-        const int r = tkz_ctz32(alive & ~tkz_lowmask32(j + 1));   // the part being swallowed
-        alive &= ~(1u << r);                            // RemoveAt(j + 1) (:63)
-        const uint32_t hi = alive & ~tkz_lowmask32(r + 1);
-        const uint32_t lo = alive & tkz_lowmask32(j);
-        const int l = lo ? tkz_msb32(lo) : 0;
-        const int rr = hi ? tkz_ctz32(hi) : 0;
-        const uint32_t idr = tkz_bpe_lane_c_id<NMAX>(w, n, pr, brank, alive, rr), idl = tkz_bpe_lane_c_id<NMAX>(w, n, pr, brank, alive, l);
-        uint32_t r1, r2s, l1, l2;
-        tkz_pair_slots(T, m, idr, &r1, &r2s);
-        tkz_pair_slots(T, idl, m, &l1, &l2);
-        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2s]);
-        const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
-        pr[r] = TKZ_NOKEY;
-        pr[j + 1] = DEAD | m;                           // the merged part's id (= the rank it was found under) in the dead slot behind it
-        const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);
-        pr[j] = (hi && rkr != TKZ_RANK_NONE) ? (((uint32_t)rkr << SH) | (uint32_t)j) : TKZ_NOKEY;
-        if (lo) pr[l] = rkl != TKZ_RANK_NONE ? (((uint32_t)rkl << SH) | (uint32_t)l) : TKZ_NOKEY;
-    }
-    int cnt = 0;
-    for (uint32_t a = alive; a; a &= a - 1) {
-        if (tkz_bpe_lane_c_id<NMAX>(w, n, pr, brank, alive, tkz_ctz32(a)) >= (uint32_t)TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;     // ranks[...] throws (:17,:73)
-        ++cnt;
-    }
-    *alive_out = alive;
-    return cnt;
-}
-
 // One LANE merges one piece of n >= 1 bytes with its state in a caller-provided span of tkz_bpe_var_dwords(n) dwords:
 //   ids[n4] | pr[n4] | alive[a4]      n4 = n rounded up to 4, a4 = ceil(n / 32) rounded up to 4 (one bit per part start)
 // The same loop as tkz_bpe_lane with the piece length a run-time value (the heavy kernel gives every missed piece of a

@@ -724,10 +724,11 @@ TKZ_DEV void tkz_load_piece16(const uint8_t* bytes, int64_t total, int64_t abs, 
     for (int i = 0; i < 4; ++i) pw[i] = (uint32_t)((((uint64_t)w[i + 1] << 32) | w[i]) >> sh);
 }
 
-// (LDS: 4 x 5 KB of merge state + 2.5 KB = 22.5 KB per workgroup and 80 VGPRs: six workgroups = 24 wavefronts per CU)
-TKZ_KERNEL_OCC(kMsThreads, 6) void k_merge_short(TkzTables T, EncodeParams P) {
-    constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride;
+// (LDS: 4 x 9.25 KB of merge state + 2.5 KB = 39.5 KB per workgroup, and 128 VGPRs: four workgroups = 16 wavefronts per CU)
+TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
+    constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride, IDSTRIDE = TkzBpeGeom<NMAX>::kIdStride;
     TKZ_SHARED uint4 s_pr_all[kMsThreads / 64][(STRIDE * 64) / 4];        // per lane pr[16] at a conflict-free stride for 16-byte reads
+    TKZ_SHARED uint32_t s_ids_all[kMsThreads / 64][IDSTRIDE * 64];        // per lane ids[16]
     TKZ_SHARED uint32_t s_rec_all[kMsThreads / 64][64];                   // the batch: record, and (sub-tile of the group) << 10 | piece index
     TKZ_SHARED uint16_t s_idx_all[kMsThreads / 64][64];
     TKZ_SHARED int32_t s_brank[256];                                     // id of every single byte: in LDS, not 16 gathers per piece
@@ -738,6 +739,7 @@ TKZ_KERNEL_OCC(kMsThreads, 6) void k_merge_short(TkzTables T, EncodeParams P) {
     if (sub0 >= P.nsub) return;
     uint32_t* s_rec = s_rec_all[wv];
     uint16_t* s_idx = s_idx_all[wv];
+    uint32_t* ids = &s_ids_all[wv][lane * IDSTRIDE];
     uint32_t* pr = reinterpret_cast<uint32_t*>(s_pr_all[wv]) + lane * STRIDE;
     // lane q < kGroup keeps what belongs to sub-tile q of the group: where its records start, how many there are, tokens added by merges
     static_assert(kGroup <= 64, "one lane per sub-tile of the group");
@@ -751,16 +753,16 @@ TKZ_KERNEL_OCC(kMsThreads, 6) void k_merge_short(TkzTables T, EncodeParams P) {
     // gets the token count and where they are
     auto run_batch = [&](int n) {
         (void)simt::ballot(true);
-        int cnt = 0, si = 0, k = 0, rel = 0, e1 = 0, len = 1;
+        int cnt = 0, si = 0, k = 0, rel = 0, e1 = 0;
         uint32_t rec = 0, alive = 1;
-        uint32_t pw[NMAX / 4] = {0, 0, 0, 0};
         if (lane < n) {
             rec = s_rec[lane];
             const uint32_t ix = s_idx[lane];
             si = (int)(ix >> 10); k = (int)(ix & 1023u); rel = (int)(rec & 1023u);
-            len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+            const int len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+            uint32_t pw[NMAX / 4];
             tkz_load_piece16(P.bytes, P.total, (sub0 + si) * kSub + rel, pw);
-            cnt = tkz_bpe_lane_c<NMAX>(T, pw, len, pr, s_brank, &alive, &e1);
+            cnt = tkz_bpe_lane<NMAX>(T, pw, len, ids, pr, s_brank, &alive, &e1);
             err |= e1;
         }
         int btot;
@@ -770,7 +772,7 @@ TKZ_KERNEL_OCC(kMsThreads, 6) void k_merge_short(TkzTables T, EncodeParams P) {
             const bool packed = doff + cnt <= kDenseCap;
             int32_t* dst = packed ? dense + doff : P.tmp + ((sub0 + si) * kSub + rel);
             int i = 0;
-            for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)tkz_bpe_lane_c_id<NMAX>(pw, len, pr, s_brank, alive, tkz_ctz32(a));
+            for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)ids[tkz_ctz32(a)];
             P.prank[pbk + k] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (packed ? (kPrDense | (uint32_t)doff) : (uint32_t)rel);
         }
         dused += btot;
