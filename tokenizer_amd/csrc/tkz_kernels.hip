@@ -616,31 +616,52 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
 #pragma unroll 1
     for (int k0 = 0; k0 < np; k0 += 64 * U) {
         int ps[U], plen[U];
-        uint4 a0[U], a1[U], b0[U], b1[U];
+        uint32_t hs[U];
+        uint4 a0[U], a1[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + 64 * u + lane;
-            ps[u] = 0; plen[u] = 0;
-            uint32_t oa = 0, ob = 0;
+            ps[u] = 0; plen[u] = 0; hs[u] = 0;
+            uint32_t oa = 0;
             if (k < np) {
                 const int s = s_pstart[k];
                 const int64_t len64 = (k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s;
                 const int len = len64 > kArenaPiece ? kArenaPiece + 1 : (int)len64;
                 ps[u] = s; plen[u] = len;
-                if (len <= TKZ_SHORT_KEY_MAX) {
-                    uint32_t s1, s2;
-                    tkz_short_slots(T, tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len, &s1, &s2);
-                    oa = 16u * s1; ob = 16u * s2;
+                if (len <= TKZ_SHORT_KEY_MAX)
+                    oa = 16u * tkz_short_slot_first(T, tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len, &hs[u]);
+            }
+            // the FIRST candidate bucket of every piece (idle lanes and longer pieces gather slot 0: a load inside a divergent branch
+            // is waited for inside it)
+            a0[u] = tkz_load16(tb0 + oa); a1[u] = tkz_load16(tb0 + oa + 16u);
+        }
+        int32_t rk[U];
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int s = ps[u], len = plen[u];
+            const bool is_short = k0 + 64 * u + lane < np && len <= TKZ_SHORT_KEY_MAX;
+            rk[u] = TKZ_RANK_NONE;
+            if (is_short) rk[u] = tkz_match_short2(tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len, a0[u], a1[u]);
+            more = more || (is_short && rk[u] == TKZ_RANK_NONE);
+        }
+        // the second bucket, for the lanes the first one did not settle only (the keys the builder could not keep in their first
+        // bucket, and the pieces that are not keys at all): ~15 % of the requests of the first step instead of another 100 %
+        if (simt::ballot(more)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool want = k0 + 64 * u + lane < np && plen[u] <= TKZ_SHORT_KEY_MAX && rk[u] == TKZ_RANK_NONE;
+                if (want) {
+                    const uint32_t ob = 16u * tkz_short_slot_second(T, hs[u]);
+                    a0[u] = tkz_load16(tb0 + ob); a1[u] = tkz_load16(tb0 + ob + 16u);
                 }
             }
-            // (idle lanes and longer pieces gather slot 0: a load inside a divergent branch is waited for inside it)
-#if defined(TKZ_EXP_LOADS) && TKZ_EXP_LOADS == 2
-            a0[u] = tkz_load16(tb0 + oa); a1[u] = tkz_load16(tb0 + oa + 16u); b0[u] = a0[u]; b1[u] = a1[u];
-#elif defined(TKZ_EXP_LOADS) && TKZ_EXP_LOADS == 1
-            a0[u] = tkz_load16(tb0 + oa); a1[u] = a0[u]; b0[u] = a0[u]; b1[u] = a0[u];
-#else
-            a0[u] = tkz_load16(tb0 + oa); a1[u] = tkz_load16(tb0 + oa + 16u); b0[u] = tkz_load16(tb0 + ob); b1[u] = tkz_load16(tb0 + ob + 16u);
-#endif
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int s = ps[u], len = plen[u];
+                const bool want = k0 + 64 * u + lane < np && len <= TKZ_SHORT_KEY_MAX && rk[u] == TKZ_RANK_NONE;
+                if (want) rk[u] = tkz_match_short2(tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len, a0[u], a1[u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -654,9 +675,7 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
             nmid += tkz_popc64(midm);
             if (valid && !is_mid) {
                 int32_t rank;                                                    // Encoder.TryGetValue(piece) (TikTokenizer.cs:262)
-                if (len <= TKZ_SHORT_KEY_MAX)
-                    rank = tkz_match_short(tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len,
-                                           a0[u], a1[u], b0[u], b1[u]);
+                if (len <= TKZ_SHORT_KEY_MAX) rank = rk[u];
                 else if (len > kArenaPiece) rank = TKZ_RANK_NONE;                // (k_giant_merge looks a giant piece up itself)
                 else if (s + len <= kSub + kHalo) rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)len);
                 else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return gbase[s + i]; }, (uint32_t)len);

@@ -147,6 +147,14 @@ TKZ_HD void tkz_short_slots(const TkzTables& T, uint32_t k0, uint32_t k1, uint32
     const uint32_t h = tkz_hash_short(k0, k1, k2, len, T.short_seed);
     *s1 = 2u * tkz_mulhi(h, T.short_nb); *s2 = 2u * tkz_mulhi(tkz_hash_short2(h), T.short_nb);
 }
+// ... in two steps: the FIRST candidate bucket (the builder puts the keys of the lowest ranks -- the frequent ones -- there whenever it
+// can), and from its hash the second one, which k_probe only fetches for the lanes the first bucket did not settle: a scattered
+// gather costs the memory pipeline one request per lane, and those requests are what k_probe runs out of
+TKZ_HD uint32_t tkz_short_slot_first(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t* h) {
+    *h = tkz_hash_short(k0, k1, k2, len, T.short_seed);
+    return 2u * tkz_mulhi(*h, T.short_nb);
+}
+TKZ_HD uint32_t tkz_short_slot_second(const TkzTables& T, uint32_t h) { return 2u * tkz_mulhi(tkz_hash_short2(h), T.short_nb); }
 TKZ_HD bool tkz_short_slot_is(uint4 v, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
     return v.x == k0 && v.y == k1 && v.z == k2 && (v.w >> TKZ_SHORT_RANK_BITS) == len;
 }
@@ -156,6 +164,11 @@ TKZ_HD int32_t tkz_match_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t l
     if (tkz_short_slot_is(a1, k0, k1, k2, len)) return (int32_t)(a1.w & TKZ_SHORT_RANK_MASK);
     if (tkz_short_slot_is(b0, k0, k1, k2, len)) return (int32_t)(b0.w & TKZ_SHORT_RANK_MASK);
     if (tkz_short_slot_is(b1, k0, k1, k2, len)) return (int32_t)(b1.w & TKZ_SHORT_RANK_MASK);
+    return TKZ_RANK_NONE;
+}
+TKZ_HD int32_t tkz_match_short2(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint4 a0, uint4 a1) {     // one bucket
+    if (tkz_short_slot_is(a0, k0, k1, k2, len)) return (int32_t)(a0.w & TKZ_SHORT_RANK_MASK);
+    if (tkz_short_slot_is(a1, k0, k1, k2, len)) return (int32_t)(a1.w & TKZ_SHORT_RANK_MASK);
     return TKZ_RANK_NONE;
 }
 TKZ_HD int32_t tkz_lookup_short(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {

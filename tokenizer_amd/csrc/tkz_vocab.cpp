@@ -8,6 +8,8 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/tkz.h"
@@ -218,23 +220,69 @@ int build_tables(Vocab* v, std::string* msg) {
                 TkzTables T{}; T.short_nb = nb; T.short_seed = seed;
                 bool ok = true;
                 uint32_t rng = 0x9E3779B9u * seed;
-                for (size_t i = 0; i < nk && ok; ++i) {
+                // k_probe fetches a key's FIRST bucket and the second one only when that did not settle the lookup, so the keys that
+                // occur most -- by construction of a BPE vocabulary the ones of the lowest ranks -- are put into their first bucket
+                // and pinned there (a quarter of the keys, in rank order, as long as a slot is free); the walk never moves them
+                std::vector<size_t> by_rank;
+                for (size_t i = 0; i < nk; ++i) if (!v->keys[i].empty() && v->keys[i].size() <= TKZ_SHORT_KEY_MAX) by_rank.push_back(i);
+                std::sort(by_rank.begin(), by_rank.end(), [&](size_t a, size_t b) { return v->ranks[a] < v->ranks[b]; });
+                std::vector<uint8_t> pinned(size_t(nb) * 2, 0), done_key(nk, 0);
+                auto item_of = [&](size_t i) {
                     const std::string& k = v->keys[i];
-                    if (k.empty() || k.size() > TKZ_SHORT_KEY_MAX) continue;
-                    TkzShortSlot item{load_dword(k, 0), load_dword(k, 4), load_dword(k, 8), uint32_t(v->ranks[i]) | (uint32_t(k.size()) << TKZ_SHORT_RANK_BITS)};
+                    return TkzShortSlot{load_dword(k, 0), load_dword(k, 4), load_dword(k, 8), uint32_t(v->ranks[i]) | (uint32_t(k.size()) << TKZ_SHORT_RANK_BITS)};
+                };
+                for (size_t q = 0; q < by_rank.size() / 16; ++q) {
+                    const TkzShortSlot item = item_of(by_rank[q]);
+                    uint32_t s1, s2;
+                    tkz_short_slots(T, item.k0, item.k1, item.k2, item.rank_len >> TKZ_SHORT_RANK_BITS, &s1, &s2);
+                    for (uint32_t c = s1; c < s1 + 2; ++c)
+                        if (v->short_slots[c].rank_len == 0) { v->short_slots[c] = item; pinned[c] = 1; done_key[by_rank[q]] = 1; break; }
+                }
+                for (size_t q = 0; q < by_rank.size() && ok; ++q) {
+                    if (done_key[by_rank[q]]) continue;
+                    TkzShortSlot item = item_of(by_rank[q]);
                     ok = false;
-                    for (int kick = 0; kick < 2000; ++kick) {
+                    for (int kick = 0; kick < 4000; ++kick) {
                         uint32_t s1, s2;
                         tkz_short_slots(T, item.k0, item.k1, item.k2, item.rank_len >> TKZ_SHORT_RANK_BITS, &s1, &s2);
-                        TkzShortSlot* cand[4] = {&v->short_slots[s1], &v->short_slots[s1 + 1], &v->short_slots[s2], &v->short_slots[s2 + 1]};
+                        const uint32_t cand[4] = {s1, s1 + 1, s2, s2 + 1};
                         bool placed = false;
-                        for (TkzShortSlot* c : cand) if (c->rank_len == 0) { *c = item; placed = true; break; }
+                        for (uint32_t c : cand) if (v->short_slots[c].rank_len == 0) { v->short_slots[c] = item; placed = true; break; }
                         if (placed) { ok = true; break; }
+                        uint32_t movable[4]; int nm = 0;
+                        for (uint32_t c : cand) if (!pinned[c]) movable[nm++] = c;
+                        if (!nm) { for (uint32_t c : cand) { pinned[c] = 0; movable[nm++] = c; } }      // (both buckets pinned: a pin is given up)
                         rng = rng * 1664525u + 1013904223u;
-                        std::swap(item, *cand[(rng >> 16) & 3]);          // random-walk eviction
+                        std::swap(item, v->short_slots[movable[(rng >> 16) % (uint32_t)nm]]);          // random-walk eviction
                     }
                 }
-                if (ok) { v->short_seed = seed; done = true; }
+                if (ok) {
+                    // repair pass, most frequent keys first: a key that ended up in its second bucket moves to the first one when a slot
+                    // is free there, or when one of the two keys in it is a rarer one that has a free slot in its own other bucket
+                    auto slots_of = [&](const TkzShortSlot& it, uint32_t* a, uint32_t* b) { tkz_short_slots(T, it.k0, it.k1, it.k2, it.rank_len >> TKZ_SHORT_RANK_BITS, a, b); };
+                    auto same = [](const TkzShortSlot& x, const TkzShortSlot& y) { return x.k0 == y.k0 && x.k1 == y.k1 && x.k2 == y.k2 && x.rank_len == y.rank_len; };
+                    for (size_t q = 0; q < by_rank.size(); ++q) {
+                        const TkzShortSlot item = item_of(by_rank[q]);
+                        uint32_t s1, s2;
+                        slots_of(item, &s1, &s2);
+                        if (s1 == s2 || same(v->short_slots[s1], item) || same(v->short_slots[s1 + 1], item)) continue;
+                        const uint32_t at = same(v->short_slots[s2], item) ? s2 : s2 + 1;
+                        uint32_t dest = UINT32_MAX;
+                        for (uint32_t c = s1; c < s1 + 2 && dest == UINT32_MAX; ++c) if (v->short_slots[c].rank_len == 0) dest = c;
+                        for (uint32_t c = s1; c < s1 + 2 && dest == UINT32_MAX; ++c) {
+                            const TkzShortSlot occ = v->short_slots[c];
+                            if ((occ.rank_len & TKZ_SHORT_RANK_MASK) <= (item.rank_len & TKZ_SHORT_RANK_MASK)) continue;     // (a more frequent key stays)
+                            uint32_t o1, o2;
+                            slots_of(occ, &o1, &o2);
+                            const uint32_t other = (c & ~1u) == o1 ? o2 : o1;
+                            if (other == (c & ~1u)) continue;
+                            for (uint32_t d = other; d < other + 2; ++d)
+                                if (v->short_slots[d].rank_len == 0) { v->short_slots[d] = occ; dest = c; break; }
+                        }
+                        if (dest != UINT32_MAX) { v->short_slots[dest] = item; v->short_slots[at] = TkzShortSlot{0, 0, 0, 0}; }
+                    }
+                    v->short_seed = seed; done = true;
+                }
             }
             if (done) break;
         }

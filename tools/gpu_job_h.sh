@@ -2,10 +2,10 @@
 # development job: parity subset (merge kernels), the bench line, the mixed shapes
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; TAG=${1:-h}; O=gpurun_out/$TAG; mkdir -p $O
-( time timeout 1200 python -m pytest tests -m gpu -x -q -k "pieces or giant or arena or batch_vs_oracle or dense or corpus_properties or adversarial or vocab_key" ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|Error" $O/pytest_gpu.log | tail -3
+( time timeout 1200 python -m pytest tests -m gpu -x -q -k "pieces or giant or arena or batch_vs_oracle or dense or corpus_properties or adversarial or vocab_key or golden or errors" ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|Error" $O/pytest_gpu.log | tail -3
 timeout 900 python bench.py --no-cpu-baseline > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"
 rm -f $O/bench_shapes.jsonl
-for spec in "--kind 2 --pattern 3 --docs 2000000" "--kind 2 --docs 2000000" "--kind 4 --docs 4000000" "--kind 3 --pattern 3 --docs 32768 --min-len 30000 --max-len 34000"; do
+for spec in "--kind 2 --pattern 3 --docs 2000000" "--kind 2 --docs 2000000" "--kind 4 --docs 4000000" "--kind 3 --pattern 2 --docs 32768 --min-len 30000 --max-len 34000" "--kind 1 --vocab gpt2 --docs 4000000"; do
   timeout 600 python bench.py $spec --no-cpu-baseline --steps 3 --warmup 1 >> $O/bench_shapes.jsonl 2>> $O/bench_shapes.err; echo "shape [$spec] rc=$?"
 done
 python - $TAG <<'P'
