@@ -7,9 +7,10 @@ rocm-smi --showproductname 2>/dev/null | head -8 > $O/gpu.txt; nproc >> $O/gpu.t
 timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log
 timeout 900 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"; cut -c1-300 $O/bench_n1.json
 rm -f $O/bench_shapes.jsonl
-for spec in "--kind 4 --docs 4000000" "--kind 2 --docs 2000000" "--kind 3 --pattern 3 --docs 32768 --min-len 30000 --max-len 34000" "--kind 3 --pattern 2 --docs 32768 --min-len 30000 --max-len 34000" "--kind 2 --pattern 3 --docs 2000000" "--kind 1 --pattern 3" "--kind 1 --pattern 1" "--kind 1 --vocab gpt2"; do
+for spec in "--kind 4 --docs 4000000" "--kind 2 --docs 2000000" "--kind 3 --pattern 3 --docs 32768 --min-len 30000 --max-len 34000" "--kind 3 --pattern 2 --docs 32768 --min-len 30000 --max-len 34000" "--kind 2 --pattern 3 --docs 2000000" "--kind 1 --pattern 3" "--kind 4 --pattern 3 --docs 4000000" "--kind 1 --pattern 1" "--kind 1 --vocab gpt2"; do
   timeout 600 python bench.py $spec --no-cpu-baseline --steps 3 --warmup 1 >> $O/bench_shapes.jsonl 2>> $O/bench_shapes.err; echo "shape [$spec] rc=$?"
 done
-timeout 200 python tools/gpu_fuzz.py 90 > $O/fuzz.log 2>&1; echo "fuzz rc=$?"; tail -2 $O/fuzz.log
+timeout 200 python tools/gpu_fuzz.py 60 > $O/fuzz.log 2>&1; echo "fuzz rc=$?"; tail -2 $O/fuzz.log
+timeout 200 python tools/o200k_scan_fuzz.py --gpu --seeds 20 > $O/o200k_fuzz.log 2>&1; echo "o200k fuzz rc=$?"; tail -7 $O/o200k_fuzz.log
 bash tools/gpu_profile.sh $TAG 10000000 > $O/profile.log 2>&1; echo "profile rc=$?"
 bash tools/gpu_profile.sh ${TAG}_mixed 2000000 "--kind 2" > $O/profile_mixed.log 2>&1; echo "profile mixed rc=$?"
