@@ -43,9 +43,20 @@ TKZ_HD uint32_t tkz_lowmask32(int n) { return n >= 32 ? 0xFFFFFFFFu : ((1u << n)
 // Written for memory-level parallelism: all first-level gathers are issued together (unconditionally: a load inside
 // a lane-divergent branch is waited for inside that branch), and each merge costs ONE round trip to the pair table
 // (both re-ranked pairs, both cuckoo slots of each, in flight together).
+// byte_id(b): id of the single byte b;  pair_rank(b0, b1): rank of the key b0 b1 or TKZ_RANK_NONE -- the caller decides where those come
+// from (k_merge_short keeps the byte ids and the ranks of the lower-case letter pairs in LDS: a gather is a request per lane)
+template <int NMAX, class ByteId, class PairRank>
+TKZ_HD int tkz_bpe_lane_f(const TkzTables& T, const uint32_t* w, int n, uint32_t* ids, uint32_t* pr, ByteId byte_id, PairRank pair_rank,
+                          uint32_t* alive_out, int* err);
 template <int NMAX>
 TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* ids, uint32_t* pr, const int32_t* brank,
                         uint32_t* alive_out, int* err) {
+    return tkz_bpe_lane_f<NMAX>(T, w, n, ids, pr, [&](uint32_t b) -> uint32_t { return (uint32_t)brank[b]; },
+                                [&](uint32_t b0, uint32_t b1) -> int32_t { return T.bytepair_rank[(b0 << 8) | b1]; }, alive_out, err);
+}
+template <int NMAX, class ByteId, class PairRank>
+TKZ_HD int tkz_bpe_lane_f(const TkzTables& T, const uint32_t* w, int n, uint32_t* ids, uint32_t* pr, ByteId byte_id, PairRank pair_rank,
+                          uint32_t* alive_out, int* err) {
     constexpr int SH = TkzBpeGeom<NMAX>::kShift;
     uint4* pr4 = reinterpret_cast<uint4*>(pr);
     // first-level state, 16 bytes at a time (keeps the register footprint of the 32-byte variant that of the 16-byte one)
@@ -58,11 +69,11 @@ TKZ_HD int tkz_bpe_lane(const TkzTables& T, const uint32_t* w, int n, uint32_t* 
         uint32_t idv[16], prv[16];
         int32_t r2[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) idv[k] = (uint32_t)brank[bk[k]];                         // parts = single bytes
+        for (int k = 0; k < 16; ++k) idv[k] = byte_id(bk[k]);                                 // parts = single bytes
         // initial pair ranks (:37-44): only the pairs the piece has (every gather is a request to the memory pipeline, and those
         // requests -- not bytes, not flops -- are what the merge kernels are made of)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) r2[k] = (16 * c + k + 1 < n) ? T.bytepair_rank[(bk[k] << 8) | bk[k + 1]] : TKZ_RANK_NONE;
+        for (int k = 0; k < 16; ++k) r2[k] = (16 * c + k + 1 < n) ? pair_rank(bk[k], bk[k + 1]) : TKZ_RANK_NONE;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int g = 16 * c + k;

@@ -728,16 +728,24 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
     if (pb + np > P.prank_cap && lane == 0) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
 }
 
-// five aligned dwords around byte position `abs` of the corpus -> the 16 bytes that start there, as four little-endian dwords
+// the 16 bytes of the corpus that start at byte position `abs`, as four little-endian dwords: the five dwords around them are fetched
+// with TWO requests per lane (16 + 4 bytes from the dword-aligned address; a scattered gather costs a request per lane and instruction)
+struct alignas(4) TkzDwords4 { uint32_t x, y, z, w; };
 TKZ_DEV void tkz_load_piece16(const uint8_t* bytes, int64_t total, int64_t abs, uint32_t* pw) {
     const int64_t a0 = abs & ~(int64_t)3;
     const int sh = (int)(abs & 3) * 8;
     uint32_t w[5];
+    if (a0 + 20 <= total) {
+        const TkzDwords4 v = *reinterpret_cast<const TkzDwords4*>(bytes + a0);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        w[4] = *reinterpret_cast<const uint32_t*>(bytes + a0 + 16);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int64_t p = a0 + 4 * i;
-        if (p + 4 <= total) w[i] = *reinterpret_cast<const uint32_t*>(bytes + p);
-        else { w[i] = 0; for (int j = 0; j < 4; ++j) if (p + j < total) w[i] |= (uint32_t)bytes[p + j] << (8 * j); }
+        for (int i = 0; i < 5; ++i) {
+            const int64_t p = a0 + 4 * i;
+            if (p + 4 <= total) w[i] = *reinterpret_cast<const uint32_t*>(bytes + p);
+            else { w[i] = 0; for (int j = 0; j < 4; ++j) if (p + j < total) w[i] |= (uint32_t)bytes[p + j] << (8 * j); }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) pw[i] = (uint32_t)((((uint64_t)w[i + 1] << 32) | w[i]) >> sh);
@@ -748,15 +756,34 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride, IDSTRIDE = TkzBpeGeom<NMAX>::kIdStride;
     TKZ_SHARED uint4 s_pr_all[kMsThreads / 64][(STRIDE * 64) / 4];        // per lane pr[16] at a conflict-free stride for 16-byte reads
     TKZ_SHARED uint32_t s_ids_all[kMsThreads / 64][IDSTRIDE * 64];        // per lane ids[16]
-    TKZ_SHARED uint32_t s_rec_all[kMsThreads / 64][64];                   // the batch: record, and (sub-tile of the group) << 10 | piece index
+    TKZ_SHARED uint16_t s_rec_all[kMsThreads / 64][64];                   // the batch: relpos | (len-1) << 10 | mark << 14, and (sub-tile of the group) << 10 | piece index
     TKZ_SHARED uint16_t s_idx_all[kMsThreads / 64][64];
-    TKZ_SHARED int32_t s_brank[256];                                     // id of every single byte: in LDS, not 16 gathers per piece
+    // in LDS, not gathers: the id of every single byte (0xFFFF: not a key, 0xFFFE: too large for 16 bits, look it up) and the rank of the key
+    // made of two lower-case ASCII letters (0xFFFF: no such key or too large, look it up) -- most first-level pairs of the missed pieces
+    TKZ_SHARED uint16_t s_brank16[256];
+    TKZ_SHARED uint16_t s_lc[26 * 26];
     const int lane = simt::lane(), wv = simt::wave();
-    for (int i = simt::tid(); i < 256; i += simt::nthreads()) s_brank[i] = T.byte_rank[i];
+    for (int i = simt::tid(); i < 256; i += simt::nthreads()) {
+        const uint32_t v = (uint32_t)T.byte_rank[i];
+        s_brank16[i] = (uint16_t)(v >= (uint32_t)TKZ_PSEUDO_BASE ? 0xFFFFu : (v < 0xFFFEu ? v : 0xFFFEu));
+    }
+    for (int i = simt::tid(); i < 26 * 26; i += simt::nthreads()) {
+        const int32_t r = T.bytepair_rank[(('a' + i / 26) << 8) | ('a' + i % 26)];
+        s_lc[i] = (uint16_t)((r != TKZ_RANK_NONE && r < 0xFFFF) ? r : 0xFFFF);
+    }
     simt::sync();
+    auto byte_id = [&](uint32_t b) -> uint32_t {
+        const uint32_t v = s_brank16[b];
+        return v < 0xFFFEu ? v : (v == 0xFFFFu ? (uint32_t)TKZ_PSEUDO_BASE + b : (uint32_t)T.byte_rank[b]);
+    };
+    auto pair_rank = [&](uint32_t b0, uint32_t b1) -> int32_t {
+        const uint32_t i0 = b0 - 'a', i1 = b1 - 'a';
+        const uint32_t v = (i0 < 26u && i1 < 26u) ? (uint32_t)s_lc[i0 * 26u + i1] : 0xFFFFu;
+        return v != 0xFFFFu ? (int32_t)v : T.bytepair_rank[(b0 << 8) | b1];
+    };
     const int64_t sub0 = (simt::bid() * (kMsThreads / 64) + wv) * kGroup;
     if (sub0 >= P.nsub) return;
-    uint32_t* s_rec = s_rec_all[wv];
+    uint16_t* s_rec = s_rec_all[wv];
     uint16_t* s_idx = s_idx_all[wv];
     uint32_t* ids = &s_ids_all[wv][lane * IDSTRIDE];
     uint32_t* pr = reinterpret_cast<uint32_t*>(s_pr_all[wv]) + lane * STRIDE;
@@ -775,13 +802,14 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
         int cnt = 0, si = 0, k = 0, rel = 0, e1 = 0;
         uint32_t rec = 0, alive = 1;
         if (lane < n) {
-            rec = s_rec[lane];
+            const uint32_t r16 = s_rec[lane];
+            rec = kPrMiss | ((r16 >> 14) & 1u ? kPrMark : 0u);
             const uint32_t ix = s_idx[lane];
-            si = (int)(ix >> 10); k = (int)(ix & 1023u); rel = (int)(rec & 1023u);
-            const int len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+            si = (int)(ix >> 10); k = (int)(ix & 1023u); rel = (int)(r16 & 1023u);
+            const int len = (int)((r16 >> 10) & 15u) + 1;
             uint32_t pw[NMAX / 4];
             tkz_load_piece16(P.bytes, P.total, (sub0 + si) * kSub + rel, pw);
-            cnt = tkz_bpe_lane<NMAX>(T, pw, len, ids, pr, s_brank, &alive, &e1);
+            cnt = tkz_bpe_lane_f<NMAX>(T, pw, len, ids, pr, byte_id, pair_rank, &alive, &e1);
             err |= e1;
         }
         int btot;
@@ -820,7 +848,11 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
                 const int c = tkz_popc64(m);
                 if (c == 0) continue;
                 if (nlist + c > 64) { run_batch(nlist); nlist = 0; }
-                if (is) { const int o = nlist + tkz_popc64(m & tkz_lowmask(lane)); s_rec[o] = rec; s_idx[o] = (uint16_t)((si << 10) | (k0 + 64 * j + lane)); }
+                if (is) {
+                    const int o = nlist + tkz_popc64(m & tkz_lowmask(lane));
+                    s_rec[o] = (uint16_t)((rec & 1023u) | (((rec >> kPrLenShift) & 15u) << 10) | ((rec & kPrMark) ? 1u << 14 : 0u));
+                    s_idx[o] = (uint16_t)((si << 10) | (k0 + 64 * j + lane));
+                }
                 nlist += c;
             }
         }
