@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--vocab", default=None, help="gpt2 | synth100k | synth200k (default: the stand-in of the pattern's vocabulary)")
     ap.add_argument("--cpu-sample-docs", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-memo", action="store_true", help="switch the piece memo (the device form of the reference's LRUCache) off")
     ap.add_argument("--write-shards", default=None, metavar="DIR", help="after the timed loop every rank writes its token shard file (SURVEY 8f-2)")
     args = ap.parse_args()
 
@@ -191,6 +192,25 @@ def main():
     d_ids = torch.empty(total, dtype=torch.int32, device=dev)          # tokens <= bytes: always enough
     d_ooffs = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
 
+    # The piece memo is part of the hot path (the reference's LRUCache, TikTokenizer.cs:254,270) and persists from call to call, like the
+    # reference's.  So that the timed steps do not meet a memo filled by THEMSELVES, the warm-up steps encode OTHER documents of the same
+    # generator (the range behind every rank's own); the timed steps then run on the bench batch with the memo as those left it.
+    memo_note = "off"
+    warm = None
+    if args.no_memo:
+        enc.set_option(N.OPT_PIECE_MEMO, 0)
+    elif seed is not None:
+        w_first = (world + rank) * n_docs
+        w_offs = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
+        w_total = N.corpus_generate_device(local_rank, args.kind, seed, w_first, n_docs, args.min_len, args.max_len, w_offs.data_ptr(), None, 0, stream)
+        w_bytes = torch.empty(w_total + 64, dtype=torch.uint8, device=dev)
+        N.corpus_generate_device(local_rank, args.kind, seed, w_first, n_docs, args.min_len, args.max_len, w_offs.data_ptr(), w_bytes.data_ptr(), w_total, stream)
+        w_ids = torch.empty(w_total, dtype=torch.int32, device=dev)
+        warm = (w_bytes, w_offs, w_total, w_ids)
+        memo_note = "on: 65,536 slots, filled during the warm-up steps from %d OTHER documents of the same generator (documents %d..)" % (n_docs, w_first)
+    else:
+        memo_note = "on: 65,536 slots, filled during the warm-up steps from the same tiled text (every piece of it repeats)"
+
     def step():
         ntok = enc.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total,
                                        d_ooffs.data_ptr(), stream)
@@ -204,7 +224,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        ntok = step()
+        if warm is not None:
+            enc.encode_batch_device(warm[0].data_ptr(), warm[1].data_ptr(), n_docs, warm[2], warm[3].data_ptr(), warm[2], d_ooffs.data_ptr(), stream)
+        else:
+            ntok = step()
+    if warm is not None:       # (after 5 GB of other documents every memo slot is taken: the timed steps cannot add entries of their own)
+        del warm, w_bytes, w_offs, w_ids
+        torch.cuda.empty_cache()
     enc.set_profiling(True)
     enc.kernel_ms(reset=True)
     fence()
@@ -353,6 +379,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workloads[args.kind] % (n_docs, args.min_len, args.max_len, job_bytes / max(1, job_docs)),
                        "pattern": {1: "pattern 1 (gpt2 / r50k / p50k)", 2: "cl100k_base", 3: "o200k_base"}[args.pattern],
+                       "piece_memo": memo_note,
                        "vocab": vocab_name, "vocab_keys": len(vocab), "docs_per_gpu": n_docs, "bytes_per_gpu": total, "tokens_per_gpu": n_tokens_rank,
                        "job_docs": job_docs, "job_bytes": job_bytes, "job_tokens": job_tokens,
                        "partitioning": "contiguous document ranges, one process per GPU; one all-gather of 3 int64 counts per rank per step"},

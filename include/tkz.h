@@ -211,7 +211,12 @@ tkz_status tkz_encode_pieces(tkz_encoder* e, const uint8_t* bytes, const int64_t
 
 /* Options.  TKZ_OPT_PRETOK_SEQUENTIAL: 1 = split with the one-lane-per-document scanner instead of
  * the position-parallel one; both must give identical bitmaps. */
-enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1 };
+enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1,
+       /* The piece memo: the device form of the reference's LRUCache (LRUCache.cs, used at TikTokenizer.cs:254,270): pieces of up to 16
+        * bytes that had to be merged leave their (up to 4) tokens in a 65,536-slot table on the device and later batches take them from
+        * there instead of running BytePairEncode again.  A pure memo: ids are identical with and without it.  Value 0 = off, 1 = on
+        * (default), 2 = on and emptied. */
+       TKZ_OPT_PIECE_MEMO = 2 };
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value);
 
 /* ---- measurement ------------------------------------------------------------------------- */

@@ -113,6 +113,8 @@ inline int scan_inclusive(int v) {
 inline int last_lane(int v) { return (int)(uint32_t)hipemu::wave_exchange((uint32_t)v)[63]; }
 inline int atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomic_or(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+inline unsigned atomic_cas(unsigned* p, unsigned expect, unsigned v) { unsigned o = *p; if (o == expect) *p = v; return o; }
+inline void fence() {}
 inline unsigned long long atomic_or64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }
 inline unsigned long long atomic_add64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
 inline long long clock() { return 0; }

@@ -301,6 +301,42 @@ def check_dense_region(lib, O, vocab, ovocab, pattern=N.CL100K, seed=17):
     assert ooff.tolist() == eoff and ids.tolist() == exp
 
 
+def check_piece_memo(lib, O, vocab, ovocab, pattern=N.CL100K, seed=23):
+    """The piece memo (TKZ_OPT_PIECE_MEMO): the same ids with the memo off, empty, filled by an earlier batch of the same text (every
+    short miss a hit), and filled by OTHER text (hits and misses mixed, slots already taken by other pieces)."""
+    rng = random.Random(seed)
+    cons, vow = "bcdfghjklmnpqrstvwxz", "aeiou"
+
+    def words(n, r):           # pronounceable non-words: they miss the vocabulary, merge to 2..5 tokens, and repeat
+        lex = ["".join(r.choice(cons) + r.choice(vow) for _ in range(r.randint(2, 4))) + r.choice(["", "s", "ed", "ing"]) for _ in range(300)]
+        out = []
+        while sum(map(len, out)) < n:
+            out.append(r.choice([" ", " ", "\n", " the "]) + r.choice(lex))
+        return "".join(out)[:n]
+
+    docs_a = [words(rng.choice([500, 3000, 9000]), random.Random(seed + 1)).encode("utf-8") for _ in range(6)]
+    docs_b = [words(rng.choice([500, 3000, 9000]), random.Random(seed + 2)).encode("utf-8") for _ in range(6)]
+    oenc = O.Encoder(ovocab, pattern)
+    exp_a, eoff_a = oracle_encode_docs(oenc, docs_a)
+    exp_b, eoff_b = oracle_encode_docs(oenc, docs_b)
+    enc = N.Encoder(vocab, pattern)
+
+    def run(docs, exp, eoff, what):
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        assert ooff.tolist() == eoff and ids.tolist() == exp, what
+
+    enc.set_option(N.OPT_PIECE_MEMO, 0)
+    run(docs_a, exp_a, eoff_a, "memo off")
+    enc.set_option(N.OPT_PIECE_MEMO, 2)
+    run(docs_a, exp_a, eoff_a, "memo empty")
+    run(docs_a, exp_a, eoff_a, "memo filled by the same text")
+    run(docs_b, exp_b, eoff_b, "memo filled by other text")
+    run(docs_a, exp_a, eoff_a, "memo filled by both")
+    enc.set_option(N.OPT_PIECE_MEMO, 0)
+    run(docs_b, exp_b, eoff_b, "memo off again")
+
+
 def check_errors(lib, O, vocab):
     enc = N.Encoder(vocab, N.CL100K)
     import pytest

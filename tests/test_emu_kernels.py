@@ -116,6 +116,13 @@ def test_pieces_vs_oracle_bpe(lib, vocabs, oracle_mod, vname):
 
 
 @pytest.mark.parametrize("vname", ["gpt2", "synth100k"])
+def test_piece_memo(lib, vocabs, oracle_mod, vname):
+    v, ov = vocabs(vname)
+    parity.check_piece_memo(lib, oracle_mod, v, ov)
+    parity.check_piece_memo(lib, oracle_mod, v, ov, pattern=N.O200K, seed=31)
+
+
+@pytest.mark.parametrize("vname", ["gpt2", "synth100k"])
 def test_dense_token_region(lib, vocabs, oracle_mod, vname):
     v, ov = vocabs(vname)
     for seed in (17, 18):

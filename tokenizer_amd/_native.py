@@ -14,6 +14,7 @@ OK = 0
 E_FORMAT, E_DUP_RANK, E_KEY_NOT_FOUND, E_CAPACITY, E_INVALID_UTF8, E_ARG, E_UNSUPPORTED, E_DEVICE, E_NO_DEVICE, E_OUT_OF_MEMORY = range(-1, -11, -1)
 P1, CL100K, O200K = 1, 2, 3
 OPT_PRETOK_SEQUENTIAL = 1
+OPT_PIECE_MEMO = 2
 K_NAMES = ["k_docmark", "k_pretok", "k_probe", "k_scan", "k_place", "k_docoffs", "k_merge_long_group", "k_merge_short"]
 
 

@@ -132,7 +132,8 @@ struct tkz_encoder {
     std::mutex mu;                         // the workspace pool, the decoder table
     std::vector<Workspace*> pool;
     // device tables (read-only once built)
-    DevBuf t_short, t_mid, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp, t_counts3;
+    DevBuf t_short, t_mid, t_long, t_blob, t_pair, t_byte, t_bpair, t_bmp, t_counts3, t_memo;
+    uint32_t memo_slots = 0;               // the piece memo (tkz_tables.h); TKZ_OPT_PIECE_MEMO switches its use
     TkzTables T{};
     // Decode: id -> bytes (vocabulary keys + registered special tokens), rebuilt when the special tokens change
     DevBuf t_decoff, t_decblob, t_decids;
@@ -623,6 +624,14 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     e->T.byte_rank = e->t_byte.as<int32_t>();
     e->T.bytepair_rank = e->t_bpair.as<int32_t>();
     e->T.bmp_class = e->t_bmp.as<uint8_t>();
+    {   // the piece memo: 65,536 slots of 32 bytes, empty
+        constexpr uint32_t kMemoSlots = 1u << 16;
+        h = e->t_memo.ensure(size_t(kMemoSlots) * sizeof(TkzMemoSlot), acc);
+        if (h == hipSuccess) h = hipMemset(e->t_memo.p, 0, size_t(kMemoSlots) * sizeof(TkzMemoSlot));
+        if (h != hipSuccess) { tkz_encoder_destroy(e); return fail(TKZ_E_OUT_OF_MEMORY, std::string("piece memo: ") + hipGetErrorString(h)); }
+        e->memo_slots = kMemoSlots;
+        e->T.memo = e->t_memo.as<TkzMemoSlot>(); e->T.memo_n = kMemoSlots;
+    }
     e->T.max_key_len = V.max_key_len;
     e->T.pattern = pattern;
     e->T.max_rank = 0;
@@ -911,6 +920,17 @@ tkz_status tkz_decode_batch(tkz_encoder* e, const int32_t* ids, const int64_t* i
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value) {
     if (!e) return fail(TKZ_E_ARG, "null encoder");
     if (option == TKZ_OPT_PRETOK_SEQUENTIAL) { e->pretok_seq = value != 0; return TKZ_OK; }
+    if (option == TKZ_OPT_PIECE_MEMO) {
+        // 0: off, 1: on, 2: on and emptied (calls in flight on other threads are not waited for: they may still fill a few slots)
+        DeviceScope scope;
+        if (value == 2) {
+            tkz_status st = check_encoder(e, scope);
+            if (st != TKZ_OK) return st;
+            if (hipMemset(e->t_memo.p, 0, size_t(e->memo_slots) * sizeof(TkzMemoSlot)) != hipSuccess) return fail(TKZ_E_DEVICE, "hipMemset");
+        }
+        e->T.memo_n = value ? e->memo_slots : 0u;
+        return TKZ_OK;
+    }
     return fail(TKZ_E_ARG, "unknown option");
 }
 

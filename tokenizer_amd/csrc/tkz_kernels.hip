@@ -751,81 +751,142 @@ TKZ_DEV void tkz_load_piece16(const uint8_t* bytes, int64_t total, int64_t abs, 
     for (int i = 0; i < 4; ++i) pw[i] = (uint32_t)((((uint64_t)w[i + 1] << 32) | w[i]) >> sh);
 }
 
-// (LDS: 4 x 9.25 KB of merge state + 2.5 KB = 39.5 KB per workgroup, and 128 VGPRs: four workgroups = 16 wavefronts per CU)
+// a DENSE record (tokens of a merged short piece in the group's packed region): count - 1 in bits 10..13, offset in bits 0..9 and 14..20
+TKZ_HD uint32_t tkz_dense_rec(int cnt, int off) {
+    return kPrDense | ((uint32_t)(cnt - 1) << kPrLenShift) | ((uint32_t)off & 1023u) | (((uint32_t)off >> 10) << 14);
+}
+TKZ_HD int tkz_dense_off(uint32_t rec) { return (int)((rec & 1023u) | (((rec >> 14) & 0x7Fu) << 10)); }
+TKZ_HD int tkz_dense_cnt(uint32_t rec) { return (int)((rec >> kPrLenShift) & 15u) + 1; }
+static_assert(kDenseCap <= (1 << 17), "the offset field of a DENSE record");
+
+// k_merge_short: one wavefront per group of kGroup = 16 sub-tiles.  It streams the group's records and collects the misses of <= 16
+// bytes in a 64-entry list; whenever the list is full the entries that have not been looked up yet go through the PIECE MEMO (the
+// device form of the reference's LRUCache, tkz_tables.h): a hit has its <= 4 tokens at once, the survivors stay in the list, and only
+// when the list is full of survivors are 64 of them merged, one per lane (BytePairEncode, TikTokenizer.cs:268).  Merged pieces of <= 4
+// tokens claim their memo slot if it is empty.  On the bench corpus 3 of 4 missed pieces are memo hits: a merge costs ~45 scattered
+// gathers and ~8 dependent round trips, a memo lookup 4 and one.
+// (LDS: 4 x 9.25 KB of merge state + 1.8 KB = 39.7 KB per workgroup, and <= 128 VGPRs: four workgroups = 16 wavefronts per CU)
 TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride, IDSTRIDE = TkzBpeGeom<NMAX>::kIdStride;
     TKZ_SHARED uint4 s_pr_all[kMsThreads / 64][(STRIDE * 64) / 4];        // per lane pr[16] at a conflict-free stride for 16-byte reads
     TKZ_SHARED uint32_t s_ids_all[kMsThreads / 64][IDSTRIDE * 64];        // per lane ids[16]
-    TKZ_SHARED uint16_t s_rec_all[kMsThreads / 64][64];                   // the batch: relpos | (len-1) << 10 | mark << 14, and (sub-tile of the group) << 10 | piece index
+    // the list: relpos | (len-1) << 10 | mark << 14 | looked-up-in-the-memo << 15, and (sub-tile of the group) << 10 | piece index
+    TKZ_SHARED uint16_t s_rec_all[kMsThreads / 64][64];
     TKZ_SHARED uint16_t s_idx_all[kMsThreads / 64][64];
-    // in LDS, not gathers: the id of every single byte (0xFFFF: not a key, 0xFFFE: too large for 16 bits, look it up) and the rank of the key
-    // made of two lower-case ASCII letters (0xFFFF: no such key or too large, look it up) -- most first-level pairs of the missed pieces
+    TKZ_SHARED int s_extra_all[kMsThreads / 64][kGroup];                  // tokens the merges added to every sub-tile of the group
+    // the id of every single byte in LDS, not 16 gathers per piece (0xFFFF: not a key, 0xFFFE: too large for 16 bits, look it up)
     TKZ_SHARED uint16_t s_brank16[256];
-    TKZ_SHARED uint16_t s_lc[26 * 26];
     const int lane = simt::lane(), wv = simt::wave();
     for (int i = simt::tid(); i < 256; i += simt::nthreads()) {
         const uint32_t v = (uint32_t)T.byte_rank[i];
         s_brank16[i] = (uint16_t)(v >= (uint32_t)TKZ_PSEUDO_BASE ? 0xFFFFu : (v < 0xFFFEu ? v : 0xFFFEu));
-    }
-    for (int i = simt::tid(); i < 26 * 26; i += simt::nthreads()) {
-        const int32_t r = T.bytepair_rank[(('a' + i / 26) << 8) | ('a' + i % 26)];
-        s_lc[i] = (uint16_t)((r != TKZ_RANK_NONE && r < 0xFFFF) ? r : 0xFFFF);
     }
     simt::sync();
     auto byte_id = [&](uint32_t b) -> uint32_t {
         const uint32_t v = s_brank16[b];
         return v < 0xFFFEu ? v : (v == 0xFFFFu ? (uint32_t)TKZ_PSEUDO_BASE + b : (uint32_t)T.byte_rank[b]);
     };
-    auto pair_rank = [&](uint32_t b0, uint32_t b1) -> int32_t {
-        const uint32_t i0 = b0 - 'a', i1 = b1 - 'a';
-        const uint32_t v = (i0 < 26u && i1 < 26u) ? (uint32_t)s_lc[i0 * 26u + i1] : 0xFFFFu;
-        return v != 0xFFFFu ? (int32_t)v : T.bytepair_rank[(b0 << 8) | b1];
-    };
+    auto pair_rank = [&](uint32_t b0, uint32_t b1) -> int32_t { return T.bytepair_rank[(b0 << 8) | b1]; };
     const int64_t sub0 = (simt::bid() * (kMsThreads / 64) + wv) * kGroup;
     if (sub0 >= P.nsub) return;
     uint16_t* s_rec = s_rec_all[wv];
     uint16_t* s_idx = s_idx_all[wv];
+    int* s_extra = s_extra_all[wv];
     uint32_t* ids = &s_ids_all[wv][lane * IDSTRIDE];
     uint32_t* pr = reinterpret_cast<uint32_t*>(s_pr_all[wv]) + lane * STRIDE;
-    // lane q < kGroup keeps what belongs to sub-tile q of the group: where its records start, how many there are, tokens added by merges
-    static_assert(kGroup <= 64, "one lane per sub-tile of the group");
-    int64_t my_pb = 0; int my_np = 0, my_extra = 0;
+    // lane q < kGroup keeps what belongs to sub-tile q of the group: where its records start and how many there are
+    static_assert(kGroup <= 64 && kGroup * 1024 <= 65536, "one lane per sub-tile of the group; (sub-tile, piece) in 16 bits");
+    int64_t my_pb = 0; int my_np = 0;
     if (lane < kGroup && sub0 + lane < P.nsub) { my_pb = P.pbase[sub0 + lane]; my_np = P.pcount[sub0 + lane]; }
+    if (lane < kGroup) s_extra[lane] = 0;
     auto pb_of = [&](int q) -> int64_t { return ((int64_t)simt::shfl((int)(my_pb >> 32), q) << 32) | (uint32_t)simt::shfl((int)my_pb, q); };
-    int err = 0, nlist = 0, dused = 0;
+    int err = 0, nlist = 0, nchk = 0, dused = 0;              // list entries [0, nchk) have been through the memo, [nchk, nlist) not yet
     int32_t* const dense = P.dense + (sub0 / kGroup) * kDenseCap;
-    // one batch: lane i < n merges the piece of list entry i (BytePairEncode, TikTokenizer.cs:268); its tokens are packed behind those
-    // of the pieces before it in the group's dense region (in tmp, at the piece's own byte position, once that is full), its record
-    // gets the token count and where they are
-    auto run_batch = [&](int n) {
-        (void)simt::ballot(true);
-        int cnt = 0, si = 0, k = 0, rel = 0, e1 = 0;
-        uint32_t rec = 0, alive = 1;
-        if (lane < n) {
-            const uint32_t r16 = s_rec[lane];
-            rec = kPrMiss | ((r16 >> 14) & 1u ? kPrMark : 0u);
-            const uint32_t ix = s_idx[lane];
-            si = (int)(ix >> 10); k = (int)(ix & 1023u); rel = (int)(r16 & 1023u);
-            const int len = (int)((r16 >> 10) & 15u) + 1;
-            uint32_t pw[NMAX / 4];
-            tkz_load_piece16(P.bytes, P.total, (sub0 + si) * kSub + rel, pw);
-            cnt = tkz_bpe_lane_f<NMAX>(T, pw, len, ids, pr, byte_id, pair_rank, &alive, &e1);
-            err |= e1;
-        }
+    const bool memo = T.memo_n != 0;
+    // where the `cnt` tokens of a piece go -- packed behind those of the pieces before it in the group's dense region (in tmp, at the
+    // piece's own byte position, once that is full) -- and its record; every lane of the wavefront calls it (a scan and a shuffle inside)
+    auto assign = [&](bool have, int cnt, int si, int k, int rel, bool mark) -> int32_t* {
         int btot;
-        const int doff = dused + tkz_wave_scan_sum(cnt, &btot);
-        const int64_t pbk = pb_of(si);                         // (a shuffle: every lane takes part)
-        if (lane < n) {
+        const int doff = dused + tkz_wave_scan_sum(have ? cnt : 0, &btot);
+        const int64_t pbk = pb_of(si);
+        int32_t* dst = nullptr;
+        if (have) {
             const bool packed = doff + cnt <= kDenseCap;
-            int32_t* dst = packed ? dense + doff : P.tmp + ((sub0 + si) * kSub + rel);
-            int i = 0;
-            for (uint32_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)ids[tkz_ctz32(a)];
-            P.prank[pbk + k] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (packed ? (kPrDense | (uint32_t)doff) : (uint32_t)rel);
+            dst = packed ? dense + doff : P.tmp + ((sub0 + si) * kSub + rel);
+            P.prank[pbk + k] = kPrMiss | (mark ? kPrMark : 0u) | kPrDone | (packed ? tkz_dense_rec(cnt, doff) : (((uint32_t)(cnt - 1) << kPrLenShift) | (uint32_t)rel));
+            if (cnt > 1) simt::atomic_add(&s_extra[si], cnt - 1);
         }
         dused += btot;
-        const int cnt1 = lane < n ? cnt - 1 : 0;
+        return dst;
+    };
+    // the piece of a list entry: its 16 bytes, zeroed beyond its length (the memo key)
+    auto load_key = [&](int si, int rel, int len, uint32_t* kw) {
+        tkz_load_piece16(P.bytes, P.total, (sub0 + si) * kSub + rel, kw);
 #pragma unroll
-        for (int q = 0; q < kGroup; ++q) { int tot; (void)tkz_wave_scan<4>((lane < n && si == q) ? cnt1 : 0, &tot); if (lane == q) my_extra += tot; }
+        for (int i = 0; i < 4; ++i) { const int nb = len - 4 * i; kw[i] = nb >= 4 ? kw[i] : (nb <= 0 ? 0u : (kw[i] & ((1u << (8 * nb)) - 1u))); }
+    };
+    // the entries that have not been through the memo: hits are done (tokens, record), the others stay in the list, in order
+    auto memo_phase = [&]() {
+        (void)simt::ballot(true);
+        uint32_t r16 = 0, ix = 0;
+        if (lane < nlist) { r16 = s_rec[lane]; ix = s_idx[lane]; }
+        const bool mine = lane >= nchk && lane < nlist;
+        const int si = (int)(ix >> 10), k = (int)(ix & 1023u), rel = (int)(r16 & 1023u), len = (int)((r16 >> 10) & 15u) + 1;
+        bool hit = false;
+        uint4 vv; vv.x = vv.y = vv.z = vv.w = 0;
+        if (mine && memo) {
+            uint32_t kw[4];
+            load_key(si, rel, len, kw);
+            const TkzMemoSlot* slot = &T.memo[tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), T.memo_n)];
+            const uint4 kk = tkz_load16(&slot->k[0]);
+            vv = tkz_load16(&slot->v[0]);
+            hit = (vv.x & kMemoValid) && vv.x != kMemoBusy && kk.x == kw[0] && kk.y == kw[1] && kk.z == kw[2] && kk.w == kw[3] && (vv.y >> 27) == (uint32_t)(len - 1);
+        }
+        const int cnt = hit ? (int)((vv.x >> 29) & 3u) + 1 : 0;
+        int32_t* dst = assign(hit, cnt, si, k, rel, ((r16 >> 14) & 1u) != 0);
+        if (hit) {
+            dst[0] = (int32_t)(vv.x & 0x07FFFFFFu);
+            if (cnt > 1) dst[1] = (int32_t)(vv.y & 0x07FFFFFFu);
+            if (cnt > 2) dst[2] = (int32_t)vv.z;
+            if (cnt > 3) dst[3] = (int32_t)vv.w;
+        }
+        const bool keep = lane < nchk || (mine && !hit);
+        const uint64_t km = simt::ballot(keep);
+        if (keep) { const int o = tkz_popc64(km & tkz_lowmask(lane)); s_rec[o] = (uint16_t)(r16 | 0x8000u); s_idx[o] = (uint16_t)ix; }
+        nlist = nchk = tkz_popc64(km);
+        (void)simt::ballot(true);
+    };
+    // one batch: lane i < n merges the piece of list entry i (all of them have missed the memo)
+    auto run_batch = [&](int n) {
+        (void)simt::ballot(true);
+        int cnt = 0, si = 0, k = 0, rel = 0, e1 = 0, len = 1;
+        bool mark = false;
+        uint32_t alive = 1;
+        uint32_t kw[4] = {0, 0, 0, 0};
+        if (lane < n) {
+            const uint32_t r16 = s_rec[lane], ix = s_idx[lane];
+            si = (int)(ix >> 10); k = (int)(ix & 1023u); rel = (int)(r16 & 1023u); len = (int)((r16 >> 10) & 15u) + 1; mark = ((r16 >> 14) & 1u) != 0;
+            load_key(si, rel, len, kw);
+            cnt = tkz_bpe_lane_f<NMAX>(T, kw, len, ids, pr, byte_id, pair_rank, &alive, &e1);
+            err |= e1;
+        }
+        int32_t* dst = assign(lane < n, cnt, si, k, rel, mark);
+        if (lane < n) {
+            uint32_t t4[4] = {0, 0, 0, 0};
+            int i = 0;
+            for (uint32_t a = alive; a; a &= a - 1) { const uint32_t t = ids[tkz_ctz32(a)]; dst[i] = (int32_t)t; if (i < 4) { if (i == 0) t4[0] = t; else if (i == 1) t4[1] = t; else if (i == 2) t4[2] = t; else t4[3] = t; } ++i; }
+            // a piece of <= 4 tokens takes its memo slot if nobody has (an entry is never replaced: a hit stays valid for good)
+            if (memo && cnt <= 4 && !e1) {
+                TkzMemoSlot* slot = &T.memo[tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), T.memo_n)];
+                if (simt::atomic_cas(&slot->v[0], 0u, kMemoBusy) == 0u) {
+                    uint4 kk; kk.x = kw[0]; kk.y = kw[1]; kk.z = kw[2]; kk.w = kw[3];
+                    *reinterpret_cast<uint4*>(&slot->k[0]) = kk;
+                    slot->v[1] = ((uint32_t)(len - 1) << 27) | t4[1]; slot->v[2] = t4[2]; slot->v[3] = t4[3];
+                    simt::fence();
+                    *reinterpret_cast<volatile uint32_t*>(&slot->v[0]) = kMemoValid | ((uint32_t)(cnt - 1) << 29) | t4[0];
+                }
+            }
+        }
         (void)simt::ballot(true);
     };
 #pragma unroll 1
@@ -847,7 +908,10 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
                 const uint64_t m = simt::ballot(is);
                 const int c = tkz_popc64(m);
                 if (c == 0) continue;
-                if (nlist + c > 64) { run_batch(nlist); nlist = 0; }
+                if (nlist + c > 64) {                       // no room: the memo first, then -- if its survivors still leave none -- a merge batch
+                    memo_phase();
+                    if (nlist + c > 64) { run_batch(nlist); nlist = nchk = 0; }
+                }
                 if (is) {
                     const int o = nlist + tkz_popc64(m & tkz_lowmask(lane));
                     s_rec[o] = (uint16_t)((rec & 1023u) | (((rec >> kPrLenShift) & 15u) << 10) | ((rec & kPrMark) ? 1u << 14 : 0u));
@@ -857,9 +921,11 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
             }
         }
     }
+    memo_phase();
     if (nlist > 0) run_batch(nlist);
+    (void)simt::ballot(true);
     // tokens of every sub-tile of the group: one per piece, plus what the merges added (k_merge_long adds its own later)
-    if (lane < kGroup && sub0 + lane < P.nsub) P.tile_count[sub0 + lane] = my_np + my_extra;
+    if (lane < kGroup && sub0 + lane < P.nsub) P.tile_count[sub0 + lane] = my_np + s_extra[lane];
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
 
@@ -994,9 +1060,9 @@ TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, in
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
           const uint32_t rec = r4[j];
-          const int32_t* src = (rec & kPrDense) ? dense + (rec & 1023u) : P.tmp + base + (rec & 1023u);
+          const int32_t* src = (rec & kPrDense) ? dense + tkz_dense_off(rec) : P.tmp + base + (rec & 1023u);
           const bool ld = (rec & kPrMiss) != 0;
-          const int cnt = (rec & kPrGiant) ? gcnt : (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+          const int cnt = (rec & kPrGiant) ? gcnt : (rec & kPrDense) ? tkz_dense_cnt(rec) : (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
 #pragma unroll
           for (int i = 0; i < 4; ++i) t4[j][i] = (ld && i < cnt) ? src[i] : 0;
       }
@@ -1008,7 +1074,7 @@ TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, in
         const bool valid = k < np && pb + k < P.prank_cap;
         const uint32_t rec = r4[j];
         const bool miss = (rec & kPrMiss) != 0;
-        int cnt = !valid ? 0 : !miss ? 1 : (rec & kPrGiant) ? gcnt : (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+        int cnt = !valid ? 0 : !miss ? 1 : (rec & kPrGiant) ? gcnt : (rec & kPrDense) ? tkz_dense_cnt(rec) : (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
         int tot;
         const int pos = running + tkz_wave_scan_sum(cnt, &tot);
         const uint64_t mm = simt::ballot(valid && (rec & kPrMark));
@@ -1019,7 +1085,7 @@ TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, in
             else if (cnt <= 16) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (i < cnt && tb + pos + i < out_cap) dst[i] = t4[j][i];
-                const int32_t* src = (rec & kPrDense) ? dense + (rec & 1023u) : P.tmp + base + (rec & 1023u);
+                const int32_t* src = (rec & kPrDense) ? dense + tkz_dense_off(rec) : P.tmp + base + (rec & 1023u);
                 for (int i = 4; i < cnt; ++i) if (tb + pos + i < out_cap) dst[i] = src[i];
             }
         }

@@ -44,6 +44,8 @@ TKZ_DEV int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 TKZ_DEV int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
 TKZ_DEV int atomic_add(int* p, int v) { return atomicAdd(p, v); }
 TKZ_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
+TKZ_DEV unsigned atomic_cas(unsigned* p, unsigned expect, unsigned v) { return atomicCAS(p, expect, v); }
+TKZ_DEV void fence() { __threadfence(); }
 TKZ_DEV unsigned long long atomic_or64(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
 TKZ_DEV unsigned long long atomic_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 TKZ_DEV unsigned long long atomic_min64(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }

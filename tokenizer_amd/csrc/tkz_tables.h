@@ -77,7 +77,19 @@ struct alignas(16) TkzPairSlot {
 TKZ_HD uint32_t tkz_pair_cid(uint32_t id) { return id >= (uint32_t)TKZ_PSEUDO_BASE ? id - (uint32_t)TKZ_PSEUDO_BASE + TKZ_PAIR_CID_LIMIT : id; }
 TKZ_HD uint64_t tkz_pair_key42(uint32_t a, uint32_t b) { return (uint64_t)tkz_pair_cid(a) | ((uint64_t)tkz_pair_cid(b) << 21); }
 
+// The piece memo: the device form of the reference's LRUCache (LRUCache.cs; used at TikTokenizer.cs:254,270 to skip BytePairEncode for a
+// piece seen before).  A direct-mapped table of 32-byte slots keyed by the piece's bytes (<= 16, zero padded) holding its <= 4 tokens:
+//   key   k0..k3
+//   val.x 0 = empty | 0xFFFFFFFF = being written | VALID (bit 31) | (count - 1) << 29 | token 0        (tokens are ranks < 2^27)
+//   val.y (len - 1) << 27 | token 1,   val.z token 2,   val.w token 3
+// Only k_merge_short reads and writes it: pieces that missed the vocabulary tables look themselves up before they are merged, and merged
+// pieces of <= 4 tokens claim their slot if it is EMPTY (compare-and-swap on val.x; an entry never changes once it is valid, so a hit in
+// one kernel cannot be invalidated by another).  A pure memo: results are identical with and without it.
+struct alignas(16) TkzMemoSlot { uint32_t k[4]; uint32_t v[4]; };
+constexpr uint32_t kMemoValid = 0x80000000u, kMemoBusy = 0xFFFFFFFFu;
+
 struct TkzTables {      // device pointers + sizes, passed to kernels by value
+    TkzMemoSlot* memo; uint32_t memo_n;                                          // piece memo (null / 0: none)
     const TkzShortSlot* short_slots; uint32_t short_nb; uint32_t short_seed;    // short_nb buckets of two slots
     const TkzMidSlot* mid_slots;     uint32_t mid_ns;   uint32_t mid_seed;      // mid_ns slots
     const TkzLongSlot* long_slots;   uint32_t long_mask;
@@ -120,6 +132,10 @@ TKZ_HD uint32_t tkz_hash_short(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t l
     return tkz_fmix(h ^ (h >> 15) ^ k1);
 }
 TKZ_HD uint32_t tkz_hash_short2(uint32_t h1) { return tkz_hash_second(h1); }
+TKZ_HD uint32_t tkz_hash_memo(const uint32_t* k, uint32_t len) {
+    const uint32_t h = (k[0] ^ tkz_rotl(k[1], 13) ^ tkz_rotl(k[2], 23) ^ tkz_rotl(k[3], 7) ^ (len << 27)) * 0x9E3779B1u;
+    return tkz_fmix(h ^ (h >> 15) ^ k[1] ^ k[3]);
+}
 // a key of 13..28 bytes given as seven zero-padded little-endian dwords
 TKZ_HD uint32_t tkz_hash_mid(const uint32_t* k, uint32_t len, uint32_t seed) {
     uint32_t h = (k[0] + seed) * 0x9E3779B1u;
