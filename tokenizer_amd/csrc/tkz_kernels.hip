@@ -878,7 +878,9 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
             // a piece of <= 4 tokens takes its memo slot if nobody has (an entry is never replaced: a hit stays valid for good)
             if (memo && cnt <= 4 && !e1) {
                 TkzMemoSlot* slot = &T.memo[tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), T.memo_n)];
-                if (simt::atomic_cas(&slot->v[0], 0u, kMemoBusy) == 0u) {
+                // (a plain load first: a piece that lost its slot to another one comes back millions of times on repetitive text, and a
+                //  failing compare-and-swap is still an atomic on one hot address)
+                if (*reinterpret_cast<volatile uint32_t*>(&slot->v[0]) == 0u && simt::atomic_cas(&slot->v[0], 0u, kMemoBusy) == 0u) {
                     uint4 kk; kk.x = kw[0]; kk.y = kw[1]; kk.z = kw[2]; kk.w = kw[3];
                     *reinterpret_cast<uint4*>(&slot->k[0]) = kk;
                     slot->v[1] = ((uint32_t)(len - 1) << 27) | t4[1]; slot->v[2] = t4[2]; slot->v[3] = t4[3];
