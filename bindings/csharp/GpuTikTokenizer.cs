@@ -28,6 +28,7 @@ namespace Microsoft.DeepDev
         [DllImport(Lib)] internal static extern void tkz_vocab_destroy(IntPtr vocab);
         [DllImport(Lib)] internal static extern int tkz_pattern_from_regex([MarshalAs(UnmanagedType.LPUTF8Str)] string regex, out int pattern);
         [DllImport(Lib)] internal static extern int tkz_encoder_create(IntPtr vocab, int pattern, int device, out IntPtr encoder);
+        [DllImport(Lib)] internal static extern int tkz_encoder_set_option(IntPtr encoder, int option, long value);
         [DllImport(Lib)] internal static extern void tkz_encoder_destroy(IntPtr encoder);
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_utf8(IntPtr encoder, byte* bytes, long* docOffsets, long nDocs,
                                                                                   int* outIds, long outCap, long* outOffsets, out long needed);
@@ -99,7 +100,8 @@ namespace Microsoft.DeepDev
             // special token is a prefix of another, the order of the alternatives decides the match
             specialTokensRegex = new Regex(string.Join("|", specialTokensEncoder.Keys.Select(s => Regex.Escape(s))), RegexOptions.Compiled);
             RegisterSpecialTokensForDecode();
-            _ = cacheSize;                                                     // the LRU piece memo has no effect on results (LRUCache.cs)
+            // the LRU piece memo (LRUCache.cs; no effect on results) lives on the device with a fixed size: cacheSize says whether it is used
+            if (cacheSize <= 0) Tkz.Check(Tkz.tkz_encoder_set_option(handle.DangerousGetHandle(), 2 /* TKZ_OPT_PIECE_MEMO */, 0));
         }
 
         // SpecialTokensDecoder (TikTokenizer.cs:79) for the device Decode

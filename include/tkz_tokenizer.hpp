@@ -238,8 +238,11 @@ private:
 struct TokenizerBuilder {
     // TokenizerBuilder.CreateTokenizer(Stream, IReadOnlyDictionary<string,int>, string pattern, int cacheSize)
     static TikTokenizer* CreateTokenizer(const std::string& tikTokenBpeFile, SpecialTokens specialTokensEncoder, const std::string& pattern,
-                                         int /*cacheSize*/ = 8192, int device = 0) {
-        return new TikTokenizer(tikTokenBpeFile, std::move(specialTokensEncoder), pattern, device);
+                                         int cacheSize = 8192, int device = 0) {
+        TikTokenizer* t = new TikTokenizer(tikTokenBpeFile, std::move(specialTokensEncoder), pattern, device);
+        // the reference's LRU piece memo (LRUCache.cs; no effect on results) lives on the device with a fixed size: cacheSize says whether it is used
+        if (cacheSize <= 0) (void)tkz_encoder_set_option(t->native(), TKZ_OPT_PIECE_MEMO, 0);
+        return t;
     }
 };
 

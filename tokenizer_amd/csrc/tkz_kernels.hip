@@ -456,17 +456,18 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
 //              hit : rank | MARK                                  (MARK: a document -- or, at piece granularity, a piece -- starts here)
 //              miss: MISS | MARK | (len-1) << 10 | relpos         (relpos: byte offset inside the 1 KiB sub-tile), GIANT if len > 1024;
 //                    after its merge: MISS | MARK | DONE | (count-1) << 10 | relpos, the tokens waiting in tmp[abs .. abs + count),
-//                    or ... | DENSE | (count-1) << 10 | offset, the tokens waiting in dense[group * kDenseCap + offset ..)
-//   dense[]    the tokens of the merged SHORT pieces of a group of 4 sub-tiles, packed in piece order (1024 per group; a miss costs
+//                    or ... | DENSE | count-1 and offset (tkz_dense_rec), the tokens waiting in dense[group * kDenseCap + offset ..)
+//   dense[]    the tokens of the merged SHORT pieces of a group of 16 sub-tiles, packed in piece order (4096 per group; a miss costs
 //              ~4 tokens = one 16-byte store next to its neighbour's, not a 64-byte line of its own in k_merge_short and again in k_place)
 //   tmp[b]     4 B per input byte, touched only under LONG missed pieces (and what overflows dense[]): a piece's tokens fit inside
 //              its own byte span (tokens <= bytes)
 //
-//   k_probe        one wavefront per 1 KiB sub-tile, 32 wavefronts per CU (64 VGPRs, 3 KB LDS): piece enumeration from the bitmap,
-//                  SHORT / MID probes (four 16-byte gathers per piece, two batches of 64 pieces in flight), records stored coalesced
-//   k_merge_short  one wavefront per 4 sub-tiles: the misses of up to 16 bytes are packed 64 to a wavefront -- every lane merges
-//                  (tkz_bpe_lane<16>) -- instead of the ~14 of 64 a sub-tile has on its own: the wave still waits for its slowest
-//                  chain, but it waits once per 64 pieces.  Also the per-sub-tile token counts.
+//   k_probe        one wavefront per 1 KiB sub-tile, 32 wavefronts per CU (48 VGPRs, 3 KB LDS): piece enumeration from the bitmap,
+//                  SHORT probes (the first candidate bucket = two 16-byte gathers per piece, the second bucket only for the lanes that
+//                  did not find their key; two batches of 64 pieces in flight), MID probes, records stored coalesced
+//   k_merge_short  one wavefront per group of 16 sub-tiles: the misses of up to 16 bytes are packed 64 to a wavefront -- looked up in
+//                  the piece memo (the reference's LRUCache on the device), the survivors merged, every lane busy (tkz_bpe_lane) --
+//                  instead of the ~14 of 64 a sub-tile has on its own.  Also the per-sub-tile token counts.
 //   k_giant_find / k_giant_merge, k_merge_long   the rare long ones: > 1024 bytes by a whole workgroup in rounds (tkz_bpe_long),
 //                  17..1024 bytes one per lane in an LDS arena (tkz_bpe_lane_var), only in the sub-tiles k_probe flagged
 //   (scan of the token counts)

@@ -86,7 +86,6 @@ class TikTokenizer:
 
     def __init__(self, tikTokenBpeFile: bytes, specialTokensEncoder: Optional[Dict[str, int]], pattern: str,
                  cacheSize: int = 8192, device: int = 0, lib: Optional[N.Library] = None):
-        del cacheSize  # the reference's LRU piece memo (LRUCache.cs) has no effect on results; the GPU path has no use for it
         self._lib = lib or N.default_library()
         pat = self._lib.L.tkz_pattern_from_regex  # maps the reference's regex text to a scanner, refuses anything else
         import ctypes as C
@@ -94,6 +93,10 @@ class TikTokenizer:
         self._lib.check(pat(pattern.encode("utf-8"), C.byref(out)))
         self._vocab = N.Vocab(tikTokenBpeFile, self._lib)     # FormatError / DuplicateRankError as in LoadTikTokenBpe + Init
         self._encoder = N.Encoder(self._vocab, out.value, device)
+        # the reference's LRU piece memo (LRUCache.cs; no effect on results) lives on the device with a fixed size: cacheSize only says
+        # whether it is used (the reference's LRUCache of size 0 keeps nothing)
+        if cacheSize <= 0:
+            self._encoder.set_option(N.OPT_PIECE_MEMO, 0)
         self.SpecialTokensEncoder: Dict[str, int] = dict(specialTokensEncoder or {})
         self.SpecialTokens = set(self.SpecialTokensEncoder)
         # alternation of the escaped literals in registration order (TikTokenizer.cs:78): leftmost match, first alternative wins
