@@ -231,6 +231,11 @@ def main():
     if warm is not None:       # (after 5 GB of other documents every memo slot is taken: the timed steps cannot add entries of their own)
         del warm, w_bytes, w_offs, w_ids
         torch.cuda.empty_cache()
+        # one untimed pass over the bench batch itself with the memo switched off (it neither reads nor fills it then): the workspace
+        # takes the size THIS batch needs -- record capacity, scratch of its giant pieces -- outside the timed region
+        enc.set_option(N.OPT_PIECE_MEMO, 0)
+        ntok = step()
+        enc.set_option(N.OPT_PIECE_MEMO, 1)
     enc.set_profiling(True)
     enc.kernel_ms(reset=True)
     fence()
