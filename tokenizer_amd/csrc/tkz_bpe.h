@@ -129,7 +129,7 @@ TKZ_HD int tkz_bpe_lane_f(const TkzTables& T, const uint32_t* w, int n, uint32_t
 
 // One LANE merges one piece of n >= 1 bytes with its state in a caller-provided span of tkz_bpe_var_dwords(n) dwords:
 //   ids[n4] | pr[n4] | alive[a4]      n4 = n rounded up to 4, a4 = ceil(n / 32) rounded up to 4 (one bit per part start)
-// The same loop as tkz_bpe_lane with the piece length a run-time value (the heavy kernel gives every missed piece of a
+// The same loop as tkz_bpe_lane with the piece length a run-time value (k_merge_long gives every missed piece of a
 // pass a span of its own size out of one LDS arena: CJK runs, emoji sequences and long identifiers are merged side by
 // side instead of one after the other).  PACKED (vocabularies whose ranks stay below 2^22, i.e. every published one):
 // pr holds rank << 10 | position and the leftmost strict minimum (:47-54) is a v_min3 tree over 16-byte LDS reads, as

@@ -1113,7 +1113,7 @@ TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, in
 // -------------------------------------------------------------------------------------------------
 TKZ_KERNEL(256) void k_giant_find(const uint8_t* heavy_flag, int64_t nsub, const uint64_t* startbits, int64_t nwords, int64_t total,
                                   int64_t* gq, unsigned long long* gcount, int64_t gcap) {
-    // only a sub-tile the lean kernel flagged can hold the start of a giant piece, and only its LAST piece start can be one
+    // only a sub-tile k_probe flagged can hold the start of a giant piece, and only its LAST piece start can be one
     // (a giant piece reaches past the end of its sub-tile)
     const int64_t stride = simt::nblocks() * simt::nthreads();
     for (int64_t t = simt::bid() * simt::nthreads() + simt::tid(); t < nsub; t += stride) {
