@@ -271,7 +271,7 @@ def check_batch(lib, O, vocab, ovocab, pattern, seed, rounds, doc_lens, n_docs_c
 
 
 def check_dense_region(lib, O, vocab, ovocab, pattern=N.CL100K, seed=17):
-    """The packed region for the tokens of merged short pieces (1024 per group of four sub-tiles): groups that fill it exactly, overflow it
+    """The packed region for the tokens of merged short pieces (4096 per group of 16 sub-tiles): groups that fill it exactly, overflow it
     (the rest waits in tmp) and stay far below it, next to each other, with long misses in between."""
     rng = random.Random(seed)
     enc = N.Encoder(vocab, pattern)
