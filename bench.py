@@ -207,9 +207,9 @@ def main():
         N.corpus_generate_device(local_rank, args.kind, seed, w_first, n_docs, args.min_len, args.max_len, w_offs.data_ptr(), w_bytes.data_ptr(), w_total, stream)
         w_ids = torch.empty(w_total, dtype=torch.int32, device=dev)
         warm = (w_bytes, w_offs, w_total, w_ids)
-        memo_note = "on: 65,536 slots, filled during the warm-up steps from %d OTHER documents of the same generator (documents %d..)" % (n_docs, w_first)
+        memo_note = "on: %d slots, filled during the warm-up steps from %d OTHER documents of the same generator (documents %d..)" % (enc.memo_slots, n_docs, w_first)
     else:
-        memo_note = "on: 65,536 slots, filled during the warm-up steps from the same tiled text (every piece of it repeats)"
+        memo_note = "on: %d slots, filled during the warm-up steps from the same tiled text (every piece of it repeats)" % enc.memo_slots
 
     def step():
         ntok = enc.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total,

@@ -213,7 +213,7 @@ tkz_status tkz_encode_pieces(tkz_encoder* e, const uint8_t* bytes, const int64_t
  * the position-parallel one; both must give identical bitmaps. */
 enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1,
        /* The piece memo: the device form of the reference's LRUCache (LRUCache.cs, used at TikTokenizer.cs:254,270): pieces of up to 16
-        * bytes that had to be merged leave their (up to 4) tokens in a 65,536-slot table on the device and later batches take them from
+        * bytes that had to be merged leave their (up to 4) tokens in a 524,288-slot (16 MB) table on the device and later batches take them from
         * there instead of running BytePairEncode again.  A pure memo: ids are identical with and without it.  Value 0 = off, 1 = on
         * (default), 2 = on and emptied. */
        TKZ_OPT_PIECE_MEMO = 2 };
@@ -232,6 +232,8 @@ tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, 
 /* o200k only, informational: of the 4 KiB blocks of the last batch, how many the ASCII block scanner handed on (blocks with multi-byte
  * chars or a state it cannot carry), and how many of those the multi-byte block scanner handed on to the sequential matcher. */
 void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_scanner, int64_t* after_multibyte_scanner);
+/* Slots of the piece memo (TKZ_OPT_PIECE_MEMO), informational. */
+int64_t tkz_encoder_memo_slots(const tkz_encoder* e);
 /* Device bytes currently held by the encoder (tables + workspace). */
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e);
 const char* tkz_kernel_name(int32_t k);

@@ -75,6 +75,8 @@ class Library:
         L.tkz_vocab_max_key_len.argtypes = [vp]
         L.tkz_vocab_pair_table_entries.argtypes = [vp]
         L.tkz_vocab_pair_table_entries.restype = i64
+        L.tkz_encoder_memo_slots.argtypes = [vp]
+        L.tkz_encoder_memo_slots.restype = i64
         L.tkz_unicode_classes.argtypes = [C.c_uint32, C.c_int32, vp]
         L.tkz_unicode_classes.restype = None
         L.tkz_encoder_pretok_leftovers.argtypes = [vp, pi64, pi64]
@@ -213,6 +215,10 @@ class Encoder:
         n = np.zeros(len(K_NAMES), np.int64)
         self.lib.check(self.lib.L.tkz_encoder_kernel_ms(self._h, ms.ctypes.data, n.ctypes.data, 1 if reset else 0))
         return {K_NAMES[i]: (float(ms[i]), int(n[i])) for i in range(len(K_NAMES))}
+
+    @property
+    def memo_slots(self):
+        return int(self.lib.L.tkz_encoder_memo_slots(self._h))
 
     def pretok_leftovers(self):
         """(blocks the o200k ASCII block scanner handed on, blocks the multi-byte block scanner handed on to the sequential matcher) of the last batch."""

@@ -12,8 +12,11 @@ constexpr int kThreads = 256;       // workgroup size of every kernel (4 wavefro
 constexpr int kSub = 1024;          // bytes of corpus per wavefront of k_probe / k_place (a "sub-tile")
 constexpr int kHalo = 64;           // bytes staged past the sub-tile (a short piece may straddle the edge)
 constexpr int kShortMax = 16;       // pieces up to this many bytes are merged one per lane, 64 to a wavefront, by k_merge_short
-constexpr int kMergeGroup = 16;     // sub-tiles per wavefront of k_merge_short ("group")
-constexpr int kDenseCap = 4096;     // tokens of merged short pieces a group keeps packed (what does not fit waits in tmp, like the long pieces' tokens)
+#ifndef TKZ_MERGE_GROUP
+#define TKZ_MERGE_GROUP 16
+#endif
+constexpr int kMergeGroup = TKZ_MERGE_GROUP;   // sub-tiles per wavefront of k_merge_short ("group")
+constexpr int kDenseCap = 256 * kMergeGroup;   // tokens of merged short pieces a group keeps packed (what does not fit waits in tmp, like the long pieces' tokens)
 constexpr int kArenaDwords = 2560;  // LDS arena of k_merge_long: a long miss of a batch gets its bytes + 1 dword + 1 bit per byte out of it (2 dwords per byte for
                                     // vocabularies with ranks of 2^21 and more, which keep an ids[] array: tkz_bpe.h)
 constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (256 + tkz_bpe_var_dwords(1024) = 2336 <= kArenaDwords)
