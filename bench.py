@@ -17,6 +17,10 @@ downloaded by the reference at run time and exists nowhere offline: unless $TKZ_
 run uses tests/golden/synth100k.tiktoken.gz, a trained stand-in of cl100k_base's size (100,256 keys, tools/train_bpe.py), and
 says so in config.vocab.
 
+The piece memo (the reference's LRUCache on the device) persists from call to call like the reference's: the W warm-up steps encode
+OTHER documents of the same generator, then one untimed pass with the memo switched off sizes the workspace for the bench batch;
+--no-memo measures without it (config.piece_memo says which).
+
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM bandwidth with the algorithmic bytes of
 SURVEY.md 8(d); `cpu_baseline` times the reference-algorithm CPU restatement (oracle/, kind "port") on a bounded sample of the
 same documents on ALL host cores and is also the parity check of the run.
