@@ -104,19 +104,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--docs", type=int, default=10_000_000, help="documents per GPU")
+    ap.add_argument("--docs", type=int, default=None, help="documents per GPU (default: 10 M at --gpus 1 = BASELINE configs[1]; 12.5 M at --gpus > 1 = "
+                                                           "one GPU's share of configs[3], 100 M documents over 8 GPUs)")
     ap.add_argument("--kind", type=int, default=1, help="corpus: 1 ASCII (config 2), 2 mixed UTF-8 (config 3), 3 long-context (config 5), "
-                                                        "4 the reference's test text lib.rs.txt tiled (real source code)")
+                                                        "4 the reference's test text lib.rs.txt tiled (real source code), "
+                                                        "5 ONE document of shuffled words joined by single spaces (the reference's own benchmark, PerfBenchmark/Program.cs:14-32)")
     ap.add_argument("--min-len", type=int, default=256)
     ap.add_argument("--max-len", type=int, default=768)
     ap.add_argument("--pattern", type=int, default=2, help="1 pattern-1, 2 cl100k, 3 o200k")
     ap.add_argument("--vocab", default=None, help="gpt2 | synth100k | synth200k (default: the stand-in of the pattern's vocabulary)")
-    ap.add_argument("--cpu-sample-docs", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-docs", type=int, default=2_000_000, help="documents of the CPU-baseline thread sweep (the all-core run covers the whole batch)")
+    ap.add_argument("--no-memo-steps", type=int, default=None, help="timed steps with the piece memo off (value_no_memo); default: as --steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-memo", action="store_true", help="switch the piece memo (the device form of the reference's LRUCache) off")
     ap.add_argument("--write-shards", default=None, metavar="DIR", help="after the timed loop every rank writes its token shard file (SURVEY 8f-2)")
     args = ap.parse_args()
 
+    if args.docs is None:
+        args.docs = 10_000_000 if args.gpus == 1 else 12_500_000
+        if args.kind == 5:
+            args.docs = 131_072          # x 512 B = one 64 MB document
+            args.min_len = args.max_len = 512
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)
 
@@ -186,13 +194,19 @@ def main():
         d_bytes = text.repeat(reps)[:total + 64].contiguous()
         seed = None
     else:
-        seed = 0x5EED0000 + {1: 2, 2: 3, 3: 5}[args.kind]
+        seed = 0x5EED0000 + {1: 2, 2: 3, 3: 5, 5: 6}[args.kind]
         d_offs = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
         total = N.corpus_generate_device(local_rank, args.kind, seed, first_doc, n_docs, args.min_len, args.max_len,
                                          d_offs.data_ptr(), None, 0, stream)
         d_bytes = torch.empty(total + 64, dtype=torch.uint8, device=dev)
         N.corpus_generate_device(local_rank, args.kind, seed, first_doc, n_docs, args.min_len, args.max_len,
                                  d_offs.data_ptr(), d_bytes.data_ptr(), total, stream)
+    gen_docs = n_docs
+    if args.kind == 5:
+        # the reference's own benchmark shape: ONE string of shuffled words joined by single spaces, one Encode call.  The generated
+        # documents (words behind single spaces) stand back to back in d_bytes; the batch is that text as a single document.
+        n_docs = 1
+        d_offs = torch.tensor([0, total], dtype=torch.int64, device=dev)
     d_ids = torch.empty(total, dtype=torch.int32, device=dev)          # tokens <= bytes: always enough
     d_ooffs = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
 
@@ -204,14 +218,18 @@ def main():
     if args.no_memo:
         enc.set_option(N.OPT_PIECE_MEMO, 0)
     elif seed is not None:
-        w_first = (world + rank) * n_docs
-        w_offs = torch.empty(n_docs + 1, dtype=torch.int64, device=dev)
-        w_total = N.corpus_generate_device(local_rank, args.kind, seed, w_first, n_docs, args.min_len, args.max_len, w_offs.data_ptr(), None, 0, stream)
+        w_first = (world + rank) * gen_docs
+        w_offs = torch.empty(gen_docs + 1, dtype=torch.int64, device=dev)
+        w_total = N.corpus_generate_device(local_rank, args.kind, seed, w_first, gen_docs, args.min_len, args.max_len, w_offs.data_ptr(), None, 0, stream)
         w_bytes = torch.empty(w_total + 64, dtype=torch.uint8, device=dev)
-        N.corpus_generate_device(local_rank, args.kind, seed, w_first, n_docs, args.min_len, args.max_len, w_offs.data_ptr(), w_bytes.data_ptr(), w_total, stream)
+        N.corpus_generate_device(local_rank, args.kind, seed, w_first, gen_docs, args.min_len, args.max_len, w_offs.data_ptr(), w_bytes.data_ptr(), w_total, stream)
         w_ids = torch.empty(w_total, dtype=torch.int32, device=dev)
-        warm = (w_bytes, w_offs, w_total, w_ids)
-        memo_note = "on: %d slots, filled during the warm-up steps from %d OTHER documents of the same generator (documents %d..)" % (enc.memo_slots, n_docs, w_first)
+        w_docs = gen_docs
+        if args.kind == 5:
+            w_docs, w_offs = 1, torch.tensor([0, w_total], dtype=torch.int64, device=dev)
+        warm = (w_bytes, w_offs, w_total, w_ids, w_docs)
+        memo_note = "on: %d slots x %d-way buckets, filled during the warm-up steps from %d OTHER documents of the same generator (documents %d..)" % (
+            enc.memo_slots, enc.memo_ways, gen_docs, w_first)
     else:
         memo_note = "on: %d slots, filled during the warm-up steps from the same tiled text (every piece of it repeats)" % enc.memo_slots
 
@@ -229,7 +247,7 @@ def main():
 
     for _ in range(args.warmup):
         if warm is not None:
-            enc.encode_batch_device(warm[0].data_ptr(), warm[1].data_ptr(), n_docs, warm[2], warm[3].data_ptr(), warm[2], d_ooffs.data_ptr(), stream)
+            enc.encode_batch_device(warm[0].data_ptr(), warm[1].data_ptr(), warm[4], warm[2], warm[3].data_ptr(), warm[2], d_ooffs.data_ptr(), stream)
         else:
             ntok = step()
     if warm is not None:       # (after 5 GB of other documents every memo slot is taken: the timed steps cannot add entries of their own)
@@ -249,11 +267,30 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     enc.set_profiling(False)
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        allt = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([dt], dtype=torch.float64, device=dev))
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
+        dt = max(float(x.item()) for x in allt)              # the slowest rank's time is the job's
     kms = enc.kernel_ms()
+    # the same steps with the piece memo switched off (it neither reads nor fills it): the companion figure `value_no_memo`
+    dt_nomemo = None
+    nm_steps = args.steps if args.no_memo_steps is None else args.no_memo_steps
+    if not args.no_memo and nm_steps > 0:
+        enc.set_option(N.OPT_PIECE_MEMO, 0)
+        step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(nm_steps):
+            step()
+        fence()
+        dt_nomemo = time.perf_counter() - t0
+        enc.set_option(N.OPT_PIECE_MEMO, 1)
+        if world > 1:
+            t = torch.tensor([dt_nomemo], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_nomemo = float(t.item())
     g = comm.result() if comm is not None else sharded.gather_counts(n_docs, total, ntok)
     n_tokens_rank = int(g["table"][rank][2])
     assert n_tokens_rank == ntok and int(g["table"][rank][0]) == n_docs and int(g["table"][rank][1]) == total
@@ -303,38 +340,50 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 from oracle import oracle as O
-                ns = min(args.cpu_sample_docs, n_docs)
-                h_offs = d_offs[:ns + 1].cpu().numpy()
-                nb = int(h_offs[-1])
-                h_bytes = d_bytes[:nb].cpu().numpy()
-                h_ooffs = d_ooffs[:ns + 1].cpu().numpy()
-                h_ids = d_ids[:int(h_ooffs[-1])].cpu().numpy()
                 ov = O.Vocab(raw)
-                threads = max(1, os.cpu_count() or 1)          # ALL host cores
+                ncpu = max(1, os.cpu_count() or 1)
+                # ---- parity: EVERY document of the batch against the oracle, on all host cores (tkzo_check_batch encodes each
+                # document and compares it in place with the ids the GPU left for it: nothing beyond the inputs is allocated) ----
+                h_offs = d_offs.cpu().numpy()
+                h_bytes = d_bytes[:total].cpu().numpy()
+                h_ooffs = d_ooffs.cpu().numpy()
+                h_ids = d_ids[:n_tokens_rank].cpu().numpy()
+                same = int(h_ooffs[0]) == 0 and int(h_ooffs[n_docs]) == n_tokens_rank and bool((np.diff(h_ooffs) >= 0).all())
                 tm = {}
-                o_ids, o_counts = O.encode_batch(ov, args.pattern, h_bytes, h_offs, threads=threads, timing=tm)
-                tcpu = tm["seconds"]
-                same = len(o_ids) == len(h_ids) and np.array_equal(o_ids, h_ids) and np.array_equal(np.diff(h_ooffs), o_counts)
-                # (not timed) the LAST documents of the batch too, and the offsets of the whole batch: placement at large indices
-                nt = min(20_000, n_docs)
-                t_offs = d_offs[n_docs - nt:n_docs + 1].cpu().numpy()
-                t_bytes = d_bytes[int(t_offs[0]):int(t_offs[-1])].cpu().numpy()
-                t_ooffs = d_ooffs[n_docs - nt:n_docs + 1].cpu().numpy()
-                t_ids = d_ids[int(t_ooffs[0]):int(t_ooffs[-1])].cpu().numpy()
-                p_ids, p_counts = O.encode_batch(ov, args.pattern, t_bytes, t_offs - t_offs[0], threads=threads)
-                same = same and np.array_equal(p_ids, t_ids) and np.array_equal(np.diff(t_ooffs), p_counts)
-                same = same and int(d_ooffs[0].item()) == 0 and int(d_ooffs[n_docs].item()) == n_tokens_rank \
-                    and bool((d_ooffs[1:n_docs + 1] >= d_ooffs[:n_docs]).all().item())
-                parity_note = ("bit-exact vs oracle on the first %d and the last %d docs (%d tokens); offsets of all %d docs monotone, ending at the token count"
-                               % (ns, nt, len(o_ids) + len(p_ids), n_docs)) if same else "MISMATCH vs oracle on the sample"
-                # one thread, on a fifth of the sample (SURVEY.md 8d asks for both figures)
-                n1 = max(1, ns // 5)
-                O.encode_batch(ov, args.pattern, h_bytes[:int(h_offs[n1])], h_offs[:n1 + 1], threads=1, timing=tm)
-                t1 = tm["seconds"]
-                cpu_1t = round(int(h_offs[n1]) / t1 / 1e6, 2)
-                cpu = {"value": round(nb / tcpu / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port", "value_1_thread": cpu_1t,
-                       "sample": "first %d documents (%.1f MB) of the same corpus on all %d host cores (one thread: the first %d documents), "
-                                 "reference-algorithm CPU restatement (oracle/), 8192-entry LRU memo per thread" % (ns, nb / 1e6, threads, n1)}
+                if n_docs >= 4 * ncpu:
+                    bad, first_bad, otok = O.check_batch(ov, args.pattern, h_bytes, h_offs, h_ids, h_ooffs, threads=ncpu, timing=tm)
+                    best = (total / tm["seconds"] / 1e6, ncpu, total, n_docs)
+                else:                                         # (one giant document: a single thread, no sweep)
+                    bad, first_bad, otok = O.check_batch(ov, args.pattern, h_bytes, h_offs, h_ids, h_ooffs, threads=1, timing=tm)
+                    best = (total / tm["seconds"] / 1e6, 1, total, n_docs)
+                same = same and bad == 0 and otok == n_tokens_rank
+                parity_note = ("bit-exact vs oracle on all %d docs (%d tokens, %.1f s on %d host threads); offsets monotone, ending at the token count"
+                               % (n_docs, otok, tm["seconds"], best[1])) if same else "MISMATCH vs oracle: %d of %d docs differ, first %d" % (bad, n_docs, first_bad)
+                # ---- CPU baseline: the same restatement timed on the host cores.  The all-core run above covers the whole batch; fewer
+                # threads (SMT siblings and memory channels decide which count is best) on a bounded sample; and one thread ----
+                ns = min(args.cpu_sample_docs, n_docs)
+                nb = int(h_offs[ns])
+                sweep = {str(best[1]): round(best[0], 1)}
+                for th in sorted({max(1, ncpu // 2), max(1, ncpu // 4)} - {best[1]}):
+                    if n_docs < 4 * ncpu:
+                        break
+                    O.check_batch(ov, args.pattern, h_bytes[:nb], h_offs[:ns + 1], h_ids, h_ooffs[:ns + 1], threads=th, timing=tm)
+                    sweep[str(th)] = round(nb / tm["seconds"] / 1e6, 1)
+                    if nb / tm["seconds"] / 1e6 > best[0]:
+                        best = (nb / tm["seconds"] / 1e6, th, nb, ns)
+                n1 = max(1, min(ns // 10, 200_000)) if n_docs > 1 else 1
+                nb1 = int(h_offs[n1]) if n_docs > 1 else min(total, 32 << 20)
+                if n_docs > 1:
+                    O.check_batch(ov, args.pattern, h_bytes[:nb1], h_offs[:n1 + 1], h_ids, h_ooffs[:n1 + 1], threads=1, timing=tm)
+                    cpu_1t = round(nb1 / tm["seconds"] / 1e6, 2)
+                else:
+                    cpu_1t = round(best[0], 2)
+                cpu = {"value": round(best[0], 2), "unit": "MB/s", "cores": best[1], "kind": "port", "value_1_thread": cpu_1t, "by_threads": sweep,
+                       "host_threads_available": ncpu,
+                       "sample": "%d documents (%.1f MB) of the same corpus on %d host threads -- the best of the thread counts tried (by_threads: MB/s; the %d-thread "
+                                 "run covers the whole batch and is the parity check); one thread: the first %d documents; reference-algorithm CPU restatement "
+                                 "(oracle/), 8192-entry LRU memo and reusable scratch per thread" % (best[3], best[2] / 1e6, best[1], ncpu, n1)}
+                ns = min(ns, n_docs)
                 # the real C# TokenizerLib beside it, when this host has a .NET SDK and a reference checkout (never in this image)
                 if shutil.which("dotnet") and os.environ.get("TKZ_REFERENCE_DIR"):
                     sp = "/tmp/tkz_bench_sample.bin"
@@ -368,12 +417,12 @@ def main():
                         else:
                             bufs = (hh_bytes, hh_offs, (o_ids_buf, o_off_buf))
                         enc.encode_batch(bufs[0], bufs[1], out=bufs[2])                   # sizes the encoder's staging buffers
-                        best = 0.0                                                        # (the better of two runs: one 12 ms call is easily disturbed)
+                        best_rate = 0.0                                                   # (the better of two runs: one 12 ms call is easily disturbed)
                         for _rep in range(2):
                             tc = time.perf_counter()
                             r_ids, r_ooffs = enc.encode_batch(bufs[0], bufs[1], out=bufs[2])
-                            best = max(best, len(hh_bytes) / (time.perf_counter() - tc) / 1e6)
-                        rates.append(round(best, 1))
+                            best_rate = max(best_rate, len(hh_bytes) / (time.perf_counter() - tc) / 1e6)
+                        rates.append(round(best_rate, 1))
                         host_same = host_same and int(r_ooffs[-1]) == int(d_ooffs[nh].item()) and np.array_equal(r_ids[:len(h_ids)], h_ids[:len(r_ids)])
                     host_path = {"value": rates[0], "value_pinned_buffers": rates[1], "unit": "MB/s", "docs": nh, "same_ids_as_device_path": bool(host_same),
                                  "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text, kernels and D2H of ids and offsets, chunked and overlapped on three streams; the better of two calls"}
@@ -384,7 +433,12 @@ def main():
         workloads = {1: "BASELINE.json configs[1]: cl100k_base pattern, %d synthetic ASCII docs/GPU, %d..%d B (mean %.0f), device-resident",
                      2: "BASELINE.json configs[2] shape: mixed UTF-8 (CJK + emoji) corpus, %d docs/GPU, %d..%d B (mean %.0f), device-resident",
                      3: "BASELINE.json configs[4] shape: long-context docs with long single-class runs, %d docs/GPU, %d..%d B (mean %.0f), device-resident",
-                     4: "real source text: the reference's lib.rs.txt tiled, %d docs/GPU, %d..%d B (mean %.0f), device-resident"}
+                     4: "real source text: the reference's lib.rs.txt tiled, %d docs/GPU, %d..%d B (mean %.0f), device-resident",
+                     5: "the reference's own benchmark shape (PerfBenchmark/Program.cs:14-32): %d document/GPU of words of the 4096-word table joined by single spaces, "
+                        "one Encode call, %d..%d B (mean %.0f), device-resident"}
+        if args.kind == 1 and world > 1:
+            workloads[1] = ("BASELINE.json configs[3]: cl100k_base pattern, %d synthetic ASCII docs/GPU (" + str(n_docs * world) + " documents sharded over " + str(world) +
+                            " GPUs), %d..%d B (mean %.0f), device-resident")
         line = {
             "metric": "input MB/s encoded (cl100k_base)", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -397,6 +451,8 @@ def main():
                        "partitioning": "contiguous document ranges, one process per GPU; one all-gather of 3 int64 counts per rank per step"},
             "comm": comm_info,
             "tokens_per_s": round(job_tokens * args.steps / dt, 1),
+            "value_no_memo": round(job_bytes * nm_steps / dt_nomemo / 1e6, 1) if dt_nomemo else None,
+            "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
             "parity": parity_note,
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -190,7 +190,8 @@ const char* tkz_comm_backend(const tkz_comm* c);   /* "rccl <major>.<minor>.<pat
 /* d_mine: 3 int64 on the device; d_table: world * 3 int64 on the device (row r = rank r's counts); enqueued on hip_stream */
 tkz_status tkz_comm_allgather_counts_device(tkz_comm* c, const int64_t* d_mine, int64_t* d_table, void* hip_stream);
 tkz_status tkz_comm_allgather_counts(tkz_comm* c, int64_t n_docs, int64_t n_bytes, int64_t n_tokens, int64_t* table);
-/* {n_docs, n_bytes, n_tokens} of the encoder's last batch, resident on its device (valid once that batch's stream work is done) */
+/* {n_docs, n_bytes, n_tokens} of the encoder's last batch, resident on its device (valid once that batch's stream work is done).
+ * ONE buffer per encoder: meaningful with one batch in flight per encoder (host threads sharing an encoder overwrite each other's). */
 const int64_t* tkz_encoder_counts_device(const tkz_encoder* e);
 /* documents [*lo, *hi) of a job of n_docs_total belong to `rank` */
 void tkz_shard_range(int64_t n_docs_total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi);
@@ -215,7 +216,7 @@ enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1,
        /* The piece memo: the device form of the reference's LRUCache (LRUCache.cs, used at TikTokenizer.cs:254,270): pieces of up to 16
         * bytes that had to be merged leave their (up to 4) tokens in a 524,288-slot (16 MB) table on the device and later batches take them from
         * there instead of running BytePairEncode again.  A pure memo: ids are identical with and without it.  Value 0 = off, 1 = on
-        * (default), 2 = on and emptied. */
+        * (default), 2 = on and emptied.  Set options while no call of the encoder is in flight (2 is refused with TKZ_E_ARG otherwise). */
        TKZ_OPT_PIECE_MEMO = 2 };
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value);
 
@@ -232,8 +233,11 @@ tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, 
 /* o200k only, informational: of the 4 KiB blocks of the last batch, how many the ASCII block scanner handed on (blocks with multi-byte
  * chars or a state it cannot carry), and how many of those the multi-byte block scanner handed on to the sequential matcher. */
 void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_scanner, int64_t* after_multibyte_scanner);
-/* Slots of the piece memo (TKZ_OPT_PIECE_MEMO), informational. */
+/* Slots of the piece memo (TKZ_OPT_PIECE_MEMO) and slots per bucket, informational; the bucket a piece of 1..16 bytes would use
+ * (-1: none -- a piece that holds a zero byte never uses the memo).  The tests use the last one to build pieces that contend for one bucket. */
 int64_t tkz_encoder_memo_slots(const tkz_encoder* e);
+int32_t tkz_encoder_memo_ways(const tkz_encoder* e);
+int64_t tkz_encoder_memo_bucket(const tkz_encoder* e, const uint8_t* piece, int32_t len);
 /* Device bytes currently held by the encoder (tables + workspace). */
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e);
 const char* tkz_kernel_name(int32_t k);
@@ -241,7 +245,8 @@ const char* tkz_kernel_name(int32_t k);
 /* Synthetic corpus of BASELINE.json's configs, generated ON DEVICE by a counter-based generator
  * (csrc/tkz_corpus.h); the same function compiled for the host regenerates any document for spot
  * checks.  kind: 1 = ASCII English/code-like (configs 1,2,4), 2 = mixed UTF-8 CJK+emoji (config 3),
- * 3 = long-context with long single-class runs (config 5).
+ * 3 = long-context with long single-class runs (config 5), 5 = words of the 4096-word table drawn uniformly, each behind a single space
+ * (back to back and taken as ONE document this is the shape of the reference's own benchmark, PerfBenchmark/Program.cs:14-32).
  * d_doc_offsets (n_docs+1 entries, device) is always written; d_bytes (device, capacity cap_bytes) is
  * filled when non-NULL and large enough; *total_bytes is returned either way, so a first call with
  * d_bytes == NULL sizes the buffer.  Document d depends only on (kind, seed, first_doc + d, min_len, max_len). */

@@ -59,6 +59,8 @@ def lib():
         L.tkzo_encode_special_utf8.argtypes = [vp, u8p, i64, vp, C.c_int, vp, i64]
         L.tkzo_encode_batch.restype = i64
         L.tkzo_encode_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, i64, vp, vp, C.c_int]
+        L.tkzo_check_batch.restype = i64
+        L.tkzo_check_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, i64, vp, vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _lib = L
     return _lib
 
@@ -210,6 +212,29 @@ def encode_batch(vocab: Vocab, pattern: int, data: np.ndarray, offsets: np.ndarr
         return np.empty(0, np.int32), counts
     idx = np.concatenate([out[offsets[d]:offsets[d] + counts[d]] for d in range(n)]) if n < 100000 else _gather(out, offsets, counts)
     return idx, counts
+
+
+def check_batch(vocab: Vocab, pattern: int, data: np.ndarray, offsets: np.ndarray, want_ids: np.ndarray, want_offsets: np.ndarray,
+                threads=1, cache_size=8192, timing=None):
+    """The checker at full size: every document is encoded on `threads` threads and compared IN PLACE with
+    want_ids[want_offsets[d]:want_offsets[d+1]] -- no result arrays, so 10 M documents need nothing beyond the inputs.
+    Returns (documents that differ, first such document or -1, tokens encoded); timing["seconds"] = wall time of the C call."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    want_ids = np.ascontiguousarray(want_ids, dtype=np.int32)
+    want_offsets = np.ascontiguousarray(want_offsets, dtype=np.int64)
+    assert len(want_offsets) == len(offsets)
+    n = len(offsets) - 1
+    first, tokens = C.c_int64(-1), C.c_int64(0)
+    import time
+    t0 = time.perf_counter()
+    bad = lib().tkzo_check_batch(vocab._h, pattern, cache_size, data.ctypes.data, offsets.ctypes.data, n,
+                                 want_ids.ctypes.data if len(want_ids) else None, want_offsets.ctypes.data, threads, C.byref(first), C.byref(tokens))
+    if timing is not None:
+        timing["seconds"] = time.perf_counter() - t0
+    if bad < 0:
+        raise OracleError(int(bad))
+    return int(bad), int(first.value), int(tokens.value)
 
 
 def _gather(out, offsets, counts):

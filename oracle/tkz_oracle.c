@@ -516,11 +516,19 @@ static void split_units(int pattern, const utext* t, piece_fn fn, void* ctx) {
 
 /* UTF-8 (valid) -> UTF-16 units + classes + byte offset of each unit (the low half of a pair maps
  * to the same byte offset as the high half; no shipped pattern can split a pair). */
-typedef struct { uint32_t* u; uint8_t* c; int64_t* off; int64_t n; } u16buf;
+typedef struct { uint32_t* u; uint8_t* c; int64_t* off; int64_t n; int64_t cap; } u16buf;
+/* (cap: a buffer that outlives the call -- the per-thread scratch of the batch baseline -- is grown, not re-allocated per document:
+ *  three malloc/free pairs per 500-byte document were a third of the CPU baseline's time on 256 threads) */
+static void u16buf_reserve(u16buf* b, int64_t n) {
+    if (b->cap >= n + 2) return;
+    free(b->u); free(b->c); free(b->off);
+    b->cap = (n + 2) * 2;
+    b->u = (uint32_t*)malloc((size_t)b->cap * sizeof(uint32_t));
+    b->c = (uint8_t*)malloc((size_t)b->cap);
+    b->off = (int64_t*)malloc((size_t)b->cap * sizeof(int64_t));
+}
 static int utf8_to_units(const uint8_t* s, int64_t n, u16buf* b, int by_code_point) {
-    b->u = (uint32_t*)malloc((size_t)(n + 1) * sizeof(uint32_t));
-    b->c = (uint8_t*)malloc((size_t)(n + 1));
-    b->off = (int64_t*)malloc((size_t)(n + 2) * sizeof(int64_t));
+    u16buf_reserve(b, n);
     int64_t i = 0, k = 0;
     while (i < n) {
         uint32_t c = s[i]; int len;
@@ -555,14 +563,12 @@ static int utf8_to_units(const uint8_t* s, int64_t n, u16buf* b, int by_code_poi
     b->off[k] = n; b->n = k;
     return TKZO_OK;
 }
-static void u16buf_free(u16buf* b) { free(b->u); free(b->c); free(b->off); }
+static void u16buf_free(u16buf* b) { free(b->u); free(b->c); free(b->off); b->u = NULL; b->c = NULL; b->off = NULL; b->cap = 0; }
 
 /* UTF-16 units -> what the engine sees + the unit offset of each entry: the units themselves (.NET), or -- by code point -- a
  * well-formed surrogate pair as ONE entry and a lone surrogate as one entry of class OTHER (Cs). */
 static void units_to_text(const uint16_t* text, int64_t n, u16buf* b, int by_code_point) {
-    b->u = (uint32_t*)malloc((size_t)(n + 1) * sizeof(uint32_t));
-    b->c = (uint8_t*)malloc((size_t)(n + 1));
-    b->off = (int64_t*)malloc((size_t)(n + 2) * sizeof(int64_t));
+    u16buf_reserve(b, n);
     int64_t k = 0;
     for (int64_t i = 0; i < n; ++i) {
         uint32_t x = text[i];
@@ -589,7 +595,8 @@ static void collect_piece(void* vc, int64_t us, int64_t ul) {
 int64_t tkzo_split_utf8(int pattern, const uint8_t* text, int64_t n, int64_t* starts,
                         int64_t* lens, int64_t cap) {
     pthread_once(&g_cls_once, cls_init);
-    u16buf b; int r = utf8_to_units(text, n, &b, pattern == TKZO_PATTERN_O200K);
+    u16buf b; memset(&b, 0, sizeof b);
+    int r = utf8_to_units(text, n, &b, pattern == TKZO_PATTERN_O200K);
     if (r) { u16buf_free(&b); return r; }
     utext t = { b.u, b.c, b.n };
     collect_ctx c = { starts, lens, cap, 0, b.off };
@@ -600,7 +607,8 @@ int64_t tkzo_split_utf8(int pattern, const uint8_t* text, int64_t n, int64_t* st
 int64_t tkzo_split_utf16(int pattern, const uint16_t* text, int64_t n, int64_t* starts,
                          int64_t* lens, int64_t cap) {
     pthread_once(&g_cls_once, cls_init);
-    u16buf b; units_to_text(text, n, &b, pattern == TKZO_PATTERN_O200K);
+    u16buf b; memset(&b, 0, sizeof b);
+    units_to_text(text, n, &b, pattern == TKZO_PATTERN_O200K);
     utext t = { b.u, b.c, b.n };
     collect_ctx c = { starts, lens, cap, 0, b.off };
     split_units(pattern, &t, collect_piece, &c);
@@ -612,8 +620,11 @@ int64_t tkzo_split_utf16(int pattern, const uint16_t* text, int64_t n, int64_t* 
 /* LruCache<string,int[]>  (Utils/LRUCache.cs:7-136): hash + recency list, capacity bound.      */
 /* A pure memo: it cannot change results, it only keeps the CPU baseline from being handicapped. */
 /* ------------------------------------------------------------------------------------------ */
+#define MEMO_KEY_INLINE 24
+#define MEMO_TOK_INLINE 8
 typedef struct memo_node {
     uint8_t* key; int32_t klen; int32_t* toks; int32_t ntok;
+    uint8_t key_in[MEMO_KEY_INLINE]; int32_t toks_in[MEMO_TOK_INLINE];   /* (short entries live in the node: no allocation per insert) */
     int32_t prev, next;   /* recency list */
     int32_t hnext;        /* hash chain */
     uint64_t h;
@@ -630,8 +641,12 @@ static void memo_init(memo* m, int cap) {
     m->buckets = (int32_t*)malloc(m->nb * sizeof(int32_t));
     for (uint32_t i = 0; i < m->nb; ++i) m->buckets[i] = -1;
 }
+static void memo_node_release(memo_node* x) {
+    if (x->key != x->key_in) free(x->key);
+    if (x->toks != x->toks_in) free(x->toks);
+}
 static void memo_free(memo* m) {
-    for (int i = 0; i < m->count; ++i) { free(m->nodes[i].key); free(m->nodes[i].toks); }
+    for (int i = 0; i < m->count; ++i) memo_node_release(&m->nodes[i]);
     free(m->nodes); free(m->buckets);
 }
 static void memo_unlink(memo* m, int i) {
@@ -666,10 +681,10 @@ static void memo_add(memo* m, const uint8_t* key, int klen, uint64_t h, const in
     if (m->cap <= 0) return;
     int i;
     if (m->count < m->cap) i = m->count++;
-    else { i = m->tail; memo_unlink(m, i); memo_hash_remove(m, i); free(m->nodes[i].key); free(m->nodes[i].toks); }
+    else { i = m->tail; memo_unlink(m, i); memo_hash_remove(m, i); memo_node_release(&m->nodes[i]); }
     memo_node* x = &m->nodes[i];
-    x->key = (uint8_t*)malloc((size_t)klen ? (size_t)klen : 1); memcpy(x->key, key, (size_t)klen); x->klen = klen;
-    x->toks = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ntok ? ntok : 1)); memcpy(x->toks, toks, sizeof(int32_t) * (size_t)ntok); x->ntok = ntok;
+    x->key = klen <= MEMO_KEY_INLINE ? x->key_in : (uint8_t*)malloc((size_t)klen); memcpy(x->key, key, (size_t)klen); x->klen = klen;
+    x->toks = ntok <= MEMO_TOK_INLINE ? x->toks_in : (int32_t*)malloc(sizeof(int32_t) * (size_t)ntok); memcpy(x->toks, toks, sizeof(int32_t) * (size_t)ntok); x->ntok = ntok;
     x->h = h; x->hnext = m->buckets[h & (m->nb - 1)]; m->buckets[h & (m->nb - 1)] = i;
     memo_push_front(m, i);
 }
@@ -681,6 +696,7 @@ typedef struct { uint8_t* lit; int len; int32_t id; } special;
 struct tkzo_encoder {
     const tkzo_vocab* v; int pattern;
     memo cache; bpe_scratch sc;
+    u16buf ub;            /* the text as the regex engine sees it: reused from document to document */
     special* sp; int nsp;
 };
 tkzo_encoder* tkzo_encoder_create(const tkzo_vocab* v, int pattern, int cache_size) {
@@ -692,7 +708,7 @@ tkzo_encoder* tkzo_encoder_create(const tkzo_vocab* v, int pattern, int cache_si
 }
 void tkzo_encoder_free(tkzo_encoder* e) {
     if (!e) return;
-    memo_free(&e->cache); free(e->sc.idx); free(e->sc.rk);
+    memo_free(&e->cache); free(e->sc.idx); free(e->sc.rk); u16buf_free(&e->ub);
     for (int i = 0; i < e->nsp; ++i) free(e->sp[i].lit);
     free(e->sp); free(e);
 }
@@ -733,12 +749,12 @@ static void encode_piece_u8(void* vc, int64_t us, int64_t ul) {
 /* Encode(text, tokenIds, start, end) over a UTF-8 segment */
 static int64_t encode_segment_utf8(tkzo_encoder* e, const uint8_t* text, int64_t n, int32_t* out, int64_t cap) {
     if (n == 0) return 0;
-    u16buf b; int r = utf8_to_units(text, n, &b, e->pattern == TKZO_PATTERN_O200K);
-    if (r) { u16buf_free(&b); return r; }
-    utext t = { b.u, b.c, b.n };
-    enc_ctx c = { e, text, b.off, out, cap, 0, 0 };
+    u16buf* b = &e->ub;
+    int r = utf8_to_units(text, n, b, e->pattern == TKZO_PATTERN_O200K);
+    if (r) return r;
+    utext t = { b->u, b->c, b->n };
+    enc_ctx c = { e, text, b->off, out, cap, 0, 0 };
     split_units(e->pattern, &t, encode_piece_u8, &c);
-    u16buf_free(&b);
     return c.err ? c.err : c.n;
 }
 int64_t tkzo_encode_utf8(tkzo_encoder* e, const uint8_t* text, int64_t n, int32_t* out, int64_t cap) {
@@ -767,7 +783,8 @@ static void encode_piece_u16(void* vc, int64_t es, int64_t el) {
 }
 int64_t tkzo_encode_utf16(tkzo_encoder* e, const uint16_t* text, int64_t n, int32_t* out, int64_t cap) {
     if (n == 0) return 0;
-    u16buf b; units_to_text(text, n, &b, e->pattern == TKZO_PATTERN_O200K);
+    u16buf b; memset(&b, 0, sizeof b);
+    units_to_text(text, n, &b, e->pattern == TKZO_PATTERN_O200K);
     utext t = { b.u, b.c, b.n };
     enc16_ctx c; memset(&c, 0, sizeof c);
     c.base.e = e; c.base.out = out; c.base.cap = cap; c.base.off = b.off; c.u = text;
@@ -837,6 +854,60 @@ static void* batch_worker(void* vj) {
     tkzo_encoder_free(e);
     return NULL;
 }
+/* The checker at full size: every document is encoded and compared, in place, with the ids another implementation produced for it
+ * (want_ids[want_offsets[d] .. want_offsets[d+1])) -- no result arrays, so 10 M documents need nothing beyond the inputs.
+ * Returns the number of documents that differ (or a negative error); *first_bad = the lowest such document, *tokens = tokens encoded. */
+typedef struct {
+    const tkzo_vocab* v; int pattern, cache; const uint8_t* bytes; const int64_t* offs;
+    const int32_t* want; const int64_t* want_offs;
+    int64_t d0, d1; int64_t bad, first_bad, total, err;
+} check_job;
+static void* check_worker(void* vj) {
+    check_job* j = (check_job*)vj;
+    tkzo_encoder* e = tkzo_encoder_create(j->v, j->pattern, j->cache);
+    int32_t* buf = NULL; int64_t cap = 0, total = 0, bad = 0, first = -1;
+    for (int64_t d = j->d0; d < j->d1; ++d) {
+        int64_t a = j->offs[d], b = j->offs[d + 1];
+        if (b - a > cap) { free(buf); cap = (b - a) * 2 + 64; buf = (int32_t*)malloc((size_t)cap * sizeof(int32_t)); }
+        int64_t k = encode_segment_utf8(e, j->bytes + a, b - a, buf, cap);
+        if (k < 0) { j->err = k; break; }
+        int64_t wa = j->want_offs[d], wb = j->want_offs[d + 1];
+        if (wb - wa != k || memcmp(buf, j->want + wa, (size_t)k * sizeof(int32_t)) != 0) { ++bad; if (first < 0) first = d; }
+        total += k;
+    }
+    free(buf);
+    j->total = total; j->bad = bad; j->first_bad = first;
+    tkzo_encoder_free(e);
+    return NULL;
+}
+int64_t tkzo_check_batch(const tkzo_vocab* v, int pattern, int cache_size, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs,
+                         const int32_t* want_ids, const int64_t* want_offsets, int threads, int64_t* first_bad, int64_t* tokens) {
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    check_job* jobs = (check_job*)calloc((size_t)threads, sizeof(check_job));
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    for (int t = 0; t < threads; ++t) {
+        check_job* j = &jobs[t];
+        j->v = v; j->pattern = pattern; j->cache = cache_size; j->bytes = bytes; j->offs = doc_offsets; j->want = want_ids; j->want_offs = want_offsets;
+        j->d0 = n_docs * t / threads; j->d1 = n_docs * (t + 1) / threads; j->first_bad = -1;
+    }
+    if (threads == 1) check_worker(&jobs[0]);
+    else {
+        for (int t = 0; t < threads; ++t) pthread_create(&th[t], NULL, check_worker, &jobs[t]);
+        for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    }
+    int64_t bad = 0, total = 0, first = -1, err = 0;
+    for (int t = 0; t < threads; ++t) {
+        if (jobs[t].err && !err) err = jobs[t].err;
+        bad += jobs[t].bad; total += jobs[t].total;
+        if (jobs[t].first_bad >= 0 && (first < 0 || jobs[t].first_bad < first)) first = jobs[t].first_bad;
+    }
+    free(jobs); free(th);
+    if (first_bad) *first_bad = first;
+    if (tokens) *tokens = total;
+    return err ? err : bad;
+}
+
 int64_t tkzo_encode_batch(const tkzo_vocab* v, int pattern, int cache_size, const uint8_t* bytes,
                           const int64_t* doc_offsets, int64_t n_docs, int32_t* out,
                           int32_t* out_counts, int threads) {

@@ -74,6 +74,7 @@ inline uint4 tkz_load16_nt(const void* p) { return *reinterpret_cast<const uint4
 inline uint32_t tkz_load_nt(const uint32_t* p) { return *p; }
 inline int32_t tkz_load_nt(const int32_t* p) { return *p; }
 inline void tkz_store_nt(int32_t* p, int32_t v) { *p = v; }
+inline void tkz_store16_nt(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
 
 namespace simt {
 inline int tid() { return hipemu::g_tid; }
@@ -111,8 +112,10 @@ inline int scan_inclusive(int v) {
     return x;
 }
 inline int last_lane(int v) { return (int)(uint32_t)hipemu::wave_exchange((uint32_t)v)[63]; }
+inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
 inline int atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomic_or(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+inline unsigned atomic_max(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 inline unsigned atomic_cas(unsigned* p, unsigned expect, unsigned v) { unsigned o = *p; if (o == expect) *p = v; return o; }
 inline void fence() {}
 inline unsigned long long atomic_or64(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o | v; return o; }

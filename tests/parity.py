@@ -337,6 +337,116 @@ def check_piece_memo(lib, O, vocab, ovocab, pattern=N.CL100K, seed=23):
     run(docs_b, exp_b, eoff_b, "memo off again")
 
 
+def check_miss_lists(lib, O, vocab, ovocab, pattern=N.CL100K, seed=41):
+    """The per-sub-tile miss lists (k_probe -> merge kernels -> k_place): sub-tiles with more misses than a list starts with (the batch
+    is redone with longer lists), short and long misses sharing one list from both ends, a sub-tile of 1024 one-byte pieces, and calls
+    after the lists have grown."""
+    rng = random.Random(seed)
+    enc = N.Encoder(vocab, pattern)
+    oenc = O.Encoder(ovocab, pattern)
+    cons = "bcdfghjklmnpqrstvwxz"
+
+    def gib(n, lo, hi):
+        out = []
+        while sum(map(len, out)) < n:
+            out.append(" " + "".join(rng.choice(cons) for _ in range(rng.randint(lo, hi))))
+        return "".join(out)[:n]
+
+    docs_small = [("the quick brown fox " * 40 + gib(200, 5, 9)).encode()]                          # a few misses: the lists as they start
+    docs_big = [gib(5000, 2, 2).encode(),                                                             # ~340 three-byte misses per KiB
+                "".join(gib(12, 3, 5) + gib(30, 17, 40) for _ in range(150)).encode(),               # short and long misses interleaved
+                gib(3000, 17, 30).encode(),                                                           # long misses only
+                ("a\nb\nc\nd\n" * 600).encode(),                                                      # 1024 pieces per sub-tile, all hits
+                "".join(rng.choice(cons) + "\n" for _ in range(2000)).encode(),
+                gib(700, 2, 3).encode() + ("x" * 1500).encode() + gib(700, 2, 16).encode()]           # a giant piece between crowded sub-tiles
+    for docs in (docs_small, docs_big, docs_small, docs_big[::-1]):
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        exp, eoff = oracle_encode_docs(oenc, docs)
+        assert ooff.tolist() == eoff and ids.tolist() == exp
+    # piece granularity on the crowded text (every record marked)
+    data, offs = pack(docs_big[:3])
+    ids, dpo, pbo, pto = enc.encode_batch_pieces(data, offs)
+    exp, _ = oracle_encode_docs(oenc, docs_big[:3])
+    assert ids.tolist() == exp
+
+
+def check_memo_zero_bytes(lib, O, vocab, ovocab, seed=43):
+    """Pieces that hold zero bytes never use the piece memo (that rule is what makes a hit exact whatever mixture of old and new slot
+    words a reader is handed): runs of NUL of every length beside letter pieces of the same lengths, memo off / empty / filled."""
+    rng = random.Random(seed)
+    enc = N.Encoder(vocab, N.CL100K)
+    pcs = []
+    for n in range(1, 17):
+        pcs.append(b"\0" * n)
+        pcs.append(bytes(rng.choice(b"bcdfghjklmnpqrstvwxz") for _ in range(n)))
+        pcs.append(bytes(rng.choice(b"qzx") for _ in range(n - 1)) + b"\0")
+        pcs.append(b"\0" + bytes(rng.choice(b"qzx") for _ in range(n - 1)))
+        assert enc.memo_bucket(pcs[-1]) == -1 and enc.memo_bucket(pcs[-3]) >= 0
+    pcs = pcs * 20
+    rng.shuffle(pcs)
+    exp, eoff = [], [0]
+    for p in pcs:
+        r = ovocab.rank(p)
+        exp += [r] if r >= 0 else ovocab.bpe(p)
+        eoff.append(len(exp))
+    data, offs = pack(pcs)
+    for mode in (0, 2, 1, 1):
+        enc.set_option(N.OPT_PIECE_MEMO, mode)
+        ids, ooff = enc.encode_pieces(data, offs)
+        assert ids.tolist() == exp and ooff.tolist() == eoff, mode
+
+
+def check_memo_contention(lib, O, vocab, ovocab, candidates=400_000, threads=2, rounds=3, seed=47):
+    """Pieces that all map to ONE bucket of the piece memo (found with tkz_encoder_memo_bucket), interleaved with NUL runs of the same
+    lengths and with pieces of other buckets, encoded by several host threads at once on one encoder (each call on its own workspace
+    and stream, all of them reading and claiming the same slots): every call must return the oracle's ids."""
+    import threading
+    rng = random.Random(seed)
+    enc = N.Encoder(vocab, N.CL100K)
+    enc.set_option(N.OPT_PIECE_MEMO, 2)
+    cons, vow = "bcdfghjklmnpqrstvwxz", "aeiou"
+    by_bucket = {}
+    seen = set()
+    for _ in range(candidates):
+        w = " " + "".join(rng.choice(cons) + rng.choice(vow) for _ in range(rng.randint(2, 5))) + rng.choice(["", "x", "q"])
+        b = w.encode()
+        if b in seen or ovocab.rank(b) >= 0:
+            continue
+        seen.add(b)
+        by_bucket.setdefault(enc.memo_bucket(b), []).append(b)
+    crowd = max(by_bucket.values(), key=len)
+    assert len(crowd) >= 2 * enc.memo_ways, len(crowd)       # more contenders than the bucket has slots
+    others = [v[0] for k, v in list(by_bucket.items())[:500]]
+    nul = [b"\0" * len(p) for p in crowd]
+    oenc = O.Encoder(ovocab, N.CL100K)
+
+    def make(r):
+        rr = random.Random(seed + r)
+        words = []
+        for _ in range(6000):
+            k = rr.random()
+            words.append(rr.choice(crowd) if k < 0.6 else rr.choice(nul) if k < 0.75 else rr.choice(others))
+        docs = [b"".join(words[i:i + 40]) for i in range(0, len(words), 40)]
+        return docs, oracle_encode_docs(oenc, docs)
+    jobs = [make(r) for r in range(threads)]
+    errors = []
+
+    def work(i):
+        docs, (exp, eoff) = jobs[i]
+        data, offs = pack(docs)
+        for _ in range(rounds):
+            ids, ooff = enc.encode_batch(data, offs)
+            if ids.tolist() != exp or ooff.tolist() != eoff:
+                errors.append(i)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
 def check_errors(lib, O, vocab):
     enc = N.Encoder(vocab, N.CL100K)
     import pytest
@@ -363,6 +473,16 @@ def check_errors(lib, O, vocab):
     needed = C.c_int64(0)
     st = lib.L.tkz_encode_batch_utf8(enc._h, data.ctypes.data, np.array([0, 11], np.int64).ctypes.data, 1, ids.ctypes.data, 1, ooff.ctypes.data, C.byref(needed))
     assert st == N.E_CAPACITY and needed.value == 2
+    # piece-granular form with piece arrays that are too small: BOTH required sizes come back from the one call (tkz.h)
+    text = np.frombuffer(b"hello world, hello there", np.uint8)
+    tiny_cap = 2
+    pids = np.empty(64, np.int32)
+    dpo = np.empty(2, np.int64); pbo = np.empty(tiny_cap + 1, np.int64); pto = np.empty(tiny_cap + 1, np.int64)
+    npieces, need_ids = C.c_int64(0), C.c_int64(0)
+    st = lib.L.tkz_encode_batch_pieces_utf8(enc._h, text.ctypes.data, np.array([0, len(text)], np.int64).ctypes.data, 1, pids.ctypes.data, 64,
+                                            dpo.ctypes.data, pbo.ctypes.data, pto.ctypes.data, tiny_cap, C.byref(npieces), C.byref(need_ids))
+    full = enc.encode_batch_pieces(text, np.array([0, len(text)]))
+    assert st == N.E_CAPACITY and npieces.value == len(full[2]) - 1 and need_ids.value == len(full[0]) > 0
     # empty inputs (TikTokenizerUnitTest.cs:103-109)
     assert enc.encode_utf8(b"") == []
     ids, ooff = enc.encode_batch(np.zeros(0, np.uint8), np.array([0, 0, 0]))

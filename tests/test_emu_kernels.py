@@ -122,6 +122,19 @@ def test_piece_memo(lib, vocabs, oracle_mod, vname):
     parity.check_piece_memo(lib, oracle_mod, v, ov, pattern=N.O200K, seed=31)
 
 
+def test_miss_lists(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_miss_lists(lib, oracle_mod, v, ov)
+    v, ov = vocabs("synth200k")
+    parity.check_miss_lists(lib, oracle_mod, v, ov, pattern=N.O200K, seed=42)
+
+
+def test_memo_zero_bytes_and_contention(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_memo_zero_bytes(lib, oracle_mod, v, ov)
+    parity.check_memo_contention(lib, oracle_mod, v, ov, candidates=300_000, threads=1, rounds=2)      # (the emulator runs one workgroup at a time)
+
+
 @pytest.mark.parametrize("vname", ["gpt2", "synth100k"])
 def test_dense_token_region(lib, vocabs, oracle_mod, vname):
     v, ov = vocabs(vname)

@@ -124,11 +124,43 @@ def test_pieces_vs_oracle_bpe(lib, vocabs, oracle_mod, vname):
                         lens=[1, 2, 3, 4, 5, 8, 12, 13, 15, 16, 17, 20, 31, 32, 33, 64, 100, 300, 400, 1000, 1023, 1024, 1025, 2048, 3000], counts=[1, 5, 300, 3000])
 
 
-@pytest.mark.parametrize("vname", ["gpt2", "synth100k"])
+@pytest.mark.parametrize("vname", ["gpt2", "synth100k", "synth200k"])
 def test_piece_memo(lib, vocabs, oracle_mod, vname):
     v, ov = vocabs(vname)
     parity.check_piece_memo(lib, oracle_mod, v, ov)
     parity.check_piece_memo(lib, oracle_mod, v, ov, pattern=N.O200K, seed=31)
+
+
+def test_miss_lists(lib, vocabs, oracle_mod):
+    for vname, pat, seed in (("gpt2", N.CL100K, 41), ("synth100k", N.CL100K, 44), ("synth200k", N.O200K, 42)):
+        v, ov = vocabs(vname)
+        parity.check_miss_lists(lib, oracle_mod, v, ov, pattern=pat, seed=seed)
+
+
+def test_memo_zero_bytes_and_contention(lib, vocabs, oracle_mod):
+    """The piece memo under concurrent readers and writers of ONE bucket (two host threads = two streams on one encoder), with NUL-run
+    pieces of the contenders' lengths in the same batches; and the rule that pieces holding a zero byte bypass the memo."""
+    for vname in ("gpt2", "synth100k"):
+        v, ov = vocabs(vname)
+        parity.check_memo_zero_bytes(lib, oracle_mod, v, ov)
+        parity.check_memo_contention(lib, oracle_mod, v, ov, candidates=400_000, threads=2, rounds=6)
+
+
+def test_encoder_create_destroy_does_not_leak(lib, vocab):
+    """Every encoder owns its tables AND its 16 MB piece memo: creating and destroying encoders must leave the device's free memory flat."""
+    import torch
+    enc = N.Encoder(vocab, N.CL100K)
+    enc.encode_utf8(b"warm up the runtime's own pools")
+    enc.close()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        e = N.Encoder(vocab, N.CL100K)
+        e.encode_utf8(b"hello world")
+        e.close()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)          # 40 leaked memos would be 640 MB
 
 
 @pytest.mark.parametrize("vname", ["gpt2", "synth100k"])
@@ -244,11 +276,14 @@ def _token_lengths(ovocab):
     ("synth200k", 3, 3, 1_500, 30_000, 34_000), ("gpt2", 1, 1, 100_000, 16, 128), ("synth100k", 3, 2, 1_500, 30_000, 34_000),
     ("synth200k", 2, 3, 100_000, 256, 768),
     # BASELINE.json configs[1], [2] and one GPU's share of [4] at full size, on the stand-ins of the vocabularies they name
-    ("synth100k", 1, 2, 10_000_000, 256, 768), ("synth100k", 2, 2, 2_000_000, 256, 768), ("synth200k", 3, 3, 32_768, 30_000, 34_000)])
+    ("synth100k", 1, 2, 10_000_000, 256, 768), ("synth100k", 2, 2, 2_000_000, 256, 768), ("synth200k", 3, 3, 32_768, 30_000, 34_000),
+    # one GPU's share of BASELINE.json configs[3] (100 M documents over 8 GPUs): the LAST rank's 12.5 M documents
+    ("synth100k", 1, 2, 12_500_000, 256, 768)])
 def test_device_corpus_properties_and_sample(lib, vocabs, oracle_mod, vname, kind, pattern, n_docs, lo, hi):
     import torch
     vocab, oracle_gpt2 = vocabs(vname)
-    r = _device_run(lib, vocab, kind, pattern, n_docs, lo, hi, 0x5EED0000 + kind)
+    first_doc = 7 * n_docs if n_docs == 12_500_000 else 0
+    r = _device_run(lib, vocab, kind, pattern, n_docs, lo, hi, 0x5EED0000 + kind, first_doc=first_doc)
     ooffs = r["d_ooffs"]
     assert int(ooffs[0]) == 0 and int(ooffs[-1]) == r["ntok"]
     counts = ooffs[1:] - ooffs[:-1]
@@ -269,17 +304,19 @@ def test_device_corpus_properties_and_sample(lib, vocabs, oracle_mod, vname, kin
                                       torch.cuda.current_stream().cuda_stream)
     assert nb == r["total"] and torch.equal(d_back[:nb], r["d_bytes"][:nb]) and torch.equal(d_boffs, r["d_offs"])
     del d_back, d_boffs
-    # bit-exact vs the oracle on a sample of documents (first, last, and a stride through the middle)
-    oenc = oracle_mod.Encoder(oracle_gpt2, pattern)
+    # bit-exact vs the oracle on EVERY document of the batch, on all host cores (tkzo_check_batch: each document is encoded and
+    # compared in place with the ids the GPU left for it -- 10 M documents / 5.1 GB take a few seconds and no extra memory)
     h_offs = r["d_offs"].cpu().numpy()
     h_ooffs = ooffs.cpu().numpy()
-    pick = sorted(set(list(range(0, min(n_docs, 300))) + list(range(0, n_docs, max(1, n_docs // 300))) + [n_docs - 1]))
     h_ids = r["d_ids"].cpu().numpy()
     h_bytes = r["d_bytes"][:r["total"]].cpu().numpy()
+    bad, first_bad, otok = oracle_mod.check_batch(oracle_gpt2, pattern, h_bytes, h_offs, h_ids, h_ooffs, threads=max(1, os.cpu_count() or 1))
+    assert (bad, first_bad, otok) == (0, -1, r["ntok"]), "%d of %d documents differ from the oracle, first %d" % (bad, n_docs, first_bad)
+    # the generator: device == host, on a stride of documents
+    pick = sorted(set(list(range(0, min(n_docs, 300))) + list(range(0, n_docs, max(1, n_docs // 300))) + [n_docs - 1]))
     for d in pick:
         doc = h_bytes[h_offs[d]:h_offs[d + 1]].tobytes()
-        assert doc == N.corpus_doc_host(kind, 0x5EED0000 + kind, d, lo, hi, lib=lib)       # generator: device == host
-        assert h_ids[h_ooffs[d]:h_ooffs[d + 1]].tolist() == oenc.encode_bytes(doc), "doc %d" % d
+        assert doc == N.corpus_doc_host(kind, 0x5EED0000 + kind, d + first_doc, lo, hi, lib=lib)
 
 
 def test_host_path_chunked_and_threads(lib, vocabs, oracle_mod):

@@ -77,6 +77,9 @@ class Library:
         L.tkz_vocab_pair_table_entries.restype = i64
         L.tkz_encoder_memo_slots.argtypes = [vp]
         L.tkz_encoder_memo_slots.restype = i64
+        L.tkz_encoder_memo_ways.argtypes = [vp]
+        L.tkz_encoder_memo_bucket.argtypes = [vp, vp, i32]
+        L.tkz_encoder_memo_bucket.restype = i64
         L.tkz_unicode_classes.argtypes = [C.c_uint32, C.c_int32, vp]
         L.tkz_unicode_classes.restype = None
         L.tkz_encoder_pretok_leftovers.argtypes = [vp, pi64, pi64]
@@ -199,10 +202,13 @@ class Encoder:
         self._h = h
         self.pattern = pattern
 
-    def __del__(self):
+    def close(self):
         if getattr(self, "_h", None):
             self.lib.L.tkz_encoder_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        self.close()
 
     def set_option(self, opt, value):
         self.lib.check(self.lib.L.tkz_encoder_set_option(self._h, opt, value))
@@ -219,6 +225,14 @@ class Encoder:
     @property
     def memo_slots(self):
         return int(self.lib.L.tkz_encoder_memo_slots(self._h))
+
+    @property
+    def memo_ways(self):
+        return int(self.lib.L.tkz_encoder_memo_ways(self._h))
+
+    def memo_bucket(self, piece: bytes):
+        """Bucket of the piece memo a piece of 1..16 bytes uses (-1: none; pieces holding a zero byte never use the memo)."""
+        return int(self.lib.L.tkz_encoder_memo_bucket(self._h, piece, len(piece)))
 
     def pretok_leftovers(self):
         """(blocks the o200k ASCII block scanner handed on, blocks the multi-byte block scanner handed on to the sequential matcher) of the last batch."""

@@ -66,7 +66,7 @@ struct DevBuf {
 };
 
 struct CounterBlock {          // mirrors the device block
-    int32_t err; int32_t pad[3];
+    int32_t err; int32_t mneed /* longest miss list of a sub-tile (kErrMissCap) */; int32_t pad[2];
     int64_t grand;
     unsigned long long pool_head;
     int64_t ndocstarts;
@@ -90,6 +90,8 @@ struct tkz_vocab { tkz::Vocab v; };
 struct Workspace {
     // kernel workspace
     DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_dense, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
+    DevBuf w_mlist, w_mcount;
+    int32_t mcap = tkz::kMissCapMin;       // entries of a sub-tile's miss list; grows (once, to what the batch needed) when a sub-tile overflows it
     // staging for the host-buffer entry points (two sets: chunk k+1 is uploaded while chunk k is encoded and chunk k-1 downloaded)
     DevBuf s_bytes[2], s_offs[2], s_out[2], s_outoffs[2];
     // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
@@ -109,7 +111,7 @@ struct Workspace {
     double ms[tkz::K_COUNT] = {};
     int64_t launches[tkz::K_COUNT] = {};
     void release_all() {
-        DevBuf* bufs[] = {&w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
+        DevBuf* bufs[] = {&w_mlist, &w_mcount, &w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
                           &w_doctok, &w_dcount, &w_dbase, &w_counters, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
                           &s_outoffs[0], &s_outoffs[1], &u_units, &u_offs, &u_docbits, &u_grp, &u_tsum, &u_tbase, &u_bsum, &u_counters, &u_bytes, &u_boffs,
                           &d_grp, &d_tsum, &d_tbase, &d_bsum, &d_counters, &d_ids, &d_idoffs, &d_out, &d_outoffs, &p_boffs, &p_toffs, &p_docp};
@@ -243,7 +245,6 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
     if (total_tokens) *total_tokens = 0;
     if (n_docs == 0 && total != 0) return fail(TKZ_E_ARG, "bytes without documents");
     const int64_t nwords = total / 64 + 1;
-    HIP_TRY(e->t_counts3.ensure(32, &e->bytes_allocated));
     if (total == 0) {
         { tkz::Launch L0{stream, nullptr, ws}; tkz::launch_counts3(L0, n_docs, 0, nullptr, e->t_counts3.as<int64_t>()); }
         if (d_out_offs) HIP_TRY(hipMemsetAsync(d_out_offs, 0, (size_t)(n_docs + 1) * sizeof(int64_t), stream));
@@ -266,7 +267,10 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         // one 4-byte record per piece.  The number of pieces is known only after the pre-tokenizer has run (English/code text: a
         // piece per ~4.5 bytes; the bound is a piece per byte): the buffer starts at a piece per 3 bytes, k_probe refuses to write
         // past it, and the batch is redone once with the exact size if that was not enough
-        HIP_TRY(ws->w_prank.ensure((size_t)(total / 3 + 4096) * 4, acc));
+        // (+ 8 per sub-tile on average: every sub-tile's records start on a 64-byte line of their own)
+        HIP_TRY(ws->w_prank.ensure((size_t)(total / 3 + 8 * ntiles + 4096) * 4, acc));
+        HIP_TRY(ws->w_mlist.ensure((size_t)ntiles * (size_t)ws->mcap * 4, acc));
+        HIP_TRY(ws->w_mcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_tbase.ensure((size_t)ntiles * 8, acc));
         HIP_TRY(ws->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
         HIP_TRY(ws->w_doctok.ensure((size_t)((po ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
@@ -279,7 +283,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
     }
     if (!ws->h_counters) HIP_TRY(hipHostMalloc((void**)&ws->h_counters, sizeof(CounterBlock), 0));
 
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        bool pieces_over = false;
         Launch L{stream, e->profiling ? prof_hook : nullptr, ws};
         int32_t* counters = ws->w_counters.as<int32_t>();
         int64_t* grand = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, grand));
@@ -307,6 +312,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.offs = d_offs; P.n_docs = n_docs;
             P.tmp = ws->w_tmp.as<int32_t>(); P.dense = ws->w_dense.as<int32_t>(); P.tile_count = ws->w_tcount.as<int32_t>();
             P.prank = ws->w_prank.as<int32_t>(); P.prank_cap = (int64_t)(ws->w_prank.cap / 4); P.pcount = ws->w_pcount.as<int32_t>(); P.pbase = ws->w_pbase.as<int64_t>();
+            P.mlist = ws->w_mlist.as<uint32_t>(); P.mcap = ws->mcap; P.mcount = ws->w_mcount.as<uint32_t>();
             P.docord_base = ws->w_dbase.as<int64_t>(); P.doc_tok = ws->w_doctok.as<int32_t>(); P.counters = counters;
             P.giant_q = ws->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = ws->w_gcnt.as<int32_t>();
             P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
@@ -336,17 +342,19 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                 HIP_TRY(hipStreamSynchronize(stream));
                 np = ws->h_counters->ndocstarts;                  // piece starts below `total` (a document start is one)
                 po->n_pieces = np;
-                if (np > po->piece_cap) return fail(TKZ_E_CAPACITY, "piece arrays too small");
-                launch_piece_index(L, startbits, nwords, total, ntiles, ws->w_dbase.as<int64_t>(), np, po->piece_boffs, d_offs, n_docs, po->doc_piece);
+                // piece arrays too small: the launch sequence still runs to its end (without the piece arrays), so that the caller
+                // learns BOTH required sizes from this one call (tkz.h: *n_pieces and *needed_ids on TKZ_E_CAPACITY)
+                pieces_over = np > po->piece_cap;
+                if (!pieces_over) launch_piece_index(L, startbits, nwords, total, ntiles, ws->w_dbase.as<int64_t>(), np, po->piece_boffs, d_offs, n_docs, po->doc_piece);
             }
             // pieces that start in each sub-tile and their scan: where a sub-tile's records live in `prank`
             int64_t* npieces = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, npieces));
             launch_doccount(L, startbits, nwords, total, ntiles, ws->w_pcount.as<int32_t>());
-            launch_scan(L, ws->w_pcount.as<int32_t>(), ntiles, ws->w_bsum.as<int64_t>(), ws->w_pbase.as<int64_t>(), npieces, -1);
+            launch_scan(L, ws->w_pcount.as<int32_t>(), ntiles, ws->w_bsum.as<int64_t>(), ws->w_pbase.as<int64_t>(), npieces, -1, kRecordLine);
             launch_encode(L, e->T, P, ntiles);
             launch_scan(L, P.tile_count, ntiles, ws->w_bsum.as<int64_t>(), ws->w_tbase.as<int64_t>(), grand, K_SCAN);
             launch_place(L, P, ws->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
-            if (po) launch_docoffs(L, po->piece_boffs, po->n_pieces, total, ws->w_tbase.as<int64_t>(), markbits, P.docord_base, P.doc_tok, grand, po->piece_toffs);
+            if (po) { if (!pieces_over) launch_docoffs(L, po->piece_boffs, po->n_pieces, total, ws->w_tbase.as<int64_t>(), markbits, P.docord_base, P.doc_tok, grand, po->piece_toffs); }
             else launch_docoffs(L, d_offs, n_docs, total, ws->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs);
             launch_counts3(L, n_docs, total, grand, e->t_counts3.as<int64_t>());
         }
@@ -370,7 +378,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         if (err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the byte count");
         if (err & kErrUtf8) return fail(TKZ_E_INVALID_UTF8, "input is not well-formed UTF-8 (or a document boundary falls inside a character)");
         if (err & kErrTooLong) return fail(TKZ_E_UNSUPPORTED, "a single piece longer than 2^30 bytes");
-        if ((err & kErrPool) && attempt < 2) {
+        if ((err & kErrPool) && attempt < 4) {
             // scratch for the giant pieces was too small.  pool_head keeps counting past the capacity, so it holds the exact need
             // (6 int32 per byte of every giant piece of the batch): size the pool for that -- not for the whole batch -- and rerun
             const size_t need = (size_t)ws->h_counters->pool_head * 4 + 4096;
@@ -379,7 +387,19 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             continue;
         }
         if (err & kErrPool) return fail(TKZ_E_OUT_OF_MEMORY, "long-piece scratch exhausted");
-        if ((err & kErrCapacity) && attempt < 2) {          // more pieces than the record buffer was sized for: the exact count is known now
+        if ((err & kErrMissCap) && attempt < 4) {
+            // a sub-tile missed more pieces than its list holds (text where nearly every piece misses the vocabulary): the longest list
+            // any sub-tile needed is known now -- longer lists for this workspace from here on, and the batch again
+            int32_t want = kMissCapMin;
+            while (want < ws->h_counters->mneed && want < kMissCapMax) want *= 2;
+            if (want <= ws->mcap) return fail(TKZ_E_DEVICE, "miss list overflow");
+            if (ws->w_mlist.ensure((size_t)ntiles * (size_t)want * 4, acc) != hipSuccess)
+                return fail(TKZ_E_OUT_OF_MEMORY, "miss lists: " + std::to_string((size_t)ntiles * (size_t)want * 4) + " bytes could not be allocated");
+            ws->mcap = want;
+            continue;
+        }
+        if (err & kErrMissCap) return fail(TKZ_E_DEVICE, "miss list overflow");
+        if ((err & kErrCapacity) && attempt < 4) {          // more pieces than the record buffer was sized for: the exact count is known now
             const size_t need = ((size_t)ws->h_counters->npieces + 4096) * 4;
             if (ws->w_prank.ensure(need, acc) != hipSuccess)
                 return fail(TKZ_E_OUT_OF_MEMORY, "piece records: " + std::to_string(need) + " bytes could not be allocated");
@@ -389,6 +409,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         if (err & kErrKeyNotFound) return fail(TKZ_E_KEY_NOT_FOUND, "a byte of the input is not in the vocabulary (KeyNotFoundException in the reference)");
         if (!d_bitmap_only) {
             if (total_tokens) *total_tokens = ws->h_counters->grand;
+            if (pieces_over) return fail(TKZ_E_CAPACITY, "piece arrays too small");
             if (ws->h_counters->grand > out_cap) return fail(TKZ_E_CAPACITY, "output capacity too small");
         }
         return TKZ_OK;
@@ -615,6 +636,9 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     if (h == hipSuccess) h = upload(e->t_byte, V.byte_rank, acc);
     if (h == hipSuccess) h = upload(e->t_bpair, V.bytepair_rank, acc);
     if (h == hipSuccess) h = upload(e->t_bmp, tkz::bmp_class_table(), acc);
+    // {n_docs, n_bytes, n_tokens} of the last batch (tkz_encoder_counts_device): allocated once, here -- never from a call in flight
+    if (h == hipSuccess) h = e->t_counts3.ensure(32, acc);
+    if (h == hipSuccess) h = hipMemset(e->t_counts3.p, 0, 32);
     if (h != hipSuccess) { tkz_encoder_destroy(e); return fail(TKZ_E_DEVICE, std::string("table upload: ") + hipGetErrorString(h)); }
     e->T.short_slots = e->t_short.as<TkzShortSlot>(); e->T.short_nb = (uint32_t)(V.short_slots.size() / 2); e->T.short_seed = V.short_seed;
     e->T.mid_slots = reinterpret_cast<const TkzMidSlot*>(e->t_short.as<char>() + short_bytes); e->T.mid_ns = (uint32_t)V.mid_slots.size(); e->T.mid_seed = V.mid_seed;
@@ -652,7 +676,7 @@ void tkz_encoder_destroy(tkz_encoder* e) {
     if (!e) return;
     DeviceScope scope;
     (void)scope.enter(e->device);
-    DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp, &e->t_counts3, &e->t_decoff, &e->t_decblob, &e->t_decids};
+    DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp, &e->t_counts3, &e->t_memo, &e->t_decoff, &e->t_decblob, &e->t_decids};
     for (DevBuf* b : bufs) b->release();
     for (Workspace* w : e->pool) { w->release_all(); delete w; }
     delete e;
@@ -910,6 +934,11 @@ tkz_status tkz_decode_batch(tkz_encoder* e, const int32_t* ids, const int64_t* i
     HIP_TRY(ws->d_ids.ensure((size_t)std::max<int64_t>(total, 1) * 4, acc));
     HIP_TRY(ws->d_idoffs.ensure((size_t)(n_docs + 1) * 8, acc));
     HIP_TRY(ws->d_outoffs.ensure((size_t)(n_docs + 1) * 8, acc));
+    // (staging no larger than the result can be: an id yields at most the longest registered byte string, however large a hint out_cap is)
+    int64_t longest = 1;
+    { std::lock_guard<std::mutex> lock(e->mu); for (const auto& kv : e->dec_special) longest = std::max<int64_t>(longest, (int64_t)kv.second.size()); }
+    longest = std::max<int64_t>(longest, e->max_key_len);
+    out_cap = std::min<int64_t>(out_cap, total * longest);
     HIP_TRY(ws->d_out.ensure((size_t)std::max<int64_t>(out_cap, 1), acc));
     if (total) HIP_TRY(hipMemcpy(ws->d_ids.p, ids, (size_t)total * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ws->d_idoffs.p, id_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
@@ -926,11 +955,16 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
     if (!e) return fail(TKZ_E_ARG, "null encoder");
     if (option == TKZ_OPT_PRETOK_SEQUENTIAL) { e->pretok_seq = value != 0; return TKZ_OK; }
     if (option == TKZ_OPT_PIECE_MEMO) {
-        // 0: off, 1: on, 2: on and emptied (calls in flight on other threads are not waited for: they may still fill a few slots)
+        // 0: off, 1: on, 2: on and emptied.  Options are set while the encoder is idle: a call in flight on another thread reads
+        // T.memo_n when it launches, and emptying the table under running kernels could pair one piece's key with another's tokens
+        // -- so value 2 is refused while any workspace is leased, and the device is drained before the table is cleared.
         DeviceScope scope;
+        std::lock_guard<std::mutex> lock(e->mu);
         if (value == 2) {
             tkz_status st = check_encoder(e, scope);
             if (st != TKZ_OK) return st;
+            for (Workspace* w : e->pool) if (w->busy) return fail(TKZ_E_ARG, "the piece memo can only be emptied while no call of this encoder is in flight");
+            if (hipDeviceSynchronize() != hipSuccess) return fail(TKZ_E_DEVICE, "hipDeviceSynchronize");
             if (hipMemset(e->t_memo.p, 0, size_t(e->memo_slots) * sizeof(TkzMemoSlot)) != hipSuccess) return fail(TKZ_E_DEVICE, "hipMemset");
         }
         e->T.memo_n = value ? e->memo_slots : 0u;
@@ -960,6 +994,13 @@ void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_sca
     if (after_multibyte_scanner) *after_multibyte_scanner = e ? e->last_xcount2.load() : 0;
 }
 int64_t tkz_encoder_memo_slots(const tkz_encoder* e) { return e ? (int64_t)e->memo_slots : 0; }
+int32_t tkz_encoder_memo_ways(const tkz_encoder* e) { return e ? (int32_t)kMemoWays : 0; }
+int64_t tkz_encoder_memo_bucket(const tkz_encoder* e, const uint8_t* piece, int32_t len) {
+    if (!e || !piece || len < 1 || len > 16 || !e->memo_slots) return -1;
+    uint32_t kw[4] = {0, 0, 0, 0};
+    for (int32_t i = 0; i < len; ++i) { if (!piece[i]) return -1; kw[i >> 2] |= (uint32_t)piece[i] << (8 * (i & 3)); }      // (pieces with a zero byte never use the memo)
+    return (int64_t)tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), e->memo_slots / kMemoWays);
+}
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) {
     if (!e) return 0;
     tkz_encoder* m = const_cast<tkz_encoder*>(e);
@@ -976,7 +1017,7 @@ const char* tkz_kernel_name(int32_t k) {
 tkz_status tkz_corpus_generate_device(int32_t device, int32_t kind, uint64_t seed, int64_t first_doc, int64_t n_docs,
                                       int32_t min_len, int32_t max_len, int64_t* d_doc_offsets, uint8_t* d_bytes,
                                       int64_t cap_bytes, void* hip_stream, int64_t* total_bytes) {
-    if (kind < 1 || kind > 3 || n_docs < 0 || min_len < 0 || max_len < min_len || !d_doc_offsets || !total_bytes)
+    if (kind < 1 || kind > 5 || kind == 4 || n_docs < 0 || min_len < 0 || max_len < min_len || !d_doc_offsets || !total_bytes)
         return fail(TKZ_E_ARG, "bad corpus arguments");
     DeviceScope scope;
     hipError_t r = scope.enter(device);
@@ -1019,7 +1060,7 @@ tkz_status tkz_shard_bases(const int64_t* table, int32_t world, int32_t rank, in
 
 int64_t tkz_corpus_generate_doc_host(int32_t kind, uint64_t seed, int64_t doc_index, int32_t min_len, int32_t max_len,
                                      uint8_t* buf, int64_t cap) {
-    if (kind < 1 || kind > 3 || min_len < 0 || max_len < min_len) return -1;
+    if (kind < 1 || kind > 5 || kind == 4 || min_len < 0 || max_len < min_len) return -1;
     return tkz_corpus_doc(kind, seed, doc_index, min_len, max_len, buf, cap);
 }
 

@@ -22,7 +22,7 @@
 
 #define TKZ_NOKEY 0xFFFFFFFFu
 
-enum : int32_t { kErrUtf8 = 1, kErrKeyNotFound = 2, kErrOffsets = 4, kErrPool = 8, kErrTooLong = 16, kErrCapacity = 32 };
+enum : int32_t { kErrUtf8 = 1, kErrKeyNotFound = 2, kErrOffsets = 4, kErrPool = 8, kErrTooLong = 16, kErrCapacity = 32, kErrMissCap = 64 };
 
 
 // Per-lane scratch of tkz_bpe_lane<NMAX>: NMAX pair keys, 16-byte aligned so that the min scan is NMAX/4 16-byte LDS reads -- the

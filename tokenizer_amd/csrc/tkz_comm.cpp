@@ -6,13 +6,13 @@
 // document / token base of its shard.  It is issued here directly on RCCL (ncclAllGather over xGMI), so that the C# / C++
 // hosts the boundary is written for can shard without any Python or torch in the process.
 //
-// RCCL is bound at run time (dlopen of librccl.so.1), not at link time: a single-GPU host needs no RCCL installed, and in a
-// process that already holds a copy (PyTorch bundles one under the same soname) the loader hands back that very copy, so
-// there is never a second RCCL -- or a second HIP runtime -- in the process.  A missing library fails loudly at
-// tkz_comm_create / tkz_comm_unique_id (TKZ_E_UNSUPPORTED), never silently.
+// RCCL is bound at run time (dlopen of librccl.so.1), not at link time, and its header is not needed at build time either (the
+// handful of types and prototypes used are declared below, as RCCL's stable C API defines them): a single-GPU host needs no
+// RCCL installed to build or to run libtkz, and in a process that already holds a copy (PyTorch bundles one under the same
+// soname) the loader hands back that very copy, so there is never a second RCCL -- or a second HIP runtime -- in the process.
+// A missing library fails loudly at tkz_comm_create / tkz_comm_unique_id (TKZ_E_UNSUPPORTED), never silently.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstring>
@@ -25,16 +25,24 @@ namespace tkz { tkz_status set_error(tkz_status s, const std::string& msg); }
 
 namespace {
 
+// the part of RCCL's C API (rccl.h; identical to NCCL's) this file calls
+struct ncclUniqueId { char internal[128]; };
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;                  // enum ncclResult_t: ncclSuccess = 0
+constexpr ncclResult_t ncclSuccess = 0;
+typedef int ncclDataType_t;                // enum ncclDataType_t: ncclInt64 = 4
+constexpr ncclDataType_t ncclInt64 = 4;
+
 struct Rccl {
     void* handle = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclAllGather) AllGather = nullptr;
-    decltype(&ncclCommCount) CommCount = nullptr;
-    decltype(&ncclCommUserRank) CommUserRank = nullptr;
-    decltype(&ncclGetVersion) GetVersion = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
 

@@ -191,6 +191,7 @@ TKZ_HD int64_t tkz_corpus_doc(int kind, uint64_t seed, int64_t doc, int min_len,
     bool first = true;
     while (!e.full()) {
         if (long_runs && r.below(64) == 0) tkz_corpus_long_run(e, r);
+        else if (kind == 5) { e.put(' '); tkz_emit_word_rank(e, r.below(4096), 0); }     // words of the table, uniformly, each behind a single space
         else if (kind == 2) tkz_corpus_utf8_item(e, r, first);
         else tkz_corpus_ascii_item(e, r, first);
         first = false;

@@ -23,6 +23,8 @@ constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are m
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan
+constexpr int kRecordLine = 16;     // piece records per 64-byte line: every sub-tile's records start on a line of their own
+constexpr int kMissCapMin = 64, kMissCapMax = 1024;   // entries of a sub-tile's miss list: what a workspace starts with, and the most a sub-tile can need (a miss per byte)
 
 enum { K_DOCMARK = 0, K_PRETOK = 1, K_ENCODE = 2, K_SCAN = 3, K_GATHER = 4, K_DOCOFFS = 5, K_HEAVY = 6, K_MERGE_SHORT = 7, K_COUNT = 8 };
 
@@ -41,11 +43,13 @@ struct EncodeParams {
     int32_t* tile_count;          // tokens produced by each sub-tile
     int32_t* prank; int64_t prank_cap;   // one record per piece, in piece order (tkz_kernels.hip, "the encode stage")
     const int32_t* pcount;        // pieces that start in each sub-tile
-    const int64_t* pbase;         // ... and their exclusive scan: first piece ordinal of each sub-tile
+    const int64_t* pbase;         // ... and the exclusive scan of the counts rounded up to 16: where the sub-tile's records (whole lines) start
+    uint32_t* mlist; int32_t mcap;       // per sub-tile mcap entries: the short misses from the front, the long ones from the back; answered in place
+    uint32_t* mcount;             // per sub-tile: short misses | long misses << 16
     const int64_t* docord_base;   // per sub-tile: number of distinct document-start positions before it
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
-    int32_t* counters;            // [0] error bits
-    uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_probe: bit 0 = a piece of 17..1024 bytes to merge, bit 1 = a giant piece
+    int32_t* counters;            // [0] error bits, [1] the longest miss list seen (kErrMissCap)
+    uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_probe: bit 0 = long misses in its list, bit 1 = a giant piece
                                                                           // (a flag, not a queue: a queue's one counter serialises a million atomics on mixed text)
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)
     // pieces > kArenaPiece bytes ("giant"): found by k_giant_find, merged by k_giant_merge (one 1024-thread workgroup each); their
@@ -70,7 +74,8 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub);
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt);
 // exclusive scan int32 -> int64 (+ grand total); kid = profiling id of the bracket, or -1
-void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid);
+// round_to (a power of two): every count is rounded up to a multiple of it before it is summed
+void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid, int round_to = 1);
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap);
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
                     const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs);

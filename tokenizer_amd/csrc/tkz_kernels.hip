@@ -445,42 +445,50 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
 }
 
 // -------------------------------------------------------------------------------------------------
-// The encode stage: PROBE -> MERGE -> PLACE, three kernels over one array of per-piece records.
+// The encode stage: PROBE -> MERGE -> PLACE, three kernels joined by one record per piece and a short list of the pieces that missed.
 //
 // The per-piece driver of the reference (TikTokenizer.cs:250-274) does, for every regex match: whole-piece lookup (:262), else
 // BytePairEncode (:268), then appends the ids (:256,264,269).  On the device those three steps have very different shapes --
 // 94 % of the pieces of English/code text end at the lookup, a merge is a chain of ~10 dependent table gathers, and the append
 // needs a prefix sum over everything before it -- so they are three kernels, each shaped for its own bottleneck, joined by
 //
-//   prank[p]   one 32-bit record per piece, in piece order (p = piece ordinal of the batch; sub-tile s owns [pbase[s], pbase[s+1])):
-//              hit : rank | MARK                                  (MARK: a document -- or, at piece granularity, a piece -- starts here)
-//              miss: MISS | MARK | (len-1) << 10 | relpos         (relpos: byte offset inside the 1 KiB sub-tile), GIANT if len > 1024;
-//                    after its merge: MISS | MARK | DONE | (count-1) << 10 | relpos, the tokens waiting in tmp[abs .. abs + count),
-//                    or ... | DENSE | count-1 and offset (tkz_dense_rec), the tokens waiting in dense[group * kDenseCap + offset ..)
-//   dense[]    the tokens of the merged SHORT pieces of a group of 16 sub-tiles, packed in piece order (4096 per group; a miss costs
+//   prank[p]   one 32-bit record per piece, in piece order.  Sub-tile s owns [pbase[s], pbase[s] + pcount[s]); pbase is the scan of the
+//              counts ROUNDED UP TO 16 records, so that every sub-tile's records are whole 64-byte lines of its own: k_probe writes them
+//              once, in full lines, k_place reads them once.
+//              hit : rank | MARK                          (MARK: a document -- or, at piece granularity, a piece -- starts here)
+//              miss: MISS | MARK | idx                    (idx: its entry in the sub-tile's miss list; LONG: the list of the 17+-byte misses)
+//                    MISS | GIANT | MARK | relpos         (a piece of more than 1024 bytes: k_giant_*)
+//   mlist[s * mcap + i]   the sub-tile's MISS LIST: the misses of <= 16 bytes from the front (i = 0, 1, ...), those of 17..1024 bytes from the
+//              back (i = mcap - 1, mcap - 2, ...); mcount[s] = n_short | n_long << 16.  An entry is  relpos | (len - 1) << 10  when k_probe
+//              writes it and  DONE | DENSE? | (count - 1) << 12 | offset  once its piece is merged (the merge kernels answer in place).
+//              The merge kernels read ONLY these lists (~6 % of the pieces), never the records; mcap starts at 64 entries per sub-tile
+//              and the batch is redone once with a larger one when a sub-tile needed more (text where nearly every piece misses).
+//   dense[]    the tokens of the merged SHORT pieces of a group of 16 sub-tiles, packed in list order (4096 per group; a miss costs
 //              ~4 tokens = one 16-byte store next to its neighbour's, not a 64-byte line of its own in k_merge_short and again in k_place)
 //   tmp[b]     4 B per input byte, touched only under LONG missed pieces (and what overflows dense[]): a piece's tokens fit inside
 //              its own byte span (tokens <= bytes)
 //
-//   k_probe        one wavefront per 1 KiB sub-tile, 32 wavefronts per CU (48 VGPRs, 3 KB LDS): piece enumeration from the bitmap,
-//                  SHORT probes (the first candidate bucket = two 16-byte gathers per piece, the second bucket only for the lanes that
-//                  did not find their key; two batches of 64 pieces in flight), MID probes, records stored coalesced
-//   k_merge_short  one wavefront per group of 16 sub-tiles: the misses of up to 16 bytes are packed 64 to a wavefront -- looked up in
+//   k_probe        one wavefront per 1 KiB sub-tile, 32 wavefronts per CU: piece enumeration from the bitmap, the 13..28-byte pieces
+//                  first (MID table, results parked in LDS), then SHORT probes (the first candidate bucket = two 16-byte gathers per
+//                  piece, the second bucket only for the lanes that did not find their key; two batches of 64 pieces in flight; key
+//                  dwords computed once and kept), every batch's 64 records stored as four full lines, misses appended to the list
+//   k_merge_short  one wavefront per group of 16 sub-tiles: their short-miss lists are packed 64 to a wavefront -- looked up in
 //                  the piece memo (the reference's LRUCache on the device), the survivors merged, every lane busy (tkz_bpe_lane) --
 //                  instead of the ~14 of 64 a sub-tile has on its own.  Also the per-sub-tile token counts.
 //   k_giant_find / k_giant_merge, k_merge_long   the rare long ones: > 1024 bytes by a whole workgroup in rounds (tkz_bpe_long),
-//                  17..1024 bytes one per lane in an LDS arena (tkz_bpe_lane_var), only in the sub-tiles k_probe flagged
+//                  17..1024 bytes from the long-miss lists of 64 sub-tiles at a time, each in a span of an LDS arena
 //   (scan of the token counts)
-//   k_place        one wavefront per sub-tile: count per record -> prefix -> ids stored at their final position, token index
-//                  of every marked piece for the document offsets
-// Round 1 did all of this in one kernel per sub-tile: 96 VGPRs + 7.6 KB LDS (20 waves/CU), a merge stage with 15 of 64 lanes
-// busy, and a second, 3x slower kernel for every sub-tile that held one piece of 17+ bytes to merge -- half of all sub-tiles
-// on text with identifiers or long words.
+//   k_place        one wavefront per sub-tile: count per record -> prefix -> ids staged in LDS and stored as whole 16-byte quads at
+//                  their final position, token index of every marked piece for the document offsets
+// Workgroup b of k_probe / k_merge_short / k_place works on sub-tile range (b % 8) * (n / 8) + b / 8: consecutive sub-tiles -- which share the
+// lines at the edges of their id and record ranges -- run on ONE XCD (workgroup b is dispatched to XCD b % 8) and meet in its L2.
 // -------------------------------------------------------------------------------------------------
-constexpr uint32_t kPrMiss = 1u << 31, kPrMark = 1u << 30, kPrDone = 1u << 29, kPrGiant = 1u << 28, kPrDense = 1u << 27;
+constexpr uint32_t kPrMiss = 1u << 31, kPrMark = 1u << 30, kPrLong = 1u << 29, kPrGiant = 1u << 28;
 constexpr uint32_t kPrRankMask = (1u << 28) - 1u;       // ranks are < 2^27 (TKZ_MAX_RANK)
-constexpr int kPrLenShift = 10;
-constexpr uint32_t kPrLenMask = 0x7FFu;                 // len - 1 / count - 1 (< 1024), in bits 10..20
+constexpr uint32_t kMrDone = 1u << 31, kMrDense = 1u << 30;
+constexpr int kMrLenShift = 10, kMrCntShift = 12;
+constexpr uint32_t kMrOffMask = (1u << kMrCntShift) - 1u;
+static_assert(kDenseCap <= (1 << kMrCntShift) && kSub <= (1 << kMrLenShift), "the offset field of a result entry");
 #ifndef TKZ_PROBE_U
 #define TKZ_PROBE_U 2
 #endif
@@ -492,6 +500,11 @@ constexpr uint32_t kPrLenMask = 0x7FFu;                 // len - 1 / count - 1 (
 #endif
 constexpr int kGroup = kMergeGroup;                     // sub-tiles per wavefront of k_merge_short
 constexpr int kMsThreads = TKZ_MS_THREADS;              // ... and the workgroup size of that kernel
+constexpr int kMidMax = kSub / (TKZ_SHORT_KEY_MAX + 1) + 2;   // pieces of 13+ bytes that can start in one sub-tile
+
+// The workgroup a block stands for: blocks b, b + 8, b + 16 ... of a grid run on one XCD (observed dispatch: XCD = b % 8; for speed only,
+// nothing depends on it), so XCD x takes the x-th eighth of the work, in order.  nblocks is a multiple of 8.
+TKZ_DEV int64_t tkz_xcd_block(int64_t b, int64_t nblocks) { return (b & 7) * (nblocks >> 3) + (b >> 3); }
 
 // exclusive prefix over the wave of a small non-negative value (< 2^BITS), and the wave total;
 // bit-sliced: one ballot + mbcnt per bit, no LDS traffic
@@ -518,22 +531,35 @@ TKZ_DEV int tkz_wave_scan_sum(int v, int* total) {
 
 // dword i of the key that starts at byte s of the LDS-staged sub-tile, zero-padded past len
 TKZ_DEV uint32_t tkz_key_dword(const uint32_t* s_bytes, int s, int len, int i) {
-    const int w = (s >> 2) + i, sh = (s & 3) * 8;
-    const uint32_t x = (uint32_t)((((uint64_t)s_bytes[w + 1] << 32) | s_bytes[w]) >> sh);
+    const int w = (s >> 2) + i;
+    const uint32_t x = simt::alignbit(s_bytes[w + 1], s_bytes[w], (uint32_t)(s & 3) * 8u);
     const int nb = len - 4 * i;
     return nb >= 4 ? x : (nb <= 0 ? 0u : (x & ((1u << (8 * nb)) - 1u)));
 }
 
 TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
-    TKZ_SHARED uint32_t s_bytes_all[kThreads / 64][(kSub + kHalo) / 4];
+    TKZ_SHARED uint4 s_bytes_all[kThreads / 64][(kSub + kHalo) / 16];
     TKZ_SHARED uint16_t s_pstart_all[kThreads / 64][kSub + 2];
-    TKZ_SHARED uint16_t s_mid_all[kThreads / 64][kSub / (TKZ_SHORT_KEY_MAX + 1) + 2];   // pieces of 13..28 bytes of the sub-tile (<= 78 of them)
+    TKZ_SHARED uint16_t s_mid_all[kThreads / 64][kMidMax];                // the pieces of 13..28 bytes of the sub-tile ...
+    TKZ_SHARED uint32_t s_midres_all[kThreads / 64][kMidMax];             // ... and what the MID table says about them
+    TKZ_SHARED uint32_t s_mark_all[kThreads / 64][kSub / 32];             // document (piece) marks of the sub-tile, 32 positions per dword
+    TKZ_SHARED uint4 s_kmask[TKZ_SHORT_KEY_MAX + 1];                      // byte mask of a zero-padded key of 0..12 bytes (three dwords)
     const int lane = simt::lane();
-    const int64_t sub = simt::bid() * (kThreads / 64) + simt::wave();
-    if (sub >= P.nsub) return;                            // (no workgroup barrier anywhere: every wavefront is on its own)
-    uint32_t* s_bytes = s_bytes_all[simt::wave()];
+    if (simt::tid() <= TKZ_SHORT_KEY_MAX) {
+        const int len = simt::tid();
+        uint32_t m[3];
+        for (int i = 0; i < 3; ++i) { const int nb = len - 4 * i; m[i] = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u)); }
+        uint4 v; v.x = m[0]; v.y = m[1]; v.z = m[2]; v.w = 0;
+        s_kmask[len] = v;
+    }
+    simt::sync();                                         // (the only workgroup barrier: from here on every wavefront is on its own)
+    const int64_t sub = tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave();
+    if (sub >= P.nsub) return;
+    uint32_t* s_bytes = reinterpret_cast<uint32_t*>(s_bytes_all[simt::wave()]);
     uint16_t* s_pstart = s_pstart_all[simt::wave()];
     uint16_t* s_mid = s_mid_all[simt::wave()];
+    uint32_t* s_midres = s_midres_all[simt::wave()];
+    uint32_t* s_mark = s_mark_all[simt::wave()];
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_bytes);
     const int64_t base = sub * kSub;
     const int nb = (int)(P.total - base < kSub ? P.total - base : kSub);
@@ -572,11 +598,11 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
     uint64_t ahead = (w0 + lane < P.nwords) ? P.startbits[w0 + lane] : 0ull;
     const int64_t pb = P.pbase[sub];
     // ---- consume ----
-    s_bytes[4 * lane + 0] = v0.x; s_bytes[4 * lane + 1] = v0.y; s_bytes[4 * lane + 2] = v0.z; s_bytes[4 * lane + 3] = v0.w;
-    if (lane + 64 < (kSub + kHalo) / 16) { const int i = lane + 64; s_bytes[4 * i + 0] = v1.x; s_bytes[4 * i + 1] = v1.y; s_bytes[4 * i + 2] = v1.z; s_bytes[4 * i + 3] = v1.w; }
+    { uint4* s4 = reinterpret_cast<uint4*>(s_bytes); s4[lane] = v0; if (lane + 64 < (kSub + kHalo) / 16) s4[lane + 64] = v1; }
     if (lane < kSub / 64) {
         const int lim = nb - lane * 64;                    // bits at or beyond the end of the corpus are not pieces
         if (lim <= 0) myword = 0; else if (lim < 64) myword &= tkz_lowmask(lim);
+        s_mark[2 * lane] = (uint32_t)mymark; s_mark[2 * lane + 1] = (uint32_t)(mymark >> 32);
     }
     // end of the last piece that starts here = first piece start at or after base+nb (the sentinel at `total` bounds it)
     int64_t last_end;
@@ -595,7 +621,8 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
         }
         last_end = found;
     }
-    const int64_t last_end_rel = last_end - base;
+    // (anything beyond kArenaPiece bytes is a giant piece, whose real length k_giant_find takes from the bitmap)
+    const int last_end_rel = (int)(last_end - base < 2 * kSub + 2 ? last_end - base : 2 * kSub + 2);
     // ---- ordered compaction of the piece starts (bit-sliced ballot prefix, no LDS scan) ----
     const uint32_t wlo = simt::shflu((uint32_t)myword, lane >> 2), whi = simt::shflu((uint32_t)(myword >> 32), lane >> 2);
     const uint32_t bits16 = (uint32_t)(((((uint64_t)whi << 32) | wlo) >> (16 * (lane & 3))) & 0xFFFFull);
@@ -603,103 +630,35 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
     {
         int off = tkz_wave_scan<5>(tkz_popc32(bits16), &np);
         for (uint32_t b = bits16; b; b &= b - 1) s_pstart[off++] = (uint16_t)(16 * lane + tkz_ctz32(b));
+        if (lane == 0) s_pstart[np] = (uint16_t)last_end_rel;         // (sentinel: the length of piece k is s_pstart[k + 1] - s_pstart[k])
     }
     (void)simt::ballot(true);                              // (LDS written by other lanes of this wavefront is read below)
     if (prof) t_1 = simt::clock();
     const char* tb0 = reinterpret_cast<const char*>(T.short_slots);
     const uint32_t mid_off = (uint32_t)(reinterpret_cast<const char*>(T.mid_slots) - tb0);   // (SHORT and MID share one allocation)
-    uint32_t flags = 0;
+    // ---- the pieces of 13..28 bytes first: a few per cent of all pieces, twice the instructions of a short one.  Looked up together,
+    // 64 per batch, and their answers parked in LDS by ordinal: the main loop below then stores every batch's 64 records as four FULL
+    // lines (patching these few records in afterwards punched holes into every line: 1.7x the write traffic) ----
     int nmid = 0;
-    // Two batches of 64 pieces per iteration, their gathers in flight together (what a sub-tile costs is its count of dependent
-    // round trips to the tables); the pieces of 13..28 bytes -- a few per cent of all pieces, whose lookup costs twice the
-    // instructions of a short one -- are only noted here and looked up together after the loop.
-    constexpr int U = TKZ_PROBE_U;                         // batches of 64 pieces whose gathers are in flight together
 #pragma unroll 1
-    for (int k0 = 0; k0 < np; k0 += 64 * U) {
-        int ps[U], plen[U];
-        uint32_t hs[U];
-        uint4 a0[U], a1[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = k0 + 64 * u + lane;
-            ps[u] = 0; plen[u] = 0; hs[u] = 0;
-            uint32_t oa = 0;
-            if (k < np) {
-                const int s = s_pstart[k];
-                const int64_t len64 = (k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s;
-                const int len = len64 > kArenaPiece ? kArenaPiece + 1 : (int)len64;
-                ps[u] = s; plen[u] = len;
-                if (len <= TKZ_SHORT_KEY_MAX)
-                    oa = 16u * tkz_short_slot_first(T, tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len, &hs[u]);
-            }
-            // the FIRST candidate bucket of every piece (idle lanes and longer pieces gather slot 0: a load inside a divergent branch
-            // is waited for inside it)
-            a0[u] = tkz_load16(tb0 + oa); a1[u] = tkz_load16(tb0 + oa + 16u);
-        }
-        int32_t rk[U];
-        bool more = false;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int s = ps[u], len = plen[u];
-            const bool is_short = k0 + 64 * u + lane < np && len <= TKZ_SHORT_KEY_MAX;
-            rk[u] = TKZ_RANK_NONE;
-            if (is_short) rk[u] = tkz_match_short2(tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len, a0[u], a1[u]);
-            more = more || (is_short && rk[u] == TKZ_RANK_NONE);
-        }
-        // the second bucket, for the lanes the first one did not settle only (the keys the builder could not keep in their first
-        // bucket, and the pieces that are not keys at all): ~15 % of the requests of the first step instead of another 100 %
-        if (simt::ballot(more)) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool want = k0 + 64 * u + lane < np && plen[u] <= TKZ_SHORT_KEY_MAX && rk[u] == TKZ_RANK_NONE;
-                if (want) {
-                    const uint32_t ob = 16u * tkz_short_slot_second(T, hs[u]);
-                    a0[u] = tkz_load16(tb0 + ob); a1[u] = tkz_load16(tb0 + ob + 16u);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int s = ps[u], len = plen[u];
-                const bool want = k0 + 64 * u + lane < np && len <= TKZ_SHORT_KEY_MAX && rk[u] == TKZ_RANK_NONE;
-                if (want) rk[u] = tkz_match_short2(tkz_key_dword(s_bytes, s, len, 0), tkz_key_dword(s_bytes, s, len, 1), tkz_key_dword(s_bytes, s, len, 2), (uint32_t)len, a0[u], a1[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int k = k0 + 64 * u + lane;
-            const bool valid = k < np;
-            const int s = ps[u], len = plen[u];
-            const uint64_t mw = ((uint64_t)simt::shflu((uint32_t)(mymark >> 32), (s >> 6) & 15) << 32) | simt::shflu((uint32_t)mymark, (s >> 6) & 15);
-            const bool is_mid = valid && len > TKZ_SHORT_KEY_MAX && len <= TKZ_MID_KEY_MAX;
-            const uint64_t midm = simt::ballot(is_mid);
-            if (is_mid) s_mid[nmid + tkz_popc64(midm & tkz_lowmask(lane))] = (uint16_t)k;
-            nmid += tkz_popc64(midm);
-            if (valid && !is_mid) {
-                int32_t rank;                                                    // Encoder.TryGetValue(piece) (TikTokenizer.cs:262)
-                if (len <= TKZ_SHORT_KEY_MAX) rank = rk[u];
-                else if (len > kArenaPiece) rank = TKZ_RANK_NONE;                // (k_giant_merge looks a giant piece up itself)
-                else if (s + len <= kSub + kHalo) rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)len);
-                else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return gbase[s + i]; }, (uint32_t)len);
-                uint32_t rec = ((mw >> (s & 63)) & 1ull) ? kPrMark : 0u;
-                if (rank != TKZ_RANK_NONE) rec |= (uint32_t)rank;
-                else if (len > kArenaPiece) { rec |= kPrMiss | kPrGiant | (uint32_t)s; flags |= 2u; }
-                else { rec |= kPrMiss | ((uint32_t)(len - 1) << kPrLenShift) | (uint32_t)s; if (len > kShortMax) flags |= 1u; }
-                if (pb + k < P.prank_cap) tkz_store_nt(&P.prank[pb + k], (int32_t)rec);
-            }
-        }
+    for (int k0 = 0; k0 < np; k0 += 64) {
+        const int k = k0 + lane;
+        int len = 0;
+        if (k < np) len = (int)s_pstart[k + 1] - (int)s_pstart[k];
+        const uint64_t midm = simt::ballot(len > TKZ_SHORT_KEY_MAX && len <= TKZ_MID_KEY_MAX);
+        if ((midm >> lane) & 1ull) s_mid[nmid + tkz_popc64(midm & tkz_lowmask(lane))] = (uint16_t)k;
+        nmid += tkz_popc64(midm);
     }
     (void)simt::ballot(true);
-    if (prof) t_2 = simt::clock();
-    // ---- the pieces of 13..28 bytes: MID table, 64 per batch ----
 #pragma unroll 1
     for (int m0 = 0; m0 < nmid; m0 += 64) {
         const bool valid = m0 + lane < nmid;
-        int k = 0, s = 0, len = 13;
+        int s = 0, len = 13;
         uint32_t kk[7] = {0, 0, 0, 0, 0, 0, 0}, oa = 0, ob = 0;
         if (valid) {
-            k = s_mid[m0 + lane];
+            const int k = s_mid[m0 + lane];
             s = s_pstart[k];
-            len = (int)((k + 1 < np ? (int64_t)s_pstart[k + 1] : last_end_rel) - s);
+            len = (int)s_pstart[k + 1] - s;
 #pragma unroll
             for (int i = 0; i < 7; ++i) kk[i] = tkz_key_dword(s_bytes, s, len, i);
             uint32_t s1, s2;
@@ -707,26 +666,112 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
             oa = mid_off + 32u * s1; ob = mid_off + 32u * s2;
         }
         const uint4 a0 = tkz_load16(tb0 + oa), a1 = tkz_load16(tb0 + oa + 16u), b0 = tkz_load16(tb0 + ob), b1 = tkz_load16(tb0 + ob + 16u);
-        const uint64_t mw = ((uint64_t)simt::shflu((uint32_t)(mymark >> 32), (s >> 6) & 15) << 32) | simt::shflu((uint32_t)mymark, (s >> 6) & 15);
-        if (valid) {
-            const int32_t rank = tkz_match_mid(kk, (uint32_t)len, a0, a1, b0, b1);
-            uint32_t rec = ((mw >> (s & 63)) & 1ull) ? kPrMark : 0u;
-            if (rank != TKZ_RANK_NONE) rec |= (uint32_t)rank;
-            else { rec |= kPrMiss | ((uint32_t)(len - 1) << kPrLenShift) | (uint32_t)s; if (len > kShortMax) flags |= 1u; }
-            if (pb + k < P.prank_cap) tkz_store_nt(&P.prank[pb + k], (int32_t)rec);
+        if (valid) s_midres[m0 + lane] = (uint32_t)tkz_match_mid(kk, (uint32_t)len, a0, a1, b0, b1);
+    }
+    (void)simt::ballot(true);
+    if (prof) t_2 = simt::clock();
+    // ---- the main loop: two batches of 64 pieces per iteration, their gathers in flight together (what a sub-tile costs is its count of
+    // dependent round trips to the tables) ----
+    uint32_t* const ml = P.mlist + sub * (int64_t)P.mcap;
+    int ns = 0, nl = 0, midseen = 0;
+    bool giant = false;
+    constexpr int U = TKZ_PROBE_U;                         // batches of 64 pieces whose gathers are in flight together
+#pragma unroll 1
+    for (int k0 = 0; k0 < np; k0 += 64 * U) {
+        int ps[U], plen[U];
+        uint32_t hs[U], kw0[U], kw1[U], kw2[U];
+        uint4 a0[U], a1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 64 * u + lane;
+            ps[u] = 0; plen[u] = 0;
+            if (k < np) { ps[u] = s_pstart[k]; plen[u] = (int)s_pstart[k + 1] - ps[u]; }
+            // the key's three dwords, zero-padded: four aligned dwords, three v_alignbit, one mask row -- computed ONCE and kept
+            const int s = ps[u], w = s >> 2;
+            const uint32_t sh = (uint32_t)(s & 3) * 8u;
+            const uint32_t d0 = s_bytes[w], d1 = s_bytes[w + 1], d2 = s_bytes[w + 2], d3 = s_bytes[w + 3];
+            const bool is_short = plen[u] >= 1 && plen[u] <= TKZ_SHORT_KEY_MAX;
+            const uint4 km = s_kmask[is_short ? plen[u] : 0];
+            kw0[u] = simt::alignbit(d1, d0, sh) & km.x; kw1[u] = simt::alignbit(d2, d1, sh) & km.y; kw2[u] = simt::alignbit(d3, d2, sh) & km.z;
+            const uint32_t slot = tkz_short_slot_first(T, kw0[u], kw1[u], kw2[u], (uint32_t)plen[u], &hs[u]);
+            // the FIRST candidate bucket of every piece (idle lanes and longer pieces gather slot 0: a load inside a divergent branch
+            // is waited for inside it)
+            const uint32_t oa = is_short ? 16u * slot : 0u;
+            a0[u] = tkz_load16(tb0 + oa); a1[u] = tkz_load16(tb0 + oa + 16u);
+        }
+        int32_t rk[U];
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool is_short = plen[u] >= 1 && plen[u] <= TKZ_SHORT_KEY_MAX;
+            rk[u] = TKZ_RANK_NONE;
+            if (is_short) rk[u] = tkz_match_short2(kw0[u], kw1[u], kw2[u], (uint32_t)plen[u], a0[u], a1[u]);
+            more = more || (is_short && rk[u] == TKZ_RANK_NONE);
+        }
+        // the second bucket, for the lanes the first one did not settle only (the keys the builder could not keep in their first
+        // bucket, and the pieces that are not keys at all): ~15 % of the requests of the first step instead of another 100 %
+        if (simt::ballot(more)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool want = plen[u] >= 1 && plen[u] <= TKZ_SHORT_KEY_MAX && rk[u] == TKZ_RANK_NONE;
+                if (want) {
+                    const uint32_t ob = 16u * tkz_short_slot_second(T, hs[u]);
+                    a0[u] = tkz_load16(tb0 + ob); a1[u] = tkz_load16(tb0 + ob + 16u);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool want = plen[u] >= 1 && plen[u] <= TKZ_SHORT_KEY_MAX && rk[u] == TKZ_RANK_NONE;
+                if (want) rk[u] = tkz_match_short2(kw0[u], kw1[u], kw2[u], (uint32_t)plen[u], a0[u], a1[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + 64 * u + lane;
+            const bool valid = k < np;
+            const int s = ps[u], len = plen[u];
+            const bool is_mid = len > TKZ_SHORT_KEY_MAX && len <= TKZ_MID_KEY_MAX;
+            const uint64_t midm = simt::ballot(is_mid);
+            int32_t rank = rk[u];                                                // Encoder.TryGetValue(piece) (TikTokenizer.cs:262)
+            if (is_mid) rank = (int32_t)s_midres[midseen + tkz_popc64(midm & tkz_lowmask(lane))];
+            midseen += tkz_popc64(midm);
+            if (len > TKZ_MID_KEY_MAX && len <= kArenaPiece) {
+                if (s + len <= kSub + kHalo) rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)len);
+                else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return gbase[s + i]; }, (uint32_t)len);
+            }
+            const bool is_giant = len > kArenaPiece;                             // (k_giant_merge looks a giant piece up itself)
+            const bool miss = valid && !is_giant && rank == TKZ_RANK_NONE;
+            const bool miss_s = miss && len <= kShortMax, miss_l = miss && len > kShortMax;
+            const uint64_t sm = simt::ballot(miss_s), lm = simt::ballot(miss_l);
+            const int is_ = ns + tkz_popc64(sm & tkz_lowmask(lane)), il = nl + tkz_popc64(lm & tkz_lowmask(lane));
+            ns += tkz_popc64(sm); nl += tkz_popc64(lm);
+            // (the two lists grow towards each other; an entry that would run into the other list is not written -- ns + nl > mcap is then
+            //  reported below and the batch redone with longer lists)
+            const uint32_t ent = (uint32_t)s | ((uint32_t)(len - 1) << kMrLenShift);
+            if (miss_s && is_ + nl < P.mcap) ml[is_] = ent;
+            if (miss_l && il + ns < P.mcap) ml[P.mcap - 1 - il] = ent;
+            uint32_t rec = ((s_mark[s >> 5] >> (s & 31)) & 1u) ? kPrMark : 0u;
+            if (is_giant) { rec |= kPrMiss | kPrGiant | (uint32_t)s; giant = giant || valid; }
+            else if (miss) rec |= kPrMiss | (miss_l ? (kPrLong | (uint32_t)il) : (uint32_t)is_);
+            else rec |= (uint32_t)rank;
+            if (valid && pb + k < P.prank_cap) tkz_store_nt(&P.prank[pb + k], (int32_t)rec);
         }
     }
     if (prof && lane == 0) {
         t_3 = simt::clock();
         simt::atomic_add64(&P.devprof[0], 1); simt::atomic_add64(&P.devprof[1], (unsigned long long)(t_3 - t_0));
-        simt::atomic_add64(&P.devprof[2], (unsigned long long)(t_1 - t_0)); simt::atomic_add64(&P.devprof[3], (unsigned long long)(t_2 - t_1));
-        simt::atomic_add64(&P.devprof[4], (unsigned long long)(t_3 - t_2)); simt::atomic_add64(&P.devprof[5], (unsigned long long)nmid);
+        simt::atomic_add64(&P.devprof[2], (unsigned long long)(t_1 - t_0)); simt::atomic_add64(&P.devprof[3], (unsigned long long)(t_3 - t_2));
+        simt::atomic_add64(&P.devprof[4], (unsigned long long)(t_2 - t_1)); simt::atomic_add64(&P.devprof[5], (unsigned long long)nmid);
         simt::atomic_add64(&P.devprof[6], (unsigned long long)np);
     }
-    // sub-tiles with a piece of 17+ bytes to merge (bit 0) or a giant piece (bit 1) are visited by k_merge_long / k_giant_find
-    const uint32_t f = (simt::ballot(flags & 1u) ? 1u : 0u) | (simt::ballot(flags & 2u) ? 2u : 0u);
-    if (lane == 0) P.heavy_flag[sub] = (uint8_t)f;
-    if (pb + np > P.prank_cap && lane == 0) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
+    // sub-tiles with long misses (bit 0: statistics only, the lists say it) or a giant piece (bit 1: k_giant_find, k_merge_long, k_place)
+    const uint32_t f = (nl ? 1u : 0u) | (simt::ballot(giant) ? 2u : 0u);
+    if (lane == 0) {
+        P.heavy_flag[sub] = (uint8_t)f;
+        P.mcount[sub] = (uint32_t)ns | ((uint32_t)nl << 16);
+        if (ns + nl > P.mcap) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&P.counters[1], (unsigned)(ns + nl)); }
+        if (pb + np > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
+    }
 }
 
 // the 16 bytes of the corpus that start at byte position `abs`, as four little-endian dwords: the five dwords around them are fetched
@@ -734,7 +779,7 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
 struct alignas(4) TkzDwords4 { uint32_t x, y, z, w; };
 TKZ_DEV void tkz_load_piece16(const uint8_t* bytes, int64_t total, int64_t abs, uint32_t* pw) {
     const int64_t a0 = abs & ~(int64_t)3;
-    const int sh = (int)(abs & 3) * 8;
+    const uint32_t sh = (uint32_t)(abs & 3) * 8u;
     uint32_t w[5];
     if (a0 + 20 <= total) {
         const TkzDwords4 v = *reinterpret_cast<const TkzDwords4*>(bytes + a0);
@@ -749,34 +794,43 @@ TKZ_DEV void tkz_load_piece16(const uint8_t* bytes, int64_t total, int64_t abs, 
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pw[i] = (uint32_t)((((uint64_t)w[i + 1] << 32) | w[i]) >> sh);
+    for (int i = 0; i < 4; ++i) pw[i] = simt::alignbit(w[i + 1], w[i], sh);
 }
 
-// a DENSE record (tokens of a merged short piece in the group's packed region): count - 1 in bits 10..13, offset in bits 0..9 and 14..20
-TKZ_HD uint32_t tkz_dense_rec(int cnt, int off) {
-    return kPrDense | ((uint32_t)(cnt - 1) << kPrLenShift) | ((uint32_t)off & 1023u) | (((uint32_t)off >> 10) << 14);
-}
-TKZ_HD int tkz_dense_off(uint32_t rec) { return (int)((rec & 1023u) | (((rec >> 14) & 0x7Fu) << 10)); }
-TKZ_HD int tkz_dense_cnt(uint32_t rec) { return (int)((rec >> kPrLenShift) & 15u) + 1; }
-static_assert(kDenseCap <= (1 << 17), "the offset field of a DENSE record");
+// the result a merge kernel leaves in a miss-list entry: the piece's tokens wait in dense[group * kDenseCap + off ..) (DENSE) or in tmp at
+// the piece's own byte position (off = relpos)
+TKZ_HD uint32_t tkz_result_entry(bool dense, int cnt, int off) { return kMrDone | (dense ? kMrDense : 0u) | ((uint32_t)(cnt - 1) << kMrCntShift) | (uint32_t)off; }
+TKZ_HD int tkz_result_cnt(uint32_t r) { return (int)((r >> kMrCntShift) & 1023u) + 1; }
+TKZ_HD int tkz_result_off(uint32_t r) { return (int)(r & kMrOffMask); }
 
-// k_merge_short: one wavefront per group of kGroup = 16 sub-tiles.  It streams the group's records and collects the misses of <= 16
-// bytes in a 64-entry list; whenever the list is full the entries that have not been looked up yet go through the PIECE MEMO (the
-// device form of the reference's LRUCache, tkz_tables.h): a hit has its <= 4 tokens at once, the survivors stay in the list, and only
-// when the list is full of survivors are 64 of them merged, one per lane (BytePairEncode, TikTokenizer.cs:268).  Merged pieces of <= 4
-// tokens claim their memo slot if it is empty.  On the bench corpus 3 of 4 missed pieces are memo hits: a merge costs ~45 scattered
-// gathers and ~8 dependent round trips, a memo lookup 4 and one.
-// (LDS: 4 x 9.25 KB of merge state + 1.8 KB = 39.7 KB per workgroup, and <= 128 VGPRs: four workgroups = 16 wavefronts per CU)
+// largest q in [0, N) with pre[q] <= g  (pre: non-decreasing exclusive prefix sums in LDS, g below the total): the list a position belongs to
+template <int N>
+TKZ_DEV int tkz_find_list(const int* pre, int g) {
+    int q = 0;
+#pragma unroll
+    for (int step = N / 2; step >= 1; step >>= 1) if (pre[q + step] <= g) q += step;
+    return q;
+}
+
+// k_merge_short: one wavefront per group of kGroup = 16 sub-tiles.  It walks the group's short-miss lists (k_probe's mlist: ~14 entries per
+// sub-tile) 64 entries at a time; the entries that have not been looked up yet go through the PIECE MEMO (the device form of the
+// reference's LRUCache, tkz_tables.h): a hit has its <= 4 tokens at once, the survivors stay in the wave's list, and only when that is
+// full of survivors are 64 of them merged, one per lane (BytePairEncode, TikTokenizer.cs:268).  Merged pieces of <= 4 tokens claim
+// their memo slot if it is empty.  On the bench corpus 3 of 4 missed pieces are memo hits: a merge costs ~45 scattered gathers and ~8
+// dependent round trips, a memo lookup 4 and one.  Every entry is answered in place (tkz_result_entry); the records are never read.
+// (LDS: 4 x 9.25 KB of merge state + 2.3 KB = 40 KB per workgroup, and <= 128 VGPRs: four workgroups = 16 wavefronts per CU)
 TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride, IDSTRIDE = TkzBpeGeom<NMAX>::kIdStride;
     TKZ_SHARED uint4 s_pr_all[kMsThreads / 64][(STRIDE * 64) / 4];        // per lane pr[16] at a conflict-free stride for 16-byte reads
     TKZ_SHARED uint32_t s_ids_all[kMsThreads / 64][IDSTRIDE * 64];        // per lane ids[16]
-    // the list: relpos | (len-1) << 10 | mark << 14 | looked-up-in-the-memo << 15, and (sub-tile of the group) << 10 | piece index
+    // the wave's list: relpos | (len-1) << 10 | looked-up-in-the-memo << 15, and (sub-tile of the group) << 10 | index in its miss list
     TKZ_SHARED uint16_t s_rec_all[kMsThreads / 64][64];
     TKZ_SHARED uint16_t s_idx_all[kMsThreads / 64][64];
     TKZ_SHARED int s_extra_all[kMsThreads / 64][kGroup];                  // tokens the merges added to every sub-tile of the group
+    TKZ_SHARED int s_pre_all[kMsThreads / 64][kGroup + 1];                // exclusive prefix of the lists' lengths
     // the id of every single byte in LDS, not 16 gathers per piece (0xFFFF: not a key, 0xFFFE: too large for 16 bits, look it up)
     TKZ_SHARED uint16_t s_brank16[256];
+    static_assert(kGroup == 16 && kShortMax == 16, "list entries: 4 bits of sub-tile, 10 of index; 10 of relpos, 4 of length, 1 flag");
     const int lane = simt::lane(), wv = simt::wave();
     for (int i = simt::tid(); i < 256; i += simt::nthreads()) {
         const uint32_t v = (uint32_t)T.byte_rank[i];
@@ -788,63 +842,84 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
         return v < 0xFFFEu ? v : (v == 0xFFFFu ? (uint32_t)TKZ_PSEUDO_BASE + b : (uint32_t)T.byte_rank[b]);
     };
     auto pair_rank = [&](uint32_t b0, uint32_t b1) -> int32_t { return T.bytepair_rank[(b0 << 8) | b1]; };
-    const int64_t sub0 = (simt::bid() * (kMsThreads / 64) + wv) * kGroup;
+    const int64_t grp = tkz_xcd_block(simt::bid(), simt::nblocks()) * (kMsThreads / 64) + wv;
+    const int64_t sub0 = grp * kGroup;
     if (sub0 >= P.nsub) return;
     uint16_t* s_rec = s_rec_all[wv];
     uint16_t* s_idx = s_idx_all[wv];
     int* s_extra = s_extra_all[wv];
+    int* s_pre = s_pre_all[wv];
     uint32_t* ids = &s_ids_all[wv][lane * IDSTRIDE];
     uint32_t* pr = reinterpret_cast<uint32_t*>(s_pr_all[wv]) + lane * STRIDE;
-    // lane q < kGroup keeps what belongs to sub-tile q of the group: where its records start and how many there are
-    static_assert(kGroup <= 64 && kGroup * 1024 <= 65536, "one lane per sub-tile of the group; (sub-tile, piece) in 16 bits");
-    int64_t my_pb = 0; int my_np = 0;
-    if (lane < kGroup && sub0 + lane < P.nsub) { my_pb = P.pbase[sub0 + lane]; my_np = P.pcount[sub0 + lane]; }
+    // lane q < kGroup looks after sub-tile q of the group: how many pieces start there, how long its short-miss list is
+    int my_np = 0, my_ns = 0;
+    if (lane < kGroup && sub0 + lane < P.nsub) { my_np = P.pcount[sub0 + lane]; my_ns = (int)(P.mcount[sub0 + lane] & 0xFFFFu); }
+    // (a list longer than mcap was cut by k_probe, which has reported it: the batch is redone; keep to what was written)
+    { const int nl_ = lane < kGroup && sub0 + lane < P.nsub ? (int)(P.mcount[sub0 + lane] >> 16) : 0; if (my_ns + nl_ > P.mcap) my_ns = 0; }
+    int ntotal;
+    { const int pre = tkz_wave_scan_sum(my_ns, &ntotal); if (lane <= kGroup) s_pre[lane] = pre; }
     if (lane < kGroup) s_extra[lane] = 0;
-    auto pb_of = [&](int q) -> int64_t { return ((int64_t)simt::shfl((int)(my_pb >> 32), q) << 32) | (uint32_t)simt::shfl((int)my_pb, q); };
-    int err = 0, nlist = 0, nchk = 0, dused = 0;              // list entries [0, nchk) have been through the memo, [nchk, nlist) not yet
-    int32_t* const dense = P.dense + (sub0 / kGroup) * kDenseCap;
+    uint32_t* const ml0 = P.mlist + sub0 * (int64_t)P.mcap;
+    int err = 0, nlist = 0, nchk = 0, dused = 0, done = 0;      // list entries [0, nchk) have been through the memo, [nchk, nlist) not yet
+    int32_t* const dense = P.dense + grp * kDenseCap;
     const bool memo = T.memo_n != 0;
     // where the `cnt` tokens of a piece go -- packed behind those of the pieces before it in the group's dense region (in tmp, at the
-    // piece's own byte position, once that is full) -- and its record; every lane of the wavefront calls it (a scan and a shuffle inside)
-    auto assign = [&](bool have, int cnt, int si, int k, int rel, bool mark) -> int32_t* {
+    // piece's own byte position, once that is full) -- and the answer in its list entry; every lane of the wavefront calls it (a scan inside)
+    auto assign = [&](bool have, int cnt, int si, int j, int rel) -> int32_t* {
         int btot;
         const int doff = dused + tkz_wave_scan_sum(have ? cnt : 0, &btot);
-        const int64_t pbk = pb_of(si);
         int32_t* dst = nullptr;
         if (have) {
             const bool packed = doff + cnt <= kDenseCap;
             dst = packed ? dense + doff : P.tmp + ((sub0 + si) * kSub + rel);
-            P.prank[pbk + k] = kPrMiss | (mark ? kPrMark : 0u) | kPrDone | (packed ? tkz_dense_rec(cnt, doff) : (((uint32_t)(cnt - 1) << kPrLenShift) | (uint32_t)rel));
+            ml0[si * (int64_t)P.mcap + j] = tkz_result_entry(packed, cnt, packed ? doff : rel);
             if (cnt > 1) simt::atomic_add(&s_extra[si], cnt - 1);
         }
         dused += btot;
         return dst;
     };
-    // the piece of a list entry: its 16 bytes, zeroed beyond its length (the memo key)
-    auto load_key = [&](int si, int rel, int len, uint32_t* kw) {
+    // the piece of a list entry: its 16 bytes, zeroed beyond its length (the memo key); *nul = it holds a zero byte
+    auto load_key = [&](int si, int rel, int len, uint32_t* kw, bool* nul) {
         tkz_load_piece16(P.bytes, P.total, (sub0 + si) * kSub + rel, kw);
+        uint32_t z = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int nb = len - 4 * i; kw[i] = nb >= 4 ? kw[i] : (nb <= 0 ? 0u : (kw[i] & ((1u << (8 * nb)) - 1u))); }
+        for (int i = 0; i < 4; ++i) {
+            const int nb = len - 4 * i;
+            const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+            kw[i] &= m;
+            z |= (kw[i] - 0x01010101u) & ~kw[i] & 0x80808080u & m;
+        }
+        *nul = z != 0;
     };
-    // the entries that have not been through the memo: hits are done (tokens, record), the others stay in the list, in order
+    // the entries that have not been through the memo: hits are done (tokens, answer), the others stay in the list, in order.
+    // A piece that holds a zero byte never uses the memo -- neither looked up nor inserted: a slot's words are either still zero or final
+    // (an entry never changes once valid), so whatever mixture of old and new words a reader may be handed -- the key and the value are
+    // two loads, and a slot can be claimed between them -- a key without zero bytes inside its length can only ever equal a COMPLETE key of the
+    // same length, and then the value it is paired with is either that key's (valid) or not valid at all.
     auto memo_phase = [&]() {
         (void)simt::ballot(true);
         uint32_t r16 = 0, ix = 0;
         if (lane < nlist) { r16 = s_rec[lane]; ix = s_idx[lane]; }
         const bool mine = lane >= nchk && lane < nlist;
-        const int si = (int)(ix >> 10), k = (int)(ix & 1023u), rel = (int)(r16 & 1023u), len = (int)((r16 >> 10) & 15u) + 1;
+        const int si = (int)(ix >> 10), j = (int)(ix & 1023u), rel = (int)(r16 & 1023u), len = (int)((r16 >> 10) & 15u) + 1;
         bool hit = false;
         uint4 vv; vv.x = vv.y = vv.z = vv.w = 0;
         if (mine && memo) {
             uint32_t kw[4];
-            load_key(si, rel, len, kw);
-            const TkzMemoSlot* slot = &T.memo[tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), T.memo_n)];
-            const uint4 kk = tkz_load16(&slot->k[0]);
-            vv = tkz_load16(&slot->v[0]);
-            hit = (vv.x & kMemoValid) && vv.x != kMemoBusy && kk.x == kw[0] && kk.y == kw[1] && kk.z == kw[2] && kk.w == kw[3] && (vv.y >> 27) == (uint32_t)(len - 1);
+            bool nul;
+            load_key(si, rel, len, kw, &nul);
+            const uint32_t b = tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), T.memo_n / kMemoWays) * kMemoWays;
+#pragma unroll
+            for (int wy = 0; wy < kMemoWays; ++wy) {
+                const TkzMemoSlot* slot = &T.memo[b + wy];
+                const uint4 kk = tkz_load16(&slot->k[0]);
+                const uint4 v = tkz_load16(&slot->v[0]);
+                const bool h = !nul && (v.x & kMemoValid) && v.x != kMemoBusy && kk.x == kw[0] && kk.y == kw[1] && kk.z == kw[2] && kk.w == kw[3] && (v.y >> 27) == (uint32_t)(len - 1);
+                if (h) { hit = true; vv = v; }
+            }
         }
         const int cnt = hit ? (int)((vv.x >> 29) & 3u) + 1 : 0;
-        int32_t* dst = assign(hit, cnt, si, k, rel, ((r16 >> 14) & 1u) != 0);
+        int32_t* dst = assign(hit, cnt, si, j, rel);
         if (hit) {
             dst[0] = (int32_t)(vv.x & 0x07FFFFFFu);
             if (cnt > 1) dst[1] = (int32_t)(vv.y & 0x07FFFFFFu);
@@ -860,71 +935,60 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     // one batch: lane i < n merges the piece of list entry i (all of them have missed the memo)
     auto run_batch = [&](int n) {
         (void)simt::ballot(true);
-        int cnt = 0, si = 0, k = 0, rel = 0, e1 = 0, len = 1;
-        bool mark = false;
+        int cnt = 0, si = 0, j = 0, rel = 0, e1 = 0, len = 1;
+        bool nul = false;
         uint32_t alive = 1;
         uint32_t kw[4] = {0, 0, 0, 0};
         if (lane < n) {
             const uint32_t r16 = s_rec[lane], ix = s_idx[lane];
-            si = (int)(ix >> 10); k = (int)(ix & 1023u); rel = (int)(r16 & 1023u); len = (int)((r16 >> 10) & 15u) + 1; mark = ((r16 >> 14) & 1u) != 0;
-            load_key(si, rel, len, kw);
+            si = (int)(ix >> 10); j = (int)(ix & 1023u); rel = (int)(r16 & 1023u); len = (int)((r16 >> 10) & 15u) + 1;
+            load_key(si, rel, len, kw, &nul);
             cnt = tkz_bpe_lane_f<NMAX>(T, kw, len, ids, pr, byte_id, pair_rank, &alive, &e1);
             err |= e1;
         }
-        int32_t* dst = assign(lane < n, cnt, si, k, rel, mark);
+        int32_t* dst = assign(lane < n, cnt, si, j, rel);
         if (lane < n) {
             uint32_t t4[4] = {0, 0, 0, 0};
             int i = 0;
             for (uint32_t a = alive; a; a &= a - 1) { const uint32_t t = ids[tkz_ctz32(a)]; dst[i] = (int32_t)t; if (i < 4) { if (i == 0) t4[0] = t; else if (i == 1) t4[1] = t; else if (i == 2) t4[2] = t; else t4[3] = t; } ++i; }
-            // a piece of <= 4 tokens takes its memo slot if nobody has (an entry is never replaced: a hit stays valid for good)
-            if (memo && cnt <= 4 && !e1) {
-                TkzMemoSlot* slot = &T.memo[tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), T.memo_n)];
-                // (a plain load first: a piece that lost its slot to another one comes back millions of times on repetitive text, and a
-                //  failing compare-and-swap is still an atomic on one hot address)
-                if (*reinterpret_cast<volatile uint32_t*>(&slot->v[0]) == 0u && simt::atomic_cas(&slot->v[0], 0u, kMemoBusy) == 0u) {
-                    uint4 kk; kk.x = kw[0]; kk.y = kw[1]; kk.z = kw[2]; kk.w = kw[3];
-                    *reinterpret_cast<uint4*>(&slot->k[0]) = kk;
-                    slot->v[1] = ((uint32_t)(len - 1) << 27) | t4[1]; slot->v[2] = t4[2]; slot->v[3] = t4[3];
-                    simt::fence();
-                    *reinterpret_cast<volatile uint32_t*>(&slot->v[0]) = kMemoValid | ((uint32_t)(cnt - 1) << 29) | t4[0];
+            // a piece of <= 4 tokens takes a memo slot of its bucket if one is free (an entry is never replaced: a hit stays valid for good)
+            if (memo && cnt <= 4 && !e1 && !nul) {
+                const uint32_t b = tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), T.memo_n / kMemoWays) * kMemoWays;
+                bool placed = false;
+#pragma unroll
+                for (int wy = 0; wy < kMemoWays; ++wy) {
+                    TkzMemoSlot* slot = &T.memo[b + wy];
+                    // (a plain load first: a piece that lost its slot to another one comes back millions of times on repetitive text, and a
+                    //  failing compare-and-swap is still an atomic on one hot address)
+                    if (!placed && *reinterpret_cast<volatile uint32_t*>(&slot->v[0]) == 0u && simt::atomic_cas(&slot->v[0], 0u, kMemoBusy) == 0u) {
+                        uint4 kk; kk.x = kw[0]; kk.y = kw[1]; kk.z = kw[2]; kk.w = kw[3];
+                        *reinterpret_cast<uint4*>(&slot->k[0]) = kk;
+                        slot->v[1] = ((uint32_t)(len - 1) << 27) | t4[1]; slot->v[2] = t4[2]; slot->v[3] = t4[3];
+                        simt::fence();
+                        *reinterpret_cast<volatile uint32_t*>(&slot->v[0]) = kMemoValid | ((uint32_t)(cnt - 1) << 29) | t4[0];
+                        placed = true;
+                    }
                 }
             }
         }
         (void)simt::ballot(true);
     };
-#pragma unroll 1
-    for (int si = 0; si < kGroup; ++si) {
-        const int64_t pb = pb_of(si);
-        const int np = simt::shfl(my_np, si);
-#pragma unroll 1
-        for (int k0 = 0; k0 < np; k0 += 256) {               // four record loads in flight per lane (a sub-tile averages ~230 pieces)
-            uint32_t r4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + 64 * j + lane;
-                r4[j] = (k < np && pb + k < P.prank_cap) ? (uint32_t)tkz_load_nt(&P.prank[pb + k]) : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t rec = r4[j];
-                const bool is = (rec & kPrMiss) && !(rec & kPrGiant) && (int)((rec >> kPrLenShift) & kPrLenMask) < kShortMax;
-                const uint64_t m = simt::ballot(is);
-                const int c = tkz_popc64(m);
-                if (c == 0) continue;
-                if (nlist + c > 64) {                       // no room: the memo first, then -- if its survivors still leave none -- a merge batch
-                    memo_phase();
-                    if (nlist + c > 64) { run_batch(nlist); nlist = nchk = 0; }
-                }
-                if (is) {
-                    const int o = nlist + tkz_popc64(m & tkz_lowmask(lane));
-                    s_rec[o] = (uint16_t)((rec & 1023u) | (((rec >> kPrLenShift) & 15u) << 10) | ((rec & kPrMark) ? 1u << 14 : 0u));
-                    s_idx[o] = (uint16_t)((si << 10) | (k0 + 64 * j + lane));
-                }
-                nlist += c;
-            }
+    (void)simt::ballot(true);
+    while (done < ntotal) {
+        // the next entries of the group's lists, as many as the wave's list has room for: position g of the concatenated lists is entry
+        // g - pre[q] of sub-tile q
+        const int take = ntotal - done < 64 - nlist ? ntotal - done : 64 - nlist;
+        if (lane < take) {
+            const int g = done + lane;
+            const int q = tkz_find_list<kGroup>(s_pre, g), j = g - s_pre[q];
+            const uint32_t ent = tkz_load_nt(&ml0[q * (int64_t)P.mcap + j]);
+            s_rec[nlist + lane] = (uint16_t)((ent & 1023u) | (((ent >> kMrLenShift) & 15u) << 10));
+            s_idx[nlist + lane] = (uint16_t)((q << 10) | j);
         }
+        nlist += take; done += take;
+        memo_phase();
+        if (nlist == 64) { run_batch(64); nlist = nchk = 0; }
     }
-    memo_phase();
     if (nlist > 0) run_batch(nlist);
     (void)simt::ballot(true);
     // tokens of every sub-tile of the group: one per piece, plus what the merges added (k_merge_long adds its own later)
@@ -932,13 +996,13 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
 
-// The pieces of 17..1024 bytes that have to be merged, and the token counts of the giant ones: only in the sub-tiles k_probe
-// flagged.  One lane per piece with its state in a span of an LDS arena sized for it (tkz_bpe_lane_var: ids | pair ranks | alive
-// bits, preceded by the piece's bytes); the long misses of the 64 sub-tiles of a chunk are packed into one wavefront's lanes -- as
-// many per batch as the arena and the 64 lanes take -- because a sub-tile on its own has one or two of them.
+// The pieces of 17..1024 bytes that have to be merged, and the token counts of the giant ones.  One lane per piece with its state in a
+// span of an LDS arena sized for it (tkz_bpe_lane_var: ids | pair ranks | alive bits, preceded by the piece's bytes); the long-miss
+// lists of the 64 sub-tiles of a chunk are walked as one list and packed into one wavefront's lanes -- as many per batch as the arena
+// and the 64 lanes take -- because a sub-tile on its own has one or two of them.
 TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
     TKZ_SHARED uint4 s_arena4[kArenaDwords / 4];
-    TKZ_SHARED uint32_t s_rec[64], s_idx[64], s_aoff[64];
+    TKZ_SHARED int s_pre[65];
     TKZ_SHARED int32_t s_brank[256];                                     // id of every single byte: in LDS, not a gather per byte
     uint32_t* s_arena = reinterpret_cast<uint32_t*>(s_arena4);
     const int lane = simt::lane();
@@ -948,32 +1012,54 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
     const bool compact = T.max_rank <= kVarCompactMaxRank;      // no ids[] array (tkz_bpe_lane_varc): 40 % more pieces per batch
     for (int64_t c = simt::bid(); c * 64 < P.nsub; c += simt::nblocks()) {
         const int64_t t = c * 64 + lane;
-        const uint32_t myflag = t < P.nsub ? P.heavy_flag[t] : 0u;
-        uint64_t fm = simt::ballot(myflag != 0);
-        if (!fm) continue;
-        int nlist = 0, aused = 0;
-        // one batch: lane i < nlist stages the bytes of its piece, merges it, leaves the tokens in tmp at the piece's own position
-        auto run_batch = [&]() {
-            (void)simt::ballot(true);
-            if (lane < nlist) {
-                const uint32_t rec = s_rec[lane], ix = s_idx[lane];
-                const int64_t sub = c * 64 + (int64_t)(ix >> 10);
-                const int rel = (int)(rec & 1023u), len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+        int my_nl = 0;
+        if (t < P.nsub) {
+            const uint32_t mc = P.mcount[t];
+            my_nl = (int)(mc >> 16);
+            if ((int)(mc & 0xFFFFu) + my_nl > P.mcap) my_nl = 0;               // (cut list: reported by k_probe, the batch is redone)
+            // the giant piece of the sub-tile (its last piece): merged by k_giant_merge, its token count is added here
+            if (P.heavy_flag[t] & 2u) { const int g = P.giant_cnt[t]; if (g > 1) simt::atomic_add(&P.tile_count[t], g - 1); }   // (< 0: no pool, the call is retried)
+        }
+        int ntotal;
+        const int pre = tkz_wave_scan_sum(my_nl, &ntotal);
+        if (!ntotal) continue;
+        (void)simt::ballot(true);
+        s_pre[lane] = pre;
+        if (lane == 0) s_pre[64] = ntotal;
+        (void)simt::ballot(true);
+        // position g of the 64 lists taken as one: entry g - pre[q] (from the back) of sub-tile q.  A batch = the next positions, one per
+        // lane, up to the first whose state no longer fits the arena.
+        for (int done = 0; done < ntotal;) {
+            const int g = done + lane;
+            const bool valid = g < ntotal;
+            int q = 0, j = 0, len = 1, rel = 0;
+            if (valid) {
+                q = tkz_find_list<64>(s_pre, g); j = g - s_pre[q];
+                const uint32_t ent = tkz_load_nt(&P.mlist[(c * 64 + q) * (int64_t)P.mcap + (P.mcap - 1 - j)]);
+                rel = (int)(ent & 1023u); len = (int)((ent >> kMrLenShift) & 1023u) + 1;
+            }
+            const int nbw = (len + 3) >> 2;
+            const int need = valid ? ((nbw + 3) & ~3) + (compact ? tkz_bpe_varc_dwords(len) : tkz_bpe_var_dwords(len)) : 0;
+            int btot;
+            const int aoff = tkz_wave_scan_sum(need, &btot);
+            const uint64_t bad = simt::ballot(valid && aoff + need > kArenaDwords);
+            const int limit = bad ? tkz_ctz64(bad) : 64;                       // lanes at or beyond `limit` wait for the next batch (limit >= 1: one piece always fits)
+            if (valid && lane < limit) {
+                const int64_t sub = c * 64 + q;
                 const int64_t abs = sub * kSub + rel;
-                uint32_t* bw = &s_arena[s_aoff[lane]];           // (len + 3) / 4 dwords of bytes, then the merge state
-                const int nbw = (len + 3) >> 2;
+                uint32_t* bw = &s_arena[aoff];                   // (len + 3) / 4 dwords of bytes, then the merge state
                 {
                     const int64_t a0 = abs & ~(int64_t)3;
-                    const int sh = (int)(abs & 3) * 8;
+                    const uint32_t sh = (uint32_t)(abs & 3) * 8u;
                     uint32_t prev = 0;
                     if (a0 + 4 <= P.total) prev = *reinterpret_cast<const uint32_t*>(P.bytes + a0);
                     else for (int b = 0; b < 4; ++b) if (a0 + b < P.total) prev |= (uint32_t)P.bytes[a0 + b] << (8 * b);
-                    for (int q = 0; q < nbw; ++q) {
-                        const int64_t p = a0 + 4 * (q + 1);
+                    for (int w = 0; w < nbw; ++w) {
+                        const int64_t p = a0 + 4 * (w + 1);
                         uint32_t nx = 0;
                         if (p + 4 <= P.total) nx = *reinterpret_cast<const uint32_t*>(P.bytes + p);
                         else for (int b = 0; b < 4; ++b) if (p + b < P.total) nx |= (uint32_t)P.bytes[p + b] << (8 * b);
-                        bw[q] = (uint32_t)((((uint64_t)nx << 32) | prev) >> sh);
+                        bw[w] = simt::alignbit(nx, prev, sh);
                         prev = nx;
                     }
                 }
@@ -987,69 +1073,77 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
                     tkz_bpe_var_emit(st, len, P.tmp + abs);
                 }
                 err |= e1;
-                P.prank[P.pbase[sub] + (ix & 1023u)] = (rec & (kPrMiss | kPrMark)) | kPrDone | ((uint32_t)(cnt - 1) << kPrLenShift) | (uint32_t)rel;
+                P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_entry(false, cnt, rel);
                 if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
             }
             (void)simt::ballot(true);
-            nlist = 0; aused = 0;
-        };
-        for (; fm; fm &= fm - 1) {
-            const int sidx = tkz_ctz64(fm);
-            const int64_t sub = c * 64 + sidx;
-            const int64_t pb = P.pbase[sub];
-            const int np = P.pcount[sub];
-#pragma unroll 1
-            for (int k0 = 0; k0 < np; k0 += 256) {               // four record loads in flight per lane
-                uint32_t r4[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = k0 + 64 * j + lane;
-                    r4[j] = (k < np && pb + k < P.prank_cap) ? (uint32_t)tkz_load_nt(&P.prank[pb + k]) : 0u;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t rec = r4[j];
-                    const int len = (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
-                    const bool is = (rec & kPrMiss) && !(rec & (kPrGiant | kPrDone)) && len > kShortMax;
-                    // the giant piece of the sub-tile (its last piece): merged by k_giant_merge, its token count is added here
-                    if ((rec & kPrMiss) && (rec & kPrGiant)) { const int g = P.giant_cnt[sub]; if (g > 1) simt::atomic_add(&P.tile_count[sub], g - 1); }   // (< 0: no pool, the call is retried)
-                    uint64_t pending = simt::ballot(is);
-                    while (pending) {
-                        const bool mine = is && ((pending >> lane) & 1ull);
-                        const int need = mine ? ((((len + 3) >> 2) + 3) & ~3) + (compact ? tkz_bpe_varc_dwords(len) : tkz_bpe_var_dwords(len)) : 0;
-                        int btot;
-                        const int aoff = aused + tkz_wave_scan_sum(need, &btot);
-                        const int qi = nlist + tkz_popc64(pending & tkz_lowmask(lane));
-                        const bool fits = mine && qi < 64 && aoff + need <= kArenaDwords;
-                        const uint64_t bad = simt::ballot(mine && !fits);
-                        const int limit = bad ? tkz_ctz64(bad) : 64;       // lanes at or beyond `limit` wait for the next batch
-                        if (fits && lane < limit) { s_rec[qi] = rec; s_idx[qi] = ((uint32_t)sidx << 10) | (uint32_t)(k0 + 64 * j + lane); s_aoff[qi] = (uint32_t)aoff; }
-                        const uint64_t took = pending & tkz_lowmask(limit);
-                        nlist += tkz_popc64(took);
-                        aused = bad ? simt::shfl(aoff, limit) : aused + btot;
-                        pending &= ~took;
-                        if (pending) run_batch();
-                    }
-                }
-            }
+            done += limit < ntotal - done ? limit : ntotal - done;
         }
-        if (nlist > 0) run_batch();
     }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
 
-// ids at their final position: count per record -> prefix -> stores; the token index (inside the sub-tile) of every marked piece
+// ids at their final position: count per record -> prefix -> the sub-tile's ids staged in LDS -> stored as whole 16-byte quads (one
+// store instruction = 16 full lines; per-lane 4-byte stores at variable offsets wrote 1.8x the bytes); the token index (inside the
+// sub-tile) of every marked piece
+constexpr int kStage = kSub + 32;                          // ids of pieces of <= 16 tokens that start in one sub-tile (<= 1024 + 15) + the alignment shift
 TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
+    TKZ_SHARED uint4 s_stage_all[kThreads / 64][kStage / 4];
+    TKZ_SHARED uint32_t s_res_all[kThreads / 64][128];                    // the first 64 answers of the sub-tile's short-miss list, and of the long one
     const int lane = simt::lane();
-    const int64_t sub = simt::bid() * (kThreads / 64) + simt::wave();
+    const int64_t sub = tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave();
     if (sub >= P.nsub) return;
+    int32_t* stage = reinterpret_cast<int32_t*>(s_stage_all[simt::wave()]);
+    uint32_t* s_res = s_res_all[simt::wave()];
     const int64_t pb = P.pbase[sub], tb = tile_base[sub], base = sub * kSub, ord0 = P.docord_base[sub];
     const int np = P.pcount[sub];
+    const uint32_t mc = P.mcount[sub];
+    const int ns = (int)(mc & 0xFFFFu), nl = (int)(mc >> 16);
+    const uint32_t* const ml = P.mlist + sub * (int64_t)P.mcap;
     const int32_t* const dense = P.dense + (sub / kGroup) * kDenseCap;
     const bool has_giant = (P.heavy_flag[sub] & 2u) != 0;
     int gcnt = has_giant ? P.giant_cnt[sub] : 0;
     if (gcnt < 0) gcnt = 0;
-    int running = 0, marks = 0;
+    const bool lists_ok = ns + nl <= P.mcap;               // (cut lists: the batch is redone, nothing of this pass is used)
+    {   // the answers of the merge kernels, in the same round trip as the first records
+        uint32_t a = 0, b = 0;
+        if (lists_ok && lane < ns) a = tkz_load_nt(&ml[lane]);
+        if (lists_ok && lane < nl) b = tkz_load_nt(&ml[P.mcap - 1 - lane]);
+        s_res[lane] = a; s_res[64 + lane] = b;
+    }
+    (void)simt::ballot(true);
+    // where the tokens of a missed piece wait, and how many there are
+    auto locate = [&](uint32_t rec, int* cnt) -> const int32_t* {
+        if (rec & kPrGiant) { *cnt = gcnt; return P.tmp + base + (rec & 1023u); }
+        const int idx = (int)(rec & 1023u);
+        const bool lg = (rec & kPrLong) != 0;
+        uint32_t r = 0;
+        if (lists_ok) r = idx < 64 ? s_res[(lg ? 64 : 0) + idx] : ml[lg ? P.mcap - 1 - idx : idx];
+        *cnt = tkz_result_cnt(r);
+        return (r & kMrDense) ? dense + tkz_result_off(r) : P.tmp + base + tkz_result_off(r);
+    };
+    // stage[i] holds the id of token sbase + i of the sub-tile; sbase is chosen so that stage[0] sits on a 16-byte boundary of `out`
+    const uintptr_t out_addr = reinterpret_cast<uintptr_t>(out);
+    auto quad_base = [&](int tok) -> int { return tok - (int)(((out_addr >> 2) + (uintptr_t)(tb + tok)) & 3u); };
+    int running = 0, marks = 0, flushed = 0, sbase = quad_base(0);
+    auto flush = [&](int upto) {                             // stores tokens [flushed, upto) of the sub-tile
+        (void)simt::ballot(true);
+        const int lo = flushed - sbase, hi = upto - sbase;
+        for (int q4 = lane; 4 * q4 < hi; q4 += 64) {
+            const int i0 = 4 * q4;
+            if (i0 + 4 <= lo) continue;
+            const uint4 v = reinterpret_cast<const uint4*>(stage)[q4];
+            int32_t* dst = out + tb + sbase + i0;
+            if (i0 >= lo && i0 + 4 <= hi && tb + sbase + i0 + 4 <= out_cap) tkz_store16_nt(dst, v);
+            else {
+                const int32_t w[4] = {(int32_t)v.x, (int32_t)v.y, (int32_t)v.z, (int32_t)v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i0 + i >= lo && i0 + i < hi && tb + sbase + i0 + i < out_cap) dst[i] = w[i];
+            }
+        }
+        (void)simt::ballot(true);
+        flushed = upto; sbase = quad_base(upto);
+    };
 #pragma unroll 1
     for (int kk = 0; kk < np; kk += 256) {                     // four record loads in flight per lane
       uint32_t r4[4];
@@ -1060,14 +1154,16 @@ TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, in
       }
       // the first four tokens of every missed piece of the four chunks: all those gathers in flight together, before any store
       int32_t t4[4][4];
+      int c4[4];
+      const int32_t* src4[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
           const uint32_t rec = r4[j];
-          const int32_t* src = (rec & kPrDense) ? dense + tkz_dense_off(rec) : P.tmp + base + (rec & 1023u);
           const bool ld = (rec & kPrMiss) != 0;
-          const int cnt = (rec & kPrGiant) ? gcnt : (rec & kPrDense) ? tkz_dense_cnt(rec) : (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+          c4[j] = 1; src4[j] = P.tmp;
+          if (ld) src4[j] = locate(rec, &c4[j]);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) t4[j][i] = (ld && i < cnt) ? src[i] : 0;
+          for (int i = 0; i < 4; ++i) t4[j][i] = (ld && i < c4[j]) ? src4[j][i] : 0;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1077,34 +1173,51 @@ TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, in
         const bool valid = k < np && pb + k < P.prank_cap;
         const uint32_t rec = r4[j];
         const bool miss = (rec & kPrMiss) != 0;
-        int cnt = !valid ? 0 : !miss ? 1 : (rec & kPrGiant) ? gcnt : (rec & kPrDense) ? tkz_dense_cnt(rec) : (int)((rec >> kPrLenShift) & kPrLenMask) + 1;
+        const int cnt = !valid ? 0 : !miss ? 1 : c4[j];
         int tot;
         const int pos = running + tkz_wave_scan_sum(cnt, &tot);
         const uint64_t mm = simt::ballot(valid && (rec & kPrMark));
-        if (valid) {
-            if (rec & kPrMark) P.doc_tok[ord0 + marks + tkz_popc64(mm & tkz_lowmask(lane))] = pos;
-            int32_t* dst = out + tb + pos;
-            if (!miss) { if (tb + pos < out_cap) tkz_store_nt(&dst[0], (int32_t)(rec & kPrRankMask)); }
-            else if (cnt <= 16) {
+        if (valid && (rec & kPrMark)) P.doc_tok[ord0 + marks + tkz_popc64(mm & tkz_lowmask(lane))] = pos;
+        const uint64_t big = simt::ballot(valid && miss && cnt > 16);
+        if (!big) {
+            if (running + tot - sbase > kStage) flush(running);
+            if (valid) {
+                int32_t* dst = stage + (pos - sbase);
+                if (!miss) dst[0] = (int32_t)(rec & kPrRankMask);
+                else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (i < cnt && tb + pos + i < out_cap) dst[i] = t4[j][i];
-                const int32_t* src = (rec & kPrDense) ? dense + tkz_dense_off(rec) : P.tmp + base + (rec & 1023u);
-                for (int i = 4; i < cnt; ++i) if (tb + pos + i < out_cap) dst[i] = src[i];
+                    for (int i = 0; i < 4; ++i) if (i < cnt) dst[i] = t4[j][i];
+                    for (int i = 4; i < cnt; ++i) dst[i] = src4[j][i];
+                }
             }
-        }
-        // long token runs (a merged piece of many bytes, a giant piece): copied by the whole wavefront, one after the other
-        for (uint64_t big = simt::ballot(valid && miss && cnt > 16); big; big &= big - 1) {
-            const int src_lane = tkz_ctz64(big);
-            const int c = simt::shfl(cnt, src_lane), p0 = simt::shfl(pos, src_lane);
-            const int rel = (int)(simt::shflu(rec, src_lane) & 1023u);
-            const int32_t* src = P.tmp + base + rel;
-            int32_t* dst = out + tb + p0;
-            for (int i = lane; i < c; i += 64) if (tb + p0 + i < out_cap) dst[i] = src[i];
+        } else {
+            // a long token run (a merged piece of many bytes, a giant piece) in this batch of 64 records: what is staged goes out, then
+            // this batch's ids go straight to their positions, the long runs copied by the whole wavefront, one after the other
+            flush(running);
+            if (valid) {
+                int32_t* dst = out + tb + pos;
+                if (!miss) { if (tb + pos < out_cap) tkz_store_nt(&dst[0], (int32_t)(rec & kPrRankMask)); }
+                else if (cnt <= 16) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (i < cnt && tb + pos + i < out_cap) dst[i] = t4[j][i];
+                    for (int i = 4; i < cnt; ++i) if (tb + pos + i < out_cap) dst[i] = src4[j][i];
+                }
+            }
+            for (uint64_t bg = big; bg; bg &= bg - 1) {
+                const int src_lane = tkz_ctz64(bg);
+                const int c = simt::shfl(cnt, src_lane), p0 = simt::shfl(pos, src_lane);
+                const uint32_t lo32 = simt::shflu((uint32_t)(reinterpret_cast<uintptr_t>(src4[j])), src_lane), hi32 = simt::shflu((uint32_t)(reinterpret_cast<uintptr_t>(src4[j]) >> 32), src_lane);
+                const int32_t* src = reinterpret_cast<const int32_t*>(((uintptr_t)hi32 << 32) | lo32);
+                int32_t* dst = out + tb + p0;
+                for (int i = lane; i < c; i += 64) if (tb + p0 + i < out_cap) dst[i] = src[i];
+            }
+            flushed = running + tot; sbase = quad_base(flushed);
         }
         running += tot;
         marks += tkz_popc64(mm);
       }
     }
+    if (flushed < running) flush(running);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1117,7 +1230,7 @@ TKZ_KERNEL(256) void k_giant_find(const uint8_t* heavy_flag, int64_t nsub, const
     // (a giant piece reaches past the end of its sub-tile)
     const int64_t stride = simt::nblocks() * simt::nthreads();
     for (int64_t t = simt::bid() * simt::nthreads() + simt::tid(); t < nsub; t += stride) {
-        if (!heavy_flag[t]) continue;
+        if (!(heavy_flag[t] & 2u)) continue;
         int64_t p = -1;
         for (int k = kSub / 64 - 1; k >= 0 && p < 0; --k) {
             const int64_t w = t * (kSub / 64) + k;
@@ -1222,11 +1335,12 @@ TKZ_KERNEL(256) void k_doccount(const uint64_t* docbits, int64_t nwords, int64_t
 // -------------------------------------------------------------------------------------------------
 // exclusive scan of tile_count (int32) -> tile_base (int64); counters[2..3] (int64) = grand total
 // -------------------------------------------------------------------------------------------------
-TKZ_KERNEL(256) void k_scan_partials(const int32_t* cnt, int64_t n, int64_t* bsum) {
+// (`round`: every count is rounded up to a multiple of round + 1 first -- the piece records of a sub-tile are whole 64-byte lines)
+TKZ_KERNEL(256) void k_scan_partials(const int32_t* cnt, int64_t n, int64_t* bsum, int round) {
     TKZ_SHARED int64_t s_w[4];
     const int64_t i0 = simt::bid() * kScanBlock;
     int64_t v = 0;
-    for (int j = simt::tid(); j < kScanBlock; j += kThreads) if (i0 + j < n) v += cnt[i0 + j];
+    for (int j = simt::tid(); j < kScanBlock; j += kThreads) if (i0 + j < n) v += (cnt[i0 + j] + round) & ~round;
     for (int d = 32; d >= 1; d >>= 1) {
         const uint32_t lo = simt::shflu((uint32_t)v, simt::lane() ^ d), hi = simt::shflu((uint32_t)((uint64_t)v >> 32), simt::lane() ^ d);
         v += (int64_t)(((uint64_t)hi << 32) | lo);
@@ -1258,12 +1372,12 @@ TKZ_KERNEL(256) void k_scan_top(int64_t* bsum, int64_t nblk, int64_t* grand) {  
     }
     if (simt::tid() == 0) *grand = carry;
 }
-TKZ_KERNEL(256) void k_scan_final(const int32_t* cnt, int64_t n, const int64_t* boff, int64_t* base) {
+TKZ_KERNEL(256) void k_scan_final(const int32_t* cnt, int64_t n, const int64_t* boff, int64_t* base, int round) {
     const int64_t i0 = simt::bid() * kScanBlock;
     // each thread owns kScanBlock/kThreads consecutive tiles
     constexpr int per = kScanBlock / kThreads;
     int local[per]; int sum = 0;
-    for (int j = 0; j < per; ++j) { const int64_t i = i0 + (int64_t)simt::tid() * per + j; local[j] = i < n ? cnt[i] : 0; sum += local[j]; }
+    for (int j = 0; j < per; ++j) { const int64_t i = i0 + (int64_t)simt::tid() * per + j; local[j] = i < n ? (cnt[i] + round) & ~round : 0; sum += local[j]; }
     // block scan in 64-bit via two 32-bit scans would overflow only past 2^31 tokens per 1024 tiles (4 MiB of text): impossible
     int tot;
     int pre = tkz_block_scan(sum, &tot);
@@ -1578,6 +1692,7 @@ TKZ_KERNEL(256) void k_offsets_scan(int64_t* offs, int64_t n, int64_t* total) {
 // =================================================================================================
 static inline void hook(const Launch& L, int id, int phase) { if (L.hook) L.hook(L.hook_ctx, id, phase, L.stream); }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t xcd_grid(int64_t blocks) { return (blocks + 7) & ~(int64_t)7; }     // tkz_xcd_block: XCD x takes the x-th eighth of the blocks
 static inline int64_t grid_for(int64_t items) { const int64_t g = cdiv(items, kThreads); return g < 1 ? 1 : (g > 16384 ? 16384 : g); }
 
 void launch_docmark(const Launch& L, const int64_t* d_offs, int64_t n_items, int64_t total, uint64_t* bits, int32_t* counters) {
@@ -1614,10 +1729,10 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
 }
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub) {
     hook(L, K_ENCODE, 0);
-    TKZ_LAUNCH(k_probe, cdiv(nsub, kThreads / 64), kThreads, L.stream, T, P);
+    TKZ_LAUNCH(k_probe, xcd_grid(cdiv(nsub, kThreads / 64)), kThreads, L.stream, T, P);
     hook(L, K_ENCODE, 1);
     hook(L, K_MERGE_SHORT, 0);
-    TKZ_LAUNCH(k_merge_short, cdiv(nsub, (kMsThreads / 64) * kGroup), kMsThreads, L.stream, T, P);
+    TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
     hook(L, K_MERGE_SHORT, 1);
     hook(L, K_HEAVY, 0);
     // giant pieces start in sub-tiles k_probe has flagged: find them, merge them; then the pieces of 17..1024 bytes and the giants' token counts
@@ -1634,18 +1749,19 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
 }
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
     hook(L, K_GATHER, 0);
-    TKZ_LAUNCH(k_place, cdiv(nsub, kThreads / 64), kThreads, L.stream, P, tile_base, out, out_cap);
+    TKZ_LAUNCH(k_place, xcd_grid(cdiv(nsub, kThreads / 64)), kThreads, L.stream, P, tile_base, out, out_cap);
     hook(L, K_GATHER, 1);
 }
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt) {
     TKZ_LAUNCH(k_doccount, grid_for(nsub * (kSub / 64)), kThreads, L.stream, docbits, nwords, total, nsub, cnt);
 }
-void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid) {
+void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid, int round_to) {
     const int64_t nblk = cdiv(ntiles, kScanBlock);
+    const int round = round_to > 1 ? round_to - 1 : 0;       // (round_to: a power of two)
     if (kid >= 0) hook(L, kid, 0);
-    TKZ_LAUNCH(k_scan_partials, nblk, kThreads, L.stream, tile_count, ntiles, bsum);
+    TKZ_LAUNCH(k_scan_partials, nblk, kThreads, L.stream, tile_count, ntiles, bsum, round);
     TKZ_LAUNCH(k_scan_top, 1, kThreads, L.stream, bsum, nblk, grand);
-    TKZ_LAUNCH(k_scan_final, nblk, kThreads, L.stream, tile_count, ntiles, (const int64_t*)bsum, tile_base);
+    TKZ_LAUNCH(k_scan_final, nblk, kThreads, L.stream, tile_count, ntiles, (const int64_t*)bsum, tile_base, round);
     if (kid >= 0) hook(L, kid, 1);
 }
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,

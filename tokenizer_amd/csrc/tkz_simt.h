@@ -44,6 +44,7 @@ TKZ_DEV int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 TKZ_DEV int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
 TKZ_DEV int atomic_add(int* p, int v) { return atomicAdd(p, v); }
 TKZ_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
+TKZ_DEV unsigned atomic_max(unsigned* p, unsigned v) { return atomicMax(p, v); }
 TKZ_DEV unsigned atomic_cas(unsigned* p, unsigned expect, unsigned v) { return atomicCAS(p, expect, v); }
 TKZ_DEV void fence() { __threadfence(); }
 TKZ_DEV unsigned long long atomic_or64(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
@@ -66,6 +67,8 @@ TKZ_DEV int scan_inclusive(int v) {
     return x;
 }
 TKZ_DEV int last_lane(int v) { return __builtin_amdgcn_readlane(v, 63); }
+// v_alignbit_b32: the low dword of ({hi, lo} >> (sh & 31)) -- an unaligned dword out of two aligned ones in ONE instruction
+TKZ_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 }  // namespace simt
 // Streaming accesses (touched once: the corpus, the per-piece records, the ids): non-temporal, so that they do not evict the
 // vocabulary tables every gather of the encode kernels wants to find in L2.
@@ -77,6 +80,10 @@ TKZ_DEV uint4 tkz_load16_nt(const void* p) {
 TKZ_DEV uint32_t tkz_load_nt(const uint32_t* p) { return __builtin_nontemporal_load(p); }
 TKZ_DEV int32_t tkz_load_nt(const int32_t* p) { return __builtin_nontemporal_load(p); }
 TKZ_DEV void tkz_store_nt(int32_t* p, int32_t v) { __builtin_nontemporal_store(v, p); }
+TKZ_DEV void tkz_store16_nt(void* p, uint4 v) {
+    tkz_u32x4 x; x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
+    __builtin_nontemporal_store(x, reinterpret_cast<tkz_u32x4*>(p));
+}
 #endif
 
 // ---- bit helpers shared by host and device code ------------------------------------------------

@@ -87,6 +87,11 @@ TKZ_HD uint64_t tkz_pair_key42(uint32_t a, uint32_t b) { return (uint64_t)tkz_pa
 // one kernel cannot be invalidated by another).  A pure memo: results are identical with and without it.
 struct alignas(16) TkzMemoSlot { uint32_t k[4]; uint32_t v[4]; };
 constexpr uint32_t kMemoValid = 0x80000000u, kMemoBusy = 0xFFFFFFFFu;
+// slots per bucket (one 64-byte line for 2): a piece may sit in any slot of its bucket and takes the first free one
+#ifndef TKZ_MEMO_WAYS
+#define TKZ_MEMO_WAYS 2
+#endif
+constexpr uint32_t kMemoWays = TKZ_MEMO_WAYS;
 
 struct TkzTables {      // device pointers + sizes, passed to kernels by value
     TkzMemoSlot* memo; uint32_t memo_n;                                          // piece memo (null / 0: none)
