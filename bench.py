@@ -378,8 +378,14 @@ def main():
                     cpu_1t = round(nb1 / tm["seconds"] / 1e6, 2)
                 else:
                     cpu_1t = round(best[0], 2)
+                quota = None
+                try:
+                    quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+                except Exception:
+                    pass
                 cpu = {"value": round(best[0], 2), "unit": "MB/s", "cores": best[1], "kind": "port", "value_1_thread": cpu_1t, "by_threads": sweep,
-                       "host_threads_available": ncpu,
+                       "host_threads_available": ncpu, "cgroup_cpu_max": quota,
+                       "host_parallel_speedup": O.host_parallelism(sorted({1, max(1, ncpu // 4), max(1, ncpu // 2), ncpu})),
                        "sample": "%d documents (%.1f MB) of the same corpus on %d host threads -- the best of the thread counts tried (by_threads: MB/s; the %d-thread "
                                  "run covers the whole batch and is the parity check); one thread: the first %d documents; reference-algorithm CPU restatement "
                                  "(oracle/), 8192-entry LRU memo and reusable scratch per thread" % (best[3], best[2] / 1e6, best[1], ncpu, n1)}

@@ -59,6 +59,8 @@ def lib():
         L.tkzo_encode_special_utf8.argtypes = [vp, u8p, i64, vp, C.c_int, vp, i64]
         L.tkzo_encode_batch.restype = i64
         L.tkzo_encode_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, i64, vp, vp, C.c_int]
+        L.tkzo_parallel_probe.restype = i64
+        L.tkzo_parallel_probe.argtypes = [C.c_int]
         L.tkzo_check_batch.restype = i64
         L.tkzo_check_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, i64, vp, vp, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _lib = L
@@ -212,6 +214,14 @@ def encode_batch(vocab: Vocab, pattern: int, data: np.ndarray, offsets: np.ndarr
         return np.empty(0, np.int32), counts
     idx = np.concatenate([out[offsets[d]:offsets[d] + counts[d]] for d in range(n)]) if n < 100000 else _gather(out, offsets, counts)
     return idx, counts
+
+
+def host_parallelism(thread_counts):
+    """{threads: speed-up over one thread} of a register-only loop run on that many threads at once: what the host really grants."""
+    probe = lambda n: min(lib().tkzo_parallel_probe(int(n)) for _ in range(2))     # (the better of two runs)
+    probe(1)
+    t1 = probe(1)
+    return {int(n): round(n * t1 / max(1, probe(n)), 1) for n in thread_counts}
 
 
 def check_batch(vocab: Vocab, pattern: int, data: np.ndarray, offsets: np.ndarray, want_ids: np.ndarray, want_offsets: np.ndarray,

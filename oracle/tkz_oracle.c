@@ -10,6 +10,7 @@
 
 #include <limits.h>
 #include <pthread.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -906,6 +907,29 @@ int64_t tkzo_check_batch(const tkzo_vocab* v, int pattern, int cache_size, const
     if (first_bad) *first_bad = first;
     if (tokens) *tokens = total;
     return err ? err : bad;
+}
+
+/* How much parallel throughput the host really grants: `threads` threads each run the same register-only loop; returns the wall time in
+ * nanoseconds.  (The CPU baseline is reported beside this: on a box whose 256 hardware threads are capped by a CPU quota or shared with
+ * other tenants, the all-core figure says more about the quota than about the algorithm.) */
+static void* spin_worker(void* p) {
+    volatile uint64_t x = (uint64_t)(uintptr_t)p | 1u;
+    uint64_t y = x;
+    for (uint64_t i = 0; i < 200000000ull; ++i) y = y * 6364136223846793005ull + 1442695040888963407ull;
+    x = y;
+    return NULL;
+}
+int64_t tkzo_parallel_probe(int threads) {
+    if (threads < 1) threads = 1;
+    if (threads > 1024) threads = 1024;
+    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    for (int t = 0; t < threads; ++t) pthread_create(&th[t], NULL, spin_worker, (void*)(uintptr_t)(t + 1));
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    free(th);
+    return (int64_t)(b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec);
 }
 
 int64_t tkzo_encode_batch(const tkzo_vocab* v, int pattern, int cache_size, const uint8_t* bytes,

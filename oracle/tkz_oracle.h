@@ -97,6 +97,8 @@ int64_t tkzo_encode_special_utf8(tkzo_encoder* e, const uint8_t* text, int64_t n
  * threads >= 1; docs are statically partitioned, one encoder (own memo) per thread.
  * out_counts[d] = tokens of doc d; ids are written per doc at out + doc_offsets[d]
  * (tokens <= bytes, so the byte offset is always a valid slot).  Returns total tokens or <0. */
+/* wall time (ns) of `threads` threads each running the same register-only loop: what parallel throughput the host grants */
+int64_t tkzo_parallel_probe(int threads);
 /* Checker for batches too large to hold a second copy of: encodes every document and compares it in place with
  * want_ids[want_offsets[d] .. want_offsets[d+1]).  Returns the number of documents that differ (negative: error). */
 int64_t tkzo_check_batch(const tkzo_vocab* v, int pattern, int cache_size, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs,

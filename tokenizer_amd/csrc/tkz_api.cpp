@@ -90,7 +90,7 @@ struct tkz_vocab { tkz::Vocab v; };
 struct Workspace {
     // kernel workspace
     DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_dense, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
-    DevBuf w_mlist, w_mcount;
+    DevBuf w_mlist, w_mquad, w_mcount;
     int32_t mcap = tkz::kMissCapMin;       // entries of a sub-tile's miss list; grows (once, to what the batch needed) when a sub-tile overflows it
     // staging for the host-buffer entry points (two sets: chunk k+1 is uploaded while chunk k is encoded and chunk k-1 downloaded)
     DevBuf s_bytes[2], s_offs[2], s_out[2], s_outoffs[2];
@@ -111,7 +111,7 @@ struct Workspace {
     double ms[tkz::K_COUNT] = {};
     int64_t launches[tkz::K_COUNT] = {};
     void release_all() {
-        DevBuf* bufs[] = {&w_mlist, &w_mcount, &w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
+        DevBuf* bufs[] = {&w_mlist, &w_mquad, &w_mcount, &w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
                           &w_doctok, &w_dcount, &w_dbase, &w_counters, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
                           &s_outoffs[0], &s_outoffs[1], &u_units, &u_offs, &u_docbits, &u_grp, &u_tsum, &u_tbase, &u_bsum, &u_counters, &u_bytes, &u_boffs,
                           &d_grp, &d_tsum, &d_tbase, &d_bsum, &d_counters, &d_ids, &d_idoffs, &d_out, &d_outoffs, &p_boffs, &p_toffs, &p_docp};
@@ -270,6 +270,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         // (+ 8 per sub-tile on average: every sub-tile's records start on a 64-byte line of their own)
         HIP_TRY(ws->w_prank.ensure((size_t)(total / 3 + 8 * ntiles + 4096) * 4, acc));
         HIP_TRY(ws->w_mlist.ensure((size_t)ntiles * (size_t)ws->mcap * 4, acc));
+        HIP_TRY(ws->w_mquad.ensure((size_t)ntiles * (size_t)ws->mcap * 16, acc));
         HIP_TRY(ws->w_mcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_tbase.ensure((size_t)ntiles * 8, acc));
         HIP_TRY(ws->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
@@ -312,7 +313,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.offs = d_offs; P.n_docs = n_docs;
             P.tmp = ws->w_tmp.as<int32_t>(); P.dense = ws->w_dense.as<int32_t>(); P.tile_count = ws->w_tcount.as<int32_t>();
             P.prank = ws->w_prank.as<int32_t>(); P.prank_cap = (int64_t)(ws->w_prank.cap / 4); P.pcount = ws->w_pcount.as<int32_t>(); P.pbase = ws->w_pbase.as<int64_t>();
-            P.mlist = ws->w_mlist.as<uint32_t>(); P.mcap = ws->mcap; P.mcount = ws->w_mcount.as<uint32_t>();
+            P.mlist = ws->w_mlist.as<uint32_t>(); P.mquad = ws->w_mquad.as<uint4>(); P.mcap = ws->mcap; P.mcount = ws->w_mcount.as<uint32_t>();
             P.docord_base = ws->w_dbase.as<int64_t>(); P.doc_tok = ws->w_doctok.as<int32_t>(); P.counters = counters;
             P.giant_q = ws->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = ws->w_gcnt.as<int32_t>();
             P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
@@ -393,8 +394,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             int32_t want = kMissCapMin;
             while (want < ws->h_counters->mneed && want < kMissCapMax) want *= 2;
             if (want <= ws->mcap) return fail(TKZ_E_DEVICE, "miss list overflow");
-            if (ws->w_mlist.ensure((size_t)ntiles * (size_t)want * 4, acc) != hipSuccess)
-                return fail(TKZ_E_OUT_OF_MEMORY, "miss lists: " + std::to_string((size_t)ntiles * (size_t)want * 4) + " bytes could not be allocated");
+            if (ws->w_mlist.ensure((size_t)ntiles * (size_t)want * 4, acc) != hipSuccess || ws->w_mquad.ensure((size_t)ntiles * (size_t)want * 16, acc) != hipSuccess)
+                return fail(TKZ_E_OUT_OF_MEMORY, "miss lists: " + std::to_string((size_t)ntiles * (size_t)want * 20) + " bytes could not be allocated");
             ws->mcap = want;
             continue;
         }

@@ -334,6 +334,92 @@ TKZ_HD void tkz_bpe_varc_emit(ByteAt at, const uint32_t* st, int n, const int32_
         for (uint32_t a = am[w]; a; a &= a - 1) dst[i++] = (int32_t)tkz_bpe_varc_id(at, n, pr, am, brank, 32 * w + tkz_ctz32(a));
 }
 
+// ---- ... and for pieces of up to 64 bytes with the alive bits in REGISTERS (one 64-bit mask) --------------------------------------
+// A merge of the LDS-mask form above is a chain of ~8 dependent LDS round trips (the scan, two walks over the alive words, the ids of the two
+// neighbours through their alive bits) before its one round trip to the pair table; k_merge_long runs at 3 wavefronts per SIMD and is bound
+// by exactly that chain.  With the mask in registers the neighbours are two bit scans, and what is left in LDS is the scan and one read per
+// neighbour id.  State: pr[n4] only.
+TKZ_HD uint64_t tkz_lowmask64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+template <class ByteAt>
+TKZ_HD uint32_t tkz_bpe_varc64_id(ByteAt at, int n, const uint32_t* pr, uint64_t alive, const int32_t* brank, int x) {
+    const int y = x + 1 < n ? x + 1 : x;
+    const bool merged = x + 1 < n && !((alive >> y) & 1ull);
+    const uint32_t a = pr[y] & ~kVarDead, b = (uint32_t)brank[at(x)];     // (both loads unconditional)
+    return merged ? a : b;
+}
+template <class ByteAt>
+TKZ_HD int tkz_bpe_lane_varc64(const TkzTables& T, ByteAt at, int n, uint32_t* pr, int* err, const int32_t* brank, uint64_t* alive_out) {
+    auto entry = [](int32_t rank, int pos) -> uint32_t {
+        return rank == TKZ_RANK_NONE ? TKZ_NOKEY : (((uint32_t)rank << kVarPosBits) | (uint32_t)pos);
+    };
+    const int n4 = tkz_bpe_var_n4(n);
+    uint4* pr4 = reinterpret_cast<uint4*>(pr);
+#pragma unroll 1
+    for (int c = 0; c < n4; c += 16) {                   // first-level pair ranks (:37-44), 16 bytes per step, their gathers in flight together
+        uint32_t b[17];
+#pragma unroll
+        for (int k = 0; k < 17; ++k) b[k] = c + k < n ? at(c + k) : 0u;
+        int32_t r2[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) r2[k] = c + k + 1 < n ? T.bytepair_rank[(b[k] << 8) | b[k + 1]] : TKZ_RANK_NONE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (c + 4 * q < n4) {
+                uint4 p;
+                p.x = c + 4 * q + 1 < n ? entry(r2[4 * q], c + 4 * q) : TKZ_NOKEY;
+                p.y = c + 4 * q + 2 < n ? entry(r2[4 * q + 1], c + 4 * q + 1) : TKZ_NOKEY;
+                p.z = c + 4 * q + 3 < n ? entry(r2[4 * q + 2], c + 4 * q + 2) : TKZ_NOKEY;
+                p.w = c + 4 * q + 4 < n ? entry(r2[4 * q + 3], c + 4 * q + 3) : TKZ_NOKEY;
+                pr4[(c >> 2) + q] = p;
+            }
+        }
+    }
+    uint64_t alive = tkz_lowmask64(n);
+    int cnt = n;
+    for (;;) {                                          // while (byteIndicesAndRanks.Count > 1) (:45)
+        uint32_t m = TKZ_NOKEY;
+#pragma unroll 4
+        for (int q = 0; q < (n4 >> 2); ++q) {           // leftmost strict min (:47-54): packed (rank, position), ties -> lower position
+            const uint4 p = pr4[q];
+            m = tkz_min3u(m, tkz_min3u(p.x, p.y, p.z), p.w);
+        }
+        if (m >= kVarDead) break;                       // minRank == int.MaxValue (:65-68)
+        const int j = (int)(m & ((1u << kVarPosBits) - 1u));
+        m >>= kVarPosBits;
+        // r: the part being swallowed (next part after j), rr: the one after it, l: the part before j
+        const uint64_t hi = alive & ~tkz_lowmask64(j + 1);          // (not empty: pr[j] was a rank)
+        const int r = tkz_ctz64(hi);
+        const uint64_t hi2 = hi & (hi - 1);
+        const bool hasr = hi2 != 0;
+        const int rr = hasr ? tkz_ctz64(hi2) : 0;
+        alive &= ~(1ull << r);                          // RemoveAt(j + 1) (:63)
+        const uint64_t lo = alive & tkz_lowmask64(j);
+        const bool hasl = lo != 0;
+        const int l = hasl ? tkz_msb64(lo) : 0;
+        const uint32_t idr = tkz_bpe_varc64_id(at, n, pr, alive, brank, rr), idl = tkz_bpe_varc64_id(at, n, pr, alive, brank, l);
+        uint32_t r1, r2s, l1, l2;
+        tkz_pair_slots(T, m, idr, &r1, &r2s);
+        tkz_pair_slots(T, idl, m, &l1, &l2);
+        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2s]);
+        const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
+        pr[r] = TKZ_NOKEY;                              // dead for good
+        pr[j + 1] = kVarDead | m;                       // ... and the slot behind j carries the id of the merged part (= the rank it was found under)
+        const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);
+        pr[j] = hasr ? entry(rkr, j) : TKZ_NOKEY;                           // (:58)
+        if (hasl) pr[l] = entry(rkl, l);                                    // (:59-62)
+        --cnt;
+    }
+    for (uint64_t a = alive; a; a &= a - 1)
+        if (tkz_bpe_varc64_id(at, n, pr, alive, brank, tkz_ctz64(a)) >= (uint32_t)TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;   // ranks[...] throws (:17,:73)
+    *alive_out = alive;
+    return cnt;
+}
+template <class ByteAt>
+TKZ_HD void tkz_bpe_varc64_emit(ByteAt at, const uint32_t* pr, uint64_t alive, int n, const int32_t* brank, int32_t* dst) {
+    int i = 0;
+    for (uint64_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)tkz_bpe_varc64_id(at, n, pr, alive, brank, tkz_ctz64(a));
+}
+
 // the tokens of a piece merged by tkz_bpe_lane_var, in order
 TKZ_HD void tkz_bpe_var_emit(const uint32_t* st, int n, int32_t* dst) {
     const int n4 = tkz_bpe_var_n4(n), nw = (n + 31) >> 5;

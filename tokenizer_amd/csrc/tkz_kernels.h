@@ -45,6 +45,7 @@ struct EncodeParams {
     const int32_t* pcount;        // pieces that start in each sub-tile
     const int64_t* pbase;         // ... and the exclusive scan of the counts rounded up to 16: where the sub-tile's records (whole lines) start
     uint32_t* mlist; int32_t mcap;       // per sub-tile mcap entries: the short misses from the front, the long ones from the back; answered in place
+    uint4* mquad;                 // 16 bytes beside every list entry: a short miss's bytes on the way in, its <= 4 tokens on the way out
     uint32_t* mcount;             // per sub-tile: short misses | long misses << 16
     const int64_t* docord_base;   // per sub-tile: number of distinct document-start positions before it
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile

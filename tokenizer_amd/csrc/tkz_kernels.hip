@@ -463,6 +463,9 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
 //              writes it and  DONE | DENSE? | (count - 1) << 12 | offset  once its piece is merged (the merge kernels answer in place).
 //              The merge kernels read ONLY these lists (~6 % of the pieces), never the records; mcap starts at 64 entries per sub-tile
 //              and the batch is redone once with a larger one when a sub-tile needed more (text where nearly every piece misses).
+//   mquad[s * mcap + i]   16 bytes beside every SHORT entry: k_probe leaves the piece's bytes there (it has them in LDS; k_merge_short then needs no
+//              gather into the text: ONE coalesced load per entry instead of two scattered requests, twice), and k_merge_short leaves the
+//              piece's tokens there when there are at most four (INLINE: k_place gets them in the round trip that fetches the answers).
 //   dense[]    the tokens of the merged SHORT pieces of a group of 16 sub-tiles, packed in list order (4096 per group; a miss costs
 //              ~4 tokens = one 16-byte store next to its neighbour's, not a 64-byte line of its own in k_merge_short and again in k_place)
 //   tmp[b]     4 B per input byte, touched only under LONG missed pieces (and what overflows dense[]): a piece's tokens fit inside
@@ -485,7 +488,7 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
 // -------------------------------------------------------------------------------------------------
 constexpr uint32_t kPrMiss = 1u << 31, kPrMark = 1u << 30, kPrLong = 1u << 29, kPrGiant = 1u << 28;
 constexpr uint32_t kPrRankMask = (1u << 28) - 1u;       // ranks are < 2^27 (TKZ_MAX_RANK)
-constexpr uint32_t kMrDone = 1u << 31, kMrDense = 1u << 30;
+constexpr uint32_t kMrDone = 1u << 31, kMrDense = 1u << 30, kMrInline = 1u << 29;
 constexpr int kMrLenShift = 10, kMrCntShift = 12;
 constexpr uint32_t kMrOffMask = (1u << kMrCntShift) - 1u;
 static_assert(kDenseCap <= (1 << kMrCntShift) && kSub <= (1 << kMrLenShift), "the offset field of a result entry");
@@ -504,7 +507,11 @@ constexpr int kMidMax = kSub / (TKZ_SHORT_KEY_MAX + 1) + 2;   // pieces of 13+ b
 
 // The workgroup a block stands for: blocks b, b + 8, b + 16 ... of a grid run on one XCD (observed dispatch: XCD = b % 8; for speed only,
 // nothing depends on it), so XCD x takes the x-th eighth of the work, in order.  nblocks is a multiple of 8.
+#ifdef TKZ_NO_XCD_REMAP      // (development: A/B of the mapping)
+TKZ_DEV int64_t tkz_xcd_block(int64_t b, int64_t nblocks) { return b; }
+#else
 TKZ_DEV int64_t tkz_xcd_block(int64_t b, int64_t nblocks) { return (b & 7) * (nblocks >> 3) + (b >> 3); }
+#endif
 
 // exclusive prefix over the wave of a small non-negative value (< 2^BITS), and the wave total;
 // bit-sliced: one ballot + mbcnt per bit, no LDS traffic
@@ -673,6 +680,7 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
     // ---- the main loop: two batches of 64 pieces per iteration, their gathers in flight together (what a sub-tile costs is its count of
     // dependent round trips to the tables) ----
     uint32_t* const ml = P.mlist + sub * (int64_t)P.mcap;
+    uint4* const mq = P.mquad + sub * (int64_t)P.mcap;
     int ns = 0, nl = 0, midseen = 0;
     bool giant = false;
     constexpr int U = TKZ_PROBE_U;                         // batches of 64 pieces whose gathers are in flight together
@@ -748,7 +756,12 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
             // (the two lists grow towards each other; an entry that would run into the other list is not written -- ns + nl > mcap is then
             //  reported below and the batch redone with longer lists)
             const uint32_t ent = (uint32_t)s | ((uint32_t)(len - 1) << kMrLenShift);
-            if (miss_s && is_ + nl < P.mcap) ml[is_] = ent;
+            if (miss_s && is_ + nl < P.mcap) {
+                ml[is_] = ent;
+                uint4 kq; kq.x = kw0[u]; kq.y = kw1[u]; kq.z = kw2[u]; kq.w = 0;          // the piece's bytes, zero-padded, for k_merge_short
+                if (len > TKZ_SHORT_KEY_MAX) { kq.x = tkz_key_dword(s_bytes, s, len, 0); kq.y = tkz_key_dword(s_bytes, s, len, 1); kq.z = tkz_key_dword(s_bytes, s, len, 2); kq.w = tkz_key_dword(s_bytes, s, len, 3); }
+                mq[is_] = kq;
+            }
             if (miss_l && il + ns < P.mcap) ml[P.mcap - 1 - il] = ent;
             uint32_t rec = ((s_mark[s >> 5] >> (s & 31)) & 1u) ? kPrMark : 0u;
             if (is_giant) { rec |= kPrMiss | kPrGiant | (uint32_t)s; giant = giant || valid; }
@@ -800,6 +813,7 @@ TKZ_DEV void tkz_load_piece16(const uint8_t* bytes, int64_t total, int64_t abs, 
 // the result a merge kernel leaves in a miss-list entry: the piece's tokens wait in dense[group * kDenseCap + off ..) (DENSE) or in tmp at
 // the piece's own byte position (off = relpos)
 TKZ_HD uint32_t tkz_result_entry(bool dense, int cnt, int off) { return kMrDone | (dense ? kMrDense : 0u) | ((uint32_t)(cnt - 1) << kMrCntShift) | (uint32_t)off; }
+TKZ_HD uint32_t tkz_result_inline(int cnt) { return kMrDone | kMrInline | ((uint32_t)(cnt - 1) << kMrCntShift); }       // <= 4 tokens, in the entry's quad
 TKZ_HD int tkz_result_cnt(uint32_t r) { return (int)((r >> kMrCntShift) & 1023u) + 1; }
 TKZ_HD int tkz_result_off(uint32_t r) { return (int)(r & kMrOffMask); }
 
@@ -863,30 +877,36 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     int err = 0, nlist = 0, nchk = 0, dused = 0, done = 0;      // list entries [0, nchk) have been through the memo, [nchk, nlist) not yet
     int32_t* const dense = P.dense + grp * kDenseCap;
     const bool memo = T.memo_n != 0;
-    // where the `cnt` tokens of a piece go -- packed behind those of the pieces before it in the group's dense region (in tmp, at the
-    // piece's own byte position, once that is full) -- and the answer in its list entry; every lane of the wavefront calls it (a scan inside)
+    // where the `cnt` tokens of a piece go -- up to four: into the entry's own quad (the caller stores them); more: packed behind those of
+    // the pieces before it in the group's dense region (in tmp, at the piece's own byte position, once that is full) -- and the answer in
+    // its list entry; every lane of the wavefront calls it (a scan inside)
     auto assign = [&](bool have, int cnt, int si, int j, int rel) -> int32_t* {
         int btot;
-        const int doff = dused + tkz_wave_scan_sum(have ? cnt : 0, &btot);
+        const bool big = have && cnt > 4;
+        const int doff = dused + tkz_wave_scan_sum(big ? cnt : 0, &btot);
         int32_t* dst = nullptr;
         if (have) {
-            const bool packed = doff + cnt <= kDenseCap;
-            dst = packed ? dense + doff : P.tmp + ((sub0 + si) * kSub + rel);
-            ml0[si * (int64_t)P.mcap + j] = tkz_result_entry(packed, cnt, packed ? doff : rel);
+            if (!big) ml0[si * (int64_t)P.mcap + j] = tkz_result_inline(cnt);
+            else {
+                const bool packed = doff + cnt <= kDenseCap;
+                dst = packed ? dense + doff : P.tmp + ((sub0 + si) * kSub + rel);
+                ml0[si * (int64_t)P.mcap + j] = tkz_result_entry(packed, cnt, packed ? doff : rel);
+            }
             if (cnt > 1) simt::atomic_add(&s_extra[si], cnt - 1);
         }
         dused += btot;
         return dst;
     };
-    // the piece of a list entry: its 16 bytes, zeroed beyond its length (the memo key); *nul = it holds a zero byte
-    auto load_key = [&](int si, int rel, int len, uint32_t* kw, bool* nul) {
-        tkz_load_piece16(P.bytes, P.total, (sub0 + si) * kSub + rel, kw);
+    // the piece of a list entry: its 16 bytes, zero beyond its length, as k_probe left them beside the entry; *nul = it holds a zero byte
+    uint4* const mq0 = P.mquad + sub0 * (int64_t)P.mcap;
+    auto load_key = [&](int si, int j, int len, uint32_t* kw, bool* nul) {
+        const uint4 kq = tkz_load16(&mq0[si * (int64_t)P.mcap + j]);
+        kw[0] = kq.x; kw[1] = kq.y; kw[2] = kq.z; kw[3] = kq.w;
         uint32_t z = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int nb = len - 4 * i;
             const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
-            kw[i] &= m;
             z |= (kw[i] - 0x01010101u) & ~kw[i] & 0x80808080u & m;
         }
         *nul = z != 0;
@@ -907,10 +927,10 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
         if (mine && memo) {
             uint32_t kw[4];
             bool nul;
-            load_key(si, rel, len, kw, &nul);
+            load_key(si, j, len, kw, &nul);
             const uint32_t b = tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), T.memo_n / kMemoWays) * kMemoWays;
 #pragma unroll
-            for (int wy = 0; wy < kMemoWays; ++wy) {
+            for (int wy = 0; wy < (int)kMemoWays; ++wy) {
                 const TkzMemoSlot* slot = &T.memo[b + wy];
                 const uint4 kk = tkz_load16(&slot->k[0]);
                 const uint4 v = tkz_load16(&slot->v[0]);
@@ -919,12 +939,10 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
             }
         }
         const int cnt = hit ? (int)((vv.x >> 29) & 3u) + 1 : 0;
-        int32_t* dst = assign(hit, cnt, si, j, rel);
-        if (hit) {
-            dst[0] = (int32_t)(vv.x & 0x07FFFFFFu);
-            if (cnt > 1) dst[1] = (int32_t)(vv.y & 0x07FFFFFFu);
-            if (cnt > 2) dst[2] = (int32_t)vv.z;
-            if (cnt > 3) dst[3] = (int32_t)vv.w;
+        (void)assign(hit, cnt, si, j, rel);
+        if (hit) {                                            // (a memo entry holds <= 4 tokens: they go into the entry's quad)
+            uint4 tq; tq.x = vv.x & 0x07FFFFFFu; tq.y = vv.y & 0x07FFFFFFu; tq.z = vv.z; tq.w = vv.w;
+            mq0[si * (int64_t)P.mcap + j] = tq;
         }
         const bool keep = lane < nchk || (mine && !hit);
         const uint64_t km = simt::ballot(keep);
@@ -942,7 +960,7 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
         if (lane < n) {
             const uint32_t r16 = s_rec[lane], ix = s_idx[lane];
             si = (int)(ix >> 10); j = (int)(ix & 1023u); rel = (int)(r16 & 1023u); len = (int)((r16 >> 10) & 15u) + 1;
-            load_key(si, rel, len, kw, &nul);
+            load_key(si, j, len, kw, &nul);
             cnt = tkz_bpe_lane_f<NMAX>(T, kw, len, ids, pr, byte_id, pair_rank, &alive, &e1);
             err |= e1;
         }
@@ -950,13 +968,14 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
         if (lane < n) {
             uint32_t t4[4] = {0, 0, 0, 0};
             int i = 0;
-            for (uint32_t a = alive; a; a &= a - 1) { const uint32_t t = ids[tkz_ctz32(a)]; dst[i] = (int32_t)t; if (i < 4) { if (i == 0) t4[0] = t; else if (i == 1) t4[1] = t; else if (i == 2) t4[2] = t; else t4[3] = t; } ++i; }
+            for (uint32_t a = alive; a; a &= a - 1) { const uint32_t t = ids[tkz_ctz32(a)]; if (dst) dst[i] = (int32_t)t; if (i < 4) { if (i == 0) t4[0] = t; else if (i == 1) t4[1] = t; else if (i == 2) t4[2] = t; else t4[3] = t; } ++i; }
+            if (cnt <= 4) { uint4 tq; tq.x = t4[0]; tq.y = t4[1]; tq.z = t4[2]; tq.w = t4[3]; mq0[si * (int64_t)P.mcap + j] = tq; }
             // a piece of <= 4 tokens takes a memo slot of its bucket if one is free (an entry is never replaced: a hit stays valid for good)
             if (memo && cnt <= 4 && !e1 && !nul) {
                 const uint32_t b = tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), T.memo_n / kMemoWays) * kMemoWays;
                 bool placed = false;
 #pragma unroll
-                for (int wy = 0; wy < kMemoWays; ++wy) {
+                for (int wy = 0; wy < (int)kMemoWays; ++wy) {
                     TkzMemoSlot* slot = &T.memo[b + wy];
                     // (a plain load first: a piece that lost its slot to another one comes back millions of times on repetitive text, and a
                     //  failing compare-and-swap is still an atomic on one hot address)
@@ -997,19 +1016,37 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
 }
 
 // The pieces of 17..1024 bytes that have to be merged, and the token counts of the giant ones.  One lane per piece with its state in a
-// span of an LDS arena sized for it (tkz_bpe_lane_var: ids | pair ranks | alive bits, preceded by the piece's bytes); the long-miss
-// lists of the 64 sub-tiles of a chunk are walked as one list and packed into one wavefront's lanes -- as many per batch as the arena
-// and the 64 lanes take -- because a sub-tile on its own has one or two of them.
+// span of an LDS arena sized for it (tkz_bpe_lane_varc64 / _varc / _var: pair ranks [| ids] [| alive bits], preceded by the piece's bytes).
+// The long-miss lists of the 64 sub-tiles of a chunk are walked as one list, kLongSeg entries at a time, and every such segment is
+// SORTED BY LENGTH (a counting sort over 16 length classes, in LDS) before it is cut into batches of up to 64 lanes: a merge costs a scan
+// over the whole piece and a piece of n bytes takes ~n/2 of them, so a 60-byte piece is ten times the work of a 17-byte one -- in list
+// order a batch took as long as its longest piece while the other lanes idled (33 % of the lanes active on CJK text).  Spans are padded to
+// an odd number of 16-byte quads: pieces of one class have equal spans, and with an even quad stride their 16-byte reads collide.
+constexpr int kLongSeg = 384;
+constexpr int kLenClasses = 16;
+TKZ_HD int tkz_len_class(int len) {          // 17..1024, monotone
+    if (len <= 32) return (len - 17) >> 2;               // 17-20, 21-24, 25-28, 29-32
+    if (len <= 64) return 4 + ((len - 33) >> 3);         // 33-40, 41-48, 49-56, 57-64
+    if (len <= 128) return len <= 96 ? 8 : 9;
+    if (len <= 256) return len <= 192 ? 10 : 11;
+    if (len <= 512) return len <= 384 ? 12 : 13;
+    return len <= 768 ? 14 : 15;
+}
+// (COMPACT: ranks below 2^21, i.e. every published vocabulary -- no ids[] array; a kernel of its own so that the general forms'
+//  registers stay out of it)
+template <bool COMPACT>
 TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
     TKZ_SHARED uint4 s_arena4[kArenaDwords / 4];
     TKZ_SHARED int s_pre[65];
+    TKZ_SHARED int s_cls[kLenClasses];
+    TKZ_SHARED uint16_t s_ord[kLongSeg];                                  // the segment's list positions, by length class
     TKZ_SHARED int32_t s_brank[256];                                     // id of every single byte: in LDS, not a gather per byte
     uint32_t* s_arena = reinterpret_cast<uint32_t*>(s_arena4);
     const int lane = simt::lane();
     for (int i = lane; i < 256; i += 64) s_brank[i] = T.byte_rank[i];
     (void)simt::ballot(true);
     int err = 0;
-    const bool compact = T.max_rank <= kVarCompactMaxRank;      // no ids[] array (tkz_bpe_lane_varc): 40 % more pieces per batch
+    constexpr bool compact = COMPACT;                           // no ids[] array (tkz_bpe_lane_varc): 40 % more pieces per batch
     for (int64_t c = simt::bid(); c * 64 < P.nsub; c += simt::nblocks()) {
         const int64_t t = c * 64 + lane;
         int my_nl = 0;
@@ -1027,57 +1064,99 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
         s_pre[lane] = pre;
         if (lane == 0) s_pre[64] = ntotal;
         (void)simt::ballot(true);
-        // position g of the 64 lists taken as one: entry g - pre[q] (from the back) of sub-tile q.  A batch = the next positions, one per
-        // lane, up to the first whose state no longer fits the arena.
-        for (int done = 0; done < ntotal;) {
-            const int g = done + lane;
-            const bool valid = g < ntotal;
-            int q = 0, j = 0, len = 1, rel = 0;
-            if (valid) {
-                q = tkz_find_list<64>(s_pre, g); j = g - s_pre[q];
-                const uint32_t ent = tkz_load_nt(&P.mlist[(c * 64 + q) * (int64_t)P.mcap + (P.mcap - 1 - j)]);
-                rel = (int)(ent & 1023u); len = (int)((ent >> kMrLenShift) & 1023u) + 1;
-            }
-            const int nbw = (len + 3) >> 2;
-            const int need = valid ? ((nbw + 3) & ~3) + (compact ? tkz_bpe_varc_dwords(len) : tkz_bpe_var_dwords(len)) : 0;
-            int btot;
-            const int aoff = tkz_wave_scan_sum(need, &btot);
-            const uint64_t bad = simt::ballot(valid && aoff + need > kArenaDwords);
-            const int limit = bad ? tkz_ctz64(bad) : 64;                       // lanes at or beyond `limit` wait for the next batch (limit >= 1: one piece always fits)
-            if (valid && lane < limit) {
-                const int64_t sub = c * 64 + q;
-                const int64_t abs = sub * kSub + rel;
-                uint32_t* bw = &s_arena[aoff];                   // (len + 3) / 4 dwords of bytes, then the merge state
-                {
-                    const int64_t a0 = abs & ~(int64_t)3;
-                    const uint32_t sh = (uint32_t)(abs & 3) * 8u;
-                    uint32_t prev = 0;
-                    if (a0 + 4 <= P.total) prev = *reinterpret_cast<const uint32_t*>(P.bytes + a0);
-                    else for (int b = 0; b < 4; ++b) if (a0 + b < P.total) prev |= (uint32_t)P.bytes[a0 + b] << (8 * b);
-                    for (int w = 0; w < nbw; ++w) {
-                        const int64_t p = a0 + 4 * (w + 1);
-                        uint32_t nx = 0;
-                        if (p + 4 <= P.total) nx = *reinterpret_cast<const uint32_t*>(P.bytes + p);
-                        else for (int b = 0; b < 4; ++b) if (p + b < P.total) nx |= (uint32_t)P.bytes[p + b] << (8 * b);
-                        bw[w] = simt::alignbit(nx, prev, sh);
-                        prev = nx;
-                    }
+        // position g of the 64 lists taken as one: entry g - pre[q] (from the back) of sub-tile q
+        auto entry_at = [&](int g, int* q, int* j) -> uint32_t {
+            *q = tkz_find_list<64>(s_pre, g); *j = g - s_pre[*q];
+            return tkz_load_nt(&P.mlist[(c * 64 + *q) * (int64_t)P.mcap + (P.mcap - 1 - *j)]);
+        };
+        for (int seg0 = 0; seg0 < ntotal; seg0 += kLongSeg) {
+            const int nseg = ntotal - seg0 < kLongSeg ? ntotal - seg0 : kLongSeg;
+            // ---- counting sort of the segment's positions by length class ----
+            if (lane < kLenClasses) s_cls[lane] = 0;
+            (void)simt::ballot(true);
+            uint32_t mycls = 0;                                  // the classes of this lane's (up to 8) entries, 4 bits each
+#pragma unroll
+            for (int i = 0; i < kLongSeg / 64; ++i) {
+                const int e = lane + 64 * i;
+                if (e < nseg) {
+                    int q, j;
+                    const uint32_t ent = entry_at(seg0 + e, &q, &j);
+                    const int cl = tkz_len_class((int)((ent >> kMrLenShift) & 1023u) + 1);
+                    mycls |= (uint32_t)cl << (4 * i);
+                    simt::atomic_add(&s_cls[cl], 1);
                 }
-                const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(bw);
-                uint32_t* st = bw + ((nbw + 3) & ~3);             // (the state arrays are read 16 bytes at a time)
-                auto at = [&](int i) -> uint32_t { return pbytes[i]; };
-                int e1 = 0, cnt;
-                if (compact) { cnt = tkz_bpe_lane_varc(T, at, len, st, &e1, s_brank); tkz_bpe_varc_emit(at, st, len, s_brank, P.tmp + abs); }
-                else {
-                    cnt = T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &e1, s_brank) : tkz_bpe_lane_var<false>(T, at, len, st, &e1, s_brank);
-                    tkz_bpe_var_emit(st, len, P.tmp + abs);
-                }
-                err |= e1;
-                P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_entry(false, cnt, rel);
-                if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
             }
             (void)simt::ballot(true);
-            done += limit < ntotal - done ? limit : ntotal - done;
+            {
+                int tot;
+                const int v = lane < kLenClasses ? s_cls[lane] : 0;
+                const int x = tkz_wave_scan_sum(v, &tot);
+                (void)simt::ballot(true);
+                if (lane < kLenClasses) s_cls[lane] = x;
+            }
+            (void)simt::ballot(true);
+#pragma unroll
+            for (int i = 0; i < kLongSeg / 64; ++i) {
+                const int e = lane + 64 * i;
+                if (e < nseg) s_ord[simt::atomic_add(&s_cls[(mycls >> (4 * i)) & 15u], 1)] = (uint16_t)e;
+            }
+            (void)simt::ballot(true);
+            // ---- batches: the next sorted positions, one per lane, up to the first whose state no longer fits the arena ----
+            for (int done = 0; done < nseg;) {
+                const bool valid = done + lane < nseg;
+                int q = 0, j = 0, len = 1, rel = 0;
+                if (valid) {
+                    const uint32_t ent = entry_at(seg0 + (int)s_ord[done + lane], &q, &j);
+                    rel = (int)(ent & 1023u); len = (int)((ent >> kMrLenShift) & 1023u) + 1;
+                }
+                const int nbw = (len + 3) >> 2;
+                const bool small = compact && len <= 64;         // alive bits in registers: the state is pr[] alone
+                int need = 0;
+                if (valid) {
+                    need = ((nbw + 3) & ~3) + (small ? tkz_bpe_var_n4(len) : compact ? tkz_bpe_varc_dwords(len) : tkz_bpe_var_dwords(len));
+                    if (!((need >> 2) & 1)) need += 4;           // an odd number of quads: equal spans then sit on distinct banks
+                }
+                int btot;
+                const int aoff = tkz_wave_scan_sum(need, &btot);
+                const uint64_t bad = simt::ballot(valid && aoff + need > kArenaDwords);
+                const int limit = bad ? tkz_ctz64(bad) : 64;                   // lanes at or beyond `limit` wait for the next batch (limit >= 1: one piece always fits)
+                if (valid && lane < limit) {
+                    const int64_t sub = c * 64 + q;
+                    const int64_t abs = sub * kSub + rel;
+                    uint32_t* bw = &s_arena[aoff];                   // (len + 3) / 4 dwords of bytes, then the merge state
+                    {
+                        const int64_t a0 = abs & ~(int64_t)3;
+                        const uint32_t sh = (uint32_t)(abs & 3) * 8u;
+                        uint32_t prev = 0;
+                        if (a0 + 4 <= P.total) prev = *reinterpret_cast<const uint32_t*>(P.bytes + a0);
+                        else for (int b = 0; b < 4; ++b) if (a0 + b < P.total) prev |= (uint32_t)P.bytes[a0 + b] << (8 * b);
+                        for (int w = 0; w < nbw; ++w) {
+                            const int64_t p = a0 + 4 * (w + 1);
+                            uint32_t nx = 0;
+                            if (p + 4 <= P.total) nx = *reinterpret_cast<const uint32_t*>(P.bytes + p);
+                            else for (int b = 0; b < 4; ++b) if (p + b < P.total) nx |= (uint32_t)P.bytes[p + b] << (8 * b);
+                            bw[w] = simt::alignbit(nx, prev, sh);
+                            prev = nx;
+                        }
+                    }
+                    const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(bw);
+                    uint32_t* st = bw + ((nbw + 3) & ~3);             // (the state arrays are read 16 bytes at a time)
+                    auto at = [&](int i) -> uint32_t { return pbytes[i]; };
+                    int e1 = 0, cnt;
+                    if constexpr (COMPACT) {
+                        if (small) { uint64_t alive; cnt = tkz_bpe_lane_varc64(T, at, len, st, &e1, s_brank, &alive); tkz_bpe_varc64_emit(at, st, alive, len, s_brank, P.tmp + abs); }
+                        else { cnt = tkz_bpe_lane_varc(T, at, len, st, &e1, s_brank); tkz_bpe_varc_emit(at, st, len, s_brank, P.tmp + abs); }
+                    } else {
+                        cnt = T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &e1, s_brank) : tkz_bpe_lane_var<false>(T, at, len, st, &e1, s_brank);
+                        tkz_bpe_var_emit(st, len, P.tmp + abs);
+                    }
+                    err |= e1;
+                    P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_entry(false, cnt, rel);
+                    if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
+                }
+                (void)simt::ballot(true);
+                done += limit < nseg - done ? limit : nseg - done;
+            }
         }
     }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
@@ -1089,17 +1168,20 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
 constexpr int kStage = kSub + 32;                          // ids of pieces of <= 16 tokens that start in one sub-tile (<= 1024 + 15) + the alignment shift
 TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
     TKZ_SHARED uint4 s_stage_all[kThreads / 64][kStage / 4];
-    TKZ_SHARED uint32_t s_res_all[kThreads / 64][128];                    // the first 64 answers of the sub-tile's short-miss list, and of the long one
+    TKZ_SHARED uint32_t s_res_all[kThreads / 64][96];                     // the first 64 answers of the sub-tile's short-miss list, the first 32 of the long one
+    TKZ_SHARED uint4 s_quad_all[kThreads / 64][64];                       // ... and the quads of those short entries (the tokens of pieces of <= 4)
     const int lane = simt::lane();
     const int64_t sub = tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave();
     if (sub >= P.nsub) return;
     int32_t* stage = reinterpret_cast<int32_t*>(s_stage_all[simt::wave()]);
     uint32_t* s_res = s_res_all[simt::wave()];
+    uint4* s_quad = s_quad_all[simt::wave()];
     const int64_t pb = P.pbase[sub], tb = tile_base[sub], base = sub * kSub, ord0 = P.docord_base[sub];
     const int np = P.pcount[sub];
     const uint32_t mc = P.mcount[sub];
     const int ns = (int)(mc & 0xFFFFu), nl = (int)(mc >> 16);
     const uint32_t* const ml = P.mlist + sub * (int64_t)P.mcap;
+    const uint4* const mqd = P.mquad + sub * (int64_t)P.mcap;
     const int32_t* const dense = P.dense + (sub / kGroup) * kDenseCap;
     const bool has_giant = (P.heavy_flag[sub] & 2u) != 0;
     int gcnt = has_giant ? P.giant_cnt[sub] : 0;
@@ -1107,19 +1189,23 @@ TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, in
     const bool lists_ok = ns + nl <= P.mcap;               // (cut lists: the batch is redone, nothing of this pass is used)
     {   // the answers of the merge kernels, in the same round trip as the first records
         uint32_t a = 0, b = 0;
-        if (lists_ok && lane < ns) a = tkz_load_nt(&ml[lane]);
-        if (lists_ok && lane < nl) b = tkz_load_nt(&ml[P.mcap - 1 - lane]);
-        s_res[lane] = a; s_res[64 + lane] = b;
+        uint4 qd; qd.x = qd.y = qd.z = qd.w = 0;
+        if (lists_ok && lane < ns) { a = tkz_load_nt(&ml[lane]); qd = tkz_load16_nt(&mqd[lane]); }
+        if (lists_ok && lane < nl && lane < 32) b = tkz_load_nt(&ml[P.mcap - 1 - lane]);
+        s_res[lane] = a; s_quad[lane] = qd;
+        if (lane < 32) s_res[64 + lane] = b;
     }
     (void)simt::ballot(true);
-    // where the tokens of a missed piece wait, and how many there are
-    auto locate = [&](uint32_t rec, int* cnt) -> const int32_t* {
+    // where the tokens of a missed piece wait, and how many there are.  INLINE (a short piece of <= 4 tokens: nearly all of them): in the
+    // entry's quad, which for the first 64 entries is already in LDS -- *q4 gets it and the returned pointer is null
+    auto locate = [&](uint32_t rec, int* cnt, uint4* q4) -> const int32_t* {
         if (rec & kPrGiant) { *cnt = gcnt; return P.tmp + base + (rec & 1023u); }
         const int idx = (int)(rec & 1023u);
         const bool lg = (rec & kPrLong) != 0;
         uint32_t r = 0;
-        if (lists_ok) r = idx < 64 ? s_res[(lg ? 64 : 0) + idx] : ml[lg ? P.mcap - 1 - idx : idx];
+        if (lists_ok) r = idx < (lg ? 32 : 64) ? s_res[(lg ? 64 : 0) + idx] : ml[lg ? P.mcap - 1 - idx : idx];
         *cnt = tkz_result_cnt(r);
+        if (r & kMrInline) { *q4 = idx < 64 ? s_quad[idx] : tkz_load16(&mqd[idx]); return nullptr; }
         return (r & kMrDense) ? dense + tkz_result_off(r) : P.tmp + base + tkz_result_off(r);
     };
     // stage[i] holds the id of token sbase + i of the sub-tile; sbase is chosen so that stage[0] sits on a 16-byte boundary of `out`
@@ -1160,10 +1246,14 @@ TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, in
       for (int j = 0; j < 4; ++j) {
           const uint32_t rec = r4[j];
           const bool ld = (rec & kPrMiss) != 0;
-          c4[j] = 1; src4[j] = P.tmp;
-          if (ld) src4[j] = locate(rec, &c4[j]);
+          c4[j] = 1; src4[j] = nullptr;
+          uint4 q4; q4.x = q4.y = q4.z = q4.w = 0;
+          if (ld) src4[j] = locate(rec, &c4[j], &q4);
+          t4[j][0] = (int32_t)q4.x; t4[j][1] = (int32_t)q4.y; t4[j][2] = (int32_t)q4.z; t4[j][3] = (int32_t)q4.w;
+          if (src4[j]) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) t4[j][i] = (ld && i < c4[j]) ? src4[j][i] : 0;
+              for (int i = 0; i < 4; ++i) t4[j][i] = i < c4[j] ? src4[j][i] : 0;
+          }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1744,7 +1834,11 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
 #endif
     TKZ_LAUNCH(k_giant_order, 1, 1024, L.stream, P);
     TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // takes pieces off the ordered queue; exits at once when it is empty
-    { const int64_t chunks = cdiv(nsub, 64); TKZ_LAUNCH(k_merge_long, chunks < 16384 ? chunks : 16384, 64, L.stream, T, P); }   // strides over 64-sub-tile chunks
+    {   // strides over 64-sub-tile chunks
+        const int64_t chunks = cdiv(nsub, 64), grid = chunks < 16384 ? chunks : 16384;
+        if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH(k_merge_long<true>, grid, 64, L.stream, T, P);
+        else TKZ_LAUNCH(k_merge_long<false>, grid, 64, L.stream, T, P);
+    }
     hook(L, K_HEAVY, 1);
 }
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {

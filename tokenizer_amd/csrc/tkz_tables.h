@@ -89,7 +89,7 @@ struct alignas(16) TkzMemoSlot { uint32_t k[4]; uint32_t v[4]; };
 constexpr uint32_t kMemoValid = 0x80000000u, kMemoBusy = 0xFFFFFFFFu;
 // slots per bucket (one 64-byte line for 2): a piece may sit in any slot of its bucket and takes the first free one
 #ifndef TKZ_MEMO_WAYS
-#define TKZ_MEMO_WAYS 2
+#define TKZ_MEMO_WAYS 1
 #endif
 constexpr uint32_t kMemoWays = TKZ_MEMO_WAYS;
 
