@@ -544,14 +544,23 @@ TKZ_DEV uint32_t tkz_key_dword(const uint32_t* s_bytes, int s, int len, int i) {
     return nb >= 4 ? x : (nb <= 0 ? 0u : (x & ((1u << (8 * nb)) - 1u)));
 }
 
-TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
-    TKZ_SHARED uint4 s_bytes_all[kThreads / 64][(kSub + kHalo) / 16];
-    TKZ_SHARED uint16_t s_pstart_all[kThreads / 64][kSub + 2];
-    TKZ_SHARED uint16_t s_mid_all[kThreads / 64][kMidMax];                // the pieces of 13..28 bytes of the sub-tile ...
-    TKZ_SHARED uint32_t s_midres_all[kThreads / 64][kMidMax];             // ... and what the MID table says about them
-    TKZ_SHARED uint32_t s_mark_all[kThreads / 64][kSub / 32];             // document (piece) marks of the sub-tile, 32 positions per dword
-    TKZ_SHARED uint4 s_kmask[TKZ_SHORT_KEY_MAX + 1];                      // byte mask of a zero-padded key of 0..12 bytes (three dwords)
-    const int lane = simt::lane();
+// LDS of one wavefront of the probe stage (+ the mask table, shared by the workgroup)
+constexpr int kProbeLdsBytes = (kSub + kHalo) + 2 * (kSub + 2) + 2 * kMidMax + 4 * kMidMax + 4 * (kSub / 32);     // per wavefront; a multiple of 4
+constexpr int kProbeLdsQuads = (kProbeLdsBytes + 15) / 16;
+struct ProbeLds { uint32_t* bytes; uint16_t* pstart; uint16_t* mid; uint32_t* midres; uint32_t* mark; const uint4* kmask; };
+TKZ_DEV ProbeLds tkz_probe_lds(uint4* wave_quads, const uint4* kmask) {
+    ProbeLds L;
+    uint8_t* b = reinterpret_cast<uint8_t*>(wave_quads);
+    L.bytes = reinterpret_cast<uint32_t*>(b); b += kSub + kHalo;
+    L.midres = reinterpret_cast<uint32_t*>(b); b += 4 * kMidMax;
+    L.mark = reinterpret_cast<uint32_t*>(b); b += 4 * (kSub / 32);
+    L.pstart = reinterpret_cast<uint16_t*>(b); b += 2 * (kSub + 2);
+    L.mid = reinterpret_cast<uint16_t*>(b);
+    L.kmask = kmask;
+    return L;
+}
+// byte mask of a zero-padded key of 0..12 bytes (three dwords): written by threads 0..12 of the workgroup, followed by a barrier
+TKZ_DEV void tkz_probe_kmask_init(uint4* s_kmask) {
     if (simt::tid() <= TKZ_SHORT_KEY_MAX) {
         const int len = simt::tid();
         uint32_t m[3];
@@ -559,14 +568,16 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
         uint4 v; v.x = m[0]; v.y = m[1]; v.z = m[2]; v.w = 0;
         s_kmask[len] = v;
     }
-    simt::sync();                                         // (the only workgroup barrier: from here on every wavefront is on its own)
-    const int64_t sub = tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave();
-    if (sub >= P.nsub) return;
-    uint32_t* s_bytes = reinterpret_cast<uint32_t*>(s_bytes_all[simt::wave()]);
-    uint16_t* s_pstart = s_pstart_all[simt::wave()];
-    uint16_t* s_mid = s_mid_all[simt::wave()];
-    uint32_t* s_midres = s_midres_all[simt::wave()];
-    uint32_t* s_mark = s_mark_all[simt::wave()];
+}
+// one sub-tile, by one wavefront (no workgroup barrier inside: every wavefront is on its own)
+TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub, const ProbeLds& LD) {
+    const int lane = simt::lane();
+    uint32_t* s_bytes = LD.bytes;
+    uint16_t* s_pstart = LD.pstart;
+    uint16_t* s_mid = LD.mid;
+    uint32_t* s_midres = LD.midres;
+    uint32_t* s_mark = LD.mark;
+    const uint4* s_kmask = LD.kmask;
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(s_bytes);
     const int64_t base = sub * kSub;
     const int nb = (int)(P.total - base < kSub ? P.total - base : kSub);
@@ -643,16 +654,17 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
     if (prof) t_1 = simt::clock();
     const char* tb0 = reinterpret_cast<const char*>(T.short_slots);
     const uint32_t mid_off = (uint32_t)(reinterpret_cast<const char*>(T.mid_slots) - tb0);   // (SHORT and MID share one allocation)
-    // ---- the pieces of 13..28 bytes first: a few per cent of all pieces, twice the instructions of a short one.  Looked up together,
-    // 64 per batch, and their answers parked in LDS by ordinal: the main loop below then stores every batch's 64 records as four FULL
-    // lines (patching these few records in afterwards punched holes into every line: 1.7x the write traffic) ----
+    // ---- the pieces of 13+ bytes first: a few per cent of all pieces, twice the instructions of a short one (13..28 bytes: MID table;
+    // 29..1024: the LONG table, rare).  Looked up together, 64 per batch, and their answers parked in LDS by ordinal: the main loop below
+    // then handles nothing but keys of up to 12 bytes and stores every batch's 64 records as four FULL lines (patching these few records
+    // in afterwards punched holes into every line: 1.7x the write traffic) ----
     int nmid = 0;
 #pragma unroll 1
     for (int k0 = 0; k0 < np; k0 += 64) {
         const int k = k0 + lane;
         int len = 0;
         if (k < np) len = (int)s_pstart[k + 1] - (int)s_pstart[k];
-        const uint64_t midm = simt::ballot(len > TKZ_SHORT_KEY_MAX && len <= TKZ_MID_KEY_MAX);
+        const uint64_t midm = simt::ballot(len > TKZ_SHORT_KEY_MAX && len <= kArenaPiece);
         if ((midm >> lane) & 1ull) s_mid[nmid + tkz_popc64(midm & tkz_lowmask(lane))] = (uint16_t)k;
         nmid += tkz_popc64(midm);
     }
@@ -666,6 +678,9 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
             const int k = s_mid[m0 + lane];
             s = s_pstart[k];
             len = (int)s_pstart[k + 1] - s;
+        }
+        const bool is_mid = valid && len <= TKZ_MID_KEY_MAX;
+        if (is_mid) {
 #pragma unroll
             for (int i = 0; i < 7; ++i) kk[i] = tkz_key_dword(s_bytes, s, len, i);
             uint32_t s1, s2;
@@ -673,7 +688,13 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
             oa = mid_off + 32u * s1; ob = mid_off + 32u * s2;
         }
         const uint4 a0 = tkz_load16(tb0 + oa), a1 = tkz_load16(tb0 + oa + 16u), b0 = tkz_load16(tb0 + ob), b1 = tkz_load16(tb0 + ob + 16u);
-        if (valid) s_midres[m0 + lane] = (uint32_t)tkz_match_mid(kk, (uint32_t)len, a0, a1, b0, b1);
+        int32_t rank = TKZ_RANK_NONE;
+        if (is_mid) rank = tkz_match_mid(kk, (uint32_t)len, a0, a1, b0, b1);
+        else if (valid) {
+            if (s + len <= kSub + kHalo) rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)len);
+            else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return gbase[s + i]; }, (uint32_t)len);
+        }
+        if (valid) s_midres[m0 + lane] = (uint32_t)rank;
     }
     (void)simt::ballot(true);
     if (prof) t_2 = simt::clock();
@@ -712,8 +733,7 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool is_short = plen[u] >= 1 && plen[u] <= TKZ_SHORT_KEY_MAX;
-            rk[u] = TKZ_RANK_NONE;
-            if (is_short) rk[u] = tkz_match_short2(kw0[u], kw1[u], kw2[u], (uint32_t)plen[u], a0[u], a1[u]);
+            rk[u] = tkz_match_short2x(kw0[u], kw1[u], kw2[u], (uint32_t)plen[u], a0[u], a1[u]);       // (a piece that is not short matches no slot: len 0 or > 12)
             more = more || (is_short && rk[u] == TKZ_RANK_NONE);
         }
         // the second bucket, for the lanes the first one did not settle only (the keys the builder could not keep in their first
@@ -730,7 +750,7 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool want = plen[u] >= 1 && plen[u] <= TKZ_SHORT_KEY_MAX && rk[u] == TKZ_RANK_NONE;
-                if (want) rk[u] = tkz_match_short2(kw0[u], kw1[u], kw2[u], (uint32_t)plen[u], a0[u], a1[u]);
+                if (want) rk[u] = tkz_match_short2x(kw0[u], kw1[u], kw2[u], (uint32_t)plen[u], a0[u], a1[u]);
             }
         }
 #pragma unroll
@@ -738,15 +758,11 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
             const int k = k0 + 64 * u + lane;
             const bool valid = k < np;
             const int s = ps[u], len = plen[u];
-            const bool is_mid = len > TKZ_SHORT_KEY_MAX && len <= TKZ_MID_KEY_MAX;
+            const bool is_mid = len > TKZ_SHORT_KEY_MAX && len <= kArenaPiece;
             const uint64_t midm = simt::ballot(is_mid);
             int32_t rank = rk[u];                                                // Encoder.TryGetValue(piece) (TikTokenizer.cs:262)
             if (is_mid) rank = (int32_t)s_midres[midseen + tkz_popc64(midm & tkz_lowmask(lane))];
             midseen += tkz_popc64(midm);
-            if (len > TKZ_MID_KEY_MAX && len <= kArenaPiece) {
-                if (s + len <= kSub + kHalo) rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return sb[s + i]; }, (uint32_t)len);
-                else rank = tkz_lookup_long(T, [&](int i) -> uint32_t { return gbase[s + i]; }, (uint32_t)len);
-            }
             const bool is_giant = len > kArenaPiece;                             // (k_giant_merge looks a giant piece up itself)
             const bool miss = valid && !is_giant && rank == TKZ_RANK_NONE;
             const bool miss_s = miss && len <= kShortMax, miss_l = miss && len > kShortMax;
@@ -785,6 +801,15 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
         if (ns + nl > P.mcap) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&P.counters[1], (unsigned)(ns + nl)); }
         if (pb + np > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
     }
+}
+TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
+    TKZ_SHARED uint4 s_wave[kThreads / 64][kProbeLdsQuads];
+    TKZ_SHARED uint4 s_kmask[TKZ_SHORT_KEY_MAX + 1];
+    tkz_probe_kmask_init(s_kmask);
+    simt::sync();                                         // (the only workgroup barrier: from here on every wavefront is on its own)
+    const int64_t sub = tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave();
+    if (sub >= P.nsub) return;
+    tkz_probe_subtile(T, P, sub, tkz_probe_lds(s_wave[simt::wave()], s_kmask));
 }
 
 // the 16 bytes of the corpus that start at byte position `abs`, as four little-endian dwords: the five dwords around them are fetched
@@ -833,38 +858,51 @@ TKZ_DEV int tkz_find_list(const int* pre, int g) {
 // their memo slot if it is empty.  On the bench corpus 3 of 4 missed pieces are memo hits: a merge costs ~45 scattered gathers and ~8
 // dependent round trips, a memo lookup 4 and one.  Every entry is answered in place (tkz_result_entry); the records are never read.
 // (LDS: 4 x 9.25 KB of merge state + 2.3 KB = 40 KB per workgroup, and <= 128 VGPRs: four workgroups = 16 wavefronts per CU)
-TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
-    constexpr int NMAX = 16, STRIDE = TkzBpeGeom<NMAX>::kStride, IDSTRIDE = TkzBpeGeom<NMAX>::kIdStride;
-    TKZ_SHARED uint4 s_pr_all[kMsThreads / 64][(STRIDE * 64) / 4];        // per lane pr[16] at a conflict-free stride for 16-byte reads
-    TKZ_SHARED uint32_t s_ids_all[kMsThreads / 64][IDSTRIDE * 64];        // per lane ids[16]
+constexpr int kMsStride = TkzBpeGeom<16>::kStride, kMsIdStride = TkzBpeGeom<16>::kIdStride;
+// LDS of one wavefront of k_merge_short (+ the byte-id table shared by the workgroup)
+struct MsLds { uint4* pr; uint32_t* ids; uint16_t* rec; uint16_t* idx; int* extra; int* pre; const uint16_t* brank16; };
+constexpr int kMsLdsBytes = kMsStride * 64 * 4 + kMsIdStride * 64 * 4 + 2 * 64 + 2 * 64 + 4 * kGroup + 4 * (kGroup + 1) + 12;   // per wavefront, rounded to 16 below
+constexpr int kMsLdsQuads = (kMsLdsBytes + 15) / 16;
+TKZ_DEV MsLds tkz_ms_lds(uint4* wave_quads, const uint16_t* brank16) {
+    MsLds L;
+    uint8_t* b = reinterpret_cast<uint8_t*>(wave_quads);
+    L.pr = reinterpret_cast<uint4*>(b); b += kMsStride * 64 * 4;              // per lane pr[16] at a conflict-free stride for 16-byte reads
+    L.ids = reinterpret_cast<uint32_t*>(b); b += kMsIdStride * 64 * 4;        // per lane ids[16]
+    L.extra = reinterpret_cast<int*>(b); b += 4 * kGroup;                     // tokens the merges added to every sub-tile of the group
+    L.pre = reinterpret_cast<int*>(b); b += 4 * (kGroup + 1);                 // exclusive prefix of the lists' lengths
     // the wave's list: relpos | (len-1) << 10 | looked-up-in-the-memo << 15, and (sub-tile of the group) << 10 | index in its miss list
-    TKZ_SHARED uint16_t s_rec_all[kMsThreads / 64][64];
-    TKZ_SHARED uint16_t s_idx_all[kMsThreads / 64][64];
-    TKZ_SHARED int s_extra_all[kMsThreads / 64][kGroup];                  // tokens the merges added to every sub-tile of the group
-    TKZ_SHARED int s_pre_all[kMsThreads / 64][kGroup + 1];                // exclusive prefix of the lists' lengths
-    // the id of every single byte in LDS, not 16 gathers per piece (0xFFFF: not a key, 0xFFFE: too large for 16 bits, look it up)
-    TKZ_SHARED uint16_t s_brank16[256];
-    static_assert(kGroup == 16 && kShortMax == 16, "list entries: 4 bits of sub-tile, 10 of index; 10 of relpos, 4 of length, 1 flag");
-    const int lane = simt::lane(), wv = simt::wave();
+    L.rec = reinterpret_cast<uint16_t*>(b); b += 2 * 64;
+    L.idx = reinterpret_cast<uint16_t*>(b);
+    L.brank16 = brank16;
+    return L;
+}
+// the id of every single byte in LDS, not 16 gathers per piece (0xFFFF: not a key, 0xFFFE: too large for 16 bits, look it up); by the whole
+// workgroup, followed by a barrier
+TKZ_DEV void tkz_ms_brank_init(const TkzTables& T, uint16_t* s_brank16) {
     for (int i = simt::tid(); i < 256; i += simt::nthreads()) {
         const uint32_t v = (uint32_t)T.byte_rank[i];
         s_brank16[i] = (uint16_t)(v >= (uint32_t)TKZ_PSEUDO_BASE ? 0xFFFFu : (v < 0xFFFEu ? v : 0xFFFEu));
     }
-    simt::sync();
+}
+// one group of kGroup sub-tiles, by one wavefront
+TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, int64_t grp, const MsLds& LD) {
+    constexpr int NMAX = 16, STRIDE = kMsStride, IDSTRIDE = kMsIdStride;
+    static_assert(kGroup == 16 && kShortMax == 16, "list entries: 4 bits of sub-tile, 10 of index; 10 of relpos, 4 of length, 1 flag");
+    const int lane = simt::lane();
+    const uint16_t* s_brank16 = LD.brank16;
     auto byte_id = [&](uint32_t b) -> uint32_t {
         const uint32_t v = s_brank16[b];
         return v < 0xFFFEu ? v : (v == 0xFFFFu ? (uint32_t)TKZ_PSEUDO_BASE + b : (uint32_t)T.byte_rank[b]);
     };
     auto pair_rank = [&](uint32_t b0, uint32_t b1) -> int32_t { return T.bytepair_rank[(b0 << 8) | b1]; };
-    const int64_t grp = tkz_xcd_block(simt::bid(), simt::nblocks()) * (kMsThreads / 64) + wv;
     const int64_t sub0 = grp * kGroup;
     if (sub0 >= P.nsub) return;
-    uint16_t* s_rec = s_rec_all[wv];
-    uint16_t* s_idx = s_idx_all[wv];
-    int* s_extra = s_extra_all[wv];
-    int* s_pre = s_pre_all[wv];
-    uint32_t* ids = &s_ids_all[wv][lane * IDSTRIDE];
-    uint32_t* pr = reinterpret_cast<uint32_t*>(s_pr_all[wv]) + lane * STRIDE;
+    uint16_t* s_rec = LD.rec;
+    uint16_t* s_idx = LD.idx;
+    int* s_extra = LD.extra;
+    int* s_pre = LD.pre;
+    uint32_t* ids = LD.ids + lane * IDSTRIDE;
+    uint32_t* pr = reinterpret_cast<uint32_t*>(LD.pr) + lane * STRIDE;
     // lane q < kGroup looks after sub-tile q of the group: how many pieces start there, how long its short-miss list is
     int my_np = 0, my_ns = 0;
     if (lane < kGroup && sub0 + lane < P.nsub) { my_np = P.pcount[sub0 + lane]; my_ns = (int)(P.mcount[sub0 + lane] & 0xFFFFu); }
@@ -1014,6 +1052,15 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     if (lane < kGroup && sub0 + lane < P.nsub) P.tile_count[sub0 + lane] = my_np + s_extra[lane];
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
+// (LDS: 4 x 9.5 KB of merge state + 0.5 KB = 38.5 KB per workgroup, and <= 128 VGPRs: four workgroups = 16 wavefronts per CU)
+TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
+    TKZ_SHARED uint4 s_wave[kMsThreads / 64][kMsLdsQuads];
+    TKZ_SHARED uint16_t s_brank16[256];
+    tkz_ms_brank_init(T, s_brank16);
+    simt::sync();
+    const int64_t grp = tkz_xcd_block(simt::bid(), simt::nblocks()) * (kMsThreads / 64) + simt::wave();
+    tkz_merge_short_group(T, P, grp, tkz_ms_lds(s_wave[simt::wave()], s_brank16));
+}
 
 // The pieces of 17..1024 bytes that have to be merged, and the token counts of the giant ones.  One lane per piece with its state in a
 // span of an LDS arena sized for it (tkz_bpe_lane_varc64 / _varc / _var: pair ranks [| ids] [| alive bits], preceded by the piece's bytes).
@@ -1032,22 +1079,37 @@ TKZ_HD int tkz_len_class(int len) {          // 17..1024, monotone
     if (len <= 512) return len <= 384 ? 12 : 13;
     return len <= 768 ? 14 : 15;
 }
-// (COMPACT: ranks below 2^21, i.e. every published vocabulary -- no ids[] array; a kernel of its own so that the general forms'
-//  registers stay out of it)
-template <bool COMPACT>
-TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
-    TKZ_SHARED uint4 s_arena4[kArenaDwords / 4];
-    TKZ_SHARED int s_pre[65];
-    TKZ_SHARED int s_cls[kLenClasses];
-    TKZ_SHARED uint16_t s_ord[kLongSeg];                                  // the segment's list positions, by length class
-    TKZ_SHARED int32_t s_brank[256];                                     // id of every single byte: in LDS, not a gather per byte
-    uint32_t* s_arena = reinterpret_cast<uint32_t*>(s_arena4);
-    const int lane = simt::lane();
-    for (int i = lane; i < 256; i += 64) s_brank[i] = T.byte_rank[i];
+// LDS of the wavefront of k_merge_long
+struct LongLds { uint32_t* arena; int* pre; int* cls; uint16_t* ord; int32_t* brank; };
+constexpr int kLongLdsBytes = kArenaDwords * 4 + 4 * 68 + 4 * kLenClasses + 2 * kLongSeg + 4 * 256;
+constexpr int kLongLdsQuads = (kLongLdsBytes + 15) / 16;
+TKZ_DEV LongLds tkz_long_lds(uint4* quads) {
+    LongLds L;
+    uint8_t* b = reinterpret_cast<uint8_t*>(quads);
+    L.arena = reinterpret_cast<uint32_t*>(b); b += kArenaDwords * 4;
+    L.brank = reinterpret_cast<int32_t*>(b); b += 4 * 256;                    // id of every single byte: in LDS, not a gather per byte
+    L.pre = reinterpret_cast<int*>(b); b += 4 * 68;
+    L.cls = reinterpret_cast<int*>(b); b += 4 * kLenClasses;
+    L.ord = reinterpret_cast<uint16_t*>(b);                                   // the segment's list positions, by length class
+    return L;
+}
+TKZ_DEV void tkz_long_brank_init(const TkzTables& T, int32_t* s_brank) {     // by one wavefront
+    for (int i = simt::lane(); i < 256; i += 64) s_brank[i] = T.byte_rank[i];
     (void)simt::ballot(true);
+}
+// chunks c0, c0 + cstep, ... of 64 sub-tiles each, by one wavefront
+// (COMPACT: ranks below 2^21, i.e. every published vocabulary -- no ids[] array)
+template <bool COMPACT>
+TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, int64_t c0, int64_t cstep, const LongLds& LD) {
+    uint32_t* s_arena = LD.arena;
+    int* s_pre = LD.pre;
+    int* s_cls = LD.cls;
+    uint16_t* s_ord = LD.ord;
+    const int32_t* s_brank = LD.brank;
+    const int lane = simt::lane();
     int err = 0;
     constexpr bool compact = COMPACT;                           // no ids[] array (tkz_bpe_lane_varc): 40 % more pieces per batch
-    for (int64_t c = simt::bid(); c * 64 < P.nsub; c += simt::nblocks()) {
+    for (int64_t c = c0; c * 64 < P.nsub; c += cstep) {
         const int64_t t = c * 64 + lane;
         int my_nl = 0;
         if (t < P.nsub) {
@@ -1151,7 +1213,14 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
                         tkz_bpe_var_emit(st, len, P.tmp + abs);
                     }
                     err |= e1;
-                    P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_entry(false, cnt, rel);
+                    // (the tokens are in tmp at the piece's position; up to four also go into the entry's quad, where k_place finds them
+                    //  in the round trip that fetches the answers)
+                    if (cnt <= 4) {
+                        const int32_t* tk = P.tmp + abs;
+                        uint4 tq; tq.x = (uint32_t)tk[0]; tq.y = cnt > 1 ? (uint32_t)tk[1] : 0u; tq.z = cnt > 2 ? (uint32_t)tk[2] : 0u; tq.w = cnt > 3 ? (uint32_t)tk[3] : 0u;
+                        P.mquad[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tq;
+                        P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_inline(cnt);
+                    } else P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_entry(false, cnt, rel);
                     if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
                 }
                 (void)simt::ballot(true);
@@ -1161,53 +1230,99 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
     }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
+// (a kernel of its own per form so that the general forms' registers stay out of the compact one)
+template <bool COMPACT>
+TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
+    TKZ_SHARED uint4 s_lds[kLongLdsQuads];
+    const LongLds LD = tkz_long_lds(s_lds);
+    tkz_long_brank_init(T, LD.brank);
+    tkz_merge_long_chunks<COMPACT>(T, P, simt::bid(), simt::nblocks(), LD);
+}
 
 // ids at their final position: count per record -> prefix -> the sub-tile's ids staged in LDS -> stored as whole 16-byte quads (one
 // store instruction = 16 full lines; per-lane 4-byte stores at variable offsets wrote 1.8x the bytes); the token index (inside the
 // sub-tile) of every marked piece
-constexpr int kStage = kSub + 32;                          // ids of pieces of <= 16 tokens that start in one sub-tile (<= 1024 + 15) + the alignment shift
-TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
-    TKZ_SHARED uint4 s_stage_all[kThreads / 64][kStage / 4];
-    TKZ_SHARED uint32_t s_res_all[kThreads / 64][96];                     // the first 64 answers of the sub-tile's short-miss list, the first 32 of the long one
-    TKZ_SHARED uint4 s_quad_all[kThreads / 64][64];                       // ... and the quads of those short entries (the tokens of pieces of <= 4)
+#ifndef TKZ_PLACE_OCC
+#define TKZ_PLACE_OCC 8
+#endif
+constexpr int kPlaceRes = 32;                              // answers (and quads) of a sub-tile's miss lists k_place keeps in LDS (of each list; a sub-tile averages 14 short misses)
+constexpr int kPlacePer = 4;                               // consecutive sub-tiles per wavefront of k_place
+constexpr int kPlaceBig = 8;                               // token runs longer than this are copied by the whole wavefront, not staged
+constexpr int kStage = 64 * kPlaceBig + 16;                // staged ids: after a flush, the <= 64 x kPlaceBig ids of one batch of records + the alignment shift always fit
+// LDS of one wavefront of k_place: the staged ids, the first answers of the sub-tile's short-miss list and of the long one, and the quads
+// of those entries (the tokens of pieces of <= 4)
+constexpr int kPlaceLdsQuads = kStage / 4 + 2 * kPlaceRes + (2 * kPlaceRes) / 4;
+struct PlaceLds { int32_t* stage; uint4* quad; uint32_t* res; };
+TKZ_DEV PlaceLds tkz_place_lds(uint4* wave_quads) {
+    PlaceLds L;
+    L.stage = reinterpret_cast<int32_t*>(wave_quads);
+    L.quad = wave_quads + kStage / 4;
+    L.res = reinterpret_cast<uint32_t*>(wave_quads + kStage / 4 + 2 * kPlaceRes);
+    return L;
+}
+// sub-tiles sub0 .. sub0 + kPlacePer - 1, by one wavefront
+TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base, int32_t* out, int64_t out_cap, int64_t sub0, const PlaceLds& LD) {
     const int lane = simt::lane();
-    const int64_t sub = tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave();
-    if (sub >= P.nsub) return;
-    int32_t* stage = reinterpret_cast<int32_t*>(s_stage_all[simt::wave()]);
-    uint32_t* s_res = s_res_all[simt::wave()];
-    uint4* s_quad = s_quad_all[simt::wave()];
-    const int64_t pb = P.pbase[sub], tb = tile_base[sub], base = sub * kSub, ord0 = P.docord_base[sub];
-    const int np = P.pcount[sub];
-    const uint32_t mc = P.mcount[sub];
+    if (sub0 >= P.nsub) return;
+    int32_t* stage = LD.stage;
+    uint32_t* s_res = LD.res;
+    uint4* s_quad = LD.quad;
+    // A wavefront places kPlacePer consecutive sub-tiles, one after the other; what it needs to know about a sub-tile before it can ask for
+    // its records (seven wave-uniform words) is requested while the sub-tile before it is placed: one of the sub-tile's three dependent
+    // round trips leaves the chain.
+    struct Sc { int64_t pb, tb, ord0; int np; uint32_t mc, hf; int gc; };
+    auto load_sc = [&](int64_t sub) -> Sc {
+        Sc c;
+        c.pb = P.pbase[sub]; c.tb = tile_base[sub]; c.ord0 = P.docord_base[sub]; c.np = P.pcount[sub]; c.mc = P.mcount[sub]; c.hf = P.heavy_flag[sub]; c.gc = P.giant_cnt[sub];
+        return c;
+    };
+    Sc nxt = load_sc(sub0);
+#pragma unroll 1
+    for (int it = 0; it < kPlacePer && sub0 + it < P.nsub; ++it) {
+    const int64_t sub = sub0 + it;
+    const Sc cur = nxt;
+    if (it + 1 < kPlacePer && sub + 1 < P.nsub) nxt = load_sc(sub + 1);
+    const int64_t pb = cur.pb, tb = cur.tb, base = sub * kSub, ord0 = cur.ord0;
+    const int np = cur.np;
+    const uint32_t mc = cur.mc;
     const int ns = (int)(mc & 0xFFFFu), nl = (int)(mc >> 16);
     const uint32_t* const ml = P.mlist + sub * (int64_t)P.mcap;
     const uint4* const mqd = P.mquad + sub * (int64_t)P.mcap;
     const int32_t* const dense = P.dense + (sub / kGroup) * kDenseCap;
-    const bool has_giant = (P.heavy_flag[sub] & 2u) != 0;
-    int gcnt = has_giant ? P.giant_cnt[sub] : 0;
+    const bool has_giant = (cur.hf & 2u) != 0;
+    int gcnt = has_giant ? cur.gc : 0;
     if (gcnt < 0) gcnt = 0;
     const bool lists_ok = ns + nl <= P.mcap;               // (cut lists: the batch is redone, nothing of this pass is used)
     {   // the answers of the merge kernels, in the same round trip as the first records
-        uint32_t a = 0, b = 0;
+        // lanes 0 .. kPlaceRes-1: the short list from the front; lanes kPlaceRes .. 2 kPlaceRes-1: the long list from the back
+        static_assert(2 * kPlaceRes <= 64, "one lane per kept entry");
+        uint32_t a = 0;
         uint4 qd; qd.x = qd.y = qd.z = qd.w = 0;
-        if (lists_ok && lane < ns) { a = tkz_load_nt(&ml[lane]); qd = tkz_load16_nt(&mqd[lane]); }
-        if (lists_ok && lane < nl && lane < 32) b = tkz_load_nt(&ml[P.mcap - 1 - lane]);
-        s_res[lane] = a; s_quad[lane] = qd;
-        if (lane < 32) s_res[64 + lane] = b;
+        const int e = lane < kPlaceRes ? lane : lane - kPlaceRes;
+        const bool want = lists_ok && lane < 2 * kPlaceRes && e < (lane < kPlaceRes ? ns : nl);
+        const int64_t at = lane < kPlaceRes ? e : P.mcap - 1 - e;
+        if (want) { a = tkz_load_nt(&ml[at]); qd = tkz_load16_nt(&mqd[at]); }
+        (void)simt::ballot(true);                                // (the sub-tile before this one is done with them)
+        if (lane < 2 * kPlaceRes) { s_res[lane] = a; s_quad[lane] = qd; }
     }
     (void)simt::ballot(true);
-    // where the tokens of a missed piece wait, and how many there are.  INLINE (a short piece of <= 4 tokens: nearly all of them): in the
-    // entry's quad, which for the first 64 entries is already in LDS -- *q4 gets it and the returned pointer is null
-    auto locate = [&](uint32_t rec, int* cnt, uint4* q4) -> const int32_t* {
-        if (rec & kPrGiant) { *cnt = gcnt; return P.tmp + base + (rec & 1023u); }
+    // the answer a merge kernel left for a missed piece (its list entry): how many tokens, and where they wait
+    auto answer = [&](uint32_t rec) -> uint32_t {
+        if (rec & kPrGiant) return tkz_result_entry(false, 1, (int)(rec & 1023u));     // (count: gcnt, see below; the tokens wait in tmp at the piece's position)
         const int idx = (int)(rec & 1023u);
         const bool lg = (rec & kPrLong) != 0;
-        uint32_t r = 0;
-        if (lists_ok) r = idx < (lg ? 32 : 64) ? s_res[(lg ? 64 : 0) + idx] : ml[lg ? P.mcap - 1 - idx : idx];
-        *cnt = tkz_result_cnt(r);
-        if (r & kMrInline) { *q4 = idx < 64 ? s_quad[idx] : tkz_load16(&mqd[idx]); return nullptr; }
-        return (r & kMrDense) ? dense + tkz_result_off(r) : P.tmp + base + tkz_result_off(r);
+        if (!lists_ok) return tkz_result_inline(1);
+        return idx < kPlaceRes ? s_res[(lg ? kPlaceRes : 0) + idx] : ml[lg ? P.mcap - 1 - idx : idx];
     };
+    // ... its tokens: INLINE (<= 4 tokens, nearly every missed piece: in the entry's quad, which for the first entries of both lists is
+    // already in LDS), else in the group's dense region or in tmp
+    auto inline_quad = [&](uint32_t rec) -> uint4 {
+        const int idx = (int)(rec & 1023u);
+        const bool lg = (rec & kPrLong) != 0;
+        if (!lists_ok) { uint4 z; z.x = z.y = z.z = z.w = 0; return z; }
+        return idx < kPlaceRes ? s_quad[(lg ? kPlaceRes : 0) + idx] : tkz_load16(&mqd[lg ? P.mcap - 1 - idx : idx]);
+    };
+    auto token_src = [&](uint32_t res) -> const int32_t* { return (res & kMrDense) ? dense + tkz_result_off(res) : P.tmp + base + tkz_result_off(res); };
     // stage[i] holds the id of token sbase + i of the sub-tile; sbase is chosen so that stage[0] sits on a 16-byte boundary of `out`
     const uintptr_t out_addr = reinterpret_cast<uintptr_t>(out);
     auto quad_base = [&](int tok) -> int { return tok - (int)(((out_addr >> 2) + (uintptr_t)(tb + tok)) & 3u); };
@@ -1238,68 +1353,63 @@ TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, in
           const int k = kk + 64 * j + lane;
           r4[j] = (k < np && pb + k < P.prank_cap) ? (uint32_t)tkz_load_nt(&P.prank[pb + k]) : 0u;
       }
-      // the first four tokens of every missed piece of the four chunks: all those gathers in flight together, before any store
-      int32_t t4[4][4];
-      int c4[4];
-      const int32_t* src4[4];
+      uint32_t a4[4];                                        // the merge kernels' answers for the missed pieces of the four chunks
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-          const uint32_t rec = r4[j];
-          const bool ld = (rec & kPrMiss) != 0;
-          c4[j] = 1; src4[j] = nullptr;
-          uint4 q4; q4.x = q4.y = q4.z = q4.w = 0;
-          if (ld) src4[j] = locate(rec, &c4[j], &q4);
-          t4[j][0] = (int32_t)q4.x; t4[j][1] = (int32_t)q4.y; t4[j][2] = (int32_t)q4.z; t4[j][3] = (int32_t)q4.w;
-          if (src4[j]) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) t4[j][i] = i < c4[j] ? src4[j][i] : 0;
-          }
-      }
+      for (int j = 0; j < 4; ++j) a4[j] = (r4[j] & kPrMiss) ? answer(r4[j]) : 0u;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k0 = kk + 64 * j;
         if (k0 >= np) break;
         const int k = k0 + lane;
         const bool valid = k < np && pb + k < P.prank_cap;
-        const uint32_t rec = r4[j];
+        const uint32_t rec = r4[j], res = a4[j];
         const bool miss = (rec & kPrMiss) != 0;
-        const int cnt = !valid ? 0 : !miss ? 1 : c4[j];
+        const int cnt = !valid ? 0 : !miss ? 1 : (rec & kPrGiant) ? gcnt : tkz_result_cnt(res);
         int tot;
         const int pos = running + tkz_wave_scan_sum(cnt, &tot);
         const uint64_t mm = simt::ballot(valid && (rec & kPrMark));
         if (valid && (rec & kPrMark)) P.doc_tok[ord0 + marks + tkz_popc64(mm & tkz_lowmask(lane))] = pos;
-        const uint64_t big = simt::ballot(valid && miss && cnt > 16);
+        const uint64_t big = simt::ballot(valid && miss && cnt > kPlaceBig);
         if (!big) {
             if (running + tot - sbase > kStage) flush(running);
             if (valid) {
                 int32_t* dst = stage + (pos - sbase);
                 if (!miss) dst[0] = (int32_t)(rec & kPrRankMask);
-                else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (i < cnt) dst[i] = t4[j][i];
-                    for (int i = 4; i < cnt; ++i) dst[i] = src4[j][i];
+                else if (res & kMrInline) {
+                    const uint4 q = inline_quad(rec);
+                    dst[0] = (int32_t)q.x;
+                    if (cnt > 1) dst[1] = (int32_t)q.y;
+                    if (cnt > 2) dst[2] = (int32_t)q.z;
+                    if (cnt > 3) dst[3] = (int32_t)q.w;
+                } else {
+                    const int32_t* src = token_src(res);
+                    for (int i = 0; i < cnt; ++i) dst[i] = src[i];
                 }
             }
         } else {
             // a long token run (a merged piece of many bytes, a giant piece) in this batch of 64 records: what is staged goes out, then
             // this batch's ids go straight to their positions, the long runs copied by the whole wavefront, one after the other
             flush(running);
+            const int32_t* src = (miss && !(res & kMrInline)) ? token_src(res) : nullptr;
             if (valid) {
                 int32_t* dst = out + tb + pos;
                 if (!miss) { if (tb + pos < out_cap) tkz_store_nt(&dst[0], (int32_t)(rec & kPrRankMask)); }
-                else if (cnt <= 16) {
+                else if (res & kMrInline) {
+                    const uint4 q = inline_quad(rec);
+                    const int32_t w[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (i < cnt && tb + pos + i < out_cap) dst[i] = t4[j][i];
-                    for (int i = 4; i < cnt; ++i) if (tb + pos + i < out_cap) dst[i] = src4[j][i];
+                    for (int i = 0; i < 4; ++i) if (i < cnt && tb + pos + i < out_cap) dst[i] = w[i];
+                } else if (cnt <= kPlaceBig) {
+                    for (int i = 0; i < cnt; ++i) if (tb + pos + i < out_cap) dst[i] = src[i];
                 }
             }
             for (uint64_t bg = big; bg; bg &= bg - 1) {
                 const int src_lane = tkz_ctz64(bg);
                 const int c = simt::shfl(cnt, src_lane), p0 = simt::shfl(pos, src_lane);
-                const uint32_t lo32 = simt::shflu((uint32_t)(reinterpret_cast<uintptr_t>(src4[j])), src_lane), hi32 = simt::shflu((uint32_t)(reinterpret_cast<uintptr_t>(src4[j]) >> 32), src_lane);
-                const int32_t* src = reinterpret_cast<const int32_t*>(((uintptr_t)hi32 << 32) | lo32);
+                const uint32_t lo32 = simt::shflu((uint32_t)(reinterpret_cast<uintptr_t>(src)), src_lane), hi32 = simt::shflu((uint32_t)(reinterpret_cast<uintptr_t>(src) >> 32), src_lane);
+                const int32_t* bsrc = reinterpret_cast<const int32_t*>(((uintptr_t)hi32 << 32) | lo32);
                 int32_t* dst = out + tb + p0;
-                for (int i = lane; i < c; i += 64) if (tb + p0 + i < out_cap) dst[i] = src[i];
+                for (int i = lane; i < c; i += 64) if (tb + p0 + i < out_cap) dst[i] = bsrc[i];
             }
             flushed = running + tot; sbase = quad_base(flushed);
         }
@@ -1308,6 +1418,12 @@ TKZ_KERNEL_OCC(256, 7) void k_place(EncodeParams P, const int64_t* tile_base, in
       }
     }
     if (flushed < running) flush(running);
+    }
+}
+TKZ_KERNEL_OCC(256, TKZ_PLACE_OCC) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
+    TKZ_SHARED uint4 s_wave[kThreads / 64][kPlaceLdsQuads];
+    const int64_t sub0 = (tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave()) * kPlacePer;
+    tkz_place_subtiles(P, tile_base, out, out_cap, sub0, tkz_place_lds(s_wave[simt::wave()]));
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1843,7 +1959,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
 }
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
     hook(L, K_GATHER, 0);
-    TKZ_LAUNCH(k_place, xcd_grid(cdiv(nsub, kThreads / 64)), kThreads, L.stream, P, tile_base, out, out_cap);
+    TKZ_LAUNCH(k_place, xcd_grid(cdiv(nsub, (kThreads / 64) * kPlacePer)), kThreads, L.stream, P, tile_base, out, out_cap);
     hook(L, K_GATHER, 1);
 }
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt) {

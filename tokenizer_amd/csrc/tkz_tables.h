@@ -192,6 +192,15 @@ TKZ_HD int32_t tkz_match_short2(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t 
     if (tkz_short_slot_is(a1, k0, k1, k2, len)) return (int32_t)(a1.w & TKZ_SHORT_RANK_MASK);
     return TKZ_RANK_NONE;
 }
+// the same, without branches (k_probe runs it for every piece of the corpus): a slot matches iff the OR of the differences is zero.  A
+// length outside 1..12 matches nothing (an empty slot has length 0, but its key dwords are zero too: callers pass a zero key only with len 0...
+// so len == 0 is excluded explicitly).
+TKZ_HD int32_t tkz_match_short2x(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint4 a0, uint4 a1) {
+    const uint32_t d0 = (a0.x ^ k0) | (a0.y ^ k1) | (a0.z ^ k2) | ((a0.w >> TKZ_SHORT_RANK_BITS) ^ len);
+    const uint32_t d1 = (a1.x ^ k0) | (a1.y ^ k1) | (a1.z ^ k2) | ((a1.w >> TKZ_SHORT_RANK_BITS) ^ len);
+    const uint32_t r = d0 == 0 ? a0.w : a1.w;
+    return ((d0 == 0 || d1 == 0) && len != 0) ? (int32_t)(r & TKZ_SHORT_RANK_MASK) : TKZ_RANK_NONE;
+}
 TKZ_HD int32_t tkz_lookup_short(const TkzTables& T, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len) {
     uint32_t s1, s2;
     tkz_short_slots(T, k0, k1, k2, len, &s1, &s2);

@@ -35,4 +35,5 @@ for l in open(sys.argv[1]):
         d=json.loads(l); print(d["config"]["pattern"][:6], d["config"]["workload"][:40], d["value"], d.get("value_no_memo"), d["ms_per_step"], d["roofline"]["kernels_ms"])
 P
 fi
+if has latency; then timeout 300 python tools/latency_probe.py > $O/latency.json 2> $O/latency.err; echo "latency rc=$?"; cat $O/latency.json; fi
 if has fuzz; then timeout 200 python tools/gpu_fuzz.py 60 > $O/fuzz.log 2>&1; echo "fuzz rc=$?"; tail -2 $O/fuzz.log; fi

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Single-call latency of the drop-in path (BASELINE.json configs[0]'s shape): ITokenizer.Encode(text) on one short prompt and
+EncodeBatch on 1,000 prompts of 16..128 bytes, through the C ABI on host buffers (tkz_encode_utf8 / tkz_encode_batch_utf8:
+upload, kernels, download, one call at a time), beside the CPU restatement of the reference (oracle/, one thread) on the same calls.
+Prints one JSON line.  usage: python tools/latency_probe.py [--reps 200]"""
+import argparse
+import gzip
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--vocab", default="gpt2")
+    ap.add_argument("--pattern", type=int, default=1)
+    args = ap.parse_args()
+    import numpy as np
+    from tokenizer_amd import _native as N
+    from oracle import oracle as O
+    raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", args.vocab + ".tiktoken.gz"), "rb").read())
+    enc = N.Encoder(N.Vocab(raw), args.pattern, device=0)
+    ov = O.Vocab(raw)
+    oenc = O.Encoder(ov, args.pattern)
+    prompts = [N.corpus_doc_host(1, 0x5EED0001, d, 16, 128) for d in range(1000)]
+    one = b"Hello World, this is a short prompt of sixty-four bytes, more or"[:64]
+    data = np.frombuffer(b"".join(prompts), np.uint8)
+    offs = np.cumsum([0] + [len(p) for p in prompts]).astype(np.int64)
+
+    def med_us(fn, reps):
+        fn(); fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e6)
+        return round(statistics.median(ts), 1), round(min(ts), 1)
+    assert enc.encode_utf8(one) == oenc.encode_bytes(one)
+    ids, ooff = enc.encode_batch(data, offs)
+    exp = []
+    for p in prompts:
+        exp += oenc.encode_bytes(p)
+    assert ids.tolist() == exp
+    out = {"what": "single-call latency through the C ABI on host buffers, microseconds per call (median, min)",
+           "vocab": args.vocab, "pattern": args.pattern, "reps": args.reps,
+           "encode_one_64B_prompt_us": med_us(lambda: enc.encode_utf8(one), args.reps),
+           "encode_batch_1000_prompts_us": med_us(lambda: enc.encode_batch(data, offs), max(20, args.reps // 4)),
+           "batch_bytes": int(len(data)),
+           "oracle_1_thread_one_prompt_us": med_us(lambda: oenc.encode_bytes(one), args.reps),
+           "oracle_1_thread_1000_prompts_us": med_us(lambda: [oenc.encode_bytes(p) for p in prompts], 10)}
+    if hasattr(enc, "last_launches"):
+        out["launches_last_call"] = enc.last_launches()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
