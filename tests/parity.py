@@ -447,6 +447,66 @@ def check_memo_contention(lib, O, vocab, ovocab, candidates=400_000, threads=2, 
     assert not errors, errors
 
 
+def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
+    """The single-launch path for small batches (k_small: at most 8 KiB in at most 2048 documents of at most 1 KiB): same ids as the
+    oracle on single prompts and small batches of all three patterns; the calls that must be handed back to the batch path (a giant
+    piece, malformed text, more misses than the lists hold) still give the batch path's answer; larger batches do not take it."""
+    rng = random.Random(seed)
+    alpha = RC.alphabet()
+    for pattern in (N.P1, N.CL100K, N.O200K):
+        enc = N.Encoder(vocab, pattern)
+        oenc = O.Encoder(ovocab, pattern)
+        for it in range(rounds):
+            kind = rng.choice(["mix", "ws", "oth", "dig", "apo", "case", "a_mix", "a_brk", "a_ws", "a_dig"])
+            nd = rng.choice([1, 1, 1, 2, 7, 60, 400])
+            docs = [gen_text(rng, kind, rng.choice([0, 1, 5, 20, 64, 100, 300, 1000]) if nd < 100 else rng.randint(0, 18), alpha).encode("utf-8")[:1024] for _ in range(nd)]
+            docs = [d.decode("utf-8", "ignore").encode("utf-8") for d in docs]           # (the cut may have split a char)
+            while sum(map(len, docs)) > 8192:
+                docs.pop()
+            if not sum(map(len, docs)):
+                continue
+            before = enc.small_path_calls()
+            data, offs = pack(docs)
+            ids, ooff = enc.encode_batch(data, offs)
+            exp, eoff = oracle_encode_docs(oenc, docs)
+            assert ids.tolist() == exp and ooff.tolist() == eoff, (pattern, it, kind, nd)
+            after = enc.small_path_calls()
+            assert after[0] == before[0] + 1, "a batch of %d bytes in %d documents must take the single-launch path" % (len(data), len(docs))
+        # single strings through both single-string entries
+        for text in ("Hello World", "Hello World, this is a short prompt of sixty-four bytes, more or", "⭐ naïve café 漢字かな 😀👍🏽 it's 12345\n\n  x", "a", " ", "\n"):
+            b = text.encode("utf-8")
+            assert enc.encode_utf8(b) == oenc.encode_bytes(b)
+            assert enc.encode_utf16(np.frombuffer(text.encode("utf-16-le"), np.uint16).tolist()) == oenc.encode_bytes(b)
+        calls, back = enc.small_path_calls()
+        assert calls > rounds // 2 and back <= calls // 4, (calls, back)      # (a document full of missed pieces outgrows a fresh encoder's lists once)
+        # handed back: a piece of more than 1024 bytes inside a small batch ...
+        docs = [b"q" * 1024, b"hello world"]                 # (1024 letters: one piece as long as a document of this path can be)
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        exp, eoff = oracle_encode_docs(oenc, docs)
+        assert ids.tolist() == exp and ooff.tolist() == eoff
+        # ... more misses than a fresh encoder's lists hold (the batch path grows them; later small calls fit)
+        cons = "bcdfghjklmnpqrstvwxz"
+        gdocs = ["".join(" " + rng.choice(cons) + rng.choice(cons) for _ in range(300)).encode() for _ in range(3)]
+        gdata, goffs = pack(gdocs)
+        gexp, geoff = oracle_encode_docs(oenc, gdocs)
+        fresh = N.Encoder(vocab, pattern)
+        for rep in range(2):
+            ids, ooff = fresh.encode_batch(gdata, goffs)
+            assert ids.tolist() == gexp and ooff.tolist() == geoff
+        assert fresh.small_path_calls() == (2, 1), fresh.small_path_calls()        # handed back once; the lists have grown, the second call fits
+        # malformed text and a document boundary inside a char: the same errors as the batch path
+        import pytest
+        with pytest.raises(N.TkzError) as ei:
+            enc.encode_utf8(b"abc\xff")
+        assert ei.value.code == N.E_INVALID_UTF8
+        # too large for the single launch: the batch path, untouched counters
+        big = ("lorem ipsum dolor sit amet " * 400).encode()
+        c0 = enc.small_path_calls()
+        assert enc.encode_utf8(big) == oenc.encode_bytes(big)
+        assert enc.small_path_calls() == c0
+
+
 def check_errors(lib, O, vocab):
     enc = N.Encoder(vocab, N.CL100K)
     import pytest

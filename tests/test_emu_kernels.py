@@ -129,6 +129,13 @@ def test_miss_lists(lib, vocabs, oracle_mod):
     parity.check_miss_lists(lib, oracle_mod, v, ov, pattern=N.O200K, seed=42)
 
 
+def test_small_batches_take_one_launch(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_small_path(lib, oracle_mod, v, ov, rounds=12)
+    v, ov = vocabs("synth100k")
+    parity.check_small_path(lib, oracle_mod, v, ov, seed=54, rounds=6)
+
+
 def test_memo_zero_bytes_and_contention(lib, vocabs, oracle_mod):
     v, ov = vocabs("gpt2")
     parity.check_memo_zero_bytes(lib, oracle_mod, v, ov)

@@ -137,6 +137,13 @@ def test_miss_lists(lib, vocabs, oracle_mod):
         parity.check_miss_lists(lib, oracle_mod, v, ov, pattern=pat, seed=seed)
 
 
+def test_small_batches_take_one_launch(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_small_path(lib, oracle_mod, v, ov, rounds=60)
+    v, ov = vocabs("synth100k")
+    parity.check_small_path(lib, oracle_mod, v, ov, seed=54, rounds=30)
+
+
 def test_memo_zero_bytes_and_contention(lib, vocabs, oracle_mod):
     """The piece memo under concurrent readers and writers of ONE bucket (two host threads = two streams on one encoder), with NUL-run
     pieces of the contenders' lengths in the same batches; and the rule that pieces holding a zero byte bypass the memo."""

@@ -78,6 +78,9 @@ class Library:
         L.tkz_encoder_memo_slots.argtypes = [vp]
         L.tkz_encoder_memo_slots.restype = i64
         L.tkz_encoder_memo_ways.argtypes = [vp]
+        L.tkz_encoder_small_path_calls.argtypes = [vp, pi64, pi64]
+        L.tkz_encoder_small_path_calls.restype = None
+        L.tkz_encoder_small_path_phases.argtypes = [vp, vp]
         L.tkz_encoder_memo_bucket.argtypes = [vp, vp, i32]
         L.tkz_encoder_memo_bucket.restype = i64
         L.tkz_unicode_classes.argtypes = [C.c_uint32, C.c_int32, vp]
@@ -233,6 +236,18 @@ class Encoder:
     def memo_bucket(self, piece: bytes):
         """Bucket of the piece memo a piece of 1..16 bytes uses (-1: none; pieces holding a zero byte never use the memo)."""
         return int(self.lib.L.tkz_encoder_memo_bucket(self._h, piece, len(piece)))
+
+    def small_path_calls(self):
+        """(calls that took the single-launch path for small batches, how many of those it handed back to the batch path)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.lib.L.tkz_encoder_small_path_calls(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def small_path_phases(self):
+        """Shader-clock stamps at the end of the phases of the last single-launch kernel (development)."""
+        a = np.zeros(16, np.int64)
+        n = self.lib.L.tkz_encoder_small_path_phases(self._h, a.ctypes.data)
+        return a[:n].tolist()
 
     def pretok_leftovers(self):
         """(blocks the o200k ASCII block scanner handed on, blocks the multi-byte block scanner handed on to the sequential matcher) of the last batch."""

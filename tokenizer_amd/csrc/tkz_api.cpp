@@ -101,6 +101,10 @@ struct Workspace {
     // piece-granular entry point: piece byte offsets, token offsets, first piece of every document
     DevBuf p_boffs, p_toffs, p_docp;
     CounterBlock* h_counters = nullptr;   // pinned
+    // the single-launch path for small batches (k_small): input, output and status in ONE page-locked block the device reads and writes directly
+    uint8_t* h_small = nullptr;
+    hipStream_t st_small = nullptr;        // (non-blocking: a small call never waits for another thread's batch on the legacy default stream)
+    int64_t small_calls = 0, small_fallbacks = 0;
     hipStream_t st_compute = nullptr, st_in = nullptr, st_out = nullptr;   // the host-buffer entry points: kernels / uploads / downloads
     hipEvent_t ev_in[2] = {}, ev_done[2] = {}, ev_out[2] = {};
     int64_t bytes_allocated = 0;
@@ -117,6 +121,8 @@ struct Workspace {
                           &d_grp, &d_tsum, &d_tbase, &d_bsum, &d_counters, &d_ids, &d_idoffs, &d_out, &d_outoffs, &p_boffs, &p_toffs, &p_docp};
         for (DevBuf* b : bufs) b->release();
         if (h_counters) (void)hipHostFree(h_counters);
+        if (h_small) (void)hipHostFree(h_small);
+        if (st_small) (void)hipStreamDestroy(st_small);
         for (int k = 0; k < tkz::K_COUNT; ++k) for (int q = 0; q < 2; ++q) if (ev[k][q]) (void)hipEventDestroy(ev[k][q]);
         for (int q = 0; q < 2; ++q) { if (ev_in[q]) (void)hipEventDestroy(ev_in[q]); if (ev_done[q]) (void)hipEventDestroy(ev_done[q]); if (ev_out[q]) (void)hipEventDestroy(ev_out[q]); }
         if (st_compute) (void)hipStreamDestroy(st_compute);
@@ -233,6 +239,43 @@ tkz_status build_decode_table(tkz_encoder* e) {
     return TKZ_OK;
 }
 
+// workspace of one batch of `total` bytes / n_docs documents (grow-only buffers: nothing happens once they are large enough)
+tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool bitmap_only, bool pieces) {
+    using namespace tkz;
+    const int64_t nwords = total / 64 + 1;
+    const int64_t ntiles = (total + kSub - 1) / kSub;
+    const int64_t nblk = (ntiles + kScanBlock - 1) / kScanBlock;
+    int64_t* acc = &ws->bytes_allocated;
+    HIP_TRY(ws->w_docbits.ensure((size_t)(nwords + 8) * 8, acc));
+    HIP_TRY(ws->w_startbits.ensure((size_t)(nwords + 8) * 8, acc));
+    HIP_TRY(ws->w_counters.ensure(sizeof(CounterBlock), acc));
+    if (!bitmap_only) {
+        HIP_TRY(ws->w_tmp.ensure((size_t)(total + 64) * 4, acc));
+        HIP_TRY(ws->w_dense.ensure((size_t)(ntiles / kMergeGroup + 1) * kDenseCap * 4, acc));
+        HIP_TRY(ws->w_tcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(ws->w_pcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(ws->w_pbase.ensure((size_t)ntiles * 8, acc));
+        // one 4-byte record per piece.  The number of pieces is known only after the pre-tokenizer has run (English/code text: a
+        // piece per ~4.5 bytes; the bound is a piece per byte): the buffer starts at a piece per 3 bytes, k_probe refuses to write
+        // past it, and the batch is redone once with the exact size if that was not enough
+        // (+ 8 per sub-tile on average: every sub-tile's records start on a 64-byte line of their own)
+        HIP_TRY(ws->w_prank.ensure((size_t)(total / 3 + 8 * ntiles + 4096) * 4, acc));
+        HIP_TRY(ws->w_mlist.ensure((size_t)ntiles * (size_t)ws->mcap * 4, acc));
+        HIP_TRY(ws->w_mquad.ensure((size_t)ntiles * (size_t)ws->mcap * 16, acc));
+        HIP_TRY(ws->w_mcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(ws->w_tbase.ensure((size_t)(ntiles + 1) * 8, acc));
+        HIP_TRY(ws->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
+        HIP_TRY(ws->w_doctok.ensure((size_t)((pieces ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
+        HIP_TRY(ws->w_dcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(ws->w_dbase.ensure((size_t)ntiles * 8, acc));
+        HIP_TRY(ws->w_heavyq.ensure((size_t)ntiles + 64, acc));
+        HIP_TRY(ws->w_gq.ensure((size_t)(total / kArenaPiece + 2) * 24, acc));     // {position, length} per giant piece + the order they are taken in
+        HIP_TRY(ws->w_gcnt.ensure((size_t)ntiles * 4, acc));
+        if (!ws->w_pool.p) HIP_TRY(ws->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
+    }
+    return TKZ_OK;
+}
+
 // where the piece-granular entry point wants its arrays (all on the device)
 struct PiecesOut { int64_t* piece_boffs; int64_t* piece_toffs; int64_t* doc_piece; int64_t piece_cap; int64_t n_pieces; };
 
@@ -253,35 +296,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         return TKZ_OK;
     }
     const int64_t ntiles = (total + kSub - 1) / kSub;       // sub-tiles: one wavefront each
-    const int64_t nblk = (ntiles + kScanBlock - 1) / kScanBlock;
+    { const tkz_status ps = prepare_workspace(ws, total, n_docs, d_bitmap_only != nullptr, po != nullptr); if (ps != TKZ_OK) return ps; }
     int64_t* acc = &ws->bytes_allocated;
-    HIP_TRY(ws->w_docbits.ensure((size_t)(nwords + 8) * 8, acc));
-    HIP_TRY(ws->w_startbits.ensure((size_t)(nwords + 8) * 8, acc));
-    HIP_TRY(ws->w_counters.ensure(sizeof(CounterBlock), acc));
-    if (!d_bitmap_only) {
-        HIP_TRY(ws->w_tmp.ensure((size_t)(total + 64) * 4, acc));
-        HIP_TRY(ws->w_dense.ensure((size_t)(ntiles / kMergeGroup + 1) * kDenseCap * 4, acc));
-        HIP_TRY(ws->w_tcount.ensure((size_t)ntiles * 4, acc));
-        HIP_TRY(ws->w_pcount.ensure((size_t)ntiles * 4, acc));
-        HIP_TRY(ws->w_pbase.ensure((size_t)ntiles * 8, acc));
-        // one 4-byte record per piece.  The number of pieces is known only after the pre-tokenizer has run (English/code text: a
-        // piece per ~4.5 bytes; the bound is a piece per byte): the buffer starts at a piece per 3 bytes, k_probe refuses to write
-        // past it, and the batch is redone once with the exact size if that was not enough
-        // (+ 8 per sub-tile on average: every sub-tile's records start on a 64-byte line of their own)
-        HIP_TRY(ws->w_prank.ensure((size_t)(total / 3 + 8 * ntiles + 4096) * 4, acc));
-        HIP_TRY(ws->w_mlist.ensure((size_t)ntiles * (size_t)ws->mcap * 4, acc));
-        HIP_TRY(ws->w_mquad.ensure((size_t)ntiles * (size_t)ws->mcap * 16, acc));
-        HIP_TRY(ws->w_mcount.ensure((size_t)ntiles * 4, acc));
-        HIP_TRY(ws->w_tbase.ensure((size_t)ntiles * 8, acc));
-        HIP_TRY(ws->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
-        HIP_TRY(ws->w_doctok.ensure((size_t)((po ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
-        HIP_TRY(ws->w_dcount.ensure((size_t)ntiles * 4, acc));
-        HIP_TRY(ws->w_dbase.ensure((size_t)ntiles * 8, acc));
-        HIP_TRY(ws->w_heavyq.ensure((size_t)ntiles + 64, acc));
-        HIP_TRY(ws->w_gq.ensure((size_t)(total / kArenaPiece + 2) * 24, acc));     // {position, length} per giant piece + the order they are taken in
-        HIP_TRY(ws->w_gcnt.ensure((size_t)ntiles * 4, acc));
-        if (!ws->w_pool.p) HIP_TRY(ws->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
-    }
     if (!ws->h_counters) HIP_TRY(hipHostMalloc((void**)&ws->h_counters, sizeof(CounterBlock), 0));
 
     for (int attempt = 0; attempt < 5; ++attempt) {
@@ -418,6 +434,71 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
     return fail(TKZ_E_DEVICE, "unreachable");
 }
 
+// ---- the single-launch path (k_small) --------------------------------------------------------------------------------------------------
+// ITokenizer.Encode(text) on a prompt is microseconds in the reference (TikTokenizer.cs:178-207); the batch path above costs ~25 kernel
+// launches, four copy commands and two synchronisations whatever the size: ~160 us for 64 bytes.  A batch of at most kSmallMaxBytes bytes
+// in at most kSmallMaxDocs documents of at most kSmallMaxDoc bytes each goes through ONE launch instead: the caller's bytes and offsets
+// are memcpy'd into a page-locked block, k_small (one workgroup, all phases) reads them from there and writes ids, offsets and status
+// back into it, one stream synchronisation, memcpy out.  Returns TKZ_OK with *handled = false when the kernel hands the batch back (a
+// piece of more than 1024 bytes, an error to be diagnosed, lists or buffers to be grown): the caller then takes the batch path.
+constexpr size_t kSmallOffBytes = 0, kSmallOffOffs = tkz::kSmallMaxBytes + 64, kSmallOffIds = kSmallOffOffs + (tkz::kSmallMaxDocs + 1) * 8,
+                 kSmallOffOut = kSmallOffIds + tkz::kSmallMaxBytes * 4, kSmallOffRes = kSmallOffOut + (tkz::kSmallMaxDocs + 1) * 8, kSmallBlock = kSmallOffRes + 256;
+bool small_eligible(const tkz_encoder* e, const int64_t* offs, int64_t n_docs, int64_t total) {
+    if (e->profiling || e->pretok_seq || total <= 0 || total > tkz::kSmallMaxBytes || n_docs < 1 || n_docs > tkz::kSmallMaxDocs) return false;
+    for (int64_t d = 0; d < n_docs; ++d) { const int64_t len = offs[d + 1] - offs[d]; if (len < 0 || len > tkz::kSmallMaxDoc) return false; }
+    return true;
+}
+tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, const int64_t* offs, int64_t n_docs, int64_t total,
+                        int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed, bool* handled) {
+    using namespace tkz;
+    *handled = false;
+    { const tkz_status ps = prepare_workspace(ws, total, n_docs, false, false); if (ps != TKZ_OK) return ps; }
+    int64_t* acc = &ws->bytes_allocated;
+    HIP_TRY(ws->s_bytes[0].ensure((size_t)kSmallMaxBytes + 64, acc));
+    HIP_TRY(ws->s_offs[0].ensure((size_t)(kSmallMaxDocs + 1) * 8, acc));
+    if (!ws->h_small) HIP_TRY(hipHostMalloc((void**)&ws->h_small, kSmallBlock, 0));
+    if (!ws->st_small) HIP_TRY(hipStreamCreateWithFlags(&ws->st_small, hipStreamNonBlocking));
+    uint8_t* H = ws->h_small;
+    memcpy(H + kSmallOffBytes, bytes, (size_t)total);
+    memcpy(H + kSmallOffOffs, offs, (size_t)(n_docs + 1) * 8);
+    int64_t* h_res = reinterpret_cast<int64_t*>(H + kSmallOffRes);
+    h_res[0] = -1; h_res[1] = 0; h_res[2] = 0;
+    const int64_t ntiles = (total + kSub - 1) / kSub;
+    EncodeParams P{};
+    P.bytes = ws->s_bytes[0].as<uint8_t>(); P.total = total; P.startbits = ws->w_startbits.as<uint64_t>(); P.docbits = ws->w_docbits.as<uint64_t>(); P.nwords = total / 64 + 1;
+    P.offs = ws->s_offs[0].as<int64_t>(); P.n_docs = n_docs;
+    P.tmp = ws->w_tmp.as<int32_t>(); P.dense = ws->w_dense.as<int32_t>(); P.tile_count = ws->w_tcount.as<int32_t>();
+    P.prank = ws->w_prank.as<int32_t>(); P.prank_cap = (int64_t)(ws->w_prank.cap / 4); P.pcount = ws->w_pcount.as<int32_t>(); P.pbase = ws->w_pbase.as<int64_t>();
+    P.mlist = ws->w_mlist.as<uint32_t>(); P.mquad = ws->w_mquad.as<uint4>(); P.mcap = ws->mcap; P.mcount = ws->w_mcount.as<uint32_t>();
+    P.docord_base = ws->w_dbase.as<int64_t>(); P.doc_tok = ws->w_doctok.as<int32_t>(); P.counters = ws->w_counters.as<int32_t>();
+    P.giant_q = ws->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = ws->w_gcnt.as<int32_t>();
+    P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
+    P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
+    P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
+    P.pool = ws->w_pool.as<int32_t>(); P.pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head)); P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
+    P.ablate = 0; P.devprof = nullptr;
+    SmallArgs A{};
+    A.h_bytes = H + kSmallOffBytes; A.h_offs = reinterpret_cast<const int64_t*>(H + kSmallOffOffs);
+    A.out = reinterpret_cast<int32_t*>(H + kSmallOffIds); A.out_cap = std::min<int64_t>(out_cap, kSmallMaxBytes); A.out_offs = reinterpret_cast<int64_t*>(H + kSmallOffOut);
+    A.h_result = h_res;
+    A.docbits = ws->w_docbits.as<uint64_t>(); A.startbits = ws->w_startbits.as<uint64_t>();
+    A.pcount = ws->w_pcount.as<int32_t>(); A.pbase = ws->w_pbase.as<int64_t>(); A.docord_base = ws->w_dbase.as<int64_t>(); A.tile_base = ws->w_tbase.as<int64_t>();
+    A.counter_words = (int32_t)(sizeof(CounterBlock) / 4);
+    Launch L{ws->st_small, nullptr, ws};
+    launch_small(L, e->T, P, A);
+    HIP_TRY(hipStreamSynchronize(ws->st_small));
+    HIP_TRY(hipGetLastError());
+    ++ws->small_calls;
+    if (h_res[0] != 0) { ++ws->small_fallbacks; return TKZ_OK; }          // (handled stays false)
+    const int64_t tokens = h_res[2];
+    if (needed) *needed = tokens;
+    *handled = true;
+    if (tokens > out_cap) return fail(TKZ_E_CAPACITY, "output capacity too small");
+    if (tokens) memcpy(out_ids, H + kSmallOffIds, (size_t)tokens * 4);
+    memcpy(out_offsets, H + kSmallOffOut, (size_t)(n_docs + 1) * 8);
+    return TKZ_OK;
+}
+
 tkz_status check_encoder(tkz_encoder* e, DeviceScope& scope) {
     if (!e) return fail(TKZ_E_ARG, "null encoder");
     hipError_t r = scope.enter(e->device);
@@ -466,6 +547,11 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const int64_t* offs
         if (cut[(size_t)k] < cut[(size_t)k - 1] || offs[cut[(size_t)k]] < offs[cut[(size_t)k - 1]]) { nchunks = 1; break; }
     }
     if (nchunks == 1) { cut.assign(2, 0); cut[1] = n_docs; }
+    if (nchunks == 1 && pretok && !bitmap && small_eligible(e, offs, n_docs, total)) {
+        bool handled = false;
+        st = encode_small(e, ws, bytes, offs, n_docs, total, out_ids, out_cap, out_offsets, needed, &handled);
+        if (st != TKZ_OK || handled) return st;
+    }
     if (nchunks == 1) {
         HIP_TRY(ws->s_bytes[0].ensure((size_t)total + 64, acc));
         HIP_TRY(ws->s_offs[0].ensure((size_t)(n_docs + 1) * 8, acc));
@@ -995,6 +1081,19 @@ void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_sca
     if (after_multibyte_scanner) *after_multibyte_scanner = e ? e->last_xcount2.load() : 0;
 }
 int64_t tkz_encoder_memo_slots(const tkz_encoder* e) { return e ? (int64_t)e->memo_slots : 0; }
+void tkz_encoder_small_path_calls(const tkz_encoder* e, int64_t* calls, int64_t* handed_back) {
+    int64_t c = 0, f = 0;
+    if (e) { tkz_encoder* m = const_cast<tkz_encoder*>(e); std::lock_guard<std::mutex> lock(m->mu); for (Workspace* w : e->pool) { c += w->small_calls; f += w->small_fallbacks; } }
+    if (calls) *calls = c;
+    if (handed_back) *handed_back = f;
+}
+int32_t tkz_encoder_small_path_phases(const tkz_encoder* e, int64_t* clocks16) {       // shader-clock stamps of the last k_small of the first workspace
+    if (!e || !clocks16) return 0;
+    tkz_encoder* m = const_cast<tkz_encoder*>(e);
+    std::lock_guard<std::mutex> lock(m->mu);
+    for (Workspace* w : e->pool) if (w->h_small) { memcpy(clocks16, w->h_small + kSmallOffRes + 32, 16 * 8); return 16; }
+    return 0;
+}
 int32_t tkz_encoder_memo_ways(const tkz_encoder* e) { return e ? (int32_t)kMemoWays : 0; }
 int64_t tkz_encoder_memo_bucket(const tkz_encoder* e, const uint8_t* piece, int32_t len) {
     if (!e || !piece || len < 1 || len > 16 || !e->memo_slots) return -1;

@@ -62,6 +62,17 @@ struct EncodeParams {
     int32_t ablate;
 };
 
+// k_small: one launch for a small batch (tkz_kernels.hip).  Input and output live in page-locked host memory the device reads and writes directly.
+constexpr int kSmallMaxBytes = 8192, kSmallMaxDocs = 2048, kSmallMaxDoc = 1024;
+struct SmallArgs {
+    const uint8_t* h_bytes; const int64_t* h_offs;          // the batch, in page-locked host memory (h_bytes kSmallMaxBytes + 64 long)
+    int32_t* out; int64_t out_cap; int64_t* out_offs;       // ids and document offsets, page-locked host memory
+    int64_t* h_result;                                      // [0] status (0 done, 1 take the batch path), [1] error bits, [2] token count
+    uint64_t* docbits; uint64_t* startbits;                 // the workspace arrays EncodeParams holds as const, writable
+    int32_t* pcount; int64_t* pbase; int64_t* docord_base; int64_t* tile_base;
+    int32_t counter_words;                                  // 32-bit words of the counter block to zero
+};
+
 typedef void (*KernelHook)(void* ctx, int kernel_id, int phase /*0 before, 1 after*/, hipStream_t s);
 struct Launch { hipStream_t stream; KernelHook hook; void* hook_ctx; };
 
@@ -73,6 +84,7 @@ void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, co
 void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                        uint64_t* startbits, const uint8_t* bmp, int32_t* counters);
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub);
+void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, const SmallArgs& A);
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt);
 // exclusive scan int32 -> int64 (+ grand total); kid = profiling id of the bracket, or -1
 // round_to (a power of two): every count is rounded up to a multiple of it before it is summed

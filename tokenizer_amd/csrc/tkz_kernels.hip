@@ -503,6 +503,10 @@ static_assert(kDenseCap <= (1 << kMrCntShift) && kSub <= (1 << kMrLenShift), "th
 #endif
 constexpr int kGroup = kMergeGroup;                     // sub-tiles per wavefront of k_merge_short
 constexpr int kMsThreads = TKZ_MS_THREADS;              // ... and the workgroup size of that kernel
+#ifndef TKZ_PROBE_PER
+#define TKZ_PROBE_PER 1
+#endif
+constexpr int kProbePer = TKZ_PROBE_PER;                // consecutive sub-tiles per wavefront of k_probe (the next one's text is requested ahead)
 constexpr int kMidMax = kSub / (TKZ_SHORT_KEY_MAX + 1) + 2;   // pieces of 13+ bytes that can start in one sub-tile
 
 // The workgroup a block stands for: blocks b, b + 8, b + 16 ... of a grid run on one XCD (observed dispatch: XCD = b % 8; for speed only,
@@ -569,8 +573,35 @@ TKZ_DEV void tkz_probe_kmask_init(uint4* s_kmask) {
         s_kmask[len] = v;
     }
 }
-// one sub-tile, by one wavefront (no workgroup barrier inside: every wavefront is on its own)
-TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub, const ProbeLds& LD) {
+// the text of a sub-tile (+ halo) in flight: 16 bytes per lane, the halo by lanes 0..3; bytes beyond the corpus read as 0
+struct ProbeText { uint4 v0, v1; };
+static_assert((kSub + kHalo) / 16 <= 128, "two 16-byte loads per lane cover the sub-tile and its halo");
+TKZ_DEV void tkz_probe_request_text(const EncodeParams& P, int64_t sub, ProbeText* tx) {
+    const int lane = simt::lane();
+    const int64_t base = sub * kSub;
+    uint4 v0, v1;
+    v0.x = v0.y = v0.z = v0.w = 0; v1 = v0;
+    const int64_t p0 = base + 16 * (int64_t)lane, p1 = base + 16 * (int64_t)(lane + 64);
+    if (p0 + 16 <= P.total) v0 = tkz_load16_nt(P.bytes + p0);
+    else {
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 16; ++j) if (p0 + j < P.total) w[j >> 2] |= (uint32_t)P.bytes[p0 + j] << (8 * (j & 3));
+        v0.x = w[0]; v0.y = w[1]; v0.z = w[2]; v0.w = w[3];
+    }
+    if (lane + 64 < (kSub + kHalo) / 16) {
+        if (p1 + 16 <= P.total) v1 = tkz_load16_nt(P.bytes + p1);
+        else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int j = 0; j < 16; ++j) if (p1 + j < P.total) w[j >> 2] |= (uint32_t)P.bytes[p1 + j] << (8 * (j & 3));
+            v1.x = w[0]; v1.y = w[1]; v1.z = w[2]; v1.w = w[3];
+        }
+    }
+    tx->v0 = v0; tx->v1 = v1;
+}
+// one sub-tile, by one wavefront (no workgroup barrier inside: every wavefront is on its own).  tx: the sub-tile's text, requested by the
+// caller; on return it holds the request for sub-tile `next` (< 0: none), issued as soon as this one's text had moved into LDS -- a
+// wavefront that probes consecutive sub-tiles never waits for text again.
+TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub, const ProbeLds& LD, ProbeText& tx, int64_t next) {
     const int lane = simt::lane();
     uint32_t* s_bytes = LD.bytes;
     uint16_t* s_pstart = LD.pstart;
@@ -587,26 +618,8 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
     // ---- everything the wavefront needs from memory is requested first, in ONE round trip: the sub-tile (+ halo), 16 B per lane
     // (the halo by lanes 0..3), the bitmap words one per lane, and the 64 bitmap words after the sub-tile in which the end of
     // its last piece is looked for -- and only then consumed ----
-    static_assert((kSub + kHalo) / 16 <= 128, "two 16-byte loads per lane cover the sub-tile and its halo");
-    uint4 v0, v1;
-    v0.x = v0.y = v0.z = v0.w = 0; v1 = v0;
-    {
-        const int64_t p0 = base + 16 * (int64_t)lane, p1 = base + 16 * (int64_t)(lane + 64);
-        if (p0 + 16 <= P.total) v0 = tkz_load16_nt(P.bytes + p0);
-        else {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (int j = 0; j < 16; ++j) if (p0 + j < P.total) w[j >> 2] |= (uint32_t)P.bytes[p0 + j] << (8 * (j & 3));
-            v0.x = w[0]; v0.y = w[1]; v0.z = w[2]; v0.w = w[3];
-        }
-        if (lane + 64 < (kSub + kHalo) / 16) {
-            if (p1 + 16 <= P.total) v1 = tkz_load16_nt(P.bytes + p1);
-            else {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (int j = 0; j < 16; ++j) if (p1 + j < P.total) w[j >> 2] |= (uint32_t)P.bytes[p1 + j] << (8 * (j & 3));
-                v1.x = w[0]; v1.y = w[1]; v1.z = w[2]; v1.w = w[3];
-            }
-        }
-    }
+    // (the text itself was requested even earlier: by the caller, or while the sub-tile before this one was probed -- tx)
+    uint4 v0 = tx.v0, v1 = tx.v1;
     uint64_t myword = 0, mymark = 0;                      // lanes 0..15: piece-start word / mark word of the sub-tile
     if (lane < kSub / 64) {
         const int64_t w = sub * (kSub / 64) + lane;
@@ -617,6 +630,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
     const int64_t pb = P.pbase[sub];
     // ---- consume ----
     { uint4* s4 = reinterpret_cast<uint4*>(s_bytes); s4[lane] = v0; if (lane + 64 < (kSub + kHalo) / 16) s4[lane + 64] = v1; }
+    if (next >= 0) tkz_probe_request_text(P, next, &tx);
     if (lane < kSub / 64) {
         const int lim = nb - lane * 64;                    // bits at or beyond the end of the corpus are not pieces
         if (lim <= 0) myword = 0; else if (lim < 64) myword &= tkz_lowmask(lim);
@@ -807,9 +821,17 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
     TKZ_SHARED uint4 s_kmask[TKZ_SHORT_KEY_MAX + 1];
     tkz_probe_kmask_init(s_kmask);
     simt::sync();                                         // (the only workgroup barrier: from here on every wavefront is on its own)
-    const int64_t sub = tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave();
-    if (sub >= P.nsub) return;
-    tkz_probe_subtile(T, P, sub, tkz_probe_lds(s_wave[simt::wave()], s_kmask));
+    const int64_t sub0 = (tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave()) * kProbePer;
+    if (sub0 >= P.nsub) return;
+    const ProbeLds LD = tkz_probe_lds(s_wave[simt::wave()], s_kmask);
+    ProbeText tx;
+    tkz_probe_request_text(P, sub0, &tx);
+#pragma unroll 1
+    for (int it = 0; it < kProbePer && sub0 + it < P.nsub; ++it) {
+        const int64_t nxt = (it + 1 < kProbePer && sub0 + it + 1 < P.nsub) ? sub0 + it + 1 : -1;
+        tkz_probe_subtile(T, P, sub0 + it, LD, tx, nxt);
+        (void)simt::ballot(true);                             // (the next sub-tile reuses the wavefront's LDS)
+    }
 }
 
 // the 16 bytes of the corpus that start at byte position `abs`, as four little-endian dwords: the five dwords around them are fetched
@@ -1893,6 +1915,182 @@ TKZ_KERNEL(256) void k_offsets_scan(int64_t* offs, int64_t n, int64_t* total) {
     if (tid == 0) *total = n ? offs[n] : 0;
 }
 
+// -------------------------------------------------------------------------------------------------
+// k_small: the WHOLE launch sequence for a small batch in ONE kernel, one workgroup (ITokenizer.Encode of a prompt, TikTokenizer.cs:178-207;
+// the shape of BASELINE.json configs[0]).  The batch path above is ~25 launches and as many dependent kernel boundaries: ~160 us for a
+// 64-byte prompt, whatever the kernels do.  Here the phases are the same device functions (tkz_probe_subtile, tkz_merge_short_group,
+// tkz_merge_long_chunks, tkz_place_subtiles), run one after the other by the four wavefronts of one workgroup with a workgroup
+// barrier between them; the text and the offsets are read straight from page-locked host memory and the ids, the document offsets and
+// the status go straight back into it: one launch, one stream synchronisation, no copy commands.
+//   limits (checked by the host): total <= kSmallMaxBytes, n_docs <= kSmallMaxDocs, every document <= kSmallMaxDoc bytes (the
+//   pre-tokenizer here is the sequential matcher -- the definition -- one lane per document over text staged in LDS)
+//   a giant piece, a miss list or record buffer that is too small: status != 0, and the host takes the batch path (which has the retries)
+// -------------------------------------------------------------------------------------------------
+constexpr int kSmallLdsQuads = 1024;       // 16 KB: the largest phase (k_probe's four wavefronts: 15.3 KB)
+static_assert(kSmallLdsQuads >= (kThreads / 64) * kProbeLdsQuads + TKZ_SHORT_KEY_MAX + 1 && kSmallLdsQuads >= kMsLdsQuads + 32 && kSmallLdsQuads >= kLongLdsQuads &&
+              kSmallLdsQuads >= (kThreads / 64) * kPlaceLdsQuads && kSmallLdsQuads * 16 >= kSmallMaxBytes + 64, "every phase fits the one LDS block");
+TKZ_KERNEL(256) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
+    TKZ_SHARED uint4 s_raw[kSmallLdsQuads];
+    TKZ_SHARED int s_flag;
+    const int tid = simt::tid(), lane = simt::lane(), wave = simt::wave();
+    const int64_t total = P.total, n_docs = P.n_docs, nwords = P.nwords;
+    const int nsub = (int)P.nsub;
+    uint8_t* const d_bytes = const_cast<uint8_t*>(P.bytes);
+    int64_t* const d_offs = const_cast<int64_t*>(P.offs);
+    uint8_t* const s_text = reinterpret_cast<uint8_t*>(s_raw);
+    int stamp_i = 4;                                              // h_result[4..]: the shader clock at the end of every phase (thread 0)
+    auto stamp = [&]() { if (tid == 0 && stamp_i < 20) A.h_result[stamp_i] = (int64_t)simt::clock(); ++stamp_i; };
+    stamp();
+    // ---- 0. the input from page-locked host memory into HBM (the later phases gather from it) and into LDS (the matcher reads it char by
+    // char); everything the phases accumulate into, zeroed ----
+    for (int64_t i = tid; 16 * i < total; i += kThreads) {
+        uint4 v = tkz_load16(A.h_bytes + 16 * i);                 // (the host buffer is kSmallMaxBytes + 64 long: whole quads can be read)
+        if (16 * i + 16 > total) {                               // bytes beyond the text read as 0
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 0; j < 16; ++j) if (16 * i + j >= total) w[j >> 2] &= ~(0xFFu << (8 * (j & 3)));
+            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        }
+        *reinterpret_cast<uint4*>(d_bytes + 16 * i) = v;
+        s_raw[i] = v;
+    }
+    for (int64_t d = tid; d <= n_docs; d += kThreads) d_offs[d] = A.h_offs[d];
+    for (int64_t w = tid; w < nwords + 1; w += kThreads) A.docbits[w] = 0;
+    for (int i = tid; i < A.counter_words; i += kThreads) P.counters[i] = 0;
+    for (int t = tid; t < nsub; t += kThreads) P.heavy_flag[t] = 0;
+    if (tid == 0) s_flag = 0;
+    simt::sync();
+    stamp();
+    // ---- 1. document marks (k_docmark) ----
+    for (int64_t d = tid; d <= n_docs; d += kThreads) {
+        const int64_t pos = d_offs[d];
+        bool ok = pos >= 0 && pos <= total;
+        if (d == 0) ok = ok && pos == 0;
+        if (d == n_docs) ok = ok && pos == total;
+        else ok = ok && pos <= d_offs[d + 1];
+        if (!ok) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrOffsets); continue; }
+        simt::atomic_or64((unsigned long long*)&A.docbits[pos >> 6], 1ull << (pos & 63));
+    }
+    simt::sync();
+    for (int64_t w = tid; w < nwords; w += kThreads) A.startbits[w] = A.docbits[w];
+    simt::sync();
+    stamp();
+    // ---- 2. Regex.Matches.  Pattern 1 / cl100k: the row evaluator (one lane per BYTE of a 64-byte row, rows one after the other, scan state
+    // carried: tkz_rows_sequential), the rows dealt out to the four wavefronts -- the sequential matcher took 55 us for a 64-byte prompt
+    // (thousands of dependent reads), this takes ~2.  o200k has no row evaluator: the matcher, one lane per document, on the text in LDS ----
+    if (T.pattern == TKZ_PAT_O200K) {
+        for (int64_t d = tid; d < n_docs; d += kThreads) {
+            const int64_t a = d_offs[d], b = d_offs[d + 1];
+            if (b <= a || a < 0 || b > total) continue;
+            TkzDoc doc; doc.b = s_text + a; doc.n = b - a; doc.bmp = T.bmp_class; doc.by_code_point = 1;
+            int bad = 0;
+            for (int64_t p = 0; p < doc.n;) { const TkzChar c = tkz_doc_char(doc, p); bad |= c.bad; p += c.len; }
+            if (bad) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrUtf8); continue; }
+            tkz_seq_emit(T.pattern, doc, a, 0, a, b, A.startbits);
+        }
+    } else {
+        simt::sync();                                             // (the text in LDS is not needed on this path: its place takes the flag table)
+        uint16_t* s_aflags = reinterpret_cast<uint16_t*>(s_raw);
+        for (int i = tid; i < 128; i += kThreads) s_aflags[i] = (uint16_t)tkz_ascii_flags((uint32_t)i, T.pattern == TKZ_PAT_CL100K);
+        simt::sync();
+        TkzSrc S;
+        S.bytes = d_bytes; S.total = total; S.stage = nullptr; S.lo = 0; S.hi = 0;
+        const int64_t per = (nwords + (kThreads / 64) - 1) / (kThreads / 64);
+        const int64_t r0 = wave * per, r1 = r0 + per < nwords ? r0 + per : nwords;
+        if (r0 < r1) {
+            if (T.pattern == TKZ_PAT_P1) tkz_rows_sequential<TKZ_PAT_P1>(S, A.docbits, A.startbits, nwords, T.bmp_class, s_aflags, r0, r1, P.counters);
+            else tkz_rows_sequential<TKZ_PAT_CL100K>(S, A.docbits, A.startbits, nwords, T.bmp_class, s_aflags, r0, r1, P.counters);
+        }
+    }
+    simt::sync();
+    stamp();
+    // ---- 3. documents and pieces that start in each sub-tile, their scans (k_doccount + k_scan_*): one lane per sub-tile ----
+    if (wave == 0) {
+        int dc = 0, pc = 0;
+        if (lane < nsub) {
+            for (int k = 0; k < kSub / 64; ++k) {
+                const int64_t w = (int64_t)lane * (kSub / 64) + k;
+                uint64_t md = w < nwords ? A.docbits[w] : 0ull, mp = w < nwords ? A.startbits[w] : 0ull;
+                const int64_t lim = total - (w << 6);                  // (the sentinel bit at `total` is not a start)
+                if (lim <= 0) { md = 0; mp = 0; } else if (lim < 64) { md &= tkz_lowmask((int)lim); mp &= tkz_lowmask((int)lim); }
+                dc += tkz_popc64(md); pc += tkz_popc64(mp);
+            }
+        }
+        int dtot, ptot;
+        const int dpre = tkz_wave_scan_sum(dc, &dtot);
+        const int ppre = tkz_wave_scan_sum((pc + kRecordLine - 1) & ~(kRecordLine - 1), &ptot);
+        if (lane < nsub) { A.docord_base[lane] = dpre; A.pcount[lane] = pc; A.pbase[lane] = ppre; }
+        if (lane == 0 && ptot > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
+    }
+    simt::sync();
+    stamp();
+    // ---- 4. whole-piece lookups (k_probe) ----
+    {
+        uint4* s_kmask = s_raw + (kThreads / 64) * kProbeLdsQuads;
+        tkz_probe_kmask_init(s_kmask);
+        simt::sync();
+        for (int sub = wave; sub < nsub; sub += kThreads / 64) {
+            ProbeText tx;
+            tkz_probe_request_text(P, sub, &tx);
+            tkz_probe_subtile(T, P, sub, tkz_probe_lds(s_raw + wave * kProbeLdsQuads, s_kmask), tx, -1);
+            (void)simt::ballot(true);
+        }
+    }
+    simt::sync();
+    if (tid == 0) { int f = P.counters[0] != 0; for (int t = 0; t < nsub; ++t) f |= (P.heavy_flag[t] & 2u) != 0; s_flag = f; }
+    simt::sync();
+    if (s_flag) {                                                 // a giant piece, an error, a buffer that is too small: the batch path's business
+        if (tid == 0) { A.h_result[0] = 1; A.h_result[1] = P.counters[0]; }
+        return;
+    }
+    stamp();
+    // ---- 5. BytePairEncode of the short misses (k_merge_short: one group of 16 sub-tiles), then of the long ones (k_merge_long: one chunk) ----
+    {
+        uint16_t* s_brank16 = reinterpret_cast<uint16_t*>(s_raw + kMsLdsQuads);
+        tkz_ms_brank_init(T, s_brank16);
+        simt::sync();
+        if (wave == 0) tkz_merge_short_group(T, P, 0, tkz_ms_lds(s_raw, s_brank16));
+    }
+    simt::sync();
+    stamp();
+    if (wave == 0) {
+        const LongLds LD = tkz_long_lds(s_raw);
+        tkz_long_brank_init(T, LD.brank);
+        if (T.max_rank <= kVarCompactMaxRank) tkz_merge_long_chunks<true>(T, P, 0, int64_t(1) << 40, LD);
+        else tkz_merge_long_chunks<false>(T, P, 0, int64_t(1) << 40, LD);
+    }
+    simt::sync();
+    stamp();
+    // ---- 6. scan of the token counts (k_scan_*), ids to their places (k_place), document offsets (k_docoffs) ----
+    if (wave == 0) {
+        int tot;
+        const int pre = tkz_wave_scan_sum(lane < nsub ? P.tile_count[lane] : 0, &tot);
+        if (lane < nsub) A.tile_base[lane] = pre;
+        if (lane == 0) A.h_result[2] = tot;
+        if (lane == 0) A.tile_base[nsub] = tot;
+    }
+    simt::sync();
+    stamp();
+    for (int s0 = wave * kPlacePer; s0 < nsub; s0 += (kThreads / 64) * kPlacePer)
+        tkz_place_subtiles(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds(s_raw + wave * kPlaceLdsQuads));
+    simt::sync();
+    stamp();
+    {
+        const int64_t grand = A.tile_base[nsub];
+        for (int64_t d = tid; d <= n_docs; d += kThreads) {
+            const int64_t pos = d_offs[d];
+            if (pos >= total) { A.out_offs[d] = grand; continue; }
+            const int64_t sub = pos / kSub, wpos = pos >> 6;
+            int64_t ord = A.docord_base[sub];
+            for (int64_t w = sub * (kSub / 64); w < wpos; ++w) ord += tkz_popc64(A.docbits[w]);
+            ord += tkz_popc64(A.docbits[wpos] & tkz_lowmask((int)(pos & 63)));
+            A.out_offs[d] = A.tile_base[sub] + P.doc_tok[ord];
+        }
+    }
+    simt::sync();
+    stamp();
+    if (tid == 0) { const int32_t err = P.counters[0]; A.h_result[1] = err; A.h_result[0] = err ? 1 : 0; }
+}
+
 // =================================================================================================
 // launchers
 // =================================================================================================
@@ -1935,7 +2133,7 @@ void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, con
 }
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub) {
     hook(L, K_ENCODE, 0);
-    TKZ_LAUNCH(k_probe, xcd_grid(cdiv(nsub, kThreads / 64)), kThreads, L.stream, T, P);
+    TKZ_LAUNCH(k_probe, xcd_grid(cdiv(nsub, (kThreads / 64) * kProbePer)), kThreads, L.stream, T, P);
     hook(L, K_ENCODE, 1);
     hook(L, K_MERGE_SHORT, 0);
     TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
@@ -1956,6 +2154,9 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
         else TKZ_LAUNCH(k_merge_long<false>, grid, 64, L.stream, T, P);
     }
     hook(L, K_HEAVY, 1);
+}
+void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, const SmallArgs& A) {
+    TKZ_LAUNCH(k_small, 1, kThreads, L.stream, T, P, A);
 }
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
     hook(L, K_GATHER, 0);

@@ -52,8 +52,23 @@ def main():
            "batch_bytes": int(len(data)),
            "oracle_1_thread_one_prompt_us": med_us(lambda: oenc.encode_bytes(one), args.reps),
            "oracle_1_thread_1000_prompts_us": med_us(lambda: [oenc.encode_bytes(p) for p in prompts], 10)}
-    if hasattr(enc, "last_launches"):
-        out["launches_last_call"] = enc.last_launches()
+    enc.encode_utf8(one)
+    ph = enc.small_path_phases()
+    out["single_launch_path"] = {"calls_handed_back": enc.small_path_calls(),
+                                 "phase_cycles_one_prompt": [ph[i + 1] - ph[i] for i in range(len(ph) - 1) if ph[i + 1] and ph[i]],
+                                 "phases": "input+zero, docmark, bitmap copy, pre-tokenizer, counts+scans, probe, merge_short, merge_long, scan, place, docoffs"}
+    # the floor: one trivial kernel launch + stream synchronisation through torch, for comparison
+    try:
+        import torch
+        x = torch.zeros(64, device="cuda")
+        st = torch.cuda.Stream()
+        def floor():
+            with torch.cuda.stream(st):
+                x.add_(1)
+            st.synchronize()
+        out["launch_plus_sync_floor_us"] = med_us(floor, args.reps)
+    except Exception as ex:
+        out["launch_plus_sync_floor_us"] = str(ex)
     print(json.dumps(out))
 
 
