@@ -233,8 +233,8 @@ tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, 
 /* o200k only, informational: of the 4 KiB blocks of the last batch, how many the ASCII block scanner handed on (blocks with multi-byte
  * chars or a state it cannot carry), and how many of those the multi-byte block scanner handed on to the sequential matcher. */
 void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_scanner, int64_t* after_multibyte_scanner);
-/* The single-launch path: a host-buffer call (tkz_encode_utf8 / _utf16, tkz_encode_batch_utf8) whose batch is at most 8 KiB in at most
- * 2048 documents of at most 1 KiB each runs as ONE kernel launch that reads the text from, and writes the ids into, page-locked host memory
+/* The single-launch path: a host-buffer call (tkz_encode_utf8 / _utf16, tkz_encode_batch_utf8) whose batch is at most 128 KiB in at most
+ * 8192 documents (o200k: at most 64 KiB, documents of at most 1 KiB) runs as ONE kernel launch that reads the text from, and writes the ids into, page-locked host memory
  * (no copy commands; ~25 launches otherwise).  Informational: how many calls took it, and how many of those the kernel handed back to the
  * batch path (a piece of more than 1024 bytes, an error to diagnose, workspace to grow). */
 void tkz_encoder_small_path_calls(const tkz_encoder* e, int64_t* calls, int64_t* handed_back);

@@ -448,7 +448,7 @@ def check_memo_contention(lib, O, vocab, ovocab, candidates=400_000, threads=2, 
 
 
 def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
-    """The single-launch path for small batches (k_small: at most 8 KiB in at most 2048 documents of at most 1 KiB): same ids as the
+    """The single-launch path for small batches (k_small: at most 64 KiB in at most 8192 documents; o200k: of at most 1 KiB each): same ids as the
     oracle on single prompts and small batches of all three patterns; the calls that must be handed back to the batch path (a giant
     piece, malformed text, more misses than the lists hold) still give the batch path's answer; larger batches do not take it."""
     rng = random.Random(seed)
@@ -461,7 +461,7 @@ def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
             nd = rng.choice([1, 1, 1, 2, 7, 60, 400])
             docs = [gen_text(rng, kind, rng.choice([0, 1, 5, 20, 64, 100, 300, 1000]) if nd < 100 else rng.randint(0, 18), alpha).encode("utf-8")[:1024] for _ in range(nd)]
             docs = [d.decode("utf-8", "ignore").encode("utf-8") for d in docs]           # (the cut may have split a char)
-            while sum(map(len, docs)) > 8192:
+            while sum(map(len, docs)) > (65536 if pattern == N.O200K else 131072):
                 docs.pop()
             if not sum(map(len, docs)):
                 continue
@@ -500,8 +500,19 @@ def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
         with pytest.raises(N.TkzError) as ei:
             enc.encode_utf8(b"abc\xff")
         assert ei.value.code == N.E_INVALID_UTF8
+        # a document of several KiB: one launch for pattern 1 / cl100k (row and block evaluators), the batch path for o200k (its
+        # single-launch form splits with the sequential matcher, one lane per document: documents of up to 1 KiB only)
+        mid = ("lorem ipsum dolor sit amet, consectetur 12345 adipiscing elit; " * 300).encode()[:rng.choice([5000, 17000, 40000])]
+        c0 = enc.small_path_calls()
+        assert enc.encode_utf8(mid) == oenc.encode_bytes(mid)
+        assert enc.small_path_calls()[0] == c0[0] + (0 if pattern == N.O200K else 1)
+        mdocs = [("doc %d: the quick brown fox, it's 2024!\n" % i).encode() * rng.randint(1, 5) for i in range(300 if pattern == N.O200K else 800)]
+        mdata, moffs = pack(mdocs)
+        ids, ooff = enc.encode_batch(mdata, moffs)
+        mexp, meoff = oracle_encode_docs(oenc, mdocs)
+        assert ids.tolist() == mexp and ooff.tolist() == meoff and len(mdata) <= (65536 if pattern == N.O200K else 131072)
         # too large for the single launch: the batch path, untouched counters
-        big = ("lorem ipsum dolor sit amet " * 400).encode()
+        big = ("lorem ipsum dolor sit amet " * 6000).encode()
         c0 = enc.small_path_calls()
         assert enc.encode_utf8(big) == oenc.encode_bytes(big)
         assert enc.small_path_calls() == c0

@@ -445,7 +445,9 @@ constexpr size_t kSmallOffBytes = 0, kSmallOffOffs = tkz::kSmallMaxBytes + 64, k
                  kSmallOffOut = kSmallOffIds + tkz::kSmallMaxBytes * 4, kSmallOffRes = kSmallOffOut + (tkz::kSmallMaxDocs + 1) * 8, kSmallBlock = kSmallOffRes + 256;
 bool small_eligible(const tkz_encoder* e, const int64_t* offs, int64_t n_docs, int64_t total) {
     if (e->profiling || e->pretok_seq || total <= 0 || total > tkz::kSmallMaxBytes || n_docs < 1 || n_docs > tkz::kSmallMaxDocs) return false;
-    for (int64_t d = 0; d < n_docs; ++d) { const int64_t len = offs[d + 1] - offs[d]; if (len < 0 || len > tkz::kSmallMaxDoc) return false; }
+    if (e->pattern == TKZ_PATTERN_O200K && total > tkz::kSmallMaxBytesO200k) return false;
+    if (e->pattern == TKZ_PATTERN_O200K)          // (split by the sequential matcher there, one lane per document)
+        for (int64_t d = 0; d < n_docs; ++d) { const int64_t len = offs[d + 1] - offs[d]; if (len < 0 || len > tkz::kSmallMaxDoc) return false; }
     return true;
 }
 tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, const int64_t* offs, int64_t n_docs, int64_t total,

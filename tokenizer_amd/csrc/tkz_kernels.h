@@ -63,7 +63,7 @@ struct EncodeParams {
 };
 
 // k_small: one launch for a small batch (tkz_kernels.hip).  Input and output live in page-locked host memory the device reads and writes directly.
-constexpr int kSmallMaxBytes = 8192, kSmallMaxDocs = 2048, kSmallMaxDoc = 1024;
+constexpr int kSmallMaxBytes = 131072, kSmallMaxBytesO200k = 65536, kSmallMaxDocs = 8192, kSmallMaxDoc = 1024;
 struct SmallArgs {
     const uint8_t* h_bytes; const int64_t* h_offs;          // the batch, in page-locked host memory (h_bytes kSmallMaxBytes + 64 long)
     int32_t* out; int64_t out_cap; int64_t* out_offs;       // ids and document offsets, page-locked host memory

@@ -170,6 +170,46 @@ TKZ_KERNEL(64) void k_pretok_rows(const uint8_t* bytes, int64_t total, const uin
     }
 }
 
+// The same for ONE block by ONE wavefront of a larger workgroup (k_small): pattern 1 / cl100k only, wavefront-level synchronisation only.
+constexpr int kPretokBlkQuads = (65 * kBlockRowStride) / 16;
+template <int PATTERN>
+TKZ_DEV void tkz_pretok_block(int64_t blk, uint4* s_blk, const uint16_t* s_aflags, const uint8_t* bytes, int64_t total, const uint64_t* docbits,
+                              uint64_t* startbits, int64_t nrows, const uint8_t* bmp, int32_t* counters) {
+    static_assert(PATTERN != TKZ_PAT_O200K, "o200k blocks need the two follow-up kernels");
+    const int lane = simt::lane();
+    const int64_t r0 = blk * kRowsPerWave;
+    if (r0 >= nrows) return;
+    const int64_t first = r0 - 1;                          // row of lane 0
+    const bool inside = ((first + 64) << 6) <= total;       // every staged row is a full row of the corpus
+    if (inside) {
+        (void)simt::ballot(true);                          // (the block before this one is no longer read)
+        for (int c = lane; c < 256; c += 64) {
+            const int64_t pos = (first << 6) + 16 * (int64_t)c;
+            uint4 v; v.x = v.y = v.z = v.w = 0;
+            if (pos >= 0) v = tkz_load16(bytes + pos);
+            s_blk[((c >> 2) * kBlockRowStride + (c & 3) * 16) / 16] = v;
+        }
+        if (lane < kBlockRowStride / 16) {
+            uint4 z; z.x = z.y = z.z = z.w = 0;
+            const int64_t pos = (first + 64) << 6;
+            if (lane == 0 && pos + 16 <= total) z = tkz_load16(bytes + pos);
+            s_blk[(64 * kBlockRowStride) / 16 + lane] = z;
+        }
+        (void)simt::ballot(true);
+        const int64_t row = first + lane;
+        const uint64_t ds = (row >= 0 && row < nrows) ? docbits[row] : 0;
+        uint64_t out;
+        if (tkz_block_eval<PATTERN>(reinterpret_cast<const uint8_t*>(s_blk), ds, bmp, &out)) {
+            if (lane >= 1 && lane <= kRowsPerWave && row < nrows) startbits[row] = out;
+            return;
+        }
+    }
+    const int64_t r1 = r0 + kRowsPerWave < nrows ? r0 + kRowsPerWave : nrows;
+    TkzSrc S;
+    S.bytes = bytes; S.total = total; S.stage = nullptr; S.lo = 0; S.hi = 0;
+    tkz_rows_sequential<PATTERN>(S, docbits, startbits, nrows, bmp, s_aflags, r0, r1, counters);
+}
+
 // o200k, second pass: the blocks k_pretok_rows<O200K> left over because they hold multi-byte chars, through the char-level block
 // evaluator (tkz_block_eval_o200k_mb).  A kernel of its own so that its registers stay out of the ASCII scanner's.  What it
 // refuses as well goes into the second queue, for k_pretok_seq_blocks.
@@ -1922,17 +1962,21 @@ TKZ_KERNEL(256) void k_offsets_scan(int64_t* offs, int64_t n, int64_t* total) {
 // tkz_merge_long_chunks, tkz_place_subtiles), run one after the other by the four wavefronts of one workgroup with a workgroup
 // barrier between them; the text and the offsets are read straight from page-locked host memory and the ids, the document offsets and
 // the status go straight back into it: one launch, one stream synchronisation, no copy commands.
-//   limits (checked by the host): total <= kSmallMaxBytes, n_docs <= kSmallMaxDocs, every document <= kSmallMaxDoc bytes (the
-//   pre-tokenizer here is the sequential matcher -- the definition -- one lane per document over text staged in LDS)
+//   limits (checked by the host): total <= kSmallMaxBytes (128 sub-tiles), n_docs <= kSmallMaxDocs; o200k, which has no row evaluator and is
+//   split by the sequential matcher -- the definition -- one lane per document over text staged in LDS: total <= kSmallMaxBytesO200k and
+//   every document <= kSmallMaxDoc bytes
 //   a giant piece, a miss list or record buffer that is too small: status != 0, and the host takes the batch path (which has the retries)
 // -------------------------------------------------------------------------------------------------
-constexpr int kSmallLdsQuads = 1024;       // 16 KB: the largest phase (k_probe's four wavefronts: 15.3 KB)
-static_assert(kSmallLdsQuads >= (kThreads / 64) * kProbeLdsQuads + TKZ_SHORT_KEY_MAX + 1 && kSmallLdsQuads >= kMsLdsQuads + 32 && kSmallLdsQuads >= kLongLdsQuads &&
-              kSmallLdsQuads >= (kThreads / 64) * kPlaceLdsQuads && kSmallLdsQuads * 16 >= kSmallMaxBytes + 64, "every phase fits the one LDS block");
-TKZ_KERNEL(256) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
+constexpr int kSmallWaves = 16;            // the workgroup is 256 threads for up to 4 sub-tiles, 1024 beyond
+constexpr int kSmallLdsQuads = kSmallWaves * kPretokBlkQuads + 16;       // 83.5 KB: the largest phase (a 4 KiB block of the pre-tokenizer per wavefront)
+static_assert(kSmallLdsQuads >= kSmallWaves * kProbeLdsQuads + TKZ_SHORT_KEY_MAX + 1 && kSmallLdsQuads >= 8 * kMsLdsQuads + 32 && kSmallLdsQuads >= kLongLdsQuads &&
+              kSmallLdsQuads >= kSmallWaves * kPlaceLdsQuads && kSmallLdsQuads * 16 >= kSmallMaxBytesO200k + 64 && kSmallMaxBytes <= 8 * kGroup * kSub,
+              "every phase fits the one LDS block; the o200k text too; at most 8 groups of k_merge_short");
+TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
     TKZ_SHARED uint4 s_raw[kSmallLdsQuads];
     TKZ_SHARED int s_flag;
     const int tid = simt::tid(), lane = simt::lane(), wave = simt::wave();
+    const int kThreads = simt::nthreads(), nwaves = kThreads >> 6;          // (shadows the constant: every stride below is the actual workgroup size)
     const int64_t total = P.total, n_docs = P.n_docs, nwords = P.nwords;
     const int nsub = (int)P.nsub;
     uint8_t* const d_bytes = const_cast<uint8_t*>(P.bytes);
@@ -1951,7 +1995,7 @@ TKZ_KERNEL(256) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
             v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
         }
         *reinterpret_cast<uint4*>(d_bytes + 16 * i) = v;
-        s_raw[i] = v;
+        if (T.pattern == TKZ_PAT_O200K) s_raw[i] = v;             // (only the sequential matcher reads the text from LDS)
     }
     for (int64_t d = tid; d <= n_docs; d += kThreads) d_offs[d] = A.h_offs[d];
     for (int64_t w = tid; w < nwords + 1; w += kThreads) A.docbits[w] = 0;
@@ -1988,47 +2032,48 @@ TKZ_KERNEL(256) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
             tkz_seq_emit(T.pattern, doc, a, 0, a, b, A.startbits);
         }
     } else {
-        simt::sync();                                             // (the text in LDS is not needed on this path: its place takes the flag table)
-        uint16_t* s_aflags = reinterpret_cast<uint16_t*>(s_raw);
+        simt::sync();                                             // (the text in LDS is not needed on this path: its place take the flag table and the blocks)
+        uint16_t* s_aflags = reinterpret_cast<uint16_t*>(s_raw + kSmallWaves * kPretokBlkQuads);
         for (int i = tid; i < 128; i += kThreads) s_aflags[i] = (uint16_t)tkz_ascii_flags((uint32_t)i, T.pattern == TKZ_PAT_CL100K);
         simt::sync();
-        TkzSrc S;
-        S.bytes = d_bytes; S.total = total; S.stage = nullptr; S.lo = 0; S.hi = 0;
-        const int64_t per = (nwords + (kThreads / 64) - 1) / (kThreads / 64);
-        const int64_t r0 = wave * per, r1 = r0 + per < nwords ? r0 + per : nwords;
-        if (r0 < r1) {
-            if (T.pattern == TKZ_PAT_P1) tkz_rows_sequential<TKZ_PAT_P1>(S, A.docbits, A.startbits, nwords, T.bmp_class, s_aflags, r0, r1, P.counters);
-            else tkz_rows_sequential<TKZ_PAT_CL100K>(S, A.docbits, A.startbits, nwords, T.bmp_class, s_aflags, r0, r1, P.counters);
+        for (int64_t blk = wave; blk * kRowsPerWave < nwords; blk += nwaves) {
+            if (T.pattern == TKZ_PAT_P1) tkz_pretok_block<TKZ_PAT_P1>(blk, s_raw + wave * kPretokBlkQuads, s_aflags, d_bytes, total, A.docbits, A.startbits, nwords, T.bmp_class, P.counters);
+            else tkz_pretok_block<TKZ_PAT_CL100K>(blk, s_raw + wave * kPretokBlkQuads, s_aflags, d_bytes, total, A.docbits, A.startbits, nwords, T.bmp_class, P.counters);
         }
     }
     simt::sync();
     stamp();
     // ---- 3. documents and pieces that start in each sub-tile, their scans (k_doccount + k_scan_*): one lane per sub-tile ----
     if (wave == 0) {
-        int dc = 0, pc = 0;
-        if (lane < nsub) {
-            for (int k = 0; k < kSub / 64; ++k) {
-                const int64_t w = (int64_t)lane * (kSub / 64) + k;
-                uint64_t md = w < nwords ? A.docbits[w] : 0ull, mp = w < nwords ? A.startbits[w] : 0ull;
-                const int64_t lim = total - (w << 6);                  // (the sentinel bit at `total` is not a start)
-                if (lim <= 0) { md = 0; mp = 0; } else if (lim < 64) { md &= tkz_lowmask((int)lim); mp &= tkz_lowmask((int)lim); }
-                dc += tkz_popc64(md); pc += tkz_popc64(mp);
+        int dcarry = 0, pcarry = 0;
+        for (int q0 = 0; q0 < nsub; q0 += 64) {                   // 64 sub-tiles per round, one per lane
+            const int q = q0 + lane;
+            int dc = 0, pc = 0;
+            if (q < nsub) {
+                for (int k = 0; k < kSub / 64; ++k) {
+                    const int64_t w = (int64_t)q * (kSub / 64) + k;
+                    uint64_t md = w < nwords ? A.docbits[w] : 0ull, mp = w < nwords ? A.startbits[w] : 0ull;
+                    const int64_t lim = total - (w << 6);                  // (the sentinel bit at `total` is not a start)
+                    if (lim <= 0) { md = 0; mp = 0; } else if (lim < 64) { md &= tkz_lowmask((int)lim); mp &= tkz_lowmask((int)lim); }
+                    dc += tkz_popc64(md); pc += tkz_popc64(mp);
+                }
             }
+            int dtot, ptot;
+            const int dpre = dcarry + tkz_wave_scan_sum(dc, &dtot);
+            const int ppre = pcarry + tkz_wave_scan_sum((pc + kRecordLine - 1) & ~(kRecordLine - 1), &ptot);
+            if (q < nsub) { A.docord_base[q] = dpre; A.pcount[q] = pc; A.pbase[q] = ppre; }
+            dcarry += dtot; pcarry += ptot;
         }
-        int dtot, ptot;
-        const int dpre = tkz_wave_scan_sum(dc, &dtot);
-        const int ppre = tkz_wave_scan_sum((pc + kRecordLine - 1) & ~(kRecordLine - 1), &ptot);
-        if (lane < nsub) { A.docord_base[lane] = dpre; A.pcount[lane] = pc; A.pbase[lane] = ppre; }
-        if (lane == 0 && ptot > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
+        if (lane == 0 && pcarry > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
     }
     simt::sync();
     stamp();
     // ---- 4. whole-piece lookups (k_probe) ----
     {
-        uint4* s_kmask = s_raw + (kThreads / 64) * kProbeLdsQuads;
+        uint4* s_kmask = s_raw + nwaves * kProbeLdsQuads;
         tkz_probe_kmask_init(s_kmask);
         simt::sync();
-        for (int sub = wave; sub < nsub; sub += kThreads / 64) {
+        for (int sub = wave; sub < nsub; sub += nwaves) {
             ProbeText tx;
             tkz_probe_request_text(P, sub, &tx);
             tkz_probe_subtile(T, P, sub, tkz_probe_lds(s_raw + wave * kProbeLdsQuads, s_kmask), tx, -1);
@@ -2045,32 +2090,36 @@ TKZ_KERNEL(256) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
     stamp();
     // ---- 5. BytePairEncode of the short misses (k_merge_short: one group of 16 sub-tiles), then of the long ones (k_merge_long: one chunk) ----
     {
-        uint16_t* s_brank16 = reinterpret_cast<uint16_t*>(s_raw + kMsLdsQuads);
+        uint16_t* s_brank16 = reinterpret_cast<uint16_t*>(s_raw + 8 * kMsLdsQuads);
         tkz_ms_brank_init(T, s_brank16);
         simt::sync();
-        if (wave == 0) tkz_merge_short_group(T, P, 0, tkz_ms_lds(s_raw, s_brank16));
+        for (int g = wave; g < 8 && g * kGroup < nsub; g += nwaves) tkz_merge_short_group(T, P, g, tkz_ms_lds(s_raw + wave * kMsLdsQuads, s_brank16));
     }
     simt::sync();
     stamp();
     if (wave == 0) {
         const LongLds LD = tkz_long_lds(s_raw);
         tkz_long_brank_init(T, LD.brank);
-        if (T.max_rank <= kVarCompactMaxRank) tkz_merge_long_chunks<true>(T, P, 0, int64_t(1) << 40, LD);
-        else tkz_merge_long_chunks<false>(T, P, 0, int64_t(1) << 40, LD);
+        if (T.max_rank <= kVarCompactMaxRank) tkz_merge_long_chunks<true>(T, P, 0, 1, LD);
+        else tkz_merge_long_chunks<false>(T, P, 0, 1, LD);
     }
     simt::sync();
     stamp();
     // ---- 6. scan of the token counts (k_scan_*), ids to their places (k_place), document offsets (k_docoffs) ----
     if (wave == 0) {
-        int tot;
-        const int pre = tkz_wave_scan_sum(lane < nsub ? P.tile_count[lane] : 0, &tot);
-        if (lane < nsub) A.tile_base[lane] = pre;
-        if (lane == 0) A.h_result[2] = tot;
-        if (lane == 0) A.tile_base[nsub] = tot;
+        int carry = 0;
+        for (int q0 = 0; q0 < nsub; q0 += 64) {
+            const int q = q0 + lane;
+            int tot;
+            const int pre = carry + tkz_wave_scan_sum(q < nsub ? P.tile_count[q] : 0, &tot);
+            if (q < nsub) A.tile_base[q] = pre;
+            carry += tot;
+        }
+        if (lane == 0) { A.h_result[2] = carry; A.tile_base[nsub] = carry; }
     }
     simt::sync();
     stamp();
-    for (int s0 = wave * kPlacePer; s0 < nsub; s0 += (kThreads / 64) * kPlacePer)
+    for (int s0 = wave * kPlacePer; s0 < nsub; s0 += nwaves * kPlacePer)
         tkz_place_subtiles(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds(s_raw + wave * kPlaceLdsQuads));
     simt::sync();
     stamp();
@@ -2156,7 +2205,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     hook(L, K_HEAVY, 1);
 }
 void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, const SmallArgs& A) {
-    TKZ_LAUNCH(k_small, 1, kThreads, L.stream, T, P, A);
+    TKZ_LAUNCH(k_small, 1, P.nsub <= 4 ? 256 : 1024, L.stream, T, P, A);
 }
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
     hook(L, K_GATHER, 0);

@@ -57,6 +57,9 @@ def main():
     out["single_launch_path"] = {"calls_handed_back": enc.small_path_calls(),
                                  "phase_cycles_one_prompt": [ph[i + 1] - ph[i] for i in range(len(ph) - 1) if ph[i + 1] and ph[i]],
                                  "phases": "input+zero, docmark, bitmap copy, pre-tokenizer, counts+scans, probe, merge_short, merge_long, scan, place, docoffs"}
+    enc.encode_batch(data, offs)
+    ph = enc.small_path_phases()
+    out["single_launch_path"]["phase_cycles_1000_prompts"] = [ph[i + 1] - ph[i] for i in range(len(ph) - 1) if ph[i + 1] and ph[i]]
     # the floor: one trivial kernel launch + stream synchronisation through torch, for comparison
     try:
         import torch
