@@ -111,6 +111,12 @@ inline int scan_inclusive(int v) {
     for (int i = 0; i <= l; ++i) x += (int)(uint32_t)a[i];
     return x;
 }
+inline uint32_t wave_min_u32(uint32_t v) {
+    uint64_t* a = hipemu::wave_exchange(v);
+    uint32_t m = 0xFFFFFFFFu;
+    for (int i = 0; i < 64; ++i) m = (uint32_t)a[i] < m ? (uint32_t)a[i] : m;
+    return m;
+}
 inline int last_lane(int v) { return (int)(uint32_t)hipemu::wave_exchange((uint32_t)v)[63]; }
 inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
 inline int atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }

@@ -518,6 +518,20 @@ def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
         assert enc.small_path_calls() == c0
 
 
+def check_long_diverse_pieces(lib, O, vocab, ovocab, lens=(3000, 9000, 20000), seed=5):
+    """Pieces of thousands of bytes that merge a few pairs per rank (chains of capitalised words under cl100k: one `\\p{L}+` piece): the
+    rounds hand them to the one-merge-at-a-time tail -- from LDS (<= 16384 parts) and from the global pool (<= 32768 parts) --, next to
+    runs of one letter, which never leave the rounds."""
+    rng = random.Random(seed)
+    enc = N.Encoder(vocab, N.CL100K)
+    oenc = O.Encoder(ovocab, N.CL100K)
+    words = [w.decode().strip() for w, _ in ovocab.entries() if w.strip().isalpha() and len(w.strip()) > 3][:3000]
+    for n in lens:
+        for text in ("".join(rng.choice(words).capitalize() for _ in range(n // 5))[:n].encode(),
+                     ("".join(rng.choice(words).capitalize() for _ in range(n // 10))[:n // 2] + "q" * (n // 2)).encode()):
+            assert enc.encode_utf8(text) == oenc.encode_bytes(text), n
+
+
 def check_errors(lib, O, vocab):
     enc = N.Encoder(vocab, N.CL100K)
     import pytest

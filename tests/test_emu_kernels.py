@@ -163,6 +163,7 @@ def test_long_and_giant_pieces(lib, vocab, vocabs, oracle_mod, oracle_gpt2):
         r = oracle_gpt2.rank(p)
         got = enc0.encode_pieces(np.frombuffer(p, np.uint8), np.array([0, len(p)]))[0].tolist()
         assert got == ([r] if r >= 0 else oracle_gpt2.bpe(p)), len(p)
+    parity.check_long_diverse_pieces(lib, oracle_mod, vocab, oracle_gpt2, lens=(3000, 18000))
     # giant pieces that collapse to a handful of tokens (runs of one byte under a vocabulary with long run keys): the in-lane copy of k_place
     v, ov = vocabs("synth100k")
     enc = N.Encoder(v, N.CL100K)

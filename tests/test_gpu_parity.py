@@ -190,6 +190,7 @@ def test_giant_pieces(lib, vocabs, oracle_mod, vname):
     oenc = oracle_mod.Encoder(oracle_gpt2, oracle_mod.CL100K)
     for text in (b"t" * 4000, b"=" * 9000, b" " * 5000 + b"x", b"ab" * 6000, bytes(range(97, 123)) * 400):
         assert enc.encode_utf8(text) == oenc.encode_bytes(text)
+    parity.check_long_diverse_pieces(lib, oracle_mod, vocab, oracle_gpt2, lens=(3000, 9000, 20000, 33000, 50000))
 
 
 @pytest.mark.parametrize("pattern,vname", [(1, "gpt2"), (2, "gpt2"), (3, "gpt2"), (2, "synth100k"), (3, "synth200k"), (1, "synth200k")])
@@ -443,3 +444,5 @@ def test_reference_unit_tests_restated(lib, gpt2_tiktoken_bytes, lib_rs_bytes, o
 
 def test_adversarial_rank_tables(lib, oracle_mod):
     parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=40, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 1024, 1025, 3000], n_pieces=200)
+    # arbitrary rank tables on pieces that start in the global pool and end in the tail that keeps only the pair ranks in LDS
+    parity.check_random_vocab(lib, oracle_mod, seed=4, n_vocabs=6, lens=[17000, 20000, 30000, 33000], n_pieces=4)

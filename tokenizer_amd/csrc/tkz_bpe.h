@@ -505,12 +505,37 @@ TKZ_DEV int tkz_block_exclusive_max(int v) {
 // The rounds, on whatever arrays the state is in.  Runs until no pair has a rank (returns true) or, when stop_at > 0, until the
 // state has shrunk to stop_at parts or fewer (returns false: the caller moves the state to faster memory and calls again).
 // ids / pr are left pointing at the current state, cnt at its length.
-TKZ_DEV bool tkz_bpe_long_rounds(const TkzTables& T, int& cnt, int32_t*& ids, int32_t*& pr, int32_t*& s1, int32_t* s2, int32_t*& idsN, int32_t* prN, int stop_at, int* rounds = nullptr) {
+// Is the state dominated by ONE pair rank?  (A run of one letter is: after a few odd merges at its end -- poor rounds -- thousands of equal
+// pairs merge in the next round; a chain of words is not.)  Three probes: the ranks of the pairs at 1/4, 1/2 and 3/4 of the state; a
+// probe that a sixteenth of all pairs share says "homogeneous": such a piece stays with the rounds.  Called by the whole workgroup.
+TKZ_DEV bool tkz_bpe_long_homogeneous(const int32_t* pr, int cnt) {
+    const int tid = simt::tid(), G = simt::nthreads();
+    if (cnt < 64) return false;
+    const int32_t v1 = pr[cnt / 4], v2 = pr[cnt / 2], v3 = pr[(3 * cnt) / 4];
+    const int c = (cnt + G - 1) / G;
+    const int lo = tid * c < cnt ? tid * c : cnt, hi = lo + c < cnt ? lo + c : cnt;
+    int n1 = 0, n2 = 0, n3 = 0;
+    for (int i = lo; i < hi; ++i) { const int32_t r = pr[i]; n1 += r == v1; n2 += r == v2; n3 += r == v3; }
+    int t1, t2, t3;
+    (void)tkz_block_scan(n1, &t1); (void)tkz_block_scan(n2, &t2); (void)tkz_block_scan(n3, &t3);
+    const int thr = cnt / 16;
+    return (v1 != TKZ_RANK_NONE && t1 >= thr) || (v2 != TKZ_RANK_NONE && t2 >= thr) || (v3 != TKZ_RANK_NONE && t3 >= thr);
+}
+// few / few_cap (> 0): also returns false -- *slow = true -- after kBpeSlowRounds consecutive rounds that merged fewer than `few` pairs each,
+// once the state is down to few_cap parts (such a piece is handed to tkz_bpe_long_tail).
+constexpr int kBpeSlowRounds = 3;
+TKZ_DEV bool tkz_bpe_long_rounds(const TkzTables& T, int& cnt, int32_t*& ids, int32_t*& pr, int32_t*& s1, int32_t* s2, int32_t*& idsN, int32_t* prN, int stop_at, int* rounds = nullptr,
+                                 int few = 0, int few_cap = 0, bool* slow = nullptr) {
     const int tid = simt::tid(), G = simt::nthreads();
     constexpr int32_t kNotMerge = 0x7FFFFFFE;
+    int nslow = 0;
     for (;;) {
         if (rounds) ++*rounds;
         if (stop_at > 0 && cnt <= stop_at) return false;
+        if (few > 0 && nslow >= kBpeSlowRounds && cnt <= few_cap) {
+            if (!tkz_bpe_long_homogeneous(pr, cnt)) { *slow = true; return false; }
+            nslow = 0;
+        }
         const int c = (cnt + G - 1) / G;                  // contiguous block of parts per thread
         const int lo = tid * c < cnt ? tid * c : cnt, hi = lo + c < cnt ? lo + c : cnt;
         // 1. the minimum rank
@@ -572,6 +597,7 @@ TKZ_DEV bool tkz_bpe_long_rounds(const TkzTables& T, int& cnt, int32_t*& ids, in
         // s1 now holds the new pr; make it the pr array of the next round
         { int32_t* t = pr; pr = s1; s1 = t; }
         { int32_t* t = ids; ids = idsN; idsN = t; }
+        nslow = cnt - tot < few ? nslow + 1 : 0;
         cnt = tot;
         simt::sync();
     }
@@ -585,9 +611,12 @@ TKZ_DEV bool tkz_bpe_long_rounds(const TkzTables& T, int& cnt, int32_t*& ids, in
 //   part j left of a merge (flag[j+1]): id' = id[j];  pr' = rank(id[j], m)                                      (:59-62)
 //   part right of a merge (flag[j-1]): swallowed                                                               (:63)
 // and the round is cut after the leftmost merge that creates a pair ranked below m, exactly as in tkz_bpe_long_rounds.
+// Returns true when no pair is left, false after kBpeSlowRounds consecutive rounds that merged fewer than `few` pairs each (what is left is
+// then better served by tkz_bpe_long_tail: a diverse piece goes on for thousands of rounds of one or two merges each, ~13 us a round).
 template <int C>
-TKZ_DEV void tkz_bpe_long_rounds_lds(const TkzTables& T, int& cnt, int32_t* ids, int32_t* pr, uint8_t* flag, int* rounds = nullptr) {
+TKZ_DEV bool tkz_bpe_long_rounds_lds(const TkzTables& T, int& cnt, int32_t* ids, int32_t* pr, uint8_t* flag, int few, int* rounds = nullptr) {
     const int tid = simt::tid();
+    int nslow = 0;
     for (;;) {
         if (rounds) ++*rounds;
         const int c = (cnt + 1023) >> 10;                 // parts per thread this round (<= C)
@@ -603,7 +632,7 @@ TKZ_DEV void tkz_bpe_long_rounds_lds(const TkzTables& T, int& cnt, int32_t* ids,
             mymin = (uint32_t)mypr[q] < mymin ? (uint32_t)mypr[q] : mymin;
         }
         const int32_t m = (int32_t)tkz_block_min32(mymin);
-        if (m == TKZ_RANK_NONE) return;                   // (:65-68)
+        if (m == TKZ_RANK_NONE) return true;              // (:65-68)
         // 2. candidates; leftmost first inside a chain of adjacent candidates: every other one, counted from the chain's start
         int lastNon = -1;
 #pragma unroll
@@ -660,9 +689,126 @@ TKZ_DEV void tkz_bpe_long_rounds_lds(const TkzTables& T, int& cnt, int32_t* ids,
         int o = tkz_block_scan(alive, &tot);              // (its barriers also separate the reads above from the writes below)
 #pragma unroll
         for (int q = 0; q < C; ++q) if ((keep >> q) & 1u) { ids[o] = nid[q]; pr[o] = npr[q]; ++o; }
+        nslow = cnt - tot < few ? nslow + 1 : 0;         // (ONE poor round says nothing: a run of one letter has a single odd merge between rounds of thousands)
         cnt = tot;
         simt::sync();
+        if (nslow >= kBpeSlowRounds) {
+            if (!tkz_bpe_long_homogeneous(pr, cnt)) return false;
+            nslow = 0;
+        }
     }
+}
+
+// The TAIL of a long diverse piece: the reference's loop itself (BytePairEncoder.cs:45-64), one merge at a time, by ONE wavefront on the
+// state in LDS -- ids[cap] | pr[cap] as the rounds above leave them, plus one alive bit per part and the minimum rank of every block
+// of 32 parts (both in what was the flag area).  A merge is: the minimum over the block minima (a few 16-byte reads per lane and a DPP
+// reduction), the leftmost part of that rank inside the first such block (:47-54), its neighbours through the alive bits, the two pair
+// lookups (:58-62; the same address in every lane: one request), three writes, and the minima of the <= 3 blocks touched: ~1 us, where a round
+// costs ~13 us and a 32 KiB run of words needs ~3000 of them for a handful of merges each.  Parts are never moved: what is left is
+// compacted by the caller.  Workgroups of 1024 threads; wavefront 0 works, the others wait at the barrier behind it.
+constexpr int kTailBlock = 32;
+constexpr uint32_t kTailDead = 0x80000000u;
+// IDS_LDS: the ids of the parts are in LDS beside pr[] (the state the LDS rounds leave, <= kBpeLongLds parts).  Otherwise (the state the
+// GLOBAL rounds leave, <= kBpeTailCap parts: only pr[] fits LDS): ids[] -- global memory -- holds the ids the parts had when the tail began,
+// and a part that has merged since keeps its id in the slot behind it, which died with its first merge and stays dead (kTailDead | id).
+template <bool IDS_LDS>
+TKZ_DEV uint32_t tkz_tail_id(const int32_t* ids, const int32_t* pr, const uint32_t* alive, int cnt, int x) {
+    if (IDS_LDS) return (uint32_t)ids[x];
+    const bool merged = x + 1 < cnt && !((alive[(x + 1) >> 5] >> ((x + 1) & 31)) & 1u);
+    return merged ? ((uint32_t)pr[x + 1] & ~kTailDead) : (uint32_t)ids[x];
+}
+template <bool IDS_LDS>
+TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_t* pr, uint32_t* alive, int32_t* bmin) {
+    const int tid = simt::tid(), lane = simt::lane();
+    const int nblk = (cnt + kTailBlock - 1) / kTailBlock, nw = (cnt + 31) >> 5;
+    // (the last part never has a pair: its pr is TKZ_RANK_NONE already; slots beyond cnt are padded so that whole blocks can be read)
+    for (int i = cnt + tid; i < nblk * kTailBlock; i += simt::nthreads()) pr[i] = TKZ_RANK_NONE;
+    for (int w = tid; w < nw; w += simt::nthreads()) alive[w] = tkz_lowmask32(cnt - 32 * w);
+    simt::sync();
+    for (int b = tid; b < ((nblk + 63) & ~63); b += simt::nthreads()) {
+        int32_t mn = TKZ_RANK_NONE;
+        if (b < nblk) for (int k = 0; k < kTailBlock; ++k) { const int32_t r = pr[b * kTailBlock + k]; mn = r < mn ? r : mn; }
+        bmin[b] = mn;
+    }
+    simt::sync();
+    if (simt::wave() == 0) {
+        const int per = ((nblk + 63) >> 6);                       // block minima per lane (consecutive)
+        auto block_min = [&](int b) {                            // recomputes bmin[b]: one part per lane of the lower half
+            // (a dead slot holds TKZ_RANK_NONE or kTailDead | id: as unsigned values both lie at or above TKZ_RANK_NONE)
+            uint32_t v = lane < kTailBlock ? (uint32_t)pr[b * kTailBlock + lane] : (uint32_t)TKZ_RANK_NONE;
+            if (v > (uint32_t)TKZ_RANK_NONE) v = (uint32_t)TKZ_RANK_NONE;
+            const uint32_t mn = simt::wave_min_u32(v);
+            if (lane == 0) bmin[b] = (int32_t)mn;
+        };
+        for (;;) {
+            // leftmost strict minimum (:47-54): the minimum over the block minima, the first block that has it, the first part in it
+            uint32_t mymin = (uint32_t)TKZ_RANK_NONE;
+            int myblk = 0;
+            for (int k = 0; k < per; ++k) {
+                const int b = lane * per + k;
+                const uint32_t v = b < nblk ? (uint32_t)bmin[b] : (uint32_t)TKZ_RANK_NONE;
+                if (v < mymin) { mymin = v; myblk = b; }
+            }
+            const uint32_t m = simt::wave_min_u32(mymin);
+            if (m == (uint32_t)TKZ_RANK_NONE) break;             // minRank == int.MaxValue (:65-68)
+            const uint64_t has = simt::ballot(mymin == m);
+            const int b0 = simt::shfl(myblk, tkz_ctz64(has));
+            const uint64_t hit = simt::ballot(lane < kTailBlock && (uint32_t)pr[b0 * kTailBlock + lane] == m);
+            const int j = b0 * kTailBlock + tkz_ctz64(hit);
+            // r: the part being swallowed (the next one alive after j), rr: the one after it, l: the one before j
+            int w = (j + 1) >> 5;
+            uint32_t bits = w < nw ? alive[w] & (0xFFFFFFFFu << ((j + 1) & 31)) : 0u;
+            while (!bits && ++w < nw) bits = alive[w];
+            const int r = 32 * w + tkz_ctz32(bits);              // exists: pr[j] was a rank
+            bits &= bits - 1;
+            while (!bits && ++w < nw) bits = alive[w];
+            const bool hasr = bits != 0;
+            const int rr = hasr ? 32 * w + tkz_ctz32(bits) : 0;
+            w = j >> 5;
+            bits = alive[w] & tkz_lowmask32(j & 31);
+            while (!bits && --w >= 0) bits = alive[w];
+            const bool hasl = bits != 0;
+            const int l = hasl ? 32 * w + tkz_msb32(bits) : 0;
+            const uint32_t idr = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, rr), idl = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, l);
+            const int32_t rkr = hasr ? tkz_lookup_pair(T, m, idr) : TKZ_RANK_NONE;        // (:58)
+            const int32_t rkl = hasl ? tkz_lookup_pair(T, idl, m) : TKZ_RANK_NONE;        // (:59-62)
+            (void)simt::ballot(true);                            // (every lane has read the state: now it changes)
+            if (lane == 0) {
+                alive[r >> 5] &= ~(1u << (r & 31));              // RemoveAt(j + 1) (:63)
+                pr[r] = TKZ_RANK_NONE;
+                if (IDS_LDS) ids[j] = (int32_t)m;                // the merged part carries the rank it was found under ...
+                else pr[j + 1] = (int32_t)(kTailDead | m);       // ... in the slot behind it (dead since this part's first merge: r == j + 1 then)
+                pr[j] = rkr;
+                if (hasl) pr[l] = rkl;
+            }
+            (void)simt::ballot(true);
+            const int bj = j / kTailBlock, br = r / kTailBlock, bl = l / kTailBlock;
+            block_min(bj);
+            if (br != bj) block_min(br);
+            if (hasl && bl != bj) block_min(bl);
+            (void)simt::ballot(true);
+        }
+    }
+    simt::sync();
+}
+// the survivors of a tail, in order (:70-75); returns their number
+template <bool IDS_LDS>
+TKZ_DEV int tkz_bpe_long_tail_emit(int cnt, const int32_t* ids, const int32_t* pr, const uint32_t* alive, int32_t* dst, int* err) {
+    const int tid = simt::tid(), G = simt::nthreads();
+    const int c0 = (cnt + G - 1) / G;
+    const int lo0 = tid * c0 < cnt ? tid * c0 : cnt, hi0 = lo0 + c0 < cnt ? lo0 + c0 : cnt;
+    int mine = 0;
+    for (int i = lo0; i < hi0; ++i) mine += (int)((alive[i >> 5] >> (i & 31)) & 1u);
+    int tot;
+    int o = tkz_block_scan(mine, &tot);
+    for (int i = lo0; i < hi0; ++i) {
+        if (!((alive[i >> 5] >> (i & 31)) & 1u)) continue;
+        const int32_t id = (int32_t)tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, i);
+        if (id >= TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;
+        dst[o++] = id;
+    }
+    simt::sync();
+    return tot;
 }
 
 // lds: 9 * kBpeLongLds bytes of LDS (workgroups of 1024 threads) or null.  The state starts in the global arrays when the piece is
@@ -670,6 +816,17 @@ TKZ_DEV void tkz_bpe_long_rounds_lds(const TkzTables& T, int& cnt, int32_t* ids,
 // many workgroup barriers, and most rounds of a long diverse piece (one per distinct rank) happen when a few thousand parts are
 // left -- in L2 / Infinity Cache a round costs ~25 us, in LDS ~5.
 constexpr int kBpeLongLds = 16384;
+#ifndef TKZ_TAIL_FEW
+#define TKZ_TAIL_FEW 16
+#endif
+#ifndef TKZ_TAIL_FEW_GLOBAL
+#define TKZ_TAIL_FEW_GLOBAL 256
+#endif
+constexpr int kBpeTailFew = TKZ_TAIL_FEW;      // rounds in LDS that merge fewer pairs than this (three in a row) hand the piece to the one-merge-at-a-time tail
+constexpr int kBpeTailFewGlobal = TKZ_TAIL_FEW_GLOBAL;   // ... rounds in global memory (~150 us each, ten times an LDS round)
+constexpr int kBpeTailCap = 32768;             // parts whose pair ranks, alive bits and block minima fit the 9 * kBpeLongLds bytes of LDS
+static_assert(kBpeLongLds / 8 + (kBpeLongLds / 32 + 64) * 4 <= kBpeLongLds, "alive bits + block minima fit the flag area");
+static_assert(kBpeTailCap * 4 + kBpeTailCap / 8 + (kBpeTailCap / 32 + 64) * 4 <= 9 * kBpeLongLds, "the tail's state for kBpeTailCap parts fits the workgroup's LDS");
 template <class ByteAt>
 TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, int32_t* prA, int32_t* s1g, int32_t* s2g,
                          int32_t* idsB, int32_t* prB, int32_t* dst, int* err, int32_t* lds = nullptr, unsigned long long* prof = nullptr) {
@@ -688,24 +845,53 @@ TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, in
     bool done = false;
     long long t0 = prof ? simt::clock() : 0, t1 = t0;
     int rg = 0, rl = 0;
+    auto finish_prof = [&](int tokens) {
+        if (prof && tid == 0) {
+            const long long t2 = simt::clock();
+            simt::atomic_add64(&prof[8], 1ull); simt::atomic_add64(&prof[9], (unsigned long long)(t1 - t0)); simt::atomic_add64(&prof[10], (unsigned long long)(t2 - t1));
+            simt::atomic_add64(&prof[11], (unsigned long long)n); simt::atomic_add64(&prof[12], (unsigned long long)tokens);
+            simt::atomic_max64(&prof[13], (unsigned long long)(t2 - t0));
+            simt::atomic_add64(&prof[14], (unsigned long long)rg); simt::atomic_add64(&prof[15], (unsigned long long)rl);
+        }
+    };
     if (!start_in_lds) {
         int32_t* s1 = s1g; int32_t* idsN = idsB;
-        done = tkz_bpe_long_rounds(T, cnt, ids, pr, s1, s2g, idsN, prB, use_lds ? kBpeLongLds : 0, prof ? &rg : nullptr);
+        bool slow = false;
+        done = tkz_bpe_long_rounds(T, cnt, ids, pr, s1, s2g, idsN, prB, use_lds ? kBpeLongLds : 0, prof ? &rg : nullptr,
+                                   use_lds ? kBpeTailFewGlobal : 0, kBpeTailCap, &slow);
         if (prof) t1 = simt::clock();
+        if (!done && slow) {
+            // A diverse piece: the rounds in global memory merge a handful of pairs each at ~150 us a round, and the piece is still too long
+            // for the LDS rounds.  Its pair ranks alone fit LDS (4 bytes a part, up to kBpeTailCap parts): the tail takes it from here, the ids
+            // the parts have now staying where they are, in global memory.
+            int32_t* lpr = lds;
+            uint32_t* alive = reinterpret_cast<uint32_t*>(lds + kBpeTailCap);
+            int32_t* bmin = reinterpret_cast<int32_t*>(alive + kBpeTailCap / 32);
+            for (int k = tid; k < cnt; k += G) lpr[k] = pr[k];
+            simt::sync();
+            tkz_bpe_long_tail<false>(T, cnt, ids, lpr, alive, bmin);
+            const int tot = tkz_bpe_long_tail_emit<false>(cnt, ids, lpr, alive, dst, err);
+            finish_prof(tot);
+            return tot;
+        }
         if (!done) {                                     // the state fits LDS now: move it
             for (int k = tid; k < cnt; k += G) { lds[k] = ids[k]; lds[kBpeLongLds + k] = pr[k]; }
             simt::sync();
             ids = lds; pr = lds + kBpeLongLds;
         }
     }
-    if (!done) tkz_bpe_long_rounds_lds<kBpeLongLds / 1024>(T, cnt, ids, pr, reinterpret_cast<uint8_t*>(lds + 2 * kBpeLongLds), prof ? &rl : nullptr);
-    if (prof && tid == 0) {
-        const long long t2 = simt::clock();
-        simt::atomic_add64(&prof[8], 1ull); simt::atomic_add64(&prof[9], (unsigned long long)(t1 - t0)); simt::atomic_add64(&prof[10], (unsigned long long)(t2 - t1));
-        simt::atomic_add64(&prof[11], (unsigned long long)n); simt::atomic_add64(&prof[12], (unsigned long long)cnt);
-        simt::atomic_max64(&prof[13], (unsigned long long)(t2 - t0));
-        simt::atomic_add64(&prof[14], (unsigned long long)rg); simt::atomic_add64(&prof[15], (unsigned long long)rl);
+    bool tail = false;
+    if (!done) tail = !tkz_bpe_long_rounds_lds<kBpeLongLds / 1024>(T, cnt, ids, pr, reinterpret_cast<uint8_t*>(lds + 2 * kBpeLongLds), kBpeTailFew, prof ? &rl : nullptr);
+    if (tail) {
+        // what the rounds left: one merge at a time, by one wavefront (tkz_bpe_long_tail); then the survivors, in order
+        uint32_t* alive = reinterpret_cast<uint32_t*>(lds + 2 * kBpeLongLds);              // (the flag area: cap bytes = alive bits + block minima)
+        int32_t* bmin = reinterpret_cast<int32_t*>(alive + kBpeLongLds / 32);
+        tkz_bpe_long_tail<true>(T, cnt, ids, pr, alive, bmin);
+        const int tot = tkz_bpe_long_tail_emit<true>(cnt, ids, pr, alive, dst, err);
+        finish_prof(tot);
+        return tot;
     }
+    finish_prof(cnt);
     // emit surviving parts in order (:70-75)
     const int c = (cnt + G - 1) / G;
     const int lo = tid * c < cnt ? tid * c : cnt, hi = lo + c < cnt ? lo + c : cnt;

@@ -67,6 +67,18 @@ TKZ_DEV int scan_inclusive(int v) {
     return x;
 }
 TKZ_DEV int last_lane(int v) { return __builtin_amdgcn_readlane(v, 63); }
+// minimum over the 64 lanes (every lane gets it), on the same DPP moves as the scan: no LDS, no ballots
+TKZ_DEV uint32_t wave_min_u32(uint32_t v) {
+    const int l = lane();
+    uint32_t x = v, t;
+    t = (uint32_t)dpp_mov<0x111>((int)x); if ((l & 15) >= 1) x = t < x ? t : x;
+    t = (uint32_t)dpp_mov<0x112>((int)x); if ((l & 15) >= 2) x = t < x ? t : x;
+    t = (uint32_t)dpp_mov<0x114>((int)x); if ((l & 15) >= 4) x = t < x ? t : x;
+    t = (uint32_t)dpp_mov<0x118>((int)x); if ((l & 15) >= 8) x = t < x ? t : x;
+    t = (uint32_t)dpp_mov<0x142>((int)x); if ((l & 31) >= 16) x = t < x ? t : x;
+    t = (uint32_t)dpp_mov<0x143>((int)x); if (l >= 32) x = t < x ? t : x;
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
 // v_alignbit_b32: the low dword of ({hi, lo} >> (sh & 31)) -- an unaligned dword out of two aligned ones in ONE instruction
 TKZ_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 }  // namespace simt
