@@ -146,6 +146,7 @@ O200K_ALPHAS = {
     "mark": list("a\u0301\u0301!!/ \n\u4e2dA'sx"),
     "emoji": ["\U0001F600", "\u200d", "\ufe0f", "\u2764", "a", "A", " ", "\u4e2d", "!", "\U0001D400", "\U00020000", "1", "\uff11"],
     "slash": list("/\n!\u0301a A;*"),
+    "chain": list(";\n/*\u0301\u4e2d\r/\n"),          # `;\n/*\n/*...`: every link of such a chain costs the R4 / ABS iteration a round
     "upper": list("AB\u4e2d\u0301. a"),
     "all": list("aAzZ\u4e2d\u6587\u304b\u02b0\u0301\u0300\u00e9 \u00c9's'S'll'LL .,!/\n\r\t 12\uff13\u3000\u00a0\ufeff\u0085\u2028") +
            ["\U0001F600", "\u200d", "\ufe0f", "\U0001D400", "\U00020000", "\U0001D7D8"],
@@ -166,11 +167,16 @@ def o200k_gen(rng, a, n):
 
 
 def check_o200k_no_sync_points(lib, O, vocab):
-    """Blocks the o200k block scanners hand on (a row of nothing but '/') inside text without blanks, digits or line breaks: the sequential
-    kernel finds no sync point within its window and takes the block from HBM; next to a document where it does find them."""
+    """Blocks the o200k block scanners hand on inside text without blanks, digits or line breaks: the sequential kernel finds no sync point
+    within its window and takes the block from HBM; next to a document where it does find them.  What makes the char-level scanner hand a
+    block on here: a run of '/' that covers the block's CONTEXT row (the last 64 bytes before the block: what flows out of it is unknown);
+    the same run inside a block is followed through the rows (the second document)."""
     rng = random.Random(5)
     cjk = "".join(chr(0x4E00 + rng.randrange(2000)) for _ in range(7000))
-    docs = [(cjk[:3000] + "/" * 200 + cjk[3000:]).encode("utf-8"), ("A" + cjk[:2500] + "/" * 130 + "x y 1" + cjk[100:2000]).encode("utf-8")]
+    # blocks start every 3968 bytes: the runs cover bytes [3904, 3968) and [7872, 7936)
+    d0 = cjk[:1290] + "/" * 200 + cjk[1290:1290 + 1256] + "/" * 200 + cjk[3000:4000]
+    assert len(d0[:1290].encode("utf-8")) == 3870
+    docs = [d0.encode("utf-8"), ("A" + cjk[:2500] + "/" * 130 + "x y 1" + cjk[100:2000]).encode("utf-8")]
     data, offs = pack(docs)
     enc = N.Encoder(vocab, N.O200K)
     got = enc.pretokenize(data, offs)
@@ -359,7 +365,19 @@ def check_miss_lists(lib, O, vocab, ovocab, pattern=N.CL100K, seed=41):
                 ("a\nb\nc\nd\n" * 600).encode(),                                                      # 1024 pieces per sub-tile, all hits
                 "".join(rng.choice(cons) + "\n" for _ in range(2000)).encode(),
                 gib(700, 2, 3).encode() + ("x" * 1500).encode() + gib(700, 2, 16).encode()]           # a giant piece between crowded sub-tiles
-    for docs in (docs_small, docs_big, docs_small, docs_big[::-1]):
+    # k_place's two paths: sub-tiles whose lists straddle what it keeps in LDS (32 of each kind), whose token runs straddle kPlaceBig (8),
+    # with more than 256 pieces, and batches of tiny documents (up to four document starts in the four records a lane holds)
+    words = "the of and to in is that for it with as was on be at by this had not are but from or have an they which one you were her all".split()
+
+    def mixed(n, every, lo, hi):
+        out = []
+        while sum(map(len, out)) < n:
+            out.append(" " + rng.choice(words) if rng.randrange(every) else " " + "".join(rng.choice(cons) for _ in range(rng.randint(lo, hi))))
+        return "".join(out)[:n]
+
+    docs_place = [mixed(6000, e, lo, hi).encode() for (e, lo, hi) in ((8, 3, 9), (6, 4, 16), (7, 17, 30), (5, 2, 40), (9, 9, 12), (4, 17, 24))]
+    tiny = [rng.choice([b"a", b" b", b"\n", b"c d", b"qz", b" the", b"x\n\n", b" zqxj"]) for _ in range(5000)]
+    for docs in (docs_small, docs_big, docs_small, docs_big[::-1], docs_place, tiny, docs_place + tiny[:700] + docs_big[:2]):
         data, offs = pack(docs)
         ids, ooff = enc.encode_batch(data, offs)
         exp, eoff = oracle_encode_docs(oenc, docs)

@@ -93,9 +93,13 @@ def test_pretok_long_runs(lib, vocab, oracle_mod, pattern):
 
 
 def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod):
-    blocks, after_ascii, after_mb = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["cjk", "case", "emoji", "upper", "all", "mark", "slash"], range(12),
+    blocks, after_ascii, after_mb = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["cjk", "case", "emoji", "upper", "all", "mark", "slash", "chain"], range(12),
                                                               doc_lens=(3000, 9000, 20000, 100000))
-    assert after_ascii > 0 and after_mb < after_ascii // 2, (blocks, after_ascii, after_mb)
+    assert after_ascii > 0 and after_mb < after_ascii // 5, (blocks, after_ascii, after_mb)
+    # `;\n/*` (a '/' swallowed by the tail of a punctuation piece, then more punctuation) and rows of nothing but '/' and line breaks no longer
+    # send a block to the sequential matcher: the R4 / ABS flows are iterated and followed through the rows
+    b2, a2, m2 = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["mark", "slash"], range(12, 24))
+    assert a2 > 0 and 10 * m2 < a2, (b2, a2, m2)
     parity.check_o200k_no_sync_points(lib, oracle_mod, vocab)
 
 

@@ -1305,21 +1305,24 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
 // store instruction = 16 full lines; per-lane 4-byte stores at variable offsets wrote 1.8x the bytes); the token index (inside the
 // sub-tile) of every marked piece
 #ifndef TKZ_PLACE_OCC
-#define TKZ_PLACE_OCC 8
+#define TKZ_PLACE_OCC 7
 #endif
 constexpr int kPlaceRes = 32;                              // answers (and quads) of a sub-tile's miss lists k_place keeps in LDS (of each list; a sub-tile averages 14 short misses)
 constexpr int kPlacePer = 4;                               // consecutive sub-tiles per wavefront of k_place
-constexpr int kPlaceBig = 8;                               // token runs longer than this are copied by the whole wavefront, not staged
+constexpr int kPlaceBig = 8;                               // the general path: token runs longer than this are copied by the whole wavefront, not staged
+constexpr int kPlaceFastBig = 32;                          // the fast path takes sub-tiles whose longest token run is at most this (a lane copies its piece's tokens into the stage)
 constexpr int kStage = 64 * kPlaceBig + 16;                // staged ids: after a flush, the <= 64 x kPlaceBig ids of one batch of records + the alignment shift always fit
 // LDS of one wavefront of k_place: the staged ids, the first answers of the sub-tile's short-miss list and of the long one, and the quads
 // of those entries (the tokens of pieces of <= 4)
-constexpr int kPlaceLdsQuads = kStage / 4 + 2 * kPlaceRes + (2 * kPlaceRes) / 4;
-struct PlaceLds { int32_t* stage; uint4* quad; uint32_t* res; };
+// ... the token position of every kept entry's piece (the fast path: the lane that owns the record tells the lane that owns the entry)
+constexpr int kPlaceLdsQuads = kStage / 4 + 2 * kPlaceRes + (2 * kPlaceRes) / 4 + 1 + (2 * kPlaceRes) / 4;
+struct PlaceLds { int32_t* stage; uint4* quad; uint32_t* res; int32_t* pos; };
 TKZ_DEV PlaceLds tkz_place_lds(uint4* wave_quads) {
     PlaceLds L;
     L.stage = reinterpret_cast<int32_t*>(wave_quads);
     L.quad = wave_quads + kStage / 4;
-    L.res = reinterpret_cast<uint32_t*>(wave_quads + kStage / 4 + 2 * kPlaceRes);
+    L.res = reinterpret_cast<uint32_t*>(wave_quads + kStage / 4 + 2 * kPlaceRes);                       // 2 kPlaceRes answers + slot 2 kPlaceRes: "one token"
+    L.pos = reinterpret_cast<int32_t*>(wave_quads + kStage / 4 + 2 * kPlaceRes + (2 * kPlaceRes) / 4 + 1);
     return L;
 }
 // sub-tiles sub0 .. sub0 + kPlacePer - 1, by one wavefront
@@ -1329,6 +1332,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     int32_t* stage = LD.stage;
     uint32_t* s_res = LD.res;
     uint4* s_quad = LD.quad;
+    int32_t* s_pos = LD.pos;
     // A wavefront places kPlacePer consecutive sub-tiles, one after the other; what it needs to know about a sub-tile before it can ask for
     // its records (seven wave-uniform words) is requested while the sub-tile before it is placed: one of the sub-tile's three dependent
     // round trips leaves the chain.
@@ -1355,17 +1359,23 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     int gcnt = has_giant ? cur.gc : 0;
     if (gcnt < 0) gcnt = 0;
     const bool lists_ok = ns + nl <= P.mcap;               // (cut lists: the batch is redone, nothing of this pass is used)
-    {   // the answers of the merge kernels, in the same round trip as the first records
-        // lanes 0 .. kPlaceRes-1: the short list from the front; lanes kPlaceRes .. 2 kPlaceRes-1: the long list from the back
-        static_assert(2 * kPlaceRes <= 64, "one lane per kept entry");
+    // the answers of the merge kernels, in the same round trip as the first records
+    // lanes 0 .. kPlaceRes-1: the short list from the front; lanes kPlaceRes .. 2 kPlaceRes-1: the long list from the back
+    static_assert(2 * kPlaceRes == 64, "one lane per kept entry");
+    bool fast_ok;
+    {
         uint32_t a = 0;
         uint4 qd; qd.x = qd.y = qd.z = qd.w = 0;
         const int e = lane < kPlaceRes ? lane : lane - kPlaceRes;
-        const bool want = lists_ok && lane < 2 * kPlaceRes && e < (lane < kPlaceRes ? ns : nl);
+        const bool want = lists_ok && e < (lane < kPlaceRes ? ns : nl);
         const int64_t at = lane < kPlaceRes ? e : P.mcap - 1 - e;
         if (want) { a = tkz_load_nt(&ml[at]); qd = tkz_load16_nt(&mqd[at]); }
         (void)simt::ballot(true);                                // (the sub-tile before this one is done with them)
-        if (lane < 2 * kPlaceRes) { s_res[lane] = a; s_quad[lane] = qd; }
+        s_res[lane] = a; s_quad[lane] = qd; s_pos[lane] = -1;
+        if (lane == 0) s_res[2 * kPlaceRes] = tkz_result_inline(1);
+        // The fast path (below) takes a sub-tile whose lists are wholly in LDS and hold no token run longer than kPlaceFastBig, and that has
+        // no giant piece: nearly all of them.
+        fast_ok = lists_ok && !has_giant && ns <= kPlaceRes && nl <= kPlaceRes && !simt::ballot(want && tkz_result_cnt(a) > kPlaceFastBig);
     }
     (void)simt::ballot(true);
     // the answer a merge kernel left for a missed piece (its list entry): how many tokens, and where they wait
@@ -1407,24 +1417,81 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         (void)simt::ballot(true);
         flushed = upto; sbase = quad_base(upto);
     };
+    // ---- the fast path: FOUR CONSECUTIVE records per lane (one 16-byte load), so that 256 records cost one wave scan, one pass over the
+    // marks and one pass over the missed pieces instead of four of each -- k_place runs at the VALU issue limit, and what it issues is
+    // mostly per-batch overhead.  A record's token count comes from LDS without a branch (a hit reads the "one token" slot); the
+    // tokens of a missed piece are written by the lane that OWNS its list entry (lane e: entry e of the short list, lane kPlaceRes + e: entry e
+    // of the long one): the lane that holds the record only tells it the position. ----
+    auto place_fast = [&](int kk) -> bool {
+        const int k0 = kk + 4 * lane;
+        uint32_t r[4] = {0u, 0u, 0u, 0u};
+        if (k0 < np) {
+            if (pb + k0 + 4 <= P.prank_cap) { const uint4 v = tkz_load16_nt(&P.prank[pb + k0]); r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+            else for (int j = 0; j < 4; ++j) if (pb + k0 + j < P.prank_cap) r[j] = (uint32_t)P.prank[pb + k0 + j];
+        }
+        int c[4], idx[4];
+        bool ok[4], ms[4];
+        int t = 0, mk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ok[j] = k0 + j < np && pb + k0 + j < P.prank_cap;
+            ms[j] = ok[j] && (r[j] & kPrMiss);
+            idx[j] = (int)(r[j] & 1023u) + ((r[j] & kPrLong) ? kPlaceRes : 0);
+            const uint32_t a = s_res[ms[j] ? (idx[j] & (2 * kPlaceRes - 1)) : 2 * kPlaceRes];
+            c[j] = ok[j] ? tkz_result_cnt(a) : 0;
+            t += c[j];
+            mk += (ok[j] && (r[j] & kPrMark)) ? 1 : 0;
+        }
+        int both;
+        const int pre = tkz_wave_scan_sum(t | (mk << 20), &both);
+        const int tot = both & 0xFFFFF, mtot = both >> 20;
+        if (running + tot - sbase > kStage) {
+            if (flushed < running) flush(running);
+            if (running + tot - sbase > kStage) return false;        // (more than two tokens a record: the general path, 64 records at a time)
+        }
+        int pos = running + (pre & 0xFFFFF), mi = marks + (pre >> 20);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ok[j] && (r[j] & kPrMark)) P.doc_tok[ord0 + mi++] = pos;
+            if (ms[j]) s_pos[idx[j] & (2 * kPlaceRes - 1)] = pos;
+            else if (ok[j]) stage[pos - sbase] = (int32_t)(r[j] & kPrRankMask);
+            pos += c[j];
+        }
+        (void)simt::ballot(true);
+        {   // the missed pieces of this chunk, by the lanes that own their entries
+            const int p = s_pos[lane];
+            if (p >= 0) {                                        // (set once per entry, by the lane that holds its record)
+                const uint32_t ans = s_res[lane];
+                const int cnt = tkz_result_cnt(ans);
+                int32_t* dst = stage + (p - sbase);
+                if (ans & kMrInline) {
+                    const uint4 q = s_quad[lane];
+                    dst[0] = (int32_t)q.x;
+                    if (cnt > 1) dst[1] = (int32_t)q.y;
+                    if (cnt > 2) dst[2] = (int32_t)q.z;
+                    if (cnt > 3) dst[3] = (int32_t)q.w;
+                } else {
+                    const int32_t* src = token_src(ans);
+                    for (int i = 0; i < cnt; ++i) dst[i] = src[i];
+                }
+                s_pos[lane] = -1;
+            }
+        }
+        running += tot; marks += mtot;
+        return true;
+    };
 #pragma unroll 1
     for (int kk = 0; kk < np; kk += 256) {                     // four record loads in flight per lane
-      uint32_t r4[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-          const int k = kk + 64 * j + lane;
-          r4[j] = (k < np && pb + k < P.prank_cap) ? (uint32_t)tkz_load_nt(&P.prank[pb + k]) : 0u;
-      }
-      uint32_t a4[4];                                        // the merge kernels' answers for the missed pieces of the four chunks
-#pragma unroll
-      for (int j = 0; j < 4; ++j) a4[j] = (r4[j] & kPrMiss) ? answer(r4[j]) : 0u;
-#pragma unroll
+      if (fast_ok && place_fast(kk)) continue;
+      // ---- the general path (giant pieces, long token runs, lists longer than LDS keeps): 64 records at a time ----
+#pragma unroll 1
       for (int j = 0; j < 4; ++j) {
         const int k0 = kk + 64 * j;
         if (k0 >= np) break;
         const int k = k0 + lane;
         const bool valid = k < np && pb + k < P.prank_cap;
-        const uint32_t rec = r4[j], res = a4[j];
+        const uint32_t rec = valid ? (uint32_t)tkz_load_nt(&P.prank[pb + k]) : 0u;
+        const uint32_t res = (rec & kPrMiss) ? answer(rec) : 0u;           // the merge kernels' answer for a missed piece
         const bool miss = (rec & kPrMiss) != 0;
         const int cnt = !valid ? 0 : !miss ? 1 : (rec & kPrGiant) ? gcnt : tkz_result_cnt(res);
         int tot;

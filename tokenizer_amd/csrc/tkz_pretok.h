@@ -1112,7 +1112,8 @@ TKZ_DEV bool tkz_block_eval_o200k(const uint8_t* stage, uint64_t ds, const TkzBl
 // it is, of a word otherwise.  An O char (other, not a mark) opens an R4 piece when it follows a blank or is not followed by a
 // word char (then it would be the one-char prefix of the word), and every O / mark behind one that is in R4 is in R4: a
 // forward flow through runs of O|M.  The tail `[\r\n/]*` (ABS) follows an R4 char; a '/' swallowed by it is NOT an R4 char
-// for what follows, which the flow above ignores: a block where a swallowed '/' is followed by another O / mark is refused.
+// for what follows (`;\n/*`: the '*' stands on its own again), while the tail itself begins behind an R4 char: the two flows
+// depend on each other from left to right and are iterated (tkz_block_core_o200k), both followed through whole rows.
 // Everything else (digits, white space, contraction suffixes) is tkz_block_eval_o200k's algebra on n <= 64 chars.
 // Refused blocks (return false) are matched sequentially; that is the definition, so refusing is always safe.
 // =================================================================================================
@@ -1165,33 +1166,67 @@ TKZ_DEV bool tkz_block_core_o200k(const TkzO2Chars& c, const TkzBlockCtx& X, uin
     const uint64_t pW = ((W << 1) | ((pb >> 7) & 1)) & nds & all, pCR = ((CR << 1) | ((pb >> 8) & 1)) & nds & all;
     const uint64_t pN = ((N << 1) | ((pb >> 4) & 1)) & nds & all;
     const uint64_t nWd = ((Wd >> 1) | ((uint64_t)((nb & 15) ? 1 : 0) << top)) & ~KN & all;
-    // ---- R4: which O / mark chars belong to a ` ?[^\s\p{L}\p{N}]+` piece ----
-    const uint64_t gR4 = O & (pSP | ~nWd) & all;
-    const uint64_t PR = Oc & nds & all;
-    const bool propR = PR == all && gR4 == 0;
-    const uint32_t genR = bit(tkz_fill_up64(gR4, PR | gR4), top);
-    uint32_t cinR;
-    {
-        const uint64_t pm = simt::ballot(propR);
-        if (pm) {
-            if (pm & 1ull) {                                   // lane 0 is context: what flows out of it is unknown
-                const int lp = tkz_ctz64z(~pm);
-                if (lp >= 2) return tkz_o2_refuse(1);
-                if (simt::ballot(lane == 1 && (PR & ~gR4 & 1ull))) return tkz_o2_refuse(2);
-            }
-            cinR = tkz_scan_flow(propR, genR, 0u);
-        } else {
-            cinR = simt::shflu(genR, (lane + 63) & 63);
-            if (lane == 0) cinR = 0;
-        }
-    }
-    const uint64_t T = tkz_fill_up64(gR4 | (cinR ? (PR & 1ull) : 0ull), PR | gR4);     // chars in R4
-    const uint64_t pR4 = ((T << 1) | cinR) & nds & all;
-    // ---- ABS: the tail `[\r\n/]*` of an R4 piece ----
+    // ---- R4 and ABS: which O / mark chars belong to a ` ?[^\s\p{L}\p{N}]+` piece (T), which CR / LF / '/' its tail `[\r\n/]*`
+    // swallows (ABS).  Left to right:   ABS(i) = Rabs(i) & (ABS(i-1) | (CR(i) & T(i-1)))      Rabs = CR | LF | '/'
+    //                                   T(i)   = Oc(i) & ~ABS(i) & (gR4(i) | T(i-1))
+    // -- a swallowed '/' is not an R4 char for what follows (`;\n/*`: the '*' is on its own again) while ABS needs T at its seeds.
+    // Both are fills along runs, so they are iterated: round 1 ignores the cuts (exact unless a swallowed '/' is followed by an
+    // O / mark that is not a '/'), every further round is exact one more such link to the right; kO2Rounds of them, then the block is
+    // refused.  Both states cross rows (a row of nothing but O / marks, of nothing but CR / LF / '/'): lane scans. ----
+    const uint64_t gR4all = O & (pSP | ~nWd) & all;
+    const uint64_t PRall = Oc & nds & all;
     const uint64_t Rabs = (CR | SL) & nds & all;
-    if (simt::ballot(Rabs == all)) return tkz_o2_refuse(3);               // a row of nothing but CR / LF / '/': the absorbed state would cross it
-    const uint64_t seeds = CR & pR4;
-    const uint64_t ABS0 = tkz_fill_up64(seeds & Rabs, Rabs);
+    const uint64_t nOcNS = (((Oc & ~SL) >> 1) | ((uint64_t)((((nb >> 3) & 1) | ((nb >> 5) & 1)) & (((nb >> 10) & 1) ^ 1)) << top)) & ~KN & all;
+    constexpr int kO2Rounds = 4;
+    {   // lane 0 is context: its leading run of O / marks that open no piece of their own is in R4 or not as the (unknown) char before the row
+        // says; a CR / LF right behind that run followed by CR / LF / '/' up to the end of the row would carry the guess into row 1
+        const int lead = tkz_ctz64z(~(PRall & ~gR4all));
+        const bool carried = lane == 0 && lead > 0 && lead < n && bit(CR & Rabs, lead) && (Rabs >> lead) == (all >> lead);
+        if (simt::ballot(carried)) return tkz_o2_refuse(12);
+    }
+    uint64_t T = 0, ABS = 0, seeds = 0;
+    uint32_t cinR = 0, abs_in = 0;
+    for (int round = 0;; ++round) {
+        const uint64_t gR4 = gR4all & ~ABS, PR = PRall & ~ABS;          // (round 0: ABS = 0, no cuts)
+        const bool propR = PR == all && gR4 == 0;
+        const uint32_t genR = bit(tkz_fill_up64(gR4, PR | gR4), top);
+        {
+            const uint64_t pm = simt::ballot(propR);
+            if (pm) {
+                if (pm & 1ull) {                                   // lane 0 is context: what flows out of it is unknown
+                    const int lp = tkz_ctz64z(~pm);
+                    if (lp >= 2) return tkz_o2_refuse(1);
+                    if (simt::ballot(lane == 1 && (PR & ~gR4 & 1ull))) return tkz_o2_refuse(2);
+                }
+                cinR = tkz_scan_flow(propR, genR, 0u);
+            } else {
+                cinR = simt::shflu(genR, (lane + 63) & 63);
+                if (lane == 0) cinR = 0;
+            }
+        }
+        T = tkz_fill_up64(gR4 | (cinR ? (PR & 1ull) : 0ull), PR | gR4);     // chars in R4
+        seeds = CR & ((T << 1) | cinR) & nds & all;                       // a CR / LF right behind an R4 char opens the tail
+        const uint32_t genA = bit(tkz_fill_up64(seeds & Rabs, Rabs), top);
+        const bool propA = Rabs == all && !genA;                           // a row of nothing but CR / LF / '/' (and no tail of its own): the absorbed state crosses it
+        {
+            const uint64_t pm = simt::ballot(propA);
+            if (pm) {
+                if (pm & 1ull) return tkz_o2_refuse(3);             // lane 0 is context: what flows out of it is unknown
+                abs_in = tkz_scan_flow(propA, genA, 0u);
+            } else {
+                abs_in = simt::shflu(genA, (lane + 63) & 63);
+                if (lane == 0) abs_in = 0;
+            }
+        }
+        const uint64_t ABSn = tkz_fill_up64((seeds | (abs_in ? (Rabs & 1ull) : 0ull)) & Rabs, Rabs);
+        const bool changed = ABSn != ABS;
+        ABS = ABSn;
+        // (round 0: T ran through the swallowed '/' chars; that is wrong only where such a char is followed by an O / mark that is not a '/')
+        if (round == 0 ? !simt::ballot((SL & ABS & nOcNS) != 0) : !simt::ballot(changed)) break;
+        if (round == kO2Rounds) return tkz_o2_refuse(8);
+    }
+    const uint64_t ABS0 = ABS;
+    const uint64_t pR4 = ((T << 1) | cinR) & nds & all;
     // ---- the two states that can cross whole rows: digit phase, CR/LF further on in the white-space run (tkz_block_core) ----
     const uint64_t Q = N & pN;
     int carry_in;
@@ -1248,13 +1283,7 @@ TKZ_DEV bool tkz_block_core_o200k(const TkzO2Chars& c, const TkzBlockCtx& X, uin
     const uint32_t c2p = p2b & 3, c3p = (p2b >> 2) & 7;
     const uint64_t cover = ((g2 << 1) | (g3 << 1) | (g3 << 2) |
                             (uint64_t)(((c2p >> 1) | (c3p >> 1) | (c3p >> 2)) & 1) | ((uint64_t)((c3p >> 2) & 1) << 1)) & all;
-    const uint32_t abs_in = (p2b >> 6) & 1;
-    const uint64_t ABS = abs_in ? tkz_fill_up64((seeds | (Rabs & 1ull)) & Rabs, Rabs) : ABS0;
     const uint64_t pABS = ((ABS << 1) | (uint64_t)abs_in) & all;
-    {   // a swallowed '/' followed by an O / mark that is not a '/': the R4 flow above would run through it
-        const uint64_t nOcNS = (((Oc & ~SL) >> 1) | ((uint64_t)((((nb >> 3) & 1) | ((nb >> 5) & 1)) & (((nb >> 10) & 1) ^ 1)) << top)) & ~KN & all;
-        if (simt::ballot((SL & ABS & nOcNS) != 0)) return tkz_o2_refuse(8);
-    }
     // ---- word runs: chars, run starts, the S1 flow (rule a) and the trailing-U flow (rule b) ----
     const uint64_t rs = (ds | contrEnd) & all;
     const uint64_t Up = U & ~cover, lp = l & ~cover, Yp = (Xl | (M & ~T)) & all, Wdp = Up | lp | Yp;

@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpu", action="store_true")
-    ap.add_argument("--kinds", default="cjk,case,mark,emoji,slash,upper,all")
+    ap.add_argument("--kinds", default="cjk,case,mark,emoji,slash,chain,upper,all")
     ap.add_argument("--seeds", type=int, default=5)
     ap.add_argument("--first-seed", type=int, default=0)
     args = ap.parse_args()
