@@ -121,6 +121,7 @@ inline int last_lane(int v) { return (int)(uint32_t)hipemu::wave_exchange((uint3
 inline uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u)); }
 inline int atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomic_or(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+inline unsigned atomic_and(unsigned* p, unsigned v) { unsigned o = *p; *p = o & v; return o; }
 inline unsigned atomic_max(unsigned* p, unsigned v) { unsigned o = *p; if (v > o) *p = v; return o; }
 inline unsigned atomic_cas(unsigned* p, unsigned expect, unsigned v) { unsigned o = *p; if (o == expect) *p = v; return o; }
 inline void fence() {}

@@ -2,7 +2,9 @@
 the C ABI above them) compiled against the fiber SIMT emulator of tests/hostemu/ and compared with the
 oracle.  Sizes are small (the emulator runs one workgroup at a time); the same checks run at full size
 on the GPU in test_gpu_parity.py."""
+import gzip
 import json
+import os
 
 import numpy as np
 import pytest
@@ -278,3 +280,16 @@ def test_reference_unit_tests_restated(lib, gpt2_tiktoken_bytes, lib_rs_bytes, o
 
 def test_adversarial_rank_tables(lib, oracle_mod):
     parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=12, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 1024, 1025], n_pieces=60)
+
+
+def test_giant_tail_on_adversarial_rank_tables(oracle_mod):
+    """The batched tail of the giant-piece merger (tkz_bpe_long_tail: one proposal per block of 32 parts, every proposal below the bound
+    applied at once) on rank tables that are NOT trained vocabularies -- new pairs rank below the pair just merged, ranks tie, ranks go up to
+    2^26 --, in a build that hands every giant piece to the tail (the rounds would finish such pieces on their own); from both entry points
+    (state in LDS; ids left in the pool) and on long diverse pieces under a real table."""
+    import emu
+    lib = emu.tail_library()
+    for seed in (0, 1):
+        parity.check_random_vocab(lib, oracle_mod, seed, 3, [1100, 1500, 2300, 4000, 7000], 3)
+    raw = gzip.decompress(open(os.path.join(os.path.dirname(__file__), "golden", "gpt2.tiktoken.gz"), "rb").read())
+    parity.check_long_diverse_pieces(lib, oracle_mod, N.Vocab(raw, lib), oracle_mod.Vocab(raw), lens=(1500, 18000, 33000), seed=3)

@@ -341,8 +341,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
 #ifdef TKZ_DEVPROF
             { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
             if (P.ablate & 16) {
-                if (!g_devprof) { HIP_TRY(hipMalloc((void**)&g_devprof, 16 * 8)); }
-                HIP_TRY(hipMemsetAsync(g_devprof, 0, 16 * 8, stream));
+                if (!g_devprof) { HIP_TRY(hipMalloc((void**)&g_devprof, 32 * 8)); }
+                HIP_TRY(hipMemsetAsync(g_devprof, 0, 32 * 8, stream));
             }
             P.devprof = g_devprof;
 #endif
@@ -381,13 +381,15 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         if (e->profiling) prof_collect(ws);
 #ifdef TKZ_DEVPROF
         if (g_devprof && getenv("TKZ_DEV_ABLATE") && (atoi(getenv("TKZ_DEV_ABLATE")) & 16) && !d_bitmap_only) {
-            unsigned long long h[16];
+            unsigned long long h[32];
             HIP_TRY(hipMemcpy(h, g_devprof, sizeof h, hipMemcpyDeviceToHost));
             const double w = h[0] ? (double)h[0] : 1.0;
             fprintf(stderr, "[tkz devprof] k_probe waves %llu  clock ticks/wave: total %.0f  load+compact %.0f  short batches %.0f  mid batches %.0f | mid pieces/wave %.1f pieces/wave %.1f\n",
                     h[0], h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w);
-            if (h[8]) fprintf(stderr, "[tkz devprof] k_giant_merge pieces %llu  clock ticks/piece: global-memory rounds %.0f  LDS rounds %.0f | bytes/piece %.0f tokens/piece %.0f | slowest piece %llu ticks | rounds/piece: global %.0f LDS %.0f\n",
-                              h[8], (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[12] / h[8], h[13], (double)h[14] / h[8], (double)h[15] / h[8]);
+            if (h[8]) fprintf(stderr, "[tkz devprof] k_giant_merge pieces %llu  clock ticks/piece: global-memory rounds %.0f  LDS rounds %.0f | bytes/piece %.0f tokens/piece %.0f | slowest piece %llu ticks | rounds/piece: global %.0f LDS %.0f | parts/piece when the tail took over %.0f\n",
+                              h[8], (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[12] / h[8], h[13], (double)h[14] / h[8], (double)h[15] / h[8], (double)h[7] / h[8]);
+            if (h[16]) fprintf(stderr, "[tkz devprof] tail: batches %llu merges %llu (%.2f a batch) proposals/batch %.1f | batches capped by two proposals that meet %llu | ticks/batch %.0f | longest tail: %llu batches, %llu ticks\n",
+                               h[16], h[17], (double)h[17] / h[16], (double)h[18] / h[16], h[19], (double)h[22] / h[16], h[20], h[23]);
         }
 #endif
         e->last_xcount = (int64_t)ws->h_counters->xcount; e->last_xcount2 = (int64_t)ws->h_counters->xcount2;

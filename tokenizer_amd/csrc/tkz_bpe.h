@@ -510,6 +510,9 @@ TKZ_DEV int tkz_block_exclusive_max(int v) {
 // probe that a sixteenth of all pairs share says "homogeneous": such a piece stays with the rounds.  Called by the whole workgroup.
 TKZ_DEV bool tkz_bpe_long_homogeneous(const int32_t* pr, int cnt) {
     const int tid = simt::tid(), G = simt::nthreads();
+#ifdef TKZ_TAIL_ALWAYS       // (development / test builds: every piece the rounds are slow on -- with TKZ_TAIL_FEW set high: every piece -- goes to the tail)
+    return false;
+#endif
     if (cnt < 64) return false;
     const int32_t v1 = pr[cnt / 4], v2 = pr[cnt / 2], v3 = pr[(3 * cnt) / 4];
     const int c = (cnt + G - 1) / G;
@@ -717,76 +720,136 @@ TKZ_DEV uint32_t tkz_tail_id(const int32_t* ids, const int32_t* pr, const uint32
     const bool merged = x + 1 < cnt && !((alive[(x + 1) >> 5] >> ((x + 1) & 31)) & 1u);
     return merged ? ((uint32_t)pr[x + 1] & ~kTailDead) : (uint32_t)ids[x];
 }
+// Many merges per round trip, exactly.  Thread b of the workgroup owns block b (32 consecutive slots) and proposes the block's smallest
+// pair (rank, then position): its neighbours, their ids and the two pair ranks the merge would create are looked up by all threads at
+// once -- one trip to the pair table for up to 1024 merges instead of one each.  Which of them may be applied NOW is decided from
+// `bound`_b = the smallest key that could come before anything else once b's proposal has merged: the second smallest pair of the block,
+// the two pairs the merge creates.  With tau = the minimum of all bounds, every proposal below tau is -- at its turn in the reference's
+// order (BytePairEncoder.cs:47-54) -- the leftmost minimum of the whole piece with the neighbourhood it was looked up in: nothing that is
+// not itself such a proposal can precede it.  Two proposals interfere exactly when the part of one is among the two parts behind the other
+// (the one it swallows, the one it is paired with next): tau is capped at the later of the two.  The global minimum is always applied.
+// Keys: rank << 10 | block, 64 bits (<= 1024 blocks; equal keys count as "not below": the next batch takes them).
+// scratch: 8 * nthreads + 2 * nthreads + 16 * (nthreads / 64) bytes of LDS behind the alive bits.
 template <bool IDS_LDS>
-TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_t* pr, uint32_t* alive, int32_t* bmin) {
-    const int tid = simt::tid(), lane = simt::lane();
-    const int nblk = (cnt + kTailBlock - 1) / kTailBlock, nw = (cnt + 31) >> 5;
+TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_t* pr, uint32_t* alive, void* scratch, unsigned long long* prof = nullptr) {
+    const int tid = simt::tid(), lane = simt::lane(), wave = simt::wave(), G = simt::nthreads();
+    const int nblk = (cnt + kTailBlock - 1) / kTailBlock, nw = (cnt + 31) >> 5;       // (nblk <= G: cnt <= kBpeTailCap, 1024 threads)
+    constexpr uint32_t NONE = (uint32_t)TKZ_RANK_NONE;
+    constexpr uint64_t NOKEY = ~0ull;                           // (keys: 64 bits -- ranks go up to TKZ_MAX_RANK = 2^27)
+    uint64_t* s_key = reinterpret_cast<uint64_t*>(scratch);
+    uint16_t* s_j = reinterpret_cast<uint16_t*>(s_key + G);
+    uint64_t* s_red = reinterpret_cast<uint64_t*>(s_j + G);
+    auto wave_min_key = [](uint64_t v) -> uint64_t {
+        const uint32_t hi = (uint32_t)(v >> 32), mh = simt::wave_min_u32(hi);
+        const uint32_t ml = simt::wave_min_u32(hi == mh ? (uint32_t)v : 0xFFFFFFFFu);
+        return ((uint64_t)mh << 32) | ml;
+    };
+    auto make_key = [](uint32_t rank, int blk) -> uint64_t { return rank >= (uint32_t)TKZ_RANK_NONE ? ~0ull : (((uint64_t)rank << 10) | (uint64_t)(uint32_t)blk); };
     // (the last part never has a pair: its pr is TKZ_RANK_NONE already; slots beyond cnt are padded so that whole blocks can be read)
-    for (int i = cnt + tid; i < nblk * kTailBlock; i += simt::nthreads()) pr[i] = TKZ_RANK_NONE;
-    for (int w = tid; w < nw; w += simt::nthreads()) alive[w] = tkz_lowmask32(cnt - 32 * w);
+    for (int i = cnt + tid; i < nblk * kTailBlock; i += G) pr[i] = TKZ_RANK_NONE;
+    for (int w = tid; w < nw; w += G) alive[w] = tkz_lowmask32(cnt - 32 * w);
     simt::sync();
-    for (int b = tid; b < ((nblk + 63) & ~63); b += simt::nthreads()) {
-        int32_t mn = TKZ_RANK_NONE;
-        if (b < nblk) for (int k = 0; k < kTailBlock; ++k) { const int32_t r = pr[b * kTailBlock + k]; mn = r < mn ? r : mn; }
-        bmin[b] = mn;
-    }
-    simt::sync();
-    if (simt::wave() == 0) {
-        const int per = ((nblk + 63) >> 6);                       // block minima per lane (consecutive)
-        auto block_min = [&](int b) {                            // recomputes bmin[b]: one part per lane of the lower half
-            // (a dead slot holds TKZ_RANK_NONE or kTailDead | id: as unsigned values both lie at or above TKZ_RANK_NONE)
-            uint32_t v = lane < kTailBlock ? (uint32_t)pr[b * kTailBlock + lane] : (uint32_t)TKZ_RANK_NONE;
-            if (v > (uint32_t)TKZ_RANK_NONE) v = (uint32_t)TKZ_RANK_NONE;
-            const uint32_t mn = simt::wave_min_u32(v);
-            if (lane == 0) bmin[b] = (int32_t)mn;
-        };
-        for (;;) {
-            // leftmost strict minimum (:47-54): the minimum over the block minima, the first block that has it, the first part in it
-            uint32_t mymin = (uint32_t)TKZ_RANK_NONE;
-            int myblk = 0;
-            for (int k = 0; k < per; ++k) {
-                const int b = lane * per + k;
-                const uint32_t v = b < nblk ? (uint32_t)bmin[b] : (uint32_t)TKZ_RANK_NONE;
-                if (v < mymin) { mymin = v; myblk = b; }
+    static_assert(kTailBlock == 32, "eight quads a block");
+    const int blk = tid;
+    const bool owner = blk < nblk;
+    long long n_batch = 0, n_merge = 0, n_cand = 0, n_cap = 0;
+    const long long tq0 = prof ? simt::clock() : 0;
+    for (;;) {
+        // ---- the block's smallest pair (leftmost of its rank) and its second smallest ----
+        // (a dead slot holds TKZ_RANK_NONE or kTailDead | id: as unsigned values both lie at or above TKZ_RANK_NONE)
+        uint32_t m = NONE, s2 = NONE;
+        int jj = 0;
+        if (owner) {
+            const uint4* q = reinterpret_cast<const uint4*>(pr + blk * kTailBlock);
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = q[k];             // (eight 16-byte reads, requested together)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t x = w4[i];
+                    if (x < m) { s2 = m; m = x; jj = 4 * k + i; } else if (x < s2) s2 = x;
+                }
             }
-            const uint32_t m = simt::wave_min_u32(mymin);
-            if (m == (uint32_t)TKZ_RANK_NONE) break;             // minRank == int.MaxValue (:65-68)
-            const uint64_t has = simt::ballot(mymin == m);
-            const int b0 = simt::shfl(myblk, tkz_ctz64(has));
-            const uint64_t hit = simt::ballot(lane < kTailBlock && (uint32_t)pr[b0 * kTailBlock + lane] == m);
-            const int j = b0 * kTailBlock + tkz_ctz64(hit);
+        }
+        const uint64_t k1 = make_key(m, blk), key2 = make_key(s2, blk);
+        const bool cand = k1 != NOKEY;
+        const int j = blk * kTailBlock + jj;
+        s_key[tid] = k1;
+        s_j[tid] = (uint16_t)j;
+        // ---- the neighbours of the proposal, and what its merge would create ----
+        uint64_t bound = NOKEY;
+        bool hasl = false, hasr = false;
+        int r = 0, l = 0, rr = -1;
+        int32_t rkr = TKZ_RANK_NONE, rkl = TKZ_RANK_NONE;
+        if (cand) {
             // r: the part being swallowed (the next one alive after j), rr: the one after it, l: the one before j
             int w = (j + 1) >> 5;
             uint32_t bits = w < nw ? alive[w] & (0xFFFFFFFFu << ((j + 1) & 31)) : 0u;
             while (!bits && ++w < nw) bits = alive[w];
-            const int r = 32 * w + tkz_ctz32(bits);              // exists: pr[j] was a rank
+            r = 32 * w + tkz_ctz32(bits);                        // exists: pr[j] was a rank
             bits &= bits - 1;
             while (!bits && ++w < nw) bits = alive[w];
-            const bool hasr = bits != 0;
-            const int rr = hasr ? 32 * w + tkz_ctz32(bits) : 0;
+            hasr = bits != 0;
+            rr = hasr ? 32 * w + tkz_ctz32(bits) : -1;
             w = j >> 5;
             bits = alive[w] & tkz_lowmask32(j & 31);
             while (!bits && --w >= 0) bits = alive[w];
-            const bool hasl = bits != 0;
-            const int l = hasl ? 32 * w + tkz_msb32(bits) : 0;
-            const uint32_t idr = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, rr), idl = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, l);
-            const int32_t rkr = hasr ? tkz_lookup_pair(T, m, idr) : TKZ_RANK_NONE;        // (:58)
-            const int32_t rkl = hasl ? tkz_lookup_pair(T, idl, m) : TKZ_RANK_NONE;        // (:59-62)
-            (void)simt::ballot(true);                            // (every lane has read the state: now it changes)
-            if (lane == 0) {
-                alive[r >> 5] &= ~(1u << (r & 31));              // RemoveAt(j + 1) (:63)
-                pr[r] = TKZ_RANK_NONE;
-                if (IDS_LDS) ids[j] = (int32_t)m;                // the merged part carries the rank it was found under ...
-                else pr[j + 1] = (int32_t)(kTailDead | m);       // ... in the slot behind it (dead since this part's first merge: r == j + 1 then)
-                pr[j] = rkr;
-                if (hasl) pr[l] = rkl;
-            }
-            (void)simt::ballot(true);
-            const int bj = j / kTailBlock, br = r / kTailBlock, bl = l / kTailBlock;
-            block_min(bj);
-            if (br != bj) block_min(br);
-            if (hasl && bl != bj) block_min(bl);
-            (void)simt::ballot(true);
+            hasl = bits != 0;
+            l = hasl ? 32 * w + tkz_msb32(bits) : 0;
+            const uint32_t idr = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, hasr ? rr : 0), idl = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, l);
+            rkr = hasr ? tkz_lookup_pair(T, m, idr) : TKZ_RANK_NONE;        // (:58)
+            rkl = hasl ? tkz_lookup_pair(T, idl, m) : TKZ_RANK_NONE;        // (:59-62)
+            const uint64_t nkr = make_key((uint32_t)rkr, j >> 5), nkl = make_key((uint32_t)rkl, l >> 5);
+            bound = key2 < nkr ? key2 : nkr;
+            if (nkl < bound) bound = nkl;
+        }
+        simt::sync();                                            // (every proposal is posted)
+        if (cand) {
+            auto meets = [&](int p) {
+                const int f = p >> 5;
+                if (p < 0 || f == blk) return;
+                const uint64_t kf = s_key[f];
+                if (kf != NOKEY && (int)s_j[f] == p) { const uint64_t later = kf > k1 ? kf : k1; if (later < bound) bound = later; }
+            };
+            meets(r); meets(rr);
+        }
+        {
+            const uint64_t wg = wave_min_key(k1), wt = wave_min_key(bound);
+            if (lane == 0) { s_red[2 * wave] = wg; s_red[2 * wave + 1] = wt; }
+        }
+        simt::sync();
+        uint64_t g, tau;
+        {
+            const int nwv = G >> 6;
+            const uint64_t a = lane < nwv ? s_red[2 * lane] : NOKEY, c = lane < nwv ? s_red[2 * lane + 1] : NOKEY;
+            g = wave_min_key(a); tau = wave_min_key(c);
+        }
+        if (g == NOKEY) break;                                   // minRank == int.MaxValue (:65-68)
+        const bool go = cand && (k1 == g || k1 < tau);
+        if (prof) {                                              // (development builds: how many merges a trip to the pair table buys)
+            const int ng = tkz_popc64(simt::ballot(go)), nc = tkz_popc64(simt::ballot(cand));
+            if (tid == 0) ++n_batch;
+            if (lane == 0) { n_merge += ng; n_cand += nc; }
+        }
+        if (go) {
+            simt::atomic_and(&alive[r >> 5], ~(1u << (r & 31)));   // RemoveAt(j + 1) (:63)  (two threads may clear bits of one word)
+            pr[r] = TKZ_RANK_NONE;
+            if (IDS_LDS) ids[j] = (int32_t)m;                    // the merged part carries the rank it was found under ...
+            else pr[j + 1] = (int32_t)(kTailDead | m);           // ... in the slot behind it (dead since this part's first merge: r == j + 1 then)
+            pr[j] = rkr;
+            if (hasl) pr[l] = rkl;
+        }
+        simt::sync();
+    }
+    if (prof && lane == 0) {
+        simt::atomic_add64(&prof[17], (unsigned long long)n_merge); simt::atomic_add64(&prof[18], (unsigned long long)n_cand);
+        if (tid == 0) {
+            simt::atomic_add64(&prof[16], (unsigned long long)n_batch); simt::atomic_add64(&prof[19], (unsigned long long)n_cap);
+            simt::atomic_max64(&prof[20], (unsigned long long)n_batch);
+            simt::atomic_add64(&prof[22], (unsigned long long)(simt::clock() - tq0)); simt::atomic_max64(&prof[23], (unsigned long long)(simt::clock() - tq0));
         }
     }
     simt::sync();
@@ -824,9 +887,9 @@ constexpr int kBpeLongLds = 16384;
 #endif
 constexpr int kBpeTailFew = TKZ_TAIL_FEW;      // rounds in LDS that merge fewer pairs than this (three in a row) hand the piece to the one-merge-at-a-time tail
 constexpr int kBpeTailFewGlobal = TKZ_TAIL_FEW_GLOBAL;   // ... rounds in global memory (~150 us each, ten times an LDS round)
-constexpr int kBpeTailCap = 32768;             // parts whose pair ranks, alive bits and block minima fit the 9 * kBpeLongLds bytes of LDS
+constexpr int kBpeTailCap = 32768;             // parts whose pair ranks and alive bits, with the tail's scratch, fit the 9 * kBpeLongLds bytes of LDS (one thread a block of 32)
 static_assert(kBpeLongLds / 8 + (kBpeLongLds / 32 + 64) * 4 <= kBpeLongLds, "alive bits + block minima fit the flag area");
-static_assert(kBpeTailCap * 4 + kBpeTailCap / 8 + (kBpeTailCap / 32 + 64) * 4 <= 9 * kBpeLongLds, "the tail's state for kBpeTailCap parts fits the workgroup's LDS");
+static_assert(kBpeTailCap * 4 + kBpeTailCap / 8 + 1024 * 10 + 16 * 16 <= 9 * kBpeLongLds && kBpeTailCap / 32 <= 1024, "the tail's state for kBpeTailCap parts (pair ranks, alive bits, scratch of 1024 threads) fits the workgroup's LDS");
 template <class ByteAt>
 TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, int32_t* prA, int32_t* s1g, int32_t* s2g,
                          int32_t* idsB, int32_t* prB, int32_t* dst, int* err, int32_t* lds = nullptr, unsigned long long* prof = nullptr) {
@@ -866,10 +929,11 @@ TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, in
             // the parts have now staying where they are, in global memory.
             int32_t* lpr = lds;
             uint32_t* alive = reinterpret_cast<uint32_t*>(lds + kBpeTailCap);
-            int32_t* bmin = reinterpret_cast<int32_t*>(alive + kBpeTailCap / 32);
+            void* bmin = alive + kBpeTailCap / 32;                // (the tail's scratch)
             for (int k = tid; k < cnt; k += G) lpr[k] = pr[k];
             simt::sync();
-            tkz_bpe_long_tail<false>(T, cnt, ids, lpr, alive, bmin);
+            if (prof && tid == 0) simt::atomic_add64(&prof[7], (unsigned long long)cnt);
+            tkz_bpe_long_tail<false>(T, cnt, ids, lpr, alive, bmin, prof);
             const int tot = tkz_bpe_long_tail_emit<false>(cnt, ids, lpr, alive, dst, err);
             finish_prof(tot);
             return tot;
@@ -885,8 +949,9 @@ TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, in
     if (tail) {
         // what the rounds left: one merge at a time, by one wavefront (tkz_bpe_long_tail); then the survivors, in order
         uint32_t* alive = reinterpret_cast<uint32_t*>(lds + 2 * kBpeLongLds);              // (the flag area: cap bytes = alive bits + block minima)
-        int32_t* bmin = reinterpret_cast<int32_t*>(alive + kBpeLongLds / 32);
-        tkz_bpe_long_tail<true>(T, cnt, ids, pr, alive, bmin);
+        void* bmin = alive + kBpeLongLds / 32;                    // (the tail's scratch)
+        if (prof && tid == 0) simt::atomic_add64(&prof[7], (unsigned long long)cnt);
+        tkz_bpe_long_tail<true>(T, cnt, ids, pr, alive, bmin, prof);
         const int tot = tkz_bpe_long_tail_emit<true>(cnt, ids, pr, alive, dst, err);
         finish_prof(tot);
         return tot;

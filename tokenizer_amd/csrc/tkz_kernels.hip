@@ -1603,7 +1603,7 @@ TKZ_KERNEL(1024) void k_giant_order(EncodeParams P) {
 }
 
 TKZ_KERNEL(1024) void k_giant_merge(TkzTables T, EncodeParams P) {
-    TKZ_SHARED int32_t s_state[(9 * kBpeLongLds + 3) / 4];        // ids | pair ranks | flag bytes of up to 16 Ki parts: 144 KB of the CU's 160
+    TKZ_SHARED alignas(16) int32_t s_state[(9 * kBpeLongLds + 3) / 4];        // ids | pair ranks | flag bytes of up to 16 Ki parts: 144 KB of the CU's 160
     TKZ_SHARED int64_t s_off;
     TKZ_SHARED int32_t s_whole;
     TKZ_SHARED unsigned long long s_ticket;

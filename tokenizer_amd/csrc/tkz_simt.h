@@ -44,6 +44,7 @@ TKZ_DEV int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 TKZ_DEV int first_lane(int v) { return __builtin_amdgcn_readfirstlane(v); }
 TKZ_DEV int atomic_add(int* p, int v) { return atomicAdd(p, v); }
 TKZ_DEV unsigned atomic_or(unsigned* p, unsigned v) { return atomicOr(p, v); }
+TKZ_DEV unsigned atomic_and(unsigned* p, unsigned v) { return atomicAnd(p, v); }
 TKZ_DEV unsigned atomic_max(unsigned* p, unsigned v) { return atomicMax(p, v); }
 TKZ_DEV unsigned atomic_cas(unsigned* p, unsigned expect, unsigned v) { return atomicCAS(p, expect, v); }
 TKZ_DEV void fence() { __threadfence(); }
