@@ -389,6 +389,26 @@ def check_miss_lists(lib, O, vocab, ovocab, pattern=N.CL100K, seed=41):
     assert ids.tolist() == exp
 
 
+def check_place_paths(lib, O):
+    """k_place's fast path hands a chunk of 256 records back to the general path when its tokens would overflow the LDS stage: under a
+    table of nothing but the 256 single bytes a 30-letter word is 30 tokens, so 24 of them among single-byte pieces (which ARE keys) make a
+    chunk of 952 tokens -- with at most 32 long misses in the sub-tile, which keeps it on the fast path until then; the chunk behind it
+    (hits only) is placed by the fast path again.  Also token runs of exactly 32 and 33 (the longest the fast path takes, the shortest it
+    refuses)."""
+    raw = random_vocab_bytes(random.Random(1), n_keys=0)
+    vocab, ovocab = N.Vocab(raw, lib), O.Vocab(raw)
+    enc = N.Encoder(vocab, N.CL100K)
+    oenc = O.Encoder(ovocab, N.CL100K)
+    docs = [(("x" * 30 + "1") * 24 + "a1" * 140).encode() * 3,
+            (("y" * 32 + "2") * 10 + "b2" * 300).encode(), (("y" * 33 + "2") * 10 + "b2" * 300).encode(),
+            ("q7" * 500 + ("z" * 17 + "3") * 30 + "c3" * 100).encode()]
+    for dd in (docs, docs[::-1], [b"".join(docs)]):
+        data, offs = pack(dd)
+        ids, ooff = enc.encode_batch(data, offs)
+        exp, eoff = oracle_encode_docs(oenc, dd)
+        assert ooff.tolist() == eoff and ids.tolist() == exp
+
+
 def check_memo_zero_bytes(lib, O, vocab, ovocab, seed=43):
     """Pieces that hold zero bytes never use the piece memo (that rule is what makes a hit exact whatever mixture of old and new slot
     words a reader is handed): runs of NUL of every length beside letter pieces of the same lengths, memo off / empty / filled."""

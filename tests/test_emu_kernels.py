@@ -133,6 +133,7 @@ def test_miss_lists(lib, vocabs, oracle_mod):
     parity.check_miss_lists(lib, oracle_mod, v, ov)
     v, ov = vocabs("synth200k")
     parity.check_miss_lists(lib, oracle_mod, v, ov, pattern=N.O200K, seed=42)
+    parity.check_place_paths(lib, oracle_mod)
 
 
 def test_small_batches_take_one_launch(lib, vocabs, oracle_mod):

@@ -139,6 +139,7 @@ def test_miss_lists(lib, vocabs, oracle_mod):
     for vname, pat, seed in (("gpt2", N.CL100K, 41), ("synth100k", N.CL100K, 44), ("synth200k", N.O200K, 42)):
         v, ov = vocabs(vname)
         parity.check_miss_lists(lib, oracle_mod, v, ov, pattern=pat, seed=seed)
+    parity.check_place_paths(lib, oracle_mod)
 
 
 def test_small_batches_take_one_launch(lib, vocabs, oracle_mod):
