@@ -999,8 +999,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     };
     // the piece of a list entry: its 16 bytes, zero beyond its length, as k_probe left them beside the entry; *nul = it holds a zero byte
     uint4* const mq0 = P.mquad + sub0 * (int64_t)P.mcap;
-    auto load_key = [&](int si, int j, int len, uint32_t* kw, bool* nul) {
-        const uint4 kq = tkz_load16(&mq0[si * (int64_t)P.mcap + j]);
+    auto key_of = [&](uint4 kq, int len, uint32_t* kw, bool* nul) {
         kw[0] = kq.x; kw[1] = kq.y; kw[2] = kq.z; kw[3] = kq.w;
         uint32_t z = 0;
 #pragma unroll
@@ -1016,18 +1015,20 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     // (an entry never changes once valid), so whatever mixture of old and new words a reader may be handed -- the key and the value are
     // two loads, and a slot can be claimed between them -- a key without zero bytes inside its length can only ever equal a COMPLETE key of the
     // same length, and then the value it is paired with is either that key's (valid) or not valid at all.
-    auto memo_phase = [&]() {
+    // (fr16 / fix / fkq: the entry and the quad of the lanes that hold a NEW entry -- list positions [nchk, nlist) --, fetched together by
+    //  those very lanes: the memo slot is the only round trip between taking an entry and answering it)
+    auto memo_phase = [&](uint32_t fr16, uint32_t fix, uint4 fkq) {
         (void)simt::ballot(true);
-        uint32_t r16 = 0, ix = 0;
-        if (lane < nlist) { r16 = s_rec[lane]; ix = s_idx[lane]; }
         const bool mine = lane >= nchk && lane < nlist;
+        uint32_t r16 = fr16, ix = fix;
+        if (lane < nchk) { r16 = s_rec[lane]; ix = s_idx[lane]; }
         const int si = (int)(ix >> 10), j = (int)(ix & 1023u), rel = (int)(r16 & 1023u), len = (int)((r16 >> 10) & 15u) + 1;
         bool hit = false;
         uint4 vv; vv.x = vv.y = vv.z = vv.w = 0;
         if (mine && memo) {
             uint32_t kw[4];
             bool nul;
-            load_key(si, j, len, kw, &nul);
+            key_of(fkq, len, kw, &nul);
             const uint32_t b = tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), T.memo_n / kMemoWays) * kMemoWays;
 #pragma unroll
             for (int wy = 0; wy < (int)kMemoWays; ++wy) {
@@ -1060,7 +1061,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
         if (lane < n) {
             const uint32_t r16 = s_rec[lane], ix = s_idx[lane];
             si = (int)(ix >> 10); j = (int)(ix & 1023u); rel = (int)(r16 & 1023u); len = (int)((r16 >> 10) & 15u) + 1;
-            load_key(si, j, len, kw, &nul);
+            key_of(tkz_load16(&mq0[si * (int64_t)P.mcap + j]), len, kw, &nul);
             cnt = tkz_bpe_lane_f<NMAX>(T, kw, len, ids, pr, byte_id, pair_rank, &alive, &e1);
             err |= e1;
         }
@@ -1093,19 +1094,33 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
         (void)simt::ballot(true);
     };
     (void)simt::ballot(true);
-    while (done < ntotal) {
-        // the next entries of the group's lists, as many as the wave's list has room for: position g of the concatenated lists is entry
-        // g - pre[q] of sub-tile q
-        const int take = ntotal - done < 64 - nlist ? ntotal - done : 64 - nlist;
-        if (lane < take) {
-            const int g = done + lane;
+    // Entry g of the group's concatenated lists is entry g - pre[q] of sub-tile q.  Lane i always has entries done + i of the lists in flight
+    // (entry, quad: two independent loads), requested while the entries before them are looked up in the memo; when the wave's list has
+    // room for `take` more, list position nlist + e gets what lane e holds (a shuffle).
+    auto request = [&](int g, uint32_t* r16, uint32_t* ix, uint4* kq) {
+        *r16 = 0; *ix = 0; kq->x = kq->y = kq->z = kq->w = 0;
+        if (g < ntotal) {
             const int q = tkz_find_list<kGroup>(s_pre, g), j = g - s_pre[q];
             const uint32_t ent = tkz_load_nt(&ml0[q * (int64_t)P.mcap + j]);
-            s_rec[nlist + lane] = (uint16_t)((ent & 1023u) | (((ent >> kMrLenShift) & 15u) << 10));
-            s_idx[nlist + lane] = (uint16_t)((q << 10) | j);
+            *kq = tkz_load16(&mq0[q * (int64_t)P.mcap + j]);
+            *r16 = (ent & 1023u) | (((ent >> kMrLenShift) & 15u) << 10);
+            *ix = (uint32_t)((q << 10) | j);
         }
+    };
+    uint32_t a_r16, a_ix;
+    uint4 a_kq;
+    request(lane, &a_r16, &a_ix, &a_kq);
+    while (done < ntotal) {
+        const int take = ntotal - done < 64 - nlist ? ntotal - done : 64 - nlist;
+        // list position p in [nlist, nlist + take) <- what lane p - nlist holds
+        const int src = (lane - nlist) & 63;
+        const uint32_t f_r16 = simt::shflu(a_r16, src), f_ix = simt::shflu(a_ix, src);
+        uint4 f_kq;
+        f_kq.x = simt::shflu(a_kq.x, src); f_kq.y = simt::shflu(a_kq.y, src); f_kq.z = simt::shflu(a_kq.z, src); f_kq.w = simt::shflu(a_kq.w, src);
+        if (lane >= nlist && lane < nlist + take) { s_rec[lane] = (uint16_t)f_r16; s_idx[lane] = (uint16_t)f_ix; }
         nlist += take; done += take;
-        memo_phase();
+        request(done + lane, &a_r16, &a_ix, &a_kq);            // (the entries behind these: in flight during the memo lookups)
+        memo_phase(f_r16, f_ix, f_kq);
         if (nlist == 64) { run_batch(64); nlist = nchk = 0; }
     }
     if (nlist > 0) run_batch(nlist);
