@@ -1322,7 +1322,7 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
 #ifndef TKZ_PLACE_OCC
 #define TKZ_PLACE_OCC 7
 #endif
-constexpr int kPlaceRes = 32;                              // answers (and quads) of a sub-tile's miss lists k_place keeps in LDS (of each list; a sub-tile averages 14 short misses)
+constexpr int kPlaceRes = 32;                              // 2 kPlaceRes = 64 answers (and quads) of a sub-tile's miss lists k_place keeps in LDS: one per lane, the short list from slot 0 up, the long one from slot 63 down (a sub-tile averages 14 short misses and one long one)
 constexpr int kPlacePer = 4;                               // consecutive sub-tiles per wavefront of k_place
 constexpr int kPlaceBig = 8;                               // the general path: token runs longer than this are copied by the whole wavefront, not staged
 constexpr int kPlaceFastBig = 32;                          // the fast path takes sub-tiles whose longest token run is at most this (a lane copies its piece's tokens into the stage)
@@ -1375,22 +1375,24 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     if (gcnt < 0) gcnt = 0;
     const bool lists_ok = ns + nl <= P.mcap;               // (cut lists: the batch is redone, nothing of this pass is used)
     // the answers of the merge kernels, in the same round trip as the first records
-    // lanes 0 .. kPlaceRes-1: the short list from the front; lanes kPlaceRes .. 2 kPlaceRes-1: the long list from the back
+    // slot = lane: slots 0 .. ks-1 hold the first ks entries of the short list, slots 63 .. 64-kl the first kl of the long one
     static_assert(2 * kPlaceRes == 64, "one lane per kept entry");
+    const int kl = ns + nl <= 64 ? nl : (nl < kPlaceRes ? nl : kPlaceRes), ks = ns < 64 - kl ? ns : 64 - kl;
     bool fast_ok;
     {
         uint32_t a = 0;
         uint4 qd; qd.x = qd.y = qd.z = qd.w = 0;
-        const int e = lane < kPlaceRes ? lane : lane - kPlaceRes;
-        const bool want = lists_ok && e < (lane < kPlaceRes ? ns : nl);
-        const int64_t at = lane < kPlaceRes ? e : P.mcap - 1 - e;
+        const bool shortside = lane < ks;
+        const int e = shortside ? lane : 63 - lane;
+        const bool want = lists_ok && (shortside || e < kl);
+        const int64_t at = shortside ? e : P.mcap - 1 - e;
         if (want) { a = tkz_load_nt(&ml[at]); qd = tkz_load16_nt(&mqd[at]); }
         (void)simt::ballot(true);                                // (the sub-tile before this one is done with them)
         s_res[lane] = a; s_quad[lane] = qd; s_pos[lane] = -1;
         if (lane == 0) s_res[2 * kPlaceRes] = tkz_result_inline(1);
-        // The fast path (below) takes a sub-tile whose lists are wholly in LDS and hold no token run longer than kPlaceFastBig, and that has
+        // The fast path (below) takes a sub-tile whose lists are wholly in LDS (64 entries together) and hold no token run longer than kPlaceFastBig, and that has
         // no giant piece: nearly all of them.
-        fast_ok = lists_ok && !has_giant && ns <= kPlaceRes && nl <= kPlaceRes && !simt::ballot(want && tkz_result_cnt(a) > kPlaceFastBig);
+        fast_ok = lists_ok && !has_giant && ns + nl <= 64 && !simt::ballot(want && tkz_result_cnt(a) > kPlaceFastBig);
     }
     (void)simt::ballot(true);
     // the answer a merge kernel left for a missed piece (its list entry): how many tokens, and where they wait
@@ -1399,7 +1401,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         const int idx = (int)(rec & 1023u);
         const bool lg = (rec & kPrLong) != 0;
         if (!lists_ok) return tkz_result_inline(1);
-        return idx < kPlaceRes ? s_res[(lg ? kPlaceRes : 0) + idx] : ml[lg ? P.mcap - 1 - idx : idx];
+        return (lg ? idx < kl : idx < ks) ? s_res[lg ? 63 - idx : idx] : ml[lg ? P.mcap - 1 - idx : idx];
     };
     // ... its tokens: INLINE (<= 4 tokens, nearly every missed piece: in the entry's quad, which for the first entries of both lists is
     // already in LDS), else in the group's dense region or in tmp
@@ -1407,7 +1409,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         const int idx = (int)(rec & 1023u);
         const bool lg = (rec & kPrLong) != 0;
         if (!lists_ok) { uint4 z; z.x = z.y = z.z = z.w = 0; return z; }
-        return idx < kPlaceRes ? s_quad[(lg ? kPlaceRes : 0) + idx] : tkz_load16(&mqd[lg ? P.mcap - 1 - idx : idx]);
+        return (lg ? idx < kl : idx < ks) ? s_quad[lg ? 63 - idx : idx] : tkz_load16(&mqd[lg ? P.mcap - 1 - idx : idx]);
     };
     auto token_src = [&](uint32_t res) -> const int32_t* { return (res & kMrDense) ? dense + tkz_result_off(res) : P.tmp + base + tkz_result_off(res); };
     // stage[i] holds the id of token sbase + i of the sub-tile; sbase is chosen so that stage[0] sits on a 16-byte boundary of `out`
@@ -1435,7 +1437,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     // ---- the fast path: FOUR CONSECUTIVE records per lane (one 16-byte load), so that 256 records cost one wave scan, one pass over the
     // marks and one pass over the missed pieces instead of four of each -- k_place runs at the VALU issue limit, and what it issues is
     // mostly per-batch overhead.  A record's token count comes from LDS without a branch (a hit reads the "one token" slot); the
-    // tokens of a missed piece are written by the lane that OWNS its list entry (lane e: entry e of the short list, lane kPlaceRes + e: entry e
+    // tokens of a missed piece are written by the lane that OWNS its list entry (lane e: entry e of the short list, lane 63 - e: entry e
     // of the long one): the lane that holds the record only tells it the position. ----
     auto place_fast = [&](int kk) -> bool {
         const int k0 = kk + 4 * lane;
@@ -1451,8 +1453,8 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         for (int j = 0; j < 4; ++j) {
             ok[j] = k0 + j < np && pb + k0 + j < P.prank_cap;
             ms[j] = ok[j] && (r[j] & kPrMiss);
-            idx[j] = (int)(r[j] & 1023u) + ((r[j] & kPrLong) ? kPlaceRes : 0);
-            const uint32_t a = s_res[ms[j] ? (idx[j] & (2 * kPlaceRes - 1)) : 2 * kPlaceRes];
+            idx[j] = ((r[j] & kPrLong) ? 63 - (int)(r[j] & 1023u) : (int)(r[j] & 1023u)) & 63;     // the slot of the piece's list entry
+            const uint32_t a = s_res[ms[j] ? idx[j] : 2 * kPlaceRes];
             c[j] = ok[j] ? tkz_result_cnt(a) : 0;
             t += c[j];
             mk += (ok[j] && (r[j] & kPrMark)) ? 1 : 0;
@@ -1468,7 +1470,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (ok[j] && (r[j] & kPrMark)) P.doc_tok[ord0 + mi++] = pos;
-            if (ms[j]) s_pos[idx[j] & (2 * kPlaceRes - 1)] = pos;
+            if (ms[j]) s_pos[idx[j]] = pos;
             else if (ok[j]) stage[pos - sbase] = (int32_t)(r[j] & kPrRankMask);
             pos += c[j];
         }
