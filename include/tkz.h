@@ -108,6 +108,19 @@ tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const
                                    int64_t out_cap, int64_t* d_out_offsets, void* hip_stream,
                                    int64_t* total_tokens);
 
+/* The same in two halves, for callers that keep several batches in flight (or do their own work while one runs):
+ * _begin enqueues the batch on `hip_stream` and returns without waiting; _end waits for it, reports errors and
+ * *total_tokens exactly as tkz_encode_batch_device, and frees the handle whatever it returns.  A batch that turns
+ * out to need a larger internal buffer than its first attempt had (more pieces, longer miss lists, scratch for
+ * pieces over 1024 bytes) is run again inside _end.  The buffers must stay valid, and the outputs unread, until
+ * _end has returned.  Every pending call holds one workspace of the encoder (about 7 bytes per input byte). */
+typedef struct tkz_pending tkz_pending;
+tkz_status tkz_encode_batch_device_begin(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets,
+                                         int64_t n_docs, int64_t total_bytes, int32_t* d_out_ids,
+                                         int64_t out_cap, int64_t* d_out_offsets, void* hip_stream,
+                                         tkz_pending** pending);
+tkz_status tkz_encode_batch_device_end(tkz_pending* pending, int64_t* total_tokens);
+
 /* EncodeBatch for hosts whose strings are UTF-16 (.NET `string`, Java, JavaScript): document d is the code units
  * units[unit_offsets[d] .. unit_offsets[d+1]).  The units are uploaded as they are and converted to UTF-8 ON THE
  * DEVICE exactly as Encoding.UTF8.GetBytes does (TikTokenizer.cs:261: a surrogate pair becomes one 4-byte char, a lone

@@ -804,3 +804,42 @@ def check_host_chunks(lib, O, vocab, ovocab, pattern=N.CL100K, seed=21):
     with pytest.raises(N.TkzError) as ei:
         enc.encode_batch(np.frombuffer(b"x" * 40000, np.uint8), np.array([0, 30000, 20000, 40000]))
     assert ei.value.code == N.E_ARG
+
+
+def check_begin_end(lib, O, vocab, ovocab, pattern=N.CL100K, seed=61, upload=None, streams=(0,)):
+    """tkz_encode_batch_device_begin / _end: several batches in flight on one encoder, ended in another order than they began; a batch whose
+    first attempt overflows the miss lists is run again inside _end.  `upload(np_array) -> (owner, pointer)` puts an array where the
+    device entry points can read it (identity on the CPU-emulated build); outputs are read back through owner.cpu() if it has one."""
+    rng = random.Random(seed)
+    alpha = RC.alphabet()
+    enc = N.Encoder(vocab, pattern)
+    oenc = O.Encoder(ovocab, pattern)
+    if upload is None:
+        upload = lambda a: (a, a.ctypes.data)
+    cons = "bcdfghjklmnpqrstvwxz"
+    batches = []
+    for k in range(4):
+        if k == 2:      # ~340 three-byte misses per KiB: the lists (64 entries a sub-tile in a fresh workspace) overflow, _end runs the batch again
+            docs = [("".join(" " + rng.choice(cons) + rng.choice(cons) for _ in range(1500))).encode() for _ in range(3)]
+        else:
+            docs = [gen_text(rng, rng.choice(["mix", "a_mix", "ws"]), rng.choice([1, 60, 900, 4000]), alpha).encode("utf-8") for _ in range(rng.choice([1, 9, 40]))]
+        data, offs = pack(docs)
+        padded = np.zeros(len(data) + 64, np.uint8); padded[:len(data)] = data
+        ids = np.zeros(max(1, len(data)), np.int32); ooff = np.zeros(len(docs) + 1, np.int64)
+        b = dict(docs=docs, n=len(docs), total=len(data), bytes=upload(padded), offs=upload(offs.astype(np.int64)), ids=upload(ids), ooff=upload(ooff))
+        b["h"] = enc.encode_batch_device_begin(b["bytes"][1], b["offs"][1], b["n"], b["total"], b["ids"][1], max(1, b["total"]), b["ooff"][1], streams[k % len(streams)])
+        batches.append(b)
+    for b in batches[::-1]:
+        ntok = enc.encode_batch_device_end(b["h"])
+        back = lambda o: (o.cpu().numpy() if hasattr(o, "cpu") else o)
+        exp, eoff = oracle_encode_docs(oenc, b["docs"])
+        assert ntok == len(exp) and back(b["ids"][0])[:ntok].tolist() == exp and back(b["ooff"][0]).tolist() == eoff
+    # an error is reported by _end (and the handle is gone either way): offsets that do not end at the byte count
+    data, offs = pack([b"abc", b"defg"])
+    bad = offs.astype(np.int64).copy(); bad[-1] += 1
+    padded = np.zeros(64, np.uint8); padded[:len(data)] = data
+    bb, bo, bi, boo = upload(padded), upload(bad), upload(np.zeros(16, np.int32)), upload(np.zeros(3, np.int64))
+    h = enc.encode_batch_device_begin(bb[1], bo[1], 2, len(data), bi[1], 16, boo[1], streams[0])
+    with pytest.raises(N.TkzError) as ei:
+        enc.encode_batch_device_end(h)
+    assert ei.value.code == N.E_ARG

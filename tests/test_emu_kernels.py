@@ -294,3 +294,8 @@ def test_giant_tail_on_adversarial_rank_tables(oracle_mod):
         parity.check_random_vocab(lib, oracle_mod, seed, 3, [1100, 1500, 2300, 4000, 7000], 3)
     raw = gzip.decompress(open(os.path.join(os.path.dirname(__file__), "golden", "gpt2.tiktoken.gz"), "rb").read())
     parity.check_long_diverse_pieces(lib, oracle_mod, N.Vocab(raw, lib), oracle_mod.Vocab(raw), lens=(1500, 18000, 33000), seed=3)
+
+
+def test_device_entry_in_two_halves(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_begin_end(lib, oracle_mod, v, ov)

@@ -451,3 +451,18 @@ def test_adversarial_rank_tables(lib, oracle_mod):
     parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=40, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 1024, 1025, 3000], n_pieces=200)
     # arbitrary rank tables on pieces that start in the global pool and end in the tail that keeps only the pair ranks in LDS
     parity.check_random_vocab(lib, oracle_mod, seed=4, n_vocabs=6, lens=[17000, 20000, 30000, 33000], n_pieces=4)
+
+
+def test_device_entry_in_two_halves(lib, vocabs, oracle_mod):
+    """tkz_encode_batch_device_begin / _end with four batches in flight on two streams."""
+    import torch
+    dev = torch.device("cuda", 0)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def upload(a):
+        tns = torch.from_numpy(a).to(dev)
+        return tns, tns.data_ptr()
+    torch.cuda.synchronize()
+    for vname in ("gpt2", "synth100k"):
+        v, ov = vocabs(vname)
+        parity.check_begin_end(lib, oracle_mod, v, ov, upload=upload, streams=(s1.cuda_stream, s2.cuda_stream))

@@ -97,6 +97,8 @@ class Library:
         L.tkz_encoder_device.argtypes = [vp]
         L.tkz_encode_batch_utf8.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
         L.tkz_encode_batch_device.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, pi64]
+        L.tkz_encode_batch_device_begin.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, C.POINTER(vp)]
+        L.tkz_encode_batch_device_end.argtypes = [vp, pi64]
         L.tkz_encode_batch_utf16.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
         L.tkz_encode_utf8.argtypes = [vp, vp, i64, vp, i64, pi64]
         L.tkz_encode_utf16.argtypes = [vp, vp, i64, vp, i64, pi64]
@@ -392,6 +394,18 @@ class Encoder:
         tot = C.c_int64(0)
         self.lib.check(self.lib.L.tkz_encode_batch_device(self._h, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap,
                                                           d_out_offsets, stream or None, C.byref(tot)))
+        return tot.value
+
+    def encode_batch_device_begin(self, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, stream=0):
+        """Enqueues the batch and returns a handle for encode_batch_device_end (several may be in flight)."""
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.tkz_encode_batch_device_begin(self._h, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap,
+                                                                d_out_offsets, stream or None, C.byref(h)))
+        return h
+
+    def encode_batch_device_end(self, pending):
+        tot = C.c_int64(0)
+        self.lib.check(self.lib.L.tkz_encode_batch_device_end(pending, C.byref(tot)))
         return tot.value
 
 

@@ -280,15 +280,19 @@ tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool 
 struct PiecesOut { int64_t* piece_boffs; int64_t* piece_toffs; int64_t* doc_piece; int64_t piece_cap; int64_t n_pieces; };
 
 // the batch on the device; when pretok == false every "document" is taken as one piece
+enum { kCallWhole = 0, kCallBegin = 1, kCallEnd = 2 };
 tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                          int32_t* d_out, int64_t out_cap, int64_t* d_out_offs, hipStream_t stream, bool pretok,
-                         uint64_t* d_bitmap_only, int64_t* total_tokens, PiecesOut* po = nullptr) {
+                         uint64_t* d_bitmap_only, int64_t* total_tokens, PiecesOut* po = nullptr, int phase = kCallWhole) {
+    // phase: kCallWhole -- enqueue, wait, evaluate (and again if a buffer had to grow); kCallBegin -- enqueue the first attempt and
+    // return; kCallEnd -- wait for that attempt, evaluate, and carry on as kCallWhole does (tkz_encode_batch_device_begin / _end)
     using namespace tkz;
     if (n_docs < 0 || total < 0 || out_cap < 0) return fail(TKZ_E_ARG, "negative size");
     if (total_tokens) *total_tokens = 0;
     if (n_docs == 0 && total != 0) return fail(TKZ_E_ARG, "bytes without documents");
     const int64_t nwords = total / 64 + 1;
     if (total == 0) {
+        if (phase == kCallEnd) return TKZ_OK;                     // (done when it began)
         { tkz::Launch L0{stream, nullptr, ws}; tkz::launch_counts3(L0, n_docs, 0, nullptr, e->t_counts3.as<int64_t>()); }
         if (d_out_offs) HIP_TRY(hipMemsetAsync(d_out_offs, 0, (size_t)(n_docs + 1) * sizeof(int64_t), stream));
         if (d_bitmap_only) { const uint64_t one = 1; HIP_TRY(hipMemcpyAsync(d_bitmap_only, &one, 8, hipMemcpyHostToDevice, stream)); }
@@ -304,6 +308,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         bool pieces_over = false;
         Launch L{stream, e->profiling ? prof_hook : nullptr, ws};
         int32_t* counters = ws->w_counters.as<int32_t>();
+        if (!(phase == kCallEnd && attempt == 0)) {              // (kCallEnd: the first attempt is in flight already)
         int64_t* grand = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, grand));
         unsigned long long* pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head));
         uint64_t* docbits = ws->w_docbits.as<uint64_t>();
@@ -376,6 +381,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             launch_counts3(L, n_docs, total, grand, e->t_counts3.as<int64_t>());
         }
         HIP_TRY(hipMemcpyAsync(ws->h_counters, counters, sizeof(CounterBlock), hipMemcpyDeviceToHost, stream));
+        }
+        if (phase == kCallBegin) return TKZ_OK;
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
         if (e->profiling) prof_collect(ws);
@@ -793,6 +800,44 @@ tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const
     Workspace* ws = lease.ws;
     return encode_device(e, ws, d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets,
                          static_cast<hipStream_t>(hip_stream), true, nullptr, total_tokens);
+}
+
+// The same in two halves: _begin enqueues the batch on the stream and returns, _end waits for it and reports as tkz_encode_batch_device
+// does (a batch that needs a larger buffer than the first attempt had is run again inside _end).  The call keeps a workspace of the
+// encoder from _begin to _end: several batches can be in flight, on one stream or on several.
+struct tkz_pending {
+    tkz_encoder* e; Lease* lease;
+    const uint8_t* d_bytes; const int64_t* d_offs; int64_t n_docs, total; int32_t* d_out; int64_t out_cap; int64_t* d_out_offs; hipStream_t stream;
+};
+tkz_status tkz_encode_batch_device_begin(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets, int64_t n_docs,
+                                         int64_t total_bytes, int32_t* d_out_ids, int64_t out_cap, int64_t* d_out_offsets,
+                                         void* hip_stream, tkz_pending** pending) {
+    if (!pending) return fail(TKZ_E_ARG, "null pending");
+    *pending = nullptr;
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
+    if (st != TKZ_OK) return st;
+    if (!d_doc_offsets || !d_out_offsets || (total_bytes > 0 && (!d_bytes || !d_out_ids))) return fail(TKZ_E_ARG, "null device buffer");
+    if (reinterpret_cast<uintptr_t>(d_bytes) & 15) return fail(TKZ_E_ARG, "d_bytes must be 16-byte aligned");
+    tkz_pending* p = new tkz_pending{e, new Lease(e), d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, static_cast<hipStream_t>(hip_stream)};
+    st = encode_device(e, p->lease->ws, d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, p->stream, true, nullptr, nullptr, nullptr, kCallBegin);
+    if (st != TKZ_OK) { (void)hipStreamSynchronize(p->stream); delete p->lease; delete p; return st; }
+    *pending = p;
+    return TKZ_OK;
+}
+tkz_status tkz_encode_batch_device_end(tkz_pending* p, int64_t* total_tokens) {
+    if (!p) return fail(TKZ_E_ARG, "null pending");
+    tkz_status st;
+    {
+        DeviceScope scope;
+        st = check_encoder(p->e, scope);
+        if (st == TKZ_OK)
+            st = encode_device(p->e, p->lease->ws, p->d_bytes, p->d_offs, p->n_docs, p->total, p->d_out, p->out_cap, p->d_out_offs, p->stream, true, nullptr, total_tokens, nullptr, kCallEnd);
+        else (void)hipStreamSynchronize(p->stream);
+    }
+    delete p->lease;
+    delete p;
+    return st;
 }
 
 tkz_status tkz_encode_utf8(tkz_encoder* e, const uint8_t* text, int64_t len, int32_t* out_ids, int64_t out_cap, int64_t* n_out) {
