@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--vocab", default=None, help="gpt2 | synth100k | synth200k (default: the stand-in of the pattern's vocabulary)")
     ap.add_argument("--cpu-sample-docs", type=int, default=2_000_000, help="documents of the CPU-baseline thread sweep (the all-core run covers the whole batch)")
     ap.add_argument("--no-memo-steps", type=int, default=None, help="timed steps with the piece memo off (value_no_memo); default: as --steps")
+    ap.add_argument("--pipelined-steps", type=int, default=4, help="timed steps of the two-batches-in-flight leg (value_two_in_flight; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-memo", action="store_true", help="switch the piece memo (the device form of the reference's LRUCache) off")
     ap.add_argument("--write-shards", default=None, metavar="DIR", help="after the timed loop every rank writes its token shard file (SURVEY 8f-2)")
@@ -291,6 +292,31 @@ def main():
             t = torch.tensor([dt_nomemo], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt_nomemo = float(t.item())
+    # the same steps two at a time through tkz_encode_batch_device_begin / _end (two streams, two output buffers, two workspaces of the
+    # encoder): what keeping batches in flight buys over one synchronous call after the other -- a companion figure, never `value`
+    dt_pipe = None
+    pipe_note = None
+    if world == 1 and args.pipelined_steps > 0 and args.kind != 5:
+        try:
+            s2 = torch.cuda.Stream()
+            d_ids2 = torch.empty_like(d_ids); d_ooffs2 = torch.empty_like(d_ooffs)
+            outs = [(d_ids, d_ooffs, stream), (d_ids2, d_ooffs2, s2.cuda_stream)]
+
+            def pair():
+                hs = [enc.encode_batch_device_begin(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, o[0].data_ptr(), total, o[1].data_ptr(), o[2]) for o in outs]
+                return [enc.encode_batch_device_end(h) for h in hs]
+            assert pair() == [ntok, ntok]                      # (untimed: the second workspace takes its size)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range((args.pipelined_steps + 1) // 2):
+                pair()
+            fence()
+            dt_pipe = (time.perf_counter() - t0) / (2 * ((args.pipelined_steps + 1) // 2))
+            assert torch.equal(d_ids2[:ntok], d_ids[:ntok]) and torch.equal(d_ooffs2, d_ooffs)
+            del d_ids2, d_ooffs2
+        except Exception as ex:                                # (e.g. no room for a second workspace)
+            dt_pipe = None
+            pipe_note = "%s: %s" % (type(ex).__name__, ex)
     g = comm.result() if comm is not None else sharded.gather_counts(n_docs, total, ntok)
     n_tokens_rank = int(g["table"][rank][2])
     assert n_tokens_rank == ntok and int(g["table"][rank][0]) == n_docs and int(g["table"][rank][1]) == total
@@ -458,6 +484,7 @@ def main():
             "comm": comm_info,
             "tokens_per_s": round(job_tokens * args.steps / dt, 1),
             "value_no_memo": round(job_bytes * nm_steps / dt_nomemo / 1e6, 1) if dt_nomemo else None,
+            "value_two_in_flight": round(job_bytes / dt_pipe / 1e6, 1) if dt_pipe else None,
             "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
             "parity": parity_note,
             "roofline": roofline,
