@@ -19,7 +19,9 @@ says so in config.vocab.
 
 The piece memo (the reference's LRUCache on the device) persists from call to call like the reference's: the W warm-up steps encode
 OTHER documents of the same generator, then one untimed pass with the memo switched off sizes the workspace for the bench batch;
---no-memo measures without it (config.piece_memo says which).
+--no-memo measures without it (config.piece_memo says which).  Companion figures of the same line, never `value`: `value_no_memo`
+(the timed steps again with the memo off) and `value_two_in_flight` (the same batch two at a time through
+tkz_encode_batch_device_begin / _end on two streams: what keeping batches in flight buys over one synchronous call after the other).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM bandwidth with the algorithmic bytes of
 SURVEY.md 8(d); `cpu_baseline` times the reference-algorithm CPU restatement (oracle/, kind "port") on a bounded sample of the
