@@ -46,10 +46,19 @@ typedef enum tkz_status {
 
 /* The three split regexes the reference defines.  A pattern is an enum, not a regex string:
  * libtkz ships a hand-written scanner per pattern and refuses anything else.
- *   TKZ_PATTERN_P1      gpt2 / r50k_base / p50k_base / p50k_edit   TokenizerBuilder.cs:128,140,155,167
- *   TKZ_PATTERN_CL100K  cl100k_base                                TokenizerBuilder.cs:112
- *   TKZ_PATTERN_O200K   o200k_base                                 tokenizer_ts/src/tokenizerBuilder.ts:79-89 */
-typedef enum tkz_pattern { TKZ_PATTERN_P1 = 1, TKZ_PATTERN_CL100K = 2, TKZ_PATTERN_O200K = 3 } tkz_pattern;
+ *   TKZ_PATTERN_P1            gpt2 / r50k_base / p50k_base / p50k_edit   TokenizerBuilder.cs:128,140,155,167
+ *   TKZ_PATTERN_CL100K        cl100k_base                                TokenizerBuilder.cs:112
+ *   TKZ_PATTERN_O200K_DOTNET  o200k_base as the C# reference runs it: the regex string of tokenizer_ts/src/tokenizerBuilder.ts:79-89 handed to
+ *                             TokenizerBuilder.CreateTokenizer(stream, specials, pattern) (TokenizerBuilder.cs:210-213) and compiled by
+ *                             `new Regex(pattern, RegexOptions.Compiled)` (TikTokenizer.cs:77): every class test looks at ONE UTF-16 code unit (a
+ *                             supplementary-plane char is two "other" units whatever its Unicode class, and never the one-unit prefix of a
+ *                             word), \s is .NET's (U+0085 is white space, U+FEFF is not) -- the semantics of the other two patterns.
+ *   TKZ_PATTERN_O200K         the same string as the TypeScript reference runs it: `new RegExp(pattern, "gu")` (tokenizer_ts/src/tikTokenizer.ts:100),
+ *                             one class test per code POINT, ECMAScript \s (U+FEFF is white space, U+0085 is not).
+ * The two o200k variants agree on every text without supplementary-plane chars, U+0085 and U+FEFF. */
+typedef enum tkz_pattern { TKZ_PATTERN_P1 = 1, TKZ_PATTERN_CL100K = 2, TKZ_PATTERN_O200K = 3, TKZ_PATTERN_O200K_DOTNET = 4 } tkz_pattern;
+/* Which engine's reading of a regex string is wanted (tkz_pattern_from_regex_engine). */
+typedef enum tkz_regex_engine { TKZ_ENGINE_DOTNET = 0, TKZ_ENGINE_ECMASCRIPT = 1 } tkz_regex_engine;
 
 typedef struct tkz_vocab tkz_vocab;
 typedef struct tkz_encoder tkz_encoder;
@@ -73,12 +82,17 @@ int32_t tkz_vocab_rank(const tkz_vocab* v, const uint8_t* key, int32_t len);
 
 /* The Unicode class the split scanners assign to code points first .. first + n - 1 (0 other, 1 Lu, 2 Ll, 3 Lt, 4 Lm, 5 Lo, 6 M, 7 N,
  * 8 white space: .NET's \s), from the table the device holds (Unicode 13.0, the data of the reference's net6.0 target).  Pattern 1 and
- * cl100k look only code UNITS up (the entries below 0x10000); o200k looks code points up.  Informational: lets a host verify the table. */
+ * cl100k and TKZ_PATTERN_O200K_DOTNET look only code UNITS up (the entries below 0x10000); TKZ_PATTERN_O200K looks code points up
+ * (and reads U+FEFF as white space, U+0085 as not).  Informational: lets a host verify the table. */
 void tkz_unicode_classes(uint32_t first, int32_t n, uint8_t* out);
 
 /* Map one of the reference's regex strings (exact text) to a tkz_pattern; anything else is
- * TKZ_E_UNSUPPORTED.  Replaces `new Regex(pattern, RegexOptions.Compiled)` (TikTokenizer.cs:77). */
+ * TKZ_E_UNSUPPORTED.  Replaces `new Regex(pattern, RegexOptions.Compiled)` (TikTokenizer.cs:77): the result has .NET's semantics
+ * (the o200k string gives TKZ_PATTERN_O200K_DOTNET).  tkz_pattern_from_regex_engine names the engine: TKZ_ENGINE_ECMASCRIPT maps the
+ * o200k string to TKZ_PATTERN_O200K (the TypeScript reference's reading) and refuses the other two strings, which libtkz implements
+ * with .NET's semantics only. */
 tkz_status tkz_pattern_from_regex(const char* regex_utf8, int32_t* pattern_out);
+tkz_status tkz_pattern_from_regex_engine(const char* regex_utf8, int32_t engine, int32_t* pattern_out);
 
 /* Replaces TokenizerBuilder.CreateTokenizer(stream, specials, pattern, cacheSize)
  * (TokenizerBuilder.cs:210-213) for the plain path: builds the device tables on HIP device
@@ -113,13 +127,27 @@ tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const
  * *total_tokens exactly as tkz_encode_batch_device, and frees the handle whatever it returns.  A batch that turns
  * out to need a larger internal buffer than its first attempt had (more pieces, longer miss lists, scratch for
  * pieces over 1024 bytes) is run again inside _end.  The buffers must stay valid, and the outputs unread, until
- * _end has returned.  Every pending call holds one workspace of the encoder (about 7 bytes per input byte). */
+ * _end has returned.  Every pending call holds one workspace of the encoder: about 7 bytes per input byte on English / code text; text where
+ * most pieces miss the vocabulary (CJK under an English table) makes the per-sub-tile miss lists grow from 64 entries towards 1024, i.e. from
+ * 1.25 to at most 20 more bytes per input byte for that workspace -- they shrink again when later batches do not need them.
+ * tkz_encoder_destroy while handles are outstanding is deferred: every such handle's _end returns TKZ_E_ARG and the last one frees the encoder. */
 typedef struct tkz_pending tkz_pending;
 tkz_status tkz_encode_batch_device_begin(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets,
                                          int64_t n_docs, int64_t total_bytes, int32_t* d_out_ids,
                                          int64_t out_cap, int64_t* d_out_offsets, void* hip_stream,
                                          tkz_pending** pending);
 tkz_status tkz_encode_batch_device_end(tkz_pending* pending, int64_t* total_tokens);
+/* _begin with a place for THIS batch's {n_docs, n_bytes, n_tokens}: d_counts3 (3 int64 on the device, the caller's, may be NULL) is written by
+ * the batch's own stream work -- what tkz_comm_allgather_counts_device sends.  Final once _end has returned TKZ_OK (a batch that is run again
+ * inside _end writes it again, on the same stream): enqueue the all-gather behind _end and any number of batches may be in flight, each with
+ * its own block.  tkz_pending_counts_device returns d_counts3, or -- when it was NULL -- a block of the handle's workspace that is valid
+ * until _end (for a gather enqueued between _begin and _end, which sees the FIRST attempt's counts: fine for a caller that treats a batch
+ * whose _end reports anything but TKZ_OK, or that had to be run again, as failed). */
+tkz_status tkz_encode_batch_device_begin_counts(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets,
+                                                int64_t n_docs, int64_t total_bytes, int32_t* d_out_ids,
+                                                int64_t out_cap, int64_t* d_out_offsets, void* hip_stream,
+                                                int64_t* d_counts3, tkz_pending** pending);
+const int64_t* tkz_pending_counts_device(const tkz_pending* pending);
 
 /* EncodeBatch for hosts whose strings are UTF-16 (.NET `string`, Java, JavaScript): document d is the code units
  * units[unit_offsets[d] .. unit_offsets[d+1]).  The units are uploaded as they are and converted to UTF-8 ON THE
@@ -203,8 +231,9 @@ const char* tkz_comm_backend(const tkz_comm* c);   /* "rccl <major>.<minor>.<pat
 /* d_mine: 3 int64 on the device; d_table: world * 3 int64 on the device (row r = rank r's counts); enqueued on hip_stream */
 tkz_status tkz_comm_allgather_counts_device(tkz_comm* c, const int64_t* d_mine, int64_t* d_table, void* hip_stream);
 tkz_status tkz_comm_allgather_counts(tkz_comm* c, int64_t n_docs, int64_t n_bytes, int64_t n_tokens, int64_t* table);
-/* {n_docs, n_bytes, n_tokens} of the encoder's last batch, resident on its device (valid once that batch's stream work is done).
- * ONE buffer per encoder: meaningful with one batch in flight per encoder (host threads sharing an encoder overwrite each other's). */
+/* {n_docs, n_bytes, n_tokens} of the encoder's LAST batch (whichever entry point ran it, the single-launch path included), resident on its
+ * device and valid once that batch's stream work is done.  One block per encoder: for callers with one batch at a time.  With several in
+ * flight (tkz_encode_batch_device_begin, host threads sharing an encoder) give every batch its own block: tkz_encode_batch_device_begin_counts. */
 const int64_t* tkz_encoder_counts_device(const tkz_encoder* e);
 /* documents [*lo, *hi) of a job of n_docs_total belong to `rank` */
 void tkz_shard_range(int64_t n_docs_total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi);

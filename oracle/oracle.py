@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libtkz_oracle.so")
 
-P1, CL100K, O200K = 1, 2, 3
+P1, CL100K, O200K, O200K_DOTNET = 1, 2, 3, 4   # O200K: ECMAScript engine (TS reference); O200K_DOTNET: the same string through .NET Regex
 E_FORMAT, E_DUP_RANK, E_KEY_NOT_FOUND, E_CAPACITY, E_UTF8, E_ARG = -1, -2, -3, -4, -5, -6
 
 

@@ -498,7 +498,8 @@ static int64_t match_at(int pattern, const utext* t, int64_t p) {
     switch (pattern) {
         case TKZO_PATTERN_P1: return match_p1(t, p);
         case TKZO_PATTERN_CL100K: return match_cl100k(t, p);
-        case TKZO_PATTERN_O200K: return match_o200k(t, p);
+        case TKZO_PATTERN_O200K: return match_o200k(t, p);          /* by code point, ECMAScript \s: what `t` holds decides */
+        case TKZO_PATTERN_O200K_DOTNET: return match_o200k(t, p);   /* by code unit, .NET \s (TikTokenizer.cs:77 given the o200k string) */
     }
     return -1;
 }
@@ -702,7 +703,7 @@ struct tkzo_encoder {
 };
 tkzo_encoder* tkzo_encoder_create(const tkzo_vocab* v, int pattern, int cache_size) {
     pthread_once(&g_cls_once, cls_init);
-    if (!v || pattern < TKZO_PATTERN_P1 || pattern > TKZO_PATTERN_O200K) return NULL;
+    if (!v || pattern < TKZO_PATTERN_P1 || pattern > TKZO_PATTERN_O200K_DOTNET) return NULL;
     tkzo_encoder* e = (tkzo_encoder*)calloc(1, sizeof *e);
     e->v = v; e->pattern = pattern; memo_init(&e->cache, cache_size);
     return e;

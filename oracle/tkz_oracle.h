@@ -41,7 +41,13 @@ extern "C" {
 #endif
 
 /* pattern ids (same numbering as include/tkz.h on purpose, so tests can pass one through) */
-enum { TKZO_PATTERN_P1 = 1, TKZO_PATTERN_CL100K = 2, TKZO_PATTERN_O200K = 3 };
+/* o200k exists twice.  The regex string is only in the TypeScript reference (tokenizer_ts/src/tokenizerBuilder.ts:79-89), whose engine
+ * (`new RegExp(pattern, "gu")`, tikTokenizer.ts:100) matches by CODE POINT with ECMAScript's \s: TKZO_PATTERN_O200K.  The C# reference
+ * can only run that string through TokenizerBuilder.CreateTokenizer(stream, specials, pattern) (TokenizerBuilder.cs:210-213 ->
+ * `new Regex(pattern, RegexOptions.Compiled)`, TikTokenizer.cs:77), i.e. by UTF-16 code UNIT (a supplementary-plane char is two OTHER
+ * units and never the one-unit prefix) with .NET's \s (U+0085 is white space, U+FEFF is not): TKZO_PATTERN_O200K_DOTNET.  The two
+ * differ only on supplementary-plane letters / digits / marks / the prefix rule, U+0085 and U+FEFF. */
+enum { TKZO_PATTERN_P1 = 1, TKZO_PATTERN_CL100K = 2, TKZO_PATTERN_O200K = 3, TKZO_PATTERN_O200K_DOTNET = 4 };
 
 /* error codes */
 enum {

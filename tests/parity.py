@@ -1,6 +1,7 @@
 """Parity checks shared by the emulated (CPU) and the real (GPU) test modules: every function takes
 the library under test (`lib`, a tokenizer_amd._native.Library) and the oracle, and compares the two on
 the same seeded inputs.  Integer work: the bar is bit-exact."""
+import ctypes as C
 import os
 import random
 
@@ -166,7 +167,7 @@ def o200k_gen(rng, a, n):
     return "".join(out[:n])
 
 
-def check_o200k_no_sync_points(lib, O, vocab):
+def check_o200k_no_sync_points(lib, O, vocab, pattern=N.O200K):
     """Blocks the o200k block scanners hand on inside text without blanks, digits or line breaks: the sequential kernel finds no sync point
     within its window and takes the block from HBM; next to a document where it does find them.  What makes the char-level scanner hand a
     block on here: a run of '/' that covers the block's CONTEXT row (the last 64 bytes before the block: what flows out of it is unknown);
@@ -178,17 +179,17 @@ def check_o200k_no_sync_points(lib, O, vocab):
     assert len(d0[:1290].encode("utf-8")) == 3870
     docs = [d0.encode("utf-8"), ("A" + cjk[:2500] + "/" * 130 + "x y 1" + cjk[100:2000]).encode("utf-8")]
     data, offs = pack(docs)
-    enc = N.Encoder(vocab, N.O200K)
+    enc = N.Encoder(vocab, pattern)
     got = enc.pretokenize(data, offs)
-    exp = oracle_bitmap(O, N.O200K, docs)
+    exp = oracle_bitmap(O, pattern, docs)
     assert np.array_equal(got, exp), explain_bitmap_diff(got, exp, docs, offs)
     assert enc.pretok_leftovers()[1] >= 2
 
 
-def check_o200k_blocks(lib, O, vocab, kinds, seeds, doc_lens=(3000, 9000, 20000), min_handled=None):
+def check_o200k_blocks(lib, O, vocab, kinds, seeds, doc_lens=(3000, 9000, 20000), min_handled=None, pattern=N.O200K):
     """Block scanners of o200k vs the oracle's sequential matcher on documents long enough to hold whole 4 KiB blocks.
     Returns (blocks, left over by the ASCII scanner, left over by the multi-byte scanner)."""
-    enc = N.Encoder(vocab, N.O200K)
+    enc = N.Encoder(vocab, pattern)
     tblk = ta = tb = 0
     for kind in kinds:
         for seed in seeds:
@@ -196,8 +197,8 @@ def check_o200k_blocks(lib, O, vocab, kinds, seeds, doc_lens=(3000, 9000, 20000)
             docs = [o200k_gen(rng, O200K_ALPHAS[kind], rng.choice(doc_lens)).encode("utf-8") for _ in range(rng.choice([1, 2, 5]))]
             data, offs = pack(docs)
             got = enc.pretokenize(data, offs)
-            exp = oracle_bitmap(O, N.O200K, docs)
-            assert np.array_equal(got, exp), "o200k kind=%s seed=%d: %s" % (kind, seed, explain_bitmap_diff(got, exp, docs, offs))
+            exp = oracle_bitmap(O, pattern, docs)
+            assert np.array_equal(got, exp), "o200k (pattern %d) kind=%s seed=%d: %s" % (pattern, kind, seed, explain_bitmap_diff(got, exp, docs, offs))
             a, b = enc.pretok_leftovers()
             ta += a
             tb += b
@@ -387,6 +388,19 @@ def check_miss_lists(lib, O, vocab, ovocab, pattern=N.CL100K, seed=41):
     ids, dpo, pbo, pto = enc.encode_batch_pieces(data, offs)
     exp, _ = oracle_encode_docs(oenc, docs_big[:3])
     assert ids.tolist() == exp
+    # lists that grew give their memory back: a crowded batch on the batch path (more than the single launch takes), then plain text of
+    # the same size twice (the first one still runs on the long lists and measures what it needs), then the crowded one again
+    enc2 = N.Encoder(vocab, pattern)
+    crowded = [gib(50000, 2, 2).encode() for _ in range(4)]
+    plain = [("the quick brown fox jumps over the lazy dog, it's 12345 o'clock\n" * 800).encode() for _ in range(4)]
+    sizes = []
+    for docs in (crowded, plain, plain, crowded, plain):
+        data, offs = pack(docs)
+        ids, ooff = enc2.encode_batch(data, offs)
+        exp, eoff = oracle_encode_docs(oenc, docs)
+        assert ooff.tolist() == eoff and ids.tolist() == exp
+        sizes.append(enc2.workspace_bytes)
+    assert sizes[1] < sizes[0] and sizes[2] < sizes[0] and sizes[3] > sizes[2] and sizes[4] < sizes[3], sizes
 
 
 def check_place_paths(lib, O):
@@ -485,13 +499,26 @@ def check_memo_contention(lib, O, vocab, ovocab, candidates=400_000, threads=2, 
     assert not errors, errors
 
 
+def read_device_i64(lib, ptr, n):
+    """n int64 at a device pointer of the library's: host memory on the CPU-emulated build, hipMemcpy (which also waits for the null
+    stream's earlier work) on the GPU."""
+    out = np.zeros(n, np.int64)
+    if "hostemu" in lib.path:
+        C.memmove(out.ctypes.data, ptr, 8 * n)
+    else:
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        assert hip.hipDeviceSynchronize() == 0 and hip.hipMemcpy(out.ctypes.data, ptr, 8 * n, 2) == 0
+    return out
+
+
 def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
     """The single-launch path for small batches (k_small: at most 64 KiB in at most 8192 documents; o200k: of at most 1 KiB each): same ids as the
     oracle on single prompts and small batches of all three patterns; the calls that must be handed back to the batch path (a giant
     piece, malformed text, more misses than the lists hold) still give the batch path's answer; larger batches do not take it."""
     rng = random.Random(seed)
     alpha = RC.alphabet()
-    for pattern in (N.P1, N.CL100K, N.O200K):
+    for pattern in (N.P1, N.CL100K, N.O200K, N.O200K_DOTNET):
         enc = N.Encoder(vocab, pattern)
         oenc = O.Encoder(ovocab, pattern)
         for it in range(rounds):
@@ -499,7 +526,7 @@ def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
             nd = rng.choice([1, 1, 1, 2, 7, 60, 400])
             docs = [gen_text(rng, kind, rng.choice([0, 1, 5, 20, 64, 100, 300, 1000]) if nd < 100 else rng.randint(0, 18), alpha).encode("utf-8")[:1024] for _ in range(nd)]
             docs = [d.decode("utf-8", "ignore").encode("utf-8") for d in docs]           # (the cut may have split a char)
-            while sum(map(len, docs)) > (65536 if pattern == N.O200K else 131072):
+            while sum(map(len, docs)) > (65536 if pattern in (N.O200K, N.O200K_DOTNET) else 131072):
                 docs.pop()
             if not sum(map(len, docs)):
                 continue
@@ -510,6 +537,8 @@ def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
             assert ids.tolist() == exp and ooff.tolist() == eoff, (pattern, it, kind, nd)
             after = enc.small_path_calls()
             assert after[0] == before[0] + 1, "a batch of %d bytes in %d documents must take the single-launch path" % (len(data), len(docs))
+            # the device-resident counts (what the count all-gather of a sharded job sends) are this batch's, whichever path it took
+            assert read_device_i64(lib, enc.counts_device, 3).tolist() == [len(docs), len(data), len(exp)], (pattern, it)
         # single strings through both single-string entries
         for text in ("Hello World", "Hello World, this is a short prompt of sixty-four bytes, more or", "⭐ naïve café 漢字かな 😀👍🏽 it's 12345\n\n  x", "a", " ", "\n"):
             b = text.encode("utf-8")
@@ -543,12 +572,12 @@ def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
         mid = ("lorem ipsum dolor sit amet, consectetur 12345 adipiscing elit; " * 300).encode()[:rng.choice([5000, 17000, 40000])]
         c0 = enc.small_path_calls()
         assert enc.encode_utf8(mid) == oenc.encode_bytes(mid)
-        assert enc.small_path_calls()[0] == c0[0] + (0 if pattern == N.O200K else 1)
-        mdocs = [("doc %d: the quick brown fox, it's 2024!\n" % i).encode() * rng.randint(1, 5) for i in range(300 if pattern == N.O200K else 800)]
+        assert enc.small_path_calls()[0] == c0[0] + (0 if pattern in (N.O200K, N.O200K_DOTNET) else 1)
+        mdocs = [("doc %d: the quick brown fox, it's 2024!\n" % i).encode() * rng.randint(1, 5) for i in range(300 if pattern in (N.O200K, N.O200K_DOTNET) else 800)]
         mdata, moffs = pack(mdocs)
         ids, ooff = enc.encode_batch(mdata, moffs)
         mexp, meoff = oracle_encode_docs(oenc, mdocs)
-        assert ids.tolist() == mexp and ooff.tolist() == meoff and len(mdata) <= (65536 if pattern == N.O200K else 131072)
+        assert ids.tolist() == mexp and ooff.tolist() == meoff and len(mdata) <= (65536 if pattern in (N.O200K, N.O200K_DOTNET) else 131072)
         # too large for the single launch: the batch path, untouched counters
         big = ("lorem ipsum dolor sit amet " * 6000).encode()
         c0 = enc.small_path_calls()
@@ -625,7 +654,7 @@ def check_utf16(lib, O, vocab, ovocab):
     """tkz_encode_utf16 vs the oracle's UTF-16 entry (lone surrogates -> U+FFFD per piece, TikTokenizer.cs:261)."""
     rng = random.Random(77)
     alpha = RC.alphabet()
-    for pattern in (N.P1, N.CL100K, N.O200K):
+    for pattern in (N.P1, N.CL100K, N.O200K, N.O200K_DOTNET):
         enc = N.Encoder(vocab, pattern)
         oenc = O.Encoder(ovocab, pattern)
         for it in range(12):
@@ -641,7 +670,7 @@ def check_utf16_batch(lib, O, vocab, ovocab, seed=91, rounds=10, doc_counts=(1, 
     other across a document boundary, pairs straddling the 16-unit lane groups and the 1024-unit tiles, empty documents."""
     rng = random.Random(seed)
     alpha = RC.alphabet()
-    for pattern in (N.P1, N.CL100K, N.O200K):
+    for pattern in (N.P1, N.CL100K, N.O200K, N.O200K_DOTNET):
         enc = N.Encoder(vocab, pattern)
         oenc = O.Encoder(ovocab, pattern)
         for it in range(rounds):
@@ -826,14 +855,28 @@ def check_begin_end(lib, O, vocab, ovocab, pattern=N.CL100K, seed=61, upload=Non
         data, offs = pack(docs)
         padded = np.zeros(len(data) + 64, np.uint8); padded[:len(data)] = data
         ids = np.zeros(max(1, len(data)), np.int32); ooff = np.zeros(len(docs) + 1, np.int64)
-        b = dict(docs=docs, n=len(docs), total=len(data), bytes=upload(padded), offs=upload(offs.astype(np.int64)), ids=upload(ids), ooff=upload(ooff))
-        b["h"] = enc.encode_batch_device_begin(b["bytes"][1], b["offs"][1], b["n"], b["total"], b["ids"][1], max(1, b["total"]), b["ooff"][1], streams[k % len(streams)])
+        b = dict(docs=docs, n=len(docs), total=len(data), bytes=upload(padded), offs=upload(offs.astype(np.int64)), ids=upload(ids), ooff=upload(ooff),
+                 counts=upload(np.full(3, -1, np.int64)))
+        # every batch its own {n_docs, n_bytes, n_tokens} block (batch 3: none given, the handle's workspace block)
+        b["h"] = enc.encode_batch_device_begin(b["bytes"][1], b["offs"][1], b["n"], b["total"], b["ids"][1], max(1, b["total"]), b["ooff"][1], streams[k % len(streams)],
+                                               d_counts3=0 if k == 3 else b["counts"][1])
+        assert enc.pending_counts_device(b["h"]) == (b["counts"][1] if k != 3 else enc.pending_counts_device(b["h"])) and enc.pending_counts_device(b["h"])
         batches.append(b)
+    back = lambda o: (o.cpu().numpy() if hasattr(o, "cpu") else o)
     for b in batches[::-1]:
         ntok = enc.encode_batch_device_end(b["h"])
-        back = lambda o: (o.cpu().numpy() if hasattr(o, "cpu") else o)
         exp, eoff = oracle_encode_docs(oenc, b["docs"])
         assert ntok == len(exp) and back(b["ids"][0])[:ntok].tolist() == exp and back(b["ooff"][0]).tolist() == eoff
+        b["ntok"] = ntok
+    # with all four ended (in reverse order, one of them run twice): every block holds ITS batch's counts
+    for k, b in enumerate(batches):
+        if k != 3:
+            assert back(b["counts"][0]).tolist() == [b["n"], b["total"], b["ntok"]], k
+    # an empty batch: _begin does not wait, the counts and offsets are there after _end
+    ec, eo = upload(np.full(3, -1, np.int64)), upload(np.full(3, -1, np.int64))
+    eb, ei_ = upload(np.zeros(64, np.uint8)), upload(np.zeros(3, np.int64))
+    h = enc.encode_batch_device_begin(eb[1], ei_[1], 2, 0, 0, 0, eo[1], streams[0], d_counts3=ec[1])
+    assert enc.encode_batch_device_end(h) == 0 and back(ec[0]).tolist() == [2, 0, 0] and back(eo[0]).tolist() == [0, 0, 0]
     # an error is reported by _end (and the handle is gone either way): offsets that do not end at the byte count
     data, offs = pack([b"abc", b"defg"])
     bad = offs.astype(np.int64).copy(); bad[-1] += 1
@@ -843,3 +886,10 @@ def check_begin_end(lib, O, vocab, ovocab, pattern=N.CL100K, seed=61, upload=Non
     with pytest.raises(N.TkzError) as ei:
         enc.encode_batch_device_end(h)
     assert ei.value.code == N.E_ARG
+    # tkz_encoder_destroy with a handle outstanding is deferred: the handle's _end reports it and frees the encoder
+    enc2 = N.Encoder(vocab, pattern)
+    b = batches[0]
+    h = enc2.encode_batch_device_begin(b["bytes"][1], b["offs"][1], b["n"], b["total"], b["ids"][1], max(1, b["total"]), b["ooff"][1], streams[0])
+    enc2.close()
+    tot = C.c_int64(0)
+    assert lib.L.tkz_encode_batch_device_end(h, C.byref(tot)) == N.E_ARG

@@ -64,7 +64,9 @@ def _compile(src, ws_in=r"\t-\r \x85\p{Z}"):
     return regex.compile("".join(out), regex.V0)
 
 
-PATTERNS = {1: _compile(P1_SRC), 2: _compile(CL_SRC), 3: _compile(O2_SRC, JS_WS_IN)}
+# pattern 4 = the o200k string as the C# reference would run it (TokenizerBuilder.cs:210-213 -> `new Regex(pattern, Compiled)`,
+# TikTokenizer.cs:77): the engine is fed code UNITS and \s is .NET's, exactly as for patterns 1 / cl100k
+PATTERNS = {1: _compile(P1_SRC), 2: _compile(CL_SRC), 3: _compile(O2_SRC, JS_WS_IN), 4: _compile(O2_SRC)}
 
 
 def to_units(s: str):
@@ -74,8 +76,9 @@ def to_units(s: str):
 
 
 def split_units_regex(pattern_id: int, units):
-    """(start, length) in UTF-16 units of every match.  Patterns 1 / cl100k: the engine is fed the code units themselves (.NET);
-    o200k: code points -- a well-formed surrogate pair is one character, a lone surrogate stays a lone (Cs) code point."""
+    """(start, length) in UTF-16 units of every match.  Patterns 1 / cl100k / 4 (o200k through .NET): the engine is fed the code units
+    themselves; 3 (o200k through ECMAScript): code points -- a well-formed surrogate pair is one character, a lone surrogate stays a lone
+    (Cs) code point."""
     if pattern_id != 3:
         s = "".join(map(chr, units))
         return [(m.start(), m.end() - m.start()) for m in PATTERNS[pattern_id].finditer(s)]

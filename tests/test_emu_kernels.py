@@ -45,7 +45,7 @@ def test_golden_gpt2_ids(lib, vocab, lib_rs_bytes):
     assert enc.encode_utf8(lib_rs_bytes) == load_golden_json("tokens_gpt2.json")
 
 
-@pytest.mark.parametrize("pattern,sequential", [(1, 0), (2, 0), (3, 0), (1, 1), (2, 1), (3, 1)])
+@pytest.mark.parametrize("pattern,sequential", [(1, 0), (2, 0), (3, 0), (4, 0), (1, 1), (2, 1), (3, 1), (4, 1)])
 def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
     parity.check_pretok(lib, oracle_mod, vocab, pattern, sequential, seeds=range(6),
                         kinds=["mix", "ws", "dig", "apo", "oth", "case", "a_ws", "a_dig", "a_apo", "a_oth", "a_mix", "a_brk", "a_case"],
@@ -84,26 +84,27 @@ def test_hand_derived_splits(lib, vocab, sequential):
             assert starts == exp_starts, (pat, text, bool(pre))
 
 
-@pytest.mark.parametrize("pattern", [1, 2, 3])
+@pytest.mark.parametrize("pattern", [1, 2, 3, 4])
 def test_pretok_long_runs(lib, vocab, oracle_mod, pattern):
     # runs that cross rows and whole 4 KiB blocks: the lane scans and the beyond-the-block searches of the block scanners
     parity.check_pretok(lib, oracle_mod, vocab, pattern, 0, seeds=range(5), kinds=("runs",), doc_lens=[3000, 30000, 70000], n_docs_choices=(1, 3))
 
 
-def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod):
+@pytest.mark.parametrize("pattern", [N.O200K, N.O200K_DOTNET])
+def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod, pattern):
     # CJK / kana / hangul / emoji / combining-mark text under o200k goes through the char-level block scanner, not the sequential matcher
-    blocks, after_ascii, after_mb = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["cjk", "case", "emoji", "upper", "all", "mark", "slash", "chain"], range(2))
+    blocks, after_ascii, after_mb = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["cjk", "case", "emoji", "upper", "all", "mark", "slash", "chain"], range(2), pattern=pattern)
     assert after_ascii > 0 and after_mb < after_ascii // 5, (blocks, after_ascii, after_mb)
     # `;\n/*` (a '/' swallowed by the tail of a punctuation piece, then more punctuation) and rows of nothing but '/' and line breaks no longer
     # send a block to the sequential matcher: the R4 / ABS flows are iterated and followed through the rows
-    b2, a2, m2 = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["mark", "slash"], range(2, 4))
+    b2, a2, m2 = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["mark", "slash"], range(2, 4), pattern=pattern)
     assert a2 > 0 and 10 * m2 < a2, (b2, a2, m2)
-    parity.check_o200k_no_sync_points(lib, oracle_mod, vocab)
+    parity.check_o200k_no_sync_points(lib, oracle_mod, vocab, pattern)
     # the bench's mixed corpus: every block holds multi-byte chars, all but the ragged last one are done by the block scanner
     docs = [N.corpus_doc_host(2, 0x5EED0001, d, 256, 768, lib=lib) for d in range(120)]
     data, offs = parity.pack(docs)
-    enc = N.Encoder(vocab, N.O200K)
-    assert np.array_equal(enc.pretokenize(data, offs), parity.oracle_bitmap(oracle_mod, N.O200K, docs))
+    enc = N.Encoder(vocab, pattern)
+    assert np.array_equal(enc.pretokenize(data, offs), parity.oracle_bitmap(oracle_mod, pattern, docs))
     a, b = enc.pretok_leftovers()
     assert a >= 10 and b == 0, (a, b)
 
@@ -182,7 +183,7 @@ def test_long_and_giant_pieces(lib, vocab, vocabs, oracle_mod, oracle_gpt2):
         assert ids[ooff[i]:ooff[i + 1]].tolist() == ([r] if r >= 0 else ov.bpe(p)), (i, len(p))
 
 
-@pytest.mark.parametrize("pattern,vname", [(1, "gpt2"), (2, "gpt2"), (3, "gpt2"), (2, "synth100k"), (3, "synth200k")])
+@pytest.mark.parametrize("pattern,vname", [(1, "gpt2"), (2, "gpt2"), (3, "gpt2"), (4, "gpt2"), (2, "synth100k"), (3, "synth200k")])
 def test_batch_vs_oracle(lib, vocabs, oracle_mod, pattern, vname):
     vocab, oracle_gpt2 = vocabs(vname)
     parity.check_batch(lib, oracle_mod, vocab, oracle_gpt2, pattern, seed=11 + pattern, rounds=5 if vname == "gpt2" else 3,
@@ -202,7 +203,7 @@ def test_decode_sparse_rank_table(lib, oracle_mod):
     parity.check_decode(lib, oracle_mod, N.Vocab(raw, lib), oracle_mod.Vocab(raw), rounds=2)
 
 
-@pytest.mark.parametrize("pattern", [1, 2, 3])
+@pytest.mark.parametrize("pattern", [1, 2, 3, 4])
 def test_piece_granular_batch(lib, vocab, oracle_mod, oracle_gpt2, pattern):
     parity.check_piece_granular(lib, oracle_mod, vocab, oracle_gpt2, pattern, rounds=6)
 

@@ -55,7 +55,7 @@ def test_golden_gpt2_ids(lib, vocab, lib_rs_bytes):
     assert enc.encode_utf16(units) == exp
 
 
-@pytest.mark.parametrize("pattern,sequential", [(1, 0), (2, 0), (3, 0), (1, 1), (2, 1), (3, 1)])
+@pytest.mark.parametrize("pattern,sequential", [(1, 0), (2, 0), (3, 0), (4, 0), (1, 1), (2, 1), (3, 1), (4, 1)])
 def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
     parity.check_pretok(lib, oracle_mod, vocab, pattern, sequential, seeds=range(25),
                         kinds=["mix", "ws", "dig", "apo", "oth", "case", "a_ws", "a_dig", "a_apo", "a_oth", "a_mix", "a_brk", "a_case"],
@@ -86,21 +86,22 @@ def test_hand_derived_splits(lib, vocab, sequential):
             assert starts == exp_starts, (pat, text, bool(pre))
 
 
-@pytest.mark.parametrize("pattern", [1, 2, 3])
+@pytest.mark.parametrize("pattern", [1, 2, 3, 4])
 def test_pretok_long_runs(lib, vocab, oracle_mod, pattern):
     # runs that cross rows and whole 4 KiB blocks: the lane scans and the beyond-the-block searches of the block scanners
     parity.check_pretok(lib, oracle_mod, vocab, pattern, 0, seeds=range(12), kinds=("runs",), doc_lens=[3000, 30000, 70000, 300000], n_docs_choices=(1, 3, 9))
 
 
-def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod):
+@pytest.mark.parametrize("pattern", [N.O200K, N.O200K_DOTNET])
+def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod, pattern):
     blocks, after_ascii, after_mb = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["cjk", "case", "emoji", "upper", "all", "mark", "slash", "chain"], range(12),
-                                                              doc_lens=(3000, 9000, 20000, 100000))
+                                                              doc_lens=(3000, 9000, 20000, 100000), pattern=pattern)
     assert after_ascii > 0 and after_mb < after_ascii // 5, (blocks, after_ascii, after_mb)
     # `;\n/*` (a '/' swallowed by the tail of a punctuation piece, then more punctuation) and rows of nothing but '/' and line breaks no longer
     # send a block to the sequential matcher: the R4 / ABS flows are iterated and followed through the rows
-    b2, a2, m2 = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["mark", "slash"], range(12, 24))
+    b2, a2, m2 = parity.check_o200k_blocks(lib, oracle_mod, vocab, ["mark", "slash"], range(12, 24), pattern=pattern)
     assert a2 > 0 and 10 * m2 < a2, (b2, a2, m2)
-    parity.check_o200k_no_sync_points(lib, oracle_mod, vocab)
+    parity.check_o200k_no_sync_points(lib, oracle_mod, vocab, pattern)
 
 
 def test_golden_splits(lib, vocab):
@@ -198,7 +199,7 @@ def test_giant_pieces(lib, vocabs, oracle_mod, vname):
     parity.check_long_diverse_pieces(lib, oracle_mod, vocab, oracle_gpt2, lens=(3000, 9000, 20000, 33000, 50000))
 
 
-@pytest.mark.parametrize("pattern,vname", [(1, "gpt2"), (2, "gpt2"), (3, "gpt2"), (2, "synth100k"), (3, "synth200k"), (1, "synth200k")])
+@pytest.mark.parametrize("pattern,vname", [(1, "gpt2"), (2, "gpt2"), (3, "gpt2"), (4, "gpt2"), (2, "synth100k"), (3, "synth200k"), (4, "synth200k"), (1, "synth200k")])
 def test_batch_vs_oracle(lib, vocabs, oracle_mod, pattern, vname):
     v, ov = vocabs(vname)
     parity.check_batch(lib, oracle_mod, v, ov, pattern, seed=11 + pattern, rounds=12 if vname == "gpt2" else 8,
@@ -218,7 +219,7 @@ def test_decode_sparse_rank_table(lib, oracle_mod):
     parity.check_decode(lib, oracle_mod, N.Vocab(raw, lib), oracle_mod.Vocab(raw), rounds=2)
 
 
-@pytest.mark.parametrize("pattern", [1, 2, 3])
+@pytest.mark.parametrize("pattern", [1, 2, 3, 4])
 def test_piece_granular_batch(lib, vocab, oracle_mod, oracle_gpt2, pattern):
     parity.check_piece_granular(lib, oracle_mod, vocab, oracle_gpt2, pattern, rounds=20)
 
@@ -287,7 +288,7 @@ def _token_lengths(ovocab):
 @pytest.mark.parametrize("vname,kind,pattern,n_docs,lo,hi", [
     ("gpt2", 1, 2, 400_000, 256, 768), ("synth100k", 1, 2, 400_000, 256, 768), ("synth100k", 2, 2, 200_000, 256, 768),
     ("synth200k", 3, 3, 1_500, 30_000, 34_000), ("gpt2", 1, 1, 100_000, 16, 128), ("synth100k", 3, 2, 1_500, 30_000, 34_000),
-    ("synth200k", 2, 3, 100_000, 256, 768),
+    ("synth200k", 2, 3, 100_000, 256, 768), ("synth200k", 2, 4, 100_000, 256, 768),
     # BASELINE.json configs[1], [2] and one GPU's share of [4] at full size, on the stand-ins of the vocabularies they name
     ("synth100k", 1, 2, 10_000_000, 256, 768), ("synth100k", 2, 2, 2_000_000, 256, 768), ("synth200k", 3, 3, 32_768, 30_000, 34_000),
     # one GPU's share of BASELINE.json configs[3] (100 M documents over 8 GPUs): the LAST rank's 12.5 M documents

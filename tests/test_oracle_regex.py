@@ -9,7 +9,7 @@ import pytest
 import regex_crosscheck as RC
 
 
-@pytest.mark.parametrize("pattern", [1, 2, 3])
+@pytest.mark.parametrize("pattern", [1, 2, 3, 4])
 def test_split_units_random(oracle_mod, pattern):
     rng = random.Random(1234 + pattern)
     alpha = RC.alphabet()
@@ -19,7 +19,7 @@ def test_split_units_random(oracle_mod, pattern):
         assert oracle_mod.split_utf16(pattern, units) == RC.split_units_regex(pattern, units), repr(s)
 
 
-@pytest.mark.parametrize("pattern", [1, 2, 3])
+@pytest.mark.parametrize("pattern", [1, 2, 3, 4])
 def test_split_utf8_equals_utf16_on_valid_text(oracle_mod, pattern):
     rng = random.Random(99 + pattern)
     alpha = RC.alphabet()

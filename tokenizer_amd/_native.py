@@ -12,7 +12,8 @@ DEFAULT_LIB = os.environ.get("TKZ_LIBTKZ") or os.path.join(_HERE, "lib", "libtkz
 
 OK = 0
 E_FORMAT, E_DUP_RANK, E_KEY_NOT_FOUND, E_CAPACITY, E_INVALID_UTF8, E_ARG, E_UNSUPPORTED, E_DEVICE, E_NO_DEVICE, E_OUT_OF_MEMORY = range(-1, -11, -1)
-P1, CL100K, O200K = 1, 2, 3
+ENGINE_DOTNET, ENGINE_ECMASCRIPT = 0, 1
+P1, CL100K, O200K, O200K_DOTNET = 1, 2, 3, 4   # O200K: ECMAScript engine (TS reference); O200K_DOTNET: the same string through .NET Regex
 OPT_PRETOK_SEQUENTIAL = 1
 OPT_PIECE_MEMO = 2
 K_NAMES = ["k_docmark", "k_pretok", "k_probe", "k_scan", "k_place", "k_docoffs", "k_merge_long_group", "k_merge_short"]
@@ -91,6 +92,7 @@ class Library:
         L.tkz_vocab_table_bytes.restype = i64
         L.tkz_vocab_rank.argtypes = [vp, vp, i32]
         L.tkz_pattern_from_regex.argtypes = [C.c_char_p, C.POINTER(i32)]
+        L.tkz_pattern_from_regex_engine.argtypes = [C.c_char_p, i32, C.POINTER(i32)]
         L.tkz_encoder_create.argtypes = [vp, i32, i32, pv]
         L.tkz_encoder_destroy.argtypes = [vp]
         L.tkz_encoder_destroy.restype = None
@@ -99,6 +101,9 @@ class Library:
         L.tkz_encode_batch_device.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, pi64]
         L.tkz_encode_batch_device_begin.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, C.POINTER(vp)]
         L.tkz_encode_batch_device_end.argtypes = [vp, pi64]
+        L.tkz_encode_batch_device_begin_counts.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, vp, C.POINTER(vp)]
+        L.tkz_pending_counts_device.argtypes = [vp]
+        L.tkz_pending_counts_device.restype = vp
         L.tkz_encode_batch_utf16.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
         L.tkz_encode_utf8.argtypes = [vp, vp, i64, vp, i64, pi64]
         L.tkz_encode_utf16.argtypes = [vp, vp, i64, vp, i64, pi64]
@@ -396,12 +401,17 @@ class Encoder:
                                                           d_out_offsets, stream or None, C.byref(tot)))
         return tot.value
 
-    def encode_batch_device_begin(self, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, stream=0):
-        """Enqueues the batch and returns a handle for encode_batch_device_end (several may be in flight)."""
+    def encode_batch_device_begin(self, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, stream=0, d_counts3=0):
+        """Enqueues the batch and returns a handle for encode_batch_device_end (several may be in flight).  d_counts3: device pointer to
+        3 int64 of the caller's that receive THIS batch's {n_docs, n_bytes, n_tokens} (final once _end has returned)."""
         h = C.c_void_p()
-        self.lib.check(self.lib.L.tkz_encode_batch_device_begin(self._h, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap,
-                                                                d_out_offsets, stream or None, C.byref(h)))
+        self.lib.check(self.lib.L.tkz_encode_batch_device_begin_counts(self._h, d_bytes, d_offsets, n_docs, total_bytes, d_out_ids, out_cap,
+                                                                       d_out_offsets, stream or None, d_counts3 or None, C.byref(h)))
         return h
+
+    def pending_counts_device(self, pending):
+        """Device pointer to the {n_docs, n_bytes, n_tokens} block of a batch in flight (tkz_pending_counts_device)."""
+        return self.lib.L.tkz_pending_counts_device(pending)
 
     def encode_batch_device_end(self, pending):
         tot = C.c_int64(0)

@@ -66,7 +66,7 @@ struct DevBuf {
 };
 
 struct CounterBlock {          // mirrors the device block
-    int32_t err; int32_t mneed /* longest miss list of a sub-tile (kErrMissCap) */; int32_t pad[2];
+    int32_t err; int32_t mneed /* longest miss list of a sub-tile (kErrMissCap) */; int32_t mhigh /* longest list above kMissCapMin that fitted */; int32_t pad;
     int64_t grand;
     unsigned long long pool_head;
     int64_t ndocstarts;
@@ -91,6 +91,7 @@ struct Workspace {
     // kernel workspace
     DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_dense, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
     DevBuf w_mlist, w_mquad, w_mcount;
+    DevBuf w_counts3;                      // {n_docs, n_bytes, n_tokens} of the batch this workspace is running (tkz_pending_counts_device)
     int32_t mcap = tkz::kMissCapMin;       // entries of a sub-tile's miss list; grows (once, to what the batch needed) when a sub-tile overflows it
     // staging for the host-buffer entry points (two sets: chunk k+1 is uploaded while chunk k is encoded and chunk k-1 downloaded)
     DevBuf s_bytes[2], s_offs[2], s_out[2], s_outoffs[2];
@@ -104,7 +105,8 @@ struct Workspace {
     // the single-launch path for small batches (k_small): input, output and status in ONE page-locked block the device reads and writes directly
     uint8_t* h_small = nullptr;
     hipStream_t st_small = nullptr;        // (non-blocking: a small call never waits for another thread's batch on the legacy default stream)
-    int64_t small_calls = 0, small_fallbacks = 0;
+    std::atomic<int64_t> small_calls{0}, small_fallbacks{0};   // (read by tkz_encoder_small_path_calls from other threads)
+    int64_t small_clocks[16] = {};         // the phase stamps of the last single-launch call, copied out after its synchronisation
     hipStream_t st_compute = nullptr, st_in = nullptr, st_out = nullptr;   // the host-buffer entry points: kernels / uploads / downloads
     hipEvent_t ev_in[2] = {}, ev_done[2] = {}, ev_out[2] = {};
     int64_t bytes_allocated = 0;
@@ -115,7 +117,7 @@ struct Workspace {
     double ms[tkz::K_COUNT] = {};
     int64_t launches[tkz::K_COUNT] = {};
     void release_all() {
-        DevBuf* bufs[] = {&w_mlist, &w_mquad, &w_mcount, &w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
+        DevBuf* bufs[] = {&w_counts3, &w_mlist, &w_mquad, &w_mcount, &w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
                           &w_doctok, &w_dcount, &w_dbase, &w_counters, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
                           &s_outoffs[0], &s_outoffs[1], &u_units, &u_offs, &u_docbits, &u_grp, &u_tsum, &u_tbase, &u_bsum, &u_counters, &u_bytes, &u_boffs,
                           &d_grp, &d_tsum, &d_tbase, &d_bsum, &d_counters, &d_ids, &d_idoffs, &d_out, &d_outoffs, &p_boffs, &p_toffs, &p_docp};
@@ -149,6 +151,8 @@ struct tkz_encoder {
     std::vector<std::pair<int32_t, std::string>> dec_vocab, dec_special;   // host copies (id, bytes)
     int64_t bytes_allocated = 0;           // tables
     std::atomic<int64_t> last_xcount{0}, last_xcount2{0};   // tkz_encoder_pretok_leftovers
+    int pending = 0;                       // tkz_pending handles outstanding (under mu)
+    bool destroyed = false;                // tkz_encoder_destroy was called while handles were outstanding: the last _end frees the encoder
 };
 
 namespace {
@@ -249,6 +253,7 @@ tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool 
     HIP_TRY(ws->w_docbits.ensure((size_t)(nwords + 8) * 8, acc));
     HIP_TRY(ws->w_startbits.ensure((size_t)(nwords + 8) * 8, acc));
     HIP_TRY(ws->w_counters.ensure(sizeof(CounterBlock), acc));
+    HIP_TRY(ws->w_counts3.ensure(32, acc));
     if (!bitmap_only) {
         HIP_TRY(ws->w_tmp.ensure((size_t)(total + 64) * 4, acc));
         HIP_TRY(ws->w_dense.ensure((size_t)(ntiles / kMergeGroup + 1) * kDenseCap * 4, acc));
@@ -283,7 +288,7 @@ struct PiecesOut { int64_t* piece_boffs; int64_t* piece_toffs; int64_t* doc_piec
 enum { kCallWhole = 0, kCallBegin = 1, kCallEnd = 2 };
 tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                          int32_t* d_out, int64_t out_cap, int64_t* d_out_offs, hipStream_t stream, bool pretok,
-                         uint64_t* d_bitmap_only, int64_t* total_tokens, PiecesOut* po = nullptr, int phase = kCallWhole) {
+                         uint64_t* d_bitmap_only, int64_t* total_tokens, PiecesOut* po = nullptr, int phase = kCallWhole, int64_t* d_counts3 = nullptr) {
     // phase: kCallWhole -- enqueue, wait, evaluate (and again if a buffer had to grow); kCallBegin -- enqueue the first attempt and
     // return; kCallEnd -- wait for that attempt, evaluate, and carry on as kCallWhole does (tkz_encode_batch_device_begin / _end)
     using namespace tkz;
@@ -292,10 +297,14 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
     if (n_docs == 0 && total != 0) return fail(TKZ_E_ARG, "bytes without documents");
     const int64_t nwords = total / 64 + 1;
     if (total == 0) {
-        if (phase == kCallEnd) return TKZ_OK;                     // (done when it began)
-        { tkz::Launch L0{stream, nullptr, ws}; tkz::launch_counts3(L0, n_docs, 0, nullptr, e->t_counts3.as<int64_t>()); }
-        if (d_out_offs) HIP_TRY(hipMemsetAsync(d_out_offs, 0, (size_t)(n_docs + 1) * sizeof(int64_t), stream));
-        if (d_bitmap_only) { const uint64_t one = 1; HIP_TRY(hipMemcpyAsync(d_bitmap_only, &one, 8, hipMemcpyHostToDevice, stream)); }
+        if (phase != kCallEnd) {                                  // (kCallEnd: enqueued when it began)
+            int64_t* acc0 = &ws->bytes_allocated;
+            HIP_TRY(ws->w_counts3.ensure(32, acc0));
+            { tkz::Launch L0{stream, nullptr, ws}; tkz::launch_counts3(L0, n_docs, 0, nullptr, e->t_counts3.as<int64_t>(), ws->w_counts3.as<int64_t>(), d_counts3); }
+            if (d_out_offs) HIP_TRY(hipMemsetAsync(d_out_offs, 0, (size_t)(n_docs + 1) * sizeof(int64_t), stream));
+            if (d_bitmap_only) { const uint64_t one = 1; HIP_TRY(hipMemcpyAsync(d_bitmap_only, &one, 8, hipMemcpyHostToDevice, stream)); }
+            if (phase == kCallBegin) return TKZ_OK;               // (_begin returns without waiting)
+        }
         HIP_TRY(hipStreamSynchronize(stream));
         return TKZ_OK;
     }
@@ -378,7 +387,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             launch_place(L, P, ws->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
             if (po) { if (!pieces_over) launch_docoffs(L, po->piece_boffs, po->n_pieces, total, ws->w_tbase.as<int64_t>(), markbits, P.docord_base, P.doc_tok, grand, po->piece_toffs); }
             else launch_docoffs(L, d_offs, n_docs, total, ws->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs);
-            launch_counts3(L, n_docs, total, grand, e->t_counts3.as<int64_t>());
+            launch_counts3(L, n_docs, total, grand, e->t_counts3.as<int64_t>(), ws->w_counts3.as<int64_t>(), d_counts3);
         }
         HIP_TRY(hipMemcpyAsync(ws->h_counters, counters, sizeof(CounterBlock), hipMemcpyDeviceToHost, stream));
         }
@@ -433,6 +442,20 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         }
         if (err & kErrCapacity) return fail(TKZ_E_DEVICE, "piece record buffer overflow");
         if (err & kErrKeyNotFound) return fail(TKZ_E_KEY_NOT_FOUND, "a byte of the input is not in the vocabulary (KeyNotFoundException in the reference)");
+        if (!d_bitmap_only && ws->mcap > kMissCapMin) {
+            // lists that were grown for an earlier batch (text where nearly every piece misses) and that this batch filled to less than
+            // half: shorter lists from here on, and the buffers given back when they are far larger than such a batch needs (the lists
+            // are ntiles * mcap * 20 bytes: 1.25 B per input byte at 64 entries, 20 B at 1024)
+            int32_t want = kMissCapMin;
+            while (want < ws->h_counters->mhigh) want *= 2;
+            if (want < ws->mcap) {
+                ws->mcap = want;
+                if (ws->w_mquad.cap > (size_t)ntiles * (size_t)want * 16 * 4) {
+                    *acc -= (int64_t)(ws->w_mquad.cap + ws->w_mlist.cap);
+                    ws->w_mquad.release(); ws->w_mlist.release();
+                }
+            }
+        }
         if (!d_bitmap_only) {
             if (total_tokens) *total_tokens = ws->h_counters->grand;
             if (pieces_over) return fail(TKZ_E_CAPACITY, "piece arrays too small");
@@ -454,8 +477,9 @@ constexpr size_t kSmallOffBytes = 0, kSmallOffOffs = tkz::kSmallMaxBytes + 64, k
                  kSmallOffOut = kSmallOffIds + tkz::kSmallMaxBytes * 4, kSmallOffRes = kSmallOffOut + (tkz::kSmallMaxDocs + 1) * 8, kSmallBlock = kSmallOffRes + 256;
 bool small_eligible(const tkz_encoder* e, const int64_t* offs, int64_t n_docs, int64_t total) {
     if (e->profiling || e->pretok_seq || total <= 0 || total > tkz::kSmallMaxBytes || n_docs < 1 || n_docs > tkz::kSmallMaxDocs) return false;
-    if (e->pattern == TKZ_PATTERN_O200K && total > tkz::kSmallMaxBytesO200k) return false;
-    if (e->pattern == TKZ_PATTERN_O200K)          // (split by the sequential matcher there, one lane per document)
+    const bool o200k = e->pattern == TKZ_PATTERN_O200K || e->pattern == TKZ_PATTERN_O200K_DOTNET;
+    if (o200k && total > tkz::kSmallMaxBytesO200k) return false;
+    if (o200k)                                    // (split by the sequential matcher there, one lane per document)
         for (int64_t d = 0; d < n_docs; ++d) { const int64_t len = offs[d + 1] - offs[d]; if (len < 0 || len > tkz::kSmallMaxDoc) return false; }
     return true;
 }
@@ -495,12 +519,14 @@ tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, con
     A.docbits = ws->w_docbits.as<uint64_t>(); A.startbits = ws->w_startbits.as<uint64_t>();
     A.pcount = ws->w_pcount.as<int32_t>(); A.pbase = ws->w_pbase.as<int64_t>(); A.docord_base = ws->w_dbase.as<int64_t>(); A.tile_base = ws->w_tbase.as<int64_t>();
     A.counter_words = (int32_t)(sizeof(CounterBlock) / 4);
+    A.counts3[0] = e->t_counts3.as<int64_t>(); A.counts3[1] = ws->w_counts3.as<int64_t>();
     Launch L{ws->st_small, nullptr, ws};
     launch_small(L, e->T, P, A);
     HIP_TRY(hipStreamSynchronize(ws->st_small));
     HIP_TRY(hipGetLastError());
-    ++ws->small_calls;
-    if (h_res[0] != 0) { ++ws->small_fallbacks; return TKZ_OK; }          // (handled stays false)
+    ws->small_calls.fetch_add(1, std::memory_order_relaxed);
+    { std::lock_guard<std::mutex> lock(e->mu); memcpy(ws->small_clocks, h_res + 4, sizeof ws->small_clocks); }
+    if (h_res[0] != 0) { ws->small_fallbacks.fetch_add(1, std::memory_order_relaxed); return TKZ_OK; }          // (handled stays false)
     const int64_t tokens = h_res[2];
     if (needed) *needed = tokens;
     *handled = true;
@@ -700,18 +726,27 @@ void tkz_unicode_classes(uint32_t first, int32_t n, uint8_t* out) {
     for (int32_t i = 0; out && i < n; ++i) out[i] = tkz_supp_class(ucd, first + (uint32_t)i);
 }
 
-tkz_status tkz_pattern_from_regex(const char* regex_utf8, int32_t* pattern_out) {
+tkz_status tkz_pattern_from_regex_engine(const char* regex_utf8, int32_t engine, int32_t* pattern_out) {
     if (!regex_utf8 || !pattern_out) return fail(TKZ_E_ARG, "null argument");
-    if (!strcmp(regex_utf8, kRegexP1)) { *pattern_out = TKZ_PATTERN_P1; return TKZ_OK; }
-    if (!strcmp(regex_utf8, kRegexCl100k)) { *pattern_out = TKZ_PATTERN_CL100K; return TKZ_OK; }
-    if (!strcmp(regex_utf8, kRegexO200k)) { *pattern_out = TKZ_PATTERN_O200K; return TKZ_OK; }
-    return fail(TKZ_E_UNSUPPORTED, "only the three split patterns the reference defines are implemented (pattern 1, cl100k_base, o200k_base)");
+    if (engine != TKZ_ENGINE_DOTNET && engine != TKZ_ENGINE_ECMASCRIPT) return fail(TKZ_E_ARG, "unknown regex engine id");
+    int32_t p = 0;
+    if (!strcmp(regex_utf8, kRegexP1)) p = TKZ_PATTERN_P1;
+    else if (!strcmp(regex_utf8, kRegexCl100k)) p = TKZ_PATTERN_CL100K;
+    else if (!strcmp(regex_utf8, kRegexO200k)) p = engine == TKZ_ENGINE_ECMASCRIPT ? TKZ_PATTERN_O200K : TKZ_PATTERN_O200K_DOTNET;
+    else return fail(TKZ_E_UNSUPPORTED, "only the three split patterns the reference defines are implemented (pattern 1, cl100k_base, o200k_base)");
+    if (engine == TKZ_ENGINE_ECMASCRIPT && p != TKZ_PATTERN_O200K)
+        return fail(TKZ_E_UNSUPPORTED, "pattern 1 and cl100k_base are implemented with the semantics of the C# reference's engine only (UTF-16 code units, .NET \\s)");
+    *pattern_out = p;
+    return TKZ_OK;
+}
+tkz_status tkz_pattern_from_regex(const char* regex_utf8, int32_t* pattern_out) {
+    return tkz_pattern_from_regex_engine(regex_utf8, TKZ_ENGINE_DOTNET, pattern_out);
 }
 
 tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t device, tkz_encoder** out) {
     if (!out || !v) return fail(TKZ_E_ARG, "null argument");
     *out = nullptr;
-    if (pattern < TKZ_PATTERN_P1 || pattern > TKZ_PATTERN_O200K) return fail(TKZ_E_UNSUPPORTED, "unknown pattern id");
+    if (pattern < TKZ_PATTERN_P1 || pattern > TKZ_PATTERN_O200K_DOTNET) return fail(TKZ_E_UNSUPPORTED, "unknown pattern id");
     int ndev = 0;
     hipError_t r = hipGetDeviceCount(&ndev);
     if (r != hipSuccess || ndev <= 0) return fail(TKZ_E_NO_DEVICE, "no HIP device available (libtkz has no CPU fallback)");
@@ -770,8 +805,20 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     return TKZ_OK;
 }
 
+namespace {
+void destroy_now(tkz_encoder* e);
+}
 void tkz_encoder_destroy(tkz_encoder* e) {
     if (!e) return;
+    {   // handles of tkz_encode_batch_device_begin still outstanding: their _end calls need the encoder and its workspaces -- the last of
+        // them frees it (and reports TKZ_E_ARG: the results of a batch whose encoder was destroyed under it are not to be trusted)
+        std::lock_guard<std::mutex> lock(e->mu);
+        if (e->pending > 0) { e->destroyed = true; return; }
+    }
+    destroy_now(e);
+}
+namespace {
+void destroy_now(tkz_encoder* e) {
     DeviceScope scope;
     (void)scope.enter(e->device);
     DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp, &e->t_counts3, &e->t_memo, &e->t_decoff, &e->t_decblob, &e->t_decids};
@@ -779,6 +826,7 @@ void tkz_encoder_destroy(tkz_encoder* e) {
     for (Workspace* w : e->pool) { w->release_all(); delete w; }
     delete e;
 }
+}  // namespace
 int32_t tkz_encoder_device(const tkz_encoder* e) { return e ? e->device : -1; }
 const int64_t* tkz_encoder_counts_device(const tkz_encoder* e) { return e ? e->t_counts3.as<int64_t>() : nullptr; }
 
@@ -808,10 +856,11 @@ tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const
 struct tkz_pending {
     tkz_encoder* e; Lease* lease;
     const uint8_t* d_bytes; const int64_t* d_offs; int64_t n_docs, total; int32_t* d_out; int64_t out_cap; int64_t* d_out_offs; hipStream_t stream;
+    int64_t* d_counts3;                    // the caller's block for this batch's {n_docs, n_bytes, n_tokens} (may be null)
 };
-tkz_status tkz_encode_batch_device_begin(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets, int64_t n_docs,
-                                         int64_t total_bytes, int32_t* d_out_ids, int64_t out_cap, int64_t* d_out_offsets,
-                                         void* hip_stream, tkz_pending** pending) {
+tkz_status tkz_encode_batch_device_begin_counts(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets, int64_t n_docs,
+                                                int64_t total_bytes, int32_t* d_out_ids, int64_t out_cap, int64_t* d_out_offsets,
+                                                void* hip_stream, int64_t* d_counts3, tkz_pending** pending) {
     if (!pending) return fail(TKZ_E_ARG, "null pending");
     *pending = nullptr;
     DeviceScope scope;
@@ -819,24 +868,48 @@ tkz_status tkz_encode_batch_device_begin(tkz_encoder* e, const uint8_t* d_bytes,
     if (st != TKZ_OK) return st;
     if (!d_doc_offsets || !d_out_offsets || (total_bytes > 0 && (!d_bytes || !d_out_ids))) return fail(TKZ_E_ARG, "null device buffer");
     if (reinterpret_cast<uintptr_t>(d_bytes) & 15) return fail(TKZ_E_ARG, "d_bytes must be 16-byte aligned");
-    tkz_pending* p = new tkz_pending{e, new Lease(e), d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, static_cast<hipStream_t>(hip_stream)};
-    st = encode_device(e, p->lease->ws, d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, p->stream, true, nullptr, nullptr, nullptr, kCallBegin);
-    if (st != TKZ_OK) { (void)hipStreamSynchronize(p->stream); delete p->lease; delete p; return st; }
+    { std::lock_guard<std::mutex> lock(e->mu); if (e->destroyed) return fail(TKZ_E_ARG, "encoder destroyed"); ++e->pending; }
+    tkz_pending* p = new tkz_pending{e, new Lease(e), d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, static_cast<hipStream_t>(hip_stream), d_counts3};
+    st = encode_device(e, p->lease->ws, d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, p->stream, true, nullptr, nullptr, nullptr, kCallBegin, d_counts3);
+    if (st != TKZ_OK) {
+        (void)hipStreamSynchronize(p->stream);
+        delete p->lease; delete p;
+        std::lock_guard<std::mutex> lock(e->mu); --e->pending;
+        return st;
+    }
     *pending = p;
     return TKZ_OK;
+}
+tkz_status tkz_encode_batch_device_begin(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets, int64_t n_docs,
+                                         int64_t total_bytes, int32_t* d_out_ids, int64_t out_cap, int64_t* d_out_offsets,
+                                         void* hip_stream, tkz_pending** pending) {
+    return tkz_encode_batch_device_begin_counts(e, d_bytes, d_doc_offsets, n_docs, total_bytes, d_out_ids, out_cap, d_out_offsets, hip_stream, nullptr, pending);
+}
+const int64_t* tkz_pending_counts_device(const tkz_pending* p) {
+    if (!p) return nullptr;
+    return p->d_counts3 ? p->d_counts3 : p->lease->ws->w_counts3.as<int64_t>();
 }
 tkz_status tkz_encode_batch_device_end(tkz_pending* p, int64_t* total_tokens) {
     if (!p) return fail(TKZ_E_ARG, "null pending");
     tkz_status st;
+    tkz_encoder* e = p->e;
     {
         DeviceScope scope;
-        st = check_encoder(p->e, scope);
-        if (st == TKZ_OK)
-            st = encode_device(p->e, p->lease->ws, p->d_bytes, p->d_offs, p->n_docs, p->total, p->d_out, p->out_cap, p->d_out_offs, p->stream, true, nullptr, total_tokens, nullptr, kCallEnd);
-        else (void)hipStreamSynchronize(p->stream);
+        st = check_encoder(e, scope);
+        bool dead;
+        { std::lock_guard<std::mutex> lock(e->mu); dead = e->destroyed; }
+        if (st == TKZ_OK && !dead)
+            st = encode_device(e, p->lease->ws, p->d_bytes, p->d_offs, p->n_docs, p->total, p->d_out, p->out_cap, p->d_out_offs, p->stream, true, nullptr, total_tokens, nullptr, kCallEnd, p->d_counts3);
+        else {
+            (void)hipStreamSynchronize(p->stream);
+            if (st == TKZ_OK) st = fail(TKZ_E_ARG, "the encoder was destroyed while this batch was in flight");
+        }
     }
     delete p->lease;
     delete p;
+    bool last;
+    { std::lock_guard<std::mutex> lock(e->mu); last = --e->pending == 0 && e->destroyed; }
+    if (last) destroy_now(e);
     return st;
 }
 
@@ -1140,7 +1213,7 @@ int32_t tkz_encoder_small_path_phases(const tkz_encoder* e, int64_t* clocks16) {
     if (!e || !clocks16) return 0;
     tkz_encoder* m = const_cast<tkz_encoder*>(e);
     std::lock_guard<std::mutex> lock(m->mu);
-    for (Workspace* w : e->pool) if (w->h_small) { memcpy(clocks16, w->h_small + kSmallOffRes + 32, 16 * 8); return 16; }
+    for (Workspace* w : e->pool) if (w->h_small) { memcpy(clocks16, w->small_clocks, 16 * 8); return 16; }      // (a snapshot taken after the call's synchronisation, never the block a kernel may be writing)
     return 0;
 }
 int32_t tkz_encoder_memo_ways(const tkz_encoder* e) { return e ? (int32_t)kMemoWays : 0; }

@@ -49,7 +49,7 @@ struct EncodeParams {
     uint32_t* mcount;             // per sub-tile: short misses | long misses << 16
     const int64_t* docord_base;   // per sub-tile: number of distinct document-start positions before it
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
-    int32_t* counters;            // [0] error bits, [1] the longest miss list seen (kErrMissCap)
+    int32_t* counters;            // [0] error bits, [1] the longest miss list seen (kErrMissCap), [2] the longest list above kMissCapMin that fitted (grown lists only)
     uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_probe: bit 0 = long misses in its list, bit 1 = a giant piece
                                                                           // (a flag, not a queue: a queue's one counter serialises a million atomics on mixed text)
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)
@@ -71,6 +71,7 @@ struct SmallArgs {
     uint64_t* docbits; uint64_t* startbits;                 // the workspace arrays EncodeParams holds as const, writable
     int32_t* pcount; int64_t* pbase; int64_t* docord_base; int64_t* tile_base;
     int32_t counter_words;                                  // 32-bit words of the counter block to zero
+    int64_t* counts3[2];                                    // {n_docs, n_bytes, n_tokens} of the batch, on the device: the encoder's block and the workspace's (either may be null)
 };
 
 typedef void (*KernelHook)(void* ctx, int kernel_id, int phase /*0 before, 1 after*/, hipStream_t s);
@@ -93,7 +94,7 @@ void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_ba
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
                     const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs);
 void launch_rebase(const Launch& L, int64_t* offs, int64_t n, int64_t base);
-void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3);
+void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3, int64_t* out3b = nullptr, int64_t* out3c = nullptr);
 // UTF-16 documents -> UTF-8 documents (Encoding.UTF8.GetBytes for a batch): lengths + group prefixes, then (after the scan of
 // the tile sums) the bytes and the byte offset of every document
 int64_t u16_tiles(int64_t total_units);

@@ -214,7 +214,8 @@ TKZ_DEV void tkz_pretok_block(int64_t blk, uint4* s_blk, const uint16_t* s_aflag
 // evaluator (tkz_block_eval_o200k_mb).  A kernel of its own so that its registers stay out of the ASCII scanner's.  What it
 // refuses as well goes into the second queue, for k_pretok_seq_blocks.
 TKZ_KERNEL_OCC(64, 3) void k_pretok_mb_blocks(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits, int64_t nrows,
-                                       const uint8_t* bmp, const uint8_t* xflag, int64_t nblk, unsigned long long* xcount, int64_t* xq2, unsigned long long* xcount2) {
+                                       const uint8_t* bmp, const uint8_t* xflag, int64_t nblk, unsigned long long* xcount, int64_t* xq2, unsigned long long* xcount2,
+                                       int by_code_point) {
     TKZ_SHARED uint4 s_blk[(65 * kBlockRowStride) / 16];
     const int lane = simt::lane();
     unsigned long long mine = 0;
@@ -248,7 +249,7 @@ TKZ_KERNEL_OCC(64, 3) void k_pretok_mb_blocks(const uint8_t* bytes, int64_t tota
             const int64_t row = first + lane;
             const uint64_t ds = (row >= 0 && row < nrows) ? docbits[row] : 0;
             TkzBlockCtx X; X.bytes = bytes; X.docbits = docbits; X.total = total; X.nrows = nrows; X.row0 = first;
-            done = tkz_block_eval_o200k_mb(reinterpret_cast<const uint8_t*>(s_blk), ds, X, bmp, &out);
+            done = tkz_block_eval_o200k_mb(reinterpret_cast<const uint8_t*>(s_blk), ds, X, bmp, by_code_point != 0, &out);
             if (done && lane >= 1 && lane <= kRowsPerWave && row < nrows) startbits[row] = out;
         }
         if (!done && lane == 0) xq2[simt::atomic_add64(xcount2, 1ull)] = blk;
@@ -853,6 +854,9 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
         P.heavy_flag[sub] = (uint8_t)f;
         P.mcount[sub] = (uint32_t)ns | ((uint32_t)nl << 16);
         if (ns + nl > P.mcap) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&P.counters[1], (unsigned)(ns + nl)); }
+        // lists that were grown: the longest one this batch really needed, so that the host can let them shrink again (read first: the
+        // maximum settles after a few sub-tiles and the rest only read it)
+        else if (P.mcap > kMissCapMin && ns + nl > kMissCapMin && *(volatile const int32_t*)&P.counters[2] < ns + nl) simt::atomic_max((unsigned*)&P.counters[2], (unsigned)(ns + nl));
         if (pb + np > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
     }
 }
@@ -1762,8 +1766,14 @@ TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
 }
 
 // {n_docs, n_bytes, n_tokens} of the batch, on the device: what tkz_comm_allgather_counts_device sends (no host round trip)
-TKZ_KERNEL(64) void k_counts3(int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3) {
-    if (simt::tid() == 0) { out3[0] = n_docs; out3[1] = total; out3[2] = grand ? *grand : 0; }
+// (up to three copies: the encoder's "last batch" block, the workspace's block of THIS batch, a block of the caller's)
+TKZ_KERNEL(64) void k_counts3(int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3, int64_t* out3b, int64_t* out3c) {
+    if (simt::tid() == 0) {
+        const int64_t g = grand ? *grand : 0;
+        out3[0] = n_docs; out3[1] = total; out3[2] = g;
+        if (out3b) { out3b[0] = n_docs; out3b[1] = total; out3b[2] = g; }
+        if (out3c) { out3c[0] = n_docs; out3c[1] = total; out3c[2] = g; }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2079,7 +2089,7 @@ TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
             v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
         }
         *reinterpret_cast<uint4*>(d_bytes + 16 * i) = v;
-        if (T.pattern == TKZ_PAT_O200K) s_raw[i] = v;             // (only the sequential matcher reads the text from LDS)
+        if (tkz_pat_is_o200k(T.pattern)) s_raw[i] = v;             // (only the sequential matcher reads the text from LDS)
     }
     for (int64_t d = tid; d <= n_docs; d += kThreads) d_offs[d] = A.h_offs[d];
     for (int64_t w = tid; w < nwords + 1; w += kThreads) A.docbits[w] = 0;
@@ -2105,11 +2115,11 @@ TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
     // ---- 2. Regex.Matches.  Pattern 1 / cl100k: the row evaluator (one lane per BYTE of a 64-byte row, rows one after the other, scan state
     // carried: tkz_rows_sequential), the rows dealt out to the four wavefronts -- the sequential matcher took 55 us for a 64-byte prompt
     // (thousands of dependent reads), this takes ~2.  o200k has no row evaluator: the matcher, one lane per document, on the text in LDS ----
-    if (T.pattern == TKZ_PAT_O200K) {
+    if (tkz_pat_is_o200k(T.pattern)) {
         for (int64_t d = tid; d < n_docs; d += kThreads) {
             const int64_t a = d_offs[d], b = d_offs[d + 1];
             if (b <= a || a < 0 || b > total) continue;
-            TkzDoc doc; doc.b = s_text + a; doc.n = b - a; doc.bmp = T.bmp_class; doc.by_code_point = 1;
+            TkzDoc doc; doc.b = s_text + a; doc.n = b - a; doc.bmp = T.bmp_class; doc.by_code_point = T.pattern == TKZ_PAT_O200K;
             int bad = 0;
             for (int64_t p = 0; p < doc.n;) { const TkzChar c = tkz_doc_char(doc, p); bad |= c.bad; p += c.len; }
             if (bad) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrUtf8); continue; }
@@ -2221,7 +2231,12 @@ TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
     }
     simt::sync();
     stamp();
-    if (tid == 0) { const int32_t err = P.counters[0]; A.h_result[1] = err; A.h_result[0] = err ? 1 : 0; }
+    if (tid == 0) {
+        const int32_t err = P.counters[0]; A.h_result[1] = err; A.h_result[0] = err ? 1 : 0;
+        // {n_docs, n_bytes, n_tokens} of this batch on the device, as k_counts3 leaves them on the batch path (a batch that is handed back
+        // gets them from there)
+        if (!err) for (int k = 0; k < 2; ++k) if (A.counts3[k]) { A.counts3[k][0] = n_docs; A.counts3[k][1] = total; A.counts3[k][2] = A.tile_base[nsub]; }
+    }
 }
 
 // =================================================================================================
@@ -2252,7 +2267,7 @@ void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, co
         int64_t* xq2 = xq + grid + 1;
         unsigned long long* xcount2 = xcount + 1;
         TKZ_LAUNCH(k_pretok_mb_blocks, grid < 8192 ? grid : 8192, 64, L.stream, d_bytes, total, docbits, startbits, nrows, bmp, (const uint8_t*)xq, grid,
-                   xcount, xq2, xcount2);
+                   xcount, xq2, xcount2, (int)(pattern == TKZ_PAT_O200K));
         TKZ_LAUNCH(k_pretok_seq_blocks, grid_for(n_docs > grid ? n_docs : grid), kThreads, L.stream, d_bytes, d_offs, n_docs, total, startbits, nrows,
                    pattern, bmp, (const int64_t*)xq2, (const unsigned long long*)xcount2, counters);
     }
@@ -2317,8 +2332,8 @@ void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int6
 void launch_rebase(const Launch& L, int64_t* offs, int64_t n, int64_t base) {
     TKZ_LAUNCH(k_rebase, grid_for(n), kThreads, L.stream, offs, n, base);
 }
-void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3) {
-    TKZ_LAUNCH(k_counts3, 1, 64, L.stream, n_docs, total, grand, out3);
+void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3, int64_t* out3b, int64_t* out3c) {
+    TKZ_LAUNCH(k_counts3, 1, 64, L.stream, n_docs, total, grand, out3, out3b, out3c);
 }
 void launch_u16_len(const Launch& L, const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum) {
     TKZ_LAUNCH(k_u16_len, cdiv(ntiles, kThreads / 64), kThreads, L.stream, units, total, docbits, ntiles, grp_prefix, tile_sum);

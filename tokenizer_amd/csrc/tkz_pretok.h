@@ -21,7 +21,11 @@
 #include "tkz_classes.h"
 #include "tkz_simt.h"
 
-enum { TKZ_PAT_P1 = 1, TKZ_PAT_CL100K = 2, TKZ_PAT_O200K = 3 };
+// o200k twice: TKZ_PAT_O200K is the TypeScript reference's engine (code points, ECMAScript \s), TKZ_PAT_O200K_NET what .NET's Regex
+// makes of the same string (code units: a supplementary-plane char is two OTHER units; .NET \s) -- tkz_classes.h.  One set of scanners:
+// the ASCII block scanner cannot tell them apart, the char-level one and the sequential matcher take `by_code_point`.
+enum { TKZ_PAT_P1 = 1, TKZ_PAT_CL100K = 2, TKZ_PAT_O200K = 3, TKZ_PAT_O200K_NET = 4 };
+TKZ_HD bool tkz_pat_is_o200k(int pattern) { return pattern >= TKZ_PAT_O200K; }
 
 // =================================================================================================
 // (1) sequential matcher
@@ -184,7 +188,7 @@ TKZ_HD int64_t tkz_match_o200k(const TkzDoc& d, int64_t p) {
 }
 
 TKZ_HD int64_t tkz_match_at(int pattern, const TkzDoc& d, int64_t p) {
-    return pattern == TKZ_PAT_P1 ? tkz_match_p1(d, p) : pattern == TKZ_PAT_CL100K ? tkz_match_cl100k(d, p) : tkz_match_o200k(d, p);
+    return pattern == TKZ_PAT_P1 ? tkz_match_p1(d, p) : pattern == TKZ_PAT_CL100K ? tkz_match_cl100k(d, p) : tkz_match_o200k(d, p);   // (both o200k variants: d.by_code_point)
 }
 
 // =================================================================================================
@@ -1132,7 +1136,7 @@ TKZ_DEV uint32_t tkz_scan_flow(bool prop, uint32_t gen, uint32_t in0) {
     return lane == 0 ? in0 : prev;
 }
 
-struct TkzO2Chars { uint64_t U, l, X, M, N, W, O, CR, SP, SL, AP, k2, k3, ds; int n; };   // one bit per CHAR of the lane's row (O excludes marks)
+struct TkzO2Chars { uint64_t U, l, X, M, N, W, O, O2, CR, SP, SL, AP, k2, k3, ds; int n; };   // one bit per CHAR of the lane's row (O excludes marks; O2: the O chars of two UTF-16 units, .NET semantics only)
 
 // (development aid of the CPU-emulated build: which rule refused a block, counted in tkz_o2_refusals[])
 #ifdef TKZ_HOSTEMU
@@ -1173,7 +1177,9 @@ TKZ_DEV bool tkz_block_core_o200k(const TkzO2Chars& c, const TkzBlockCtx& X, uin
     // Both are fills along runs, so they are iterated: round 1 ignores the cuts (exact unless a swallowed '/' is followed by an
     // O / mark that is not a '/'), every further round is exact one more such link to the right; kO2Rounds of them, then the block is
     // refused.  Both states cross rows (a row of nothing but O / marks, of nothing but CR / LF / '/'): lane scans. ----
-    const uint64_t gR4all = O & (pSP | ~nWd) & all;
+    // (.NET: a char of two units is never the one-unit prefix of a word -- the \p{L} behind the prefix would have to match its low surrogate --,
+    //  so it always belongs to a ` ?[^\s\p{L}\p{N}]+` piece)
+    const uint64_t gR4all = O & (pSP | ~nWd | c.O2) & all;
     const uint64_t PRall = Oc & nds & all;
     const uint64_t Rabs = (CR | SL) & nds & all;
     const uint64_t nOcNS = (((Oc & ~SL) >> 1) | ((uint64_t)((((nb >> 3) & 1) | ((nb >> 5) & 1)) & (((nb >> 10) & 1) ^ 1)) << top)) & ~KN & all;
@@ -1369,13 +1375,16 @@ TKZ_DEV bool tkz_block_core_o200k(const TkzO2Chars& c, const TkzBlockCtx& X, uin
 }
 
 // Evaluates rows first_row .. first_row+63 (lane = row - first_row) staged at `stage` as tkz_block_eval does, for o200k, any UTF-8.
-TKZ_DEV bool tkz_block_eval_o200k_mb(const uint8_t* stage, uint64_t dsb, const TkzBlockCtx& X, const uint8_t* ucd, uint64_t* out) {
+// by_code_point: the ECMAScript engine's view (tkz_char_to_code_point_semantics); otherwise .NET's (tkz_classes.h: a char of four bytes is two
+// OTHER units whatever its Unicode class, \s as the table has it).
+TKZ_DEV bool tkz_block_eval_o200k_mb(const uint8_t* stage, uint64_t dsb, const TkzBlockCtx& X, const uint8_t* ucd, bool by_code_point, uint64_t* out) {
     const int lane = simt::lane();
     const TkzBlockMasks m = tkz_block_classify<true>(reinterpret_cast<const uint4*>(stage + lane * kBlockRowStride));
     const uint64_t HI = m.HI, CONT = m.CONT, A = ~HI;
     uint64_t U = m.UP & A, l = m.L & ~m.UP & A, Xl = 0, M = 0, N = m.N & A, W = m.W & A, O = ~(m.L | m.N | m.W) & A;
     const uint64_t CR = m.CR & A, SP = m.SP & A, SL = m.SL & A, AP = m.AP & A;
     int bad = 0;
+    uint64_t O2 = 0;
     uint64_t E = 0;                                        // where continuation bytes are expected, from the leads of my row
     uint32_t spill = 0;                                    // ... and in the first three bytes of the next row
     // every non-ASCII lead of my row: decode, class by code point from the table -- four chars per step, their gathers in flight
@@ -1408,8 +1417,9 @@ TKZ_DEV bool tkz_block_eval_o200k_mb(const uint8_t* stage, uint64_t dsb, const T
         for (int j = 0; j < 4; ++j) {
             if (pos[j] < 0) continue;
             uint32_t uc = cls[j];
-            if (cp[j] == 0xFEFFu) uc = UC_WS; else if (cp[j] == 0x85u) uc = UC_OTHER;      // ECMAScript \s (tkz_char_to_code_point_semantics)
             const uint64_t bitp = 1ull << pos[j];
+            if (by_code_point) { if (cp[j] == 0xFEFFu) uc = UC_WS; else if (cp[j] == 0x85u) uc = UC_OTHER; }   // ECMAScript \s (tkz_char_to_code_point_semantics)
+            else if (cp[j] >= 0x10000u) { uc = UC_OTHER; O2 |= bitp; }                                       // .NET: two Cs units
             if (uc == UC_LU || uc == UC_LT) U |= bitp;
             else if (uc == UC_LL) l |= bitp;
             else if (uc == UC_LM || uc == UC_LO) Xl |= bitp;
@@ -1440,7 +1450,7 @@ TKZ_DEV bool tkz_block_eval_o200k_mb(const uint8_t* stage, uint64_t dsb, const T
     TkzO2Chars c;
     c.n = tkz_popc64(LEAD);
     c.U = tkz_pext(U, LEAD, px); c.l = tkz_pext(l, LEAD, px); c.X = tkz_pext(Xl, LEAD, px); c.M = tkz_pext(M, LEAD, px);
-    c.N = tkz_pext(N, LEAD, px); c.W = tkz_pext(W, LEAD, px); c.O = tkz_pext(O, LEAD, px);
+    c.N = tkz_pext(N, LEAD, px); c.W = tkz_pext(W, LEAD, px); c.O = tkz_pext(O, LEAD, px); c.O2 = tkz_pext(O2, LEAD, px);
     c.CR = tkz_pext(CR, LEAD, px); c.SP = tkz_pext(SP, LEAD, px); c.SL = tkz_pext(SL, LEAD, px); c.AP = tkz_pext(AP, LEAD, px);
     c.k2 = tkz_pext(k2b, LEAD, px); c.k3 = tkz_pext(k3b, LEAD, px);
     c.ds = tkz_pext(dsb, LEAD, px);

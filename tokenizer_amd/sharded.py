@@ -35,9 +35,13 @@ class RcclCounts:
         self.rank, self.world, self.lib = rank, world, lib
         self.d_table = torch.zeros(world * 3, dtype=torch.int64, device=torch.device("cuda", device))
 
-    def gather_async(self, encoder, stream=0):
-        """Enqueue the all-gather of the encoder's last batch counts on `stream`: no host synchronisation, the table stays in HBM."""
-        self.comm.allgather_counts_device(encoder.counts_device, self.d_table.data_ptr(), stream)
+    def gather_async(self, counts, stream=0, d_table=None):
+        """Enqueue the all-gather of one batch's counts on `stream`: no host synchronisation, the table stays in HBM.  `counts` is an
+        Encoder (its last batch: one batch at a time) or the device pointer of a batch's own block (the d_counts3 given to
+        Encoder.encode_batch_device_begin -- any number of batches in flight; enqueue behind encode_batch_device_end).  d_table: another
+        world*3 int64 device block than the communicator's own (one per batch in flight)."""
+        ptr = counts.counts_device if hasattr(counts, "counts_device") else counts
+        self.comm.allgather_counts_device(ptr, d_table or self.d_table.data_ptr(), stream)
 
     def result(self):
         """The gathered table on the host (synchronises) with this rank's bases and the job totals."""

@@ -85,12 +85,18 @@ class TikTokenizer:
     bytes of a .tiktoken rank file (the reference takes a Stream, TikTokenizer.cs:60-65)."""
 
     def __init__(self, tikTokenBpeFile: bytes, specialTokensEncoder: Optional[Dict[str, int]], pattern: str,
-                 cacheSize: int = 8192, device: int = 0, lib: Optional[N.Library] = None):
+                 cacheSize: int = 8192, device: int = 0, lib: Optional[N.Library] = None, host: str = "dotnet"):
+        """`host` names the regex engine whose reading of `pattern` is wanted: "dotnet" (the default: `new Regex(pattern,
+        RegexOptions.Compiled)`, TikTokenizer.cs:77 -- UTF-16 code units, .NET's \\s) or "js" (`new RegExp(pattern, "gu")`,
+        tokenizer_ts/src/tikTokenizer.ts:100 -- code points, ECMAScript's \\s; implemented for the o200k string only, the one
+        pattern that exists only in the TypeScript reference).  The two differ on supplementary-plane chars, U+0085 and U+FEFF."""
         self._lib = lib or N.default_library()
-        pat = self._lib.L.tkz_pattern_from_regex  # maps the reference's regex text to a scanner, refuses anything else
+        if host not in ("dotnet", "js"):
+            raise ValueError("host must be 'dotnet' or 'js'")
+        pat = self._lib.L.tkz_pattern_from_regex_engine  # maps the reference's regex text to a scanner, refuses anything else
         import ctypes as C
         out = C.c_int32(0)
-        self._lib.check(pat(pattern.encode("utf-8"), C.byref(out)))
+        self._lib.check(pat(pattern.encode("utf-8"), N.ENGINE_ECMASCRIPT if host == "js" else N.ENGINE_DOTNET, C.byref(out)))
         self._vocab = N.Vocab(tikTokenBpeFile, self._lib)     # FormatError / DuplicateRankError as in LoadTikTokenBpe + Init
         self._encoder = N.Encoder(self._vocab, out.value, device)
         # the reference's LRU piece memo (LRUCache.cs; no effect on results) lives on the device with a fixed size: cacheSize only says
@@ -141,7 +147,24 @@ class TikTokenizer:
         return self.EncodeBatch([text], allowedSpecialOrApply)[0]
 
     def EncodeBatch(self, texts: Sequence[str], allowedSpecialOrApply: Union[bool, Sequence[str], None] = True) -> List[List[int]]:
+        ids, offs = self.EncodeBatchFlat(texts, allowedSpecialOrApply)
+        flat = ids.tolist()
+        return [flat[offs[d]:offs[d + 1]] for d in range(len(texts))]
+
+    def EncodeBatchFlat(self, texts: Sequence[str], allowedSpecialOrApply: Union[bool, Sequence[str], None] = True):
+        """EncodeBatch without a list per text: (ids int32[total], offsets int64[len(texts) + 1]); text d is ids[offsets[d]:offsets[d+1]].
+        When no special token applies (the reference's plain path, TikTokenizer.cs:180-183,196-199) the arrays are the device call's own
+        output, untouched; otherwise the special ids are spliced in between the plain segments' ids with array copies."""
         allowed = self._resolve_allowed(allowedSpecialOrApply)
+        if not allowed or self._special_re is None:
+            segs = [_utf8_like_dotnet(t) for t in texts]
+            if not segs:
+                return np.zeros(0, np.int32), np.zeros(1, np.int64)
+            lens = np.fromiter(map(len, segs), np.int64, len(segs))
+            offs = np.zeros(len(segs) + 1, np.int64)
+            np.cumsum(lens, out=offs[1:])
+            data = np.frombuffer(b"".join(segs), np.uint8) if offs[-1] else np.zeros(0, np.uint8)
+            return self._encoder.encode_batch(data, offs)
         plans = [self._segments(t, allowed) for t in texts]
         segs = [_utf8_like_dotnet(s) for plan in plans for kind, s, _ in plan if kind == "t"]
         if segs:
@@ -150,17 +173,22 @@ class TikTokenizer:
             ids, ooff = self._encoder.encode_batch(data, offs)
         else:
             ids, ooff = np.zeros(0, np.int32), np.zeros(1, np.int64)
-        out, k = [], 0
-        for plan in plans:
-            cur: List[int] = []
+        n_special = sum(1 for plan in plans for kind, _, _ in plan if kind == "s")
+        out = np.empty(len(ids) + n_special, np.int32)
+        out_offs = np.zeros(len(texts) + 1, np.int64)
+        w, k = 0, 0
+        for d, plan in enumerate(plans):
             for kind, v, _ in plan:
                 if kind == "s":
-                    cur.append(v)
+                    out[w] = v
+                    w += 1
                 else:
-                    cur.extend(ids[ooff[k]:ooff[k + 1]].tolist())
+                    n = int(ooff[k + 1] - ooff[k])
+                    out[w:w + n] = ids[ooff[k]:ooff[k + 1]]
+                    w += n
                     k += 1
-            out.append(cur)
-        return out
+            out_offs[d + 1] = w
+        return out, out_offs
 
     # ---- trim variants (TikTokenizer.cs:288-579) --------------------------------------------------
     def _piece_items(self, text: str, allowed):
@@ -283,11 +311,13 @@ class TokenizerBuilder:
         return enc
 
     @staticmethod
-    def CreateByModelName(modelName: str, extraSpecialTokens: Optional[Dict[str, int]] = None, vocab_dir: Optional[str] = None, device: int = 0):
-        return TokenizerBuilder.CreateByEncoderName(TokenizerBuilder._encoder_for_model(modelName), extraSpecialTokens, vocab_dir, device)
+    def CreateByModelName(modelName: str, extraSpecialTokens: Optional[Dict[str, int]] = None, vocab_dir: Optional[str] = None, device: int = 0,
+                          host: str = "dotnet"):
+        return TokenizerBuilder.CreateByEncoderName(TokenizerBuilder._encoder_for_model(modelName), extraSpecialTokens, vocab_dir, device, host)
 
     @staticmethod
-    def CreateByEncoderName(encoderName: str, extraSpecialTokens: Optional[Dict[str, int]] = None, vocab_dir: Optional[str] = None, device: int = 0):
+    def CreateByEncoderName(encoderName: str, extraSpecialTokens: Optional[Dict[str, int]] = None, vocab_dir: Optional[str] = None, device: int = 0,
+                            host: str = "dotnet"):
         if encoderName not in ENCODERS:
             raise NotImplementedError("Doesn't support this encoder [%s]" % encoderName)  # TokenizerBuilder.cs:179
         regex, fname, specials = ENCODERS[encoderName]
@@ -300,9 +330,9 @@ class TokenizerBuilder:
             raise FileNotFoundError("%s not found: the reference downloads it at run time (TokenizerBuilder.cs:113,195); "
                                     "place it in vocab_dir / $TKZ_VOCAB_DIR" % path)
         with open(path, "rb") as f:
-            return TokenizerBuilder.CreateTokenizer(f.read(), specials, regex, device=device)
+            return TokenizerBuilder.CreateTokenizer(f.read(), specials, regex, device=device, host=host)
 
     @staticmethod
     def CreateTokenizer(tikTokenBpeFile: bytes, specialTokensEncoder: Optional[Dict[str, int]], pattern: str, cacheSize: int = 8192,
-                        device: int = 0, lib: Optional[N.Library] = None) -> TikTokenizer:
-        return TikTokenizer(tikTokenBpeFile, specialTokensEncoder, pattern, cacheSize, device, lib)
+                        device: int = 0, lib: Optional[N.Library] = None, host: str = "dotnet") -> TikTokenizer:
+        return TikTokenizer(tikTokenBpeFile, specialTokensEncoder, pattern, cacheSize, device, lib, host)
