@@ -2,6 +2,12 @@
 // (no dotnet / mono / csc), so this file is not compiled or tested here; the same boundary is exercised through
 // ctypes (tokenizer_amd/_native.py) and C++ (include/tkz_tokenizer.hpp).  See INTEGRATION.md.
 //
+// Written against what the reference's project gives it: netstandard2.0, LangVersion 8.0, Nullable enable, no package
+// references beyond the BCL (TokenizerLib.csproj:4-5,10) plus <AllowUnsafeBlocks>.  So: no System.Memory (no Span, no
+// AsSpan, no Encoding overloads over spans -- the char* / byte* overloads instead), no System.Range / System.Index (Substring,
+// not text[a..b]), no Marshal.PtrToStringUTF8 and no UnmanagedType.LPUTF8Str (UTF-8 strings cross the boundary as byte[]).
+// INTEGRATION.md lists every BCL member used with where it comes from.
+//
 // Drop it into Tokenizer_C#/TokenizerLib next to TikTokenizer.cs.  It keeps the two Encode overloads of
 // ITokenizer (ITokenizer.cs:12,28) and adds EncodeBatch; special-token segmentation is the reference's own
 // EncodeInternal / FindNextSpecialToken (TikTokenizer.cs:141-170,230-241) with the plain segments sent to the
@@ -26,7 +32,7 @@ namespace Microsoft.DeepDev
         [DllImport(Lib)] internal static extern IntPtr tkz_last_error();
         [DllImport(Lib)] internal static extern int tkz_vocab_from_tiktoken(byte[] file, UIntPtr n, out IntPtr vocab);
         [DllImport(Lib)] internal static extern void tkz_vocab_destroy(IntPtr vocab);
-        [DllImport(Lib)] internal static extern int tkz_pattern_from_regex([MarshalAs(UnmanagedType.LPUTF8Str)] string regex, out int pattern);
+        [DllImport(Lib)] internal static extern int tkz_pattern_from_regex(byte[] regexUtf8Z, out int pattern);   // .NET semantics (TikTokenizer.cs:77): the o200k string gives TKZ_PATTERN_O200K_DOTNET
         [DllImport(Lib)] internal static extern int tkz_encoder_create(IntPtr vocab, int pattern, int device, out IntPtr encoder);
         [DllImport(Lib)] internal static extern int tkz_encoder_set_option(IntPtr encoder, int option, long value);
         [DllImport(Lib)] internal static extern void tkz_encoder_destroy(IntPtr encoder);
@@ -45,15 +51,34 @@ namespace Microsoft.DeepDev
         [DllImport(Lib)] internal static extern int tkz_comm_allgather_counts(IntPtr comm, long nDocs, long nBytes, long nTokens, long[] table);
         [DllImport(Lib)] internal static extern void tkz_shard_range(long nDocsTotal, int rank, int world, out long lo, out long hi);
         [DllImport(Lib)] internal static extern int tkz_shard_bases(long[] table, int world, int rank, long[] bases3, long[] totals3);
-        [DllImport(Lib)] internal static extern int tkz_shard_write([MarshalAs(UnmanagedType.LPUTF8Str)] string path, int[] ids, long nTokens, long[] offsets, long nDocs, long docBase, long tokenBase);
+        [DllImport(Lib)] internal static extern int tkz_shard_write(byte[] pathUtf8Z, int[] ids, long nTokens, long[] offsets, long nDocs, long docBase, long tokenBase);
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_pieces_utf8(IntPtr encoder, byte* bytes, long* docOffsets, long nDocs, int* outIds, long outCap,
                                                                                          long* docPieceOffsets, long* pieceByteOffsets, long* pieceTokenOffsets,
                                                                                          long pieceCap, out long nPieces, out long neededIds);
 
+        /// <summary>A C string argument: the UTF-8 bytes and a terminating zero.</summary>
+        internal static byte[] Utf8Z(string s)
+        {
+            var b = new byte[Encoding.UTF8.GetByteCount(s) + 1];
+            Encoding.UTF8.GetBytes(s, 0, s.Length, b, 0);
+            return b;
+        }
+
+        /// <summary>A zero-terminated UTF-8 string owned by the library (tkz_last_error).</summary>
+        internal static string Utf8ToString(IntPtr p)
+        {
+            if (p == IntPtr.Zero) return "";
+            int n = 0;
+            while (Marshal.ReadByte(p, n) != 0) ++n;
+            var b = new byte[n];
+            Marshal.Copy(p, b, 0, n);
+            return Encoding.UTF8.GetString(b, 0, n);
+        }
+
         internal static void Check(int status)
         {
             if (status == 0) return;
-            string msg = Marshal.PtrToStringUTF8(tkz_last_error()) ?? "";
+            string msg = Utf8ToString(tkz_last_error());
             switch (status)
             {
                 case -1: throw new InvalidOperationException("Failed to load from BPE encoder file stream: " + msg, new FormatException(msg));  // TikTokenizer.cs:133-136
@@ -88,7 +113,7 @@ namespace Microsoft.DeepDev
         {
             byte[] file;
             using (var ms = new MemoryStream()) { tikTokenBpeFileStream.CopyTo(ms); file = ms.ToArray(); }
-            Tkz.Check(Tkz.tkz_pattern_from_regex(pattern, out int pat));          // only the reference's own three patterns are implemented
+            Tkz.Check(Tkz.tkz_pattern_from_regex(Tkz.Utf8Z(pattern), out int pat));   // only the reference's own three patterns are implemented
             Tkz.Check(Tkz.tkz_vocab_from_tiktoken(file, (UIntPtr)file.Length, out IntPtr vocab));
             IntPtr enc;
             try { Tkz.Check(Tkz.tkz_encoder_create(vocab, pat, device, out enc)); }
@@ -124,28 +149,48 @@ namespace Microsoft.DeepDev
         public List<int> Encode(string text, bool applySpecialTokens = true)
             => EncodeBatch(new[] { text }, applySpecialTokens && specialTokens.Count > 0 ? specialTokens : null)[0];
 
-        /// <summary>Encodes every text as Encode(text, allowedSpecial) would; all plain segments go to the GPU as one batch.</summary>
-        public unsafe List<List<int>> EncodeBatch(IReadOnlyList<string> texts, IReadOnlyCollection<string>? allowedSpecial = null)
+        /// <summary>Encodes every text as Encode(text, allowedSpecial) would; all plain segments go to the GPU as one batch.
+        /// One List per text, each filled with ONE AddRange over its segment of the flat result.</summary>
+        public List<List<int>> EncodeBatch(IReadOnlyList<string> texts, IReadOnlyCollection<string>? allowedSpecial = null)
         {
+            var (ids, offsets) = EncodeBatchFlat(texts, allowedSpecial);
+            var result = new List<List<int>>(texts.Count);
+            for (int t = 0; t < texts.Count; ++t)
+            {
+                int n = (int)(offsets[t + 1] - offsets[t]);
+                var one = new List<int>(n);
+                if (n > 0) one.AddRange(new ArraySegment<int>(ids, (int)offsets[t], n));      // (ICollection<int>.CopyTo: one block copy)
+                result.Add(one);
+            }
+            return result;
+        }
+
+        /// <summary>EncodeBatch without a List per text: text t is Ids[Offsets[t] .. Offsets[t + 1]).  When no special token applies
+        /// (the reference's plain path, TikTokenizer.cs:180-183,196-199) Offsets is the device call's own output and Ids its own
+        /// buffer, untouched (longer than Offsets[texts.Count]: tokens never outnumber bytes); otherwise the special ids are
+        /// spliced in between the plain segments' ids with block copies.</summary>
+        public unsafe (int[] Ids, long[] Offsets) EncodeBatchFlat(IReadOnlyList<string> texts, IReadOnlyCollection<string>? allowedSpecial = null)
+        {
+            bool plain = allowedSpecial is null || allowedSpecial.Count == 0 || specialTokensEncoder.Count == 0;
             // 1. segmentation on the host: (text index, plain segment) and literal special ids, in order
             var plan = new List<(int text, int special, int segment)>();
-            var segments = new List<(string text, int start, int end)>();
+            var segments = new List<(string text, int start, int end)>(texts.Count);
             for (int t = 0; t < texts.Count; ++t)
             {
                 string text = texts[t];
-                if (allowedSpecial is null || allowedSpecial.Count == 0)
+                if (plain)
                 {
-                    if (text.Length > 0) { plan.Add((t, -1, segments.Count)); segments.Add((text, 0, text.Length)); }
+                    segments.Add((text, 0, text.Length));                     // (one segment per text, empty ones included: the offsets line up)
                     continue;
                 }
                 int start = 0;
-                while (true)
+                while (text.Length > 0)
                 {
                     Match next; int startFind = start;
                     while (true)                                              // FindNextSpecialToken (TikTokenizer.cs:230-241)
                     {
                         next = specialTokensRegex.Match(text, startFind);
-                        if (!next.Success || allowedSpecial.Contains(next.Value)) break;
+                        if (!next.Success || allowedSpecial!.Contains(next.Value)) break;
                         startFind = next.Index + 1;
                     }
                     int end = next.Success ? next.Index : text.Length;
@@ -158,26 +203,34 @@ namespace Microsoft.DeepDev
             }
             // 2. the plain segments as one batch of UTF-16 code units: a memcpy per string; Encoding.UTF8.GetBytes
             //    (TikTokenizer.cs:261) is done for the whole batch on the device by tkz_encode_batch_utf16
-            var offsets = new long[segments.Count + 1];
+            var unitOffsets = new long[segments.Count + 1];
             long total = 0;
-            for (int i = 0; i < segments.Count; ++i) { offsets[i] = total; total += segments[i].end - segments[i].start; }
-            offsets[segments.Count] = total;
+            for (int i = 0; i < segments.Count; ++i) { unitOffsets[i] = total; total += segments[i].end - segments[i].start; }
+            unitOffsets[segments.Count] = total;
             var units = new char[Math.Max(1, total)];
             for (int i = 0; i < segments.Count; ++i)
-                segments[i].text.CopyTo(segments[i].start, units, (int)offsets[i], segments[i].end - segments[i].start);
+                segments[i].text.CopyTo(segments[i].start, units, (int)unitOffsets[i], segments[i].end - segments[i].start);
             var ids = new int[Math.Max(1, 3 * total)];                         // a code unit is at most three UTF-8 bytes, a token at least one byte
-            var outOffsets = new long[segments.Count + 1];
-            fixed (char* pu = units) fixed (long* po = offsets) fixed (int* pi = ids) fixed (long* poo = outOffsets)
+            var segOffsets = new long[segments.Count + 1];
+            fixed (char* pu = units) fixed (long* po = unitOffsets) fixed (int* pi = ids) fixed (long* poo = segOffsets)
                 Tkz.Check(Tkz.tkz_encode_batch_utf16(encoder, pu, po, segments.Count, pi, ids.Length, poo, out _));
-            // 3. stitch
-            var result = new List<List<int>>(texts.Count);
-            for (int t = 0; t < texts.Count; ++t) result.Add(new List<int>());
+            if (plain) return (ids, segOffsets);
+            // 3. splice the special ids in: block copies of the segments' id ranges
+            long nSpecial = 0;
+            foreach (var item in plan) if (item.segment < 0) ++nSpecial;
+            var flat = new int[Math.Max(1, segOffsets[segments.Count] + nSpecial)];
+            var offsets = new long[texts.Count + 1];
+            long w = 0; int cur = 0;
             foreach (var (t, special, segment) in plan)
             {
-                if (segment < 0) { result[t].Add(special); continue; }
-                for (long k = outOffsets[segment]; k < outOffsets[segment + 1]; ++k) result[t].Add(ids[k]);
+                while (cur < t) offsets[++cur] = w;
+                if (segment < 0) { flat[w++] = special; continue; }
+                long n = segOffsets[segment + 1] - segOffsets[segment];
+                Array.Copy(ids, segOffsets[segment], flat, w, n);
+                w += n;
             }
-            return result;
+            while (cur < texts.Count) offsets[++cur] = w;
+            return (flat, offsets);
         }
 
         // One item per regex piece of every plain segment and one per special token, in order: its ids and its length in
@@ -209,10 +262,13 @@ namespace Microsoft.DeepDev
             var segs = plan.Where(p => p.special < 0).ToList();
             var offsets = new long[segs.Count + 1];
             long total = 0;
-            for (int i = 0; i < segs.Count; ++i) { offsets[i] = total; total += Encoding.UTF8.GetByteCount(text.AsSpan(segs[i].start, segs[i].end - segs[i].start)); }
+            fixed (char* pc = text)                                          // (the char* overloads: netstandard2.0 has no Span)
+                for (int i = 0; i < segs.Count; ++i) { offsets[i] = total; total += Encoding.UTF8.GetByteCount(pc + segs[i].start, segs[i].end - segs[i].start); }
             offsets[segs.Count] = total;
             var bytes = new byte[Math.Max(1, total)];
-            for (int i = 0; i < segs.Count; ++i) Encoding.UTF8.GetBytes(text.AsSpan(segs[i].start, segs[i].end - segs[i].start), bytes.AsSpan((int)offsets[i]));
+            fixed (char* pc = text) fixed (byte* pbytes = bytes)
+                for (int i = 0; i < segs.Count; ++i)
+                    Encoding.UTF8.GetBytes(pc + segs[i].start, segs[i].end - segs[i].start, pbytes + offsets[i], (int)(offsets[i + 1] - offsets[i]));
             int cap = (int)Math.Max(1, total);
             var ids = new int[cap]; var dpo = new long[segs.Count + 1]; var pbo = new long[cap + 1]; var pto = new long[cap + 1];
             fixed (byte* pb = bytes) fixed (long* po = offsets) fixed (int* pi = ids) fixed (long* pd = dpo) fixed (long* pp = pbo) fixed (long* pt = pto)
@@ -248,7 +304,7 @@ namespace Microsoft.DeepDev
                 encodeLength += length;
                 if (tokenCount >= maxTokenCount) break;
             }
-            return (tokenIds, encodeLength == text.Length ? text : text[..encodeLength]);
+            return (tokenIds, encodeLength == text.Length ? text : text.Substring(0, encodeLength));
         }
         public (List<int> TokenIds, string Text) EncodeTrimSuffix(string text, int maxTokenCount, bool applySpecialTokens = true)
             => EncodeTrimSuffix(text, applySpecialTokens && specialTokens.Count > 0 ? specialTokens : null!, maxTokenCount);
@@ -267,7 +323,7 @@ namespace Microsoft.DeepDev
             if (tokenCount <= maxTokenCount) return (tokenIds, text);                  // TrimPrefix (:470-483)
             int prefixTokenCount = tokenCount - maxTokenCount, cutTokens = 0, cutLength = 0;
             foreach (var pair in tokenCountMap) if (pair.Key >= prefixTokenCount) { cutTokens = pair.Key; cutLength = pair.Value; break; }
-            return (tokenIds.Skip(cutTokens).ToList(), text[cutLength..]);
+            return (tokenIds.GetRange(cutTokens, tokenIds.Count - cutTokens), text.Substring(cutLength));
         }
         public (List<int> TokenIds, string Text) EncodeTrimPrefix(string text, int maxTokenCount, bool applySpecialTokens = true)
             => EncodeTrimPrefix(text, applySpecialTokens && specialTokens.Count > 0 ? specialTokens : null!, maxTokenCount);
@@ -323,7 +379,7 @@ namespace Microsoft.DeepDev
             Tkz.Check(Tkz.tkz_comm_allgather_counts(comm, nDocs, nBytes, nTokens, table));
             var bases = new long[3]; var totals = new long[3];
             Tkz.Check(Tkz.tkz_shard_bases(table, World, Rank, bases, totals));
-            Tkz.Check(Tkz.tkz_shard_write(shardPath, ids, nTokens, offsets, nDocs, bases[0], bases[2]));
+            Tkz.Check(Tkz.tkz_shard_write(Tkz.Utf8Z(shardPath), ids, nTokens, offsets, nDocs, bases[0], bases[2]));
             return totals;
         }
         public void Dispose() { Tkz.tkz_comm_destroy(comm); }

@@ -101,6 +101,13 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
 void tkz_encoder_destroy(tkz_encoder* e);
 int32_t tkz_encoder_device(const tkz_encoder* e);
 
+/* Page-locked host memory for the buffers a host hands to the host-buffer entry points: copies from and to it run asynchronously at
+ * the PCIe rate (tkz_encode_batch_utf8 overlaps the upload of one document range with the kernels of the previous one and the download
+ * of the one before; from pageable memory every copy is staged by the runtime first: about half the rate).  A host without a HIP
+ * binding of its own (C#, a plain C++ program) gets such memory here.  tkz_host_free(NULL) is a no-op. */
+tkz_status tkz_host_alloc(size_t bytes, void** out);
+void tkz_host_free(void* p);
+
 /* ---- the hot path ------------------------------------------------------------------------ */
 
 /* EncodeBatch over HOST buffers: n_docs documents, document d = bytes[doc_offsets[d] .. doc_offsets[d+1]).

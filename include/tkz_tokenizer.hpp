@@ -2,6 +2,7 @@
 // C ABI of include/tkz.h.  Header-only; link with libtkz.so.
 //
 //   tkz::TikTokenizer          ITokenizer.Encode x2 + EncodeBatch     Tokenizer_C#/TokenizerLib/ITokenizer.cs:12,28
+//                              EncodeBatchFlat: (ids, offsets) in page-locked buffers that are kept from call to call (tkz::FlatBatch)
 //                              EncodeTrimSuffix / EncodeTrimPrefix x2   ITokenizer.cs:30-44, TikTokenizer.cs:288-579
 //   tkz::TokenizerBuilder      CreateTokenizer(stream, specials, pattern)   TokenizerBuilder.cs:210-213
 //
@@ -11,9 +12,12 @@
 // named after the reference's: FormatException -> tkz::FormatError, ArgumentException -> tkz::DuplicateRankError,
 // KeyNotFoundException -> tkz::KeyNotFoundError, NotImplementedException -> tkz::NotImplementedError.
 #pragma once
+#include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -40,6 +44,45 @@ inline void check(tkz_status s) {
 }
 
 using SpecialTokens = std::vector<std::pair<std::string, int32_t>>;   // registration order matters (alternation order)
+
+// A grow-only page-locked host buffer (tkz_host_alloc): copies from and to it run at the PCIe rate.
+class PinnedBuffer {
+public:
+    PinnedBuffer() = default;
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    ~PinnedBuffer() { tkz_host_free(p_); }
+    void* ensure(size_t bytes) {
+        if (bytes > cap_) {
+            tkz_host_free(p_); p_ = nullptr; cap_ = 0;
+            const size_t want = bytes + bytes / 4 + 4096;
+            check(tkz_host_alloc(want, &p_));
+            cap_ = want;
+        }
+        return p_;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p_); }
+private:
+    void* p_ = nullptr; size_t cap_ = 0;
+};
+
+// The result of TikTokenizer::EncodeBatchFlat: text t is ids()[offsets()[t] .. offsets()[t + 1]).  It owns the page-locked buffers the
+// call works in (the gathered text, the ids, the offsets) and keeps them from call to call: hand the same FlatBatch to every call of a
+// loop and nothing is allocated after the first.  The views are valid until the next call that is given this object.
+class FlatBatch {
+public:
+    const int32_t* ids() const { return ids_; }
+    const int64_t* offsets() const { return offsets_; }
+    int64_t n_texts() const { return n_texts_; }
+    int64_t n_ids() const { return n_texts_ >= 0 && offsets_ ? offsets_[n_texts_] : 0; }
+    std::vector<int32_t> text(int64_t t) const { return std::vector<int32_t>(ids_ + offsets_[t], ids_ + offsets_[t + 1]); }
+private:
+    friend class TikTokenizer;
+    PinnedBuffer in_bytes_, in_offs_, out_ids_, out_offs_;
+    std::vector<int32_t> spliced_ids_; std::vector<int64_t> spliced_offs_;     // (only when special tokens were spliced in)
+    const int32_t* ids_ = nullptr; const int64_t* offsets_ = nullptr; int64_t n_texts_ = 0;
+    double tokens_per_byte_ = 0;                                               // the densest batch seen: sizes the id buffer of the next one
+};
 
 class TikTokenizer {
 public:
@@ -95,6 +138,84 @@ public:
             out[it.text].insert(out[it.text].end(), ids.begin() + ooff[it.segment], ids.begin() + ooff[it.segment + 1]);
         }
         return out;
+    }
+
+    // EncodeBatch without a vector per text (FlatBatch above).  The texts are gathered into page-locked memory by `threads` host threads
+    // (0: as many as the batch is worth, at most 8), encoded by ONE tkz_encode_batch_utf8 call that reads and writes page-locked buffers,
+    // and -- when no special token applies, the reference's plain path (TikTokenizer.cs:180-183,196-199) -- the views of `out` are the
+    // call's own output, untouched.
+    void EncodeBatchFlat(const std::vector<std::string>& texts, FlatBatch& out, bool applySpecialTokens = true, int threads = 0) const {
+        EncodeBatchFlat(texts, applySpecialTokens ? all_specials() : std::vector<std::string>{}, out, threads);
+    }
+    void EncodeBatchFlat(const std::vector<std::string>& texts, const std::vector<std::string>& allowedSpecial, FlatBatch& out, int threads = 0) const {
+        const bool plain = allowedSpecial.empty() || specials_.empty();
+        // 1. what goes to the device: (source pointer, length) of every plain segment, and where the special ids go
+        struct Item { size_t text; int32_t special; int64_t segment; };
+        std::vector<Item> plan;
+        std::vector<std::pair<const char*, size_t>> segs;
+        if (plain) {
+            segs.reserve(texts.size());
+            for (const std::string& t : texts) segs.emplace_back(t.data(), t.size());
+        } else {
+            for (size_t t = 0; t < texts.size(); ++t)
+                for (const Segment& g : segments(texts[t], allowedSpecial)) {
+                    if (g.special) { plan.push_back({t, g.id, -1}); continue; }
+                    plan.push_back({t, 0, static_cast<int64_t>(segs.size())});
+                    segs.emplace_back(texts[t].data() + g.begin, g.end - g.begin);
+                }
+        }
+        const int64_t nseg = static_cast<int64_t>(segs.size());
+        int64_t* offs = static_cast<int64_t*>(out.in_offs_.ensure((static_cast<size_t>(nseg) + 1) * 8));
+        offs[0] = 0;
+        for (int64_t i = 0; i < nseg; ++i) offs[i + 1] = offs[i] + static_cast<int64_t>(segs[static_cast<size_t>(i)].second);
+        const int64_t total = offs[nseg];
+        uint8_t* bytes = static_cast<uint8_t*>(out.in_bytes_.ensure(static_cast<size_t>(total) + 64));
+        // 2. gather (a memcpy per segment; the ranges of the threads hold about the same number of bytes)
+        int nth = threads > 0 ? threads : static_cast<int>(std::min<int64_t>(8, total >> 22));
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && nth > static_cast<int>(hw)) nth = static_cast<int>(hw);
+        auto gather = [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) std::memcpy(bytes + offs[i], segs[static_cast<size_t>(i)].first, segs[static_cast<size_t>(i)].second); };
+        if (nth <= 1) gather(0, nseg);
+        else {
+            std::vector<std::thread> pool;
+            int64_t lo = 0;
+            for (int k = 1; k <= nth; ++k) {
+                const int64_t hi = k == nth ? nseg : std::lower_bound(offs, offs + nseg, total / nth * k) - offs;
+                pool.emplace_back(gather, lo, hi);
+                lo = hi;
+            }
+            for (std::thread& th : pool) th.join();
+        }
+        // 3. one call; a token is at least one byte, English-like text has one per ~4: room for a token per two bytes first, the exact need
+        //    (the call reports it) when that was not enough, and from then on
+        int64_t* ooff = static_cast<int64_t*>(out.out_offs_.ensure((static_cast<size_t>(nseg) + 1) * 8));
+        int64_t cap = std::max<int64_t>(1, std::min<int64_t>(total, std::max<int64_t>(total / 2 + 4096, static_cast<int64_t>(static_cast<double>(total) * out.tokens_per_byte_ * 1.1))));
+        int32_t* ids = nullptr;
+        for (;;) {
+            ids = static_cast<int32_t*>(out.out_ids_.ensure(static_cast<size_t>(cap) * 4));
+            int64_t needed = 0;
+            const tkz_status st = tkz_encode_batch_utf8(enc_, bytes, offs, nseg, ids, cap, ooff, &needed);
+            if (st == TKZ_E_CAPACITY && needed > cap) { cap = needed; out.tokens_per_byte_ = std::max(out.tokens_per_byte_, static_cast<double>(needed) / static_cast<double>(total)); continue; }
+            check(st);
+            break;
+        }
+        out.n_texts_ = static_cast<int64_t>(texts.size());
+        if (plain) { out.ids_ = ids; out.offsets_ = ooff; return; }
+        // 4. splice the special ids in between the segments' id ranges
+        size_t nspecial = 0;
+        for (const Item& it : plan) if (it.segment < 0) ++nspecial;
+        out.spliced_ids_.resize(static_cast<size_t>(ooff[nseg]) + nspecial);
+        out.spliced_offs_.assign(texts.size() + 1, 0);
+        int64_t w = 0; size_t cur = 0;
+        for (const Item& it : plan) {
+            while (cur < it.text) out.spliced_offs_[++cur] = w;
+            if (it.segment < 0) { out.spliced_ids_[static_cast<size_t>(w++)] = it.special; continue; }
+            const int64_t n = ooff[it.segment + 1] - ooff[it.segment];
+            std::memcpy(out.spliced_ids_.data() + w, ids + ooff[it.segment], static_cast<size_t>(n) * 4);
+            w += n;
+        }
+        while (cur < texts.size()) out.spliced_offs_[++cur] = w;
+        out.ids_ = out.spliced_ids_.data(); out.offsets_ = out.spliced_offs_.data();
     }
 
     using Trimmed = std::pair<std::vector<int32_t>, std::string>;   // (List<int> TokenIds, string Text)

@@ -1,0 +1,58 @@
+// Times the ITokenizer-shaped host surface -- tkz::TikTokenizer::EncodeBatchFlat(std::vector<std::string>) of include/tkz_tokenizer.hpp --
+// on a batch of documents bench.py hands over in a file: what a C++ host that holds its texts as strings gets, gather and PCIe included
+// (`value_host_api` of the bench line; never `value`).
+//   argv: vocab.tiktoken  regex-file  sample.bin  [threads]      sample.bin = int64 n_docs, int64 offsets[n_docs + 1], bytes
+// Prints one JSON line.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+
+#include "tkz_tokenizer.hpp"
+
+static std::string slurp(const char* p) { std::ifstream f(p, std::ios::binary); std::stringstream ss; ss << f.rdbuf(); return ss.str(); }
+
+int main(int argc, char** argv) {
+    if (argc < 4) { std::fprintf(stderr, "usage: bench_host_api vocab regex-file sample.bin [threads]\n"); return 2; }
+    const int threads = argc > 4 ? std::atoi(argv[4]) : 0;
+    try {
+        const std::string vocab = slurp(argv[1]), regex = slurp(argv[2]);
+        std::vector<std::string> texts;
+        int64_t total = 0;
+        {
+            std::ifstream f(argv[3], std::ios::binary);
+            int64_t n = 0;
+            f.read(reinterpret_cast<char*>(&n), 8);
+            std::vector<int64_t> offs(static_cast<size_t>(n) + 1);
+            f.read(reinterpret_cast<char*>(offs.data()), static_cast<std::streamsize>((n + 1) * 8));
+            texts.resize(static_cast<size_t>(n));
+            for (int64_t d = 0; d < n; ++d) {
+                texts[static_cast<size_t>(d)].resize(static_cast<size_t>(offs[d + 1] - offs[d]));
+                f.read(&texts[static_cast<size_t>(d)][0], static_cast<std::streamsize>(offs[d + 1] - offs[d]));
+            }
+            total = offs[static_cast<size_t>(n)];
+            if (!f) { std::fprintf(stderr, "short sample file\n"); return 2; }
+        }
+        tkz::TikTokenizer tok(vocab, {}, regex);
+        tkz::FlatBatch fb;
+        tok.EncodeBatchFlat(texts, fb, false, threads);                 // untimed: the page-locked buffers and the encoder's staging take their size
+        double best = 0;
+        const int reps = 3;
+        for (int r = 0; r < reps; ++r) {
+            const auto t0 = std::chrono::steady_clock::now();
+            tok.EncodeBatchFlat(texts, fb, false, threads);
+            const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            best = std::max(best, static_cast<double>(total) / s / 1e6);
+        }
+        uint64_t sum = 1469598103934665603ull;                          // FNV-1a over the ids: bench.py compares it with the device path's
+        for (int64_t i = 0; i < fb.n_ids(); ++i) { sum ^= static_cast<uint32_t>(fb.ids()[i]); sum *= 1099511628211ull; }
+        std::printf("{\"value\": %.1f, \"unit\": \"MB/s\", \"docs\": %lld, \"bytes\": %lld, \"tokens\": %lld, \"ids_fnv1a\": \"%016llx\", \"gather_threads\": %d, \"reps\": %d}\n",
+                    best, static_cast<long long>(texts.size()), static_cast<long long>(total), static_cast<long long>(fb.n_ids()),
+                    static_cast<unsigned long long>(sum), threads, reps);
+    } catch (const std::exception& ex) {
+        std::fprintf(stderr, "bench_host_api: %s\n", ex.what());
+        return 1;
+    }
+    return 0;
+}

@@ -35,6 +35,27 @@ int main(int argc, char** argv) {
     REQUIRE(batch.size() == 4 && batch[0].empty() && batch[1] == hw && batch[2] == std::vector<int32_t>{50301});
     REQUIRE(batch[3] == tok.Encode(text.substr(0, 2000)));
     REQUIRE(tok.EncodeUtf16(u"Hello World") == hw);
+    {   // EncodeBatchFlat: the same ids as EncodeBatch, plain (the call's own buffers) and with special tokens spliced in; the FlatBatch is reused
+        tkz::FlatBatch fb;
+        std::vector<std::string> texts = {"", "Hello World", "<|im_end|>", text.substr(0, 2000), "", "<|im_start|>Hello World<|im_end|>", "<|im_start|>"};
+        for (int round = 0; round < 2; ++round) {
+            for (int apply = 0; apply < 2; ++apply) {
+                const auto ref = tok.EncodeBatch(texts, apply != 0);
+                tok.EncodeBatchFlat(texts, fb, apply != 0, round ? 3 : 0);
+                REQUIRE(fb.n_texts() == (int64_t)texts.size() && fb.offsets()[0] == 0);
+                for (size_t t = 0; t < texts.size(); ++t) REQUIRE(fb.text((int64_t)t) == ref[t]);
+                REQUIRE(fb.n_ids() == fb.offsets()[texts.size()]);
+            }
+            texts.push_back(text);                    // (the second round: a larger batch in the same buffers, gathered by three threads)
+            for (int k = 0; k < 40; ++k) texts.push_back(text.substr((size_t)k * 100, 3000));
+        }
+        tok.EncodeBatchFlat({}, fb);
+        REQUIRE(fb.n_texts() == 0 && fb.n_ids() == 0);
+        // text that is one token per byte (no merges in the table for these): the first guess of the id buffer is too small, the call is repeated
+        const std::string dense(20000, '\x01');
+        tok.EncodeBatchFlat({dense, dense}, fb, false);
+        REQUIRE(fb.text(0) == tok.Encode(dense, false) && fb.text(1) == fb.text(0));
+    }
     {
         const std::u16string lone = {u'a', char16_t(0xD83D)}, pair = {char16_t(0xD83D), char16_t(0xDE00), u'b'}, half = {char16_t(0xDE00), u'c'};
         const auto b16 = tok.EncodeBatchUtf16({u"Hello World", u"", lone, half, pair});

@@ -21,6 +21,45 @@ def _build_and_run(tmp_path, libdir, libname):
     assert "cpp host mirror ok" in out.stdout
 
 
+def fnv1a_ids(ids):
+    h = 1469598103934665603
+    for v in ids:
+        h = ((h ^ (int(v) & 0xFFFFFFFF)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+def build_host_api_bench(outdir, libdir, libname):
+    exe = os.path.join(str(outdir), "bench_host_api")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "bench_host_api.cpp"),
+                           "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_host_api_bench_driver_on_emulated_kernels(tmp_path):
+    """bench.py's `value_host_api` leg (tests/cpp/bench_host_api.cpp: TikTokenizer::EncodeBatchFlat on std::strings read from a sample
+    file) gives the ids the Python binding gives, here on the CPU-emulated kernels."""
+    import json
+    import numpy as np
+    import emu
+    import parity
+    from tokenizer_amd import _native as N
+    from tokenizer_amd import tokenizer as TK
+    lib = emu.library()
+    raw = gzip.decompress(open(os.path.join(GOLDEN, "gpt2.tiktoken.gz"), "rb").read())
+    (tmp_path / "v.tiktoken").write_bytes(raw)
+    (tmp_path / "regex.txt").write_text(TK.REGEX_CL100K)
+    docs = [N.corpus_doc_host(1, 0x5EED0002, d, 64, 400, lib=lib) for d in range(150)]
+    data, offs = parity.pack(docs)
+    with open(tmp_path / "sample.bin", "wb") as f:
+        f.write(np.int64(len(docs)).tobytes()); f.write(offs.astype(np.int64).tobytes()); f.write(data.tobytes())
+    ids, _ = N.Encoder(N.Vocab(raw, lib), N.CL100K).encode_batch(data, offs)
+    exe = build_host_api_bench(tmp_path, os.path.dirname(emu.EMU_LIB), "tkz_hostemu")
+    out = subprocess.run([exe, str(tmp_path / "v.tiktoken"), str(tmp_path / "regex.txt"), str(tmp_path / "sample.bin"), "2"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads(out.stdout)
+    assert r["docs"] == 150 and r["bytes"] == len(data) and r["tokens"] == len(ids) and r["ids_fnv1a"] == fnv1a_ids(ids)
+
+
 def test_cpp_host_mirror_on_emulated_kernels(tmp_path):
     import emu
     emu.library()

@@ -98,6 +98,9 @@ class Library:
         L.tkz_encoder_destroy.restype = None
         L.tkz_encoder_device.argtypes = [vp]
         L.tkz_encode_batch_utf8.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
+        L.tkz_host_alloc.argtypes = [C.c_size_t, pv]
+        L.tkz_host_free.argtypes = [vp]
+        L.tkz_host_free.restype = None
         L.tkz_encode_batch_device.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, pi64]
         L.tkz_encode_batch_device_begin.argtypes = [vp, vp, vp, i64, i64, vp, i64, vp, vp, C.POINTER(vp)]
         L.tkz_encode_batch_device_end.argtypes = [vp, pi64]

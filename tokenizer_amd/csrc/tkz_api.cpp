@@ -830,6 +830,17 @@ void destroy_now(tkz_encoder* e) {
 int32_t tkz_encoder_device(const tkz_encoder* e) { return e ? e->device : -1; }
 const int64_t* tkz_encoder_counts_device(const tkz_encoder* e) { return e ? e->t_counts3.as<int64_t>() : nullptr; }
 
+tkz_status tkz_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(TKZ_E_ARG, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TKZ_E_NO_DEVICE, "no HIP device available");
+    const hipError_t r = hipHostMalloc(out, bytes ? bytes : 1, 0);
+    if (r != hipSuccess) { *out = nullptr; return fail(TKZ_E_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(r)); }
+    return TKZ_OK;
+}
+void tkz_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 tkz_status tkz_encode_batch_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs,
                                  int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed) {
     if (!out_offsets || (out_cap > 0 && !out_ids)) return fail(TKZ_E_ARG, "null output buffer");
