@@ -266,7 +266,10 @@ enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1,
         * bytes that had to be merged leave their (up to 4) tokens in a 524,288-slot (16 MB) table on the device and later batches take them from
         * there instead of running BytePairEncode again.  A pure memo: ids are identical with and without it.  Value 0 = off, 1 = on
         * (default), 2 = on and emptied.  Set options while no call of the encoder is in flight (2 is refused with TKZ_E_ARG otherwise). */
-       TKZ_OPT_PIECE_MEMO = 2 };
+       TKZ_OPT_PIECE_MEMO = 2,
+       /* 1: the batch path counts what it meets (tkz_encoder_piece_stats); 0 (default): it does not -- the counting adds a few atomics per
+        * wavefront and one small kernel per batch, so measure with it off. */
+       TKZ_OPT_PIECE_STATS = 3 };
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
@@ -289,6 +292,11 @@ void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_sca
 void tkz_encoder_small_path_calls(const tkz_encoder* e, int64_t* calls, int64_t* handed_back);
 /* development: the shader-clock stamps the last single-launch kernel left at the end of each of its phases (16 values; returns how many) */
 int32_t tkz_encoder_small_path_phases(const tkz_encoder* e, int64_t* clocks16);
+/* What the batches since the last reset met, with TKZ_OPT_PIECE_STATS on (8 values): [0] batches, [1] pieces (regex matches), [2] pieces of
+ * at most 16 bytes that missed the vocabulary as a whole (TikTokenizer.cs:262 -> :268), [3] of 17..1024 bytes, [4] of more than 1024 bytes,
+ * [5] piece-memo lookups and [6] hits among them (the misses went through BytePairEncode), [7] 0.  Whole-piece hit rate =
+ * 1 - ([2] + [3] + [4]) / [1]. */
+tkz_status tkz_encoder_piece_stats(tkz_encoder* e, int64_t* out8, int32_t reset);
 /* Slots of the piece memo (TKZ_OPT_PIECE_MEMO) and slots per bucket, informational; the bucket a piece of 1..16 bytes would use
  * (-1: none -- a piece that holds a zero byte never uses the memo).  The tests use the last one to build pieces that contend for one bucket. */
 int64_t tkz_encoder_memo_slots(const tkz_encoder* e);

@@ -16,6 +16,7 @@ ENGINE_DOTNET, ENGINE_ECMASCRIPT = 0, 1
 P1, CL100K, O200K, O200K_DOTNET = 1, 2, 3, 4   # O200K: ECMAScript engine (TS reference); O200K_DOTNET: the same string through .NET Regex
 OPT_PRETOK_SEQUENTIAL = 1
 OPT_PIECE_MEMO = 2
+OPT_PIECE_STATS = 3
 K_NAMES = ["k_docmark", "k_pretok", "k_probe", "k_scan", "k_place", "k_docoffs", "k_merge_long_group", "k_merge_short"]
 
 
@@ -114,6 +115,7 @@ class Library:
         L.tkz_encode_pieces.argtypes = [vp, vp, vp, i64, vp, i64, vp, pi64]
         L.tkz_encode_batch_pieces_utf8.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, pi64, pi64]
         L.tkz_encoder_set_option.argtypes = [vp, i32, i64]
+        L.tkz_encoder_piece_stats.argtypes = [vp, vp, i32]
         L.tkz_encoder_set_profiling.argtypes = [vp, i32]
         L.tkz_encoder_kernel_ms.argtypes = [vp, vp, vp, i32]
         L.tkz_encoder_workspace_bytes.argtypes = [vp]
@@ -225,6 +227,16 @@ class Encoder:
 
     def set_option(self, opt, value):
         self.lib.check(self.lib.L.tkz_encoder_set_option(self._h, opt, value))
+
+    def piece_stats(self, reset=False):
+        """What the batch path met since the last reset, with OPT_PIECE_STATS on (tkz_encoder_piece_stats)."""
+        out = np.zeros(8, np.int64)
+        self.lib.check(self.lib.L.tkz_encoder_piece_stats(self._h, out.ctypes.data, 1 if reset else 0))
+        pieces, sm, lm, gm, look, hit = (int(out[i]) for i in (1, 2, 3, 4, 5, 6))
+        return {"batches": int(out[0]), "pieces": pieces, "short_misses": sm, "long_misses": lm, "giant_pieces": gm,
+                "whole_piece_hit_rate": round(1.0 - (sm + lm + gm) / pieces, 5) if pieces else None,
+                "memo_lookups": look, "memo_hits": hit, "memo_hit_rate": round(hit / look, 5) if look else None,
+                "merged_short": look - hit if look else sm}
 
     def set_profiling(self, on):
         self.lib.check(self.lib.L.tkz_encoder_set_profiling(self._h, 1 if on else 0))

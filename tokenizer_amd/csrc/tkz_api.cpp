@@ -151,6 +151,9 @@ struct tkz_encoder {
     std::vector<std::pair<int32_t, std::string>> dec_vocab, dec_special;   // host copies (id, bytes)
     int64_t bytes_allocated = 0;           // tables
     std::atomic<int64_t> last_xcount{0}, last_xcount2{0};   // tkz_encoder_pretok_leftovers
+    bool piece_stats = false;              // TKZ_OPT_PIECE_STATS
+    DevBuf t_stats;                        // its device block (EncodeParams::stats)
+    int64_t stat_batches = 0, stat_giants = 0;   // ... and what the host adds per batch (under mu)
     int pending = 0;                       // tkz_pending handles outstanding (under mu)
     bool destroyed = false;                // tkz_encoder_destroy was called while handles were outstanding: the last _end frees the encoder
 };
@@ -352,6 +355,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             HIP_TRY(hipMemsetAsync(P.heavy_flag, 0, (size_t)ntiles, stream));
             P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
             P.ablate = 0; P.devprof = nullptr;
+            P.stats = e->piece_stats ? e->t_stats.as<unsigned long long>() : nullptr;
 #ifdef TKZ_DEVPROF
             { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
             if (P.ablate & 16) {
@@ -383,6 +387,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             launch_doccount(L, startbits, nwords, total, ntiles, ws->w_pcount.as<int32_t>());
             launch_scan(L, ws->w_pcount.as<int32_t>(), ntiles, ws->w_bsum.as<int64_t>(), ws->w_pbase.as<int64_t>(), npieces, -1, kRecordLine);
             launch_encode(L, e->T, P, ntiles);
+            if (P.stats) launch_miss_stats(L, P, ntiles);
             launch_scan(L, P.tile_count, ntiles, ws->w_bsum.as<int64_t>(), ws->w_tbase.as<int64_t>(), grand, K_SCAN);
             launch_place(L, P, ws->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
             if (po) { if (!pieces_over) launch_docoffs(L, po->piece_boffs, po->n_pieces, total, ws->w_tbase.as<int64_t>(), markbits, P.docord_base, P.doc_tok, grand, po->piece_toffs); }
@@ -442,6 +447,10 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         }
         if (err & kErrCapacity) return fail(TKZ_E_DEVICE, "piece record buffer overflow");
         if (err & kErrKeyNotFound) return fail(TKZ_E_KEY_NOT_FOUND, "a byte of the input is not in the vocabulary (KeyNotFoundException in the reference)");
+        if (!d_bitmap_only && e->piece_stats) {
+            std::lock_guard<std::mutex> lock(e->mu);
+            ++e->stat_batches; e->stat_giants += (int64_t)ws->h_counters->heavy_count;
+        }
         if (!d_bitmap_only && ws->mcap > kMissCapMin) {
             // lists that were grown for an earlier batch (text where nearly every piece misses) and that this batch filled to less than
             // half: shorter lists from here on, and the buffers given back when they are far larger than such a batch needs (the lists
@@ -511,7 +520,7 @@ tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, con
     P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
     P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
     P.pool = ws->w_pool.as<int32_t>(); P.pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head)); P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
-    P.ablate = 0; P.devprof = nullptr;
+    P.ablate = 0; P.devprof = nullptr; P.stats = nullptr;
     SmallArgs A{};
     A.h_bytes = H + kSmallOffBytes; A.h_offs = reinterpret_cast<const int64_t*>(H + kSmallOffOffs);
     A.out = reinterpret_cast<int32_t*>(H + kSmallOffIds); A.out_cap = std::min<int64_t>(out_cap, kSmallMaxBytes); A.out_offs = reinterpret_cast<int64_t*>(H + kSmallOffOut);
@@ -821,7 +830,7 @@ namespace {
 void destroy_now(tkz_encoder* e) {
     DeviceScope scope;
     (void)scope.enter(e->device);
-    DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp, &e->t_counts3, &e->t_memo, &e->t_decoff, &e->t_decblob, &e->t_decids};
+    DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp, &e->t_counts3, &e->t_memo, &e->t_stats, &e->t_decoff, &e->t_decblob, &e->t_decids};
     for (DevBuf* b : bufs) b->release();
     for (Workspace* w : e->pool) { w->release_all(); delete w; }
     delete e;
@@ -1174,6 +1183,19 @@ tkz_status tkz_decode_batch(tkz_encoder* e, const int32_t* ids, const int64_t* i
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value) {
     if (!e) return fail(TKZ_E_ARG, "null encoder");
     if (option == TKZ_OPT_PRETOK_SEQUENTIAL) { e->pretok_seq = value != 0; return TKZ_OK; }
+    if (option == TKZ_OPT_PIECE_STATS) {
+        // statistics of the batch path (the single-launch path does not count): the device block is made on first use
+        DeviceScope scope;
+        tkz_status st = check_encoder(e, scope);
+        if (st != TKZ_OK) return st;
+        std::lock_guard<std::mutex> lock(e->mu);
+        if (value && !e->t_stats.p) {
+            HIP_TRY(e->t_stats.ensure(64, &e->bytes_allocated));
+            HIP_TRY(hipMemset(e->t_stats.p, 0, 64));
+        }
+        e->piece_stats = value != 0;
+        return TKZ_OK;
+    }
     if (option == TKZ_OPT_PIECE_MEMO) {
         // 0: off, 1: on, 2: on and emptied.  Options are set while the encoder is idle: a call in flight on another thread reads
         // T.memo_n when it launches, and emptying the table under running kernels could pair one piece's key with another's tokens
@@ -1212,6 +1234,22 @@ tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, 
 void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_scanner, int64_t* after_multibyte_scanner) {
     if (after_ascii_scanner) *after_ascii_scanner = e ? e->last_xcount.load() : 0;
     if (after_multibyte_scanner) *after_multibyte_scanner = e ? e->last_xcount2.load() : 0;
+}
+tkz_status tkz_encoder_piece_stats(tkz_encoder* e, int64_t* out8, int32_t reset) {
+    if (!e || !out8) return fail(TKZ_E_ARG, "null argument");
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!e->t_stats.p) return TKZ_OK;
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
+    if (st != TKZ_OK) return st;
+    unsigned long long h[8] = {};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h, e->t_stats.p, sizeof h, hipMemcpyDeviceToHost));
+    std::lock_guard<std::mutex> lock(e->mu);
+    out8[0] = e->stat_batches; out8[1] = (int64_t)h[4]; out8[2] = (int64_t)h[2]; out8[3] = (int64_t)h[3]; out8[4] = e->stat_giants;
+    out8[5] = (int64_t)h[0]; out8[6] = (int64_t)h[1];
+    if (reset) { HIP_TRY(hipMemset(e->t_stats.p, 0, 64)); e->stat_batches = e->stat_giants = 0; }
+    return TKZ_OK;
 }
 int64_t tkz_encoder_memo_slots(const tkz_encoder* e) { return e ? (int64_t)e->memo_slots : 0; }
 void tkz_encoder_small_path_calls(const tkz_encoder* e, int64_t* calls, int64_t* handed_back) {

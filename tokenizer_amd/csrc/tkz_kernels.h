@@ -60,6 +60,9 @@ struct EncodeParams {
     // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE bit 4): per-phase clock counters of k_probe.  Compiled out of libtkz.so otherwise.
     unsigned long long* devprof;
     int32_t ablate;
+    // TKZ_OPT_PIECE_STATS: null, or the encoder's statistics block -- [0] memo lookups, [1] memo hits, [2] short misses, [3] long misses, [4] pieces
+    // (what tkz_encoder_piece_stats reports; the timed runs leave it null)
+    unsigned long long* stats;
 };
 
 // k_small: one launch for a small batch (tkz_kernels.hip).  Input and output live in page-locked host memory the device reads and writes directly.
@@ -94,6 +97,7 @@ void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_ba
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
                     const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs);
 void launch_rebase(const Launch& L, int64_t* offs, int64_t n, int64_t base);
+void launch_miss_stats(const Launch& L, const EncodeParams& P, int64_t nsub);
 void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3, int64_t* out3b = nullptr, int64_t* out3c = nullptr);
 // UTF-16 documents -> UTF-8 documents (Encoding.UTF8.GetBytes for a batch): lengths + group prefixes, then (after the scan of
 // the tile sums) the bytes and the byte offset of every document

@@ -1043,6 +1043,10 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
                 if (h) { hit = true; vv = v; }
             }
         }
+        if (P.stats) {                                        // (statistics run only: wave-uniform, null in the timed runs)
+            const int nlook = tkz_popc64(simt::ballot(mine && memo)), nhit = tkz_popc64(simt::ballot(hit));
+            if (lane == 0 && nlook) { simt::atomic_add64(&P.stats[0], (unsigned long long)nlook); simt::atomic_add64(&P.stats[1], (unsigned long long)nhit); }
+        }
         const int cnt = hit ? (int)((vv.x >> 29) & 3u) + 1 : 0;
         (void)assign(hit, cnt, si, j, rel);
         if (hit) {                                            // (a memo entry holds <= 4 tokens: they go into the entry's quad)
@@ -1765,6 +1769,20 @@ TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
     for (int64_t i = simt::bid() * simt::nthreads() + simt::tid(); i < n; i += stride) offs[i] -= base;
 }
 
+// TKZ_OPT_PIECE_STATS: the lengths of the miss lists of all sub-tiles, summed (short | long << 16 per sub-tile)
+TKZ_KERNEL(256) void k_miss_stats(const uint32_t* mcount, const int32_t* pcount, int64_t nsub, unsigned long long* stats) {
+    const int64_t stride = simt::nblocks() * simt::nthreads();
+    int ns = 0, nl = 0, np = 0;
+    for (int64_t i = simt::bid() * simt::nthreads() + simt::tid(); i < nsub; i += stride) { const uint32_t m = mcount[i]; ns += (int)(m & 0xFFFFu); nl += (int)(m >> 16); np += pcount[i]; }
+    int ts, tl, tp;
+    (void)tkz_wave_scan_sum(ns, &ts);
+    (void)tkz_wave_scan_sum(nl, &tl);
+    (void)tkz_wave_scan_sum(np, &tp);
+    if (simt::lane() == 0 && (ts | tl | tp)) {
+        simt::atomic_add64(&stats[2], (unsigned long long)ts); simt::atomic_add64(&stats[3], (unsigned long long)tl); simt::atomic_add64(&stats[4], (unsigned long long)tp);
+    }
+}
+
 // {n_docs, n_bytes, n_tokens} of the batch, on the device: what tkz_comm_allgather_counts_device sends (no host round trip)
 // (up to three copies: the encoder's "last batch" block, the workspace's block of THIS batch, a block of the caller's)
 TKZ_KERNEL(64) void k_counts3(int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3, int64_t* out3b, int64_t* out3c) {
@@ -2331,6 +2349,10 @@ void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int6
 }
 void launch_rebase(const Launch& L, int64_t* offs, int64_t n, int64_t base) {
     TKZ_LAUNCH(k_rebase, grid_for(n), kThreads, L.stream, offs, n, base);
+}
+void launch_miss_stats(const Launch& L, const EncodeParams& P, int64_t nsub) {
+    const int64_t g = grid_for(nsub);
+    TKZ_LAUNCH(k_miss_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, P.pcount, nsub, P.stats);
 }
 void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3, int64_t* out3b, int64_t* out3c) {
     TKZ_LAUNCH(k_counts3, 1, 64, L.stream, n_docs, total, grand, out3, out3b, out3c);
