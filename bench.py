@@ -23,8 +23,14 @@ OTHER documents of the same generator, then one untimed pass with the memo switc
 (the timed steps again with the memo off) and `value_two_in_flight` (the same batch two at a time through
 tkz_encode_batch_device_begin / _end on two streams: what keeping batches in flight buys over one synchronous call after the other).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM bandwidth with the algorithmic bytes of
-SURVEY.md 8(d); `cpu_baseline` times the reference-algorithm CPU restatement (oracle/, kind "port") on a bounded sample of the
+Further companions: `piece_stats` (what the timed steps met: pieces, whole-piece hit rate, misses by kind, memo lookups and hits),
+`value_heldout_vocab` (the same corpus under synth100k_heldout, a stand-in of the same size trained WITHOUT the bench's generator: synth100k
+has seen the generator's output, the real cl100k_base lies between the two), `pcie_inclusive` (the host-buffer entry point on numpy buffers)
+and `value_host_api` (tkz::TikTokenizer::EncodeBatchFlat on a million std::strings: the ITokenizer-shaped surface, gather included).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the step against HBM bandwidth with the algorithmic bytes of SURVEY.md 8(d) (`frac`: the
+whole launch sequence; `frac_dominant`: the dominant kernel alone; `traffic_pipeline` / `wasted`: the counted HBM bytes of all kernels and
+their ratio to the algorithmic ones); `cpu_baseline` times the reference-algorithm CPU restatement (oracle/, kind "port") on a bounded sample of the
 same documents on ALL host cores and is also the parity check of the run.
 """
 import argparse
@@ -44,7 +50,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
-VOCAB_OF_PATTERN = {1: ("gpt2", None), 2: ("synth100k", "cl100k_base"), 3: ("synth200k", "o200k_base")}
+VOCAB_OF_PATTERN = {1: ("gpt2", None), 2: ("synth100k", "cl100k_base"), 3: ("synth200k", "o200k_base"), 4: ("synth200k", "o200k_base")}
+PATTERN_NAME = {1: "pattern 1 (gpt2 / r50k / p50k)", 2: "cl100k_base", 3: "o200k_base (ECMAScript reading: the TypeScript reference's engine)",
+                4: "o200k_base (.NET reading: the string through the C# reference's Regex)"}
 
 
 def load_vocab_bytes(pattern, want=None):
@@ -54,7 +62,7 @@ def load_vocab_bytes(pattern, want=None):
         stand_in, real = want, None
     d = os.environ.get("TKZ_VOCAB_DIR")
     if real and d and os.path.exists(os.path.join(d, real + ".tiktoken")):
-        return open(os.path.join(d, real + ".tiktoken"), "rb").read(), real
+        return open(os.path.join(d, real + ".tiktoken"), "rb").read(), real + " (REAL-VOCAB: $TKZ_VOCAB_DIR/" + real + ".tiktoken)"
     raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", stand_in + ".tiktoken.gz"), "rb").read())
     if stand_in == "gpt2":
         return raw, "gpt2" + ("" if pattern == 1 else " (VOCAB-SUBSTITUTED)")
@@ -113,8 +121,12 @@ def main():
                                                         "5 ONE document of shuffled words joined by single spaces (the reference's own benchmark, PerfBenchmark/Program.cs:14-32)")
     ap.add_argument("--min-len", type=int, default=256)
     ap.add_argument("--max-len", type=int, default=768)
-    ap.add_argument("--pattern", type=int, default=2, help="1 pattern-1, 2 cl100k, 3 o200k")
-    ap.add_argument("--vocab", default=None, help="gpt2 | synth100k | synth200k (default: the stand-in of the pattern's vocabulary)")
+    ap.add_argument("--pattern", type=int, default=2, help="1 pattern-1, 2 cl100k, 3 o200k as the TypeScript reference's engine reads it, 4 o200k as .NET's Regex reads it")
+    ap.add_argument("--vocab", default=None, help="gpt2 | synth100k | synth100k_heldout | synth200k (default: the stand-in of the pattern's vocabulary)")
+    ap.add_argument("--parity-only", action="store_true", help="the oracle compares every document of the batch (all host cores) but the thread sweep of the CPU baseline, "
+                                                               "the PCIe-inclusive and the host-API legs are skipped: for the shape runs of tools/gpu_job_*.sh")
+    ap.add_argument("--heldout-steps", type=int, default=None, help="timed steps of the value_heldout_vocab leg (the same corpus under synth100k_heldout, a stand-in trained "
+                                                                    "WITHOUT the bench's generator); default: as --steps at N = 1 with the cl100k pattern and the default vocabulary, else 0")
     ap.add_argument("--cpu-sample-docs", type=int, default=2_000_000, help="documents of the CPU-baseline thread sweep (the all-core run covers the whole batch)")
     ap.add_argument("--no-memo-steps", type=int, default=None, help="timed steps with the piece memo off (value_no_memo); default: as --steps")
     ap.add_argument("--pipelined-steps", type=int, default=4, help="timed steps of the two-batches-in-flight leg (value_two_in_flight; 0 = skip)")
@@ -236,11 +248,12 @@ def main():
     else:
         memo_note = "on: %d slots, filled during the warm-up steps from the same tiled text (every piece of it repeats)" % enc.memo_slots
 
-    def step():
-        ntok = enc.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total,
-                                       d_ooffs.data_ptr(), stream)
+    def step(en=None):
+        en = en or enc
+        ntok = en.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total,
+                                      d_ooffs.data_ptr(), stream)
         if comm is not None:
-            comm.gather_async(enc, stream)      # ncclAllGather of {docs, bytes, tokens}, enqueued on the encode stream; the table stays in HBM
+            comm.gather_async(en, stream)      # ncclAllGather of {docs, bytes, tokens}, enqueued on the encode stream; the table stays in HBM
         return ntok
 
     def fence():
@@ -248,19 +261,51 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        if warm is not None:
-            enc.encode_batch_device(warm[0].data_ptr(), warm[1].data_ptr(), warm[4], warm[2], warm[3].data_ptr(), warm[2], d_ooffs.data_ptr(), stream)
-        else:
-            ntok = step()
-    if warm is not None:       # (after 5 GB of other documents every memo slot is taken: the timed steps cannot add entries of their own)
-        del warm, w_bytes, w_offs, w_ids
-        torch.cuda.empty_cache()
-        # one untimed pass over the bench batch itself with the memo switched off (it neither reads nor fills it then): the workspace
-        # takes the size THIS batch needs -- record capacity, scratch of its giant pieces -- outside the timed region
-        enc.set_option(N.OPT_PIECE_MEMO, 0)
-        ntok = step()
-        enc.set_option(N.OPT_PIECE_MEMO, 1)
+    def prepare(en):
+        """The W untimed warm-up steps of an encoder (on the OTHER documents when there are any: they fill the piece memo), then one untimed
+        pass over the bench batch itself with the memo switched off (it neither reads nor fills it then): the workspace takes the size THIS
+        batch needs -- record capacity, scratch of its giant pieces -- outside the timed region."""
+        nt = 0
+        for _ in range(args.warmup):
+            if warm is not None:
+                en.encode_batch_device(warm[0].data_ptr(), warm[1].data_ptr(), warm[4], warm[2], warm[3].data_ptr(), warm[2], d_ooffs.data_ptr(), stream)
+            else:
+                nt = step(en)
+        if warm is not None:       # (after 5 GB of other documents every memo slot is taken: the timed steps cannot add entries of their own)
+            en.set_option(N.OPT_PIECE_MEMO, 0)
+            nt = step(en)
+            en.set_option(N.OPT_PIECE_MEMO, 1)
+        return nt
+
+    def timed(en, steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            nt = step(en)
+        fence()
+        d = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d, nt
+
+    def stats_of(en):
+        """One more untimed step with the counting switched on (TKZ_OPT_PIECE_STATS): what the timed steps met -- pieces, whole-piece hits,
+        misses by kind, memo lookups and hits (the memo as the timed steps found it: full, so this step adds nothing to it)."""
+        try:
+            en.set_option(N.OPT_PIECE_STATS, 1)
+            en.piece_stats(reset=True)
+            en.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total, d_ooffs.data_ptr(), stream)   # (no collective: rank 0 alone)
+            torch.cuda.synchronize()
+            st = en.piece_stats(reset=True)
+            en.set_option(N.OPT_PIECE_STATS, 0)
+            st.pop("batches", None)
+            return st
+        except Exception as ex:
+            return {"error": "%s: %s" % (type(ex).__name__, ex)}
+
+    ntok = prepare(enc)
     enc.set_profiling(True)
     enc.kernel_ms(reset=True)
     fence()
@@ -277,23 +322,50 @@ def main():
         rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
         dt = max(float(x.item()) for x in allt)              # the slowest rank's time is the job's
     kms = enc.kernel_ms()
+    piece_stats = stats_of(enc) if rank == 0 else None
+    if world > 1:
+        fence()
     # the same steps with the piece memo switched off (it neither reads nor fills it): the companion figure `value_no_memo`
     dt_nomemo = None
     nm_steps = args.steps if args.no_memo_steps is None else args.no_memo_steps
     if not args.no_memo and nm_steps > 0:
         enc.set_option(N.OPT_PIECE_MEMO, 0)
         step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(nm_steps):
-            step()
-        fence()
-        dt_nomemo = time.perf_counter() - t0
+        dt_nomemo, _ = timed(enc, nm_steps)
         enc.set_option(N.OPT_PIECE_MEMO, 1)
-        if world > 1:
-            t = torch.tensor([dt_nomemo], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_nomemo = float(t.item())
+    # the same corpus under a stand-in vocabulary that has never seen it (tools/train_bpe.py synth100k_heldout: the same size and recipe
+    # WITHOUT the bench's generator in the training text): `value_heldout_vocab`.  synth100k is trained on the generator's own output, so
+    # its whole-piece hit rate flatters; the real cl100k_base lies somewhere between the two.  Its own encoder, its own memo, the same
+    # warm-up; every document against the oracle under that vocabulary as well.
+    heldout = None
+    ho_steps = args.heldout_steps
+    if ho_steps is None:
+        ho_steps = args.steps if (world == 1 and args.pattern == 2 and args.vocab is None and not args.no_memo and "VOCAB-SUBSTITUTED" in vocab_name) else 0
+    if ho_steps > 0:
+        try:
+            raw_h, name_h = load_vocab_bytes(args.pattern, "synth100k_heldout")
+            enc_h = N.Encoder(N.Vocab(raw_h), args.pattern, device=local_rank)
+            ntok_h = prepare(enc_h)
+            dt_h, ntok_h = timed(enc_h, ho_steps)
+            heldout = {"value": round(total * world * ho_steps / dt_h / 1e6, 1), "unit": "MB/s", "ms_per_step": round(dt_h / ho_steps * 1e3, 3), "vocab": name_h,
+                       "vocab_sha256": hashlib.sha256(raw_h).hexdigest(), "tokens_per_gpu": ntok_h, "piece_stats": stats_of(enc_h) if rank == 0 else None,
+                       "parity": "unchecked"}
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                from oracle import oracle as O
+                tm = {}
+                bad, first_bad, otok = O.check_batch(O.Vocab(raw_h), args.pattern, d_bytes[:total].cpu().numpy(), d_offs.cpu().numpy(), d_ids[:ntok_h].cpu().numpy(),
+                                                     d_ooffs.cpu().numpy(), threads=max(1, os.cpu_count() or 1), timing=tm)
+                heldout["parity"] = ("bit-exact vs oracle on all %d docs (%d tokens)" % (n_docs, otok)) if (bad == 0 and otok == ntok_h) else \
+                                    "MISMATCH vs oracle: %d of %d docs differ, first %d" % (bad, n_docs, first_bad)
+            del enc_h
+            torch.cuda.empty_cache()
+            ntok = step()                      # (the output buffers hold the headline vocabulary's ids again: the parity check below reads them)
+            fence()
+        except Exception as ex:
+            heldout = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    if warm is not None:
+        del warm, w_bytes, w_offs, w_ids
+        torch.cuda.empty_cache()
     # the same steps two at a time through tkz_encode_batch_device_begin / _end (two streams, two output buffers, two workspaces of the
     # encoder): what keeping batches in flight buys over one synchronous call after the other -- a companion figure, never `value`
     dt_pipe = None
@@ -340,7 +412,7 @@ def main():
         dom_ms = kms[dom][0] / max(1, kms[dom][1])
         alg_bytes = total + 4 * n_tokens_rank + 16 * n_docs      # read text + write int32 ids + 8 B offset in + 8 B offset out
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
-        traffic, traffic_note = None, "no PMC summary for this build"
+        traffic, traffic_pipeline, traffic_by_kernel, traffic_note = None, None, None, "no PMC summary for this build"
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
@@ -351,20 +423,31 @@ def main():
                     traffic_note = "profiles/traffic_latest.json is for another workload / kernel: not reported"
                 else:
                     traffic, traffic_note = tj["by_kernel"][dom]["hbm_bytes_per_launch"], "rocprofv3 PMC passes of this build (profiles/traffic_latest.json)"
+                    traffic_by_kernel = {k: v["hbm_bytes_per_launch"] for k, v in tj["by_kernel"].items()}
+                    traffic_pipeline = int(sum(traffic_by_kernel.values()))
             except Exception:
                 traffic = None
         leftovers = enc.pretok_leftovers() if hasattr(enc, "pretok_leftovers") else (0, 0)
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_note": traffic_note,
+        pipe_achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9
+        # `achieved` / `frac` price the WHOLE step (every kernel of the launch sequence has to move its share of the algorithmic bytes: crediting
+        # the dominant kernel alone with all of them flatters); the dominant kernel's own figure is beside it (`*_dominant`).  `traffic` is the
+        # dominant kernel's counted HBM bytes per launch, `traffic_pipeline` all kernels' together, `wasted` = traffic_pipeline / algorithmic.
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(pipe_achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(pipe_achieved / HBM_PEAK_GBPS, 5),
+                    "achieved_dominant": round(achieved, 2), "frac_dominant": round(achieved / HBM_PEAK_GBPS, 5),
+                    "traffic": traffic, "traffic_pipeline": traffic_pipeline,
+                    "wasted": round(traffic_pipeline / alg_bytes, 3) if traffic_pipeline else None, "traffic_by_kernel": traffic_by_kernel, "traffic_note": traffic_note,
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
                     "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kms.items()},
-                    "pipeline_frac": round(alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)}
-        if args.pattern == 3:     # of the 4 KiB blocks: handed on by the ASCII block scanner / by the multi-byte one as well (to the sequential matcher)
+                    "note": "achieved = algorithmic bytes (SURVEY.md 8d: text + 4 B per id + 16 B per document) / the step's time; *_dominant = the same bytes / "
+                            "the dominant kernel's average launch duration (HIP events on the launch stream)"}
+        if args.pattern in (3, 4):     # of the 4 KiB blocks: handed on by the ASCII block scanner / by the multi-byte one as well (to the sequential matcher)
             roofline["o200k_blocks"] = {"total": (total + 3967) // 3968, "after_ascii_scanner": leftovers[0], "after_multibyte_scanner": leftovers[1]}
         # ---- CPU baseline (the oracle = reference-algorithm restatement, "port") + parity on the sample ----
         cpu = None
         host_path = None
         parity_note = "unchecked"
+        host_api = None
         if world == 1 and not args.no_cpu_baseline:
             try:
                 from oracle import oracle as O
@@ -387,6 +470,8 @@ def main():
                 same = same and bad == 0 and otok == n_tokens_rank
                 parity_note = ("bit-exact vs oracle on all %d docs (%d tokens, %.1f s on %d host threads); offsets monotone, ending at the token count"
                                % (n_docs, otok, tm["seconds"], best[1])) if same else "MISMATCH vs oracle: %d of %d docs differ, first %d" % (bad, n_docs, first_bad)
+                if args.parity_only:
+                    raise StopIteration
                 # ---- CPU baseline: the same restatement timed on the host cores.  The all-core run above covers the whole batch; fewer
                 # threads (SMT siblings and memory channels decide which count is best) on a bounded sample; and one thread ----
                 ns = min(args.cpu_sample_docs, n_docs)
@@ -406,15 +491,22 @@ def main():
                     cpu_1t = round(nb1 / tm["seconds"] / 1e6, 2)
                 else:
                     cpu_1t = round(best[0], 2)
-                quota = None
+                quota, eff = None, None
                 try:
                     quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+                    q = quota.split()
+                    if q[0] != "max":
+                        eff = float(q[0]) / float(q[1])
                 except Exception:
                     pass
-                cpu = {"value": round(best[0], 2), "unit": "MB/s", "cores": best[1], "kind": "port", "value_1_thread": cpu_1t, "by_threads": sweep,
+                # `cores` = the CPUs the run could really use: the cgroup's quota when there is one (the box shows 256 hardware threads and grants 16
+                # CPUs of time), else the thread count; `threads` = how many threads the best run used
+                cores_eff = min(best[1], eff) if eff else best[1]
+                cpu = {"value": round(best[0], 2), "unit": "MB/s", "cores": int(cores_eff) if float(cores_eff).is_integer() else round(cores_eff, 2), "threads": best[1],
+                       "kind": "port", "value_1_thread": cpu_1t, "by_threads": sweep,
                        "host_threads_available": ncpu, "cgroup_cpu_max": quota,
                        "host_parallel_speedup": O.host_parallelism(sorted({1, max(1, ncpu // 4), max(1, ncpu // 2), ncpu})),
-                       "sample": "%d documents (%.1f MB) of the same corpus on %d host threads -- the best of the thread counts tried (by_threads: MB/s; the %d-thread "
+                       "sample": "%d documents (%.1f MB) of the same corpus on %d host threads (`cores`: the CPUs the cgroup grants them) -- the best of the thread counts tried (by_threads: MB/s; the %d-thread "
                                  "run covers the whole batch and is the parity check); one thread: the first %d documents; reference-algorithm CPU restatement "
                                  "(oracle/), 8192-entry LRU memo and reusable scratch per thread" % (best[3], best[2] / 1e6, best[1], ncpu, n1)}
                 ns = min(ns, n_docs)
@@ -427,7 +519,7 @@ def main():
                     open("/tmp/tkz_bench_vocab.tiktoken", "wb").write(raw)
                     from tokenizer_amd import tokenizer as TK
                     os.environ["TKZ_BENCH_VOCAB"] = "/tmp/tkz_bench_vocab.tiktoken"
-                    os.environ["TKZ_BENCH_PATTERN"] = {1: TK.REGEX_PATTERN_1, 2: TK.REGEX_CL100K, 3: TK.REGEX_O200K}[args.pattern]
+                    os.environ["TKZ_BENCH_PATTERN"] = {1: TK.REGEX_PATTERN_1, 2: TK.REGEX_CL100K, 3: TK.REGEX_O200K, 4: TK.REGEX_O200K}[args.pattern]
                     cpu["reference_dotnet"] = reference_dotnet_baseline(sp)
                 # PCIe-inclusive rate through the host-buffer entry point (tkz_encode_batch_utf8: H2D of the text, the kernels,
                 # D2H of ids + offsets), on ordinary (pageable) numpy buffers and on page-locked ones.  Output buffers are
@@ -462,6 +554,37 @@ def main():
                                  "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text, kernels and D2H of ids and offsets, chunked and overlapped on three streams; the better of two calls"}
                 except Exception as ex:                      # an auxiliary figure must never cost the bench line
                     host_path = {"error": "%s: %s" % (type(ex).__name__, ex)}
+                # The ITokenizer-shaped surface: tkz::TikTokenizer::EncodeBatchFlat(std::vector<std::string>) of include/tkz_tokenizer.hpp on the
+                # same documents held as strings -- a gather into page-locked memory by host threads, then the host-buffer entry point.  A C++
+                # program (tests/cpp/bench_host_api.cpp) built here with g++ against the same libtkz.so; its ids are compared by checksum.
+                try:
+                    import tempfile
+                    from tokenizer_amd import tokenizer as TK
+                    tdir = tempfile.mkdtemp(prefix="tkz_host_api_")
+                    exe = os.path.join(tdir, "bench_host_api")
+                    libdir = os.path.dirname(enc.lib.path)
+                    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "bench_host_api.cpp"),
+                                           "-L", libdir, "-ltkz", "-Wl,-rpath," + libdir, "-o", exe])
+                    open(os.path.join(tdir, "v.tiktoken"), "wb").write(raw)
+                    open(os.path.join(tdir, "regex.txt"), "w").write({1: TK.REGEX_PATTERN_1, 2: TK.REGEX_CL100K, 3: TK.REGEX_O200K, 4: TK.REGEX_O200K}[args.pattern])
+                    with open(os.path.join(tdir, "sample.bin"), "wb") as f:
+                        f.write(np.int64(nh).tobytes()); f.write(hh_offs.astype(np.int64).tobytes()); f.write(hh_bytes.tobytes())
+                    out = subprocess.run([exe, os.path.join(tdir, "v.tiktoken"), os.path.join(tdir, "regex.txt"), os.path.join(tdir, "sample.bin"), "0"],
+                                         capture_output=True, text=True, timeout=600)
+                    shutil.rmtree(tdir, ignore_errors=True)
+                    if out.returncode != 0 or args.pattern == 3:       # (pattern 3 is not what the C++ mirror makes of the o200k string: it reads it as .NET does)
+                        host_api = {"error": (out.stderr or out.stdout)[-300:] if out.returncode else "the C++ mirror reads the o200k string with the C# engine's semantics (pattern 4)"}
+                    else:
+                        host_api = json.loads(out.stdout.strip().splitlines()[-1])
+                        want = h_ids[:int(h_ooffs[nh])].astype(np.uint32).astype(np.uint64) + np.uint64(1)      # (the driver's position-weighted sum mod 2^64)
+                        wsum = int((want * (np.arange(len(want), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1))).sum(dtype=np.uint64))
+                        host_api["same_ids_as_device_path"] = bool(host_api["tokens"] == len(want) and host_api["ids_checksum"] == "%016x" % wsum)
+                        host_api["note"] = ("tkz::TikTokenizer::EncodeBatchFlat on %d std::strings (include/tkz_tokenizer.hpp): threaded gather into page-locked memory + "
+                                            "tkz_encode_batch_utf8 + ids left in page-locked memory; the best of %d calls" % (nh, host_api.get("reps", 0)))
+                except Exception as ex:
+                    host_api = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            except StopIteration:
+                pass
             except Exception as ex:                          # (e.g. no C compiler for the oracle on this host)
                 parity_note = "unchecked: CPU oracle unavailable (%s: %s)" % (type(ex).__name__, ex)
         workloads = {1: "BASELINE.json configs[1]: cl100k_base pattern, %d synthetic ASCII docs/GPU, %d..%d B (mean %.0f), device-resident",
@@ -478,20 +601,25 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workloads[args.kind] % (n_docs, args.min_len, args.max_len, job_bytes / max(1, job_docs)),
-                       "pattern": {1: "pattern 1 (gpt2 / r50k / p50k)", 2: "cl100k_base", 3: "o200k_base"}[args.pattern],
+                       "pattern": PATTERN_NAME[args.pattern],
                        "piece_memo": memo_note,
-                       "vocab": vocab_name, "vocab_keys": len(vocab), "docs_per_gpu": n_docs, "bytes_per_gpu": total, "tokens_per_gpu": n_tokens_rank,
+                       "vocab": vocab_name, "vocab_keys": len(vocab), "vocab_sha256": hashlib.sha256(raw).hexdigest(), "docs_per_gpu": n_docs, "bytes_per_gpu": total, "tokens_per_gpu": n_tokens_rank,
                        "job_docs": job_docs, "job_bytes": job_bytes, "job_tokens": job_tokens,
                        "partitioning": "contiguous document ranges, one process per GPU; one all-gather of 3 int64 counts per rank per step"},
             "comm": comm_info,
             "tokens_per_s": round(job_tokens * args.steps / dt, 1),
+            "piece_stats": piece_stats,
             "value_no_memo": round(job_bytes * nm_steps / dt_nomemo / 1e6, 1) if dt_nomemo else None,
+            "value_heldout_vocab": heldout["value"] if heldout and "value" in heldout else None,
+            "heldout_vocab": heldout,
             "value_two_in_flight": round(job_bytes / dt_pipe / 1e6, 1) if dt_pipe else None,
             "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
             "parity": parity_note,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "pcie_inclusive": host_path,
+            "value_host_api": host_api["value"] if host_api and "value" in host_api else None,
+            "host_api": host_api,
         }
         if shard_note:
             line["shard_file"] = shard_note

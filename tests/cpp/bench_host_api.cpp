@@ -45,9 +45,10 @@ int main(int argc, char** argv) {
             const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             best = std::max(best, static_cast<double>(total) / s / 1e6);
         }
-        uint64_t sum = 1469598103934665603ull;                          // FNV-1a over the ids: bench.py compares it with the device path's
-        for (int64_t i = 0; i < fb.n_ids(); ++i) { sum ^= static_cast<uint32_t>(fb.ids()[i]); sum *= 1099511628211ull; }
-        std::printf("{\"value\": %.1f, \"unit\": \"MB/s\", \"docs\": %lld, \"bytes\": %lld, \"tokens\": %lld, \"ids_fnv1a\": \"%016llx\", \"gather_threads\": %d, \"reps\": %d}\n",
+        // a position-weighted sum of the ids mod 2^64 (numpy computes the same in one expression): bench.py compares it with the device path's
+        uint64_t sum = 0;
+        for (int64_t i = 0; i < fb.n_ids(); ++i) sum += (static_cast<uint64_t>(static_cast<uint32_t>(fb.ids()[i])) + 1) * (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull + 1);
+        std::printf("{\"value\": %.1f, \"unit\": \"MB/s\", \"docs\": %lld, \"bytes\": %lld, \"tokens\": %lld, \"ids_checksum\": \"%016llx\", \"gather_threads\": %d, \"reps\": %d}\n",
                     best, static_cast<long long>(texts.size()), static_cast<long long>(total), static_cast<long long>(fb.n_ids()),
                     static_cast<unsigned long long>(sum), threads, reps);
     } catch (const std::exception& ex) {

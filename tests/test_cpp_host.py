@@ -21,11 +21,12 @@ def _build_and_run(tmp_path, libdir, libname):
     assert "cpp host mirror ok" in out.stdout
 
 
-def fnv1a_ids(ids):
-    h = 1469598103934665603
-    for v in ids:
-        h = ((h ^ (int(v) & 0xFFFFFFFF)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
-    return "%016x" % h
+def ids_checksum(ids):
+    """The position-weighted sum mod 2^64 that tests/cpp/bench_host_api.cpp prints."""
+    import numpy as np
+    a = np.asarray(ids).astype(np.uint32).astype(np.uint64) + np.uint64(1)
+    w = np.arange(len(a), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1)
+    return "%016x" % int((a * w).sum(dtype=np.uint64))
 
 
 def build_host_api_bench(outdir, libdir, libname):
@@ -57,7 +58,7 @@ def test_host_api_bench_driver_on_emulated_kernels(tmp_path):
     out = subprocess.run([exe, str(tmp_path / "v.tiktoken"), str(tmp_path / "regex.txt"), str(tmp_path / "sample.bin"), "2"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     r = json.loads(out.stdout)
-    assert r["docs"] == 150 and r["bytes"] == len(data) and r["tokens"] == len(ids) and r["ids_fnv1a"] == fnv1a_ids(ids)
+    assert r["docs"] == 150 and r["bytes"] == len(data) and r["tokens"] == len(ids) and r["ids_checksum"] == ids_checksum(ids)
 
 
 def test_cpp_host_mirror_on_emulated_kernels(tmp_path):

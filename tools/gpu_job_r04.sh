@@ -24,15 +24,16 @@ P
 fi
 if has shapes; then
   rm -f $O/bench_shapes.jsonl
-  IFS='|' read -ra SPECS <<< "${SHAPES:---kind 2 --docs 2000000|--kind 4 --docs 4000000|--kind 5|--kind 3 --pattern 2 --docs 32768 --min-len 30000 --max-len 34000|--kind 3 --pattern 3 --docs 32768 --min-len 30000 --max-len 34000|--kind 2 --pattern 3 --docs 2000000}"
+  IFS='|' read -ra SPECS <<< "${SHAPES:---kind 2 --docs 2000000|--kind 4 --docs 4000000|--kind 5|--kind 3 --pattern 2 --docs 32768 --min-len 30000 --max-len 34000|--kind 3 --pattern 4 --docs 32768 --min-len 30000 --max-len 34000|--kind 2 --pattern 4 --docs 2000000|--kind 2 --pattern 3 --docs 2000000|--pattern 4|--vocab gpt2|--vocab gpt2 --pattern 1}"
   for spec in "${SPECS[@]}"; do
-    timeout 600 python bench.py $spec --no-cpu-baseline --steps 3 --warmup 1 >> $O/bench_shapes.jsonl 2>> $O/bench_shapes.err; echo "shape [$spec] rc=$?"
+    # (--parity-only: the oracle compares EVERY document of the shape's batch; no thread sweep, no PCIe / host-API legs)
+    timeout 900 python bench.py $spec --parity-only --steps 3 --warmup 1 >> $O/bench_shapes.jsonl 2>> $O/bench_shapes.err; echo "shape [$spec] rc=$?"
   done
   python - $O/bench_shapes.jsonl <<'P'
 import json,sys
 for l in open(sys.argv[1]):
     if l.startswith("{"):
-        d=json.loads(l); print(d["config"]["pattern"][:6], d["config"]["workload"][:40], d["value"], d.get("value_no_memo"), d["ms_per_step"], d["roofline"]["kernels_ms"])
+        d=json.loads(l); print(d["config"]["pattern"][:12], d["config"]["vocab"][:10], d["config"]["workload"][:40], d["value"], d.get("value_no_memo"), d.get("value_two_in_flight"), d["ms_per_step"], d["parity"][:28], d["roofline"]["kernels_ms"])
 P
 fi
 if has latency; then timeout 300 python tools/latency_probe.py > $O/latency.json 2> $O/latency.err; echo "latency rc=$?"; cat $O/latency.json; fi
