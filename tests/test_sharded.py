@@ -81,6 +81,42 @@ def test_two_rank_shards_match_single_batch(tmp_path):
     assert np.concatenate([np.asarray(sh.ids) for sh in shards]).tolist() == ids.tolist()
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_tkz_comm_fake_rccl(tmp_path, world):
+    """tkz_comm_* (the C ABI's direct-RCCL count exchange) at world sizes RCCL itself cannot run at here: the real tkz_comm.cpp in the
+    CPU-emulated build, its dlopen("librccl.so.1") satisfied by tests/hostemu/fake_rccl.cpp (a Unix-socket all-gather) through LD_LIBRARY_PATH.
+    Exercises the id exchange, ncclCommInitRank's argument order, the ncclInt64 value, count = 3, the table layout and tkz_shard_bases."""
+    import json
+    import subprocess
+    import emu
+    emu.library()
+    fake = os.path.join(emu.EMU_DIR, "_build", "fake_rccl")
+    assert os.path.exists(os.path.join(fake, "librccl.so.1"))
+    env = dict(os.environ, LD_LIBRARY_PATH=fake + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "comm_worker.py"), str(r), str(world), str(tmp_path / "id.bin"), str(tmp_path / ("out%d.json" % r))],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, out.decode()
+    res = [json.load(open(tmp_path / ("out%d.json" % r))) for r in range(world)]
+    table = [x for r in res for x in r["mine"]]
+    doc_base = tok_base = byte_base = 0
+    for r in res:
+        assert r["world"] == world and r["comm_rank"] == r["rank"] and r["backend"].startswith("rccl 2.")
+        assert r["table_dev"] == table and r["table_host"] == table              # every rank holds every rank's counts, in rank order
+        assert r["bases"] == [doc_base, byte_base, tok_base]
+        assert r["totals"] == [sum(table[0::3]), sum(table[1::3]), sum(table[2::3])] and r["totals"][0] == 173
+        doc_base += r["mine"][0]; byte_base += r["mine"][1]; tok_base += r["mine"][2]
+    # the shards concatenate into the whole batch
+    import gzip
+    from tokenizer_amd import _native as N
+    lib = emu.library()
+    raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "gpt2.tiktoken.gz"), "rb").read())
+    docs = [N.corpus_doc_host(1, 0x5EED0002, d, 20, 200, lib=lib) for d in range(173)]
+    ids, _ = N.Encoder(N.Vocab(raw, lib), N.CL100K).encode_batch(np.frombuffer(b"".join(docs), np.uint8), np.cumsum([0] + [len(d) for d in docs]).astype(np.int64))
+    assert [x for r in res for x in r["ids"]] == ids.tolist()
+
+
 def test_shard_file_round_trip_and_errors(tmp_path):
     from tokenizer_amd import Shard, write_shard
     ids = np.arange(17, dtype=np.int32) * 3

@@ -12,7 +12,11 @@
 // soname) the loader hands back that very copy, so there is never a second RCCL -- or a second HIP runtime -- in the process.
 // A missing library fails loudly at tkz_comm_create / tkz_comm_unique_id (TKZ_E_UNSUPPORTED), never silently.
 #include <dlfcn.h>
+#ifdef TKZ_HOSTEMU
+#include "hip_emu.h"      // (the CPU-emulated build of the tests: the same code against the emulator's HIP and tests/hostemu/fake_rccl.cpp)
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include <cstdio>
 #include <cstring>
