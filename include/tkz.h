@@ -100,6 +100,8 @@ tkz_status tkz_pattern_from_regex_engine(const char* regex_utf8, int32_t engine,
 tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t device, tkz_encoder** out);
 void tkz_encoder_destroy(tkz_encoder* e);
 int32_t tkz_encoder_device(const tkz_encoder* e);
+/* tkz_unicode_classes, read from the table image the encoder's DEVICE holds (downloaded for the call): verifies the upload. */
+tkz_status tkz_encoder_unicode_classes(tkz_encoder* e, uint32_t first, int32_t n, uint8_t* out);
 
 /* Page-locked host memory for the buffers a host hands to the host-buffer entry points: copies from and to it run asynchronously at
  * the PCIe rate (tkz_encode_batch_utf8 overlaps the upload of one document range with the kernels of the previous one and the download

@@ -126,7 +126,7 @@ hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidVal
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     memset(p, 0, sizeof *p); strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "gfx950:emulated");
-    p->totalGlobalMem = (size_t)8 << 30; p->multiProcessorCount = 1; return hipSuccess;
+    p->totalGlobalMem = (size_t)8 << 30; p->multiProcessorCount = 1; p->sharedMemPerBlock = (size_t)160 << 10; return hipSuccess;
 }
 hipError_t hipMalloc(void** p, size_t n) {
     size_t m = (n + 255) & ~(size_t)255; if (!m) m = 256;

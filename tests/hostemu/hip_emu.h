@@ -27,7 +27,7 @@ enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErr
 typedef struct hipemu_stream* hipStream_t;
 typedef struct hipemu_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
-struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; size_t totalGlobalMem; int multiProcessorCount; };
+struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; size_t totalGlobalMem; int multiProcessorCount; size_t sharedMemPerBlock; };
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);

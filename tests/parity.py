@@ -499,6 +499,19 @@ def check_memo_contention(lib, O, vocab, ovocab, candidates=400_000, threads=2, 
     assert not errors, errors
 
 
+def check_device_unicode_table(lib, vocab):
+    """The Unicode class table as the DEVICE holds it (downloaded through tkz_encoder_unicode_classes) against `unicodedata` 13.0, all
+    1,114,112 code points: the oracle and the product share one generated table, so this -- not a comparison of the two -- is what would
+    catch a wrong class (tests/test_unicode_tables.py does the same for the host copies)."""
+    from test_unicode_tables import expected_class
+    enc = N.Encoder(vocab, N.O200K)
+    got = np.zeros(0x110000, np.uint8)
+    lib.check(lib.L.tkz_encoder_unicode_classes(enc._h, 0, 0x110000, got.ctypes.data))
+    exp = np.fromiter((expected_class(u) for u in range(0x110000)), np.uint8, 0x110000)
+    bad = np.nonzero(got != exp)[0]
+    assert len(bad) == 0, [(hex(int(u)), int(got[u]), int(exp[u])) for u in bad[:10]]
+
+
 def read_device_i64(lib, ptr, n):
     """n int64 at a device pointer of the library's: host memory on the CPU-emulated build, hipMemcpy (which also waits for the null
     stream's earlier work) on the GPU."""

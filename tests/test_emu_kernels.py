@@ -52,6 +52,10 @@ def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
                         doc_lens=[0, 1, 7, 63, 64, 65, 127, 128, 129, 200, 1000, 5000, 9000])
 
 
+def test_device_unicode_table(lib, vocab):
+    parity.check_device_unicode_table(lib, vocab)
+
+
 def test_golden_splits(lib, vocab):
     for rec in load_golden_json("splits.json"):
         enc = N.Encoder(vocab, rec["pattern"])

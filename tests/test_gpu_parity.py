@@ -104,6 +104,10 @@ def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod, pattern):
     parity.check_o200k_no_sync_points(lib, oracle_mod, vocab, pattern)
 
 
+def test_device_unicode_table(lib, vocab):
+    parity.check_device_unicode_table(lib, vocab)
+
+
 def test_golden_splits(lib, vocab):
     for rec in load_golden_json("splits.json"):
         enc = N.Encoder(vocab, rec["pattern"])

@@ -87,6 +87,7 @@ class Library:
         L.tkz_encoder_memo_bucket.restype = i64
         L.tkz_unicode_classes.argtypes = [C.c_uint32, C.c_int32, vp]
         L.tkz_unicode_classes.restype = None
+        L.tkz_encoder_unicode_classes.argtypes = [vp, C.c_uint32, C.c_int32, vp]
         L.tkz_encoder_pretok_leftovers.argtypes = [vp, pi64, pi64]
         L.tkz_encoder_pretok_leftovers.restype = None
         L.tkz_vocab_table_bytes.argtypes = [vp, C.c_int32]

@@ -151,6 +151,7 @@ struct tkz_encoder {
     std::vector<std::pair<int32_t, std::string>> dec_vocab, dec_special;   // host copies (id, bytes)
     int64_t bytes_allocated = 0;           // tables
     std::atomic<int64_t> last_xcount{0}, last_xcount2{0};   // tkz_encoder_pretok_leftovers
+    bool small_ok = false;                 // the device's LDS per workgroup holds k_small's (kSmallLdsBytesNeeded)
     bool piece_stats = false;              // TKZ_OPT_PIECE_STATS
     DevBuf t_stats;                        // its device block (EncodeParams::stats)
     int64_t stat_batches = 0, stat_giants = 0;   // ... and what the host adds per batch (under mu)
@@ -485,7 +486,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
 constexpr size_t kSmallOffBytes = 0, kSmallOffOffs = tkz::kSmallMaxBytes + 64, kSmallOffIds = kSmallOffOffs + (tkz::kSmallMaxDocs + 1) * 8,
                  kSmallOffOut = kSmallOffIds + tkz::kSmallMaxBytes * 4, kSmallOffRes = kSmallOffOut + (tkz::kSmallMaxDocs + 1) * 8, kSmallBlock = kSmallOffRes + 256;
 bool small_eligible(const tkz_encoder* e, const int64_t* offs, int64_t n_docs, int64_t total) {
-    if (e->profiling || e->pretok_seq || total <= 0 || total > tkz::kSmallMaxBytes || n_docs < 1 || n_docs > tkz::kSmallMaxDocs) return false;
+    if (!e->small_ok || e->profiling || e->pretok_seq || total <= 0 || total > tkz::kSmallMaxBytes || n_docs < 1 || n_docs > tkz::kSmallMaxDocs) return false;
     const bool o200k = e->pattern == TKZ_PATTERN_O200K || e->pattern == TKZ_PATTERN_O200K_DOTNET;
     if (o200k && total > tkz::kSmallMaxBytesO200k) return false;
     if (o200k)                                    // (split by the sequential matcher there, one lane per document)
@@ -735,6 +736,18 @@ void tkz_unicode_classes(uint32_t first, int32_t n, uint8_t* out) {
     for (int32_t i = 0; out && i < n; ++i) out[i] = tkz_supp_class(ucd, first + (uint32_t)i);
 }
 
+tkz_status tkz_encoder_unicode_classes(tkz_encoder* e, uint32_t first, int32_t n, uint8_t* out) {
+    // the table image as the DEVICE holds it (downloaded, then read as the kernels read it): a check of the upload, not of the host copy
+    if (!out || n < 0) return fail(TKZ_E_ARG, "bad argument");
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
+    if (st != TKZ_OK) return st;
+    std::vector<uint8_t> img(tkz::bmp_class_table().size());
+    HIP_TRY(hipMemcpy(img.data(), e->t_bmp.p, img.size(), hipMemcpyDeviceToHost));
+    for (int32_t i = 0; i < n; ++i) out[i] = tkz_supp_class(img.data(), first + (uint32_t)i);
+    return TKZ_OK;
+}
+
 tkz_status tkz_pattern_from_regex_engine(const char* regex_utf8, int32_t engine, int32_t* pattern_out) {
     if (!regex_utf8 || !pattern_out) return fail(TKZ_E_ARG, "null argument");
     if (engine != TKZ_ENGINE_DOTNET && engine != TKZ_ENGINE_ECMASCRIPT) return fail(TKZ_E_ARG, "unknown regex engine id");
@@ -764,6 +777,7 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     HIP_TRY(scope.enter(device));
     tkz_encoder* e = new tkz_encoder();
     e->device = device; e->pattern = pattern; e->max_key_len = v->v.max_key_len;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) e->small_ok = prop.sharedMemPerBlock >= (size_t)tkz::kSmallLdsBytesNeeded; }
     int64_t* acc = &e->bytes_allocated;
     const tkz::Vocab& V = v->v;
     hipError_t h = hipSuccess;

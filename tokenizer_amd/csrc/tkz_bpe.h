@@ -110,8 +110,8 @@ TKZ_HD int tkz_bpe_lane_f(const TkzTables& T, const uint32_t* w, int n, uint32_t
         uint32_t r1, r2s, l1, l2;
         tkz_pair_slots(T, m, idr, &r1, &r2s);
         tkz_pair_slots(T, idl, m, &l1, &l2);
-        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2s]);
-        const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
+        const uint4 vr1 = tkz_load_pair_slot(T, r1), vr2 = tkz_load_pair_slot(T, r2s);
+        const uint4 vl1 = tkz_load_pair_slot(T, l1), vl2 = tkz_load_pair_slot(T, l2);
         ids[j] = m;
         pr[r] = TKZ_NOKEY;
         const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);
@@ -219,8 +219,8 @@ TKZ_HD int tkz_bpe_lane_var(const TkzTables& T, ByteAt at, int n, uint32_t* st, 
         uint32_t r1, r2s, l1, l2;
         tkz_pair_slots(T, m, idr, &r1, &r2s);
         tkz_pair_slots(T, idl, m, &l1, &l2);
-        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2s]);
-        const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
+        const uint4 vr1 = tkz_load_pair_slot(T, r1), vr2 = tkz_load_pair_slot(T, r2s);
+        const uint4 vl1 = tkz_load_pair_slot(T, l1), vl2 = tkz_load_pair_slot(T, l2);
         ids[j] = m;                                     // the merged part carries the rank it was found under
         pr[r] = NONE;
         const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);
@@ -311,8 +311,8 @@ TKZ_HD int tkz_bpe_lane_varc(const TkzTables& T, ByteAt at, int n, uint32_t* st,
         uint32_t r1, r2s, l1, l2;
         tkz_pair_slots(T, m, idr, &r1, &r2s);
         tkz_pair_slots(T, idl, m, &l1, &l2);
-        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2s]);
-        const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
+        const uint4 vr1 = tkz_load_pair_slot(T, r1), vr2 = tkz_load_pair_slot(T, r2s);
+        const uint4 vl1 = tkz_load_pair_slot(T, l1), vl2 = tkz_load_pair_slot(T, l2);
         pr[r] = TKZ_NOKEY;                              // dead for good
         pr[j + 1] = kVarDead | m;                       // ... and the slot behind j carries the id of the merged part (= the rank it was found under)
         const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);
@@ -400,8 +400,8 @@ TKZ_HD int tkz_bpe_lane_varc64(const TkzTables& T, ByteAt at, int n, uint32_t* p
         uint32_t r1, r2s, l1, l2;
         tkz_pair_slots(T, m, idr, &r1, &r2s);
         tkz_pair_slots(T, idl, m, &l1, &l2);
-        const uint4 vr1 = tkz_load16(&T.pair_slots[r1]), vr2 = tkz_load16(&T.pair_slots[r2s]);
-        const uint4 vl1 = tkz_load16(&T.pair_slots[l1]), vl2 = tkz_load16(&T.pair_slots[l2]);
+        const uint4 vr1 = tkz_load_pair_slot(T, r1), vr2 = tkz_load_pair_slot(T, r2s);
+        const uint4 vl1 = tkz_load_pair_slot(T, l1), vl2 = tkz_load_pair_slot(T, l2);
         pr[r] = TKZ_NOKEY;                              // dead for good
         pr[j + 1] = kVarDead | m;                       // ... and the slot behind j carries the id of the merged part (= the rank it was found under)
         const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);

@@ -66,6 +66,9 @@ struct EncodeParams {
 };
 
 // k_small: one launch for a small batch (tkz_kernels.hip).  Input and output live in page-locked host memory the device reads and writes directly.
+// (k_small's static LDS: 83.5 KB of gfx950's 160 KB per workgroup -- more than the 64 KB of earlier CDNA parts: the host takes the single-launch path only
+//  on a device whose sharedMemPerBlock covers it, the batch path otherwise)
+constexpr int kSmallLdsBytesNeeded = 86 * 1024;
 constexpr int kSmallMaxBytes = 131072, kSmallMaxBytesO200k = 65536, kSmallMaxDocs = 8192, kSmallMaxDoc = 1024;
 struct SmallArgs {
     const uint8_t* h_bytes; const int64_t* h_offs;          // the batch, in page-locked host memory (h_bytes kSmallMaxBytes + 64 long)

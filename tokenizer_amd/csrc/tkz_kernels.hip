@@ -2085,6 +2085,7 @@ static_assert(kSmallLdsQuads >= kSmallWaves * kProbeLdsQuads + TKZ_SHORT_KEY_MAX
               kSmallLdsQuads >= kSmallWaves * kPlaceLdsQuads && kSmallLdsQuads * 16 >= kSmallMaxBytesO200k + 64 && kSmallMaxBytes <= 8 * kGroup * kSub,
               "every phase fits the one LDS block; the o200k text too; at most 8 groups of k_merge_short");
 TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
+    static_assert(kSmallLdsQuads * 16 <= kSmallLdsBytesNeeded, "tkz_kernels.h: what the host checks against the device's LDS per workgroup");
     TKZ_SHARED uint4 s_raw[kSmallLdsQuads];
     TKZ_SHARED int s_flag;
     const int tid = simt::tid(), lane = simt::lane(), wave = simt::wave();

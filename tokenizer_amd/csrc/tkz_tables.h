@@ -233,16 +233,24 @@ TKZ_HD void tkz_pair_slots(const TkzTables& T, uint32_t a, uint32_t b, uint32_t*
     const uint32_t h = tkz_hash_pair(a, b, T.pair_seed);
     *s1 = tkz_mulhi(h, T.pair_n); *s2 = tkz_mulhi(tkz_hash_pair2(h), T.pair_n);
 }
+// a slot of the pair table by a 32-BIT byte offset from the (wave-uniform) table base: the load takes the base from scalar registers and the
+// offset from one VGPR, instead of a 64-bit address made of a 64-bit shift, two masks and a 64-bit add per slot (the table is far below 4 GB:
+// tkz_vocab.cpp refuses more than 2^27 slots)
+TKZ_HD uint4 tkz_load_pair_slot(const TkzTables& T, uint32_t slot) {
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(T.pair_slots) + (uint32_t)(slot << 4));
+}
 TKZ_HD int32_t tkz_match_pair(const TkzTables& T, uint32_t a, uint32_t b, uint4 v1, uint4 v2) {
     if (T.pair_compact) {
-        const uint64_t want = tkz_pair_key42(a, b) | (1ull << 63), mask = ((1ull << 42) - 1ull) | (1ull << 63);
-        const uint64_t e0 = ((uint64_t)v1.y << 32) | v1.x, e1 = ((uint64_t)v1.w << 32) | v1.z;
-        const uint64_t e2 = ((uint64_t)v2.y << 32) | v2.x, e3 = ((uint64_t)v2.w << 32) | v2.z;
-        if ((e0 & mask) == want) return (int32_t)((e0 >> 42) & 0x1FFFFFu);
-        if ((e1 & mask) == want) return (int32_t)((e1 >> 42) & 0x1FFFFFu);
-        if ((e2 & mask) == want) return (int32_t)((e2 >> 42) & 0x1FFFFFu);
-        if ((e3 & mask) == want) return (int32_t)((e3 >> 42) & 0x1FFFFFu);
-        return TKZ_RANK_NONE;
+        // entry = valid:1 | rank:21 | b:21 | a:21 as two dwords: lo = a | b << 21, hi = b >> 11 | rank << 10 | valid << 31.  Branch-free and in
+        // 32-bit operations (the early-return form compiled into four nested EXEC-mask branches with 64-bit compares: the merge kernels are
+        // bound by instruction issue, and a divergent branch is instructions on the scalar unit as well): an entry matches when
+        // (lo ^ want_lo) | ((hi & 0x800003FF) ^ want_hi) is zero; at most one of the four does (the builder never stores a key twice).
+        const uint32_t ca = tkz_pair_cid(a), cb = tkz_pair_cid(b);
+        const uint32_t wlo = ca | (cb << 21), whi = (cb >> 11) | 0x80000000u, mhi = 0x800003FFu;
+        const uint32_t d0 = (v1.x ^ wlo) | ((v1.y & mhi) ^ whi), d1 = (v1.z ^ wlo) | ((v1.w & mhi) ^ whi);
+        const uint32_t d2 = (v2.x ^ wlo) | ((v2.y & mhi) ^ whi), d3 = (v2.z ^ wlo) | ((v2.w & mhi) ^ whi);
+        const uint32_t hit = (d0 == 0 ? v1.y : 0u) | (d1 == 0 ? v1.w : 0u) | (d2 == 0 ? v2.y : 0u) | (d3 == 0 ? v2.w : 0u);
+        return hit ? (int32_t)((hit >> 10) & 0x1FFFFFu) : TKZ_RANK_NONE;      // (a matching entry has its valid bit set: hit != 0)
     }
     if (v1.w != 0 && v1.x == a && v1.y == b) return (int32_t)v1.z;
     if (v2.w != 0 && v2.x == a && v2.y == b) return (int32_t)v2.z;
@@ -251,7 +259,7 @@ TKZ_HD int32_t tkz_match_pair(const TkzTables& T, uint32_t a, uint32_t b, uint4 
 TKZ_HD int32_t tkz_lookup_pair(const TkzTables& T, uint32_t a, uint32_t b) {
     uint32_t s1, s2;
     tkz_pair_slots(T, a, b, &s1, &s2);
-    return tkz_match_pair(T, a, b, tkz_load16(&T.pair_slots[s1]), tkz_load16(&T.pair_slots[s2]));
+    return tkz_match_pair(T, a, b, tkz_load_pair_slot(T, s1), tkz_load_pair_slot(T, s2));
 }
 
 // Encoder.TryGetValue(piece) for a piece of 29..max_key_len bytes; `at(i)` yields byte i of the piece.

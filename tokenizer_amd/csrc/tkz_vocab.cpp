@@ -385,6 +385,7 @@ int build_tables(Vocab* v, std::string* msg) {
         }
         if (done) break;
     }
+    if (v->pair_slots.size() >= (size_t(1) << 27)) { if (msg) *msg = "pair table too large (the kernels address it with 32-bit byte offsets)"; return TKZ_E_UNSUPPORTED; }
     // two-single-byte pairs, directly indexed by the BYTES (not ranks): first-level lookups
     for (int a = 0; a < 256; ++a)
         for (int b = 0; b < 256; ++b) {

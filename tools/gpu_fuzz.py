@@ -1,5 +1,5 @@
 """Soak test on the GPU: random batches (wide Unicode mix, adversarial small alphabets, long single-class runs, corpus kinds)
-through tkz_encode_batch_utf8 against the oracle, all three patterns, for a fixed wall-clock budget.  usage: gpu_fuzz.py [seconds] [seed]"""
+through tkz_encode_batch_utf8 against the oracle, all four patterns (both readings of the o200k string), for a fixed wall-clock budget.  usage: gpu_fuzz.py [seconds] [seed]"""
 import gzip, os, random, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,13 +14,13 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "gpt2.tiktoken.gz"), "rb").read())
 vocab, ovocab = N.Vocab(raw), O.Vocab(raw)
-encs = {p: N.Encoder(vocab, p) for p in (1, 2, 3)}
+encs = {p: N.Encoder(vocab, p) for p in (1, 2, 3, 4)}
 alpha = RC.alphabet()
 rng = random.Random(seed)
 kinds = ["mix", "runs"] + list(parity.SMALL_ALPHAS)
 t0 = time.time(); rounds = 0; total = 0
 while time.time() - t0 < budget:
-    pattern = rng.choice((1, 2, 3))
+    pattern = rng.choice((1, 2, 3, 4))
     k = rng.random()
     if k < 0.25:
         kind = rng.choice((1, 2, 3)); n = rng.choice((1, 50, 2000)); lo = rng.choice((0, 16, 256, 20000)); hi = lo + rng.choice((1, 100, 512, 9000))

@@ -4,7 +4,7 @@ kernels (default) or on the GPU (--gpu).  Alphabets are chosen so that every flo
 transitions through runs of Lo/Lm/M chars, marks after punctuation, swallowed '/' runs, contraction suffixes, supplementary-plane
 letters, digits and symbols, JS white space.  Prints how many 4 KiB blocks each scanner handed on.
 
-    python tools/o200k_scan_fuzz.py [--gpu] [--kinds cjk,case,...] [--seeds N]
+    python tools/o200k_scan_fuzz.py [--gpu] [--pattern 3|4] [--kinds cjk,case,...] [--seeds N]
 """
 import argparse
 import gzip
@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--kinds", default="cjk,case,mark,emoji,slash,chain,upper,all")
     ap.add_argument("--seeds", type=int, default=5)
     ap.add_argument("--first-seed", type=int, default=0)
+    ap.add_argument("--pattern", type=int, default=3, help="3: the ECMAScript reading of the o200k string (code points), 4: .NET's (code units)")
     args = ap.parse_args()
     import oracle as O
     import parity
@@ -37,7 +38,7 @@ def main():
         lib = emu.library()
     raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "gpt2.tiktoken.gz"), "rb").read())
     vocab = N.Vocab(raw, lib) if lib else N.Vocab(raw)
-    enc = N.Encoder(vocab, N.O200K)
+    enc = N.Encoder(vocab, args.pattern)
     for kind in args.kinds.split(","):
         ta = tb = tblk = 0
         for seed in range(args.first_seed, args.first_seed + args.seeds):
@@ -45,7 +46,7 @@ def main():
             docs = [gen(rng, ALPHAS[kind], rng.choice([3000, 9000, 20000])).encode("utf-8") for _ in range(rng.choice([1, 2, 5]))]
             data, offs = parity.pack(docs)
             got = enc.pretokenize(data, offs)
-            exp = parity.oracle_bitmap(O, N.O200K, docs)
+            exp = parity.oracle_bitmap(O, args.pattern, docs)
             a, b = enc.pretok_leftovers()
             ta += a
             tb += b
@@ -60,7 +61,7 @@ def main():
             why = "  refusals by rule: " + " ".join("%d:%d" % (i, arr[i]) for i in range(32) if arr[i])
             for i in range(32):
                 arr[i] = 0
-        print("%-6s ok: %d blocks, %d left by the ASCII scanner, %d of them left by the multi-byte scanner%s" % (kind, tblk, ta, tb, why))
+        print("pattern %d %-6s ok: %d blocks, %d left by the ASCII scanner, %d of them left by the multi-byte scanner%s" % (args.pattern, kind, tblk, ta, tb, why))
     return 0
 
 
