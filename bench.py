@@ -359,10 +359,10 @@ def main():
                                     "MISMATCH vs oracle: %d of %d docs differ, first %d" % (bad, n_docs, first_bad)
             del enc_h
             torch.cuda.empty_cache()
-            ntok = step()                      # (the output buffers hold the headline vocabulary's ids again: the parity check below reads them)
-            fence()
         except Exception as ex:
             heldout = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        ntok = step()                          # (the output buffers and the gathered counts are the headline vocabulary's again: the checks below read them)
+        fence()
     if warm is not None:
         del warm, w_bytes, w_offs, w_ids
         torch.cuda.empty_cache()
