@@ -14,6 +14,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -78,7 +79,7 @@ public:
     std::vector<int32_t> text(int64_t t) const { return std::vector<int32_t>(ids_ + offsets_[t], ids_ + offsets_[t + 1]); }
 private:
     friend class TikTokenizer;
-    PinnedBuffer in_bytes_, in_offs_, out_ids_, out_offs_;
+    PinnedBuffer in_bytes_, in_offs_, sub_offs_, out_ids_, out_offs_;
     std::vector<int32_t> spliced_ids_; std::vector<int64_t> spliced_offs_;     // (only when special tokens were spliced in)
     const int32_t* ids_ = nullptr; const int64_t* offsets_ = nullptr; int64_t n_texts_ = 0;
     double tokens_per_byte_ = 0;                                               // the densest batch seen: sizes the id buffer of the next one
@@ -170,35 +171,69 @@ public:
         for (int64_t i = 0; i < nseg; ++i) offs[i + 1] = offs[i] + static_cast<int64_t>(segs[static_cast<size_t>(i)].second);
         const int64_t total = offs[nseg];
         uint8_t* bytes = static_cast<uint8_t*>(out.in_bytes_.ensure(static_cast<size_t>(total) + 64));
-        // 2. gather (a memcpy per segment; the ranges of the threads hold about the same number of bytes)
-        int nth = threads > 0 ? threads : static_cast<int>(std::min<int64_t>(8, total >> 22));
+        // 2. gather and encode, in sub-batches of ~128 MB: host threads gather sub-batch k + 1 (a memcpy per segment; the threads' ranges hold
+        //    about the same number of bytes) while libtkz uploads, encodes and downloads sub-batch k (tkz_encode_batch_utf8 overlaps those
+        //    three among its own chunks).  A token is at least one byte, English-like text has one per ~4: room for a token per two bytes
+        //    first; when that was not enough, room for a token per byte (always enough) and the calls again, and from then on.
+        static const int64_t kSubBytes = [] { const char* v = std::getenv("TKZ_FLAT_SUBBATCH_BYTES"); const long long n = v ? std::atoll(v) : 0; return n > 0 ? static_cast<int64_t>(n) : (int64_t(128) << 20); }();
+        const int nsb = total >= 2 * kSubBytes ? static_cast<int>(std::min<int64_t>(64, total / kSubBytes)) : 1;
+        std::vector<int64_t> cut(static_cast<size_t>(nsb) + 1, 0);
+        cut[static_cast<size_t>(nsb)] = nseg;
+        for (int k = 1; k < nsb; ++k) cut[static_cast<size_t>(k)] = std::lower_bound(offs, offs + nseg, total / nsb * k) - offs;
+        int nth = threads > 0 ? threads : static_cast<int>(std::min<int64_t>(16, (total / nsb) >> 22));
         const unsigned hw = std::thread::hardware_concurrency();
         if (hw && nth > static_cast<int>(hw)) nth = static_cast<int>(hw);
-        auto gather = [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) std::memcpy(bytes + offs[i], segs[static_cast<size_t>(i)].first, segs[static_cast<size_t>(i)].second); };
-        if (nth <= 1) gather(0, nseg);
-        else {
+        // the offsets of sub-batch k, starting at 0 as the entry point wants them: sub[cut[k] + k .. cut[k + 1] + k]
+        int64_t* sub = nsb > 1 ? static_cast<int64_t*>(out.sub_offs_.ensure((static_cast<size_t>(nseg) + static_cast<size_t>(nsb) + 1) * 8)) : offs;
+        auto gather = [&](int64_t lo, int64_t hi, int k) {
+            const int64_t b0 = offs[cut[static_cast<size_t>(k)]];
+            for (int64_t i = lo; i < hi; ++i) {
+                std::memcpy(bytes + offs[i], segs[static_cast<size_t>(i)].first, segs[static_cast<size_t>(i)].second);
+                if (nsb > 1) sub[i + k] = offs[i] - b0;
+            }
+        };
+        auto start_gather = [&](int k) -> std::vector<std::thread> {
             std::vector<std::thread> pool;
-            int64_t lo = 0;
-            for (int k = 1; k <= nth; ++k) {
-                const int64_t hi = k == nth ? nseg : std::lower_bound(offs, offs + nseg, total / nth * k) - offs;
-                pool.emplace_back(gather, lo, hi);
+            const int64_t lo0 = cut[static_cast<size_t>(k)], hi0 = cut[static_cast<size_t>(k) + 1], b0 = offs[lo0], nb = offs[hi0] - b0;
+            if (nsb > 1) sub[hi0 + k] = nb;
+            if (nth <= 1) { gather(lo0, hi0, k); return pool; }
+            int64_t lo = lo0;
+            for (int t = 1; t <= nth; ++t) {
+                const int64_t hi = t == nth ? hi0 : std::lower_bound(offs + lo0, offs + hi0, b0 + nb / nth * t) - offs;
+                pool.emplace_back(gather, lo, hi, k);
                 lo = hi;
             }
-            for (std::thread& th : pool) th.join();
-        }
-        // 3. one call; a token is at least one byte, English-like text has one per ~4: room for a token per two bytes first, the exact need
-        //    (the call reports it) when that was not enough, and from then on
+            return pool;
+        };
+        auto join = [](std::vector<std::thread>& pool) { for (std::thread& th : pool) th.join(); pool.clear(); };
         int64_t* ooff = static_cast<int64_t*>(out.out_offs_.ensure((static_cast<size_t>(nseg) + 1) * 8));
-        int64_t cap = std::max<int64_t>(1, std::min<int64_t>(total, std::max<int64_t>(total / 2 + 4096, static_cast<int64_t>(static_cast<double>(total) * out.tokens_per_byte_ * 1.1))));
         int32_t* ids = nullptr;
-        for (;;) {
+        std::vector<char> gathered(static_cast<size_t>(nsb), 0);
+        bool full = false;
+        for (int attempt = 0;; ++attempt) {
+            const int64_t cap = full ? std::max<int64_t>(1, total)
+                                     : std::max<int64_t>(1, std::min<int64_t>(total, std::max<int64_t>(total / 2 + 4096, static_cast<int64_t>(static_cast<double>(total) * out.tokens_per_byte_ * 1.1))));
             ids = static_cast<int32_t*>(out.out_ids_.ensure(static_cast<size_t>(cap) * 4));
-            int64_t needed = 0;
-            const tkz_status st = tkz_encode_batch_utf8(enc_, bytes, offs, nseg, ids, cap, ooff, &needed);
-            if (st == TKZ_E_CAPACITY && needed > cap) { cap = needed; out.tokens_per_byte_ = std::max(out.tokens_per_byte_, static_cast<double>(needed) / static_cast<double>(total)); continue; }
-            check(st);
-            break;
+            int64_t tok_base = 0;
+            bool over = false;
+            std::vector<std::thread> pool;
+            if (!gathered[0]) { pool = start_gather(0); join(pool); gathered[0] = 1; }
+            for (int k = 0; k < nsb; ++k) {
+                if (k + 1 < nsb && !gathered[static_cast<size_t>(k) + 1]) { pool = start_gather(k + 1); gathered[static_cast<size_t>(k) + 1] = 1; }
+                const int64_t d0 = cut[static_cast<size_t>(k)], nd = cut[static_cast<size_t>(k) + 1] - d0;
+                int64_t needed = 0;
+                const tkz_status st = tkz_encode_batch_utf8(enc_, bytes + offs[d0], nsb > 1 ? sub + d0 + k : offs, nd, ids + tok_base, cap - tok_base, ooff + d0, &needed);
+                join(pool);
+                if (st == TKZ_E_CAPACITY) { over = true; break; }
+                check(st);
+                if (tok_base) for (int64_t i = d0; i <= d0 + nd; ++i) ooff[i] += tok_base;
+                tok_base += needed;
+            }
+            if (!over) break;
+            if (attempt || cap >= total) check(TKZ_E_CAPACITY);                      // (cannot happen: a token per byte is always enough)
+            full = true;
         }
+        if (total > 0) out.tokens_per_byte_ = std::max(out.tokens_per_byte_, static_cast<double>(ooff[nseg]) / static_cast<double>(total));
         out.n_texts_ = static_cast<int64_t>(texts.size());
         if (plain) { out.ids_ = ids; out.offsets_ = ooff; return; }
         // 4. splice the special ids in between the segments' id ranges

@@ -53,8 +53,10 @@ int main(int argc, char** argv) {
         REQUIRE(fb.n_texts() == 0 && fb.n_ids() == 0);
         // text that is one token per byte (no merges in the table for these): the first guess of the id buffer is too small, the call is repeated
         const std::string dense(20000, '\x01');
-        tok.EncodeBatchFlat({dense, dense}, fb, false);
-        REQUIRE(fb.text(0) == tok.Encode(dense, false) && fb.text(1) == fb.text(0));
+        tok.EncodeBatchFlat({dense, dense, dense, dense}, fb, false);       // (with TKZ_FLAT_SUBBATCH_BYTES = 30000: two sub-batches, the second attempt in both)
+        REQUIRE(fb.text(0) == tok.Encode(dense, false) && fb.text(1) == fb.text(0) && fb.text(3) == fb.text(0) && fb.n_ids() == 80000);
+        tok.EncodeBatchFlat({"Hello World"}, fb, false);                    // (a sparse batch after a dense one: the buffers are simply large enough)
+        REQUIRE(fb.text(0) == hw);
     }
     {
         const std::u16string lone = {u'a', char16_t(0xD83D)}, pair = {char16_t(0xD83D), char16_t(0xDE00), u'b'}, half = {char16_t(0xDE00), u'c'};

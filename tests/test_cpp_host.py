@@ -15,10 +15,13 @@ def _build_and_run(tmp_path, libdir, libname):
     exe = str(tmp_path / "test_tokenizer")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_tokenizer.cpp"),
                            "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-o", exe])
-    out = subprocess.run([exe, str(vocab), os.path.join(GOLDEN, "lib.rs.txt"), os.path.join(GOLDEN, "tokens_gpt2.json")],
-                         capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout + out.stderr
-    assert "cpp host mirror ok" in out.stdout
+    # once as it ships, once with EncodeBatchFlat's sub-batches cut at 30 KB (128 MB in production: the gather of one sub-batch overlaps the
+    # device work of the one before it)
+    for env in (None, dict(os.environ, TKZ_FLAT_SUBBATCH_BYTES="30000")):
+        out = subprocess.run([exe, str(vocab), os.path.join(GOLDEN, "lib.rs.txt"), os.path.join(GOLDEN, "tokens_gpt2.json")],
+                             capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "cpp host mirror ok" in out.stdout
 
 
 def ids_checksum(ids):
@@ -55,10 +58,11 @@ def test_host_api_bench_driver_on_emulated_kernels(tmp_path):
         f.write(np.int64(len(docs)).tobytes()); f.write(offs.astype(np.int64).tobytes()); f.write(data.tobytes())
     ids, _ = N.Encoder(N.Vocab(raw, lib), N.CL100K).encode_batch(data, offs)
     exe = build_host_api_bench(tmp_path, os.path.dirname(emu.EMU_LIB), "tkz_hostemu")
-    out = subprocess.run([exe, str(tmp_path / "v.tiktoken"), str(tmp_path / "regex.txt"), str(tmp_path / "sample.bin"), "2"], capture_output=True, text=True)
-    assert out.returncode == 0, out.stdout + out.stderr
-    r = json.loads(out.stdout)
-    assert r["docs"] == 150 and r["bytes"] == len(data) and r["tokens"] == len(ids) and r["ids_checksum"] == ids_checksum(ids)
+    for env in (None, dict(os.environ, TKZ_FLAT_SUBBATCH_BYTES="9000")):          # (in one call; in three pipelined sub-batches)
+        out = subprocess.run([exe, str(tmp_path / "v.tiktoken"), str(tmp_path / "regex.txt"), str(tmp_path / "sample.bin"), "2"], capture_output=True, text=True, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        r = json.loads(out.stdout)
+        assert r["docs"] == 150 and r["bytes"] == len(data) and r["tokens"] == len(ids) and r["ids_checksum"] == ids_checksum(ids)
 
 
 def test_cpp_host_mirror_on_emulated_kernels(tmp_path):
