@@ -370,27 +370,57 @@ def main():
     # encoder): what keeping batches in flight buys over one synchronous call after the other -- a companion figure, never `value`
     dt_pipe = None
     pipe_note = None
-    if world == 1 and args.pipelined_steps > 0 and args.kind != 5:
+    if args.pipelined_steps > 0 and args.kind != 5:
+        # every batch in flight has its own {docs, bytes, tokens} block (tkz_encode_batch_device_begin_counts) and its own gathered table: the
+        # count all-gather of a batch is enqueued on that batch's stream behind its _end, at any N.  The untimed pass (the second workspace
+        # takes its size) runs WITHOUT the collective, and the ranks agree that every one of them got through it before any enters a
+        # gather: a rank that could not allocate must not leave the others waiting inside RCCL.
+        pair = None
+        ok_local = 0
         try:
             s2 = torch.cuda.Stream()
             d_ids2 = torch.empty_like(d_ids); d_ooffs2 = torch.empty_like(d_ooffs)
-            outs = [(d_ids, d_ooffs, stream), (d_ids2, d_ooffs2, s2.cuda_stream)]
+            d_cnt = torch.zeros(2, 3, dtype=torch.int64, device=dev)
+            d_tab = torch.zeros(2, world * 3, dtype=torch.int64, device=dev)
+            outs = [(d_ids, d_ooffs, stream, d_cnt[0], d_tab[0]), (d_ids2, d_ooffs2, s2.cuda_stream, d_cnt[1], d_tab[1])]
 
-            def pair():
-                hs = [enc.encode_batch_device_begin(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, o[0].data_ptr(), total, o[1].data_ptr(), o[2]) for o in outs]
-                return [enc.encode_batch_device_end(h) for h in hs]
-            assert pair() == [ntok, ntok]                      # (untimed: the second workspace takes its size)
+            def pair(gather=True):
+                hs = [enc.encode_batch_device_begin(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, o[0].data_ptr(), total, o[1].data_ptr(), o[2],
+                                                    d_counts3=o[3].data_ptr()) for o in outs]
+                res = []
+                for h, o in zip(hs, outs):
+                    res.append(enc.encode_batch_device_end(h))
+                    if comm is not None and gather:
+                        comm.gather_async(o[3].data_ptr(), o[2], d_table=o[4].data_ptr())
+                return res
+            ok_local = 1 if pair(gather=False) == [ntok, ntok] else 0
+            if not ok_local:
+                pipe_note = "the untimed pass gave another token count"
+        except Exception as ex:                                # (e.g. no room for a second workspace)
+            ok_local = 0
+            pipe_note = "%s: %s" % (type(ex).__name__, ex)
+        if world > 1:
+            t = torch.tensor([ok_local], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok_local = int(t.item())
+        if ok_local:
             fence()
             t0 = time.perf_counter()
             for _ in range((args.pipelined_steps + 1) // 2):
                 pair()
             fence()
             dt_pipe = (time.perf_counter() - t0) / (2 * ((args.pipelined_steps + 1) // 2))
+            if world > 1:
+                t = torch.tensor([dt_pipe], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_pipe = float(t.item())
             assert torch.equal(d_ids2[:ntok], d_ids[:ntok]) and torch.equal(d_ooffs2, d_ooffs)
+            assert d_cnt.cpu().tolist() == [[n_docs, total, ntok]] * 2
+            if comm is not None:
+                assert d_tab[0].cpu().tolist()[3 * rank:3 * rank + 3] == [n_docs, total, ntok] and torch.equal(d_tab[0], d_tab[1])
             del d_ids2, d_ooffs2
-        except Exception as ex:                                # (e.g. no room for a second workspace)
-            dt_pipe = None
-            pipe_note = "%s: %s" % (type(ex).__name__, ex)
+        elif pipe_note is None:
+            pipe_note = "skipped: the untimed pass failed on another rank"
     g = comm.result() if comm is not None else sharded.gather_counts(n_docs, total, ntok)
     n_tokens_rank = int(g["table"][rank][2])
     assert n_tokens_rank == ntok and int(g["table"][rank][0]) == n_docs and int(g["table"][rank][1]) == total
@@ -613,6 +643,7 @@ def main():
             "value_heldout_vocab": heldout["value"] if heldout and "value" in heldout else None,
             "heldout_vocab": heldout,
             "value_two_in_flight": round(job_bytes / dt_pipe / 1e6, 1) if dt_pipe else None,
+            "two_in_flight_note": pipe_note,
             "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
             "parity": parity_note,
             "roofline": roofline,
