@@ -499,6 +499,32 @@ def check_memo_contention(lib, O, vocab, ovocab, candidates=400_000, threads=2, 
     assert not errors, errors
 
 
+def check_host_alloc(lib, O, vocab, ovocab):
+    """tkz_host_alloc / tkz_host_free: page-locked buffers for the host-buffer entry points, used as input and output of a batch call."""
+    hp = [C.c_void_p() for _ in range(4)]
+    docs = [("doc %d: the quick brown fox, it's 2024!\n" % i).encode() * (1 + i % 7) for i in range(2000)]
+    data, offs = pack(docs)
+    sizes = [len(data) + 64, 8 * (len(docs) + 1), 4 * len(data), 8 * (len(docs) + 1)]
+    for h, n in zip(hp, sizes):
+        lib.check(lib.L.tkz_host_alloc(n, C.byref(h)))
+        assert h.value and h.value % 64 == 0
+    offs64 = np.ascontiguousarray(offs, np.int64)
+    C.memmove(hp[0], data.ctypes.data, len(data)); C.memmove(hp[1], offs64.ctypes.data, 8 * (len(docs) + 1))
+    enc = N.Encoder(vocab, N.CL100K)
+    needed = C.c_int64(0)
+    lib.check(lib.L.tkz_encode_batch_utf8(enc._h, hp[0], hp[1], len(docs), hp[2], len(data), hp[3], C.byref(needed)))
+    ids = np.ctypeslib.as_array(C.cast(hp[2], C.POINTER(C.c_int32)), (needed.value,)).copy()
+    ooff = np.ctypeslib.as_array(C.cast(hp[3], C.POINTER(C.c_int64)), (len(docs) + 1,)).copy()
+    exp, eoff = oracle_encode_docs(O.Encoder(ovocab, O.CL100K), docs)
+    assert ids.tolist() == exp and ooff.tolist() == eoff
+    for h in hp:
+        lib.L.tkz_host_free(h)
+    lib.L.tkz_host_free(None)
+    z = C.c_void_p()
+    lib.check(lib.L.tkz_host_alloc(0, C.byref(z)))          # (a zero-byte request still yields a pointer that can be freed)
+    lib.L.tkz_host_free(z)
+
+
 def check_device_unicode_table(lib, vocab):
     """The Unicode class table as the DEVICE holds it (downloaded through tkz_encoder_unicode_classes) against `unicodedata` 13.0, all
     1,114,112 code points: the oracle and the product share one generated table, so this -- not a comparison of the two -- is what would

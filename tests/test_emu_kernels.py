@@ -52,6 +52,10 @@ def test_pretok_vs_oracle(lib, vocab, oracle_mod, pattern, sequential):
                         doc_lens=[0, 1, 7, 63, 64, 65, 127, 128, 129, 200, 1000, 5000, 9000])
 
 
+def test_host_alloc_buffers(lib, vocab, oracle_mod, oracle_gpt2):
+    parity.check_host_alloc(lib, oracle_mod, vocab, oracle_gpt2)
+
+
 def test_device_unicode_table(lib, vocab):
     parity.check_device_unicode_table(lib, vocab)
 

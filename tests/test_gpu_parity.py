@@ -104,6 +104,10 @@ def test_o200k_multibyte_block_scanner(lib, vocab, oracle_mod, pattern):
     parity.check_o200k_no_sync_points(lib, oracle_mod, vocab, pattern)
 
 
+def test_host_alloc_buffers(lib, vocab, oracle_mod, oracle_gpt2):
+    parity.check_host_alloc(lib, oracle_mod, vocab, oracle_gpt2)
+
+
 def test_device_unicode_table(lib, vocab):
     parity.check_device_unicode_table(lib, vocab)
 
