@@ -13,6 +13,8 @@
 // KeyNotFoundException -> tkz::KeyNotFoundError, NotImplementedException -> tkz::NotImplementedError.
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -77,6 +79,8 @@ public:
     int64_t n_texts() const { return n_texts_; }
     int64_t n_ids() const { return n_texts_ >= 0 && offsets_ ? offsets_[n_texts_] : 0; }
     std::vector<int32_t> text(int64_t t) const { return std::vector<int32_t>(ids_ + offsets_[t], ids_ + offsets_[t + 1]); }
+    // where the last call's time went, in milliseconds: the offsets pass, waiting for gathered sub-batches, inside tkz_encode_batch_utf8
+    double last_offsets_ms = 0, last_wait_ms = 0, last_encode_ms = 0;
 private:
     friend class TikTokenizer;
     PinnedBuffer in_bytes_, in_offs_, sub_offs_, out_ids_, out_offs_;
@@ -150,93 +154,27 @@ public:
     }
     void EncodeBatchFlat(const std::vector<std::string>& texts, const std::vector<std::string>& allowedSpecial, FlatBatch& out, int threads = 0) const {
         const bool plain = allowedSpecial.empty() || specials_.empty();
-        // 1. what goes to the device: (source pointer, length) of every plain segment, and where the special ids go
+        out.n_texts_ = static_cast<int64_t>(texts.size());
+        if (plain) {                                           // one segment per text, the texts themselves
+            encode_segments(static_cast<int64_t>(texts.size()), [&](int64_t i) { return std::pair<const char*, size_t>(texts[static_cast<size_t>(i)].data(), texts[static_cast<size_t>(i)].size()); }, out, threads);
+            out.ids_ = out.out_ids_.as<int32_t>(); out.offsets_ = out.out_offs_.as<int64_t>();
+            return;
+        }
+        // what goes to the device: (source pointer, length) of every plain segment, and where the special ids go
         struct Item { size_t text; int32_t special; int64_t segment; };
         std::vector<Item> plan;
         std::vector<std::pair<const char*, size_t>> segs;
-        if (plain) {
-            segs.reserve(texts.size());
-            for (const std::string& t : texts) segs.emplace_back(t.data(), t.size());
-        } else {
-            for (size_t t = 0; t < texts.size(); ++t)
-                for (const Segment& g : segments(texts[t], allowedSpecial)) {
-                    if (g.special) { plan.push_back({t, g.id, -1}); continue; }
-                    plan.push_back({t, 0, static_cast<int64_t>(segs.size())});
-                    segs.emplace_back(texts[t].data() + g.begin, g.end - g.begin);
-                }
-        }
+        for (size_t t = 0; t < texts.size(); ++t)
+            for (const Segment& g : segments(texts[t], allowedSpecial)) {
+                if (g.special) { plan.push_back({t, g.id, -1}); continue; }
+                plan.push_back({t, 0, static_cast<int64_t>(segs.size())});
+                segs.emplace_back(texts[t].data() + g.begin, g.end - g.begin);
+            }
         const int64_t nseg = static_cast<int64_t>(segs.size());
-        int64_t* offs = static_cast<int64_t*>(out.in_offs_.ensure((static_cast<size_t>(nseg) + 1) * 8));
-        offs[0] = 0;
-        for (int64_t i = 0; i < nseg; ++i) offs[i + 1] = offs[i] + static_cast<int64_t>(segs[static_cast<size_t>(i)].second);
-        const int64_t total = offs[nseg];
-        uint8_t* bytes = static_cast<uint8_t*>(out.in_bytes_.ensure(static_cast<size_t>(total) + 64));
-        // 2. gather and encode, in sub-batches of ~128 MB: host threads gather sub-batch k + 1 (a memcpy per segment; the threads' ranges hold
-        //    about the same number of bytes) while libtkz uploads, encodes and downloads sub-batch k (tkz_encode_batch_utf8 overlaps those
-        //    three among its own chunks).  A token is at least one byte, English-like text has one per ~4: room for a token per two bytes
-        //    first; when that was not enough, room for a token per byte (always enough) and the calls again, and from then on.
-        static const int64_t kSubBytes = [] { const char* v = std::getenv("TKZ_FLAT_SUBBATCH_BYTES"); const long long n = v ? std::atoll(v) : 0; return n > 0 ? static_cast<int64_t>(n) : (int64_t(128) << 20); }();
-        const int nsb = total >= 2 * kSubBytes ? static_cast<int>(std::min<int64_t>(64, total / kSubBytes)) : 1;
-        std::vector<int64_t> cut(static_cast<size_t>(nsb) + 1, 0);
-        cut[static_cast<size_t>(nsb)] = nseg;
-        for (int k = 1; k < nsb; ++k) cut[static_cast<size_t>(k)] = std::lower_bound(offs, offs + nseg, total / nsb * k) - offs;
-        int nth = threads > 0 ? threads : static_cast<int>(std::min<int64_t>(16, (total / nsb) >> 22));
-        const unsigned hw = std::thread::hardware_concurrency();
-        if (hw && nth > static_cast<int>(hw)) nth = static_cast<int>(hw);
-        // the offsets of sub-batch k, starting at 0 as the entry point wants them: sub[cut[k] + k .. cut[k + 1] + k]
-        int64_t* sub = nsb > 1 ? static_cast<int64_t*>(out.sub_offs_.ensure((static_cast<size_t>(nseg) + static_cast<size_t>(nsb) + 1) * 8)) : offs;
-        auto gather = [&](int64_t lo, int64_t hi, int k) {
-            const int64_t b0 = offs[cut[static_cast<size_t>(k)]];
-            for (int64_t i = lo; i < hi; ++i) {
-                std::memcpy(bytes + offs[i], segs[static_cast<size_t>(i)].first, segs[static_cast<size_t>(i)].second);
-                if (nsb > 1) sub[i + k] = offs[i] - b0;
-            }
-        };
-        auto start_gather = [&](int k) -> std::vector<std::thread> {
-            std::vector<std::thread> pool;
-            const int64_t lo0 = cut[static_cast<size_t>(k)], hi0 = cut[static_cast<size_t>(k) + 1], b0 = offs[lo0], nb = offs[hi0] - b0;
-            if (nsb > 1) sub[hi0 + k] = nb;
-            if (nth <= 1) { gather(lo0, hi0, k); return pool; }
-            int64_t lo = lo0;
-            for (int t = 1; t <= nth; ++t) {
-                const int64_t hi = t == nth ? hi0 : std::lower_bound(offs + lo0, offs + hi0, b0 + nb / nth * t) - offs;
-                pool.emplace_back(gather, lo, hi, k);
-                lo = hi;
-            }
-            return pool;
-        };
-        auto join = [](std::vector<std::thread>& pool) { for (std::thread& th : pool) th.join(); pool.clear(); };
-        int64_t* ooff = static_cast<int64_t*>(out.out_offs_.ensure((static_cast<size_t>(nseg) + 1) * 8));
-        int32_t* ids = nullptr;
-        std::vector<char> gathered(static_cast<size_t>(nsb), 0);
-        bool full = false;
-        for (int attempt = 0;; ++attempt) {
-            const int64_t cap = full ? std::max<int64_t>(1, total)
-                                     : std::max<int64_t>(1, std::min<int64_t>(total, std::max<int64_t>(total / 2 + 4096, static_cast<int64_t>(static_cast<double>(total) * out.tokens_per_byte_ * 1.1))));
-            ids = static_cast<int32_t*>(out.out_ids_.ensure(static_cast<size_t>(cap) * 4));
-            int64_t tok_base = 0;
-            bool over = false;
-            std::vector<std::thread> pool;
-            if (!gathered[0]) { pool = start_gather(0); join(pool); gathered[0] = 1; }
-            for (int k = 0; k < nsb; ++k) {
-                if (k + 1 < nsb && !gathered[static_cast<size_t>(k) + 1]) { pool = start_gather(k + 1); gathered[static_cast<size_t>(k) + 1] = 1; }
-                const int64_t d0 = cut[static_cast<size_t>(k)], nd = cut[static_cast<size_t>(k) + 1] - d0;
-                int64_t needed = 0;
-                const tkz_status st = tkz_encode_batch_utf8(enc_, bytes + offs[d0], nsb > 1 ? sub + d0 + k : offs, nd, ids + tok_base, cap - tok_base, ooff + d0, &needed);
-                join(pool);
-                if (st == TKZ_E_CAPACITY) { over = true; break; }
-                check(st);
-                if (tok_base) for (int64_t i = d0; i <= d0 + nd; ++i) ooff[i] += tok_base;
-                tok_base += needed;
-            }
-            if (!over) break;
-            if (attempt || cap >= total) check(TKZ_E_CAPACITY);                      // (cannot happen: a token per byte is always enough)
-            full = true;
-        }
-        if (total > 0) out.tokens_per_byte_ = std::max(out.tokens_per_byte_, static_cast<double>(ooff[nseg]) / static_cast<double>(total));
-        out.n_texts_ = static_cast<int64_t>(texts.size());
-        if (plain) { out.ids_ = ids; out.offsets_ = ooff; return; }
-        // 4. splice the special ids in between the segments' id ranges
+        encode_segments(nseg, [&](int64_t i) { return segs[static_cast<size_t>(i)]; }, out, threads);
+        const int32_t* ids = out.out_ids_.as<int32_t>();
+        const int64_t* ooff = out.out_offs_.as<int64_t>();
+        // splice the special ids in between the segments' id ranges
         size_t nspecial = 0;
         for (const Item& it : plan) if (it.segment < 0) ++nspecial;
         out.spliced_ids_.resize(static_cast<size_t>(ooff[nseg]) + nspecial);
@@ -379,6 +317,91 @@ private:
             ++k;
         }
         return out;
+    }
+    // The work of EncodeBatchFlat on nseg segments, seg_at(i) = (pointer, length) of segment i: the ids land in out.out_ids_, the offsets
+    // (nseg + 1) in out.out_offs_.  Everything that touches every segment runs on `threads` host threads (0: one per ~16 k segments, at most
+    // 16): the segment offsets (a two-pass prefix sum) and the gather into page-locked memory.  The gather is cut into sub-batches of ~128 MB
+    // and runs AHEAD of the device: the workers go through the sub-batches in order without waiting for anything, the calling thread hands
+    // sub-batch k to tkz_encode_batch_utf8 (which overlaps upload, kernels and download among its own chunks) as soon as it is gathered.
+    // A token is at least one byte, English-like text has one per ~4: room for a token per two bytes first; when that was not enough, room
+    // for a token per byte (always enough) and the calls again.
+    struct Joiner { std::vector<std::thread> pool; ~Joiner() { for (std::thread& t : pool) if (t.joinable()) t.join(); } };
+    template <class SegAt>
+    void encode_segments(int64_t nseg, SegAt seg_at, FlatBatch& out, int threads) const {
+        int nth = threads > 0 ? threads : static_cast<int>(std::min<int64_t>(16, nseg >> 14));
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && nth > static_cast<int>(hw)) nth = static_cast<int>(hw);
+        if (nth < 1) nth = 1;
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+        int64_t* offs = static_cast<int64_t*>(out.in_offs_.ensure((static_cast<size_t>(nseg) + 1) * 8));
+        auto slice = [&](int t) { return nseg * t / nth; };      // thread t owns segments [slice(t), slice(t + 1)) of every pass over the segments
+        // 1. offsets: every thread sums its slice, then writes its offsets from the sum of the slices before it
+        offs[0] = 0;
+        if (nth == 1) { for (int64_t i = 0; i < nseg; ++i) offs[i + 1] = offs[i] + static_cast<int64_t>(seg_at(i).second); }
+        else {
+            std::vector<int64_t> part(static_cast<size_t>(nth) + 1, 0);
+            { Joiner j; for (int t = 0; t < nth; ++t) j.pool.emplace_back([&, t] { int64_t sum = 0; for (int64_t i = slice(t); i < slice(t + 1); ++i) sum += static_cast<int64_t>(seg_at(i).second); part[static_cast<size_t>(t) + 1] = sum; }); }
+            for (int t = 0; t < nth; ++t) part[static_cast<size_t>(t) + 1] += part[static_cast<size_t>(t)];
+            { Joiner j; for (int t = 0; t < nth; ++t) j.pool.emplace_back([&, t] { int64_t at = part[static_cast<size_t>(t)]; for (int64_t i = slice(t); i < slice(t + 1); ++i) { at += static_cast<int64_t>(seg_at(i).second); offs[i + 1] = at; } }); }
+        }
+        const int64_t total = offs[nseg];
+        out.last_offsets_ms = ms_since(t_begin); out.last_wait_ms = out.last_encode_ms = 0;
+        uint8_t* bytes = static_cast<uint8_t*>(out.in_bytes_.ensure(static_cast<size_t>(total) + 64));
+        // 2. sub-batches
+        static const int64_t kSubBytes = [] { const char* v = std::getenv("TKZ_FLAT_SUBBATCH_BYTES"); const long long n = v ? std::atoll(v) : 0; return n > 0 ? static_cast<int64_t>(n) : (int64_t(128) << 20); }();
+        const int nsb = total >= 2 * kSubBytes ? static_cast<int>(std::min<int64_t>(64, total / kSubBytes)) : 1;
+        std::vector<int64_t> cut(static_cast<size_t>(nsb) + 1, 0);
+        cut[static_cast<size_t>(nsb)] = nseg;
+        for (int k = 1; k < nsb; ++k) cut[static_cast<size_t>(k)] = std::lower_bound(offs, offs + nseg, total / nsb * k) - offs;
+        // the offsets of sub-batch k, starting at 0 as the entry point wants them: sub[cut[k] + k .. cut[k + 1] + k]
+        int64_t* sub = nsb > 1 ? static_cast<int64_t*>(out.sub_offs_.ensure((static_cast<size_t>(nseg) + static_cast<size_t>(nsb) + 1) * 8)) : offs;
+        std::vector<std::atomic<int>> done(static_cast<size_t>(nsb));
+        for (auto& d : done) d.store(0, std::memory_order_relaxed);
+        auto gather_slice = [&](int k, int t) {                  // thread t's share of sub-batch k: about the same number of bytes for every thread
+            const int64_t lo0 = cut[static_cast<size_t>(k)], hi0 = cut[static_cast<size_t>(k) + 1], b0 = offs[lo0], nb = offs[hi0] - b0;
+            const int64_t lo = t == 0 ? lo0 : std::lower_bound(offs + lo0, offs + hi0, b0 + nb / nth * t) - offs;
+            const int64_t hi = t == nth - 1 ? hi0 : std::lower_bound(offs + lo0, offs + hi0, b0 + nb / nth * (t + 1)) - offs;
+            for (int64_t i = lo; i < hi; ++i) {
+                const std::pair<const char*, size_t> g = seg_at(i);
+                std::memcpy(bytes + offs[i], g.first, g.second);
+                if (nsb > 1) sub[i + k] = offs[i] - b0;
+            }
+            if (nsb > 1 && t == nth - 1) sub[hi0 + k] = nb;
+        };
+        Joiner workers;
+        if (nth == 1 && nsb == 1) { gather_slice(0, 0); done[0].store(1, std::memory_order_release); }
+        else for (int t = 0; t < nth; ++t)
+            workers.pool.emplace_back([&, t] { for (int k = 0; k < nsb; ++k) { gather_slice(k, t); done[static_cast<size_t>(k)].fetch_add(1, std::memory_order_release); } });
+        const int need = (nth == 1 && nsb == 1) ? 1 : nth;
+        // 3. encode
+        int64_t* ooff = static_cast<int64_t*>(out.out_offs_.ensure((static_cast<size_t>(nseg) + 1) * 8));
+        bool full = false;
+        for (int attempt = 0;; ++attempt) {
+            const int64_t cap = full ? std::max<int64_t>(1, total)
+                                     : std::max<int64_t>(1, std::min<int64_t>(total, std::max<int64_t>(total / 2 + 4096, static_cast<int64_t>(static_cast<double>(total) * out.tokens_per_byte_ * 1.1))));
+            int32_t* ids = static_cast<int32_t*>(out.out_ids_.ensure(static_cast<size_t>(cap) * 4));
+            int64_t tok_base = 0;
+            bool over = false;
+            for (int k = 0; k < nsb && !over; ++k) {
+                const auto t_w = std::chrono::steady_clock::now();
+                while (done[static_cast<size_t>(k)].load(std::memory_order_acquire) < need) std::this_thread::yield();
+                out.last_wait_ms += ms_since(t_w);
+                const auto t_e = std::chrono::steady_clock::now();
+                const int64_t d0 = cut[static_cast<size_t>(k)], nd = cut[static_cast<size_t>(k) + 1] - d0;
+                int64_t needed = 0;
+                const tkz_status st = tkz_encode_batch_utf8(enc_, bytes + offs[d0], nsb > 1 ? sub + d0 + k : offs, nd, ids + tok_base, cap - tok_base, ooff + d0, &needed);
+                out.last_encode_ms += ms_since(t_e);
+                if (st == TKZ_E_CAPACITY) { over = true; break; }
+                check(st);
+                if (tok_base) for (int64_t i = d0; i <= d0 + nd; ++i) ooff[i] += tok_base;
+                tok_base += needed;
+            }
+            if (!over) break;
+            if (attempt || cap >= total) check(TKZ_E_CAPACITY);                      // (cannot happen: a token per byte is always enough)
+            full = true;
+        }
+        if (total > 0) out.tokens_per_byte_ = std::max(out.tokens_per_byte_, static_cast<double>(ooff[nseg]) / static_cast<double>(total));
     }
     int match_at(const std::string& text, size_t p) const {       // first registered literal that matches at p
         for (size_t i = 0; i < specials_.size(); ++i) {

@@ -37,20 +37,20 @@ int main(int argc, char** argv) {
         tkz::TikTokenizer tok(vocab, {}, regex);
         tkz::FlatBatch fb;
         tok.EncodeBatchFlat(texts, fb, false, threads);                 // untimed: the page-locked buffers and the encoder's staging take their size
-        double best = 0;
+        double best = 0, b_off = 0, b_wait = 0, b_enc = 0;
         const int reps = 3;
         for (int r = 0; r < reps; ++r) {
             const auto t0 = std::chrono::steady_clock::now();
             tok.EncodeBatchFlat(texts, fb, false, threads);
             const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            best = std::max(best, static_cast<double>(total) / s / 1e6);
+            if (static_cast<double>(total) / s / 1e6 > best) { best = static_cast<double>(total) / s / 1e6; b_off = fb.last_offsets_ms; b_wait = fb.last_wait_ms; b_enc = fb.last_encode_ms; }
         }
         // a position-weighted sum of the ids mod 2^64 (numpy computes the same in one expression): bench.py compares it with the device path's
         uint64_t sum = 0;
         for (int64_t i = 0; i < fb.n_ids(); ++i) sum += (static_cast<uint64_t>(static_cast<uint32_t>(fb.ids()[i])) + 1) * (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull + 1);
-        std::printf("{\"value\": %.1f, \"unit\": \"MB/s\", \"docs\": %lld, \"bytes\": %lld, \"tokens\": %lld, \"ids_checksum\": \"%016llx\", \"gather_threads\": %d, \"reps\": %d}\n",
+        std::printf("{\"value\": %.1f, \"unit\": \"MB/s\", \"docs\": %lld, \"bytes\": %lld, \"tokens\": %lld, \"ids_checksum\": \"%016llx\", \"gather_threads\": %d, \"reps\": %d, \"ms\": {\"call\": %.2f, \"offsets_pass\": %.2f, \"waiting_for_gather\": %.2f, \"in_tkz_encode_batch_utf8\": %.2f}}\n",
                     best, static_cast<long long>(texts.size()), static_cast<long long>(total), static_cast<long long>(fb.n_ids()),
-                    static_cast<unsigned long long>(sum), threads, reps);
+                    static_cast<unsigned long long>(sum), threads, reps, static_cast<double>(total) / best / 1e3, b_off, b_wait, b_enc);
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "bench_host_api: %s\n", ex.what());
         return 1;
