@@ -40,3 +40,4 @@ if has latency; then timeout 300 python tools/latency_probe.py > $O/latency.json
 if has fuzz; then timeout 200 python tools/gpu_fuzz.py 60 > $O/fuzz.log 2>&1; echo "fuzz rc=$?"; tail -2 $O/fuzz.log; fi
 if has o2fuzz; then ( timeout 300 python tools/o200k_scan_fuzz.py --gpu --pattern 4 --seeds 40 --first-seed 200; timeout 200 python tools/o200k_scan_fuzz.py --gpu --pattern 3 --seeds 20 --first-seed 300 ) > $O/o200k_fuzz.log 2>&1; echo "o2fuzz rc=$?"; tail -3 $O/o200k_fuzz.log; fi
 if has cold; then timeout 300 python tools/cold_probe.py synth100k_heldout > $O/cold_heldout.json 2> $O/cold.err; timeout 300 python tools/cold_probe.py synth100k >> $O/cold_heldout.json 2>> $O/cold.err; echo "cold rc=$?"; cat $O/cold_heldout.json; fi
+if has fuzzlong; then timeout 460 python tools/gpu_fuzz.py 420 7 > $O/fuzz_long.log 2>&1; echo "fuzzlong rc=$?"; tail -1 $O/fuzz_long.log; ( timeout 400 python tools/o200k_scan_fuzz.py --gpu --pattern 4 --seeds 60 --first-seed 1000; timeout 300 python tools/o200k_scan_fuzz.py --gpu --pattern 3 --seeds 40 --first-seed 2000 ) > $O/o200k_fuzz_long.log 2>&1; echo "o2fuzzlong rc=$?"; tail -2 $O/o200k_fuzz_long.log; fi
