@@ -167,7 +167,7 @@ namespace Microsoft.DeepDev
 
         /// <summary>EncodeBatch without a List per text: text t is Ids[Offsets[t] .. Offsets[t + 1]).  When no special token applies
         /// (the reference's plain path, TikTokenizer.cs:180-183,196-199) Offsets is the device call's own output and Ids its own
-        /// buffer, untouched (longer than Offsets[texts.Count]: tokens never outnumber bytes); otherwise the special ids are
+        /// buffer, untouched (it may be longer than Offsets[texts.Count]: it is sized before the token count is known); otherwise the special ids are
         /// spliced in between the plain segments' ids with block copies.</summary>
         public unsafe (int[] Ids, long[] Offsets) EncodeBatchFlat(IReadOnlyList<string> texts, IReadOnlyCollection<string>? allowedSpecial = null)
         {
@@ -210,10 +210,22 @@ namespace Microsoft.DeepDev
             var units = new char[Math.Max(1, total)];
             for (int i = 0; i < segments.Count; ++i)
                 segments[i].text.CopyTo(segments[i].start, units, (int)unitOffsets[i], segments[i].end - segments[i].start);
-            var ids = new int[Math.Max(1, 3 * total)];                         // a code unit is at most three UTF-8 bytes, a token at least one byte
+            // A code unit is at most three UTF-8 bytes and a token at least one byte, so 3 * total ids always suffice; text has a token per
+            // ~4 units, so the first call gets room for one per two and the call is repeated with the exact count (the library reports
+            // it with TKZ_E_CAPACITY = -4) only when that was not enough.
+            long cap = Math.Max(1, Math.Min(3 * total, total / 2 + 4096));
+            int[] ids;
             var segOffsets = new long[segments.Count + 1];
-            fixed (char* pu = units) fixed (long* po = unitOffsets) fixed (int* pi = ids) fixed (long* poo = segOffsets)
-                Tkz.Check(Tkz.tkz_encode_batch_utf16(encoder, pu, po, segments.Count, pi, ids.Length, poo, out _));
+            while (true)
+            {
+                ids = new int[cap];
+                int st; long needed;
+                fixed (char* pu = units) fixed (long* po = unitOffsets) fixed (int* pi = ids) fixed (long* poo = segOffsets)
+                    st = Tkz.tkz_encode_batch_utf16(encoder, pu, po, segments.Count, pi, cap, poo, out needed);
+                if (st == -4 && needed > cap) { cap = needed; continue; }
+                Tkz.Check(st);
+                break;
+            }
             if (plain) return (ids, segOffsets);
             // 3. splice the special ids in: block copies of the segments' id ranges
             long nSpecial = 0;
