@@ -61,7 +61,8 @@ def test_device_unicode_table(lib, vocab):
 
 
 def test_golden_splits(lib, vocab):
-    for rec in load_golden_json("splits.json"):
+    # (splits.json: the oracle's, cross-checked against `regex`; splits_o200k_dotnet.json: computed by `regex` on code units, not by the oracle)
+    for rec in load_golden_json("splits.json") + load_golden_json("splits_o200k_dotnet.json"):
         enc = N.Encoder(vocab, rec["pattern"])
         b = rec["text"].encode("utf-8")
         got = enc.pretokenize(np.frombuffer(b, np.uint8) if b else np.zeros(0, np.uint8), np.array([0, len(b)]))
