@@ -377,6 +377,18 @@ def check_miss_lists(lib, O, vocab, ovocab, pattern=N.CL100K, seed=41):
         return "".join(out)[:n]
 
     docs_place = [mixed(6000, e, lo, hi).encode() for (e, lo, hi) in ((8, 3, 9), (6, 4, 16), (7, 17, 30), (5, 2, 40), (9, 9, 12), (4, 17, 24))]
+    # ... sub-tiles with 65 .. 128 misses (k_place keeps 128 list entries in LDS, two per lane, the long list from the top slot down: the
+    # second half is only loaded when more than 64 are kept) and a little beyond 128 (the general path): one piece in three / in two misses
+    docs_place += [mixed(9000, e, lo, hi).encode() for (e, lo, hi) in ((3, 3, 9), (3, 3, 30), (2, 4, 24), (2, 2, 40), (3, 17, 22), (2, 2, 4))]
+
+    def crowded(n, hits):        # per `hits` common words: four short misses and one long one -- ~100 .. 135 list entries per sub-tile, a fifth of them long
+        out = []
+        while sum(map(len, out)) < n:
+            out += [" " + rng.choice(words) for _ in range(hits)]
+            out += [" " + rng.choice(cons) + rng.choice(cons) for _ in range(4)]
+            out.append(" " + "".join(rng.choice(cons) for _ in range(17)))
+        return "".join(out)[:n]
+    docs_place += [crowded(7000, h).encode() for h in (5, 3, 2)]
     tiny = [rng.choice([b"a", b" b", b"\n", b"c d", b"qz", b" the", b"x\n\n", b" zqxj"]) for _ in range(5000)]
     for docs in (docs_small, docs_big, docs_small, docs_big[::-1], docs_place, tiny, docs_place + tiny[:700] + docs_big[:2]):
         data, offs = pack(docs)

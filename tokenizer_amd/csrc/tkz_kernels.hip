@@ -1335,7 +1335,8 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
 #ifndef TKZ_PLACE_OCC
 #define TKZ_PLACE_OCC 7
 #endif
-constexpr int kPlaceRes = 32;                              // 2 kPlaceRes = 64 answers (and quads) of a sub-tile's miss lists k_place keeps in LDS: one per lane, the short list from slot 0 up, the long one from slot 63 down (a sub-tile averages 14 short misses and one long one)
+constexpr int kPlaceRes = 64;                              // 2 kPlaceRes = 128 answers (and quads) of a sub-tile's miss lists k_place keeps in LDS: two per lane, the short list from slot 0 up, the long one from slot 127 down (a sub-tile of the bench corpus averages 14 short misses and one long one; under a vocabulary that has not seen the text, 75)
+constexpr int kPlaceSlots = 2 * kPlaceRes;
 constexpr int kPlacePer = 4;                               // consecutive sub-tiles per wavefront of k_place
 constexpr int kPlaceBig = 8;                               // the general path: token runs longer than this are copied by the whole wavefront, not staged
 constexpr int kPlaceFastBig = 32;                          // the fast path takes sub-tiles whose longest token run is at most this (a lane copies its piece's tokens into the stage)
@@ -1389,23 +1390,36 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     const bool lists_ok = ns + nl <= P.mcap;               // (cut lists: the batch is redone, nothing of this pass is used)
     // the answers of the merge kernels, in the same round trip as the first records
     // slot = lane: slots 0 .. ks-1 hold the first ks entries of the short list, slots 63 .. 64-kl the first kl of the long one
-    static_assert(2 * kPlaceRes == 64, "one lane per kept entry");
-    const int kl = ns + nl <= 64 ? nl : (nl < kPlaceRes ? nl : kPlaceRes), ks = ns < 64 - kl ? ns : 64 - kl;
+    static_assert(kPlaceSlots == 128, "two kept entries per lane: slots lane and lane + 64");
+    const int kl = ns + nl <= kPlaceSlots ? nl : (nl < kPlaceRes ? nl : kPlaceRes), ks = ns < kPlaceSlots - kl ? ns : kPlaceSlots - kl;
+    const bool two = ks + kl > 64;                         // (wave-uniform: the second slot of every lane is in use)
+    const int top = two ? kPlaceSlots - 1 : 63;           // entry e of the long list is kept in slot top - e
     bool fast_ok;
     {
-        uint32_t a = 0;
-        uint4 qd; qd.x = qd.y = qd.z = qd.w = 0;
-        const bool shortside = lane < ks;
-        const int e = shortside ? lane : 63 - lane;
-        const bool want = lists_ok && (shortside || e < kl);
-        const int64_t at = shortside ? e : P.mcap - 1 - e;
-        if (want) { a = tkz_load_nt(&ml[at]); qd = tkz_load16_nt(&mqd[at]); }
+        // slot s holds entry s of the short list (s < ks) or entry top - s of the long one (s > top - kl); lane l loads slot l and -- only when
+        // more than 64 entries are kept (top = 127 then, else 63) -- slot l + 64
+        uint32_t a[2] = {0u, 0u};
+        uint4 qd[2];
+        bool big = false;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            qd[h].x = qd[h].y = qd[h].z = qd[h].w = 0;
+            if (h == 1 && !two) break;
+            const int slot = lane + 64 * h;
+            const bool shortside = slot < ks;
+            const int e = shortside ? slot : top - slot;
+            const bool want = lists_ok && (shortside || e < kl);
+            const int64_t at = shortside ? e : P.mcap - 1 - e;
+            if (want) { a[h] = tkz_load_nt(&ml[at]); qd[h] = tkz_load16_nt(&mqd[at]); }
+            big = big || (want && tkz_result_cnt(a[h]) > kPlaceFastBig);
+        }
         (void)simt::ballot(true);                                // (the sub-tile before this one is done with them)
-        s_res[lane] = a; s_quad[lane] = qd; s_pos[lane] = -1;
-        if (lane == 0) s_res[2 * kPlaceRes] = tkz_result_inline(1);
-        // The fast path (below) takes a sub-tile whose lists are wholly in LDS (64 entries together) and hold no token run longer than kPlaceFastBig, and that has
-        // no giant piece: nearly all of them.
-        fast_ok = lists_ok && !has_giant && ns + nl <= 64 && !simt::ballot(want && tkz_result_cnt(a) > kPlaceFastBig);
+        s_res[lane] = a[0]; s_quad[lane] = qd[0]; s_pos[lane] = -1;
+        s_res[lane + 64] = a[1]; s_quad[lane + 64] = qd[1]; s_pos[lane + 64] = -1;
+        if (lane == 0) s_res[kPlaceSlots] = tkz_result_inline(1);
+        // The fast path (below) takes a sub-tile whose lists are wholly in LDS (kPlaceSlots entries together) and hold no token run longer
+        // than kPlaceFastBig, and that has no giant piece: nearly all of them.
+        fast_ok = lists_ok && !has_giant && ns + nl <= kPlaceSlots && !simt::ballot(big);
     }
     (void)simt::ballot(true);
     // the answer a merge kernel left for a missed piece (its list entry): how many tokens, and where they wait
@@ -1414,7 +1428,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         const int idx = (int)(rec & 1023u);
         const bool lg = (rec & kPrLong) != 0;
         if (!lists_ok) return tkz_result_inline(1);
-        return (lg ? idx < kl : idx < ks) ? s_res[lg ? 63 - idx : idx] : ml[lg ? P.mcap - 1 - idx : idx];
+        return (lg ? idx < kl : idx < ks) ? s_res[lg ? top - idx : idx] : ml[lg ? P.mcap - 1 - idx : idx];
     };
     // ... its tokens: INLINE (<= 4 tokens, nearly every missed piece: in the entry's quad, which for the first entries of both lists is
     // already in LDS), else in the group's dense region or in tmp
@@ -1422,7 +1436,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         const int idx = (int)(rec & 1023u);
         const bool lg = (rec & kPrLong) != 0;
         if (!lists_ok) { uint4 z; z.x = z.y = z.z = z.w = 0; return z; }
-        return (lg ? idx < kl : idx < ks) ? s_quad[lg ? 63 - idx : idx] : tkz_load16(&mqd[lg ? P.mcap - 1 - idx : idx]);
+        return (lg ? idx < kl : idx < ks) ? s_quad[lg ? top - idx : idx] : tkz_load16(&mqd[lg ? P.mcap - 1 - idx : idx]);
     };
     auto token_src = [&](uint32_t res) -> const int32_t* { return (res & kMrDense) ? dense + tkz_result_off(res) : P.tmp + base + tkz_result_off(res); };
     // stage[i] holds the id of token sbase + i of the sub-tile; sbase is chosen so that stage[0] sits on a 16-byte boundary of `out`
@@ -1450,8 +1464,8 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     // ---- the fast path: FOUR CONSECUTIVE records per lane (one 16-byte load), so that 256 records cost one wave scan, one pass over the
     // marks and one pass over the missed pieces instead of four of each -- k_place runs at the VALU issue limit, and what it issues is
     // mostly per-batch overhead.  A record's token count comes from LDS without a branch (a hit reads the "one token" slot); the
-    // tokens of a missed piece are written by the lane that OWNS its list entry (lane e: entry e of the short list, lane 63 - e: entry e
-    // of the long one): the lane that holds the record only tells it the position. ----
+    // tokens of a missed piece are written by the lane that OWNS its list entry's slot (slot e: entry e of the short list, slot top - e: entry e
+    // of the long one; lane l owns slots l and l + 64): the lane that holds the record only tells it the position. ----
     auto place_fast = [&](int kk) -> bool {
         const int k0 = kk + 4 * lane;
         uint32_t r[4] = {0u, 0u, 0u, 0u};
@@ -1466,8 +1480,8 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         for (int j = 0; j < 4; ++j) {
             ok[j] = k0 + j < np && pb + k0 + j < P.prank_cap;
             ms[j] = ok[j] && (r[j] & kPrMiss);
-            idx[j] = ((r[j] & kPrLong) ? 63 - (int)(r[j] & 1023u) : (int)(r[j] & 1023u)) & 63;     // the slot of the piece's list entry
-            const uint32_t a = s_res[ms[j] ? idx[j] : 2 * kPlaceRes];
+            idx[j] = ((r[j] & kPrLong) ? top - (int)(r[j] & 1023u) : (int)(r[j] & 1023u)) & (kPlaceSlots - 1);     // the slot of the piece's list entry
+            const uint32_t a = s_res[ms[j] ? idx[j] : kPlaceSlots];
             c[j] = ok[j] ? tkz_result_cnt(a) : 0;
             t += c[j];
             mk += (ok[j] && (r[j] & kPrMark)) ? 1 : 0;
@@ -1488,14 +1502,18 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
             pos += c[j];
         }
         (void)simt::ballot(true);
-        {   // the missed pieces of this chunk, by the lanes that own their entries
-            const int p = s_pos[lane];
+        // the missed pieces of this chunk, by the lanes that own their entries (slot lane, and slot lane + 64 when that half is in use)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h == 1 && !two) break;
+            const int slot = lane + 64 * h;
+            const int p = s_pos[slot];
             if (p >= 0) {                                        // (set once per entry, by the lane that holds its record)
-                const uint32_t ans = s_res[lane];
+                const uint32_t ans = s_res[slot];
                 const int cnt = tkz_result_cnt(ans);
                 int32_t* dst = stage + (p - sbase);
                 if (ans & kMrInline) {
-                    const uint4 q = s_quad[lane];
+                    const uint4 q = s_quad[slot];
                     dst[0] = (int32_t)q.x;
                     if (cnt > 1) dst[1] = (int32_t)q.y;
                     if (cnt > 2) dst[2] = (int32_t)q.z;
@@ -1504,7 +1522,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
                     const int32_t* src = token_src(ans);
                     for (int i = 0; i < cnt; ++i) dst[i] = src[i];
                 }
-                s_pos[lane] = -1;
+                s_pos[slot] = -1;
             }
         }
         running += tot; marks += mtot;
