@@ -1335,8 +1335,11 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
 #ifndef TKZ_PLACE_OCC
 #define TKZ_PLACE_OCC 7
 #endif
-constexpr int kPlaceRes = 64;                              // 2 kPlaceRes = 128 answers (and quads) of a sub-tile's miss lists k_place keeps in LDS: two per lane, the short list from slot 0 up, the long one from slot 127 down (a sub-tile of the bench corpus averages 14 short misses and one long one; under a vocabulary that has not seen the text, 75)
-constexpr int kPlaceSlots = 2 * kPlaceRes;
+// Answers (and quads) of a sub-tile's miss lists that k_place keeps in LDS: SLOTS = 64 (one per lane: the short list from slot 0 up, the long one from
+// slot 63 down; a sub-tile of the bench corpus averages 14 short misses and one long one) or 128 (two per lane, the second half only for
+// sub-tiles that keep more than 64).  The 128-slot form costs every sub-tile ~5 % (its instructions, its LDS) and saves a miss-heavy batch
+// 40 % of the kernel (a vocabulary that has not seen the text: 75 misses per sub-tile, most of them above 64, which the 64-slot form hands
+// to its general path): the host launches it for workspaces whose lists have grown to 256 entries or more (launch_place).
 constexpr int kPlacePer = 4;                               // consecutive sub-tiles per wavefront of k_place
 constexpr int kPlaceBig = 8;                               // the general path: token runs longer than this are copied by the whole wavefront, not staged
 constexpr int kPlaceFastBig = 32;                          // the fast path takes sub-tiles whose longest token run is at most this (a lane copies its piece's tokens into the stage)
@@ -1344,18 +1347,22 @@ constexpr int kStage = 64 * kPlaceBig + 16;                // staged ids: after 
 // LDS of one wavefront of k_place: the staged ids, the first answers of the sub-tile's short-miss list and of the long one, and the quads
 // of those entries (the tokens of pieces of <= 4)
 // ... the token position of every kept entry's piece (the fast path: the lane that owns the record tells the lane that owns the entry)
-constexpr int kPlaceLdsQuads = kStage / 4 + 2 * kPlaceRes + (2 * kPlaceRes) / 4 + 1 + (2 * kPlaceRes) / 4;
+template <int SLOTS> constexpr int kPlaceLdsQuadsT = kStage / 4 + SLOTS + SLOTS / 4 + 1 + SLOTS / 4;
+constexpr int kPlaceLdsQuads = kPlaceLdsQuadsT<64>;       // (the single-launch kernel always uses the 64-slot form)
 struct PlaceLds { int32_t* stage; uint4* quad; uint32_t* res; int32_t* pos; };
+template <int SLOTS>
 TKZ_DEV PlaceLds tkz_place_lds(uint4* wave_quads) {
     PlaceLds L;
     L.stage = reinterpret_cast<int32_t*>(wave_quads);
     L.quad = wave_quads + kStage / 4;
-    L.res = reinterpret_cast<uint32_t*>(wave_quads + kStage / 4 + 2 * kPlaceRes);                       // 2 kPlaceRes answers + slot 2 kPlaceRes: "one token"
-    L.pos = reinterpret_cast<int32_t*>(wave_quads + kStage / 4 + 2 * kPlaceRes + (2 * kPlaceRes) / 4 + 1);
+    L.res = reinterpret_cast<uint32_t*>(wave_quads + kStage / 4 + SLOTS);                       // SLOTS answers + slot SLOTS: "one token"
+    L.pos = reinterpret_cast<int32_t*>(wave_quads + kStage / 4 + SLOTS + SLOTS / 4 + 1);
     return L;
 }
 // sub-tiles sub0 .. sub0 + kPlacePer - 1, by one wavefront
+template <int SLOTS>
 TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base, int32_t* out, int64_t out_cap, int64_t sub0, const PlaceLds& LD) {
+    constexpr int kPlaceSlots = SLOTS, kPlaceRes = SLOTS / 2;
     const int lane = simt::lane();
     if (sub0 >= P.nsub) return;
     int32_t* stage = LD.stage;
@@ -1390,9 +1397,9 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     const bool lists_ok = ns + nl <= P.mcap;               // (cut lists: the batch is redone, nothing of this pass is used)
     // the answers of the merge kernels, in the same round trip as the first records
     // slot = lane: slots 0 .. ks-1 hold the first ks entries of the short list, slots 63 .. 64-kl the first kl of the long one
-    static_assert(kPlaceSlots == 128, "two kept entries per lane: slots lane and lane + 64");
+    static_assert(SLOTS == 64 || SLOTS == 128, "one or two kept entries per lane: slots lane and lane + 64");
     const int kl = ns + nl <= kPlaceSlots ? nl : (nl < kPlaceRes ? nl : kPlaceRes), ks = ns < kPlaceSlots - kl ? ns : kPlaceSlots - kl;
-    const bool two = ks + kl > 64;                         // (wave-uniform: the second slot of every lane is in use)
+    const bool two = SLOTS == 128 && ks + kl > 64;         // (wave-uniform: the second slot of every lane is in use; never with 64 slots)
     const int top = two ? kPlaceSlots - 1 : 63;           // entry e of the long list is kept in slot top - e
     bool fast_ok;
     {
@@ -1415,7 +1422,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         }
         (void)simt::ballot(true);                                // (the sub-tile before this one is done with them)
         s_res[lane] = a[0]; s_quad[lane] = qd[0]; s_pos[lane] = -1;
-        s_res[lane + 64] = a[1]; s_quad[lane + 64] = qd[1]; s_pos[lane + 64] = -1;
+        if constexpr (SLOTS == 128) { s_res[lane + 64] = a[1]; s_quad[lane + 64] = qd[1]; s_pos[lane + 64] = -1; }
         if (lane == 0) s_res[kPlaceSlots] = tkz_result_inline(1);
         // The fast path (below) takes a sub-tile whose lists are wholly in LDS (kPlaceSlots entries together) and hold no token run longer
         // than kPlaceFastBig, and that has no giant piece: nearly all of them.
@@ -1597,10 +1604,11 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     if (flushed < running) flush(running);
     }
 }
+template <int SLOTS>
 TKZ_KERNEL_OCC(256, TKZ_PLACE_OCC) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
-    TKZ_SHARED uint4 s_wave[kThreads / 64][kPlaceLdsQuads];
+    TKZ_SHARED uint4 s_wave[kThreads / 64][kPlaceLdsQuadsT<SLOTS>];
     const int64_t sub0 = (tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave()) * kPlacePer;
-    tkz_place_subtiles(P, tile_base, out, out_cap, sub0, tkz_place_lds(s_wave[simt::wave()]));
+    tkz_place_subtiles<SLOTS>(P, tile_base, out, out_cap, sub0, tkz_place_lds<SLOTS>(s_wave[simt::wave()]));
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2256,7 +2264,7 @@ TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
     simt::sync();
     stamp();
     for (int s0 = wave * kPlacePer; s0 < nsub; s0 += nwaves * kPlacePer)
-        tkz_place_subtiles(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds(s_raw + wave * kPlaceLdsQuads));
+        tkz_place_subtiles<64>(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds<64>(s_raw + wave * kPlaceLdsQuads));
     simt::sync();
     stamp();
     {
@@ -2350,7 +2358,9 @@ void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, co
 }
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
     hook(L, K_GATHER, 0);
-    TKZ_LAUNCH(k_place, xcd_grid(cdiv(nsub, (kThreads / 64) * kPlacePer)), kThreads, L.stream, P, tile_base, out, out_cap);
+    // (lists that have grown to 256 entries say that most sub-tiles of this workspace's batches miss more than 64 pieces: the 128-slot form)
+    if (P.mcap >= 256) TKZ_LAUNCH(k_place<128>, xcd_grid(cdiv(nsub, (kThreads / 64) * kPlacePer)), kThreads, L.stream, P, tile_base, out, out_cap);
+    else TKZ_LAUNCH(k_place<64>, xcd_grid(cdiv(nsub, (kThreads / 64) * kPlacePer)), kThreads, L.stream, P, tile_base, out, out_cap);
     hook(L, K_GATHER, 1);
 }
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt) {
