@@ -395,13 +395,14 @@ def check_miss_lists(lib, O, vocab, ovocab, pattern=N.CL100K, seed=41):
         ids, ooff = enc.encode_batch(data, offs)
         exp, eoff = oracle_encode_docs(oenc, docs)
         assert ooff.tolist() == eoff and ids.tolist() == exp
-    # the 128-slot form of k_place (launched once a workspace's lists have grown to 256 entries): a batch too large for the single launch,
+    # the 128-slot form of k_place (launched when more than a fifth of the sub-tiles of the workspace's previous batch held more than 64 list
+    # entries): a batch too large for the single launch,
     # most of its sub-tiles with 65 .. 128 list entries of both kinds, one document with far more; twice (the second call starts on the grown lists)
     enc3 = N.Encoder(vocab, pattern)
     docs128 = [crowded(40000, h).encode() for h in (5, 3, 4, 3)] + [gib(5000, 2, 2).encode(), mixed(9000, 3, 3, 9).encode()]
     data, offs = pack(docs128)
     exp, eoff = oracle_encode_docs(oenc, docs128)
-    for rep in range(2):
+    for rep in range(3):           # (the form is chosen from the batch before: the first call runs k_place<64>, the later ones k_place<128>)
         ids, ooff = enc3.encode_batch(data, offs)
         assert ooff.tolist() == eoff and ids.tolist() == exp, rep
     # piece granularity on the crowded text (every record marked)

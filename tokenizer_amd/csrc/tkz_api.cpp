@@ -66,7 +66,8 @@ struct DevBuf {
 };
 
 struct CounterBlock {          // mirrors the device block
-    int32_t err; int32_t mneed /* longest miss list of a sub-tile (kErrMissCap) */; int32_t mhigh /* longest list above kMissCapMin that fitted */; int32_t pad;
+    int32_t err; int32_t mneed /* longest miss list of a sub-tile (kErrMissCap) */; int32_t mhigh /* longest list above kMissCapMin that fitted */;
+    int32_t over64 /* sub-tiles with more than 64 list entries, among every 64th sub-tile */;
     int64_t grand;
     unsigned long long pool_head;
     int64_t ndocstarts;
@@ -93,6 +94,7 @@ struct Workspace {
     DevBuf w_mlist, w_mquad, w_mcount;
     DevBuf w_counts3;                      // {n_docs, n_bytes, n_tokens} of the batch this workspace is running (tkz_pending_counts_device)
     int32_t mcap = tkz::kMissCapMin;       // entries of a sub-tile's miss list; grows (once, to what the batch needed) when a sub-tile overflows it
+    bool place128 = false;                 // the previous batch of this workspace had more than a fifth of its sub-tiles above 64 list entries: k_place<128>
     // staging for the host-buffer entry points (two sets: chunk k+1 is uploaded while chunk k is encoded and chunk k-1 downloaded)
     DevBuf s_bytes[2], s_offs[2], s_out[2], s_outoffs[2];
     // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
@@ -357,6 +359,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
             P.ablate = 0; P.devprof = nullptr;
             P.stats = e->piece_stats ? e->t_stats.as<unsigned long long>() : nullptr;
+            P.place128 = ws->place128 ? 1 : 0;
 #ifdef TKZ_DEVPROF
             { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
             if (P.ablate & 16) {
@@ -452,6 +455,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             std::lock_guard<std::mutex> lock(e->mu);
             ++e->stat_batches; e->stat_giants += (int64_t)ws->h_counters->heavy_count;
         }
+        if (!d_bitmap_only) ws->place128 = (int64_t)ws->h_counters->over64 * 64 * 5 > ntiles;      // (more than a fifth of the sub-tiles: the next batch's k_place)
         if (!d_bitmap_only && ws->mcap > kMissCapMin) {
             // lists that were grown for an earlier batch (text where nearly every piece misses) and that this batch filled to less than
             // half: shorter lists from here on, and the buffers given back when they are far larger than such a batch needs (the lists
@@ -521,7 +525,7 @@ tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, con
     P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
     P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
     P.pool = ws->w_pool.as<int32_t>(); P.pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head)); P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
-    P.ablate = 0; P.devprof = nullptr; P.stats = nullptr;
+    P.ablate = 0; P.devprof = nullptr; P.stats = nullptr; P.place128 = 0;
     SmallArgs A{};
     A.h_bytes = H + kSmallOffBytes; A.h_offs = reinterpret_cast<const int64_t*>(H + kSmallOffOffs);
     A.out = reinterpret_cast<int32_t*>(H + kSmallOffIds); A.out_cap = std::min<int64_t>(out_cap, kSmallMaxBytes); A.out_offs = reinterpret_cast<int64_t*>(H + kSmallOffOut);

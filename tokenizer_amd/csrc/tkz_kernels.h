@@ -49,7 +49,8 @@ struct EncodeParams {
     uint32_t* mcount;             // per sub-tile: short misses | long misses << 16
     const int64_t* docord_base;   // per sub-tile: number of distinct document-start positions before it
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
-    int32_t* counters;            // [0] error bits, [1] the longest miss list seen (kErrMissCap), [2] the longest list above kMissCapMin that fitted (grown lists only)
+    int32_t* counters;            // [0] error bits, [1] the longest miss list seen (kErrMissCap), [2] the longest list above kMissCapMin that fitted (grown lists only),
+                                  // [3] sub-tiles with more than 64 list entries among every 64th sub-tile
     uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_probe: bit 0 = long misses in its list, bit 1 = a giant piece
                                                                           // (a flag, not a queue: a queue's one counter serialises a million atomics on mixed text)
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)
@@ -63,6 +64,7 @@ struct EncodeParams {
     // TKZ_OPT_PIECE_STATS: null, or the encoder's statistics block -- [0] memo lookups, [1] memo hits, [2] short misses, [3] long misses, [4] pieces
     // (what tkz_encoder_piece_stats reports; the timed runs leave it null)
     unsigned long long* stats;
+    int32_t place128;             // launch k_place<128> (two kept list entries per lane) instead of k_place<64>: the previous batch of the workspace was miss-heavy
 };
 
 // k_small: one launch for a small batch (tkz_kernels.hip).  Input and output live in page-locked host memory the device reads and writes directly.

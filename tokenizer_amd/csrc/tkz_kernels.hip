@@ -857,6 +857,8 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
         // lists that were grown: the longest one this batch really needed, so that the host can let them shrink again (read first: the
         // maximum settles after a few sub-tiles and the rest only read it)
         else if (P.mcap > kMissCapMin && ns + nl > kMissCapMin && *(volatile const int32_t*)&P.counters[2] < ns + nl) simt::atomic_max((unsigned*)&P.counters[2], (unsigned)(ns + nl));
+        // how many sub-tiles hold more than 64 list entries, counted on every 64th sub-tile: the host picks k_place's form for the workspace's next batch by it
+        if (ns + nl > 64 && (sub & 63) == 0) simt::atomic_add(&P.counters[3], 1);
         if (pb + np > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
     }
 }
@@ -1339,7 +1341,8 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
 // slot 63 down; a sub-tile of the bench corpus averages 14 short misses and one long one) or 128 (two per lane, the second half only for
 // sub-tiles that keep more than 64).  The 128-slot form costs every sub-tile ~5 % (its instructions, its LDS) and saves a miss-heavy batch
 // 40 % of the kernel (a vocabulary that has not seen the text: 75 misses per sub-tile, most of them above 64, which the 64-slot form hands
-// to its general path): the host launches it for workspaces whose lists have grown to 256 entries or more (launch_place).
+// to its general path): the host launches it when more than a fifth of the sub-tiles of the workspace's previous batch held more than 64
+// entries (k_probe counts them on every 64th sub-tile; EncodeParams::place128).
 constexpr int kPlacePer = 4;                               // consecutive sub-tiles per wavefront of k_place
 constexpr int kPlaceBig = 8;                               // the general path: token runs longer than this are copied by the whole wavefront, not staged
 constexpr int kPlaceFastBig = 32;                          // the fast path takes sub-tiles whose longest token run is at most this (a lane copies its piece's tokens into the stage)
@@ -2358,8 +2361,7 @@ void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, co
 }
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
     hook(L, K_GATHER, 0);
-    // (lists that have grown to 256 entries say that most sub-tiles of this workspace's batches miss more than 64 pieces: the 128-slot form)
-    if (P.mcap >= 256) TKZ_LAUNCH(k_place<128>, xcd_grid(cdiv(nsub, (kThreads / 64) * kPlacePer)), kThreads, L.stream, P, tile_base, out, out_cap);
+    if (P.place128) TKZ_LAUNCH(k_place<128>, xcd_grid(cdiv(nsub, (kThreads / 64) * kPlacePer)), kThreads, L.stream, P, tile_base, out, out_cap);
     else TKZ_LAUNCH(k_place<64>, xcd_grid(cdiv(nsub, (kThreads / 64) * kPlacePer)), kThreads, L.stream, P, tile_base, out, out_cap);
     hook(L, K_GATHER, 1);
 }
