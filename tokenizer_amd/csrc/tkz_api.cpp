@@ -67,7 +67,7 @@ struct DevBuf {
 
 struct CounterBlock {          // mirrors the device block
     int32_t err; int32_t mneed /* longest miss list of a sub-tile (kErrMissCap) */; int32_t mhigh /* longest list above kMissCapMin that fitted */;
-    int32_t over64 /* sub-tiles with more than 64 list entries, among every 64th sub-tile */;
+    int32_t over64 /* sub-tiles with more than 64 list entries (k_list_stats; grown lists only) */;
     int64_t grand;
     unsigned long long pool_head;
     int64_t ndocstarts;
@@ -455,7 +455,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             std::lock_guard<std::mutex> lock(e->mu);
             ++e->stat_batches; e->stat_giants += (int64_t)ws->h_counters->heavy_count;
         }
-        if (!d_bitmap_only) ws->place128 = (int64_t)ws->h_counters->over64 * 64 * 5 > ntiles;      // (more than a fifth of the sub-tiles: the next batch's k_place)
+        if (!d_bitmap_only) ws->place128 = (int64_t)ws->h_counters->over64 * 5 > ntiles;      // (more than a fifth of the sub-tiles: the next batch's k_place)
         if (!d_bitmap_only && ws->mcap > kMissCapMin) {
             // lists that were grown for an earlier batch (text where nearly every piece misses) and that this batch filled to less than
             // half: shorter lists from here on, and the buffers given back when they are far larger than such a batch needs (the lists

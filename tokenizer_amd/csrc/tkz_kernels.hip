@@ -854,11 +854,6 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
         P.heavy_flag[sub] = (uint8_t)f;
         P.mcount[sub] = (uint32_t)ns | ((uint32_t)nl << 16);
         if (ns + nl > P.mcap) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&P.counters[1], (unsigned)(ns + nl)); }
-        // lists that were grown: the longest one this batch really needed, so that the host can let them shrink again (read first: the
-        // maximum settles after a few sub-tiles and the rest only read it)
-        else if (P.mcap > kMissCapMin && ns + nl > kMissCapMin && *(volatile const int32_t*)&P.counters[2] < ns + nl) simt::atomic_max((unsigned*)&P.counters[2], (unsigned)(ns + nl));
-        // how many sub-tiles hold more than 64 list entries, counted on every 64th sub-tile: the host picks k_place's form for the workspace's next batch by it
-        if (ns + nl > 64 && (sub & 63) == 0) simt::atomic_add(&P.counters[3], 1);
         if (pb + np > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
     }
 }
@@ -1803,6 +1798,28 @@ TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
     for (int64_t i = simt::bid() * simt::nthreads() + simt::tid(); i < n; i += stride) offs[i] -= base;
 }
 
+// Grown miss lists only (mcap > kMissCapMin): the longest list the batch really needed (counters[2]: the host lets the lists shrink again by it) and
+// how many sub-tiles hold more than 64 entries (counters[3]: the host picks k_place's form for the workspace's next batch by it).  A pass of its
+// own over mcount, a few atomics per workgroup -- k_probe used to keep both, every wavefront reading (and some updating) one hot line of the
+// counter block: 8 ms of a miss-heavy batch.
+TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t mcap, int32_t* counters) {
+    const int64_t stride = simt::nblocks() * simt::nthreads();
+    int mx = 0, over = 0;
+    for (int64_t i = simt::bid() * simt::nthreads() + simt::tid(); i < nsub; i += stride) {
+        const uint32_t m = mcount[i];
+        const int n = (int)(m & 0xFFFFu) + (int)(m >> 16);
+        if (n <= mcap && n > mx) mx = n;
+        over += n > 64 ? 1 : 0;
+    }
+    int tot;
+    (void)tkz_wave_scan_sum(over, &tot);
+    for (int d = 32; d >= 1; d >>= 1) { const int o = simt::shfl(mx, simt::lane() ^ d); mx = o > mx ? o : mx; }
+    if (simt::lane() == 0) {
+        if (mx > kMissCapMin) simt::atomic_max((unsigned*)&counters[2], (unsigned)mx);
+        if (tot) simt::atomic_add(&counters[3], tot);
+    }
+}
+
 // TKZ_OPT_PIECE_STATS: the lengths of the miss lists of all sub-tiles, summed (short | long << 16 per sub-tile)
 TKZ_KERNEL(256) void k_miss_stats(const uint32_t* mcount, const int32_t* pcount, int64_t nsub, unsigned long long* stats) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
@@ -2336,6 +2353,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     hook(L, K_ENCODE, 0);
     TKZ_LAUNCH(k_probe, xcd_grid(cdiv(nsub, (kThreads / 64) * kProbePer)), kThreads, L.stream, T, P);
     hook(L, K_ENCODE, 1);
+    if (P.mcap > kMissCapMin) { const int64_t g = grid_for(nsub); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsub, P.mcap, P.counters); }
     hook(L, K_MERGE_SHORT, 0);
     TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
     hook(L, K_MERGE_SHORT, 1);
