@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--no-memo-steps", type=int, default=None, help="timed steps with the piece memo off (value_no_memo); default: as --steps")
     ap.add_argument("--pipelined-steps", type=int, default=4, help="timed steps of the two-batches-in-flight leg (value_two_in_flight; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-piece-stats", action="store_true", help="skip the untimed step that counts pieces / misses / memo hits (tools/gpu_profile.sh: only the headline steps, their "
+                                                                  "warm-up and the sizing pass run under the profiler)")
     ap.add_argument("--no-memo", action="store_true", help="switch the piece memo (the device form of the reference's LRUCache) off")
     ap.add_argument("--write-shards", default=None, metavar="DIR", help="after the timed loop every rank writes its token shard file (SURVEY 8f-2)")
     args = ap.parse_args()
@@ -322,7 +324,7 @@ def main():
         rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
         dt = max(float(x.item()) for x in allt)              # the slowest rank's time is the job's
     kms = enc.kernel_ms()
-    piece_stats = stats_of(enc) if rank == 0 else None
+    piece_stats = stats_of(enc) if (rank == 0 and not args.no_piece_stats) else None
     if world > 1:
         fence()
     # the same steps with the piece memo switched off (it neither reads nor fills it): the companion figure `value_no_memo`

@@ -976,6 +976,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     if (lane < kGroup) s_extra[lane] = 0;
     uint32_t* const ml0 = P.mlist + sub0 * (int64_t)P.mcap;
     int err = 0, nlist = 0, nchk = 0, dused = 0, done = 0;      // list entries [0, nchk) have been through the memo, [nchk, nlist) not yet
+    int st_look = 0, st_hit = 0;                                // TKZ_OPT_PIECE_STATS: memo lookups and hits of this group (one pair of atomics at its end)
     int32_t* const dense = P.dense + grp * kDenseCap;
     const bool memo = T.memo_n != 0;
     // where the `cnt` tokens of a piece go -- up to four: into the entry's own quad (the caller stores them); more: packed behind those of
@@ -1040,10 +1041,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
                 if (h) { hit = true; vv = v; }
             }
         }
-        if (P.stats) {                                        // (statistics run only: wave-uniform, null in the timed runs)
-            const int nlook = tkz_popc64(simt::ballot(mine && memo)), nhit = tkz_popc64(simt::ballot(hit));
-            if (lane == 0 && nlook) { simt::atomic_add64(&P.stats[0], (unsigned long long)nlook); simt::atomic_add64(&P.stats[1], (unsigned long long)nhit); }
-        }
+        if (P.stats) { st_look += tkz_popc64(simt::ballot(mine && memo)); st_hit += tkz_popc64(simt::ballot(hit)); }   // (statistics run only: wave-uniform, null in the timed runs)
         const int cnt = hit ? (int)((vv.x >> 29) & 3u) + 1 : 0;
         (void)assign(hit, cnt, si, j, rel);
         if (hit) {                                            // (a memo entry holds <= 4 tokens: they go into the entry's quad)
@@ -1138,6 +1136,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     // tokens of every sub-tile of the group: one per piece, plus what the merges added (k_merge_long adds its own later)
     if (lane < kGroup && sub0 + lane < P.nsub) P.tile_count[sub0 + lane] = my_np + s_extra[lane];
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
+    if (P.stats && lane == 0 && st_look) { simt::atomic_add64(&P.stats[0], (unsigned long long)st_look); simt::atomic_add64(&P.stats[1], (unsigned long long)st_hit); }
 }
 // (LDS: 4 x 9.5 KB of merge state + 0.5 KB = 38.5 KB per workgroup, and <= 128 VGPRs: four workgroups = 16 wavefronts per CU)
 TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {

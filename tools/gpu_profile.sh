@@ -6,8 +6,8 @@ TAG=${1:-r01}; DOCS=${2:-2000000}; EXTRA=${3:-}
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$REPO"; mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
-# (--heldout-steps 0 --pipelined-steps 0: nothing but the headline steps, their warm-up and the sizing pass run under the profiler -- per-launch averages of a kernel are over THOSE launches)
-BENCH="python $REPO/bench.py --docs $DOCS --steps 3 --warmup 1 --no-cpu-baseline --heldout-steps 0 --pipelined-steps 0 $EXTRA"
+# (--heldout-steps 0 --pipelined-steps 0 --no-piece-stats: nothing but the headline steps, their warm-up and the sizing pass run under the profiler -- per-launch averages of a kernel are over THOSE launches)
+BENCH="python $REPO/bench.py --docs $DOCS --steps 3 --warmup 1 --no-cpu-baseline --heldout-steps 0 --pipelined-steps 0 --no-piece-stats $EXTRA"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG/trace -o trace -- $BENCH > $REPO/gpurun_out/prof_$TAG/trace.log 2>&1; echo "trace rc=$?"
 i=0
