@@ -642,6 +642,10 @@ TKZ_DEV void tkz_probe_request_text(const EncodeParams& P, int64_t sub, ProbeTex
 // one sub-tile, by one wavefront (no workgroup barrier inside: every wavefront is on its own).  tx: the sub-tile's text, requested by the
 // caller; on return it holds the request for sub-tile `next` (< 0: none), issued as soon as this one's text had moved into LDS -- a
 // wavefront that probes consecutive sub-tiles never waits for text again.
+// REPORT: a list that does not fit is reported here, by two atomics on the counter block (the single-launch kernel: one workgroup); the batch path
+// leaves that to k_list_stats, which reads the lengths from mcount -- when nearly every sub-tile overflows (the first batch of text that is
+// full of missed pieces) ten million atomics on one line cost 100 ms.
+template <bool REPORT>
 TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_t sub, const ProbeLds& LD, ProbeText& tx, int64_t next) {
     const int lane = simt::lane();
     uint32_t* s_bytes = LD.bytes;
@@ -853,7 +857,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
     if (lane == 0) {
         P.heavy_flag[sub] = (uint8_t)f;
         P.mcount[sub] = (uint32_t)ns | ((uint32_t)nl << 16);
-        if (ns + nl > P.mcap) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&P.counters[1], (unsigned)(ns + nl)); }
+        if (REPORT && ns + nl > P.mcap) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&P.counters[1], (unsigned)(ns + nl)); }
         if (pb + np > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
     }
 }
@@ -870,7 +874,7 @@ TKZ_KERNEL_OCC(256, TKZ_PROBE_OCC) void k_probe(TkzTables T, EncodeParams P) {
 #pragma unroll 1
     for (int it = 0; it < kProbePer && sub0 + it < P.nsub; ++it) {
         const int64_t nxt = (it + 1 < kProbePer && sub0 + it + 1 < P.nsub) ? sub0 + it + 1 : -1;
-        tkz_probe_subtile(T, P, sub0 + it, LD, tx, nxt);
+        tkz_probe_subtile<false>(T, P, sub0 + it, LD, tx, nxt);
         (void)simt::ballot(true);                             // (the next sub-tile reuses the wavefront's LDS)
     }
 }
@@ -1797,23 +1801,28 @@ TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
     for (int64_t i = simt::bid() * simt::nthreads() + simt::tid(); i < n; i += stride) offs[i] -= base;
 }
 
-// Grown miss lists only (mcap > kMissCapMin): the longest list the batch really needed (counters[2]: the host lets the lists shrink again by it) and
-// how many sub-tiles hold more than 64 entries (counters[3]: the host picks k_place's form for the workspace's next batch by it).  A pass of its
-// own over mcount, a few atomics per workgroup -- k_probe used to keep both, every wavefront reading (and some updating) one hot line of the
-// counter block: 8 ms of a miss-heavy batch.
+// What the miss lists of the batch needed, from a pass over mcount (a few atomics per workgroup; k_probe used to keep these itself, every wavefront
+// reading -- and many updating -- ONE line of the counter block: 8 ms of a miss-heavy batch, 100 ms of a batch whose lists all overflow):
+//   counters[0] |= kErrMissCap, counters[1] = the longest list, when some list did not fit mcap (the host grows the lists and runs the batch again);
+//   counters[2] = the longest list above kMissCapMin that did fit (the host lets grown lists shrink again by it);
+//   counters[3] = how many sub-tiles hold more than 64 entries (the host picks k_place's form for the workspace's next batch by it).
 TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t mcap, int32_t* counters) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
-    int mx = 0, over = 0;
+    int mx = 0, big = 0, over = 0;
     for (int64_t i = simt::bid() * simt::nthreads() + simt::tid(); i < nsub; i += stride) {
         const uint32_t m = mcount[i];
         const int n = (int)(m & 0xFFFFu) + (int)(m >> 16);
-        if (n <= mcap && n > mx) mx = n;
+        if (n <= mcap) { if (n > mx) mx = n; } else if (n > big) big = n;
         over += n > 64 ? 1 : 0;
     }
     int tot;
     (void)tkz_wave_scan_sum(over, &tot);
-    for (int d = 32; d >= 1; d >>= 1) { const int o = simt::shfl(mx, simt::lane() ^ d); mx = o > mx ? o : mx; }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = simt::shfl(mx, simt::lane() ^ d), b = simt::shfl(big, simt::lane() ^ d);
+        mx = o > mx ? o : mx; big = b > big ? b : big;
+    }
     if (simt::lane() == 0) {
+        if (big) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&counters[1], (unsigned)big); }
         if (mx > kMissCapMin) simt::atomic_max((unsigned*)&counters[2], (unsigned)mx);
         if (tot) simt::atomic_add(&counters[3], tot);
     }
@@ -2239,7 +2248,7 @@ TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
         for (int sub = wave; sub < nsub; sub += nwaves) {
             ProbeText tx;
             tkz_probe_request_text(P, sub, &tx);
-            tkz_probe_subtile(T, P, sub, tkz_probe_lds(s_raw + wave * kProbeLdsQuads, s_kmask), tx, -1);
+            tkz_probe_subtile<true>(T, P, sub, tkz_probe_lds(s_raw + wave * kProbeLdsQuads, s_kmask), tx, -1);
             (void)simt::ballot(true);
         }
     }
@@ -2352,7 +2361,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     hook(L, K_ENCODE, 0);
     TKZ_LAUNCH(k_probe, xcd_grid(cdiv(nsub, (kThreads / 64) * kProbePer)), kThreads, L.stream, T, P);
     hook(L, K_ENCODE, 1);
-    if (P.mcap > kMissCapMin) { const int64_t g = grid_for(nsub); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsub, P.mcap, P.counters); }
+    { const int64_t g = grid_for(nsub); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsub, P.mcap, P.counters); }
     hook(L, K_MERGE_SHORT, 0);
     TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
     hook(L, K_MERGE_SHORT, 1);
