@@ -60,6 +60,30 @@ def main():
     enc.encode_batch(data, offs)
     ph = enc.small_path_phases()
     out["single_launch_path"]["phase_cycles_1000_prompts"] = [ph[i + 1] - ph[i] for i in range(len(ph) - 1) if ph[i + 1] and ph[i]]
+    # mid-size host batches (between the single-launch path's 128 KiB and the chunk-pipelined path's 96 MB): documents of ~512 bytes, MB/s of one
+    # tkz_encode_batch_utf8 call on pageable and on page-locked buffers
+    try:
+        import torch
+        mid = {}
+        for mb in (0.25, 1, 4, 16, 64):
+            nd = max(1, int(mb * (1 << 20) / 512))
+            docs = [N.corpus_doc_host(1, 0x5EED0002, d, 256, 768) for d in range(min(nd, 4096))]
+            reps_d = (nd + len(docs) - 1) // len(docs)
+            docs = (docs * reps_d)[:nd]
+            bdata = np.frombuffer(b"".join(docs), np.uint8)
+            boffs = np.cumsum([0] + [len(x) for x in docs]).astype(np.int64)
+            oi, oo = np.zeros(len(bdata), np.int32), np.zeros(nd + 1, np.int64)
+            tb = torch.empty(len(bdata), dtype=torch.uint8).pin_memory(); tb.numpy()[:] = bdata
+            to = torch.empty(nd + 1, dtype=torch.int64).pin_memory(); to.numpy()[:] = boffs
+            ti = torch.zeros(len(bdata), dtype=torch.int32).pin_memory(); too = torch.zeros(nd + 1, dtype=torch.int64).pin_memory()
+            r = max(5, min(50, int(200 / max(mb, 0.25))))
+            us_pageable = med_us(lambda: enc.encode_batch(bdata, boffs, out=(oi, oo)), r)
+            us_pinned = med_us(lambda: enc.encode_batch(tb.numpy(), to.numpy(), out=(ti.numpy(), too.numpy())), r)
+            mid["%g MB" % mb] = {"bytes": int(len(bdata)), "pageable_us": us_pageable[0], "pageable_MBps": round(len(bdata) / us_pageable[0], 1),
+                                 "pinned_us": us_pinned[0], "pinned_MBps": round(len(bdata) / us_pinned[0], 1)}
+        out["mid_size_host_batches"] = mid
+    except Exception as ex:
+        out["mid_size_host_batches"] = "%s: %s" % (type(ex).__name__, ex)
     # the floor: one trivial kernel launch + stream synchronisation through torch, for comparison
     try:
         import torch
