@@ -17,16 +17,3 @@ def library():
         from tokenizer_amd import _native
         _lib = _native.Library(EMU_LIB)
     return _lib
-
-
-_tail_lib = None
-
-
-def tail_library():
-    """The build in which every giant piece goes to the batched tail of the merger (tests/hostemu/Makefile, target `tail`)."""
-    global _tail_lib
-    if _tail_lib is None:
-        subprocess.check_call(["make", "-C", EMU_DIR, "-s", "tail"])
-        from tokenizer_amd import _native
-        _tail_lib = _native.Library(os.path.join(EMU_DIR, "_build", "libtkz_hostemu_tail.so"))
-    return _tail_lib

@@ -606,13 +606,19 @@ def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
             assert enc.encode_utf8(b) == oenc.encode_bytes(b)
             assert enc.encode_utf16(np.frombuffer(text.encode("utf-16-le"), np.uint16).tolist()) == oenc.encode_bytes(b)
         calls, back = enc.small_path_calls()
-        assert calls > rounds // 2 and back <= calls // 4, (calls, back)      # (a document full of missed pieces outgrows a fresh encoder's lists once)
-        # handed back: a piece of more than 1024 bytes inside a small batch ...
-        docs = [b"q" * 1024, b"hello world"]                 # (1024 letters: one piece as long as a document of this path can be)
-        data, offs = pack(docs)
-        ids, ooff = enc.encode_batch(data, offs)
-        exp, eoff = oracle_encode_docs(oenc, docs)
-        assert ids.tolist() == exp and ooff.tolist() == eoff
+        # (a document full of missed pieces outgrows a fresh encoder's lists once; the generator's 300- and 1000-char documents of ONE class hold missed
+        #  pieces of more than 256 bytes, which the batch path merges a wavefront a piece -- k_merge_coop --: handed back)
+        assert calls > rounds // 2 and back <= calls // 3, (calls, back)
+        # handed back: a piece of more than 1024 bytes inside a small batch, a missed piece of more than 256 ...
+        for docs in ([b"q" * 1024, b"hello world"],           # (1024 letters: one piece as long as a document of this path can be)
+                     [b"hello " + b"q" * 300 + b" world", b"x"]):
+            data, offs = pack(docs)
+            c0 = enc.small_path_calls()
+            ids, ooff = enc.encode_batch(data, offs)
+            exp, eoff = oracle_encode_docs(oenc, docs)
+            assert ids.tolist() == exp and ooff.tolist() == eoff
+            c1 = enc.small_path_calls()
+            assert (c1[0] - c0[0], c1[1] - c0[1]) == (1, 1), (c0, c1)
         # ... more misses than a fresh encoder's lists hold (the batch path grows them; later small calls fit)
         cons = "bcdfghjklmnpqrstvwxz"
         gdocs = ["".join(" " + rng.choice(cons) + rng.choice(cons) for _ in range(300)).encode() for _ in range(3)]
@@ -647,9 +653,9 @@ def check_small_path(lib, O, vocab, ovocab, seed=53, rounds=40):
 
 
 def check_long_diverse_pieces(lib, O, vocab, ovocab, lens=(3000, 9000, 20000), seed=5):
-    """Pieces of thousands of bytes that merge a few pairs per rank (chains of capitalised words under cl100k: one `\\p{L}+` piece): the
-    rounds hand them to the one-merge-at-a-time tail -- from LDS (<= 16384 parts) and from the global pool (<= 32768 parts) --, next to
-    runs of one letter, which never leave the rounds."""
+    """Long pieces that merge a few pairs per rank (chains of capitalised words under cl100k: one `\\p{L}+` piece), alone and followed by a run of one letter:
+    tkz_bpe_long_tail from its entry points -- k_merge_coop (257..1024 bytes), the giant pieces' workgroup with the state in LDS (<= 16384 parts) and with
+    the ids in the pool (<= 32768 parts), after rounds in global memory beyond."""
     rng = random.Random(seed)
     enc = N.Encoder(vocab, N.CL100K)
     oenc = O.Encoder(ovocab, N.CL100K)
@@ -658,6 +664,24 @@ def check_long_diverse_pieces(lib, O, vocab, ovocab, lens=(3000, 9000, 20000), s
         for text in ("".join(rng.choice(words).capitalize() for _ in range(n // 5))[:n].encode(),
                      ("".join(rng.choice(words).capitalize() for _ in range(n // 10))[:n // 2] + "q" * (n // 2)).encode()):
             assert enc.encode_utf8(text) == oenc.encode_bytes(text), n
+
+
+def check_runs_with_words(lib, O, vocab, ovocab, seed=9):
+    """Runs of one byte (letters whose doubles are keys and letters whose doubles are not, '=', spaces) with a word before, between and behind them: what the
+    proposals of the tail serialise on and its rounds for chains of equal pairs are for; every length class of the three mergers, both o200k readings too."""
+    rng = random.Random(seed)
+    for pattern in (N.CL100K, N.O200K_DOTNET):
+        enc, oenc = N.Encoder(vocab, pattern), O.Encoder(ovocab, pattern)
+        docs = []
+        for n in (260, 700, 1024, 1025, 5000, 17000, 31000):
+            for ch in "neq= ":
+                docs.append((" they" + ch * n).encode())
+                docs.append((" delogicality" + ch * (n // 2) + "Word" + rng.choice("wst") * (n // 2) + "stop").encode())
+            docs.append(("ab" * (n // 2)).encode()); docs.append(("the" * (n // 3) + "quick" * 40).encode())
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        exp, eoff = oracle_encode_docs(oenc, docs)
+        assert ids.tolist() == exp and ooff.tolist() == eoff, pattern
 
 
 def check_errors(lib, O, vocab):
@@ -782,12 +806,12 @@ def random_vocab_bytes(rng, alphabet=b"abc", n_keys=300, max_len=6, rank_step=1,
     return b"".join(base64.b64encode(k) + b" " + str(rank_base + rank_step * i).encode() + b"\n" for i, k in enumerate(keys))
 
 
-def check_random_vocab(lib, O, seed, n_vocabs, lens, n_pieces):
+def check_random_vocab(lib, O, seed, n_vocabs, lens, n_pieces, max_len=6):
     """Every merge path (lean lane, arena lane packed and unpacked, whole-wave rounds in the pool) on adversarial rank tables."""
     rng = random.Random(seed)
     for vi in range(n_vocabs):
         big = vi % 3 == 2                                        # every third vocabulary: sparse ranks up to ~2^26
-        raw = random_vocab_bytes(rng, alphabet=rng.choice([b"ab", b"abc", b"abcd"]), n_keys=rng.choice([20, 100, 400]),
+        raw = random_vocab_bytes(rng, alphabet=rng.choice([b"ab", b"abc", b"abcd"]), n_keys=rng.choice([20, 100, 400]), max_len=max_len,
                                  rank_step=97_003 if big else 1, rank_base=4_200_000 if big else 0)
         vocab, ovocab = N.Vocab(raw, lib), O.Vocab(raw)
         enc = N.Encoder(vocab, N.CL100K)

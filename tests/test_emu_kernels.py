@@ -293,17 +293,20 @@ def test_adversarial_rank_tables(lib, oracle_mod):
     parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=12, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 1024, 1025], n_pieces=60)
 
 
-def test_giant_tail_on_adversarial_rank_tables(oracle_mod):
-    """The batched tail of the giant-piece merger (tkz_bpe_long_tail: one proposal per block of 32 parts, every proposal below the bound
-    applied at once) on rank tables that are NOT trained vocabularies -- new pairs rank below the pair just merged, ranks tie, ranks go up to
-    2^26 --, in a build that hands every giant piece to the tail (the rounds would finish such pieces on their own); from both entry points
-    (state in LDS; ids left in the pool) and on long diverse pieces under a real table."""
-    import emu
-    lib = emu.tail_library()
+def test_giant_tail_on_adversarial_rank_tables(lib, oracle_mod):
+    """The merger of the giant pieces and, one wavefront a piece, of the missed pieces of 257..1024 bytes (tkz_bpe_long_tail: batches of proposals applied
+    together when nothing can disturb them before their turn -- the bound of a proposal is LOCAL, the longest key wide --, rounds for chains of equal pairs)
+    on rank tables that are NOT trained vocabularies -- new pairs rank below the pair just merged, ranks tie, ranks go up to 2^26, keys of 2..6 bytes (a
+    window of one block) and of up to 300 and 1100 (the local bound, the global one) --, from all three entry points (state in LDS; ids left in the pool;
+    k_merge_coop), and on long diverse pieces and runs of one letter with a word before them under a real table."""
     for seed in (0, 1):
-        parity.check_random_vocab(lib, oracle_mod, seed, 3, [1100, 1500, 2300, 4000, 7000], 3)
+        parity.check_random_vocab(lib, oracle_mod, seed, 3, [300, 777, 1024, 1100, 1500, 2300, 4000, 7000], 4)
+    parity.check_random_vocab(lib, oracle_mod, 7, 2, [300, 1024, 3000, 18000], 3, max_len=300)
+    parity.check_random_vocab(lib, oracle_mod, 8, 2, [300, 1024, 3000, 18000], 3, max_len=1100)
     raw = gzip.decompress(open(os.path.join(os.path.dirname(__file__), "golden", "gpt2.tiktoken.gz"), "rb").read())
-    parity.check_long_diverse_pieces(lib, oracle_mod, N.Vocab(raw, lib), oracle_mod.Vocab(raw), lens=(1500, 18000, 33000), seed=3)
+    v, ov = N.Vocab(raw, lib), oracle_mod.Vocab(raw)
+    parity.check_long_diverse_pieces(lib, oracle_mod, v, ov, lens=(300, 1000, 1500, 18000, 33000), seed=3)
+    parity.check_runs_with_words(lib, oracle_mod, v, ov)
 
 
 def test_device_entry_in_two_halves(lib, vocabs, oracle_mod):

@@ -205,7 +205,8 @@ def test_giant_pieces(lib, vocabs, oracle_mod, vname):
     oenc = oracle_mod.Encoder(oracle_gpt2, oracle_mod.CL100K)
     for text in (b"t" * 4000, b"=" * 9000, b" " * 5000 + b"x", b"ab" * 6000, bytes(range(97, 123)) * 400):
         assert enc.encode_utf8(text) == oenc.encode_bytes(text)
-    parity.check_long_diverse_pieces(lib, oracle_mod, vocab, oracle_gpt2, lens=(3000, 9000, 20000, 33000, 50000))
+    parity.check_long_diverse_pieces(lib, oracle_mod, vocab, oracle_gpt2, lens=(300, 1000, 3000, 9000, 20000, 33000, 50000, 100000))
+    parity.check_runs_with_words(lib, oracle_mod, vocab, oracle_gpt2)
 
 
 @pytest.mark.parametrize("pattern,vname", [(1, "gpt2"), (2, "gpt2"), (3, "gpt2"), (4, "gpt2"), (2, "synth100k"), (3, "synth200k"), (4, "synth200k"), (1, "synth200k")])
@@ -461,6 +462,9 @@ def test_adversarial_rank_tables(lib, oracle_mod):
     parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=40, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 1024, 1025, 3000], n_pieces=200)
     # arbitrary rank tables on pieces that start in the global pool and end in the tail that keeps only the pair ranks in LDS
     parity.check_random_vocab(lib, oracle_mod, seed=4, n_vocabs=6, lens=[17000, 20000, 30000, 33000], n_pieces=4)
+    # ... with keys of up to 300 bytes (the local bound of the tail's proposals, a window of ten blocks) and of up to 1100 (the global bound)
+    parity.check_random_vocab(lib, oracle_mod, seed=5, n_vocabs=6, lens=[300, 777, 1024, 3000, 18000, 33000], n_pieces=6, max_len=300)
+    parity.check_random_vocab(lib, oracle_mod, seed=6, n_vocabs=4, lens=[300, 1024, 3000, 18000], n_pieces=6, max_len=1100)
 
 
 def test_device_entry_in_two_halves(lib, vocabs, oracle_mod):

@@ -279,7 +279,7 @@ tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool 
         HIP_TRY(ws->w_doctok.ensure((size_t)((pieces ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
         HIP_TRY(ws->w_dcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_dbase.ensure((size_t)ntiles * 8, acc));
-        HIP_TRY(ws->w_heavyq.ensure((size_t)ntiles + 64, acc));
+        HIP_TRY(ws->w_heavyq.ensure((size_t)ntiles + 64 + (size_t)ntiles / 64 + 64, acc));      // (+ a flag per 64 sub-tiles: k_merge_long -> k_merge_coop)
         HIP_TRY(ws->w_gq.ensure((size_t)(total / kArenaPiece + 2) * 24, acc));     // {position, length} per giant piece + the order they are taken in
         HIP_TRY(ws->w_gcnt.ensure((size_t)ntiles * 4, acc));
         if (!ws->w_pool.p) HIP_TRY(ws->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
@@ -354,7 +354,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.giant_q = ws->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = ws->w_gcnt.as<int32_t>();
             P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
             P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
-            P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
+            P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles; P.coop_flag = P.heavy_flag + ntiles + 64;
             HIP_TRY(hipMemsetAsync(P.heavy_flag, 0, (size_t)ntiles, stream));
             P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
             P.ablate = 0; P.devprof = nullptr;
@@ -411,9 +411,11 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             const double w = h[0] ? (double)h[0] : 1.0;
             fprintf(stderr, "[tkz devprof] k_probe waves %llu  clock ticks/wave: total %.0f  load+compact %.0f  short batches %.0f  mid batches %.0f | mid pieces/wave %.1f pieces/wave %.1f\n",
                     h[0], h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w);
-            if (h[8]) fprintf(stderr, "[tkz devprof] k_giant_merge pieces %llu  clock ticks/piece: global-memory rounds %.0f  LDS rounds %.0f | bytes/piece %.0f tokens/piece %.0f | slowest piece %llu ticks | rounds/piece: global %.0f LDS %.0f | parts/piece when the tail took over %.0f\n",
-                              h[8], (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[12] / h[8], h[13], (double)h[14] / h[8], (double)h[15] / h[8], (double)h[7] / h[8]);
-            if (h[16]) fprintf(stderr, "[tkz devprof] tail: batches %llu merges %llu (%.2f a batch) proposals/batch %.1f | batches capped by two proposals that meet %llu | ticks/batch %.0f | longest tail: %llu batches, %llu ticks\n",
+            if (h[8]) fprintf(stderr, "[tkz devprof] k_giant_merge pieces %llu  clock ticks/piece: rounds in global memory %.0f  the tail %.0f | bytes/piece %.0f tokens/piece %.0f | slowest piece %llu ticks | global rounds/piece %.2f | parts/piece when the tail took over %.0f\n",
+                              h[8], (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[12] / h[8], h[13], (double)h[14] / h[8], (double)h[7] / h[8]);
+            if (h[8]) fprintf(stderr, "[tkz devprof] slowest giant piece: %llu bytes -> %llu tokens, global rounds %llu (%llu ticks), bytes first/middle/last %02llx %02llx %02llx\n",
+                              h[24], h[27], h[25], h[28], h[29] & 255, (h[29] >> 8) & 255, (h[29] >> 16) & 255);
+            if (h[16]) fprintf(stderr, "[tkz devprof] tail: batches %llu merges %llu (%.2f a batch) proposals/batch %.1f | rounds for chains of equal pairs %llu | ticks/batch %.0f | longest tail: %llu batches, %llu ticks\n",
                                h[16], h[17], (double)h[17] / h[16], (double)h[18] / h[16], h[19], (double)h[22] / h[16], h[20], h[23]);
         }
 #endif
@@ -523,7 +525,7 @@ tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, con
     P.giant_q = ws->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = ws->w_gcnt.as<int32_t>();
     P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
     P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
-    P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
+    P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles; P.coop_flag = nullptr;
     P.pool = ws->w_pool.as<int32_t>(); P.pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head)); P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
     P.ablate = 0; P.devprof = nullptr; P.stats = nullptr; P.place128 = 0;
     SmallArgs A{};

@@ -6,9 +6,12 @@
 //                   starts at byte k, pr[k] = packed (rank << 4|5 | k) of the pair (part at k, next
 //                   part) or NOKEY.  One u32 min over the 16 pr slots is the reference's leftmost
 //                   strict-min scan (:47-54): equal ranks tie-break on the lower position.
-//   tkz_bpe_long    one WORKGROUP per piece of any length: the list is a doubly linked list in
-//                   LDS or global scratch, each round is a workgroup-wide min of (rank, position)
-//                   followed by the reference's three updates (:58-63).
+//   tkz_bpe_long    one WORKGROUP per piece of any length (the same code with a workgroup of ONE wavefront for the pieces of
+//                   257..1024 bytes): the parts stay in their slots in LDS (pair ranks, ids, alive bits) and every step
+//                   applies MANY of the reference's merges at once, each exactly as the reference would get to it --
+//                   batches of proposals that provably cannot be disturbed before their turn, rounds for chains of equal
+//                   pairs (tkz_bpe_long_tail); pieces beyond 32 Ki parts are first brought down to that by rounds on
+//                   dense arrays in global memory (tkz_bpe_long_rounds).
 //
 // In both, `ranks.TryGetValue(slice)` of GetRank (:25-36) is a PAIR-table probe on the ids of the two
 // adjacent parts (tkz_tables.h), and the first-level ranks come from the directly indexed two-byte
@@ -505,40 +508,12 @@ TKZ_DEV int tkz_block_exclusive_max(int v) {
 // The rounds, on whatever arrays the state is in.  Runs until no pair has a rank (returns true) or, when stop_at > 0, until the
 // state has shrunk to stop_at parts or fewer (returns false: the caller moves the state to faster memory and calls again).
 // ids / pr are left pointing at the current state, cnt at its length.
-// Is the state dominated by ONE pair rank?  (A run of one letter is: after a few odd merges at its end -- poor rounds -- thousands of equal
-// pairs merge in the next round; a chain of words is not.)  Three probes: the ranks of the pairs at 1/4, 1/2 and 3/4 of the state; a
-// probe that a sixteenth of all pairs share says "homogeneous": such a piece stays with the rounds.  Called by the whole workgroup.
-TKZ_DEV bool tkz_bpe_long_homogeneous(const int32_t* pr, int cnt) {
-    const int tid = simt::tid(), G = simt::nthreads();
-#ifdef TKZ_TAIL_ALWAYS       // (development / test builds: every piece the rounds are slow on -- with TKZ_TAIL_FEW set high: every piece -- goes to the tail)
-    return false;
-#endif
-    if (cnt < 64) return false;
-    const int32_t v1 = pr[cnt / 4], v2 = pr[cnt / 2], v3 = pr[(3 * cnt) / 4];
-    const int c = (cnt + G - 1) / G;
-    const int lo = tid * c < cnt ? tid * c : cnt, hi = lo + c < cnt ? lo + c : cnt;
-    int n1 = 0, n2 = 0, n3 = 0;
-    for (int i = lo; i < hi; ++i) { const int32_t r = pr[i]; n1 += r == v1; n2 += r == v2; n3 += r == v3; }
-    int t1, t2, t3;
-    (void)tkz_block_scan(n1, &t1); (void)tkz_block_scan(n2, &t2); (void)tkz_block_scan(n3, &t3);
-    const int thr = cnt / 16;
-    return (v1 != TKZ_RANK_NONE && t1 >= thr) || (v2 != TKZ_RANK_NONE && t2 >= thr) || (v3 != TKZ_RANK_NONE && t3 >= thr);
-}
-// few / few_cap (> 0): also returns false -- *slow = true -- after kBpeSlowRounds consecutive rounds that merged fewer than `few` pairs each,
-// once the state is down to few_cap parts (such a piece is handed to tkz_bpe_long_tail).
-constexpr int kBpeSlowRounds = 3;
-TKZ_DEV bool tkz_bpe_long_rounds(const TkzTables& T, int& cnt, int32_t*& ids, int32_t*& pr, int32_t*& s1, int32_t* s2, int32_t*& idsN, int32_t* prN, int stop_at, int* rounds = nullptr,
-                                 int few = 0, int few_cap = 0, bool* slow = nullptr) {
+TKZ_DEV bool tkz_bpe_long_rounds(const TkzTables& T, int& cnt, int32_t*& ids, int32_t*& pr, int32_t*& s1, int32_t* s2, int32_t*& idsN, int32_t* prN, int stop_at, int* rounds = nullptr) {
     const int tid = simt::tid(), G = simt::nthreads();
     constexpr int32_t kNotMerge = 0x7FFFFFFE;
-    int nslow = 0;
     for (;;) {
-        if (rounds) ++*rounds;
         if (stop_at > 0 && cnt <= stop_at) return false;
-        if (few > 0 && nslow >= kBpeSlowRounds && cnt <= few_cap) {
-            if (!tkz_bpe_long_homogeneous(pr, cnt)) { *slow = true; return false; }
-            nslow = 0;
-        }
+        if (rounds) ++*rounds;
         const int c = (cnt + G - 1) / G;                  // contiguous block of parts per thread
         const int lo = tid * c < cnt ? tid * c : cnt, hi = lo + c < cnt ? lo + c : cnt;
         // 1. the minimum rank
@@ -600,126 +575,135 @@ TKZ_DEV bool tkz_bpe_long_rounds(const TkzTables& T, int& cnt, int32_t*& ids, in
         // s1 now holds the new pr; make it the pr array of the next round
         { int32_t* t = pr; pr = s1; s1 = t; }
         { int32_t* t = ids; ids = idsN; idsN = t; }
-        nslow = cnt - tot < few ? nslow + 1 : 0;
         cnt = tot;
         simt::sync();
     }
 }
 
-// The same rounds with the state in LDS in its COMPACT form -- ids[cap] | pr[cap] | one flag byte per part (9 bytes per part, so
-// 16 Ki parts fit a CU's LDS) -- for a workgroup of exactly 1024 threads, each owning C = cap / 1024 consecutive parts in a fully
-// unrolled loop (what it computes for its parts stays in registers between the phases).  What a round needs from a merge's
-// neighbours is recomputed by the thread that needs it instead of being passed through scratch arrays:
-//   merge at i (flag[i], i <= istar):  id' = m;  pr' = rank(m, id[i+2])   or rank(m, m) when i+2 merges too      (:58)
-//   part j left of a merge (flag[j+1]): id' = id[j];  pr' = rank(id[j], m)                                      (:59-62)
-//   part right of a merge (flag[j-1]): swallowed                                                               (:63)
-// and the round is cut after the leftmost merge that creates a pair ranked below m, exactly as in tkz_bpe_long_rounds.
-// Returns true when no pair is left, false after kBpeSlowRounds consecutive rounds that merged fewer than `few` pairs each (what is left is
-// then better served by tkz_bpe_long_tail: a diverse piece goes on for thousands of rounds of one or two merges each, ~13 us a round).
-template <int C>
-TKZ_DEV bool tkz_bpe_long_rounds_lds(const TkzTables& T, int& cnt, int32_t* ids, int32_t* pr, uint8_t* flag, int few, int* rounds = nullptr) {
-    const int tid = simt::tid();
-    int nslow = 0;
-    for (;;) {
-        if (rounds) ++*rounds;
-        const int c = (cnt + 1023) >> 10;                 // parts per thread this round (<= C)
-        const int lo = tid * c < cnt ? tid * c : cnt;
-        // 1. the minimum rank
-        int32_t mypr[C], myid[C];
-        uint32_t mymin = (uint32_t)TKZ_RANK_NONE;
-#pragma unroll
-        for (int q = 0; q < C; ++q) {
-            const int i = lo + q;
-            const bool in = q < c && i < cnt;
-            mypr[q] = in ? pr[i] : TKZ_RANK_NONE; myid[q] = in ? ids[i] : 0;
-            mymin = (uint32_t)mypr[q] < mymin ? (uint32_t)mypr[q] : mymin;
-        }
-        const int32_t m = (int32_t)tkz_block_min32(mymin);
-        if (m == TKZ_RANK_NONE) return true;              // (:65-68)
-        // 2. candidates; leftmost first inside a chain of adjacent candidates: every other one, counted from the chain's start
-        int lastNon = -1;
-#pragma unroll
-        for (int q = 0; q < C; ++q) if (q < c && lo + q < cnt && mypr[q] != m) lastNon = lo + q;
-        int ln = tkz_block_exclusive_max(lastNon);
-        uint32_t myflags = 0;
-#pragma unroll
-        for (int q = 0; q < C; ++q) {
-            const int i = lo + q;
-            if (q < c && i < cnt) {
-                if (mypr[q] != m) { ln = i; flag[i] = 0; }
-                else { const bool mg = ((i - (ln + 1)) & 1) == 0; flag[i] = mg ? 1 : 0; myflags |= mg ? (1u << q) : 0u; }
-            }
-        }
-        simt::sync();
-        // 3. the leftmost merge that creates a pair ranked below m: merges beyond it wait for a later round
-        uint32_t firstViol = 0xFFFFFFFFu;
-        int32_t Rv[C];                                    // rank(m, next part) of my merges (the transient pair)
-#pragma unroll
-        for (int q = 0; q < C; ++q) {
-            Rv[q] = TKZ_RANK_NONE;
-            if ((myflags >> q) & 1u) {
-                const int i = lo + q;
-                int32_t L = TKZ_RANK_NONE;
-                if (i >= 1) L = tkz_lookup_pair(T, (i >= 2 && flag[i - 2]) ? (uint32_t)m : (uint32_t)ids[i - 1], (uint32_t)m);
-                if (i + 2 < cnt) Rv[q] = tkz_lookup_pair(T, (uint32_t)m, (uint32_t)ids[i + 2]);
-                if ((L < m || Rv[q] < m) && (uint32_t)i < firstViol) firstViol = (uint32_t)i;
-                // a merging part's own pair rank is m (known): its slot carries rank(left part, m) to whoever needs it in step 4 -- the
-                // part on its left, or a merge two to the left -- instead of a second table round trip there
-                pr[i] = L;
-            }
-        }
-        const uint32_t istar = tkz_block_min32(firstViol);   // (its barriers publish the slots written above)
-        // 4. the new state of my parts, in registers; then compaction in place (everything is read before anything is written)
-        int32_t nid[C], npr[C];
-        int alive = 0;
-        uint32_t keep = 0;
-#pragma unroll
-        for (int q = 0; q < C; ++q) {
-            const int i = lo + q;
-            nid[q] = 0; npr[q] = TKZ_RANK_NONE;
-            if (!(q < c && i < cnt)) continue;
-            if (i >= 1 && flag[i - 1] && (uint32_t)(i - 1) <= istar) continue;                       // swallowed (:63)
-            keep |= 1u << q; ++alive;
-            if (((myflags >> q) & 1u) && (uint32_t)i <= istar) {
-                nid[q] = m;
-                if (i + 2 < cnt) npr[q] = (flag[i + 2] && (uint32_t)(i + 2) <= istar) ? pr[i + 2] : Rv[q];      // rank(m, m) left there by the merge at i + 2
-            } else {
-                nid[q] = myid[q];
-                npr[q] = (i + 1 < cnt && flag[i + 1] && (uint32_t)(i + 1) <= istar) ? pr[i + 1] : mypr[q];          // rank(id, m) left there by the merge at i + 1
-            }
-        }
-        int tot;
-        int o = tkz_block_scan(alive, &tot);              // (its barriers also separate the reads above from the writes below)
-#pragma unroll
-        for (int q = 0; q < C; ++q) if ((keep >> q) & 1u) { ids[o] = nid[q]; pr[o] = npr[q]; ++o; }
-        nslow = cnt - tot < few ? nslow + 1 : 0;         // (ONE poor round says nothing: a run of one letter has a single odd merge between rounds of thousands)
-        cnt = tot;
-        simt::sync();
-        if (nslow >= kBpeSlowRounds) {
-            if (!tkz_bpe_long_homogeneous(pr, cnt)) return false;
-            nslow = 0;
-        }
-    }
-}
-
-// The TAIL of a long diverse piece: the reference's loop itself (BytePairEncoder.cs:45-64), one merge at a time, by ONE wavefront on the
-// state in LDS -- ids[cap] | pr[cap] as the rounds above leave them, plus one alive bit per part and the minimum rank of every block
-// of 32 parts (both in what was the flag area).  A merge is: the minimum over the block minima (a few 16-byte reads per lane and a DPP
-// reduction), the leftmost part of that rank inside the first such block (:47-54), its neighbours through the alive bits, the two pair
-// lookups (:58-62; the same address in every lane: one request), three writes, and the minima of the <= 3 blocks touched: ~1 us, where a round
-// costs ~13 us and a 32 KiB run of words needs ~3000 of them for a handful of merges each.  Parts are never moved: what is left is
-// compacted by the caller.  Workgroups of 1024 threads; wavefront 0 works, the others wait at the barrier behind it.
+// The merger of everything up to kBpeTailCap parts (tkz_bpe_long_tail), by one workgroup on the state in LDS: the parts NEVER MOVE -- a slot per part as the
+// piece began (a byte each, or what the rounds in global memory left), pr[slot] = rank of (part, next alive part), one alive bit a part, ids beside them or
+// in global memory -- and every step applies many of the reference's merges (BytePairEncoder.cs:45-64) at once, each exactly as the reference would get to it:
+//   * a BATCH OF PROPOSALS (below): every thread proposes the smallest pair of each of its sub-blocks, looks up what its merge would create, and the proposals
+//     that provably cannot be disturbed before their turn are applied -- hundreds a batch on diverse text (a 32 KiB chain of words: 37 batches; it took
+//     2,283 when a proposal had to lie below a bound over the WHOLE piece, and ~3,000 rounds of one rank each before that);
+//   * a ROUND FOR THE LOWEST RANK (tkz_tail_chain_round) when a batch merged few: a chain of equal pairs (a run of one letter) serialises the proposals.
+// What is left is compacted by tkz_bpe_long_tail_emit.
 constexpr int kTailBlock = 32;
 constexpr uint32_t kTailDead = 0x80000000u;
-// IDS_LDS: the ids of the parts are in LDS beside pr[] (the state the LDS rounds leave, <= kBpeLongLds parts).  Otherwise (the state the
-// GLOBAL rounds leave, <= kBpeTailCap parts: only pr[] fits LDS): ids[] -- global memory -- holds the ids the parts had when the tail began,
-// and a part that has merged since keeps its id in the slot behind it, which died with its first merge and stays dead (kTailDead | id).
+// IDS_LDS: the ids of the parts are in LDS beside pr[] (<= kBpeLongLds parts).  Otherwise (<= kBpeTailCap parts: only pr[] fits LDS): ids[] -- global
+// memory -- holds the ids the parts had when the tail began, and a part that has merged since keeps its id in the slot behind it, which died with its
+// first merge and stays dead (kTailDead | id).
 template <bool IDS_LDS>
 TKZ_DEV uint32_t tkz_tail_id(const int32_t* ids, const int32_t* pr, const uint32_t* alive, int cnt, int x) {
     if (IDS_LDS) return (uint32_t)ids[x];
     const bool merged = x + 1 < cnt && !((alive[(x + 1) >> 5] >> ((x + 1) & 31)) & 1u);
     return merged ? ((uint32_t)pr[x + 1] & ~kTailDead) : (uint32_t)ids[x];
 }
+// ONE round of tkz_bpe_long_rounds -- every pair of the LOWEST rank gm at once, leftmost first inside a chain of adjacent candidates (every other one,
+// counted from the chain's start), cut after the leftmost merge that creates a pair ranked below gm -- on the tail's state: the parts stay in their slots
+// (alive bits, neighbours by bit scans) instead of being compacted.  The tail's batches below serialise on such chains (a run of one letter inside a long
+// piece: every proposal waits for the pair on its left, which waits for the one on ITS left ...); the tail calls this when a batch of proposals merged few.
+// The position inside a chain is the part's index among the alive parts (a workgroup scan of the alive counts) minus that of the last part before it
+// whose pair is not a candidate (an exclusive maximum over the workgroup), exactly as in the rounds.  What a merge needs from its neighbours:
+//   merge at j (r: the part it swallows, rr: the one behind, l / ll: the ones before):   id' = gm;  pr'[j] = rank(gm, id(rr)), or rank(gm, gm) when rr merges too  (:58)
+//   the part before it: swallowed itself when ll merges; otherwise pr'[l] = rank(id(l), gm)                                                             (:59-62)
+// pass 1 looks up L = rank(left part as it will be, gm) and the transient R = rank(gm, id(rr) as it is) of every merge (violations: L or R below gm) and
+// leaves L in the merging part's own slot; pass 2a, for the merges at or before the cut, computes pr'[j] (the L of the merge at rr, or R) into r's slot --
+// r dies in this round, nobody reads its slot -- and decides, while the alive bits are still whole, whether l survives; pass 2b writes.
+// s_mm: one word a thread (the merge flags of every block).  Returns the number of merges applied (the same in every thread); ends with a barrier.
+template <bool IDS_LDS>
+TKZ_DEV int tkz_tail_chain_round(const TkzTables& T, int cnt, int32_t* ids, int32_t* pr, uint32_t* alive, uint32_t* s_mm, uint32_t gm) {
+    const int tid = simt::tid(), blk = tid;
+    const int nw = (cnt + 31) >> 5;
+    const bool owner = blk < nw;
+    const uint32_t aw = owner ? alive[blk] : 0u;
+    uint32_t cm = 0;                                             // my alive parts whose pair has rank gm
+    if (owner) {
+        const uint4* qp = reinterpret_cast<const uint4*>(pr + blk * kTailBlock);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint4 v = qp[k];
+            cm |= ((v.x == gm ? 1u : 0u) | (v.y == gm ? 2u : 0u) | (v.z == gm ? 4u : 0u) | (v.w == gm ? 8u : 0u)) << (4 * k);
+        }
+        cm &= aw;
+    }
+    int tot;
+    const int base = tkz_block_scan(tkz_popc32(aw), &tot);      // the index of my first alive part among all alive parts
+    const uint32_t non = aw & ~cm;
+    const int lastNon = non ? base + tkz_popc32(aw & tkz_lowmask32(tkz_msb32(non))) : -1;
+    int ln = tkz_block_exclusive_max(lastNon);                   // ... of the last part before my block whose pair is not a candidate
+    uint32_t mm = 0;
+    {
+        int idx = base;
+        for (uint32_t b = aw; b; b &= b - 1, ++idx) {
+            const int i = tkz_ctz32(b);
+            if ((cm >> i) & 1u) { if (((idx - (ln + 1)) & 1) == 0) mm |= 1u << i; }
+            else ln = idx;
+        }
+    }
+    s_mm[tid] = mm;
+    simt::sync();
+    auto next_alive = [&](int x) -> int {                        // the first alive part behind slot x, -1: none
+        int w = (x + 1) >> 5;
+        uint32_t bits = w < nw ? alive[w] & (0xFFFFFFFFu << ((x + 1) & 31)) : 0u;
+        while (!bits && ++w < nw) bits = alive[w];
+        return bits ? 32 * w + tkz_ctz32(bits) : -1;
+    };
+    auto prev_alive = [&](int x) -> int {                        // the last alive part before slot x, -1: none
+        int w = x >> 5;
+        uint32_t bits = alive[w] & tkz_lowmask32(x & 31);
+        while (!bits && --w >= 0) bits = alive[w];
+        return bits ? 32 * w + tkz_msb32(bits) : -1;
+    };
+    auto merges = [&](int x) -> bool { return x >= 0 && ((s_mm[x >> 5] >> (x & 31)) & 1u) != 0; };
+    // pass 1: the two re-ranked pairs of every merge; the leftmost merge that creates a pair ranked below gm
+    uint32_t firstViol = 0xFFFFFFFFu;
+    for (uint32_t b = mm; b; b &= b - 1) {
+        const int j = blk * kTailBlock + tkz_ctz32(b);
+        const int r = next_alive(j);                             // exists: pr[j] was a rank
+        const int rr = next_alive(r);
+        const int l = prev_alive(j);
+        int32_t L = TKZ_RANK_NONE, R = TKZ_RANK_NONE;
+        if (l >= 0) L = tkz_lookup_pair(T, merges(prev_alive(l)) ? gm : tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, l), gm);
+        if (rr >= 0) R = tkz_lookup_pair(T, gm, tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, rr));
+        if ((L < (int32_t)gm || R < (int32_t)gm) && (uint32_t)j < firstViol) firstViol = (uint32_t)j;
+        pr[j] = L;                                               // (a merging part's own pair rank is gm, known: its slot carries L to pass 2)
+    }
+    const uint32_t istar = tkz_block_min32(firstViol);           // merges beyond istar wait (its barriers publish the slots written above)
+    // pass 2a: pr'[j] into r's slot; does l survive?  (alive bits still whole)
+    uint32_t wl = 0;
+    for (uint32_t b = mm; b; b &= b - 1) {
+        const int i = tkz_ctz32(b), j = blk * kTailBlock + i;
+        if ((uint32_t)j > istar) continue;
+        const int r = next_alive(j), rr = next_alive(r);
+        int32_t npr = TKZ_RANK_NONE;
+        if (rr >= 0) npr = (merges(rr) && (uint32_t)rr <= istar) ? pr[rr] : tkz_lookup_pair(T, gm, tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, rr));
+        pr[r] = npr;
+        const int l = prev_alive(j);
+        if (l >= 0 && !merges(prev_alive(l))) wl |= 1u << i;
+    }
+    simt::sync();
+    // pass 2b: the writes
+    int nm = 0;
+    for (uint32_t b = mm; b; b &= b - 1) {
+        const int i = tkz_ctz32(b), j = blk * kTailBlock + i;
+        if ((uint32_t)j > istar) { pr[j] = (int32_t)gm; continue; }       // cut: the pair waits, with its rank
+        const int r = next_alive(j);                             // (only this merge clears r's bit)
+        const int32_t L = pr[j], npr = pr[r];
+        const int l = ((wl >> i) & 1u) ? prev_alive(j) : -1;     // (a part that survives keeps its bit: the scan finds it whatever the others clear)
+        simt::atomic_and(&alive[r >> 5], ~(1u << (r & 31)));     // RemoveAt(j + 1) (:63)
+        pr[r] = TKZ_RANK_NONE;
+        if (IDS_LDS) ids[j] = (int32_t)gm;
+        else pr[j + 1] = (int32_t)(kTailDead | gm);              // (the slot behind j: dead since this part's first merge, r == j + 1 then)
+        pr[j] = npr;
+        if (l >= 0) pr[l] = L;
+        ++nm;
+    }
+    int merged;
+    (void)tkz_block_scan(nm, &merged);                           // (ends with a barrier)
+    return merged;
+}
+
 // Many merges per round trip, exactly.  Thread b of the workgroup owns block b (32 consecutive slots) and proposes the block's smallest
 // pair (rank, then position): its neighbours, their ids and the two pair ranks the merge would create are looked up by all threads at
 // once -- one trip to the pair table for up to 1024 merges instead of one each.  Which of them may be applied NOW is decided from
@@ -728,96 +712,181 @@ TKZ_DEV uint32_t tkz_tail_id(const int32_t* ids, const int32_t* pr, const uint32
 // order (BytePairEncoder.cs:47-54) -- the leftmost minimum of the whole piece with the neighbourhood it was looked up in: nothing that is
 // not itself such a proposal can precede it.  Two proposals interfere exactly when the part of one is among the two parts behind the other
 // (the one it swallows, the one it is paired with next): tau is capped at the later of the two.  The global minimum is always applied.
-// Keys: rank << 10 | block, 64 bits (<= 1024 blocks; equal keys count as "not below": the next batch takes them).
-// scratch: 8 * nthreads + 2 * nthreads + 16 * (nthreads / 64) bytes of LDS behind the alive bits.
+// Keys: rank << 15 | slot, 64 bits (slots < kBpeTailCap = 2^15: the reference's order -- rank, then position -- exactly; equal keys count
+// as "not below").
+//
+// Several proposals a thread (kTailSubs: one per sub-block of 32 / kTailSubs slots, the thread's bound the minimum over them): a trip to
+// the pair table costs the same for four lookups as for one, and a sub-block of 8 slots seldom holds two pairs of the lowest ranks.
+//
+// tau is LOCAL when the vocabulary's keys are short (max_key_len <= kTailLocalKeyMax, every published vocabulary): the minimum of the bounds of the
+// blocks within max_key_len slots of the proposal's neighbourhood only -- one block in a thousand with a low bound no longer holds back the
+// other 999.  Why that is exact, for ANY rank table:
+// let s = (j, r) be a proposal with key k, l / rr the parts before and behind it, and suppose every block that owns a slot in
+// [l - max_key_len, rrr + max_key_len] (rrr: the part after rr) has bound > k.  Everything the reference merges while s is waiting has a key below k
+// (it takes the minimum each time, :47-54).  Take the FIRST such merge that touches l, j, r or rr.  Either both its parts are as they are now
+// -- then it is (ll, l), (l, j), (r, rr) or (rr, rrr), a pair that exists now: the proposal of its sub-block (then the two proposals meet and
+// the later one is capped, as before) or a pair at or above that block's bound > k -- or one of its parts is l or rr, unchanged, and the other
+// a part P formed since, ending right before l or starting at rrr.  P is a token: at most max_key_len bytes, so at most that many slots (a slot
+// was a part of >= 1 byte when the tail began, and slots never move), and every merge that went into P lies inside the window, below k.  The
+// first of THOSE that is not a pair existing now pairs the result of a now-existing pair o (key < k, hence a proposal, since its
+// block's bound > k) with (a) an unchanged neighbour -- but those two ranks were looked up and are part of o's bound > k --, or (b) the result
+// of another proposal below k next to it -- but two proposals that meet cap the bound of the left one's block at the later of the two, < k.
+// Contradiction: nothing touches s's neighbourhood before s's turn, and s merges then exactly as looked up now; and the pairs its merge
+// creates lie above k (they are part of its own bound), so nothing that was to come before s is displaced by merging s early.  (The global
+// minimum g is applied whatever the bounds say.)  Slots, not bytes, measure the window: it is wider than needed, never narrower.
+// scratch: (4 * kTailSubs + 8) * nthreads + 16 * (nthreads / 64) + 16 bytes of LDS behind the alive bits.
+#ifndef TKZ_TAIL_SUBS
+#define TKZ_TAIL_SUBS 4
+#endif
+constexpr int kTailSubs = TKZ_TAIL_SUBS, kTailSB = kTailBlock / kTailSubs;
+constexpr int kTailChainFew = 8;          // a batch of proposals that merges fewer pairs than this is followed by a round for the lowest rank (tkz_tail_chain_round)
+constexpr int kTailLocalKeyMax = 1024;    // (beyond: the window would be most of the piece anyway)
+constexpr int kTailPosBits = 15;
+static_assert(kTailBlock == 32 && kTailSubs * kTailSB == kTailBlock && (kTailSB & (kTailSB - 1)) == 0, "sub-blocks tile a block of 32 slots");
 template <bool IDS_LDS>
 TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_t* pr, uint32_t* alive, void* scratch, unsigned long long* prof = nullptr) {
     const int tid = simt::tid(), lane = simt::lane(), wave = simt::wave(), G = simt::nthreads();
     const int nblk = (cnt + kTailBlock - 1) / kTailBlock, nw = (cnt + 31) >> 5;       // (nblk <= G: cnt <= kBpeTailCap, 1024 threads)
     constexpr uint32_t NONE = (uint32_t)TKZ_RANK_NONE;
+    constexpr uint32_t NOPROP = 0xFFFFFFFFu;
     constexpr uint64_t NOKEY = ~0ull;                           // (keys: 64 bits -- ranks go up to TKZ_MAX_RANK = 2^27)
-    uint64_t* s_key = reinterpret_cast<uint64_t*>(scratch);
-    uint16_t* s_j = reinterpret_cast<uint16_t*>(s_key + G);
-    uint64_t* s_red = reinterpret_cast<uint64_t*>(s_j + G);
+    uint32_t* s_prop = reinterpret_cast<uint32_t*>(scratch);    // the proposal of every sub-block: rank << 5 | slot inside its block of 32, or NOPROP
+    uint64_t* s_bound = reinterpret_cast<uint64_t*>(s_prop + G * kTailSubs);
+    uint64_t* s_red = s_bound + G;
     auto wave_min_key = [](uint64_t v) -> uint64_t {
         const uint32_t hi = (uint32_t)(v >> 32), mh = simt::wave_min_u32(hi);
         const uint32_t ml = simt::wave_min_u32(hi == mh ? (uint32_t)v : 0xFFFFFFFFu);
         return ((uint64_t)mh << 32) | ml;
     };
-    auto make_key = [](uint32_t rank, int blk) -> uint64_t { return rank >= (uint32_t)TKZ_RANK_NONE ? ~0ull : (((uint64_t)rank << 10) | (uint64_t)(uint32_t)blk); };
+    auto make_key = [](uint32_t rank, int slot) -> uint64_t { return rank >= (uint32_t)TKZ_RANK_NONE ? ~0ull : (((uint64_t)rank << kTailPosBits) | (uint64_t)(uint32_t)slot); };
     // (the last part never has a pair: its pr is TKZ_RANK_NONE already; slots beyond cnt are padded so that whole blocks can be read)
     for (int i = cnt + tid; i < nblk * kTailBlock; i += G) pr[i] = TKZ_RANK_NONE;
     for (int w = tid; w < nw; w += G) alive[w] = tkz_lowmask32(cnt - 32 * w);
+    if (tid == 0) { reinterpret_cast<int*>(s_red + 2 * (G >> 6))[0] = 0; reinterpret_cast<int*>(s_red + 2 * (G >> 6))[1] = 0; }
     simt::sync();
-    static_assert(kTailBlock == 32, "eight quads a block");
+#ifdef TKZ_TAIL_GLOBAL_TAU       // (development builds: the global tau whatever the vocabulary)
+    const bool local = false;
+#else
+    const bool local = T.max_key_len <= kTailLocalKeyMax;
+#endif
+    const int reach = T.max_key_len;
     const int blk = tid;
     const bool owner = blk < nblk;
-    long long n_batch = 0, n_merge = 0, n_cand = 0, n_cap = 0;
+    long long n_batch = 0, n_merge = 0, n_cand = 0, n_chain = 0;
     const long long tq0 = prof ? simt::clock() : 0;
+    int* s_cnt = reinterpret_cast<int*>(s_red + 2 * (G >> 6));  // merges of the batch: two counters, taken in turn (the one not in use is reset between two barriers)
+    int it = 0;
+    bool chain = false;                                          // the next step is a round for the lowest rank (the same in every thread)
     for (;;) {
-        // ---- the block's smallest pair (leftmost of its rank) and its second smallest ----
+        if (chain) {
+            uint32_t mymin = NONE;
+            if (owner) {
+                const uint4* qp = reinterpret_cast<const uint4*>(pr + blk * kTailBlock);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const uint4 v = qp[k]; mymin = tkz_min3u(mymin, v.x < v.y ? v.x : v.y, v.z < v.w ? v.z : v.w); }
+            }
+            const uint32_t gm = tkz_block_min32(mymin);
+            if (gm >= NONE) break;                               // minRank == int.MaxValue (:65-68)
+            const int merged = tkz_tail_chain_round<IDS_LDS>(T, cnt, ids, pr, alive, s_prop, gm);
+            if (prof && tid == 0) { ++n_chain; n_merge += merged; }
+            chain = merged >= kTailChainFew;                     // (a run collapsing: stay with the rounds; else back to the proposals)
+            continue;
+        }
+        // ---- every sub-block's smallest pair (leftmost of its rank) and its second smallest ----
         // (a dead slot holds TKZ_RANK_NONE or kTailDead | id: as unsigned values both lie at or above TKZ_RANK_NONE)
-        uint32_t m = NONE, s2 = NONE;
-        int jj = 0;
+        uint32_t m[kTailSubs], s2[kTailSubs];
+        int jj[kTailSubs], j2[kTailSubs];
+#pragma unroll
+        for (int q = 0; q < kTailSubs; ++q) { m[q] = NONE; s2[q] = NONE; jj[q] = 0; j2[q] = 0; }
         if (owner) {
-            const uint4* q = reinterpret_cast<const uint4*>(pr + blk * kTailBlock);
+            const uint4* qp = reinterpret_cast<const uint4*>(pr + blk * kTailBlock);
             uint4 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = q[k];             // (eight 16-byte reads, requested together)
+            for (int k = 0; k < 8; ++k) v[k] = qp[k];            // (eight 16-byte reads, requested together)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const uint32_t w4[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    const int e = 4 * k + i, q = e / kTailSB;
                     const uint32_t x = w4[i];
-                    if (x < m) { s2 = m; m = x; jj = 4 * k + i; } else if (x < s2) s2 = x;
+                    if (x < m[q]) { s2[q] = m[q]; j2[q] = jj[q]; m[q] = x; jj[q] = e; } else if (x < s2[q]) { s2[q] = x; j2[q] = e; }
                 }
             }
         }
-        const uint64_t k1 = make_key(m, blk), key2 = make_key(s2, blk);
-        const bool cand = k1 != NOKEY;
-        const int j = blk * kTailBlock + jj;
-        s_key[tid] = k1;
-        s_j[tid] = (uint16_t)j;
-        // ---- the neighbours of the proposal, and what its merge would create ----
-        uint64_t bound = NOKEY;
-        bool hasl = false, hasr = false;
-        int r = 0, l = 0, rr = -1;
-        int32_t rkr = TKZ_RANK_NONE, rkl = TKZ_RANK_NONE;
-        if (cand) {
-            // r: the part being swallowed (the next one alive after j), rr: the one after it, l: the one before j
-            int w = (j + 1) >> 5;
-            uint32_t bits = w < nw ? alive[w] & (0xFFFFFFFFu << ((j + 1) & 31)) : 0u;
-            while (!bits && ++w < nw) bits = alive[w];
-            r = 32 * w + tkz_ctz32(bits);                        // exists: pr[j] was a rank
-            bits &= bits - 1;
-            while (!bits && ++w < nw) bits = alive[w];
-            hasr = bits != 0;
-            rr = hasr ? 32 * w + tkz_ctz32(bits) : -1;
-            w = j >> 5;
-            bits = alive[w] & tkz_lowmask32(j & 31);
-            while (!bits && --w >= 0) bits = alive[w];
-            hasl = bits != 0;
-            l = hasl ? 32 * w + tkz_msb32(bits) : 0;
-            const uint32_t idr = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, hasr ? rr : 0), idl = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, l);
-            rkr = hasr ? tkz_lookup_pair(T, m, idr) : TKZ_RANK_NONE;        // (:58)
-            rkl = hasl ? tkz_lookup_pair(T, idl, m) : TKZ_RANK_NONE;        // (:59-62)
-            const uint64_t nkr = make_key((uint32_t)rkr, j >> 5), nkl = make_key((uint32_t)rkl, l >> 5);
-            bound = key2 < nkr ? key2 : nkr;
-            if (nkl < bound) bound = nkl;
+        // (what a proposal needs after the barriers is kept small: its key -- rank and slot --, its bound, r / rr / l (-1: none), the two looked-up ranks)
+        uint64_t k1[kTailSubs], bound[kTailSubs];
+        int r[kTailSubs], l[kTailSubs], rr[kTailSubs];
+        int32_t rkr[kTailSubs], rkl[kTailSubs];
+        int wlo = blk, whi = blk;
+        uint64_t mykey = NOKEY;
+#pragma unroll
+        for (int q = 0; q < kTailSubs; ++q) {
+            const int jq = blk * kTailBlock + jj[q];
+            k1[q] = make_key(m[q], jq);
+            const bool cand = k1[q] != NOKEY;
+            s_prop[tid * kTailSubs + q] = cand ? ((m[q] << 5) | (uint32_t)jj[q]) : NOPROP;
+            mykey = k1[q] < mykey ? k1[q] : mykey;
+            // ---- the neighbours of the proposal, and what its merge would create ----
+            bound[q] = NOKEY; r[q] = -1; l[q] = -1; rr[q] = -1; rkr[q] = TKZ_RANK_NONE; rkl[q] = TKZ_RANK_NONE;
+            if (cand) {
+                // r: the part being swallowed (the next one alive after j), rr: the one after it, l: the one before j
+                int w = (jq + 1) >> 5;
+                uint32_t bits = w < nw ? alive[w] & (0xFFFFFFFFu << ((jq + 1) & 31)) : 0u;
+                while (!bits && ++w < nw) bits = alive[w];
+                r[q] = 32 * w + tkz_ctz32(bits);                 // exists: pr[j] was a rank
+                bits &= bits - 1;
+                while (!bits && ++w < nw) bits = alive[w];
+                const bool hasr = bits != 0;
+                rr[q] = hasr ? 32 * w + tkz_ctz32(bits) : -1;
+                if (local) {                                     // the window's right end: max_key_len slots beyond the part after rr (rr, or r, when there is none)
+                    int last = hasr ? rr[q] : r[q];
+                    if (hasr) {
+                        bits &= bits - 1;
+                        while (!bits && ++w < nw) bits = alive[w];
+                        if (bits) last = 32 * w + tkz_ctz32(bits) + reach;
+                    }
+                    const int hi = (last < cnt - 1 ? last : cnt - 1) >> 5;
+                    whi = hi > whi ? hi : whi;
+                }
+                w = jq >> 5;
+                bits = alive[w] & tkz_lowmask32(jq & 31);
+                while (!bits && --w >= 0) bits = alive[w];
+                const bool hasl = bits != 0;
+                l[q] = hasl ? 32 * w + tkz_msb32(bits) : -1;
+                if (local && hasl) { const int lo = (l[q] - reach > 0 ? l[q] - reach : 0) >> 5; wlo = lo < wlo ? lo : wlo; }
+                const uint32_t idr = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, hasr ? rr[q] : 0), idl = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, hasl ? l[q] : 0);
+                rkr[q] = hasr ? tkz_lookup_pair(T, m[q], idr) : TKZ_RANK_NONE;        // (:58)
+                rkl[q] = hasl ? tkz_lookup_pair(T, idl, m[q]) : TKZ_RANK_NONE;        // (:59-62)
+                const uint64_t key2 = make_key(s2[q], blk * kTailBlock + j2[q]);
+                const uint64_t nkr = make_key((uint32_t)rkr[q], jq), nkl = make_key((uint32_t)rkl[q], hasl ? l[q] : 0);
+                bound[q] = key2 < nkr ? key2 : nkr;
+                if (nkl < bound[q]) bound[q] = nkl;
+            }
         }
         simt::sync();                                            // (every proposal is posted)
-        if (cand) {
-            auto meets = [&](int p) {
-                const int f = p >> 5;
-                if (p < 0 || f == blk) return;
-                const uint64_t kf = s_key[f];
-                if (kf != NOKEY && (int)s_j[f] == p) { const uint64_t later = kf > k1 ? kf : k1; if (later < bound) bound = later; }
-            };
-            meets(r); meets(rr);
+        if (tid == 0) s_cnt[(it + 1) & 1] = 0;
+        uint64_t mybound = NOKEY;
+#pragma unroll
+        for (int q = 0; q < kTailSubs; ++q) {
+            if (k1[q] != NOKEY) {
+                auto meets = [&](int p) {
+                    if (p < 0) return;
+                    const int f = p / kTailSB;
+                    if (f == tid * kTailSubs + q) return;
+                    const uint32_t pf = s_prop[f];
+                    if (pf != NOPROP && (f / kTailSubs) * kTailBlock + (int)(pf & 31u) == p) {
+                        const uint64_t kf = make_key(pf >> 5, p), later = kf > k1[q] ? kf : k1[q];
+                        if (later < bound[q]) bound[q] = later;
+                    }
+                };
+                meets(r[q]); meets(rr[q]);
+            }
+            mybound = bound[q] < mybound ? bound[q] : mybound;
         }
+        s_bound[tid] = mybound;
         {
-            const uint64_t wg = wave_min_key(k1), wt = wave_min_key(bound);
+            const uint64_t wg = wave_min_key(mykey), wt = wave_min_key(mybound);
             if (lane == 0) { s_red[2 * wave] = wg; s_red[2 * wave + 1] = wt; }
         }
         simt::sync();
@@ -828,26 +897,41 @@ TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_
             g = wave_min_key(a); tau = wave_min_key(c);
         }
         if (g == NOKEY) break;                                   // minRank == int.MaxValue (:65-68)
-        const bool go = cand && (k1 == g || k1 < tau);
-        if (prof) {                                              // (development builds: how many merges a trip to the pair table buys)
-            const int ng = tkz_popc64(simt::ballot(go)), nc = tkz_popc64(simt::ballot(cand));
-            if (tid == 0) ++n_batch;
-            if (lane == 0) { n_merge += ng; n_cand += nc; }
+        if (local && mykey != NOKEY) {                           // the bounds of the window's blocks only (s_bound: published by the barrier above)
+            tau = NOKEY;
+            for (int f = wlo; f <= whi; ++f) { const uint64_t bf = s_bound[f]; tau = bf < tau ? bf : tau; }
         }
-        if (go) {
-            simt::atomic_and(&alive[r >> 5], ~(1u << (r & 31)));   // RemoveAt(j + 1) (:63)  (two threads may clear bits of one word)
-            pr[r] = TKZ_RANK_NONE;
-            if (IDS_LDS) ids[j] = (int32_t)m;                    // the merged part carries the rank it was found under ...
-            else pr[j + 1] = (int32_t)(kTailDead | m);           // ... in the slot behind it (dead since this part's first merge: r == j + 1 then)
-            pr[j] = rkr;
-            if (hasl) pr[l] = rkl;
+        {
+            int tg = 0, tc = 0;
+#pragma unroll
+            for (int q = 0; q < kTailSubs; ++q) { tg += tkz_popc64(simt::ballot(k1[q] != NOKEY && (k1[q] == g || k1[q] < tau))); if (prof) tc += tkz_popc64(simt::ballot(k1[q] != NOKEY)); }
+            if (lane == 0 && tg) simt::atomic_add(&s_cnt[it & 1], tg);
+            if (prof) {                                          // (development builds: how many merges a trip to the pair table buys)
+                if (tid == 0) ++n_batch;
+                if (lane == 0) { n_merge += tg; n_cand += tc; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kTailSubs; ++q) {
+            if (k1[q] != NOKEY && (k1[q] == g || k1[q] < tau)) {
+                const int jq = (int)(k1[q] & ((1u << kTailPosBits) - 1u));
+                const uint32_t mq = (uint32_t)(k1[q] >> kTailPosBits);
+                simt::atomic_and(&alive[r[q] >> 5], ~(1u << (r[q] & 31)));   // RemoveAt(j + 1) (:63)  (several threads may clear bits of one word)
+                pr[r[q]] = TKZ_RANK_NONE;
+                if (IDS_LDS) ids[jq] = (int32_t)mq;              // the merged part carries the rank it was found under ...
+                else pr[jq + 1] = (int32_t)(kTailDead | mq);     // ... in the slot behind it (dead since this part's first merge: r == j + 1 then)
+                pr[jq] = rkr[q];
+                if (l[q] >= 0) pr[l[q]] = rkl[q];
+            }
         }
         simt::sync();
+        chain = s_cnt[it & 1] < kTailChainFew;                   // few merges: a chain of equal pairs may be holding the proposals back
+        ++it;
     }
     if (prof && lane == 0) {
         simt::atomic_add64(&prof[17], (unsigned long long)n_merge); simt::atomic_add64(&prof[18], (unsigned long long)n_cand);
         if (tid == 0) {
-            simt::atomic_add64(&prof[16], (unsigned long long)n_batch); simt::atomic_add64(&prof[19], (unsigned long long)n_cap);
+            simt::atomic_add64(&prof[16], (unsigned long long)n_batch); simt::atomic_add64(&prof[19], (unsigned long long)n_chain);
             simt::atomic_max64(&prof[20], (unsigned long long)n_batch);
             simt::atomic_add64(&prof[22], (unsigned long long)(simt::clock() - tq0)); simt::atomic_max64(&prof[23], (unsigned long long)(simt::clock() - tq0));
         }
@@ -874,22 +958,18 @@ TKZ_DEV int tkz_bpe_long_tail_emit(int cnt, const int32_t* ids, const int32_t* p
     return tot;
 }
 
-// lds: 9 * kBpeLongLds bytes of LDS (workgroups of 1024 threads) or null.  The state starts in the global arrays when the piece is
-// longer than kBpeLongLds parts and MOVES INTO LDS as soon as it has shrunk to that: a round is ten passes over the state and as
-// many workgroup barriers, and most rounds of a long diverse piece (one per distinct rank) happen when a few thousand parts are
-// left -- in L2 / Infinity Cache a round costs ~25 us, in LDS ~5.
+// lds: kBpeLongLdsBytes bytes of LDS (workgroups of 1024 threads) or null.  A piece of up to kBpeLongLds bytes has its whole state in LDS from the start;
+// up to kBpeTailCap parts, its pair ranks (the ids stay in the global arrays); a longer one is first brought down to kBpeTailCap parts by the rounds on the
+// global arrays (~150 us a round, ONE rank a round: a run of one letter halves in a round, a diverse piece of that size crawls -- the known cliff of this
+// path).  Without LDS (any other workgroup shape): the rounds to the end.
 constexpr int kBpeLongLds = 16384;
-#ifndef TKZ_TAIL_FEW
-#define TKZ_TAIL_FEW 16
-#endif
-#ifndef TKZ_TAIL_FEW_GLOBAL
-#define TKZ_TAIL_FEW_GLOBAL 256
-#endif
-constexpr int kBpeTailFew = TKZ_TAIL_FEW;      // rounds in LDS that merge fewer pairs than this (three in a row) hand the piece to the one-merge-at-a-time tail
-constexpr int kBpeTailFewGlobal = TKZ_TAIL_FEW_GLOBAL;   // ... rounds in global memory (~150 us each, ten times an LDS round)
-constexpr int kBpeTailCap = 32768;             // parts whose pair ranks and alive bits, with the tail's scratch, fit the 9 * kBpeLongLds bytes of LDS (one thread a block of 32)
-static_assert(kBpeLongLds / 8 + (kBpeLongLds / 32 + 64) * 4 <= kBpeLongLds, "alive bits + block minima fit the flag area");
-static_assert(kBpeTailCap * 4 + kBpeTailCap / 8 + 1024 * 10 + 16 * 16 <= 9 * kBpeLongLds && kBpeTailCap / 32 <= 1024, "the tail's state for kBpeTailCap parts (pair ranks, alive bits, scratch of 1024 threads) fits the workgroup's LDS");
+constexpr int kBpeTailCap = 32768;             // parts whose pair ranks and alive bits, with the tail's scratch, fit the workgroup's LDS (one thread a block of 32)
+constexpr int kBpeTailScratch = (4 * kTailSubs + 8) * 1024 + 16 * 16 + 16;  // (tkz_bpe_long_tail: proposals, bounds, the two reductions, the batch's merge count; 1024 threads)
+// the workgroup's LDS: the tail's state (pair ranks of kBpeTailCap parts, or ids and pair ranks of kBpeLongLds; alive bits; scratch)
+constexpr int kBpeLongLdsBytes = (kBpeTailCap * 4 + kBpeTailCap / 8 + kBpeTailScratch + 15) & ~15;
+static_assert(kBpeLongLdsBytes >= 8 * kBpeLongLds + kBpeLongLds / 8 + kBpeTailScratch, "ids and pair ranks of kBpeLongLds parts fit too");
+static_assert(kBpeTailCap / 32 <= 1024 && kBpeTailCap <= (1 << kTailPosBits), "one thread a block of 32 slots; a slot index fits the key");
+static_assert(kBpeLongLdsBytes + 64 <= 160 * 1024, "gfx950: 160 KB of LDS a workgroup");
 template <class ByteAt>
 TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, int32_t* prA, int32_t* s1g, int32_t* s2g,
                          int32_t* idsB, int32_t* prB, int32_t* dst, int* err, int32_t* lds = nullptr, unsigned long long* prof = nullptr) {
@@ -907,52 +987,35 @@ TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, in
     int cnt = n;
     bool done = false;
     long long t0 = prof ? simt::clock() : 0, t1 = t0;
-    int rg = 0, rl = 0;
+    int rg = 0;
     auto finish_prof = [&](int tokens) {
         if (prof && tid == 0) {
             const long long t2 = simt::clock();
             simt::atomic_add64(&prof[8], 1ull); simt::atomic_add64(&prof[9], (unsigned long long)(t1 - t0)); simt::atomic_add64(&prof[10], (unsigned long long)(t2 - t1));
             simt::atomic_add64(&prof[11], (unsigned long long)n); simt::atomic_add64(&prof[12], (unsigned long long)tokens);
             simt::atomic_max64(&prof[13], (unsigned long long)(t2 - t0));
-            simt::atomic_add64(&prof[14], (unsigned long long)rg); simt::atomic_add64(&prof[15], (unsigned long long)rl);
+            if ((unsigned long long)(t2 - t0) >= prof[13]) { prof[24] = (unsigned long long)n; prof[25] = (unsigned long long)rg; prof[27] = (unsigned long long)tokens; prof[28] = (unsigned long long)(t1 - t0); prof[29] = at(0) | (at(n / 2) << 8) | ((unsigned long long)at(n - 1) << 16); }   // (the slowest piece: racy, development only)
+            simt::atomic_add64(&prof[14], (unsigned long long)rg);
         }
     };
-    if (!start_in_lds) {
+    if (!start_in_lds && (!use_lds || cnt > kBpeTailCap)) {
         int32_t* s1 = s1g; int32_t* idsN = idsB;
-        bool slow = false;
-        done = tkz_bpe_long_rounds(T, cnt, ids, pr, s1, s2g, idsN, prB, use_lds ? kBpeLongLds : 0, prof ? &rg : nullptr,
-                                   use_lds ? kBpeTailFewGlobal : 0, kBpeTailCap, &slow);
-        if (prof) t1 = simt::clock();
-        if (!done && slow) {
-            // A diverse piece: the rounds in global memory merge a handful of pairs each at ~150 us a round, and the piece is still too long
-            // for the LDS rounds.  Its pair ranks alone fit LDS (4 bytes a part, up to kBpeTailCap parts): the tail takes it from here, the ids
-            // the parts have now staying where they are, in global memory.
-            int32_t* lpr = lds;
-            uint32_t* alive = reinterpret_cast<uint32_t*>(lds + kBpeTailCap);
-            void* bmin = alive + kBpeTailCap / 32;                // (the tail's scratch)
+        done = tkz_bpe_long_rounds(T, cnt, ids, pr, s1, s2g, idsN, prB, use_lds ? kBpeTailCap : 0, prof ? &rg : nullptr);
+    }
+    if (prof) t1 = simt::clock();
+    if (!done) {                                          // (use_lds, cnt <= kBpeTailCap)
+        int32_t* lpr = pr;
+        uint32_t* alive = reinterpret_cast<uint32_t*>(lds + 2 * kBpeLongLds);
+        if (!start_in_lds) {                              // the pair ranks move into LDS (4 bytes a part), the ids the parts have now stay in global memory
+            lpr = lds; alive = reinterpret_cast<uint32_t*>(lds + kBpeTailCap);
             for (int k = tid; k < cnt; k += G) lpr[k] = pr[k];
             simt::sync();
-            if (prof && tid == 0) simt::atomic_add64(&prof[7], (unsigned long long)cnt);
-            tkz_bpe_long_tail<false>(T, cnt, ids, lpr, alive, bmin, prof);
-            const int tot = tkz_bpe_long_tail_emit<false>(cnt, ids, lpr, alive, dst, err);
-            finish_prof(tot);
-            return tot;
         }
-        if (!done) {                                     // the state fits LDS now: move it
-            for (int k = tid; k < cnt; k += G) { lds[k] = ids[k]; lds[kBpeLongLds + k] = pr[k]; }
-            simt::sync();
-            ids = lds; pr = lds + kBpeLongLds;
-        }
-    }
-    bool tail = false;
-    if (!done) tail = !tkz_bpe_long_rounds_lds<kBpeLongLds / 1024>(T, cnt, ids, pr, reinterpret_cast<uint8_t*>(lds + 2 * kBpeLongLds), kBpeTailFew, prof ? &rl : nullptr);
-    if (tail) {
-        // what the rounds left: one merge at a time, by one wavefront (tkz_bpe_long_tail); then the survivors, in order
-        uint32_t* alive = reinterpret_cast<uint32_t*>(lds + 2 * kBpeLongLds);              // (the flag area: cap bytes = alive bits + block minima)
-        void* bmin = alive + kBpeLongLds / 32;                    // (the tail's scratch)
+        void* scratch = alive + (start_in_lds ? kBpeLongLds : kBpeTailCap) / 32;
         if (prof && tid == 0) simt::atomic_add64(&prof[7], (unsigned long long)cnt);
-        tkz_bpe_long_tail<true>(T, cnt, ids, pr, alive, bmin, prof);
-        const int tot = tkz_bpe_long_tail_emit<true>(cnt, ids, pr, alive, dst, err);
+        int tot;
+        if (start_in_lds) { tkz_bpe_long_tail<true>(T, cnt, ids, lpr, alive, scratch, prof); tot = tkz_bpe_long_tail_emit<true>(cnt, ids, lpr, alive, dst, err); }
+        else { tkz_bpe_long_tail<false>(T, cnt, ids, lpr, alive, scratch, prof); tot = tkz_bpe_long_tail_emit<false>(cnt, ids, lpr, alive, dst, err); }
         finish_prof(tot);
         return tot;
     }

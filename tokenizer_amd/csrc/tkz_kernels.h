@@ -20,6 +20,7 @@ constexpr int kDenseCap = 256 * kMergeGroup;   // tokens of merged short pieces 
 constexpr int kArenaDwords = 2560;  // LDS arena of k_merge_long: a long miss of a batch gets its bytes + 1 dword + 1 bit per byte out of it (2 dwords per byte for
                                     // vocabularies with ranks of 2^21 and more, which keep an ids[] array: tkz_bpe.h)
 constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (256 + tkz_bpe_var_dwords(1024) = 2336 <= kArenaDwords)
+constexpr int kLanePiece = 256;    // ... but a missed piece longer than this is merged by a whole wavefront (k_merge_coop): one lane takes ~n^2 steps, and the kernel waits for it
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan
@@ -60,6 +61,7 @@ struct EncodeParams {
     unsigned long long* giant_ticket;       // k_giant_merge: next entry of the (longest first) order, giant_q[2 * giant_cap + t], to be taken
     // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE bit 4): per-phase clock counters of k_probe.  Compiled out of libtkz.so otherwise.
     unsigned long long* devprof;
+    uint8_t* coop_flag;                 // [nsub / 64 + 1] chunks of 64 sub-tiles whose long-miss lists hold a piece of more than kLanePiece bytes (k_merge_long -> k_merge_coop); null: k_small
     int32_t ablate;
     // TKZ_OPT_PIECE_STATS: null, or the encoder's statistics block -- [0] memo lookups, [1] memo hits, [2] short misses, [3] long misses, [4] pieces
     // (what tkz_encoder_piece_stats reports; the timed runs leave it null)

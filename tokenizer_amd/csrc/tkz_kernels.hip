@@ -12,7 +12,7 @@
 //   k_probe          per sub-tile, one wavefront: enumerate pieces from the bitmap, whole-piece lookup
 //                    (TikTokenizer.cs:262) -> one 32-bit record per piece
 //   k_merge_short    BytePairEncode (BytePairEncoder.cs:13-76) of the missed pieces of <= 16 bytes, 64 per wavefront
-//   k_giant_* / k_merge_long   the missed pieces of > 1024 / 17..1024 bytes
+//   k_giant_* / k_merge_long / k_merge_coop   the missed pieces of > 1024 bytes (a workgroup each) / 17..256 (a lane each) / 257..1024 (a wavefront each)
 //   k_scan_*         exclusive scan of the per-sub-tile token counts
 //   k_place          ids stored at their final position
 //   k_docoffs        out_offsets[d] = tile base + position inside the tile
@@ -519,8 +519,9 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
 //   k_merge_short  one wavefront per group of 16 sub-tiles: their short-miss lists are packed 64 to a wavefront -- looked up in
 //                  the piece memo (the reference's LRUCache on the device), the survivors merged, every lane busy (tkz_bpe_lane) --
 //                  instead of the ~14 of 64 a sub-tile has on its own.  Also the per-sub-tile token counts.
-//   k_giant_find / k_giant_merge, k_merge_long   the rare long ones: > 1024 bytes by a whole workgroup in rounds (tkz_bpe_long),
-//                  17..1024 bytes from the long-miss lists of 64 sub-tiles at a time, each in a span of an LDS arena
+//   k_giant_find / k_giant_merge, k_merge_long, k_merge_coop   the rare long ones: > 1024 bytes by a whole workgroup (tkz_bpe_long: batches of
+//                  merges that cannot disturb one another, rounds for chains of equal pairs); 17..256 bytes from the long-miss lists of 64
+//                  sub-tiles at a time, one LANE each in a span of an LDS arena; 257..1024 bytes one WAVEFRONT each, with the workgroup's merger
 //   (scan of the token counts)
 //   k_place        one wavefront per sub-tile: count per record -> prefix -> ids staged in LDS and stored as whole 16-byte quads at
 //                  their final position, token index of every marked piece for the document offsets
@@ -839,6 +840,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
             }
             if (miss_l && il + ns < P.mcap) ml[P.mcap - 1 - il] = ent;
             uint32_t rec = ((s_mark[s >> 5] >> (s & 31)) & 1u) ? kPrMark : 0u;
+            if (REPORT) giant = giant || (miss_l && len > kLanePiece);      // (k_small, the only REPORT user, hands a batch with such a piece back like one with a giant piece: k_merge_coop is a kernel of the batch path)
             if (is_giant) { rec |= kPrMiss | kPrGiant | (uint32_t)s; giant = giant || valid; }
             else if (miss) rec |= kPrMiss | (miss_l ? (kPrLong | (uint32_t)il) : (uint32_t)is_);
             else rec |= (uint32_t)rank;
@@ -1152,7 +1154,7 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
     tkz_merge_short_group(T, P, grp, tkz_ms_lds(s_wave[simt::wave()], s_brank16));
 }
 
-// The pieces of 17..1024 bytes that have to be merged, and the token counts of the giant ones.  One lane per piece with its state in a
+// The pieces of 17..256 bytes that have to be merged (longer ones: k_merge_coop below), and the token counts of the giant ones.  One lane per piece with its state in a
 // span of an LDS arena sized for it (tkz_bpe_lane_varc64 / _varc / _var: pair ranks [| ids] [| alive bits], preceded by the piece's bytes).
 // The long-miss lists of the 64 sub-tiles of a chunk are walked as one list, kLongSeg entries at a time, and every such segment is
 // SORTED BY LENGTH (a counting sort over 16 length classes, in LDS) before it is cut into batches of up to 64 lanes: a merge costs a scan
@@ -1202,6 +1204,8 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
     for (int64_t c = c0; c * 64 < P.nsub; c += cstep) {
         const int64_t t = c * 64 + lane;
         int my_nl = 0;
+        bool coop = false;                                      // a piece of more than kLanePiece bytes in this chunk: left to k_merge_coop
+        if (lane == 0 && P.coop_flag) P.coop_flag[c] = 0;
         if (t < P.nsub) {
             const uint32_t mc = P.mcount[t];
             my_nl = (int)(mc >> 16);
@@ -1263,16 +1267,18 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                 }
                 const int nbw = (len + 3) >> 2;
                 const bool small = compact && len <= 64;         // alive bits in registers: the state is pr[] alone
+                const bool mine = valid && len <= kLanePiece;    // (a longer piece keeps its entry as it is: k_merge_coop answers it)
+                coop = coop || (valid && !mine);
                 int need = 0;
-                if (valid) {
+                if (mine) {
                     need = ((nbw + 3) & ~3) + (small ? tkz_bpe_var_n4(len) : compact ? tkz_bpe_varc_dwords(len) : tkz_bpe_var_dwords(len));
                     if (!((need >> 2) & 1)) need += 4;           // an odd number of quads: equal spans then sit on distinct banks
                 }
                 int btot;
                 const int aoff = tkz_wave_scan_sum(need, &btot);
-                const uint64_t bad = simt::ballot(valid && aoff + need > kArenaDwords);
+                const uint64_t bad = simt::ballot(mine && aoff + need > kArenaDwords);
                 const int limit = bad ? tkz_ctz64(bad) : 64;                   // lanes at or beyond `limit` wait for the next batch (limit >= 1: one piece always fits)
-                if (valid && lane < limit) {
+                if (mine && lane < limit) {
                     const int64_t sub = c * 64 + q;
                     const int64_t abs = sub * kSub + rel;
                     uint32_t* bw = &s_arena[aoff];                   // (len + 3) / 4 dwords of bytes, then the merge state
@@ -1317,6 +1323,7 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                 done += limit < nseg - done ? limit : nseg - done;
             }
         }
+        if (simt::ballot(coop) && lane == 0 && P.coop_flag) P.coop_flag[c] = 1;
     }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
@@ -1327,6 +1334,70 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
     const LongLds LD = tkz_long_lds(s_lds);
     tkz_long_brank_init(T, LD.brank);
     tkz_merge_long_chunks<COMPACT>(T, P, simt::bid(), simt::nblocks(), LD);
+}
+
+// The missed pieces of kLanePiece + 1 .. kArenaPiece bytes: ONE WAVEFRONT per piece, with the giant pieces' merger (tkz_bpe_long_tail: batches of proposals with
+// local bounds + rounds for chains of equal pairs -- its workgroup is this kernel's single wavefront, 32 slots a lane).  A lane of k_merge_long takes ~n^2 steps
+// for a piece of n bytes and the kernel lasts as long as its slowest lane: one 1000-byte run of one letter held it for 3.4 ms, 40 times what the rest of a
+// 1 GB batch needed; the wavefront takes ~30 batches whatever the length.  (Below kLanePiece the lanes win: 64 pieces a wavefront instead of one.)
+// k_merge_long leaves such an entry as k_probe wrote it and flags the chunk of 64 sub-tiles; this kernel walks the lists of the flagged chunks only.
+constexpr int kCoopScratch = (4 * kTailSubs + 8) * 64 + 16 + 16;
+constexpr int kCoopLdsBytes = 2 * 4 * kArenaPiece + 4 * (kArenaPiece / 32) + kCoopScratch + 4 * 68;
+TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
+    TKZ_SHARED uint4 s_lds[(kCoopLdsBytes + 15) / 16];
+    int32_t* ids = reinterpret_cast<int32_t*>(s_lds);
+    int32_t* pr = ids + kArenaPiece;
+    uint32_t* alive = reinterpret_cast<uint32_t*>(pr + kArenaPiece);
+    uint8_t* scratch = reinterpret_cast<uint8_t*>(alive + kArenaPiece / 32);
+    int* s_pre = reinterpret_cast<int*>(scratch + kCoopScratch);
+    const int lane = simt::lane();
+    const int64_t nchunks = (P.nsub + 63) / 64;
+    int err = 0;
+    for (int64_t c = simt::bid(); c < nchunks; c += simt::nblocks()) {
+        if (!P.coop_flag[c]) continue;
+        const int64_t t = c * 64 + lane;
+        int my_nl = 0;
+        if (t < P.nsub) {
+            const uint32_t mc = P.mcount[t];
+            my_nl = (int)(mc >> 16);
+            if ((int)(mc & 0xFFFFu) + my_nl > P.mcap) my_nl = 0;               // (cut list: the batch is redone)
+        }
+        int ntotal;
+        const int pre = tkz_wave_scan_sum(my_nl, &ntotal);
+        simt::sync();
+        s_pre[lane] = pre;
+        if (lane == 0) s_pre[64] = ntotal;
+        simt::sync();
+        for (int g0 = 0; g0 < ntotal; g0 += 64) {
+            const int g = g0 + lane;
+            int q = 0, j = 0;
+            uint32_t ent = kMrDone;
+            if (g < ntotal) { q = tkz_find_list<64>(s_pre, g); j = g - s_pre[q]; ent = P.mlist[(c * 64 + q) * (int64_t)P.mcap + (P.mcap - 1 - j)]; }
+            uint64_t todo = simt::ballot(!(ent & kMrDone) && (int)((ent >> kMrLenShift) & 1023u) + 1 > kLanePiece);
+            for (; todo; todo &= todo - 1) {
+                const int src = tkz_ctz64(todo);
+                const int qq = simt::shfl(q, src), jj = simt::shfl(j, src);
+                const uint32_t ee = simt::shflu(ent, src);
+                const int rel = (int)(ee & 1023u), n = (int)((ee >> kMrLenShift) & 1023u) + 1;
+                const int64_t sub = c * 64 + qq, abs = sub * kSub + rel;
+                const uint8_t* gb = P.bytes + abs;
+                for (int k = lane; k < n; k += 64) {
+                    const uint32_t b = gb[k];
+                    ids[k] = T.byte_rank[b];
+                    pr[k] = (k + 1 < n) ? T.bytepair_rank[(b << 8) | gb[k + 1]] : TKZ_RANK_NONE;
+                }
+                simt::sync();
+                tkz_bpe_long_tail<true>(T, n, ids, pr, alive, scratch, nullptr);
+                const int cnt = tkz_bpe_long_tail_emit<true>(n, ids, pr, alive, P.tmp + abs, &err);
+                if (lane == 0) {
+                    P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - jj)] = tkz_result_entry(false, cnt, rel);      // (the tokens are in tmp at the piece's position)
+                    if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
+                }
+                simt::sync();
+            }
+        }
+    }
+    if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
 
 // ids at their final position: count per record -> prefix -> the sub-tile's ids staged in LDS -> stored as whole 16-byte quads (one
@@ -1660,7 +1731,7 @@ TKZ_KERNEL(1024) void k_giant_order(EncodeParams P) {
 }
 
 TKZ_KERNEL(1024) void k_giant_merge(TkzTables T, EncodeParams P) {
-    TKZ_SHARED alignas(16) int32_t s_state[(9 * kBpeLongLds + 3) / 4];        // ids | pair ranks | flag bytes of up to 16 Ki parts: 144 KB of the CU's 160
+    TKZ_SHARED alignas(16) int32_t s_state[kBpeLongLdsBytes / 4];             // ids | pair ranks | flag bytes of up to 16 Ki parts + the tail's bounds: 152 KB of the CU's 160
     TKZ_SHARED int64_t s_off;
     TKZ_SHARED int32_t s_whole;
     TKZ_SHARED unsigned long long s_ticket;
@@ -2136,7 +2207,8 @@ TKZ_KERNEL(256) void k_offsets_scan(int64_t* offs, int64_t n, int64_t* total) {
 //   limits (checked by the host): total <= kSmallMaxBytes (128 sub-tiles), n_docs <= kSmallMaxDocs; o200k, which has no row evaluator and is
 //   split by the sequential matcher -- the definition -- one lane per document over text staged in LDS: total <= kSmallMaxBytesO200k and
 //   every document <= kSmallMaxDoc bytes
-//   a giant piece, a miss list or record buffer that is too small: status != 0, and the host takes the batch path (which has the retries)
+//   a giant piece, a missed piece of more than kLanePiece bytes (k_merge_coop's), a miss list or record buffer that is too small: status != 0, and the
+//   host takes the batch path (which has the retries)
 // -------------------------------------------------------------------------------------------------
 constexpr int kSmallWaves = 16;            // the workgroup is 256 threads for up to 4 sub-tiles, 1024 beyond
 constexpr int kSmallLdsQuads = kSmallWaves * kPretokBlkQuads + 16;       // 83.5 KB: the largest phase (a 4 KiB block of the pre-tokenizer per wavefront)
@@ -2379,6 +2451,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
         const int64_t chunks = cdiv(nsub, 64), grid = chunks < 16384 ? chunks : 16384;
         if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH(k_merge_long<true>, grid, 64, L.stream, T, P);
         else TKZ_LAUNCH(k_merge_long<false>, grid, 64, L.stream, T, P);
+        TKZ_LAUNCH(k_merge_coop, chunks < 2048 ? chunks : 2048, 64, L.stream, T, P);      // the pieces k_merge_long left to a whole wavefront (it exits at once when no chunk is flagged)
     }
     hook(L, K_HEAVY, 1);
 }
