@@ -277,7 +277,7 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
 /* ---- measurement ------------------------------------------------------------------------- */
 
 enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_PROBE = 2 /* k_probe alone */, TKZ_K_SCAN = 3, TKZ_K_PLACE = 4,
-       TKZ_K_DOCOFFS = 5, TKZ_K_MERGE_LONG = 6 /* k_giant_find + k_giant_merge + k_merge_long */, TKZ_K_MERGE_SHORT = 7 /* k_merge_short alone */,
+       TKZ_K_DOCOFFS = 5, TKZ_K_MERGE_LONG = 6 /* k_giant_find + k_giant_merge + k_merge_long + k_merge_coop */, TKZ_K_MERGE_SHORT = 7 /* k_merge_short alone */,
        TKZ_K_COUNT = 8 };
 /* When enabled, every kernel launch of tkz_encode_batch_device is bracketed by HIP events on the
  * launch stream; tkz_encoder_kernel_ms returns the accumulated milliseconds and launch counts per
@@ -290,7 +290,7 @@ void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_sca
 /* The single-launch path: a host-buffer call (tkz_encode_utf8 / _utf16, tkz_encode_batch_utf8) whose batch is at most 128 KiB in at most
  * 8192 documents (o200k: at most 64 KiB, documents of at most 1 KiB) runs as ONE kernel launch that reads the text from, and writes the ids into, page-locked host memory
  * (no copy commands; ~25 launches otherwise).  Informational: how many calls took it, and how many of those the kernel handed back to the
- * batch path (a piece of more than 1024 bytes, an error to diagnose, workspace to grow). */
+ * batch path (a piece of more than 1024 bytes or one of more than 256 that is not a key, an error to diagnose, workspace to grow). */
 void tkz_encoder_small_path_calls(const tkz_encoder* e, int64_t* calls, int64_t* handed_back);
 /* development: the shader-clock stamps the last single-launch kernel left at the end of each of its phases (16 values; returns how many) */
 int32_t tkz_encoder_small_path_phases(const tkz_encoder* e, int64_t* clocks16);
