@@ -684,6 +684,53 @@ def check_runs_with_words(lib, O, vocab, ovocab, seed=9):
         assert ids.tolist() == exp and ooff.tolist() == eoff, pattern
 
 
+def check_long_pieces_entry_points(lib, O, vocab, ovocab, seed=13):
+    """Missed pieces of 257..1024 bytes (k_merge_coop) and giant ones (k_giant_merge) through the OTHER entry points: the UTF-16 batch (transcoded on the
+    device), the piece-granular batch (token ranges of every piece), single strings, with special tokens between them (the C# segmentation), and many of
+    them in one chunk of sub-tiles beside short and 17..256-byte misses -- every one against the oracle."""
+    rng = random.Random(seed)
+    cons = "bcdfghjklmnpqrstvwxz"
+    def run(n):
+        k = rng.randrange(4)
+        if k == 0: return rng.choice("nqe= ") * n
+        if k == 1: return "".join(rng.choice(cons) for _ in range(n))
+        if k == 2: return ("the" * n)[:n]
+        return "".join(rng.choice(["Word", "Stop", "Quick", "Zq", "X"]) for _ in range(n))[:n]
+    for pattern in (N.CL100K, N.O200K_DOTNET):
+        enc, oenc = N.Encoder(vocab, pattern), O.Encoder(ovocab, pattern)
+        docs = []
+        for _ in range(24):
+            parts = []
+            for _ in range(rng.randrange(1, 6)):
+                parts.append(run(rng.choice([20, 100, 257, 300, 600, 1024, 1025, 2000, 6000])))
+                parts.append(rng.choice([" ", "\n", " hello world, it's 12345 ", "", " \u6f22\u5b57 "]))
+            docs.append("".join(parts))
+        b = [d.encode("utf-8") for d in docs]
+        data, offs = pack(b)
+        exp, eoff = oracle_encode_docs(oenc, b)
+        ids, ooff = enc.encode_batch(data, offs)
+        assert ids.tolist() == exp and ooff.tolist() == eoff, pattern
+        # UTF-16 code units, transcoded on the device
+        units = [np.frombuffer(d.encode("utf-16-le"), np.uint16) for d in docs]
+        uoffs = np.cumsum([0] + [len(u) for u in units]).astype(np.int64)
+        ids16, ooff16 = enc.encode_batch_utf16(np.concatenate(units) if units else np.zeros(0, np.uint16), uoffs)
+        assert ids16.tolist() == exp and ooff16.tolist() == eoff, pattern
+        # piece granularity: the token range of every piece
+        pids, dpo, pbo, pto = enc.encode_batch_pieces(data, offs)
+        assert pids.tolist() == exp, pattern
+        e_pto, pos, k = [0], 0, 0
+        for d in b:
+            for (a, n) in O.split_utf8(pattern, d):
+                p = d[a:a + n]
+                r = ovocab.rank(p)
+                k += 1 if r >= 0 else len(ovocab.bpe(p))
+                e_pto.append(k)
+        assert pto.tolist() == e_pto and dpo[-1] == len(e_pto) - 1, pattern
+        # single strings (a batch of one: the single-launch path hands these back)
+        for d in b[:4]:
+            assert enc.encode_utf8(d) == oenc.encode_bytes(d)
+
+
 def check_errors(lib, O, vocab):
     enc = N.Encoder(vocab, N.CL100K)
     import pytest

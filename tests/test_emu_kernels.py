@@ -309,6 +309,11 @@ def test_giant_tail_on_adversarial_rank_tables(lib, oracle_mod):
     parity.check_runs_with_words(lib, oracle_mod, v, ov)
 
 
+def test_long_pieces_through_every_entry_point(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_long_pieces_entry_points(lib, oracle_mod, v, ov)
+
+
 def test_device_entry_in_two_halves(lib, vocabs, oracle_mod):
     v, ov = vocabs("gpt2")
     parity.check_begin_end(lib, oracle_mod, v, ov)

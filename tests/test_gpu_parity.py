@@ -467,6 +467,13 @@ def test_adversarial_rank_tables(lib, oracle_mod):
     parity.check_random_vocab(lib, oracle_mod, seed=6, n_vocabs=4, lens=[300, 1024, 3000, 18000], n_pieces=6, max_len=1100)
 
 
+@pytest.mark.parametrize("vname", ["gpt2", "synth100k"])
+def test_long_pieces_through_every_entry_point(lib, vocabs, oracle_mod, vname):
+    v, ov = vocabs(vname)
+    for seed in (13, 14, 15):
+        parity.check_long_pieces_entry_points(lib, oracle_mod, v, ov, seed=seed)
+
+
 def test_device_entry_in_two_halves(lib, vocabs, oracle_mod):
     """tkz_encode_batch_device_begin / _end with four batches in flight on two streams."""
     import torch
