@@ -295,7 +295,7 @@ void tkz_encoder_small_path_calls(const tkz_encoder* e, int64_t* calls, int64_t*
 /* development: the shader-clock stamps the last single-launch kernel left at the end of each of its phases (16 values; returns how many) */
 int32_t tkz_encoder_small_path_phases(const tkz_encoder* e, int64_t* clocks16);
 /* What the batches since the last reset met, with TKZ_OPT_PIECE_STATS on (8 values): [0] batches, [1] pieces (regex matches), [2] pieces of
- * at most 16 bytes that missed the vocabulary as a whole (TikTokenizer.cs:262 -> :268), [3] of 17..1024 bytes, [4] of more than 1024 bytes,
+ * at most 16 bytes that missed the vocabulary as a whole (TikTokenizer.cs:262 -> :268), [3] of 17..1024 bytes (merged a lane each up to 256 bytes, a wavefront each beyond), [4] of more than 1024 bytes (a workgroup each),
  * [5] piece-memo lookups and [6] hits among them (the misses went through BytePairEncode), [7] 0.  Whole-piece hit rate =
  * 1 - ([2] + [3] + [4]) / [1]. */
 tkz_status tkz_encoder_piece_stats(tkz_encoder* e, int64_t* out8, int32_t reset);
