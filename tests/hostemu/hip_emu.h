@@ -42,7 +42,7 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
 hipError_t hipMemset(void* d, int v, size_t n);
 hipError_t hipStreamSynchronize(hipStream_t st);
 hipError_t hipStreamCreate(hipStream_t* st);
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocPortable = 1 };
 hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned flags);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t st);

@@ -79,6 +79,47 @@ def run_gpt2_suite(lib, gpt2_bytes, lib_rs_text, oracle_mod, oracle_vocab):
     run_trim_suite(tok, oracle_mod.TrimOracle(oracle_vocab, oracle_mod.P1, specials), specials, lib_rs_text)
 
 
+def run_by_name_suite(lib, vocab_bytes, oracle_mod, tmpdir):
+    """CreateByEncoderName / CreateByModelName pick the engine of the reference that DEFINES the encoder (round-4 advisor): o200k_base / gpt-4o exist
+    only in the TypeScript reference -- code points, ECMAScript \\s (tokenizer_ts/src/tikTokenizer.ts:100) --, cl100k_base and the pattern-1 encoders
+    in the C# one.  Rank files: the stand-ins of the right size under the names the builders look for (the real ones are not available offline)."""
+    from tokenizer_amd import tokenizer as TK
+    d = str(tmpdir)
+    raw200, raw100 = vocab_bytes("synth200k"), vocab_bytes("synth100k")
+    open(os.path.join(d, "o200k_base.tiktoken"), "wb").write(raw200)
+    open(os.path.join(d, "cl100k_base.tiktoken"), "wb").write(raw100)
+    ov200 = oracle_mod.Vocab(raw200)
+    o_js, o_net = oracle_mod.Encoder(ov200, oracle_mod.O200K), oracle_mod.Encoder(ov200, oracle_mod.O200K_DOTNET)
+    # text on which the two engines cut differently: supplementary-plane letters, digits and marks, U+0085, U+FEFF
+    texts = ["\U0001d400bc fooBAR's", "a\x85\x85b", "\ufeffx a\ufeff\ufeffb", "\U0001F600\u4e2d x\U0001F600\u0301y", "1\U0001d7cf\U0001d7d0\U0001d7d1\U0001d7d2 \U0001F600abc",
+             "\U00010400\U00010428\U00010400 \U0001e900\U0001e922 x\U000e0100y", "plain ASCII text, it's 12345 fine\r\n"]
+    by_enc = TK.TokenizerBuilder.CreateByEncoderName("o200k_base", vocab_dir=d, lib=lib)
+    by_model = TK.TokenizerBuilder.CreateByModelName("gpt-4o", vocab_dir=d, lib=lib)
+    by_prefix = TK.TokenizerBuilder.CreateByModelName("gpt-4o-mini", vocab_dir=d, lib=lib)
+    as_net = TK.TokenizerBuilder.CreateByEncoderName("o200k_base", vocab_dir=d, lib=lib, host="dotnet")
+    differ = 0
+    for t in texts:
+        want_js, want_net = o_js.encode(t), o_net.encode(t)
+        assert by_enc.Encode(t, False) == want_js and by_model.Encode(t, False) == want_js and by_prefix.Encode(t, False) == want_js, t
+        assert as_net.Encode(t, False) == want_net, t
+        b = t.encode("utf-8")
+        arr = np.frombuffer(b, np.uint8)
+        differ += int(not np.array_equal(by_enc.native.pretokenize(arr, np.array([0, len(b)])), as_net.native.pretokenize(arr, np.array([0, len(b)]))))
+    assert differ >= 5                      # the by-name default is not the .NET reading on such text
+    assert by_enc.SpecialTokensEncoder == {"<|endoftext|>": 199999, "<|endofprompt|>": 200018}
+    # cl100k by name: the C# engine's reading, the only one there is
+    ov100 = oracle_mod.Vocab(raw100)
+    c = TK.TokenizerBuilder.CreateByModelName("gpt-4", vocab_dir=d, lib=lib)
+    oc = oracle_mod.Encoder(ov100, oracle_mod.CL100K)
+    for t in texts:
+        assert c.Encode(t, False) == oc.encode(t), t
+    import pytest
+    with pytest.raises(NotImplementedError):
+        TK.TokenizerBuilder.CreateByEncoderName("cl100k_base", vocab_dir=d, lib=lib, host="js")
+    with pytest.raises(NotImplementedError):
+        TK.TokenizerBuilder.CreateByModelName("no-such-model", vocab_dir=d, lib=lib)
+
+
 def run_trim_suite(tok, trim_oracle, specials, long_text):
     """TestEncodeTrimSuffix/2, TestEncodeTrimPrefix/2 (TikTokenizerUnitTest.cs:128-225): the same scenarios, every
     maxTokenCount from 0 past the full length, all three overload shapes, against the oracle's restatement of

@@ -458,6 +458,11 @@ def test_reference_unit_tests_restated(lib, gpt2_tiktoken_bytes, lib_rs_bytes, o
     reference_style.run_cl100k_suite(lib)      # runs only when cl100k_base.tiktoken is supplied
 
 
+def test_builders_by_name_pick_the_defining_engine(lib, vocab_bytes, oracle_mod, tmp_path):
+    import reference_style
+    reference_style.run_by_name_suite(lib, vocab_bytes, oracle_mod, tmp_path)
+
+
 def test_adversarial_rank_tables(lib, oracle_mod):
     parity.check_random_vocab(lib, oracle_mod, seed=3, n_vocabs=40, lens=[2, 5, 9, 16, 17, 25, 32, 33, 60, 150, 320, 1024, 1025, 3000], n_pieces=200)
     # arbitrary rank tables on pieces that start in the global pool and end in the tail that keeps only the pair ranks in LDS

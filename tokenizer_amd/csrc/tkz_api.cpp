@@ -94,7 +94,8 @@ struct Workspace {
     DevBuf w_mlist, w_mquad, w_mcount;
     DevBuf w_counts3;                      // {n_docs, n_bytes, n_tokens} of the batch this workspace is running (tkz_pending_counts_device)
     int32_t mcap = tkz::kMissCapMin;       // entries of a sub-tile's miss list; grows (once, to what the batch needed) when a sub-tile overflows it
-    bool place128 = false;                 // the previous batch of this workspace had more than a fifth of its sub-tiles above 64 list entries: k_place<128>
+    bool place128 = false;                 // a recent batch of this workspace had more than a fifth of its sub-tiles above 64 list entries: k_place<128>
+    int low_lists = 0, low_place = 0;      // consecutive batches that would have done with shorter lists / with k_place<64> (hysteresis: kLowBatches)
     // staging for the host-buffer entry points (two sets: chunk k+1 is uploaded while chunk k is encoded and chunk k-1 downloaded)
     DevBuf s_bytes[2], s_offs[2], s_out[2], s_outoffs[2];
     // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
@@ -457,16 +458,26 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             std::lock_guard<std::mutex> lock(e->mu);
             ++e->stat_batches; e->stat_giants += (int64_t)ws->h_counters->heavy_count;
         }
-        if (!d_bitmap_only) ws->place128 = (int64_t)ws->h_counters->over64 * 5 > ntiles;      // (more than a fifth of the sub-tiles: the next batch's k_place)
+        // Growing is immediate, shrinking waits for kLowBatches consecutive batches that would have done with less (the round-4 advisor: a
+        // workspace that alternates miss-heavy and ordinary batches -- or the 48 MB chunks of one host call that does -- must not overflow,
+        // re-run, free and re-allocate on every other batch).
+        constexpr int kLowBatches = 3;
+        if (!d_bitmap_only) {
+            const bool heavy = (int64_t)ws->h_counters->over64 * 5 > ntiles;      // (more than a fifth of the sub-tiles: the next batches' k_place)
+            if (heavy) { ws->place128 = true; ws->low_place = 0; }
+            else if (ws->place128 && ++ws->low_place >= kLowBatches) { ws->place128 = false; ws->low_place = 0; }
+        }
         if (!d_bitmap_only && ws->mcap > kMissCapMin) {
-            // lists that were grown for an earlier batch (text where nearly every piece misses) and that this batch filled to less than
-            // half: shorter lists from here on, and the buffers given back when they are far larger than such a batch needs (the lists
-            // are ntiles * mcap * 20 bytes: 1.25 B per input byte at 64 entries, 20 B at 1024)
+            // lists that were grown for an earlier batch (text where nearly every piece misses) and that the last kLowBatches batches filled to
+            // less than half: half as long from here on (one step at a time), and the buffers given back when they are far larger than such
+            // batches need (the lists are ntiles * mcap * 20 bytes: 1.25 B per input byte at 64 entries, 20 B at 1024)
             int32_t want = kMissCapMin;
             while (want < ws->h_counters->mhigh) want *= 2;
-            if (want < ws->mcap) {
-                ws->mcap = want;
-                if (ws->w_mquad.cap > (size_t)ntiles * (size_t)want * 16 * 4) {
+            if (want >= ws->mcap) ws->low_lists = 0;
+            else if (++ws->low_lists >= kLowBatches) {
+                ws->low_lists = 0;
+                ws->mcap = std::max(want, ws->mcap / 2);
+                if (ws->w_mquad.cap > (size_t)ntiles * (size_t)ws->mcap * 16 * 4) {
                     *acc -= (int64_t)(ws->w_mquad.cap + ws->w_mlist.cap);
                     ws->w_mquad.release(); ws->w_mlist.release();
                 }
@@ -840,9 +851,13 @@ void destroy_now(tkz_encoder* e);
 void tkz_encoder_destroy(tkz_encoder* e) {
     if (!e) return;
     {   // handles of tkz_encode_batch_device_begin still outstanding: their _end calls need the encoder and its workspaces -- the last of
-        // them frees it (and reports TKZ_E_ARG: the results of a batch whose encoder was destroyed under it are not to be trusted)
+        // them frees it (and reports TKZ_E_ARG: the results of a batch whose encoder was destroyed under it are not to be trusted).
+        // `destroyed` is set under the lock in either case, so that a _begin racing with this call is refused instead of leasing a
+        // workspace of an encoder that is being deleted.
         std::lock_guard<std::mutex> lock(e->mu);
-        if (e->pending > 0) { e->destroyed = true; return; }
+        if (e->destroyed) return;                       // (a second destroy while the first is deferred)
+        e->destroyed = true;
+        if (e->pending > 0) return;
     }
     destroy_now(e);
 }
@@ -864,7 +879,9 @@ tkz_status tkz_host_alloc(size_t bytes, void** out) {
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(TKZ_E_NO_DEVICE, "no HIP device available");
-    const hipError_t r = hipHostMalloc(out, bytes ? bytes : 1, 0);
+    // (portable: page-locked for EVERY device of the process, whichever is current here -- a host with encoders on several GPUs hands the same
+    //  buffers to any of them)
+    const hipError_t r = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);
     if (r != hipSuccess) { *out = nullptr; return fail(TKZ_E_OUT_OF_MEMORY, std::string("hipHostMalloc: ") + hipGetErrorString(r)); }
     return TKZ_OK;
 }
@@ -914,7 +931,11 @@ tkz_status tkz_encode_batch_device_begin_counts(tkz_encoder* e, const uint8_t* d
     if (st != TKZ_OK) {
         (void)hipStreamSynchronize(p->stream);
         delete p->lease; delete p;
-        std::lock_guard<std::mutex> lock(e->mu); --e->pending;
+        const std::string msg = g_err;
+        bool last;
+        { std::lock_guard<std::mutex> lock(e->mu); last = --e->pending == 0 && e->destroyed; }
+        if (last) destroy_now(e);                       // (destroy arrived while this _begin was running and no other handle is left)
+        g_err = msg;
         return st;
     }
     *pending = p;

@@ -1043,7 +1043,10 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
                 const TkzMemoSlot* slot = &T.memo[b + wy];
                 const uint4 kk = tkz_load16(&slot->k[0]);
                 const uint4 v = tkz_load16(&slot->v[0]);
-                const bool h = !nul && (v.x & kMemoValid) && v.x != kMemoBusy && kk.x == kw[0] && kk.y == kw[1] && kk.z == kw[2] && kk.w == kw[3] && (v.y >> 27) == (uint32_t)(len - 1);
+                // (the valid tag is in ALL FOUR value words: a value whose 16-byte store became visible word by word -- nothing in HIP's memory
+                //  model says a dwordx4 access is single-copy atomic across CUs / XCDs -- is not valid until its last word is there)
+                const bool h = !nul && ((v.x & v.y & v.z & v.w) & kMemoValid) && v.x != kMemoBusy && kk.x == kw[0] && kk.y == kw[1] && kk.z == kw[2] && kk.w == kw[3] &&
+                               ((v.y >> 27) & 15u) == (uint32_t)(len - 1);
                 if (h) { hit = true; vv = v; }
             }
         }
@@ -1051,7 +1054,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
         const int cnt = hit ? (int)((vv.x >> 29) & 3u) + 1 : 0;
         (void)assign(hit, cnt, si, j, rel);
         if (hit) {                                            // (a memo entry holds <= 4 tokens: they go into the entry's quad)
-            uint4 tq; tq.x = vv.x & 0x07FFFFFFu; tq.y = vv.y & 0x07FFFFFFu; tq.z = vv.z; tq.w = vv.w;
+            uint4 tq; tq.x = vv.x & 0x07FFFFFFu; tq.y = vv.y & 0x07FFFFFFu; tq.z = vv.z & 0x07FFFFFFu; tq.w = vv.w & 0x07FFFFFFu;
             mq0[si * (int64_t)P.mcap + j] = tq;
         }
         const bool keep = lane < nchk || (mine && !hit);
@@ -1090,15 +1093,18 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
                     // (a plain load first: a piece that lost its slot to another one comes back millions of times on repetitive text, and a
                     //  failing compare-and-swap is still an atomic on one hot address)
                     if (!placed && *reinterpret_cast<volatile uint32_t*>(&slot->v[0]) == 0u && simt::atomic_cas(&slot->v[0], 0u, kMemoBusy) == 0u) {
-                        // The key and the value are ONE 16-byte store each, and there is NO fence between them: a reader takes each with one
-                        // 16-byte load, so it sees a value that is wholly old (zero / BUSY: not valid) or wholly new, beside a key that is
-                        // wholly old (zero: equals no piece -- a looked-up piece has no zero byte) or wholly new: every mixture is a miss or
-                        // the right hit.  (A device-scope release fence here wrote the XCD's dirty L2 lines back for EVERY insertion: the
+                        // The key and the value are one 16-byte store each, and there is NO fence between or behind them.  The protocol does
+                        // not rely on those stores (or a reader's 16-byte loads) being single-copy atomic: EVERY value word carries the valid
+                        // tag (bit 31), so a value is accepted only when all four words are the new ones -- any mixture with the old words
+                        // (zero, or BUSY in v[0]) is a miss --, and then its length field is the key's; a key seen word by word is a mixture of
+                        // the new words and zero words, and a looked-up piece (no zero byte inside its length) can equal such a mixture only
+                        // if the missing words lie beyond its length -- where the complete key is zero too: every mixture is a miss or the
+                        // right hit, in whatever order the eight words become visible.  (A device-scope release fence here wrote the XCD's dirty L2 lines back for EVERY insertion: the
                         // first batch on an empty memo with many misses -- 369 M short misses of the held-out vocabulary -- spent 566 ms
                         // in this kernel, ten times what it takes with the memo switched off.)
                         uint4 kk; kk.x = kw[0]; kk.y = kw[1]; kk.z = kw[2]; kk.w = kw[3];
                         *reinterpret_cast<uint4*>(&slot->k[0]) = kk;
-                        uint4 nv; nv.x = kMemoValid | ((uint32_t)(cnt - 1) << 29) | t4[0]; nv.y = ((uint32_t)(len - 1) << 27) | t4[1]; nv.z = t4[2]; nv.w = t4[3];
+                        uint4 nv; nv.x = kMemoValid | ((uint32_t)(cnt - 1) << 29) | t4[0]; nv.y = kMemoValid | ((uint32_t)(len - 1) << 27) | t4[1]; nv.z = kMemoValid | t4[2]; nv.w = kMemoValid | t4[3];
                         *reinterpret_cast<uint4*>(&slot->v[0]) = nv;
                         placed = true;
                     }

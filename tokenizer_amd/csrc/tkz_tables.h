@@ -81,7 +81,9 @@ TKZ_HD uint64_t tkz_pair_key42(uint32_t a, uint32_t b) { return (uint64_t)tkz_pa
 // piece seen before).  A direct-mapped table of 32-byte slots keyed by the piece's bytes (<= 16, zero padded) holding its <= 4 tokens:
 //   key   k0..k3
 //   val.x 0 = empty | 0xFFFFFFFF = being written | VALID (bit 31) | (count - 1) << 29 | token 0        (tokens are ranks < 2^27)
-//   val.y (len - 1) << 27 | token 1,   val.z token 2,   val.w token 3
+//   val.y VALID | (len - 1) << 27 | token 1,   val.z VALID | token 2,   val.w VALID | token 3
+//   (VALID in every value word: a reader accepts a value only when all four words are the new ones, so the protocol does not lean on a
+//    16-byte store or load being atomic across CUs / XCDs)
 // Only k_merge_short reads and writes it: pieces that missed the vocabulary tables look themselves up before they are merged, and merged
 // pieces of <= 4 tokens claim their slot if it is EMPTY (compare-and-swap on val.x; an entry never changes once it is valid, so a hit in
 // one kernel cannot be invalidated by another).  A pure memo: results are identical with and without it.

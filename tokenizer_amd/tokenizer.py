@@ -70,6 +70,10 @@ ENCODERS = {
     "gpt2": (REGEX_PATTERN_1, "gpt2.tiktoken", {ENDOFTEXT: 50256}),
     "o200k_base": (REGEX_O200K, "o200k_base.tiktoken", {ENDOFTEXT: 199999, ENDOFPROMPT: 200018}),
 }
+# the engine of the reference that defines each encoder: o200k_base ships only with the TypeScript reference (tokenizer_ts/src/tokenizerBuilder.ts:79-89,
+# compiled by `new RegExp(pattern, "gu")`, tikTokenizer.ts:100); everything else is TokenizerBuilder.cs's.  By-name construction follows this table;
+# CreateTokenizer with an explicit pattern string keeps the .NET reading (it replaces `new Regex(pattern)`, TikTokenizer.cs:77).
+ENCODER_ENGINE = {"o200k_base": "js"}
 
 
 def _utf8_like_dotnet(s: str) -> bytes:
@@ -312,14 +316,20 @@ class TokenizerBuilder:
 
     @staticmethod
     def CreateByModelName(modelName: str, extraSpecialTokens: Optional[Dict[str, int]] = None, vocab_dir: Optional[str] = None, device: int = 0,
-                          host: str = "dotnet"):
-        return TokenizerBuilder.CreateByEncoderName(TokenizerBuilder._encoder_for_model(modelName), extraSpecialTokens, vocab_dir, device, host)
+                          host: Optional[str] = None, lib: Optional[N.Library] = None):
+        return TokenizerBuilder.CreateByEncoderName(TokenizerBuilder._encoder_for_model(modelName), extraSpecialTokens, vocab_dir, device, host, lib)
 
     @staticmethod
     def CreateByEncoderName(encoderName: str, extraSpecialTokens: Optional[Dict[str, int]] = None, vocab_dir: Optional[str] = None, device: int = 0,
-                            host: str = "dotnet"):
+                            host: Optional[str] = None, lib: Optional[N.Library] = None):
+        """`host=None` picks the engine of the reference that DEFINES the encoder (ENCODER_ENGINE): o200k_base / gpt-4o exist only in the
+        TypeScript reference, whose `new RegExp(pattern, "gu")` matches by code point with ECMAScript's \\s ("js"); every other encoder is the
+        C# reference's ("dotnet").  An explicit `host` overrides that (e.g. "dotnet" for a C# host that hands the o200k string to
+        TokenizerBuilder.CreateTokenizer(stream, specials, pattern) itself)."""
         if encoderName not in ENCODERS:
             raise NotImplementedError("Doesn't support this encoder [%s]" % encoderName)  # TokenizerBuilder.cs:179
+        if host is None:
+            host = ENCODER_ENGINE.get(encoderName, "dotnet")
         regex, fname, specials = ENCODERS[encoderName]
         specials = dict(specials)
         if extraSpecialTokens:
@@ -330,7 +340,7 @@ class TokenizerBuilder:
             raise FileNotFoundError("%s not found: the reference downloads it at run time (TokenizerBuilder.cs:113,195); "
                                     "place it in vocab_dir / $TKZ_VOCAB_DIR" % path)
         with open(path, "rb") as f:
-            return TokenizerBuilder.CreateTokenizer(f.read(), specials, regex, device=device, host=host)
+            return TokenizerBuilder.CreateTokenizer(f.read(), specials, regex, device=device, lib=lib, host=host)
 
     @staticmethod
     def CreateTokenizer(tikTokenBpeFile: bytes, specialTokensEncoder: Optional[Dict[str, int]], pattern: str, cacheSize: int = 8192,
