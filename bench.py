@@ -109,6 +109,104 @@ def reference_dotnet_baseline(sample_path):
         return {"error": "%s: %s" % (type(ex).__name__, ex)}
 
 
+# ---- real text (kind 6) -------------------------------------------------------------------------------------------------------------------
+# The reference benches real words (PerfBenchmark/Program.cs:14-38), the synthetic kinds a 4096-word Zipf lexicon.  Kind 6 is the source and
+# documentation text that exists on the box -- the Python standard library, the installed Python packages (torch and its headers among them),
+# the ROCm and system C / C++ headers --, every file once, in sorted order, NOT tiled, cut into documents of min..max bytes at character
+# boundaries.  Files that are not well-formed UTF-8 or hold a NUL byte are left out.  The sha256 of the concatenation goes into the bench line.
+REAL_TEXT_ROOTS = ["/usr/lib/python3.10", "/usr/local/lib/python3.10/dist-packages", "/opt/rocm/include", "/usr/include"]
+REAL_TEXT_EXT = {".py", ".pyi", ".h", ".hpp", ".c", ".cc", ".cpp", ".cu", ".cuh", ".hip", ".md", ".rst", ".js", ".html", ".cmake", ".css", ".sh", ".toml", ".cfg"}
+
+
+def real_text_corpus(limit_bytes, min_len, max_len, seed=0x5EED0006, roots=None):
+    """(bytes uint8[total], offsets int64[n + 1], meta).  limit_bytes <= 0: everything there is."""
+    import numpy as np
+    t0 = time.perf_counter()
+    files = []
+    for r in (roots or REAL_TEXT_ROOTS):
+        for dp, dn, fn in os.walk(r):
+            dn.sort()
+            for f in sorted(fn):
+                if os.path.splitext(f)[1].lower() in REAL_TEXT_EXT:
+                    q = os.path.join(dp, f)
+                    if not os.path.islink(q):
+                        files.append(q)
+    parts, total, used, skipped = [], 0, 0, 0
+    h = hashlib.sha256()
+    for q in files:
+        if limit_bytes > 0 and total >= limit_bytes:
+            break
+        try:
+            b = open(q, "rb").read()
+            if b"\0" in b:
+                raise ValueError
+            b.decode("utf-8")
+        except (OSError, ValueError):
+            skipped += 1
+            continue
+        if not b:
+            continue
+        parts.append(b)
+        h.update(b)
+        total += len(b)
+        used += 1
+    data = np.frombuffer(b"".join(parts), np.uint8) if parts else np.zeros(0, np.uint8)
+    del parts
+    # document cuts: lengths drawn uniformly from min..max, every cut moved forward to the next character boundary
+    rng = np.random.default_rng(seed)
+    n_guess = int(total // max(1, (min_len + max_len) // 2) * 1.05) + 4096
+    cuts = np.cumsum(rng.integers(min_len, max_len + 1, n_guess, dtype=np.int64))
+    cuts = cuts[cuts < total]
+    if len(cuts):
+        lead = (data & 0xC0) != 0x80                              # True at the first byte of a character
+        nxt = np.flatnonzero(lead)
+        cuts = nxt[np.minimum(np.searchsorted(nxt, cuts), len(nxt) - 1)]      # first lead byte at or after the cut (the text ends in a whole char)
+        cuts = np.unique(cuts[(cuts > 0) & (cuts < total)])
+    offs = np.concatenate([[0], cuts, [total]]).astype(np.int64) if total else np.zeros(1, np.int64)
+    meta = {"files": used, "files_skipped": skipped, "bytes": int(total), "docs": int(len(offs) - 1), "sha256": h.hexdigest(),
+            "roots": roots or REAL_TEXT_ROOTS, "seconds_to_read": round(time.perf_counter() - t0, 2),
+            "non_ascii_bytes": int((data >= 0x80).sum()) if total else 0}
+    return data, offs, meta
+
+
+# ---- the oracle as the checker on document ranges of a device-resident batch ----------------------------------------------------------------
+def sample_ranges(n_docs, sample):
+    """The first and the last `sample` documents of a shard (all of it when it has no more than two samples' worth)."""
+    if sample <= 0 or n_docs <= 2 * sample:
+        return [(0, n_docs)]
+    return [(0, sample), (n_docs - sample, n_docs)]
+
+
+def check_ranges(O, ov, pattern, d_bytes, d_offs, d_ids, d_ooffs, n_tokens, ranges, threads):
+    """tkzo_check_batch on the documents [a, b) of every range: only those documents' bytes and ids are downloaded.  Returns
+    {"docs", "bad", "first_bad" (document index in the shard or -1), "tokens", "bytes", "seconds"}."""
+    import numpy as np
+    res = {"docs": 0, "bad": 0, "first_bad": -1, "tokens": 0, "bytes": 0, "seconds": 0.0}
+    for a, b in ranges:
+        if b <= a:
+            continue
+        offs = d_offs[a:b + 1].cpu().numpy()
+        oo = d_ooffs[a:b + 1].cpu().numpy()
+        b0, b1, t0, t1 = int(offs[0]), int(offs[-1]), int(oo[0]), int(oo[-1])
+        res["docs"] += b - a
+        res["bytes"] += b1 - b0
+        sane = 0 <= t0 <= t1 <= n_tokens and bool((np.diff(oo) >= 0).all()) and (t1 - t0) <= (b1 - b0)
+        if not sane:                                             # (offsets that are not even monotone: every document of the range counts as wrong)
+            res["bad"] += b - a
+            res["first_bad"] = a if res["first_bad"] < 0 else res["first_bad"]
+            continue
+        tm = {}
+        bad, first, otok = O.check_batch(ov, pattern, d_bytes[b0:b1].cpu().numpy(), offs - b0, d_ids[t0:t1].cpu().numpy(), oo - t0, threads=threads, timing=tm)
+        if otok != t1 - t0 and bad == 0:
+            bad, first = 1, 0
+        res["bad"] += bad
+        if bad and res["first_bad"] < 0:
+            res["first_bad"] = a + max(0, first)
+        res["tokens"] += otok
+        res["seconds"] += tm["seconds"]
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,7 +216,14 @@ def main():
                                                            "one GPU's share of configs[3], 100 M documents over 8 GPUs)")
     ap.add_argument("--kind", type=int, default=1, help="corpus: 1 ASCII (config 2), 2 mixed UTF-8 (config 3), 3 long-context (config 5), "
                                                         "4 the reference's test text lib.rs.txt tiled (real source code), "
-                                                        "5 ONE document of shuffled words joined by single spaces (the reference's own benchmark, PerfBenchmark/Program.cs:14-32)")
+                                                        "5 ONE document of shuffled words joined by single spaces (the reference's own benchmark, PerfBenchmark/Program.cs:14-32), "
+                                                        "6 REAL text: the source / documentation files on the box, every file once, not tiled (--real-text-mb)")
+    ap.add_argument("--real-text-mb", type=int, default=None, help="kind 6: at most this many MB of the box's text (0: everything there is); "
+                                                                   "default run (kind 1, N = 1): size of the `real_text` companion leg (default 256; 0: skip the leg)")
+    ap.add_argument("--parity-sample-docs", type=int, default=200_000, help="N > 1: every rank checks the first and the last this-many documents of ITS OWN shard against the oracle")
+    ap.add_argument("--emulated", action="store_true", help="TEST INFRASTRUCTURE (tests/test_bench_line.py): run the kernels through the CPU emulator of tests/hostemu with gloo "
+                                                            "instead of a GPU and RCCL, to exercise this script's own logic at world sizes the 1-GPU boxes cannot run.  The line says so "
+                                                            "(`emulated`: true, `data`: 'EMULATED ...') and is not a measurement of anything")
     ap.add_argument("--min-len", type=int, default=256)
     ap.add_argument("--max-len", type=int, default=768)
     ap.add_argument("--pattern", type=int, default=2, help="1 pattern-1, 2 cl100k, 3 o200k as the TypeScript reference's engine reads it, 4 o200k as .NET's Regex reads it")
@@ -164,14 +269,27 @@ def main():
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
-    if torch.cuda.device_count() <= local_rank:
-        print("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()), file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    emu = args.emulated
+    if emu:
+        # test infrastructure: the real kernel sources on the CPU emulator (tests/hostemu), "device" memory = host memory, gloo for RCCL
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import emu as emu_mod
+        N._default = emu_mod.library()
+        local_rank = 0
+        dev = torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            print("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()), file=sys.stderr)
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=dev)
+    device_sync = (lambda: None) if emu else torch.cuda.synchronize
 
     raw, vocab_name = load_vocab_bytes(args.pattern, args.vocab)
     vocab = N.Vocab(raw)
@@ -185,19 +303,39 @@ def main():
         dist.broadcast_object_list(box, src=0, device=dev)
         return box[0]
     comm, comm_info = None, None
-    try:
-        comm = sharded.RcclCounts(rank, world, local_rank, exchange)
-        comm_info = comm.info()
-    except Exception as ex:
-        if world > 1:
-            raise
-        comm_info = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    if emu:
+        comm_info = {"backend": "gloo (EMULATED run: torch.distributed all_gather of the counts, tokenizer_amd.sharded.gather_counts)", "world_size": world, "rank": rank}
+    else:
+        try:
+            comm = sharded.RcclCounts(rank, world, local_rank, exchange)
+            comm_info = comm.info()
+        except Exception as ex:
+            if world > 1:
+                raise
+            comm_info = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     # ---- synthetic corpus, generated on the device; rank r owns documents [r*docs, (r+1)*docs) ----
     n_docs = args.docs
     first_doc = rank * n_docs
-    stream = torch.cuda.current_stream().cuda_stream
-    if args.kind == 4:
+    stream = 0 if emu else torch.cuda.current_stream().cuda_stream
+    real_meta = None
+    if args.kind == 6:
+        # REAL text, every file once: rank r takes the r-th of `world` contiguous shares of the documents
+        lim = 0 if args.real_text_mb is None else args.real_text_mb
+        r_bytes, r_offs, real_meta = real_text_corpus(lim << 20, args.min_len, args.max_len)
+        nd_all = len(r_offs) - 1
+        lo, hi = N.shard_range(nd_all, rank, world)
+        b0, b1 = int(r_offs[lo]), int(r_offs[hi])
+        n_docs = hi - lo
+        first_doc = lo
+        total = b1 - b0
+        d_bytes = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
+        d_bytes[:total] = torch.from_numpy(r_bytes[b0:b1].copy()).to(dev)
+        d_offs = torch.from_numpy((r_offs[lo:hi + 1] - b0).copy()).to(dev)
+        real_meta["docs_this_rank"] = n_docs
+        del r_bytes, r_offs
+        seed = None
+    elif args.kind == 4:
         # the reference's own test input (Tokenizer_C#/TokenizerTest/testData/lib.rs.txt, real Rust source) tiled; document lengths
         # drawn like the synthetic kinds.  A document is a slice of the tiled text, so pieces are cut at document edges as anywhere.
         text = torch.from_numpy(np.frombuffer(open(os.path.join(ROOT, "tests", "golden", "lib.rs.txt"), "rb").read(), np.uint8).copy()).to(dev)
@@ -247,11 +385,19 @@ def main():
         warm = (w_bytes, w_offs, w_total, w_ids, w_docs)
         memo_note = "on: %d slots x %d-way buckets, filled during the warm-up steps from %d OTHER documents of the same generator (documents %d..)" % (
             enc.memo_slots, enc.memo_ways, gen_docs, w_first)
+    elif args.kind == 6:
+        # real, non-repeating text has no "other documents of the same generator": every timed step starts on an EMPTY memo, as a fresh
+        # TikTokenizer's LRUCache does on a text it has never seen -- the memo then holds only what this very pass put there
+        memo_note = "on: %d slots, EMPTIED before every step (real text is not tiled and there is no second corpus to warm it on: every step is a first pass)" % enc.memo_slots
     else:
         memo_note = "on: %d slots, filled during the warm-up steps from the same tiled text (every piece of it repeats)" % enc.memo_slots
+    empty_memo_each_step = args.kind == 6 and not args.no_memo
+    memo_on = {}                                                    # encoder -> the memo is switched on (so that a step only empties a memo that is in use)
 
     def step(en=None):
         en = en or enc
+        if empty_memo_each_step and memo_on.get(id(en), True):
+            en.set_option(N.OPT_PIECE_MEMO, 2)                      # (on and emptied: a device synchronisation + a 16 MB memset, inside the timed region)
         ntok = en.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total,
                                       d_ooffs.data_ptr(), stream)
         if comm is not None:
@@ -261,7 +407,7 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     def prepare(en):
         """The W untimed warm-up steps of an encoder (on the OTHER documents when there are any: they fill the piece memo), then one untimed
@@ -296,10 +442,12 @@ def main():
         """One more untimed step with the counting switched on (TKZ_OPT_PIECE_STATS): what the timed steps met -- pieces, whole-piece hits,
         misses by kind, memo lookups and hits (the memo as the timed steps found it: full, so this step adds nothing to it)."""
         try:
+            if empty_memo_each_step and memo_on.get(id(en), True):
+                en.set_option(N.OPT_PIECE_MEMO, 2)                  # (the statistics of a FIRST pass, like the timed steps)
             en.set_option(N.OPT_PIECE_STATS, 1)
             en.piece_stats(reset=True)
             en.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total, d_ooffs.data_ptr(), stream)   # (no collective: rank 0 alone)
-            torch.cuda.synchronize()
+            device_sync()
             st = en.piece_stats(reset=True)
             en.set_option(N.OPT_PIECE_STATS, 0)
             st.pop("batches", None)
@@ -316,6 +464,7 @@ def main():
         ntok = step()
     fence()
     dt = time.perf_counter() - t0
+    dt_own = dt
     enc.set_profiling(False)
     rank_ms = [dt / args.steps * 1e3]
     if world > 1:
@@ -324,17 +473,36 @@ def main():
         rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
         dt = max(float(x.item()) for x in allt)              # the slowest rank's time is the job's
     kms = enc.kernel_ms()
+    kms_rank = rank
+    if world > 1:
+        # the roofline prices the SLOWEST rank's kernels (its time is the job's): every rank's per-kernel milliseconds travel with its step time
+        names = sorted(kms)
+        mine = torch.tensor([dt_own] + [kms[k][0] for k in names] + [float(kms[k][1]) for k in names], dtype=torch.float64, device=dev)
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        rows = [r.cpu().tolist() for r in rows]
+        kms_rank = max(range(world), key=lambda r: rows[r][0])
+        kms = {k: (rows[kms_rank][1 + i], int(rows[kms_rank][1 + len(names) + i])) for i, k in enumerate(names)}
     piece_stats = stats_of(enc) if (rank == 0 and not args.no_piece_stats) else None
     if world > 1:
         fence()
+    # kind 6 only: the same steps WITHOUT emptying the memo in between (it holds what the passes before put there from this very text: an upper
+    # bound, every piece has been seen) -- `value_warm_memo`
+    dt_warm = None
+    if empty_memo_each_step and args.steps > 0:
+        memo_on[id(enc)] = False                                    # (step() leaves the memo alone)
+        dt_warm, _ = timed(enc, args.steps)
+        memo_on[id(enc)] = True
     # the same steps with the piece memo switched off (it neither reads nor fills it): the companion figure `value_no_memo`
     dt_nomemo = None
     nm_steps = args.steps if args.no_memo_steps is None else args.no_memo_steps
     if not args.no_memo and nm_steps > 0:
         enc.set_option(N.OPT_PIECE_MEMO, 0)
+        memo_on[id(enc)] = False
         step()
         dt_nomemo, _ = timed(enc, nm_steps)
         enc.set_option(N.OPT_PIECE_MEMO, 1)
+        memo_on[id(enc)] = True
     # the same corpus under a stand-in vocabulary that has never seen it (tools/train_bpe.py synth100k_heldout: the same size and recipe
     # WITHOUT the bench's generator in the training text): `value_heldout_vocab`.  synth100k is trained on the generator's own output, so
     # its whole-piece hit rate flatters; the real cl100k_base lies somewhere between the two.  Its own encoder, its own memo, the same
@@ -360,19 +528,100 @@ def main():
                 heldout["parity"] = ("bit-exact vs oracle on all %d docs (%d tokens)" % (n_docs, otok)) if (bad == 0 and otok == ntok_h) else \
                                     "MISMATCH vs oracle: %d of %d docs differ, first %d" % (bad, n_docs, first_bad)
             del enc_h
-            torch.cuda.empty_cache()
+            if not emu:
+                torch.cuda.empty_cache()
         except Exception as ex:
             heldout = {"error": "%s: %s" % (type(ex).__name__, ex)}
         ntok = step()                          # (the output buffers and the gathered counts are the headline vocabulary's again: the checks below read them)
         fence()
+    # ---- `real_text` (default run only: kind 1, N = 1): what the number is worth on REAL, non-repeating text under a REAL table.  The only real
+    # vocabulary available offline is gpt2.tiktoken (the reference's model/gpt2.tiktoken); the text is the box's own source and documentation
+    # files (real_text_corpus above: every file once, NOT tiled).  gpt2 with its own pattern 1 and with the cl100k pattern (REAL vocabulary x REAL
+    # text), and the two cl100k-sized stand-ins on the same text.  Every figure: the memo EMPTIED before every step (a first pass, as a fresh
+    # TikTokenizer meets the text), full-batch parity against the oracle, piece statistics.  Companion figures, never `value`.
+    real_leg = None
+    rt_mb = 256 if args.real_text_mb is None else args.real_text_mb
+    if world == 1 and args.kind == 1 and not args.parity_only and rt_mb > 0 and not args.no_memo:
+        try:
+            r_bytes, r_offs, r_meta = real_text_corpus(rt_mb << 20, 256, 768)
+            r_nd, r_total = len(r_offs) - 1, int(r_offs[-1])
+            rd_bytes = torch.zeros(r_total + 64, dtype=torch.uint8, device=dev)
+            rd_bytes[:r_total] = torch.from_numpy(r_bytes).to(dev)
+            rd_offs = torch.from_numpy(r_offs).to(dev)
+            rd_ids = torch.empty(r_total, dtype=torch.int32, device=dev)
+            rd_ooffs = torch.empty(r_nd + 1, dtype=torch.int64, device=dev)
+            r_steps = max(1, min(args.steps, 5))
+            real_leg = {"corpus": r_meta, "steps": r_steps, "unit": "MB/s",
+                        "piece_memo": "EMPTIED before every timed step (`value`): real text is not tiled, every step is a first pass; `value_warm_memo`: the memo as "
+                                      "earlier passes over this very text left it (an upper bound); `value_no_memo`: switched off",
+                        "by_vocab": {}}
+            combos = [("gpt2", 1), ("gpt2", 2), (None, 2), ("synth100k_heldout", 2)]
+            for vname, pat in combos:
+                raw_v, label_v = load_vocab_bytes(pat, vname)
+                en = N.Encoder(N.Vocab(raw_v), pat, device=local_rank)
+
+                def r_step(mode):
+                    if mode == "empty":
+                        en.set_option(N.OPT_PIECE_MEMO, 2)
+                    return en.encode_batch_device(rd_bytes.data_ptr(), rd_offs.data_ptr(), r_nd, r_total, rd_ids.data_ptr(), r_total, rd_ooffs.data_ptr(), stream)
+
+                def r_timed(mode):
+                    device_sync()
+                    t0 = time.perf_counter()
+                    for _ in range(r_steps):
+                        nt = r_step(mode)
+                    device_sync()
+                    return (time.perf_counter() - t0) / r_steps, nt
+                en.set_option(N.OPT_PIECE_MEMO, 0)
+                r_step("off")                                       # (untimed: the workspace takes the size this batch needs)
+                en.set_option(N.OPT_PIECE_MEMO, 1)
+                r_step("empty")                                     # (untimed: lists that grow under a miss-heavy table grow here)
+                en.set_profiling(True)
+                en.kernel_ms(reset=True)
+                t_first, r_ntok = r_timed("empty")
+                r_kms = en.kernel_ms()
+                en.set_profiling(False)
+                t_warm, _ = r_timed("warm")
+                en.set_option(N.OPT_PIECE_MEMO, 0)
+                t_off, _ = r_timed("off")
+                en.set_option(N.OPT_PIECE_MEMO, 2)
+                en.set_option(N.OPT_PIECE_STATS, 1)
+                en.piece_stats(reset=True)
+                r_ntok = r_step("empty")
+                device_sync()
+                r_stats = en.piece_stats(reset=True)
+                en.set_option(N.OPT_PIECE_STATS, 0)
+                r_stats.pop("batches", None)
+                ent = {"vocab": label_v, "pattern": PATTERN_NAME[pat], "value": round(r_total / t_first / 1e6, 1), "ms_per_step": round(t_first * 1e3, 3),
+                       "value_warm_memo": round(r_total / t_warm / 1e6, 1), "value_no_memo": round(r_total / t_off / 1e6, 1),
+                       "tokens": r_ntok, "bytes_per_token": round(r_total / max(1, r_ntok), 3), "piece_stats": r_stats,
+                       "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in r_kms.items()}, "parity": "unchecked"}
+                if not args.no_cpu_baseline:
+                    from oracle import oracle as O
+                    tm = {}
+                    bad, first_bad, otok = O.check_batch(O.Vocab(raw_v), pat, r_bytes, r_offs, rd_ids[:r_ntok].cpu().numpy(), rd_ooffs.cpu().numpy(),
+                                                         threads=max(1, os.cpu_count() or 1), timing=tm)
+                    ent["parity"] = ("bit-exact vs oracle on all %d docs (%d tokens)" % (r_nd, otok)) if (bad == 0 and otok == r_ntok) else \
+                                    "MISMATCH vs oracle: %d of %d docs differ, first %d" % (bad, r_nd, first_bad)
+                    ent["cpu_oracle_all_threads_mbps"] = round(r_total / tm["seconds"] / 1e6, 1)
+                real_leg["by_vocab"]["%s/pattern%d" % (vname or VOCAB_OF_PATTERN[pat][0], pat)] = ent
+                del en
+            del rd_bytes, rd_offs, rd_ids, rd_ooffs, r_bytes, r_offs
+            if not emu:
+                torch.cuda.empty_cache()
+        except Exception as ex:                                      # an auxiliary figure must never cost the bench line
+            real_leg = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        ntok = step()                                                # (the output buffers hold the headline batch's result again)
+        fence()
     if warm is not None:
         del warm, w_bytes, w_offs, w_ids
-        torch.cuda.empty_cache()
+        if not emu:
+            torch.cuda.empty_cache()
     # the same steps two at a time through tkz_encode_batch_device_begin / _end (two streams, two output buffers, two workspaces of the
     # encoder): what keeping batches in flight buys over one synchronous call after the other -- a companion figure, never `value`
     dt_pipe = None
     pipe_note = None
-    if args.pipelined_steps > 0 and args.kind != 5:
+    if args.pipelined_steps > 0 and args.kind != 5 and not emu:
         # every batch in flight has its own {docs, bytes, tokens} block (tkz_encode_batch_device_begin_counts) and its own gathered table: the
         # count all-gather of a batch is enqueued on that batch's stream behind its _end, at any N.  The untimed pass (the second workspace
         # takes its size) runs WITHOUT the collective, and the ranks agree that every one of them got through it before any enters a
@@ -435,6 +684,58 @@ def main():
         N.shard_write_device(path, d_ids.data_ptr(), ntok, d_ooffs.data_ptr(), n_docs, g["doc_base"], g["token_base"], device=local_rank)
         shard_note = {"file": path, "bytes": os.path.getsize(path), "seconds": round(time.perf_counter() - ts, 3)}
 
+    # ---- N > 1: parity on every rank.  Each rank checks the first and the last --parity-sample-docs documents of ITS OWN shard against the oracle
+    # (tkzo_check_batch on its share of the host's CPUs, all ranks at the same time), the verdicts are reduced, and rank 0's line says
+    # "bit-exact on N x ... sampled docs" or names the first bad (rank, document).  Nothing of this is inside a timed region.
+    multi = None
+    if world > 1 and not args.no_cpu_baseline:
+        verdict = [0, 0, 0, 0, 1 << 62, 0.0]                     # bad docs, docs checked, tokens, ranks that could not check, first bad (rank << 40 | doc), seconds
+        note_err = None
+        try:
+            from oracle import oracle as O
+            ncpu = max(1, os.cpu_count() or 1)
+            try:
+                q = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q[0] != "max":
+                    ncpu = max(1, min(ncpu, int(float(q[0]) / float(q[1]) + 0.5)))
+            except Exception:
+                pass
+            th = max(1, ncpu // world)
+            res = check_ranges(O, O.Vocab(raw), args.pattern, d_bytes, d_offs, d_ids, d_ooffs, ntok, sample_ranges(n_docs, args.parity_sample_docs), th)
+            same_counts = int(d_ooffs[0].item()) == 0 and int(d_ooffs[n_docs].item()) == ntok
+            if not same_counts and res["bad"] == 0:
+                res["bad"], res["first_bad"] = 1, 0
+            verdict = [res["bad"], res["docs"], res["tokens"], 0, ((rank << 40) | max(0, res["first_bad"])) if res["bad"] else (1 << 62), res["seconds"]]
+        except Exception as ex:                                  # (e.g. no C compiler for the oracle on this host: the line says so instead of claiming parity)
+            verdict[3] = 1
+            note_err = "%s: %s" % (type(ex).__name__, ex)
+        tsum = torch.tensor(verdict[:4], dtype=torch.int64, device=dev)
+        tmin = torch.tensor([verdict[4]], dtype=torch.int64, device=dev)
+        tmax = torch.tensor([verdict[5]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        bad_all, docs_all, tok_all, failed = (int(x) for x in tsum.cpu().tolist())
+        first_code = int(tmin.item())
+        per = min(args.parity_sample_docs, n_docs) if n_docs > 2 * args.parity_sample_docs else None
+        where = ("the first and the last %d documents of every rank's shard" % per) if per else "every document of every rank's shard"
+        if failed:
+            note = "unchecked on %d of %d ranks (CPU oracle unavailable%s); %d sampled docs checked elsewhere, %d differ" % (failed, world, ": " + note_err if note_err else "", docs_all, bad_all)
+        elif bad_all:
+            note = "MISMATCH vs oracle: %d of %d sampled docs differ; first: rank %d, document %d of its shard" % (bad_all, docs_all, first_code >> 40, first_code & ((1 << 40) - 1))
+        else:
+            note = ("bit-exact vs oracle on %d x %d = %d sampled docs (%s; %d tokens; every rank's offsets start at 0 and end at its token count; "
+                    "all ranks at once, %.1f s for the slowest)" % (world, docs_all // world, docs_all, where, tok_all, float(tmax.item())))
+        multi = {"note": note, "bad": bad_all, "docs": docs_all, "tokens": tok_all, "ranks_unchecked": failed}
+        # the other ranks sleep on the rendezvous store (a blocking socket wait, no spinning) while rank 0 times the CPU baseline on the host's cores
+        store = dist.distributed_c10d._get_default_store()
+        if rank != 0:
+            try:
+                import datetime
+                store.wait(["tkz_bench_cpu_baseline_done"], datetime.timedelta(seconds=1200))
+            except Exception:                                    # (rank 0 died before its line: nothing to wait for)
+                pass
+
     if rank == 0:
         job_bytes, job_tokens, job_docs = g["bytes"], g["tokens"], g["docs"]
         ms_per_step = dt / args.steps * 1e3
@@ -442,7 +743,8 @@ def main():
         # ---- roofline of the dominant kernel (HBM-bound integer/indexing work; no MFMA) ----
         dom = max(kms, key=lambda k: kms[k][0])
         dom_ms = kms[dom][0] / max(1, kms[dom][1])
-        alg_bytes = total + 4 * n_tokens_rank + 16 * n_docs      # read text + write int32 ids + 8 B offset in + 8 B offset out
+        # read text + write int32 ids + 8 B offset in + 8 B offset out -- of the rank whose kernels are priced (the slowest one at N > 1)
+        alg_bytes = int(g["table"][kms_rank][1]) + 4 * int(g["table"][kms_rank][2]) + 16 * int(g["table"][kms_rank][0])
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         traffic, traffic_pipeline, traffic_by_kernel, traffic_note = None, None, None, "no PMC summary for this build"
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -460,7 +762,7 @@ def main():
             except Exception:
                 traffic = None
         leftovers = enc.pretok_leftovers() if hasattr(enc, "pretok_leftovers") else (0, 0)
-        pipe_achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9
+        pipe_achieved = alg_bytes / (ms_per_step * 1e-3) / 1e9      # (ms_per_step: the slowest rank's; alg_bytes: that rank's)
         # `achieved` / `frac` price the WHOLE step (every kernel of the launch sequence has to move its share of the algorithmic bytes: crediting
         # the dominant kernel alone with all of them flatters); the dominant kernel's own figure is beside it (`*_dominant`).  `traffic` is the
         # dominant kernel's counted HBM bytes per launch, `traffic_pipeline` all kernels' together, `wasted` = traffic_pipeline / algorithmic.
@@ -469,7 +771,7 @@ def main():
                     "achieved_dominant": round(achieved, 2), "frac_dominant": round(achieved / HBM_PEAK_GBPS, 5),
                     "traffic": traffic, "traffic_pipeline": traffic_pipeline,
                     "wasted": round(traffic_pipeline / alg_bytes, 3) if traffic_pipeline else None, "traffic_by_kernel": traffic_by_kernel, "traffic_note": traffic_note,
-                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
+                    "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4), "rank": kms_rank,
                     "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kms.items()},
                     "note": "achieved = algorithmic bytes (SURVEY.md 8d: text + 4 B per id + 16 B per document) / the step's time; *_dominant = the same bytes / "
                             "the dominant kernel's average launch duration (HIP events on the launch stream)"}
@@ -480,31 +782,50 @@ def main():
         host_path = None
         parity_note = "unchecked"
         host_api = None
-        if world == 1 and not args.no_cpu_baseline:
+        if multi is not None:
+            # N > 1: every rank has checked the first and the last --parity-sample-docs documents of ITS OWN shard (above, all ranks at once); the CPU
+            # baseline is rank 0's alone, on a bounded sample of its shard, while the other ranks sleep on the store
+            parity_note = multi["note"]
+        if not args.no_cpu_baseline and (world == 1 or multi is not None):
             try:
                 from oracle import oracle as O
                 ov = O.Vocab(raw)
                 ncpu = max(1, os.cpu_count() or 1)
-                # ---- parity: EVERY document of the batch against the oracle, on all host cores (tkzo_check_batch encodes each
-                # document and compares it in place with the ids the GPU left for it: nothing beyond the inputs is allocated) ----
-                h_offs = d_offs.cpu().numpy()
-                h_bytes = d_bytes[:total].cpu().numpy()
-                h_ooffs = d_ooffs.cpu().numpy()
-                h_ids = d_ids[:n_tokens_rank].cpu().numpy()
-                same = int(h_ooffs[0]) == 0 and int(h_ooffs[n_docs]) == n_tokens_rank and bool((np.diff(h_ooffs) >= 0).all())
-                tm = {}
-                if n_docs >= 4 * ncpu:
-                    bad, first_bad, otok = O.check_batch(ov, args.pattern, h_bytes, h_offs, h_ids, h_ooffs, threads=ncpu, timing=tm)
-                    best = (total / tm["seconds"] / 1e6, ncpu, total, n_docs)
-                else:                                         # (one giant document: a single thread, no sweep)
-                    bad, first_bad, otok = O.check_batch(ov, args.pattern, h_bytes, h_offs, h_ids, h_ooffs, threads=1, timing=tm)
-                    best = (total / tm["seconds"] / 1e6, 1, total, n_docs)
-                same = same and bad == 0 and otok == n_tokens_rank
-                parity_note = ("bit-exact vs oracle on all %d docs (%d tokens, %.1f s on %d host threads); offsets monotone, ending at the token count"
-                               % (n_docs, otok, tm["seconds"], best[1])) if same else "MISMATCH vs oracle: %d of %d docs differ, first %d" % (bad, n_docs, first_bad)
-                if args.parity_only:
-                    raise StopIteration
-                # ---- CPU baseline: the same restatement timed on the host cores.  The all-core run above covers the whole batch; fewer
+                if world == 1:
+                    # ---- parity: EVERY document of the batch against the oracle, on all host cores (tkzo_check_batch encodes each
+                    # document and compares it in place with the ids the GPU left for it: nothing beyond the inputs is allocated) ----
+                    h_offs = d_offs.cpu().numpy()
+                    h_bytes = d_bytes[:total].cpu().numpy()
+                    h_ooffs = d_ooffs.cpu().numpy()
+                    h_ids = d_ids[:n_tokens_rank].cpu().numpy()
+                    same = int(h_ooffs[0]) == 0 and int(h_ooffs[n_docs]) == n_tokens_rank and bool((np.diff(h_ooffs) >= 0).all())
+                    tm = {}
+                    if n_docs >= 4 * ncpu:
+                        bad, first_bad, otok = O.check_batch(ov, args.pattern, h_bytes, h_offs, h_ids, h_ooffs, threads=ncpu, timing=tm)
+                        best = (total / tm["seconds"] / 1e6, ncpu, total, n_docs)
+                    else:                                         # (one giant document: a single thread, no sweep)
+                        bad, first_bad, otok = O.check_batch(ov, args.pattern, h_bytes, h_offs, h_ids, h_ooffs, threads=1, timing=tm)
+                        best = (total / tm["seconds"] / 1e6, 1, total, n_docs)
+                    same = same and bad == 0 and otok == n_tokens_rank
+                    parity_note = ("bit-exact vs oracle on all %d docs (%d tokens, %.1f s on %d host threads); offsets monotone, ending at the token count"
+                                   % (n_docs, otok, tm["seconds"], best[1])) if same else "MISMATCH vs oracle: %d of %d docs differ, first %d" % (bad, n_docs, first_bad)
+                    if args.parity_only:
+                        raise StopIteration
+                    covers = "the %d-thread run covers the whole batch and is the parity check" % ncpu
+                else:
+                    # (rank 0's sample: the first --cpu-sample-docs documents of its shard; the all-thread run of the sweep is its first point)
+                    ns0 = min(args.cpu_sample_docs, n_docs)
+                    h_offs = d_offs[:ns0 + 1].cpu().numpy()
+                    h_bytes = d_bytes[:int(h_offs[-1])].cpu().numpy()
+                    h_ooffs = d_ooffs[:ns0 + 1].cpu().numpy()
+                    h_ids = d_ids[:int(h_ooffs[-1])].cpu().numpy()
+                    tm = {}
+                    bad0, _, _ = O.check_batch(ov, args.pattern, h_bytes, h_offs, h_ids, h_ooffs, threads=ncpu, timing=tm)
+                    best = (len(h_bytes) / tm["seconds"] / 1e6, ncpu, len(h_bytes), ns0)
+                    if bad0:
+                        parity_note += "; MISMATCH in rank 0's CPU-baseline sample: %d documents" % bad0
+                    covers = "every run on rank 0's first %d documents, the other ranks asleep" % ns0
+                # ---- CPU baseline: the same restatement timed on the host cores.  The all-core run above is the first point; fewer
                 # threads (SMT siblings and memory channels decide which count is best) on a bounded sample; and one thread ----
                 ns = min(args.cpu_sample_docs, n_docs)
                 nb = int(h_offs[ns])
@@ -538,9 +859,11 @@ def main():
                        "kind": "port", "value_1_thread": cpu_1t, "by_threads": sweep,
                        "host_threads_available": ncpu, "cgroup_cpu_max": quota,
                        "host_parallel_speedup": O.host_parallelism(sorted({1, max(1, ncpu // 4), max(1, ncpu // 2), ncpu})),
-                       "sample": "%d documents (%.1f MB) of the same corpus on %d host threads (`cores`: the CPUs the cgroup grants them) -- the best of the thread counts tried (by_threads: MB/s; the %d-thread "
-                                 "run covers the whole batch and is the parity check); one thread: the first %d documents; reference-algorithm CPU restatement "
-                                 "(oracle/), 8192-entry LRU memo and reusable scratch per thread" % (best[3], best[2] / 1e6, best[1], ncpu, n1)}
+                       "sample": "%d documents (%.1f MB) of the same corpus on %d host threads (`cores`: the CPUs the cgroup grants them) -- the best of the thread counts tried (by_threads: MB/s; "
+                                 "%s); one thread: the first %d documents; reference-algorithm CPU restatement "
+                                 "(oracle/), 8192-entry LRU memo and reusable scratch per thread" % (best[3], best[2] / 1e6, best[1], covers, n1)}
+                if world > 1 or emu:
+                    raise StopIteration              # (the PCIe-inclusive and host-API legs are single-GPU companions)
                 ns = min(ns, n_docs)
                 # the real C# TokenizerLib beside it, when this host has a .NET SDK and a reference checkout (never in this image)
                 if shutil.which("dotnet") and os.environ.get("TKZ_REFERENCE_DIR"):
@@ -624,14 +947,18 @@ def main():
                      3: "BASELINE.json configs[4] shape: long-context docs with long single-class runs, %d docs/GPU, %d..%d B (mean %.0f), device-resident",
                      4: "real source text: the reference's lib.rs.txt tiled, %d docs/GPU, %d..%d B (mean %.0f), device-resident",
                      5: "the reference's own benchmark shape (PerfBenchmark/Program.cs:14-32): %d document/GPU of words of the 4096-word table joined by single spaces, "
-                        "one Encode call, %d..%d B (mean %.0f), device-resident"}
+                        "one Encode call, %d..%d B (mean %.0f), device-resident",
+                     6: "REAL text: the source / documentation files of the box (every file once, sorted, NOT tiled; sha256 in config.real_text), %d docs/GPU, "
+                        "%d..%d B (mean %.0f), device-resident"}
         if args.kind == 1 and world > 1:
             workloads[1] = ("BASELINE.json configs[3]: cl100k_base pattern, %d synthetic ASCII docs/GPU (" + str(n_docs * world) + " documents sharded over " + str(world) +
                             " GPUs), %d..%d B (mean %.0f), device-resident")
         line = {
             "metric": "input MB/s encoded (cl100k_base)", "value": round(value, 1), "unit": "MB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": ("EMULATED: the kernels ran on the CPU emulator of tests/hostemu (a test of this script, not a measurement)" if emu else
+                     "real text of the box (not tiled)" if args.kind == 6 else "synthetic"),
             "config": {"workload": workloads[args.kind] % (n_docs, args.min_len, args.max_len, job_bytes / max(1, job_docs)),
                        "pattern": PATTERN_NAME[args.pattern],
                        "piece_memo": memo_note,
@@ -642,6 +969,9 @@ def main():
             "tokens_per_s": round(job_tokens * args.steps / dt, 1),
             "piece_stats": piece_stats,
             "value_no_memo": round(job_bytes * nm_steps / dt_nomemo / 1e6, 1) if dt_nomemo else None,
+            "value_warm_memo": round(job_bytes / dt_warm * args.steps / 1e6, 1) if dt_warm else None,
+            "value_real_text": (real_leg.get("by_vocab", {}).get("gpt2/pattern1", {}).get("value") if real_leg else None),
+            "real_text": real_leg,
             "value_heldout_vocab": heldout["value"] if heldout and "value" in heldout else None,
             "heldout_vocab": heldout,
             "value_two_in_flight": round(job_bytes / dt_pipe / 1e6, 1) if dt_pipe else None,
@@ -654,9 +984,15 @@ def main():
             "value_host_api": host_api["value"] if host_api and "value" in host_api else None,
             "host_api": host_api,
         }
+        if real_meta:
+            line["config"]["real_text"] = real_meta
+        if emu:
+            line["emulated"] = True
         if shard_note:
             line["shard_file"] = shard_note
         os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if multi is not None:
+            dist.distributed_c10d._get_default_store().set("tkz_bench_cpu_baseline_done", "1")
     if comm is not None:
         comm.close()
     if world > 1:
