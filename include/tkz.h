@@ -272,7 +272,17 @@ enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1,
        TKZ_OPT_PIECE_MEMO = 2,
        /* 1: the batch path counts what it meets (tkz_encoder_piece_stats); 0 (default): it does not -- the counting adds a few atomics per
         * wavefront and one small kernel per batch, so measure with it off. */
-       TKZ_OPT_PIECE_STATS = 3 };
+       TKZ_OPT_PIECE_STATS = 3,
+       /* Promoted pieces.  The memo's answers never change, so the encoder moves its hottest entries into the whole-piece key tables themselves: such
+        * a piece is then found by the lookup every piece goes through anyway (TikTokenizer.cs:262 -- with its <= 4 tokens in place of a rank) instead of
+        * being listed, looked up in the memo and answered again in every batch.  Same ids by construction.  Value 1 (default): automatic -- the first
+        * batch of at least 8 MB on the batch path counts the memo's hits per slot and the hottest entries (at most 65,536) are promoted when it ends (the
+        * memo is copied back and the key tables rebuilt on the host: tens of milliseconds, once), and once more a gigabyte of text later; 0: never
+        * automatically; 2: promote now whatever the memo holds; 3: drop every promotion.  2 and 3 are refused with TKZ_E_ARG while a call is in flight. */
+       TKZ_OPT_PROMOTE = 4,
+       /* tuning knobs of the automatic promotion: the smallest batch (bytes) that may be a learning batch (default 8 MB), and the most promoted
+        * pieces the key tables hold (default 65,536; at most 2^22) */
+       TKZ_OPT_PROMOTE_MIN_BYTES = 5, TKZ_OPT_PROMOTE_CAP = 6 };
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
@@ -297,7 +307,8 @@ void tkz_encoder_small_path_calls(const tkz_encoder* e, int64_t* calls, int64_t*
 int32_t tkz_encoder_small_path_phases(const tkz_encoder* e, int64_t* clocks16);
 /* What the batches since the last reset met, with TKZ_OPT_PIECE_STATS on (8 values): [0] batches, [1] pieces (regex matches), [2] pieces of
  * at most 16 bytes that missed the vocabulary as a whole (TikTokenizer.cs:262 -> :268), [3] of 17..1024 bytes (merged a lane each up to 256 bytes, a wavefront each beyond), [4] of more than 1024 bytes (a workgroup each),
- * [5] piece-memo lookups and [6] hits among them (the misses went through BytePairEncode), [7] 0.  Whole-piece hit rate =
+ * [5] piece-memo lookups and [6] hits among them (the misses went through BytePairEncode), [7] promoted pieces the key tables hold now
+ * (TKZ_OPT_PROMOTE: they count as whole-piece hits).  Whole-piece hit rate =
  * 1 - ([2] + [3] + [4]) / [1]. */
 tkz_status tkz_encoder_piece_stats(tkz_encoder* e, int64_t* out8, int32_t reset);
 /* Slots of the piece memo (TKZ_OPT_PIECE_MEMO) and slots per bucket, informational; the bucket a piece of 1..16 bytes would use

@@ -344,6 +344,119 @@ def check_piece_memo(lib, O, vocab, ovocab, pattern=N.CL100K, seed=23):
     run(docs_b, exp_b, eoff_b, "memo off again")
 
 
+def check_promotion(lib, O, vocab, ovocab, pattern=N.CL100K, seed=61):
+    """Promoted pieces (TKZ_OPT_PROMOTE): hot memo entries moved into the SHORT / MID key tables with their <= 4 tokens in place of a rank.  Same ids
+    as the oracle before, after, and after dropping them again -- on the batch path, the single-launch path, the piece-granular entry and pieces
+    handed over one by one; by hand (value 2) and automatically (a learning batch counts the memo's hits, the batch's end promotes)."""
+    rng = random.Random(seed)
+    cons, vow = "bcdfghjklmnpqrstvwxz", "aeiou"
+    r1 = random.Random(seed + 1)
+    # pronounceable non-words of 4..16 bytes (the last ones go to the MID table: 13..16), repeated: they miss the vocabulary and fill the memo
+    lex = ["".join(r1.choice(cons) + r1.choice(vow) for _ in range(r1.randint(2, 7))) + r1.choice(["", "s", "ed", "ing"]) for _ in range(400)]
+    lex = [w for w in lex if len(w) <= 15] + ["zqxjkvbwpfyhgm", "qzqzqzqzqzqzqz", "xv", "ĳĳĳ", "żółć"]
+
+    def words(n, r, lexicon):
+        out = []
+        while sum(map(len, out)) < n:
+            out.append(r.choice([" ", " ", "\n", " the ", ", ", " 12 "]) + r.choice(lexicon))
+        return "".join(out)
+    # (both batches are too large for the single-launch path, which keeps no statistics)
+    docs_a = [words(n, random.Random(seed + 10 + i), lex).encode("utf-8") for i, n in enumerate([400, 3000, 9000, 40000, 60000, 30000, 3000, 500])]
+    docs_b = [words(n, random.Random(seed + 30 + i), lex[::2] + ["brandnewword", "anotherone"]).encode("utf-8") for i, n in enumerate([600, 5000, 30000, 50000, 40000, 20000])]
+    small = [words(300, random.Random(seed + 50 + i), lex).encode("utf-8") for i in range(5)] + [b""]
+    oenc = O.Encoder(ovocab, pattern)
+    exp = {id(d): oracle_encode_docs(oenc, d) for d in (docs_a, docs_b, small)}
+    enc = N.Encoder(vocab, pattern)
+    enc.set_option(N.OPT_PROMOTE, 0)                     # (nothing automatic in the first half of the test)
+
+    def run(docs, what):
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        e, eo = exp[id(docs)]
+        assert ooff.tolist() == eo and ids.tolist() == e, what
+
+    def stats(docs):
+        enc.set_option(N.OPT_PIECE_STATS, 1)
+        enc.piece_stats(reset=True)
+        run(docs, "statistics run")
+        st = enc.piece_stats(reset=True)
+        enc.set_option(N.OPT_PIECE_STATS, 0)
+        return st
+    run(docs_a, "before: memo empty")
+    before = stats(docs_a)
+    assert before["promoted_pieces_in_tables"] == 0 and before["short_misses"] > 100
+    enc.set_option(N.OPT_PROMOTE, 2)                     # by hand: whatever the memo holds
+    after = stats(docs_a)
+    assert after["promoted_pieces_in_tables"] > 50, after
+    # the pieces the memo answered are whole-piece hits now (what is left are pieces of more than 4 tokens, which no memo entry holds)
+    assert after["short_misses"] <= before["short_misses"] - int(0.9 * before["memo_hits"]) and before["memo_hits"] > 1000, (before, after)
+    assert after["pieces"] == before["pieces"]
+    run(docs_a, "promoted, same text")
+    run(docs_b, "promoted, other text (promoted pieces beside pieces that are not)")
+    small_before = enc.small_path_calls()
+    run(small, "promoted, single-launch path")
+    for d in small[:3]:
+        data, offs = pack([d])
+        ids, ooff = enc.encode_batch(data, offs)
+        assert ids.tolist() == oenc.encode_bytes(d)
+    assert enc.small_path_calls()[0] > small_before[0]
+    # piece granularity, and promoted pieces handed over as pieces
+    data, offs = pack(docs_a[:3])
+    ids, dpo, pbo, pto = enc.encode_batch_pieces(data, offs)
+    assert ids.tolist() == oracle_encode_docs(oenc, docs_a[:3])[0]
+    pcs = [w.encode("utf-8") for w in lex[:200]] + [(" " + w).encode("utf-8") for w in lex[:200]]
+    data, offs = pack(pcs)
+    ids, ooff = enc.encode_pieces(data, offs)
+    want = []
+    for q in pcs:
+        want += ovocab.bpe(q) if ovocab.rank(q) < 0 else [ovocab.rank(q)]
+    assert ids.tolist() == want
+    # a second promotion by hand adds what the memo has learnt since (docs_b's new words), never a piece twice
+    n1 = after["promoted_pieces_in_tables"]
+    run(docs_b, "fill")
+    enc.set_option(N.OPT_PROMOTE, 2)
+    n2 = stats(docs_b)["promoted_pieces_in_tables"]
+    assert n2 >= n1
+    run(docs_a, "after the second promotion")
+    # the cap
+    enc.set_option(N.OPT_PROMOTE, 3)                     # dropped: the vocabulary's own tables again
+    dropped = stats(docs_a)
+    assert dropped["promoted_pieces_in_tables"] == 0 and dropped["short_misses"] == before["short_misses"], (before, dropped)
+    enc.set_option(N.OPT_PROMOTE_CAP, 7)
+    enc.set_option(N.OPT_PROMOTE, 2)
+    assert stats(docs_a)["promoted_pieces_in_tables"] == 7
+    run(docs_b, "capped")
+    # ---- automatic: a learning batch (the first one of at least PROMOTE_MIN_BYTES) counts hits, its end promotes the entries that were hit ----
+    enc2 = N.Encoder(vocab, pattern)
+    enc2.set_option(N.OPT_PROMOTE_MIN_BYTES, 20000)
+    data, offs = pack(small)
+    enc2.encode_batch(data, offs)                        # too small: not a learning batch
+    enc2.set_option(N.OPT_PIECE_STATS, 1)
+    big = docs_a + docs_b
+    data, offs = pack(big)
+    ids, ooff = enc2.encode_batch(data, offs)            # learns (its memo starts empty: the hits are those of this very batch), promotes at its end
+    e_a, e_b = exp[id(docs_a)][0], exp[id(docs_b)][0]
+    assert ids.tolist() == e_a + e_b
+    st1 = enc2.piece_stats(reset=True)
+    assert st1["promoted_pieces_in_tables"] > 20, st1
+    ids, ooff = enc2.encode_batch(data, offs)
+    assert ids.tolist() == e_a + e_b
+    st2 = enc2.piece_stats(reset=True)
+    assert st2["short_misses"] <= st1["short_misses"] - int(0.8 * st1["memo_hits"]) and st1["memo_hits"] > 1000, (st1, st2)      # (the hits are sampled: one group in eight)
+    # the second automatic round waits for a gigabyte more: no further promotion here, and the same ids
+    ids, ooff = enc2.encode_batch(data, offs)
+    assert ids.tolist() == e_a + e_b and enc2.piece_stats()["promoted_pieces_in_tables"] == st1["promoted_pieces_in_tables"]
+    # automatic promotion switched off: nothing is promoted
+    enc3 = N.Encoder(vocab, pattern)
+    enc3.set_option(N.OPT_PROMOTE, 0)
+    enc3.set_option(N.OPT_PROMOTE_MIN_BYTES, 20000)
+    enc3.set_option(N.OPT_PIECE_STATS, 1)
+    for _ in range(2):
+        ids, ooff = enc3.encode_batch(data, offs)
+        assert ids.tolist() == e_a + e_b
+    assert enc3.piece_stats()["promoted_pieces_in_tables"] == 0
+
+
 def check_miss_lists(lib, O, vocab, ovocab, pattern=N.CL100K, seed=41):
     """The per-sub-tile miss lists (k_probe -> merge kernels -> k_place): sub-tiles with more misses than a list starts with (the batch
     is redone with longer lists), short and long misses sharing one list from both ends, a sub-tile of 1024 one-byte pieces, and calls
@@ -982,6 +1095,9 @@ def check_begin_end(lib, O, vocab, ovocab, pattern=N.CL100K, seed=61, upload=Non
     rng = random.Random(seed)
     alpha = RC.alphabet()
     enc = N.Encoder(vocab, pattern)
+    # (the first begun batch of a few kilobytes is a LEARNING batch -- it counts the memo's hits -- and its _end, the last one below, promotes the
+    #  hottest entries into the key tables while nothing else is in flight any more; the batches after that run on the promoted tables)
+    enc.set_option(N.OPT_PROMOTE_MIN_BYTES, 3000)
     oenc = O.Encoder(ovocab, pattern)
     if upload is None:
         upload = lambda a: (a, a.ctypes.data)
@@ -1012,6 +1128,12 @@ def check_begin_end(lib, O, vocab, ovocab, pattern=N.CL100K, seed=61, upload=Non
     for k, b in enumerate(batches):
         if k != 3:
             assert back(b["counts"][0]).tolist() == [b["n"], b["total"], b["ntok"]], k
+    # the same four again, begun and ended in order: whatever the learning batch promoted is in the tables now
+    for b in batches:
+        h = enc.encode_batch_device_begin(b["bytes"][1], b["offs"][1], b["n"], b["total"], b["ids"][1], max(1, b["total"]), b["ooff"][1], streams[0])
+        ntok = enc.encode_batch_device_end(h)
+        exp, eoff = oracle_encode_docs(oenc, b["docs"])
+        assert ntok == len(exp) and back(b["ids"][0])[:ntok].tolist() == exp and back(b["ooff"][0]).tolist() == eoff
     # an empty batch: _begin does not wait, the counts and offsets are there after _end
     ec, eo = upload(np.full(3, -1, np.int64)), upload(np.full(3, -1, np.int64))
     eb, ei_ = upload(np.zeros(64, np.uint8)), upload(np.zeros(3, np.int64))

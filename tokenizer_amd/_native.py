@@ -17,6 +17,8 @@ P1, CL100K, O200K, O200K_DOTNET = 1, 2, 3, 4   # O200K: ECMAScript engine (TS re
 OPT_PRETOK_SEQUENTIAL = 1
 OPT_PIECE_MEMO = 2
 OPT_PIECE_STATS = 3
+OPT_PROMOTE_MIN_BYTES, OPT_PROMOTE_CAP = 5, 6
+OPT_PROMOTE = 4        # 0 / 1: automatic promotion of hot memo entries into the key tables off / on; 2: promote now; 3: drop the promotions
 K_NAMES = ["k_docmark", "k_pretok", "k_probe", "k_scan", "k_place", "k_docoffs", "k_merge_long_group", "k_merge_short"]
 
 
@@ -237,7 +239,7 @@ class Encoder:
         return {"batches": int(out[0]), "pieces": pieces, "short_misses": sm, "long_misses": lm, "giant_pieces": gm,
                 "whole_piece_hit_rate": round(1.0 - (sm + lm + gm) / pieces, 5) if pieces else None,
                 "memo_lookups": look, "memo_hits": hit, "memo_hit_rate": round(hit / look, 5) if look else None,
-                "merged_short": look - hit if look else sm}
+                "merged_short": look - hit if look else sm, "promoted_pieces_in_tables": int(out[7])}
 
     def set_profiling(self, on):
         self.lib.check(self.lib.L.tkz_encoder_set_profiling(self._h, 1 if on else 0))

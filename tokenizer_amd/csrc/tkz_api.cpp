@@ -7,6 +7,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/tkz.h"
@@ -91,11 +92,12 @@ struct tkz_vocab { tkz::Vocab v; };
 struct Workspace {
     // kernel workspace
     DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_dense, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
-    DevBuf w_mlist, w_mquad, w_mcount;
+    DevBuf w_mlist, w_mquad, w_mcount, w_pextra;
     DevBuf w_counts3;                      // {n_docs, n_bytes, n_tokens} of the batch this workspace is running (tkz_pending_counts_device)
     int32_t mcap = tkz::kMissCapMin;       // entries of a sub-tile's miss list; grows (once, to what the batch needed) when a sub-tile overflows it
     bool place128 = false;                 // a recent batch of this workspace had more than a fifth of its sub-tiles above 64 list entries: k_place<128>
     int low_lists = 0, low_place = 0;      // consecutive batches that would have done with shorter lists / with k_place<64> (hysteresis: kLowBatches)
+    bool learning = false;                 // this workspace's batch counts memo hits per slot (TkzTables::memo_hits): the encoder promotes the hottest entries when it ends
     // staging for the host-buffer entry points (two sets: chunk k+1 is uploaded while chunk k is encoded and chunk k-1 downloaded)
     DevBuf s_bytes[2], s_offs[2], s_out[2], s_outoffs[2];
     // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
@@ -120,7 +122,7 @@ struct Workspace {
     double ms[tkz::K_COUNT] = {};
     int64_t launches[tkz::K_COUNT] = {};
     void release_all() {
-        DevBuf* bufs[] = {&w_counts3, &w_mlist, &w_mquad, &w_mcount, &w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
+        DevBuf* bufs[] = {&w_counts3, &w_mlist, &w_mquad, &w_mcount, &w_pextra, &w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
                           &w_doctok, &w_dcount, &w_dbase, &w_counters, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
                           &s_outoffs[0], &s_outoffs[1], &u_units, &u_offs, &u_docbits, &u_grp, &u_tsum, &u_tbase, &u_bsum, &u_counters, &u_bytes, &u_boffs,
                           &d_grp, &d_tsum, &d_tbase, &d_bsum, &d_counters, &d_ids, &d_idoffs, &d_out, &d_outoffs, &p_boffs, &p_toffs, &p_docp};
@@ -160,6 +162,19 @@ struct tkz_encoder {
     int64_t stat_batches = 0, stat_giants = 0;   // ... and what the host adds per batch (under mu)
     int pending = 0;                       // tkz_pending handles outstanding (under mu)
     bool destroyed = false;                // tkz_encoder_destroy was called while handles were outstanding: the last _end frees the encoder
+    // ---- promoted pieces (tkz_tables.h): hot memo entries moved into the SHORT / MID tables themselves.  All under mu. ----
+    int promo_mode = 1;                    // TKZ_OPT_PROMOTE: 0 never on its own, 1 automatic (default)
+    int promo_rounds = 0;                  // automatic promotions so far
+    int64_t promo_min_bytes = int64_t(8) << 20;   // a batch of at least this many bytes may be a learning batch (TKZ_OPT_PROMOTE_MIN_BYTES)
+    size_t promo_cap = 65536;              // promoted pieces the key tables hold at most (TKZ_OPT_PROMOTE_CAP)
+    bool learning = false;                 // a batch that counts memo hits is in flight (one at a time)
+    int64_t bytes_seen = 0, bytes_at_promo = 0;   // bytes the batch path has encoded; ... when the last promotion happened
+    DevBuf t_memo_hits, t_promo;           // the hit counters of a learning batch; the token quads of the promoted pieces
+    std::vector<DevBuf> retired;           // table images replaced by a promotion while other calls may still have been probing them: freed with the encoder
+    std::vector<tkz::KeyItem> promo_items; // promoted piece -> promo code, in order of promotion
+    std::unordered_set<std::string> promo_keys;
+    std::vector<uint32_t> promo_quads;     // 4 tokens per promoted piece (host copy of t_promo)
+    uint32_t short_slots_n = 0, mid_slots_n = 0;
 };
 
 namespace {
@@ -250,6 +265,96 @@ tkz_status build_decode_table(tkz_encoder* e) {
     return TKZ_OK;
 }
 
+// ---- promoted pieces ------------------------------------------------------------------------------------------------------------------------
+// The reference's LRUCache (TikTokenizer.cs:254,270) answers a piece it has seen before without running BytePairEncode again; the device memo does
+// the same inside k_merge_short -- at the price of a list entry, a quad, a 32-byte slot and an answer per missed piece and batch.  Under a
+// vocabulary that has not seen the text 7 of 8 short misses are such hits and that kernel is 40 % of the step.  A memo answer never changes, so the
+// hottest ones are PROMOTED: the host reads the memo (and, after a learning batch, the sampled hit count of every slot) back, adds the pieces to the
+// SHORT / MID key tables with a promo code in place of a rank (tkz_tables.h), and uploads the new images; k_probe then finds such a piece like any
+// key, the merge kernels never see it, k_place gathers its <= 4 tokens.  Results are the same ids by construction (the memo's answers are exact and a
+// slot is read back under the same validity rule the kernels use); the tests compare a promoted encoder with the oracle.
+constexpr int kPromoAutoRounds = 2;                // automatic promotions: the first batch of >= kPromoMinBytes, and one more after kPromoSecondBytes more
+constexpr int64_t kPromoSecondBytes = int64_t(1) << 30;
+
+// (re)builds the SHORT / MID images from the vocabulary's keys + the promoted pieces and publishes them; `retire`: other calls may be probing the
+// current images (they are kept until the encoder is destroyed), else they are freed
+tkz_status publish_key_tables(tkz_encoder* e, bool retire) {
+    std::vector<tkz::KeyItem> items;
+    items.reserve(e->dec_vocab.size() + e->promo_items.size());
+    {
+        std::vector<size_t> order(e->dec_vocab.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return e->dec_vocab[a].first < e->dec_vocab[b].first; });      // rank order: most frequent first
+        for (size_t i : order) { const std::string& k = e->dec_vocab[i].second; if (!k.empty() && k.size() <= TKZ_MID_KEY_MAX) items.push_back(tkz::KeyItem{k, (uint32_t)e->dec_vocab[i].first}); }
+    }
+    for (const tkz::KeyItem& it : e->promo_items) items.push_back(it);
+    std::vector<TkzShortSlot> ss; std::vector<TkzMidSlot> ms;
+    uint32_t sseed = 0, mseed = 0;
+    tkz::build_key_tables(items, &ss, &sseed, &ms, &mseed);
+    const size_t short_bytes = ss.size() * sizeof(TkzShortSlot), mid_bytes = ms.size() * sizeof(TkzMidSlot);
+    DevBuf nt, np;
+    int64_t* acc = &e->bytes_allocated;
+    hipError_t h = nt.ensure(std::max<size_t>(64, short_bytes + mid_bytes), acc);
+    if (h == hipSuccess && short_bytes) h = hipMemcpy(nt.p, ss.data(), short_bytes, hipMemcpyHostToDevice);
+    if (h == hipSuccess && mid_bytes) h = hipMemcpy(static_cast<char*>(nt.p) + short_bytes, ms.data(), mid_bytes, hipMemcpyHostToDevice);
+    if (h == hipSuccess) h = np.ensure(std::max<size_t>(64, e->promo_quads.size() * 4), acc);
+    if (h == hipSuccess && !e->promo_quads.empty()) h = hipMemcpy(np.p, e->promo_quads.data(), e->promo_quads.size() * 4, hipMemcpyHostToDevice);
+    if (h != hipSuccess) { nt.release(); np.release(); return fail(TKZ_E_DEVICE, std::string("promoted tables: ") + hipGetErrorString(h)); }
+    if (retire) { e->retired.push_back(e->t_short); e->retired.push_back(e->t_promo); }
+    else { *acc -= (int64_t)(e->t_short.cap + e->t_promo.cap); e->t_short.release(); e->t_promo.release(); }
+    e->t_short = nt; e->t_promo = np;
+    e->T.short_slots = e->t_short.as<TkzShortSlot>(); e->T.short_nb = (uint32_t)(ss.size() / 2); e->T.short_seed = sseed;
+    e->T.mid_slots = reinterpret_cast<const TkzMidSlot*>(e->t_short.as<char>() + short_bytes); e->T.mid_ns = (uint32_t)ms.size(); e->T.mid_seed = mseed;
+    e->T.promo = e->promo_items.empty() ? nullptr : e->t_promo.as<uint4>(); e->T.promo_n = (uint32_t)e->promo_items.size();
+    e->short_slots_n = (uint32_t)ss.size(); e->mid_slots_n = (uint32_t)ms.size();
+    return TKZ_OK;
+}
+
+// The memo (and the hit counters of a learning batch, or null: every valid entry counts alike) is read back and its hottest entries are promoted.
+// Called with no lock held; takes e->mu for the bookkeeping and the publication.  *added: entries promoted by this call.
+tkz_status promote_from_memo(tkz_encoder* e, bool use_hits, bool retire, int64_t* added) {
+    if (added) *added = 0;
+    if (!e->memo_slots || e->T.max_rank >= (int32_t)kPromoFlag) return TKZ_OK;      // (a promo code must not look like a rank)
+    std::vector<TkzMemoSlot> memo(e->memo_slots);
+    std::vector<uint32_t> hits;
+    HIP_TRY(hipMemcpy(memo.data(), e->t_memo.p, memo.size() * sizeof(TkzMemoSlot), hipMemcpyDeviceToHost));
+    if (use_hits) { hits.resize(e->memo_slots); HIP_TRY(hipMemcpy(hits.data(), e->t_memo_hits.p, hits.size() * 4, hipMemcpyDeviceToHost)); }
+    std::lock_guard<std::mutex> lock(e->mu);
+    const size_t cap = e->promo_cap;
+    if (e->promo_items.size() >= cap) return TKZ_OK;
+    struct Cand { uint32_t hits, slot; };
+    std::vector<Cand> cand;
+    for (uint32_t i = 0; i < e->memo_slots; ++i) {
+        const uint32_t* v = memo[i].v;
+        // the kernels' validity rule: the valid tag in every value word, not the BUSY mark; and a complete key: no zero byte inside its length, nothing
+        // but zero bytes beyond it (other calls may be inserting while this copy was taken)
+        if (!((v[0] & v[1] & v[2] & v[3]) & kMemoValid) || v[0] == kMemoBusy) continue;
+        if (use_hits && hits[i] == 0) continue;
+        const uint32_t len = ((v[1] >> 27) & 15u) + 1u;
+        bool ok = true;
+        for (uint32_t b = 0; b < 16 && ok; ++b) { const uint32_t byte = (memo[i].k[b >> 2] >> (8 * (b & 3))) & 0xFFu; ok = b < len ? byte != 0 : byte == 0; }
+        if (!ok) continue;
+        cand.push_back(Cand{use_hits ? hits[i] : 1u, i});
+    }
+    std::stable_sort(cand.begin(), cand.end(), [](const Cand& a, const Cand& b) { return a.hits > b.hits; });
+    int64_t n_new = 0;
+    for (const Cand& c : cand) {
+        if (e->promo_items.size() >= cap) break;
+        const TkzMemoSlot& m = memo[c.slot];
+        const uint32_t len = ((m.v[1] >> 27) & 15u) + 1u, cnt = ((m.v[0] >> 29) & 3u) + 1u;
+        std::string key(len, '\0');
+        for (uint32_t b = 0; b < len; ++b) key[b] = (char)((m.k[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+        if (!e->promo_keys.insert(key).second) continue;                        // (promoted before: a stale memo entry)
+        const uint32_t index = (uint32_t)e->promo_items.size();
+        e->promo_items.push_back(tkz::KeyItem{key, kPromoFlag | ((cnt - 1u) << kPromoCntShift) | index});
+        for (int t = 0; t < 4; ++t) e->promo_quads.push_back((uint32_t)t < cnt ? (m.v[t] & 0x07FFFFFFu) : 0u);
+        ++n_new;
+    }
+    if (added) *added = n_new;
+    if (!n_new) return TKZ_OK;
+    return publish_key_tables(e, retire);
+}
+
 // workspace of one batch of `total` bytes / n_docs documents (grow-only buffers: nothing happens once they are large enough)
 tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool bitmap_only, bool pieces) {
     using namespace tkz;
@@ -275,6 +380,7 @@ tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool 
         HIP_TRY(ws->w_mlist.ensure((size_t)ntiles * (size_t)ws->mcap * 4, acc));
         HIP_TRY(ws->w_mquad.ensure((size_t)ntiles * (size_t)ws->mcap * 16, acc));
         HIP_TRY(ws->w_mcount.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(ws->w_pextra.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_tbase.ensure((size_t)(ntiles + 1) * 8, acc));
         HIP_TRY(ws->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
         HIP_TRY(ws->w_doctok.ensure((size_t)((pieces ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
@@ -320,11 +426,33 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
     int64_t* acc = &ws->bytes_allocated;
     if (!ws->h_counters) HIP_TRY(hipHostMalloc((void**)&ws->h_counters, sizeof(CounterBlock), 0));
 
+    // a learning batch that ends any other way than with its promotion gives the encoder's one learning slot back
+    struct LearnGuard {
+        tkz_encoder* e; Workspace* ws; bool keep = false;
+        ~LearnGuard() { if (!keep && ws->learning) { ws->learning = false; std::lock_guard<std::mutex> lock(e->mu); e->learning = false; } }
+    } learn_guard{e, ws};
     for (int attempt = 0; attempt < 5; ++attempt) {
         bool pieces_over = false;
         Launch L{stream, e->profiling ? prof_hook : nullptr, ws};
         int32_t* counters = ws->w_counters.as<int32_t>();
         if (!(phase == kCallEnd && attempt == 0)) {              // (kCallEnd: the first attempt is in flight already)
+        // the tables as they are NOW, one consistent copy for the whole attempt (a promotion at the end of another call's batch replaces the
+        // SHORT / MID images and the promo array together: k_probe and k_place of one attempt must see the same generation)
+        TkzTables T;
+        {
+            std::lock_guard<std::mutex> lock(e->mu);
+            // LEARNING: the first large batch of documents on the batch path (and one more, kPromoSecondBytes later) counts the memo's hits per slot
+            if (attempt == 0 && !ws->learning && pretok && !d_bitmap_only && e->promo_mode == 1 && !e->learning && e->promo_rounds < kPromoAutoRounds &&
+                e->T.memo_n != 0 && e->T.max_rank < (int32_t)kPromoFlag && total >= e->promo_min_bytes && e->promo_items.size() < e->promo_cap &&
+                (e->promo_rounds == 0 || e->bytes_seen - e->bytes_at_promo >= kPromoSecondBytes)) {
+                if (e->t_memo_hits.ensure((size_t)e->memo_slots * 4, &e->bytes_allocated) == hipSuccess) { e->learning = true; ws->learning = true; }
+            }
+            T = e->T;
+        }
+        if (ws->learning) {
+            T.memo_hits = e->t_memo_hits.as<uint32_t>();
+            HIP_TRY(hipMemsetAsync(T.memo_hits, 0, (size_t)e->memo_slots * 4, stream));
+        }
         int64_t* grand = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, grand));
         unsigned long long* pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head));
         uint64_t* docbits = ws->w_docbits.as<uint64_t>();
@@ -336,10 +464,10 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
         } else if (e->pretok_seq) {
             HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
-            launch_pretok_seq(L, e->pattern, d_bytes, d_offs, n_docs, total, startbits, e->T.bmp_class, counters);
+            launch_pretok_seq(L, e->pattern, d_bytes, d_offs, n_docs, total, startbits, T.bmp_class, counters);
         } else {
             HIP_TRY(ws->w_xq.ensure((size_t)(nwords / kRowsPerWave + 4) * 16, acc));     // two queues (launch_pretok_rows)
-            launch_pretok_rows(L, e->pattern, d_bytes, d_offs, n_docs, total, docbits, startbits, nwords, e->T.bmp_class, counters,
+            launch_pretok_rows(L, e->pattern, d_bytes, d_offs, n_docs, total, docbits, startbits, nwords, T.bmp_class, counters,
                                ws->w_xq.as<int64_t>(), reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, xcount)));
         }
         if (d_bitmap_only) {
@@ -360,7 +488,11 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
             P.ablate = 0; P.devprof = nullptr;
             P.stats = e->piece_stats ? e->t_stats.as<unsigned long long>() : nullptr;
+            // (statistics: an attempt that has to be run again -- lists or records to grow -- must not be counted twice: the block as it was before
+            //  this attempt waits behind it and is put back on a retry)
+            if (P.stats) HIP_TRY(hipMemcpyAsync(e->t_stats.as<char>() + 64, P.stats, 64, hipMemcpyDeviceToDevice, stream));
             P.place128 = ws->place128 ? 1 : 0;
+            P.promo = T.promo; P.pextra = T.promo ? ws->w_pextra.as<int32_t>() : nullptr;
 #ifdef TKZ_DEVPROF
             { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
             if (P.ablate & 16) {
@@ -391,7 +523,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             int64_t* npieces = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, npieces));
             launch_doccount(L, startbits, nwords, total, ntiles, ws->w_pcount.as<int32_t>());
             launch_scan(L, ws->w_pcount.as<int32_t>(), ntiles, ws->w_bsum.as<int64_t>(), ws->w_pbase.as<int64_t>(), npieces, -1, kRecordLine);
-            launch_encode(L, e->T, P, ntiles);
+            launch_encode(L, T, P, ntiles);
             if (P.stats) launch_miss_stats(L, P, ntiles);
             launch_scan(L, P.tile_count, ntiles, ws->w_bsum.as<int64_t>(), ws->w_tbase.as<int64_t>(), grand, K_SCAN);
             launch_place(L, P, ws->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
@@ -401,7 +533,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         }
         HIP_TRY(hipMemcpyAsync(ws->h_counters, counters, sizeof(CounterBlock), hipMemcpyDeviceToHost, stream));
         }
-        if (phase == kCallBegin) return TKZ_OK;
+        if (phase == kCallBegin) { learn_guard.keep = true; return TKZ_OK; }
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipGetLastError());
         if (e->profiling) prof_collect(ws);
@@ -431,6 +563,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             const size_t need = (size_t)ws->h_counters->pool_head * 4 + 4096;
             if (ws->w_pool.ensure(need, acc) != hipSuccess)
                 return fail(TKZ_E_OUT_OF_MEMORY, "scratch for the pieces longer than 1024 bytes: " + std::to_string(need) + " bytes could not be allocated");
+            if (e->piece_stats && e->t_stats.p && !d_bitmap_only) HIP_TRY(hipMemcpyAsync(e->t_stats.p, e->t_stats.as<char>() + 64, 64, hipMemcpyDeviceToDevice, stream));
             continue;
         }
         if (err & kErrPool) return fail(TKZ_E_OUT_OF_MEMORY, "long-piece scratch exhausted");
@@ -443,6 +576,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             if (ws->w_mlist.ensure((size_t)ntiles * (size_t)want * 4, acc) != hipSuccess || ws->w_mquad.ensure((size_t)ntiles * (size_t)want * 16, acc) != hipSuccess)
                 return fail(TKZ_E_OUT_OF_MEMORY, "miss lists: " + std::to_string((size_t)ntiles * (size_t)want * 20) + " bytes could not be allocated");
             ws->mcap = want;
+            if (e->piece_stats && e->t_stats.p && !d_bitmap_only) HIP_TRY(hipMemcpyAsync(e->t_stats.p, e->t_stats.as<char>() + 64, 64, hipMemcpyDeviceToDevice, stream));
             continue;
         }
         if (err & kErrMissCap) return fail(TKZ_E_DEVICE, "miss list overflow");
@@ -450,6 +584,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             const size_t need = ((size_t)ws->h_counters->npieces + 4096) * 4;
             if (ws->w_prank.ensure(need, acc) != hipSuccess)
                 return fail(TKZ_E_OUT_OF_MEMORY, "piece records: " + std::to_string(need) + " bytes could not be allocated");
+            if (e->piece_stats && e->t_stats.p && !d_bitmap_only) HIP_TRY(hipMemcpyAsync(e->t_stats.p, e->t_stats.as<char>() + 64, 64, hipMemcpyDeviceToDevice, stream));
             continue;
         }
         if (err & kErrCapacity) return fail(TKZ_E_DEVICE, "piece record buffer overflow");
@@ -481,6 +616,25 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                     *acc -= (int64_t)(ws->w_mquad.cap + ws->w_mlist.cap);
                     ws->w_mquad.release(); ws->w_mlist.release();
                 }
+            }
+        }
+        if (!d_bitmap_only && pretok) {
+            // the batch is done: if it counted the memo's hits, the hottest entries are promoted now (once or twice in an encoder's life: the copy
+            // of the memo back to the host and the rebuilt key tables cost tens of milliseconds)
+            bool promote = false;
+            {
+                std::lock_guard<std::mutex> lock(e->mu);
+                e->bytes_seen += total;
+                promote = ws->learning;
+            }
+            if (promote) {
+                int64_t n_new = 0;
+                const std::string keep_msg = g_err;
+                const tkz_status ps = promote_from_memo(e, true, true, &n_new);       // (a failure leaves the tables as they were: the batch itself is fine)
+                g_err = keep_msg;
+                (void)ps;
+                std::lock_guard<std::mutex> lock(e->mu);
+                ws->learning = false; e->learning = false; ++e->promo_rounds; e->bytes_at_promo = e->bytes_seen;
             }
         }
         if (!d_bitmap_only) {
@@ -538,7 +692,7 @@ tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, con
     P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
     P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles; P.coop_flag = nullptr;
     P.pool = ws->w_pool.as<int32_t>(); P.pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head)); P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
-    P.ablate = 0; P.devprof = nullptr; P.stats = nullptr; P.place128 = 0;
+    P.ablate = 0; P.devprof = nullptr; P.stats = nullptr; P.place128 = 0; P.promo = nullptr; P.pextra = nullptr;
     SmallArgs A{};
     A.h_bytes = H + kSmallOffBytes; A.h_offs = reinterpret_cast<const int64_t*>(H + kSmallOffOffs);
     A.out = reinterpret_cast<int32_t*>(H + kSmallOffIds); A.out_cap = std::min<int64_t>(out_cap, kSmallMaxBytes); A.out_offs = reinterpret_cast<int64_t*>(H + kSmallOffOut);
@@ -547,8 +701,11 @@ tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, con
     A.pcount = ws->w_pcount.as<int32_t>(); A.pbase = ws->w_pbase.as<int64_t>(); A.docord_base = ws->w_dbase.as<int64_t>(); A.tile_base = ws->w_tbase.as<int64_t>();
     A.counter_words = (int32_t)(sizeof(CounterBlock) / 4);
     A.counts3[0] = e->t_counts3.as<int64_t>(); A.counts3[1] = ws->w_counts3.as<int64_t>();
+    TkzTables T;
+    { std::lock_guard<std::mutex> lock(e->mu); T = e->T; }
+    P.promo = T.promo; P.pextra = T.promo ? ws->w_pextra.as<int32_t>() : nullptr;
     Launch L{ws->st_small, nullptr, ws};
-    launch_small(L, e->T, P, A);
+    launch_small(L, T, P, A);
     HIP_TRY(hipStreamSynchronize(ws->st_small));
     HIP_TRY(hipGetLastError());
     ws->small_calls.fetch_add(1, std::memory_order_relaxed);
@@ -834,6 +991,8 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
         e->memo_slots = kMemoSlots;
         e->T.memo = e->t_memo.as<TkzMemoSlot>(); e->T.memo_n = kMemoSlots;
     }
+    e->T.memo_hits = nullptr; e->T.promo = nullptr; e->T.promo_n = 0;
+    e->short_slots_n = (uint32_t)V.short_slots.size(); e->mid_slots_n = (uint32_t)V.mid_slots.size();
     e->T.max_key_len = V.max_key_len;
     e->T.pattern = pattern;
     e->T.max_rank = 0;
@@ -865,8 +1024,10 @@ namespace {
 void destroy_now(tkz_encoder* e) {
     DeviceScope scope;
     (void)scope.enter(e->device);
-    DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp, &e->t_counts3, &e->t_memo, &e->t_stats, &e->t_decoff, &e->t_decblob, &e->t_decids};
+    DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp, &e->t_counts3, &e->t_memo, &e->t_stats, &e->t_decoff, &e->t_decblob, &e->t_decids,
+                      &e->t_memo_hits, &e->t_promo};
     for (DevBuf* b : bufs) b->release();
+    for (DevBuf& b : e->retired) b.release();
     for (Workspace* w : e->pool) { w->release_all(); delete w; }
     delete e;
 }
@@ -1231,11 +1392,36 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
         if (st != TKZ_OK) return st;
         std::lock_guard<std::mutex> lock(e->mu);
         if (value && !e->t_stats.p) {
-            HIP_TRY(e->t_stats.ensure(64, &e->bytes_allocated));
-            HIP_TRY(hipMemset(e->t_stats.p, 0, 64));
+            HIP_TRY(e->t_stats.ensure(128, &e->bytes_allocated));        // (the block + the copy an attempt is rolled back to)
+            HIP_TRY(hipMemset(e->t_stats.p, 0, 128));
         }
         e->piece_stats = value != 0;
         return TKZ_OK;
+    }
+    if (option == TKZ_OPT_PROMOTE_MIN_BYTES || option == TKZ_OPT_PROMOTE_CAP) {
+        if (value < 0) return fail(TKZ_E_ARG, "negative value");
+        std::lock_guard<std::mutex> lock(e->mu);
+        if (option == TKZ_OPT_PROMOTE_MIN_BYTES) e->promo_min_bytes = value;
+        else e->promo_cap = (size_t)std::min<int64_t>(value, (int64_t)kPromoMaxEntries);
+        return TKZ_OK;
+    }
+    if (option == TKZ_OPT_PROMOTE) {
+        // 0 / 1: automatic promotion off / on.  2: promote NOW whatever the memo holds (every valid entry counts alike); 3: drop every promotion (the
+        // key tables as the vocabulary alone gives them).  2 and 3 replace table images that a call in flight may be probing: refused unless the encoder is idle.
+        DeviceScope scope;
+        tkz_status st = check_encoder(e, scope);
+        if (st != TKZ_OK) return st;
+        if (value == 0 || value == 1) { std::lock_guard<std::mutex> lock(e->mu); e->promo_mode = (int)value; return TKZ_OK; }
+        if (value != 2 && value != 3) return fail(TKZ_E_ARG, "TKZ_OPT_PROMOTE takes 0, 1, 2 or 3");
+        {
+            std::lock_guard<std::mutex> lock(e->mu);
+            for (Workspace* w : e->pool) if (w->busy) return fail(TKZ_E_ARG, "promotions can only be made or dropped by hand while no call of this encoder is in flight");
+        }
+        if (hipDeviceSynchronize() != hipSuccess) return fail(TKZ_E_DEVICE, "hipDeviceSynchronize");
+        if (value == 2) return promote_from_memo(e, false, false, nullptr);
+        std::lock_guard<std::mutex> lock(e->mu);
+        e->promo_items.clear(); e->promo_keys.clear(); e->promo_quads.clear(); e->promo_rounds = 0; e->bytes_at_promo = e->bytes_seen;
+        return publish_key_tables(e, false);
     }
     if (option == TKZ_OPT_PIECE_MEMO) {
         // 0: off, 1: on, 2: on and emptied.  Options are set while the encoder is idle: a call in flight on another thread reads
@@ -1288,7 +1474,7 @@ tkz_status tkz_encoder_piece_stats(tkz_encoder* e, int64_t* out8, int32_t reset)
     HIP_TRY(hipMemcpy(h, e->t_stats.p, sizeof h, hipMemcpyDeviceToHost));
     std::lock_guard<std::mutex> lock(e->mu);
     out8[0] = e->stat_batches; out8[1] = (int64_t)h[4]; out8[2] = (int64_t)h[2]; out8[3] = (int64_t)h[3]; out8[4] = e->stat_giants;
-    out8[5] = (int64_t)h[0]; out8[6] = (int64_t)h[1];
+    out8[5] = (int64_t)h[0]; out8[6] = (int64_t)h[1]; out8[7] = (int64_t)e->promo_items.size();
     if (reset) { HIP_TRY(hipMemset(e->t_stats.p, 0, 64)); e->stat_batches = e->stat_giants = 0; }
     return TKZ_OK;
 }

@@ -66,6 +66,8 @@ struct EncodeParams {
     // TKZ_OPT_PIECE_STATS: null, or the encoder's statistics block -- [0] memo lookups, [1] memo hits, [2] short misses, [3] long misses, [4] pieces
     // (what tkz_encoder_piece_stats reports; the timed runs leave it null)
     unsigned long long* stats;
+    int32_t* pextra;              // null, or (promoted pieces in the tables) per sub-tile: tokens beyond one per piece that its promoted pieces stand for (k_probe -> k_merge_short's counts)
+    const uint4* promo;           // token quads of the promoted pieces (TkzTables::promo of the tables this batch was probed with), or null: k_place
     int32_t place128;             // launch k_place<128> (two kept list entries per lane) instead of k_place<64>: the previous batch of the workspace was miss-heavy
 };
 

@@ -763,6 +763,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
     uint32_t* const ml = P.mlist + sub * (int64_t)P.mcap;
     uint4* const mq = P.mquad + sub * (int64_t)P.mcap;
     int ns = 0, nl = 0, midseen = 0;
+    int promo_extra = 0;                                   // tokens beyond one per piece that the promoted pieces of this sub-tile stand for (P.pextra)
     bool giant = false;
     constexpr int U = TKZ_PROBE_U;                         // batches of 64 pieces whose gathers are in flight together
 #pragma unroll 1
@@ -825,6 +826,10 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
             midseen += tkz_popc64(midm);
             const bool is_giant = len > kArenaPiece;                             // (k_giant_merge looks a giant piece up itself)
             const bool miss = valid && !is_giant && rank == TKZ_RANK_NONE;
+            if (P.pextra) {                                                      // (wave-uniform: only when the tables hold promoted pieces)
+                const uint32_t ex = (valid && !is_giant && !miss && ((uint32_t)rank & kPromoFlag)) ? (((uint32_t)rank >> kPromoCntShift) & 3u) : 0u;
+                promo_extra += tkz_popc64(simt::ballot(ex & 1u)) + 2 * tkz_popc64(simt::ballot(ex & 2u));
+            }
             const bool miss_s = miss && len <= kShortMax, miss_l = miss && len > kShortMax;
             const uint64_t sm = simt::ballot(miss_s), lm = simt::ballot(miss_l);
             const int is_ = ns + tkz_popc64(sm & tkz_lowmask(lane)), il = nl + tkz_popc64(lm & tkz_lowmask(lane));
@@ -859,6 +864,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
     if (lane == 0) {
         P.heavy_flag[sub] = (uint8_t)f;
         P.mcount[sub] = (uint32_t)ns | ((uint32_t)nl << 16);
+        if (P.pextra) P.pextra[sub] = promo_extra;
         if (REPORT && ns + nl > P.mcap) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&P.counters[1], (unsigned)(ns + nl)); }
         if (pb + np > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
     }
@@ -985,6 +991,9 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     int st_look = 0, st_hit = 0;                                // TKZ_OPT_PIECE_STATS: memo lookups and hits of this group (one pair of atomics at its end)
     int32_t* const dense = P.dense + grp * kDenseCap;
     const bool memo = T.memo_n != 0;
+    // a LEARNING batch (tkz_api.cpp, promote_from_memo): the hits of every eighth group are counted per memo slot -- the host promotes the hottest
+    // entries into the SHORT / MID tables afterwards.  Null in every other batch.
+    const bool count_hits = T.memo_hits != nullptr && (grp & 7) == 0;
     // where the `cnt` tokens of a piece go -- up to four: into the entry's own quad (the caller stores them); more: packed behind those of
     // the pieces before it in the group's dense region (in tmp, at the piece's own byte position, once that is full) -- and the answer in
     // its list entry; every lane of the wavefront calls it (a scan inside)
@@ -1047,7 +1056,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
                 //  model says a dwordx4 access is single-copy atomic across CUs / XCDs -- is not valid until its last word is there)
                 const bool h = !nul && ((v.x & v.y & v.z & v.w) & kMemoValid) && v.x != kMemoBusy && kk.x == kw[0] && kk.y == kw[1] && kk.z == kw[2] && kk.w == kw[3] &&
                                ((v.y >> 27) & 15u) == (uint32_t)(len - 1);
-                if (h) { hit = true; vv = v; }
+                if (h) { hit = true; vv = v; if (count_hits) simt::atomic_add(reinterpret_cast<int*>(&T.memo_hits[b + wy]), 1); }
             }
         }
         if (P.stats) { st_look += tkz_popc64(simt::ballot(mine && memo)); st_hit += tkz_popc64(simt::ballot(hit)); }   // (statistics run only: wave-uniform, null in the timed runs)
@@ -1146,7 +1155,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     if (nlist > 0) run_batch(nlist);
     (void)simt::ballot(true);
     // tokens of every sub-tile of the group: one per piece, plus what the merges added (k_merge_long adds its own later)
-    if (lane < kGroup && sub0 + lane < P.nsub) P.tile_count[sub0 + lane] = my_np + s_extra[lane];
+    if (lane < kGroup && sub0 + lane < P.nsub) P.tile_count[sub0 + lane] = my_np + s_extra[lane] + (P.pextra ? P.pextra[sub0 + lane] : 0);
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
     if (P.stats && lane == 0 && st_look) { simt::atomic_add64(&P.stats[0], (unsigned long long)st_look); simt::atomic_add64(&P.stats[1], (unsigned long long)st_hit); }
 }
@@ -1438,7 +1447,9 @@ TKZ_DEV PlaceLds tkz_place_lds(uint4* wave_quads) {
     return L;
 }
 // sub-tiles sub0 .. sub0 + kPlacePer - 1, by one wavefront
-template <int SLOTS>
+// PROMO: the tables hold promoted pieces (tkz_tables.h): a hit record may carry a promo code instead of a rank -- its count is in the record, its
+// tokens are one 16-byte gather from P.promo.  The form without them is the kernel of every batch before the first promotion, instruction for instruction.
+template <int SLOTS, bool PROMO>
 TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base, int32_t* out, int64_t out_cap, int64_t sub0, const PlaceLds& LD) {
     constexpr int kPlaceSlots = SLOTS, kPlaceRes = SLOTS / 2;
     const int lane = simt::lane();
@@ -1559,8 +1570,13 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
             else for (int j = 0; j < 4; ++j) if (pb + k0 + j < P.prank_cap) r[j] = (uint32_t)P.prank[pb + k0 + j];
         }
         int c[4], idx[4];
-        bool ok[4], ms[4];
+        bool ok[4], ms[4], pm[4];
+        uint4 pq[4];
         int t = 0, mk = 0;
+        if constexpr (PROMO) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pm[j] = k0 + j < np && pb + k0 + j < P.prank_cap && !(r[j] & kPrMiss) && (r[j] & kPromoFlag);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             ok[j] = k0 + j < np && pb + k0 + j < P.prank_cap;
@@ -1568,6 +1584,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
             idx[j] = ((r[j] & kPrLong) ? top - (int)(r[j] & 1023u) : (int)(r[j] & 1023u)) & (kPlaceSlots - 1);     // the slot of the piece's list entry
             const uint32_t a = s_res[ms[j] ? idx[j] : kPlaceSlots];
             c[j] = ok[j] ? tkz_result_cnt(a) : 0;
+            if constexpr (PROMO) { if (pm[j]) c[j] = (int)((r[j] >> kPromoCntShift) & 3u) + 1; }
             t += c[j];
             mk += (ok[j] && (r[j] & kPrMark)) ? 1 : 0;
         }
@@ -1578,11 +1595,24 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
             if (flushed < running) flush(running);
             if (running + tot - sbase > kStage) return false;        // (more than two tokens a record: the general path, 64 records at a time)
         }
+        if constexpr (PROMO) {
+            // the token quads of the promoted pieces among the lane's four records, requested together (a record that is not promoted asks for
+            // quad 0: one line for the whole wavefront).  (Requested ahead of the scan they cost 16 registers across it: spills at 7 and at 6 waves per SIMD.)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pq[j] = tkz_load16(&P.promo[pm[j] ? (r[j] & kPromoIdxMask) : 0u]);
+        }
         int pos = running + (pre & 0xFFFFF), mi = marks + (pre >> 20);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (ok[j] && (r[j] & kPrMark)) P.doc_tok[ord0 + mi++] = pos;
             if (ms[j]) s_pos[idx[j]] = pos;
+            else if (PROMO && pm[j]) {
+                int32_t* dst = stage + (pos - sbase);
+                dst[0] = (int32_t)pq[j].x;
+                if (c[j] > 1) dst[1] = (int32_t)pq[j].y;
+                if (c[j] > 2) dst[2] = (int32_t)pq[j].z;
+                if (c[j] > 3) dst[3] = (int32_t)pq[j].w;
+            }
             else if (ok[j]) stage[pos - sbase] = (int32_t)(r[j] & kPrRankMask);
             pos += c[j];
         }
@@ -1626,7 +1656,10 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         const uint32_t rec = valid ? (uint32_t)tkz_load_nt(&P.prank[pb + k]) : 0u;
         const uint32_t res = (rec & kPrMiss) ? answer(rec) : 0u;           // the merge kernels' answer for a missed piece
         const bool miss = (rec & kPrMiss) != 0;
-        const int cnt = !valid ? 0 : !miss ? 1 : (rec & kPrGiant) ? gcnt : tkz_result_cnt(res);
+        const bool promoted = PROMO && valid && !miss && (rec & kPromoFlag);
+        uint4 pquad; pquad.x = pquad.y = pquad.z = pquad.w = 0;
+        if constexpr (PROMO) { if (promoted) pquad = tkz_load16(&P.promo[rec & kPromoIdxMask]); }
+        const int cnt = !valid ? 0 : !miss ? (promoted ? (int)((rec >> kPromoCntShift) & 3u) + 1 : 1) : (rec & kPrGiant) ? gcnt : tkz_result_cnt(res);
         int tot;
         const int pos = running + tkz_wave_scan_sum(cnt, &tot);
         const uint64_t mm = simt::ballot(valid && (rec & kPrMark));
@@ -1636,7 +1669,13 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
             if (running + tot - sbase > kStage) flush(running);
             if (valid) {
                 int32_t* dst = stage + (pos - sbase);
-                if (!miss) dst[0] = (int32_t)(rec & kPrRankMask);
+                if (promoted) {
+                    dst[0] = (int32_t)pquad.x;
+                    if (cnt > 1) dst[1] = (int32_t)pquad.y;
+                    if (cnt > 2) dst[2] = (int32_t)pquad.z;
+                    if (cnt > 3) dst[3] = (int32_t)pquad.w;
+                }
+                else if (!miss) dst[0] = (int32_t)(rec & kPrRankMask);
                 else if (res & kMrInline) {
                     const uint4 q = inline_quad(rec);
                     dst[0] = (int32_t)q.x;
@@ -1655,7 +1694,12 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
             const int32_t* src = (miss && !(res & kMrInline)) ? token_src(res) : nullptr;
             if (valid) {
                 int32_t* dst = out + tb + pos;
-                if (!miss) { if (tb + pos < out_cap) tkz_store_nt(&dst[0], (int32_t)(rec & kPrRankMask)); }
+                if (promoted) {
+                    const int32_t w[4] = {(int32_t)pquad.x, (int32_t)pquad.y, (int32_t)pquad.z, (int32_t)pquad.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (i < cnt && tb + pos + i < out_cap) dst[i] = w[i];
+                }
+                else if (!miss) { if (tb + pos < out_cap) tkz_store_nt(&dst[0], (int32_t)(rec & kPrRankMask)); }
                 else if (res & kMrInline) {
                     const uint4 q = inline_quad(rec);
                     const int32_t w[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
@@ -1682,11 +1726,11 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     if (flushed < running) flush(running);
     }
 }
-template <int SLOTS>
+template <int SLOTS, bool PROMO>
 TKZ_KERNEL_OCC(256, TKZ_PLACE_OCC) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
     TKZ_SHARED uint4 s_wave[kThreads / 64][kPlaceLdsQuadsT<SLOTS>];
     const int64_t sub0 = (tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave()) * kPlacePer;
-    tkz_place_subtiles<SLOTS>(P, tile_base, out, out_cap, sub0, tkz_place_lds<SLOTS>(s_wave[simt::wave()]));
+    tkz_place_subtiles<SLOTS, PROMO>(P, tile_base, out, out_cap, sub0, tkz_place_lds<SLOTS>(s_wave[simt::wave()]));
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2370,7 +2414,10 @@ TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
     simt::sync();
     stamp();
     for (int s0 = wave * kPlacePer; s0 < nsub; s0 += nwaves * kPlacePer)
-        tkz_place_subtiles<64>(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds<64>(s_raw + wave * kPlaceLdsQuads));
+    {
+        if (P.promo) tkz_place_subtiles<64, true>(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds<64>(s_raw + wave * kPlaceLdsQuads));
+        else tkz_place_subtiles<64, false>(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds<64>(s_raw + wave * kPlaceLdsQuads));
+    }
     simt::sync();
     stamp();
     {
@@ -2466,8 +2513,14 @@ void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, co
 }
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap) {
     hook(L, K_GATHER, 0);
-    if (P.place128) TKZ_LAUNCH(k_place<128>, xcd_grid(cdiv(nsub, (kThreads / 64) * kPlacePer)), kThreads, L.stream, P, tile_base, out, out_cap);
-    else TKZ_LAUNCH(k_place<64>, xcd_grid(cdiv(nsub, (kThreads / 64) * kPlacePer)), kThreads, L.stream, P, tile_base, out, out_cap);
+    const int64_t grid = xcd_grid(cdiv(nsub, (kThreads / 64) * kPlacePer));
+    if (P.promo) {      // (promoted pieces in the tables: the records may carry promo codes)
+        if (P.place128) TKZ_LAUNCH((k_place<128, true>), grid, kThreads, L.stream, P, tile_base, out, out_cap);
+        else TKZ_LAUNCH((k_place<64, true>), grid, kThreads, L.stream, P, tile_base, out, out_cap);
+    } else {
+        if (P.place128) TKZ_LAUNCH((k_place<128, false>), grid, kThreads, L.stream, P, tile_base, out, out_cap);
+        else TKZ_LAUNCH((k_place<64, false>), grid, kThreads, L.stream, P, tile_base, out, out_cap);
+    }
     hook(L, K_GATHER, 1);
 }
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt) {

@@ -95,8 +95,22 @@ constexpr uint32_t kMemoValid = 0x80000000u, kMemoBusy = 0xFFFFFFFFu;
 #endif
 constexpr uint32_t kMemoWays = TKZ_MEMO_WAYS;
 
+// PROMOTED pieces (round 5).  The memo answers a missed piece in k_merge_short: list entry + quad + a 32-byte slot + the answer, per piece and
+// batch, for text whose hot pieces are not keys (a vocabulary that has not seen the text: 7 of 8 short misses are memo hits).  Those answers
+// never change, so the host PROMOTES the hottest memo entries into the SHORT / MID tables themselves (tkz_api.cpp: promote_from_memo): the slot
+// of a promoted piece carries, in place of a rank,
+//     kPromoFlag | (count - 1) << kPromoCntShift | index          (count <= 4; index: a quad of tokens in TkzTables::promo)
+// k_probe needs no change -- it writes the slot's value into the piece's record like any rank --, the merge kernels never see the piece, and
+// k_place, which already reads every record, takes the count from the record and the tokens with ONE 16-byte gather from the (cache-resident)
+// promo array.  Ranks are < 2^26 whenever anything is promoted (every published vocabulary is below 2^18; checked by the host).
+constexpr uint32_t kPromoFlag = 1u << 26, kPromoIdxMask = (1u << 22) - 1u;
+constexpr int kPromoCntShift = 22;
+constexpr uint32_t kPromoMaxEntries = 1u << 22;
+
 struct TkzTables {      // device pointers + sizes, passed to kernels by value
     TkzMemoSlot* memo; uint32_t memo_n;                                          // piece memo (null / 0: none)
+    uint32_t* memo_hits;                                                         // null, or (a LEARNING batch) memo_n counters: hits per slot, sampled (k_merge_short)
+    const uint4* promo; uint32_t promo_n;                                        // token quads of the promoted pieces (null / 0: none)
     const TkzShortSlot* short_slots; uint32_t short_nb; uint32_t short_seed;    // short_nb buckets of two slots
     const TkzMidSlot* mid_slots;     uint32_t mid_ns;   uint32_t mid_seed;      // mid_ns slots
     const TkzLongSlot* long_slots;   uint32_t long_mask;

@@ -178,6 +178,114 @@ bool cuckoo_insert(std::vector<Slot>& table, Slot item, Occupied occupied, Slots
 }
 }  // namespace
 
+void build_key_tables(const std::vector<KeyItem>& items, std::vector<TkzShortSlot>* short_slots, uint32_t* short_seed,
+                      std::vector<TkzMidSlot>* mid_slots, uint32_t* mid_seed) {
+    const size_t nk = items.size();
+    size_t n_short = 0, n_mid = 0;
+    for (const auto& it : items) {
+        if (it.key.empty()) continue;
+        if (it.key.size() <= TKZ_SHORT_KEY_MAX) ++n_short; else if (it.key.size() <= TKZ_MID_KEY_MAX) ++n_mid;
+    }
+    // SHORT: (2,2) cuckoo -- buckets of two 16-byte slots, two candidate buckets per key -- at a load of 0.8 (the threshold
+    // of that scheme is ~0.89); sizes are arbitrary (slot = mulhi(hash, size)), grown 4 % at a time when 16 seeds fail
+    {
+        uint32_t nb = uint32_t(std::max<uint64_t>(8, (uint64_t(n_short) * 10 + 15) / 16));          // n / (2 * 0.8)
+        for (bool done = false; !done; nb += nb / 25 + 1) {
+            for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
+                (*short_slots).assign(size_t(nb) * 2, TkzShortSlot{0, 0, 0, 0});
+                TkzTables T{}; T.short_nb = nb; T.short_seed = seed;
+                bool ok = true;
+                uint32_t rng = 0x9E3779B9u * seed;
+                // k_probe fetches a key's FIRST bucket and the second one only when that did not settle the lookup, so the keys that
+                // occur most -- by construction of a BPE vocabulary the ones of the lowest ranks -- are put into their first bucket
+                // and pinned there (a quarter of the keys, in rank order, as long as a slot is free); the walk never moves them
+                std::vector<size_t> by_rank;                  // (the items arrive most frequent first)
+                for (size_t i = 0; i < nk; ++i) if (!items[i].key.empty() && items[i].key.size() <= TKZ_SHORT_KEY_MAX) by_rank.push_back(i);
+                std::vector<uint8_t> pinned(size_t(nb) * 2, 0), done_key(nk, 0);
+                auto item_of = [&](size_t i) {
+                    const std::string& k = items[i].key;
+                    return TkzShortSlot{load_dword(k, 0), load_dword(k, 4), load_dword(k, 8), items[i].value | (uint32_t(k.size()) << TKZ_SHORT_RANK_BITS)};
+                };
+                for (size_t q = 0; q < by_rank.size() / 16; ++q) {
+                    const TkzShortSlot item = item_of(by_rank[q]);
+                    uint32_t s1, s2;
+                    tkz_short_slots(T, item.k0, item.k1, item.k2, item.rank_len >> TKZ_SHORT_RANK_BITS, &s1, &s2);
+                    for (uint32_t c = s1; c < s1 + 2; ++c)
+                        if ((*short_slots)[c].rank_len == 0) { (*short_slots)[c] = item; pinned[c] = 1; done_key[by_rank[q]] = 1; break; }
+                }
+                for (size_t q = 0; q < by_rank.size() && ok; ++q) {
+                    if (done_key[by_rank[q]]) continue;
+                    TkzShortSlot item = item_of(by_rank[q]);
+                    ok = false;
+                    for (int kick = 0; kick < 4000; ++kick) {
+                        uint32_t s1, s2;
+                        tkz_short_slots(T, item.k0, item.k1, item.k2, item.rank_len >> TKZ_SHORT_RANK_BITS, &s1, &s2);
+                        const uint32_t cand[4] = {s1, s1 + 1, s2, s2 + 1};
+                        bool placed = false;
+                        for (uint32_t c : cand) if ((*short_slots)[c].rank_len == 0) { (*short_slots)[c] = item; placed = true; break; }
+                        if (placed) { ok = true; break; }
+                        uint32_t movable[4]; int nm = 0;
+                        for (uint32_t c : cand) if (!pinned[c]) movable[nm++] = c;
+                        if (!nm) { for (uint32_t c : cand) { pinned[c] = 0; movable[nm++] = c; } }      // (both buckets pinned: a pin is given up)
+                        rng = rng * 1664525u + 1013904223u;
+                        std::swap(item, (*short_slots)[movable[(rng >> 16) % (uint32_t)nm]]);          // random-walk eviction
+                    }
+                }
+                if (ok) {
+                    // repair pass, most frequent keys first: a key that ended up in its second bucket moves to the first one when a slot
+                    // is free there, or when one of the two keys in it is a rarer one that has a free slot in its own other bucket
+                    auto slots_of = [&](const TkzShortSlot& it, uint32_t* a, uint32_t* b) { tkz_short_slots(T, it.k0, it.k1, it.k2, it.rank_len >> TKZ_SHORT_RANK_BITS, a, b); };
+                    auto same = [](const TkzShortSlot& x, const TkzShortSlot& y) { return x.k0 == y.k0 && x.k1 == y.k1 && x.k2 == y.k2 && x.rank_len == y.rank_len; };
+                    for (size_t q = 0; q < by_rank.size(); ++q) {
+                        const TkzShortSlot item = item_of(by_rank[q]);
+                        uint32_t s1, s2;
+                        slots_of(item, &s1, &s2);
+                        if (s1 == s2 || same((*short_slots)[s1], item) || same((*short_slots)[s1 + 1], item)) continue;
+                        const uint32_t at = same((*short_slots)[s2], item) ? s2 : s2 + 1;
+                        uint32_t dest = UINT32_MAX;
+                        for (uint32_t c = s1; c < s1 + 2 && dest == UINT32_MAX; ++c) if ((*short_slots)[c].rank_len == 0) dest = c;
+                        for (uint32_t c = s1; c < s1 + 2 && dest == UINT32_MAX; ++c) {
+                            const TkzShortSlot occ = (*short_slots)[c];
+                            if ((occ.rank_len & TKZ_SHORT_RANK_MASK) <= (item.rank_len & TKZ_SHORT_RANK_MASK)) continue;     // (a more frequent key stays)
+                            uint32_t o1, o2;
+                            slots_of(occ, &o1, &o2);
+                            const uint32_t other = (c & ~1u) == o1 ? o2 : o1;
+                            if (other == (c & ~1u)) continue;
+                            for (uint32_t d = other; d < other + 2; ++d)
+                                if ((*short_slots)[d].rank_len == 0) { (*short_slots)[d] = occ; dest = c; break; }
+                        }
+                        if (dest != UINT32_MAX) { (*short_slots)[dest] = item; (*short_slots)[at] = TkzShortSlot{0, 0, 0, 0}; }
+                    }
+                    *short_seed = seed; done = true;
+                }
+            }
+            if (done) break;
+        }
+    }
+    // MID: (2,1) cuckoo of 32-byte slots at a load of 0.45
+    {
+        uint32_t ns = uint32_t(std::max<uint64_t>(8, (uint64_t(n_mid) * 20 + 8) / 9));
+        for (bool done = false; !done; ns += ns / 25 + 1) {
+            for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
+                (*mid_slots).assign(ns, TkzMidSlot{{0, 0, 0, 0, 0, 0, 0}, 0});
+                TkzTables T{}; T.mid_ns = ns; T.mid_seed = seed;
+                bool ok = true;
+                for (size_t i = 0; i < nk && ok; ++i) {
+                    const std::string& k = items[i].key;
+                    if (k.size() <= TKZ_SHORT_KEY_MAX || k.size() > TKZ_MID_KEY_MAX) continue;
+                    TkzMidSlot item;
+                    for (int d = 0; d < 7; ++d) item.k[d] = load_dword(k, 4 * size_t(d));
+                    item.rank_len = items[i].value | (uint32_t(k.size() - 12) << TKZ_SHORT_RANK_BITS);
+                    ok = cuckoo_insert((*mid_slots), item, [](const TkzMidSlot& s) { return s.rank_len != 0; },
+                                       [&](const TkzMidSlot& s, uint32_t* a, uint32_t* b) { tkz_mid_slots(T, s.k, (s.rank_len >> TKZ_SHORT_RANK_BITS) + 12u, a, b); });
+                }
+                if (ok) { *mid_seed = seed; done = true; }
+            }
+            if (done) break;
+        }
+    }
+}
+
 int build_tables(Vocab* v, std::string* msg) {
     (void)msg;
     const size_t nk = v->keys.size();
@@ -189,10 +297,10 @@ int build_tables(Vocab* v, std::string* msg) {
         v->byte_rank[b] = v->lookup(k, &r) ? r : int32_t(TKZ_PSEUDO_BASE + b);
     }
     // ---- SHORT / MID / LONG whole-key tables ----
-    size_t n_short = 0, n_mid = 0, n_long = 0, blob = 0;
+    size_t n_long = 0, blob = 0;
     for (const auto& k : v->keys) {
         if (k.empty()) continue;                       // (an empty key can never equal a regex match or a merge slice)
-        if (k.size() <= TKZ_SHORT_KEY_MAX) ++n_short; else if (k.size() <= TKZ_MID_KEY_MAX) ++n_mid; else { ++n_long; blob += k.size(); }
+        if (k.size() > TKZ_MID_KEY_MAX) { ++n_long; blob += k.size(); }
     }
     const uint32_t long_cap = next_pow2(std::max<uint64_t>(16, uint64_t(n_long) * 2));
     v->long_slots.assign(long_cap, TkzLongSlot{0, 0, 0, 0});
@@ -210,104 +318,14 @@ int build_tables(Vocab* v, std::string* msg) {
         v->long_blob.insert(v->long_blob.end(), k.begin(), k.end());
     }
     v->long_blob.resize(v->long_blob.size() + 16, 0);   // kernels may read a few bytes past a key
-    // SHORT: (2,2) cuckoo -- buckets of two 16-byte slots, two candidate buckets per key -- at a load of 0.8 (the threshold
-    // of that scheme is ~0.89); sizes are arbitrary (slot = mulhi(hash, size)), grown 4 % at a time when 16 seeds fail
-    {
-        uint32_t nb = uint32_t(std::max<uint64_t>(8, (uint64_t(n_short) * 10 + 15) / 16));          // n / (2 * 0.8)
-        for (bool done = false; !done; nb += nb / 25 + 1) {
-            for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
-                v->short_slots.assign(size_t(nb) * 2, TkzShortSlot{0, 0, 0, 0});
-                TkzTables T{}; T.short_nb = nb; T.short_seed = seed;
-                bool ok = true;
-                uint32_t rng = 0x9E3779B9u * seed;
-                // k_probe fetches a key's FIRST bucket and the second one only when that did not settle the lookup, so the keys that
-                // occur most -- by construction of a BPE vocabulary the ones of the lowest ranks -- are put into their first bucket
-                // and pinned there (a quarter of the keys, in rank order, as long as a slot is free); the walk never moves them
-                std::vector<size_t> by_rank;
-                for (size_t i = 0; i < nk; ++i) if (!v->keys[i].empty() && v->keys[i].size() <= TKZ_SHORT_KEY_MAX) by_rank.push_back(i);
-                std::sort(by_rank.begin(), by_rank.end(), [&](size_t a, size_t b) { return v->ranks[a] < v->ranks[b]; });
-                std::vector<uint8_t> pinned(size_t(nb) * 2, 0), done_key(nk, 0);
-                auto item_of = [&](size_t i) {
-                    const std::string& k = v->keys[i];
-                    return TkzShortSlot{load_dword(k, 0), load_dword(k, 4), load_dword(k, 8), uint32_t(v->ranks[i]) | (uint32_t(k.size()) << TKZ_SHORT_RANK_BITS)};
-                };
-                for (size_t q = 0; q < by_rank.size() / 16; ++q) {
-                    const TkzShortSlot item = item_of(by_rank[q]);
-                    uint32_t s1, s2;
-                    tkz_short_slots(T, item.k0, item.k1, item.k2, item.rank_len >> TKZ_SHORT_RANK_BITS, &s1, &s2);
-                    for (uint32_t c = s1; c < s1 + 2; ++c)
-                        if (v->short_slots[c].rank_len == 0) { v->short_slots[c] = item; pinned[c] = 1; done_key[by_rank[q]] = 1; break; }
-                }
-                for (size_t q = 0; q < by_rank.size() && ok; ++q) {
-                    if (done_key[by_rank[q]]) continue;
-                    TkzShortSlot item = item_of(by_rank[q]);
-                    ok = false;
-                    for (int kick = 0; kick < 4000; ++kick) {
-                        uint32_t s1, s2;
-                        tkz_short_slots(T, item.k0, item.k1, item.k2, item.rank_len >> TKZ_SHORT_RANK_BITS, &s1, &s2);
-                        const uint32_t cand[4] = {s1, s1 + 1, s2, s2 + 1};
-                        bool placed = false;
-                        for (uint32_t c : cand) if (v->short_slots[c].rank_len == 0) { v->short_slots[c] = item; placed = true; break; }
-                        if (placed) { ok = true; break; }
-                        uint32_t movable[4]; int nm = 0;
-                        for (uint32_t c : cand) if (!pinned[c]) movable[nm++] = c;
-                        if (!nm) { for (uint32_t c : cand) { pinned[c] = 0; movable[nm++] = c; } }      // (both buckets pinned: a pin is given up)
-                        rng = rng * 1664525u + 1013904223u;
-                        std::swap(item, v->short_slots[movable[(rng >> 16) % (uint32_t)nm]]);          // random-walk eviction
-                    }
-                }
-                if (ok) {
-                    // repair pass, most frequent keys first: a key that ended up in its second bucket moves to the first one when a slot
-                    // is free there, or when one of the two keys in it is a rarer one that has a free slot in its own other bucket
-                    auto slots_of = [&](const TkzShortSlot& it, uint32_t* a, uint32_t* b) { tkz_short_slots(T, it.k0, it.k1, it.k2, it.rank_len >> TKZ_SHORT_RANK_BITS, a, b); };
-                    auto same = [](const TkzShortSlot& x, const TkzShortSlot& y) { return x.k0 == y.k0 && x.k1 == y.k1 && x.k2 == y.k2 && x.rank_len == y.rank_len; };
-                    for (size_t q = 0; q < by_rank.size(); ++q) {
-                        const TkzShortSlot item = item_of(by_rank[q]);
-                        uint32_t s1, s2;
-                        slots_of(item, &s1, &s2);
-                        if (s1 == s2 || same(v->short_slots[s1], item) || same(v->short_slots[s1 + 1], item)) continue;
-                        const uint32_t at = same(v->short_slots[s2], item) ? s2 : s2 + 1;
-                        uint32_t dest = UINT32_MAX;
-                        for (uint32_t c = s1; c < s1 + 2 && dest == UINT32_MAX; ++c) if (v->short_slots[c].rank_len == 0) dest = c;
-                        for (uint32_t c = s1; c < s1 + 2 && dest == UINT32_MAX; ++c) {
-                            const TkzShortSlot occ = v->short_slots[c];
-                            if ((occ.rank_len & TKZ_SHORT_RANK_MASK) <= (item.rank_len & TKZ_SHORT_RANK_MASK)) continue;     // (a more frequent key stays)
-                            uint32_t o1, o2;
-                            slots_of(occ, &o1, &o2);
-                            const uint32_t other = (c & ~1u) == o1 ? o2 : o1;
-                            if (other == (c & ~1u)) continue;
-                            for (uint32_t d = other; d < other + 2; ++d)
-                                if (v->short_slots[d].rank_len == 0) { v->short_slots[d] = occ; dest = c; break; }
-                        }
-                        if (dest != UINT32_MAX) { v->short_slots[dest] = item; v->short_slots[at] = TkzShortSlot{0, 0, 0, 0}; }
-                    }
-                    v->short_seed = seed; done = true;
-                }
-            }
-            if (done) break;
-        }
-    }
-    // MID: (2,1) cuckoo of 32-byte slots at a load of 0.45
-    {
-        uint32_t ns = uint32_t(std::max<uint64_t>(8, (uint64_t(n_mid) * 20 + 8) / 9));
-        for (bool done = false; !done; ns += ns / 25 + 1) {
-            for (uint32_t seed = 1; seed <= 16 && !done; ++seed) {
-                v->mid_slots.assign(ns, TkzMidSlot{{0, 0, 0, 0, 0, 0, 0}, 0});
-                TkzTables T{}; T.mid_ns = ns; T.mid_seed = seed;
-                bool ok = true;
-                for (size_t i = 0; i < nk && ok; ++i) {
-                    const std::string& k = v->keys[i];
-                    if (k.size() <= TKZ_SHORT_KEY_MAX || k.size() > TKZ_MID_KEY_MAX) continue;
-                    TkzMidSlot item;
-                    for (int d = 0; d < 7; ++d) item.k[d] = load_dword(k, 4 * size_t(d));
-                    item.rank_len = uint32_t(v->ranks[i]) | (uint32_t(k.size() - 12) << TKZ_SHORT_RANK_BITS);
-                    ok = cuckoo_insert(v->mid_slots, item, [](const TkzMidSlot& s) { return s.rank_len != 0; },
-                                       [&](const TkzMidSlot& s, uint32_t* a, uint32_t* b) { tkz_mid_slots(T, s.k, (s.rank_len >> TKZ_SHORT_RANK_BITS) + 12u, a, b); });
-                }
-                if (ok) { v->mid_seed = seed; done = true; }
-            }
-            if (done) break;
-        }
+    {   // SHORT + MID: the keys in rank order (by construction of a BPE vocabulary the lowest ranks occur most)
+        std::vector<KeyItem> items;
+        items.reserve(nk);
+        std::vector<size_t> order(nk);
+        for (size_t i = 0; i < nk; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return v->ranks[a] < v->ranks[b]; });
+        for (size_t i : order) if (!v->keys[i].empty() && v->keys[i].size() <= TKZ_MID_KEY_MAX) items.push_back(KeyItem{v->keys[i], uint32_t(v->ranks[i])});
+        build_key_tables(items, &v->short_slots, &v->short_seed, &v->mid_slots, &v->mid_seed);
     }
     // ---- PAIR table: every split of every key into two keys (or not-in-vocab single bytes) ----
     struct P { uint32_t a, b; int32_t r; };

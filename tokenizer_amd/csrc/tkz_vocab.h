@@ -40,6 +40,13 @@ struct Vocab {
     }
 };
 
+// The SHORT (keys of 1..12 bytes) and MID (13..28) whole-key tables from (key, value) items: value = the key's rank, or -- for a promoted piece
+// (tkz_tables.h) -- its promo code.  Items in order of frequency, most frequent first (the builder keeps the first sixteenth of the SHORT keys
+// in their first bucket, which is all k_probe fetches for them); longer and empty keys are skipped.
+struct KeyItem { std::string key; uint32_t value; };
+void build_key_tables(const std::vector<KeyItem>& items, std::vector<TkzShortSlot>* short_slots, uint32_t* short_seed,
+                      std::vector<TkzMidSlot>* mid_slots, uint32_t* mid_seed);
+
 // Parses a .tiktoken image.  Returns 0 (TKZ_OK) or a negative tkz_status; msg receives a description.
 int parse_tiktoken(const uint8_t* file, size_t n, Vocab* out, std::string* msg);
 // Builds every table image (requires parse_tiktoken to have succeeded).
