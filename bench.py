@@ -473,6 +473,12 @@ def main():
         rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
         dt = max(float(x.item()) for x in allt)              # the slowest rank's time is the job's
     kms = enc.kernel_ms()
+    try:
+        npromo = enc.piece_stats().get("promoted_pieces_in_tables", 0)
+        promoted_note = ("%d memo entries promoted into the key tables during the warm-up steps (TKZ_OPT_PROMOTE, automatic: learnt from the warm-up documents, "
+                         "not from the timed batch)" % npromo) if npromo else "none"
+    except Exception as ex:
+        promoted_note = "unknown (%s)" % ex
     kms_rank = rank
     if world > 1:
         # the roofline prices the SLOWEST rank's kernels (its time is the job's): every rank's per-kernel milliseconds travel with its step time
@@ -497,12 +503,23 @@ def main():
     dt_nomemo = None
     nm_steps = args.steps if args.no_memo_steps is None else args.no_memo_steps
     if not args.no_memo and nm_steps > 0:
+        # (no memo means no promoted pieces either -- they are memo answers moved into the key tables: dropped for this leg, learnt again after it by two
+        #  untimed steps, the two automatic rounds an encoder gets)
+        promoted_before = enc.piece_stats().get("promoted_pieces_in_tables", 0)
+        enc.set_option(N.OPT_PROMOTE, 0)
+        enc.set_option(N.OPT_PROMOTE, 3)
         enc.set_option(N.OPT_PIECE_MEMO, 0)
         memo_on[id(enc)] = False
         step()
         dt_nomemo, _ = timed(enc, nm_steps)
         enc.set_option(N.OPT_PIECE_MEMO, 1)
+        enc.set_option(N.OPT_PROMOTE, 1)
         memo_on[id(enc)] = True
+        if promoted_before:
+            memo_on[id(enc)] = False                              # (kind 6: these two steps must not empty the memo they learn from)
+            step(); step()
+            memo_on[id(enc)] = True
+            fence()
     # the same corpus under a stand-in vocabulary that has never seen it (tools/train_bpe.py synth100k_heldout: the same size and recipe
     # WITHOUT the bench's generator in the training text): `value_heldout_vocab`.  synth100k is trained on the generator's own output, so
     # its whole-piece hit rate flatters; the real cl100k_base lies somewhere between the two.  Its own encoder, its own memo, the same
@@ -962,6 +979,7 @@ def main():
             "config": {"workload": workloads[args.kind] % (n_docs, args.min_len, args.max_len, job_bytes / max(1, job_docs)),
                        "pattern": PATTERN_NAME[args.pattern],
                        "piece_memo": memo_note,
+                       "promoted_pieces": promoted_note,
                        "vocab": vocab_name, "vocab_keys": len(vocab), "vocab_sha256": hashlib.sha256(raw).hexdigest(), "docs_per_gpu": n_docs, "bytes_per_gpu": total, "tokens_per_gpu": n_tokens_rank,
                        "job_docs": job_docs, "job_bytes": job_bytes, "job_tokens": job_tokens,
                        "partitioning": "contiguous document ranges, one process per GPU; one all-gather of 3 int64 counts per rank per step"},

@@ -1465,7 +1465,7 @@ void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_sca
 tkz_status tkz_encoder_piece_stats(tkz_encoder* e, int64_t* out8, int32_t reset) {
     if (!e || !out8) return fail(TKZ_E_ARG, "null argument");
     for (int i = 0; i < 8; ++i) out8[i] = 0;
-    if (!e->t_stats.p) return TKZ_OK;
+    if (!e->t_stats.p) { std::lock_guard<std::mutex> lock(e->mu); out8[7] = (int64_t)e->promo_items.size(); return TKZ_OK; }
     DeviceScope scope;
     tkz_status st = check_encoder(e, scope);
     if (st != TKZ_OK) return st;
