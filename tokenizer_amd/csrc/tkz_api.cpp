@@ -386,7 +386,7 @@ tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool 
         HIP_TRY(ws->w_doctok.ensure((size_t)((pieces ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
         HIP_TRY(ws->w_dcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_dbase.ensure((size_t)ntiles * 8, acc));
-        HIP_TRY(ws->w_heavyq.ensure((size_t)ntiles + 64 + (size_t)ntiles / 64 + 64, acc));      // (+ a flag per 64 sub-tiles: k_merge_long -> k_merge_coop)
+        HIP_TRY(ws->w_heavyq.ensure((size_t)ntiles + 64, acc));
         HIP_TRY(ws->w_gq.ensure((size_t)(total / kArenaPiece + 2) * 24, acc));     // {position, length} per giant piece + the order they are taken in
         HIP_TRY(ws->w_gcnt.ensure((size_t)ntiles * 4, acc));
         if (!ws->w_pool.p) HIP_TRY(ws->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
@@ -483,7 +483,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.giant_q = ws->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = ws->w_gcnt.as<int32_t>();
             P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
             P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
-            P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles; P.coop_flag = P.heavy_flag + ntiles + 64;
+            P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
             HIP_TRY(hipMemsetAsync(P.heavy_flag, 0, (size_t)ntiles, stream));
             P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
             P.ablate = 0; P.devprof = nullptr;
@@ -690,7 +690,7 @@ tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, con
     P.giant_q = ws->w_gq.as<int64_t>(); P.giant_cap = total / kArenaPiece + 1; P.giant_cnt = ws->w_gcnt.as<int32_t>();
     P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
     P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
-    P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles; P.coop_flag = nullptr;
+    P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
     P.pool = ws->w_pool.as<int32_t>(); P.pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head)); P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
     P.ablate = 0; P.devprof = nullptr; P.stats = nullptr; P.place128 = 0; P.promo = nullptr; P.pextra = nullptr;
     SmallArgs A{};

@@ -17,7 +17,10 @@ constexpr int kShortMax = 16;       // pieces up to this many bytes are merged o
 #endif
 constexpr int kMergeGroup = TKZ_MERGE_GROUP;   // sub-tiles per wavefront of k_merge_short ("group")
 constexpr int kDenseCap = 256 * kMergeGroup;   // tokens of merged short pieces a group keeps packed (what does not fit waits in tmp, like the long pieces' tokens)
-constexpr int kArenaDwords = 2560;  // LDS arena of k_merge_long: a long miss of a batch gets its bytes + 1 dword + 1 bit per byte out of it (2 dwords per byte for
+#ifndef TKZ_ARENA_DWORDS
+#define TKZ_ARENA_DWORDS 2560
+#endif
+constexpr int kArenaDwords = TKZ_ARENA_DWORDS;  // LDS arena of k_merge_long: a long miss of a batch gets its bytes + 1 dword + 1 bit per byte out of it (2 dwords per byte for
                                     // vocabularies with ranks of 2^21 and more, which keep an ids[] array: tkz_bpe.h)
 constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (256 + tkz_bpe_var_dwords(1024) = 2336 <= kArenaDwords)
 constexpr int kLanePiece = 256;    // ... but a missed piece longer than this is merged by a whole wavefront (k_merge_coop): one lane takes ~n^2 steps, and the kernel waits for it
@@ -52,7 +55,7 @@ struct EncodeParams {
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
     int32_t* counters;            // [0] error bits, [1] the longest miss list seen (kErrMissCap), [2] the longest list above kMissCapMin that fitted (grown lists only),
                                   // [3] sub-tiles with more than 64 list entries ([2], [3]: k_list_stats, grown lists only)
-    uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_probe: bit 0 = long misses in its list, bit 1 = a giant piece
+    uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_probe: bit 0 = long misses in its list, bit 1 = a giant piece, bit 2 = a long miss of more than kLanePiece bytes (k_merge_coop)
                                                                           // (a flag, not a queue: a queue's one counter serialises a million atomics on mixed text)
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)
     // pieces > kArenaPiece bytes ("giant"): found by k_giant_find, merged by k_giant_merge (one 1024-thread workgroup each); their
@@ -61,7 +64,6 @@ struct EncodeParams {
     unsigned long long* giant_ticket;       // k_giant_merge: next entry of the (longest first) order, giant_q[2 * giant_cap + t], to be taken
     // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE bit 4): per-phase clock counters of k_probe.  Compiled out of libtkz.so otherwise.
     unsigned long long* devprof;
-    uint8_t* coop_flag;                 // [nsub / 64 + 1] chunks of 64 sub-tiles whose long-miss lists hold a piece of more than kLanePiece bytes (k_merge_long -> k_merge_coop); null: k_small
     int32_t ablate;
     // TKZ_OPT_PIECE_STATS: null, or the encoder's statistics block -- [0] memo lookups, [1] memo hits, [2] short misses, [3] long misses, [4] pieces
     // (what tkz_encoder_piece_stats reports; the timed runs leave it null)

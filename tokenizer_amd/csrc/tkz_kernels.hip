@@ -764,7 +764,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
     uint4* const mq = P.mquad + sub * (int64_t)P.mcap;
     int ns = 0, nl = 0, midseen = 0;
     int promo_extra = 0;                                   // tokens beyond one per piece that the promoted pieces of this sub-tile stand for (P.pextra)
-    bool giant = false;
+    bool giant = false, coopl = false;                     // coopl: a long miss of more than kLanePiece bytes (k_merge_coop's: bit 2 of the sub-tile's flag)
     constexpr int U = TKZ_PROBE_U;                         // batches of 64 pieces whose gathers are in flight together
 #pragma unroll 1
     for (int k0 = 0; k0 < np; k0 += 64 * U) {
@@ -846,6 +846,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
             if (miss_l && il + ns < P.mcap) ml[P.mcap - 1 - il] = ent;
             uint32_t rec = ((s_mark[s >> 5] >> (s & 31)) & 1u) ? kPrMark : 0u;
             if (REPORT) giant = giant || (miss_l && len > kLanePiece);      // (k_small, the only REPORT user, hands a batch with such a piece back like one with a giant piece: k_merge_coop is a kernel of the batch path)
+            else coopl = coopl || (miss_l && len > kLanePiece);
             if (is_giant) { rec |= kPrMiss | kPrGiant | (uint32_t)s; giant = giant || valid; }
             else if (miss) rec |= kPrMiss | (miss_l ? (kPrLong | (uint32_t)il) : (uint32_t)is_);
             else rec |= (uint32_t)rank;
@@ -859,8 +860,10 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
         simt::atomic_add64(&P.devprof[4], (unsigned long long)(t_2 - t_1)); simt::atomic_add64(&P.devprof[5], (unsigned long long)nmid);
         simt::atomic_add64(&P.devprof[6], (unsigned long long)np);
     }
-    // sub-tiles with long misses (bit 0: statistics only, the lists say it) or a giant piece (bit 1: k_giant_find, k_merge_long, k_place)
-    const uint32_t f = (nl ? 1u : 0u) | (simt::ballot(giant) ? 2u : 0u);
+    // sub-tiles with long misses (bit 0: statistics only, the lists say it), a giant piece (bit 1: k_giant_find, k_merge_long, k_place), a long miss of more
+    // than kLanePiece bytes (bit 2: k_merge_coop -- k_merge_long used to flag those chunks itself: a pointer, an index and a flag alive across its merge
+    // loops, 14 more spilled scalars and 4 % of that kernel on mixed text)
+    const uint32_t f = (nl ? 1u : 0u) | (simt::ballot(giant) ? 2u : 0u) | (simt::ballot(coopl) ? 4u : 0u);
     if (lane == 0) {
         P.heavy_flag[sub] = (uint8_t)f;
         P.mcount[sub] = (uint32_t)ns | ((uint32_t)nl << 16);
@@ -1219,8 +1222,6 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
     for (int64_t c = c0; c * 64 < P.nsub; c += cstep) {
         const int64_t t = c * 64 + lane;
         int my_nl = 0;
-        bool coop = false;                                      // a piece of more than kLanePiece bytes in this chunk: left to k_merge_coop
-        if (lane == 0 && P.coop_flag) P.coop_flag[c] = 0;
         if (t < P.nsub) {
             const uint32_t mc = P.mcount[t];
             my_nl = (int)(mc >> 16);
@@ -1281,12 +1282,19 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                     rel = (int)(ent & 1023u); len = (int)((ent >> kMrLenShift) & 1023u) + 1;
                 }
                 const int nbw = (len + 3) >> 2;
+#ifdef TKZ_ML_LANE32
+                // (development A/B, round 5: the fixed 32-entry form of k_merge_short's merger -- ids[32] | pr[32], the bytes in registers -- for the pieces
+                //  of up to 32 bytes, which are 70 % of mixed text's long misses)
+                const bool lane32 = compact && len <= 32;
+#else
+                constexpr bool lane32 = false;
+#endif
                 const bool small = compact && len <= 64;         // alive bits in registers: the state is pr[] alone
-                const bool mine = valid && len <= kLanePiece;    // (a longer piece keeps its entry as it is: k_merge_coop answers it)
-                coop = coop || (valid && !mine);
+                const bool mine = valid && len <= kLanePiece;    // (a longer piece keeps its entry as it is: k_merge_coop answers it -- k_probe has flagged its sub-tile)
                 int need = 0;
                 if (mine) {
                     need = ((nbw + 3) & ~3) + (small ? tkz_bpe_var_n4(len) : compact ? tkz_bpe_varc_dwords(len) : tkz_bpe_var_dwords(len));
+                    if (lane32) need = 64;
                     if (!((need >> 2) & 1)) need += 4;           // an odd number of quads: equal spans then sit on distinct banks
                 }
                 int btot;
@@ -1297,6 +1305,27 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                     const int64_t sub = c * 64 + q;
                     const int64_t abs = sub * kSub + rel;
                     uint32_t* bw = &s_arena[aoff];                   // (len + 3) / 4 dwords of bytes, then the merge state
+#ifdef TKZ_ML_LANE32
+                    if (lane32) {
+                        uint32_t w8[8];
+                        tkz_load_piece16(P.bytes, P.total, abs, w8);
+                        tkz_load_piece16(P.bytes, P.total, abs + 16, w8 + 4);
+                        uint32_t alive32 = 0;
+                        int e1 = 0;
+                        uint32_t* ids32 = bw; uint32_t* pr32 = bw + 32;
+                        const int cnt = tkz_bpe_lane_f<32>(T, w8, len, ids32, pr32, [&](uint32_t b) -> uint32_t { return (uint32_t)s_brank[b]; },
+                                                           [&](uint32_t b0, uint32_t b1) -> int32_t { return T.bytepair_rank[(b0 << 8) | b1]; }, &alive32, &e1);
+                        err |= e1;
+                        int32_t* tk = P.tmp + abs;
+                        { int i = 0; for (uint32_t a = alive32; a; a &= a - 1) tk[i++] = (int32_t)ids32[tkz_ctz32(a)]; }
+                        if (cnt <= 4) {
+                            uint4 tq; tq.x = (uint32_t)tk[0]; tq.y = cnt > 1 ? (uint32_t)tk[1] : 0u; tq.z = cnt > 2 ? (uint32_t)tk[2] : 0u; tq.w = cnt > 3 ? (uint32_t)tk[3] : 0u;
+                            P.mquad[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tq;
+                            P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_inline(cnt);
+                        } else P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_entry(false, cnt, rel);
+                        if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
+                    } else
+#endif
                     {
                         const int64_t a0 = abs & ~(int64_t)3;
                         const uint32_t sh = (uint32_t)(abs & 3) * 8u;
@@ -1311,7 +1340,6 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                             bw[w] = simt::alignbit(nx, prev, sh);
                             prev = nx;
                         }
-                    }
                     const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(bw);
                     uint32_t* st = bw + ((nbw + 3) & ~3);             // (the state arrays are read 16 bytes at a time)
                     auto at = [&](int i) -> uint32_t { return pbytes[i]; };
@@ -1333,12 +1361,12 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                         P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_inline(cnt);
                     } else P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_entry(false, cnt, rel);
                     if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
+                    }
                 }
                 (void)simt::ballot(true);
                 done += limit < nseg - done ? limit : nseg - done;
             }
         }
-        if (simt::ballot(coop) && lane == 0 && P.coop_flag) P.coop_flag[c] = 1;
     }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
@@ -1355,7 +1383,7 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
 // local bounds + rounds for chains of equal pairs -- its workgroup is this kernel's single wavefront, 32 slots a lane).  A lane of k_merge_long takes ~n^2 steps
 // for a piece of n bytes and the kernel lasts as long as its slowest lane: one 1000-byte run of one letter held it for 3.4 ms, 40 times what the rest of a
 // 1 GB batch needed; the wavefront takes ~30 batches whatever the length.  (Below kLanePiece the lanes win: 64 pieces a wavefront instead of one.)
-// k_merge_long leaves such an entry as k_probe wrote it and flags the chunk of 64 sub-tiles; this kernel walks the lists of the flagged chunks only.
+// k_merge_long leaves such an entry as k_probe wrote it; k_probe has flagged the sub-tile (bit 2 of heavy_flag) and this kernel walks the lists of the chunks with a flagged sub-tile only.
 constexpr int kCoopScratch = (4 * kTailSubs + 8) * 64 + 16 + 16;
 constexpr int kCoopLdsBytes = 2 * 4 * kArenaPiece + 4 * (kArenaPiece / 32) + kCoopScratch + 4 * 68;
 TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
@@ -1369,8 +1397,8 @@ TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
     const int64_t nchunks = (P.nsub + 63) / 64;
     int err = 0;
     for (int64_t c = simt::bid(); c < nchunks; c += simt::nblocks()) {
-        if (!P.coop_flag[c]) continue;
         const int64_t t = c * 64 + lane;
+        if (!simt::ballot(t < P.nsub && (P.heavy_flag[t] & 4u))) continue;       // (k_probe flags the sub-tiles that hold such a piece)
         int my_nl = 0;
         if (t < P.nsub) {
             const uint32_t mc = P.mcount[t];
