@@ -72,6 +72,7 @@ extern int64_t g_bid, g_nblocks;
 
 inline uint4 tkz_load16_nt(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 inline uint32_t tkz_load_nt(const uint32_t* p) { return *p; }
+inline uint32_t tkz_atomic_load_agent(const uint32_t* p) { return *p; }
 inline int32_t tkz_load_nt(const int32_t* p) { return *p; }
 inline void tkz_store_nt(int32_t* p, int32_t v) { *p = v; }
 inline void tkz_store16_nt(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }

@@ -66,6 +66,12 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// a part of another buffer (not owned)
+struct DevView {
+    void* p = nullptr;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
 struct CounterBlock {          // mirrors the device block
     int32_t err; int32_t mneed /* longest miss list of a sub-tile (kErrMissCap) */; int32_t mhigh /* longest list above kMissCapMin that fitted */;
     int32_t over64 /* sub-tiles with more than 64 list entries (k_list_stats; grown lists only) */;
@@ -76,6 +82,7 @@ struct CounterBlock {          // mirrors the device block
     int64_t npieces;
     unsigned long long giant_ticket;       // k_giant_merge's work counter
     unsigned long long xcount, xcount2;    // (adjacent: launch_pretok_rows) blocks the o200k ASCII scanner left over, blocks the multi-byte one left over as well
+    unsigned long long coop_count, coop_ticket;   // k_list_stats -> k_merge_coop: queued long misses of more than kLanePiece bytes, the next one to be taken
 };
 
 }  // namespace
@@ -91,8 +98,12 @@ struct tkz_vocab { tkz::Vocab v; };
 // memo, is locked: LRUCache.cs:61,99).
 struct Workspace {
     // kernel workspace
-    DevBuf w_gq, w_gcnt, w_xq, w_heavyq, w_docbits, w_startbits, w_tmp, w_dense, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_counters, w_pool;
-    DevBuf w_mlist, w_mquad, w_mcount, w_pextra;
+    DevBuf w_gq, w_gcnt, w_xq, w_startbits, w_tmp, w_dense, w_tcount, w_prank, w_pcount, w_pbase, w_tbase, w_bsum, w_doctok, w_dcount, w_dbase, w_pool;
+    // what every batch starts from as zeros -- the counter block, the document-start bitmap, the per-sub-tile flags -- lives in ONE buffer, zeroed by ONE
+    // memset (three launches were three dependent launches: a batch of a few megabytes is made of little else)
+    DevBuf w_zero; size_t zero_bytes = 0;
+    DevView w_counters, w_docbits, w_heavyq;
+    DevBuf w_mlist, w_mquad, w_mcount, w_pextra, w_coopq;
     DevBuf w_counts3;                      // {n_docs, n_bytes, n_tokens} of the batch this workspace is running (tkz_pending_counts_device)
     int32_t mcap = tkz::kMissCapMin;       // entries of a sub-tile's miss list; grows (once, to what the batch needed) when a sub-tile overflows it
     bool place128 = false;                 // a recent batch of this workspace had more than a fifth of its sub-tiles above 64 list entries: k_place<128>
@@ -122,8 +133,8 @@ struct Workspace {
     double ms[tkz::K_COUNT] = {};
     int64_t launches[tkz::K_COUNT] = {};
     void release_all() {
-        DevBuf* bufs[] = {&w_counts3, &w_mlist, &w_mquad, &w_mcount, &w_pextra, &w_gq, &w_gcnt, &w_xq, &w_heavyq, &w_docbits, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
-                          &w_doctok, &w_dcount, &w_dbase, &w_counters, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
+        DevBuf* bufs[] = {&w_counts3, &w_mlist, &w_mquad, &w_mcount, &w_pextra, &w_coopq, &w_gq, &w_gcnt, &w_xq, &w_zero, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
+                          &w_doctok, &w_dcount, &w_dbase, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
                           &s_outoffs[0], &s_outoffs[1], &u_units, &u_offs, &u_docbits, &u_grp, &u_tsum, &u_tbase, &u_bsum, &u_counters, &u_bytes, &u_boffs,
                           &d_grp, &d_tsum, &d_tbase, &d_bsum, &d_counters, &d_ids, &d_idoffs, &d_out, &d_outoffs, &p_boffs, &p_toffs, &p_docp};
         for (DevBuf* b : bufs) b->release();
@@ -362,9 +373,14 @@ tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool 
     const int64_t ntiles = (total + kSub - 1) / kSub;
     const int64_t nblk = (ntiles + kScanBlock - 1) / kScanBlock;
     int64_t* acc = &ws->bytes_allocated;
-    HIP_TRY(ws->w_docbits.ensure((size_t)(nwords + 8) * 8, acc));
+    {   // [counter block, 256 B] [document-start bits, nwords + 8 words] [a flag per sub-tile, ntiles + 64 bytes]: zeroed together
+        static_assert(sizeof(CounterBlock) <= 256, "the counter block's place in the zero region");
+        const size_t off_bits = 256, off_flags = off_bits + (size_t)(nwords + 8) * 8, end = off_flags + (size_t)ntiles + 64;
+        HIP_TRY(ws->w_zero.ensure(end, acc));
+        ws->w_counters.p = ws->w_zero.p; ws->w_docbits.p = ws->w_zero.as<char>() + off_bits; ws->w_heavyq.p = ws->w_zero.as<char>() + off_flags;
+        ws->zero_bytes = bitmap_only ? off_flags : end;
+    }
     HIP_TRY(ws->w_startbits.ensure((size_t)(nwords + 8) * 8, acc));
-    HIP_TRY(ws->w_counters.ensure(sizeof(CounterBlock), acc));
     HIP_TRY(ws->w_counts3.ensure(32, acc));
     if (!bitmap_only) {
         HIP_TRY(ws->w_tmp.ensure((size_t)(total + 64) * 4, acc));
@@ -381,12 +397,12 @@ tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool 
         HIP_TRY(ws->w_mquad.ensure((size_t)ntiles * (size_t)ws->mcap * 16, acc));
         HIP_TRY(ws->w_mcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_pextra.ensure((size_t)ntiles * 4, acc));
+        HIP_TRY(ws->w_coopq.ensure((size_t)(total / kLanePiece + 64) * 8, acc));
         HIP_TRY(ws->w_tbase.ensure((size_t)(ntiles + 1) * 8, acc));
         HIP_TRY(ws->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
         HIP_TRY(ws->w_doctok.ensure((size_t)((pieces ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
         HIP_TRY(ws->w_dcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_dbase.ensure((size_t)ntiles * 8, acc));
-        HIP_TRY(ws->w_heavyq.ensure((size_t)ntiles + 64, acc));
         HIP_TRY(ws->w_gq.ensure((size_t)(total / kArenaPiece + 2) * 24, acc));     // {position, length} per giant piece + the order they are taken in
         HIP_TRY(ws->w_gcnt.ensure((size_t)ntiles * 4, acc));
         if (!ws->w_pool.p) HIP_TRY(ws->w_pool.ensure((size_t)std::min<int64_t>(24 * total + 4096, int64_t(64) << 20), acc));
@@ -451,14 +467,14 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         }
         if (ws->learning) {
             T.memo_hits = e->t_memo_hits.as<uint32_t>();
+            T.memo_hits_sparse = total >= (int64_t(64) << 20) ? 1u : 0u;       // (below 64 MB every hit is counted: a few million atomics at most)
             HIP_TRY(hipMemsetAsync(T.memo_hits, 0, (size_t)e->memo_slots * 4, stream));
         }
         int64_t* grand = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, grand));
         unsigned long long* pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head));
         uint64_t* docbits = ws->w_docbits.as<uint64_t>();
         uint64_t* startbits = ws->w_startbits.as<uint64_t>();
-        HIP_TRY(hipMemsetAsync(counters, 0, sizeof(CounterBlock), stream));
-        HIP_TRY(hipMemsetAsync(docbits, 0, (size_t)nwords * 8, stream));
+        HIP_TRY(hipMemsetAsync(ws->w_zero.p, 0, ws->zero_bytes, stream));      // counters, document-start bits, sub-tile flags
         launch_docmark(L, d_offs, n_docs, total, docbits, counters);
         if (!pretok) {
             HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
@@ -484,7 +500,9 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
             P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
             P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
-            HIP_TRY(hipMemsetAsync(P.heavy_flag, 0, (size_t)ntiles, stream));
+            P.coop_q = ws->w_coopq.as<uint64_t>(); P.coop_cap = total / kLanePiece + 64;
+            P.coop_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, coop_count));
+            P.coop_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, coop_ticket));
             P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
             P.ablate = 0; P.devprof = nullptr;
             P.stats = e->piece_stats ? e->t_stats.as<unsigned long long>() : nullptr;
@@ -506,8 +524,12 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             // kernels record the token position of every PIECE start and k_docoffs yields the token range of every piece
             const uint64_t* markbits = po ? startbits : docbits;
             P.docbits = markbits;
-            launch_doccount(L, markbits, nwords, total, ntiles, ws->w_dcount.as<int32_t>());
-            launch_scan(L, ws->w_dcount.as<int32_t>(), ntiles, ws->w_bsum.as<int64_t>(), ws->w_dbase.as<int64_t>(), ndocstarts, -1);
+            int64_t* npieces = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, npieces));
+            // the marks (document starts; at piece granularity the piece starts) and the piece starts of every sub-tile, counted in ONE pass over
+            // the two bitmaps and scanned by ONE launch (the piece counts rounded up to whole record lines: where a sub-tile's records live in `prank`)
+            launch_doccount2(L, markbits, startbits, nwords, total, ntiles, ws->w_dcount.as<int32_t>(), ws->w_pcount.as<int32_t>());
+            launch_scan2(L, ntiles, ws->w_bsum.as<int64_t>(), ws->w_dcount.as<int32_t>(), ws->w_dbase.as<int64_t>(), ndocstarts, 1,
+                         ws->w_pcount.as<int32_t>(), ws->w_pbase.as<int64_t>(), npieces, kRecordLine, -1);
             if (po) {
                 int64_t np = 0;
                 HIP_TRY(hipMemcpyAsync(&ws->h_counters->ndocstarts, ndocstarts, 8, hipMemcpyDeviceToHost, stream));
@@ -519,17 +541,16 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                 pieces_over = np > po->piece_cap;
                 if (!pieces_over) launch_piece_index(L, startbits, nwords, total, ntiles, ws->w_dbase.as<int64_t>(), np, po->piece_boffs, d_offs, n_docs, po->doc_piece);
             }
-            // pieces that start in each sub-tile and their scan: where a sub-tile's records live in `prank`
-            int64_t* npieces = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, npieces));
-            launch_doccount(L, startbits, nwords, total, ntiles, ws->w_pcount.as<int32_t>());
-            launch_scan(L, ws->w_pcount.as<int32_t>(), ntiles, ws->w_bsum.as<int64_t>(), ws->w_pbase.as<int64_t>(), npieces, -1, kRecordLine);
             launch_encode(L, T, P, ntiles);
             if (P.stats) launch_miss_stats(L, P, ntiles);
-            launch_scan(L, P.tile_count, ntiles, ws->w_bsum.as<int64_t>(), ws->w_tbase.as<int64_t>(), grand, K_SCAN);
+            launch_scan2(L, ntiles, ws->w_bsum.as<int64_t>(), P.tile_count, ws->w_tbase.as<int64_t>(), grand, 1, nullptr, nullptr, nullptr, 1, K_SCAN);
             launch_place(L, P, ws->w_tbase.as<int64_t>(), ntiles, d_out, out_cap);
-            if (po) { if (!pieces_over) launch_docoffs(L, po->piece_boffs, po->n_pieces, total, ws->w_tbase.as<int64_t>(), markbits, P.docord_base, P.doc_tok, grand, po->piece_toffs); }
-            else launch_docoffs(L, d_offs, n_docs, total, ws->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs);
-            launch_counts3(L, n_docs, total, grand, e->t_counts3.as<int64_t>(), ws->w_counts3.as<int64_t>(), d_counts3);
+            if (po) {
+                if (!pieces_over) launch_docoffs(L, po->piece_boffs, po->n_pieces, total, ws->w_tbase.as<int64_t>(), markbits, P.docord_base, P.doc_tok, grand, po->piece_toffs);
+                launch_counts3(L, n_docs, total, grand, e->t_counts3.as<int64_t>(), ws->w_counts3.as<int64_t>(), d_counts3);
+            } else      // (the batch's {n_docs, n_bytes, n_tokens} blocks by the same launch)
+                launch_docoffs(L, d_offs, n_docs, total, ws->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs,
+                               n_docs, e->t_counts3.as<int64_t>(), ws->w_counts3.as<int64_t>(), d_counts3);
         }
         HIP_TRY(hipMemcpyAsync(ws->h_counters, counters, sizeof(CounterBlock), hipMemcpyDeviceToHost, stream));
         }
@@ -991,7 +1012,7 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
         e->memo_slots = kMemoSlots;
         e->T.memo = e->t_memo.as<TkzMemoSlot>(); e->T.memo_n = kMemoSlots;
     }
-    e->T.memo_hits = nullptr; e->T.promo = nullptr; e->T.promo_n = 0;
+    e->T.memo_hits = nullptr; e->T.memo_hits_sparse = 0; e->T.promo = nullptr; e->T.promo_n = 0;
     e->short_slots_n = (uint32_t)V.short_slots.size(); e->mid_slots_n = (uint32_t)V.mid_slots.size();
     e->T.max_key_len = V.max_key_len;
     e->T.pattern = pattern;

@@ -23,7 +23,10 @@ constexpr int kDenseCap = 256 * kMergeGroup;   // tokens of merged short pieces 
 constexpr int kArenaDwords = TKZ_ARENA_DWORDS;  // LDS arena of k_merge_long: a long miss of a batch gets its bytes + 1 dword + 1 bit per byte out of it (2 dwords per byte for
                                     // vocabularies with ranks of 2^21 and more, which keep an ids[] array: tkz_bpe.h)
 constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (256 + tkz_bpe_var_dwords(1024) = 2336 <= kArenaDwords)
-constexpr int kLanePiece = 256;    // ... but a missed piece longer than this is merged by a whole wavefront (k_merge_coop): one lane takes ~n^2 steps, and the kernel waits for it
+#ifndef TKZ_LANE_PIECE
+#define TKZ_LANE_PIECE 256
+#endif
+constexpr int kLanePiece = TKZ_LANE_PIECE;    // ... but a missed piece longer than this is merged by a whole wavefront (k_merge_coop): one lane takes ~n^2 steps, and the kernel waits for it
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan
@@ -62,6 +65,8 @@ struct EncodeParams {
     // tokens wait in tmp at the piece's own byte position, their count in giant_cnt[sub-tile of the piece start]
     int64_t* giant_q; unsigned long long* giant_count; int64_t giant_cap; int32_t* giant_cnt;
     unsigned long long* giant_ticket;       // k_giant_merge: next entry of the (longest first) order, giant_q[2 * giant_cap + t], to be taken
+    // long misses of more than kLanePiece bytes (k_merge_coop: a wavefront each): queued by k_list_stats as sub-tile << 10 | index in the sub-tile's long list
+    uint64_t* coop_q; unsigned long long* coop_count; unsigned long long* coop_ticket; int64_t coop_cap;
     // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE bit 4): per-phase clock counters of k_probe.  Compiled out of libtkz.so otherwise.
     unsigned long long* devprof;
     int32_t ablate;
@@ -105,8 +110,14 @@ void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, i
 // round_to (a power of two): every count is rounded up to a multiple of it before it is summed
 void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid, int round_to = 1);
 void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_base, int64_t nsub, int32_t* out, int64_t out_cap);
+// (c3a / c3b / c3c: null, or blocks that receive {c3_docs, total, *grand}: launch_counts3's job done by the same launch)
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
-                    const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs);
+                    const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs,
+                    int64_t c3_docs = 0, int64_t* c3a = nullptr, int64_t* c3b = nullptr, int64_t* c3c = nullptr);
+// the counts of two bitmaps per sub-tile in one pass; the scan of one or two count arrays -- a single launch up to 65,536 sub-tiles
+void launch_doccount2(const Launch& L, const uint64_t* bits_a, const uint64_t* bits_b, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt_a, int32_t* cnt_b);
+void launch_scan2(const Launch& L, int64_t ntiles, int64_t* bsum, const int32_t* cnt_a, int64_t* base_a, int64_t* grand_a, int round_to_a,
+                  const int32_t* cnt_b, int64_t* base_b, int64_t* grand_b, int round_to_b, int kid);
 void launch_rebase(const Launch& L, int64_t* offs, int64_t n, int64_t base);
 void launch_miss_stats(const Launch& L, const EncodeParams& P, int64_t nsub);
 void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3, int64_t* out3b = nullptr, int64_t* out3c = nullptr);

@@ -994,9 +994,10 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     int st_look = 0, st_hit = 0;                                // TKZ_OPT_PIECE_STATS: memo lookups and hits of this group (one pair of atomics at its end)
     int32_t* const dense = P.dense + grp * kDenseCap;
     const bool memo = T.memo_n != 0;
-    // a LEARNING batch (tkz_api.cpp, promote_from_memo): the hits of every eighth group are counted per memo slot -- the host promotes the hottest
-    // entries into the SHORT / MID tables afterwards.  Null in every other batch.
-    const bool count_hits = T.memo_hits != nullptr && (grp & 7) == 0;
+    // a LEARNING batch (tkz_api.cpp, promote_from_memo): hits of every eighth group are sampled per memo slot (memo_phase below) -- the host promotes
+    // the hottest entries into the SHORT / MID tables afterwards.  Null in every other batch.
+    const bool sparse = T.memo_hits_sparse != 0;                            // (a large batch: every eighth group, one lane a time; a small one: every hit)
+    const bool count_hits = T.memo_hits != nullptr && (!sparse || (grp & 7) == 0);       // (wave-uniform)
     // where the `cnt` tokens of a piece go -- up to four: into the entry's own quad (the caller stores them); more: packed behind those of
     // the pieces before it in the group's dense region (in tmp, at the piece's own byte position, once that is full) -- and the answer in
     // its list entry; every lane of the wavefront calls it (a scan inside)
@@ -1044,6 +1045,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
         if (lane < nchk) { r16 = s_rec[lane]; ix = s_idx[lane]; }
         const int si = (int)(ix >> 10), j = (int)(ix & 1023u), rel = (int)(r16 & 1023u), len = (int)((r16 >> 10) & 15u) + 1;
         bool hit = false;
+        uint32_t hit_slot = 0;
         uint4 vv; vv.x = vv.y = vv.z = vv.w = 0;
         if (mine && memo) {
             uint32_t kw[4];
@@ -1059,8 +1061,16 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
                 //  model says a dwordx4 access is single-copy atomic across CUs / XCDs -- is not valid until its last word is there)
                 const bool h = !nul && ((v.x & v.y & v.z & v.w) & kMemoValid) && v.x != kMemoBusy && kk.x == kw[0] && kk.y == kw[1] && kk.z == kw[2] && kk.w == kw[3] &&
                                ((v.y >> 27) & 15u) == (uint32_t)(len - 1);
-                if (h) { hit = true; vv = v; if (count_hits) simt::atomic_add(reinterpret_cast<int*>(&T.memo_hits[b + wy]), 1); }
+                if (h) { hit = true; vv = v; hit_slot = b + wy; }
             }
+        }
+        // A learning batch: in a large batch ONE lane of the wavefront (another one every time) reports its hit -- a sample of one hit in 64 x 8.  Not every hit: the
+        // hottest pieces of Zipf-distributed text are hit millions of times a batch, and device-scope atomics on ONE address serialise at about a
+        // microsecond each (the first batch under synth100k took 2.4 s instead of 25 ms when every hit of every eighth group was counted).  A counter
+        // also stops at kMemoHitsSat (read with an agent-scope atomic load: the line in this XCD's L2 may be stale): such a slot is promoted anyway.
+        if (count_hits) {
+            if (hit && (!sparse || lane == ((done * 5 + nlist) & 63)) && tkz_atomic_load_agent(&T.memo_hits[hit_slot]) < kMemoHitsSat)
+                simt::atomic_add(reinterpret_cast<int*>(&T.memo_hits[hit_slot]), 1);
         }
         if (P.stats) { st_look += tkz_popc64(simt::ballot(mine && memo)); st_hit += tkz_popc64(simt::ballot(hit)); }   // (statistics run only: wave-uniform, null in the timed runs)
         const int cnt = hit ? (int)((vv.x >> 29) & 3u) + 1 : 0;
@@ -1179,6 +1189,15 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
 // over the whole piece and a piece of n bytes takes ~n/2 of them, so a 60-byte piece is ten times the work of a 17-byte one -- in list
 // order a batch took as long as its longest piece while the other lanes idled (33 % of the lanes active on CJK text).  Spans are padded to
 // an odd number of 16-byte quads: pieces of one class have equal spans, and with an even quad stride their 16-byte reads collide.
+// A chunk = kLongChunk consecutive sub-tiles, the unit a wavefront takes.  64 until round 5; REAL text showed what that costs: its long pieces are not
+// spread evenly -- one file of CJK prose is 64 KiB after 64 KiB of nothing but 100..250-byte pieces, ~10 ms of merging for the ONE wavefront that owns such a
+// chunk while the other 3,000 have long finished (k_merge_long 13 ms of a 17 ms step on 436 MB of source text; 0.3 ms of work).  16 sub-tiles: the tail is a
+// quarter as long, and mixed text (18 long misses per KiB) still fills its batches.
+#ifndef TKZ_LONG_CHUNK
+#define TKZ_LONG_CHUNK 16
+#endif
+constexpr int kLongChunk = TKZ_LONG_CHUNK;
+static_assert(kLongChunk >= 1 && kLongChunk <= 64, "one sub-tile of a chunk per lane");
 constexpr int kLongSeg = 384;
 constexpr int kLenClasses = 16;
 TKZ_HD int tkz_len_class(int len) {          // 17..1024, monotone
@@ -1219,10 +1238,10 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
     const int lane = simt::lane();
     int err = 0;
     constexpr bool compact = COMPACT;                           // no ids[] array (tkz_bpe_lane_varc): 40 % more pieces per batch
-    for (int64_t c = c0; c * 64 < P.nsub; c += cstep) {
-        const int64_t t = c * 64 + lane;
+    for (int64_t c = c0; c * kLongChunk < P.nsub; c += cstep) {
+        const int64_t t = c * kLongChunk + lane;
         int my_nl = 0;
-        if (t < P.nsub) {
+        if (lane < kLongChunk && t < P.nsub) {
             const uint32_t mc = P.mcount[t];
             my_nl = (int)(mc >> 16);
             if ((int)(mc & 0xFFFFu) + my_nl > P.mcap) my_nl = 0;               // (cut list: reported by k_probe, the batch is redone)
@@ -1239,7 +1258,7 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
         // position g of the 64 lists taken as one: entry g - pre[q] (from the back) of sub-tile q
         auto entry_at = [&](int g, int* q, int* j) -> uint32_t {
             *q = tkz_find_list<64>(s_pre, g); *j = g - s_pre[*q];
-            return tkz_load_nt(&P.mlist[(c * 64 + *q) * (int64_t)P.mcap + (P.mcap - 1 - *j)]);
+            return tkz_load_nt(&P.mlist[(c * kLongChunk + *q) * (int64_t)P.mcap + (P.mcap - 1 - *j)]);
         };
         for (int seg0 = 0; seg0 < ntotal; seg0 += kLongSeg) {
             const int nseg = ntotal - seg0 < kLongSeg ? ntotal - seg0 : kLongSeg;
@@ -1302,7 +1321,7 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                 const uint64_t bad = simt::ballot(mine && aoff + need > kArenaDwords);
                 const int limit = bad ? tkz_ctz64(bad) : 64;                   // lanes at or beyond `limit` wait for the next batch (limit >= 1: one piece always fits)
                 if (mine && lane < limit) {
-                    const int64_t sub = c * 64 + q;
+                    const int64_t sub = c * kLongChunk + q;
                     const int64_t abs = sub * kSub + rel;
                     uint32_t* bw = &s_arena[aoff];                   // (len + 3) / 4 dwords of bytes, then the merge state
 #ifdef TKZ_ML_LANE32
@@ -1383,62 +1402,52 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
 // local bounds + rounds for chains of equal pairs -- its workgroup is this kernel's single wavefront, 32 slots a lane).  A lane of k_merge_long takes ~n^2 steps
 // for a piece of n bytes and the kernel lasts as long as its slowest lane: one 1000-byte run of one letter held it for 3.4 ms, 40 times what the rest of a
 // 1 GB batch needed; the wavefront takes ~30 batches whatever the length.  (Below kLanePiece the lanes win: 64 pieces a wavefront instead of one.)
-// k_merge_long leaves such an entry as k_probe wrote it; k_probe has flagged the sub-tile (bit 2 of heavy_flag) and this kernel walks the lists of the chunks with a flagged sub-tile only.
+// k_merge_long leaves such an entry as k_probe wrote it; k_probe has flagged the sub-tile (bit 2 of heavy_flag), k_list_stats queues the flagged sub-tiles' entries.
 constexpr int kCoopScratch = (4 * kTailSubs + 8) * 64 + 16 + 16;
-constexpr int kCoopLdsBytes = 2 * 4 * kArenaPiece + 4 * (kArenaPiece / 32) + kCoopScratch + 4 * 68;
+constexpr int kCoopLdsBytes = 2 * 4 * kArenaPiece + 4 * (kArenaPiece / 32) + kCoopScratch;
+#ifdef TKZ_HOSTEMU
+constexpr int kCoopGrid = 4;          // (the CPU emulator pays for every idle workgroup)
+#else
+constexpr int kCoopGrid = 2048;
+#endif
 TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
     TKZ_SHARED uint4 s_lds[(kCoopLdsBytes + 15) / 16];
     int32_t* ids = reinterpret_cast<int32_t*>(s_lds);
     int32_t* pr = ids + kArenaPiece;
     uint32_t* alive = reinterpret_cast<uint32_t*>(pr + kArenaPiece);
     uint8_t* scratch = reinterpret_cast<uint8_t*>(alive + kArenaPiece / 32);
-    int* s_pre = reinterpret_cast<int*>(scratch + kCoopScratch);
     const int lane = simt::lane();
-    const int64_t nchunks = (P.nsub + 63) / 64;
     int err = 0;
-    for (int64_t c = simt::bid(); c < nchunks; c += simt::nblocks()) {
-        const int64_t t = c * 64 + lane;
-        if (!simt::ballot(t < P.nsub && (P.heavy_flag[t] & 4u))) continue;       // (k_probe flags the sub-tiles that hold such a piece)
-        int my_nl = 0;
-        if (t < P.nsub) {
-            const uint32_t mc = P.mcount[t];
-            my_nl = (int)(mc >> 16);
-            if ((int)(mc & 0xFFFFu) + my_nl > P.mcap) my_nl = 0;               // (cut list: the batch is redone)
+    // The pieces wait in a queue (k_list_stats: sub-tile << 10 | index in its long list); a wavefront takes the next one off a ticket counter until
+    // there is none.  (Until round 5 a wavefront owned chunks of 64 sub-tiles and merged the pieces of a chunk one after the other: a file of CJK prose --
+    // 64 KiB of nothing but such pieces -- kept ONE wavefront busy for milliseconds.)
+    const unsigned long long count = *P.coop_count < (unsigned long long)P.coop_cap ? *P.coop_count : (unsigned long long)P.coop_cap;
+    for (;;) {
+        unsigned long long tk = 0;
+        if (lane == 0) tk = simt::atomic_add64(P.coop_ticket, 1ull);
+        tk = ((unsigned long long)simt::shflu((uint32_t)(tk >> 32), 0) << 32) | simt::shflu((uint32_t)tk, 0);
+        if (tk >= count) break;
+        const uint64_t qe = P.coop_q[tk];
+        const int64_t sub = (int64_t)(qe >> 10);
+        const int jj = (int)(qe & 1023u);
+        const uint32_t ee = P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - jj)];
+        if (ee & kMrDone) continue;                             // (cannot happen: an entry is queued once)
+        const int rel = (int)(ee & 1023u), n = (int)((ee >> kMrLenShift) & 1023u) + 1;
+        const int64_t abs = sub * kSub + rel;
+        const uint8_t* gb = P.bytes + abs;
+        for (int k = lane; k < n; k += 64) {
+            const uint32_t b = gb[k];
+            ids[k] = T.byte_rank[b];
+            pr[k] = (k + 1 < n) ? T.bytepair_rank[(b << 8) | gb[k + 1]] : TKZ_RANK_NONE;
         }
-        int ntotal;
-        const int pre = tkz_wave_scan_sum(my_nl, &ntotal);
         simt::sync();
-        s_pre[lane] = pre;
-        if (lane == 0) s_pre[64] = ntotal;
-        simt::sync();
-        for (int g0 = 0; g0 < ntotal; g0 += 64) {
-            const int g = g0 + lane;
-            int q = 0, j = 0;
-            uint32_t ent = kMrDone;
-            if (g < ntotal) { q = tkz_find_list<64>(s_pre, g); j = g - s_pre[q]; ent = P.mlist[(c * 64 + q) * (int64_t)P.mcap + (P.mcap - 1 - j)]; }
-            uint64_t todo = simt::ballot(!(ent & kMrDone) && (int)((ent >> kMrLenShift) & 1023u) + 1 > kLanePiece);
-            for (; todo; todo &= todo - 1) {
-                const int src = tkz_ctz64(todo);
-                const int qq = simt::shfl(q, src), jj = simt::shfl(j, src);
-                const uint32_t ee = simt::shflu(ent, src);
-                const int rel = (int)(ee & 1023u), n = (int)((ee >> kMrLenShift) & 1023u) + 1;
-                const int64_t sub = c * 64 + qq, abs = sub * kSub + rel;
-                const uint8_t* gb = P.bytes + abs;
-                for (int k = lane; k < n; k += 64) {
-                    const uint32_t b = gb[k];
-                    ids[k] = T.byte_rank[b];
-                    pr[k] = (k + 1 < n) ? T.bytepair_rank[(b << 8) | gb[k + 1]] : TKZ_RANK_NONE;
-                }
-                simt::sync();
-                tkz_bpe_long_tail<true>(T, n, ids, pr, alive, scratch, nullptr);
-                const int cnt = tkz_bpe_long_tail_emit<true>(n, ids, pr, alive, P.tmp + abs, &err);
-                if (lane == 0) {
-                    P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - jj)] = tkz_result_entry(false, cnt, rel);      // (the tokens are in tmp at the piece's position)
-                    if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
-                }
-                simt::sync();
-            }
+        tkz_bpe_long_tail<true>(T, n, ids, pr, alive, scratch, nullptr);
+        const int cnt = tkz_bpe_long_tail_emit<true>(n, ids, pr, alive, P.tmp + abs, &err);
+        if (lane == 0) {
+            P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - jj)] = tkz_result_entry(false, cnt, rel);      // (the tokens are in tmp at the piece's position)
+            if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
         }
+        simt::sync();
     }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
@@ -1765,29 +1774,24 @@ TKZ_KERNEL_OCC(256, TKZ_PLACE_OCC) void k_place(EncodeParams P, const int64_t* t
 // giant pieces (> kArenaPiece bytes: a run of thousands of letters, of '=' ...): found on the bitmap, merged by a whole
 // 1024-thread workgroup each (tkz_bpe_long, rounds) before the encode kernels run
 // -------------------------------------------------------------------------------------------------
-TKZ_KERNEL(256) void k_giant_find(const uint8_t* heavy_flag, int64_t nsub, const uint64_t* startbits, int64_t nwords, int64_t total,
-                                  int64_t* gq, unsigned long long* gcount, int64_t gcap) {
-    // only a sub-tile k_probe flagged can hold the start of a giant piece, and only its LAST piece start can be one
-    // (a giant piece reaches past the end of its sub-tile)
-    const int64_t stride = simt::nblocks() * simt::nthreads();
-    for (int64_t t = simt::bid() * simt::nthreads() + simt::tid(); t < nsub; t += stride) {
-        if (!(heavy_flag[t] & 2u)) continue;
-        int64_t p = -1;
-        for (int k = kSub / 64 - 1; k >= 0 && p < 0; --k) {
-            const int64_t w = t * (kSub / 64) + k;
-            const uint64_t m = w < nwords ? startbits[w] : 0;
-            if (m) p = (w << 6) + tkz_msb64(m);
-        }
-        if (p < 0 || p >= total) continue;                   // (no piece starts here / the sentinel)
-        int64_t next = total;
-        for (int64_t v = (t + 1) * (kSub / 64); v < nwords; ++v) {
-            const uint64_t x = startbits[v];
-            if (x) { next = (v << 6) + tkz_ctz64(x); break; }
-        }
-        if (next - p > kArenaPiece) {
-            const unsigned long long q = simt::atomic_add64(gcount, 1ull);
-            if ((int64_t)q < gcap) { gq[2 * q] = p; gq[2 * q + 1] = next - p; }
-        }
+// only a sub-tile k_probe flagged can hold the start of a giant piece, and only its LAST piece start can be one (a giant piece reaches past the
+// end of its sub-tile): sub-tile t's, queued with its length (k_list_stats calls this for the flagged sub-tiles)
+TKZ_DEV void tkz_giant_find_one(int64_t t, const uint64_t* startbits, int64_t nwords, int64_t total, int64_t* gq, unsigned long long* gcount, int64_t gcap) {
+    int64_t p = -1;
+    for (int k = kSub / 64 - 1; k >= 0 && p < 0; --k) {
+        const int64_t w = t * (kSub / 64) + k;
+        const uint64_t m = w < nwords ? startbits[w] : 0;
+        if (m) p = (w << 6) + tkz_msb64(m);
+    }
+    if (p < 0 || p >= total) return;                         // (no piece starts here / the sentinel)
+    int64_t next = total;
+    for (int64_t v = (t + 1) * (kSub / 64); v < nwords; ++v) {
+        const uint64_t x = startbits[v];
+        if (x) { next = (v << 6) + tkz_ctz64(x); break; }
+    }
+    if (next - p > kArenaPiece) {
+        const unsigned long long q = simt::atomic_add64(gcount, 1ull);
+        if ((int64_t)q < gcap) { gq[2 * q] = p; gq[2 * q + 1] = next - p; }
     }
 }
 // The order the giant pieces are taken in: longest first (a diverse piece of tens of KiB is merged in thousands of rounds and sets the
@@ -1873,9 +1877,48 @@ TKZ_KERNEL(256) void k_doccount(const uint64_t* docbits, int64_t nwords, int64_t
     }
 }
 
+// the same for TWO bitmaps in one pass (document starts and piece starts: one launch instead of two, the words of both read by the same lane)
+TKZ_KERNEL(256) void k_doccount2(const uint64_t* bits_a, const uint64_t* bits_b, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt_a, int32_t* cnt_b) {
+    static_assert(kSub / 64 == 16, "k_doccount2 sums 16 lanes per sub-tile");
+    const int lane = simt::lane();
+    const int64_t stride = simt::nblocks() * simt::nthreads(), nw = nsub * (kSub / 64);
+    for (int64_t w0 = simt::bid() * simt::nthreads() + (simt::tid() & ~63); w0 < nw; w0 += stride) {
+        const int64_t w = w0 + lane;
+        uint64_t ma = (w < nw && w < nwords) ? bits_a[w] : 0ull, mb = (w < nw && w < nwords) ? bits_b[w] : 0ull;
+        const int64_t lim = total - (w << 6);              // (the sentinel bit at `total` is not a start)
+        if (lim <= 0) { ma = 0; mb = 0; } else if (lim < 64) { ma &= tkz_lowmask((int)lim); mb &= tkz_lowmask((int)lim); }
+        int c = tkz_popc64(ma) | (tkz_popc64(mb) << 16);  // (at most 1024 of either in a sub-tile: the two sums share the shuffles)
+        c += simt::shfl_xor(c, 1); c += simt::shfl_xor(c, 2); c += simt::shfl_xor(c, 4); c += simt::shfl_xor(c, 8);
+        if ((lane & 15) == 0 && w < nw) { cnt_a[w >> 4] = c & 0xFFFF; cnt_b[w >> 4] = c >> 16; }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // exclusive scan of tile_count (int32) -> tile_base (int64); counters[2..3] (int64) = grand total
 // -------------------------------------------------------------------------------------------------
+// Up to kScanSmallMax sub-tiles (64 MB of text): ONE workgroup, one launch -- a thread owns n / 1024 consecutive counts, one workgroup scan of the
+// threads' sums -- for one or two arrays at once; the three-kernel form below (partials, top, final) costs three dependent launches per array, and a
+// batch of a few megabytes is made of little else than launches.
+constexpr int kScanSmallMax = 65536;
+TKZ_KERNEL(1024) void k_scan_small(const int32_t* cnt_a, int64_t* base_a, int64_t* grand_a, int round_a,
+                                   const int32_t* cnt_b, int64_t* base_b, int64_t* grand_b, int round_b, int n) {
+    const int tid = simt::tid(), nth = simt::nthreads();
+    const int per = (n + nth - 1) / nth, lo = tid * per, hi = lo + per < n ? lo + per : n;
+    for (int arr = 0; arr < 2; ++arr) {
+        const int32_t* cnt = arr ? cnt_b : cnt_a;
+        int64_t* base = arr ? base_b : base_a;
+        int64_t* grand = arr ? grand_b : grand_a;
+        const int round = arr ? round_b : round_a;
+        if (!cnt) continue;                                   // (workgroup-uniform)
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += (cnt[i] + round) & ~round;
+        int tot;
+        int run = tkz_block_scan(sum, &tot);                  // (<= 1024 per sub-tile, <= 65536 sub-tiles: 2^26 at most)
+        for (int i = lo; i < hi; ++i) { base[i] = run; run += (cnt[i] + round) & ~round; }
+        if (tid == 0 && grand) *grand = tot;
+        simt::sync();
+    }
+}
 // (`round`: every count is rounded up to a multiple of round + 1 first -- the piece records of a sub-tile are whole 64-byte lines)
 TKZ_KERNEL(256) void k_scan_partials(const int32_t* cnt, int64_t n, int64_t* bsum, int round) {
     TKZ_SHARED int64_t s_w[4];
@@ -1929,9 +1972,17 @@ TKZ_KERNEL(256) void k_scan_final(const int32_t* cnt, int64_t n, const int64_t* 
 // -------------------------------------------------------------------------------------------------
 // k_docoffs
 // -------------------------------------------------------------------------------------------------
+// (c3a / c3b / c3c: null, or blocks that receive {c3_docs, total, *grand} -- the batch's counts, k_counts3's job, by the first thread: one launch less)
 TKZ_KERNEL(256) void k_docoffs(const int64_t* offs, int64_t n_docs, int64_t total, const int64_t* tile_base, const uint64_t* docbits,
-                               const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs) {
+                               const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs,
+                               int64_t c3_docs, int64_t* c3a, int64_t* c3b, int64_t* c3c) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
+    if (simt::bid() == 0 && simt::tid() == 0) {
+        const int64_t g = *grand;
+        if (c3a) { c3a[0] = c3_docs; c3a[1] = total; c3a[2] = g; }
+        if (c3b) { c3b[0] = c3_docs; c3b[1] = total; c3b[2] = g; }
+        if (c3c) { c3c[0] = c3_docs; c3c[1] = total; c3c[2] = g; }
+    }
     for (int64_t d = simt::bid() * simt::nthreads() + simt::tid(); d <= n_docs; d += stride) {
         const int64_t pos = offs[d];
         if (pos >= total) { out_offs[d] = *grand; continue; }
@@ -1955,14 +2006,40 @@ TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
 //   counters[0] |= kErrMissCap, counters[1] = the longest list, when some list did not fit mcap (the host grows the lists and runs the batch again);
 //   counters[2] = the longest list above kMissCapMin that did fit (the host lets grown lists shrink again by it);
 //   counters[3] = how many sub-tiles hold more than 64 entries (the host picks k_place's form for the workspace's next batch by it).
-TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t mcap, int32_t* counters) {
+// (... and, in the same pass over the sub-tiles, k_giant_find's: a sub-tile k_probe flagged as holding a giant piece queues it -- one launch less)
+TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t mcap, int32_t* counters,
+                                  const uint8_t* heavy_flag, const uint64_t* startbits, int64_t nwords, int64_t total, int64_t* gq, unsigned long long* gcount, int64_t gcap,
+                                  const uint32_t* mlist, uint64_t* coop_q, unsigned long long* coop_count, int64_t coop_cap) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
+    const int lane = simt::lane();
     int mx = 0, big = 0, over = 0;
-    for (int64_t i = simt::bid() * simt::nthreads() + simt::tid(); i < nsub; i += stride) {
-        const uint32_t m = mcount[i];
+    for (int64_t i0 = simt::bid() * simt::nthreads() + (simt::tid() & ~63); i0 < nsub; i0 += stride) {      // (wave-uniform: the queueing below is a wave scan)
+        const int64_t i = i0 + lane;
+        const bool in = i < nsub;
+        const uint32_t m = in ? mcount[i] : 0u;
         const int n = (int)(m & 0xFFFFu) + (int)(m >> 16);
         if (n <= mcap) { if (n > mx) mx = n; } else if (n > big) big = n;
         over += n > 64 ? 1 : 0;
+        const uint32_t hf = in ? heavy_flag[i] : 0u;
+        if (hf & 2u) tkz_giant_find_one(i, startbits, nwords, total, gq, gcount, gcap);
+        // the long misses of more than kLanePiece bytes (k_probe flagged their sub-tiles: bit 2) are queued for k_merge_coop: sub-tile << 10 | index in
+        // its long list.  One atomic per wavefront of 64 sub-tiles, not per piece.
+        if (simt::ballot((hf & 4u) != 0)) {
+            const int nl = (int)(m >> 16);
+            int mine = 0;
+            if ((hf & 4u) && n <= mcap)
+                for (int j = 0; j < nl; ++j) mine += ((int)((mlist[i * (int64_t)mcap + (mcap - 1 - j)] >> kMrLenShift) & 1023u) + 1 > kLanePiece) ? 1 : 0;
+            int tot;
+            const int pre = tkz_wave_scan_sum(mine, &tot);
+            unsigned long long base = 0;
+            if (lane == 0 && tot) base = simt::atomic_add64(coop_count, (unsigned long long)tot);
+            base = ((unsigned long long)simt::shflu((uint32_t)(base >> 32), 0) << 32) | simt::shflu((uint32_t)base, 0);
+            if (mine) {
+                unsigned long long at = base + (unsigned long long)pre;
+                for (int j = 0; j < nl; ++j)
+                    if ((int)((mlist[i * (int64_t)mcap + (mcap - 1 - j)] >> kMrLenShift) & 1023u) + 1 > kLanePiece) { if ((int64_t)at < coop_cap) coop_q[at] = ((uint64_t)i << 10) | (uint64_t)j; ++at; }
+            }
+        }
     }
     int tot;
     (void)tkz_wave_scan_sum(over, &tot);
@@ -2514,13 +2591,15 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     hook(L, K_ENCODE, 0);
     TKZ_LAUNCH(k_probe, xcd_grid(cdiv(nsub, (kThreads / 64) * kProbePer)), kThreads, L.stream, T, P);
     hook(L, K_ENCODE, 1);
-    { const int64_t g = grid_for(nsub); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsub, P.mcap, P.counters); }
+    // (the list statistics and, in the same pass, the giant pieces of the sub-tiles k_probe flagged: queued for k_giant_order / k_giant_merge)
+    { const int64_t g = grid_for(nsub); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsub, P.mcap, P.counters,
+                                                     (const uint8_t*)P.heavy_flag, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap,
+                                                     (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap); }
     hook(L, K_MERGE_SHORT, 0);
     TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
     hook(L, K_MERGE_SHORT, 1);
     hook(L, K_HEAVY, 0);
-    // giant pieces start in sub-tiles k_probe has flagged: find them, merge them; then the pieces of 17..1024 bytes and the giants' token counts
-    TKZ_LAUNCH(k_giant_find, grid_for(nsub), kThreads, L.stream, (const uint8_t*)P.heavy_flag, nsub, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap);
+    // giant pieces (queued by k_list_stats): ordered, merged; then the pieces of 17..1024 bytes and the giants' token counts
 #ifdef TKZ_HOSTEMU
     constexpr int kGiantGrid = 2;       // (the CPU emulator pays for every thread of an idle workgroup)
 #else
@@ -2529,10 +2608,12 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     TKZ_LAUNCH(k_giant_order, 1, 1024, L.stream, P);
     TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // takes pieces off the ordered queue; exits at once when it is empty
     {   // strides over 64-sub-tile chunks
-        const int64_t chunks = cdiv(nsub, 64), grid = chunks < 16384 ? chunks : 16384;
+        const int64_t chunks = cdiv(nsub, kLongChunk), grid = chunks < 65536 ? chunks : 65536;
         if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH(k_merge_long<true>, grid, 64, L.stream, T, P);
         else TKZ_LAUNCH(k_merge_long<false>, grid, 64, L.stream, T, P);
-        TKZ_LAUNCH(k_merge_coop, chunks < 2048 ? chunks : 2048, 64, L.stream, T, P);      // the pieces k_merge_long left to a whole wavefront (it exits at once when no chunk is flagged)
+        // the pieces k_merge_long leaves to a whole wavefront, off the queue k_list_stats filled (every wavefront exits at once when it is empty)
+        const int64_t cgrid = cdiv(nsub, 64);
+        TKZ_LAUNCH(k_merge_coop, cgrid < kCoopGrid ? cgrid : kCoopGrid, 64, L.stream, T, P);
     }
     hook(L, K_HEAVY, 1);
 }
@@ -2554,6 +2635,20 @@ void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_ba
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt) {
     TKZ_LAUNCH(k_doccount, grid_for(nsub * (kSub / 64)), kThreads, L.stream, docbits, nwords, total, nsub, cnt);
 }
+void launch_doccount2(const Launch& L, const uint64_t* bits_a, const uint64_t* bits_b, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt_a, int32_t* cnt_b) {
+    TKZ_LAUNCH(k_doccount2, grid_for(nsub * (kSub / 64)), kThreads, L.stream, bits_a, bits_b, nwords, total, nsub, cnt_a, cnt_b);
+}
+void launch_scan2(const Launch& L, int64_t ntiles, int64_t* bsum, const int32_t* cnt_a, int64_t* base_a, int64_t* grand_a, int round_to_a,
+                  const int32_t* cnt_b, int64_t* base_b, int64_t* grand_b, int round_to_b, int kid) {
+    if (ntiles <= kScanSmallMax) {
+        if (kid >= 0) hook(L, kid, 0);
+        TKZ_LAUNCH(k_scan_small, 1, 1024, L.stream, cnt_a, base_a, grand_a, round_to_a > 1 ? round_to_a - 1 : 0, cnt_b, base_b, grand_b, round_to_b > 1 ? round_to_b - 1 : 0, (int)ntiles);
+        if (kid >= 0) hook(L, kid, 1);
+        return;
+    }
+    launch_scan(L, cnt_a, ntiles, bsum, base_a, grand_a, kid, round_to_a);
+    if (cnt_b) launch_scan(L, cnt_b, ntiles, bsum, base_b, grand_b, kid, round_to_b);
+}
 void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid, int round_to) {
     const int64_t nblk = cdiv(ntiles, kScanBlock);
     const int round = round_to > 1 ? round_to - 1 : 0;       // (round_to: a power of two)
@@ -2564,9 +2659,10 @@ void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int
     if (kid >= 0) hook(L, kid, 1);
 }
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
-                    const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs) {
+                    const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs,
+                    int64_t c3_docs, int64_t* c3a, int64_t* c3b, int64_t* c3c) {
     hook(L, K_DOCOFFS, 0);
-    TKZ_LAUNCH(k_docoffs, grid_for(n_docs + 1), kThreads, L.stream, d_offs, n_docs, total, tile_base, docbits, docord_base, doc_tok, grand, out_offs);
+    TKZ_LAUNCH(k_docoffs, grid_for(n_docs + 1), kThreads, L.stream, d_offs, n_docs, total, tile_base, docbits, docord_base, doc_tok, grand, out_offs, c3_docs, c3a, c3b, c3c);
     hook(L, K_DOCOFFS, 1);
 }
 void launch_rebase(const Launch& L, int64_t* offs, int64_t n, int64_t base) {

@@ -91,6 +91,8 @@ TKZ_DEV uint4 tkz_load16_nt(const void* p) {
     uint4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
 }
 TKZ_DEV uint32_t tkz_load_nt(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+// a word other workgroups -- on other XCDs, whose L2 is not this one's -- update with device-scope atomics: read where those atomics are performed
+TKZ_DEV uint32_t tkz_atomic_load_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 TKZ_DEV int32_t tkz_load_nt(const int32_t* p) { return __builtin_nontemporal_load(p); }
 TKZ_DEV void tkz_store_nt(int32_t* p, int32_t v) { __builtin_nontemporal_store(v, p); }
 TKZ_DEV void tkz_store16_nt(void* p, uint4 v) {

@@ -106,10 +106,11 @@ constexpr uint32_t kMemoWays = TKZ_MEMO_WAYS;
 constexpr uint32_t kPromoFlag = 1u << 26, kPromoIdxMask = (1u << 22) - 1u;
 constexpr int kPromoCntShift = 22;
 constexpr uint32_t kPromoMaxEntries = 1u << 22;
+constexpr uint32_t kMemoHitsSat = 64;          // a learning batch counts a slot's (sampled) hits up to here
 
 struct TkzTables {      // device pointers + sizes, passed to kernels by value
     TkzMemoSlot* memo; uint32_t memo_n;                                          // piece memo (null / 0: none)
-    uint32_t* memo_hits;                                                         // null, or (a LEARNING batch) memo_n counters: hits per slot, sampled (k_merge_short)
+    uint32_t* memo_hits; uint32_t memo_hits_sparse;                              // null, or (a LEARNING batch) memo_n counters: hits per slot (k_merge_short); sparse: sampled, one hit in 512
     const uint4* promo; uint32_t promo_n;                                        // token quads of the promoted pieces (null / 0: none)
     const TkzShortSlot* short_slots; uint32_t short_nb; uint32_t short_seed;    // short_nb buckets of two slots
     const TkzMidSlot* mid_slots;     uint32_t mid_ns;   uint32_t mid_seed;      // mid_ns slots
