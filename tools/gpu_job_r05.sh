@@ -46,6 +46,18 @@ d=json.load(open(sys.argv[1])); print(sys.argv[2], d["value"], d["ms_per_step"],
 P
   done
   lap "variants"; cat $O/variants.txt
+  if [ -n "${VARGS2:-}" ]; then
+    rm -f $O/variants2.txt
+    for v in ${VARIANTS:-lib}; do
+      [ -f tokenizer_amd/$v/libtkz.so ] || continue
+      TKZ_LIBTKZ=$REPO/tokenizer_amd/$v/libtkz.so timeout 600 python bench.py --no-cpu-baseline --steps 4 --warmup 1 --pipelined-steps 0 --no-memo-steps 0 --real-text-mb 0 --heldout-steps 0 ${VARGS2} > $O/b2_$v.json 2>> $O/variants.err
+      python - $O/b2_$v.json $v >> $O/variants2.txt <<'P'
+import json,sys
+d=json.load(open(sys.argv[1])); print(sys.argv[2], d["value"], d["ms_per_step"], d["roofline"]["kernels_ms"])
+P
+    done
+    lap "variants2"; cat $O/variants2.txt
+  fi
 fi
 if has shapes; then
   rm -f $O/bench_shapes.jsonl
