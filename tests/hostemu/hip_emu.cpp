@@ -6,6 +6,8 @@
 #include <sys/mman.h>
 
 #include <chrono>
+#include <map>
+#include <mutex>
 
 #if !defined(__x86_64__)
 #error "the SIMT emulator's context switch is written for x86-64"
@@ -136,8 +138,21 @@ hipError_t hipMalloc(void** p, size_t n) {
     *p = q; return hipSuccess;
 }
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
-hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+namespace { std::mutex g_pin_mu; std::map<uintptr_t, size_t> g_pinned; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) {
+    const hipError_t r = hipMalloc(p, n);
+    if (r == hipSuccess) { std::lock_guard<std::mutex> lock(g_pin_mu); g_pinned[reinterpret_cast<uintptr_t>(*p)] = n; }
+    return r;
+}
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
+    std::lock_guard<std::mutex> lock(g_pin_mu);
+    const uintptr_t x = reinterpret_cast<uintptr_t>(p);
+    auto it = g_pinned.upper_bound(x);
+    if (it != g_pinned.begin()) { --it; if (x < it->first + it->second) { a->type = hipMemoryTypeHost; return hipSuccess; } }
+    return hipErrorInvalidValue;
+}
+hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+hipError_t hipHostFree(void* p) { { std::lock_guard<std::mutex> lock(g_pin_mu); g_pinned.erase(reinterpret_cast<uintptr_t>(p)); } free(p); return hipSuccess; }
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }

@@ -36,6 +36,10 @@ hipError_t hipMalloc(void** p, size_t n);
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t n, unsigned flags = 0);
 hipError_t hipHostFree(void* p);
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; };
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p);     // (memory from hipHostMalloc: host; anything else: an error, as for pageable memory)
+hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned flags);
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);

@@ -111,8 +111,10 @@ struct Workspace {
     bool learning = false;                 // this workspace's batch counts memo hits per slot (TkzTables::memo_hits): the encoder promotes the hottest entries when it ends
     // staging for the host-buffer entry points (two sets: chunk k+1 is uploaded while chunk k is encoded and chunk k-1 downloaded)
     DevBuf s_bytes[2], s_offs[2], s_out[2], s_outoffs[2];
-    // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths, the UTF-8 batch they become
-    DevBuf u_units, u_offs, u_docbits, u_grp, u_tsum, u_tbase, u_bsum, u_counters, u_bytes, u_boffs;
+    // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths (two sets: the units of chunk k+1 are uploaded and
+    // measured while chunk k is encoded), the UTF-8 batch they become
+    struct U16Stage { DevBuf units, offs, docbits, grp, tsum, tbase, bsum, counters, boffs; struct Host { int32_t err; int32_t pad; int64_t grand; }* h = nullptr; } u16[2];
+    DevBuf u_bytes;
     // Decode
     DevBuf d_grp, d_tsum, d_tbase, d_bsum, d_counters, d_ids, d_idoffs, d_out, d_outoffs;
     // piece-granular entry point: piece byte offsets, token offsets, first piece of every document
@@ -135,10 +137,13 @@ struct Workspace {
     void release_all() {
         DevBuf* bufs[] = {&w_counts3, &w_mlist, &w_mquad, &w_mcount, &w_pextra, &w_coopq, &w_gq, &w_gcnt, &w_xq, &w_zero, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
                           &w_doctok, &w_dcount, &w_dbase, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
-                          &s_outoffs[0], &s_outoffs[1], &u_units, &u_offs, &u_docbits, &u_grp, &u_tsum, &u_tbase, &u_bsum, &u_counters, &u_bytes, &u_boffs,
+                          &s_outoffs[0], &s_outoffs[1], &u_bytes,
+                          &u16[0].units, &u16[0].offs, &u16[0].docbits, &u16[0].grp, &u16[0].tsum, &u16[0].tbase, &u16[0].bsum, &u16[0].counters, &u16[0].boffs,
+                          &u16[1].units, &u16[1].offs, &u16[1].docbits, &u16[1].grp, &u16[1].tsum, &u16[1].tbase, &u16[1].bsum, &u16[1].counters, &u16[1].boffs,
                           &d_grp, &d_tsum, &d_tbase, &d_bsum, &d_counters, &d_ids, &d_idoffs, &d_out, &d_outoffs, &p_boffs, &p_toffs, &p_docp};
         for (DevBuf* b : bufs) b->release();
         if (h_counters) (void)hipHostFree(h_counters);
+        for (int q = 0; q < 2; ++q) if (u16[q].h) (void)hipHostFree(u16[q].h);
         if (h_small) (void)hipHostFree(h_small);
         if (st_small) (void)hipStreamDestroy(st_small);
         for (int k = 0; k < tkz::K_COUNT; ++k) for (int q = 0; q < 2; ++q) if (ev[k][q]) (void)hipEventDestroy(ev[k][q]);
@@ -760,25 +765,51 @@ hipError_t ensure_streams(Workspace* ws) {
     return r;
 }
 
-// host buffers -> staging -> device path -> back.  A large batch is cut into document ranges (chunks): the upload of chunk k+1
-// (stream st_in), the kernels of chunk k (st_compute) and the download of chunk k-1 (st_out) run at the same time -- PCIe is full
-// duplex and the kernels need a fifth of a transfer's time -- on two sets of staging buffers.  (The copies are asynchronous for
-// page-locked caller buffers; for pageable ones the HIP runtime stages them itself and overlaps what it can.)
-tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const int64_t* offs, int64_t n_docs, int32_t* out_ids,
+// Is p page-locked host memory the device can address (tkz_host_alloc, hipHostMalloc, a torch pinned tensor)?  *dev: its device-side address.
+bool pinned_host(const void* p, void** dev) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // (pageable memory: an error by design)
+    if (a.type != hipMemoryTypeHost) return false;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, const_cast<void*>(p), 0) != hipSuccess || !d) { (void)hipGetLastError(); return false; }
+    *dev = d;
+    return true;
+}
+
+// host buffers -> staging -> device path -> back, for documents given as UTF-8 bytes (`bytes`) or as UTF-16 code units (`units`: uploaded as they are,
+// Encoding.UTF8.GetBytes -- TikTokenizer.cs:261 -- runs on the device; offsets in units then).
+//  * at most 128 KiB of UTF-8: the single-launch kernel (encode_small);
+//  * a batch whose upload is below 1.5 chunks (a chunk: 16 MB): one launch sequence.  From page-locked caller buffers the inputs are copied
+//    asynchronously and the ids and offsets are written by the kernels STRAIGHT into the caller's memory (k_place / k_docoffs store whole lines over
+//    PCIe): no download commands, one synchronisation;
+//  * larger: document ranges of ~16 MB of upload, pipelined on three streams -- the upload of chunk k+1 (and, for UTF-16, its length pass), the kernels
+//    of chunk k and the download of chunk k-1 run at the same time; PCIe is full duplex and the kernels need a fraction of a transfer's time.
+//    (48 MB chunks from 96 MB up until round 5: a 64 MB batch was one chunk, upload, kernels and download one after the other.)
+tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* units, const int64_t* offs, int64_t n_docs, int32_t* out_ids,
                        int64_t out_cap, int64_t* out_offsets, int64_t* needed, bool pretok, uint64_t* bitmap) {
+    using namespace tkz;
     DeviceScope scope;
     tkz_status st = check_encoder(e, scope);
     if (st != TKZ_OK) return st;
-    if (n_docs < 0 || !offs || (n_docs > 0 && !bytes && offs[n_docs] > 0)) return fail(TKZ_E_ARG, "null buffer");
+    const bool u16 = units != nullptr;
+    if (n_docs < 0 || !offs || (n_docs > 0 && !bytes && !units && offs[n_docs] > 0)) return fail(TKZ_E_ARG, "null buffer");
     if (offs[0] != 0) return fail(TKZ_E_ARG, "doc_offsets[0] must be 0");
-    const int64_t total = offs[n_docs];
-    if (total < 0) return fail(TKZ_E_ARG, "negative byte count");
+    const int64_t total = offs[n_docs];                      // bytes, or code units
+    if (total < 0) return fail(TKZ_E_ARG, u16 ? "negative unit count" : "negative byte count");
+    if (needed) *needed = 0;
+    if (u16 && total == 0) {
+        for (int64_t d = 0; d <= n_docs; ++d) { if (offs[d] != 0) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count"); out_offsets[d] = 0; }
+        return TKZ_OK;
+    }
     Lease lease(e);
     Workspace* ws = lease.ws;
     int64_t* acc = &ws->bytes_allocated;
+    const int64_t unit = u16 ? 2 : 1;
     // ($TKZ_HOST_CHUNK_BYTES: test knob, so that the CPU-emulated tests can exercise the pipeline on kilobytes)
-    static const int64_t kChunkBytes = [] { const char* v = getenv("TKZ_HOST_CHUNK_BYTES"); const long long n = v ? atoll(v) : 0; return n > 0 ? (int64_t)n : (int64_t(48) << 20); }();
-    int64_t nchunks = (bitmap || !pretok || total < 2 * kChunkBytes) ? 1 : std::min<int64_t>(64, (total + kChunkBytes - 1) / kChunkBytes);
+    static const int64_t kChunkBytes = [] { const char* v = getenv("TKZ_HOST_CHUNK_BYTES"); const long long n = v ? atoll(v) : 0; return n > 0 ? (int64_t)n : (int64_t(16) << 20); }();
+    const int64_t up_bytes = total * unit;
+    int64_t nchunks = (bitmap || !pretok || 2 * up_bytes < 3 * kChunkBytes) ? 1 : std::min<int64_t>(1024, std::max<int64_t>(2, (up_bytes + kChunkBytes / 2) / kChunkBytes));
     // chunk boundaries on documents: chunk k = documents [cut[k], cut[k+1]).  Offsets that are not monotone cannot be cut: the
     // whole batch then goes as one chunk and the device reports them (k_docmark)
     std::vector<int64_t> cut((size_t)nchunks + 1, 0);
@@ -789,12 +820,17 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const int64_t* offs
         if (cut[(size_t)k] < cut[(size_t)k - 1] || offs[cut[(size_t)k]] < offs[cut[(size_t)k - 1]]) { nchunks = 1; break; }
     }
     if (nchunks == 1) { cut.assign(2, 0); cut[1] = n_docs; }
-    if (nchunks == 1 && pretok && !bitmap && small_eligible(e, offs, n_docs, total)) {
+    if (!u16 && nchunks == 1 && pretok && !bitmap && small_eligible(e, offs, n_docs, total)) {
         bool handled = false;
         st = encode_small(e, ws, bytes, offs, n_docs, total, out_ids, out_cap, out_offsets, needed, &handled);
         if (st != TKZ_OK || handled) return st;
     }
-    if (nchunks == 1) {
+    // page-locked caller buffers?  (a single chunk then needs no staging for its results; the copies of every path are asynchronous)
+    void *dv_in = nullptr, *dv_offs = nullptr, *dv_ids = nullptr, *dv_ooffs = nullptr;
+    const bool pin_in = pinned_host(u16 ? (const void*)units : (const void*)bytes, &dv_in) && pinned_host(offs, &dv_offs);
+    const bool pin_out = !bitmap && pinned_host(out_offsets, &dv_ooffs) && (out_cap == 0 || pinned_host(out_ids, &dv_ids));
+    if (!u16 && nchunks == 1 && !(pin_in && pin_out && pretok && !bitmap && total > 0)) {
+        // ---- one chunk, ordinary (pageable) buffers: blocking copies either side of the launch sequence ----
         HIP_TRY(ws->s_bytes[0].ensure((size_t)total + 64, acc));
         HIP_TRY(ws->s_offs[0].ensure((size_t)(n_docs + 1) * 8, acc));
         const int64_t cap = bitmap ? 0 : std::min<int64_t>(out_cap, total);   // tokens <= bytes: more capacity is never used
@@ -819,48 +855,98 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const int64_t* offs
         HIP_TRY(hipMemcpy(out_offsets, ws->s_outoffs[0].p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
         return TKZ_OK;
     }
-    // ---- pipelined chunks ----
+    // ---- chunks on three streams (a single chunk is the loop's one iteration) ----
     HIP_TRY(ensure_streams(ws));
-    int64_t max_bytes = 0, max_docs = 0;
+    const bool direct_out = nchunks == 1 && pin_out;          // the kernels write the caller's page-locked ids and offsets themselves
+    int64_t max_units = 0, max_docs = 0;
     for (int64_t k = 0; k < nchunks; ++k) {
-        max_bytes = std::max(max_bytes, offs[cut[(size_t)k + 1]] - offs[cut[(size_t)k]]);
+        max_units = std::max(max_units, offs[cut[(size_t)k + 1]] - offs[cut[(size_t)k]]);
         max_docs = std::max(max_docs, cut[(size_t)k + 1] - cut[(size_t)k]);
     }
-    for (int q = 0; q < 2; ++q) {
-        HIP_TRY(ws->s_bytes[q].ensure((size_t)max_bytes + 64, acc));
-        HIP_TRY(ws->s_offs[q].ensure((size_t)(max_docs + 1) * 8, acc));
-        HIP_TRY(ws->s_out[q].ensure((size_t)std::max<int64_t>(max_bytes, 1) * 4, acc));
-        HIP_TRY(ws->s_outoffs[q].ensure((size_t)(max_docs + 1) * 8, acc));
+    for (int q = 0; q < (nchunks > 1 ? 2 : 1); ++q) {
+        if (u16) {
+            Workspace::U16Stage& U = ws->u16[q];
+            const int64_t nw = max_units / 64 + 1, nt = u16_tiles(max_units), nblk = (nt + kScanBlock - 1) / kScanBlock;
+            HIP_TRY(U.units.ensure((size_t)(max_units + 64) * 2, acc));
+            HIP_TRY(U.offs.ensure((size_t)(max_docs + 1) * 8, acc));
+            HIP_TRY(U.docbits.ensure((size_t)(nw + 8) * 8, acc));
+            HIP_TRY(U.grp.ensure((size_t)nt * 64 * 4, acc));
+            HIP_TRY(U.tsum.ensure((size_t)nt * 4, acc));
+            HIP_TRY(U.tbase.ensure((size_t)nt * 8, acc));
+            HIP_TRY(U.bsum.ensure((size_t)(nblk + 1) * 8, acc));
+            HIP_TRY(U.counters.ensure(64, acc));
+            HIP_TRY(U.boffs.ensure((size_t)(max_docs + 1) * 8, acc));
+            if (!U.h) HIP_TRY(hipHostMalloc((void**)&U.h, 64, 0));
+        } else {
+            HIP_TRY(ws->s_bytes[q].ensure((size_t)max_units + 64, acc));
+            HIP_TRY(ws->s_offs[q].ensure((size_t)(max_docs + 1) * 8, acc));
+        }
+        if (!direct_out) {
+            HIP_TRY(ws->s_out[q].ensure((size_t)std::max<int64_t>(std::min<int64_t>(out_cap, (u16 ? 3 : 1) * max_units), 1) * 4, acc));      // (a token is at least one byte, a code unit at most three)
+            HIP_TRY(ws->s_outoffs[q].ensure((size_t)(max_docs + 1) * 8, acc));
+        }
     }
-    auto upload_chunk = [&](int64_t k) -> hipError_t {
+    // the input of chunk k, on its way to the device (stream st_in); for UTF-16 also its document marks, the UTF-8 length of every unit and their scan
+    auto stage_in = [&](int64_t k) -> tkz_status {
         const int q = (int)(k & 1);
-        const int64_t d0 = cut[(size_t)k], d1 = cut[(size_t)k + 1], b0 = offs[d0], nb = offs[d1] - b0;
-        hipError_t r = hipSuccess;
-        if (nb) r = hipMemcpyAsync(ws->s_bytes[q].p, bytes + b0, (size_t)nb, hipMemcpyHostToDevice, ws->st_in);
-        if (r == hipSuccess) r = hipMemcpyAsync(ws->s_offs[q].p, offs + d0, (size_t)(d1 - d0 + 1) * 8, hipMemcpyHostToDevice, ws->st_in);
-        if (r == hipSuccess) r = hipEventRecord(ws->ev_in[q], ws->st_in);
-        return r;
+        const int64_t d0 = cut[(size_t)k], d1 = cut[(size_t)k + 1], u0 = offs[d0], nu = offs[d1] - u0, nd = d1 - d0;
+        Launch L{ws->st_in, nullptr, ws};
+        if (u16) {
+            Workspace::U16Stage& U = ws->u16[q];
+            if (nu) HIP_TRY(hipMemcpyAsync(U.units.p, units + u0, (size_t)nu * 2, hipMemcpyHostToDevice, ws->st_in));
+            HIP_TRY(hipMemcpyAsync(U.offs.p, offs + d0, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, ws->st_in));
+            if (u0) launch_rebase(L, U.offs.as<int64_t>(), nd + 1, u0);
+            const int64_t nw = nu / 64 + 1, nt = u16_tiles(nu);
+            HIP_TRY(hipMemsetAsync(U.counters.p, 0, 64, ws->st_in));
+            HIP_TRY(hipMemsetAsync(U.docbits.p, 0, (size_t)(nw + 8) * 8, ws->st_in));
+            launch_docmark(L, U.offs.as<int64_t>(), nd, nu, U.docbits.as<uint64_t>(), U.counters.as<int32_t>());
+            launch_u16_len(L, U.units.as<uint16_t>(), nu, U.docbits.as<uint64_t>(), nt, U.grp.as<int32_t>(), U.tsum.as<int32_t>());
+            launch_scan(L, U.tsum.as<int32_t>(), nt, U.bsum.as<int64_t>(), U.tbase.as<int64_t>(), reinterpret_cast<int64_t*>(U.counters.as<char>() + 8), -1);
+            HIP_TRY(hipMemcpyAsync(U.h, U.counters.p, 16, hipMemcpyDeviceToHost, ws->st_in));
+        } else {
+            if (nu) HIP_TRY(hipMemcpyAsync(ws->s_bytes[q].p, bytes + u0, (size_t)nu, hipMemcpyHostToDevice, ws->st_in));
+            HIP_TRY(hipMemcpyAsync(ws->s_offs[q].p, offs + d0, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, ws->st_in));
+            if (u0) launch_rebase(L, ws->s_offs[q].as<int64_t>(), nd + 1, u0);
+        }
+        HIP_TRY(hipEventRecord(ws->ev_in[q], ws->st_in));
+        return TKZ_OK;
     };
     std::vector<int64_t> tok_base((size_t)nchunks + 1, 0);
     bool over = false;                                       // out_cap exceeded: the remaining chunks are only counted
     tkz_status first_err = TKZ_OK;
     std::string first_msg;
-    HIP_TRY(upload_chunk(0));
+    st = stage_in(0);
+    if (st != TKZ_OK) return st;
     for (int64_t k = 0; k < nchunks; ++k) {
         const int q = (int)(k & 1);
-        const int64_t d0 = cut[(size_t)k], d1 = cut[(size_t)k + 1], b0 = offs[d0], nb = offs[d1] - b0, nd = d1 - d0;
-        if (k + 1 < nchunks) HIP_TRY(upload_chunk(k + 1));                      // (its staging set was last read by the kernels of chunk k-1: done)
-        HIP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_in[q], 0));
+        const int64_t d0 = cut[(size_t)k], d1 = cut[(size_t)k + 1], nu = offs[d1] - offs[d0], nd = d1 - d0;
+        if (k + 1 < nchunks) { st = stage_in(k + 1); if (st != TKZ_OK) { first_err = st; first_msg = g_err; break; } }     // (its staging set was last read by the kernels of chunk k-1: done)
+        const uint8_t* cb; const int64_t* co; int64_t cbytes;
+        if (u16) {
+            // the UTF-8 size of the chunk is known once its length pass is through (the host needs it: the launch shapes of the encode path)
+            Workspace::U16Stage& U = ws->u16[q];
+            HIP_TRY(hipEventSynchronize(ws->ev_in[q]));
+            if (U.h->err & kErrOffsets) { first_err = fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count"); first_msg = g_err; break; }
+            cbytes = U.h->grand;
+            HIP_TRY(ws->u_bytes.ensure((size_t)cbytes + 64, acc));
+            Launch L{ws->st_compute, nullptr, ws};
+            launch_u16_write(L, U.units.as<uint16_t>(), nu, U.docbits.as<uint64_t>(), u16_tiles(nu), U.tbase.as<int64_t>(), ws->u_bytes.as<uint8_t>(),
+                             U.offs.as<int64_t>(), nd, U.grp.as<int32_t>(), reinterpret_cast<int64_t*>(U.counters.as<char>() + 8), U.boffs.as<int64_t>());
+            cb = ws->u_bytes.as<uint8_t>(); co = U.boffs.as<int64_t>();
+        } else {
+            HIP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_in[q], 0));
+            cb = ws->s_bytes[q].as<uint8_t>(); co = ws->s_offs[q].as<int64_t>(); cbytes = nu;
+        }
         if (k >= 2) HIP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_out[q], 0));   // the download of chunk k-2 has left this set's output buffers
-        { tkz::Launch L{ws->st_compute, nullptr, ws}; tkz::launch_rebase(L, ws->s_offs[q].as<int64_t>(), nd + 1, b0); }
-        const int64_t cap = over ? 0 : std::min<int64_t>(out_cap - tok_base[(size_t)k], nb);
+        int32_t* dst_ids = direct_out ? static_cast<int32_t*>(dv_ids) : ws->s_out[q].as<int32_t>();
+        int64_t* dst_offs = direct_out ? static_cast<int64_t*>(dv_ooffs) : ws->s_outoffs[q].as<int64_t>();
+        const int64_t cap = over ? 0 : (direct_out ? std::min<int64_t>(out_cap, cbytes) : std::min<int64_t>(out_cap - tok_base[(size_t)k], cbytes));
         int64_t tokens = 0;
-        st = encode_device(e, ws, ws->s_bytes[q].as<uint8_t>(), ws->s_offs[q].as<int64_t>(), nd, nb, ws->s_out[q].as<int32_t>(), cap,
-                           ws->s_outoffs[q].as<int64_t>(), ws->st_compute, true, nullptr, &tokens);      // (returns when st_compute has drained)
+        st = encode_device(e, ws, cb, co, nd, cbytes, dst_ids, cap, dst_offs, ws->st_compute, true, nullptr, &tokens);      // (returns when st_compute has drained)
         tok_base[(size_t)k + 1] = tok_base[(size_t)k] + tokens;
         if (st == TKZ_E_CAPACITY) { over = true; continue; }
         if (st != TKZ_OK) { first_err = st; first_msg = g_err; break; }
-        if (!over) {
+        if (!over && !direct_out) {
             if (tokens) HIP_TRY(hipMemcpyAsync(out_ids + tok_base[(size_t)k], ws->s_out[q].p, (size_t)tokens * 4, hipMemcpyDeviceToHost, ws->st_out));
             HIP_TRY(hipMemcpyAsync(out_offsets + d0, ws->s_outoffs[q].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, ws->st_out));
             HIP_TRY(hipEventRecord(ws->ev_out[q], ws->st_out));
@@ -1072,7 +1158,7 @@ void tkz_host_free(void* p) { if (p) (void)hipHostFree(p); }
 tkz_status tkz_encode_batch_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs,
                                  int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed) {
     if (!out_offsets || (out_cap > 0 && !out_ids)) return fail(TKZ_E_ARG, "null output buffer");
-    return encode_host(e, bytes, doc_offsets, n_docs, out_ids, out_cap, out_offsets, needed, true, nullptr);
+    return encode_host(e, bytes, nullptr, doc_offsets, n_docs, out_ids, out_cap, out_offsets, needed, true, nullptr);
 }
 
 tkz_status tkz_encode_batch_device(tkz_encoder* e, const uint8_t* d_bytes, const int64_t* d_doc_offsets, int64_t n_docs,
@@ -1160,7 +1246,7 @@ tkz_status tkz_encode_utf8(tkz_encoder* e, const uint8_t* text, int64_t len, int
     if (len < 0 || !n_out) return fail(TKZ_E_ARG, "bad argument");
     const int64_t offs[2] = {0, len};
     int64_t oo[2] = {0, 0}, needed = 0;
-    tkz_status st = encode_host(e, text, offs, 1, out_ids, out_cap, oo, &needed, true, nullptr);
+    tkz_status st = encode_host(e, text, nullptr, offs, 1, out_ids, out_cap, oo, &needed, true, nullptr);
     *n_out = needed;
     return st;
 }
@@ -1186,76 +1272,21 @@ tkz_status tkz_encode_utf16(tkz_encoder* e, const uint16_t* text, int64_t len, i
 
 tkz_status tkz_encode_batch_utf16(tkz_encoder* e, const uint16_t* units, const int64_t* unit_offsets, int64_t n_docs,
                                   int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed) {
-    using namespace tkz;
-    DeviceScope scope;
-    tkz_status st = check_encoder(e, scope);
-    if (st != TKZ_OK) return st;
     if (!out_offsets || (out_cap > 0 && !out_ids)) return fail(TKZ_E_ARG, "null output buffer");
     if (n_docs < 0 || !unit_offsets || (n_docs > 0 && !units && unit_offsets[n_docs] > 0)) return fail(TKZ_E_ARG, "null buffer");
-    if (unit_offsets[0] != 0) return fail(TKZ_E_ARG, "doc_offsets[0] must be 0");
-    const int64_t total_units = unit_offsets[n_docs];
-    if (total_units < 0) return fail(TKZ_E_ARG, "negative unit count");
-    if (needed) *needed = 0;
-    if (total_units == 0) {
-        for (int64_t d = 0; d <= n_docs; ++d) { if (unit_offsets[d] != 0) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count"); out_offsets[d] = 0; }
-        return TKZ_OK;
-    }
-    Lease lease(e);
-    Workspace* ws = lease.ws;
-    int64_t* acc = &ws->bytes_allocated;
-    hipStream_t stream = nullptr;
-    const int64_t nwords = total_units / 64 + 1, ntiles = u16_tiles(total_units), nblk = (ntiles + kScanBlock - 1) / kScanBlock;
-    HIP_TRY(ws->u_units.ensure((size_t)(total_units + 64) * 2, acc));
-    HIP_TRY(ws->u_offs.ensure((size_t)(n_docs + 1) * 8, acc));
-    HIP_TRY(ws->u_docbits.ensure((size_t)(nwords + 8) * 8, acc));
-    HIP_TRY(ws->u_grp.ensure((size_t)ntiles * 64 * 4, acc));
-    HIP_TRY(ws->u_tsum.ensure((size_t)ntiles * 4, acc));
-    HIP_TRY(ws->u_tbase.ensure((size_t)ntiles * 8, acc));
-    HIP_TRY(ws->u_bsum.ensure((size_t)(nblk + 1) * 8, acc));
-    HIP_TRY(ws->u_counters.ensure(64, acc));
-    HIP_TRY(ws->u_boffs.ensure((size_t)(n_docs + 1) * 8, acc));
-    HIP_TRY(hipMemcpy(ws->u_units.p, units, (size_t)total_units * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(ws->u_offs.p, unit_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice));
-    // 1. document marks over the code units, UTF-8 length of every unit, scan
-    Launch L{stream, nullptr, ws};
-    int32_t* counters = ws->u_counters.as<int32_t>();
-    int64_t* grand = reinterpret_cast<int64_t*>(ws->u_counters.as<char>() + 8);
-    HIP_TRY(hipMemsetAsync(counters, 0, 64, stream));
-    HIP_TRY(hipMemsetAsync(ws->u_docbits.p, 0, (size_t)(nwords + 8) * 8, stream));
-    launch_docmark(L, ws->u_offs.as<int64_t>(), n_docs, total_units, ws->u_docbits.as<uint64_t>(), counters);
-    launch_u16_len(L, ws->u_units.as<uint16_t>(), total_units, ws->u_docbits.as<uint64_t>(), ntiles, ws->u_grp.as<int32_t>(), ws->u_tsum.as<int32_t>());
-    launch_scan(L, ws->u_tsum.as<int32_t>(), ntiles, ws->u_bsum.as<int64_t>(), ws->u_tbase.as<int64_t>(), grand, -1);
-    struct { int32_t err; int32_t pad; int64_t grand; } h{};
-    HIP_TRY(hipMemcpy(&h, counters, sizeof h, hipMemcpyDeviceToHost));
-    HIP_TRY(hipGetLastError());
-    if (h.err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count");
-    const int64_t total = h.grand;                       // UTF-8 bytes of the batch
-    // 2. the UTF-8 batch, in HBM; 3. the same path as every other entry point
-    HIP_TRY(ws->u_bytes.ensure((size_t)total + 64, acc));
-    launch_u16_write(L, ws->u_units.as<uint16_t>(), total_units, ws->u_docbits.as<uint64_t>(), ntiles, ws->u_tbase.as<int64_t>(), ws->u_bytes.as<uint8_t>(),
-                     ws->u_offs.as<int64_t>(), n_docs, ws->u_grp.as<int32_t>(), grand, ws->u_boffs.as<int64_t>());
-    const int64_t cap = std::min<int64_t>(out_cap, total);
-    HIP_TRY(ws->s_out[0].ensure((size_t)std::max<int64_t>(cap, 1) * 4, acc));
-    HIP_TRY(ws->s_outoffs[0].ensure((size_t)(n_docs + 1) * 8, acc));
-    int64_t tokens = 0;
-    st = encode_device(e, ws, ws->u_bytes.as<uint8_t>(), ws->u_boffs.as<int64_t>(), n_docs, total, ws->s_out[0].as<int32_t>(), cap,
-                       ws->s_outoffs[0].as<int64_t>(), stream, true, nullptr, &tokens);
-    if (needed) *needed = tokens;
-    if (st != TKZ_OK) return st;
-    if (tokens) HIP_TRY(hipMemcpy(out_ids, ws->s_out[0].p, (size_t)tokens * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(out_offsets, ws->s_outoffs[0].p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
-    return TKZ_OK;
+    static const uint16_t none = 0;
+    return encode_host(e, nullptr, units ? units : &none, unit_offsets, n_docs, out_ids, out_cap, out_offsets, needed, true, nullptr);
 }
 
 tkz_status tkz_pretokenize_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs, uint64_t* out_bitmap_words) {
     if (!out_bitmap_words) return fail(TKZ_E_ARG, "null output buffer");
-    return encode_host(e, bytes, doc_offsets, n_docs, nullptr, 0, nullptr, nullptr, true, out_bitmap_words);
+    return encode_host(e, bytes, nullptr, doc_offsets, n_docs, nullptr, 0, nullptr, nullptr, true, out_bitmap_words);
 }
 
 tkz_status tkz_encode_pieces(tkz_encoder* e, const uint8_t* bytes, const int64_t* piece_offsets, int64_t n_pieces,
                              int32_t* out_ids, int64_t out_cap, int64_t* out_offsets, int64_t* needed) {
     if (!out_offsets || (out_cap > 0 && !out_ids)) return fail(TKZ_E_ARG, "null output buffer");
-    return encode_host(e, bytes, piece_offsets, n_pieces, out_ids, out_cap, out_offsets, needed, false, nullptr);
+    return encode_host(e, bytes, nullptr, piece_offsets, n_pieces, out_ids, out_cap, out_offsets, needed, false, nullptr);
 }
 
 tkz_status tkz_encode_batch_pieces_utf8(tkz_encoder* e, const uint8_t* bytes, const int64_t* doc_offsets, int64_t n_docs,

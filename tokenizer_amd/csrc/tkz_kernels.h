@@ -24,7 +24,7 @@ constexpr int kArenaDwords = TKZ_ARENA_DWORDS;  // LDS arena of k_merge_long: a 
                                     // vocabularies with ranks of 2^21 and more, which keep an ids[] array: tkz_bpe.h)
 constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are merged one per lane there (256 + tkz_bpe_var_dwords(1024) = 2336 <= kArenaDwords)
 #ifndef TKZ_LANE_PIECE
-#define TKZ_LANE_PIECE 256
+#define TKZ_LANE_PIECE 128
 #endif
 constexpr int kLanePiece = TKZ_LANE_PIECE;    // ... but a missed piece longer than this is merged by a whole wavefront (k_merge_coop): one lane takes ~n^2 steps, and the kernel waits for it
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)

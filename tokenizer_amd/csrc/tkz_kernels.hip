@@ -1189,15 +1189,20 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
 // over the whole piece and a piece of n bytes takes ~n/2 of them, so a 60-byte piece is ten times the work of a 17-byte one -- in list
 // order a batch took as long as its longest piece while the other lanes idled (33 % of the lanes active on CJK text).  Spans are padded to
 // an odd number of 16-byte quads: pieces of one class have equal spans, and with an even quad stride their 16-byte reads collide.
-// A chunk = kLongChunk consecutive sub-tiles, the unit a wavefront takes.  64 until round 5; REAL text showed what that costs: its long pieces are not
-// spread evenly -- one file of CJK prose is 64 KiB after 64 KiB of nothing but 100..250-byte pieces, ~10 ms of merging for the ONE wavefront that owns such a
-// chunk while the other 3,000 have long finished (k_merge_long 13 ms of a 17 ms step on 436 MB of source text; 0.3 ms of work).  16 sub-tiles: the tail is a
-// quarter as long, and mixed text (18 long misses per KiB) still fills its batches.
-#ifndef TKZ_LONG_CHUNK
-#define TKZ_LONG_CHUNK 16
+// A chunk = 64 consecutive sub-tiles (one per lane: their long-miss lists walked as one list).  Until round 5 a chunk was the unit of work a wavefront
+// takes; REAL text showed what that costs: its long pieces are not spread evenly -- one file of CJK prose is 64 KiB after 64 KiB of nothing but 100..250-byte
+// pieces, ~10 ms of merging for the ONE wavefront that owns such a chunk while the other 3,000 have long finished (k_merge_long 13 ms of a 17 ms step on
+// 436 MB of source text, for 0.3 ms of work).  Smaller chunks cut that tail and cost sparse text its lane fill (16 sub-tiles: the headline workload's one
+// long miss per KiB makes batches of 16 lanes instead of 64, k_merge_long 1.4 -> 3.7 ms).  So: a chunk whose lists hold more than kLongDense entries is
+// split into kLongParts units of work, a sparse one stays whole.
+#ifndef TKZ_LONG_PARTS
+#define TKZ_LONG_PARTS 4
 #endif
-constexpr int kLongChunk = TKZ_LONG_CHUNK;
-static_assert(kLongChunk >= 1 && kLongChunk <= 64, "one sub-tile of a chunk per lane");
+#ifndef TKZ_LONG_DENSE
+#define TKZ_LONG_DENSE 192
+#endif
+constexpr int kLongParts = TKZ_LONG_PARTS, kLongDense = TKZ_LONG_DENSE;
+static_assert(kLongParts >= 1 && kLongParts <= 64 && 64 % kLongParts == 0, "a part is a whole number of the chunk's 64 sub-tiles");
 constexpr int kLongSeg = 384;
 constexpr int kLenClasses = 16;
 TKZ_HD int tkz_len_class(int len) {          // 17..1024, monotone
@@ -1238,17 +1243,24 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
     const int lane = simt::lane();
     int err = 0;
     constexpr bool compact = COMPACT;                           // no ids[] array (tkz_bpe_lane_varc): 40 % more pieces per batch
-    for (int64_t c = c0; c * kLongChunk < P.nsub; c += cstep) {
-        const int64_t t = c * kLongChunk + lane;
+    // A unit of work = a chunk of 64 sub-tiles, or -- when the chunk's lists hold more than kLongDense entries -- one of its kLongParts parts
+    // (unit u = chunk u / kLongParts, part u % kLongParts; the parts of a sparse chunk other than part 0 have nothing to do).
+    for (int64_t u = c0; (u / kLongParts) * 64 < P.nsub; u += cstep) {
+        const int64_t c = u / kLongParts;
+        const int part = (int)(u % kLongParts);
+        const int64_t t = c * 64 + lane;
         int my_nl = 0;
-        if (lane < kLongChunk && t < P.nsub) {
+        if (t < P.nsub) {
             const uint32_t mc = P.mcount[t];
             my_nl = (int)(mc >> 16);
             if ((int)(mc & 0xFFFFu) + my_nl > P.mcap) my_nl = 0;               // (cut list: reported by k_probe, the batch is redone)
-            // the giant piece of the sub-tile (its last piece): merged by k_giant_merge, its token count is added here
-            if (P.heavy_flag[t] & 2u) { const int g = P.giant_cnt[t]; if (g > 1) simt::atomic_add(&P.tile_count[t], g - 1); }   // (< 0: no pool, the call is retried)
+            // the giant piece of the sub-tile (its last piece): merged by k_giant_merge, its token count is added here (by the chunk's part 0)
+            if (part == 0 && (P.heavy_flag[t] & 2u)) { const int g = P.giant_cnt[t]; if (g > 1) simt::atomic_add(&P.tile_count[t], g - 1); }   // (< 0: no pool, the call is retried)
         }
         int ntotal;
+        (void)tkz_wave_scan_sum(my_nl, &ntotal);
+        if (ntotal > kLongDense) { if (lane / (64 / kLongParts) != part) my_nl = 0; }      // dense: this unit's share of the sub-tiles
+        else if (part != 0) continue;                                                    // sparse: the whole chunk is part 0's
         const int pre = tkz_wave_scan_sum(my_nl, &ntotal);
         if (!ntotal) continue;
         (void)simt::ballot(true);
@@ -1258,7 +1270,7 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
         // position g of the 64 lists taken as one: entry g - pre[q] (from the back) of sub-tile q
         auto entry_at = [&](int g, int* q, int* j) -> uint32_t {
             *q = tkz_find_list<64>(s_pre, g); *j = g - s_pre[*q];
-            return tkz_load_nt(&P.mlist[(c * kLongChunk + *q) * (int64_t)P.mcap + (P.mcap - 1 - *j)]);
+            return tkz_load_nt(&P.mlist[(c * 64 + *q) * (int64_t)P.mcap + (P.mcap - 1 - *j)]);
         };
         for (int seg0 = 0; seg0 < ntotal; seg0 += kLongSeg) {
             const int nseg = ntotal - seg0 < kLongSeg ? ntotal - seg0 : kLongSeg;
@@ -1321,7 +1333,7 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                 const uint64_t bad = simt::ballot(mine && aoff + need > kArenaDwords);
                 const int limit = bad ? tkz_ctz64(bad) : 64;                   // lanes at or beyond `limit` wait for the next batch (limit >= 1: one piece always fits)
                 if (mine && lane < limit) {
-                    const int64_t sub = c * kLongChunk + q;
+                    const int64_t sub = c * 64 + q;
                     const int64_t abs = sub * kSub + rel;
                     uint32_t* bw = &s_arena[aoff];                   // (len + 3) / 4 dwords of bytes, then the merge state
 #ifdef TKZ_ML_LANE32
@@ -2608,7 +2620,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     TKZ_LAUNCH(k_giant_order, 1, 1024, L.stream, P);
     TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // takes pieces off the ordered queue; exits at once when it is empty
     {   // strides over 64-sub-tile chunks
-        const int64_t chunks = cdiv(nsub, kLongChunk), grid = chunks < 65536 ? chunks : 65536;
+        const int64_t chunks = cdiv(nsub, 64) * kLongParts, grid = chunks < 65536 ? chunks : 65536;      // (units of work: see kLongParts)
         if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH(k_merge_long<true>, grid, 64, L.stream, T, P);
         else TKZ_LAUNCH(k_merge_long<false>, grid, 64, L.stream, T, P);
         // the pieces k_merge_long leaves to a whole wavefront, off the queue k_list_stats filled (every wavefront exits at once when it is empty)
