@@ -951,6 +951,13 @@ def main():
                         want = h_ids[:int(h_ooffs[nh])].astype(np.uint32).astype(np.uint64) + np.uint64(1)      # (the driver's position-weighted sum mod 2^64)
                         wsum = int((want * (np.arange(len(want), dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(1))).sum(dtype=np.uint64))
                         host_api["same_ids_as_device_path"] = bool(host_api["tokens"] == len(want) and host_api["ids_checksum"] == "%016x" % wsum)
+                        if isinstance(host_api.get("utf16"), dict):
+                            u = host_api["utf16"]
+                            u["same_ids_as_device_path"] = bool(u.get("tokens") == len(want) and u.get("ids_checksum") == "%016x" % wsum)
+                            u["unit"] = "MB/s of UTF-8 text (the input is twice that in UTF-16 code units)"
+                            u["note"] = ("tkz::TikTokenizer::EncodeBatchFlatUtf16 on the same documents as std::u16strings: threaded gather of the code units into page-locked memory + ONE "
+                                         "tkz_encode_batch_utf16 (chunked upload, Encoding.UTF8.GetBytes on the device); value_as_the_csharp_class_calls: the calls "
+                                         "bindings/csharp/GpuTikTokenizer.EncodeBatchFlat makes, as it makes them -- one thread copies the strings into a pageable array, a fresh id array per call")
                         host_api["note"] = ("tkz::TikTokenizer::EncodeBatchFlat on %d std::strings (include/tkz_tokenizer.hpp): threaded gather into page-locked memory + "
                                             "tkz_encode_batch_utf8 + ids left in page-locked memory; the best of %d calls" % (nh, host_api.get("reps", 0)))
                 except Exception as ex:
@@ -1000,6 +1007,7 @@ def main():
             "cpu_baseline": cpu,
             "pcie_inclusive": host_path,
             "value_host_api": host_api["value"] if host_api and "value" in host_api else None,
+            "value_host_api_utf16": (host_api.get("utf16") or {}).get("value") if host_api else None,
             "host_api": host_api,
         }
         if real_meta:

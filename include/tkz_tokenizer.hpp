@@ -191,6 +191,47 @@ public:
         out.ids_ = out.spliced_ids_.data(); out.offsets_ = out.spliced_offs_.data();
     }
 
+    // The same for hosts whose strings are UTF-16 (a .NET `string`, Java, JavaScript): the plain path (no special tokens applied) on code units --
+    // what bindings/csharp/GpuTikTokenizer.EncodeBatchFlat does with `string.CopyTo` + tkz_encode_batch_utf16.  The units are gathered into
+    // page-locked memory by `threads` host threads, uploaded as they are (the library cuts the batch into chunks and runs Encoding.UTF8.GetBytes
+    // -- TikTokenizer.cs:261 -- on the device while the next chunk is on its way) and the ids come back into page-locked memory.
+    void EncodeBatchFlatUtf16(const std::vector<std::u16string>& texts, FlatBatch& out, int threads = 0) const {
+        const int64_t n = static_cast<int64_t>(texts.size());
+        out.n_texts_ = n;
+        int nth = threads > 0 ? threads : static_cast<int>(std::min<int64_t>(16, n >> 14));
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && nth > static_cast<int>(hw)) nth = static_cast<int>(hw);
+        if (nth < 1) nth = 1;
+        int64_t* offs = static_cast<int64_t*>(out.in_offs_.ensure((static_cast<size_t>(n) + 1) * 8));
+        offs[0] = 0;
+        for (int64_t i = 0; i < n; ++i) offs[i + 1] = offs[i] + static_cast<int64_t>(texts[static_cast<size_t>(i)].size());
+        const int64_t total = offs[n];
+        uint16_t* units = static_cast<uint16_t*>(out.in_bytes_.ensure(static_cast<size_t>(total) * 2 + 64));
+        {
+            Joiner j;
+            for (int t = 0; t < nth; ++t)
+                j.pool.emplace_back([&, t] {
+                    const int64_t lo = t == 0 ? 0 : std::lower_bound(offs, offs + n, total / nth * t) - offs;
+                    const int64_t hi = t == nth - 1 ? n : std::lower_bound(offs, offs + n, total / nth * (t + 1)) - offs;
+                    for (int64_t i = lo; i < hi; ++i) std::memcpy(units + offs[i], texts[static_cast<size_t>(i)].data(), texts[static_cast<size_t>(i)].size() * 2);
+                });
+        }
+        int64_t* ooff = static_cast<int64_t*>(out.out_offs_.ensure((static_cast<size_t>(n) + 1) * 8));
+        // a code unit is at most three UTF-8 bytes and a token at least one byte: 3 * total ids always suffice; text has a token per ~4 units, so the
+        // first call gets room for one per two and the call is repeated with the exact count when that was not enough
+        int64_t cap = std::max<int64_t>(1, std::min<int64_t>(3 * total, std::max<int64_t>(total / 2 + 4096, static_cast<int64_t>(static_cast<double>(total) * out.tokens_per_byte_ * 1.1))));
+        for (;;) {
+            int32_t* ids = static_cast<int32_t*>(out.out_ids_.ensure(static_cast<size_t>(cap) * 4));
+            int64_t needed = 0;
+            const tkz_status st = tkz_encode_batch_utf16(enc_, units, offs, n, ids, cap, ooff, &needed);
+            if (st == TKZ_E_CAPACITY && needed > cap) { cap = needed; continue; }
+            check(st);
+            if (total > 0) out.tokens_per_byte_ = std::max(out.tokens_per_byte_, static_cast<double>(needed) / static_cast<double>(total));
+            break;
+        }
+        out.ids_ = out.out_ids_.as<int32_t>(); out.offsets_ = out.out_offs_.as<int64_t>();
+    }
+
     using Trimmed = std::pair<std::vector<int32_t>, std::string>;   // (List<int> TokenIds, string Text)
     // EncodeTrimSuffix(string, IReadOnlyCollection<string> allowedSpecial, int maxTokenCount)     TikTokenizer.cs:394-403
     Trimmed EncodeTrimSuffix(const std::string& text, const std::vector<std::string>& allowedSpecial, int maxTokenCount) const {

@@ -62,6 +62,19 @@ int main(int argc, char** argv) {
         const std::u16string lone = {u'a', char16_t(0xD83D)}, pair = {char16_t(0xD83D), char16_t(0xDE00), u'b'}, half = {char16_t(0xDE00), u'c'};
         const auto b16 = tok.EncodeBatchUtf16({u"Hello World", u"", lone, half, pair});
         REQUIRE(b16.size() == 5 && b16[0] == hw && b16[1].empty());
+        {   // the flat form on UTF-16 strings: the same ids, the FlatBatch's page-locked buffers reused across calls of either kind
+            tkz::FlatBatch fb16;
+            std::vector<std::u16string> t16 = {u"Hello World", u"", lone, half, pair};
+            for (int round = 0; round < 2; ++round) {
+                tok.EncodeBatchFlatUtf16(t16, fb16, round ? 2 : 0);
+                REQUIRE(fb16.n_texts() == (int64_t)t16.size() && fb16.offsets()[0] == 0 && fb16.n_ids() == fb16.offsets()[t16.size()]);
+                const auto ref16 = tok.EncodeBatchUtf16(t16);
+                for (size_t t = 0; t < t16.size(); ++t) REQUIRE(fb16.text((int64_t)t) == ref16[t]);
+                for (int k = 0; k < 60; ++k) { std::u16string w; for (char ch : text.substr((size_t)k * 97, 2500)) w.push_back((char16_t)(unsigned char)ch); t16.push_back(w); }
+            }
+            tok.EncodeBatchFlatUtf16({}, fb16);
+            REQUIRE(fb16.n_texts() == 0 && fb16.n_ids() == 0);
+        }
         REQUIRE(b16[2] == tok.Encode("a\xEF\xBF\xBD", false));                    // a lone high half at the end of a document -> U+FFFD
         REQUIRE(b16[3] == tok.Encode("\xEF\xBF\xBD" "c", false));                 // ... and the low half that starts the next one
         REQUIRE(b16[4] == tok.Encode("\xF0\x9F\x98\x80" "b", false));            // a pair inside one document is one 4-byte char
