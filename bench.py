@@ -392,6 +392,8 @@ def main():
     else:
         memo_note = "on: %d slots, filled during the warm-up steps from the same tiled text (every piece of it repeats)" % enc.memo_slots
     empty_memo_each_step = args.kind == 6 and not args.no_memo
+    if empty_memo_each_step:
+        enc.set_option(N.OPT_PROMOTE, 0)                          # (a first pass has nothing promoted: promoted pieces are memo answers of EARLIER text)
     memo_on = {}                                                    # encoder -> the memo is switched on (so that a step only empties a memo that is in use)
 
     def step(en=None):
@@ -497,7 +499,12 @@ def main():
     dt_warm = None
     if empty_memo_each_step and args.steps > 0:
         memo_on[id(enc)] = False                                    # (step() leaves the memo alone)
+        enc.set_option(N.OPT_PROMOTE, 1)
+        for _ in range(min(6, 2 + int((1 << 30) // max(1, total)))):         # (untimed: the two learning batches an encoder gets -- the second one a gigabyte after the first -- and their promotions)
+            step()
         dt_warm, _ = timed(enc, args.steps)
+        enc.set_option(N.OPT_PROMOTE, 0)
+        enc.set_option(N.OPT_PROMOTE, 3)
         memo_on[id(enc)] = True
     # the same steps with the piece memo switched off (it neither reads nor fills it): the companion figure `value_no_memo`
     dt_nomemo = None
@@ -569,8 +576,8 @@ def main():
             rd_ooffs = torch.empty(r_nd + 1, dtype=torch.int64, device=dev)
             r_steps = max(1, min(args.steps, 5))
             real_leg = {"corpus": r_meta, "steps": r_steps, "unit": "MB/s",
-                        "piece_memo": "EMPTIED before every timed step (`value`): real text is not tiled, every step is a first pass; `value_warm_memo`: the memo as "
-                                      "earlier passes over this very text left it (an upper bound); `value_no_memo`: switched off",
+                        "piece_memo": "EMPTIED before every timed step and nothing promoted (`value`): real text is not tiled, every step is a first pass; `value_warm_memo`: the "
+                                      "memo and the promoted pieces as earlier passes over this very text left them (an upper bound); `value_no_memo`: switched off",
                         "by_vocab": {}}
             combos = [("gpt2", 1), ("gpt2", 2), (None, 2), ("synth100k_heldout", 2)]
             for vname, pat in combos:
@@ -589,8 +596,10 @@ def main():
                         nt = r_step(mode)
                     device_sync()
                     return (time.perf_counter() - t0) / r_steps, nt
+                en.set_option(N.OPT_PROMOTE, 0)                     # (a first pass has nothing promoted)
                 en.set_option(N.OPT_PIECE_MEMO, 0)
                 r_step("off")                                       # (untimed: the workspace takes the size this batch needs)
+                t_off, _ = r_timed("off")
                 en.set_option(N.OPT_PIECE_MEMO, 1)
                 r_step("empty")                                     # (untimed: lists that grow under a miss-heavy table grow here)
                 en.set_profiling(True)
@@ -598,9 +607,13 @@ def main():
                 t_first, r_ntok = r_timed("empty")
                 r_kms = en.kernel_ms()
                 en.set_profiling(False)
+                en.set_option(N.OPT_PROMOTE, 1)                     # warm: the memo kept, and what the encoder promotes out of it (two learning batches, untimed)
+                for _ in range(min(6, 2 + int((1 << 30) // max(1, r_total)))):
+                    r_step("warm")
                 t_warm, _ = r_timed("warm")
-                en.set_option(N.OPT_PIECE_MEMO, 0)
-                t_off, _ = r_timed("off")
+                r_promoted = en.piece_stats().get("promoted_pieces_in_tables", 0)
+                en.set_option(N.OPT_PROMOTE, 0)
+                en.set_option(N.OPT_PROMOTE, 3)
                 en.set_option(N.OPT_PIECE_MEMO, 2)
                 en.set_option(N.OPT_PIECE_STATS, 1)
                 en.piece_stats(reset=True)
@@ -610,7 +623,7 @@ def main():
                 en.set_option(N.OPT_PIECE_STATS, 0)
                 r_stats.pop("batches", None)
                 ent = {"vocab": label_v, "pattern": PATTERN_NAME[pat], "value": round(r_total / t_first / 1e6, 1), "ms_per_step": round(t_first * 1e3, 3),
-                       "value_warm_memo": round(r_total / t_warm / 1e6, 1), "value_no_memo": round(r_total / t_off / 1e6, 1),
+                       "value_warm_memo": round(r_total / t_warm / 1e6, 1), "promoted_pieces_warm": r_promoted, "value_no_memo": round(r_total / t_off / 1e6, 1),
                        "tokens": r_ntok, "bytes_per_token": round(r_total / max(1, r_ntok), 3), "piece_stats": r_stats,
                        "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in r_kms.items()}, "parity": "unchecked"}
                 if not args.no_cpu_baseline:

@@ -103,6 +103,15 @@ int32_t tkz_encoder_device(const tkz_encoder* e);
 /* tkz_unicode_classes, read from the table image the encoder's DEVICE holds (downloaded for the call): verifies the upload. */
 tkz_status tkz_encoder_unicode_classes(tkz_encoder* e, uint32_t first, int32_t n, uint8_t* out);
 
+/* The HOST's Unicode classification.  The reference's split is whatever the running process's regex engine makes of \p{L}, \p{N}, \p{Lu} ... and \s
+ * (`new Regex(pattern, RegexOptions.Compiled)`, TikTokenizer.cs:77): the categories of the runtime's Unicode data -- 13.0 under net6.0, 15.0 under .NET 8,
+ * whatever the engine ships in Node.  libtkz is built with the 13.0 table (net6.0, the reference's target); a host on another runtime hands ITS table
+ * over: classes[cp] in 0..8 (the codes of tkz_unicode_classes; 8 = what the host's \s matches) for cp < n_code_points, n_code_points = 65536 (a .NET host
+ * classifies code UNITS: `char.GetUnicodeCategory` / `char.IsWhiteSpace` over the BMP is all pattern 1, cl100k and TKZ_PATTERN_O200K_DOTNET ever look
+ * at) or 1114112 (every code point: TKZ_PATTERN_O200K).  The ASCII range keeps its classes (the same in every Unicode version) and a surrogate code
+ * unit is class 0.  classes == NULL: the built-in table again.  Refused with TKZ_E_ARG while a call of the encoder is in flight. */
+tkz_status tkz_encoder_set_unicode_classes(tkz_encoder* e, const uint8_t* classes, int64_t n_code_points);
+
 /* Page-locked host memory for the buffers a host hands to the host-buffer entry points: copies from and to it run asynchronously at
  * the PCIe rate (tkz_encode_batch_utf8 overlaps the upload of one document range with the kernels of the previous one and the download
  * of the one before; from pageable memory every copy is staged by the runtime first: about half the rate).  A host without a HIP
@@ -282,7 +291,12 @@ enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1,
        TKZ_OPT_PROMOTE = 4,
        /* tuning knobs of the automatic promotion: the smallest batch (bytes) that may be a learning batch (default 8 MB), and the most promoted
         * pieces the key tables hold (default 65,536; at most 2^22) */
-       TKZ_OPT_PROMOTE_MIN_BYTES = 5, TKZ_OPT_PROMOTE_CAP = 6 };
+       TKZ_OPT_PROMOTE_MIN_BYTES = 5, TKZ_OPT_PROMOTE_CAP = 6,
+       /* cl100k's `(?i:'s|'t|'re|'ve|'m|'ll|'d)` as the host's engine reads it: 0 (default) = ASCII case pairs only -- net6.0, the reference's target; 1 =
+        * with .NET >= 7's case-equivalence tables, under which U+017F (long s) is an `s`: an apostrophe at which a match starts, followed by U+017F,
+        * is the contraction (none of the other letters of the seven literals has a non-ASCII equivalent).  No effect on the other patterns (pattern 1 is
+        * case-sensitive, o200k lists its case variants). */
+       TKZ_OPT_CASE_EQUIVALENCE = 7 };
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value);
 
 /* ---- measurement ------------------------------------------------------------------------- */

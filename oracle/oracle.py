@@ -119,6 +119,33 @@ class Vocab:
         return out[:k].tolist()
 
 
+_cls_keep = None
+
+
+def set_unicode_classes(classes):
+    """The checker with a caller-supplied Unicode classification (uint8[65536] or uint8[1114112], codes 0..8) instead of the built-in 13.0 data;
+    None: the built-in data again.  Process-wide."""
+    global _cls_keep
+    L = lib()
+    L.tkzo_set_unicode_classes.argtypes = [C.c_void_p, C.c_int64]
+    L.tkzo_set_unicode_classes.restype = None
+    if classes is None:
+        L.tkzo_set_unicode_classes(None, 0)
+        _cls_keep = None
+        return
+    a = np.ascontiguousarray(classes, dtype=np.uint8)
+    _cls_keep = a                                    # (the C side keeps a reference)
+    L.tkzo_set_unicode_classes(a.ctypes.data, len(a))
+
+
+def set_case_equivalence(on: bool):
+    """cl100k's (?i:...) with .NET >= 7's case-equivalence tables (U+017F is an s).  Process-wide."""
+    L = lib()
+    L.tkzo_set_case_equivalence.argtypes = [C.c_int]
+    L.tkzo_set_case_equivalence.restype = None
+    L.tkzo_set_case_equivalence(1 if on else 0)
+
+
 def split_utf8(pattern: int, text: bytes):
     """Regex.Matches: list of (byte_start, byte_len)."""
     cap = len(text) + 1

@@ -35,7 +35,14 @@ static void cls_init(void) {
 static const struct { uint32_t a, b; uint8_t c; } k_supp[] = {
 #include "unicode13_supp.inc"
 };
+/* Overrides (tests of tkz_encoder_set_unicode_classes / TKZ_OPT_CASE_EQUIVALENCE: the host's runtime defines the split, TikTokenizer.cs:77): a class
+ * per code point handed over by the caller instead of the built-in Unicode 13.0 data, and U+017F as an `s` in cl100k's (?i:...) (.NET >= 7).  Process-wide;
+ * the checker is not used from several threads with different settings. */
+static const uint8_t* g_cls_override = NULL;      /* 65536 or 0x110000 entries */
+static int64_t g_cls_override_n = 0;
+static int g_case_equiv = 0;
 static uint8_t supp_class(uint32_t cp) {
+    if (g_cls_override && (int64_t)cp < g_cls_override_n) return g_cls_override[cp];
     size_t lo = 0, hi = sizeof k_supp / sizeof k_supp[0];
     while (lo < hi) { size_t mid = (lo + hi) / 2; if (k_supp[mid].b < cp) lo = mid + 1; else hi = mid; }
     return (lo < sizeof k_supp / sizeof k_supp[0] && k_supp[lo].a <= cp) ? k_supp[lo].c : C_OTHER;
@@ -48,6 +55,16 @@ static uint8_t js_class(uint32_t cp) {
     if (cp == 0x85) return C_OTHER;
     return cp < 0x10000 ? g_cls[cp] : supp_class(cp);
 }
+void tkzo_set_unicode_classes(const uint8_t* classes, int64_t n) {
+    pthread_once(&g_cls_once, cls_init);
+    cls_init();                                      /* the built-in table again ... */
+    g_cls_override = NULL; g_cls_override_n = 0;
+    if (!classes) return;
+    /* ... then the caller's classes for everything but ASCII and the surrogate code units, as the library takes them */
+    for (int64_t cp = 128; cp < 65536 && cp < n; ++cp) g_cls[cp] = (cp >= 0xD800 && cp <= 0xDFFF) ? 0 : classes[cp];
+    if (n > 65536) { g_cls_override = classes; g_cls_override_n = n; }      /* (kept by reference: the caller keeps the array alive) */
+}
+void tkzo_set_case_equivalence(int on) { g_case_equiv = on; }
 static inline int isL(uint8_t c) { return c >= C_LU && c <= C_LO; }
 static inline int isN(uint8_t c) { return c == C_N; }
 static inline int isWS(uint8_t c) { return c == C_WS; }
@@ -353,6 +370,7 @@ static int64_t m_contraction(const utext* t, int64_t p, int mode) {
     int64_t r = t->n - p - 1;
     if (r < 1) return -1;
     int a = (int)U(p + 1), b = r >= 2 ? (int)U(p + 2) : -1;
+    if (mode == 1 && g_case_equiv && a == 0x17F) return p + 2;      /* .NET >= 7: U+017F is case-equivalent to s / S */
     if (a > 127) return -1;
     if (mode == 0) {
         if (a == 's' || a == 't') return p + 2;

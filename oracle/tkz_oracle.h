@@ -85,6 +85,10 @@ int64_t tkzo_bpe(const tkzo_vocab* v, const uint8_t* bytes, int64_t n, int32_t* 
 /* Regex.Matches over a valid UTF-8 document: writes the BYTE offset of every piece start into
  * starts (cap entries) and returns the piece count (or <0).  The concatenation of pieces may skip
  * units no alternative matches (cannot happen for the three shipped patterns). */
+/* Overrides for the tests of tkz_encoder_set_unicode_classes / TKZ_OPT_CASE_EQUIVALENCE (process-wide): classes[cp] in 0..8 for cp < n (n = 65536
+ * or 1114112; NULL: the built-in Unicode 13.0 data; the array must stay alive); U+017F as an `s` in cl100k's (?i:...). */
+void tkzo_set_unicode_classes(const uint8_t* classes, int64_t n);
+void tkzo_set_case_equivalence(int on);
 int64_t tkzo_split_utf8(int pattern, const uint8_t* text, int64_t n, int64_t* starts,
                         int64_t* lens, int64_t cap);
 /* Same over UTF-16 code units (lone surrogates allowed); offsets are in code units. */

@@ -457,6 +457,117 @@ def check_promotion(lib, O, vocab, ovocab, pattern=N.CL100K, seed=61):
     assert enc3.piece_stats()["promoted_pieces_in_tables"] == 0
 
 
+def check_runtime_overrides(lib, O, vocab, ovocab, seed=71):
+    """The host's runtime defines the split (TikTokenizer.cs:77 compiles the pattern with the RUNNING process's regex engine): a Unicode class table
+    handed over by the host (tkz_encoder_set_unicode_classes) and cl100k's (?i:...) with .NET >= 7's case-equivalence tables
+    (TKZ_OPT_CASE_EQUIVALENCE).  The device (parallel and sequential scanners, whole encode) against the oracle given the same overrides; the case mode
+    also against the `regex` engine, whose (?i) folds U+017F onto s like .NET >= 7 does."""
+    import regex_crosscheck as RC
+    rng = random.Random(seed)
+    try:
+        # ---- a perturbed class table: 60+ code points reclassified -- CJK, digits, white space, marks, symbols; supplementary-plane chars for o200k ----
+        enc0 = N.Encoder(vocab, N.O200K)
+        base = enc0.unicode_classes(0, 0x110000).copy()
+        del enc0
+        moved = {}
+        for cp in range(0x4E00, 0x4E10):
+            moved[cp] = 0                      # 16 CJK ideographs: letters -> other
+        for cp in range(0x6F22, 0x6F32):
+            moved[cp] = 7                      # ... and 16 more -> digits
+        moved.update({0x0663: 5, 0x0664: 0, 0xFF11: 0, 0xFF12: 2, 0x00B2: 0,             # digits -> letter / other
+                      0x3000: 0, 0x00A0: 5, 0x200B: 8, 0x2603: 8, 0x0085: 0,              # white space <-> other / letter
+                      0x0301: 5, 0x0300: 0, 0x093F: 7,                                    # marks
+                      0x2603 + 1: 5, 0x2764: 1, 0x2B50: 2, 0x00E9: 1, 0x00C9: 2, 0x0416: 2, 0x0436: 1, 0x01C5: 6, 0x02B0: 0, 0x3042: 7, 0x30AB: 0, 0xAC00: 6})
+        for cp in (0x1F600, 0x1F468, 0x1D400, 0x1D7CE, 0x10428, 0x20000, 0x2A700, 0xE0100, 0xE0101):
+            moved[cp] = {0: 5, 5: 0, 1: 7, 2: 7, 7: 5, 6: 1}.get(int(base[cp]), 0)         # supplementary plane (and plane 14: beyond the direct part of the table)
+        assert len(moved) >= 60
+        full = base.copy()
+        for cp, c in moved.items():
+            full[cp] = c
+        chars = [chr(cp) for cp in moved] + list("abcXYZ019  \n\r\t'.,;-_/") + ["'s", "'S", "'re", " ", "\n\n", "12345", "é", "中", "あ"]
+
+        def text(n):
+            out = []
+            while sum(map(len, out)) < n:
+                ch = rng.choice(chars)
+                out.append(ch * rng.choice([1, 1, 1, 2, 3, 5]))
+            return "".join(out)
+        docs = [text(rng.choice([40, 300, 2500, 9000])).encode("utf-8") for _ in range(14)] + [b"", text(70000).encode("utf-8")]
+        data, offs = pack(docs)
+        for pattern, table in ((N.P1, full[:65536]), (N.CL100K, full[:65536]), (N.O200K_DOTNET, full[:65536]), (N.O200K, full)):
+            enc = N.Encoder(vocab, pattern)
+            before = enc.pretokenize(data, offs)
+            enc.set_unicode_classes(table)
+            O.set_unicode_classes(table)
+            # the device's table IS the host's (ASCII and the surrogate code units aside), read back from the device
+            got = enc.unicode_classes(0, 0x110000)
+            want = base.copy(); want[:len(table)] = table; want[:128] = base[:128]; want[0xD800:0xE000] = 0
+            assert np.array_equal(got, want), pattern
+            oenc = O.Encoder(ovocab, pattern)
+            exp, eoff = oracle_encode_docs(oenc, docs)
+            for seq in (0, 1):
+                enc.set_option(N.OPT_PRETOK_SEQUENTIAL, seq)
+                bits = enc.pretokenize(data, offs)
+                want_bits = oracle_bitmap(O, pattern, docs)
+                assert np.array_equal(bits[:len(want_bits)], want_bits), (pattern, seq, int(np.flatnonzero(bits[:len(want_bits)] != want_bits)[0]))
+                ids, ooff = enc.encode_batch(data, offs)
+                assert ooff.tolist() == eoff and ids.tolist() == exp, (pattern, seq)
+            assert not np.array_equal(before, bits)          # (the perturbed table cuts this text differently)
+            # small batches (the single-launch path reads the same table)
+            for d in docs[:4]:
+                assert enc.encode_utf8(d) == oenc.encode_bytes(d)
+            # the built-in table again
+            enc.set_unicode_classes(None)
+            O.set_unicode_classes(None)
+            assert np.array_equal(enc.pretokenize(data, offs), before) and np.array_equal(enc.unicode_classes(0, 0x110000), base)
+        with pytest.raises(N.TkzError):
+            N.Encoder(vocab, N.CL100K).set_unicode_classes(np.zeros(1000, np.uint8))          # neither the BMP nor every code point
+        with pytest.raises(N.TkzError):
+            N.Encoder(vocab, N.CL100K).set_unicode_classes(np.full(65536, 9, np.uint8))        # a class code that does not exist
+        # ---- cl100k's (?i:...) with .NET >= 7's case-equivalence tables: 'ſ is 's ----
+        O.set_case_equivalence(True)
+        enc = N.Encoder(vocab, N.CL100K)
+        oenc = O.Encoder(ovocab, N.CL100K)
+        hand = ["it'ſ fine", "it'ſabc", "'ſ", "x'ſ", " 'ſa", "''ſa", "a'ſ'ſ's'S", "a'ſ", "a'ſ\n", "don'ſt", "a'ſ1", "a'ſ é", "é'ſé", "a'\u017f\u0301b", "a'ſ" + "z" * 200]
+        alpha = RC.alphabet() + ["ſ", "'ſ", "'ſ", "K"]
+        cdocs = [t.encode("utf-8") for t in hand] + [RC.random_text(rng, alpha, rng.choice([30, 400, 3000])).encode("utf-8") for _ in range(40)]
+        cdata, coffs = pack(cdocs)
+        plain_bits = enc.pretokenize(cdata, coffs)
+        enc.set_option(N.OPT_CASE_EQUIVALENCE, 1)
+        cexp, ceoff = oracle_encode_docs(oenc, cdocs)
+        for seq in (0, 1):
+            enc.set_option(N.OPT_PRETOK_SEQUENTIAL, seq)
+            bits = enc.pretokenize(cdata, coffs)
+            want_bits = oracle_bitmap(O, N.CL100K, cdocs)
+            assert np.array_equal(bits[:len(want_bits)], want_bits), (seq, int(np.flatnonzero(bits[:len(want_bits)] != want_bits)[0]))
+            ids, ooff = enc.encode_batch(cdata, coffs)
+            assert ooff.tolist() == ceoff and ids.tolist() == cexp, seq
+        assert not np.array_equal(plain_bits, bits)
+        for d in cdocs[:12]:                                 # (single strings: the batch path, the single-launch kernel stands aside in this mode)
+            assert enc.encode_utf8(d) == oenc.encode_bytes(d)
+        # ... and the oracle in this mode against `regex`, whose (?i) folds U+017F onto s as .NET >= 7 does (code units, .NET's \\s)
+        for d in cdocs:
+            u = RC.to_units(d.decode("utf-8"))
+            want = RC.split_units_regex(2, u)
+            got = O.split_utf16(N.CL100K, u)
+            assert [tuple(x) for x in got] == want, d
+        # the piece after 'ſ really is a piece of its own now
+        assert [bytes(cdocs[1][a:a + l]) for a, l in O.split_utf8(N.CL100K, cdocs[1])] == [b"it", "'ſ".encode(), b"abc"]
+        enc.set_option(N.OPT_CASE_EQUIVALENCE, 0)
+        O.set_case_equivalence(False)
+        assert np.array_equal(enc.pretokenize(cdata, coffs), plain_bits)
+        assert [bytes(cdocs[1][a:a + l]) for a, l in O.split_utf8(N.CL100K, cdocs[1])] == [b"it", "'ſabc".encode()]
+        # the option does nothing to the other patterns
+        for pattern in (N.P1, N.O200K_DOTNET):
+            e2 = N.Encoder(vocab, pattern)
+            b0 = e2.pretokenize(cdata, coffs)
+            e2.set_option(N.OPT_CASE_EQUIVALENCE, 1)
+            assert np.array_equal(e2.pretokenize(cdata, coffs), b0)
+    finally:
+        O.set_unicode_classes(None)
+        O.set_case_equivalence(False)
+
+
 def check_miss_lists(lib, O, vocab, ovocab, pattern=N.CL100K, seed=41):
     """The per-sub-tile miss lists (k_probe -> merge kernels -> k_place): sub-tiles with more misses than a list starts with (the batch
     is redone with longer lists), short and long misses sharing one list from both ends, a sub-tile of 1024 one-byte pieces, and calls

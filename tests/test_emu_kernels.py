@@ -144,6 +144,11 @@ def test_promoted_pieces(lib, vocabs, oracle_mod, vname, pattern):
     parity.check_promotion(lib, oracle_mod, v, ov, pattern=pattern)
 
 
+def test_host_runtime_defines_the_split(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_runtime_overrides(lib, oracle_mod, v, ov)
+
+
 def test_miss_lists(lib, vocabs, oracle_mod):
     v, ov = vocabs("gpt2")
     parity.check_miss_lists(lib, oracle_mod, v, ov)

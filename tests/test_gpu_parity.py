@@ -151,6 +151,11 @@ def test_promoted_pieces(lib, vocabs, oracle_mod, vname, pattern):
     parity.check_promotion(lib, oracle_mod, v, ov, pattern=pattern)
 
 
+def test_host_runtime_defines_the_split(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_runtime_overrides(lib, oracle_mod, v, ov)
+
+
 def test_miss_lists(lib, vocabs, oracle_mod):
     for vname, pat, seed in (("gpt2", N.CL100K, 41), ("synth100k", N.CL100K, 44), ("synth200k", N.O200K, 42)):
         v, ov = vocabs(vname)

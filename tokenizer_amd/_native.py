@@ -18,6 +18,7 @@ OPT_PRETOK_SEQUENTIAL = 1
 OPT_PIECE_MEMO = 2
 OPT_PIECE_STATS = 3
 OPT_PROMOTE_MIN_BYTES, OPT_PROMOTE_CAP = 5, 6
+OPT_CASE_EQUIVALENCE = 7    # cl100k's (?i:...) with .NET >= 7's case-equivalence tables ('ſ is 's)
 OPT_PROMOTE = 4        # 0 / 1: automatic promotion of hot memo entries into the key tables off / on; 2: promote now; 3: drop the promotions
 K_NAMES = ["k_docmark", "k_pretok", "k_probe", "k_scan", "k_place", "k_docoffs", "k_merge_long_group", "k_merge_short"]
 
@@ -90,6 +91,7 @@ class Library:
         L.tkz_unicode_classes.argtypes = [C.c_uint32, C.c_int32, vp]
         L.tkz_unicode_classes.restype = None
         L.tkz_encoder_unicode_classes.argtypes = [vp, C.c_uint32, C.c_int32, vp]
+        L.tkz_encoder_set_unicode_classes.argtypes = [vp, vp, i64]
         L.tkz_encoder_pretok_leftovers.argtypes = [vp, pi64, pi64]
         L.tkz_encoder_pretok_leftovers.restype = None
         L.tkz_vocab_table_bytes.argtypes = [vp, C.c_int32]
@@ -230,6 +232,21 @@ class Encoder:
 
     def set_option(self, opt, value):
         self.lib.check(self.lib.L.tkz_encoder_set_option(self._h, opt, value))
+
+    def set_unicode_classes(self, classes):
+        """The host's Unicode classification (tkz_encoder_set_unicode_classes): uint8[65536] (code units) or uint8[1114112] (code points) of class
+        codes 0..8, or None for the built-in Unicode 13.0 table."""
+        if classes is None:
+            self.lib.check(self.lib.L.tkz_encoder_set_unicode_classes(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(classes, dtype=np.uint8)
+        self.lib.check(self.lib.L.tkz_encoder_set_unicode_classes(self._h, a.ctypes.data, len(a)))
+
+    def unicode_classes(self, first, n):
+        """Classes of code points first .. first + n - 1 as the DEVICE's table has them (tkz_encoder_unicode_classes)."""
+        out = np.zeros(n, np.uint8)
+        self.lib.check(self.lib.L.tkz_encoder_unicode_classes(self._h, first, n, out.ctypes.data))
+        return out
 
     def piece_stats(self, reset=False):
         """What the batch path met since the last reset, with OPT_PIECE_STATS on (tkz_encoder_piece_stats)."""

@@ -174,6 +174,8 @@ struct tkz_encoder {
     std::atomic<int64_t> last_xcount{0}, last_xcount2{0};   // tkz_encoder_pretok_leftovers
     bool small_ok = false;                 // the device's LDS per workgroup holds k_small's (kSmallLdsBytesNeeded)
     bool piece_stats = false;              // TKZ_OPT_PIECE_STATS
+    bool case_equiv = false;               // TKZ_OPT_CASE_EQUIVALENCE: `'` + U+017F is a contraction under cl100k (a .NET >= 7 host)
+    size_t bmp_image_bytes = 0;            // the class table image on the device (t_bmp)
     DevBuf t_stats;                        // its device block (EncodeParams::stats)
     int64_t stat_batches = 0, stat_giants = 0;   // ... and what the host adds per batch (under mu)
     int pending = 0;                       // tkz_pending handles outstanding (under mu)
@@ -491,6 +493,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             launch_pretok_rows(L, e->pattern, d_bytes, d_offs, n_docs, total, docbits, startbits, nwords, T.bmp_class, counters,
                                ws->w_xq.as<int64_t>(), reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, xcount)));
         }
+        if (pretok && e->case_equiv && e->pattern == TKZ_PATTERN_CL100K) launch_case_equiv_fix(L, d_bytes, total, docbits, startbits);
         if (d_bitmap_only) {
             HIP_TRY(hipMemcpyAsync(d_bitmap_only, startbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
         } else {
@@ -683,7 +686,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
 constexpr size_t kSmallOffBytes = 0, kSmallOffOffs = tkz::kSmallMaxBytes + 64, kSmallOffIds = kSmallOffOffs + (tkz::kSmallMaxDocs + 1) * 8,
                  kSmallOffOut = kSmallOffIds + tkz::kSmallMaxBytes * 4, kSmallOffRes = kSmallOffOut + (tkz::kSmallMaxDocs + 1) * 8, kSmallBlock = kSmallOffRes + 256;
 bool small_eligible(const tkz_encoder* e, const int64_t* offs, int64_t n_docs, int64_t total) {
-    if (!e->small_ok || e->profiling || e->pretok_seq || total <= 0 || total > tkz::kSmallMaxBytes || n_docs < 1 || n_docs > tkz::kSmallMaxDocs) return false;
+    if (!e->small_ok || e->profiling || e->pretok_seq || (e->case_equiv && e->pattern == TKZ_PATTERN_CL100K) || total <= 0 || total > tkz::kSmallMaxBytes || n_docs < 1 || n_docs > tkz::kSmallMaxDocs) return false;
     const bool o200k = e->pattern == TKZ_PATTERN_O200K || e->pattern == TKZ_PATTERN_O200K_DOTNET;
     if (o200k && total > tkz::kSmallMaxBytesO200k) return false;
     if (o200k)                                    // (split by the sequential matcher there, one lane per document)
@@ -780,10 +783,10 @@ bool pinned_host(const void* p, void** dev) {
 // host buffers -> staging -> device path -> back, for documents given as UTF-8 bytes (`bytes`) or as UTF-16 code units (`units`: uploaded as they are,
 // Encoding.UTF8.GetBytes -- TikTokenizer.cs:261 -- runs on the device; offsets in units then).
 //  * at most 128 KiB of UTF-8: the single-launch kernel (encode_small);
-//  * a batch whose upload is below 1.5 chunks (a chunk: 16 MB): one launch sequence.  From page-locked caller buffers the inputs are copied
-//    asynchronously and the ids and offsets are written by the kernels STRAIGHT into the caller's memory (k_place / k_docoffs store whole lines over
-//    PCIe): no download commands, one synchronisation;
-//  * larger: document ranges of ~16 MB of upload, pipelined on three streams -- the upload of chunk k+1 (and, for UTF-16, its length pass), the kernels
+//  * a batch whose upload is below 1.5 chunks (a chunk: 32 MB): one launch sequence.  From page-locked caller buffers the inputs are copied
+//    asynchronously and -- up to 8 MB of text -- the ids and offsets are written by the kernels STRAIGHT into the caller's memory (k_place / k_docoffs
+//    store whole lines over PCIe): no download commands, one synchronisation;
+//  * larger: document ranges of ~32 MB of upload, pipelined on three streams -- the upload of chunk k+1 (and, for UTF-16, its length pass), the kernels
 //    of chunk k and the download of chunk k-1 run at the same time; PCIe is full duplex and the kernels need a fraction of a transfer's time.
 //    (48 MB chunks from 96 MB up until round 5: a 64 MB batch was one chunk, upload, kernels and download one after the other.)
 tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* units, const int64_t* offs, int64_t n_docs, int32_t* out_ids,
@@ -807,7 +810,9 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
     int64_t* acc = &ws->bytes_allocated;
     const int64_t unit = u16 ? 2 : 1;
     // ($TKZ_HOST_CHUNK_BYTES: test knob, so that the CPU-emulated tests can exercise the pipeline on kilobytes)
-    static const int64_t kChunkBytes = [] { const char* v = getenv("TKZ_HOST_CHUNK_BYTES"); const long long n = v ? atoll(v) : 0; return n > 0 ? (int64_t)n : (int64_t(16) << 20); }();
+    // (32 MB of upload a chunk: the launch sequence of a chunk has a floor of ~0.4 ms whatever its size, a 16 MB chunk's transfer is 0.3 ms -- measured,
+    //  round 5: 16 MB chunks ran a 512 MB batch at 26 GB/s where 48 MB chunks had run it at 42)
+    static const int64_t kChunkBytes = [] { const char* v = getenv("TKZ_HOST_CHUNK_BYTES"); const long long n = v ? atoll(v) : 0; return n > 0 ? (int64_t)n : (int64_t(32) << 20); }();
     const int64_t up_bytes = total * unit;
     int64_t nchunks = (bitmap || !pretok || 2 * up_bytes < 3 * kChunkBytes) ? 1 : std::min<int64_t>(1024, std::max<int64_t>(2, (up_bytes + kChunkBytes / 2) / kChunkBytes));
     // chunk boundaries on documents: chunk k = documents [cut[k], cut[k+1]).  Offsets that are not monotone cannot be cut: the
@@ -857,7 +862,9 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
     }
     // ---- chunks on three streams (a single chunk is the loop's one iteration) ----
     HIP_TRY(ensure_streams(ws));
-    const bool direct_out = nchunks == 1 && pin_out;          // the kernels write the caller's page-locked ids and offsets themselves
+    // the kernels write the caller's page-locked ids and offsets themselves -- up to 8 MB of text: beyond that a DMA download beats k_place's stores over PCIe
+    // (measured, round 5: 16 MB 1.08 ms direct, 1.00 ms staged)
+    const bool direct_out = nchunks == 1 && pin_out && up_bytes <= (int64_t(8) << 20) * unit;
     int64_t max_units = 0, max_docs = 0;
     for (int64_t k = 0; k < nchunks; ++k) {
         max_units = std::max(max_units, offs[cut[(size_t)k + 1]] - offs[cut[(size_t)k]]);
@@ -1023,9 +1030,49 @@ tkz_status tkz_encoder_unicode_classes(tkz_encoder* e, uint32_t first, int32_t n
     DeviceScope scope;
     tkz_status st = check_encoder(e, scope);
     if (st != TKZ_OK) return st;
-    std::vector<uint8_t> img(tkz::bmp_class_table().size());
+    std::vector<uint8_t> img(e->bmp_image_bytes);
     HIP_TRY(hipMemcpy(img.data(), e->t_bmp.p, img.size(), hipMemcpyDeviceToHost));
     for (int32_t i = 0; i < n; ++i) out[i] = tkz_supp_class(img.data(), first + (uint32_t)i);
+    return TKZ_OK;
+}
+
+tkz_status tkz_encoder_set_unicode_classes(tkz_encoder* e, const uint8_t* classes, int64_t n_code_points) {
+    // The split regexes are whatever the HOST's regex engine makes of \p{L}, \p{N}, \s: the reference compiles them with the running process's
+    // System.Text.RegularExpressions (TikTokenizer.cs:77), whose Unicode data is the runtime's (13.0 under net6.0, 15.0 under .NET 8).  A host hands its
+    // own classification over here; classes == NULL puts the built-in Unicode 13.0 table back.
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
+    if (st != TKZ_OK) return st;
+    if (classes && n_code_points != 0x10000 && n_code_points != 0x110000) return fail(TKZ_E_ARG, "n_code_points must be 65536 (the BMP: code units) or 1114112 (every code point)");
+    std::vector<uint8_t> img = tkz::bmp_class_table();                 // [TKZ_UCD_DIRECT direct classes][n][n x {first, last | class << 24}]
+    if (classes) {
+        for (int64_t cp = 0; cp < n_code_points; ++cp) if (classes[cp] > 8) return fail(TKZ_E_ARG, "a class code above 8 (0 other, 1 Lu, 2 Ll, 3 Lt, 4 Lm, 5 Lo, 6 M, 7 N, 8 white space)");
+        // (the ASCII range keeps its classes: the scanners' fast paths know them; and a surrogate code unit is never a letter, digit or space)
+        const int64_t direct = std::min<int64_t>(n_code_points, (int64_t)TKZ_UCD_DIRECT);
+        for (int64_t cp = 128; cp < direct; ++cp) img[(size_t)cp] = (cp >= 0xD800 && cp <= 0xDFFF) ? 0 : classes[cp];
+        if (n_code_points > (int64_t)TKZ_UCD_DIRECT) {
+            std::vector<uint32_t> hi;
+            for (int64_t cp = TKZ_UCD_DIRECT; cp < n_code_points;) {
+                if (!classes[cp]) { ++cp; continue; }
+                int64_t end = cp;
+                while (end + 1 < n_code_points && classes[end + 1] == classes[cp]) ++end;
+                hi.push_back((uint32_t)cp); hi.push_back((uint32_t)end | ((uint32_t)classes[cp] << 24));
+                cp = end + 1;
+            }
+            if (hi.size() / 2 > 4096) return fail(TKZ_E_UNSUPPORTED, "more than 4096 classified ranges above U+3FFFF");
+            const uint32_t n = (uint32_t)(hi.size() / 2);
+            hi.insert(hi.begin(), n);
+            img.resize(TKZ_UCD_DIRECT + hi.size() * 4);
+            memcpy(img.data() + TKZ_UCD_DIRECT, hi.data(), hi.size() * 4);
+        }
+    }
+    std::lock_guard<std::mutex> lock(e->mu);
+    for (Workspace* w : e->pool) if (w->busy) return fail(TKZ_E_ARG, "the class table can only be replaced while no call of this encoder is in flight");
+    if (hipDeviceSynchronize() != hipSuccess) return fail(TKZ_E_DEVICE, "hipDeviceSynchronize");
+    const hipError_t h = upload(e->t_bmp, img, &e->bytes_allocated);
+    if (h != hipSuccess) return fail(TKZ_E_DEVICE, std::string("class table upload: ") + hipGetErrorString(h));
+    e->bmp_image_bytes = img.size();
+    e->T.bmp_class = e->t_bmp.as<uint8_t>();
     return TKZ_OK;
 }
 
@@ -1073,6 +1120,7 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
     if (h == hipSuccess) h = upload(e->t_byte, V.byte_rank, acc);
     if (h == hipSuccess) h = upload(e->t_bpair, V.bytepair_rank, acc);
     if (h == hipSuccess) h = upload(e->t_bmp, tkz::bmp_class_table(), acc);
+    e->bmp_image_bytes = tkz::bmp_class_table().size();
     // {n_docs, n_bytes, n_tokens} of the last batch (tkz_encoder_counts_device): allocated once, here -- never from a call in flight
     if (h == hipSuccess) h = e->t_counts3.ensure(32, acc);
     if (h == hipSuccess) h = hipMemset(e->t_counts3.p, 0, 32);
@@ -1448,6 +1496,12 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
             HIP_TRY(hipMemset(e->t_stats.p, 0, 128));
         }
         e->piece_stats = value != 0;
+        return TKZ_OK;
+    }
+    if (option == TKZ_OPT_CASE_EQUIVALENCE) {
+        if (value != 0 && value != 1) return fail(TKZ_E_ARG, "TKZ_OPT_CASE_EQUIVALENCE takes 0 or 1");
+        std::lock_guard<std::mutex> lock(e->mu);
+        e->case_equiv = value != 0;
         return TKZ_OK;
     }
     if (option == TKZ_OPT_PROMOTE_MIN_BYTES || option == TKZ_OPT_PROMOTE_CAP) {

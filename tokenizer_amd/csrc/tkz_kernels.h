@@ -26,7 +26,8 @@ constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are m
 #ifndef TKZ_LANE_PIECE
 #define TKZ_LANE_PIECE 128
 #endif
-constexpr int kLanePiece = TKZ_LANE_PIECE;    // ... but a missed piece longer than this is merged by a whole wavefront (k_merge_coop): one lane takes ~n^2 steps, and the kernel waits for it
+constexpr int kLanePiece = TKZ_LANE_PIECE;
+constexpr int kSmallLanePiece = 256;  // ... the single-launch kernel (no k_merge_coop there) merges pieces of up to this many bytes a lane each and hands a batch with a longer missed piece back    // ... but a missed piece longer than this is merged by a whole wavefront (k_merge_coop): one lane takes ~n^2 steps, and the kernel waits for it
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
 constexpr int kScanBlock = 1024;    // tiles per workgroup in the tile-count scan
@@ -119,6 +120,8 @@ void launch_doccount2(const Launch& L, const uint64_t* bits_a, const uint64_t* b
 void launch_scan2(const Launch& L, int64_t ntiles, int64_t* bsum, const int32_t* cnt_a, int64_t* base_a, int64_t* grand_a, int round_to_a,
                   const int32_t* cnt_b, int64_t* base_b, int64_t* grand_b, int round_to_b, int kid);
 void launch_rebase(const Launch& L, int64_t* offs, int64_t n, int64_t base);
+// TKZ_OPT_CASE_EQUIVALENCE: a piece start behind every `'` + U+017F at whose apostrophe a match starts (cl100k on a .NET >= 7 host)
+void launch_case_equiv_fix(const Launch& L, const uint8_t* d_bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits);
 void launch_miss_stats(const Launch& L, const EncodeParams& P, int64_t nsub);
 void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_t* grand, int64_t* out3, int64_t* out3b = nullptr, int64_t* out3c = nullptr);
 // UTF-16 documents -> UTF-8 documents (Encoding.UTF8.GetBytes for a batch): lengths + group prefixes, then (after the scan of

@@ -845,7 +845,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
             }
             if (miss_l && il + ns < P.mcap) ml[P.mcap - 1 - il] = ent;
             uint32_t rec = ((s_mark[s >> 5] >> (s & 31)) & 1u) ? kPrMark : 0u;
-            if (REPORT) giant = giant || (miss_l && len > kLanePiece);      // (k_small, the only REPORT user, hands a batch with such a piece back like one with a giant piece: k_merge_coop is a kernel of the batch path)
+            if (REPORT) giant = giant || (miss_l && len > kSmallLanePiece);      // (k_small, the only REPORT user, hands a batch with such a piece back like one with a giant piece: k_merge_coop is a kernel of the batch path)
             else coopl = coopl || (miss_l && len > kLanePiece);
             if (is_giant) { rec |= kPrMiss | kPrGiant | (uint32_t)s; giant = giant || valid; }
             else if (miss) rec |= kPrMiss | (miss_l ? (kPrLong | (uint32_t)il) : (uint32_t)is_);
@@ -1234,7 +1234,9 @@ TKZ_DEV void tkz_long_brank_init(const TkzTables& T, int32_t* s_brank) {     // 
 // chunks c0, c0 + cstep, ... of 64 sub-tiles each, by one wavefront
 // (COMPACT: ranks below 2^21, i.e. every published vocabulary -- no ids[] array)
 template <bool COMPACT>
-TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, int64_t c0, int64_t cstep, const LongLds& LD) {
+// (lane_piece: pieces of up to this many bytes are merged here -- kLanePiece on the batch path, which has k_merge_coop for the longer ones; the
+//  single-launch kernel has no such kernel and takes kSmallLanePiece)
+TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, int64_t c0, int64_t cstep, const LongLds& LD, const int lane_piece = kLanePiece) {
     uint32_t* s_arena = LD.arena;
     int* s_pre = LD.pre;
     int* s_cls = LD.cls;
@@ -1244,10 +1246,13 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
     int err = 0;
     constexpr bool compact = COMPACT;                           // no ids[] array (tkz_bpe_lane_varc): 40 % more pieces per batch
     // A unit of work = a chunk of 64 sub-tiles, or -- when the chunk's lists hold more than kLongDense entries -- one of its kLongParts parts
-    // (unit u = chunk u / kLongParts, part u % kLongParts; the parts of a sparse chunk other than part 0 have nothing to do).
-    for (int64_t u = c0; (u / kLongParts) * 64 < P.nsub; u += cstep) {
-        const int64_t c = u / kLongParts;
-        const int part = (int)(u % kLongParts);
+    // (the parts of a sparse chunk other than part 0 have nothing to do).
+    // (part-major: units 0 .. nchunks-1 are part 0 of every chunk.  Chunk-major -- unit u = part u % 4 of chunk u / 4 -- put the only units that have
+    //  work in sparse text, the parts 0, on workgroups 0, 4, 8 ...: workgroups go round the 8 XCDs, so two of them did everything, 1.4 -> 5 ms.)
+    const int64_t nchunks = (P.nsub + 63) / 64;
+    for (int64_t u = c0; u < nchunks * kLongParts; u += cstep) {
+        const int64_t c = u % nchunks;
+        const int part = (int)(u / nchunks);
         const int64_t t = c * 64 + lane;
         int my_nl = 0;
         if (t < P.nsub) {
@@ -1321,7 +1326,7 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                 constexpr bool lane32 = false;
 #endif
                 const bool small = compact && len <= 64;         // alive bits in registers: the state is pr[] alone
-                const bool mine = valid && len <= kLanePiece;    // (a longer piece keeps its entry as it is: k_merge_coop answers it -- k_probe has flagged its sub-tile)
+                const bool mine = valid && len <= lane_piece;    // (a longer piece keeps its entry as it is: k_merge_coop answers it -- k_probe has flagged its sub-tile)
                 int need = 0;
                 if (mine) {
                     need = ((nbw + 3) & ~3) + (small ? tkz_bpe_var_n4(len) : compact ? tkz_bpe_varc_dwords(len) : tkz_bpe_var_dwords(len));
@@ -1433,11 +1438,17 @@ TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
     // The pieces wait in a queue (k_list_stats: sub-tile << 10 | index in its long list); a wavefront takes the next one off a ticket counter until
     // there is none.  (Until round 5 a wavefront owned chunks of 64 sub-tiles and merged the pieces of a chunk one after the other: a file of CJK prose --
     // 64 KiB of nothing but such pieces -- kept ONE wavefront busy for milliseconds.)
+    // (a workgroup's FIRST piece is the one with its own number -- no atomic at all when the queue is shorter than the grid, in particular when it is
+    //  empty: two thousand device-scope atomics on one address are not free --, the later ones come off the ticket counter)
     const unsigned long long count = *P.coop_count < (unsigned long long)P.coop_cap ? *P.coop_count : (unsigned long long)P.coop_cap;
+    bool first = true;
     for (;;) {
-        unsigned long long tk = 0;
-        if (lane == 0) tk = simt::atomic_add64(P.coop_ticket, 1ull);
-        tk = ((unsigned long long)simt::shflu((uint32_t)(tk >> 32), 0) << 32) | simt::shflu((uint32_t)tk, 0);
+        unsigned long long tk = (unsigned long long)simt::bid();
+        if (!first) {
+            if (lane == 0) tk = (unsigned long long)simt::nblocks() + simt::atomic_add64(P.coop_ticket, 1ull);
+            tk = ((unsigned long long)simt::shflu((uint32_t)(tk >> 32), 0) << 32) | simt::shflu((uint32_t)tk, 0);
+        }
+        first = false;
         if (tk >= count) break;
         const uint64_t qe = P.coop_q[tk];
         const int64_t sub = (int64_t)(qe >> 10);
@@ -2007,6 +2018,30 @@ TKZ_KERNEL(256) void k_docoffs(const int64_t* offs, int64_t n_docs, int64_t tota
     }
 }
 
+// TKZ_OPT_CASE_EQUIVALENCE (cl100k on a .NET >= 7 host): `(?i:'s|'t|...)` there is matched with the runtime's case-equivalence tables, under which
+// U+017F (LATIN SMALL LETTER LONG S, bytes C5 BF) is an `s`: an apostrophe at which a match starts, followed by U+017F, IS the contraction -- the piece
+// ends behind the long s.  Every scanner treats U+017F as the letter it is (net6.0: ASCII case pairs only; the apostrophe is then the one-char prefix
+// of the word that follows), so the only difference is one more piece start: right behind the long s.  This pass over the text adds it, whichever scanner
+// wrote the bitmap.  (None of the other letters of the seven literals has a non-ASCII equivalent: U+212A KELVIN SIGN is a `k`.)
+TKZ_KERNEL(256) void k_case_equiv_fix(const uint8_t* bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits) {
+    const int64_t stride = simt::nblocks() * simt::nthreads() * 8;
+    for (int64_t i0 = (simt::bid() * (int64_t)simt::nthreads() + simt::tid()) * 8; i0 < total; i0 += stride) {
+        uint64_t w = 0;                                      // (bytes is 16-byte aligned; nothing is read beyond `total`)
+        if (i0 + 8 <= total) w = *reinterpret_cast<const uint64_t*>(bytes + i0);
+        else for (int k = 0; i0 + k < total; ++k) w |= (uint64_t)bytes[i0 + k] << (8 * k);
+        const uint64_t x = w ^ 0x2727272727272727ull;
+        if (!((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull)) continue;      // no apostrophe among these eight bytes
+        for (int k = 0; k < 8; ++k) {
+            const int64_t i = i0 + k;
+            if (i + 3 > total || ((w >> (8 * k)) & 0xFFu) != 0x27u) continue;
+            if (bytes[i + 1] != 0xC5u || bytes[i + 2] != 0xBFu) continue;
+            if (!((startbits[i >> 6] >> (i & 63)) & 1ull)) continue;                     // no match starts at the apostrophe
+            if (((docbits[(i + 1) >> 6] >> ((i + 1) & 63)) & 1ull) || ((docbits[(i + 2) >> 6] >> ((i + 2) & 63)) & 1ull)) continue;   // (the document ends behind the apostrophe)
+            simt::atomic_or64((unsigned long long*)&startbits[(i + 3) >> 6], 1ull << ((i + 3) & 63));
+        }
+    }
+}
+
 // document offsets of a chunk cut out of a larger batch: made relative to the chunk's first byte
 TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
@@ -2511,8 +2546,8 @@ TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
     if (wave == 0) {
         const LongLds LD = tkz_long_lds(s_raw);
         tkz_long_brank_init(T, LD.brank);
-        if (T.max_rank <= kVarCompactMaxRank) tkz_merge_long_chunks<true>(T, P, 0, 1, LD);
-        else tkz_merge_long_chunks<false>(T, P, 0, 1, LD);
+        if (T.max_rank <= kVarCompactMaxRank) tkz_merge_long_chunks<true>(T, P, 0, 1, LD, kSmallLanePiece);
+        else tkz_merge_long_chunks<false>(T, P, 0, 1, LD, kSmallLanePiece);
     }
     simt::sync();
     stamp();
@@ -2676,6 +2711,9 @@ void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int6
     hook(L, K_DOCOFFS, 0);
     TKZ_LAUNCH(k_docoffs, grid_for(n_docs + 1), kThreads, L.stream, d_offs, n_docs, total, tile_base, docbits, docord_base, doc_tok, grand, out_offs, c3_docs, c3a, c3b, c3c);
     hook(L, K_DOCOFFS, 1);
+}
+void launch_case_equiv_fix(const Launch& L, const uint8_t* d_bytes, int64_t total, const uint64_t* docbits, uint64_t* startbits) {
+    TKZ_LAUNCH(k_case_equiv_fix, grid_for((total + 7) / 8), kThreads, L.stream, d_bytes, total, docbits, startbits);
 }
 void launch_rebase(const Launch& L, int64_t* offs, int64_t n, int64_t base) {
     TKZ_LAUNCH(k_rebase, grid_for(n), kThreads, L.stream, offs, n, base);
