@@ -35,6 +35,9 @@ namespace Microsoft.DeepDev
         [DllImport(Lib)] internal static extern int tkz_pattern_from_regex(byte[] regexUtf8Z, out int pattern);   // .NET semantics (TikTokenizer.cs:77): the o200k string gives TKZ_PATTERN_O200K_DOTNET
         [DllImport(Lib)] internal static extern int tkz_encoder_create(IntPtr vocab, int pattern, int device, out IntPtr encoder);
         [DllImport(Lib)] internal static extern int tkz_encoder_set_option(IntPtr encoder, int option, long value);
+        [DllImport(Lib)] internal static extern int tkz_encoder_set_unicode_classes(IntPtr encoder, byte[] classes, long nCodePoints);   // the HOST's Unicode classification (TikTokenizer.cs:77: the running process's regex engine defines the split)
+        [DllImport(Lib)] internal static extern int tkz_host_alloc(UIntPtr bytes, out IntPtr p);        // page-locked memory: copies to and from it run at the PCIe rate
+        [DllImport(Lib)] internal static extern void tkz_host_free(IntPtr p);
         [DllImport(Lib)] internal static extern void tkz_encoder_destroy(IntPtr encoder);
         [DllImport(Lib)] internal static extern unsafe int tkz_encode_batch_utf8(IntPtr encoder, byte* bytes, long* docOffsets, long nDocs,
                                                                                   int* outIds, long outCap, long* outOffsets, out long needed);
@@ -100,8 +103,37 @@ namespace Microsoft.DeepDev
         protected override bool ReleaseHandle() { Tkz.tkz_encoder_destroy(handle); return true; }
     }
 
+    /// <summary>Two grow-only page-locked buffers (tkz_host_alloc) a tokenizer keeps from call to call: the code units on their way to the
+    /// device, the ids on their way back.  Used under `lock`: one EncodeBatchFlat at a time per tokenizer (the device call is the long part).</summary>
+    internal sealed class PinnedBuffers : IDisposable
+    {
+        private IntPtr units, ids; private long unitsCap, idsCap;
+        private static IntPtr Ensure(ref IntPtr p, ref long cap, long bytes)
+        {
+            if (bytes > cap)
+            {
+                if (p != IntPtr.Zero) Tkz.tkz_host_free(p);
+                p = IntPtr.Zero; cap = 0;
+                long want = bytes + bytes / 4 + 4096;
+                Tkz.Check(Tkz.tkz_host_alloc((UIntPtr)(ulong)want, out p));
+                cap = want;
+            }
+            return p;
+        }
+        public IntPtr Units(long bytes) => Ensure(ref units, ref unitsCap, bytes);
+        public IntPtr Ids(long bytes) => Ensure(ref ids, ref idsCap, bytes);
+        public void Dispose()
+        {
+            if (units != IntPtr.Zero) Tkz.tkz_host_free(units);
+            if (ids != IntPtr.Zero) Tkz.tkz_host_free(ids);
+            units = ids = IntPtr.Zero; unitsCap = idsCap = 0;
+        }
+        ~PinnedBuffers() { Dispose(); }
+    }
+
     public sealed class GpuTikTokenizer : ITokenizer, IDisposable
     {
+        private readonly PinnedBuffers pinned = new PinnedBuffers();
         private readonly EncoderHandle handle;
         private IntPtr encoder => handle.DangerousGetHandle();
         private readonly IReadOnlyDictionary<string, int> specialTokensEncoder;
@@ -127,6 +159,45 @@ namespace Microsoft.DeepDev
             RegisterSpecialTokensForDecode();
             // the LRU piece memo (LRUCache.cs; no effect on results) lives on the device with a fixed size: cacheSize says whether it is used
             if (cacheSize <= 0) Tkz.Check(Tkz.tkz_encoder_set_option(handle.DangerousGetHandle(), 2 /* TKZ_OPT_PIECE_MEMO */, 0));
+            UseThisRuntimesRegexSemantics();
+        }
+
+        /// <summary>The reference's split is `new Regex(pattern, RegexOptions.Compiled)` of the RUNNING process (TikTokenizer.cs:77): \p{L}, \p{N} ... are the
+        /// categories of this runtime's Unicode data (13.0 under net6.0, 15.0 under .NET 8) and (?i:...) is this runtime's case folding (ASCII pairs up to
+        /// .NET 6; the case-equivalence tables from .NET 7 on, under which U+017F is an `s`).  libtkz is built for net6.0; here it is told what THIS
+        /// runtime says: the class of every UTF-16 code unit (all that pattern 1, cl100k and the o200k string through .NET's engine ever look at), and
+        /// the case mode.</summary>
+        private void UseThisRuntimesRegexSemantics()
+        {
+            var classes = new byte[65536];
+            for (int c = 0; c < 65536; ++c)
+            {
+                char ch = (char)c;
+                byte k;
+                switch (char.GetUnicodeCategory(ch))
+                {
+                    case System.Globalization.UnicodeCategory.UppercaseLetter: k = 1; break;
+                    case System.Globalization.UnicodeCategory.LowercaseLetter: k = 2; break;
+                    case System.Globalization.UnicodeCategory.TitlecaseLetter: k = 3; break;
+                    case System.Globalization.UnicodeCategory.ModifierLetter: k = 4; break;
+                    case System.Globalization.UnicodeCategory.OtherLetter: k = 5; break;
+                    case System.Globalization.UnicodeCategory.NonSpacingMark:
+                    case System.Globalization.UnicodeCategory.SpacingCombiningMark:
+                    case System.Globalization.UnicodeCategory.EnclosingMark: k = 6; break;
+                    case System.Globalization.UnicodeCategory.DecimalDigitNumber:
+                    case System.Globalization.UnicodeCategory.LetterNumber:
+                    case System.Globalization.UnicodeCategory.OtherNumber: k = 7; break;
+                    // \s of System.Text.RegularExpressions: [\f\n\r\t\v\x85\p{Z}]
+                    case System.Globalization.UnicodeCategory.SpaceSeparator:
+                    case System.Globalization.UnicodeCategory.LineSeparator:
+                    case System.Globalization.UnicodeCategory.ParagraphSeparator: k = 8; break;
+                    default: k = (byte)((c >= 9 && c <= 13) || c == 0x85 ? 8 : 0); break;
+                }
+                classes[c] = k;
+            }
+            Tkz.Check(Tkz.tkz_encoder_set_unicode_classes(encoder, classes, classes.Length));
+            // Environment.Version: 4.x on .NET Framework, 3.1 on .NET Core 3.1, 5 / 6 / 7 / 8 ... on .NET 5+
+            Tkz.Check(Tkz.tkz_encoder_set_option(encoder, 7 /* TKZ_OPT_CASE_EQUIVALENCE */, Environment.Version.Major >= 7 ? 1 : 0));
         }
 
         // SpecialTokensDecoder (TikTokenizer.cs:79) for the device Decode
@@ -166,9 +237,8 @@ namespace Microsoft.DeepDev
         }
 
         /// <summary>EncodeBatch without a List per text: text t is Ids[Offsets[t] .. Offsets[t + 1]).  When no special token applies
-        /// (the reference's plain path, TikTokenizer.cs:180-183,196-199) Offsets is the device call's own output and Ids its own
-        /// buffer, untouched (it may be longer than Offsets[texts.Count]: it is sized before the token count is known); otherwise the special ids are
-        /// spliced in between the plain segments' ids with block copies.</summary>
+        /// (the reference's plain path, TikTokenizer.cs:180-183,196-199) Offsets is the device call's own output and Ids holds exactly
+        /// Offsets[texts.Count] ids; otherwise the special ids are spliced in between the plain segments' ids with block copies.</summary>
         public unsafe (int[] Ids, long[] Offsets) EncodeBatchFlat(IReadOnlyList<string> texts, IReadOnlyCollection<string>? allowedSpecial = null)
         {
             bool plain = allowedSpecial is null || allowedSpecial.Count == 0 || specialTokensEncoder.Count == 0;
@@ -201,30 +271,52 @@ namespace Microsoft.DeepDev
                     if (start >= text.Length) break;
                 }
             }
-            // 2. the plain segments as one batch of UTF-16 code units: a memcpy per string; Encoding.UTF8.GetBytes
-            //    (TikTokenizer.cs:261) is done for the whole batch on the device by tkz_encode_batch_utf16
-            var unitOffsets = new long[segments.Count + 1];
+            // 2. the plain segments as one batch of UTF-16 code units in PAGE-LOCKED memory (tkz_host_alloc; kept from call to call): the strings are
+            //    copied by all cores (Parallel.For over slices of the batch: one thread copying 10^6 strings into a fresh `new char[]` and a fresh
+            //    `new int[]` for the ids -- both zero-filled by the runtime first -- ran at 1 GB/s in the C++ stand-in of this method, the library
+            //    behind it at 14); Encoding.UTF8.GetBytes (TikTokenizer.cs:261) is done for the whole batch on the device by tkz_encode_batch_utf16.
+            int nseg = segments.Count;
+            var unitOffsets = new long[nseg + 1];
             long total = 0;
-            for (int i = 0; i < segments.Count; ++i) { unitOffsets[i] = total; total += segments[i].end - segments[i].start; }
-            unitOffsets[segments.Count] = total;
-            var units = new char[Math.Max(1, total)];
-            for (int i = 0; i < segments.Count; ++i)
-                segments[i].text.CopyTo(segments[i].start, units, (int)unitOffsets[i], segments[i].end - segments[i].start);
-            // A code unit is at most three UTF-8 bytes and a token at least one byte, so 3 * total ids always suffice; text has a token per
-            // ~4 units, so the first call gets room for one per two and the call is repeated with the exact count (the library reports
-            // it with TKZ_E_CAPACITY = -4) only when that was not enough.
-            long cap = Math.Max(1, Math.Min(3 * total, total / 2 + 4096));
+            for (int i = 0; i < nseg; ++i) { unitOffsets[i] = total; total += segments[i].end - segments[i].start; }
+            unitOffsets[nseg] = total;
             int[] ids;
-            var segOffsets = new long[segments.Count + 1];
-            while (true)
+            var segOffsets = new long[nseg + 1];
+            lock (pinned)
             {
-                ids = new int[cap];
-                int st; long needed;
-                fixed (char* pu = units) fixed (long* po = unitOffsets) fixed (int* pi = ids) fixed (long* poo = segOffsets)
-                    st = Tkz.tkz_encode_batch_utf16(encoder, pu, po, segments.Count, pi, cap, poo, out needed);
-                if (st == -4 && needed > cap) { cap = needed; continue; }
-                Tkz.Check(st);
-                break;
+                IntPtr unitsPtr = pinned.Units((total + 32) * 2);       // (an IntPtr: a lambda cannot capture a pointer-typed local)
+                char* units = (char*)unitsPtr;
+                int slices = Math.Max(1, Math.Min(Environment.ProcessorCount, nseg / 4096));
+                System.Threading.Tasks.Parallel.For(0, slices, sl =>
+                {
+                    char* dstUnits = (char*)unitsPtr;
+                    int lo = (int)((long)nseg * sl / slices), hi = (int)((long)nseg * (sl + 1) / slices);
+                    for (int i = lo; i < hi; ++i)
+                    {
+                        int n = segments[i].end - segments[i].start;
+                        if (n == 0) continue;
+                        fixed (char* src = segments[i].text)
+                            Buffer.MemoryCopy(src + segments[i].start, dstUnits + unitOffsets[i], (long)n * 2, (long)n * 2);
+                    }
+                });
+                // A code unit is at most three UTF-8 bytes and a token at least one byte, so 3 * total ids always suffice; text has a token per
+                // ~4 units, so the first call gets room for one per two and the call is repeated with the exact count (the library reports
+                // it with TKZ_E_CAPACITY = -4) only when that was not enough.
+                long cap = Math.Max(1, Math.Min(3 * total, total / 2 + 4096));
+                long needed;
+                while (true)
+                {
+                    int* pi = (int*)pinned.Ids(cap * 4);
+                    int st;
+                    fixed (long* po = unitOffsets) fixed (long* poo = segOffsets)
+                        st = Tkz.tkz_encode_batch_utf16(encoder, units, po, nseg, pi, cap, poo, out needed);
+                    if (st == -4 && needed > cap) { cap = needed; continue; }
+                    Tkz.Check(st);
+                    break;
+                }
+                // the ids leave the page-locked buffer as an array of exactly their number
+                ids = new int[Math.Max(1, needed)];
+                fixed (int* dst = ids) Buffer.MemoryCopy((void*)pinned.Ids(0), dst, needed * 4, needed * 4);
             }
             if (plain) return (ids, segOffsets);
             // 3. splice the special ids in: block copies of the segments' id ranges
@@ -365,7 +457,7 @@ namespace Microsoft.DeepDev
             return result;
         }
 
-        public void Dispose() { handle.Dispose(); }                              // idempotent (SafeHandle)
+        public void Dispose() { pinned.Dispose(); GC.SuppressFinalize(pinned); handle.Dispose(); }      // idempotent (SafeHandle; the buffers null their pointers)
     }
 
     /// <summary>One rank of a sharded job (BASELINE configs[3]): rank r of `world` encodes documents tkz_shard_range(r) on its own GPU;

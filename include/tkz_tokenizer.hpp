@@ -295,6 +295,11 @@ public:
         return ids;
     }
     tkz_encoder* native() const { return enc_; }
+    // The split is whatever the HOST's regex engine makes of the pattern (TikTokenizer.cs:77 compiles it in the running process).  A host on another
+    // runtime than net6.0 hands its Unicode classification over (classes[cp] in 0..8 for cp < n: 65536 code units or 1114112 code points; nullptr:
+    // the built-in Unicode 13.0 table) and says how it reads cl100k's (?i:...): .NET >= 7 folds U+017F onto `s`.
+    void SetUnicodeClasses(const uint8_t* classes, int64_t n_code_points) { check(tkz_encoder_set_unicode_classes(enc_, classes, n_code_points)); }
+    void SetCaseEquivalence(bool dotnet7_or_later) { check(tkz_encoder_set_option(enc_, TKZ_OPT_CASE_EQUIVALENCE, dotnet7_or_later ? 1 : 0)); }
 
 private:
     struct Segment { bool special; int32_t id; size_t begin, end; };          // bytes [begin, end) of the text

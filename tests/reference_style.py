@@ -120,6 +120,32 @@ def run_by_name_suite(lib, vocab_bytes, oracle_mod, tmpdir):
         TK.TokenizerBuilder.CreateByModelName("no-such-model", vocab_dir=d, lib=lib)
 
 
+def run_host_runtime_suite(lib, gpt2_bytes, oracle_mod, oracle_vocab):
+    """The mirror's two knobs for a host on another runtime than net6.0: this Python's own Unicode tables (a newer version than the 13.0 libtkz ships)
+    as the class table, and .NET >= 7's (?i:...).  Against the oracle given the same."""
+    import unicodedata
+    from tokenizer_amd import host_unicode_classes
+    classes = host_unicode_classes(n_code_points=65536)
+    builtin = np.zeros(65536, np.uint8)
+    lib.L.tkz_unicode_classes(0, 65536, builtin.ctypes.data)
+    moved = np.flatnonzero(classes[128:] != builtin[128:]) + 128
+    moved = moved[(moved < 0xD800) | (moved > 0xDFFF)]
+    assert unicodedata.unidata_version >= "13.0.0"
+    tok = TokenizerBuilder.CreateTokenizer(gpt2_bytes, {}, REGEX_CL100K, lib=lib, unicode_classes=classes, case_equivalence=True)
+    try:
+        oracle_mod.set_unicode_classes(classes)
+        oracle_mod.set_case_equivalence(True)
+        oenc = oracle_mod.Encoder(oracle_vocab, oracle_mod.CL100K)
+        texts = ["it'ſ fine'ſabc", "Hello World it's 12345", "".join(chr(int(c)) + "a1 " for c in moved[:400]), "漢字かな交じり文 😀 naïve"]
+        for t in texts:
+            assert tok.Encode(t, False) == oenc.encode(t), t
+        assert tok.EncodeBatch(texts, False) == [oenc.encode(t) for t in texts]
+    finally:
+        oracle_mod.set_unicode_classes(None)
+        oracle_mod.set_case_equivalence(False)
+    return int(len(moved))
+
+
 def run_trim_suite(tok, trim_oracle, specials, long_text):
     """TestEncodeTrimSuffix/2, TestEncodeTrimPrefix/2 (TikTokenizerUnitTest.cs:128-225): the same scenarios, every
     maxTokenCount from 0 past the full length, all three overload shapes, against the oracle's restatement of

@@ -300,6 +300,11 @@ def test_reference_unit_tests_restated(lib, gpt2_tiktoken_bytes, lib_rs_bytes, o
     reference_style.run_cl100k_suite(lib)      # runs only when cl100k_base.tiktoken is supplied
 
 
+def test_mirror_takes_the_hosts_runtime(lib, gpt2_tiktoken_bytes, oracle_mod, oracle_gpt2):
+    import reference_style
+    reference_style.run_host_runtime_suite(lib, gpt2_tiktoken_bytes, oracle_mod, oracle_gpt2)
+
+
 def test_builders_by_name_pick_the_defining_engine(lib, vocab_bytes, oracle_mod, tmp_path):
     import reference_style
     reference_style.run_by_name_suite(lib, vocab_bytes, oracle_mod, tmp_path)

@@ -9,9 +9,9 @@ Everything below the class surface is libtkz (tokenizer_amd/csrc, C ABI in inclu
 HIP kernels for gfx950.  There is no CPU implementation in this package.
 """
 from .tokenizer import (ENCODERS, MODEL_PREFIX_TO_ENCODING, MODEL_TO_ENCODING, REGEX_CL100K, REGEX_O200K, REGEX_PATTERN_1,
-                        TikTokenizer, TokenizerBuilder)
+                        TikTokenizer, TokenizerBuilder, host_unicode_classes)
 
 from .shardfile import Shard, write_shard
 
 __all__ = ["Shard", "write_shard", "TikTokenizer", "TokenizerBuilder", "REGEX_PATTERN_1", "REGEX_CL100K", "REGEX_O200K", "ENCODERS",
-           "MODEL_TO_ENCODING", "MODEL_PREFIX_TO_ENCODING"]
+           "MODEL_TO_ENCODING", "MODEL_PREFIX_TO_ENCODING", "host_unicode_classes"]

@@ -76,6 +76,23 @@ ENCODERS = {
 ENCODER_ENGINE = {"o200k_base": "js"}
 
 
+def host_unicode_classes(ucd=None, n_code_points: int = 0x110000, engine: str = "dotnet"):
+    """The class table a host hands to TikTokenizer(unicode_classes=...): class 0..8 of every code point below n_code_points (65536: code units) from
+    a `unicodedata`-like module (default: this Python's -- another Unicode version than the 13.0 libtkz is built with).  \\s is .NET's
+    ([\\f\\n\\r\\t\\v\\x85\\p{Z}]) or, engine="js", ECMAScript's as far as the table holds it (U+FEFF / U+0085 are the library's business there)."""
+    import unicodedata
+    ucd = ucd or unicodedata
+    out = np.zeros(n_code_points, np.uint8)
+    code = {"Lu": 1, "Ll": 2, "Lt": 3, "Lm": 4, "Lo": 5, "Mn": 6, "Mc": 6, "Me": 6, "Nd": 7, "Nl": 7, "No": 7, "Zs": 8, "Zl": 8, "Zp": 8}
+    for cp in range(n_code_points):
+        if 0xD800 <= cp <= 0xDFFF:
+            continue
+        out[cp] = code.get(ucd.category(chr(cp)), 0)
+    for cp in (9, 10, 11, 12, 13, 0x85):
+        out[cp] = 8
+    return out
+
+
 def _utf8_like_dotnet(s: str) -> bytes:
     """Encoding.UTF8.GetBytes: a lone surrogate becomes U+FFFD (TikTokenizer.cs:261)."""
     try:
@@ -89,7 +106,8 @@ class TikTokenizer:
     bytes of a .tiktoken rank file (the reference takes a Stream, TikTokenizer.cs:60-65)."""
 
     def __init__(self, tikTokenBpeFile: bytes, specialTokensEncoder: Optional[Dict[str, int]], pattern: str,
-                 cacheSize: int = 8192, device: int = 0, lib: Optional[N.Library] = None, host: str = "dotnet"):
+                 cacheSize: int = 8192, device: int = 0, lib: Optional[N.Library] = None, host: str = "dotnet",
+                 unicode_classes=None, case_equivalence: bool = False):
         """`host` names the regex engine whose reading of `pattern` is wanted: "dotnet" (the default: `new Regex(pattern,
         RegexOptions.Compiled)`, TikTokenizer.cs:77 -- UTF-16 code units, .NET's \\s) or "js" (`new RegExp(pattern, "gu")`,
         tokenizer_ts/src/tikTokenizer.ts:100 -- code points, ECMAScript's \\s; implemented for the o200k string only, the one
@@ -103,6 +121,13 @@ class TikTokenizer:
         self._lib.check(pat(pattern.encode("utf-8"), N.ENGINE_ECMASCRIPT if host == "js" else N.ENGINE_DOTNET, C.byref(out)))
         self._vocab = N.Vocab(tikTokenBpeFile, self._lib)     # FormatError / DuplicateRankError as in LoadTikTokenBpe + Init
         self._encoder = N.Encoder(self._vocab, out.value, device)
+        # The split is whatever the HOST's regex engine makes of the pattern (TikTokenizer.cs:77 compiles it in the running process): `unicode_classes`
+        # hands that runtime's classification over (uint8[65536] per code unit, or uint8[1114112] per code point; host_unicode_classes() builds
+        # one from a `unicodedata`-like module), `case_equivalence` is .NET >= 7's reading of cl100k's (?i:...) ('ſ is 's).  Default: net6.0's.
+        if unicode_classes is not None:
+            self._encoder.set_unicode_classes(unicode_classes)
+        if case_equivalence:
+            self._encoder.set_option(N.OPT_CASE_EQUIVALENCE, 1)
         # the reference's LRU piece memo (LRUCache.cs; no effect on results) lives on the device with a fixed size: cacheSize only says
         # whether it is used (the reference's LRUCache of size 0 keeps nothing)
         if cacheSize <= 0:
@@ -344,5 +369,6 @@ class TokenizerBuilder:
 
     @staticmethod
     def CreateTokenizer(tikTokenBpeFile: bytes, specialTokensEncoder: Optional[Dict[str, int]], pattern: str, cacheSize: int = 8192,
-                        device: int = 0, lib: Optional[N.Library] = None, host: str = "dotnet") -> TikTokenizer:
-        return TikTokenizer(tikTokenBpeFile, specialTokensEncoder, pattern, cacheSize, device, lib, host)
+                        device: int = 0, lib: Optional[N.Library] = None, host: str = "dotnet", unicode_classes=None,
+                        case_equivalence: bool = False) -> TikTokenizer:
+        return TikTokenizer(tikTokenBpeFile, specialTokensEncoder, pattern, cacheSize, device, lib, host, unicode_classes, case_equivalence)
