@@ -425,6 +425,11 @@ def main():
             en.set_option(N.OPT_PIECE_MEMO, 0)
             nt = step(en)
             en.set_option(N.OPT_PIECE_MEMO, 1)
+        # What the encoder promoted out of its memo during the warm-up stays; nothing more is learnt from here on: a timed step must not be the
+        # encoder's next learning batch (it counts hits and ends with the key tables rebuilt on the host: tens of milliseconds, once or twice in an
+        # encoder's life -- with --warmup 2 the second of them fell into the timed loop: 29.6 ms a step instead of 21.6)
+        if not empty_memo_each_step:
+            en.set_option(N.OPT_PROMOTE, 0)
         return nt
 
     def timed(en, steps):
@@ -527,6 +532,7 @@ def main():
             step(); step()
             memo_on[id(enc)] = True
             fence()
+        enc.set_option(N.OPT_PROMOTE, 0)
     # the same corpus under a stand-in vocabulary that has never seen it (tools/train_bpe.py synth100k_heldout: the same size and recipe
     # WITHOUT the bench's generator in the training text): `value_heldout_vocab`.  synth100k is trained on the generator's own output, so
     # its whole-piece hit rate flatters; the real cl100k_base lies somewhere between the two.  Its own encoder, its own memo, the same

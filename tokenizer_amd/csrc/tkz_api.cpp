@@ -468,7 +468,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             if (attempt == 0 && !ws->learning && pretok && !d_bitmap_only && e->promo_mode == 1 && !e->learning && e->promo_rounds < kPromoAutoRounds &&
                 e->T.memo_n != 0 && e->T.max_rank < (int32_t)kPromoFlag && total >= e->promo_min_bytes && e->promo_items.size() < e->promo_cap &&
                 (e->promo_rounds == 0 || e->bytes_seen - e->bytes_at_promo >= kPromoSecondBytes)) {
-                if (e->t_memo_hits.ensure((size_t)e->memo_slots * 4, &e->bytes_allocated) == hipSuccess) { e->learning = true; ws->learning = true; }
+                // (the gigabyte to the second round counts from the START of the first learning batch: a job of 5 GB batches learns in its first two)
+                if (e->t_memo_hits.ensure((size_t)e->memo_slots * 4, &e->bytes_allocated) == hipSuccess) { e->learning = true; ws->learning = true; e->bytes_at_promo = e->bytes_seen; }
             }
             T = e->T;
         }
@@ -663,7 +664,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                 g_err = keep_msg;
                 (void)ps;
                 std::lock_guard<std::mutex> lock(e->mu);
-                ws->learning = false; e->learning = false; ++e->promo_rounds; e->bytes_at_promo = e->bytes_seen;
+                ws->learning = false; e->learning = false; ++e->promo_rounds;
             }
         }
         if (!d_bitmap_only) {
