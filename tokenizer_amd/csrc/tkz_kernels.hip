@@ -1528,11 +1528,30 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         return c;
     };
     Sc nxt = load_sc(sub0);
+    // the lane's four records of the FIRST chunk of a sub-tile (records 4 * lane .. + 3: one 16-byte load)
+    auto load_recs = [&](int64_t pb_, int np_, int kk, uint32_t* r) {
+        const int k0 = kk + 4 * lane;
+        r[0] = r[1] = r[2] = r[3] = 0u;
+        if (k0 < np_) {
+            if (pb_ + k0 + 4 <= P.prank_cap) { const uint4 v = tkz_load16_nt(&P.prank[pb_ + k0]); r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+            else for (int j = 0; j < 4; ++j) if (pb_ + k0 + j < P.prank_cap) r[j] = (uint32_t)P.prank[pb_ + k0 + j];
+        }
+    };
+#ifndef TKZ_PLACE_NO_PREFETCH
+    // ... requested one sub-tile AHEAD (round 5): the records of sub-tile s + 1 travel while sub-tile s is placed, so that a sub-tile is ONE dependent
+    // round trip (its list answers) instead of two (answers, then records); and the token quads of promoted pieces (PROMO), which depend on the
+    // records, can be asked for at the top of the iteration, beside the answers.
+    uint32_t rn[4];
+    load_recs(nxt.pb, nxt.np, 0, rn);
+#endif
 #pragma unroll 1
     for (int it = 0; it < kPlacePer && sub0 + it < P.nsub; ++it) {
     const int64_t sub = sub0 + it;
     const Sc cur = nxt;
     if (it + 1 < kPlacePer && sub + 1 < P.nsub) nxt = load_sc(sub + 1);
+#ifndef TKZ_PLACE_NO_PREFETCH
+    uint32_t rc[4] = {rn[0], rn[1], rn[2], rn[3]};            // this sub-tile's first chunk
+#endif
     const int64_t pb = cur.pb, tb = cur.tb, base = sub * kSub, ord0 = cur.ord0;
     const int np = cur.np;
     const uint32_t mc = cur.mc;
@@ -1578,6 +1597,9 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         fast_ok = lists_ok && !has_giant && ns + nl <= kPlaceSlots && !simt::ballot(big);
     }
     (void)simt::ballot(true);
+#ifndef TKZ_PLACE_NO_PREFETCH
+    if (it + 1 < kPlacePer && sub + 1 < P.nsub) load_recs(nxt.pb, nxt.np, 0, rn);      // (nxt's scalars arrived with this sub-tile's answers)
+#endif
     // the answer a merge kernel left for a missed piece (its list entry): how many tokens, and where they wait
     auto answer = [&](uint32_t rec) -> uint32_t {
         if (rec & kPrGiant) return tkz_result_entry(false, 1, (int)(rec & 1023u));     // (count: gcnt, see below; the tokens wait in tmp at the piece's position)
@@ -1624,11 +1646,11 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     // of the long one; lane l owns slots l and l + 64): the lane that holds the record only tells it the position. ----
     auto place_fast = [&](int kk) -> bool {
         const int k0 = kk + 4 * lane;
-        uint32_t r[4] = {0u, 0u, 0u, 0u};
-        if (k0 < np) {
-            if (pb + k0 + 4 <= P.prank_cap) { const uint4 v = tkz_load16_nt(&P.prank[pb + k0]); r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
-            else for (int j = 0; j < 4; ++j) if (pb + k0 + j < P.prank_cap) r[j] = (uint32_t)P.prank[pb + k0 + j];
-        }
+        uint32_t r[4];
+#ifndef TKZ_PLACE_NO_PREFETCH
+        if (kk == 0) { r[0] = rc[0]; r[1] = rc[1]; r[2] = rc[2]; r[3] = rc[3]; } else
+#endif
+        load_recs(pb, np, kk, r);
         int c[4], idx[4];
         bool ok[4], ms[4], pm[4];
         uint4 pq[4];
