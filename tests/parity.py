@@ -443,6 +443,29 @@ def check_promotion(lib, O, vocab, ovocab, pattern=N.CL100K, seed=61):
     assert ids.tolist() == e_a + e_b
     st2 = enc2.piece_stats(reset=True)
     assert st2["short_misses"] <= st1["short_misses"] - int(0.8 * st1["memo_hits"]) and st1["memo_hits"] > 1000, (st1, st2)      # (the hits are sampled: one group in eight)
+    # pieces of 17..28 bytes that repeat and merge into at most 4 tokens (k_merge_long logs them during the learning batch) are promoted too: the
+    # indentation runs of source code -- "\n" + 16..27 blanks -- under a table that holds runs of blanks as keys
+    lines = []
+    r4 = random.Random(seed + 4)
+    for _ in range(7000):                                 # (more than the single-launch path takes: it keeps no statistics)
+        lines.append("\n" + " " * r4.choice([16, 19, 20, 23, 24, 27, 31, 40]) + r4.choice(["return x", "if a:", "pass", "x = 1"]))
+    code = "".join(lines).encode()
+    cdocs = [code[i:i + 30000] for i in range(0, len(code), 30000)]
+    cexp, ceoff = oracle_encode_docs(oenc, cdocs)
+    enc4 = N.Encoder(vocab, pattern)
+    enc4.set_option(N.OPT_PROMOTE_MIN_BYTES, 20000)
+    enc4.set_option(N.OPT_PIECE_STATS, 1)
+    cdata, coffs = pack(cdocs)
+    long_misses = []
+    for rep in range(2):
+        enc4.piece_stats(reset=True)
+        ids, ooff = enc4.encode_batch(cdata, coffs)
+        assert ids.tolist() == cexp and ooff.tolist() == ceoff, rep
+        long_misses.append(enc4.piece_stats(reset=True)["long_misses"])
+    # (pattern 1 cuts "\n" + n - 1 blanks -- the last blank goes with the word --; cl100k cuts the "\n" off first, o200k too)
+    few_tokens = sum(1 for n in (16, 19, 20, 23, 24, 27) if ovocab.rank(b"\n" + b" " * (n - 1)) < 0 and len(ovocab.bpe(b"\n" + b" " * (n - 1))) <= 4)
+    if few_tokens >= 3 and pattern == N.P1:
+        assert long_misses[1] < long_misses[0] * 0.8, long_misses
     # the second automatic round waits for a gigabyte more: no further promotion here, and the same ids
     ids, ooff = enc2.encode_batch(data, offs)
     assert ids.tolist() == e_a + e_b and enc2.piece_stats()["promoted_pieces_in_tables"] == st1["promoted_pieces_in_tables"]

@@ -138,7 +138,7 @@ def test_piece_memo(lib, vocabs, oracle_mod, vname):
     parity.check_piece_memo(lib, oracle_mod, v, ov, pattern=N.O200K, seed=31)
 
 
-@pytest.mark.parametrize("vname,pattern", [("gpt2", N.CL100K), ("synth100k", N.CL100K), ("synth200k", N.O200K_DOTNET)])
+@pytest.mark.parametrize("vname,pattern", [("gpt2", N.CL100K), ("synth100k", N.CL100K), ("synth100k", N.P1), ("synth200k", N.O200K_DOTNET)])
 def test_promoted_pieces(lib, vocabs, oracle_mod, vname, pattern):
     v, ov = vocabs(vname)
     parity.check_promotion(lib, oracle_mod, v, ov, pattern=pattern)

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -83,6 +84,7 @@ struct CounterBlock {          // mirrors the device block
     unsigned long long giant_ticket;       // k_giant_merge's work counter
     unsigned long long xcount, xcount2;    // (adjacent: launch_pretok_rows) blocks the o200k ASCII scanner left over, blocks the multi-byte one left over as well
     unsigned long long coop_count, coop_ticket;   // k_list_stats -> k_merge_coop: queued long misses of more than kLanePiece bytes, the next one to be taken
+    unsigned long long long_log_count;     // a learning batch: records k_merge_long wanted to log (EncodeParams::long_log)
 };
 
 }  // namespace
@@ -188,6 +190,8 @@ struct tkz_encoder {
     bool learning = false;                 // a batch that counts memo hits is in flight (one at a time)
     int64_t bytes_seen = 0, bytes_at_promo = 0;   // bytes the batch path has encoded; ... when the last promotion happened
     DevBuf t_memo_hits, t_promo;           // the hit counters of a learning batch; the token quads of the promoted pieces
+    DevBuf t_long_log;                     // ... and its log of merged pieces of 17..28 bytes (EncodeParams::long_log)
+    int64_t long_log_n = 0;                // records the last learning batch left there (set when it ended)
     std::vector<DevBuf> retired;           // table images replaced by a promotion while other calls may still have been probing them: freed with the encoder
     std::vector<tkz::KeyItem> promo_items; // promoted piece -> promo code, in order of promotion
     std::unordered_set<std::string> promo_keys;
@@ -291,6 +295,7 @@ tkz_status build_decode_table(tkz_encoder* e) {
 // SHORT / MID key tables with a promo code in place of a rank (tkz_tables.h), and uploads the new images; k_probe then finds such a piece like any
 // key, the merge kernels never see it, k_place gathers its <= 4 tokens.  Results are the same ids by construction (the memo's answers are exact and a
 // slot is read back under the same validity rule the kernels use); the tests compare a promoted encoder with the oracle.
+constexpr int64_t kLongLogCap = 65536;             // records of merged 17..28-byte pieces a learning batch may log (EncodeParams::long_log)
 constexpr int kPromoAutoRounds = 2;                // automatic promotions: the first batch of >= kPromoMinBytes, and one more after kPromoSecondBytes more
 constexpr int64_t kPromoSecondBytes = int64_t(1) << 30;
 
@@ -331,15 +336,51 @@ tkz_status publish_key_tables(tkz_encoder* e, bool retire) {
 // The memo (and the hit counters of a learning batch, or null: every valid entry counts alike) is read back and its hottest entries are promoted.
 // Called with no lock held; takes e->mu for the bookkeeping and the publication.  *added: entries promoted by this call.
 tkz_status promote_from_memo(tkz_encoder* e, bool use_hits, bool retire, int64_t* added) {
+    using tkz::kLongLogDwords; using tkz::kLongLogMaxLen;
     if (added) *added = 0;
     if (!e->memo_slots || e->T.max_rank >= (int32_t)kPromoFlag) return TKZ_OK;      // (a promo code must not look like a rank)
     std::vector<TkzMemoSlot> memo(e->memo_slots);
     std::vector<uint32_t> hits;
     HIP_TRY(hipMemcpy(memo.data(), e->t_memo.p, memo.size() * sizeof(TkzMemoSlot), hipMemcpyDeviceToHost));
     if (use_hits) { hits.resize(e->memo_slots); HIP_TRY(hipMemcpy(hits.data(), e->t_memo_hits.p, hits.size() * 4, hipMemcpyDeviceToHost)); }
+    // ... and the pieces of 17..28 bytes k_merge_long logged during the learning batch (each with its <= 4 tokens): those that were logged at least
+    // twice -- real source text is full of them: "\n" + 19 spaces, by the hundred thousand -- go into the MID key table the same way
+    std::vector<uint32_t> llog;
+    if (use_hits && e->long_log_n > 0) {
+        llog.resize((size_t)e->long_log_n * kLongLogDwords);
+        HIP_TRY(hipMemcpy(llog.data(), e->t_long_log.p, llog.size() * 4, hipMemcpyDeviceToHost));
+    }
     std::lock_guard<std::mutex> lock(e->mu);
     const size_t cap = e->promo_cap;
     if (e->promo_items.size() >= cap) return TKZ_OK;
+    int64_t n_new = 0;
+    if (!llog.empty()) {
+        struct LongCand { uint32_t count; uint32_t rec; };
+        std::unordered_map<std::string, LongCand> seen;
+        for (int64_t r = 0; r < e->long_log_n; ++r) {
+            const uint32_t* rec = &llog[(size_t)r * kLongLogDwords];
+            const uint32_t len = rec[7] & 0xFFu, cnt = (rec[7] >> 8) & 0xFFu;
+            if (len <= 16 || len > (uint32_t)kLongLogMaxLen || cnt < 1 || cnt > 4) continue;
+            std::string key(len, '\0');
+            for (uint32_t b = 0; b < len; ++b) key[b] = (char)((rec[b >> 2] >> (8 * (b & 3))) & 0xFFu);
+            auto it = seen.find(key);
+            if (it == seen.end()) seen.emplace(key, LongCand{1u, (uint32_t)r}); else ++it->second.count;
+        }
+        std::vector<std::pair<uint32_t, const std::string*>> order;
+        for (const auto& kv : seen) if (kv.second.count >= 2 && !e->promo_keys.count(kv.first)) order.emplace_back(kv.second.count, &kv.first);
+        std::sort(order.begin(), order.end(), [](const std::pair<uint32_t, const std::string*>& a, const std::pair<uint32_t, const std::string*>& b) { return a.first != b.first ? a.first > b.first : *a.second < *b.second; });
+        const size_t long_room = std::min(cap - e->promo_items.size(), std::max<size_t>(cap / 4, 1));
+        for (size_t i = 0; i < order.size() && (size_t)n_new < long_room; ++i) {
+            const std::string& key = *order[i].second;
+            const uint32_t* rec = &llog[(size_t)seen[key].rec * kLongLogDwords];
+            const uint32_t cnt = (rec[7] >> 8) & 0xFFu;
+            e->promo_keys.insert(key);
+            const uint32_t index = (uint32_t)e->promo_items.size();
+            e->promo_items.push_back(tkz::KeyItem{key, kPromoFlag | ((cnt - 1u) << kPromoCntShift) | index});
+            for (uint32_t t = 0; t < 4; ++t) e->promo_quads.push_back(t < cnt ? (rec[8 + t] & 0x07FFFFFFu) : 0u);
+            ++n_new;
+        }
+    }
     struct Cand { uint32_t hits, slot; };
     std::vector<Cand> cand;
     for (uint32_t i = 0; i < e->memo_slots; ++i) {
@@ -355,7 +396,6 @@ tkz_status promote_from_memo(tkz_encoder* e, bool use_hits, bool retire, int64_t
         cand.push_back(Cand{use_hits ? hits[i] : 1u, i});
     }
     std::stable_sort(cand.begin(), cand.end(), [](const Cand& a, const Cand& b) { return a.hits > b.hits; });
-    int64_t n_new = 0;
     for (const Cand& c : cand) {
         if (e->promo_items.size() >= cap) break;
         const TkzMemoSlot& m = memo[c.slot];
@@ -469,7 +509,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                 e->T.memo_n != 0 && e->T.max_rank < (int32_t)kPromoFlag && total >= e->promo_min_bytes && e->promo_items.size() < e->promo_cap &&
                 (e->promo_rounds == 0 || e->bytes_seen - e->bytes_at_promo >= kPromoSecondBytes)) {
                 // (the gigabyte to the second round counts from the START of the first learning batch: a job of 5 GB batches learns in its first two)
-                if (e->t_memo_hits.ensure((size_t)e->memo_slots * 4, &e->bytes_allocated) == hipSuccess) { e->learning = true; ws->learning = true; e->bytes_at_promo = e->bytes_seen; }
+                if (e->t_memo_hits.ensure((size_t)e->memo_slots * 4, &e->bytes_allocated) == hipSuccess &&
+                    e->t_long_log.ensure((size_t)kLongLogCap * kLongLogDwords * 4, &e->bytes_allocated) == hipSuccess) { e->learning = true; ws->learning = true; e->bytes_at_promo = e->bytes_seen; }
             }
             T = e->T;
         }
@@ -520,6 +561,10 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             if (P.stats) HIP_TRY(hipMemcpyAsync(e->t_stats.as<char>() + 64, P.stats, 64, hipMemcpyDeviceToDevice, stream));
             P.place128 = ws->place128 ? 1 : 0;
             P.promo = T.promo; P.pextra = T.promo ? ws->w_pextra.as<int32_t>() : nullptr;
+            if (ws->learning) {
+                P.long_log = e->t_long_log.as<uint32_t>(); P.long_log_cap = (int32_t)kLongLogCap; P.long_log_sparse = T.memo_hits_sparse ? 1 : 0;
+                P.long_log_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, long_log_count));
+            }
 #ifdef TKZ_DEVPROF
             { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
             if (P.ablate & 16) {
@@ -659,6 +704,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             }
             if (promote) {
                 int64_t n_new = 0;
+                e->long_log_n = (int64_t)std::min<unsigned long long>(ws->h_counters->long_log_count, (unsigned long long)kLongLogCap);
                 const std::string keep_msg = g_err;
                 const tkz_status ps = promote_from_memo(e, true, true, &n_new);       // (a failure leaves the tables as they were: the batch itself is fine)
                 g_err = keep_msg;
@@ -1181,7 +1227,7 @@ void destroy_now(tkz_encoder* e) {
     DeviceScope scope;
     (void)scope.enter(e->device);
     DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp, &e->t_counts3, &e->t_memo, &e->t_stats, &e->t_decoff, &e->t_decblob, &e->t_decids,
-                      &e->t_memo_hits, &e->t_promo};
+                      &e->t_memo_hits, &e->t_promo, &e->t_long_log};
     for (DevBuf* b : bufs) b->release();
     for (DevBuf& b : e->retired) b.release();
     for (Workspace* w : e->pool) { w->release_all(); delete w; }

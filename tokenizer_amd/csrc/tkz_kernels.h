@@ -27,6 +27,7 @@ constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are m
 #define TKZ_LANE_PIECE 128
 #endif
 constexpr int kLanePiece = TKZ_LANE_PIECE;
+constexpr int kLongLogDwords = 12, kLongLogMaxLen = 28;      // (28 = TKZ_MID_KEY_MAX: what the MID key table can hold)
 constexpr int kSmallLanePiece = 256;  // ... the single-launch kernel (no k_merge_coop there) merges pieces of up to this many bytes a lane each and hands a batch with a longer missed piece back    // ... but a missed piece longer than this is merged by a whole wavefront (k_merge_coop): one lane takes ~n^2 steps, and the kernel waits for it
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
@@ -74,6 +75,10 @@ struct EncodeParams {
     // TKZ_OPT_PIECE_STATS: null, or the encoder's statistics block -- [0] memo lookups, [1] memo hits, [2] short misses, [3] long misses, [4] pieces
     // (what tkz_encoder_piece_stats reports; the timed runs leave it null)
     unsigned long long* stats;
+    // a LEARNING batch (tkz_api.cpp): k_merge_long logs the pieces of 17..28 bytes it merged into at most 4 tokens -- {7 dwords of bytes, len | count << 8,
+    // 4 tokens} = kLongLogDwords dwords a record, up to long_log_cap records (the counter runs on) -- so that the host can promote the ones that repeat
+    // (the indentation runs of source code: "\n" + 19 spaces is a missed piece of 20 bytes that real text holds by the hundred thousand)
+    uint32_t* long_log; unsigned long long* long_log_count; int32_t long_log_cap; int32_t long_log_sparse;
     int32_t* pextra;              // null, or (promoted pieces in the tables) per sub-tile: tokens beyond one per piece that its promoted pieces stand for (k_probe -> k_merge_short's counts)
     const uint4* promo;           // token quads of the promoted pieces (TkzTables::promo of the tables this batch was probed with), or null: k_place
     int32_t place128;             // launch k_place<128> (two kept list entries per lane) instead of k_place<64>: the previous batch of the workspace was miss-heavy

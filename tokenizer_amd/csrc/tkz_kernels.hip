@@ -1337,6 +1337,9 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                 const int aoff = tkz_wave_scan_sum(need, &btot);
                 const uint64_t bad = simt::ballot(mine && aoff + need > kArenaDwords);
                 const int limit = bad ? tkz_ctz64(bad) : 64;                   // lanes at or beyond `limit` wait for the next batch (limit >= 1: one piece always fits)
+                bool log_it = false;                             // (a learning batch: this lane's piece goes into the log below)
+                uint4 log_tok; log_tok.x = log_tok.y = log_tok.z = log_tok.w = 0;
+                int log_cnt = 0;
                 if (mine && lane < limit) {
                     const int64_t sub = c * 64 + q;
                     const int64_t abs = sub * kSub + rel;
@@ -1395,8 +1398,26 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                         uint4 tq; tq.x = (uint32_t)tk[0]; tq.y = cnt > 1 ? (uint32_t)tk[1] : 0u; tq.z = cnt > 2 ? (uint32_t)tk[2] : 0u; tq.w = cnt > 3 ? (uint32_t)tk[3] : 0u;
                         P.mquad[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tq;
                         P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_inline(cnt);
+                        if (P.long_log && len <= kLongLogMaxLen && !e1 && (!P.long_log_sparse || (c & 7) == 0)) { log_it = true; log_tok = tq; log_cnt = cnt; }
                     } else P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_entry(false, cnt, rel);
                     if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
+                    }
+                }
+                if (P.long_log) {                                // (wave-uniform; a learning batch only) one atomic for the wavefront's records
+                    int ltot;
+                    const int lpre = tkz_wave_scan_sum(log_it ? 1 : 0, &ltot);
+                    unsigned long long lbase = 0;
+                    if (lane == 0 && ltot) lbase = simt::atomic_add64(P.long_log_count, (unsigned long long)ltot);
+                    lbase = ((unsigned long long)simt::shflu((uint32_t)(lbase >> 32), 0) << 32) | simt::shflu((uint32_t)lbase, 0);
+                    if (log_it && lbase + (unsigned long long)lpre < (unsigned long long)P.long_log_cap) {
+                        uint32_t* rec = P.long_log + (lbase + (unsigned long long)lpre) * kLongLogDwords;
+                        const uint32_t* bw = &s_arena[aoff];            // the piece's bytes, still in the arena
+                        for (int w = 0; w < 7; ++w) {
+                            const int nbz = len - 4 * w;
+                            rec[w] = nbz <= 0 ? 0u : (nbz >= 4 ? bw[w] : (bw[w] & ((1u << (8 * nbz)) - 1u)));
+                        }
+                        rec[7] = (uint32_t)len | ((uint32_t)log_cnt << 8);
+                        rec[8] = log_tok.x; rec[9] = log_tok.y; rec[10] = log_tok.z; rec[11] = log_tok.w;
                     }
                 }
                 (void)simt::ballot(true);
@@ -1537,10 +1558,10 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
             else for (int j = 0; j < 4; ++j) if (pb_ + k0 + j < P.prank_cap) r[j] = (uint32_t)P.prank[pb_ + k0 + j];
         }
     };
-#ifndef TKZ_PLACE_NO_PREFETCH
-    // ... requested one sub-tile AHEAD (round 5): the records of sub-tile s + 1 travel while sub-tile s is placed, so that a sub-tile is ONE dependent
-    // round trip (its list answers) instead of two (answers, then records); and the token quads of promoted pieces (PROMO), which depend on the
-    // records, can be asked for at the top of the iteration, beside the answers.
+#ifdef TKZ_PLACE_PREFETCH
+    // (development A/B, round 5, NOT the shipped form: the records of sub-tile s + 1 requested while sub-tile s is placed -- one dependent round trip a
+    //  sub-tile instead of two.  Measured: the four more registers across the iteration spill at 7 waves per SIMD, k_place 4.78 -> 7.89 ms on the headline
+    //  workload; at 6 waves per SIMD without spills 6.09 ms.  As with every attempt so far to buy latency with registers in this kernel: a loss.)
     uint32_t rn[4];
     load_recs(nxt.pb, nxt.np, 0, rn);
 #endif
@@ -1549,7 +1570,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     const int64_t sub = sub0 + it;
     const Sc cur = nxt;
     if (it + 1 < kPlacePer && sub + 1 < P.nsub) nxt = load_sc(sub + 1);
-#ifndef TKZ_PLACE_NO_PREFETCH
+#ifdef TKZ_PLACE_PREFETCH
     uint32_t rc[4] = {rn[0], rn[1], rn[2], rn[3]};            // this sub-tile's first chunk
 #endif
     const int64_t pb = cur.pb, tb = cur.tb, base = sub * kSub, ord0 = cur.ord0;
@@ -1597,7 +1618,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         fast_ok = lists_ok && !has_giant && ns + nl <= kPlaceSlots && !simt::ballot(big);
     }
     (void)simt::ballot(true);
-#ifndef TKZ_PLACE_NO_PREFETCH
+#ifdef TKZ_PLACE_PREFETCH
     if (it + 1 < kPlacePer && sub + 1 < P.nsub) load_recs(nxt.pb, nxt.np, 0, rn);      // (nxt's scalars arrived with this sub-tile's answers)
 #endif
     // the answer a merge kernel left for a missed piece (its list entry): how many tokens, and where they wait
@@ -1647,7 +1668,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     auto place_fast = [&](int kk) -> bool {
         const int k0 = kk + 4 * lane;
         uint32_t r[4];
-#ifndef TKZ_PLACE_NO_PREFETCH
+#ifdef TKZ_PLACE_PREFETCH
         if (kk == 0) { r[0] = rc[0]; r[1] = rc[1]; r[2] = rc[2]; r[3] = rc[3]; } else
 #endif
         load_recs(pb, np, kk, r);
