@@ -324,9 +324,12 @@ def test_giant_tail_on_adversarial_rank_tables(lib, oracle_mod):
         parity.check_random_vocab(lib, oracle_mod, seed, 3, [300, 777, 1024, 1100, 1500, 2300, 4000, 7000], 4)
     parity.check_random_vocab(lib, oracle_mod, 7, 2, [300, 1024, 3000, 18000], 3, max_len=300)
     parity.check_random_vocab(lib, oracle_mod, 8, 2, [300, 1024, 3000, 18000], 3, max_len=1100)
+    # more parts than the tail's LDS holds (32,768): sweeps of windows under the local bound first (tkz_bpe_window_sweep), then the tail
+    parity.check_random_vocab(lib, oracle_mod, 11, 1, [34000], 2)
+    parity.check_random_vocab(lib, oracle_mod, 12, 1, [36000], 1, max_len=300)
     raw = gzip.decompress(open(os.path.join(os.path.dirname(__file__), "golden", "gpt2.tiktoken.gz"), "rb").read())
     v, ov = N.Vocab(raw, lib), oracle_mod.Vocab(raw)
-    parity.check_long_diverse_pieces(lib, oracle_mod, v, ov, lens=(300, 1000, 1500, 18000, 33000), seed=3)
+    parity.check_long_diverse_pieces(lib, oracle_mod, v, ov, lens=(300, 1000, 1500, 18000, 33000, 50000), seed=3)
     parity.check_runs_with_words(lib, oracle_mod, v, ov)
 
 

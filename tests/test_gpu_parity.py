@@ -218,6 +218,23 @@ def test_giant_pieces(lib, vocabs, oracle_mod, vname):
         assert enc.encode_utf8(text) == oenc.encode_bytes(text)
     parity.check_long_diverse_pieces(lib, oracle_mod, vocab, oracle_gpt2, lens=(300, 1000, 3000, 9000, 20000, 33000, 50000, 100000))
     parity.check_runs_with_words(lib, oracle_mod, vocab, oracle_gpt2)
+    if vname == "gpt2":
+        # The last cliff (round-4 review): a piece of more than 32,768 parts used to be brought down to that by rounds in global memory, ONE rank a round --
+        # seconds for 100 KB of diverse letters.  Now: sweeps of windows under the local bound (tkz_bpe_window_sweep).  300 KB against the oracle's literal
+        # loop (BytePairEncoder.cs:45-64: O(n^2), half a minute on the host), and a bound on the time of the 100 KB piece.
+        import random
+        import time
+        rng = random.Random(77)
+        words = [w.decode().strip() for w, _ in oracle_gpt2.entries() if w.strip().isalpha() and len(w.strip()) > 3][:3000]
+        big = "".join(rng.choice(words).capitalize() for _ in range(70000))[:300000].encode()
+        assert enc.encode_utf8(big) == oenc.encode_bytes(big)
+        t100 = big[:100000]
+        enc.encode_utf8(t100)
+        t0 = time.perf_counter()
+        got = enc.encode_utf8(t100)
+        ms = (time.perf_counter() - t0) * 1e3
+        assert got == oenc.encode_bytes(t100)
+        assert ms < 50.0, "100 KB of diverse letters (ONE piece) took %.1f ms" % ms
 
 
 @pytest.mark.parametrize("pattern,vname", [(1, "gpt2"), (2, "gpt2"), (3, "gpt2"), (4, "gpt2"), (2, "synth100k"), (3, "synth200k"), (4, "synth200k"), (1, "synth200k")])

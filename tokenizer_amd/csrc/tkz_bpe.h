@@ -743,8 +743,14 @@ constexpr int kTailChainFew = 8;          // a batch of proposals that merges fe
 constexpr int kTailLocalKeyMax = 1024;    // (beyond: the window would be most of the piece anyway)
 constexpr int kTailPosBits = 15;
 static_assert(kTailBlock == 32 && kTailSubs * kTailSB == kTailBlock && (kTailSB & (kTailSB - 1)) == 0, "sub-blocks tile a block of 32 slots");
+// WINDOW mode (open_lo / open_hi: round 5): the cnt parts are a WINDOW of a longer piece -- parts exist before slot 0 and / or behind slot cnt - 1 that this
+// call knows nothing about.  The local bound then also says which proposals may be applied without knowing them: exactly those whose window [l - reach,
+// rrr + reach] lies inside the parts that are here (the unknown blocks count as bound 0: "something smaller may be there").  No global minimum (the window's
+// is not the piece's), no rounds for the lowest rank; the call ends when a batch applies nothing.  pr[cnt - 1] must be TKZ_RANK_NONE on entry (the caller
+// keeps the last part's pair with the first part behind the window): tkz_bpe_window_sweep.
 template <bool IDS_LDS>
-TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_t* pr, uint32_t* alive, void* scratch, unsigned long long* prof = nullptr) {
+TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_t* pr, uint32_t* alive, void* scratch, unsigned long long* prof = nullptr,
+                               const bool open_lo = false, const bool open_hi = false) {
     const int tid = simt::tid(), lane = simt::lane(), wave = simt::wave(), G = simt::nthreads();
     const int nblk = (cnt + kTailBlock - 1) / kTailBlock, nw = (cnt + 31) >> 5;       // (nblk <= G: cnt <= kBpeTailCap, 1024 threads)
     constexpr uint32_t NONE = (uint32_t)TKZ_RANK_NONE;
@@ -769,6 +775,7 @@ TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_
 #else
     const bool local = T.max_key_len <= kTailLocalKeyMax;
 #endif
+    const bool windowed = open_lo || open_hi;                    // (only with the local bound: the caller checks)
     const int reach = T.max_key_len;
     const int blk = tid;
     const bool owner = blk < nblk;
@@ -819,6 +826,7 @@ TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_
         int r[kTailSubs], l[kTailSubs], rr[kTailSubs];
         int32_t rkr[kTailSubs], rkl[kTailSubs];
         int wlo = blk, whi = blk;
+        bool beyond = false;                                     // (window mode) a proposal of this thread reaches parts that are not here
         uint64_t mykey = NOKEY;
 #pragma unroll
         for (int q = 0; q < kTailSubs; ++q) {
@@ -841,11 +849,13 @@ TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_
                 rr[q] = hasr ? 32 * w + tkz_ctz32(bits) : -1;
                 if (local) {                                     // the window's right end: max_key_len slots beyond the part after rr (rr, or r, when there is none)
                     int last = hasr ? rr[q] : r[q];
+                    bool has_rrr = false;
                     if (hasr) {
                         bits &= bits - 1;
                         while (!bits && ++w < nw) bits = alive[w];
-                        if (bits) last = 32 * w + tkz_ctz32(bits) + reach;
+                        if (bits) { last = 32 * w + tkz_ctz32(bits) + reach; has_rrr = true; }
                     }
+                    if (open_hi && (!has_rrr || last > cnt - 1)) beyond = true;      // (the part after rr, and max_key_len slots behind it, must be HERE)
                     const int hi = (last < cnt - 1 ? last : cnt - 1) >> 5;
                     whi = hi > whi ? hi : whi;
                 }
@@ -855,6 +865,7 @@ TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_
                 const bool hasl = bits != 0;
                 l[q] = hasl ? 32 * w + tkz_msb32(bits) : -1;
                 if (local && hasl) { const int lo = (l[q] - reach > 0 ? l[q] - reach : 0) >> 5; wlo = lo < wlo ? lo : wlo; }
+                if (open_lo && (!hasl || l[q] - reach < 0)) beyond = true;
                 const uint32_t idr = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, hasr ? rr[q] : 0), idl = tkz_tail_id<IDS_LDS>(ids, pr, alive, cnt, hasl ? l[q] : 0);
                 rkr[q] = hasr ? tkz_lookup_pair(T, m[q], idr) : TKZ_RANK_NONE;        // (:58)
                 rkl[q] = hasl ? tkz_lookup_pair(T, idl, m[q]) : TKZ_RANK_NONE;        // (:59-62)
@@ -901,6 +912,7 @@ TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_
             tau = NOKEY;
             for (int f = wlo; f <= whi; ++f) { const uint64_t bf = s_bound[f]; tau = bf < tau ? bf : tau; }
         }
+        if (windowed) { if (beyond) tau = 0; g = NOKEY - 1; }    // (g: a key no proposal has -- the window's minimum is not the piece's)
         {
             int tg = 0, tc = 0;
 #pragma unroll
@@ -925,7 +937,8 @@ TKZ_DEV void tkz_bpe_long_tail(const TkzTables& T, int cnt, int32_t* ids, int32_
             }
         }
         simt::sync();
-        chain = s_cnt[it & 1] < kTailChainFew;                   // few merges: a chain of equal pairs may be holding the proposals back
+        if (windowed) { if (s_cnt[it & 1] == 0) break; }         // nothing applied: what is left waits for the parts beyond the window
+        else chain = s_cnt[it & 1] < kTailChainFew;              // few merges: a chain of equal pairs may be holding the proposals back
         ++it;
     }
     if (prof && lane == 0) {
@@ -970,6 +983,49 @@ constexpr int kBpeLongLdsBytes = (kBpeTailCap * 4 + kBpeTailCap / 8 + kBpeTailSc
 static_assert(kBpeLongLdsBytes >= 8 * kBpeLongLds + kBpeLongLds / 8 + kBpeTailScratch, "ids and pair ranks of kBpeLongLds parts fit too");
 static_assert(kBpeTailCap / 32 <= 1024 && kBpeTailCap <= (1 << kTailPosBits), "one thread a block of 32 slots; a slot index fits the key");
 static_assert(kBpeLongLdsBytes + 64 <= 160 * 1024, "gfx950: 160 KB of LDS a workgroup");
+// One SWEEP over a piece of more than kBpeTailCap parts (dense arrays in global memory: ids / pr -> idsN / prN): the parts are taken kBpeLongLds at a time
+// (windows starting at k * kBpeLongLds - shift), every window is merged by tkz_bpe_long_tail in window mode -- everything the local bound allows without
+// knowing what lies beyond the window's ends -- and what is alive afterwards is appended to the new arrays.  Each applied merge is one the reference makes
+// (the bound's proof, with the unknown blocks at 0); the parts within ~max_key_len slots of a window's ends wait for the next sweep, whose windows are
+// shifted by half a window.  A diverse piece shrinks ~3.5x a sweep: 100 KB of letters is one sweep of 7 windows (~40 batches each) away from the
+// ordinary tail -- it was ~10^4 rounds in global memory, one rank a round, seconds.  Returns the new part count.
+TKZ_DEV int tkz_bpe_window_sweep(const TkzTables& T, int cnt, const int32_t* ids, const int32_t* pr, int32_t* idsN, int32_t* prN, int32_t* lds, int shift) {
+    const int tid = simt::tid(), G = simt::nthreads();
+    int32_t* lids = lds;
+    int32_t* lpr = lds + kBpeLongLds;
+    uint32_t* alive = reinterpret_cast<uint32_t*>(lds + 2 * kBpeLongLds);
+    void* scratch = alive + kBpeLongLds / 32;
+    int out = 0;
+    for (int a = 0; a < cnt;) {
+        int e = a == 0 && shift > 0 ? kBpeLongLds - shift : a + kBpeLongLds;
+        if (e > cnt) e = cnt;
+        const int wn = e - a;
+        const bool open_lo = a > 0, open_hi = e < cnt;
+        for (int k = tid; k < wn; k += G) { lids[k] = ids[a + k]; lpr[k] = (k == wn - 1 && open_hi) ? TKZ_RANK_NONE : pr[a + k]; }
+        const int32_t pr_last = pr[e - 1];                       // the last part's pair with the first part behind the window: neither of them changes
+        simt::sync();
+        if (wn >= 2) tkz_bpe_long_tail<true>(T, wn, lids, lpr, alive, scratch, nullptr, open_lo, open_hi);
+        else { if (tid == 0) alive[0] = 1u; simt::sync(); }
+        // what is alive, in order, behind what the windows before left
+        const int c0 = (wn + G - 1) / G;
+        const int lo0 = tid * c0 < wn ? tid * c0 : wn, hi0 = lo0 + c0 < wn ? lo0 + c0 : wn;
+        int mine = 0;
+        for (int i = lo0; i < hi0; ++i) mine += (int)((alive[i >> 5] >> (i & 31)) & 1u);
+        int tot;
+        int o = out + tkz_block_scan(mine, &tot);
+        for (int i = lo0; i < hi0; ++i) {
+            if (!((alive[i >> 5] >> (i & 31)) & 1u)) continue;
+            idsN[o] = lids[i];
+            prN[o] = (o == out + tot - 1 && open_hi) ? pr_last : lpr[i];
+            ++o;
+        }
+        simt::sync();
+        out += tot;
+        a = e;
+    }
+    return out;
+}
+
 template <class ByteAt>
 TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, int32_t* prA, int32_t* s1g, int32_t* s2g,
                          int32_t* idsB, int32_t* prB, int32_t* dst, int* err, int32_t* lds = nullptr, unsigned long long* prof = nullptr) {
@@ -998,6 +1054,22 @@ TKZ_DEV int tkz_bpe_long(const TkzTables& T, ByteAt at, int n, int32_t* idsA, in
             simt::atomic_add64(&prof[14], (unsigned long long)rg);
         }
     };
+    // more parts than the tail's LDS holds: sweeps of windows first (each ~3.5x fewer parts on diverse text), as long as they pay
+    if (use_lds && cnt > kBpeTailCap && T.max_key_len <= kTailLocalKeyMax && 4 * T.max_key_len < kBpeLongLds) {
+        int32_t* cur_ids = ids; int32_t* cur_pr = pr; int32_t* nxt_ids = idsB; int32_t* nxt_pr = prB;
+        for (int sweep = 0; cnt > kBpeTailCap && sweep < 12; ++sweep) {
+            const int before = cnt;
+            cnt = tkz_bpe_window_sweep(T, cnt, cur_ids, cur_pr, nxt_ids, nxt_pr, lds, (sweep & 1) ? kBpeLongLds / 2 : 0);
+            { int32_t* t = cur_ids; cur_ids = nxt_ids; nxt_ids = t; } { int32_t* t = cur_pr; cur_pr = nxt_pr; nxt_pr = t; }
+            if (prof) ++rg;
+            if (cnt > before - before / 8) break;                // (a run of one letter, a chain of equal pairs: the rounds below halve those)
+        }
+        // the state is in (cur_ids, cur_pr); the rounds below want it in (ids, pr) with (idsB, prB) free
+        if (cur_ids != ids) {
+            for (int k = tid; k < cnt; k += G) { ids[k] = cur_ids[k]; pr[k] = cur_pr[k]; }
+            simt::sync();
+        }
+    }
     if (!start_in_lds && (!use_lds || cnt > kBpeTailCap)) {
         int32_t* s1 = s1g; int32_t* idsN = idsB;
         done = tkz_bpe_long_rounds(T, cnt, ids, pr, s1, s2g, idsN, prB, use_lds ? kBpeTailCap : 0, prof ? &rg : nullptr);
