@@ -6,6 +6,7 @@
 #include <cstring>
 #include <atomic>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
@@ -197,6 +198,11 @@ struct tkz_encoder {
     std::unordered_set<std::string> promo_keys;
     std::vector<uint32_t> promo_quads;     // 4 tokens per promoted piece (host copy of t_promo)
     uint32_t short_slots_n = 0, mid_slots_n = 0;
+    // an automatic promotion runs behind the batch that gathered its statistics (the copy of the memo back to the host, the choice and the rebuilt key
+    // tables are ~50 ms of host work: not something the call that happened to be the learning batch should wait for).  `learning` stays set until it
+    // is done, so there is one at a time; joined by join_promotion()
+    std::thread promo_thread;
+    std::mutex promo_join_mu;
 };
 
 namespace {
@@ -301,38 +307,49 @@ constexpr int64_t kPromoSecondBytes = int64_t(1) << 30;
 
 // (re)builds the SHORT / MID images from the vocabulary's keys + the promoted pieces and publishes them; `retire`: other calls may be probing the
 // current images (they are kept until the encoder is destroyed), else they are freed
-tkz_status publish_key_tables(tkz_encoder* e, bool retire) {
+struct KeyTablesImage { DevBuf nt, np; size_t short_bytes = 0, n_short_slots = 0, n_mid_slots = 0, n_promo = 0; uint32_t sseed = 0, mseed = 0; };
+// the images on the device, built from the vocabulary's keys + `promo_items` (copies: no lock is held here, the build takes tens of milliseconds)
+tkz_status build_key_tables_image(tkz_encoder* e, const std::vector<tkz::KeyItem>& promo_items, const std::vector<uint32_t>& promo_quads, KeyTablesImage* img) {
     std::vector<tkz::KeyItem> items;
-    items.reserve(e->dec_vocab.size() + e->promo_items.size());
-    {
+    items.reserve(e->dec_vocab.size() + promo_items.size());
+    {   // (dec_vocab's vocabulary part never changes after tkz_encoder_create)
         std::vector<size_t> order(e->dec_vocab.size());
         for (size_t i = 0; i < order.size(); ++i) order[i] = i;
         std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return e->dec_vocab[a].first < e->dec_vocab[b].first; });      // rank order: most frequent first
         for (size_t i : order) { const std::string& k = e->dec_vocab[i].second; if (!k.empty() && k.size() <= TKZ_MID_KEY_MAX) items.push_back(tkz::KeyItem{k, (uint32_t)e->dec_vocab[i].first}); }
     }
-    for (const tkz::KeyItem& it : e->promo_items) items.push_back(it);
+    for (const tkz::KeyItem& it : promo_items) items.push_back(it);
     std::vector<TkzShortSlot> ss; std::vector<TkzMidSlot> ms;
-    uint32_t sseed = 0, mseed = 0;
-    tkz::build_key_tables(items, &ss, &sseed, &ms, &mseed);
+    tkz::build_key_tables(items, &ss, &img->sseed, &ms, &img->mseed);
     const size_t short_bytes = ss.size() * sizeof(TkzShortSlot), mid_bytes = ms.size() * sizeof(TkzMidSlot);
-    DevBuf nt, np;
-    int64_t* acc = &e->bytes_allocated;
-    hipError_t h = nt.ensure(std::max<size_t>(64, short_bytes + mid_bytes), acc);
-    if (h == hipSuccess && short_bytes) h = hipMemcpy(nt.p, ss.data(), short_bytes, hipMemcpyHostToDevice);
-    if (h == hipSuccess && mid_bytes) h = hipMemcpy(static_cast<char*>(nt.p) + short_bytes, ms.data(), mid_bytes, hipMemcpyHostToDevice);
-    if (h == hipSuccess) h = np.ensure(std::max<size_t>(64, e->promo_quads.size() * 4), acc);
-    if (h == hipSuccess && !e->promo_quads.empty()) h = hipMemcpy(np.p, e->promo_quads.data(), e->promo_quads.size() * 4, hipMemcpyHostToDevice);
-    if (h != hipSuccess) { nt.release(); np.release(); return fail(TKZ_E_DEVICE, std::string("promoted tables: ") + hipGetErrorString(h)); }
-    if (retire) { e->retired.push_back(e->t_short); e->retired.push_back(e->t_promo); }
-    else { *acc -= (int64_t)(e->t_short.cap + e->t_promo.cap); e->t_short.release(); e->t_promo.release(); }
-    e->t_short = nt; e->t_promo = np;
-    e->T.short_slots = e->t_short.as<TkzShortSlot>(); e->T.short_nb = (uint32_t)(ss.size() / 2); e->T.short_seed = sseed;
-    e->T.mid_slots = reinterpret_cast<const TkzMidSlot*>(e->t_short.as<char>() + short_bytes); e->T.mid_ns = (uint32_t)ms.size(); e->T.mid_seed = mseed;
-    e->T.promo = e->promo_items.empty() ? nullptr : e->t_promo.as<uint4>(); e->T.promo_n = (uint32_t)e->promo_items.size();
-    e->short_slots_n = (uint32_t)ss.size(); e->mid_slots_n = (uint32_t)ms.size();
+    int64_t acc = 0;
+    hipError_t h = img->nt.ensure(std::max<size_t>(64, short_bytes + mid_bytes), &acc);
+    if (h == hipSuccess && short_bytes) h = hipMemcpy(img->nt.p, ss.data(), short_bytes, hipMemcpyHostToDevice);
+    if (h == hipSuccess && mid_bytes) h = hipMemcpy(static_cast<char*>(img->nt.p) + short_bytes, ms.data(), mid_bytes, hipMemcpyHostToDevice);
+    if (h == hipSuccess) h = img->np.ensure(std::max<size_t>(64, promo_quads.size() * 4), &acc);
+    if (h == hipSuccess && !promo_quads.empty()) h = hipMemcpy(img->np.p, promo_quads.data(), promo_quads.size() * 4, hipMemcpyHostToDevice);
+    if (h != hipSuccess) { img->nt.release(); img->np.release(); return fail(TKZ_E_DEVICE, std::string("promoted tables: ") + hipGetErrorString(h)); }
+    img->short_bytes = short_bytes; img->n_short_slots = ss.size(); img->n_mid_slots = ms.size(); img->n_promo = promo_items.size();
     return TKZ_OK;
 }
+// ... and put in place (e->mu held).  `retire`: other calls may be probing the current images (kept until the encoder is destroyed), else they are freed
+void install_key_tables(tkz_encoder* e, KeyTablesImage& img, bool retire) {
+    int64_t* acc = &e->bytes_allocated;
+    *acc += (int64_t)(img.nt.cap + img.np.cap);
+    if (retire) { e->retired.push_back(e->t_short); e->retired.push_back(e->t_promo); }
+    else { *acc -= (int64_t)(e->t_short.cap + e->t_promo.cap); e->t_short.release(); e->t_promo.release(); }
+    e->t_short = img.nt; e->t_promo = img.np;
+    e->T.short_slots = e->t_short.as<TkzShortSlot>(); e->T.short_nb = (uint32_t)(img.n_short_slots / 2); e->T.short_seed = img.sseed;
+    e->T.mid_slots = reinterpret_cast<const TkzMidSlot*>(e->t_short.as<char>() + img.short_bytes); e->T.mid_ns = (uint32_t)img.n_mid_slots; e->T.mid_seed = img.mseed;
+    e->T.promo = img.n_promo ? e->t_promo.as<uint4>() : nullptr; e->T.promo_n = (uint32_t)img.n_promo;
+    e->short_slots_n = (uint32_t)img.n_short_slots; e->mid_slots_n = (uint32_t)img.n_mid_slots;
+}
 
+// waits for the automatic promotion in the background, if any (never with e->mu held: the promotion takes it)
+void join_promotion(tkz_encoder* e) {
+    std::lock_guard<std::mutex> lock(e->promo_join_mu);
+    if (e->promo_thread.joinable()) e->promo_thread.join();
+}
 // The memo (and the hit counters of a learning batch, or null: every valid entry counts alike) is read back and its hottest entries are promoted.
 // Called with no lock held; takes e->mu for the bookkeeping and the publication.  *added: entries promoted by this call.
 tkz_status promote_from_memo(tkz_encoder* e, bool use_hits, bool retire, int64_t* added) {
@@ -341,19 +358,29 @@ tkz_status promote_from_memo(tkz_encoder* e, bool use_hits, bool retire, int64_t
     if (!e->memo_slots || e->T.max_rank >= (int32_t)kPromoFlag) return TKZ_OK;      // (a promo code must not look like a rank)
     std::vector<TkzMemoSlot> memo(e->memo_slots);
     std::vector<uint32_t> hits;
-    HIP_TRY(hipMemcpy(memo.data(), e->t_memo.p, memo.size() * sizeof(TkzMemoSlot), hipMemcpyDeviceToHost));
-    if (use_hits) { hits.resize(e->memo_slots); HIP_TRY(hipMemcpy(hits.data(), e->t_memo_hits.p, hits.size() * 4, hipMemcpyDeviceToHost)); }
+    // (a stream of its own: this may be the background thread of an automatic promotion, and a copy on the null stream would wait for -- and hold up --
+    //  whatever the host has queued there)
+    hipStream_t cs = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } stream_guard{cs};
+    HIP_TRY(hipMemcpyAsync(memo.data(), e->t_memo.p, memo.size() * sizeof(TkzMemoSlot), hipMemcpyDeviceToHost, cs));
+    if (use_hits) { hits.resize(e->memo_slots); HIP_TRY(hipMemcpyAsync(hits.data(), e->t_memo_hits.p, hits.size() * 4, hipMemcpyDeviceToHost, cs)); }
+    HIP_TRY(hipStreamSynchronize(cs));
     // ... and the pieces of 17..28 bytes k_merge_long logged during the learning batch (each with its <= 4 tokens): those that were logged at least
     // twice -- real source text is full of them: "\n" + 19 spaces, by the hundred thousand -- go into the MID key table the same way
     std::vector<uint32_t> llog;
     if (use_hits && e->long_log_n > 0) {
         llog.resize((size_t)e->long_log_n * kLongLogDwords);
-        HIP_TRY(hipMemcpy(llog.data(), e->t_long_log.p, llog.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(llog.data(), e->t_long_log.p, llog.size() * 4, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipStreamSynchronize(cs));
     }
+    std::vector<tkz::KeyItem> items_copy;
+    std::vector<uint32_t> quads_copy;
+    int64_t n_new = 0;
+    {
     std::lock_guard<std::mutex> lock(e->mu);
     const size_t cap = e->promo_cap;
     if (e->promo_items.size() >= cap) return TKZ_OK;
-    int64_t n_new = 0;
     if (!llog.empty()) {
         struct LongCand { uint32_t count; uint32_t rec; };
         std::unordered_map<std::string, LongCand> seen;
@@ -410,7 +437,16 @@ tkz_status promote_from_memo(tkz_encoder* e, bool use_hits, bool retire, int64_t
     }
     if (added) *added = n_new;
     if (!n_new) return TKZ_OK;
-    return publish_key_tables(e, retire);
+    items_copy = e->promo_items; quads_copy = e->promo_quads;
+    }
+    // the key tables with the promoted pieces in them: built and uploaded WITHOUT the lock (tens of milliseconds), then put in place under it (only one
+    // promotion runs at a time -- the encoder's one learning slot, or an idle encoder --, so the list has not changed in between)
+    KeyTablesImage img;
+    const tkz_status bs = build_key_tables_image(e, items_copy, quads_copy, &img);
+    if (bs != TKZ_OK) return bs;
+    std::lock_guard<std::mutex> lock(e->mu);
+    install_key_tables(e, img, retire);
+    return TKZ_OK;
 }
 
 // workspace of one batch of `total` bytes / n_docs documents (grow-only buffers: nothing happens once they are large enough)
@@ -703,14 +739,18 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                 promote = ws->learning;
             }
             if (promote) {
-                int64_t n_new = 0;
                 e->long_log_n = (int64_t)std::min<unsigned long long>(ws->h_counters->long_log_count, (unsigned long long)kLongLogCap);
-                const std::string keep_msg = g_err;
-                const tkz_status ps = promote_from_memo(e, true, true, &n_new);       // (a failure leaves the tables as they were: the batch itself is fine)
-                g_err = keep_msg;
-                (void)ps;
-                std::lock_guard<std::mutex> lock(e->mu);
-                ws->learning = false; e->learning = false; ++e->promo_rounds;
+                { std::lock_guard<std::mutex> lock(e->mu); ws->learning = false; }
+                // (the workspace is this call's no longer once it returns; the counters, the log and the memo are the encoder's, and no other batch writes the
+                //  first two while e->learning is set)
+                join_promotion(e);                 // (the previous one ended before this batch could be armed: this only reaps the thread)
+                std::lock_guard<std::mutex> jl(e->promo_join_mu);
+                e->promo_thread = std::thread([e] {
+                    DeviceScope scope;
+                    if (scope.enter(e->device) == hipSuccess) (void)promote_from_memo(e, true, true, nullptr);   // (a failure leaves the tables as they were)
+                    std::lock_guard<std::mutex> lock(e->mu);
+                    e->learning = false; ++e->promo_rounds;
+                });
             }
         }
         if (!d_bitmap_only) {
@@ -1224,6 +1264,7 @@ void tkz_encoder_destroy(tkz_encoder* e) {
 }
 namespace {
 void destroy_now(tkz_encoder* e) {
+    join_promotion(e);
     DeviceScope scope;
     (void)scope.enter(e->device);
     DevBuf* bufs[] = {&e->t_short, &e->t_mid, &e->t_long, &e->t_blob, &e->t_pair, &e->t_byte, &e->t_bpair, &e->t_bmp, &e->t_counts3, &e->t_memo, &e->t_stats, &e->t_decoff, &e->t_decblob, &e->t_decids,
@@ -1564,17 +1605,29 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
         DeviceScope scope;
         tkz_status st = check_encoder(e, scope);
         if (st != TKZ_OK) return st;
-        if (value == 0 || value == 1) { std::lock_guard<std::mutex> lock(e->mu); e->promo_mode = (int)value; return TKZ_OK; }
+        if (value == 0 || value == 1) {
+            { std::lock_guard<std::mutex> lock(e->mu); e->promo_mode = (int)value; }
+            if (value == 0) join_promotion(e);     // off: the tables do not change once this has returned
+            return TKZ_OK;
+        }
         if (value != 2 && value != 3) return fail(TKZ_E_ARG, "TKZ_OPT_PROMOTE takes 0, 1, 2 or 3");
+        join_promotion(e);
         {
             std::lock_guard<std::mutex> lock(e->mu);
             for (Workspace* w : e->pool) if (w->busy) return fail(TKZ_E_ARG, "promotions can only be made or dropped by hand while no call of this encoder is in flight");
         }
         if (hipDeviceSynchronize() != hipSuccess) return fail(TKZ_E_DEVICE, "hipDeviceSynchronize");
         if (value == 2) return promote_from_memo(e, false, false, nullptr);
+        {
+            std::lock_guard<std::mutex> lock(e->mu);
+            e->promo_items.clear(); e->promo_keys.clear(); e->promo_quads.clear(); e->promo_rounds = 0; e->bytes_at_promo = e->bytes_seen;
+        }
+        KeyTablesImage img;
+        st = build_key_tables_image(e, {}, {}, &img);
+        if (st != TKZ_OK) return st;
         std::lock_guard<std::mutex> lock(e->mu);
-        e->promo_items.clear(); e->promo_keys.clear(); e->promo_quads.clear(); e->promo_rounds = 0; e->bytes_at_promo = e->bytes_seen;
-        return publish_key_tables(e, false);
+        install_key_tables(e, img, false);
+        return TKZ_OK;
     }
     if (option == TKZ_OPT_PIECE_MEMO) {
         // 0: off, 1: on, 2: on and emptied.  Options are set while the encoder is idle: a call in flight on another thread reads
@@ -1618,6 +1671,7 @@ void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_sca
 tkz_status tkz_encoder_piece_stats(tkz_encoder* e, int64_t* out8, int32_t reset) {
     if (!e || !out8) return fail(TKZ_E_ARG, "null argument");
     for (int i = 0; i < 8; ++i) out8[i] = 0;
+    join_promotion(e);                     // (the count of promoted pieces below is the one after a promotion in the background, if one is running)
     if (!e->t_stats.p) { std::lock_guard<std::mutex> lock(e->mu); out8[7] = (int64_t)e->promo_items.size(); return TKZ_OK; }
     DeviceScope scope;
     tkz_status st = check_encoder(e, scope);

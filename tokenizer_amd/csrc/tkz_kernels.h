@@ -120,7 +120,7 @@ void launch_place(const Launch& L, const EncodeParams& P, const int64_t* tile_ba
 void launch_docoffs(const Launch& L, const int64_t* d_offs, int64_t n_docs, int64_t total, const int64_t* tile_base,
                     const uint64_t* docbits, const int64_t* docord_base, const int32_t* doc_tok, const int64_t* grand, int64_t* out_offs,
                     int64_t c3_docs = 0, int64_t* c3a = nullptr, int64_t* c3b = nullptr, int64_t* c3c = nullptr);
-// the counts of two bitmaps per sub-tile in one pass; the scan of one or two count arrays -- a single launch up to 65,536 sub-tiles
+// the counts of two bitmaps per sub-tile in one pass; the scan of one or two count arrays -- a single launch up to 8,192 sub-tiles
 void launch_doccount2(const Launch& L, const uint64_t* bits_a, const uint64_t* bits_b, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt_a, int32_t* cnt_b);
 void launch_scan2(const Launch& L, int64_t ntiles, int64_t* bsum, const int32_t* cnt_a, int64_t* base_a, int64_t* grand_a, int round_to_a,
                   const int32_t* cnt_b, int64_t* base_b, int64_t* grand_b, int round_to_b, int kid);

@@ -1173,7 +1173,13 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     if (P.stats && lane == 0 && st_look) { simt::atomic_add64(&P.stats[0], (unsigned long long)st_look); simt::atomic_add64(&P.stats[1], (unsigned long long)st_hit); }
 }
 // (LDS: 4 x 9.5 KB of merge state + 0.5 KB = 38.5 KB per workgroup, and <= 128 VGPRs: four workgroups = 16 wavefronts per CU)
+// A batch whose miss lists or record buffer turned out too small (k_probe / k_list_stats flag it) is run again by the host with larger ones: the
+// kernels behind those two have nothing to add to an attempt that is thrown away, and on a fresh encoder's first miss-heavy batch that attempt was
+// costing as much as the one that counts.
+TKZ_DEV bool tkz_attempt_failed(const EncodeParams& P) { return (P.counters[0] & (kErrMissCap | kErrCapacity)) != 0; }
+
 TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
+    if (tkz_attempt_failed(P)) return;
     TKZ_SHARED uint4 s_wave[kMsThreads / 64][kMsLdsQuads];
     TKZ_SHARED uint16_t s_brank16[256];
     tkz_ms_brank_init(T, s_brank16);
@@ -1430,6 +1436,7 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
 // (a kernel of its own per form so that the general forms' registers stay out of the compact one)
 template <bool COMPACT>
 TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
+    if (tkz_attempt_failed(P)) return;
     TKZ_SHARED uint4 s_lds[kLongLdsQuads];
     const LongLds LD = tkz_long_lds(s_lds);
     tkz_long_brank_init(T, LD.brank);
@@ -1449,6 +1456,7 @@ constexpr int kCoopGrid = 4;          // (the CPU emulator pays for every idle w
 constexpr int kCoopGrid = 2048;
 #endif
 TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
+    if (tkz_attempt_failed(P)) return;
     TKZ_SHARED uint4 s_lds[(kCoopLdsBytes + 15) / 16];
     int32_t* ids = reinterpret_cast<int32_t*>(s_lds);
     int32_t* pr = ids + kArenaPiece;
@@ -1831,6 +1839,7 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
 }
 template <int SLOTS, bool PROMO>
 TKZ_KERNEL_OCC(256, TKZ_PLACE_OCC) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
+    if (tkz_attempt_failed(P)) return;
     TKZ_SHARED uint4 s_wave[kThreads / 64][kPlaceLdsQuadsT<SLOTS>];
     const int64_t sub0 = (tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave()) * kPlacePer;
     tkz_place_subtiles<SLOTS, PROMO>(P, tile_base, out, out_cap, sub0, tkz_place_lds<SLOTS>(s_wave[simt::wave()]));
@@ -1864,6 +1873,7 @@ TKZ_DEV void tkz_giant_find_one(int64_t t, const uint64_t* startbits, int64_t nw
 // kernel's duration, so those must start first), by rank counting in one workgroup; identity beyond 8192 pieces.
 constexpr int kGiantSort = 8192;
 TKZ_KERNEL(1024) void k_giant_order(EncodeParams P) {
+    if (tkz_attempt_failed(P)) return;
     TKZ_SHARED int32_t s_len[kGiantSort];
     const int64_t n = (int64_t)*P.giant_count < P.giant_cap ? (int64_t)*P.giant_count : P.giant_cap;
     int64_t* order = P.giant_q + 2 * P.giant_cap;
@@ -1879,6 +1889,7 @@ TKZ_KERNEL(1024) void k_giant_order(EncodeParams P) {
 }
 
 TKZ_KERNEL(1024) void k_giant_merge(TkzTables T, EncodeParams P) {
+    if (tkz_attempt_failed(P)) return;
     TKZ_SHARED alignas(16) int32_t s_state[kBpeLongLdsBytes / 4];             // ids | pair ranks | flag bytes of up to 16 Ki parts + the tail's bounds: 152 KB of the CU's 160
     TKZ_SHARED int64_t s_off;
     TKZ_SHARED int32_t s_whole;
@@ -1962,10 +1973,10 @@ TKZ_KERNEL(256) void k_doccount2(const uint64_t* bits_a, const uint64_t* bits_b,
 // -------------------------------------------------------------------------------------------------
 // exclusive scan of tile_count (int32) -> tile_base (int64); counters[2..3] (int64) = grand total
 // -------------------------------------------------------------------------------------------------
-// Up to kScanSmallMax sub-tiles (64 MB of text): ONE workgroup, one launch -- a thread owns n / 1024 consecutive counts, one workgroup scan of the
+// Up to kScanSmallMax sub-tiles: ONE workgroup, one launch -- a thread owns n / 1024 consecutive counts, one workgroup scan of the
 // threads' sums -- for one or two arrays at once; the three-kernel form below (partials, top, final) costs three dependent launches per array, and a
 // batch of a few megabytes is made of little else than launches.
-constexpr int kScanSmallMax = 65536;
+constexpr int kScanSmallMax = 8192;          // (8 MB of text.  At 65,536 sub-tiles the one workgroup took 35 us a scan against 17 us for the three kernels: measured on the 64 MB single document of --kind 5)
 TKZ_KERNEL(1024) void k_scan_small(const int32_t* cnt_a, int64_t* base_a, int64_t* grand_a, int round_a,
                                    const int32_t* cnt_b, int64_t* base_b, int64_t* grand_b, int round_b, int n) {
     const int tid = simt::tid(), nth = simt::nthreads();
