@@ -421,6 +421,7 @@ def main():
                 en.encode_batch_device(warm[0].data_ptr(), warm[1].data_ptr(), warm[4], warm[2], warm[3].data_ptr(), warm[2], d_ooffs.data_ptr(), stream)
             else:
                 nt = step(en)
+            en.piece_stats()       # (waits for the promotion a learning warm-up step left running behind it: the next warm-up step can be the second round)
         if warm is not None:       # (after 5 GB of other documents every memo slot is taken: the timed steps cannot add entries of their own)
             en.set_option(N.OPT_PIECE_MEMO, 0)
             nt = step(en)

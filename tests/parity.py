@@ -591,6 +591,54 @@ def check_runtime_overrides(lib, O, vocab, ovocab, seed=71):
         O.set_case_equivalence(False)
 
 
+def check_sizing_attempt(lib, O, vocab, ovocab, capfd, pattern=N.CL100K, seed=43):
+    """A fresh workspace's first large batch probes a sample of its sub-tiles first (encode_device: the sizing attempt) and every attempt after the first
+    starts behind the pre-tokenizer, on the bitmaps the first one left.  Same ids as the oracle when the sample predicts the lists the batch needs (two
+    attempts), when the crowded text lies behind the sample (three: sample, overflow, again), and on ordinary text (two); the attempts are read off the
+    library's TKZ_LOG_SLOW_MS line.  The threshold is 64 MB of text: TKZ_SIZING_MIN_SUB brings it down to what a test can afford."""
+    import re
+    rng = random.Random(seed)
+    cons = "bcdfghjklmnpqrstvwxz"
+    words = "the of and to in is that for it with as was on be at by this had not are but from or have an they which one you were her all".split()
+
+    def gib(n, lo, hi):
+        out = []
+        while sum(map(len, out)) < n:
+            out.append(" " + "".join(rng.choice(cons) for _ in range(rng.randint(lo, hi))))
+        return "".join(out)[:n]
+
+    def plain(n):
+        out = []
+        while sum(map(len, out)) < n:
+            out.append(" " + rng.choice(words))
+        return "".join(out)[:n]
+    oenc = O.Encoder(ovocab, pattern)
+    crowded_all = [gib(4000, 2, 3).encode() for _ in range(45)]                                     # every sub-tile overflows a fresh list
+    crowded_tail = [plain(4000).encode() for _ in range(40)] + [gib(4000, 2, 2).encode() for _ in range(5)]
+    ordinary = [(plain(3000) + gib(300, 4, 9)).encode() for _ in range(50)]
+    old = {k: os.environ.get(k) for k in ("TKZ_SIZING_MIN_SUB", "TKZ_LOG_SLOW_MS")}
+    os.environ["TKZ_SIZING_MIN_SUB"] = "128"; os.environ["TKZ_LOG_SLOW_MS"] = "0"
+    try:
+        for docs, attempts in ((crowded_all, 2), (crowded_tail, 3), (ordinary, 2)):
+            enc = N.Encoder(vocab, pattern)
+            data, offs = pack(docs)
+            assert len(data) > 140000
+            exp, eoff = oracle_encode_docs(oenc, docs)
+            for rep, want in ((0, attempts), (1, 1)):              # (the second call: a sized workspace, one attempt)
+                capfd.readouterr()
+                ids, ooff = enc.encode_batch(data, offs)
+                err = capfd.readouterr().err
+                assert ooff.tolist() == eoff and ids.tolist() == exp, (attempts, rep)
+                got = [int(m) for m in re.findall(r"(\d+) attempt", err)]
+                assert got and got[-1] == want, (attempts, rep, err)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def check_miss_lists(lib, O, vocab, ovocab, pattern=N.CL100K, seed=41):
     """The per-sub-tile miss lists (k_probe -> merge kernels -> k_place): sub-tiles with more misses than a list starts with (the batch
     is redone with longer lists), short and long misses sharing one list from both ends, a sub-tile of 1024 one-byte pieces, and calls

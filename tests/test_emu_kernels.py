@@ -149,6 +149,11 @@ def test_host_runtime_defines_the_split(lib, vocabs, oracle_mod):
     parity.check_runtime_overrides(lib, oracle_mod, v, ov)
 
 
+def test_sizing_attempt_and_reused_bitmaps(lib, vocabs, oracle_mod, capfd):
+    v, ov = vocabs("gpt2")
+    parity.check_sizing_attempt(lib, oracle_mod, v, ov, capfd)
+
+
 def test_miss_lists(lib, vocabs, oracle_mod):
     v, ov = vocabs("gpt2")
     parity.check_miss_lists(lib, oracle_mod, v, ov)

@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -49,10 +50,19 @@ struct DeviceScope {
     } while (0)
 
 // a grow-only device buffer
+// TKZ_LOG_SLOW_MS=<n> in the environment: a batch call that takes longer than n ms on the host says so on stderr, with the time it spent in
+// hipMalloc/hipFree (a fresh encoder's first large batch sizes its workspace: gigabytes from the driver, which on some boxes takes seconds)
+thread_local int64_t g_alloc_ns = 0;
+thread_local int g_alloc_calls = 0;
+struct AllocClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~AllocClock() { g_alloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); ++g_alloc_calls; }
+};
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
     hipError_t ensure(size_t n, int64_t* accounted) {
         if (n <= cap) return hipSuccess;
+        AllocClock clock;
         size_t want = std::max(n, cap + cap / 2);
         want = (want + 255) & ~size_t(255);
         void* q = nullptr;
@@ -64,7 +74,7 @@ struct DevBuf {
         p = q; cap = want;
         return hipSuccess;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) { AllocClock clock; (void)hipFree(p); } p = nullptr; cap = 0; }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -108,6 +118,7 @@ struct Workspace {
     DevView w_counters, w_docbits, w_heavyq;
     DevBuf w_mlist, w_mquad, w_mcount, w_pextra, w_coopq;
     DevBuf w_counts3;                      // {n_docs, n_bytes, n_tokens} of the batch this workspace is running (tkz_pending_counts_device)
+    bool sized = false;                    // a batch has run to its end here: the lists and the record buffer have seen real text (encode_device: the sizing attempt)
     int32_t mcap = tkz::kMissCapMin;       // entries of a sub-tile's miss list; grows (once, to what the batch needed) when a sub-tile overflows it
     bool place128 = false;                 // a recent batch of this workspace had more than a fifth of its sub-tiles above 64 list entries: k_place<128>
     int low_lists = 0, low_place = 0;      // consecutive batches that would have done with shorter lists / with k_place<64> (hysteresis: kLowBatches)
@@ -530,8 +541,32 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         tkz_encoder* e; Workspace* ws; bool keep = false;
         ~LearnGuard() { if (!keep && ws->learning) { ws->learning = false; std::lock_guard<std::mutex> lock(e->mu); e->learning = false; } }
     } learn_guard{e, ws};
+    struct SlowCallLog {
+        int64_t total; int attempts = 0; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        SlowCallLog(int64_t n) : total(n) { g_alloc_ns = 0; g_alloc_calls = 0; }
+        ~SlowCallLog() {
+            const char* v = getenv("TKZ_LOG_SLOW_MS");
+            const long limit_ms = v ? atol(v) : -1L;
+            if (limit_ms < 0) return;
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > (double)limit_ms)
+                { fprintf(stderr, "tkz: batch call of %lld bytes: %.1f ms on the host, %.1f ms of it in %d hipMalloc/hipFree calls, %d attempt(s)\n", (long long)total, ms, (double)g_alloc_ns * 1e-6, g_alloc_calls, attempts); fflush(stderr); }
+        }
+    } slow_log(total);
+    // An attempt that has to be run again (lists, records or scratch to grow) leaves the document marks and the piece-start bitmap as they are: the
+    // next one starts behind the pre-tokenizer.
+    bool marks_ready = false;
     for (int attempt = 0; attempt < 5; ++attempt) {
+        slow_log.attempts = attempt + 1;
         bool pieces_over = false;
+        // THE SIZING ATTEMPT: a fresh workspace's first large batch probes a sixteenth of its sub-tiles first.  How long the miss lists must be (and, from the
+        // scan, how many records there are) is known after ~1 ms instead of after a whole attempt up to k_probe that is thrown away: a fresh encoder's first
+        // batch of text its vocabulary has not seen (5.1 GB, held-out vocabulary) went from 100 ms to ~50.  The full attempt follows on the same bitmaps; a
+        // sample that under-estimates leaves the ordinary retry.
+        int64_t kSizingMinSub = (int64_t(64) << 20) / kSub;                     // (64 MB of text; TKZ_SIZING_MIN_SUB: the tests' handle on it)
+        if (attempt == 0 && !ws->sized) { const char* v = getenv("TKZ_SIZING_MIN_SUB"); if (v && atoll(v) > 0) kSizingMinSub = atoll(v); }
+        const bool sizing = attempt == 0 && phase == kCallWhole && !ws->sized && pretok && !d_bitmap_only && !po && (total + kSub - 1) / kSub >= kSizingMinSub;
+        const bool marks_reused = marks_ready;
         Launch L{stream, e->profiling ? prof_hook : nullptr, ws};
         int32_t* counters = ws->w_counters.as<int32_t>();
         if (!(phase == kCallEnd && attempt == 0)) {              // (kCallEnd: the first attempt is in flight already)
@@ -559,6 +594,10 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         unsigned long long* pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head));
         uint64_t* docbits = ws->w_docbits.as<uint64_t>();
         uint64_t* startbits = ws->w_startbits.as<uint64_t>();
+        if (marks_reused) {      // (the counters and the sub-tile flags only)
+            HIP_TRY(hipMemsetAsync(ws->w_zero.p, 0, 256, stream));
+            if (!d_bitmap_only) HIP_TRY(hipMemsetAsync(ws->w_heavyq.p, 0, (size_t)(ws->w_zero.as<char>() + ws->zero_bytes - ws->w_heavyq.as<char>()), stream));
+        } else {
         HIP_TRY(hipMemsetAsync(ws->w_zero.p, 0, ws->zero_bytes, stream));      // counters, document-start bits, sub-tile flags
         launch_docmark(L, d_offs, n_docs, total, docbits, counters);
         if (!pretok) {
@@ -572,6 +611,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                                ws->w_xq.as<int64_t>(), reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, xcount)));
         }
         if (pretok && e->case_equiv && e->pattern == TKZ_PATTERN_CL100K) launch_case_equiv_fix(L, d_bytes, total, docbits, startbits);
+        }
         if (d_bitmap_only) {
             HIP_TRY(hipMemcpyAsync(d_bitmap_only, startbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
         } else {
@@ -631,6 +671,9 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                 pieces_over = np > po->piece_cap;
                 if (!pieces_over) launch_piece_index(L, startbits, nwords, total, ntiles, ws->w_dbase.as<int64_t>(), np, po->piece_boffs, d_offs, n_docs, po->doc_piece);
             }
+            if (sizing) {
+                launch_probe_sample(L, T, P, std::max<int64_t>(ntiles / 16, kSizingMinSub / 16));
+            } else {
             launch_encode(L, T, P, ntiles);
             if (P.stats) launch_miss_stats(L, P, ntiles);
             launch_scan2(L, ntiles, ws->w_bsum.as<int64_t>(), P.tile_count, ws->w_tbase.as<int64_t>(), grand, 1, nullptr, nullptr, nullptr, 1, K_SCAN);
@@ -641,6 +684,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             } else      // (the batch's {n_docs, n_bytes, n_tokens} blocks by the same launch)
                 launch_docoffs(L, d_offs, n_docs, total, ws->w_tbase.as<int64_t>(), docbits, P.docord_base, P.doc_tok, grand, d_out_offs,
                                n_docs, e->t_counts3.as<int64_t>(), ws->w_counts3.as<int64_t>(), d_counts3);
+            }
         }
         HIP_TRY(hipMemcpyAsync(ws->h_counters, counters, sizeof(CounterBlock), hipMemcpyDeviceToHost, stream));
         }
@@ -663,11 +707,13 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                                h[16], h[17], (double)h[17] / h[16], (double)h[18] / h[16], h[19], (double)h[22] / h[16], h[20], h[23]);
         }
 #endif
-        e->last_xcount = (int64_t)ws->h_counters->xcount; e->last_xcount2 = (int64_t)ws->h_counters->xcount2;
+        if (!marks_reused) { e->last_xcount = (int64_t)ws->h_counters->xcount; e->last_xcount2 = (int64_t)ws->h_counters->xcount2; }
         const int32_t err = ws->h_counters->err;
         if (err & kErrOffsets) return fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the byte count");
         if (err & kErrUtf8) return fail(TKZ_E_INVALID_UTF8, "input is not well-formed UTF-8 (or a document boundary falls inside a character)");
         if (err & kErrTooLong) return fail(TKZ_E_UNSUPPORTED, "a single piece longer than 2^30 bytes");
+        marks_ready = true;                // (what is wrong from here on is the size of a buffer)
+        if (!d_bitmap_only) ws->sized = true;
         if ((err & kErrPool) && attempt < 4) {
             // scratch for the giant pieces was too small.  pool_head keeps counting past the capacity, so it holds the exact need
             // (6 int32 per byte of every giant piece of the batch): size the pool for that -- not for the whole batch -- and rerun
@@ -699,6 +745,13 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             continue;
         }
         if (err & kErrCapacity) return fail(TKZ_E_DEVICE, "piece record buffer overflow");
+        if (sizing) {       // (the sample fitted the lists as they are; the records are counted exactly by the scan)
+            const size_t need = ((size_t)ws->h_counters->npieces + 4096) * 4;
+            if (need > ws->w_prank.cap && ws->w_prank.ensure(need, acc) != hipSuccess)
+                return fail(TKZ_E_OUT_OF_MEMORY, "piece records: " + std::to_string(need) + " bytes could not be allocated");
+            if (e->piece_stats && e->t_stats.p) HIP_TRY(hipMemcpyAsync(e->t_stats.p, e->t_stats.as<char>() + 64, 64, hipMemcpyDeviceToDevice, stream));
+            continue;
+        }
         if (err & kErrKeyNotFound) return fail(TKZ_E_KEY_NOT_FOUND, "a byte of the input is not in the vocabulary (KeyNotFoundException in the reference)");
         if (!d_bitmap_only && e->piece_stats) {
             std::lock_guard<std::mutex> lock(e->mu);

@@ -109,6 +109,7 @@ void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, co
                         int64_t* xq, unsigned long long* xcount);
 void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                        uint64_t* startbits, const uint8_t* bmp, int32_t* counters);
+void launch_probe_sample(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsample);
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub);
 void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, const SmallArgs& A);
 void launch_doccount(const Launch& L, const uint64_t* docbits, int64_t nwords, int64_t total, int64_t nsub, int32_t* cnt);

@@ -2718,6 +2718,16 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     }
     hook(L, K_HEAVY, 1);
 }
+// k_probe and the list statistics over the first `nsample` sub-tiles only (tkz_api.cpp: the sizing attempt of a fresh workspace)
+void launch_probe_sample(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsample) {
+    if (nsample > P.nsub) nsample = P.nsub;
+    hook(L, K_ENCODE, 0);
+    TKZ_LAUNCH(k_probe, xcd_grid(cdiv(nsample, (kThreads / 64) * kProbePer)), kThreads, L.stream, T, P);
+    hook(L, K_ENCODE, 1);
+    { const int64_t g = grid_for(nsample); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsample, P.mcap, P.counters,
+                                                     (const uint8_t*)P.heavy_flag, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap,
+                                                     (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap); }
+}
 void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, const SmallArgs& A) {
     TKZ_LAUNCH(k_small, 1, P.nsub <= 4 ? 256 : 1024, L.stream, T, P, A);
 }
