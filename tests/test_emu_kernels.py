@@ -149,6 +149,20 @@ def test_host_runtime_defines_the_split(lib, vocabs, oracle_mod):
     parity.check_runtime_overrides(lib, oracle_mod, v, ov)
 
 
+def test_throughput_setting_on_small_batches(lib, vocabs, oracle_mod, monkeypatch):
+    """Batches of at most TKZ_OPT_LATENCY_BYTES (16 MB: every batch of this suite) hand missed pieces of more than 32 bytes to k_merge_coop; with the option
+    at 0 they are merged a lane each up to 128 bytes, as in the large batches the bench times: the same checks on that setting."""
+    monkeypatch.setenv("TKZ_LATENCY_BYTES", "0")
+    v, ov = vocabs("gpt2")
+    parity.check_miss_lists(lib, oracle_mod, v, ov)
+    parity.check_long_pieces_entry_points(lib, oracle_mod, v, ov)
+    parity.check_batch(lib, oracle_mod, v, ov, N.CL100K, seed=97, rounds=3, doc_lens=[0, 1, 10, 100, 1000, 6000], n_docs_choices=[1, 4, 40], kinds=("mix", "ws", "oth"))
+    enc = N.Encoder(v, N.CL100K)
+    enc.set_option(N.OPT_LATENCY_BYTES, 1 << 20)
+    with pytest.raises(N.TkzError):
+        enc.set_option(N.OPT_LATENCY_BYTES, -1)
+
+
 def test_sizing_attempt_and_reused_bitmaps(lib, vocabs, oracle_mod, capfd):
     v, ov = vocabs("gpt2")
     parity.check_sizing_attempt(lib, oracle_mod, v, ov, capfd)

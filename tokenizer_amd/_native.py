@@ -19,6 +19,7 @@ OPT_PIECE_MEMO = 2
 OPT_PIECE_STATS = 3
 OPT_PROMOTE_MIN_BYTES, OPT_PROMOTE_CAP = 5, 6
 OPT_CASE_EQUIVALENCE = 7    # cl100k's (?i:...) with .NET >= 7's case-equivalence tables ('ſ is 's)
+OPT_LATENCY_BYTES = 8       # batches of at most this many bytes merge long missed pieces a wavefront each (tkz.h)
 OPT_PROMOTE = 4        # 0 / 1: automatic promotion of hot memo entries into the key tables off / on; 2: promote now; 3: drop the promotions
 K_NAMES = ["k_docmark", "k_pretok", "k_probe", "k_scan", "k_place", "k_docoffs", "k_merge_long_group", "k_merge_short"]
 

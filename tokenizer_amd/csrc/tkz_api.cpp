@@ -188,6 +188,7 @@ struct tkz_encoder {
     std::atomic<int64_t> last_xcount{0}, last_xcount2{0};   // tkz_encoder_pretok_leftovers
     bool small_ok = false;                 // the device's LDS per workgroup holds k_small's (kSmallLdsBytesNeeded)
     bool piece_stats = false;              // TKZ_OPT_PIECE_STATS
+    int64_t latency_bytes = [] { const char* v = getenv("TKZ_LATENCY_BYTES"); return v ? (int64_t)atoll(v) : int64_t(16) << 20; }();   // TKZ_OPT_LATENCY_BYTES
     bool case_equiv = false;               // TKZ_OPT_CASE_EQUIVALENCE: `'` + U+017F is a contraction under cl100k (a .NET >= 7 host)
     size_t bmp_image_bytes = 0;            // the class table image on the device (t_bmp)
     DevBuf t_stats;                        // its device block (EncodeParams::stats)
@@ -334,11 +335,16 @@ tkz_status build_key_tables_image(tkz_encoder* e, const std::vector<tkz::KeyItem
     tkz::build_key_tables(items, &ss, &img->sseed, &ms, &img->mseed);
     const size_t short_bytes = ss.size() * sizeof(TkzShortSlot), mid_bytes = ms.size() * sizeof(TkzMidSlot);
     int64_t acc = 0;
-    hipError_t h = img->nt.ensure(std::max<size_t>(64, short_bytes + mid_bytes), &acc);
-    if (h == hipSuccess && short_bytes) h = hipMemcpy(img->nt.p, ss.data(), short_bytes, hipMemcpyHostToDevice);
-    if (h == hipSuccess && mid_bytes) h = hipMemcpy(static_cast<char*>(img->nt.p) + short_bytes, ms.data(), mid_bytes, hipMemcpyHostToDevice);
+    // (uploads on a stream of their own: on the null stream they would queue behind the batches the host has in flight there)
+    hipStream_t cs = nullptr;
+    hipError_t h = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (h == hipSuccess) h = img->nt.ensure(std::max<size_t>(64, short_bytes + mid_bytes), &acc);
+    if (h == hipSuccess && short_bytes) h = hipMemcpyAsync(img->nt.p, ss.data(), short_bytes, hipMemcpyHostToDevice, cs);
+    if (h == hipSuccess && mid_bytes) h = hipMemcpyAsync(static_cast<char*>(img->nt.p) + short_bytes, ms.data(), mid_bytes, hipMemcpyHostToDevice, cs);
     if (h == hipSuccess) h = img->np.ensure(std::max<size_t>(64, promo_quads.size() * 4), &acc);
-    if (h == hipSuccess && !promo_quads.empty()) h = hipMemcpy(img->np.p, promo_quads.data(), promo_quads.size() * 4, hipMemcpyHostToDevice);
+    if (h == hipSuccess && !promo_quads.empty()) h = hipMemcpyAsync(img->np.p, promo_quads.data(), promo_quads.size() * 4, hipMemcpyHostToDevice, cs);
+    if (h == hipSuccess) h = hipStreamSynchronize(cs);
+    if (cs) (void)hipStreamDestroy(cs);
     if (h != hipSuccess) { img->nt.release(); img->np.release(); return fail(TKZ_E_DEVICE, std::string("promoted tables: ") + hipGetErrorString(h)); }
     img->short_bytes = short_bytes; img->n_short_slots = ss.size(); img->n_mid_slots = ms.size(); img->n_promo = promo_items.size();
     return TKZ_OK;
@@ -508,10 +514,25 @@ tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool 
 struct PiecesOut { int64_t* piece_boffs; int64_t* piece_toffs; int64_t* doc_piece; int64_t piece_cap; int64_t n_pieces; };
 
 // the batch on the device; when pretok == false every "document" is taken as one piece
+struct SlowCallLog {
+    int64_t total; int attempts = 0; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    SlowCallLog(int64_t n) : total(n) { g_alloc_ns = 0; g_alloc_calls = 0; }
+    ~SlowCallLog() {
+        const char* v = getenv("TKZ_LOG_SLOW_MS");
+        const long limit_ms = v ? atol(v) : -1L;
+        if (limit_ms < 0) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > (double)limit_ms)
+            { fprintf(stderr, "tkz: batch call of %lld bytes: %.1f ms on the host, %.1f ms of it in %d hipMalloc/hipFree calls, %d attempt(s)\n", (long long)total, ms, (double)g_alloc_ns * 1e-6, g_alloc_calls, attempts); fflush(stderr); }
+    }
+};
 enum { kCallWhole = 0, kCallBegin = 1, kCallEnd = 2 };
+// the caller's page-locked text and offsets as the device sees them: encode_device fetches them itself (k_ingest) into d_bytes / d_offs
+struct IngestSrc { const uint8_t* h_bytes; const int64_t* h_offs; };
 tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                          int32_t* d_out, int64_t out_cap, int64_t* d_out_offs, hipStream_t stream, bool pretok,
-                         uint64_t* d_bitmap_only, int64_t* total_tokens, PiecesOut* po = nullptr, int phase = kCallWhole, int64_t* d_counts3 = nullptr) {
+                         uint64_t* d_bitmap_only, int64_t* total_tokens, PiecesOut* po = nullptr, int phase = kCallWhole, int64_t* d_counts3 = nullptr,
+                         const IngestSrc* ingest = nullptr) {
     // phase: kCallWhole -- enqueue, wait, evaluate (and again if a buffer had to grow); kCallBegin -- enqueue the first attempt and
     // return; kCallEnd -- wait for that attempt, evaluate, and carry on as kCallWhole does (tkz_encode_batch_device_begin / _end)
     using namespace tkz;
@@ -532,6 +553,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         return TKZ_OK;
     }
     const int64_t ntiles = (total + kSub - 1) / kSub;       // sub-tiles: one wavefront each
+    SlowCallLog slow_log(total);
     { const tkz_status ps = prepare_workspace(ws, total, n_docs, d_bitmap_only != nullptr, po != nullptr); if (ps != TKZ_OK) return ps; }
     int64_t* acc = &ws->bytes_allocated;
     if (!ws->h_counters) HIP_TRY(hipHostMalloc((void**)&ws->h_counters, sizeof(CounterBlock), 0));
@@ -541,18 +563,6 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         tkz_encoder* e; Workspace* ws; bool keep = false;
         ~LearnGuard() { if (!keep && ws->learning) { ws->learning = false; std::lock_guard<std::mutex> lock(e->mu); e->learning = false; } }
     } learn_guard{e, ws};
-    struct SlowCallLog {
-        int64_t total; int attempts = 0; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-        SlowCallLog(int64_t n) : total(n) { g_alloc_ns = 0; g_alloc_calls = 0; }
-        ~SlowCallLog() {
-            const char* v = getenv("TKZ_LOG_SLOW_MS");
-            const long limit_ms = v ? atol(v) : -1L;
-            if (limit_ms < 0) return;
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (ms > (double)limit_ms)
-                { fprintf(stderr, "tkz: batch call of %lld bytes: %.1f ms on the host, %.1f ms of it in %d hipMalloc/hipFree calls, %d attempt(s)\n", (long long)total, ms, (double)g_alloc_ns * 1e-6, g_alloc_calls, attempts); fflush(stderr); }
-        }
-    } slow_log(total);
     // An attempt that has to be run again (lists, records or scratch to grow) leaves the document marks and the piece-start bitmap as they are: the
     // next one starts behind the pre-tokenizer.
     bool marks_ready = false;
@@ -598,7 +608,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             HIP_TRY(hipMemsetAsync(ws->w_zero.p, 0, 256, stream));
             if (!d_bitmap_only) HIP_TRY(hipMemsetAsync(ws->w_heavyq.p, 0, (size_t)(ws->w_zero.as<char>() + ws->zero_bytes - ws->w_heavyq.as<char>()), stream));
         } else {
-        HIP_TRY(hipMemsetAsync(ws->w_zero.p, 0, ws->zero_bytes, stream));      // counters, document-start bits, sub-tile flags
+        if (ingest) launch_ingest(L, ingest->h_bytes, total, const_cast<uint8_t*>(d_bytes), ingest->h_offs, n_docs + 1, const_cast<int64_t*>(d_offs), ws->w_zero.p, (int64_t)ws->zero_bytes);
+        else HIP_TRY(hipMemsetAsync(ws->w_zero.p, 0, ws->zero_bytes, stream));      // counters, document-start bits, sub-tile flags
         launch_docmark(L, d_offs, n_docs, total, docbits, counters);
         if (!pretok) {
             HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
@@ -626,7 +637,12 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
             P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
             P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
-            P.coop_q = ws->w_coopq.as<uint64_t>(); P.coop_cap = total / kLanePiece + 64;
+            // (a batch of at most 16 MB waits for its slowest wavefront, not for throughput: a lone 100-byte piece in a lane of k_merge_long was 100 us of
+            //  the 340 a 1 MB call took; a wavefront of k_merge_coop has it in ~10.  TKZ_OPT_LATENCY_BYTES)
+            P.lane_piece = total <= e->latency_bytes ? kLatencyLanePiece : kLanePiece;
+            P.coop_cap = total / P.lane_piece + 64;
+            HIP_TRY(ws->w_coopq.ensure((size_t)P.coop_cap * 8, acc));
+            P.coop_q = ws->w_coopq.as<uint64_t>();
             P.coop_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, coop_count));
             P.coop_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, coop_ticket));
             P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
@@ -861,7 +877,7 @@ tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, con
     P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
     P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
     P.pool = ws->w_pool.as<int32_t>(); P.pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head)); P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
-    P.ablate = 0; P.devprof = nullptr; P.stats = nullptr; P.place128 = 0; P.promo = nullptr; P.pextra = nullptr;
+    P.ablate = 0; P.devprof = nullptr; P.stats = nullptr; P.place128 = 0; P.promo = nullptr; P.pextra = nullptr; P.lane_piece = kSmallLanePiece;
     SmallArgs A{};
     A.h_bytes = H + kSmallOffBytes; A.h_offs = reinterpret_cast<const int64_t*>(H + kSmallOffOffs);
     A.out = reinterpret_cast<int32_t*>(H + kSmallOffIds); A.out_cap = std::min<int64_t>(out_cap, kSmallMaxBytes); A.out_offs = reinterpret_cast<int64_t*>(H + kSmallOffOut);
@@ -1062,8 +1078,13 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
     bool over = false;                                       // out_cap exceeded: the remaining chunks are only counted
     tkz_status first_err = TKZ_OK;
     std::string first_msg;
-    st = stage_in(0);
-    if (st != TKZ_OK) return st;
+    // (one small chunk on page-locked buffers: no upload stream at all -- the launch sequence starts with k_ingest, which fetches the text itself)
+    const bool ingest_in = direct_out && !u16 && pin_in && total > 0 && (reinterpret_cast<uintptr_t>(dv_in) & 15) == 0;
+    const IngestSrc ingest_src{static_cast<const uint8_t*>(dv_in), static_cast<const int64_t*>(dv_offs)};
+    if (!ingest_in) {
+        st = stage_in(0);
+        if (st != TKZ_OK) return st;
+    }
     for (int64_t k = 0; k < nchunks; ++k) {
         const int q = (int)(k & 1);
         const int64_t d0 = cut[(size_t)k], d1 = cut[(size_t)k + 1], nu = offs[d1] - offs[d0], nd = d1 - d0;
@@ -1081,7 +1102,7 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
                              U.offs.as<int64_t>(), nd, U.grp.as<int32_t>(), reinterpret_cast<int64_t*>(U.counters.as<char>() + 8), U.boffs.as<int64_t>());
             cb = ws->u_bytes.as<uint8_t>(); co = U.boffs.as<int64_t>();
         } else {
-            HIP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_in[q], 0));
+            if (!ingest_in) HIP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_in[q], 0));
             cb = ws->s_bytes[q].as<uint8_t>(); co = ws->s_offs[q].as<int64_t>(); cbytes = nu;
         }
         if (k >= 2) HIP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_out[q], 0));   // the download of chunk k-2 has left this set's output buffers
@@ -1089,7 +1110,8 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
         int64_t* dst_offs = direct_out ? static_cast<int64_t*>(dv_ooffs) : ws->s_outoffs[q].as<int64_t>();
         const int64_t cap = over ? 0 : (direct_out ? std::min<int64_t>(out_cap, cbytes) : std::min<int64_t>(out_cap - tok_base[(size_t)k], cbytes));
         int64_t tokens = 0;
-        st = encode_device(e, ws, cb, co, nd, cbytes, dst_ids, cap, dst_offs, ws->st_compute, true, nullptr, &tokens);      // (returns when st_compute has drained)
+        st = encode_device(e, ws, cb, co, nd, cbytes, dst_ids, cap, dst_offs, ws->st_compute, true, nullptr, &tokens, nullptr, kCallWhole, nullptr,
+                           ingest_in ? &ingest_src : nullptr);      // (returns when st_compute has drained)
         tok_base[(size_t)k + 1] = tok_base[(size_t)k] + tokens;
         if (st == TKZ_E_CAPACITY) { over = true; continue; }
         if (st != TKZ_OK) { first_err = st; first_msg = g_err; break; }
@@ -1637,6 +1659,12 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
             HIP_TRY(hipMemset(e->t_stats.p, 0, 128));
         }
         e->piece_stats = value != 0;
+        return TKZ_OK;
+    }
+    if (option == TKZ_OPT_LATENCY_BYTES) {
+        if (value < 0) return fail(TKZ_E_ARG, "negative value");
+        std::lock_guard<std::mutex> lock(e->mu);
+        e->latency_bytes = value;
         return TKZ_OK;
     }
     if (option == TKZ_OPT_CASE_EQUIVALENCE) {

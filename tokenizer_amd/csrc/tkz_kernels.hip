@@ -846,7 +846,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
             if (miss_l && il + ns < P.mcap) ml[P.mcap - 1 - il] = ent;
             uint32_t rec = ((s_mark[s >> 5] >> (s & 31)) & 1u) ? kPrMark : 0u;
             if (REPORT) giant = giant || (miss_l && len > kSmallLanePiece);      // (k_small, the only REPORT user, hands a batch with such a piece back like one with a giant piece: k_merge_coop is a kernel of the batch path)
-            else coopl = coopl || (miss_l && len > kLanePiece);
+            else coopl = coopl || (miss_l && len > P.lane_piece);
             if (is_giant) { rec |= kPrMiss | kPrGiant | (uint32_t)s; giant = giant || valid; }
             else if (miss) rec |= kPrMiss | (miss_l ? (kPrLong | (uint32_t)il) : (uint32_t)is_);
             else rec |= (uint32_t)rank;
@@ -1440,7 +1440,7 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
     TKZ_SHARED uint4 s_lds[kLongLdsQuads];
     const LongLds LD = tkz_long_lds(s_lds);
     tkz_long_brank_init(T, LD.brank);
-    tkz_merge_long_chunks<COMPACT>(T, P, simt::bid(), simt::nblocks(), LD);
+    tkz_merge_long_chunks<COMPACT>(T, P, simt::bid(), simt::nblocks(), LD, P.lane_piece);
 }
 
 // The missed pieces of kLanePiece + 1 .. kArenaPiece bytes: ONE WAVEFRONT per piece, with the giant pieces' merger (tkz_bpe_long_tail: batches of proposals with
@@ -2097,6 +2097,18 @@ TKZ_KERNEL(256) void k_case_equiv_fix(const uint8_t* bytes, int64_t total, const
 }
 
 // document offsets of a chunk cut out of a larger batch: made relative to the chunk's first byte
+// A small host batch on page-locked buffers: the text and the offsets come over PCIe by this kernel's own loads (they are device-visible), into the
+// staging buffers the other kernels read, and the workspace's zero region is cleared by the same launch -- in place of two copy commands, two fills and
+// the stream hand-over between them (68 us before the first kernel of a 1 MB call; this is ~25).  h_bytes 16-byte aligned.
+TKZ_KERNEL(256) void k_ingest(const uint8_t* h_bytes, int64_t total, uint8_t* d_bytes, const int64_t* h_offs, int64_t n_offs, int64_t* d_offs, uint4* zero, int64_t zero_quads) {
+    const int64_t i0 = (int64_t)simt::bid() * simt::nthreads() + simt::tid(), stride = (int64_t)simt::nblocks() * simt::nthreads();
+    const int64_t full = total >> 4;
+    for (int64_t i = i0; i < full; i += stride) *reinterpret_cast<uint4*>(d_bytes + 16 * i) = tkz_load16(h_bytes + 16 * i);
+    for (int64_t i = (full << 4) + i0; i < total; i += stride) d_bytes[i] = h_bytes[i];          // (nothing is read beyond the caller's buffer)
+    for (int64_t i = i0; i < n_offs; i += stride) d_offs[i] = h_offs[i];
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (int64_t i = i0; i < zero_quads; i += stride) zero[i] = z;
+}
 TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
     for (int64_t i = simt::bid() * simt::nthreads() + simt::tid(); i < n; i += stride) offs[i] -= base;
@@ -2110,7 +2122,7 @@ TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
 // (... and, in the same pass over the sub-tiles, k_giant_find's: a sub-tile k_probe flagged as holding a giant piece queues it -- one launch less)
 TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t mcap, int32_t* counters,
                                   const uint8_t* heavy_flag, const uint64_t* startbits, int64_t nwords, int64_t total, int64_t* gq, unsigned long long* gcount, int64_t gcap,
-                                  const uint32_t* mlist, uint64_t* coop_q, unsigned long long* coop_count, int64_t coop_cap) {
+                                  const uint32_t* mlist, uint64_t* coop_q, unsigned long long* coop_count, int64_t coop_cap, int lane_piece) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
     const int lane = simt::lane();
     int mx = 0, big = 0, over = 0;
@@ -2129,7 +2141,7 @@ TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t 
             const int nl = (int)(m >> 16);
             int mine = 0;
             if ((hf & 4u) && n <= mcap)
-                for (int j = 0; j < nl; ++j) mine += ((int)((mlist[i * (int64_t)mcap + (mcap - 1 - j)] >> kMrLenShift) & 1023u) + 1 > kLanePiece) ? 1 : 0;
+                for (int j = 0; j < nl; ++j) mine += ((int)((mlist[i * (int64_t)mcap + (mcap - 1 - j)] >> kMrLenShift) & 1023u) + 1 > lane_piece) ? 1 : 0;
             int tot;
             const int pre = tkz_wave_scan_sum(mine, &tot);
             unsigned long long base = 0;
@@ -2138,7 +2150,7 @@ TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t 
             if (mine) {
                 unsigned long long at = base + (unsigned long long)pre;
                 for (int j = 0; j < nl; ++j)
-                    if ((int)((mlist[i * (int64_t)mcap + (mcap - 1 - j)] >> kMrLenShift) & 1023u) + 1 > kLanePiece) { if ((int64_t)at < coop_cap) coop_q[at] = ((uint64_t)i << 10) | (uint64_t)j; ++at; }
+                    if ((int)((mlist[i * (int64_t)mcap + (mcap - 1 - j)] >> kMrLenShift) & 1023u) + 1 > lane_piece) { if ((int64_t)at < coop_cap) coop_q[at] = ((uint64_t)i << 10) | (uint64_t)j; ++at; }
             }
         }
     }
@@ -2695,7 +2707,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     // (the list statistics and, in the same pass, the giant pieces of the sub-tiles k_probe flagged: queued for k_giant_order / k_giant_merge)
     { const int64_t g = grid_for(nsub); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsub, P.mcap, P.counters,
                                                      (const uint8_t*)P.heavy_flag, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap,
-                                                     (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap); }
+                                                     (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap, (int)P.lane_piece); }
     hook(L, K_MERGE_SHORT, 0);
     TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
     hook(L, K_MERGE_SHORT, 1);
@@ -2726,7 +2738,12 @@ void launch_probe_sample(const Launch& L, const TkzTables& T, const EncodeParams
     hook(L, K_ENCODE, 1);
     { const int64_t g = grid_for(nsample); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsample, P.mcap, P.counters,
                                                      (const uint8_t*)P.heavy_flag, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap,
-                                                     (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap); }
+                                                     (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap, (int)P.lane_piece); }
+}
+void launch_ingest(const Launch& L, const uint8_t* h_bytes, int64_t total, uint8_t* d_bytes, const int64_t* h_offs, int64_t n_offs, int64_t* d_offs, void* zero, int64_t zero_bytes) {
+    const int64_t quads = std::max<int64_t>(total / 16 + 1, (zero_bytes + 15) / 16);
+    const int64_t g = cdiv(quads, kThreads * 4);               // (four quads a thread: ~64 loads over PCIe in flight per wavefront is what fills the link)
+    TKZ_LAUNCH(k_ingest, g < 1 ? 1 : (g > 2048 ? 2048 : g), kThreads, L.stream, h_bytes, total, d_bytes, h_offs, n_offs, d_offs, reinterpret_cast<uint4*>(zero), (zero_bytes + 15) / 16);
 }
 void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, const SmallArgs& A) {
     TKZ_LAUNCH(k_small, 1, P.nsub <= 4 ? 256 : 1024, L.stream, T, P, A);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-5 GPU job: stages selected by name.  usage: tools/gpu_job_r05.sh <tag> "<stages>"
-#   stages: tests subset smoke bench kind6 variants profile profile_mixed profile_real shapes latency cold fuzz
+#   stages: tests subset smoke bench kind6 variants profile profile_mixed profile_real shapes latency midtrace cold fuzz
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; TAG=${1:-r05}; STAGES=${2:-"subset bench"}; O=gpurun_out/$TAG; mkdir -p $O
 has() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
@@ -77,5 +77,13 @@ if has profile_mixed; then bash tools/gpu_profile.sh ${TAG}_mixed 2000000 "--kin
 if has profile_real; then bash tools/gpu_profile.sh ${TAG}_real 0 "--kind 6 --real-text-mb 0 --vocab gpt2 --pattern 1 --no-memo-steps 0" > $O/profile_real.log 2>&1; lap "profile real rc=$?"; fi
 if has latency; then timeout 300 python tools/latency_probe.py > $O/latency.json 2> $O/latency.err; lap "latency rc=$?"; cat $O/latency.json; fi
 if has fuzz; then timeout 200 python tools/gpu_fuzz.py 60 > $O/fuzz.log 2>&1; lap "fuzz rc=$?"; tail -2 $O/fuzz.log; fi
-if has cold; then timeout 300 python tools/cold_probe.py synth100k_heldout > $O/cold_probe.jsonl 2> $O/cold.err; timeout 300 python tools/cold_probe.py synth100k >> $O/cold_probe.jsonl 2>> $O/cold.err; lap "cold rc=$?"; cat $O/cold_probe.jsonl; fi
+if has midtrace; then
+  for mb in ${MIDMB:-0.25 1 4}; do
+    ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $REPO/$O/midtrace_$mb -- python $REPO/tools/midsize_trace.py run $mb 12 ) > $O/midtrace_$mb.json 2> $O/midtrace_$mb.err
+    tail -1 $O/midtrace_$mb.json; python tools/midsize_trace.py show $O/midtrace_$mb | tee $O/midtrace_$mb.txt
+    find $O/midtrace_$mb -name "*.csv" -size +2M -delete
+  done
+  lap "midtrace"
+fi
+if has cold; then export TKZ_LOG_SLOW_MS=300; timeout 300 python tools/cold_probe.py synth100k_heldout > $O/cold_probe.jsonl 2> $O/cold.err; timeout 300 python tools/cold_probe.py synth100k >> $O/cold_probe.jsonl 2>> $O/cold.err; lap "cold rc=$?"; cat $O/cold_probe.jsonl; fi
 lap done
