@@ -970,7 +970,10 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
     //  round 5: 16 MB chunks ran a 512 MB batch at 26 GB/s where 48 MB chunks had run it at 42)
     static const int64_t kChunkBytes = [] { const char* v = getenv("TKZ_HOST_CHUNK_BYTES"); const long long n = v ? atoll(v) : 0; return n > 0 ? (int64_t)n : (int64_t(32) << 20); }();
     const int64_t up_bytes = total * unit;
-    int64_t nchunks = (bitmap || !pretok || 2 * up_bytes < 3 * kChunkBytes) ? 1 : std::min<int64_t>(1024, std::max<int64_t>(2, (up_bytes + kChunkBytes / 2) / kChunkBytes));
+    // (between 12 MB and 4 chunks' worth the chunks are a quarter of the batch, but at least 8 MB: a 64 MB batch as 4 x 16 MB has its uploads, kernels and
+    //  downloads overlapped -- 2 x 32 MB ran at 24.8 GB/s, no faster than one after the other)
+    const int64_t chunk_bytes = std::min(kChunkBytes, std::max(std::min(kChunkBytes, int64_t(8) << 20), up_bytes / 4));
+    int64_t nchunks = (bitmap || !pretok || 2 * up_bytes < 3 * chunk_bytes) ? 1 : std::min<int64_t>(1024, std::max<int64_t>(2, (up_bytes + chunk_bytes / 2) / chunk_bytes));
     // chunk boundaries on documents: chunk k = documents [cut[k], cut[k+1]).  Offsets that are not monotone cannot be cut: the
     // whole batch then goes as one chunk and the device reports them (k_docmark)
     std::vector<int64_t> cut((size_t)nchunks + 1, 0);

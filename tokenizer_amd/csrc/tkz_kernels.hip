@@ -1239,7 +1239,7 @@ TKZ_DEV void tkz_long_brank_init(const TkzTables& T, int32_t* s_brank) {     // 
 }
 // chunks c0, c0 + cstep, ... of 64 sub-tiles each, by one wavefront
 // (COMPACT: ranks below 2^21, i.e. every published vocabulary -- no ids[] array)
-template <bool COMPACT>
+template <bool COMPACT, int PARTS = kLongParts, int DENSE = kLongDense>
 // (lane_piece: pieces of up to this many bytes are merged here -- kLanePiece on the batch path, which has k_merge_coop for the longer ones; the
 //  single-launch kernel has no such kernel and takes kSmallLanePiece)
 TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, int64_t c0, int64_t cstep, const LongLds& LD, const int lane_piece = kLanePiece) {
@@ -1256,7 +1256,7 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
     // (part-major: units 0 .. nchunks-1 are part 0 of every chunk.  Chunk-major -- unit u = part u % 4 of chunk u / 4 -- put the only units that have
     //  work in sparse text, the parts 0, on workgroups 0, 4, 8 ...: workgroups go round the 8 XCDs, so two of them did everything, 1.4 -> 5 ms.)
     const int64_t nchunks = (P.nsub + 63) / 64;
-    for (int64_t u = c0; u < nchunks * kLongParts; u += cstep) {
+    for (int64_t u = c0; u < nchunks * PARTS; u += cstep) {
         const int64_t c = u % nchunks;
         const int part = (int)(u / nchunks);
         const int64_t t = c * 64 + lane;
@@ -1270,7 +1270,7 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
         }
         int ntotal;
         (void)tkz_wave_scan_sum(my_nl, &ntotal);
-        if (ntotal > kLongDense) { if (lane / (64 / kLongParts) != part) my_nl = 0; }      // dense: this unit's share of the sub-tiles
+        if (ntotal > DENSE) { if (lane / (64 / PARTS) != part) my_nl = 0; }      // dense: this unit's share of the sub-tiles
         else if (part != 0) continue;                                                    // sparse: the whole chunk is part 0's
         const int pre = tkz_wave_scan_sum(my_nl, &ntotal);
         if (!ntotal) continue;
@@ -1434,13 +1434,17 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
 }
 // (a kernel of its own per form so that the general forms' registers stay out of the compact one)
-template <bool COMPACT>
+// (LATENCY: a small batch -- TKZ_OPT_LATENCY_BYTES --, where the call waits for the slowest wavefront: a unit of work is 4 sub-tiles whatever their lists hold
+//  -- ~20 entries of ordinary text, one batch of lanes -- instead of up to 64 sub-tiles and five batches one after the other: 93 us of a 1 MB call)
+constexpr int kLongPartsLatency = 16;
+template <bool COMPACT, bool LATENCY>
 TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
     if (tkz_attempt_failed(P)) return;
     TKZ_SHARED uint4 s_lds[kLongLdsQuads];
     const LongLds LD = tkz_long_lds(s_lds);
     tkz_long_brank_init(T, LD.brank);
-    tkz_merge_long_chunks<COMPACT>(T, P, simt::bid(), simt::nblocks(), LD, P.lane_piece);
+    if (LATENCY) tkz_merge_long_chunks<COMPACT, kLongPartsLatency, -1>(T, P, simt::bid(), simt::nblocks(), LD, P.lane_piece);
+    else tkz_merge_long_chunks<COMPACT>(T, P, simt::bid(), simt::nblocks(), LD, P.lane_piece);
 }
 
 // The missed pieces of kLanePiece + 1 .. kArenaPiece bytes: ONE WAVEFRONT per piece, with the giant pieces' merger (tkz_bpe_long_tail: batches of proposals with
@@ -2721,11 +2725,18 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     TKZ_LAUNCH(k_giant_order, 1, 1024, L.stream, P);
     TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // takes pieces off the ordered queue; exits at once when it is empty
     {   // strides over 64-sub-tile chunks
-        const int64_t chunks = cdiv(nsub, 64) * kLongParts, grid = chunks < 65536 ? chunks : 65536;      // (units of work: see kLongParts)
-        if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH(k_merge_long<true>, grid, 64, L.stream, T, P);
-        else TKZ_LAUNCH(k_merge_long<false>, grid, 64, L.stream, T, P);
-        // the pieces k_merge_long leaves to a whole wavefront, off the queue k_list_stats filled (every wavefront exits at once when it is empty)
-        const int64_t cgrid = cdiv(nsub, 64);
+        const bool latency = P.lane_piece == kLatencyLanePiece;
+        const int64_t chunks = cdiv(nsub, 64) * (latency ? kLongPartsLatency : kLongParts), grid = chunks < 65536 ? chunks : 65536;      // (units of work: see kLongParts)
+        if (latency) {
+            if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long<true, true>), grid, 64, L.stream, T, P);
+            else TKZ_LAUNCH((k_merge_long<false, true>), grid, 64, L.stream, T, P);
+        } else {
+            if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long<true, false>), grid, 64, L.stream, T, P);
+            else TKZ_LAUNCH((k_merge_long<false, false>), grid, 64, L.stream, T, P);
+        }
+        // the pieces k_merge_long leaves to a whole wavefront, off the queue k_list_stats filled (every wavefront exits at once when it is empty).  A small batch
+        // gets as many wavefronts as a large one: 16 of them took 107 us over the queue of a 1 MB call
+        const int64_t cgrid = latency ? 512 : cdiv(nsub, 64);
         TKZ_LAUNCH(k_merge_coop, cgrid < kCoopGrid ? cgrid : kCoopGrid, 64, L.stream, T, P);
     }
     hook(L, K_HEAVY, 1);
