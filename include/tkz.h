@@ -297,10 +297,10 @@ enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1,
         * is the contraction (none of the other letters of the seven literals has a non-ASCII equivalent).  No effect on the other patterns (pattern 1 is
         * case-sensitive, o200k lists its case variants). */
        TKZ_OPT_CASE_EQUIVALENCE = 7,
-       /* Batches of at most this many bytes are run for latency rather than throughput (default 16 MB; 0: never): a missed piece of more than 32 bytes is
-        * merged by a wavefront of its own instead of by one lane among 64 pieces -- at these sizes the call waits for the slowest wavefront of each kernel,
-        * and a lone 100-byte piece in a lane was 100 us of the 340 a 1 MB call took.  Same ids either way.  (TKZ_LATENCY_BYTES in the environment sets the
-        * value an encoder is created with.) */
+       /* Batches of at most this many bytes are run for latency rather than throughput (default 16 MB; 0: never): at these sizes the call waits for the
+        * slowest wavefront of each kernel, so the merge of the long missed pieces is dealt out in units of 4 sub-tiles instead of 64 (93 -> 44 us of a 1 MB
+        * call) and its queue of very long pieces gets a full grid.  Same ids either way.  (TKZ_LATENCY_BYTES in the environment sets the value an encoder
+        * is created with.) */
        TKZ_OPT_LATENCY_BYTES = 8 };
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value);
 

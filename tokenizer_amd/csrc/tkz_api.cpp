@@ -637,9 +637,10 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.giant_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, heavy_count));
             P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
             P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
-            // (a batch of at most 16 MB waits for its slowest wavefront, not for throughput: a lone 100-byte piece in a lane of k_merge_long was 100 us of
-            //  the 340 a 1 MB call took; a wavefront of k_merge_coop has it in ~10.  TKZ_OPT_LATENCY_BYTES)
-            P.lane_piece = total <= e->latency_bytes ? kLatencyLanePiece : kLanePiece;
+            // (a batch of at most 16 MB waits for the slowest wavefront of every kernel, not for throughput: TKZ_OPT_LATENCY_BYTES, launch_encode.  Handing its
+            //  pieces of 33..128 bytes to k_merge_coop as well was tried: 115 us in that kernel for what the lanes do in 6 -- a wavefront takes ~30 us a piece)
+            P.lane_piece = kLanePiece;
+            P.latency = total <= e->latency_bytes ? 1 : 0;
             P.coop_cap = total / P.lane_piece + 64;
             HIP_TRY(ws->w_coopq.ensure((size_t)P.coop_cap * 8, acc));
             P.coop_q = ws->w_coopq.as<uint64_t>();
@@ -877,7 +878,7 @@ tkz_status encode_small(tkz_encoder* e, Workspace* ws, const uint8_t* bytes, con
     P.giant_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, giant_ticket));
     P.heavy_flag = ws->w_heavyq.as<uint8_t>(); P.nsub = ntiles;
     P.pool = ws->w_pool.as<int32_t>(); P.pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head)); P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
-    P.ablate = 0; P.devprof = nullptr; P.stats = nullptr; P.place128 = 0; P.promo = nullptr; P.pextra = nullptr; P.lane_piece = kSmallLanePiece;
+    P.ablate = 0; P.devprof = nullptr; P.stats = nullptr; P.place128 = 0; P.promo = nullptr; P.pextra = nullptr; P.lane_piece = kSmallLanePiece; P.latency = 0;
     SmallArgs A{};
     A.h_bytes = H + kSmallOffBytes; A.h_offs = reinterpret_cast<const int64_t*>(H + kSmallOffOffs);
     A.out = reinterpret_cast<int32_t*>(H + kSmallOffIds); A.out_cap = std::min<int64_t>(out_cap, kSmallMaxBytes); A.out_offs = reinterpret_cast<int64_t*>(H + kSmallOffOut);

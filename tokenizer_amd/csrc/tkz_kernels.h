@@ -28,7 +28,6 @@ constexpr int kArenaPiece = 1024;   // ... so pieces up to this many bytes are m
 #endif
 constexpr int kLanePiece = TKZ_LANE_PIECE;
 constexpr int kLongLogDwords = 12, kLongLogMaxLen = 28;      // (28 = TKZ_MID_KEY_MAX: what the MID key table can hold)
-constexpr int kLatencyLanePiece = 32;
 constexpr int kSmallLanePiece = 256;  // ... the single-launch kernel (no k_merge_coop there) merges pieces of up to this many bytes a lane each and hands a batch with a longer missed piece back    // ... but a missed piece longer than this is merged by a whole wavefront (k_merge_coop): one lane takes ~n^2 steps, and the kernel waits for it
 constexpr int kMaxPiece = 1 << 30;  // longer single pieces are refused (kErrTooLong)
 constexpr int kRowsPerWave = 62;    // k_pretok_rows: output rows per wavefront (64 staged rows, one per lane; the outer two are context)
@@ -61,8 +60,8 @@ struct EncodeParams {
     int32_t* doc_tok;             // per document-start position (by ordinal): token index inside its sub-tile
     int32_t* counters;            // [0] error bits, [1] the longest miss list seen (kErrMissCap), [2] the longest list above kMissCapMin that fitted (grown lists only),
                                   // [3] sub-tiles with more than 64 list entries ([2], [3]: k_list_stats, grown lists only)
-    int32_t lane_piece;           // long misses of up to this many bytes are merged a lane each (k_merge_long), longer ones a wavefront each (k_merge_coop): kLanePiece, or
-                                  // kLatencyLanePiece for a batch small enough that the one slowest lane is what the call waits for
+    int32_t latency;              // a batch run for latency (TKZ_OPT_LATENCY_BYTES): the launchers pick the forms with the smaller units of work
+    int32_t lane_piece;           // long misses of up to this many bytes are merged a lane each (k_merge_long), longer ones a wavefront each (k_merge_coop): kLanePiece
     uint8_t* heavy_flag; int64_t nsub;                                    // one byte per sub-tile, set by k_probe: bit 0 = long misses in its list, bit 1 = a giant piece, bit 2 = a long miss of more than kLanePiece bytes (k_merge_coop)
                                                                           // (a flag, not a queue: a queue's one counter serialises a million atomics on mixed text)
     int32_t* pool; unsigned long long* pool_head; int64_t pool_cap;       // scratch for pieces > kArenaPiece (int32 units)

@@ -2725,7 +2725,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     TKZ_LAUNCH(k_giant_order, 1, 1024, L.stream, P);
     TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // takes pieces off the ordered queue; exits at once when it is empty
     {   // strides over 64-sub-tile chunks
-        const bool latency = P.lane_piece == kLatencyLanePiece;
+        const bool latency = P.latency != 0;
         const int64_t chunks = cdiv(nsub, 64) * (latency ? kLongPartsLatency : kLongParts), grid = chunks < 65536 ? chunks : 65536;      // (units of work: see kLongParts)
         if (latency) {
             if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long<true, true>), grid, 64, L.stream, T, P);
