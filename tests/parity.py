@@ -591,6 +591,21 @@ def check_runtime_overrides(lib, O, vocab, ovocab, seed=71):
         O.set_case_equivalence(False)
 
 
+def check_document_marks(lib, O, vocab, ovocab):
+    """k_docmark writes every word of the document-start bitmap once, by the first document that starts in it: runs of empty documents (stepped over by
+    bisection), 64 one-byte documents in a word, empty documents at both ends, on the batch path and through the single launch."""
+    oenc = O.Encoder(ovocab, O.CL100K)
+    enc = N.Encoder(vocab, N.CL100K)
+    filler = [b"the quick brown fox jumps over the lazy dog. " * 40] * 80            # (beyond the single launch's 128 KiB)
+    for docs in ([b""] * 3000 + [b"a"] * 200 + [b""] * 70 + [b"hello world"] + [b""] * 5,
+                 [b""] * 3000 + [b"a"] * 200 + [b""] * 70 + filler + [b""] * 1500 + [b"x", b"", b"yz", b""] * 40 + filler[:3] + [b""] * 5,
+                 [b""] * 9, filler + [b""]):
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        exp, eoff = oracle_encode_docs(oenc, docs)
+        assert ids.tolist() == exp and ooff.tolist() == eoff, len(docs)
+
+
 def check_sizing_attempt(lib, O, vocab, ovocab, capfd, pattern=N.CL100K, seed=43):
     """A fresh workspace's first large batch probes a sample of its sub-tiles first (encode_device: the sizing attempt) and every attempt after the first
     starts behind the pre-tokenizer, on the bitmaps the first one left.  Same ids as the oracle when the sample predicts the lists the batch needs (two

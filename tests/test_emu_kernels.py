@@ -163,6 +163,11 @@ def test_throughput_setting_on_small_batches(lib, vocabs, oracle_mod, monkeypatc
         enc.set_option(N.OPT_LATENCY_BYTES, -1)
 
 
+def test_document_marks(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_document_marks(lib, oracle_mod, v, ov)
+
+
 def test_sizing_attempt_and_reused_bitmaps(lib, vocabs, oracle_mod, capfd):
     v, ov = vocabs("gpt2")
     parity.check_sizing_attempt(lib, oracle_mod, v, ov, capfd)
@@ -344,11 +349,11 @@ def test_giant_tail_on_adversarial_rank_tables(lib, oracle_mod):
     parity.check_random_vocab(lib, oracle_mod, 7, 2, [300, 1024, 3000, 18000], 3, max_len=300)
     parity.check_random_vocab(lib, oracle_mod, 8, 2, [300, 1024, 3000, 18000], 3, max_len=1100)
     # more parts than the tail's LDS holds (32,768): sweeps of windows under the local bound first (tkz_bpe_window_sweep), then the tail
-    parity.check_random_vocab(lib, oracle_mod, 11, 1, [34000], 2)
-    parity.check_random_vocab(lib, oracle_mod, 12, 1, [36000], 1, max_len=300)
+    # (the GPU suite runs these at 36,000 parts under 300-byte keys and at 50,000 .. 300,000 bytes as well: the emulator takes a minute for each)
+    parity.check_random_vocab(lib, oracle_mod, 11, 1, [34000], 1)
     raw = gzip.decompress(open(os.path.join(os.path.dirname(__file__), "golden", "gpt2.tiktoken.gz"), "rb").read())
     v, ov = N.Vocab(raw, lib), oracle_mod.Vocab(raw)
-    parity.check_long_diverse_pieces(lib, oracle_mod, v, ov, lens=(300, 1000, 1500, 18000, 33000, 50000), seed=3)
+    parity.check_long_diverse_pieces(lib, oracle_mod, v, ov, lens=(300, 1000, 1500, 18000, 33000), seed=3)
     parity.check_runs_with_words(lib, oracle_mod, v, ov)
 
 

@@ -170,6 +170,11 @@ def test_throughput_setting_on_small_batches(lib, vocabs, oracle_mod, monkeypatc
         enc.set_option(N.OPT_LATENCY_BYTES, -1)
 
 
+def test_document_marks(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_document_marks(lib, oracle_mod, v, ov)
+
+
 def test_sizing_attempt_and_reused_bitmaps(lib, vocabs, oracle_mod, capfd):
     v, ov = vocabs("gpt2")
     parity.check_sizing_attempt(lib, oracle_mod, v, ov, capfd)

@@ -38,7 +38,25 @@ TKZ_KERNEL(256) void k_docmark(const int64_t* offs, int64_t n_items, int64_t tot
         if (d == n_items) ok = ok && pos == total;
         else ok = ok && pos <= offs[d + 1];
         if (!ok) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrOffsets); continue; }
-        simt::atomic_or64((unsigned long long*)&bits[pos >> 6], 1ull << (pos & 63));
+        // One plain store per bitmap word, by the first item that starts in it (the words were zeroed; 10 M atomics were a read-modify-write of nearly every
+        // line of a 640 MB bitmap).  Offsets that are not monotone are reported by the item that sees it and the batch fails: what is stored then is never used.
+        const int64_t w = pos >> 6;
+        if (d > 0) { const int64_t prev = offs[d - 1]; if (prev >= 0 && prev <= pos && (prev >> 6) == w) continue; }
+        uint64_t m = 1ull << (pos & 63);
+        int64_t cur = pos;
+        for (int64_t e = d + 1; e <= n_items;) {
+            const int64_t q = offs[e];
+            if (q < cur || (q >> 6) != w) break;
+            if (q == cur) {                                // a run of empty documents: to its end by bisection (a million of them are 20 steps, not a million)
+                int64_t lo = e + 1, hi = n_items + 1;
+                while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (offs[mid] <= cur) lo = mid + 1; else hi = mid; }
+                e = lo;
+                continue;
+            }
+            m |= 1ull << (q & 63);
+            cur = q; ++e;
+        }
+        bits[w] = m;
     }
 }
 
