@@ -1704,11 +1704,17 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         load_recs(pb, np, kk, r);
         int c[4], idx[4];
         bool ok[4], ms[4], pm[4];
-        uint4 pq[4];
+        uint4 pq0;                                               // the token quad of the lane's FIRST promoted record
+        int pj = -1, pdst = 0, pcnt = 0;
         int t = 0, mk = 0;
         if constexpr (PROMO) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pm[j] = k0 + j < np && pb + k0 + j < P.prank_cap && !(r[j] & kPrMiss) && (r[j] & kPromoFlag);
+            for (int j = 3; j >= 0; --j) { pm[j] = k0 + j < np && pb + k0 + j < P.prank_cap && !(r[j] & kPrMiss) && (r[j] & kPromoFlag); if (pm[j]) pj = j; }
+            // One promoted piece in a hundred: a lane's four records hold one at most, nearly always.  ITS quad is requested here, ahead of the scan, and its
+            // tokens are staged after the missed pieces' below -- the round trip to the promo array overlaps both (four registers across them; all four
+            // records' quads, requested after the scan and waited for at once, were a dependent round trip per 256 records: 1.0 of k_place's 4.75 ms).  A
+            // second promoted record of the same lane fetches its quad on the spot.
+            pq0 = tkz_load16(&P.promo[pj >= 0 ? (r[pj >= 0 ? pj : 0] & kPromoIdxMask) : 0u]);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1728,23 +1734,21 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
             if (flushed < running) flush(running);
             if (running + tot - sbase > kStage) return false;        // (more than two tokens a record: the general path, 64 records at a time)
         }
-        if constexpr (PROMO) {
-            // the token quads of the promoted pieces among the lane's four records, requested together (a record that is not promoted asks for
-            // quad 0: one line for the whole wavefront).  (Requested ahead of the scan they cost 16 registers across it: spills at 7 and at 6 waves per SIMD.)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pq[j] = tkz_load16(&P.promo[pm[j] ? (r[j] & kPromoIdxMask) : 0u]);
-        }
         int pos = running + (pre & 0xFFFFF), mi = marks + (pre >> 20);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (ok[j] && (r[j] & kPrMark)) P.doc_tok[ord0 + mi++] = pos;
             if (ms[j]) s_pos[idx[j]] = pos;
             else if (PROMO && pm[j]) {
-                int32_t* dst = stage + (pos - sbase);
-                dst[0] = (int32_t)pq[j].x;
-                if (c[j] > 1) dst[1] = (int32_t)pq[j].y;
-                if (c[j] > 2) dst[2] = (int32_t)pq[j].z;
-                if (c[j] > 3) dst[3] = (int32_t)pq[j].w;
+                if (j == pj) { pdst = pos - sbase; pcnt = c[j]; }
+                else {                                           // (rare: a second promoted record in this lane's four)
+                    const uint4 q = tkz_load16(&P.promo[r[j] & kPromoIdxMask]);
+                    int32_t* dst = stage + (pos - sbase);
+                    dst[0] = (int32_t)q.x;
+                    if (c[j] > 1) dst[1] = (int32_t)q.y;
+                    if (c[j] > 2) dst[2] = (int32_t)q.z;
+                    if (c[j] > 3) dst[3] = (int32_t)q.w;
+                }
             }
             else if (ok[j]) stage[pos - sbase] = (int32_t)(r[j] & kPrRankMask);
             pos += c[j];
@@ -1771,6 +1775,15 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
                     for (int i = 0; i < cnt; ++i) dst[i] = src[i];
                 }
                 s_pos[slot] = -1;
+            }
+        }
+        if constexpr (PROMO) {
+            if (pcnt) {
+                int32_t* dst = stage + pdst;
+                dst[0] = (int32_t)pq0.x;
+                if (pcnt > 1) dst[1] = (int32_t)pq0.y;
+                if (pcnt > 2) dst[2] = (int32_t)pq0.z;
+                if (pcnt > 3) dst[3] = (int32_t)pq0.w;
             }
         }
         running += tot; marks += mtot;
