@@ -609,7 +609,10 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             if (!d_bitmap_only) HIP_TRY(hipMemsetAsync(ws->w_heavyq.p, 0, (size_t)(ws->w_zero.as<char>() + ws->zero_bytes - ws->w_heavyq.as<char>()), stream));
         } else {
         if (ingest) launch_ingest(L, ingest->h_bytes, total, const_cast<uint8_t*>(d_bytes), ingest->h_offs, n_docs + 1, const_cast<int64_t*>(d_offs), ws->w_zero.p, (int64_t)ws->zero_bytes);
-        else HIP_TRY(hipMemsetAsync(ws->w_zero.p, 0, ws->zero_bytes, stream));      // counters, document-start bits, sub-tile flags
+        // counters, document-start bits, sub-tile flags.  (A chunk of a host batch clears them with a kernel of its own, not a fill command: the runtime's fill is
+        //  a blit kernel that queued behind its D2H blit of the chunk before -- the 16 MB call's second chunk started when the first one's download ended.)
+        else if (ws->zero_bytes <= (size_t(8) << 20)) launch_ingest(L, nullptr, 0, nullptr, nullptr, 0, nullptr, ws->w_zero.p, (int64_t)ws->zero_bytes);
+        else HIP_TRY(hipMemsetAsync(ws->w_zero.p, 0, ws->zero_bytes, stream));
         launch_docmark(L, d_offs, n_docs, total, docbits, counters);
         if (!pretok) {
             HIP_TRY(hipMemcpyAsync(startbits, docbits, (size_t)nwords * 8, hipMemcpyDeviceToDevice, stream));
