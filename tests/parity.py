@@ -1298,6 +1298,23 @@ def check_host_chunks(lib, O, vocab, ovocab, pattern=N.CL100K, seed=21):
     with pytest.raises(N.TkzError) as ei:
         enc.encode_batch(np.frombuffer(b"x" * 40000, np.uint8), np.array([0, 30000, 20000, 40000]))
     assert ei.value.code == N.E_ARG
+    # page-locked caller buffers through the chunks: the ids and offsets of every chunk are put into the caller's arrays by a kernel (k_download), each at
+    # the token base of its chunk
+    import ctypes as C
+    docs = [b"" if rng.random() < 0.1 else gen_text(rng, rng.choice(["mix", "a_mix", "ws"]), rng.choice([1, 50, 700, 3000]), alpha).encode("utf-8") for _ in range(90)]
+    data, offs = pack(docs)
+    hp = [C.c_void_p() for _ in range(4)]
+    for h, n in zip(hp, [len(data) + 64, 8 * (len(docs) + 1), 4 * len(data) + 64, 8 * (len(docs) + 1)]):
+        lib.check(lib.L.tkz_host_alloc(n, C.byref(h)))
+    offs64 = np.ascontiguousarray(offs, np.int64)
+    C.memmove(hp[0], data.ctypes.data, len(data)); C.memmove(hp[1], offs64.ctypes.data, 8 * (len(docs) + 1))
+    needed = C.c_int64(0)
+    lib.check(lib.L.tkz_encode_batch_utf8(enc._h, hp[0], hp[1], len(docs), hp[2], len(data), hp[3], C.byref(needed)))
+    exp, eoff = oracle_encode_docs(oenc, docs)
+    assert np.ctypeslib.as_array(C.cast(hp[2], C.POINTER(C.c_int32)), (needed.value,)).tolist() == exp
+    assert np.ctypeslib.as_array(C.cast(hp[3], C.POINTER(C.c_int64)), (len(docs) + 1,)).tolist() == eoff
+    for h in hp:
+        lib.L.tkz_host_free(h)
 
 
 def check_begin_end(lib, O, vocab, ovocab, pattern=N.CL100K, seed=61, upload=None, streams=(0,)):

@@ -1123,8 +1123,14 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
         if (st == TKZ_E_CAPACITY) { over = true; continue; }
         if (st != TKZ_OK) { first_err = st; first_msg = g_err; break; }
         if (!over && !direct_out) {
+            if (pin_out && dv_ooffs && (dv_ids || !tokens)) {       // (page-locked results: a small-grid kernel of our own, see k_download)
+                Launch Lo{ws->st_out, nullptr, ws};
+                launch_download(Lo, ws->s_out[q].p, dv_ids ? static_cast<int32_t*>(dv_ids) + tok_base[(size_t)k] : nullptr, tokens,
+                                ws->s_outoffs[q].p, static_cast<int64_t*>(dv_ooffs) + d0, nd + 1);
+            } else {
             if (tokens) HIP_TRY(hipMemcpyAsync(out_ids + tok_base[(size_t)k], ws->s_out[q].p, (size_t)tokens * 4, hipMemcpyDeviceToHost, ws->st_out));
             HIP_TRY(hipMemcpyAsync(out_offsets + d0, ws->s_outoffs[q].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, ws->st_out));
+            }
             HIP_TRY(hipEventRecord(ws->ev_out[q], ws->st_out));
         }
     }
