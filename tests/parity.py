@@ -1298,8 +1298,8 @@ def check_host_chunks(lib, O, vocab, ovocab, pattern=N.CL100K, seed=21):
     with pytest.raises(N.TkzError) as ei:
         enc.encode_batch(np.frombuffer(b"x" * 40000, np.uint8), np.array([0, 30000, 20000, 40000]))
     assert ei.value.code == N.E_ARG
-    # page-locked caller buffers through the chunks: the ids and offsets of every chunk are put into the caller's arrays by a kernel (k_download), each at
-    # the token base of its chunk
+    # page-locked caller buffers through the chunks: the ids and offsets of every chunk are copied into the caller's arrays at the token base of
+    # its chunk
     import ctypes as C
     docs = [b"" if rng.random() < 0.1 else gen_text(rng, rng.choice(["mix", "a_mix", "ws"]), rng.choice([1, 50, 700, 3000]), alpha).encode("utf-8") for _ in range(90)]
     data, offs = pack(docs)

@@ -419,7 +419,7 @@ def test_host_path_chunked_and_threads(lib, vocabs, oracle_mod):
     dt = time.perf_counter() - t0
     assert np.array_equal(ids, want_ids) and np.array_equal(ooff, want_offs)
     print("host path, page-locked buffers: %.1f GB/s" % (len(h_bytes) / dt / 1e9))
-    # mid-size page-locked batches: 20 MB (chunks of a quarter of the batch, results put in place by k_download), 3 MB (one chunk, fetched by k_ingest, ids
+    # mid-size page-locked batches: 20 MB (chunks of a quarter of the batch), 3 MB (one chunk, fetched by k_ingest, ids
     # written by k_place itself) -- twice each: a fresh workspace, then a sized one
     for nd in (40_000, 6_000):
         cb = int(h_offs[nd]); nt = int(want_offs[nd])

@@ -974,9 +974,10 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
     //  round 5: 16 MB chunks ran a 512 MB batch at 26 GB/s where 48 MB chunks had run it at 42)
     static const int64_t kChunkBytes = [] { const char* v = getenv("TKZ_HOST_CHUNK_BYTES"); const long long n = v ? atoll(v) : 0; return n > 0 ? (int64_t)n : (int64_t(32) << 20); }();
     const int64_t up_bytes = total * unit;
-    // (between 12 MB and 4 chunks' worth the chunks are a quarter of the batch, but at least 8 MB: a 64 MB batch as 4 x 16 MB has its uploads, kernels and
-    //  downloads overlapped -- 2 x 32 MB ran at 24.8 GB/s, no faster than one after the other)
-    const int64_t chunk_bytes = std::min(kChunkBytes, std::max(std::min(kChunkBytes, int64_t(8) << 20), up_bytes / 4));
+    // (from 12 MB up a batch is two chunks at least, of 8 MB or more: the second chunk's upload runs beside the first one's kernels -- 16 MB: 1.00 -> 0.89 ms.
+    //  More, smaller chunks do not pay: a chunk's kernels wait for the download of the chunk before -- the comment at the download below -- so every chunk adds
+    //  its launch sequence's floor: 64 MB as 4 x 16 MB 2.83 ms, as 2 x 32 MB 2.71)
+    const int64_t chunk_bytes = std::min(kChunkBytes, std::max(std::min(kChunkBytes, int64_t(8) << 20), up_bytes / 2));
     int64_t nchunks = (bitmap || !pretok || 2 * up_bytes < 3 * chunk_bytes) ? 1 : std::min<int64_t>(1024, std::max<int64_t>(2, (up_bytes + chunk_bytes / 2) / chunk_bytes));
     // chunk boundaries on documents: chunk k = documents [cut[k], cut[k+1]).  Offsets that are not monotone cannot be cut: the
     // whole batch then goes as one chunk and the device reports them (k_docmark)
@@ -1123,14 +1124,11 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
         if (st == TKZ_E_CAPACITY) { over = true; continue; }
         if (st != TKZ_OK) { first_err = st; first_msg = g_err; break; }
         if (!over && !direct_out) {
-            if (pin_out && dv_ooffs && (dv_ids || !tokens)) {       // (page-locked results: a small-grid kernel of our own, see k_download)
-                Launch Lo{ws->st_out, nullptr, ws};
-                launch_download(Lo, ws->s_out[q].p, dv_ids ? static_cast<int32_t*>(dv_ids) + tok_base[(size_t)k] : nullptr, tokens,
-                                ws->s_outoffs[q].p, static_cast<int64_t*>(dv_ooffs) + d0, nd + 1);
-            } else {
+            // (the runtime's D2H copy of page-locked memory is a blit kernel and the next chunk's kernels make no progress beside it -- traced: chunk k+1 starts
+            //  the moment chunk k's download ends.  A small-grid download kernel of our own was tried: the next chunk's kernels then start at once but stall in
+            //  their first stores until the PCIe writes have drained, and the kernel is slower than the blit -- 16 MB 0.89 -> 1.05 ms.  DESIGN.md 6)
             if (tokens) HIP_TRY(hipMemcpyAsync(out_ids + tok_base[(size_t)k], ws->s_out[q].p, (size_t)tokens * 4, hipMemcpyDeviceToHost, ws->st_out));
             HIP_TRY(hipMemcpyAsync(out_offsets + d0, ws->s_outoffs[q].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, ws->st_out));
-            }
             HIP_TRY(hipEventRecord(ws->ev_out[q], ws->st_out));
         }
     }

@@ -112,7 +112,6 @@ void launch_pretok_rows(const Launch& L, int pattern, const uint8_t* d_bytes, co
 void launch_pretok_seq(const Launch& L, int pattern, const uint8_t* d_bytes, const int64_t* d_offs, int64_t n_docs, int64_t total,
                        uint64_t* startbits, const uint8_t* bmp, int32_t* counters);
 void launch_ingest(const Launch& L, const uint8_t* h_bytes, int64_t total, uint8_t* d_bytes, const int64_t* h_offs, int64_t n_offs, int64_t* d_offs, void* zero, int64_t zero_bytes);
-void launch_download(const Launch& L, const void* src, void* dst, int64_t n_dwords, const void* src2, void* dst2, int64_t n_qwords);
 void launch_probe_sample(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsample);
 void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsub);
 void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, const SmallArgs& A);

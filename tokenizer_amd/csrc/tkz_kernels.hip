@@ -2144,14 +2144,6 @@ TKZ_KERNEL(256) void k_ingest(const uint8_t* h_bytes, int64_t total, uint8_t* d_
     const uint4 z = {0u, 0u, 0u, 0u};
     for (int64_t i = i0; i < zero_quads; i += stride) zero[i] = z;
 }
-// A chunk's ids (and offsets) from the staging buffer into the caller's page-locked array, by a SMALL grid: the runtime's D2H copy of page-locked memory is a
-// blit kernel that fills the chip for as long as PCIe takes, and the next chunk's kernels did not get a wavefront in until it was done (traced: the 16 MB call's
-// second chunk started the moment the first one's download ended).  128 workgroups saturate the link and leave the other CUs to the next chunk.
-TKZ_KERNEL(256) void k_download(const uint32_t* src, uint32_t* dst, int64_t n_dwords, const uint64_t* src2, uint64_t* dst2, int64_t n_qwords) {
-    const int64_t i0 = (int64_t)simt::bid() * simt::nthreads() + simt::tid(), stride = (int64_t)simt::nblocks() * simt::nthreads();
-    for (int64_t i = i0; i < n_dwords; i += stride) dst[i] = src[i];
-    for (int64_t i = i0; i < n_qwords; i += stride) dst2[i] = src2[i];
-}
 TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
     for (int64_t i = simt::bid() * simt::nthreads() + simt::tid(); i < n; i += stride) offs[i] -= base;
@@ -2794,10 +2786,6 @@ void launch_ingest(const Launch& L, const uint8_t* h_bytes, int64_t total, uint8
     const int64_t quads = std::max<int64_t>(total / 16 + 1, (zero_bytes + 15) / 16);
     const int64_t g = cdiv(quads, kThreads * 4);               // (four quads a thread: ~64 loads over PCIe in flight per wavefront is what fills the link)
     TKZ_LAUNCH(k_ingest, g < 1 ? 1 : (g > 2048 ? 2048 : g), kThreads, L.stream, h_bytes, total, d_bytes, h_offs, n_offs, d_offs, reinterpret_cast<uint4*>(zero), (zero_bytes + 15) / 16);
-}
-void launch_download(const Launch& L, const void* src, void* dst, int64_t n_dwords, const void* src2, void* dst2, int64_t n_qwords) {
-    TKZ_LAUNCH(k_download, 128, kThreads, L.stream, static_cast<const uint32_t*>(src), static_cast<uint32_t*>(dst), n_dwords,
-               static_cast<const uint64_t*>(src2), static_cast<uint64_t*>(dst2), n_qwords);
 }
 void launch_small(const Launch& L, const TkzTables& T, const EncodeParams& P, const SmallArgs& A) {
     TKZ_LAUNCH(k_small, 1, P.nsub <= 4 ? 256 : 1024, L.stream, T, P, A);
