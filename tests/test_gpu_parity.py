@@ -258,6 +258,12 @@ def test_giant_pieces(lib, vocabs, oracle_mod, vname):
         got = enc.encode_utf8(t100)
         ms = (time.perf_counter() - t0) * 1e3
         assert got == oenc.encode_bytes(t100)
+        try:       # (the figure DESIGN.md quotes; the directory exists on the GPU box of a gpurun call)
+            os.makedirs(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out"), exist_ok=True)
+            with open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out", "giant_100kb_ms.txt"), "w") as f:
+                f.write("%.2f ms: one piece of 100,000 bytes of diverse letters, tkz_encode_utf8, second call\n" % ms)
+        except OSError:
+            pass
         assert ms < 50.0, "100 KB of diverse letters (ONE piece) took %.1f ms" % ms
 
 

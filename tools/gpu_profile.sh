@@ -6,6 +6,9 @@ TAG=${1:-r01}; DOCS=${2:-2000000}; EXTRA=${3:-}
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"
 cd "$REPO"; mkdir -p gpurun_out/prof_$TAG
 export TMPDIR=/tmp
+# (no sizing attempt under the profiler: a fresh workspace's first large batch otherwise launches k_probe once more on a sixteenth of the sub-tiles, and the
+#  per-launch average of that kernel in the stats would be over five full launches and one short one)
+export TKZ_SIZING_MIN_SUB=4000000000
 # (--heldout-steps 0 --pipelined-steps 0 --no-piece-stats: nothing but the headline steps, their warm-up and the sizing pass run under the profiler -- per-launch averages of a kernel are over THOSE launches)
 BENCH="python $REPO/bench.py --docs $DOCS --steps 3 --warmup 1 --no-cpu-baseline --heldout-steps 0 --pipelined-steps 0 --no-piece-stats $EXTRA"
 cd /tmp
