@@ -781,7 +781,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
     uint32_t* const ml = P.mlist + sub * (int64_t)P.mcap;
     uint4* const mq = P.mquad + sub * (int64_t)P.mcap;
     int ns = 0, nl = 0, midseen = 0;
-    int promo_extra = 0;                                   // tokens beyond one per piece that the promoted pieces of this sub-tile stand for (P.pextra)
+    int promo_extra = 0;                                   // tokens beyond one per piece that the promoted pieces of this sub-tile stand for (P.pextra): this lane's share
     bool giant = false, coopl = false;                     // coopl: a long miss of more than kLanePiece bytes (k_merge_coop's: bit 2 of the sub-tile's flag)
     constexpr int U = TKZ_PROBE_U;                         // batches of 64 pieces whose gathers are in flight together
 #pragma unroll 1
@@ -846,7 +846,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
             const bool miss = valid && !is_giant && rank == TKZ_RANK_NONE;
             if (P.pextra) {                                                      // (wave-uniform: only when the tables hold promoted pieces)
                 const uint32_t ex = (valid && !is_giant && !miss && ((uint32_t)rank & kPromoFlag)) ? (((uint32_t)rank >> kPromoCntShift) & 3u) : 0u;
-                promo_extra += tkz_popc64(simt::ballot(ex & 1u)) + 2 * tkz_popc64(simt::ballot(ex & 2u));
+                promo_extra += (int)ex;                                          // (per lane: one add a batch; summed over the wavefront once, at the end)
             }
             const bool miss_s = miss && len <= kShortMax, miss_l = miss && len > kShortMax;
             const uint64_t sm = simt::ballot(miss_s), lm = simt::ballot(miss_l);
@@ -882,6 +882,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
     // than kLanePiece bytes (bit 2: k_merge_coop -- k_merge_long used to flag those chunks itself: a pointer, an index and a flag alive across its merge
     // loops, 14 more spilled scalars and 4 % of that kernel on mixed text)
     const uint32_t f = (nl ? 1u : 0u) | (simt::ballot(giant) ? 2u : 0u) | (simt::ballot(coopl) ? 4u : 0u);
+    if (P.pextra) { int tot; (void)tkz_wave_scan_sum(promo_extra, &tot); promo_extra = tot; }      // (wave-uniform branch)
     if (lane == 0) {
         P.heavy_flag[sub] = (uint8_t)f;
         P.mcount[sub] = (uint32_t)ns | ((uint32_t)nl << 16);
