@@ -692,7 +692,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                 if (!pieces_over) launch_piece_index(L, startbits, nwords, total, ntiles, ws->w_dbase.as<int64_t>(), np, po->piece_boffs, d_offs, n_docs, po->doc_piece);
             }
             if (sizing) {
-                launch_probe_sample(L, T, P, std::max<int64_t>(ntiles / 16, kSizingMinSub / 16));
+                launch_probe_sample(L, T, P, std::min<int64_t>(ntiles, std::max<int64_t>(ntiles / 16, kSizingMinSub / 16)));
             } else {
             launch_encode(L, T, P, ntiles);
             if (P.stats) launch_miss_stats(L, P, ntiles);
@@ -734,6 +734,12 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         if (err & kErrTooLong) return fail(TKZ_E_UNSUPPORTED, "a single piece longer than 2^30 bytes");
         marks_ready = true;                // (what is wrong from here on is the size of a buffer)
         if (!d_bitmap_only) ws->sized = true;
+        if (sizing) {
+            // k_place's form for THIS batch from the sample (it is otherwise chosen from the batch before: a fresh encoder's first miss-heavy batch ran
+            // k_place<64> with most sub-tiles on its general path, 11.7 ms against 7)
+            const int64_t nsample = std::min<int64_t>(ntiles, std::max<int64_t>(ntiles / 16, kSizingMinSub / 16));
+            if ((int64_t)ws->h_counters->over64 * 5 > nsample) { ws->place128 = true; ws->low_place = 0; }
+        }
         if ((err & kErrPool) && attempt < 4) {
             // scratch for the giant pieces was too small.  pool_head keeps counting past the capacity, so it holds the exact need
             // (6 int32 per byte of every giant piece of the batch): size the pool for that -- not for the whole batch -- and rerun
