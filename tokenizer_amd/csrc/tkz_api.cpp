@@ -823,13 +823,18 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                 // (the workspace is this call's no longer once it returns; the counters, the log and the memo are the encoder's, and no other batch writes the
                 //  first two while e->learning is set)
                 join_promotion(e);                 // (the previous one ended before this batch could be armed: this only reaps the thread)
-                std::lock_guard<std::mutex> jl(e->promo_join_mu);
-                e->promo_thread = std::thread([e] {
+                auto work = [e] {
                     DeviceScope scope;
                     if (scope.enter(e->device) == hipSuccess) (void)promote_from_memo(e, true, true, nullptr);   // (a failure leaves the tables as they were)
                     std::lock_guard<std::mutex> lock(e->mu);
                     e->learning = false; ++e->promo_rounds;
-                });
+                };
+                bool started = false;
+                {
+                    std::lock_guard<std::mutex> jl(e->promo_join_mu);
+                    try { e->promo_thread = std::thread(work); started = true; } catch (...) {}      // (no thread to be had: built here, as before round 5)
+                }
+                if (!started) { const std::string keep_msg = g_err; work(); g_err = keep_msg; }
             }
         }
         if (!d_bitmap_only) {
