@@ -20,6 +20,10 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 raw = gzip.decompress(open(os.path.join(ROOT, "tests", "golden", "gpt2.tiktoken.gz"), "rb").read())
 vocab, ovocab = (N.Vocab(raw, emu.library()) if EMU else N.Vocab(raw)), O.Vocab(raw)
 encs = {p: N.Encoder(vocab, p) for p in (1, 2, 3, 4)}
+# (two of the four encoders learn their promotions from the soak's own batches -- the default threshold, 8 MB, is above most of them --: the batches after that run
+#  on key tables with promoted pieces in them, rebuilt behind a batch that is still being compared)
+for p in (2, 4):
+    encs[p].set_option(N.OPT_PROMOTE_MIN_BYTES, 2000 if EMU else 200000)
 alpha = RC.alphabet()
 rng = random.Random(seed)
 kinds = ["mix", "runs"] + list(parity.SMALL_ALPHAS)
@@ -42,4 +46,5 @@ while time.time() - t0 < budget:
     if not (np.array_equal(ids, o_ids) and np.array_equal(np.diff(ooff), o_counts)):
         print("MISMATCH round", rounds, "pattern", pattern, "kind", kind, "docs", len(docs), "bytes", len(data)); sys.exit(1)
     rounds += 1; total += len(data)
-print(("emulated fuzz" if EMU else "gpu fuzz") + " ok: %d rounds, %.1f MB, seed %d" % (rounds, total / 1e6, seed))
+print(("emulated fuzz" if EMU else "gpu fuzz") + " ok: %d rounds, %.1f MB, seed %d; promoted pieces in the tables of the four encoders: %s" %
+      (rounds, total / 1e6, seed, {p: encs[p].piece_stats()["promoted_pieces_in_tables"] for p in encs}))
