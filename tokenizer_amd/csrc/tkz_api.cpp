@@ -1737,6 +1737,7 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
         // T.memo_n when it launches, and emptying the table under running kernels could pair one piece's key with another's tokens
         // -- so value 2 is refused while any workspace is leased, and the device is drained before the table is cleared.
         DeviceScope scope;
+        if (value == 2) join_promotion(e);     // (a promotion being built reads the memo back: not under its feet)
         std::lock_guard<std::mutex> lock(e->mu);
         if (value == 2) {
             tkz_status st = check_encoder(e, scope);
