@@ -609,12 +609,26 @@ TKZ_DEV uint32_t tkz_key_dword(const uint32_t* s_bytes, int s, int len, int i) {
 }
 
 // LDS of one wavefront of the probe stage (+ the mask table, shared by the workgroup)
-constexpr int kProbeLdsBytes = (kSub + kHalo) + 2 * (kSub + 2) + 2 * kMidMax + 4 * kMidMax + 4 * (kSub / 32);     // per wavefront; a multiple of 4
+// (TKZ_PROBE_B2_COMPACT: development A/B, round 5, NOT the shipped form -- the second-bucket pass of the two batches of an iteration compacted into one:
+//  the lanes that need it, ~10 of 64 a batch, park key, length and hash in LDS by ordinal, the first lanes look them up, the ranks go back the same way.
+//  32 entries a pass keep the workgroup's LDS at eight wavefronts per SIMD; more unresolved lanes than that take the two-pass form.  DESIGN.md 6.1.)
+#ifdef TKZ_PROBE_B2_COMPACT
+constexpr int kProbeB2 = 32, kProbeB2Bytes = kProbeB2 * (16 + 4 + 4);
+#else
+constexpr int kProbeB2Bytes = 0;
+#endif
+constexpr int kProbeLdsBytes = kProbeB2Bytes + (kSub + kHalo) + 2 * (kSub + 2) + 2 * kMidMax + 4 * kMidMax + 4 * (kSub / 32);     // per wavefront; a multiple of 4
 constexpr int kProbeLdsQuads = (kProbeLdsBytes + 15) / 16;
-struct ProbeLds { uint32_t* bytes; uint16_t* pstart; uint16_t* mid; uint32_t* midres; uint32_t* mark; const uint4* kmask; };
+struct ProbeLds { uint32_t* bytes; uint16_t* pstart; uint16_t* mid; uint32_t* midres; uint32_t* mark; const uint4* kmask; uint4* b2key; uint32_t* b2hs; uint32_t* b2res; };
 TKZ_DEV ProbeLds tkz_probe_lds(uint4* wave_quads, const uint4* kmask) {
     ProbeLds L;
     uint8_t* b = reinterpret_cast<uint8_t*>(wave_quads);
+    L.b2key = nullptr; L.b2hs = nullptr; L.b2res = nullptr;
+#ifdef TKZ_PROBE_B2_COMPACT
+    L.b2key = reinterpret_cast<uint4*>(b); b += 16 * kProbeB2;
+    L.b2hs = reinterpret_cast<uint32_t*>(b); b += 4 * kProbeB2;
+    L.b2res = reinterpret_cast<uint32_t*>(b); b += 4 * kProbeB2;
+#endif
     L.bytes = reinterpret_cast<uint32_t*>(b); b += kSub + kHalo;
     L.midres = reinterpret_cast<uint32_t*>(b); b += 4 * kMidMax;
     L.mark = reinterpret_cast<uint32_t*>(b); b += 4 * (kSub / 32);
@@ -817,7 +831,34 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
         }
         // the second bucket, for the lanes the first one did not settle only (the keys the builder could not keep in their first
         // bucket, and the pieces that are not keys at all): ~15 % of the requests of the first step instead of another 100 %
-        if (simt::ballot(more)) {
+        bool two_pass = simt::ballot(more) != 0;
+#ifdef TKZ_PROBE_B2_COMPACT
+        if (two_pass) {
+            static_assert(U == 2, "the compacted pass takes the unresolved lanes of the iteration's two batches");
+            const bool w0 = plen[0] >= 1 && plen[0] <= TKZ_SHORT_KEY_MAX && rk[0] == TKZ_RANK_NONE;
+            const bool w1 = plen[1] >= 1 && plen[1] <= TKZ_SHORT_KEY_MAX && rk[1] == TKZ_RANK_NONE;
+            const uint64_t m0 = simt::ballot(w0), m1 = simt::ballot(w1);
+            const int n0 = tkz_popc64(m0), n01 = n0 + tkz_popc64(m1);
+            if (n01 <= kProbeB2) {
+                two_pass = false;
+                const int j0 = tkz_popc64(m0 & tkz_lowmask(lane)), j1 = n0 + tkz_popc64(m1 & tkz_lowmask(lane));
+                if (w0) { uint4 c; c.x = kw0[0]; c.y = kw1[0]; c.z = kw2[0]; c.w = (uint32_t)plen[0]; LD.b2key[j0] = c; LD.b2hs[j0] = hs[0]; }
+                if (w1) { uint4 c; c.x = kw0[1]; c.y = kw1[1]; c.z = kw2[1]; c.w = (uint32_t)plen[1]; LD.b2key[j1] = c; LD.b2hs[j1] = hs[1]; }
+                (void)simt::ballot(true);
+                const bool act = lane < n01;
+                uint4 c; c.x = c.y = c.z = c.w = 0; uint32_t h = 0;
+                if (act) { c = LD.b2key[lane]; h = LD.b2hs[lane]; }
+                const uint32_t ob = act ? 16u * tkz_short_slot_second(T, h) : 0u;
+                const uint4 b0 = tkz_load16(tb0 + ob), b1 = tkz_load16(tb0 + ob + 16u);
+                if (act) LD.b2res[lane] = (uint32_t)tkz_match_short2x(c.x, c.y, c.z, c.w, b0, b1);
+                (void)simt::ballot(true);
+                if (w0) rk[0] = (int32_t)LD.b2res[j0];
+                if (w1) rk[1] = (int32_t)LD.b2res[j1];
+                (void)simt::ballot(true);                  // (the next iteration writes the same slots)
+            }
+        }
+#endif
+        if (two_pass) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool want = plen[u] >= 1 && plen[u] <= TKZ_SHORT_KEY_MAX && rk[u] == TKZ_RANK_NONE;
