@@ -87,12 +87,4 @@ if has midtrace; then
 fi
 if has cold; then export TKZ_LOG_SLOW_MS=300; timeout 300 python tools/cold_probe.py synth100k_heldout > $O/cold_probe.jsonl 2> $O/cold.err; timeout 300 python tools/cold_probe.py synth100k >> $O/cold_probe.jsonl 2>> $O/cold.err; lap "cold rc=$?"; cat $O/cold_probe.jsonl; fi
 lap done
-if has lanepiece; then
-  for lp in 32 48 64 96 128; do
-    echo "== TKZ_LATENCY_LANE_PIECE=$lp"
-    ( cd /tmp && export TMPDIR=/tmp && TKZ_LATENCY_LANE_PIECE=$lp timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $REPO/$O/lp_$lp -- python $REPO/tools/midsize_trace.py run 1 12 ) > $O/lp_$lp.json 2> $O/lp_$lp.err
-    tail -1 $O/lp_$lp.json | cut -c1-200; python tools/midsize_trace.py show $O/lp_$lp | grep -E "calls in|merge_long|merge_coop"
-    rm -rf $O/lp_$lp
-  done
-  lap "lanepiece"
-fi
+# (the `lanepiece` stage of the round -- TKZ_LATENCY_LANE_PIECE=32..128 under the 1 MB trace -- went with the knob: profiles/r05/lanepiece_latency.txt has its result)
