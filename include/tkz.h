@@ -307,11 +307,12 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
 /* ---- measurement ------------------------------------------------------------------------- */
 
 enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_PROBE = 2 /* k_probe alone */, TKZ_K_SCAN = 3, TKZ_K_PLACE = 4,
-       TKZ_K_DOCOFFS = 5, TKZ_K_MERGE_LONG = 6 /* k_giant_find + k_giant_merge + k_merge_long + k_merge_coop */, TKZ_K_MERGE_SHORT = 7 /* k_merge_short alone */,
+       TKZ_K_DOCOFFS = 5, TKZ_K_MERGE_LONG = 6 /* k_giant_order + k_giant_merge + k_merge_long + k_merge_coop */, TKZ_K_MERGE_SHORT = 7 /* k_merge_short alone */,
        TKZ_K_COUNT = 8 };
 /* When enabled, every kernel launch of tkz_encode_batch_device is bracketed by HIP events on the
  * launch stream; tkz_encoder_kernel_ms returns the accumulated milliseconds and launch counts per
- * kernel since the last reset (arrays of TKZ_K_COUNT). */
+ * kernel since the last reset (arrays of TKZ_K_COUNT).  Not inside any bracket (microseconds each): the fill of the workspace's zero region,
+ * k_doccount2 and the scan of its counts, k_list_stats (which also finds the giant pieces and fills k_merge_coop's queue). */
 tkz_status tkz_encoder_set_profiling(tkz_encoder* e, int32_t enabled);
 tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, int32_t reset);
 /* o200k only, informational: of the 4 KiB blocks of the last batch, how many the ASCII block scanner handed on (blocks with multi-byte
@@ -319,13 +320,13 @@ tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, 
 void tkz_encoder_pretok_leftovers(const tkz_encoder* e, int64_t* after_ascii_scanner, int64_t* after_multibyte_scanner);
 /* The single-launch path: a host-buffer call (tkz_encode_utf8 / _utf16, tkz_encode_batch_utf8) whose batch is at most 128 KiB in at most
  * 8192 documents (o200k: at most 64 KiB, documents of at most 1 KiB) runs as ONE kernel launch that reads the text from, and writes the ids into, page-locked host memory
- * (no copy commands; ~25 launches otherwise).  Informational: how many calls took it, and how many of those the kernel handed back to the
+ * (no copy commands; 16 launches otherwise).  Informational: how many calls took it, and how many of those the kernel handed back to the
  * batch path (a piece of more than 1024 bytes or one of more than 256 that is not a key, an error to diagnose, workspace to grow). */
 void tkz_encoder_small_path_calls(const tkz_encoder* e, int64_t* calls, int64_t* handed_back);
 /* development: the shader-clock stamps the last single-launch kernel left at the end of each of its phases (16 values; returns how many) */
 int32_t tkz_encoder_small_path_phases(const tkz_encoder* e, int64_t* clocks16);
 /* What the batches since the last reset met, with TKZ_OPT_PIECE_STATS on (8 values): [0] batches, [1] pieces (regex matches), [2] pieces of
- * at most 16 bytes that missed the vocabulary as a whole (TikTokenizer.cs:262 -> :268), [3] of 17..1024 bytes (merged a lane each up to 256 bytes, a wavefront each beyond), [4] of more than 1024 bytes (a workgroup each),
+ * at most 16 bytes that missed the vocabulary as a whole (TikTokenizer.cs:262 -> :268), [3] of 17..1024 bytes (merged a lane each up to 128 bytes, a wavefront each beyond), [4] of more than 1024 bytes (a workgroup each),
  * [5] piece-memo lookups and [6] hits among them (the misses went through BytePairEncode), [7] promoted pieces the key tables hold now
  * (TKZ_OPT_PROMOTE: they count as whole-piece hits).  Whole-piece hit rate =
  * 1 - ([2] + [3] + [4]) / [1]. */
