@@ -103,8 +103,8 @@ namespace Microsoft.DeepDev
         protected override bool ReleaseHandle() { Tkz.tkz_encoder_destroy(handle); return true; }
     }
 
-    /// <summary>Two grow-only page-locked buffers (tkz_host_alloc) a tokenizer keeps from call to call: the code units on their way to the
-    /// device, the ids on their way back.  Used under `lock`: one EncodeBatchFlat at a time per tokenizer (the device call is the long part).</summary>
+    /// <summary>Two grow-only page-locked buffers (tkz_host_alloc): the code units on their way to the device, the ids on their way back.  A tokenizer
+    /// keeps a pool of these sets; every EncodeBatchFlat in flight rents its own (two for a batch that goes in sub-batches) and returns them.</summary>
     internal sealed class PinnedBuffers : IDisposable
     {
         private IntPtr units, ids; private long unitsCap, idsCap;
@@ -133,7 +133,6 @@ namespace Microsoft.DeepDev
 
     public sealed class GpuTikTokenizer : ITokenizer, IDisposable
     {
-        private readonly PinnedBuffers pinned = new PinnedBuffers();
         private readonly EncoderHandle handle;
         private IntPtr encoder => handle.DangerousGetHandle();
         private readonly IReadOnlyDictionary<string, int> specialTokensEncoder;
@@ -271,52 +270,73 @@ namespace Microsoft.DeepDev
                     if (start >= text.Length) break;
                 }
             }
-            // 2. the plain segments as one batch of UTF-16 code units in PAGE-LOCKED memory (tkz_host_alloc; kept from call to call): the strings are
-            //    copied by all cores (Parallel.For over slices of the batch: one thread copying 10^6 strings into a fresh `new char[]` and a fresh
-            //    `new int[]` for the ids -- both zero-filled by the runtime first -- ran at 1 GB/s in the C++ stand-in of this method, the library
-            //    behind it at 14); Encoding.UTF8.GetBytes (TikTokenizer.cs:261) is done for the whole batch on the device by tkz_encode_batch_utf16.
+            // 2. the plain segments as batches of UTF-16 code units in PAGE-LOCKED memory (tkz_host_alloc; buffer sets are pooled, one set per call in
+            //    flight: concurrent EncodeBatch callers do not wait for one another -- the library leases a workspace per call as well).  The strings are
+            //    copied by all cores (Parallel.For over slices; one thread copying 10^6 strings into a fresh `new char[]` ran at 1 GB/s in the C++
+            //    stand-in of this method, tests/cpp/bench_host_api.cpp, the library behind it at 15); Encoding.UTF8.GetBytes (TikTokenizer.cs:261) is done
+            //    for the whole batch on the device by tkz_encode_batch_utf16.  A large batch goes in SUB-BATCHES of ~128 MB of code units: the gather of
+            //    sub-batch k + 1 runs while the device encodes sub-batch k (two buffer sets), as include/tkz_tokenizer.hpp's EncodeBatchFlat does.
             int nseg = segments.Count;
             var unitOffsets = new long[nseg + 1];
             long total = 0;
             for (int i = 0; i < nseg; ++i) { unitOffsets[i] = total; total += segments[i].end - segments[i].start; }
             unitOffsets[nseg] = total;
-            int[] ids;
             var segOffsets = new long[nseg + 1];
-            lock (pinned)
+            var cuts = new List<int> { 0 };                                   // sub-batch k = segments [cuts[k], cuts[k + 1])
+            for (int i = 1; i < nseg; ++i)
+                if (unitOffsets[i + 1] - unitOffsets[cuts[cuts.Count - 1]] > SubBatchUnits) cuts.Add(i);
+            cuts.Add(nseg);
+            int nsub = cuts.Count - 1;
+            var chunks = new int[nsub][];
+            var chunkTokens = new long[nsub];
+            var sets = new PinnedBuffers[] { RentBuffers(), nsub > 1 ? RentBuffers() : null };
+            try
             {
-                IntPtr unitsPtr = pinned.Units((total + 32) * 2);       // (an IntPtr: a lambda cannot capture a pointer-typed local)
-                char* units = (char*)unitsPtr;
-                int slices = Math.Max(1, Math.Min(Environment.ProcessorCount, nseg / 4096));
-                System.Threading.Tasks.Parallel.For(0, slices, sl =>
+                System.Threading.Tasks.Task pending = null;
+                for (int k = 0; k < nsub; ++k)
                 {
-                    char* dstUnits = (char*)unitsPtr;
-                    int lo = (int)((long)nseg * sl / slices), hi = (int)((long)nseg * (sl + 1) / slices);
-                    for (int i = lo; i < hi; ++i)
+                    PinnedBuffers set = sets[k & 1];                          // (last used by sub-batch k - 2, whose call has been waited for)
+                    int lo = cuts[k], hi = cuts[k + 1], n = hi - lo;
+                    long u0 = unitOffsets[lo], nu = unitOffsets[hi] - u0;
+                    IntPtr unitsPtr = set.Units((nu + 32) * 2);               // (an IntPtr: a lambda cannot capture a pointer-typed local)
+                    int slices = Math.Max(1, Math.Min(Environment.ProcessorCount, n / 4096));
+                    System.Threading.Tasks.Parallel.For(0, slices, sl =>
                     {
-                        int n = segments[i].end - segments[i].start;
-                        if (n == 0) continue;
-                        fixed (char* src = segments[i].text)
-                            Buffer.MemoryCopy(src + segments[i].start, dstUnits + unitOffsets[i], (long)n * 2, (long)n * 2);
-                    }
-                });
-                // A code unit is at most three UTF-8 bytes and a token at least one byte, so 3 * total ids always suffice; text has a token per
-                // ~4 units, so the first call gets room for one per two and the call is repeated with the exact count (the library reports
-                // it with TKZ_E_CAPACITY = -4) only when that was not enough.
-                long cap = Math.Max(1, Math.Min(3 * total, total / 2 + 4096));
-                long needed;
-                while (true)
-                {
-                    int* pi = (int*)pinned.Ids(cap * 4);
-                    int st;
-                    fixed (long* po = unitOffsets) fixed (long* poo = segOffsets)
-                        st = Tkz.tkz_encode_batch_utf16(encoder, units, po, nseg, pi, cap, poo, out needed);
-                    if (st == -4 && needed > cap) { cap = needed; continue; }
-                    Tkz.Check(st);
-                    break;
+                        char* dstUnits = (char*)unitsPtr;
+                        int a = lo + (int)((long)n * sl / slices), b = lo + (int)((long)n * (sl + 1) / slices);
+                        for (int i = a; i < b; ++i)
+                        {
+                            int len = segments[i].end - segments[i].start;
+                            if (len == 0) continue;
+                            fixed (char* src = segments[i].text)
+                                Buffer.MemoryCopy(src + segments[i].start, dstUnits + (unitOffsets[i] - u0), (long)len * 2, (long)len * 2);
+                        }
+                    });
+                    if (pending != null) pending.Wait();                      // the device call of sub-batch k - 1 (its exception surfaces here)
+                    int kk = k;
+                    pending = System.Threading.Tasks.Task.Run(() => EncodeSubBatch(set, unitsPtr, unitOffsets, lo, n, nu, segOffsets, chunks, chunkTokens, kk));
                 }
-                // the ids leave the page-locked buffer as an array of exactly their number
-                ids = new int[Math.Max(1, needed)];
-                fixed (int* dst = ids) Buffer.MemoryCopy((void*)pinned.Ids(0), dst, needed * 4, needed * 4);
+                if (pending != null) pending.Wait();
+            }
+            finally
+            {
+                ReturnBuffers(sets[0]);
+                if (sets[1] != null) ReturnBuffers(sets[1]);
+            }
+            // the ids of sub-batch k follow those of k - 1: offsets become global, the chunks one array of exactly the ids' number
+            int[] ids;
+            if (nsub == 1) ids = chunks[0];
+            else
+            {
+                long sum = 0;
+                for (int k = 0; k < nsub; ++k)
+                {
+                    for (int i = cuts[k] + 1; i <= cuts[k + 1]; ++i) segOffsets[i] += sum;
+                    sum += chunkTokens[k];
+                }
+                ids = new int[Math.Max(1, sum)];
+                long w0 = 0;
+                for (int k = 0; k < nsub; ++k) { Array.Copy(chunks[k], 0, ids, w0, chunkTokens[k]); w0 += chunkTokens[k]; }
             }
             if (plain) return (ids, segOffsets);
             // 3. splice the special ids in: block copies of the segments' id ranges
@@ -335,6 +355,63 @@ namespace Microsoft.DeepDev
             }
             while (cur < texts.Count) offsets[++cur] = w;
             return (flat, offsets);
+        }
+
+        private const long SubBatchUnits = 64L << 20;                          // code units per device call of a large batch (128 MB)
+        private readonly System.Collections.Concurrent.ConcurrentBag<PinnedBuffers> bufferPool = new System.Collections.Concurrent.ConcurrentBag<PinnedBuffers>();
+        private volatile bool disposed;
+        private long tokensPerUnitQ20;                                           // the densest batch seen, tokens per code unit << 20: sizes the id buffer of the next one
+        private PinnedBuffers RentBuffers()
+        {
+            if (disposed) throw new ObjectDisposedException(nameof(GpuTikTokenizer));
+            return bufferPool.TryTake(out PinnedBuffers b) ? b : new PinnedBuffers();
+        }
+        private void ReturnBuffers(PinnedBuffers b)
+        {
+            if (disposed) { b.Dispose(); GC.SuppressFinalize(b); } else bufferPool.Add(b);
+        }
+        // One device call: the n segments from `lo` on, nu code units at unitsPtr; fills segOffsets[lo + 1 .. lo + n] (relative to this sub-batch's
+        // first id) and chunks[k] with the ids.  A code unit is at most three UTF-8 bytes and a token at least one byte, so 3 * nu ids always suffice;
+        // English text has a token per ~4 units and CJK text about one per unit: the buffer gets room for what the densest batch so far needed (+ 10 %),
+        // a token per two units at least, and the call is repeated with the exact count (TKZ_E_CAPACITY = -4 reports it) only when that was not
+        // enough -- once in a tokenizer's life per kind of text, not once per batch.
+        private unsafe void EncodeSubBatch(PinnedBuffers set, IntPtr unitsPtr, long[] unitOffsets, int lo, int n, long nu, long[] segOffsets, int[][] chunks, long[] chunkTokens, int k)
+        {
+            var rel = new long[n + 1];
+            long u0 = unitOffsets[lo];
+            for (int i = 0; i <= n; ++i) rel[i] = unitOffsets[lo + i] - u0;
+            var outOffs = new long[n + 1];
+            long learnt = (long)((double)nu * (System.Threading.Interlocked.Read(ref tokensPerUnitQ20) / 1048576.0) * 1.1);
+            long cap = Math.Max(1, Math.Min(3 * nu, Math.Max(nu / 2 + 4096, learnt)));
+            long needed;
+            bool held = false;
+            try
+            {
+                handle.DangerousAddRef(ref held);                                // (Dispose on another thread: the native encoder outlives this call)
+                while (true)
+                {
+                    int* pi = (int*)set.Ids(cap * 4);
+                    int st;
+                    fixed (long* po = rel) fixed (long* poo = outOffs)
+                        st = Tkz.tkz_encode_batch_utf16(encoder, (char*)unitsPtr, po, n, pi, cap, poo, out needed);
+                    if (st == -4 && needed > cap) { cap = needed; continue; }
+                    Tkz.Check(st);
+                    break;
+                }
+            }
+            finally { if (held) handle.DangerousRelease(); }
+            if (nu > 0)
+            {
+                long q = (long)((double)needed / nu * 1048576.0), seen;
+                while ((seen = System.Threading.Interlocked.Read(ref tokensPerUnitQ20)) < q &&
+                       System.Threading.Interlocked.CompareExchange(ref tokensPerUnitQ20, q, seen) != seen) { }
+            }
+            var mine = new int[Math.Max(1, needed)];                             // the ids leave the page-locked buffer as an array of exactly their number
+            fixed (int* dst = mine) Buffer.MemoryCopy((void*)set.Ids(0), dst, needed * 4, needed * 4);
+            chunks[k] = mine; chunkTokens[k] = needed;
+            for (int i = 1; i <= n; ++i) segOffsets[lo + i] = outOffs[i];
+            GC.KeepAlive(set);                                                   // (the buffers' finalizer must not run while the native call reads them)
+            GC.KeepAlive(this);
         }
 
         // One item per regex piece of every plain segment and one per special token, in order: its ids and its length in
@@ -457,7 +534,14 @@ namespace Microsoft.DeepDev
             return result;
         }
 
-        public void Dispose() { pinned.Dispose(); GC.SuppressFinalize(pinned); handle.Dispose(); }      // idempotent (SafeHandle; the buffers null their pointers)
+        /// <summary>Idempotent.  The pooled page-locked buffers go at once; a buffer set a call in flight holds is freed when that call returns it
+        /// (ReturnBuffers), never under it; the native encoder goes when the last call that holds a reference on the SafeHandle has returned.</summary>
+        public void Dispose()
+        {
+            disposed = true;
+            while (bufferPool.TryTake(out PinnedBuffers b)) { b.Dispose(); GC.SuppressFinalize(b); }
+            handle.Dispose();
+        }
     }
 
     /// <summary>One rank of a sharded job (BASELINE configs[3]): rank r of `world` encodes documents tkz_shard_range(r) on its own GPU;

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <future>
+#include <thread>
 #include <sstream>
 #include <cstring>
 
@@ -50,12 +52,11 @@ int main(int argc, char** argv) {
         uint64_t sum = 0;
         for (int64_t i = 0; i < fb.n_ids(); ++i) sum += (static_cast<uint64_t>(static_cast<uint32_t>(fb.ids()[i])) + 1) * (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull + 1);
         // ---- the same documents as UTF-16 strings (what a .NET host holds): tkz::TikTokenizer::EncodeBatchFlatUtf16 (page-locked buffers, threaded
-        // gather, ONE tkz_encode_batch_utf16 call), and the calls bindings/csharp/GpuTikTokenizer.EncodeBatchFlat makes, as it makes them: the strings
-        // copied one after the other by the calling thread into an ordinary (pageable) array, a fresh int array for the ids every call.  The rate is
-        // counted in UTF-8 bytes, so that it compares with the figures above.
+        // gather, ONE tkz_encode_batch_utf16 call), and the calls bindings/csharp/GpuTikTokenizer.EncodeBatchFlat makes, as it makes them (below).  The rate
+        // is counted in UTF-8 bytes, so that it compares with the figures above.
         double best16 = 0, best16_cs = 0;
-        uint64_t sum16 = 0;
-        int64_t ntok16 = 0;
+        uint64_t sum16 = 0, sum16_cs = 0;
+        int64_t ntok16 = 0, ntok16_cs = 0;
         {
             std::vector<std::u16string> t16(texts.size());
             for (size_t d = 0; d < texts.size(); ++d) {
@@ -83,31 +84,77 @@ int main(int argc, char** argv) {
             }
             ntok16 = fb16.n_ids();
             for (int64_t i = 0; i < fb16.n_ids(); ++i) sum16 += (static_cast<uint64_t>(static_cast<uint32_t>(fb16.ids()[i])) + 1) * (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull + 1);
-            // as the C# class does it
-            for (int r = 0; r < reps; ++r) {
-                const auto t0 = std::chrono::steady_clock::now();
-                std::vector<int64_t> uo(t16.size() + 1, 0);
-                int64_t tu = 0;
-                for (size_t i = 0; i < t16.size(); ++i) { uo[i] = tu; tu += static_cast<int64_t>(t16[i].size()); }
-                uo[t16.size()] = tu;
-                std::vector<uint16_t> un(static_cast<size_t>(std::max<int64_t>(1, tu)));
-                for (size_t i = 0; i < t16.size(); ++i) std::memcpy(un.data() + uo[i], t16[i].data(), t16[i].size() * 2);
-                int64_t cap = std::max<int64_t>(1, std::min<int64_t>(3 * tu, tu / 2 + 4096));
-                std::vector<int64_t> so(t16.size() + 1);
-                for (;;) {
-                    std::vector<int32_t> ids(static_cast<size_t>(cap));
-                    int64_t needed = 0;
-                    const tkz_status st = tkz_encode_batch_utf16(tok.native(), un.data(), uo.data(), static_cast<int64_t>(t16.size()), ids.data(), cap, so.data(), &needed);
-                    if (st == TKZ_E_CAPACITY && needed > cap) { cap = needed; continue; }
-                    tkz::check(st);
-                    break;
+            // as the C# class does it (bindings/csharp/GpuTikTokenizer.EncodeBatchFlat, round 6), call for call: sub-batches of 64 M code units, two page-locked
+            // buffer sets, the strings of sub-batch k + 1 copied by `gather` threads (Parallel.For over slices) while a task runs tkz_encode_batch_utf16 on
+            // sub-batch k, the id buffer sized by the densest batch seen so far, every sub-batch's ids copied into a fresh array of exactly their number and the
+            // arrays joined at the end (the C# method returns a managed int[]).  Warm: the first call has sized the buffers, as a tokenizer's second batch finds them.
+            {
+                const int64_t kSubUnits = int64_t(64) << 20;
+                const size_t nseg = t16.size();
+                const unsigned hw = std::thread::hardware_concurrency();
+                tkz::PinnedBuffer set_units[2], set_ids[2];
+                double tokens_per_unit = 0;
+                std::vector<int32_t> joined;
+                for (int r = 0; r < reps + 1; ++r) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    std::vector<int64_t> uo(nseg + 1, 0), so(nseg + 1, 0);
+                    int64_t tu = 0;
+                    for (size_t i = 0; i < nseg; ++i) { uo[i] = tu; tu += static_cast<int64_t>(t16[i].size()); }
+                    uo[nseg] = tu;
+                    std::vector<size_t> cuts{0};
+                    for (size_t i = 1; i < nseg; ++i) if (uo[i + 1] - uo[cuts.back()] > kSubUnits) cuts.push_back(i);
+                    cuts.push_back(nseg);
+                    const size_t nsub = cuts.size() - 1;
+                    std::vector<std::vector<int32_t>> chunks(nsub);
+                    std::vector<int64_t> chunk_tokens(nsub, 0);
+                    std::future<void> pending;
+                    for (size_t k = 0; k < nsub; ++k) {
+                        const size_t lo = cuts[k], hi = cuts[k + 1], n = hi - lo;
+                        const int64_t u0 = uo[lo], nu = uo[hi] - u0;
+                        uint16_t* units = static_cast<uint16_t*>(set_units[k & 1].ensure(static_cast<size_t>(nu + 32) * 2));
+                        const size_t slices = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, n / 4096));
+                        {
+                            std::vector<std::thread> pool;
+                            for (size_t sl = 0; sl < slices; ++sl)
+                                pool.emplace_back([&, sl] {
+                                    const size_t a = lo + n * sl / slices, b = lo + n * (sl + 1) / slices;
+                                    for (size_t i = a; i < b; ++i) std::memcpy(units + (uo[i] - u0), t16[i].data(), t16[i].size() * 2);
+                                });
+                            for (auto& th : pool) th.join();
+                        }
+                        if (pending.valid()) pending.get();
+                        pending = std::async(std::launch::async, [&, k, lo, n, u0, nu, units] {
+                            std::vector<int64_t> rel(n + 1), oo(n + 1, 0);
+                            for (size_t i = 0; i <= n; ++i) rel[i] = uo[lo + i] - u0;
+                            int64_t cap = std::max<int64_t>(1, std::min<int64_t>(3 * nu, std::max<int64_t>(nu / 2 + 4096, static_cast<int64_t>(static_cast<double>(nu) * tokens_per_unit * 1.1))));
+                            int64_t needed = 0;
+                            for (;;) {
+                                int32_t* ids = static_cast<int32_t*>(set_ids[k & 1].ensure(static_cast<size_t>(cap) * 4));
+                                const tkz_status st = tkz_encode_batch_utf16(tok.native(), units, rel.data(), static_cast<int64_t>(n), ids, cap, oo.data(), &needed);
+                                if (st == TKZ_E_CAPACITY && needed > cap) { cap = needed; continue; }
+                                tkz::check(st);
+                                break;
+                            }
+                            if (nu > 0) tokens_per_unit = std::max(tokens_per_unit, static_cast<double>(needed) / static_cast<double>(nu));
+                            chunks[k].assign(set_ids[k & 1].as<int32_t>(), set_ids[k & 1].as<int32_t>() + needed);
+                            chunk_tokens[k] = needed;
+                            for (size_t i = 1; i <= n; ++i) so[lo + i] = oo[i];
+                        });
+                    }
+                    if (pending.valid()) pending.get();
+                    int64_t sum = 0;
+                    for (size_t k = 0; k < nsub; ++k) { for (size_t i = cuts[k] + 1; i <= cuts[k + 1]; ++i) so[i] += sum; sum += chunk_tokens[k]; }
+                    if (nsub == 1) joined.swap(chunks[0]);
+                    else { joined.resize(static_cast<size_t>(sum)); int64_t w = 0; for (size_t k = 0; k < nsub; ++k) { std::memcpy(joined.data() + w, chunks[k].data(), static_cast<size_t>(chunk_tokens[k]) * 4); w += chunk_tokens[k]; } }
+                    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                    if (r > 0) best16_cs = std::max(best16_cs, static_cast<double>(total) / s / 1e6);
+                    ntok16_cs = so[nseg];
                 }
-                const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                best16_cs = std::max(best16_cs, static_cast<double>(total) / s / 1e6);
+                for (int64_t i = 0; i < ntok16_cs; ++i) sum16_cs += (static_cast<uint64_t>(static_cast<uint32_t>(joined[static_cast<size_t>(i)])) + 1) * (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull + 1);
             }
         }
-        std::printf("{\"utf16\": {\"value\": %.1f, \"value_as_the_csharp_class_calls\": %.1f, \"tokens\": %lld, \"ids_checksum\": \"%016llx\"}, ",
-                    best16, best16_cs, static_cast<long long>(ntok16), static_cast<unsigned long long>(sum16));
+        std::printf("{\"utf16\": {\"value\": %.1f, \"value_as_csharp\": %.1f, \"tokens\": %lld, \"ids_checksum\": \"%016llx\", \"as_csharp_same_ids\": %s}, ",
+                    best16, best16_cs, static_cast<long long>(ntok16), static_cast<unsigned long long>(sum16), ntok16_cs == ntok16 && sum16_cs == sum16 ? "true" : "false");
         std::printf("\"value\": %.1f, \"unit\": \"MB/s\", \"docs\": %lld, \"bytes\": %lld, \"tokens\": %lld, \"ids_checksum\": \"%016llx\", \"gather_threads\": %d, \"reps\": %d, \"ms\": {\"call\": %.2f, \"offsets_pass\": %.2f, \"waiting_for_gather\": %.2f, \"in_tkz_encode_batch_utf8\": %.2f}}\n",
                     best, static_cast<long long>(texts.size()), static_cast<long long>(total), static_cast<long long>(fb.n_ids()),
                     static_cast<unsigned long long>(sum), threads, reps, static_cast<double>(total) / best / 1e3, b_off, b_wait, b_enc);

@@ -157,6 +157,11 @@ def test_throughput_setting_on_small_batches(lib, vocabs, oracle_mod, monkeypatc
     parity.check_miss_lists(lib, oracle_mod, v, ov)
     parity.check_long_pieces_entry_points(lib, oracle_mod, v, ov)
     parity.check_batch(lib, oracle_mod, v, ov, N.CL100K, seed=97, rounds=3, doc_lens=[0, 1, 10, 100, 1000, 6000], n_docs_choices=[1, 4, 40], kinds=("mix", "ws", "oth"))
+    # (round 6: the large batches' long misses are binned by length class across the batch and merged off that queue -- k_long_count / k_long_scatter /
+    #  k_merge_long_q --: the piece-level checks on that form, trained and adversarial rank tables)
+    parity.check_pieces(lib, oracle_mod, v, ov, seed=23, rounds=2, lens=[12, 16, 17, 20, 24, 31, 32, 33, 40, 63, 64, 65, 100, 128, 129, 300], counts=[5, 300, 1200])
+    parity.check_pieces(lib, oracle_mod, v, ov, seed=29, rounds=2, lens=[17, 24, 33, 40, 48, 64, 90, 128, 200, 400, 1023, 1024], counts=[40, 400], p_listed=1.0)
+    parity.check_random_vocab(lib, oracle_mod, seed=5, n_vocabs=6, lens=[2, 9, 16, 17, 25, 32, 33, 60, 64, 65, 150, 320], n_pieces=60)
     enc = N.Encoder(v, N.CL100K)
     enc.set_option(N.OPT_LATENCY_BYTES, 1 << 20)
     with pytest.raises(N.TkzError):

@@ -96,6 +96,7 @@ struct CounterBlock {          // mirrors the device block
     unsigned long long xcount, xcount2;    // (adjacent: launch_pretok_rows) blocks the o200k ASCII scanner left over, blocks the multi-byte one left over as well
     unsigned long long coop_count, coop_ticket;   // k_list_stats -> k_merge_coop: queued long misses of more than kLanePiece bytes, the next one to be taken
     unsigned long long long_log_count;     // a learning batch: records k_merge_long wanted to log (EncodeParams::long_log)
+    int64_t lq_total;                      // long misses in the class queue (the scan of EncodeParams::lq_cnt)
 };
 
 }  // namespace
@@ -116,7 +117,7 @@ struct Workspace {
     // memset (three launches were three dependent launches: a batch of a few megabytes is made of little else)
     DevBuf w_zero; size_t zero_bytes = 0;
     DevView w_counters, w_docbits, w_heavyq;
-    DevBuf w_mlist, w_mquad, w_mcount, w_pextra, w_coopq;
+    DevBuf w_mlist, w_mquad, w_mcount, w_pextra, w_coopq, w_lqcnt, w_lqbase, w_lq;
     DevBuf w_counts3;                      // {n_docs, n_bytes, n_tokens} of the batch this workspace is running (tkz_pending_counts_device)
     bool sized = false;                    // a batch has run to its end here: the lists and the record buffer have seen real text (encode_device: the sizing attempt)
     int32_t mcap = tkz::kMissCapMin;       // entries of a sub-tile's miss list; grows (once, to what the batch needed) when a sub-tile overflows it
@@ -149,7 +150,7 @@ struct Workspace {
     double ms[tkz::K_COUNT] = {};
     int64_t launches[tkz::K_COUNT] = {};
     void release_all() {
-        DevBuf* bufs[] = {&w_counts3, &w_mlist, &w_mquad, &w_mcount, &w_pextra, &w_coopq, &w_gq, &w_gcnt, &w_xq, &w_zero, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
+        DevBuf* bufs[] = {&w_counts3, &w_mlist, &w_mquad, &w_mcount, &w_pextra, &w_coopq, &w_lqcnt, &w_lqbase, &w_lq, &w_gq, &w_gcnt, &w_xq, &w_zero, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
                           &w_doctok, &w_dcount, &w_dbase, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
                           &s_outoffs[0], &s_outoffs[1], &u_bytes,
                           &u16[0].units, &u16[0].offs, &u16[0].docbits, &u16[0].grp, &u16[0].tsum, &u16[0].tbase, &u16[0].bsum, &u16[0].counters, &u16[0].boffs,
@@ -498,6 +499,12 @@ tkz_status prepare_workspace(Workspace* ws, int64_t total, int64_t n_docs, bool 
         HIP_TRY(ws->w_mcount.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_pextra.ensure((size_t)ntiles * 4, acc));
         HIP_TRY(ws->w_coopq.ensure((size_t)(total / kLanePiece + 64) * 8, acc));
+        {   // the class queue of the long misses (a long miss is 17 bytes at least): counts and bases per (class, chunk of 64 sub-tiles), 8 bytes an entry
+            const int64_t nchunks = (ntiles + 63) / 64;
+            HIP_TRY(ws->w_lqcnt.ensure((size_t)nchunks * 16 * 4, acc));
+            HIP_TRY(ws->w_lqbase.ensure((size_t)(nchunks * 16 + 1) * 8, acc));
+            HIP_TRY(ws->w_lq.ensure((size_t)(total / (kShortMax + 1) + 64) * 8, acc));
+        }
         HIP_TRY(ws->w_tbase.ensure((size_t)(ntiles + 1) * 8, acc));
         HIP_TRY(ws->w_bsum.ensure((size_t)(nblk + 1) * 8, acc));
         HIP_TRY(ws->w_doctok.ensure((size_t)((pieces ? total : n_docs) + 2) * 4, acc));    // (piece mode: one entry per piece)
@@ -650,6 +657,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.coop_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, coop_count));
             P.coop_ticket = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, coop_ticket));
             P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
+            P.lq_cnt = ws->w_lqcnt.as<int32_t>(); P.lq_base = ws->w_lqbase.as<int64_t>(); P.lq = ws->w_lq.as<uint64_t>(); P.lq_cap = total / (kShortMax + 1) + 64;
+            P.lq_total = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, lq_total)); P.lq_bsum = ws->w_bsum.as<int64_t>();
             P.ablate = 0; P.devprof = nullptr;
             P.stats = e->piece_stats ? e->t_stats.as<unsigned long long>() : nullptr;
             // (statistics: an attempt that has to be run again -- lists or records to grow -- must not be counted twice: the block as it was before
@@ -664,8 +673,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
 #ifdef TKZ_DEVPROF
             { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
             if (P.ablate & 16) {
-                if (!g_devprof) { HIP_TRY(hipMalloc((void**)&g_devprof, 32 * 8)); }
-                HIP_TRY(hipMemsetAsync(g_devprof, 0, 32 * 8, stream));
+                if (!g_devprof) { HIP_TRY(hipMalloc((void**)&g_devprof, 64 * 8)); }
+                HIP_TRY(hipMemsetAsync(g_devprof, 0, 64 * 8, stream));
             }
             P.devprof = g_devprof;
 #endif
@@ -714,7 +723,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         if (e->profiling) prof_collect(ws);
 #ifdef TKZ_DEVPROF
         if (g_devprof && getenv("TKZ_DEV_ABLATE") && (atoi(getenv("TKZ_DEV_ABLATE")) & 16) && !d_bitmap_only) {
-            unsigned long long h[32];
+            unsigned long long h[64];
             HIP_TRY(hipMemcpy(h, g_devprof, sizeof h, hipMemcpyDeviceToHost));
             const double w = h[0] ? (double)h[0] : 1.0;
             fprintf(stderr, "[tkz devprof] k_probe waves %llu  clock ticks/wave: total %.0f  load+compact %.0f  short batches %.0f  mid batches %.0f | mid pieces/wave %.1f pieces/wave %.1f\n",
@@ -723,6 +732,9 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                               h[8], (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[12] / h[8], h[13], (double)h[14] / h[8], (double)h[7] / h[8]);
             if (h[8]) fprintf(stderr, "[tkz devprof] slowest giant piece: %llu bytes -> %llu tokens, global rounds %llu (%llu ticks), bytes first/middle/last %02llx %02llx %02llx\n",
                               h[24], h[27], h[25], h[28], h[29] & 255, (h[29] >> 8) & 255, (h[29] >> 16) & 255);
+            if (h[32]) fprintf(stderr, "[tkz devprof] k_merge_long waves %llu units %llu  ticks/wave %.0f | of all ticks: sort %.3f batch formation %.3f bytes %.3f first level %.3f merges %.3f emission %.3f | fast batches %llu lanes/batch %.1f steps/batch %.1f merges/lane %.2f lane use in the merge loop %.3f ticks/step %.0f\n",
+                               h[32], h[44], (double)h[33] / h[32], (double)h[34] / h[33], (double)h[35] / h[33], (double)h[36] / h[33], (double)h[37] / h[33], (double)h[38] / h[33], (double)h[39] / h[33],
+                               h[40], (double)h[41] / (h[40] ? h[40] : 1), (double)h[42] / (h[40] ? h[40] : 1), (double)h[43] / (h[41] ? h[41] : 1), (double)h[43] / (64.0 * (h[42] ? h[42] : 1)), (double)h[38] / (h[42] ? h[42] : 1));
             if (h[16]) fprintf(stderr, "[tkz devprof] tail: batches %llu merges %llu (%.2f a batch) proposals/batch %.1f | rounds for chains of equal pairs %llu | ticks/batch %.0f | longest tail: %llu batches, %llu ticks\n",
                                h[16], h[17], (double)h[17] / h[16], (double)h[18] / h[16], h[19], (double)h[22] / h[16], h[20], h[23]);
         }

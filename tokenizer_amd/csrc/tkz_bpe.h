@@ -92,14 +92,20 @@ TKZ_HD int tkz_bpe_lane_f(const TkzTables& T, const uint32_t* w, int n, uint32_t
         }
     }
     uint32_t alive = tkz_lowmask32(n);
-    for (;;) {                                          // while (byteIndicesAndRanks.Count > 1) (:45)
+    // leftmost strict min (:47-54): packed (rank, position), ties -> lower position
+    auto scan = [&]() -> uint32_t {
         uint32_t key = TKZ_NOKEY;
 #pragma unroll
-        for (int q = 0; q < NMAX / 4; ++q) {            // leftmost strict min (:47-54): packed (rank, position), ties -> lower position
+        for (int q = 0; q < NMAX / 4; ++q) {
             const uint4 p = pr4[q];
             key = tkz_min3u(key, tkz_min3u(p.x, p.y, p.z), p.w);
         }
-        if (key == TKZ_NOKEY) break;                    // minRank == int.MaxValue (:65-68)
+        return key;
+    };
+    // (round 6: the scan is taken out of the merge's chain of dependent round trips, as in tkz_bpe_lane_u below: while the four gathers of a merge are in
+    //  flight the two slots it re-ranks are blanked and the minimum over the others is taken; the next pair is the smaller of that and the two new keys)
+    uint32_t key = scan();
+    while (key != TKZ_NOKEY) {                          // while (byteIndicesAndRanks.Count > 1) (:45); minRank == int.MaxValue (:65-68)
         const int j = (int)(key & (uint32_t)(NMAX - 1));
         const uint32_t m = key >> SH;
         const int r = tkz_ctz32(alive & ~tkz_lowmask32(j + 1));   // the part being swallowed
@@ -107,7 +113,7 @@ TKZ_HD int tkz_bpe_lane_f(const TkzTables& T, const uint32_t* w, int n, uint32_t
         // the two re-ranked pairs (:58, :59-62)
         const uint32_t hi = alive & ~tkz_lowmask32(r + 1);
         const uint32_t lo = alive & tkz_lowmask32(j);
-        const int l = lo ? tkz_msb32(lo) : 0;
+        const int l = lo ? tkz_msb32(lo) : j;
         const int rr = hi ? tkz_ctz32(hi) : 0;
         const uint32_t idr = ids[rr], idl = ids[l];     // (unconditional: see above)
         uint32_t r1, r2s, l1, l2;
@@ -117,9 +123,15 @@ TKZ_HD int tkz_bpe_lane_f(const TkzTables& T, const uint32_t* w, int n, uint32_t
         const uint4 vl1 = tkz_load_pair_slot(T, l1), vl2 = tkz_load_pair_slot(T, l2);
         ids[j] = m;
         pr[r] = TKZ_NOKEY;
+        pr[j] = TKZ_NOKEY;                              // (blanked for the scan below)
+        pr[l] = TKZ_NOKEY;                              // (without a left part: slot j once more)
+        const uint32_t rest = scan();
         const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);
-        pr[j] = (hi && rkr != TKZ_RANK_NONE) ? (((uint32_t)rkr << SH) | (uint32_t)j) : TKZ_NOKEY;
-        if (lo) pr[l] = rkl != TKZ_RANK_NONE ? (((uint32_t)rkl << SH) | (uint32_t)l) : TKZ_NOKEY;
+        const uint32_t ej = (hi && rkr != TKZ_RANK_NONE) ? (((uint32_t)rkr << SH) | (uint32_t)j) : TKZ_NOKEY;
+        const uint32_t el = lo ? (rkl != TKZ_RANK_NONE ? (((uint32_t)rkl << SH) | (uint32_t)l) : TKZ_NOKEY) : ej;
+        pr[j] = ej;
+        pr[l] = el;
+        key = tkz_min3u(rest, ej, el);
     }
     int cnt = 0;
     for (uint32_t a = alive; a; a &= a - 1) {
@@ -337,69 +349,109 @@ TKZ_HD void tkz_bpe_varc_emit(ByteAt at, const uint32_t* st, int n, const int32_
         for (uint32_t a = am[w]; a; a &= a - 1) dst[i++] = (int32_t)tkz_bpe_varc_id(at, n, pr, am, brank, 32 * w + tkz_ctz32(a));
 }
 
-// ---- ... and for pieces of up to 64 bytes with the alive bits in REGISTERS (one 64-bit mask) --------------------------------------
-// A merge of the LDS-mask form above is a chain of ~8 dependent LDS round trips (the scan, two walks over the alive words, the ids of the two
-// neighbours through their alive bits) before its one round trip to the pair table; k_merge_long runs at 3 wavefronts per SIMD and is bound
-// by exactly that chain.  With the mask in registers the neighbours are two bit scans, and what is left in LDS is the scan and one read per
-// neighbour id.  State: pr[n4] only.
-TKZ_HD uint64_t tkz_lowmask64(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
-template <class ByteAt>
-TKZ_HD uint32_t tkz_bpe_varc64_id(ByteAt at, int n, const uint32_t* pr, uint64_t alive, const int32_t* brank, int x) {
-    const int y = x + 1 < n ? x + 1 : x;
-    const bool merged = x + 1 < n && !((alive >> y) & 1ull);
-    const uint32_t a = pr[y] & ~kVarDead, b = (uint32_t)brank[at(x)];     // (both loads unconditional)
-    return merged ? a : b;
+// ---- round 6: the lane form the 17..64-byte pieces run on (k_merge_long's fast batches) -------------------------------------------
+// The same merge sequence as above (BytePairEncoder.cs:45-64), rebuilt around what the ISA of round 5's form (tkz_bpe_lane_varc with a 64-bit alive mask in registers) showed: of ~230 VALU
+// wave-instructions a merge, ~140 were 64-bit mask arithmetic, lane-divergent branches around the neighbour searches and a scan loop whose trip
+// count differed from lane to lane.  Here
+//   * every piece of a batch has a span of ONE size: nq quads of pair keys behind its bytes (nq = the batch's longest piece; a shorter piece's
+//     spare quads hold NOKEY), so the min scan is a loop on the SCALAR unit and its reads are the same instruction in every lane;
+//   * the alive bits are ONE register of the width the batch needs (M = uint32_t up to 32 bytes: 70 % of mixed text's long misses);
+//   * nothing in a merge is a branch: a missing neighbour is an index that reads something harmless and a value that is replaced by a select;
+//   * a pair key is rank << 10 | position built with one shift-or: "no such pair" (int.MaxValue, :23,35) shifts to 0xFFFFFC00 | position, which like
+//     every dead slot lies at or above kVarDead -- "no pair left" (:65-68) is min >= kVarDead as before;
+//   * the first-level ranks (:37-44) are read off the piece's dwords (one byte permute an index) and the tokens leave in one walk that also finds
+//     the bytes that are no key (:73).
+// State: bw[] = the piece's bytes as dwords in LDS, 16-byte aligned, readable up to dword nq (what lies past byte n is never used as a value);
+// pr[4 * nq] pair keys / dead slots (a merged part keeps its id in the dead slot behind its first byte, as in tkz_bpe_lane_varc).
+template <class M> TKZ_HD M tkz_um_bit(int i) { return (M)((M)1 << i); }
+template <class M> TKZ_HD M tkz_um_low(int n) { return n >= (int)(8 * sizeof(M)) ? (M)~(M)0 : (M)(((M)1 << n) - (M)1); }
+TKZ_HD int tkz_um_ctz(uint32_t x) { return tkz_ctz32(x); }
+TKZ_HD int tkz_um_ctz(uint64_t x) { return tkz_ctz64(x); }
+TKZ_HD int tkz_um_msb(uint32_t x) { return tkz_msb32(x); }
+TKZ_HD int tkz_um_msb(uint64_t x) { return tkz_msb64(x); }
+TKZ_HD int tkz_um_popc(uint32_t x) { return tkz_popc32(x); }
+TKZ_HD int tkz_um_popc(uint64_t x) { return tkz_popc64(x); }
+// index into bytepair_rank of the pair that starts at byte k (0..3) of the little-endian dword w (wn: the dword behind it)
+TKZ_HD uint32_t tkz_pair_index(uint32_t w, uint32_t wn, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_perm_b32: byte 0 <- the pair's second byte, byte 1 <- its first, bytes 2, 3 <- 0
+    return k == 0 ? __builtin_amdgcn_perm(wn, w, 0x0c0c0001u) : k == 1 ? __builtin_amdgcn_perm(wn, w, 0x0c0c0102u)
+         : k == 2 ? __builtin_amdgcn_perm(wn, w, 0x0c0c0203u) : __builtin_amdgcn_perm(wn, w, 0x0c0c0304u);
+#else
+    const uint32_t b0 = (w >> (8 * k)) & 0xFFu, b1 = k < 3 ? (w >> (8 * k + 8)) & 0xFFu : wn & 0xFFu;
+    return (b0 << 8) | b1;
+#endif
 }
-template <class ByteAt>
-TKZ_HD int tkz_bpe_lane_varc64(const TkzTables& T, ByteAt at, int n, uint32_t* pr, int* err, const int32_t* brank, uint64_t* alive_out) {
-    auto entry = [](int32_t rank, int pos) -> uint32_t {
-        return rank == TKZ_RANK_NONE ? TKZ_NOKEY : (((uint32_t)rank << kVarPosBits) | (uint32_t)pos);
-    };
-    const int n4 = tkz_bpe_var_n4(n);
+// the id of the part that starts at byte x (alive): a single byte's from brank, a merged part's from the dead slot behind x
+template <class M>
+TKZ_HD uint32_t tkz_bpe_u_id(const uint8_t* pb, const uint32_t* pr, const int32_t* brank, M dead, int x, int last_slot) {
+    const int y = x < last_slot ? x + 1 : last_slot;
+    const uint32_t a = pr[y] & ~kVarDead, b = (uint32_t)brank[pb[x]];          // (both loads unconditional)
+    return ((dead >> x) & (M)2) ? a : b;                                       // bit x + 1 of dead: the part has swallowed its right neighbour
+}
+// first-level pair ranks (:37-44): four positions a dword, sixteen positions a step -- all sixteen gathers of a step are requested before the first is
+// used (the loop over single quads waited for its four gathers quad after quad: nq round trips to the table instead of nq / 4)
+TKZ_HD void tkz_bpe_lane_u_init(const TkzTables& T, const uint32_t* bw, int n, int nq, uint32_t* pr) {
     uint4* pr4 = reinterpret_cast<uint4*>(pr);
-#pragma unroll 1
-    for (int c = 0; c < n4; c += 16) {                   // first-level pair ranks (:37-44), 16 bytes per step, their gathers in flight together
-        uint32_t b[17];
+    const uint4* bw4 = reinterpret_cast<const uint4*>(bw);
+    for (int q0 = 0; q0 < nq; q0 += 4) {
+        const uint4 wv = bw4[q0 >> 2];                  // (the bytes are padded to whole quads; the dword behind them is the first pair key: never used as a value)
+        const uint32_t w[5] = {wv.x, wv.y, wv.z, wv.w, bw[q0 + 4]};
+        int32_t r[16];
 #pragma unroll
-        for (int k = 0; k < 17; ++k) b[k] = c + k < n ? at(c + k) : 0u;
-        int32_t r2[16];
+        for (int k = 0; k < 16; ++k) r[k] = T.bytepair_rank[tkz_pair_index(w[k >> 2], w[(k >> 2) + 1], k & 3)];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) r2[k] = c + k + 1 < n ? T.bytepair_rank[(b[k] << 8) | b[k + 1]] : TKZ_RANK_NONE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (c + 4 * q < n4) {
+        for (int d = 0; d < 4; ++d) {
+            const int q = q0 + d;
+            if (q < nq) {                               // (wave-uniform)
                 uint4 p;
-                p.x = c + 4 * q + 1 < n ? entry(r2[4 * q], c + 4 * q) : TKZ_NOKEY;
-                p.y = c + 4 * q + 2 < n ? entry(r2[4 * q + 1], c + 4 * q + 1) : TKZ_NOKEY;
-                p.z = c + 4 * q + 3 < n ? entry(r2[4 * q + 2], c + 4 * q + 2) : TKZ_NOKEY;
-                p.w = c + 4 * q + 4 < n ? entry(r2[4 * q + 3], c + 4 * q + 3) : TKZ_NOKEY;
-                pr4[(c >> 2) + q] = p;
+                p.x = 4 * q + 1 < n ? (((uint32_t)r[4 * d] << kVarPosBits) | (uint32_t)(4 * q)) : TKZ_NOKEY;
+                p.y = 4 * q + 2 < n ? (((uint32_t)r[4 * d + 1] << kVarPosBits) | (uint32_t)(4 * q + 1)) : TKZ_NOKEY;
+                p.z = 4 * q + 3 < n ? (((uint32_t)r[4 * d + 2] << kVarPosBits) | (uint32_t)(4 * q + 2)) : TKZ_NOKEY;
+                p.w = 4 * q + 4 < n ? (((uint32_t)r[4 * d + 3] << kVarPosBits) | (uint32_t)(4 * q + 3)) : TKZ_NOKEY;
+                pr4[q] = p;
             }
         }
     }
-    uint64_t alive = tkz_lowmask64(n);
-    int cnt = n;
-    for (;;) {                                          // while (byteIndicesAndRanks.Count > 1) (:45)
-        uint32_t m = TKZ_NOKEY;
-#pragma unroll 4
-        for (int q = 0; q < (n4 >> 2); ++q) {           // leftmost strict min (:47-54): packed (rank, position), ties -> lower position
-            const uint4 p = pr4[q];
-            m = tkz_min3u(m, tkz_min3u(p.x, p.y, p.z), p.w);
+}
+// the merges; returns the number of tokens, *alive_out: one bit per part that is left (its first byte)
+template <class M>
+TKZ_HD int tkz_bpe_lane_u_merge(const TkzTables& T, const uint32_t* bw, int n, int nq, uint32_t* pr, const int32_t* brank, M* alive_out) {
+    const uint8_t* pb = reinterpret_cast<const uint8_t*>(bw);
+    uint4* pr4 = reinterpret_cast<uint4*>(pr);
+    const int last_slot = 4 * nq - 1;
+    const M nmask = tkz_um_low<M>(n);
+    M alive = nmask;
+    // leftmost strict min (:47-54): packed (rank, position), ties -> lower position
+    auto scan = [&]() -> uint32_t {
+        uint32_t k0 = TKZ_NOKEY, k1 = TKZ_NOKEY;
+        for (int q = 0; q < nq; q += 2) {
+            const uint4 a = pr4[q];
+            k0 = tkz_min3u(k0, tkz_min3u(a.x, a.y, a.z), a.w);
+            if (q + 1 < nq) { const uint4 b = pr4[q + 1]; k1 = tkz_min3u(k1, tkz_min3u(b.x, b.y, b.z), b.w); }
         }
-        if (m >= kVarDead) break;                       // minRank == int.MaxValue (:65-68)
-        const int j = (int)(m & ((1u << kVarPosBits) - 1u));
-        m >>= kVarPosBits;
+        return k0 < k1 ? k0 : k1;
+    };
+    // The scan is kept OUT of the merge's chain of dependent round trips (alive bits -> neighbour ids in LDS -> pair table -> match): while the four
+    // gathers of a merge are in flight, the slots the merge re-ranks are blanked and the minimum over everything else is taken; the next pair is then
+    // the smaller of that and the two new keys (keys differ in their position bits, so the minimum is the reference's (rank, position) order exactly).
+    uint32_t key = scan();
+    while (key < kVarDead) {                            // while (byteIndicesAndRanks.Count > 1) (:45); minRank == int.MaxValue (:65-68)
+        const int j = (int)(key & ((1u << kVarPosBits) - 1u));
+        const uint32_t m = key >> kVarPosBits;
         // r: the part being swallowed (next part after j), rr: the one after it, l: the part before j
-        const uint64_t hi = alive & ~tkz_lowmask64(j + 1);          // (not empty: pr[j] was a rank)
-        const int r = tkz_ctz64(hi);
-        const uint64_t hi2 = hi & (hi - 1);
+        const M hi = alive & (M)(((M)~(M)1) << j);      // (not empty: pr[j] was a rank)
+        const int r = tkz_um_ctz(hi);
+        const M hi2 = hi & (hi - 1);
         const bool hasr = hi2 != 0;
-        const int rr = hasr ? tkz_ctz64(hi2) : 0;
-        alive &= ~(1ull << r);                          // RemoveAt(j + 1) (:63)
-        const uint64_t lo = alive & tkz_lowmask64(j);
+        const int rr = tkz_um_ctz((M)(hi2 | tkz_um_bit<M>(8 * (int)sizeof(M) - 1)));
+        alive &= ~tkz_um_bit<M>(r);                     // RemoveAt(j + 1) (:63)
+        const M lo = alive & (M)(tkz_um_bit<M>(j) - 1);
         const bool hasl = lo != 0;
-        const int l = hasl ? tkz_msb64(lo) : 0;
-        const uint32_t idr = tkz_bpe_varc64_id(at, n, pr, alive, brank, rr), idl = tkz_bpe_varc64_id(at, n, pr, alive, brank, l);
+        const int l = hasl ? tkz_um_msb(lo) : j;
+        const M dead = nmask & ~alive;
+        const uint32_t idr = tkz_bpe_u_id<M>(pb, pr, brank, dead, rr < last_slot ? rr : last_slot, last_slot);
+        const uint32_t idl = tkz_bpe_u_id<M>(pb, pr, brank, dead, l, last_slot);
         uint32_t r1, r2s, l1, l2;
         tkz_pair_slots(T, m, idr, &r1, &r2s);
         tkz_pair_slots(T, idl, m, &l1, &l2);
@@ -407,20 +459,50 @@ TKZ_HD int tkz_bpe_lane_varc64(const TkzTables& T, ByteAt at, int n, uint32_t* p
         const uint4 vl1 = tkz_load_pair_slot(T, l1), vl2 = tkz_load_pair_slot(T, l2);
         pr[r] = TKZ_NOKEY;                              // dead for good
         pr[j + 1] = kVarDead | m;                       // ... and the slot behind j carries the id of the merged part (= the rank it was found under)
+        pr[j] = TKZ_NOKEY;                              // (blanked for the scan below)
+        pr[l] = TKZ_NOKEY;
+        const uint32_t rest = scan();
         const int32_t rkr = tkz_match_pair(T, m, idr, vr1, vr2), rkl = tkz_match_pair(T, idl, m, vl1, vl2);
-        pr[j] = hasr ? entry(rkr, j) : TKZ_NOKEY;                           // (:58)
-        if (hasl) pr[l] = entry(rkl, l);                                    // (:59-62)
-        --cnt;
+        const uint32_t ej = hasr ? (((uint32_t)rkr << kVarPosBits) | (uint32_t)j) : TKZ_NOKEY;      // (:58)
+        const uint32_t el = hasl ? (((uint32_t)rkl << kVarPosBits) | (uint32_t)l) : ej;             // (:59-62; without a left part: slot j once more)
+        pr[j] = ej;
+        pr[l] = el;
+        key = tkz_min3u(rest, ej, el);
     }
-    for (uint64_t a = alive; a; a &= a - 1)
-        if (tkz_bpe_varc64_id(at, n, pr, alive, brank, tkz_ctz64(a)) >= (uint32_t)TKZ_PSEUDO_BASE) *err |= kErrKeyNotFound;   // ranks[...] throws (:17,:73)
     *alive_out = alive;
-    return cnt;
+    return tkz_um_popc(alive);
 }
-template <class ByteAt>
-TKZ_HD void tkz_bpe_varc64_emit(ByteAt at, const uint32_t* pr, uint64_t alive, int n, const int32_t* brank, int32_t* dst) {
-    int i = 0;
-    for (uint64_t a = alive; a; a &= a - 1) dst[i++] = (int32_t)tkz_bpe_varc64_id(at, n, pr, alive, brank, tkz_ctz64(a));
+template <class M>
+TKZ_HD int tkz_bpe_lane_u(const TkzTables& T, const uint32_t* bw, int n, int nq, uint32_t* pr, const int32_t* brank, M* alive_out) {
+    tkz_bpe_lane_u_init(T, bw, n, nq, pr);
+    return tkz_bpe_lane_u_merge<M>(T, bw, n, nq, pr, brank, alive_out);
+}
+// the tokens of such a piece, in order: dst[0 .. count) when store, the first four also in q4; *err: a surviving byte that is no key (:17,:73)
+template <class M>
+TKZ_HD void tkz_bpe_lane_u_emit(const uint32_t* bw, int n, int nq, const uint32_t* pr, const int32_t* brank, M alive, bool store, int32_t* dst, uint32_t* q4, int* err) {
+    const uint8_t* pb = reinterpret_cast<const uint8_t*>(bw);
+    const int last_slot = 4 * nq - 1;
+    M a = alive;
+    uint32_t bad = 0;
+    auto next = [&]() -> uint32_t {                     // (a != 0)
+        const int p = tkz_um_ctz(a);
+        a &= a - 1;
+        const int pn = a ? tkz_um_ctz(a) : n;           // the next part's start: the part is bytes [p, pn)
+        const int y = p < last_slot ? p + 1 : last_slot;
+        const uint32_t m = pr[y] & ~kVarDead, b = (uint32_t)brank[pb[p]];      // (both loads unconditional)
+        const uint32_t id = pn - p > 1 ? m : b;
+        bad |= id >= (uint32_t)TKZ_PSEUDO_BASE ? 1u : 0u;
+        return id;
+    };
+    // (two parts a step -- both parts' LDS reads requested together -- was measured: emission 11 -> 13 % of the kernel on mixed text, 15 -> 19 % on real text)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                       // (the first four by name: the quad lives in registers)
+        q4[i] = 0u;
+        if (a) { q4[i] = next(); if (store) dst[i] = (int32_t)q4[i]; }
+    }
+    int32_t* d = dst + 4;
+    while (a) *d++ = (int32_t)next();                   // (a fifth token: the caller stores -- count > 4)
+    if (bad) *err |= kErrKeyNotFound;
 }
 
 // the tokens of a piece merged by tkz_bpe_lane_var, in order

@@ -71,6 +71,9 @@ struct EncodeParams {
     unsigned long long* giant_ticket;       // k_giant_merge: next entry of the (longest first) order, giant_q[2 * giant_cap + t], to be taken
     // long misses of more than kLanePiece bytes (k_merge_coop: a wavefront each): queued by k_list_stats as sub-tile << 10 | index in the sub-tile's long list
     uint64_t* coop_q; unsigned long long* coop_count; unsigned long long* coop_ticket; int64_t coop_cap;
+    // the long misses of up to lane_piece bytes, binned by length class across the batch (large batches: k_long_count -> scan -> k_long_scatter -> k_merge_long_q).
+    // lq null: the chunk form (k_merge_long).  lq_cnt / lq_base: [16 classes x chunks of 64 sub-tiles]; lq: sub-tile << 30 | list index << 20 | (len - 1) << 10 | byte in the sub-tile
+    int32_t* lq_cnt; int64_t* lq_base; int64_t* lq_total; int64_t* lq_bsum; uint64_t* lq; int64_t lq_cap;
     // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE bit 4): per-phase clock counters of k_probe.  Compiled out of libtkz.so otherwise.
     unsigned long long* devprof;
     int32_t ablate;

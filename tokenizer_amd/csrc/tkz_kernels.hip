@@ -18,6 +18,8 @@
 //   k_docoffs        out_offsets[d] = tile base + position inside the tile
 #include "tkz_kernels.h"
 
+#include <type_traits>
+
 #include "tkz_bpe.h"
 #include "tkz_classes.h"
 #include "tkz_corpus.h"
@@ -1249,7 +1251,7 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
 }
 
 // The pieces of 17..256 bytes that have to be merged (longer ones: k_merge_coop below), and the token counts of the giant ones.  One lane per piece with its state in a
-// span of an LDS arena sized for it (tkz_bpe_lane_varc64 / _varc / _var: pair ranks [| ids] [| alive bits], preceded by the piece's bytes).
+// span of an LDS arena sized for it (tkz_bpe_lane_u up to 64 bytes; tkz_bpe_lane_varc / _var beyond: pair ranks [| ids] [| alive bits], preceded by the piece's bytes).
 // The long-miss lists of the 64 sub-tiles of a chunk are walked as one list, kLongSeg entries at a time, and every such segment is
 // SORTED BY LENGTH (a counting sort over 16 length classes, in LDS) before it is cut into batches of up to 64 lanes: a merge costs a scan
 // over the whole piece and a piece of n bytes takes ~n/2 of them, so a 60-byte piece is ten times the work of a 17-byte one -- in list
@@ -1270,6 +1272,8 @@ TKZ_KERNEL_OCC(kMsThreads, 4) void k_merge_short(TkzTables T, EncodeParams P) {
 constexpr int kLongParts = TKZ_LONG_PARTS, kLongDense = TKZ_LONG_DENSE;
 static_assert(kLongParts >= 1 && kLongParts <= 64 && 64 % kLongParts == 0, "a part is a whole number of the chunk's 64 sub-tiles");
 constexpr int kLongSeg = 384;
+constexpr int kFastPiece = 64;           // long misses of up to this many bytes: the fast batches of k_merge_long (tkz_bpe_lane_u)
+static_assert(kFastPiece <= kLanePiece && kFastPiece <= kSmallLanePiece, "every caller's lane limit covers the fast batches");
 constexpr int kLenClasses = 16;
 TKZ_HD int tkz_len_class(int len) {          // 17..1024, monotone
     if (len <= 32) return (len - 17) >> 2;               // 17-20, 21-24, 25-28, 29-32
@@ -1280,13 +1284,13 @@ TKZ_HD int tkz_len_class(int len) {          // 17..1024, monotone
     return len <= 768 ? 14 : 15;
 }
 // LDS of the wavefront of k_merge_long
-struct LongLds { uint32_t* arena; int* pre; int* cls; uint16_t* ord; int32_t* brank; };
+struct LongLds { uint32_t* arena; int arena_dwords; int* pre; int* cls; uint16_t* ord; int32_t* brank; };
 constexpr int kLongLdsBytes = kArenaDwords * 4 + 4 * 68 + 4 * kLenClasses + 2 * kLongSeg + 4 * 256;
 constexpr int kLongLdsQuads = (kLongLdsBytes + 15) / 16;
 TKZ_DEV LongLds tkz_long_lds(uint4* quads) {
     LongLds L;
     uint8_t* b = reinterpret_cast<uint8_t*>(quads);
-    L.arena = reinterpret_cast<uint32_t*>(b); b += kArenaDwords * 4;
+    L.arena = reinterpret_cast<uint32_t*>(b); b += kArenaDwords * 4; L.arena_dwords = kArenaDwords;
     L.brank = reinterpret_cast<int32_t*>(b); b += 4 * 256;                    // id of every single byte: in LDS, not a gather per byte
     L.pre = reinterpret_cast<int*>(b); b += 4 * 68;
     L.cls = reinterpret_cast<int*>(b); b += 4 * kLenClasses;
@@ -1297,20 +1301,226 @@ TKZ_DEV void tkz_long_brank_init(const TkzTables& T, int32_t* s_brank) {     // 
     for (int i = simt::lane(); i < 256; i += 64) s_brank[i] = T.byte_rank[i];
     (void)simt::ballot(true);
 }
+// The development counters of the long-miss kernels (make DEVPROF=1, TKZ_DEV_ABLATE bit 4): clock ticks of a wavefront by phase, batches, lanes, merges
+struct LongProf {
+    bool on = false;
+    long long t[6] = {0, 0, 0, 0, 0, 0};            // sort / queue | batch formation | bytes | first level | merges | emission and answers
+    long long batches = 0, lanes = 0, steps = 0, merges = 0, units = 0, t0 = 0, begin = 0;
+};
+#ifdef TKZ_DEVPROF
+#define TKZ_PF_MARK(i) do { if (PF.on) { const long long pf_now = simt::clock(); PF.t[i] += pf_now - PF.t0; PF.t0 = pf_now; } } while (0)
+TKZ_DEV void tkz_long_prof_begin(const EncodeParams& P, LongProf& PF) { PF.on = TKZ_DEV_FLAG(P, 16) && P.devprof; if (PF.on) PF.begin = PF.t0 = simt::clock(); }
+TKZ_DEV void tkz_long_prof_end(const EncodeParams& P, LongProf& PF) {
+    if (!PF.on) return;
+    int mt;
+    (void)tkz_wave_scan_sum((int)PF.merges, &mt);
+    if (simt::lane() == 0) {
+        simt::atomic_add64(&P.devprof[32], 1); simt::atomic_add64(&P.devprof[33], (unsigned long long)(simt::clock() - PF.begin));
+        for (int i = 0; i < 6; ++i) simt::atomic_add64(&P.devprof[34 + i], (unsigned long long)PF.t[i]);
+        simt::atomic_add64(&P.devprof[40], (unsigned long long)PF.batches); simt::atomic_add64(&P.devprof[41], (unsigned long long)PF.lanes);
+        simt::atomic_add64(&P.devprof[42], (unsigned long long)PF.steps); simt::atomic_add64(&P.devprof[43], (unsigned long long)mt);
+        simt::atomic_add64(&P.devprof[44], (unsigned long long)PF.units);
+    }
+}
+#else
+#define TKZ_PF_MARK(i) do { } while (0)
+TKZ_DEV void tkz_long_prof_begin(const EncodeParams&, LongProf&) {}
+TKZ_DEV void tkz_long_prof_end(const EncodeParams&, LongProf&) {}
+#endif
+// ONE BATCH of long misses: the lanes for which `valid` holds (a prefix of the wavefront, lane 0 among them) each bring a piece -- entry j of sub-tile
+// sub's long list, len bytes at byte rel of the sub-tile -- in ascending order of tkz_len_class.  Merges a prefix of them, one piece a lane, answers their
+// list entries and returns how many it took (>= 1); the caller comes back with the rest.  (COMPACT: ranks below 2^21, i.e. every published vocabulary.)
+// (on_limit(n): called as soon as the number of pieces the batch takes is known, before anything is merged -- the queue form requests its next entries there)
+template <bool COMPACT, class OnLimit>
+TKZ_DEV int tkz_long_batch(const TkzTables& T, const EncodeParams& P, const LongLds& LD, bool valid, int64_t sub, int j, int rel, int len, int lane_piece, int& err, LongProf& PF, OnLimit on_limit) {
+    uint32_t* s_arena = LD.arena;
+    const int32_t* s_brank = LD.brank;
+    const int lane = simt::lane();
+    constexpr bool compact = COMPACT;                           // no ids[] array (tkz_bpe_lane_varc): 40 % more pieces per batch
+    const int64_t abs = sub * kSub + rel;
+    const int64_t lidx = sub * (int64_t)P.mcap + (P.mcap - 1 - j);     // the piece's list entry (and quad)
+    bool log_it = false;                             // (a learning batch: this lane's piece goes into the log below)
+    uint4 log_tok; log_tok.x = log_tok.y = log_tok.z = log_tok.w = 0;
+    int log_cnt = 0;
+    const uint32_t* log_bw = s_arena;                // the piece's bytes in the arena
+    int limit;
+    // ---- a FAST batch (round 6): the next pieces of up to 32 (else: up to 64) bytes, every one in a span of the size the longest of them
+    //      needs, merged by tkz_bpe_lane_u (tkz_bpe.h).  The positions are sorted by length class and 32 | 33, 64 | 65 are class edges,
+    //      so the pieces of a batch are a prefix of the lanes.
+    const int len0 = simt::first_lane(len);          // (lane 0 always holds a piece)
+    if (COMPACT && len0 <= kFastPiece) {           // (kFastPiece <= lane_piece: static_assert below)
+        const int cut = len0 <= 32 ? 32 : kFastPiece;
+        const int nok = tkz_ctz64z(~simt::ballot(valid && len <= cut));
+        const int maxlen = (int)~simt::wave_min_u32(~(uint32_t)(lane < nok ? len : 0));
+        const int nq = (maxlen + 3) >> 2;            // dwords of bytes = quads of pair keys, the same for every piece of the batch
+        const int nbd = (nq + 3) & ~3;
+        const int spanq = ((nbd >> 2) + nq) | 1;     // an odd number of quads: the spans' 16-byte reads then sit on distinct banks
+        const int fit = (LD.arena_dwords / 4) / spanq; // (>= 1: the arena covers a piece of lane_piece bytes)
+        limit = nok < fit ? nok : fit;
+        on_limit(limit);
+        TKZ_PF_MARK(1);
+#ifdef TKZ_DEVPROF
+        int pf_mg = 0;
+#endif
+        if (lane < limit) {
+            uint32_t* bw = s_arena + lane * (spanq * 4);
+            log_bw = bw;
+            {   // nbd dwords of text from the piece's first byte on (past its end: whatever follows; past the end of the text: 0): every load is requested
+                // before the first is used (a loop over the dwords waited for one round trip to the text after the other)
+                const int64_t a0 = abs & ~(int64_t)3;
+                const uint32_t sh = (uint32_t)(abs & 3) * 8u;
+                auto fetch = [&](auto NDW) {
+                    constexpr int ND = decltype(NDW)::value;
+                    uint32_t t[ND + 1];
+                    if (a0 + 4 * (int64_t)(ND + 1) <= P.total) {
+#pragma unroll
+                        for (int w = 0; w <= ND; ++w) t[w] = *reinterpret_cast<const uint32_t*>(P.bytes + a0 + 4 * w);
+                    } else {
+                        for (int w = 0; w <= ND; ++w) {
+                            uint32_t v = 0;
+                            for (int b = 0; b < 4; ++b) if (a0 + 4 * w + b < P.total) v |= (uint32_t)P.bytes[a0 + 4 * w + b] << (8 * b);
+                            t[w] = v;
+                        }
+                    }
+                    uint4* bw4 = reinterpret_cast<uint4*>(bw);
+#pragma unroll
+                    for (int g = 0; g < ND / 4; ++g)
+                        if (4 * g < nbd) {                  // (wave-uniform)
+                            uint4 v;
+                            v.x = simt::alignbit(t[4 * g + 1], t[4 * g], sh); v.y = simt::alignbit(t[4 * g + 2], t[4 * g + 1], sh);
+                            v.z = simt::alignbit(t[4 * g + 3], t[4 * g + 2], sh); v.w = simt::alignbit(t[4 * g + 4], t[4 * g + 3], sh);
+                            bw4[g] = v;
+                        }
+                };
+                if (cut == 32) fetch(std::integral_constant<int, 8>{}); else fetch(std::integral_constant<int, 16>{});
+            }
+            uint32_t* pr = bw + nbd;
+            uint32_t q4[4];
+            int e1 = 0, cnt;
+            TKZ_PF_MARK(2);
+            tkz_bpe_lane_u_init(T, bw, len, nq, pr);
+            TKZ_PF_MARK(3);
+            if (cut == 32) {
+                uint32_t alive;
+                cnt = tkz_bpe_lane_u_merge<uint32_t>(T, bw, len, nq, pr, s_brank, &alive);
+                TKZ_PF_MARK(4);
+                tkz_bpe_lane_u_emit<uint32_t>(bw, len, nq, pr, s_brank, alive, cnt > 4, P.tmp + abs, q4, &e1);
+            } else {
+                uint64_t alive;
+                cnt = tkz_bpe_lane_u_merge<uint64_t>(T, bw, len, nq, pr, s_brank, &alive);
+                TKZ_PF_MARK(4);
+                tkz_bpe_lane_u_emit<uint64_t>(bw, len, nq, pr, s_brank, alive, cnt > 4, P.tmp + abs, q4, &e1);
+            }
+            err |= e1;
+#ifdef TKZ_DEVPROF
+            pf_mg = len - cnt;
+#endif
+            // (five tokens and more wait in tmp at the piece's position; up to four go into the entry's quad, where k_place finds them in the
+            //  round trip that fetches the answers)
+            if (cnt <= 4) {
+                uint4 tq; tq.x = q4[0]; tq.y = q4[1]; tq.z = q4[2]; tq.w = q4[3];
+                P.mquad[lidx] = tq;
+                P.mlist[lidx] = tkz_result_inline(cnt);
+                if (P.long_log && len <= kLongLogMaxLen && !e1 && (!P.long_log_sparse || ((sub >> 6) & 7) == 0)) { log_it = true; log_tok = tq; log_cnt = cnt; }
+            } else P.mlist[lidx] = tkz_result_entry(false, cnt, rel);
+            if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
+        }
+        TKZ_PF_MARK(5);
+#ifdef TKZ_DEVPROF
+        if (PF.on) {
+            PF.merges += pf_mg;                                        // (per lane; summed over the wave at the end)
+            const int mx = (int)~simt::wave_min_u32(~(uint32_t)pf_mg);
+            if (lane == 0) { ++PF.batches; PF.lanes += limit; PF.steps += mx; }
+        }
+#endif
+    } else {
+    // ---- the general batch: pieces of more than kFastPiece bytes (and every piece of a vocabulary with ranks of 2^21 and more), each in a span of
+    //      its own size, up to the first whose state no longer fits the arena
+    const int nbw = (len + 3) >> 2;
+    const bool mine = valid && len <= lane_piece;    // (a longer piece keeps its entry as it is: k_merge_coop answers it -- k_probe has flagged its sub-tile)
+    int need = 0;
+    if (mine) {
+        need = ((nbw + 3) & ~3) + (compact ? tkz_bpe_varc_dwords(len) : tkz_bpe_var_dwords(len));
+        if (!((need >> 2) & 1)) need += 4;           // an odd number of quads: equal spans then sit on distinct banks
+    }
+    int btot;
+    const int aoff = tkz_wave_scan_sum(need, &btot);
+    const uint64_t bad = simt::ballot(mine && aoff + need > LD.arena_dwords);
+    limit = bad ? tkz_ctz64(bad) : 64;               // lanes at or beyond `limit` wait for the next batch (limit >= 1: one piece always fits)
+    on_limit(limit);
+    if (mine && lane < limit) {
+        uint32_t* bw = &s_arena[aoff];                   // (len + 3) / 4 dwords of bytes, then the merge state
+        log_bw = bw;
+        {
+            const int64_t a0 = abs & ~(int64_t)3;
+            const uint32_t sh = (uint32_t)(abs & 3) * 8u;
+            uint32_t prev = 0;
+            if (a0 + 4 <= P.total) prev = *reinterpret_cast<const uint32_t*>(P.bytes + a0);
+            else for (int b = 0; b < 4; ++b) if (a0 + b < P.total) prev |= (uint32_t)P.bytes[a0 + b] << (8 * b);
+            for (int w = 0; w < nbw; ++w) {
+                const int64_t p = a0 + 4 * (w + 1);
+                uint32_t nx = 0;
+                if (p + 4 <= P.total) nx = *reinterpret_cast<const uint32_t*>(P.bytes + p);
+                else for (int b = 0; b < 4; ++b) if (p + b < P.total) nx |= (uint32_t)P.bytes[p + b] << (8 * b);
+                bw[w] = simt::alignbit(nx, prev, sh);
+                prev = nx;
+            }
+        }
+        const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(bw);
+        uint32_t* st = bw + ((nbw + 3) & ~3);             // (the state arrays are read 16 bytes at a time)
+        auto at = [&](int i) -> uint32_t { return pbytes[i]; };
+        int e1 = 0, cnt;
+        if constexpr (COMPACT) {
+            cnt = tkz_bpe_lane_varc(T, at, len, st, &e1, s_brank); tkz_bpe_varc_emit(at, st, len, s_brank, P.tmp + abs);
+        } else {
+            cnt = T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &e1, s_brank) : tkz_bpe_lane_var<false>(T, at, len, st, &e1, s_brank);
+            tkz_bpe_var_emit(st, len, P.tmp + abs);
+        }
+        err |= e1;
+        // (the tokens are in tmp at the piece's position; up to four also go into the entry's quad, where k_place finds them
+        //  in the round trip that fetches the answers)
+        if (cnt <= 4) {
+            const int32_t* tk = P.tmp + abs;
+            uint4 tq; tq.x = (uint32_t)tk[0]; tq.y = cnt > 1 ? (uint32_t)tk[1] : 0u; tq.z = cnt > 2 ? (uint32_t)tk[2] : 0u; tq.w = cnt > 3 ? (uint32_t)tk[3] : 0u;
+            P.mquad[lidx] = tq;
+            P.mlist[lidx] = tkz_result_inline(cnt);
+            if (P.long_log && len <= kLongLogMaxLen && !e1 && (!P.long_log_sparse || ((sub >> 6) & 7) == 0)) { log_it = true; log_tok = tq; log_cnt = cnt; }
+        } else P.mlist[lidx] = tkz_result_entry(false, cnt, rel);
+        if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
+    }
+    }
+    if (P.long_log) {                                // (wave-uniform; a learning batch only) one atomic for the wavefront's records
+        int ltot;
+        const int lpre = tkz_wave_scan_sum(log_it ? 1 : 0, &ltot);
+        unsigned long long lbase = 0;
+        if (lane == 0 && ltot) lbase = simt::atomic_add64(P.long_log_count, (unsigned long long)ltot);
+        lbase = ((unsigned long long)simt::shflu((uint32_t)(lbase >> 32), 0) << 32) | simt::shflu((uint32_t)lbase, 0);
+        if (log_it && lbase + (unsigned long long)lpre < (unsigned long long)P.long_log_cap) {
+            uint32_t* rec = P.long_log + (lbase + (unsigned long long)lpre) * kLongLogDwords;
+            for (int w = 0; w < 7; ++w) {                    // (the piece's bytes, still in the arena)
+                const int nbz = len - 4 * w;
+                rec[w] = nbz <= 0 ? 0u : (nbz >= 4 ? log_bw[w] : (log_bw[w] & ((1u << (8 * nbz)) - 1u)));
+            }
+            rec[7] = (uint32_t)len | ((uint32_t)log_cnt << 8);
+            rec[8] = log_tok.x; rec[9] = log_tok.y; rec[10] = log_tok.z; rec[11] = log_tok.w;
+        }
+    }
+    (void)simt::ballot(true);
+    return limit;
+}
 // chunks c0, c0 + cstep, ... of 64 sub-tiles each, by one wavefront
 // (COMPACT: ranks below 2^21, i.e. every published vocabulary -- no ids[] array)
 template <bool COMPACT, int PARTS = kLongParts, int DENSE = kLongDense>
 // (lane_piece: pieces of up to this many bytes are merged here -- kLanePiece on the batch path, which has k_merge_coop for the longer ones; the
 //  single-launch kernel has no such kernel and takes kSmallLanePiece)
 TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, int64_t c0, int64_t cstep, const LongLds& LD, const int lane_piece = kLanePiece) {
-    uint32_t* s_arena = LD.arena;
     int* s_pre = LD.pre;
     int* s_cls = LD.cls;
     uint16_t* s_ord = LD.ord;
-    const int32_t* s_brank = LD.brank;
     const int lane = simt::lane();
     int err = 0;
-    constexpr bool compact = COMPACT;                           // no ids[] array (tkz_bpe_lane_varc): 40 % more pieces per batch
+    LongProf PF;
+    tkz_long_prof_begin(P, PF);
     // A unit of work = a chunk of 64 sub-tiles, or -- when the chunk's lists hold more than kLongDense entries -- one of its kLongParts parts
     // (the parts of a sparse chunk other than part 0 have nothing to do).
     // (part-major: units 0 .. nchunks-1 are part 0 of every chunk.  Chunk-major -- unit u = part u % 4 of chunk u / 4 -- put the only units that have
@@ -1343,6 +1553,9 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
             *q = tkz_find_list<64>(s_pre, g); *j = g - s_pre[*q];
             return tkz_load_nt(&P.mlist[(c * 64 + *q) * (int64_t)P.mcap + (P.mcap - 1 - *j)]);
         };
+#ifdef TKZ_DEVPROF
+        if (PF.on) { ++PF.units; PF.t0 = simt::clock(); }
+#endif
         for (int seg0 = 0; seg0 < ntotal; seg0 += kLongSeg) {
             const int nseg = ntotal - seg0 < kLongSeg ? ntotal - seg0 : kLongSeg;
             // ---- counting sort of the segment's positions by length class ----
@@ -1375,6 +1588,7 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                 if (e < nseg) s_ord[simt::atomic_add(&s_cls[(mycls >> (4 * i)) & 15u], 1)] = (uint16_t)e;
             }
             (void)simt::ballot(true);
+            TKZ_PF_MARK(0);
             // ---- batches: the next sorted positions, one per lane, up to the first whose state no longer fits the arena ----
             for (int done = 0; done < nseg;) {
                 const bool valid = done + lane < nseg;
@@ -1383,115 +1597,15 @@ TKZ_DEV void tkz_merge_long_chunks(const TkzTables& T, const EncodeParams& P, in
                     const uint32_t ent = entry_at(seg0 + (int)s_ord[done + lane], &q, &j);
                     rel = (int)(ent & 1023u); len = (int)((ent >> kMrLenShift) & 1023u) + 1;
                 }
-                const int nbw = (len + 3) >> 2;
-#ifdef TKZ_ML_LANE32
-                // (development A/B, round 5: the fixed 32-entry form of k_merge_short's merger -- ids[32] | pr[32], the bytes in registers -- for the pieces
-                //  of up to 32 bytes, which are 70 % of mixed text's long misses)
-                const bool lane32 = compact && len <= 32;
-#else
-                constexpr bool lane32 = false;
-#endif
-                const bool small = compact && len <= 64;         // alive bits in registers: the state is pr[] alone
-                const bool mine = valid && len <= lane_piece;    // (a longer piece keeps its entry as it is: k_merge_coop answers it -- k_probe has flagged its sub-tile)
-                int need = 0;
-                if (mine) {
-                    need = ((nbw + 3) & ~3) + (small ? tkz_bpe_var_n4(len) : compact ? tkz_bpe_varc_dwords(len) : tkz_bpe_var_dwords(len));
-                    if (lane32) need = 64;
-                    if (!((need >> 2) & 1)) need += 4;           // an odd number of quads: equal spans then sit on distinct banks
-                }
-                int btot;
-                const int aoff = tkz_wave_scan_sum(need, &btot);
-                const uint64_t bad = simt::ballot(mine && aoff + need > kArenaDwords);
-                const int limit = bad ? tkz_ctz64(bad) : 64;                   // lanes at or beyond `limit` wait for the next batch (limit >= 1: one piece always fits)
-                bool log_it = false;                             // (a learning batch: this lane's piece goes into the log below)
-                uint4 log_tok; log_tok.x = log_tok.y = log_tok.z = log_tok.w = 0;
-                int log_cnt = 0;
-                if (mine && lane < limit) {
-                    const int64_t sub = c * 64 + q;
-                    const int64_t abs = sub * kSub + rel;
-                    uint32_t* bw = &s_arena[aoff];                   // (len + 3) / 4 dwords of bytes, then the merge state
-#ifdef TKZ_ML_LANE32
-                    if (lane32) {
-                        uint32_t w8[8];
-                        tkz_load_piece16(P.bytes, P.total, abs, w8);
-                        tkz_load_piece16(P.bytes, P.total, abs + 16, w8 + 4);
-                        uint32_t alive32 = 0;
-                        int e1 = 0;
-                        uint32_t* ids32 = bw; uint32_t* pr32 = bw + 32;
-                        const int cnt = tkz_bpe_lane_f<32>(T, w8, len, ids32, pr32, [&](uint32_t b) -> uint32_t { return (uint32_t)s_brank[b]; },
-                                                           [&](uint32_t b0, uint32_t b1) -> int32_t { return T.bytepair_rank[(b0 << 8) | b1]; }, &alive32, &e1);
-                        err |= e1;
-                        int32_t* tk = P.tmp + abs;
-                        { int i = 0; for (uint32_t a = alive32; a; a &= a - 1) tk[i++] = (int32_t)ids32[tkz_ctz32(a)]; }
-                        if (cnt <= 4) {
-                            uint4 tq; tq.x = (uint32_t)tk[0]; tq.y = cnt > 1 ? (uint32_t)tk[1] : 0u; tq.z = cnt > 2 ? (uint32_t)tk[2] : 0u; tq.w = cnt > 3 ? (uint32_t)tk[3] : 0u;
-                            P.mquad[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tq;
-                            P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_inline(cnt);
-                        } else P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_entry(false, cnt, rel);
-                        if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
-                    } else
-#endif
-                    {
-                        const int64_t a0 = abs & ~(int64_t)3;
-                        const uint32_t sh = (uint32_t)(abs & 3) * 8u;
-                        uint32_t prev = 0;
-                        if (a0 + 4 <= P.total) prev = *reinterpret_cast<const uint32_t*>(P.bytes + a0);
-                        else for (int b = 0; b < 4; ++b) if (a0 + b < P.total) prev |= (uint32_t)P.bytes[a0 + b] << (8 * b);
-                        for (int w = 0; w < nbw; ++w) {
-                            const int64_t p = a0 + 4 * (w + 1);
-                            uint32_t nx = 0;
-                            if (p + 4 <= P.total) nx = *reinterpret_cast<const uint32_t*>(P.bytes + p);
-                            else for (int b = 0; b < 4; ++b) if (p + b < P.total) nx |= (uint32_t)P.bytes[p + b] << (8 * b);
-                            bw[w] = simt::alignbit(nx, prev, sh);
-                            prev = nx;
-                        }
-                    const uint8_t* pbytes = reinterpret_cast<const uint8_t*>(bw);
-                    uint32_t* st = bw + ((nbw + 3) & ~3);             // (the state arrays are read 16 bytes at a time)
-                    auto at = [&](int i) -> uint32_t { return pbytes[i]; };
-                    int e1 = 0, cnt;
-                    if constexpr (COMPACT) {
-                        if (small) { uint64_t alive; cnt = tkz_bpe_lane_varc64(T, at, len, st, &e1, s_brank, &alive); tkz_bpe_varc64_emit(at, st, alive, len, s_brank, P.tmp + abs); }
-                        else { cnt = tkz_bpe_lane_varc(T, at, len, st, &e1, s_brank); tkz_bpe_varc_emit(at, st, len, s_brank, P.tmp + abs); }
-                    } else {
-                        cnt = T.max_rank <= kVarPackedMaxRank ? tkz_bpe_lane_var<true>(T, at, len, st, &e1, s_brank) : tkz_bpe_lane_var<false>(T, at, len, st, &e1, s_brank);
-                        tkz_bpe_var_emit(st, len, P.tmp + abs);
-                    }
-                    err |= e1;
-                    // (the tokens are in tmp at the piece's position; up to four also go into the entry's quad, where k_place finds them
-                    //  in the round trip that fetches the answers)
-                    if (cnt <= 4) {
-                        const int32_t* tk = P.tmp + abs;
-                        uint4 tq; tq.x = (uint32_t)tk[0]; tq.y = cnt > 1 ? (uint32_t)tk[1] : 0u; tq.z = cnt > 2 ? (uint32_t)tk[2] : 0u; tq.w = cnt > 3 ? (uint32_t)tk[3] : 0u;
-                        P.mquad[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tq;
-                        P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_inline(cnt);
-                        if (P.long_log && len <= kLongLogMaxLen && !e1 && (!P.long_log_sparse || (c & 7) == 0)) { log_it = true; log_tok = tq; log_cnt = cnt; }
-                    } else P.mlist[sub * (int64_t)P.mcap + (P.mcap - 1 - j)] = tkz_result_entry(false, cnt, rel);
-                    if (cnt > 1) simt::atomic_add(&P.tile_count[sub], cnt - 1);
-                    }
-                }
-                if (P.long_log) {                                // (wave-uniform; a learning batch only) one atomic for the wavefront's records
-                    int ltot;
-                    const int lpre = tkz_wave_scan_sum(log_it ? 1 : 0, &ltot);
-                    unsigned long long lbase = 0;
-                    if (lane == 0 && ltot) lbase = simt::atomic_add64(P.long_log_count, (unsigned long long)ltot);
-                    lbase = ((unsigned long long)simt::shflu((uint32_t)(lbase >> 32), 0) << 32) | simt::shflu((uint32_t)lbase, 0);
-                    if (log_it && lbase + (unsigned long long)lpre < (unsigned long long)P.long_log_cap) {
-                        uint32_t* rec = P.long_log + (lbase + (unsigned long long)lpre) * kLongLogDwords;
-                        const uint32_t* bw = &s_arena[aoff];            // the piece's bytes, still in the arena
-                        for (int w = 0; w < 7; ++w) {
-                            const int nbz = len - 4 * w;
-                            rec[w] = nbz <= 0 ? 0u : (nbz >= 4 ? bw[w] : (bw[w] & ((1u << (8 * nbz)) - 1u)));
-                        }
-                        rec[7] = (uint32_t)len | ((uint32_t)log_cnt << 8);
-                        rec[8] = log_tok.x; rec[9] = log_tok.y; rec[10] = log_tok.z; rec[11] = log_tok.w;
-                    }
-                }
+                const int64_t sub = c * 64 + q;
+                const int limit = tkz_long_batch<COMPACT>(T, P, LD, valid, sub, j, rel, len, lane_piece, err, PF, [](int) {});
                 (void)simt::ballot(true);
                 done += limit < nseg - done ? limit : nseg - done;
             }
         }
     }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
+    tkz_long_prof_end(P, PF);
 }
 // (a kernel of its own per form so that the general forms' registers stay out of the compact one)
 // (LATENCY: a small batch -- TKZ_OPT_LATENCY_BYTES --, where the call waits for the slowest wavefront: a unit of work is 4 sub-tiles whatever their lists hold
@@ -1505,6 +1619,137 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long(TkzTables T, EncodeParams P) {
     tkz_long_brank_init(T, LD.brank);
     if (LATENCY) tkz_merge_long_chunks<COMPACT, kLongPartsLatency, -1>(T, P, simt::bid(), simt::nblocks(), LD, P.lane_piece);
     else tkz_merge_long_chunks<COMPACT>(T, P, simt::bid(), simt::nblocks(), LD, P.lane_piece);
+}
+
+// ---- The long misses of a LARGE batch, binned by length class ACROSS the batch (round 6) ----------------------------------------------------------
+// The chunk form above forms its batches inside one unit of work (a chunk of 64 sub-tiles or a quarter of it): on mixed text that is ~290 entries cut
+// by length class into seven batches of 41 lanes on average (the development counters: lanes/batch 40.7 of 64), and a file of CJK prose in real text is
+// a few chunks that keep their wavefronts for milliseconds.  Here the entries of the WHOLE batch are binned first:
+//   k_long_count    per chunk of 64 sub-tiles, the number of its long misses in each of the 16 length classes -> lq_cnt[class * nchunks + chunk]
+//   (scan)          exclusive scan of lq_cnt in that order = class-major: all entries of class 0, chunk after chunk, then class 1, ...
+//   k_long_scatter  every entry to its place in the queue:  lq[] = sub-tile << 30 | index in its long list << 20 | (len - 1) << 10 | byte in the sub-tile
+//   k_merge_long_q  a wavefront takes RANGES of kLqRange queue entries (kLqRangeLong beyond kFastPiece bytes) -- the longest classes first -- and merges them (tkz_long_batch):
+//                   full batches of ONE length class, whichever chunks the pieces come from; the work is dealt out 256 pieces at a time, not by chunk.
+// No atomics on shared counters (the two passes over the lists cost ~0.1 ms a GB of mixed text); a small batch (TKZ_OPT_LATENCY_BYTES) and the
+// single-launch kernel keep the chunk form: three more launches are 15 us.
+constexpr int kLqRange = 256, kLqRangeLong = 16;
+#ifndef TKZ_QARENA_DWORDS
+#define TKZ_QARENA_DWORDS 2304
+#endif
+constexpr int kQArenaDwords = TKZ_QARENA_DWORDS;   // the arena of k_merge_long_q
+static_assert(kQArenaDwords % 4 == 0 && kQArenaDwords >= (kLanePiece + 3) / 4 + 8 + 2 * kLanePiece + 16, "a piece of kLanePiece bytes fits the arena in every form");
+#ifdef TKZ_HOSTEMU
+constexpr int kLongQGrid = 8;           // (the CPU emulator pays for every idle workgroup)
+#else
+constexpr int kLongQGrid = 8192;        // wavefronts of k_merge_long_q (13 fit a CU: 3,328 run at once; the ranges beyond are taken round-robin)
+#endif
+// the entries of chunk c's long lists that a lane merges (<= lane_piece bytes), lane = sub-tile: f(list index j, entry)
+template <class F>
+TKZ_DEV void tkz_long_walk(const EncodeParams& P, int64_t c, int lane_piece, F f) {
+    const int64_t t = c * 64 + simt::lane();
+    int nl = 0;
+    if (t < P.nsub) {
+        const uint32_t mc = P.mcount[t];
+        nl = (int)(mc >> 16);
+        if ((int)(mc & 0xFFFFu) + nl > P.mcap) nl = 0;                         // (cut list: reported by k_list_stats, the batch is redone)
+    }
+    // (four entries a step, their loads requested together: a list is read from its end down, one entry a round trip otherwise)
+    const uint32_t* top = &P.mlist[t * (int64_t)P.mcap + (P.mcap - 1)];
+    for (int j = 0; j < nl; j += 4) {
+        uint32_t ent[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ent[k] = j + k < nl ? tkz_load_nt(top - (j + k)) : 0xFFFFFFFFu;        // (0xFFFFFFFF: 1024 bytes, no lane's piece)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (j + k < nl && (int)((ent[k] >> kMrLenShift) & 1023u) + 1 <= lane_piece) f(t, j + k, ent[k]);
+    }
+}
+TKZ_KERNEL(256) void k_long_count(EncodeParams P) {
+    if (tkz_attempt_failed(P)) return;
+    TKZ_SHARED int s_hist[4][kLenClasses];
+    const int lane = simt::lane(), wave = simt::wave();
+    const int64_t nchunks = (P.nsub + 63) / 64;
+    for (int64_t c = simt::bid() * 4 + wave; c < nchunks; c += simt::nblocks() * 4) {
+        if (lane < kLenClasses) s_hist[wave][lane] = 0;
+        (void)simt::ballot(true);
+        tkz_long_walk(P, c, P.lane_piece, [&](int64_t, int, uint32_t ent) { simt::atomic_add(&s_hist[wave][tkz_len_class((int)((ent >> kMrLenShift) & 1023u) + 1)], 1); });
+        (void)simt::ballot(true);
+        if (lane < kLenClasses) P.lq_cnt[(int64_t)lane * nchunks + c] = s_hist[wave][lane];
+        (void)simt::ballot(true);
+    }
+}
+TKZ_KERNEL(256) void k_long_scatter(EncodeParams P) {
+    if (tkz_attempt_failed(P)) return;
+    TKZ_SHARED int s_hist[4][kLenClasses];
+    const int lane = simt::lane(), wave = simt::wave();
+    const int64_t nchunks = (P.nsub + 63) / 64;
+    for (int64_t c = simt::bid() * 4 + wave; c < nchunks; c += simt::nblocks() * 4) {
+        if (lane < kLenClasses) s_hist[wave][lane] = 0;
+        (void)simt::ballot(true);
+        // the giant piece of a sub-tile (its last piece): merged by k_giant_merge before this kernel, its token count joins the sub-tile's here
+        { const int64_t t = c * 64 + lane; if (t < P.nsub && (P.heavy_flag[t] & 2u)) { const int g = P.giant_cnt[t]; if (g > 1) simt::atomic_add(&P.tile_count[t], g - 1); } }   // (< 0: no pool, the call is retried)
+        tkz_long_walk(P, c, P.lane_piece, [&](int64_t t, int j, uint32_t ent) {
+            const int cl = tkz_len_class((int)((ent >> kMrLenShift) & 1023u) + 1);
+            const int64_t at = P.lq_base[(int64_t)cl * nchunks + c] + simt::atomic_add(&s_hist[wave][cl], 1);
+            if (at < P.lq_cap) P.lq[at] = ((uint64_t)t << 30) | ((uint64_t)j << 20) | (uint64_t)(ent & 0xFFFFFu);      // (ent: relpos | (len - 1) << 10)
+        });
+        (void)simt::ballot(true);
+    }
+}
+template <bool COMPACT>
+TKZ_KERNEL_OCC(64, 4) void k_merge_long_q(TkzTables T, EncodeParams P) {
+    if (tkz_attempt_failed(P)) return;
+    // LDS: the arena and the byte ids, 10 KB together -- sixteen wavefronts a CU (the chunk form's 12.4 KB: thirteen) --; 2,304 dwords are 64 spans of the
+    // nine quads a piece of up to 28 bytes takes (52 of the eleven of 29..32 bytes)
+    TKZ_SHARED uint4 s_lds[(kQArenaDwords + 256) / 4];
+    LongLds LD;
+    LD.arena = reinterpret_cast<uint32_t*>(s_lds); LD.arena_dwords = kQArenaDwords; LD.brank = reinterpret_cast<int32_t*>(s_lds) + kQArenaDwords;
+    LD.pre = nullptr; LD.cls = nullptr; LD.ord = nullptr;
+    tkz_long_brank_init(T, LD.brank);
+    const int lane = simt::lane();
+    int err = 0;
+    LongProf PF;
+    tkz_long_prof_begin(P, PF);
+    const int64_t total = *P.lq_total < P.lq_cap ? *P.lq_total : P.lq_cap;
+    // Ranges: kLqRange entries of the classes the fast batches take (up to kFastPiece bytes: four or five batches of one class), kLqRangeLong of the longer
+    // ones (a lane takes ~n^2 steps for those and a batch holds ~15 of them: in ranges of 256 real text's 100..128-byte pieces kept a few wavefronts for
+    // 3.5 ms).  From the END of the queue -- the longest classes first --, so that what runs last is short.
+    const int64_t nchunks = (P.nsub + 63) / 64;
+    int64_t nfast = P.lq_base[(int64_t)tkz_len_class(kFastPiece + 1) * nchunks];
+    if (nfast > total) nfast = total;
+    const int64_t nrf = (nfast + kLqRange - 1) / kLqRange, nrl = (total - nfast + kLqRangeLong - 1) / kLqRangeLong;
+    auto range_of = [&](int64_t r, int64_t* lo, int64_t* hi) {
+        if (r >= nrf) { *lo = nfast + (r - nrf) * kLqRangeLong; *hi = *lo + kLqRangeLong < total ? *lo + kLqRangeLong : total; }
+        else { *lo = r * kLqRange; *hi = *lo + kLqRange < nfast ? *lo + kLqRange : nfast; }
+    };
+    auto entry_of = [&](int64_t pos, int64_t hi) -> uint64_t { return pos < hi ? P.lq[pos] : 0ull; };
+    int64_t rg = nrf + nrl - 1 - simt::bid();
+    int64_t lo = 0, hi = 0;
+    if (rg >= 0) range_of(rg, &lo, &hi);
+    uint64_t ent = rg >= 0 ? entry_of(lo + lane, hi) : 0ull;        // this batch's entry; the next batch's is requested as soon as this one's size is known
+    while (rg >= 0) {
+#ifdef TKZ_DEVPROF
+        if (PF.on) { ++PF.units; PF.t0 = simt::clock(); }
+#endif
+        int64_t nlo = 0, nhi = 0;
+        const int64_t nrg = rg - simt::nblocks();
+        if (nrg >= 0) range_of(nrg, &nlo, &nhi);
+        for (int64_t at = lo; at < hi;) {
+            const bool valid = at + lane < hi;
+            const int64_t sub = valid ? (int64_t)(ent >> 30) : 0;
+            const int j = valid ? (int)((ent >> 20) & 1023u) : 0, len = valid ? (int)((ent >> 10) & 1023u) + 1 : 1, rel = valid ? (int)(ent & 1023u) : 0;
+            uint64_t ent_next = 0;
+            TKZ_PF_MARK(0);
+            const int limit = tkz_long_batch<COMPACT>(T, P, LD, valid, sub, j, rel, len, P.lane_piece, err, PF, [&](int n) {
+                const int64_t nx = at + n;                                  // the next batch: the rest of this range, else the wavefront's next range
+                ent_next = nx < hi ? entry_of(nx + lane, hi) : (nrg >= 0 ? entry_of(nlo + lane, nhi) : 0ull);
+            });
+            at += limit;
+            ent = ent_next;
+        }
+        rg = nrg; lo = nlo; hi = nhi;
+    }
+    if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
+    tkz_long_prof_end(P, PF);
 }
 
 // The missed pieces of kLanePiece + 1 .. kArenaPiece bytes: ONE WAVEFRONT per piece, with the giant pieces' merger (tkz_bpe_long_tail: batches of proposals with
@@ -2797,15 +3042,20 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
 #endif
     TKZ_LAUNCH(k_giant_order, 1, 1024, L.stream, P);
     TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // takes pieces off the ordered queue; exits at once when it is empty
-    {   // strides over 64-sub-tile chunks
-        const bool latency = P.latency != 0;
-        const int64_t chunks = cdiv(nsub, 64) * (latency ? kLongPartsLatency : kLongParts), grid = chunks < 65536 ? chunks : 65536;      // (units of work: see kLongParts)
-        if (latency) {
+    {
+        const bool latency = P.latency != 0 || !P.lq;
+        if (latency) {      // the chunk form: strides over units of 4 sub-tiles
+            const int64_t chunks = cdiv(nsub, 64) * kLongPartsLatency, grid = chunks < 65536 ? chunks : 65536;
             if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long<true, true>), grid, 64, L.stream, T, P);
             else TKZ_LAUNCH((k_merge_long<false, true>), grid, 64, L.stream, T, P);
-        } else {
-            if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long<true, false>), grid, 64, L.stream, T, P);
-            else TKZ_LAUNCH((k_merge_long<false, false>), grid, 64, L.stream, T, P);
+        } else {            // the queue form: the batch's long misses binned by length class, then merged off the queue 256 at a time
+            const int64_t nchunks = cdiv(nsub, 64), g4 = cdiv(nchunks, 4);
+            TKZ_LAUNCH(k_long_count, g4 < 4096 ? g4 : 4096, kThreads, L.stream, P);
+            launch_scan2(L, nchunks * kLenClasses, P.lq_bsum, P.lq_cnt, P.lq_base, P.lq_total, 1, nullptr, nullptr, nullptr, 1, -1);
+            TKZ_LAUNCH(k_long_scatter, g4 < 4096 ? g4 : 4096, kThreads, L.stream, P);
+            const int64_t ranges = cdiv(P.lq_cap, kLqRangeLong), grid = ranges < kLongQGrid ? (ranges < 1 ? 1 : ranges) : kLongQGrid;
+            if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long_q<true>), grid, 64, L.stream, T, P);
+            else TKZ_LAUNCH((k_merge_long_q<false>), grid, 64, L.stream, T, P);
         }
         // the pieces k_merge_long leaves to a whole wavefront, off the queue k_list_stats filled (every wavefront exits at once when it is empty).  A small batch
         // gets as many wavefronts as a large one: 16 of them took 107 us over the queue of a 1 MB call
