@@ -50,6 +50,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
+VALU_PEAK_TPS = 256 * 4 * 2.4e9 / 4 / 1e12      # wave64 VALU instructions a second, in T/s: 256 CUs x 4 SIMDs, one instruction per 4 cycles at 2.4 GHz
 VOCAB_OF_PATTERN = {1: ("gpt2", None), 2: ("synth100k", "cl100k_base"), 3: ("synth200k", "o200k_base"), 4: ("synth200k", "o200k_base")}
 PATTERN_NAME = {1: "pattern 1 (gpt2 / r50k / p50k)", 2: "cl100k_base", 3: "o200k_base (ECMAScript reading: the TypeScript reference's engine)",
                 4: "o200k_base (.NET reading: the string through the C# reference's Regex)"}
@@ -633,6 +634,18 @@ def main():
                        "value_warm_memo": round(r_total / t_warm / 1e6, 1), "promoted_pieces_warm": r_promoted, "value_no_memo": round(r_total / t_off / 1e6, 1),
                        "tokens": r_ntok, "bytes_per_token": round(r_total / max(1, r_ntok), 3), "piece_stats": r_stats,
                        "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in r_kms.items()}, "parity": "unchecked"}
+                # the same roofline arithmetic as the headline's, on the first-pass step; counted traffic from profiles/traffic_real_latest.json
+                # when it was collected on these kernel sources and this very text
+                r_alg = r_total + 4 * int(r_ntok) + 16 * r_nd
+                r_traffic, r_tnote = None, "no PMC summary of this text for this build"
+                try:
+                    tjr = json.load(open(os.path.join(ROOT, "profiles", "traffic_real_latest.json")))
+                    if tjr.get("src_sha") == kernel_sources_sha() and tjr.get("corpus_sha256") == r_meta.get("sha256") and tjr.get("vocab_pattern") == "%s/pattern%d" % (vname or "", pat):
+                        r_traffic, r_tnote = int(sum(v["hbm_bytes_per_launch"] for v in tjr["by_kernel"].values())), "rocprofv3 PMC passes of this build on this text (profiles/traffic_real_latest.json)"
+                except Exception:
+                    pass
+                ent["roofline"] = {"bound": "hbm", "achieved": round(r_alg / t_first / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(r_alg / t_first / 1e9 / HBM_PEAK_GBPS, 5),
+                                   "algorithmic_bytes_per_launch": r_alg, "traffic_pipeline": r_traffic, "wasted": round(r_traffic / r_alg, 3) if r_traffic else None, "traffic_note": r_tnote}
                 if not args.no_cpu_baseline:
                     from oracle import oracle as O
                     tm = {}
@@ -642,6 +655,49 @@ def main():
                                     "MISMATCH vs oracle: %d of %d docs differ, first %d" % (bad, r_nd, first_bad)
                     ent["cpu_oracle_all_threads_mbps"] = round(r_total / tm["seconds"] / 1e6, 1)
                 real_leg["by_vocab"]["%s/pattern%d" % (vname or VOCAB_OF_PATTERN[pat][0], pat)] = ent
+                # ---- DRIFT (round 6, TKZ_OPT_ADAPT): ONE encoder whose text changes under it.  An encoder that has learnt the headline's synthetic text
+                #      meets the real text (and the reverse): GB/s of every step after the change, against an encoder that only ever saw the second text,
+                #      both on repeated passes with memo and promotions left as they come (`value_warm_memo`'s conditions).  gpt2 / pattern 1 only.
+                if vname == "gpt2" and pat == 1 and not args.no_cpu_baseline and seed is not None:
+                    try:
+                        def rate_steps(e2, fn, nbytes, nsteps):
+                            out = []
+                            for _ in range(nsteps):
+                                device_sync(); t0 = time.perf_counter(); fn(e2); device_sync()
+                                out.append(round(nbytes / (time.perf_counter() - t0) / 1e6, 1))
+                            return out
+                        sl_docs = min(n_docs, 2_000_000)                                   # a ~1 GB slice of the headline corpus: a step of the synthetic side
+                        sl_total = int(d_offs[sl_docs].item())
+
+                        def syn(e2):
+                            return e2.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), sl_docs, sl_total, d_ids.data_ptr(), sl_total, d_ooffs.data_ptr(), stream)
+
+                        def real(e2):
+                            return e2.encode_batch_device(rd_bytes.data_ptr(), rd_offs.data_ptr(), r_nd, r_total, rd_ids.data_ptr(), r_total, rd_ooffs.data_ptr(), stream)
+                        drift = {"unit": "MB/s per step", "synthetic_step_bytes": sl_total, "real_step_bytes": r_total}
+                        for name, first, first_b, second, second_b in (("synthetic_then_real", syn, sl_total, real, r_total), ("real_then_synthetic", real, r_total, syn, sl_total)):
+                            e_d = N.Encoder(N.Vocab(raw_v), pat, device=local_rank)        # default options: promotions automatic, TKZ_OPT_ADAPT on
+                            for _ in range(max(3, int((3 << 30) // max(1, first_b)))):
+                                first(e_d)                                                 # ~3 GB of the first text: learnt, promoted, settled
+                            before = e_d.adapt_stats()
+                            n2 = max(4, int((3 << 30) // max(1, second_b)))
+                            series = rate_steps(e_d, second, second_b, n2)
+                            after = e_d.adapt_stats()
+                            e_f = N.Encoder(N.Vocab(raw_v), pat, device=local_rank)        # ... and one that only ever sees the second text
+                            fresh = rate_steps(e_f, second, second_b, n2)
+                            k2gb = min(n2, max(1, int((2 << 30) // max(1, second_b))))     # steps within 2 GB of the change
+                            tail_d, tail_f = series[k2gb:] or series[-1:], fresh[k2gb:] or fresh[-1:]
+                            drift[name] = {"mbps_by_step_after_the_change": series, "mbps_by_step_fresh_encoder": fresh,
+                                           "first_call_ms": first_call.get("first_call_ms") if first_call else None,
+            "first_call": first_call,
+            "value_after_drift": round(sum(tail_d) / len(tail_d), 1), "value_fresh": round(sum(tail_f) / len(tail_f), 1),
+                                           "ratio": round((sum(tail_d) / len(tail_d)) / (sum(tail_f) / len(tail_f)), 3), "steps_within_2GB": k2gb,
+                                           "relearns": after["relearns"] - before["relearns"], "promoted_before": before["promoted_pieces"], "promoted_after": after["promoted_pieces"],
+                                           "miss_share_settled_before": before["settled_miss_share"], "miss_share_recent_after": after["recent_miss_share"]}
+                            del e_d, e_f
+                        real_leg["drift"] = drift
+                    except Exception as ex:
+                        real_leg["drift"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
                 del en
             del rd_bytes, rd_offs, rd_ids, rd_ooffs, r_bytes, r_offs
             if not emu:
@@ -649,6 +705,33 @@ def main():
         except Exception as ex:                                      # an auxiliary figure must never cost the bench line
             real_leg = {"error": "%s: %s" % (type(ex).__name__, ex)}
         ntok = step()                                                # (the output buffers hold the headline batch's result again)
+        fence()
+    # ---- `first_call`: what a job that encodes ONE batch pays.  A FRESH encoder, its workspace reserved at construction (tkz_encoder_reserve: the
+    # reference pays construction costs in CreateTokenizer, TokenizerBuilder.cs:210-213), then the bench batch ONCE, timed, with nothing untimed before
+    # it: empty memo, nothing promoted, cold tables, the sizing attempt and the learning window's counting inside the call.  `value` never includes it.
+    first_call = None
+    if world == 1 and not args.parity_only and not args.no_memo:
+        try:
+            e_fc = N.Encoder(vocab, args.pattern, device=local_rank)
+            device_sync(); t0 = time.perf_counter()
+            e_fc.reserve(total, n_docs)
+            device_sync(); t_res = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            nt_fc = e_fc.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total, d_ooffs.data_ptr(), stream)
+            device_sync(); t_first_call = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            e_fc.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total, d_ooffs.data_ptr(), stream)
+            device_sync(); t_second = time.perf_counter() - t0
+            first_call = {"first_call_ms": round(t_first_call * 1e3, 3), "second_call_ms": round(t_second * 1e3, 3), "reserve_ms": round(t_res * 1e3, 1),
+                          "workspace_bytes": int(e_fc.workspace_bytes), "tokens": int(nt_fc),
+                          "note": "a fresh encoder: tkz_encoder_reserve(batch size) at construction (reserve_ms: its hipMallocs), then the bench batch once -- empty memo, nothing "
+                                  "promoted, sizing attempt and learning window inside the call -- and once more"}
+            del e_fc
+            if not emu:
+                torch.cuda.empty_cache()
+        except Exception as ex:
+            first_call = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        ntok = step()
         fence()
     if warm is not None:
         del warm, w_bytes, w_offs, w_ids
@@ -784,6 +867,7 @@ def main():
         alg_bytes = int(g["table"][kms_rank][1]) + 4 * int(g["table"][kms_rank][2]) + 16 * int(g["table"][kms_rank][0])
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         traffic, traffic_pipeline, traffic_by_kernel, traffic_note = None, None, None, "no PMC summary for this build"
+        issue = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
@@ -796,6 +880,17 @@ def main():
                     traffic, traffic_note = tj["by_kernel"][dom]["hbm_bytes_per_launch"], "rocprofv3 PMC passes of this build (profiles/traffic_latest.json)"
                     traffic_by_kernel = {k: v["hbm_bytes_per_launch"] for k, v in tj["by_kernel"].items()}
                     traffic_pipeline = int(sum(traffic_by_kernel.values()))
+                    # the binding limit in the record, not only in prose: the dominant kernel's VALU wave-instructions of the same PMC passes against the chip's
+                    # issue rate (256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz = 0.614 T/s), and the lanes they had switched on
+                    iss = tj["by_kernel"][dom].get("issue")
+                    if iss and iss.get("valu_insts"):
+                        rate = iss["valu_insts"] / (dom_ms * 1e-3) / 1e12
+                        issue = {"kernel": dom, "valu_per_kib": round(iss["valu_insts"] / (int(g["table"][kms_rank][1]) / 1024.0), 1), "valu_rate_tps": round(rate, 3),
+                                 "frac_of_valu_peak": round(rate / VALU_PEAK_TPS, 3), "lanes_active": iss.get("lanes_active"), "peak_tps": VALU_PEAK_TPS,
+                                 "salu_per_kib": round(iss["salu_insts"] / (int(g["table"][kms_rank][1]) / 1024.0), 1) if iss.get("salu_insts") else None,
+                                 "by_kernel": {k: v.get("issue") for k, v in tj["by_kernel"].items() if v.get("issue")},
+                                 "note": "SQ_INSTS_VALU / SQ_INSTS_SALU / SQ_THREAD_CYCLES_VALU of the rocprofv3 PMC passes of this build (profiles/traffic_latest.json), "
+                                         "per launch; rate = instructions / this run's launch duration"}
             except Exception:
                 traffic = None
         leftovers = enc.pretok_leftovers() if hasattr(enc, "pretok_leftovers") else (0, 0)
@@ -808,6 +903,7 @@ def main():
                     "achieved_dominant": round(achieved, 2), "frac_dominant": round(achieved / HBM_PEAK_GBPS, 5),
                     "traffic": traffic, "traffic_pipeline": traffic_pipeline,
                     "wasted": round(traffic_pipeline / alg_bytes, 3) if traffic_pipeline else None, "traffic_by_kernel": traffic_by_kernel, "traffic_note": traffic_note,
+                    "issue": issue,
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4), "rank": kms_rank,
                     "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kms.items()},
                     "note": "achieved = algorithmic bytes (SURVEY.md 8d: text + 4 B per id + 16 B per document) / the step's time; *_dominant = the same bytes / "
@@ -976,8 +1072,10 @@ def main():
                             u["same_ids_as_device_path"] = bool(u.get("tokens") == len(want) and u.get("ids_checksum") == "%016x" % wsum)
                             u["unit"] = "MB/s of UTF-8 text (the input is twice that in UTF-16 code units)"
                             u["note"] = ("tkz::TikTokenizer::EncodeBatchFlatUtf16 on the same documents as std::u16strings: threaded gather of the code units into page-locked memory + ONE "
-                                         "tkz_encode_batch_utf16 (chunked upload, Encoding.UTF8.GetBytes on the device); value_as_the_csharp_class_calls: the calls "
-                                         "bindings/csharp/GpuTikTokenizer.EncodeBatchFlat makes, as it makes them -- one thread copies the strings into a pageable array, a fresh id array per call")
+                                         "tkz_encode_batch_utf16 (chunked upload, Encoding.UTF8.GetBytes on the device); value_as_csharp: the call sequence of "
+                                         "bindings/csharp/GpuTikTokenizer.EncodeBatchFlat replayed in C++ (tests/cpp/bench_host_api.cpp) -- sub-batches of 64 M code units, two pooled "
+                                         "page-locked buffer sets, the gather of sub-batch k + 1 on all cores beside the device call of sub-batch k, the id buffer sized by the densest "
+                                         "batch seen, ids copied into arrays of exactly their number and joined; the C# file itself cannot be compiled here")
                         host_api["note"] = ("tkz::TikTokenizer::EncodeBatchFlat on %d std::strings (include/tkz_tokenizer.hpp): threaded gather into page-locked memory + "
                                             "tkz_encode_batch_utf8 + ids left in page-locked memory; the best of %d calls" % (nh, host_api.get("reps", 0)))
                 except Exception as ex:
@@ -1004,7 +1102,7 @@ def main():
             "data": ("EMULATED: the kernels ran on the CPU emulator of tests/hostemu (a test of this script, not a measurement)" if emu else
                      "real text of the box (not tiled)" if args.kind == 6 else "synthetic"),
             "config": {"workload": workloads[args.kind] % (n_docs, args.min_len, args.max_len, job_bytes / max(1, job_docs)),
-                       "pattern": PATTERN_NAME[args.pattern],
+                       "pattern": PATTERN_NAME[args.pattern], "vocab_pattern_key": "%s/pattern%d" % (args.vocab or VOCAB_OF_PATTERN[args.pattern][0], args.pattern),
                        "piece_memo": memo_note,
                        "promoted_pieces": promoted_note,
                        "vocab": vocab_name, "vocab_keys": len(vocab), "vocab_sha256": hashlib.sha256(raw).hexdigest(), "docs_per_gpu": n_docs, "bytes_per_gpu": total, "tokens_per_gpu": n_tokens_rank,
@@ -1016,6 +1114,8 @@ def main():
             "value_no_memo": round(job_bytes * nm_steps / dt_nomemo / 1e6, 1) if dt_nomemo else None,
             "value_warm_memo": round(job_bytes / dt_warm * args.steps / 1e6, 1) if dt_warm else None,
             "value_real_text": (real_leg.get("by_vocab", {}).get("gpt2/pattern1", {}).get("value") if real_leg else None),
+            "value_after_drift": ((real_leg.get("drift") or {}).get("synthetic_then_real", {}).get("value_after_drift") if real_leg else None),
+            "real_text_roofline": (real_leg.get("by_vocab", {}).get("gpt2/pattern1", {}).get("roofline") if real_leg else None),
             "real_text": real_leg,
             "value_heldout_vocab": heldout["value"] if heldout and "value" in heldout else None,
             "heldout_vocab": heldout,
@@ -1028,6 +1128,7 @@ def main():
             "pcie_inclusive": host_path,
             "value_host_api": host_api["value"] if host_api and "value" in host_api else None,
             "value_host_api_utf16": (host_api.get("utf16") or {}).get("value") if host_api else None,
+            "value_host_api_utf16_as_csharp": (host_api.get("utf16") or {}).get("value_as_csharp") if host_api else None,
             "host_api": host_api,
         }
         if real_meta:

@@ -35,6 +35,7 @@ namespace Microsoft.DeepDev
         [DllImport(Lib)] internal static extern int tkz_pattern_from_regex(byte[] regexUtf8Z, out int pattern);   // .NET semantics (TikTokenizer.cs:77): the o200k string gives TKZ_PATTERN_O200K_DOTNET
         [DllImport(Lib)] internal static extern int tkz_encoder_create(IntPtr vocab, int pattern, int device, out IntPtr encoder);
         [DllImport(Lib)] internal static extern int tkz_encoder_set_option(IntPtr encoder, int option, long value);
+        [DllImport(Lib)] internal static extern int tkz_encoder_reserve(IntPtr encoder, long maxBytes, long maxDocs);   // the workspace of batches up to that size, allocated now (TokenizerBuilder.cs:210-213: construction pays, not the first Encode)
         [DllImport(Lib)] internal static extern int tkz_encoder_set_unicode_classes(IntPtr encoder, byte[] classes, long nCodePoints);   // the HOST's Unicode classification (TikTokenizer.cs:77: the running process's regex engine defines the split)
         [DllImport(Lib)] internal static extern int tkz_host_alloc(UIntPtr bytes, out IntPtr p);        // page-locked memory: copies to and from it run at the PCIe rate
         [DllImport(Lib)] internal static extern void tkz_host_free(IntPtr p);
@@ -140,7 +141,10 @@ namespace Microsoft.DeepDev
         private readonly Regex specialTokensRegex;
 
         /// <summary>Same arguments as TokenizerBuilder.CreateTokenizer (TokenizerBuilder.cs:210-213) plus the HIP device index.</summary>
-        public GpuTikTokenizer(Stream tikTokenBpeFileStream, IReadOnlyDictionary<string, int> specialTokensEncoder, string pattern, int cacheSize = 8192, int device = 0)
+        /// <param name="reserveBytes">when &gt; 0: the device workspace of batches of up to this many UTF-8 bytes (in up to reserveDocs texts) is allocated here,
+        /// by the constructor, instead of inside the first EncodeBatch (tkz_encoder_reserve: ~7.8 device bytes per byte of text)</param>
+        public GpuTikTokenizer(Stream tikTokenBpeFileStream, IReadOnlyDictionary<string, int> specialTokensEncoder, string pattern, int cacheSize = 8192, int device = 0,
+                               long reserveBytes = 0, long reserveDocs = 0)
         {
             byte[] file;
             using (var ms = new MemoryStream()) { tikTokenBpeFileStream.CopyTo(ms); file = ms.ToArray(); }
@@ -159,6 +163,7 @@ namespace Microsoft.DeepDev
             // the LRU piece memo (LRUCache.cs; no effect on results) lives on the device with a fixed size: cacheSize says whether it is used
             if (cacheSize <= 0) Tkz.Check(Tkz.tkz_encoder_set_option(handle.DangerousGetHandle(), 2 /* TKZ_OPT_PIECE_MEMO */, 0));
             UseThisRuntimesRegexSemantics();
+            if (reserveBytes > 0) Tkz.Check(Tkz.tkz_encoder_reserve(encoder, reserveBytes, Math.Max(1, reserveDocs)));
         }
 
         /// <summary>The reference's split is `new Regex(pattern, RegexOptions.Compiled)` of the RUNNING process (TikTokenizer.cs:77): \p{L}, \p{N} ... are the

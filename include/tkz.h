@@ -286,8 +286,9 @@ enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1,
         * a piece is then found by the lookup every piece goes through anyway (TikTokenizer.cs:262 -- with its <= 4 tokens in place of a rank) instead of
         * being listed, looked up in the memo and answered again in every batch.  Same ids by construction.  Value 1 (default): automatic -- the first
         * batch of at least 8 MB on the batch path counts the memo's hits per slot and the hottest entries (at most 65,536) are promoted when it ends (the
-        * memo is copied back and the key tables rebuilt on the host: tens of milliseconds, once), and once more a gigabyte of text later; 0: never
-        * automatically; 2: promote now whatever the memo holds; 3: drop every promotion.  2 and 3 are refused with TKZ_E_ARG while a call is in flight. */
+        * memo is copied back and the key tables rebuilt on the host: tens of milliseconds, once), once more a gigabyte of text later, and again whenever
+        * the text has drifted (TKZ_OPT_ADAPT); 0: never automatically; 2: promote now whatever the memo holds; 3: drop every promotion.  2 and 3 are refused
+        * with TKZ_E_ARG while a call is in flight. */
        TKZ_OPT_PROMOTE = 4,
        /* tuning knobs of the automatic promotion: the smallest batch (bytes) that may be a learning batch (default 8 MB), and the most promoted
         * pieces the key tables hold (default 65,536; at most 2^22) */
@@ -301,7 +302,16 @@ enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1,
         * slowest wavefront of each kernel, so the merge of the long missed pieces is dealt out in units of 4 sub-tiles instead of 64 (93 -> 44 us of a 1 MB
         * call) and its queue of very long pieces gets a full grid.  Same ids either way.  (TKZ_LATENCY_BYTES in the environment sets the value an encoder
         * is created with.) */
-       TKZ_OPT_LATENCY_BYTES = 8 };
+       TKZ_OPT_LATENCY_BYTES = 8,
+       /* The cache adapts (default 1).  The reference's LRUCache evicts and refills for ever (LRUCache.cs:79-121); the device memo takes no entry once it is
+        * full and a promoted piece stays promoted.  With this option on the encoder follows, from batch to batch, the share of pieces that miss its key
+        * tables as a whole (counted by a kernel that runs anyway); when that share has left the level at which it settled after the last promotion -- by
+        * more than a quarter and a percentage point, either way, 256 MB of text or more after it -- the encoder learns again: every promotion is dropped
+        * (so a piece that stopped hitting is not chosen again), the memo is emptied (while no other call is in flight), the next learning window counts
+        * hits and the hottest pieces of the text as it is now are promoted.  Also with it on, batches smaller than TKZ_OPT_PROMOTE_MIN_BYTES add up to a
+        * learning window instead of never learning.  0: learn in the first batch of at least that size and once more a gigabyte later, never again
+        * (round 5's behaviour).  Same ids either way. */
+       TKZ_OPT_ADAPT = 9 };
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value);
 
 /* ---- measurement ------------------------------------------------------------------------- */
@@ -331,11 +341,22 @@ int32_t tkz_encoder_small_path_phases(const tkz_encoder* e, int64_t* clocks16);
  * (TKZ_OPT_PROMOTE: they count as whole-piece hits).  Whole-piece hit rate =
  * 1 - ([2] + [3] + [4]) / [1]. */
 tkz_status tkz_encoder_piece_stats(tkz_encoder* e, int64_t* out8, int32_t reset);
+/* TKZ_OPT_ADAPT, informational (8 values; waits for a promotion being built in the background): [0] promotions installed so far, [1] times the encoder
+ * decided to learn again, [2] promoted pieces the key tables hold now, [3] replaced table images not freed yet (they go when no call is in flight),
+ * [4] the share of pieces that missed the key tables as it settled after the last promotion, in millionths (-1: not settled yet), [5] the same share
+ * over the recent batches (-1: none yet), [6] bytes encoded since the key tables last changed, [7] bytes of the learning window in progress. */
+tkz_status tkz_encoder_adapt_stats(tkz_encoder* e, int64_t* out8);
 /* Slots of the piece memo (TKZ_OPT_PIECE_MEMO) and slots per bucket, informational; the bucket a piece of 1..16 bytes would use
  * (-1: none -- a piece that holds a zero byte never uses the memo).  The tests use the last one to build pieces that contend for one bucket. */
 int64_t tkz_encoder_memo_slots(const tkz_encoder* e);
 int32_t tkz_encoder_memo_ways(const tkz_encoder* e);
 int64_t tkz_encoder_memo_bucket(const tkz_encoder* e, const uint8_t* piece, int32_t len);
+/* Allocates, now, the workspace of a batch of up to max_bytes bytes in up to max_docs documents (about 7.8 device bytes per input byte: records, miss
+ * lists, bitmaps, scratch, the staging of the host-buffer entry points, streams): replaces the allocations the first batch call of a fresh encoder
+ * otherwise makes inside the call.  The reference pays its construction costs in TokenizerBuilder.CreateTokenizer (TokenizerBuilder.cs:210-213) --
+ * call this right after tkz_encoder_create.  Batches up to that size then allocate nothing; larger ones grow the workspace as before.  An encoder whose
+ * host threads run batches concurrently reserves one workspace per call of this function. */
+tkz_status tkz_encoder_reserve(tkz_encoder* e, int64_t max_bytes, int64_t max_docs);
 /* Device bytes currently held by the encoder (tables + workspace). */
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e);
 const char* tkz_kernel_name(int32_t k);

@@ -295,6 +295,9 @@ public:
         return ids;
     }
     tkz_encoder* native() const { return enc_; }
+    // the device workspace of batches of up to max_bytes / max_docs, allocated now instead of inside the first batch call (tkz_encoder_reserve): what
+    // TokenizerBuilder.CreateTokenizer (TokenizerBuilder.cs:210-213) is for a drop-in -- construction pays, not the first Encode
+    void Reserve(int64_t max_bytes, int64_t max_docs) { check(tkz_encoder_reserve(enc_, max_bytes, max_docs)); }
     // The split is whatever the HOST's regex engine makes of the pattern (TikTokenizer.cs:77 compiles it in the running process).  A host on another
     // runtime than net6.0 hands its Unicode classification over (classes[cp] in 0..8 for cp < n: 65536 code units or 1114112 code points; nullptr:
     // the built-in Unicode 13.0 table) and says how it reads cl100k's (?i:...): .NET >= 7 folds U+017F onto `s`.

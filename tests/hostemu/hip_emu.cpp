@@ -78,6 +78,7 @@ void block_barrier() {
 
 void launch(int64_t grid, int block, const std::function<void()>& body) {
     if (block <= 0 || block > kMaxThreads) { fprintf(stderr, "hipemu: bad block size %d\n", block); abort(); }
+    if (grid <= 0) { fprintf(stderr, "hipemu: a launch with a grid of %lld workgroups (an invalid configuration on HIP: the real runtime fails the call)\n", (long long)grid); abort(); }
     for (int t = 0; t < block; ++t)
         if (!g_f[t].stack) {
             g_f[t].stack = (char*)mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);

@@ -308,6 +308,129 @@ def check_dense_region(lib, O, vocab, ovocab, pattern=N.CL100K, seed=17):
     assert ooff.tolist() == eoff and ids.tolist() == exp
 
 
+def check_reserve(lib, O, vocab, ovocab, pattern=N.CL100K, seed=13):
+    """tkz_encoder_reserve: the workspace of a stated batch size is allocated by the call, and batches up to that size allocate nothing more (the
+    reference pays construction costs in CreateTokenizer, TokenizerBuilder.cs:210-213, not in the first Encode)."""
+    rng = random.Random(seed)
+    alpha = RC.alphabet()
+    enc = N.Encoder(vocab, pattern)
+    enc.set_option(N.OPT_PROMOTE, 0)                        # (a promotion builds new key-table images: megabytes that are not workspace)
+    w0 = enc.workspace_bytes
+    with pytest.raises(N.TkzError) as ei:
+        enc.reserve(-1, 10)
+    assert ei.value.code == N.E_ARG
+    enc.reserve(2_000_000, 4_000)
+    w1 = enc.workspace_bytes
+    assert w1 - w0 > 7 * 2_000_000, (w0, w1)                # ~7.8 bytes per input byte + staging
+    oenc = O.Encoder(ovocab, pattern)
+    for total in (300_000, 1_500_000):                      # (above the single-launch path; a learning window allocates its counters: reserved too)
+        # (ordinary prose: a piece per ~5 bytes.  Text with a piece per byte needs more piece records than a workspace starts with -- a piece per 3 bytes --
+        #  and lists of misses longer than 64: those two still grow, once, inside the call that meets such text)
+        words = ["the", "and", "with", "from", "this", "that", "have", "will", "token", "encoder", "value", "return", "12", ",", "."]
+        docs = []
+        while sum(map(len, docs)) < total:
+            docs.append(" ".join(rng.choice(words) for _ in range(rng.choice([40, 400, 1800]))).encode("utf-8"))
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        e, eo = oracle_encode_docs(oenc, docs)
+        assert ids.tolist() == e and ooff.tolist() == eo
+    assert enc.workspace_bytes == w1, (w1, enc.workspace_bytes)
+    enc.reserve(1_000_000, 100)                             # smaller than what is there: nothing happens
+    assert enc.workspace_bytes == w1
+
+
+def check_adaptation(lib, O, vocab, ovocab, monkeypatch, pattern=N.CL100K, seed=71):
+    """TKZ_OPT_ADAPT: the cache follows the text.  An encoder learns text A, the text drifts to B (other words: the share of pieces that miss the key
+    tables rises), the encoder drops its promotions, empties the memo, learns B -- A's pieces are promoted no longer (eviction) --, and back again.
+    Batches smaller than the learning window add up to one.  Replaced table images are freed once no call is in flight; the ids are the oracle's
+    throughout.  (The thresholds are megabytes; $TKZ_ADAPT_* brings them down to the size of these batches.)"""
+    monkeypatch.setenv("TKZ_ADAPT_SETTLE_BYTES", "100000")
+    monkeypatch.setenv("TKZ_ADAPT_MIN_BYTES", "300000")
+    cons, vow = "bcdfghjklmnpqrstvwxz", "aeiou"
+
+    def lexicon(r, n):
+        return ["".join(r.choice(cons) + r.choice(vow) for _ in range(r.randint(2, 6))) + r.choice(["", "s", "ed", "ing"]) for _ in range(n)]
+    lex_a, lex_b = lexicon(random.Random(seed + 1), 300), lexicon(random.Random(seed + 2), 300)
+    known = ["the", "and", "with", "from", "this", "that", "have", "will"]           # (vocabulary words: whole-piece hits whatever is promoted)
+
+    def batch(lex, r, nbytes=160_000, hit_share=0.5):
+        docs, size = [], 0
+        while size < nbytes:
+            words = []
+            n = r.choice([300, 2000, 9000])
+            while sum(map(len, words)) < n:
+                words.append(r.choice([" ", " ", "\n", ", "]) + (r.choice(known) if r.random() < hit_share else r.choice(lex)))
+            docs.append("".join(words).encode("utf-8"))
+            size += len(docs[-1])
+        return docs
+    oenc = O.Encoder(ovocab, pattern)
+    enc = N.Encoder(vocab, pattern)
+    enc.set_option(N.OPT_PROMOTE_MIN_BYTES, 100_000)
+    rr = random.Random(seed + 3)
+    mem0 = None
+
+    def run(docs):
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        e, eo = oracle_encode_docs(oenc, docs)
+        assert ids.tolist() == e and ooff.tolist() == eo
+        return enc.adapt_stats()
+    st = run(batch(lex_a, rr))                            # the learning window (one batch): promoted at its end
+    assert st["promotions"] == 1 and st["promoted_pieces"] > 50 and st["relearns"] == 0, st
+    promoted_a = st["promoted_pieces"]
+    for _ in range(3):
+        st = run(batch(lex_a, rr))
+    assert st["settled_miss_share"] is not None and st["relearns"] == 0 and st["retired_images"] == 0, st
+    settled_a = st["settled_miss_share"]
+    mem0 = enc.workspace_bytes
+    # the text drifts: other words.  The miss share rises; once it has, the encoder learns again
+    seen_relearn = None
+    for i in range(6):
+        st = run(batch(lex_b, rr))
+        if st["relearns"] == 1 and seen_relearn is None:
+            seen_relearn = i
+            assert st["promoted_pieces"] == 0, st          # every promotion dropped: the next window starts from the vocabulary alone
+    assert seen_relearn is not None and seen_relearn <= 3, st
+    assert st["promotions"] >= 2 and st["promoted_pieces"] > 50, st
+    # eviction: text A's pieces are not promoted any more -- they miss the key tables again
+    enc.set_option(N.OPT_PROMOTE, 0)                      # (nothing automatic while the two texts are probed: text A would be a drift of its own)
+    enc.set_option(N.OPT_PIECE_STATS, 1)
+    enc.piece_stats(reset=True)
+    probe_a = batch(lex_a, random.Random(seed + 9), 150_000)
+    run(probe_a)
+    ps_a = enc.piece_stats(reset=True)
+    run(batch(lex_b, random.Random(seed + 10), 150_000))
+    ps_b = enc.piece_stats(reset=True)
+    enc.set_option(N.OPT_PIECE_STATS, 0)
+    enc.set_option(N.OPT_PROMOTE, 1)
+    assert ps_a["whole_piece_hit_rate"] < ps_b["whole_piece_hit_rate"] - 0.15, (ps_a, ps_b)
+    # ... and back to A: a second re-learn
+    for i in range(8):
+        st = run(batch(lex_a, rr))
+    assert st["relearns"] >= 2 and st["promoted_pieces"] > 50, st
+    run(batch(lex_a, rr))
+    assert enc.adapt_stats()["retired_images"] == 0       # freed when the call that followed the swap returned
+    assert enc.workspace_bytes <= mem0 + (4 << 20), (mem0, enc.workspace_bytes)
+    # small batches add up to a learning window (the single-launch path -- up to 128 KiB -- keeps no statistics: these are just above it)
+    enc2 = N.Encoder(vocab, pattern)
+    enc2.set_option(N.OPT_PROMOTE_MIN_BYTES, 600_000)
+    enc3 = N.Encoder(vocab, pattern)
+    enc3.set_option(N.OPT_PROMOTE_MIN_BYTES, 600_000)
+    enc3.set_option(N.OPT_ADAPT, 0)                       # round 5's rule: only a batch of that size learns
+    r5 = random.Random(seed + 5)
+    for i in range(5):
+        docs = batch(lex_a, r5, 140_000)
+        data, offs = pack(docs)
+        e, eo = oracle_encode_docs(oenc, docs)
+        for en in (enc2, enc3):
+            ids, ooff = en.encode_batch(data, offs)
+            assert ids.tolist() == e and ooff.tolist() == eo
+        if i < 3:
+            assert enc2.adapt_stats()["promotions"] == 0 and enc2.adapt_stats()["learning_window_bytes"] > 0
+    assert enc2.adapt_stats()["promotions"] == 1 and enc2.adapt_stats()["promoted_pieces"] > 50, enc2.adapt_stats()
+    assert enc3.adapt_stats()["promotions"] == 0 and enc3.adapt_stats()["promoted_pieces"] == 0
+
+
 def check_piece_memo(lib, O, vocab, ovocab, pattern=N.CL100K, seed=23):
     """The piece memo (TKZ_OPT_PIECE_MEMO): the same ids with the memo off, empty, filled by an earlier batch of the same text (every
     short miss a hit), and filled by OTHER text (hits and misses mixed, slots already taken by other pieces)."""
@@ -1298,6 +1421,17 @@ def check_host_chunks(lib, O, vocab, ovocab, pattern=N.CL100K, seed=21):
     with pytest.raises(N.TkzError) as ei:
         enc.encode_batch(np.frombuffer(b"x" * 40000, np.uint8), np.array([0, 30000, 20000, 40000]))
     assert ei.value.code == N.E_ARG
+    # UTF-16 batches through the chunks (round 6: the chunk loop serves that entry too): a document that spans a chunk cut -- or several -- leaves chunks
+    # WITHOUT any document or unit: no kernel may be launched on nothing (a grid of 0 workgroups is an invalid configuration on HIP; the emulator aborts on it)
+    for shape in ("one", "last", "first", "empties"):
+        long_doc = RC.to_units(RC.random_text(rng, alpha, 9000))
+        small = [RC.to_units(RC.random_text(rng, alpha, rng.randint(0, 60))) for _ in range(6)]
+        docs16 = {"one": [long_doc], "last": small + [long_doc], "first": [long_doc] + small, "empties": [[]] * 3 + [long_doc] + [[]] * 3 + small}[shape]
+        flat = np.asarray([u for d in docs16 for u in d], dtype=np.uint16)
+        offs16 = np.cumsum([0] + [len(d) for d in docs16]).astype(np.int64)
+        ids, ooff = enc.encode_batch_utf16(flat, offs16)
+        for d, units in enumerate(docs16):
+            assert ids[ooff[d]:ooff[d + 1]].tolist() == oenc.encode_utf16(units), (shape, d)
     # page-locked caller buffers through the chunks: the ids and offsets of every chunk are copied into the caller's arrays at the token base of
     # its chunk
     import ctypes as C

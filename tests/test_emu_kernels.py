@@ -144,6 +144,16 @@ def test_promoted_pieces(lib, vocabs, oracle_mod, vname, pattern):
     parity.check_promotion(lib, oracle_mod, v, ov, pattern=pattern)
 
 
+def test_reserve_takes_allocation_out_of_the_first_call(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_reserve(lib, oracle_mod, v, ov)
+
+
+def test_cache_adapts_to_drift(lib, vocabs, oracle_mod, monkeypatch):
+    v, ov = vocabs("gpt2")
+    parity.check_adaptation(lib, oracle_mod, v, ov, monkeypatch)
+
+
 def test_host_runtime_defines_the_split(lib, vocabs, oracle_mod):
     v, ov = vocabs("gpt2")
     parity.check_runtime_overrides(lib, oracle_mod, v, ov)

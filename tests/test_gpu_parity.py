@@ -151,6 +151,16 @@ def test_promoted_pieces(lib, vocabs, oracle_mod, vname, pattern):
     parity.check_promotion(lib, oracle_mod, v, ov, pattern=pattern)
 
 
+def test_reserve_takes_allocation_out_of_the_first_call(lib, vocabs, oracle_mod):
+    v, ov = vocabs("gpt2")
+    parity.check_reserve(lib, oracle_mod, v, ov)
+
+
+def test_cache_adapts_to_drift(lib, vocabs, oracle_mod, monkeypatch):
+    v, ov = vocabs("gpt2")
+    parity.check_adaptation(lib, oracle_mod, v, ov, monkeypatch)
+
+
 def test_host_runtime_defines_the_split(lib, vocabs, oracle_mod):
     v, ov = vocabs("gpt2")
     parity.check_runtime_overrides(lib, oracle_mod, v, ov)
@@ -404,6 +414,31 @@ def test_device_corpus_properties_and_sample(lib, vocabs, oracle_mod, vname, kin
     for d in pick:
         doc = h_bytes[h_offs[d]:h_offs[d + 1]].tobytes()
         assert doc == N.corpus_doc_host(kind, 0x5EED0000 + kind, d + first_doc, lo, hi, lib=lib)
+
+
+def test_utf16_document_spanning_chunk_cuts(lib, vocabs, oracle_mod):
+    """tkz_encode_batch_utf16 with ONE document of 7 M code units (14 MB: the batch is cut into two chunks on document boundaries, so one chunk holds the
+    document and the other nothing at all) -- alone, last and first in its batch.  Round 5's advisor: the empty chunk launched k_u16_len / the scan on a grid
+    of 0 workgroups, which HIP refuses."""
+    import random
+    import regex_crosscheck as RC
+    vocab, ov = vocabs("gpt2")
+    enc = N.Encoder(vocab, N.CL100K)
+    oenc = oracle_mod.Encoder(ov, N.CL100K)
+    rng = random.Random(5)
+    alpha = RC.alphabet()
+    piece = RC.to_units(RC.random_text(rng, alpha, 70_000))
+    long_doc = (piece * (7_000_000 // len(piece) + 1))[:7_000_000]
+    if 0xD800 <= long_doc[-1] < 0xDC00: long_doc[-1] = 0x41                        # (no lone half at the cut of the tiling)
+    want_long = oenc.encode_utf16(long_doc)
+    small = [RC.to_units(RC.random_text(rng, alpha, rng.randint(0, 200))) for _ in range(5)]
+    for docs in ([long_doc], small + [long_doc], [long_doc] + small, [[]] * 2 + [long_doc] + [[]] * 2):
+        flat = np.concatenate([np.asarray(d, dtype=np.uint16) for d in docs]) if docs else np.zeros(0, np.uint16)
+        offs = np.cumsum([0] + [len(d) for d in docs]).astype(np.int64)
+        ids, ooff = enc.encode_batch_utf16(flat, offs)
+        for d, units in enumerate(docs):
+            got = ids[ooff[d]:ooff[d + 1]].tolist()
+            assert got == (want_long if units is long_doc else oenc.encode_utf16(units)), (len(docs), d)
 
 
 def test_host_path_chunked_and_threads(lib, vocabs, oracle_mod):

@@ -20,6 +20,7 @@ OPT_PIECE_STATS = 3
 OPT_PROMOTE_MIN_BYTES, OPT_PROMOTE_CAP = 5, 6
 OPT_CASE_EQUIVALENCE = 7    # cl100k's (?i:...) with .NET >= 7's case-equivalence tables ('ſ is 's)
 OPT_LATENCY_BYTES = 8       # batches of at most this many bytes merge long missed pieces a wavefront each (tkz.h)
+OPT_ADAPT = 9               # 1 (default): the encoder learns again when the text has drifted; small batches add up to a learning window (tkz.h)
 OPT_PROMOTE = 4        # 0 / 1: automatic promotion of hot memo entries into the key tables off / on; 2: promote now; 3: drop the promotions
 K_NAMES = ["k_docmark", "k_pretok", "k_probe", "k_scan", "k_place", "k_docoffs", "k_merge_long_group", "k_merge_short"]
 
@@ -122,6 +123,8 @@ class Library:
         L.tkz_encode_batch_pieces_utf8.argtypes = [vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, pi64, pi64]
         L.tkz_encoder_set_option.argtypes = [vp, i32, i64]
         L.tkz_encoder_piece_stats.argtypes = [vp, vp, i32]
+        L.tkz_encoder_adapt_stats.argtypes = [vp, vp]
+        L.tkz_encoder_reserve.argtypes = [vp, i64, i64]
         L.tkz_encoder_set_profiling.argtypes = [vp, i32]
         L.tkz_encoder_kernel_ms.argtypes = [vp, vp, vp, i32]
         L.tkz_encoder_workspace_bytes.argtypes = [vp]
@@ -258,6 +261,18 @@ class Encoder:
                 "whole_piece_hit_rate": round(1.0 - (sm + lm + gm) / pieces, 5) if pieces else None,
                 "memo_lookups": look, "memo_hits": hit, "memo_hit_rate": round(hit / look, 5) if look else None,
                 "merged_short": look - hit if look else sm, "promoted_pieces_in_tables": int(out[7])}
+
+    def reserve(self, max_bytes, max_docs):
+        """The workspace of batches of up to max_bytes / max_docs, allocated now instead of inside the first batch call (tkz_encoder_reserve)."""
+        self.lib.check(self.lib.L.tkz_encoder_reserve(self._h, int(max_bytes), int(max_docs)))
+
+    def adapt_stats(self):
+        """TKZ_OPT_ADAPT's bookkeeping (tkz_encoder_adapt_stats): promotions, re-learns, promoted pieces, the settled and the recent miss share."""
+        out = np.zeros(8, np.int64)
+        self.lib.check(self.lib.L.tkz_encoder_adapt_stats(self._h, out.ctypes.data))
+        return {"promotions": int(out[0]), "relearns": int(out[1]), "promoted_pieces": int(out[2]), "retired_images": int(out[3]),
+                "settled_miss_share": None if out[4] < 0 else out[4] / 1e6, "recent_miss_share": None if out[5] < 0 else out[5] / 1e6,
+                "bytes_since_tables_changed": int(out[6]), "learning_window_bytes": int(out[7])}
 
     def set_profiling(self, on):
         self.lib.check(self.lib.L.tkz_encoder_set_profiling(self._h, 1 if on else 0))

@@ -70,6 +70,7 @@ struct DevBuf {
         if (e != hipSuccess && want > n) { want = (n + 255) & ~size_t(255); e = hipMalloc(&q, want); }
         if (e != hipSuccess) return e;
         if (p) (void)hipFree(p);
+        if (getenv("TKZ_LOG_ALLOC")) fprintf(stderr, "tkz alloc: %zu -> %zu bytes (asked %zu)\n", cap, want, n);
         *accounted += (int64_t)want - (int64_t)cap;
         p = q; cap = want;
         return hipSuccess;
@@ -97,6 +98,7 @@ struct CounterBlock {          // mirrors the device block
     unsigned long long coop_count, coop_ticket;   // k_list_stats -> k_merge_coop: queued long misses of more than kLanePiece bytes, the next one to be taken
     unsigned long long long_log_count;     // a learning batch: records k_merge_long wanted to log (EncodeParams::long_log)
     int64_t lq_total;                      // long misses in the class queue (the scan of EncodeParams::lq_cnt)
+    unsigned long long miss_short, miss_long;   // pieces of the batch that missed the key tables as a whole (k_list_stats: the sums of mcount)
 };
 
 }  // namespace
@@ -118,6 +120,7 @@ struct Workspace {
     DevBuf w_zero; size_t zero_bytes = 0;
     DevView w_counters, w_docbits, w_heavyq;
     DevBuf w_mlist, w_mquad, w_mcount, w_pextra, w_coopq, w_lqcnt, w_lqbase, w_lq;
+    bool learn_window_start = false;       // this learning batch opens a window: the hit counters and the log start from zero
     DevBuf w_counts3;                      // {n_docs, n_bytes, n_tokens} of the batch this workspace is running (tkz_pending_counts_device)
     bool sized = false;                    // a batch has run to its end here: the lists and the record buffer have seen real text (encode_device: the sizing attempt)
     int32_t mcap = tkz::kMissCapMin;       // entries of a sub-tile's miss list; grows (once, to what the batch needed) when a sub-tile overflows it
@@ -206,7 +209,22 @@ struct tkz_encoder {
     DevBuf t_memo_hits, t_promo;           // the hit counters of a learning batch; the token quads of the promoted pieces
     DevBuf t_long_log;                     // ... and its log of merged pieces of 17..28 bytes (EncodeParams::long_log)
     int64_t long_log_n = 0;                // records the last learning batch left there (set when it ended)
-    std::vector<DevBuf> retired;           // table images replaced by a promotion while other calls may still have been probing them: freed with the encoder
+    std::vector<DevBuf> retired;           // table images replaced while other calls may still have been probing them: freed when no call of the encoder is in flight (Lease)
+    // ---- the cache ADAPTS (round 6; TKZ_OPT_ADAPT, all under mu).  The reference's LRUCache evicts and refills for ever (LRUCache.cs:79-121); here the share
+    // of pieces that miss the key tables as a whole is followed from batch to batch (k_list_stats sums the miss lists: no extra kernel), and when it leaves
+    // the level it had after the last promotion the encoder LEARNS AGAIN: promotions dropped, memo emptied, the next batches count hits, the hottest pieces of
+    // the text as it is NOW are promoted (pieces that stopped hitting are simply not chosen again).
+    int adapt = 1;                         // TKZ_OPT_ADAPT
+    // (how much text the miss share is averaged over / has to settle for after a promotion, and how soon after one the encoder may learn again; the
+    //  environment variables are the tests' handle on them: their batches are kilobytes)
+    int64_t adapt_settle_bytes = [] { const char* v = getenv("TKZ_ADAPT_SETTLE_BYTES"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : int64_t(64) << 20; }();
+    int64_t adapt_min_bytes = [] { const char* v = getenv("TKZ_ADAPT_MIN_BYTES"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : int64_t(256) << 20; }();
+    double ew_miss = 0, base_miss = 0;     // miss share of the recent batches (weighted by their bytes, 64 MB time constant); ... as it settled after the last promotion
+    bool ew_valid = false, base_valid = false;
+    int64_t bytes_at_install = 0;          // bytes_seen when the key tables were last replaced
+    int64_t learn_bytes = 0;               // bytes of the learning window so far (batches smaller than promo_min_bytes add up to one)
+    bool memo_clear_pending = false;       // the memo is emptied before the next learning window starts (only while no other call is in flight)
+    int64_t n_promotions = 0, n_relearns = 0;
     std::vector<tkz::KeyItem> promo_items; // promoted piece -> promo code, in order of promotion
     std::unordered_set<std::string> promo_keys;
     std::vector<uint32_t> promo_quads;     // 4 tokens per promoted piece (host copy of t_promo)
@@ -229,7 +247,17 @@ struct Lease {
         if (!ws) { ws = new Workspace(); e->pool.push_back(ws); }
         ws->busy = true;
     }
-    ~Lease() { std::lock_guard<std::mutex> lock(e->mu); ws->busy = false; }
+    ~Lease() {
+        std::lock_guard<std::mutex> lock(e->mu);
+        ws->busy = false;
+        // table images a promotion replaced: every call takes its copy of the table descriptor while it holds a workspace, so with no workspace leased
+        // nothing can be probing them any more
+        if (!e->retired.empty()) {
+            for (Workspace* w : e->pool) if (w->busy) return;
+            for (DevBuf& b : e->retired) { e->bytes_allocated -= (int64_t)b.cap; b.release(); }
+            e->retired.clear();
+        }
+    }
     Lease(const Lease&) = delete;
     Lease& operator=(const Lease&) = delete;
 };
@@ -387,6 +415,12 @@ tkz_status promote_from_memo(tkz_encoder* e, bool use_hits, bool retire, int64_t
     // ... and the pieces of 17..28 bytes k_merge_long logged during the learning batch (each with its <= 4 tokens): those that were logged at least
     // twice -- real source text is full of them: "\n" + 19 spaces, by the hundred thousand -- go into the MID key table the same way
     std::vector<uint32_t> llog;
+    if (use_hits && e->t_long_log.p) {      // (the log's record count lives behind the records: it runs on through the batches of a learning window)
+        unsigned long long n = 0;
+        HIP_TRY(hipMemcpyAsync(&n, e->t_long_log.as<char>() + (size_t)kLongLogCap * kLongLogDwords * 4, 8, hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipStreamSynchronize(cs));
+        e->long_log_n = (int64_t)std::min<unsigned long long>(n, (unsigned long long)kLongLogCap);
+    }
     if (use_hits && e->long_log_n > 0) {
         llog.resize((size_t)e->long_log_n * kLongLogDwords);
         HIP_TRY(hipMemcpyAsync(llog.data(), e->t_long_log.p, llog.size() * 4, hipMemcpyDeviceToHost, cs));
@@ -465,6 +499,42 @@ tkz_status promote_from_memo(tkz_encoder* e, bool use_hits, bool retire, int64_t
     std::lock_guard<std::mutex> lock(e->mu);
     install_key_tables(e, img, retire);
     return TKZ_OK;
+}
+
+// every promotion dropped: the key tables as the vocabulary alone gives them.  `retire`: see install_key_tables.  No lock held on entry.
+tkz_status drop_promotions(tkz_encoder* e, bool retire) {
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        if (e->promo_items.empty()) return TKZ_OK;
+    }
+    KeyTablesImage img;
+    const tkz_status st = build_key_tables_image(e, {}, {}, &img);
+    if (st != TKZ_OK) return st;
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->promo_items.clear(); e->promo_keys.clear(); e->promo_quads.clear();
+    install_key_tables(e, img, retire);
+    return TKZ_OK;
+}
+
+// TKZ_OPT_ADAPT (e->mu held): a batch that was not a learning batch has ended; `misses` of its `pieces` regex matches were not found in the key tables
+// as a whole (vocabulary + promoted pieces).  Returns true when the encoder should learn again: the share of such pieces, averaged over the recent
+// batches by their bytes, has left the level at which it settled after the last promotion by more than a quarter (and a percentage point) either way
+// -- text whose pieces the promotions no longer answer, or text that a fresh encoder would answer better.  Not within adapt_min_bytes (256 MB) of the last
+// change of the tables: a re-learn costs one window at the speed of an encoder without promotions and two table builds on the host.
+bool adapt_after_batch(tkz_encoder* e, int64_t total, double misses, double pieces) {
+    if (!e->adapt || e->promo_mode != 1 || pieces < 1) return false;
+    const int64_t kAdaptSettleBytes = e->adapt_settle_bytes, kAdaptMinBytes = e->adapt_min_bytes;
+    const double rate = misses / pieces, w = std::min(1.0, (double)total / (double)kAdaptSettleBytes);
+    e->ew_miss = e->ew_valid ? e->ew_miss + (rate - e->ew_miss) * w : rate;
+    e->ew_valid = true;
+    if (e->learning || e->promo_rounds < 1) return false;
+    const int64_t since = e->bytes_seen - e->bytes_at_install;
+    if (!e->base_valid) {
+        if (since >= kAdaptSettleBytes) { e->base_miss = e->ew_miss; e->base_valid = true; }
+        return false;
+    }
+    if (since < kAdaptMinBytes) return false;
+    return e->ew_miss > e->base_miss * 1.25 + 0.01 || e->ew_miss < e->base_miss * 0.75 - 0.01;
 }
 
 // workspace of one batch of `total` bytes / n_docs documents (grow-only buffers: nothing happens once they are large enough)
@@ -592,20 +662,41 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         TkzTables T;
         {
             std::lock_guard<std::mutex> lock(e->mu);
-            // LEARNING: the first large batch of documents on the batch path (and one more, kPromoSecondBytes later) counts the memo's hits per slot
+            // LEARNING: the first batches of documents on the batch path (and once more, kPromoSecondBytes later; and again whenever the text has drifted:
+            // adapt_after_batch below) count the memo's hits per slot.  A learning WINDOW is promo_min_bytes of text: one large batch, or -- TKZ_OPT_ADAPT --
+            // as many smaller ones as it takes (a caller whose batches are 1 MB learns too).
             if (attempt == 0 && !ws->learning && pretok && !d_bitmap_only && e->promo_mode == 1 && !e->learning && e->promo_rounds < kPromoAutoRounds &&
-                e->T.memo_n != 0 && e->T.max_rank < (int32_t)kPromoFlag && total >= e->promo_min_bytes && e->promo_items.size() < e->promo_cap &&
+                e->T.memo_n != 0 && e->T.max_rank < (int32_t)kPromoFlag && (e->adapt || total >= e->promo_min_bytes) && e->promo_items.size() < e->promo_cap &&
                 (e->promo_rounds == 0 || e->bytes_seen - e->bytes_at_promo >= kPromoSecondBytes)) {
-                // (the gigabyte to the second round counts from the START of the first learning batch: a job of 5 GB batches learns in its first two)
-                if (e->t_memo_hits.ensure((size_t)e->memo_slots * 4, &e->bytes_allocated) == hipSuccess &&
-                    e->t_long_log.ensure((size_t)kLongLogCap * kLongLogDwords * 4, &e->bytes_allocated) == hipSuccess) { e->learning = true; ws->learning = true; e->bytes_at_promo = e->bytes_seen; }
+                // (the gigabyte to the second round counts from the START of the first learning window: a job of 5 GB batches learns in its first two)
+                // The memo is emptied for a window that follows a drift -- it is full of the old text's pieces and takes no new ones --, and that only while
+                // no OTHER call is in flight: an entry never changes once it is valid (tkz_tables.h), which is what makes a hit exact, so the table is
+                // cleared under nobody's feet, synchronously, with the encoder's lock held (16 MB: microseconds, once per drift)
+                bool quiet = true;
+                if (e->memo_clear_pending) for (Workspace* w : e->pool) if (w != ws && w->busy) quiet = false;
+                if (quiet && e->t_memo_hits.ensure((size_t)e->memo_slots * 4, &e->bytes_allocated) == hipSuccess &&
+                    e->t_long_log.ensure((size_t)kLongLogCap * kLongLogDwords * 4 + 64, &e->bytes_allocated) == hipSuccess) {
+                    bool ok = true;
+                    if (e->memo_clear_pending) {
+                        ok = hipMemsetAsync(e->t_memo.p, 0, size_t(e->memo_slots) * sizeof(TkzMemoSlot), stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+                        if (ok) e->memo_clear_pending = false;
+                    }
+                    if (ok) {
+                        ws->learn_window_start = e->learn_bytes == 0;
+                        if (ws->learn_window_start) e->bytes_at_promo = e->bytes_seen;
+                        e->learning = true; ws->learning = true;
+                    }
+                }
             }
             T = e->T;
         }
         if (ws->learning) {
             T.memo_hits = e->t_memo_hits.as<uint32_t>();
             T.memo_hits_sparse = total >= (int64_t(64) << 20) ? 1u : 0u;       // (below 64 MB every hit is counted: a few million atomics at most)
-            HIP_TRY(hipMemsetAsync(T.memo_hits, 0, (size_t)e->memo_slots * 4, stream));
+            if (ws->learn_window_start && attempt == 0) {                       // (a window's later batches add to its counters and its log)
+                HIP_TRY(hipMemsetAsync(T.memo_hits, 0, (size_t)e->memo_slots * 4, stream));
+                HIP_TRY(hipMemsetAsync(e->t_long_log.as<char>() + (size_t)kLongLogCap * kLongLogDwords * 4, 0, 64, stream));
+            }
         }
         int64_t* grand = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, grand));
         unsigned long long* pool_head = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, pool_head));
@@ -659,6 +750,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.pool = ws->w_pool.as<int32_t>(); P.pool_head = pool_head; P.pool_cap = (int64_t)(ws->w_pool.cap / 4);
             P.lq_cnt = ws->w_lqcnt.as<int32_t>(); P.lq_base = ws->w_lqbase.as<int64_t>(); P.lq = ws->w_lq.as<uint64_t>(); P.lq_cap = total / (kShortMax + 1) + 64;
             P.lq_total = reinterpret_cast<int64_t*>(ws->w_counters.as<char>() + offsetof(CounterBlock, lq_total)); P.lq_bsum = ws->w_bsum.as<int64_t>();
+            P.miss_sums = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, miss_short));
             P.ablate = 0; P.devprof = nullptr;
             P.stats = e->piece_stats ? e->t_stats.as<unsigned long long>() : nullptr;
             // (statistics: an attempt that has to be run again -- lists or records to grow -- must not be counted twice: the block as it was before
@@ -668,7 +760,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             P.promo = T.promo; P.pextra = T.promo ? ws->w_pextra.as<int32_t>() : nullptr;
             if (ws->learning) {
                 P.long_log = e->t_long_log.as<uint32_t>(); P.long_log_cap = (int32_t)kLongLogCap; P.long_log_sparse = T.memo_hits_sparse ? 1 : 0;
-                P.long_log_count = reinterpret_cast<unsigned long long*>(ws->w_counters.as<char>() + offsetof(CounterBlock, long_log_count));
+                P.long_log_count = reinterpret_cast<unsigned long long*>(e->t_long_log.as<char>() + (size_t)kLongLogCap * kLongLogDwords * 4);   // (the encoder's: it runs on through the batches of a window)
             }
 #ifdef TKZ_DEVPROF
             { const char* ab = getenv("TKZ_DEV_ABLATE"); P.ablate = ab ? atoi(ab) : 0; }
@@ -821,25 +913,39 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             }
         }
         if (!d_bitmap_only && pretok) {
-            // the batch is done: if it counted the memo's hits, the hottest entries are promoted now (once or twice in an encoder's life: the copy
-            // of the memo back to the host and the rebuilt key tables cost tens of milliseconds)
-            bool promote = false;
+            // the batch is done: if it completes a learning window, the hottest entries are promoted now (the copy of the memo back to the host and the
+            // rebuilt key tables cost tens of milliseconds: on a thread, behind the batch); else the share of pieces that missed the key tables is
+            // compared with what it was after the last promotion (adapt_after_batch)
+            bool promote = false, relearn = false;
             {
                 std::lock_guard<std::mutex> lock(e->mu);
                 e->bytes_seen += total;
-                promote = ws->learning;
+                if (ws->learning) {
+                    e->learn_bytes += total;
+                    promote = !e->adapt || e->learn_bytes >= e->promo_min_bytes;
+                    if (!promote) { ws->learning = false; e->learning = false; }      // (the window goes on with the next batch)
+                } else relearn = adapt_after_batch(e, total, (double)(ws->h_counters->miss_short + ws->h_counters->miss_long), (double)ws->h_counters->npieces);
+                if (relearn) e->learning = true;                                     // (nothing learns while the promotions are being dropped)
             }
-            if (promote) {
-                e->long_log_n = (int64_t)std::min<unsigned long long>(ws->h_counters->long_log_count, (unsigned long long)kLongLogCap);
-                { std::lock_guard<std::mutex> lock(e->mu); ws->learning = false; }
+            if (promote || relearn) {
+                if (promote) { std::lock_guard<std::mutex> lock(e->mu); ws->learning = false; e->learn_bytes = 0; }
                 // (the workspace is this call's no longer once it returns; the counters, the log and the memo are the encoder's, and no other batch writes the
                 //  first two while e->learning is set)
                 join_promotion(e);                 // (the previous one ended before this batch could be armed: this only reaps the thread)
-                auto work = [e] {
+                auto work = [e, promote] {
                     DeviceScope scope;
-                    if (scope.enter(e->device) == hipSuccess) (void)promote_from_memo(e, true, true, nullptr);   // (a failure leaves the tables as they were)
-                    std::lock_guard<std::mutex> lock(e->mu);
-                    e->learning = false; ++e->promo_rounds;
+                    const bool dev = scope.enter(e->device) == hipSuccess;
+                    if (promote) {
+                        if (dev) (void)promote_from_memo(e, true, true, nullptr);   // (a failure leaves the tables as they were)
+                        std::lock_guard<std::mutex> lock(e->mu);
+                        e->learning = false; ++e->promo_rounds; ++e->n_promotions;
+                        e->bytes_at_install = e->bytes_seen; e->ew_valid = e->base_valid = false;
+                    } else {
+                        if (dev) (void)drop_promotions(e, true);
+                        std::lock_guard<std::mutex> lock(e->mu);
+                        e->learning = false; e->promo_rounds = 0; e->learn_bytes = 0; e->memo_clear_pending = true; ++e->n_relearns;
+                        e->bytes_at_install = e->bytes_at_promo = e->bytes_seen; e->ew_valid = e->base_valid = false;
+                    }
                 };
                 bool started = false;
                 {
@@ -1732,17 +1838,19 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
             for (Workspace* w : e->pool) if (w->busy) return fail(TKZ_E_ARG, "promotions can only be made or dropped by hand while no call of this encoder is in flight");
         }
         if (hipDeviceSynchronize() != hipSuccess) return fail(TKZ_E_DEVICE, "hipDeviceSynchronize");
-        if (value == 2) return promote_from_memo(e, false, false, nullptr);
+        // (the images these two replace are RETIRED, not freed here: the check above is not held until the new ones are in place, and a call that started in
+        //  between has taken its copy of the table descriptor -- the round-5 advisor; they go when no call is in flight, ~Lease)
+        if (value == 2) return promote_from_memo(e, false, true, nullptr);
         {
             std::lock_guard<std::mutex> lock(e->mu);
-            e->promo_items.clear(); e->promo_keys.clear(); e->promo_quads.clear(); e->promo_rounds = 0; e->bytes_at_promo = e->bytes_seen;
+            e->promo_rounds = 0; e->learn_bytes = 0; e->bytes_at_promo = e->bytes_at_install = e->bytes_seen; e->ew_valid = e->base_valid = false;
         }
-        KeyTablesImage img;
-        st = build_key_tables_image(e, {}, {}, &img);
-        if (st != TKZ_OK) return st;
-        std::lock_guard<std::mutex> lock(e->mu);
-        install_key_tables(e, img, false);
-        return TKZ_OK;
+        {
+            bool none;
+            { std::lock_guard<std::mutex> lock(e->mu); none = e->promo_items.empty(); }
+            if (none) return TKZ_OK;
+        }
+        return drop_promotions(e, true);
     }
     if (option == TKZ_OPT_PIECE_MEMO) {
         // 0: off, 1: on, 2: on and emptied.  Options are set while the encoder is idle: a call in flight on another thread reads
@@ -1761,7 +1869,23 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
         e->T.memo_n = value ? e->memo_slots : 0u;
         return TKZ_OK;
     }
+    if (option == TKZ_OPT_ADAPT) {
+        if (value != 0 && value != 1) return fail(TKZ_E_ARG, "TKZ_OPT_ADAPT takes 0 or 1");
+        std::lock_guard<std::mutex> lock(e->mu);
+        e->adapt = (int)value;
+        return TKZ_OK;
+    }
     return fail(TKZ_E_ARG, "unknown option");
+}
+
+tkz_status tkz_encoder_adapt_stats(tkz_encoder* e, int64_t* out8) {
+    if (!e || !out8) return fail(TKZ_E_ARG, "null argument");
+    join_promotion(e);                     // (the figures after whatever is being built in the background)
+    std::lock_guard<std::mutex> lock(e->mu);
+    out8[0] = e->n_promotions; out8[1] = e->n_relearns; out8[2] = (int64_t)e->promo_items.size(); out8[3] = (int64_t)e->retired.size();
+    out8[4] = e->base_valid ? (int64_t)(e->base_miss * 1e6) : -1; out8[5] = e->ew_valid ? (int64_t)(e->ew_miss * 1e6) : -1;
+    out8[6] = e->bytes_seen - e->bytes_at_install; out8[7] = e->learn_bytes;
+    return TKZ_OK;
 }
 
 tkz_status tkz_encoder_set_profiling(tkz_encoder* e, int32_t enabled) {
@@ -1821,6 +1945,45 @@ int64_t tkz_encoder_memo_bucket(const tkz_encoder* e, const uint8_t* piece, int3
     uint32_t kw[4] = {0, 0, 0, 0};
     for (int32_t i = 0; i < len; ++i) { if (!piece[i]) return -1; kw[i >> 2] |= (uint32_t)piece[i] << (8 * (i & 3)); }      // (pieces with a zero byte never use the memo)
     return (int64_t)tkz_mulhi(tkz_hash_memo(kw, (uint32_t)len), e->memo_slots / kMemoWays);
+}
+// CreateTokenizer is where a drop-in pays construction costs (TokenizerBuilder.cs:210-213), not the first Encode: the workspace of a batch of up to
+// max_bytes bytes in max_docs documents -- ~7.8 bytes per input byte -- is allocated here instead of inside the first batch call, where its hipMallocs
+// took anything from 5 ms to seconds.  Later batches of up to that size allocate nothing (lists that a miss-heavy text needs longer still grow once).
+tkz_status tkz_encoder_reserve(tkz_encoder* e, int64_t max_bytes, int64_t max_docs) {
+    using namespace tkz;
+    if (!e) return fail(TKZ_E_ARG, "null encoder");
+    if (max_bytes < 0 || max_docs < 0) return fail(TKZ_E_ARG, "negative size");
+    DeviceScope scope;
+    tkz_status st = check_encoder(e, scope);
+    if (st != TKZ_OK) return st;
+    Lease lease(e);
+    Workspace* ws = lease.ws;
+    int64_t* acc = &ws->bytes_allocated;
+    st = prepare_workspace(ws, max_bytes, max_docs, false, false);
+    if (st != TKZ_OK) return st;
+    const int64_t nwords = max_bytes / 64 + 1;
+    HIP_TRY(ws->w_xq.ensure((size_t)(nwords / kRowsPerWave + 4) * 16, acc));                      // (the o200k scanners' queues)
+    if (!ws->h_counters) HIP_TRY(hipHostMalloc((void**)&ws->h_counters, sizeof(CounterBlock), 0));
+    HIP_TRY(ensure_streams(ws));
+    {   // what the host-buffer entry points stage a chunk in (two sets: tkz_encode_batch_utf8 cuts a large batch into chunks of 32 MB)
+        const int64_t chunk = std::min<int64_t>(max_bytes, int64_t(32) << 20), cdocs = std::min<int64_t>(max_docs, std::max<int64_t>(1, chunk / 16));
+        for (int q = 0; q < 2; ++q) {
+            HIP_TRY(ws->s_bytes[q].ensure((size_t)chunk + 64, acc));
+            HIP_TRY(ws->s_offs[q].ensure((size_t)(cdocs + 1) * 8, acc));
+            HIP_TRY(ws->s_out[q].ensure((size_t)std::max<int64_t>(chunk, 1) * 4, acc));
+            HIP_TRY(ws->s_outoffs[q].ensure((size_t)(cdocs + 1) * 8, acc));
+        }
+    }
+    {   // the counters and the log of a learning window (TKZ_OPT_PROMOTE)
+        std::lock_guard<std::mutex> lock(e->mu);
+        if (e->memo_slots && e->promo_mode == 1) {
+            if (e->t_memo_hits.ensure((size_t)e->memo_slots * 4, &e->bytes_allocated) != hipSuccess ||
+                e->t_long_log.ensure((size_t)kLongLogCap * kLongLogDwords * 4 + 64, &e->bytes_allocated) != hipSuccess)
+                return fail(TKZ_E_OUT_OF_MEMORY, "learning buffers could not be allocated");
+        }
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return TKZ_OK;
 }
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) {
     if (!e) return 0;

@@ -74,6 +74,7 @@ struct EncodeParams {
     // the long misses of up to lane_piece bytes, binned by length class across the batch (large batches: k_long_count -> scan -> k_long_scatter -> k_merge_long_q).
     // lq null: the chunk form (k_merge_long).  lq_cnt / lq_base: [16 classes x chunks of 64 sub-tiles]; lq: sub-tile << 30 | list index << 20 | (len - 1) << 10 | byte in the sub-tile
     int32_t* lq_cnt; int64_t* lq_base; int64_t* lq_total; int64_t* lq_bsum; uint64_t* lq; int64_t lq_cap;
+    unsigned long long* miss_sums;   // null, or [2]: k_list_stats adds the batch's short and long misses (the sums of mcount) -- TKZ_OPT_ADAPT follows their share of the pieces
     // development builds only (make DEVPROF=1; env TKZ_DEV_ABLATE bit 4): per-phase clock counters of k_probe.  Compiled out of libtkz.so otherwise.
     unsigned long long* devprof;
     int32_t ablate;

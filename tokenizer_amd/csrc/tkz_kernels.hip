@@ -2444,15 +2444,17 @@ TKZ_KERNEL(256) void k_rebase(int64_t* offs, int64_t n, int64_t base) {
 // (... and, in the same pass over the sub-tiles, k_giant_find's: a sub-tile k_probe flagged as holding a giant piece queues it -- one launch less)
 TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t mcap, int32_t* counters,
                                   const uint8_t* heavy_flag, const uint64_t* startbits, int64_t nwords, int64_t total, int64_t* gq, unsigned long long* gcount, int64_t gcap,
-                                  const uint32_t* mlist, uint64_t* coop_q, unsigned long long* coop_count, int64_t coop_cap, int lane_piece) {
+                                  const uint32_t* mlist, uint64_t* coop_q, unsigned long long* coop_count, int64_t coop_cap, int lane_piece, unsigned long long* miss_sums) {
     const int64_t stride = simt::nblocks() * simt::nthreads();
     const int lane = simt::lane();
     int mx = 0, big = 0, over = 0;
+    long long n_short = 0, n_long = 0;       // (miss_sums: what the batch's pieces missed -- the host follows that share from batch to batch, TKZ_OPT_ADAPT)
     for (int64_t i0 = simt::bid() * simt::nthreads() + (simt::tid() & ~63); i0 < nsub; i0 += stride) {      // (wave-uniform: the queueing below is a wave scan)
         const int64_t i = i0 + lane;
         const bool in = i < nsub;
         const uint32_t m = in ? mcount[i] : 0u;
         const int n = (int)(m & 0xFFFFu) + (int)(m >> 16);
+        n_short += (int)(m & 0xFFFFu); n_long += (int)(m >> 16);
         if (n <= mcap) { if (n > mx) mx = n; } else if (n > big) big = n;
         over += n > 64 ? 1 : 0;
         const uint32_t hf = in ? heavy_flag[i] : 0u;
@@ -2486,6 +2488,13 @@ TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t 
         if (big) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&counters[1], (unsigned)big); }
         if (mx > kMissCapMin) simt::atomic_max((unsigned*)&counters[2], (unsigned)mx);
         if (tot) simt::atomic_add(&counters[3], tot);
+    }
+    if (miss_sums) {
+        // (64-bit sums over the wave by two 32-bit scans: a wavefront's share is far below 2^31)
+        int ts, tl;
+        (void)tkz_wave_scan_sum((int)n_short, &ts);
+        (void)tkz_wave_scan_sum((int)n_long, &tl);
+        if (simt::lane() == 0 && (ts | tl)) { simt::atomic_add64(&miss_sums[0], (unsigned long long)ts); simt::atomic_add64(&miss_sums[1], (unsigned long long)tl); }
     }
 }
 
@@ -2987,6 +2996,9 @@ TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
 // =================================================================================================
 static inline void hook(const Launch& L, int id, int phase) { if (L.hook) L.hook(L.hook_ctx, id, phase, L.stream); }
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// a launch needs one workgroup at least (a grid of 0 is an invalid configuration on HIP; the kernels return at once for items beyond their count):
+// an empty chunk of a host batch -- a UTF-16 document that spans a chunk cut -- has no tiles at all
+static inline int64_t grid1(int64_t g) { return g < 1 ? 1 : g; }
 static inline int64_t xcd_grid(int64_t blocks) { return (blocks + 7) & ~(int64_t)7; }     // tkz_xcd_block: XCD x takes the x-th eighth of the blocks
 static inline int64_t grid_for(int64_t items) { const int64_t g = cdiv(items, kThreads); return g < 1 ? 1 : (g > 16384 ? 16384 : g); }
 
@@ -3029,7 +3041,7 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     // (the list statistics and, in the same pass, the giant pieces of the sub-tiles k_probe flagged: queued for k_giant_order / k_giant_merge)
     { const int64_t g = grid_for(nsub); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsub, P.mcap, P.counters,
                                                      (const uint8_t*)P.heavy_flag, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap,
-                                                     (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap, (int)P.lane_piece); }
+                                                     (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap, (int)P.lane_piece, P.miss_sums); }
     hook(L, K_MERGE_SHORT, 0);
     TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
     hook(L, K_MERGE_SHORT, 1);
@@ -3072,7 +3084,7 @@ void launch_probe_sample(const Launch& L, const TkzTables& T, const EncodeParams
     hook(L, K_ENCODE, 1);
     { const int64_t g = grid_for(nsample); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsample, P.mcap, P.counters,
                                                      (const uint8_t*)P.heavy_flag, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap,
-                                                     (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap, (int)P.lane_piece); }
+                                                     (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap, (int)P.lane_piece, P.miss_sums); }
 }
 void launch_ingest(const Launch& L, const uint8_t* h_bytes, int64_t total, uint8_t* d_bytes, const int64_t* h_offs, int64_t n_offs, int64_t* d_offs, void* zero, int64_t zero_bytes) {
     const int64_t quads = std::max<int64_t>(total / 16 + 1, (zero_bytes + 15) / 16);
@@ -3112,7 +3124,7 @@ void launch_scan2(const Launch& L, int64_t ntiles, int64_t* bsum, const int32_t*
     if (cnt_b) launch_scan(L, cnt_b, ntiles, bsum, base_b, grand_b, kid, round_to_b);
 }
 void launch_scan(const Launch& L, const int32_t* tile_count, int64_t ntiles, int64_t* bsum, int64_t* tile_base, int64_t* grand, int kid, int round_to) {
-    const int64_t nblk = cdiv(ntiles, kScanBlock);
+    const int64_t nblk = grid1(cdiv(ntiles, kScanBlock));     // (no tiles: one workgroup that writes a zero sum)
     const int round = round_to > 1 ? round_to - 1 : 0;       // (round_to: a power of two)
     if (kid >= 0) hook(L, kid, 0);
     TKZ_LAUNCH(k_scan_partials, nblk, kThreads, L.stream, tile_count, ntiles, bsum, round);
@@ -3141,26 +3153,26 @@ void launch_counts3(const Launch& L, int64_t n_docs, int64_t total, const int64_
     TKZ_LAUNCH(k_counts3, 1, 64, L.stream, n_docs, total, grand, out3, out3b, out3c);
 }
 void launch_u16_len(const Launch& L, const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum) {
-    TKZ_LAUNCH(k_u16_len, cdiv(ntiles, kThreads / 64), kThreads, L.stream, units, total, docbits, ntiles, grp_prefix, tile_sum);
+    TKZ_LAUNCH(k_u16_len, grid1(cdiv(ntiles, kThreads / 64)), kThreads, L.stream, units, total, docbits, ntiles, grp_prefix, tile_sum);
 }
 void launch_u16_write(const Launch& L, const uint16_t* units, int64_t total, const uint64_t* docbits, int64_t ntiles, const int64_t* tile_base,
                       uint8_t* out, const int64_t* unit_offs, int64_t n_docs, const int32_t* grp_prefix, const int64_t* grand, int64_t* byte_offs) {
-    TKZ_LAUNCH(k_u16_write, cdiv(ntiles, kThreads / 64), kThreads, L.stream, units, total, docbits, ntiles, tile_base, out);
+    TKZ_LAUNCH(k_u16_write, grid1(cdiv(ntiles, kThreads / 64)), kThreads, L.stream, units, total, docbits, ntiles, tile_base, out);
     TKZ_LAUNCH(k_u16_docoffs, grid_for(n_docs + 1), kThreads, L.stream, units, total, docbits, unit_offs, n_docs, tile_base, grp_prefix, grand, byte_offs);
 }
 int64_t u16_tiles(int64_t total_units) { return cdiv(total_units, kU16Tile); }
 void launch_piece_index(const Launch& L, const uint64_t* startbits, int64_t nwords, int64_t total, int64_t nsub, const int64_t* ord_base,
                         int64_t n_pieces, int64_t* piece_offs, const int64_t* d_offs, int64_t n_docs, int64_t* doc_piece) {
-    TKZ_LAUNCH(k_piece_index, cdiv(nsub, kThreads / 64), kThreads, L.stream, startbits, nwords, total, nsub, ord_base, n_pieces, piece_offs);
+    TKZ_LAUNCH(k_piece_index, grid1(cdiv(nsub, kThreads / 64)), kThreads, L.stream, startbits, nwords, total, nsub, ord_base, n_pieces, piece_offs);
     TKZ_LAUNCH(k_doc_piece, grid_for(n_docs + 1), kThreads, L.stream, d_offs, n_docs, total, startbits, ord_base, n_pieces, doc_piece);
 }
 int64_t dec_tiles(int64_t total_ids) { return cdiv(total_ids, kDecTile); }
 void launch_dec_len(const Launch& L, const TkzDecodeTable& D, const int32_t* ids, int64_t total, int64_t ntiles, int32_t* grp_prefix, int32_t* tile_sum) {
-    TKZ_LAUNCH(k_dec_len, cdiv(ntiles, kThreads / 64), kThreads, L.stream, D, ids, total, ntiles, grp_prefix, tile_sum);
+    TKZ_LAUNCH(k_dec_len, grid1(cdiv(ntiles, kThreads / 64)), kThreads, L.stream, D, ids, total, ntiles, grp_prefix, tile_sum);
 }
 void launch_dec_write(const Launch& L, const TkzDecodeTable& D, const int32_t* ids, int64_t total, int64_t ntiles, const int64_t* tile_base, uint8_t* out,
                       int64_t out_cap, const int64_t* id_offs, int64_t n_docs, const int32_t* grp_prefix, const int64_t* grand, int64_t* byte_offs, int32_t* counters) {
-    TKZ_LAUNCH(k_dec_write, cdiv(ntiles, kThreads / 64), kThreads, L.stream, D, ids, total, ntiles, tile_base, out, out_cap);
+    TKZ_LAUNCH(k_dec_write, grid1(cdiv(ntiles, kThreads / 64)), kThreads, L.stream, D, ids, total, ntiles, tile_base, out, out_cap);
     TKZ_LAUNCH(k_dec_docoffs, grid_for(n_docs + 1), kThreads, L.stream, D, ids, total, id_offs, n_docs, tile_base, grp_prefix, grand, byte_offs, counters);
 }
 void launch_corpus(hipStream_t s, int kind, uint64_t seed, int64_t first_doc, int64_t n_docs, int min_len, int max_len,

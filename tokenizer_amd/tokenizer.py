@@ -107,7 +107,7 @@ class TikTokenizer:
 
     def __init__(self, tikTokenBpeFile: bytes, specialTokensEncoder: Optional[Dict[str, int]], pattern: str,
                  cacheSize: int = 8192, device: int = 0, lib: Optional[N.Library] = None, host: str = "dotnet",
-                 unicode_classes=None, case_equivalence: bool = False):
+                 unicode_classes=None, case_equivalence: bool = False, reserve_bytes: int = 0, reserve_docs: int = 0):
         """`host` names the regex engine whose reading of `pattern` is wanted: "dotnet" (the default: `new Regex(pattern,
         RegexOptions.Compiled)`, TikTokenizer.cs:77 -- UTF-16 code units, .NET's \\s) or "js" (`new RegExp(pattern, "gu")`,
         tokenizer_ts/src/tikTokenizer.ts:100 -- code points, ECMAScript's \\s; implemented for the o200k string only, the one
@@ -128,6 +128,9 @@ class TikTokenizer:
             self._encoder.set_unicode_classes(unicode_classes)
         if case_equivalence:
             self._encoder.set_option(N.OPT_CASE_EQUIVALENCE, 1)
+        # construction pays, not the first Encode (TokenizerBuilder.cs:210-213): the device workspace of batches of up to reserve_bytes / reserve_docs
+        if reserve_bytes > 0:
+            self._encoder.reserve(reserve_bytes, max(1, reserve_docs))
         # the reference's LRU piece memo (LRUCache.cs; no effect on results) lives on the device with a fixed size: cacheSize only says
         # whether it is used (the reference's LRUCache of size 0 keeps nothing)
         if cacheSize <= 0:

@@ -22,8 +22,8 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
 done
 cd $REPO
 python tools/summarize_prof.py gpurun_out/prof_$TAG > gpurun_out/prof_$TAG/summary.txt 2>&1
-KIND=1; case "$EXTRA" in *"--kind 2"*) KIND=2;; *"--kind 3"*) KIND=3;; *"--kind 4"*) KIND=4;; esac
-python tools/make_traffic_json.py gpurun_out/prof_$TAG/summary.txt $DOCS $KIND gpurun_out/prof_$TAG/traffic.json > /dev/null 2>&1
+KIND=1; case "$EXTRA" in *"--kind 2"*) KIND=2;; *"--kind 3"*) KIND=3;; *"--kind 4"*) KIND=4;; *"--kind 6"*) KIND=6;; esac
+python tools/make_traffic_json.py gpurun_out/prof_$TAG/summary.txt $DOCS $KIND gpurun_out/prof_$TAG/traffic.json gpurun_out/prof_$TAG/trace.log > /dev/null 2>&1
 cat gpurun_out/prof_$TAG/summary.txt
 # keep only the summaries small enough to merge back
 find gpurun_out/prof_$TAG -name "*.db" -delete

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
-    for k in ("k_merge_short", "k_merge_long", "k_giant_merge", "k_giant_find", "k_probe", "k_place", "k_counts3", "k_pretok_rows", "k_pretok_seq", "k_docmark", "k_docoffs", "k_scan_partials", "k_scan_top",
+    for k in ("k_merge_short", "k_merge_long", "k_long_count", "k_long_scatter", "k_merge_coop", "k_list_stats", "k_giant_order", "k_giant_merge", "k_giant_find", "k_probe", "k_place", "k_counts3", "k_pretok_rows", "k_pretok_seq", "k_docmark", "k_docoffs", "k_scan_partials", "k_scan_top",
               "k_scan_final", "k_corpus_fill", "k_corpus_lengths", "k_offsets_scan", "k_doccount"):
         if k in name:
             return k
