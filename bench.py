@@ -618,6 +618,7 @@ def main():
                 en.set_option(N.OPT_PROMOTE, 1)                     # warm: the memo kept, and what the encoder promotes out of it (two learning batches, untimed)
                 for _ in range(min(6, 2 + int((1 << 30) // max(1, r_total)))):
                     r_step("warm")
+                en.adapt_stats()                                    # (waits for the promotion being built behind the last learning batch: the timed steps meet settled tables)
                 t_warm, _ = r_timed("warm")
                 r_promoted = en.piece_stats().get("promoted_pieces_in_tables", 0)
                 en.set_option(N.OPT_PROMOTE, 0)
@@ -680,18 +681,19 @@ def main():
                             for _ in range(max(3, int((3 << 30) // max(1, first_b)))):
                                 first(e_d)                                                 # ~3 GB of the first text: learnt, promoted, settled
                             before = e_d.adapt_stats()
-                            n2 = max(4, int((3 << 30) // max(1, second_b)))
+                            n2 = max(7, int((3 << 30) // max(1, second_b)))
                             series = rate_steps(e_d, second, second_b, n2)
                             after = e_d.adapt_stats()
                             e_f = N.Encoder(N.Vocab(raw_v), pat, device=local_rank)        # ... and one that only ever sees the second text
                             fresh = rate_steps(e_f, second, second_b, n2)
                             k2gb = min(n2, max(1, int((2 << 30) // max(1, second_b))))     # steps within 2 GB of the change
-                            tail_d, tail_f = series[k2gb:] or series[-1:], fresh[k2gb:] or fresh[-1:]
+                            # (the MEDIAN of the steps beyond 2 GB: a step that happens to be a learning batch, or to run beside a promotion being built, is slower on
+                            #  either encoder and falls on different steps of the two)
+                            tail_d, tail_f = sorted(series[k2gb:] or series[-1:]), sorted(fresh[k2gb:] or fresh[-1:])
+                            med_d, med_f = tail_d[len(tail_d) // 2], tail_f[len(tail_f) // 2]
                             drift[name] = {"mbps_by_step_after_the_change": series, "mbps_by_step_fresh_encoder": fresh,
-                                           "first_call_ms": first_call.get("first_call_ms") if first_call else None,
-            "first_call": first_call,
-            "value_after_drift": round(sum(tail_d) / len(tail_d), 1), "value_fresh": round(sum(tail_f) / len(tail_f), 1),
-                                           "ratio": round((sum(tail_d) / len(tail_d)) / (sum(tail_f) / len(tail_f)), 3), "steps_within_2GB": k2gb,
+                                           "value_after_drift": med_d, "value_fresh": med_f,
+                                           "ratio": round(med_d / med_f, 3), "steps_within_2GB": k2gb,
                                            "relearns": after["relearns"] - before["relearns"], "promoted_before": before["promoted_pieces"], "promoted_after": after["promoted_pieces"],
                                            "miss_share_settled_before": before["settled_miss_share"], "miss_share_recent_after": after["recent_miss_share"]}
                             del e_d, e_f
@@ -1073,9 +1075,10 @@ def main():
                             u["unit"] = "MB/s of UTF-8 text (the input is twice that in UTF-16 code units)"
                             u["note"] = ("tkz::TikTokenizer::EncodeBatchFlatUtf16 on the same documents as std::u16strings: threaded gather of the code units into page-locked memory + ONE "
                                          "tkz_encode_batch_utf16 (chunked upload, Encoding.UTF8.GetBytes on the device); value_as_csharp: the call sequence of "
-                                         "bindings/csharp/GpuTikTokenizer.EncodeBatchFlat replayed in C++ (tests/cpp/bench_host_api.cpp) -- sub-batches of 64 M code units, two pooled "
-                                         "page-locked buffer sets, the gather of sub-batch k + 1 on all cores beside the device call of sub-batch k, the id buffer sized by the densest "
-                                         "batch seen, ids copied into arrays of exactly their number and joined; the C# file itself cannot be compiled here")
+                                         "bindings/csharp/GpuTikTokenizer.EncodeBatchFlatPinned replayed in C++ (tests/cpp/bench_host_api.cpp) -- sub-batches of 64 M code units, two "
+                                         "page-locked unit buffers, the gather of sub-batch k + 1 on all cores beside the device call of sub-batch k, every sub-batch's ids written "
+                                         "straight into ONE page-locked id buffer sized by the densest batch seen; value_as_csharp_managed_array: EncodeBatchFlat, i.e. plus a fresh "
+                                         "zero-filled int array of exactly the ids' number filled by all cores; the C# file itself cannot be compiled here")
                         host_api["note"] = ("tkz::TikTokenizer::EncodeBatchFlat on %d std::strings (include/tkz_tokenizer.hpp): threaded gather into page-locked memory + "
                                             "tkz_encode_batch_utf8 + ids left in page-locked memory; the best of %d calls" % (nh, host_api.get("reps", 0)))
                 except Exception as ex:
@@ -1114,6 +1117,8 @@ def main():
             "value_no_memo": round(job_bytes * nm_steps / dt_nomemo / 1e6, 1) if dt_nomemo else None,
             "value_warm_memo": round(job_bytes / dt_warm * args.steps / 1e6, 1) if dt_warm else None,
             "value_real_text": (real_leg.get("by_vocab", {}).get("gpt2/pattern1", {}).get("value") if real_leg else None),
+            "first_call_ms": first_call.get("first_call_ms") if first_call else None,
+            "first_call": first_call,
             "value_after_drift": ((real_leg.get("drift") or {}).get("synthetic_then_real", {}).get("value_after_drift") if real_leg else None),
             "real_text_roofline": (real_leg.get("by_vocab", {}).get("gpt2/pattern1", {}).get("roofline") if real_leg else None),
             "real_text": real_leg,
@@ -1129,6 +1134,7 @@ def main():
             "value_host_api": host_api["value"] if host_api and "value" in host_api else None,
             "value_host_api_utf16": (host_api.get("utf16") or {}).get("value") if host_api else None,
             "value_host_api_utf16_as_csharp": (host_api.get("utf16") or {}).get("value_as_csharp") if host_api else None,
+            "value_host_api_utf16_as_csharp_managed_array": (host_api.get("utf16") or {}).get("value_as_csharp_managed_array") if host_api else None,
             "host_api": host_api,
         }
         if real_meta:

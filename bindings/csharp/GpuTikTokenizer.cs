@@ -123,6 +123,19 @@ namespace Microsoft.DeepDev
         }
         public IntPtr Units(long bytes) => Ensure(ref units, ref unitsCap, bytes);
         public IntPtr Ids(long bytes) => Ensure(ref ids, ref idsCap, bytes);
+        /// <summary>A larger id buffer that still holds the first keepBytes of the old one.</summary>
+        public unsafe void GrowIdsKeeping(long keepBytes, long newBytes)
+        {
+            if (newBytes <= idsCap) return;
+            long want = newBytes + newBytes / 4 + 4096;
+            Tkz.Check(Tkz.tkz_host_alloc((UIntPtr)(ulong)want, out IntPtr p));
+            if (ids != IntPtr.Zero)
+            {
+                if (keepBytes > 0) Buffer.MemoryCopy((void*)ids, (void*)p, want, keepBytes);
+                Tkz.tkz_host_free(ids);
+            }
+            ids = p; idsCap = want;
+        }
         public void Dispose()
         {
             if (units != IntPtr.Zero) Tkz.tkz_host_free(units);
@@ -130,6 +143,27 @@ namespace Microsoft.DeepDev
             units = ids = IntPtr.Zero; unitsCap = idsCap = 0;
         }
         ~PinnedBuffers() { Dispose(); }
+    }
+
+    /// <summary>The result of GpuTikTokenizer.EncodeBatchFlatPinned: the ids of all texts in page-locked memory, text t at [Offsets[t], Offsets[t + 1]).
+    /// Owns a buffer set of the tokenizer's pool until it is disposed.</summary>
+    public sealed class FlatBatchResult : IDisposable
+    {
+        private readonly GpuTikTokenizer owner; private PinnedBuffers holder;
+        public long[] Offsets { get; }
+        public long Count => Offsets[Offsets.Length - 1];
+        public IntPtr Ids => holder != null ? holder.Ids(0) : throw new ObjectDisposedException(nameof(FlatBatchResult));
+        internal FlatBatchResult(GpuTikTokenizer owner, PinnedBuffers holder, long[] offsets) { this.owner = owner; this.holder = holder; Offsets = offsets; }
+        public unsafe int this[long i] => ((int*)Ids)[i];
+        /// <summary>The ids of text t as a managed array.</summary>
+        public unsafe int[] Text(int t)
+        {
+            long n = Offsets[t + 1] - Offsets[t];
+            var a = new int[n];
+            if (n > 0) fixed (int* dst = a) Buffer.MemoryCopy((int*)Ids + Offsets[t], dst, n * 4, n * 4);
+            return a;
+        }
+        public void Dispose() { PinnedBuffers h = System.Threading.Interlocked.Exchange(ref holder, null); if (h != null) owner.ReturnBuffers(h); }
     }
 
     public sealed class GpuTikTokenizer : ITokenizer, IDisposable
@@ -275,74 +309,25 @@ namespace Microsoft.DeepDev
                     if (start >= text.Length) break;
                 }
             }
-            // 2. the plain segments as batches of UTF-16 code units in PAGE-LOCKED memory (tkz_host_alloc; buffer sets are pooled, one set per call in
-            //    flight: concurrent EncodeBatch callers do not wait for one another -- the library leases a workspace per call as well).  The strings are
-            //    copied by all cores (Parallel.For over slices; one thread copying 10^6 strings into a fresh `new char[]` ran at 1 GB/s in the C++
-            //    stand-in of this method, tests/cpp/bench_host_api.cpp, the library behind it at 15); Encoding.UTF8.GetBytes (TikTokenizer.cs:261) is done
-            //    for the whole batch on the device by tkz_encode_batch_utf16.  A large batch goes in SUB-BATCHES of ~128 MB of code units: the gather of
-            //    sub-batch k + 1 runs while the device encodes sub-batch k (two buffer sets), as include/tkz_tokenizer.hpp's EncodeBatchFlat does.
-            int nseg = segments.Count;
-            var unitOffsets = new long[nseg + 1];
-            long total = 0;
-            for (int i = 0; i < nseg; ++i) { unitOffsets[i] = total; total += segments[i].end - segments[i].start; }
-            unitOffsets[nseg] = total;
-            var segOffsets = new long[nseg + 1];
-            var cuts = new List<int> { 0 };                                   // sub-batch k = segments [cuts[k], cuts[k + 1])
-            for (int i = 1; i < nseg; ++i)
-                if (unitOffsets[i + 1] - unitOffsets[cuts[cuts.Count - 1]] > SubBatchUnits) cuts.Add(i);
-            cuts.Add(nseg);
-            int nsub = cuts.Count - 1;
-            var chunks = new int[nsub][];
-            var chunkTokens = new long[nsub];
-            var sets = new PinnedBuffers[] { RentBuffers(), nsub > 1 ? RentBuffers() : null };
+            // 2. the plain segments through the device (EncodeSegments below: page-locked buffers, sub-batches, the gather ahead of the device call); the ids
+            //    arrive in ONE page-locked buffer and leave it as a managed array of exactly their number -- `new int[]` is zero-filled by the runtime and
+            //    then written: on a million texts that copy is the larger part of this method's time, which is why EncodeBatchFlatPinned exists
+            var segOffsets = new long[segments.Count + 1];
+            int[] ids;
+            PinnedBuffers holder = EncodeSegments(segments, segOffsets);
             try
             {
-                System.Threading.Tasks.Task pending = null;
-                for (int k = 0; k < nsub; ++k)
+                long n = segOffsets[segments.Count];
+                ids = new int[Math.Max(1, n)];
+                IntPtr src = holder.Ids(0);
+                int parts = (int)Math.Max(1, Math.Min(Environment.ProcessorCount, n >> 20));     // (first touch of a fresh array: page faults, spread over the cores)
+                System.Threading.Tasks.Parallel.For(0, parts, part =>
                 {
-                    PinnedBuffers set = sets[k & 1];                          // (last used by sub-batch k - 2, whose call has been waited for)
-                    int lo = cuts[k], hi = cuts[k + 1], n = hi - lo;
-                    long u0 = unitOffsets[lo], nu = unitOffsets[hi] - u0;
-                    IntPtr unitsPtr = set.Units((nu + 32) * 2);               // (an IntPtr: a lambda cannot capture a pointer-typed local)
-                    int slices = Math.Max(1, Math.Min(Environment.ProcessorCount, n / 4096));
-                    System.Threading.Tasks.Parallel.For(0, slices, sl =>
-                    {
-                        char* dstUnits = (char*)unitsPtr;
-                        int a = lo + (int)((long)n * sl / slices), b = lo + (int)((long)n * (sl + 1) / slices);
-                        for (int i = a; i < b; ++i)
-                        {
-                            int len = segments[i].end - segments[i].start;
-                            if (len == 0) continue;
-                            fixed (char* src = segments[i].text)
-                                Buffer.MemoryCopy(src + segments[i].start, dstUnits + (unitOffsets[i] - u0), (long)len * 2, (long)len * 2);
-                        }
-                    });
-                    if (pending != null) pending.Wait();                      // the device call of sub-batch k - 1 (its exception surfaces here)
-                    int kk = k;
-                    pending = System.Threading.Tasks.Task.Run(() => EncodeSubBatch(set, unitsPtr, unitOffsets, lo, n, nu, segOffsets, chunks, chunkTokens, kk));
-                }
-                if (pending != null) pending.Wait();
+                    long lo = n * part / parts, hi = n * (part + 1) / parts;
+                    fixed (int* dst = ids) Buffer.MemoryCopy((int*)src + lo, dst + lo, (hi - lo) * 4, (hi - lo) * 4);
+                });
             }
-            finally
-            {
-                ReturnBuffers(sets[0]);
-                if (sets[1] != null) ReturnBuffers(sets[1]);
-            }
-            // the ids of sub-batch k follow those of k - 1: offsets become global, the chunks one array of exactly the ids' number
-            int[] ids;
-            if (nsub == 1) ids = chunks[0];
-            else
-            {
-                long sum = 0;
-                for (int k = 0; k < nsub; ++k)
-                {
-                    for (int i = cuts[k] + 1; i <= cuts[k + 1]; ++i) segOffsets[i] += sum;
-                    sum += chunkTokens[k];
-                }
-                ids = new int[Math.Max(1, sum)];
-                long w0 = 0;
-                for (int k = 0; k < nsub; ++k) { Array.Copy(chunks[k], 0, ids, w0, chunkTokens[k]); w0 += chunkTokens[k]; }
-            }
+            finally { ReturnBuffers(holder); }
             if (plain) return (ids, segOffsets);
             // 3. splice the special ids in: block copies of the segments' id ranges
             long nSpecial = 0;
@@ -371,23 +356,89 @@ namespace Microsoft.DeepDev
             if (disposed) throw new ObjectDisposedException(nameof(GpuTikTokenizer));
             return bufferPool.TryTake(out PinnedBuffers b) ? b : new PinnedBuffers();
         }
-        private void ReturnBuffers(PinnedBuffers b)
+        internal void ReturnBuffers(PinnedBuffers b)
         {
             if (disposed) { b.Dispose(); GC.SuppressFinalize(b); } else bufferPool.Add(b);
         }
-        // One device call: the n segments from `lo` on, nu code units at unitsPtr; fills segOffsets[lo + 1 .. lo + n] (relative to this sub-batch's
-        // first id) and chunks[k] with the ids.  A code unit is at most three UTF-8 bytes and a token at least one byte, so 3 * nu ids always suffice;
-        // English text has a token per ~4 units and CJK text about one per unit: the buffer gets room for what the densest batch so far needed (+ 10 %),
-        // a token per two units at least, and the call is repeated with the exact count (TKZ_E_CAPACITY = -4 reports it) only when that was not
-        // enough -- once in a tokenizer's life per kind of text, not once per batch.
-        private unsafe void EncodeSubBatch(PinnedBuffers set, IntPtr unitsPtr, long[] unitOffsets, int lo, int n, long nu, long[] segOffsets, int[][] chunks, long[] chunkTokens, int k)
+
+        /// <summary>The plain segments as batches of UTF-16 code units in PAGE-LOCKED memory (tkz_host_alloc; buffer sets are pooled, one per call in flight:
+        /// concurrent EncodeBatch callers do not wait for one another -- the library leases a workspace per call as well).  The strings are copied by all
+        /// cores (Parallel.For over slices); Encoding.UTF8.GetBytes (TikTokenizer.cs:261) is done for the whole batch on the device by
+        /// tkz_encode_batch_utf16.  A large batch goes in SUB-BATCHES of ~128 MB of code units: the gather of sub-batch k + 1 runs while the device encodes
+        /// sub-batch k (two unit buffers), as include/tkz_tokenizer.hpp's EncodeBatchFlat does.  Every sub-batch's ids are written by the device call straight
+        /// behind those of the one before, into ONE page-locked buffer: the returned set's Ids(0), segOffsets[segments.Count] of them; segOffsets are global.
+        /// The caller gives the returned set back with ReturnBuffers.</summary>
+        private unsafe PinnedBuffers EncodeSegments(List<(string text, int start, int end)> segments, long[] segOffsets)
+        {
+            int nseg = segments.Count;
+            var unitOffsets = new long[nseg + 1];
+            long total = 0;
+            for (int i = 0; i < nseg; ++i) { unitOffsets[i] = total; total += segments[i].end - segments[i].start; }
+            unitOffsets[nseg] = total;
+            var cuts = new List<int> { 0 };                                   // sub-batch k = segments [cuts[k], cuts[k + 1])
+            for (int i = 1; i < nseg; ++i)
+                if (unitOffsets[i + 1] - unitOffsets[cuts[cuts.Count - 1]] > SubBatchUnits) cuts.Add(i);
+            cuts.Add(nseg);
+            int nsub = cuts.Count - 1;
+            // A code unit is at most three UTF-8 bytes and a token at least one byte, so 3 * total ids always suffice; English text has a token per ~4 units
+            // and CJK text about one per unit: the buffer gets room for what the densest batch so far needed (+ 10 %), a token per two units at least, and
+            // grows -- keeping what is in it -- when a sub-batch reports TKZ_E_CAPACITY (-4): once in a tokenizer's life per kind of text, not once per batch.
+            long learnt = (long)((double)total * (System.Threading.Interlocked.Read(ref tokensPerUnitQ20) / 1048576.0) * 1.1);
+            long cap = Math.Max(1, Math.Min(3 * total, Math.Max(total / 2 + 4096, learnt)));
+            PinnedBuffers holder = RentBuffers();                             // its Units: sub-batches 0, 2, 4 ...; its Ids: the whole batch's
+            PinnedBuffers second = nsub > 1 ? RentBuffers() : null;           // its Units: sub-batches 1, 3, 5 ...
+            bool ok = false;
+            try
+            {
+                holder.Ids(cap * 4);
+                long[] state = { 0, cap };                                    // ids so far; capacity of the id buffer (both only touched by the one device call in flight)
+                System.Threading.Tasks.Task pending = null;
+                for (int k = 0; k < nsub; ++k)
+                {
+                    PinnedBuffers set = (k & 1) == 0 ? holder : second;       // (its Units were last read by sub-batch k - 2, whose call has been waited for)
+                    int lo = cuts[k], hi = cuts[k + 1], n = hi - lo;
+                    long u0 = unitOffsets[lo], nu = unitOffsets[hi] - u0;
+                    IntPtr unitsPtr = set.Units((nu + 32) * 2);               // (an IntPtr: a lambda cannot capture a pointer-typed local)
+                    int slices = Math.Max(1, Math.Min(Environment.ProcessorCount, n / 4096));
+                    System.Threading.Tasks.Parallel.For(0, slices, sl =>
+                    {
+                        char* dstUnits = (char*)unitsPtr;
+                        int a = lo + (int)((long)n * sl / slices), b = lo + (int)((long)n * (sl + 1) / slices);
+                        for (int i = a; i < b; ++i)
+                        {
+                            int len = segments[i].end - segments[i].start;
+                            if (len == 0) continue;
+                            fixed (char* src = segments[i].text)
+                                Buffer.MemoryCopy(src + segments[i].start, dstUnits + (unitOffsets[i] - u0), (long)len * 2, (long)len * 2);
+                        }
+                    });
+                    if (pending != null) pending.Wait();                      // the device call of sub-batch k - 1 (its exception surfaces here)
+                    pending = System.Threading.Tasks.Task.Run(() => EncodeSubBatch(holder, unitsPtr, unitOffsets, lo, n, nu, total - u0, segOffsets, state));
+                }
+                if (pending != null) pending.Wait();
+                if (total > 0)
+                {
+                    long q = (long)((double)state[0] / total * 1048576.0), seen;
+                    while ((seen = System.Threading.Interlocked.Read(ref tokensPerUnitQ20)) < q &&
+                           System.Threading.Interlocked.CompareExchange(ref tokensPerUnitQ20, q, seen) != seen) { }
+                }
+                ok = true;
+                return holder;
+            }
+            finally
+            {
+                if (second != null) ReturnBuffers(second);
+                if (!ok) ReturnBuffers(holder);
+            }
+        }
+        // One device call: the n segments from `lo` on, nu code units at unitsPtr, their ids behind the state[0] ids already in holder's id buffer
+        // (capacity state[1]); fills segOffsets[lo + 1 .. lo + n] (global) and advances state[0].  unitsLeft: code units from this sub-batch to the batch's end.
+        private unsafe void EncodeSubBatch(PinnedBuffers holder, IntPtr unitsPtr, long[] unitOffsets, int lo, int n, long nu, long unitsLeft, long[] segOffsets, long[] state)
         {
             var rel = new long[n + 1];
             long u0 = unitOffsets[lo];
             for (int i = 0; i <= n; ++i) rel[i] = unitOffsets[lo + i] - u0;
             var outOffs = new long[n + 1];
-            long learnt = (long)((double)nu * (System.Threading.Interlocked.Read(ref tokensPerUnitQ20) / 1048576.0) * 1.1);
-            long cap = Math.Max(1, Math.Min(3 * nu, Math.Max(nu / 2 + 4096, learnt)));
             long needed;
             bool held = false;
             try
@@ -395,28 +446,39 @@ namespace Microsoft.DeepDev
                 handle.DangerousAddRef(ref held);                                // (Dispose on another thread: the native encoder outlives this call)
                 while (true)
                 {
-                    int* pi = (int*)set.Ids(cap * 4);
+                    long done = state[0], room = state[1] - done;
+                    int* pi = (int*)holder.Ids(0) + done;
                     int st;
                     fixed (long* po = rel) fixed (long* poo = outOffs)
-                        st = Tkz.tkz_encode_batch_utf16(encoder, (char*)unitsPtr, po, n, pi, cap, poo, out needed);
-                    if (st == -4 && needed > cap) { cap = needed; continue; }
+                        st = Tkz.tkz_encode_batch_utf16(encoder, (char*)unitsPtr, po, n, pi, room, poo, out needed);
+                    if (st == -4 && needed > room)
+                    {   // this sub-batch needs `needed`; what follows it, at the same density at least
+                        long want = done + needed + (long)((double)needed / Math.Max(1, nu) * (unitsLeft - nu) * 1.1) + 4096;
+                        holder.GrowIdsKeeping(done * 4, want * 4);
+                        state[1] = want;
+                        continue;
+                    }
                     Tkz.Check(st);
                     break;
                 }
             }
             finally { if (held) handle.DangerousRelease(); }
-            if (nu > 0)
-            {
-                long q = (long)((double)needed / nu * 1048576.0), seen;
-                while ((seen = System.Threading.Interlocked.Read(ref tokensPerUnitQ20)) < q &&
-                       System.Threading.Interlocked.CompareExchange(ref tokensPerUnitQ20, q, seen) != seen) { }
-            }
-            var mine = new int[Math.Max(1, needed)];                             // the ids leave the page-locked buffer as an array of exactly their number
-            fixed (int* dst = mine) Buffer.MemoryCopy((void*)set.Ids(0), dst, needed * 4, needed * 4);
-            chunks[k] = mine; chunkTokens[k] = needed;
-            for (int i = 1; i <= n; ++i) segOffsets[lo + i] = outOffs[i];
-            GC.KeepAlive(set);                                                   // (the buffers' finalizer must not run while the native call reads them)
+            for (int i = 1; i <= n; ++i) segOffsets[lo + i] = state[0] + outOffs[i];
+            state[0] += needed;
+            GC.KeepAlive(holder);                                                // (the buffers' finalizer must not run while the native call reads them)
             GC.KeepAlive(this);
+        }
+
+        /// <summary>EncodeBatchFlat with the ids LEFT in page-locked memory (no special tokens: the reference's plain path, TikTokenizer.cs:180-183): text t is
+        /// ids [Offsets[t], Offsets[t + 1]) of the result.  Nothing is copied after the device has written the ids -- on a million texts the managed
+        /// `int[]` of EncodeBatchFlat (zero-filled by the runtime, then written) costs more than the encoding.  Dispose the result to give the buffers back.</summary>
+        public FlatBatchResult EncodeBatchFlatPinned(IReadOnlyList<string> texts)
+        {
+            var segments = new List<(string text, int start, int end)>(texts.Count);
+            for (int t = 0; t < texts.Count; ++t) segments.Add((texts[t], 0, texts[t].Length));
+            var offsets = new long[texts.Count + 1];
+            PinnedBuffers holder = EncodeSegments(segments, offsets);
+            return new FlatBatchResult(this, holder, offsets);
         }
 
         // One item per regex piece of every plain segment and one per special token, in order: its ids and its length in

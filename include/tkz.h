@@ -308,8 +308,9 @@ enum { TKZ_OPT_PRETOK_SEQUENTIAL = 1,
         * tables as a whole (counted by a kernel that runs anyway); when that share has left the level at which it settled after the last promotion -- by
         * more than a quarter and a percentage point, either way, 256 MB of text or more after it -- the encoder learns again: every promotion is dropped
         * (so a piece that stopped hitting is not chosen again), the memo is emptied (while no other call is in flight), the next learning window counts
-        * hits and the hottest pieces of the text as it is now are promoted.  Also with it on, batches smaller than TKZ_OPT_PROMOTE_MIN_BYTES add up to a
-        * learning window instead of never learning.  0: learn in the first batch of at least that size and once more a gigabyte later, never again
+        * hits and the hottest pieces of the text as it is now are promoted.  Also with it on: the learning rounds go on (1, 2, 4, 8 ... GB apart: a change
+        * of text that does not move the miss share is still learnt; a round only adds pieces, a list that reaches its cap starts over), and batches smaller
+        * than TKZ_OPT_PROMOTE_MIN_BYTES add up to a learning window instead of never learning.  0: learn in the first batch of at least that size and once more a gigabyte later, never again
         * (round 5's behaviour).  Same ids either way. */
        TKZ_OPT_ADAPT = 9 };
 tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value);

@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
         // ---- the same documents as UTF-16 strings (what a .NET host holds): tkz::TikTokenizer::EncodeBatchFlatUtf16 (page-locked buffers, threaded
         // gather, ONE tkz_encode_batch_utf16 call), and the calls bindings/csharp/GpuTikTokenizer.EncodeBatchFlat makes, as it makes them (below).  The rate
         // is counted in UTF-8 bytes, so that it compares with the figures above.
-        double best16 = 0, best16_cs = 0;
+        double best16 = 0, best16_cs = 0, best16_cs_managed = 0;
         uint64_t sum16 = 0, sum16_cs = 0;
         int64_t ntok16 = 0, ntok16_cs = 0;
         {
@@ -84,17 +84,18 @@ int main(int argc, char** argv) {
             }
             ntok16 = fb16.n_ids();
             for (int64_t i = 0; i < fb16.n_ids(); ++i) sum16 += (static_cast<uint64_t>(static_cast<uint32_t>(fb16.ids()[i])) + 1) * (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull + 1);
-            // as the C# class does it (bindings/csharp/GpuTikTokenizer.EncodeBatchFlat, round 6), call for call: sub-batches of 64 M code units, two page-locked
-            // buffer sets, the strings of sub-batch k + 1 copied by `gather` threads (Parallel.For over slices) while a task runs tkz_encode_batch_utf16 on
-            // sub-batch k, the id buffer sized by the densest batch seen so far, every sub-batch's ids copied into a fresh array of exactly their number and the
-            // arrays joined at the end (the C# method returns a managed int[]).  Warm: the first call has sized the buffers, as a tokenizer's second batch finds them.
+            // as the C# class does it (bindings/csharp/GpuTikTokenizer, round 6), call for call -- EncodeSegments: sub-batches of 64 M code units, two page-locked
+            // unit buffers, the strings of sub-batch k + 1 copied by `gather` threads (Parallel.For over slices) while a task runs tkz_encode_batch_utf16 on
+            // sub-batch k, every sub-batch's ids written by the device call straight behind those of the one before into ONE page-locked id buffer sized by the
+            // densest batch seen so far.  `pinned` = EncodeBatchFlatPinned (the ids stay there); `managed` = EncodeBatchFlat: a fresh zero-filled array of exactly
+            // the ids' number, filled by all cores (what `new int[n]` + Buffer.MemoryCopy under Parallel.For cost).  Warm: a tokenizer's second batch.
             {
                 const int64_t kSubUnits = int64_t(64) << 20;
                 const size_t nseg = t16.size();
                 const unsigned hw = std::thread::hardware_concurrency();
-                tkz::PinnedBuffer set_units[2], set_ids[2];
+                tkz::PinnedBuffer set_units[2], all_ids;
                 double tokens_per_unit = 0;
-                std::vector<int32_t> joined;
+                for (int managed = 0; managed < 2; ++managed)
                 for (int r = 0; r < reps + 1; ++r) {
                     const auto t0 = std::chrono::steady_clock::now();
                     std::vector<int64_t> uo(nseg + 1, 0), so(nseg + 1, 0);
@@ -105,8 +106,9 @@ int main(int argc, char** argv) {
                     for (size_t i = 1; i < nseg; ++i) if (uo[i + 1] - uo[cuts.back()] > kSubUnits) cuts.push_back(i);
                     cuts.push_back(nseg);
                     const size_t nsub = cuts.size() - 1;
-                    std::vector<std::vector<int32_t>> chunks(nsub);
-                    std::vector<int64_t> chunk_tokens(nsub, 0);
+                    int64_t cap = std::max<int64_t>(1, std::min<int64_t>(3 * tu, std::max<int64_t>(tu / 2 + 4096, static_cast<int64_t>(static_cast<double>(tu) * tokens_per_unit * 1.1))));
+                    all_ids.ensure(static_cast<size_t>(cap) * 4);
+                    int64_t done = 0;
                     std::future<void> pending;
                     for (size_t k = 0; k < nsub; ++k) {
                         const size_t lo = cuts[k], hi = cuts[k + 1], n = hi - lo;
@@ -123,38 +125,50 @@ int main(int argc, char** argv) {
                             for (auto& th : pool) th.join();
                         }
                         if (pending.valid()) pending.get();
-                        pending = std::async(std::launch::async, [&, k, lo, n, u0, nu, units] {
+                        pending = std::async(std::launch::async, [&, lo, n, u0, nu, units] {
                             std::vector<int64_t> rel(n + 1), oo(n + 1, 0);
                             for (size_t i = 0; i <= n; ++i) rel[i] = uo[lo + i] - u0;
-                            int64_t cap = std::max<int64_t>(1, std::min<int64_t>(3 * nu, std::max<int64_t>(nu / 2 + 4096, static_cast<int64_t>(static_cast<double>(nu) * tokens_per_unit * 1.1))));
                             int64_t needed = 0;
                             for (;;) {
-                                int32_t* ids = static_cast<int32_t*>(set_ids[k & 1].ensure(static_cast<size_t>(cap) * 4));
-                                const tkz_status st = tkz_encode_batch_utf16(tok.native(), units, rel.data(), static_cast<int64_t>(n), ids, cap, oo.data(), &needed);
-                                if (st == TKZ_E_CAPACITY && needed > cap) { cap = needed; continue; }
+                                const tkz_status st = tkz_encode_batch_utf16(tok.native(), units, rel.data(), static_cast<int64_t>(n), all_ids.as<int32_t>() + done, cap - done, oo.data(), &needed);
+                                if (st == TKZ_E_CAPACITY && needed > cap - done) {          // (GrowIdsKeeping: a larger buffer that keeps what is there)
+                                    const int64_t want = done + needed + static_cast<int64_t>(static_cast<double>(needed) / static_cast<double>(std::max<int64_t>(1, nu)) * static_cast<double>(tu - u0 - nu) * 1.1) + 4096;
+                                    std::vector<int32_t> keep(all_ids.as<int32_t>(), all_ids.as<int32_t>() + done);
+                                    all_ids.ensure(static_cast<size_t>(want) * 4);
+                                    std::memcpy(all_ids.as<int32_t>(), keep.data(), keep.size() * 4);
+                                    cap = want;
+                                    continue;
+                                }
                                 tkz::check(st);
                                 break;
                             }
-                            if (nu > 0) tokens_per_unit = std::max(tokens_per_unit, static_cast<double>(needed) / static_cast<double>(nu));
-                            chunks[k].assign(set_ids[k & 1].as<int32_t>(), set_ids[k & 1].as<int32_t>() + needed);
-                            chunk_tokens[k] = needed;
-                            for (size_t i = 1; i <= n; ++i) so[lo + i] = oo[i];
+                            for (size_t i = 1; i <= n; ++i) so[lo + i] = done + oo[i];
+                            done += needed;
                         });
                     }
                     if (pending.valid()) pending.get();
-                    int64_t sum = 0;
-                    for (size_t k = 0; k < nsub; ++k) { for (size_t i = cuts[k] + 1; i <= cuts[k + 1]; ++i) so[i] += sum; sum += chunk_tokens[k]; }
-                    if (nsub == 1) joined.swap(chunks[0]);
-                    else { joined.resize(static_cast<size_t>(sum)); int64_t w = 0; for (size_t k = 0; k < nsub; ++k) { std::memcpy(joined.data() + w, chunks[k].data(), static_cast<size_t>(chunk_tokens[k]) * 4); w += chunk_tokens[k]; } }
+                    if (tu > 0) tokens_per_unit = std::max(tokens_per_unit, static_cast<double>(done) / static_cast<double>(tu));
+                    std::vector<int32_t> arr;
+                    if (managed) {                                                       // ids = new int[n] (zero-filled) + Parallel.For of Buffer.MemoryCopy
+                        arr.assign(static_cast<size_t>(std::max<int64_t>(1, done)), 0);
+                        const size_t parts = static_cast<size_t>(std::max<int64_t>(1, std::min<int64_t>(hw ? hw : 1, done >> 20)));
+                        std::vector<std::thread> pool;
+                        for (size_t pt = 0; pt < parts; ++pt)
+                            pool.emplace_back([&, pt] {
+                                const int64_t a = done * static_cast<int64_t>(pt) / static_cast<int64_t>(parts), b = done * static_cast<int64_t>(pt + 1) / static_cast<int64_t>(parts);
+                                std::memcpy(arr.data() + a, all_ids.as<int32_t>() + a, static_cast<size_t>(b - a) * 4);
+                            });
+                        for (auto& th : pool) th.join();
+                    }
                     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                    if (r > 0) best16_cs = std::max(best16_cs, static_cast<double>(total) / s / 1e6);
+                    if (r > 0) (managed ? best16_cs_managed : best16_cs) = std::max(managed ? best16_cs_managed : best16_cs, static_cast<double>(total) / s / 1e6);
                     ntok16_cs = so[nseg];
                 }
-                for (int64_t i = 0; i < ntok16_cs; ++i) sum16_cs += (static_cast<uint64_t>(static_cast<uint32_t>(joined[static_cast<size_t>(i)])) + 1) * (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull + 1);
+                for (int64_t i = 0; i < ntok16_cs; ++i) sum16_cs += (static_cast<uint64_t>(static_cast<uint32_t>(all_ids.as<int32_t>()[i])) + 1) * (static_cast<uint64_t>(i) * 0x9E3779B97F4A7C15ull + 1);
             }
         }
-        std::printf("{\"utf16\": {\"value\": %.1f, \"value_as_csharp\": %.1f, \"tokens\": %lld, \"ids_checksum\": \"%016llx\", \"as_csharp_same_ids\": %s}, ",
-                    best16, best16_cs, static_cast<long long>(ntok16), static_cast<unsigned long long>(sum16), ntok16_cs == ntok16 && sum16_cs == sum16 ? "true" : "false");
+        std::printf("{\"utf16\": {\"value\": %.1f, \"value_as_csharp\": %.1f, \"value_as_csharp_managed_array\": %.1f, \"tokens\": %lld, \"ids_checksum\": \"%016llx\", \"as_csharp_same_ids\": %s}, ",
+                    best16, best16_cs, best16_cs_managed, static_cast<long long>(ntok16), static_cast<unsigned long long>(sum16), ntok16_cs == ntok16 && sum16_cs == sum16 ? "true" : "false");
         std::printf("\"value\": %.1f, \"unit\": \"MB/s\", \"docs\": %lld, \"bytes\": %lld, \"tokens\": %lld, \"ids_checksum\": \"%016llx\", \"gather_threads\": %d, \"reps\": %d, \"ms\": {\"call\": %.2f, \"offsets_pass\": %.2f, \"waiting_for_gather\": %.2f, \"in_tkz_encode_batch_utf8\": %.2f}}\n",
                     best, static_cast<long long>(texts.size()), static_cast<long long>(total), static_cast<long long>(fb.n_ids()),
                     static_cast<unsigned long long>(sum), threads, reps, static_cast<double>(total) / best / 1e3, b_off, b_wait, b_enc);

@@ -534,6 +534,7 @@ bool adapt_after_batch(tkz_encoder* e, int64_t total, double misses, double piec
         return false;
     }
     if (since < kAdaptMinBytes) return false;
+    if (e->promo_items.size() * 10 >= e->promo_cap * 9) return true;     // the list is (nearly) full of what the rounds have added: start over from the text as it is now
     return e->ew_miss > e->base_miss * 1.25 + 0.01 || e->ew_miss < e->base_miss * 0.75 - 0.01;
 }
 
@@ -665,9 +666,13 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             // LEARNING: the first batches of documents on the batch path (and once more, kPromoSecondBytes later; and again whenever the text has drifted:
             // adapt_after_batch below) count the memo's hits per slot.  A learning WINDOW is promo_min_bytes of text: one large batch, or -- TKZ_OPT_ADAPT --
             // as many smaller ones as it takes (a caller whose batches are 1 MB learns too).
-            if (attempt == 0 && !ws->learning && pretok && !d_bitmap_only && e->promo_mode == 1 && !e->learning && e->promo_rounds < kPromoAutoRounds &&
+            // (TKZ_OPT_ADAPT: the rounds go on -- a gigabyte after the first window began, then two, four, eight ... gigabytes after the one before: text that
+            //  changed without moving the miss share, or right behind a promotion, is still learnt, a round costs one batch that counts hits and ~50 ms of a
+            //  host thread; pieces are only ever ADDED by a round -- what empties the list is a drift, or the list reaching its cap: adapt_after_batch)
+            const int64_t round_gap = kPromoSecondBytes << std::min(std::max(e->promo_rounds - 1, 0), 20);
+            if (attempt == 0 && !ws->learning && pretok && !d_bitmap_only && e->promo_mode == 1 && !e->learning && (e->adapt || e->promo_rounds < kPromoAutoRounds) &&
                 e->T.memo_n != 0 && e->T.max_rank < (int32_t)kPromoFlag && (e->adapt || total >= e->promo_min_bytes) && e->promo_items.size() < e->promo_cap &&
-                (e->promo_rounds == 0 || e->bytes_seen - e->bytes_at_promo >= kPromoSecondBytes)) {
+                (e->promo_rounds == 0 || e->bytes_seen - e->bytes_at_promo >= round_gap)) {
                 // (the gigabyte to the second round counts from the START of the first learning window: a job of 5 GB batches learns in its first two)
                 // The memo is emptied for a window that follows a drift -- it is full of the old text's pieces and takes no new ones --, and that only while
                 // no OTHER call is in flight: an entry never changes once it is valid (tkz_tables.h), which is what makes a hit exact, so the table is
@@ -820,6 +825,10 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             const double w = h[0] ? (double)h[0] : 1.0;
             fprintf(stderr, "[tkz devprof] k_probe waves %llu  clock ticks/wave: total %.0f  load+compact %.0f  short batches %.0f  mid batches %.0f | mid pieces/wave %.1f pieces/wave %.1f\n",
                     h[0], h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[5] / w, h[6] / w);
+            if (h[51]) fprintf(stderr, "[tkz devprof] k_probe lane-cycle table, per sub-tile: load+compact %.0f ticks (64 lanes) | 13+-byte pre-pass %.0f ticks, %.1f pieces in %.2f passes of 64 (lane use %.3f) | main loop: first bucket %.0f ticks at lane use %.3f (%.2f batches of 64, %.1f pieces), second bucket %.0f ticks for %.1f lanes (%.3f of the lanes of the iterations that run it: %.2f of %.2f iterations), records and lists %.0f ticks at lane use %.3f\n",
+                               h[2] / w, h[4] / w, h[5] / w, (double)((h[5] + 63 * h[0]) / 64) / w, h[5] ? (double)h[5] / (64.0 * (double)((h[5] + 63 * h[0]) / 64)) : 0.0,
+                               h[48] / w, (double)h[52] / (64.0 * (double)h[51]), h[51] / w, h[52] / w, h[49] / w, h[53] / w, h[54] ? (double)h[53] / (128.0 * (double)h[54]) : 0.0, h[54] / w, (double)((h[51] + 1) / 2) / w,
+                               h[50] / w, (double)h[52] / (64.0 * (double)h[51]));
             if (h[8]) fprintf(stderr, "[tkz devprof] k_giant_merge pieces %llu  clock ticks/piece: rounds in global memory %.0f  the tail %.0f | bytes/piece %.0f tokens/piece %.0f | slowest piece %llu ticks | global rounds/piece %.2f | parts/piece when the tail took over %.0f\n",
                               h[8], (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[12] / h[8], h[13], (double)h[14] / h[8], (double)h[7] / h[8]);
             if (h[8]) fprintf(stderr, "[tkz devprof] slowest giant piece: %llu bytes -> %llu tokens, global rounds %llu (%llu ticks), bytes first/middle/last %02llx %02llx %02llx\n",

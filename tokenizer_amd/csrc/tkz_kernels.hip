@@ -611,26 +611,12 @@ TKZ_DEV uint32_t tkz_key_dword(const uint32_t* s_bytes, int s, int len, int i) {
 }
 
 // LDS of one wavefront of the probe stage (+ the mask table, shared by the workgroup)
-// (TKZ_PROBE_B2_COMPACT: development A/B, round 5, NOT the shipped form -- the second-bucket pass of the two batches of an iteration compacted into one:
-//  the lanes that need it, ~10 of 64 a batch, park key, length and hash in LDS by ordinal, the first lanes look them up, the ranks go back the same way.
-//  32 entries a pass keep the workgroup's LDS at eight wavefronts per SIMD; more unresolved lanes than that take the two-pass form.  DESIGN.md 6.1.)
-#ifdef TKZ_PROBE_B2_COMPACT
-constexpr int kProbeB2 = 32, kProbeB2Bytes = kProbeB2 * (16 + 4 + 4);
-#else
-constexpr int kProbeB2Bytes = 0;
-#endif
-constexpr int kProbeLdsBytes = kProbeB2Bytes + (kSub + kHalo) + 2 * (kSub + 2) + 2 * kMidMax + 4 * kMidMax + 4 * (kSub / 32);     // per wavefront; a multiple of 4
+constexpr int kProbeLdsBytes = (kSub + kHalo) + 2 * (kSub + 2) + 2 * kMidMax + 4 * kMidMax + 4 * (kSub / 32);     // per wavefront; a multiple of 4
 constexpr int kProbeLdsQuads = (kProbeLdsBytes + 15) / 16;
-struct ProbeLds { uint32_t* bytes; uint16_t* pstart; uint16_t* mid; uint32_t* midres; uint32_t* mark; const uint4* kmask; uint4* b2key; uint32_t* b2hs; uint32_t* b2res; };
+struct ProbeLds { uint32_t* bytes; uint16_t* pstart; uint16_t* mid; uint32_t* midres; uint32_t* mark; const uint4* kmask; };
 TKZ_DEV ProbeLds tkz_probe_lds(uint4* wave_quads, const uint4* kmask) {
     ProbeLds L;
     uint8_t* b = reinterpret_cast<uint8_t*>(wave_quads);
-    L.b2key = nullptr; L.b2hs = nullptr; L.b2res = nullptr;
-#ifdef TKZ_PROBE_B2_COMPACT
-    L.b2key = reinterpret_cast<uint4*>(b); b += 16 * kProbeB2;
-    L.b2hs = reinterpret_cast<uint32_t*>(b); b += 4 * kProbeB2;
-    L.b2res = reinterpret_cast<uint32_t*>(b); b += 4 * kProbeB2;
-#endif
     L.bytes = reinterpret_cast<uint32_t*>(b); b += kSub + kHalo;
     L.midres = reinterpret_cast<uint32_t*>(b); b += 4 * kMidMax;
     L.mark = reinterpret_cast<uint32_t*>(b); b += 4 * (kSub / 32);
@@ -800,6 +786,15 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
     int promo_extra = 0;                                   // tokens beyond one per piece that the promoted pieces of this sub-tile stand for (P.pextra): this lane's share
     bool giant = false, coopl = false;                     // coopl: a long miss of more than kLanePiece bytes (k_merge_coop's: bit 2 of the sub-tile's flag)
     constexpr int U = TKZ_PROBE_U;                         // batches of 64 pieces whose gathers are in flight together
+#ifdef TKZ_DEVPROF
+    // (development counters: where the main loop's ticks go and how many lanes each part has switched on -- the lane-cycle table of DESIGN.md 3)
+    long long pf_first = 0, pf_second = 0, pf_emit = 0, pf_t = 0;
+    int pf_batches = 0, pf_valid = 0, pf_want2 = 0, pf_iters2 = 0;
+#define TKZ_PROBE_MARK(acc) do { if (prof) { const long long pf_now = simt::clock(); acc += pf_now - pf_t; pf_t = pf_now; } } while (0)
+    if (prof) pf_t = simt::clock();
+#else
+#define TKZ_PROBE_MARK(acc) do { } while (0)
+#endif
 #pragma unroll 1
     for (int k0 = 0; k0 < np; k0 += 64 * U) {
         int ps[U], plen[U];
@@ -834,30 +829,13 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
         // the second bucket, for the lanes the first one did not settle only (the keys the builder could not keep in their first
         // bucket, and the pieces that are not keys at all): ~15 % of the requests of the first step instead of another 100 %
         bool two_pass = simt::ballot(more) != 0;
-#ifdef TKZ_PROBE_B2_COMPACT
-        if (two_pass) {
-            static_assert(U == 2, "the compacted pass takes the unresolved lanes of the iteration's two batches");
-            const bool w0 = plen[0] >= 1 && plen[0] <= TKZ_SHORT_KEY_MAX && rk[0] == TKZ_RANK_NONE;
-            const bool w1 = plen[1] >= 1 && plen[1] <= TKZ_SHORT_KEY_MAX && rk[1] == TKZ_RANK_NONE;
-            const uint64_t m0 = simt::ballot(w0), m1 = simt::ballot(w1);
-            const int n0 = tkz_popc64(m0), n01 = n0 + tkz_popc64(m1);
-            if (n01 <= kProbeB2) {
-                two_pass = false;
-                const int j0 = tkz_popc64(m0 & tkz_lowmask(lane)), j1 = n0 + tkz_popc64(m1 & tkz_lowmask(lane));
-                if (w0) { uint4 c; c.x = kw0[0]; c.y = kw1[0]; c.z = kw2[0]; c.w = (uint32_t)plen[0]; LD.b2key[j0] = c; LD.b2hs[j0] = hs[0]; }
-                if (w1) { uint4 c; c.x = kw0[1]; c.y = kw1[1]; c.z = kw2[1]; c.w = (uint32_t)plen[1]; LD.b2key[j1] = c; LD.b2hs[j1] = hs[1]; }
-                (void)simt::ballot(true);
-                const bool act = lane < n01;
-                uint4 c; c.x = c.y = c.z = c.w = 0; uint32_t h = 0;
-                if (act) { c = LD.b2key[lane]; h = LD.b2hs[lane]; }
-                const uint32_t ob = act ? 16u * tkz_short_slot_second(T, h) : 0u;
-                const uint4 b0 = tkz_load16(tb0 + ob), b1 = tkz_load16(tb0 + ob + 16u);
-                if (act) LD.b2res[lane] = (uint32_t)tkz_match_short2x(c.x, c.y, c.z, c.w, b0, b1);
-                (void)simt::ballot(true);
-                if (w0) rk[0] = (int32_t)LD.b2res[j0];
-                if (w1) rk[1] = (int32_t)LD.b2res[j1];
-                (void)simt::ballot(true);                  // (the next iteration writes the same slots)
-            }
+        TKZ_PROBE_MARK(pf_first);
+#ifdef TKZ_DEVPROF
+        if (prof) {
+            for (int u = 0; u < U; ++u) { const int nv = np - (k0 + 64 * u); if (nv > 0) { ++pf_batches; pf_valid += nv < 64 ? nv : 64; } }
+            for (int u = 0; u < U; ++u) pf_want2 += tkz_popc64(simt::ballot(plen[u] >= 1 && plen[u] <= TKZ_SHORT_KEY_MAX && rk[u] == TKZ_RANK_NONE));
+            pf_iters2 += two_pass ? 1 : 0;
+            pf_t = simt::clock();
         }
 #endif
         if (two_pass) {
@@ -875,6 +853,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
                 if (want) rk[u] = tkz_match_short2x(kw0[u], kw1[u], kw2[u], (uint32_t)plen[u], a0[u], a1[u]);
             }
         }
+        TKZ_PROBE_MARK(pf_second);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int k = k0 + 64 * u + lane;
@@ -913,7 +892,17 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
             else rec |= (uint32_t)rank;
             if (valid && pb + k < P.prank_cap) tkz_store_nt(&P.prank[pb + k], (int32_t)rec);
         }
+        TKZ_PROBE_MARK(pf_emit);
     }
+#undef TKZ_PROBE_MARK
+#ifdef TKZ_DEVPROF
+    if (prof && lane == 0) {
+        simt::atomic_add64(&P.devprof[48], (unsigned long long)pf_first); simt::atomic_add64(&P.devprof[49], (unsigned long long)pf_second);
+        simt::atomic_add64(&P.devprof[50], (unsigned long long)pf_emit); simt::atomic_add64(&P.devprof[51], (unsigned long long)pf_batches);
+        simt::atomic_add64(&P.devprof[52], (unsigned long long)pf_valid); simt::atomic_add64(&P.devprof[53], (unsigned long long)pf_want2);
+        simt::atomic_add64(&P.devprof[54], (unsigned long long)pf_iters2);
+    }
+#endif
     if (prof && lane == 0) {
         t_3 = simt::clock();
         simt::atomic_add64(&P.devprof[0], 1); simt::atomic_add64(&P.devprof[1], (unsigned long long)(t_3 - t_0));
@@ -1716,10 +1705,14 @@ TKZ_KERNEL_OCC(64, 4) void k_merge_long_q(TkzTables T, EncodeParams P) {
     const int64_t nchunks = (P.nsub + 63) / 64;
     int64_t nfast = P.lq_base[(int64_t)tkz_len_class(kFastPiece + 1) * nchunks];
     if (nfast > total) nfast = total;
-    const int64_t nrf = (nfast + kLqRange - 1) / kLqRange, nrl = (total - nfast + kLqRangeLong - 1) / kLqRangeLong;
+    // (a SHORT queue -- real text: half a million long misses in 268 MB -- is dealt out in smaller ranges, down to one batch of 64: with 256 a range there
+    //  are fewer ranges than wavefronts and the kernel lasts as long as one wavefront's four or five batches one after the other)
+    int64_t rfast = kLqRange;
+    while (rfast > 64 && (nfast + rfast - 1) / rfast < simt::nblocks()) rfast >>= 1;
+    const int64_t nrf = (nfast + rfast - 1) / rfast, nrl = (total - nfast + kLqRangeLong - 1) / kLqRangeLong;
     auto range_of = [&](int64_t r, int64_t* lo, int64_t* hi) {
         if (r >= nrf) { *lo = nfast + (r - nrf) * kLqRangeLong; *hi = *lo + kLqRangeLong < total ? *lo + kLqRangeLong : total; }
-        else { *lo = r * kLqRange; *hi = *lo + kLqRange < nfast ? *lo + kLqRange : nfast; }
+        else { *lo = r * rfast; *hi = *lo + rfast < nfast ? *lo + rfast : nfast; }
     };
     auto entry_of = [&](int64_t pos, int64_t hi) -> uint64_t { return pos < hi ? P.lq[pos] : 0ull; };
     int64_t rg = nrf + nrl - 1 - simt::bid();
@@ -1875,21 +1868,11 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
             else for (int j = 0; j < 4; ++j) if (pb_ + k0 + j < P.prank_cap) r[j] = (uint32_t)P.prank[pb_ + k0 + j];
         }
     };
-#ifdef TKZ_PLACE_PREFETCH
-    // (development A/B, round 5, NOT the shipped form: the records of sub-tile s + 1 requested while sub-tile s is placed -- one dependent round trip a
-    //  sub-tile instead of two.  Measured: the four more registers across the iteration spill at 7 waves per SIMD, k_place 4.78 -> 7.89 ms on the headline
-    //  workload; at 6 waves per SIMD without spills 6.09 ms.  As with every attempt so far to buy latency with registers in this kernel: a loss.)
-    uint32_t rn[4];
-    load_recs(nxt.pb, nxt.np, 0, rn);
-#endif
 #pragma unroll 1
     for (int it = 0; it < kPlacePer && sub0 + it < P.nsub; ++it) {
     const int64_t sub = sub0 + it;
     const Sc cur = nxt;
     if (it + 1 < kPlacePer && sub + 1 < P.nsub) nxt = load_sc(sub + 1);
-#ifdef TKZ_PLACE_PREFETCH
-    uint32_t rc[4] = {rn[0], rn[1], rn[2], rn[3]};            // this sub-tile's first chunk
-#endif
     const int64_t pb = cur.pb, tb = cur.tb, base = sub * kSub, ord0 = cur.ord0;
     const int np = cur.np;
     const uint32_t mc = cur.mc;
@@ -1935,9 +1918,6 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
         fast_ok = lists_ok && !has_giant && ns + nl <= kPlaceSlots && !simt::ballot(big);
     }
     (void)simt::ballot(true);
-#ifdef TKZ_PLACE_PREFETCH
-    if (it + 1 < kPlacePer && sub + 1 < P.nsub) load_recs(nxt.pb, nxt.np, 0, rn);      // (nxt's scalars arrived with this sub-tile's answers)
-#endif
     // the answer a merge kernel left for a missed piece (its list entry): how many tokens, and where they wait
     auto answer = [&](uint32_t rec) -> uint32_t {
         if (rec & kPrGiant) return tkz_result_entry(false, 1, (int)(rec & 1023u));     // (count: gcnt, see below; the tokens wait in tmp at the piece's position)
@@ -1985,9 +1965,6 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
     auto place_fast = [&](int kk) -> bool {
         const int k0 = kk + 4 * lane;
         uint32_t r[4];
-#ifdef TKZ_PLACE_PREFETCH
-        if (kk == 0) { r[0] = rc[0]; r[1] = rc[1]; r[2] = rc[2]; r[3] = rc[3]; } else
-#endif
         load_recs(pb, np, kk, r);
         int c[4], idx[4];
         bool ok[4], ms[4], pm[4];

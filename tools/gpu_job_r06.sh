@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-6 GPU job: stages selected by name.  usage: tools/gpu_job_r06.sh <tag> "<stages>"
-#   stages: tests subset smoke bench kind6 variants profile profile_mixed profile_real shapes latency midtrace cold fuzz
+#   stages: tests subset smoke bench kind6 variants profile profile_mixed profile_real shapes latency midtrace cold fuzz tailfuzz lanefuzz adapt
 set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; TAG=${1:-r06}; STAGES=${2:-"subset bench"}; O=gpurun_out/$TAG; mkdir -p $O
 has() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
@@ -25,7 +25,7 @@ except Exception as ex: print("bench summary:", ex)
 P
 fi
 if has kind6; then
-  for spec in "--vocab gpt2 --pattern 1" "--vocab gpt2 --pattern 2" "" "--vocab synth100k_heldout"; do
+  for spec in "--vocab gpt2 --pattern 1" "--vocab gpt2 --pattern 2" "" "--vocab synth100k_heldout" "--vocab gpt2 --pattern 1 --min-len 8192 --max-len 32768"; do
     timeout 900 python bench.py --kind 6 --real-text-mb 0 $spec --steps 5 --warmup 1 --pipelined-steps 0 ${K6ARGS:-} >> $O/bench_kind6.jsonl 2>> $O/bench_kind6.err; lap "kind6 [$spec] rc=$?"
   done
   python - $O/bench_kind6.jsonl <<'P'
@@ -74,7 +74,8 @@ P
 fi
 if has profile; then bash tools/gpu_profile.sh $TAG 10000000 "--no-memo-steps 0 --real-text-mb 0 --heldout-steps 0" > $O/profile.log 2>&1; lap "profile rc=$?"; cp gpurun_out/prof_$TAG/traffic.json profiles/traffic_latest.json 2>/dev/null; fi
 if has profile_mixed; then bash tools/gpu_profile.sh ${TAG}_mixed 2000000 "--kind 2 --no-memo-steps 0 --real-text-mb 0" > $O/profile_mixed.log 2>&1; lap "profile mixed rc=$?"; fi
-if has profile_real; then bash tools/gpu_profile.sh ${TAG}_real 0 "--kind 6 --real-text-mb 0 --vocab gpt2 --pattern 1 --no-memo-steps 0" > $O/profile_real.log 2>&1; lap "profile real rc=$?"; fi
+# (the 256 MB of real text the default run's `real_text` leg encodes, under the real gpt2 table: its counted traffic goes into that leg's roofline)
+if has profile_real; then bash tools/gpu_profile.sh ${TAG}_real 0 "--kind 6 --real-text-mb 256 --vocab gpt2 --pattern 1 --no-memo-steps 0" > $O/profile_real.log 2>&1; lap "profile real rc=$?"; cp gpurun_out/prof_${TAG}_real/traffic.json profiles/traffic_real_latest.json 2>/dev/null; fi
 if has latency; then timeout 300 python tools/latency_probe.py > $O/latency.json 2> $O/latency.err; lap "latency rc=$?"; cat $O/latency.json; fi
 if has fuzz; then timeout 200 python tools/gpu_fuzz.py 60 > $O/fuzz.log 2>&1; lap "fuzz rc=$?"; tail -2 $O/fuzz.log; fi
 if has midtrace; then
@@ -86,5 +87,8 @@ if has midtrace; then
   lap "midtrace"
 fi
 if has cold; then export TKZ_LOG_SLOW_MS=300; timeout 300 python tools/cold_probe.py synth100k_heldout > $O/cold_probe.jsonl 2> $O/cold.err; timeout 300 python tools/cold_probe.py synth100k >> $O/cold_probe.jsonl 2>> $O/cold.err; lap "cold rc=$?"; cat $O/cold_probe.jsonl; fi
+if has tailfuzz; then TKZ_EMU_LIB=$REPO/tokenizer_amd/lib/libtkz.so timeout 400 python tools/tail_fuzz.py 240 > $O/tail_fuzz_gpu.log 2>&1; lap "tail fuzz rc=$?"; tail -2 $O/tail_fuzz_gpu.log; fi
+if has lanefuzz; then TKZ_EMU_LIB=$REPO/tokenizer_amd/lib/libtkz.so timeout 400 python tools/lane_fuzz.py 240 > $O/lane_fuzz_gpu.log 2>&1; lap "lane fuzz rc=$?"; tail -2 $O/lane_fuzz_gpu.log; fi
+if has adapt; then timeout 300 python tools/adapt_probe.py gpt2 1 1 > $O/adapt_probe.jsonl 2> $O/adapt.err; lap "adapt rc=$?"; tail -3 $O/adapt_probe.jsonl; fi
 lap done
 # (the `lanepiece` stage of the round -- TKZ_LATENCY_LANE_PIECE=32..128 under the 1 MB trace -- went with the knob: profiles/r05/lanepiece_latency.txt has its result)
