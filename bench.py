@@ -237,6 +237,7 @@ def main():
     ap.add_argument("--no-memo-steps", type=int, default=None, help="timed steps with the piece memo off (value_no_memo); default: as --steps")
     ap.add_argument("--pipelined-steps", type=int, default=4, help="timed steps of the two-batches-in-flight leg (value_two_in_flight; 0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-first-call", action="store_true", help="skip the `first_call` leg (a fresh encoder, reserved, the bench batch once): the profiling runs, whose per-launch averages are over the headline steps")
     ap.add_argument("--no-piece-stats", action="store_true", help="skip the untimed step that counts pieces / misses / memo hits (tools/gpu_profile.sh: only the headline steps, their "
                                                                   "warm-up and the sizing pass run under the profiler)")
     ap.add_argument("--no-memo", action="store_true", help="switch the piece memo (the device form of the reference's LRUCache) off")
@@ -712,7 +713,7 @@ def main():
     # reference pays construction costs in CreateTokenizer, TokenizerBuilder.cs:210-213), then the bench batch ONCE, timed, with nothing untimed before
     # it: empty memo, nothing promoted, cold tables, the sizing attempt and the learning window's counting inside the call.  `value` never includes it.
     first_call = None
-    if world == 1 and not args.parity_only and not args.no_memo:
+    if world == 1 and not args.parity_only and not args.no_memo and not args.no_first_call:
         try:
             e_fc = N.Encoder(vocab, args.pattern, device=local_rank)
             device_sync(); t0 = time.perf_counter()

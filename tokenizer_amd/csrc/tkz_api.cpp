@@ -1231,6 +1231,10 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
         st = stage_in(0);
         if (st != TKZ_OK) return st;
     }
+    // (inside the loop a failed runtime call is RECORDED and the loop left -- never returned from: the upload of chunk k + 1 may still be reading the caller's text
+    //  and the download of chunk k - 1 writing the caller's ids, and the caller is free to release both the moment it sees the error; the two stream
+    //  synchronisations behind the loop always run first -- the round-5 advisor)
+#define LOOP_TRY(expr) { const hipError_t e_ = (expr); if (e_ != hipSuccess) { first_err = fail(TKZ_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); first_msg = g_err; break; } }
     for (int64_t k = 0; k < nchunks; ++k) {
         const int q = (int)(k & 1);
         const int64_t d0 = cut[(size_t)k], d1 = cut[(size_t)k + 1], nu = offs[d1] - offs[d0], nd = d1 - d0;
@@ -1239,19 +1243,19 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
         if (u16) {
             // the UTF-8 size of the chunk is known once its length pass is through (the host needs it: the launch shapes of the encode path)
             Workspace::U16Stage& U = ws->u16[q];
-            HIP_TRY(hipEventSynchronize(ws->ev_in[q]));
+            LOOP_TRY(hipEventSynchronize(ws->ev_in[q]));
             if (U.h->err & kErrOffsets) { first_err = fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count"); first_msg = g_err; break; }
             cbytes = U.h->grand;
-            HIP_TRY(ws->u_bytes.ensure((size_t)cbytes + 64, acc));
+            LOOP_TRY(ws->u_bytes.ensure((size_t)cbytes + 64, acc));
             Launch L{ws->st_compute, nullptr, ws};
             launch_u16_write(L, U.units.as<uint16_t>(), nu, U.docbits.as<uint64_t>(), u16_tiles(nu), U.tbase.as<int64_t>(), ws->u_bytes.as<uint8_t>(),
                              U.offs.as<int64_t>(), nd, U.grp.as<int32_t>(), reinterpret_cast<int64_t*>(U.counters.as<char>() + 8), U.boffs.as<int64_t>());
             cb = ws->u_bytes.as<uint8_t>(); co = U.boffs.as<int64_t>();
         } else {
-            if (!ingest_in) HIP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_in[q], 0));
+            if (!ingest_in) LOOP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_in[q], 0));
             cb = ws->s_bytes[q].as<uint8_t>(); co = ws->s_offs[q].as<int64_t>(); cbytes = nu;
         }
-        if (k >= 2) HIP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_out[q], 0));   // the download of chunk k-2 has left this set's output buffers
+        if (k >= 2) LOOP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_out[q], 0));   // the download of chunk k-2 has left this set's output buffers
         int32_t* dst_ids = direct_out ? static_cast<int32_t*>(dv_ids) : ws->s_out[q].as<int32_t>();
         int64_t* dst_offs = direct_out ? static_cast<int64_t*>(dv_ooffs) : ws->s_outoffs[q].as<int64_t>();
         const int64_t cap = over ? 0 : (direct_out ? std::min<int64_t>(out_cap, cbytes) : std::min<int64_t>(out_cap - tok_base[(size_t)k], cbytes));
@@ -1265,13 +1269,14 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
             // (the runtime's D2H copy of page-locked memory is a blit kernel and the next chunk's kernels make no progress beside it -- traced: chunk k+1 starts
             //  the moment chunk k's download ends.  A small-grid download kernel of our own was tried: the next chunk's kernels then start at once but stall in
             //  their first stores until the PCIe writes have drained, and the kernel is slower than the blit -- 16 MB 0.89 -> 1.05 ms.  DESIGN.md 6)
-            if (tokens) HIP_TRY(hipMemcpyAsync(out_ids + tok_base[(size_t)k], ws->s_out[q].p, (size_t)tokens * 4, hipMemcpyDeviceToHost, ws->st_out));
-            HIP_TRY(hipMemcpyAsync(out_offsets + d0, ws->s_outoffs[q].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, ws->st_out));
-            HIP_TRY(hipEventRecord(ws->ev_out[q], ws->st_out));
+            if (tokens) LOOP_TRY(hipMemcpyAsync(out_ids + tok_base[(size_t)k], ws->s_out[q].p, (size_t)tokens * 4, hipMemcpyDeviceToHost, ws->st_out));
+            LOOP_TRY(hipMemcpyAsync(out_offsets + d0, ws->s_outoffs[q].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, ws->st_out));
+            LOOP_TRY(hipEventRecord(ws->ev_out[q], ws->st_out));
         }
     }
-    HIP_TRY(hipStreamSynchronize(ws->st_in));
-    HIP_TRY(hipStreamSynchronize(ws->st_out));
+#undef LOOP_TRY
+    (void)hipStreamSynchronize(ws->st_in);      // (an error of the runtime here is an error of the copies above: reported by them or by the next call)
+    (void)hipStreamSynchronize(ws->st_out);
     if (first_err != TKZ_OK) return fail(first_err, first_msg);
     if (needed) *needed = tok_base[(size_t)nchunks];
     if (over) return fail(TKZ_E_CAPACITY, "output capacity too small");

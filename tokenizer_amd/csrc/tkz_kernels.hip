@@ -12,7 +12,10 @@
 //   k_probe          per sub-tile, one wavefront: enumerate pieces from the bitmap, whole-piece lookup
 //                    (TikTokenizer.cs:262) -> one 32-bit record per piece
 //   k_merge_short    BytePairEncode (BytePairEncoder.cs:13-76) of the missed pieces of <= 16 bytes, 64 per wavefront
-//   k_giant_* / k_merge_long / k_merge_coop   the missed pieces of > 1024 bytes (a workgroup each) / 17..256 (a lane each) / 257..1024 (a wavefront each)
+//   k_giant_* / k_merge_coop   the missed pieces of > 1024 bytes (a workgroup each) / of 129..1024 bytes (a wavefront each)
+//   k_long_count / k_long_scatter / k_merge_long_q   the missed pieces of 17..128 bytes of a LARGE batch, a lane each: binned by length class across the
+//                    whole batch, then merged off that queue 64 of one class at a time (k_merge_long: the same batches formed inside a unit of a few
+//                    sub-tiles -- a small batch, and the single-launch kernel)
 //   k_scan_*         exclusive scan of the per-sub-tile token counts
 //   k_place          ids stored at their final position
 //   k_docoffs        out_offsets[d] = tile base + position inside the tile
@@ -539,9 +542,9 @@ TKZ_KERNEL(256) void k_pretok_seq(const uint8_t* bytes, const int64_t* offs, int
 //   k_merge_short  one wavefront per group of 16 sub-tiles: their short-miss lists are packed 64 to a wavefront -- looked up in
 //                  the piece memo (the reference's LRUCache on the device), the survivors merged, every lane busy (tkz_bpe_lane) --
 //                  instead of the ~14 of 64 a sub-tile has on its own.  Also the per-sub-tile token counts.
-//   k_giant_find / k_giant_merge, k_merge_long, k_merge_coop   the rare long ones: > 1024 bytes by a whole workgroup (tkz_bpe_long: batches of
-//                  merges that cannot disturb one another, rounds for chains of equal pairs); 17..256 bytes from the long-miss lists of 64
-//                  sub-tiles at a time, one LANE each in a span of an LDS arena; 257..1024 bytes one WAVEFRONT each, with the workgroup's merger
+//   k_giant_order / k_giant_merge, k_long_* + k_merge_long_q (k_merge_long), k_merge_coop   the rare long ones: > 1024 bytes by a whole workgroup
+//                  (tkz_bpe_long_tail: batches of merges that cannot disturb one another, rounds for chains of equal pairs); 17..128 bytes one LANE each in a
+//                  span of an LDS arena, 64 pieces of one length class a batch; 129..1024 bytes one WAVEFRONT each, with the workgroup's merger
 //   (scan of the token counts)
 //   k_place        one wavefront per sub-tile: count per record -> prefix -> ids staged in LDS and stored as whole 16-byte quads at
 //                  their final position, token index of every marked piece for the document offsets

@@ -79,7 +79,7 @@ ENCODER_ENGINE = {"o200k_base": "js"}
 def host_unicode_classes(ucd=None, n_code_points: int = 0x110000, engine: str = "dotnet"):
     """The class table a host hands to TikTokenizer(unicode_classes=...): class 0..8 of every code point below n_code_points (65536: code units) from
     a `unicodedata`-like module (default: this Python's -- another Unicode version than the 13.0 libtkz is built with).  \\s is .NET's
-    ([\\f\\n\\r\\t\\v\\x85\\p{Z}]) or, engine="js", ECMAScript's as far as the table holds it (U+FEFF / U+0085 are the library's business there)."""
+    ([\\f\\n\\r\\t\\v\\x85\\p{Z}]) or, engine="js", ECMAScript's ([\\t\\n\\v\\f\\r\\ufeff\\p{Zs}\\u2028\\u2029])."""
     import unicodedata
     ucd = ucd or unicodedata
     out = np.zeros(n_code_points, np.uint8)
@@ -88,8 +88,10 @@ def host_unicode_classes(ucd=None, n_code_points: int = 0x110000, engine: str = 
         if 0xD800 <= cp <= 0xDFFF:
             continue
         out[cp] = code.get(ucd.category(chr(cp)), 0)
-    for cp in (9, 10, 11, 12, 13, 0x85):
-        out[cp] = 8
+    # \s beyond \p{Z}: .NET adds [\f\n\r\t\v\x85]; ECMAScript adds [\t\n\v\f\r\ufeff] (U+0085 is NOT white space there)
+    for cp in ((9, 10, 11, 12, 13, 0xFEFF) if engine == "js" else (9, 10, 11, 12, 13, 0x85)):
+        if cp < n_code_points:
+            out[cp] = 8
     return out
 
 
@@ -125,6 +127,11 @@ class TikTokenizer:
         # hands that runtime's classification over (uint8[65536] per code unit, or uint8[1114112] per code point; host_unicode_classes() builds
         # one from a `unicodedata`-like module), `case_equivalence` is .NET >= 7's reading of cl100k's (?i:...) ('ſ is 's).  Default: net6.0's.
         if unicode_classes is not None:
+            if host == "js" and len(unicode_classes) == 65536:
+                # the ECMAScript reading classifies by CODE POINT: a table of code units leaves the supplementary planes on the built-in Unicode 13.0 data
+                import warnings
+                warnings.warn("host='js' classifies by code point: a 65536-entry unicode_classes table covers the BMP only, the supplementary planes keep "
+                              "libtkz's built-in Unicode 13.0 classes (pass 1114112 entries to override them too)")
             self._encoder.set_unicode_classes(unicode_classes)
         if case_equivalence:
             self._encoder.set_option(N.OPT_CASE_EQUIVALENCE, 1)

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 #  per-launch average of that kernel in the stats would be over five full launches and one short one)
 export TKZ_SIZING_MIN_SUB=4000000000
 # (--heldout-steps 0 --pipelined-steps 0 --no-piece-stats: nothing but the headline steps, their warm-up and the sizing pass run under the profiler -- per-launch averages of a kernel are over THOSE launches)
-BENCH="python $REPO/bench.py --docs $DOCS --steps 3 --warmup 1 --no-cpu-baseline --heldout-steps 0 --pipelined-steps 0 --no-piece-stats $EXTRA"
+BENCH="python $REPO/bench.py --docs $DOCS --steps 3 --warmup 1 --no-cpu-baseline --heldout-steps 0 --pipelined-steps 0 --no-piece-stats --no-first-call $EXTRA"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_$TAG/trace -o trace -- $BENCH > $REPO/gpurun_out/prof_$TAG/trace.log 2>&1; echo "trace rc=$?"
 i=0
