@@ -318,12 +318,15 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
 /* ---- measurement ------------------------------------------------------------------------- */
 
 enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_PROBE = 2 /* k_probe alone */, TKZ_K_SCAN = 3, TKZ_K_PLACE = 4,
-       TKZ_K_DOCOFFS = 5, TKZ_K_MERGE_LONG = 6 /* k_giant_order + k_giant_merge + k_merge_long + k_merge_coop */, TKZ_K_MERGE_SHORT = 7 /* k_merge_short alone */,
+       TKZ_K_DOCOFFS = 5, TKZ_K_MERGE_LONG = 6 /* k_giant_order + k_giant_merge + k_long_count / scan / k_long_scatter + k_merge_long_q (k_merge_long) + k_merge_coop */, TKZ_K_MERGE_SHORT = 7 /* k_merge_short alone */,
        TKZ_K_COUNT = 8 };
 /* When enabled, every kernel launch of tkz_encode_batch_device is bracketed by HIP events on the
  * launch stream; tkz_encoder_kernel_ms returns the accumulated milliseconds and launch counts per
  * kernel since the last reset (arrays of TKZ_K_COUNT).  Not inside any bracket (microseconds each): the fill of the workspace's zero region,
- * k_doccount2 and the scan of its counts, k_list_stats (which also finds the giant pieces and fills k_merge_coop's queue). */
+ * k_doccount2 and the scan of its counts, k_list_stats (which also finds the giant pieces and fills k_merge_coop's queue).
+ * A batch that runs the long pieces' kernels beside k_merge_short (tkz_encoder_side_by_side_batches) has k_merge_long_q and k_merge_coop INSIDE the
+ * TKZ_K_MERGE_SHORT bracket -- the three side by side, from the fork to the join -- and only what runs in front of them (the giant pieces, the class
+ * queue's counting, scan and scatter) in TKZ_K_MERGE_LONG. */
 tkz_status tkz_encoder_set_profiling(tkz_encoder* e, int32_t enabled);
 tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, int32_t reset);
 /* o200k only, informational: of the 4 KiB blocks of the last batch, how many the ASCII block scanner handed on (blocks with multi-byte
@@ -360,6 +363,9 @@ int64_t tkz_encoder_memo_bucket(const tkz_encoder* e, const uint8_t* piece, int3
 tkz_status tkz_encoder_reserve(tkz_encoder* e, int64_t max_bytes, int64_t max_docs);
 /* Device bytes currently held by the encoder (tables + workspace). */
 int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e);
+/* Informational: batches whose kernels of the long missed pieces (k_merge_long_q, k_merge_coop) ran BESIDE k_merge_short on streams of their own instead of behind it --
+ * a batch above TKZ_OPT_LATENCY_BYTES on a workspace whose previous such batch left at most 2^20 long misses (the launch sequence of a large batch). */
+int64_t tkz_encoder_side_by_side_batches(const tkz_encoder* e);
 const char* tkz_kernel_name(int32_t k);
 
 /* Synthetic corpus of BASELINE.json's configs, generated ON DEVICE by a counter-based generator

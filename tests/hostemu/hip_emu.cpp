@@ -161,6 +161,8 @@ hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return 
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamCreate(hipStream_t* st) { *st = nullptr; return hipSuccess; }      // (everything is synchronous here)
 // (a created-with-flags stream is a distinct non-null handle, so that code choosing a path on "is there a second stream" takes it)
+hipError_t hipStreamCreateWithPriority(hipStream_t* st, unsigned flags, int) { return hipStreamCreateWithFlags(st, flags); }
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { if (least) *least = 0; if (greatest) *greatest = 0; return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned) { static int dummy; *st = reinterpret_cast<hipStream_t>(&dummy); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipemu_event(); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

@@ -48,6 +48,8 @@ hipError_t hipStreamSynchronize(hipStream_t st);
 hipError_t hipStreamCreate(hipStream_t* st);
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocPortable = 1 };
 hipError_t hipStreamCreateWithFlags(hipStream_t* st, unsigned flags);
+hipError_t hipStreamCreateWithPriority(hipStream_t* st, unsigned flags, int priority);
+hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t st);
 hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t e, unsigned flags = 0);

@@ -277,6 +277,36 @@ def check_batch(lib, O, vocab, ovocab, pattern, seed, rounds, doc_lens, n_docs_c
             raise AssertionError("trailing mismatch")
 
 
+def check_side_by_side(lib, O, vocab, ovocab, pattern=N.CL100K, seed=71, rounds=4):
+    """Large batches (above TKZ_OPT_LATENCY_BYTES) on a workspace whose previous batch left few long misses run k_merge_long_q and k_merge_coop on streams of
+    their own BESIDE k_merge_short (launch_encode): the sub-tiles' token counts are then summed with atomics from zero, by kernels in any order.  One encoder,
+    several batches full of short, long (17..128 bytes), wavefront (129..1024) and giant missed pieces, every document against the oracle; the encoder must
+    report that the later batches took that form.  (The small-batch form on the same text is the rest of the suite.)"""
+    alpha = RC.alphabet()
+    rng = random.Random(seed)
+    enc = N.Encoder(vocab, pattern)
+    enc.set_option(N.OPT_LATENCY_BYTES, 0)
+    oenc = O.Encoder(ovocab, pattern)
+    cons = "bcdfghjklmnpqrstvwxz"
+    for it in range(rounds):
+        docs = []
+        for _ in range(rng.choice([3, 30, 120])):
+            parts = []
+            for _ in range(rng.randint(1, 12)):
+                r = rng.random()
+                if r < 0.4: parts.append(gen_text(rng, "mix", rng.choice([5, 80, 700]), alpha))
+                elif r < 0.7: parts.append(" " + "".join(rng.choice(cons) for _ in range(rng.choice([3, 9, 17, 30, 64, 100, 128]))))
+                elif r < 0.9: parts.append(" " + "".join(rng.choice(cons) for _ in range(rng.choice([129, 300, 1024]))))
+                else: parts.append(" " + "".join(rng.choice("ab") for _ in range(rng.choice([1025, 2500]))))
+            docs.append("".join(parts).encode("utf-8"))
+        data, offs = pack(docs)
+        ids, ooff = enc.encode_batch(data, offs)
+        exp, eoff = oracle_encode_docs(oenc, docs)
+        assert ooff.tolist() == eoff, "round %d: offsets" % it
+        assert ids.tolist() == exp, "round %d: ids" % it
+    assert enc.side_by_side_batches >= rounds - 1, (enc.side_by_side_batches, rounds)
+
+
 def check_dense_region(lib, O, vocab, ovocab, pattern=N.CL100K, seed=17):
     """The packed region for the tokens of merged short pieces (4096 per group of 16 sub-tiles): groups that fill it exactly, overflow it
     (the rest waits in tmp) and stay far below it, next to each other, with long misses in between."""

@@ -185,6 +185,12 @@ def test_throughput_setting_on_small_batches(lib, vocabs, oracle_mod, monkeypatc
         enc.set_option(N.OPT_LATENCY_BYTES, -1)
 
 
+def test_long_pieces_beside_the_short_ones(lib, vocabs, oracle_mod):
+    for vname, pat in (("gpt2", N.CL100K), ("synth100k", N.P1)):
+        v, ov = vocabs(vname)
+        parity.check_side_by_side(lib, oracle_mod, v, ov, pattern=pat)
+
+
 def test_document_marks(lib, vocabs, oracle_mod):
     v, ov = vocabs("gpt2")
     parity.check_document_marks(lib, oracle_mod, v, ov)

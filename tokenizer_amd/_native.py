@@ -129,6 +129,8 @@ class Library:
         L.tkz_encoder_kernel_ms.argtypes = [vp, vp, vp, i32]
         L.tkz_encoder_workspace_bytes.argtypes = [vp]
         L.tkz_encoder_workspace_bytes.restype = i64
+        L.tkz_encoder_side_by_side_batches.argtypes = [vp]
+        L.tkz_encoder_side_by_side_batches.restype = i64
         L.tkz_kernel_name.argtypes = [i32]
         L.tkz_kernel_name.restype = C.c_char_p
         L.tkz_corpus_generate_device.argtypes = [i32, i32, C.c_uint64, i64, i64, i32, i32, vp, vp, i64, vp, pi64]
@@ -316,6 +318,11 @@ class Encoder:
     @property
     def workspace_bytes(self):
         return self.lib.L.tkz_encoder_workspace_bytes(self._h)
+
+    @property
+    def side_by_side_batches(self):
+        """Batches whose long-piece kernels ran beside k_merge_short on streams of their own (tkz_encoder_side_by_side_batches)."""
+        return self.lib.L.tkz_encoder_side_by_side_batches(self._h)
 
     # -- host buffers --
     def encode_batch(self, data: np.ndarray, offsets: np.ndarray, out_cap=None, out=None):

@@ -140,6 +140,9 @@ struct Workspace {
     CounterBlock* h_counters = nullptr;   // pinned
     // the single-launch path for small batches (k_small): input, output and status in ONE page-locked block the device reads and writes directly
     uint8_t* h_small = nullptr;
+    int64_t forked_batches = 0;            // batches that ran the long pieces' kernels beside k_merge_short (tkz_encoder_side_by_side_batches)
+    int64_t last_lq_total = -1;            // entries of the class queue of the long misses in the workspace's last batch on the batch path (-1: none yet)
+    hipStream_t st_side = nullptr, st_side2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;   // large batches: k_merge_long_q and k_merge_coop run beside k_merge_short (launch_encode)
     hipStream_t st_small = nullptr;        // (non-blocking: a small call never waits for another thread's batch on the legacy default stream)
     std::atomic<int64_t> small_calls{0}, small_fallbacks{0};   // (read by tkz_encoder_small_path_calls from other threads)
     int64_t small_clocks[16] = {};         // the phase stamps of the last single-launch call, copied out after its synchronisation
@@ -164,6 +167,8 @@ struct Workspace {
         for (int q = 0; q < 2; ++q) if (u16[q].h) (void)hipHostFree(u16[q].h);
         if (h_small) (void)hipHostFree(h_small);
         if (st_small) (void)hipStreamDestroy(st_small);
+        for (hipStream_t st : {st_side, st_side2}) if (st) (void)hipStreamDestroy(st);
+        for (hipEvent_t ev : {ev_fork, ev_join, ev_join2}) if (ev) (void)hipEventDestroy(ev);
         for (int k = 0; k < tkz::K_COUNT; ++k) for (int q = 0; q < 2; ++q) if (ev[k][q]) (void)hipEventDestroy(ev[k][q]);
         for (int q = 0; q < 2; ++q) { if (ev_in[q]) (void)hipEventDestroy(ev_in[q]); if (ev_done[q]) (void)hipEventDestroy(ev_done[q]); if (ev_out[q]) (void)hipEventDestroy(ev_out[q]); }
         if (st_compute) (void)hipStreamDestroy(st_compute);
@@ -656,6 +661,22 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         const bool sizing = attempt == 0 && phase == kCallWhole && !ws->sized && pretok && !d_bitmap_only && !po && (total + kSub - 1) / kSub >= kSizingMinSub;
         const bool marks_reused = marks_ready;
         Launch L{stream, e->profiling ? prof_hook : nullptr, ws};
+        // a large batch: two more streams, for the two kernels of the long pieces that last as long as their slowest wavefront (launch_encode runs them beside k_merge_short;
+        // without the streams -- the runtime refused one, or an event -- they follow it as they always did)
+        static const bool kNoFork = getenv("TKZ_NO_FORK") != nullptr;          // (development: A/B of the forked form)
+        static const int kSideLong = [] { const char* v = getenv("TKZ_SIDE_LONG_GRID"); return v ? atoi(v) : 2048; }();
+        static const int kSideCoop = [] { const char* v = getenv("TKZ_SIDE_COOP_GRID"); return v ? atoi(v) : 1024; }();
+        // WHEN: the workspace's previous batch left a class queue short enough for its kernel to be a matter of latency -- at most kForkMaxLong entries, ~4 batches of 64 for
+        // each of the 4,096 wavefronts the chip holds --; with a long queue (mixed text: 17 M entries in 1 GB) the queue kernel is the step's largest and needs the whole chip
+        // (measured with the tail grids: 17.0 -> 19.8 ms), and on the bench text (1.3 M) the two forms are equal (20.6 / 20.8 ms).
+        static const int64_t kForkMaxLong = [] { const char* v = getenv("TKZ_FORK_MAX_LONG"); return v ? (int64_t)atoll(v) : int64_t(1) << 20; }();
+        if (total > e->latency_bytes && !kNoFork && ws->last_lq_total >= 0 && ws->last_lq_total <= kForkMaxLong) {
+            bool ok = true;
+            for (hipStream_t* st : {&ws->st_side, &ws->st_side2}) if (!*st && hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) { *st = nullptr; ok = false; }
+            for (hipEvent_t* ev : {&ws->ev_fork, &ws->ev_join, &ws->ev_join2}) if (!*ev && hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { *ev = nullptr; ok = false; }
+            if (ok) { L.side = ws->st_side; L.side2 = ws->st_side2; L.ev_fork = ws->ev_fork; L.ev_join = ws->ev_join; L.ev_join2 = ws->ev_join2; L.side_long_grid = kSideLong; L.side_coop_grid = kSideCoop; }
+            else (void)hipGetLastError();
+        }
         int32_t* counters = ws->w_counters.as<int32_t>();
         if (!(phase == kCallEnd && attempt == 0)) {              // (kCallEnd: the first attempt is in flight already)
         // the tables as they are NOW, one consistent copy for the whole attempt (a promotion at the end of another call's batch replaces the
@@ -747,6 +768,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             //  pieces of 33..128 bytes to k_merge_coop as well was tried: 115 us in that kernel for what the lanes do in 6 -- a wavefront takes ~30 us a piece)
             P.lane_piece = kLanePiece;
             P.latency = total <= e->latency_bytes ? 1 : 0;
+            P.tc_atomic = L.side ? 1 : 0;
+            if (L.side && !sizing) ++ws->forked_batches;
             P.coop_cap = total / P.lane_piece + 64;
             HIP_TRY(ws->w_coopq.ensure((size_t)P.coop_cap * 8, acc));
             P.coop_q = ws->w_coopq.as<uint64_t>();
@@ -847,6 +870,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         if (err & kErrTooLong) return fail(TKZ_E_UNSUPPORTED, "a single piece longer than 2^30 bytes");
         marks_ready = true;                // (what is wrong from here on is the size of a buffer)
         if (!d_bitmap_only) ws->sized = true;
+        if (!d_bitmap_only && !sizing && total > e->latency_bytes) ws->last_lq_total = ws->h_counters->lq_total;      // (the next batch's form of the long pieces' kernels: above)
         if (sizing) {
             // k_place's form for THIS batch from the sample (it is otherwise chosen from the batch before: a fresh encoder's first miss-heavy batch ran
             // k_place<64> with most sub-tiles on its general path, 11.7 ms against 7)
@@ -2005,6 +2029,14 @@ int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e) {
     std::lock_guard<std::mutex> lock(m->mu);
     int64_t n = e->bytes_allocated;
     for (Workspace* w : e->pool) n += w->bytes_allocated;
+    return n;
+}
+int64_t tkz_encoder_side_by_side_batches(const tkz_encoder* e) {
+    if (!e) return 0;
+    tkz_encoder* m = const_cast<tkz_encoder*>(e);
+    std::lock_guard<std::mutex> lock(m->mu);
+    int64_t n = 0;
+    for (Workspace* w : e->pool) n += w->forked_batches;
     return n;
 }
 const char* tkz_kernel_name(int32_t k) {

@@ -87,6 +87,7 @@ struct EncodeParams {
     uint32_t* long_log; unsigned long long* long_log_count; int32_t long_log_cap; int32_t long_log_sparse;
     int32_t* pextra;              // null, or (promoted pieces in the tables) per sub-tile: tokens beyond one per piece that its promoted pieces stand for (k_probe -> k_merge_short's counts)
     const uint4* promo;           // token quads of the promoted pieces (TkzTables::promo of the tables this batch was probed with), or null: k_place
+    int32_t tc_atomic;            // k_probe zeroes tile_count and k_merge_short ADDS its counts (atomics) instead of storing them: the long-piece kernels, which add theirs, may run beside it (Launch::side)
     int32_t place128;             // launch k_place<128> (two kept list entries per lane) instead of k_place<64>: the previous batch of the workspace was miss-heavy
 };
 
@@ -106,7 +107,11 @@ struct SmallArgs {
 };
 
 typedef void (*KernelHook)(void* ctx, int kernel_id, int phase /*0 before, 1 after*/, hipStream_t s);
-struct Launch { hipStream_t stream; KernelHook hook; void* hook_ctx; };
+// side / side2 / ev_fork / ev_join / ev_join2: null, or two more streams and three events of the workspace -- launch_encode runs k_merge_long_q and k_merge_coop there, beside
+// k_merge_short on `stream`, with grids of at most side_long_grid / side_coop_grid wavefronts (a large batch only: EncodeParams::tc_atomic says that the token counts of the
+// sub-tiles are summed with atomics from zero)
+struct Launch { hipStream_t stream; KernelHook hook; void* hook_ctx; hipStream_t side = nullptr, side2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+                int side_long_grid = 2048, side_coop_grid = 1024; };
 
 void launch_docmark(const Launch& L, const int64_t* d_offs, int64_t n_items, int64_t total, uint64_t* bits, int32_t* counters);
 // position-parallel Regex.Matches; xq / xcount: queue of row blocks left to the sequential matcher (o200k only)

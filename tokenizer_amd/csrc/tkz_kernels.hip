@@ -922,6 +922,7 @@ TKZ_DEV void tkz_probe_subtile(const TkzTables& T, const EncodeParams& P, int64_
         P.heavy_flag[sub] = (uint8_t)f;
         P.mcount[sub] = (uint32_t)ns | ((uint32_t)nl << 16);
         if (P.pextra) P.pextra[sub] = promo_extra;
+        if (!REPORT && P.tc_atomic) P.tile_count[sub] = 0;                   // (the merge kernels of both streams add to it: launch_encode)
         if (REPORT && ns + nl > P.mcap) { simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&P.counters[1], (unsigned)(ns + nl)); }
         if (pb + np > P.prank_cap) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)kErrCapacity);
     }
@@ -1222,7 +1223,11 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     if (nlist > 0) run_batch(nlist);
     (void)simt::ballot(true);
     // tokens of every sub-tile of the group: one per piece, plus what the merges added (k_merge_long adds its own later)
-    if (lane < kGroup && sub0 + lane < P.nsub) P.tile_count[sub0 + lane] = my_np + s_extra[lane] + (P.pextra ? P.pextra[sub0 + lane] : 0);
+    if (lane < kGroup && sub0 + lane < P.nsub) {
+        const int tc = my_np + s_extra[lane] + (P.pextra ? P.pextra[sub0 + lane] : 0);
+        if (P.tc_atomic) simt::atomic_add(&P.tile_count[sub0 + lane], tc);            // (the long pieces' kernels run beside this one and add theirs: k_probe has zeroed the counts)
+        else P.tile_count[sub0 + lane] = tc;
+    }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
     if (P.stats && lane == 0 && st_look) { simt::atomic_add64(&P.stats[0], (unsigned long long)st_look); simt::atomic_add64(&P.stats[1], (unsigned long long)st_hit); }
 }
@@ -3022,39 +3027,64 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     { const int64_t g = grid_for(nsub); TKZ_LAUNCH(k_list_stats, g < 1024 ? g : 1024, kThreads, L.stream, (const uint32_t*)P.mcount, nsub, P.mcap, P.counters,
                                                      (const uint8_t*)P.heavy_flag, P.startbits, P.nwords, P.total, P.giant_q, P.giant_count, P.giant_cap,
                                                      (const uint32_t*)P.mlist, P.coop_q, P.coop_count, P.coop_cap, (int)P.lane_piece, P.miss_sums); }
-    hook(L, K_MERGE_SHORT, 0);
-    TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
-    hook(L, K_MERGE_SHORT, 1);
-    hook(L, K_HEAVY, 0);
+    // The short misses and the long ones touch different list entries and the sub-tiles' token counts are summed with atomics from zero (P.tc_atomic), so the
+    // kernels of the two kinds may run side by side.  What makes that worth having: k_merge_long_q and k_merge_coop last as long as their slowest wavefronts, not as
+    // long as their work (0.43 + 0.31 of the 3.7 ms of a 268 MB batch of real text, for 0.6 M pieces), while k_merge_short keeps the whole chip busy.
+    // How: this chip starts no workgroup of a second kernel while a first one still has workgroups waiting (tools/stream_overlap_probe.hip: 8,192 + 64 workgroups on two
+    // streams take 20 + 5 ms whatever the streams' priorities; 1,024 + 64 take 5) -- so the two tail kernels go FIRST, each on a stream of its own with a grid that fits
+    // the chip beside the other, and k_merge_short behind them on L.stream takes what is left and, as their wavefronts retire, everything.
+    // The counting, the scan and the scatter of the class queue stay in front on L.stream (they are short and the queue kernel needs them).
+    const bool fork = L.side && L.side2 && L.ev_fork && L.ev_join && L.ev_join2 && P.tc_atomic && P.latency == 0 && P.lq != nullptr;
     // giant pieces (queued by k_list_stats): ordered, merged; then the pieces of 17..1024 bytes and the giants' token counts
 #ifdef TKZ_HOSTEMU
     constexpr int kGiantGrid = 2;       // (the CPU emulator pays for every thread of an idle workgroup)
 #else
     constexpr int kGiantGrid = 256;
 #endif
+    const bool latency = P.latency != 0 || !P.lq;
+    if (!fork) {                        // (the serial form keeps k_merge_short in front, as it always was)
+        hook(L, K_MERGE_SHORT, 0);
+        TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
+        hook(L, K_MERGE_SHORT, 1);
+    }
+    hook(L, K_HEAVY, 0);
     TKZ_LAUNCH(k_giant_order, 1, 1024, L.stream, P);
     TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);   // takes pieces off the ordered queue; exits at once when it is empty
+    if (!latency) {         // the queue form: the batch's long misses binned by length class ...
+        const int64_t nchunks = cdiv(nsub, 64), g4 = cdiv(nchunks, 4);
+        TKZ_LAUNCH(k_long_count, g4 < 4096 ? g4 : 4096, kThreads, L.stream, P);
+        launch_scan2(L, nchunks * kLenClasses, P.lq_bsum, P.lq_cnt, P.lq_base, P.lq_total, 1, nullptr, nullptr, nullptr, 1, -1);
+        TKZ_LAUNCH(k_long_scatter, g4 < 4096 ? g4 : 4096, kThreads, L.stream, P);
+    }
+    hipStream_t sq = L.stream, sc = L.stream;           // the streams of the queue kernel and of k_merge_coop
+    int64_t qcap = kLongQGrid, ccap = kCoopGrid;
+    if (fork) {
+        hook(L, K_HEAVY, 1);            // (the bracket of the forked form: what runs in front of the three; K_MERGE_SHORT's is the three side by side)
+        hook(L, K_MERGE_SHORT, 0);
+        (void)hipEventRecord(L.ev_fork, L.stream); (void)hipStreamWaitEvent(L.side, L.ev_fork, 0); (void)hipStreamWaitEvent(L.side2, L.ev_fork, 0);
+        sq = L.side; sc = L.side2; qcap = L.side_long_grid; ccap = L.side_coop_grid;
+    }
+    if (latency) {          // the chunk form: strides over units of 4 sub-tiles
+        const int64_t chunks = cdiv(nsub, 64) * kLongPartsLatency, grid = chunks < 65536 ? chunks : 65536;
+        if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long<true, true>), grid, 64, sq, T, P);
+        else TKZ_LAUNCH((k_merge_long<false, true>), grid, 64, sq, T, P);
+    } else {                // ... and merged off the queue 256 at a time
+        const int64_t ranges = cdiv(P.lq_cap, kLqRangeLong), grid = ranges < qcap ? (ranges < 1 ? 1 : ranges) : qcap;
+        if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long_q<true>), grid, 64, sq, T, P);
+        else TKZ_LAUNCH((k_merge_long_q<false>), grid, 64, sq, T, P);
+    }
     {
-        const bool latency = P.latency != 0 || !P.lq;
-        if (latency) {      // the chunk form: strides over units of 4 sub-tiles
-            const int64_t chunks = cdiv(nsub, 64) * kLongPartsLatency, grid = chunks < 65536 ? chunks : 65536;
-            if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long<true, true>), grid, 64, L.stream, T, P);
-            else TKZ_LAUNCH((k_merge_long<false, true>), grid, 64, L.stream, T, P);
-        } else {            // the queue form: the batch's long misses binned by length class, then merged off the queue 256 at a time
-            const int64_t nchunks = cdiv(nsub, 64), g4 = cdiv(nchunks, 4);
-            TKZ_LAUNCH(k_long_count, g4 < 4096 ? g4 : 4096, kThreads, L.stream, P);
-            launch_scan2(L, nchunks * kLenClasses, P.lq_bsum, P.lq_cnt, P.lq_base, P.lq_total, 1, nullptr, nullptr, nullptr, 1, -1);
-            TKZ_LAUNCH(k_long_scatter, g4 < 4096 ? g4 : 4096, kThreads, L.stream, P);
-            const int64_t ranges = cdiv(P.lq_cap, kLqRangeLong), grid = ranges < kLongQGrid ? (ranges < 1 ? 1 : ranges) : kLongQGrid;
-            if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long_q<true>), grid, 64, L.stream, T, P);
-            else TKZ_LAUNCH((k_merge_long_q<false>), grid, 64, L.stream, T, P);
-        }
         // the pieces k_merge_long leaves to a whole wavefront, off the queue k_list_stats filled (every wavefront exits at once when it is empty).  A small batch
         // gets as many wavefronts as a large one: 16 of them took 107 us over the queue of a 1 MB call
         const int64_t cgrid = latency ? 512 : cdiv(nsub, 64);
-        TKZ_LAUNCH(k_merge_coop, cgrid < kCoopGrid ? cgrid : kCoopGrid, 64, L.stream, T, P);
+        TKZ_LAUNCH(k_merge_coop, cgrid < ccap ? cgrid : ccap, 64, sc, T, P);
     }
-    hook(L, K_HEAVY, 1);
+    if (fork) {
+        (void)hipEventRecord(L.ev_join, L.side); (void)hipEventRecord(L.ev_join2, L.side2);
+        TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
+        (void)hipStreamWaitEvent(L.stream, L.ev_join, 0); (void)hipStreamWaitEvent(L.stream, L.ev_join2, 0);
+        hook(L, K_MERGE_SHORT, 1);
+    } else hook(L, K_HEAVY, 1);
 }
 // k_probe and the list statistics over the first `nsample` sub-tiles only (tkz_api.cpp: the sizing attempt of a fresh workspace)
 void launch_probe_sample(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsample) {

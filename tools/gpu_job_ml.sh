@@ -5,7 +5,9 @@ set -u
 REPO="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$REPO"; TAG=${1:-ml}; VARS=${2:-lib}; O=gpurun_out/$TAG; mkdir -p $O
 COMMON="--no-cpu-baseline --steps 4 --warmup 1 --pipelined-steps 0 --no-memo-steps 0 --real-text-mb 0 --heldout-steps 0"
 for v in $VARS; do
-  for shape in "mixed:--kind 2 --docs 2000000" "real:--kind 6 --vocab gpt2 --pattern 1" ${EXTRA_SHAPES:-}; do
+  IFS='|' read -ra XS <<< "${EXTRA_SHAPES:-}"          # e.g. EXTRA_SHAPES='head:|heldout:--vocab synth100k_heldout'
+  for shape in "mixed:--kind 2 --docs 2000000" "real:--kind 6 --vocab gpt2 --pattern 1" "${XS[@]}"; do
+    [ -n "$shape" ] || continue
     name=${shape%%:*}; args=${shape#*:}
     TKZ_LIBTKZ=$REPO/tokenizer_amd/$v/libtkz.so timeout 600 python bench.py $COMMON $args > $O/${name}_$v.json 2>> $O/err.txt
     python - $O/${name}_$v.json $v $name <<'P'
