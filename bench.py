@@ -635,7 +635,10 @@ def main():
                 ent = {"vocab": label_v, "pattern": PATTERN_NAME[pat], "value": round(r_total / t_first / 1e6, 1), "ms_per_step": round(t_first * 1e3, 3),
                        "value_warm_memo": round(r_total / t_warm / 1e6, 1), "promoted_pieces_warm": r_promoted, "value_no_memo": round(r_total / t_off / 1e6, 1),
                        "tokens": r_ntok, "bytes_per_token": round(r_total / max(1, r_ntok), 3), "piece_stats": r_stats,
-                       "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in r_kms.items()}, "parity": "unchecked"}
+                       "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in r_kms.items()}, "parity": "unchecked",
+                       "side_by_side_batches": int(en.side_by_side_batches),
+                       "kernels_note": "side_by_side_batches > 0: this encoder's batches ran k_merge_long_q and k_merge_coop BESIDE k_merge_short on streams of their own "
+                                       "(a previous batch left <= 2^20 long misses): kernels_ms.k_merge_short is then the three side by side, k_merge_long_group what runs in front of them"}
                 # the same roofline arithmetic as the headline's, on the first-pass step; counted traffic from profiles/traffic_real_latest.json
                 # when it was collected on these kernel sources and this very text
                 r_alg = r_total + 4 * int(r_ntok) + 16 * r_nd
@@ -909,6 +912,7 @@ def main():
                     "issue": issue,
                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4), "rank": kms_rank,
                     "kernels_ms": {k: round(v[0] / max(1, v[1]), 4) for k, v in kms.items()},
+                    "side_by_side_batches": int(enc.side_by_side_batches) if hasattr(enc, "side_by_side_batches") else None,
                     "note": "achieved = algorithmic bytes (SURVEY.md 8d: text + 4 B per id + 16 B per document) / the step's time; *_dominant = the same bytes / "
                             "the dominant kernel's average launch duration (HIP events on the launch stream)"}
         if args.pattern in (3, 4):     # of the 4 KiB blocks: handed on by the ASCII block scanner / by the multi-byte one as well (to the sequential matcher)

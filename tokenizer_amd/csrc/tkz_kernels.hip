@@ -1657,7 +1657,8 @@ TKZ_DEV void tkz_long_walk(const EncodeParams& P, int64_t c, int lane_piece, F f
 #pragma unroll
         for (int k = 0; k < 4; ++k) ent[k] = j + k < nl ? tkz_load_nt(top - (j + k)) : 0xFFFFFFFFu;        // (0xFFFFFFFF: 1024 bytes, no lane's piece)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (j + k < nl && (int)((ent[k] >> kMrLenShift) & 1023u) + 1 <= lane_piece) f(t, j + k, ent[k]);
+        // (an entry that is answered already is k_merge_coop's, which may run BEFORE or beside this walk -- launch_encode --: its length was above lane_piece)
+        for (int k = 0; k < 4; ++k) if (j + k < nl && !(ent[k] & kMrDone) && (int)((ent[k] >> kMrLenShift) & 1023u) + 1 <= lane_piece) f(t, j + k, ent[k]);
     }
 }
 TKZ_KERNEL(256) void k_long_count(EncodeParams P) {
@@ -1828,16 +1829,27 @@ TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
 // entries (k_probe counts them on every 64th sub-tile; EncodeParams::place128).
 constexpr int kPlacePer = 4;                               // consecutive sub-tiles per wavefront of k_place
 constexpr int kPlaceBig = 8;                               // the general path: token runs longer than this are copied by the whole wavefront, not staged
-constexpr int kPlaceFastBig = 32;                          // the fast path takes sub-tiles whose longest token run is at most this (a lane copies its piece's tokens into the stage)
-constexpr int kStage = 64 * kPlaceBig + 16;                // staged ids: after a flush, the <= 64 x kPlaceBig ids of one batch of records + the alignment shift always fit
+#ifndef TKZ_PLACE_FAST_BIG
+#define TKZ_PLACE_FAST_BIG 64
+#endif
+constexpr int kPlaceFastBig = TKZ_PLACE_FAST_BIG;                          // the fast path takes sub-tiles whose longest token run is at most this (a lane copies its piece's tokens into the stage)
+constexpr int kStageMin = 64 * kPlaceBig + 16;             // staged ids: after a flush, the <= 64 x kPlaceBig ids of one batch of records + the alignment shift always fit
+// ... and what k_place's wavefronts keep: the fast path stages the ids of 256 records at once and hands a chunk that does not fit to the general path (64 records at a
+// time, four times the scans) -- text of two tokens a piece (source text under the gpt2 table: 1.75) did that for every fifth chunk with 528 ids of room
+#ifndef TKZ_PLACE_STAGE
+#define TKZ_PLACE_STAGE 784
+#endif
+constexpr int kStageBatch = TKZ_PLACE_STAGE;
+static_assert(kStageBatch >= kStageMin && kStageBatch % 16 == 0, "whole quads, and room for one batch of the general path");
 // LDS of one wavefront of k_place: the staged ids, the first answers of the sub-tile's short-miss list and of the long one, and the quads
 // of those entries (the tokens of pieces of <= 4)
 // ... the token position of every kept entry's piece (the fast path: the lane that owns the record tells the lane that owns the entry)
-template <int SLOTS> constexpr int kPlaceLdsQuadsT = kStage / 4 + SLOTS + SLOTS / 4 + 1 + SLOTS / 4;
-constexpr int kPlaceLdsQuads = kPlaceLdsQuadsT<64>;       // (the single-launch kernel always uses the 64-slot form)
+template <int SLOTS, int STAGE> constexpr int kPlaceLdsQuadsT = STAGE / 4 + SLOTS + SLOTS / 4 + 1 + SLOTS / 4;
+constexpr int kPlaceLdsQuads = kPlaceLdsQuadsT<64, kStageMin>;       // (the single-launch kernel always uses the 64-slot form, with the smallest stage)
 struct PlaceLds { int32_t* stage; uint4* quad; uint32_t* res; int32_t* pos; };
-template <int SLOTS>
+template <int SLOTS, int STAGE>
 TKZ_DEV PlaceLds tkz_place_lds(uint4* wave_quads) {
+    constexpr int kStage = STAGE;
     PlaceLds L;
     L.stage = reinterpret_cast<int32_t*>(wave_quads);
     L.quad = wave_quads + kStage / 4;
@@ -1848,9 +1860,9 @@ TKZ_DEV PlaceLds tkz_place_lds(uint4* wave_quads) {
 // sub-tiles sub0 .. sub0 + kPlacePer - 1, by one wavefront
 // PROMO: the tables hold promoted pieces (tkz_tables.h): a hit record may carry a promo code instead of a rank -- its count is in the record, its
 // tokens are one 16-byte gather from P.promo.  The form without them is the kernel of every batch before the first promotion, instruction for instruction.
-template <int SLOTS, bool PROMO>
+template <int SLOTS, bool PROMO, int STAGE>
 TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base, int32_t* out, int64_t out_cap, int64_t sub0, const PlaceLds& LD) {
-    constexpr int kPlaceSlots = SLOTS, kPlaceRes = SLOTS / 2;
+    constexpr int kPlaceSlots = SLOTS, kPlaceRes = SLOTS / 2, kStage = STAGE;
     const int lane = simt::lane();
     if (sub0 >= P.nsub) return;
     int32_t* stage = LD.stage;
@@ -2147,9 +2159,9 @@ TKZ_DEV void tkz_place_subtiles(const EncodeParams& P, const int64_t* tile_base,
 template <int SLOTS, bool PROMO>
 TKZ_KERNEL_OCC(256, TKZ_PLACE_OCC) void k_place(EncodeParams P, const int64_t* tile_base, int32_t* out, int64_t out_cap) {
     if (tkz_attempt_failed(P)) return;
-    TKZ_SHARED uint4 s_wave[kThreads / 64][kPlaceLdsQuadsT<SLOTS>];
+    TKZ_SHARED uint4 s_wave[kThreads / 64][kPlaceLdsQuadsT<SLOTS, kStageBatch>];
     const int64_t sub0 = (tkz_xcd_block(simt::bid(), simt::nblocks()) * (kThreads / 64) + simt::wave()) * kPlacePer;
-    tkz_place_subtiles<SLOTS, PROMO>(P, tile_base, out, out_cap, sub0, tkz_place_lds<SLOTS>(s_wave[simt::wave()]));
+    tkz_place_subtiles<SLOTS, PROMO, kStageBatch>(P, tile_base, out, out_cap, sub0, tkz_place_lds<SLOTS, kStageBatch>(s_wave[simt::wave()]));
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -2449,8 +2461,18 @@ TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t 
         if (simt::ballot((hf & 4u) != 0)) {
             const int nl = (int)(m >> 16);
             int mine = 0;
-            if ((hf & 4u) && n <= mcap)
-                for (int j = 0; j < nl; ++j) mine += ((int)((mlist[i * (int64_t)mcap + (mcap - 1 - j)] >> kMrLenShift) & 1023u) + 1 > lane_piece) ? 1 : 0;
+            // (four entries a step, their loads requested together: a lane walks its sub-tile's long list alone -- real text has lists of forty entries, one
+            //  round trip each was 139 us of this kernel on 268 MB)
+            const uint32_t* const top = mlist + i * (int64_t)mcap + (mcap - 1);
+            const bool walk = (hf & 4u) && n <= mcap;
+            if (walk)
+                for (int j = 0; j < nl; j += 4) {
+                    uint32_t ent[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ent[k] = j + k < nl ? top[-(j + k)] : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) mine += ((int)((ent[k] >> kMrLenShift) & 1023u) + 1 > lane_piece) ? 1 : 0;
+                }
             int tot;
             const int pre = tkz_wave_scan_sum(mine, &tot);
             unsigned long long base = 0;
@@ -2458,8 +2480,14 @@ TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t 
             base = ((unsigned long long)simt::shflu((uint32_t)(base >> 32), 0) << 32) | simt::shflu((uint32_t)base, 0);
             if (mine) {
                 unsigned long long at = base + (unsigned long long)pre;
-                for (int j = 0; j < nl; ++j)
-                    if ((int)((mlist[i * (int64_t)mcap + (mcap - 1 - j)] >> kMrLenShift) & 1023u) + 1 > lane_piece) { if ((int64_t)at < coop_cap) coop_q[at] = ((uint64_t)i << 10) | (uint64_t)j; ++at; }
+                for (int j = 0; j < nl; j += 4) {
+                    uint32_t ent[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ent[k] = j + k < nl ? top[-(j + k)] : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if ((int)((ent[k] >> kMrLenShift) & 1023u) + 1 > lane_piece) { if ((int64_t)at < coop_cap) coop_q[at] = ((uint64_t)i << 10) | (uint64_t)(j + k); ++at; }
+                }
             }
         }
     }
@@ -2949,8 +2977,8 @@ TKZ_KERNEL(1024) void k_small(TkzTables T, EncodeParams P, SmallArgs A) {
     stamp();
     for (int s0 = wave * kPlacePer; s0 < nsub; s0 += nwaves * kPlacePer)
     {
-        if (P.promo) tkz_place_subtiles<64, true>(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds<64>(s_raw + wave * kPlaceLdsQuads));
-        else tkz_place_subtiles<64, false>(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds<64>(s_raw + wave * kPlaceLdsQuads));
+        if (P.promo) tkz_place_subtiles<64, true, kStageMin>(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds<64, kStageMin>(s_raw + wave * kPlaceLdsQuads));
+        else tkz_place_subtiles<64, false, kStageMin>(P, A.tile_base, A.out, A.out_cap, s0, tkz_place_lds<64, kStageMin>(s_raw + wave * kPlaceLdsQuads));
     }
     simt::sync();
     stamp();
@@ -3034,15 +3062,22 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
     // streams take 20 + 5 ms whatever the streams' priorities; 1,024 + 64 take 5) -- so the two tail kernels go FIRST, each on a stream of its own with a grid that fits
     // the chip beside the other, and k_merge_short behind them on L.stream takes what is left and, as their wavefronts retire, everything.
     // The counting, the scan and the scatter of the class queue stay in front on L.stream (they are short and the queue kernel needs them).
+    // (k_merge_coop ALONE beside k_merge_short, for workspaces whose class queue is long, was measured too: mixed text 15.97 -> 15.87 ms, headline 20.59 -> 20.84 -- not kept.)
     const bool fork = L.side && L.side2 && L.ev_fork && L.ev_join && L.ev_join2 && P.tc_atomic && P.latency == 0 && P.lq != nullptr;
-    // giant pieces (queued by k_list_stats): ordered, merged; then the pieces of 17..1024 bytes and the giants' token counts
+        // giant pieces (queued by k_list_stats): ordered, merged; then the pieces of 17..1024 bytes and the giants' token counts
 #ifdef TKZ_HOSTEMU
     constexpr int kGiantGrid = 2;       // (the CPU emulator pays for every thread of an idle workgroup)
 #else
     constexpr int kGiantGrid = 256;
 #endif
     const bool latency = P.latency != 0 || !P.lq;
-    if (!fork) {                        // (the serial form keeps k_merge_short in front, as it always was)
+    auto coop = [&](hipStream_t st, int64_t cap) {
+        // the pieces k_merge_long leaves to a whole wavefront, off the queue k_list_stats filled (every wavefront exits at once when it is empty).  A small batch
+        // gets as many wavefronts as a large one: 16 of them took 107 us over the queue of a 1 MB call
+        const int64_t cgrid = latency ? 512 : cdiv(nsub, 64);
+        TKZ_LAUNCH(k_merge_coop, cgrid < cap ? cgrid : cap, 64, st, T, P);
+    };
+    if (!fork) {                   // (the serial form keeps k_merge_short in front, as it always was)
         hook(L, K_MERGE_SHORT, 0);
         TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
         hook(L, K_MERGE_SHORT, 1);
@@ -3056,13 +3091,13 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
         launch_scan2(L, nchunks * kLenClasses, P.lq_bsum, P.lq_cnt, P.lq_base, P.lq_total, 1, nullptr, nullptr, nullptr, 1, -1);
         TKZ_LAUNCH(k_long_scatter, g4 < 4096 ? g4 : 4096, kThreads, L.stream, P);
     }
-    hipStream_t sq = L.stream, sc = L.stream;           // the streams of the queue kernel and of k_merge_coop
-    int64_t qcap = kLongQGrid, ccap = kCoopGrid;
+    hipStream_t sq = L.stream;                           // the stream of the queue kernel
+    int64_t qcap = kLongQGrid;
     if (fork) {
-        hook(L, K_HEAVY, 1);            // (the bracket of the forked form: what runs in front of the three; K_MERGE_SHORT's is the three side by side)
+        hook(L, K_HEAVY, 1);            // (the bracket of this form: what runs in front of the three; K_MERGE_SHORT's is the three side by side)
         hook(L, K_MERGE_SHORT, 0);
         (void)hipEventRecord(L.ev_fork, L.stream); (void)hipStreamWaitEvent(L.side, L.ev_fork, 0); (void)hipStreamWaitEvent(L.side2, L.ev_fork, 0);
-        sq = L.side; sc = L.side2; qcap = L.side_long_grid; ccap = L.side_coop_grid;
+        sq = L.side; qcap = L.side_long_grid;
     }
     if (latency) {          // the chunk form: strides over units of 4 sub-tiles
         const int64_t chunks = cdiv(nsub, 64) * kLongPartsLatency, grid = chunks < 65536 ? chunks : 65536;
@@ -3073,18 +3108,16 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
         if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_long_q<true>), grid, 64, sq, T, P);
         else TKZ_LAUNCH((k_merge_long_q<false>), grid, 64, sq, T, P);
     }
-    {
-        // the pieces k_merge_long leaves to a whole wavefront, off the queue k_list_stats filled (every wavefront exits at once when it is empty).  A small batch
-        // gets as many wavefronts as a large one: 16 of them took 107 us over the queue of a 1 MB call
-        const int64_t cgrid = latency ? 512 : cdiv(nsub, 64);
-        TKZ_LAUNCH(k_merge_coop, cgrid < ccap ? cgrid : ccap, 64, sc, T, P);
-    }
     if (fork) {
+        coop(L.side2, L.side_coop_grid);
         (void)hipEventRecord(L.ev_join, L.side); (void)hipEventRecord(L.ev_join2, L.side2);
         TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
         (void)hipStreamWaitEvent(L.stream, L.ev_join, 0); (void)hipStreamWaitEvent(L.stream, L.ev_join2, 0);
         hook(L, K_MERGE_SHORT, 1);
-    } else hook(L, K_HEAVY, 1);
+    } else {
+        coop(L.stream, kCoopGrid);
+        hook(L, K_HEAVY, 1);
+    }
 }
 // k_probe and the list statistics over the first `nsample` sub-tiles only (tkz_api.cpp: the sizing attempt of a fresh workspace)
 void launch_probe_sample(const Launch& L, const TkzTables& T, const EncodeParams& P, int64_t nsample) {
