@@ -77,6 +77,9 @@ void block_barrier() {
 }
 
 void launch(int64_t grid, int block, const std::function<void()>& body) {
+    // (one launch at a time: the fibers and the block state are globals -- callers on several host threads take turns, as kernels of one queue do)
+    static std::mutex launch_mu;
+    std::lock_guard<std::mutex> launch_lock(launch_mu);
     if (block <= 0 || block > kMaxThreads) { fprintf(stderr, "hipemu: bad block size %d\n", block); abort(); }
     if (grid <= 0) { fprintf(stderr, "hipemu: a launch with a grid of %lld workgroups (an invalid configuration on HIP: the real runtime fails the call)\n", (long long)grid); abort(); }
     for (int t = 0; t < block; ++t)

@@ -307,6 +307,47 @@ def check_side_by_side(lib, O, vocab, ovocab, pattern=N.CL100K, seed=71, rounds=
     assert enc.side_by_side_batches >= rounds - 1, (enc.side_by_side_batches, rounds)
 
 
+def check_side_by_side_threads(lib, O, vocab, ovocab, pattern=N.CL100K, seed=73, threads=3, rounds=3):
+    """Several callers at once on ONE encoder (a workspace each), every batch large enough for the side-by-side form: only one batch in the process takes it
+    at a time (the others keep the serial form), none may hang, every document equals the oracle's."""
+    import threading
+    alpha = RC.alphabet()
+    enc = N.Encoder(vocab, pattern)
+    enc.set_option(N.OPT_LATENCY_BYTES, 0)
+    oenc = O.Encoder(ovocab, pattern)
+    cons = "bcdfghjklmnpqrstvwxz"
+    jobs = []
+    for t in range(threads):
+        rng = random.Random(seed + t)
+        mine = []
+        for _ in range(rounds):
+            docs = []
+            for _ in range(rng.choice([8, 40])):
+                parts = [gen_text(rng, "mix", rng.choice([20, 300]), alpha)]
+                for _ in range(rng.randint(0, 5)):
+                    parts.append(" " + "".join(rng.choice(cons) for _ in range(rng.choice([5, 20, 70, 140, 400]))))
+                docs.append("".join(parts).encode("utf-8"))
+            mine.append((docs, oracle_encode_docs(oenc, docs)))
+        jobs.append(mine)
+    errs = []
+
+    def work(mine):
+        try:
+            for docs, (exp, eoff) in mine:
+                data, offs = pack(docs)
+                ids, ooff = enc.encode_batch(data, offs)
+                if ids.tolist() != exp or ooff.tolist() != eoff:
+                    errs.append("mismatch")
+        except Exception as ex:      # noqa: BLE001
+            errs.append(repr(ex))
+    ths = [threading.Thread(target=work, args=(m,)) for m in jobs]
+    for th in ths: th.start()
+    for th in ths: th.join(timeout=300)
+    assert not any(th.is_alive() for th in ths), "a caller hangs"
+    assert not errs, errs
+    assert enc.side_by_side_batches >= 1
+
+
 def check_dense_region(lib, O, vocab, ovocab, pattern=N.CL100K, seed=17):
     """The packed region for the tokens of merged short pieces (4096 per group of 16 sub-tiles): groups that fill it exactly, overflow it
     (the rest waits in tmp) and stay far below it, next to each other, with long misses in between."""

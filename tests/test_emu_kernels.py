@@ -182,6 +182,8 @@ def test_long_pieces_beside_the_short_ones(lib, vocabs, oracle_mod):
     for vname, pat in (("gpt2", N.CL100K), ("synth100k", N.P1)):
         v, ov = vocabs(vname)
         parity.check_side_by_side(lib, oracle_mod, v, ov, pattern=pat)
+    v, ov = vocabs("gpt2")
+    parity.check_side_by_side_threads(lib, oracle_mod, v, ov)
 
 
 def test_document_marks(lib, vocabs, oracle_mod):

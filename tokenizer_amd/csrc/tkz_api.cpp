@@ -140,6 +140,7 @@ struct Workspace {
     CounterBlock* h_counters = nullptr;   // pinned
     // the single-launch path for small batches (k_small): input, output and status in ONE page-locked block the device reads and writes directly
     uint8_t* h_small = nullptr;
+    bool fork_token = false;               // this workspace's call holds the process's one permission to use the side streams (g_fork_in_flight)
     int64_t forked_batches = 0;            // batches that ran the long pieces' kernels beside k_merge_short (tkz_encoder_side_by_side_batches)
     int64_t last_lq_total = -1;            // entries of the class queue of the long misses in the workspace's last batch on the batch path (-1: none yet)
     hipStream_t st_side = nullptr, st_side2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;   // large batches: k_merge_long_q and k_merge_coop run beside k_merge_short (launch_encode)
@@ -243,6 +244,10 @@ struct tkz_encoder {
 
 namespace {
 
+// ONE batch at a time in the whole process runs kernels on side streams behind events (launch_encode's forked form): two such batches at once are six streams with
+// waits on one another's events, on a runtime that maps streams onto a handful of hardware queues -- a call that finds the permission taken keeps the serial form
+std::atomic<int> g_fork_in_flight{0};
+
 // a workspace of the encoder's pool for the duration of one call
 struct Lease {
     tkz_encoder* e; Workspace* ws = nullptr;
@@ -254,6 +259,7 @@ struct Lease {
     }
     ~Lease() {
         std::lock_guard<std::mutex> lock(e->mu);
+        if (ws->fork_token) { ws->fork_token = false; g_fork_in_flight.store(0); }
         ws->busy = false;
         // table images a promotion replaced: every call takes its copy of the table descriptor while it holds a workspace, so with no workspace leased
         // nothing can be probing them any more
@@ -671,7 +677,8 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         // (measured with the tail grids: 17.0 -> 19.8 ms), and on the bench text (1.3 M) the two forms are equal (20.6 / 20.8 ms).
         static const int64_t kForkMaxLong = [] { const char* v = getenv("TKZ_FORK_MAX_LONG"); return v ? (int64_t)atoll(v) : int64_t(1) << 20; }();
         if (total > e->latency_bytes && !kNoFork && ws->last_lq_total >= 0 && ws->last_lq_total <= kForkMaxLong) {
-            bool ok = true;
+            if (!ws->fork_token) { int none = 0; ws->fork_token = g_fork_in_flight.compare_exchange_strong(none, 1); }      // (given back when the call ends: ~Lease)
+            bool ok = ws->fork_token;
             for (hipStream_t* st : {&ws->st_side, &ws->st_side2}) if (!*st && hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) { *st = nullptr; ok = false; }
             for (hipEvent_t* ev : {&ws->ev_fork, &ws->ev_join, &ws->ev_join2}) if (!*ev && hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { *ev = nullptr; ok = false; }
             if (ok) { L.side = ws->st_side; L.side2 = ws->st_side2; L.ev_fork = ws->ev_fork; L.ev_join = ws->ev_join; L.ev_join2 = ws->ev_join2; L.side_long_grid = kSideLong; L.side_coop_grid = kSideCoop; }
