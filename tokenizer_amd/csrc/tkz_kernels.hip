@@ -2497,17 +2497,25 @@ TKZ_KERNEL(256) void k_list_stats(const uint32_t* mcount, int64_t nsub, int32_t 
         const int o = simt::shfl(mx, simt::lane() ^ d), b = simt::shfl(big, simt::lane() ^ d);
         mx = o > mx ? o : mx; big = b > big ? b : big;
     }
-    if (simt::lane() == 0) {
+    // (64-bit sums over the wave by two 32-bit scans: a wavefront's share is far below 2^31)
+    int ts = 0, tl = 0;
+    if (miss_sums) { (void)tkz_wave_scan_sum((int)n_short, &ts); (void)tkz_wave_scan_sum((int)n_long, &tl); }
+    // One set of atomics a WORKGROUP: its four wavefronts meet in LDS first.  (A set per wavefront was 4,096 x 6 atomics on the same few words: ~110 us of this
+    // kernel whatever the batch -- 268 MB of real text or the 5 GB headline.)
+    TKZ_SHARED int s_red[kThreads / 64][5];
+    if (simt::lane() == 0) { int* r = s_red[simt::wave()]; r[0] = big; r[1] = mx; r[2] = tot; r[3] = ts; r[4] = tl; }
+    simt::sync();
+    if (simt::tid() == 0) {
+        long long sum_s = 0, sum_l = 0;
+        big = 0; mx = 0; tot = 0;
+        for (int w = 0; w < kThreads / 64; ++w) {
+            const int* r = s_red[w];
+            big = r[0] > big ? r[0] : big; mx = r[1] > mx ? r[1] : mx; tot += r[2]; sum_s += r[3]; sum_l += r[4];
+        }
         if (big) { simt::atomic_or((unsigned*)&counters[0], (unsigned)kErrMissCap); simt::atomic_max((unsigned*)&counters[1], (unsigned)big); }
         if (mx > kMissCapMin) simt::atomic_max((unsigned*)&counters[2], (unsigned)mx);
         if (tot) simt::atomic_add(&counters[3], tot);
-    }
-    if (miss_sums) {
-        // (64-bit sums over the wave by two 32-bit scans: a wavefront's share is far below 2^31)
-        int ts, tl;
-        (void)tkz_wave_scan_sum((int)n_short, &ts);
-        (void)tkz_wave_scan_sum((int)n_long, &tl);
-        if (simt::lane() == 0 && (ts | tl)) { simt::atomic_add64(&miss_sums[0], (unsigned long long)ts); simt::atomic_add64(&miss_sums[1], (unsigned long long)tl); }
+        if (miss_sums && (sum_s | sum_l)) { simt::atomic_add64(&miss_sums[0], (unsigned long long)sum_s); simt::atomic_add64(&miss_sums[1], (unsigned long long)sum_l); }
     }
 }
 

@@ -9,6 +9,11 @@ rocm-smi --showproductname 2>/dev/null | head -8 > $O/gpu.txt; nproc >> $O/gpu.t
 if has tests; then ( time timeout 1800 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu.log 2>&1; lap "pytest rc=$?"; grep -E "passed|failed|Error|error" $O/pytest_gpu.log | tail -4; fi
 if has subset; then ( time timeout 1200 python -m pytest tests -m gpu -x -q -k "${KEXPR:-promoted or memo or miss or two_halves or small_batches or batch_vs_oracle or golden or by_name or long_pieces or host_path or utf16}" ) > $O/pytest_subset.log 2>&1; lap "pytest subset rc=$?"; grep -E "passed|failed|Error|error" $O/pytest_subset.log | tail -6; fi
 if has smoke; then timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; lap "smoke rc=$?"; tail -1 $O/smoke.log; fi
+# (the profiles first: the bench line then carries the counted traffic and the issue figures of THESE sources -- bench.py reads profiles/traffic_latest.json)
+if has profile; then bash tools/gpu_profile.sh $TAG 10000000 "--no-memo-steps 0 --real-text-mb 0 --heldout-steps 0" > $O/profile.log 2>&1; lap "profile rc=$?"; cp gpurun_out/prof_$TAG/traffic.json profiles/traffic_latest.json 2>/dev/null; fi
+if has profile_mixed; then bash tools/gpu_profile.sh ${TAG}_mixed 2000000 "--kind 2 --no-memo-steps 0 --real-text-mb 0" > $O/profile_mixed.log 2>&1; lap "profile mixed rc=$?"; fi
+# (the 256 MB of real text the default run's `real_text` leg encodes, under the real gpt2 table: its counted traffic goes into that leg's roofline)
+if has profile_real; then bash tools/gpu_profile.sh ${TAG}_real 0 "--kind 6 --real-text-mb 256 --vocab gpt2 --pattern 1 --no-memo-steps 0" > $O/profile_real.log 2>&1; lap "profile real rc=$?"; cp gpurun_out/prof_${TAG}_real/traffic.json profiles/traffic_real_latest.json 2>/dev/null; fi
 if has bench; then timeout 1200 python bench.py ${BARGS:-} > $O/bench_n1.json 2> $O/bench_n1.err; lap "bench rc=$?"; cut -c1-300 $O/bench_n1.json; tail -3 $O/bench_n1.err
   python - $O/bench_n1.json <<'P'
 import json,sys
@@ -72,10 +77,6 @@ for l in open(sys.argv[1]):
         d=json.loads(l); print(d["config"]["pattern"][:12], d["config"]["vocab"][:10], d["config"]["workload"][:40], d["value"], d.get("value_no_memo"), d.get("value_two_in_flight"), d["ms_per_step"], d["parity"][:28], d["roofline"]["kernels_ms"])
 P
 fi
-if has profile; then bash tools/gpu_profile.sh $TAG 10000000 "--no-memo-steps 0 --real-text-mb 0 --heldout-steps 0" > $O/profile.log 2>&1; lap "profile rc=$?"; cp gpurun_out/prof_$TAG/traffic.json profiles/traffic_latest.json 2>/dev/null; fi
-if has profile_mixed; then bash tools/gpu_profile.sh ${TAG}_mixed 2000000 "--kind 2 --no-memo-steps 0 --real-text-mb 0" > $O/profile_mixed.log 2>&1; lap "profile mixed rc=$?"; fi
-# (the 256 MB of real text the default run's `real_text` leg encodes, under the real gpt2 table: its counted traffic goes into that leg's roofline)
-if has profile_real; then bash tools/gpu_profile.sh ${TAG}_real 0 "--kind 6 --real-text-mb 256 --vocab gpt2 --pattern 1 --no-memo-steps 0" > $O/profile_real.log 2>&1; lap "profile real rc=$?"; cp gpurun_out/prof_${TAG}_real/traffic.json profiles/traffic_real_latest.json 2>/dev/null; fi
 if has latency; then timeout 300 python tools/latency_probe.py > $O/latency.json 2> $O/latency.err; lap "latency rc=$?"; cat $O/latency.json; fi
 if has fuzz; then timeout 200 python tools/gpu_fuzz.py 60 > $O/fuzz.log 2>&1; lap "fuzz rc=$?"; tail -2 $O/fuzz.log; fi
 if has midtrace; then
