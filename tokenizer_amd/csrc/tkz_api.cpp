@@ -6,6 +6,7 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <string>
@@ -18,6 +19,7 @@
 #include "tkz_corpus.h"
 #include "tkz_kernels.h"
 #include "tkz_pretok.h"
+#include "tkz_sdma.h"
 #include "tkz_vocab.h"
 
 namespace {
@@ -128,11 +130,11 @@ struct Workspace {
     int low_lists = 0, low_place = 0;      // consecutive batches that would have done with shorter lists / with k_place<64> (hysteresis: kLowBatches)
     bool learning = false;                 // this workspace's batch counts memo hits per slot (TkzTables::memo_hits): the encoder promotes the hottest entries when it ends
     // staging for the host-buffer entry points (two sets: chunk k+1 is uploaded while chunk k is encoded and chunk k-1 downloaded)
-    DevBuf s_bytes[2], s_offs[2], s_out[2], s_outoffs[2];
+    DevBuf s_bytes[2], s_offs[2], s_out[3], s_outoffs[3];      // staging of the host-buffer entry points: two input sets, three output sets (encode_host)
     // the UTF-16 batch entry point: code units, their document marks, per-tile / per-group lengths (two sets: the units of chunk k+1 are uploaded and
     // measured while chunk k is encoded), the UTF-8 batch they become
     struct U16Stage { DevBuf units, offs, docbits, grp, tsum, tbase, bsum, counters, boffs; struct Host { int32_t err; int32_t pad; int64_t grand; }* h = nullptr; } u16[2];
-    DevBuf u_bytes;
+    DevBuf u_bytes[2];
     // Decode
     DevBuf d_grp, d_tsum, d_tbase, d_bsum, d_counters, d_ids, d_idoffs, d_out, d_outoffs;
     // piece-granular entry point: piece byte offsets, token offsets, first piece of every document
@@ -148,7 +150,9 @@ struct Workspace {
     std::atomic<int64_t> small_calls{0}, small_fallbacks{0};   // (read by tkz_encoder_small_path_calls from other threads)
     int64_t small_clocks[16] = {};         // the phase stamps of the last single-launch call, copied out after its synchronisation
     hipStream_t st_compute = nullptr, st_in = nullptr, st_out = nullptr;   // the host-buffer entry points: kernels / uploads / downloads
-    hipEvent_t ev_in[2] = {}, ev_done[2] = {}, ev_out[2] = {};
+    hipEvent_t ev_in[2] = {}, ev_done[2] = {}, ev_out[3] = {};
+    tkz::SdmaSignal sig_out[3], sig_outoffs[3];   // downloads on a copy engine of their own (tkz_sdma.h): the completion signal of each staging set
+    int sdma_state = 0;                    // 0 not looked at, 1 in use, -1 not available: the runtime's hipMemcpyAsync
     int64_t bytes_allocated = 0;
     bool busy = false;
     // profiling
@@ -158,8 +162,8 @@ struct Workspace {
     int64_t launches[tkz::K_COUNT] = {};
     void release_all() {
         DevBuf* bufs[] = {&w_counts3, &w_mlist, &w_mquad, &w_mcount, &w_pextra, &w_coopq, &w_lqcnt, &w_lqbase, &w_lq, &w_gq, &w_gcnt, &w_xq, &w_zero, &w_startbits, &w_tmp, &w_dense, &w_tcount, &w_prank, &w_pcount, &w_pbase, &w_tbase, &w_bsum,
-                          &w_doctok, &w_dcount, &w_dbase, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1],
-                          &s_outoffs[0], &s_outoffs[1], &u_bytes,
+                          &w_doctok, &w_dcount, &w_dbase, &w_pool, &s_bytes[0], &s_bytes[1], &s_offs[0], &s_offs[1], &s_out[0], &s_out[1], &s_out[2],
+                          &s_outoffs[0], &s_outoffs[1], &s_outoffs[2], &u_bytes[0], &u_bytes[1],
                           &u16[0].units, &u16[0].offs, &u16[0].docbits, &u16[0].grp, &u16[0].tsum, &u16[0].tbase, &u16[0].bsum, &u16[0].counters, &u16[0].boffs,
                           &u16[1].units, &u16[1].offs, &u16[1].docbits, &u16[1].grp, &u16[1].tsum, &u16[1].tbase, &u16[1].bsum, &u16[1].counters, &u16[1].boffs,
                           &d_grp, &d_tsum, &d_tbase, &d_bsum, &d_counters, &d_ids, &d_idoffs, &d_out, &d_outoffs, &p_boffs, &p_toffs, &p_docp};
@@ -171,10 +175,12 @@ struct Workspace {
         for (hipStream_t st : {st_side, st_side2}) if (st) (void)hipStreamDestroy(st);
         for (hipEvent_t ev : {ev_fork, ev_join, ev_join2}) if (ev) (void)hipEventDestroy(ev);
         for (int k = 0; k < tkz::K_COUNT; ++k) for (int q = 0; q < 2; ++q) if (ev[k][q]) (void)hipEventDestroy(ev[k][q]);
-        for (int q = 0; q < 2; ++q) { if (ev_in[q]) (void)hipEventDestroy(ev_in[q]); if (ev_done[q]) (void)hipEventDestroy(ev_done[q]); if (ev_out[q]) (void)hipEventDestroy(ev_out[q]); }
+        for (int q = 0; q < 2; ++q) { if (ev_in[q]) (void)hipEventDestroy(ev_in[q]); if (ev_done[q]) (void)hipEventDestroy(ev_done[q]); }
+        for (int q = 0; q < 3; ++q) if (ev_out[q]) (void)hipEventDestroy(ev_out[q]);
         if (st_compute) (void)hipStreamDestroy(st_compute);
         if (st_in) (void)hipStreamDestroy(st_in);
         if (st_out) (void)hipStreamDestroy(st_out);
+        for (int q = 0; q < 3; ++q) { tkz::sdma_signal_destroy(&sig_out[q]); tkz::sdma_signal_destroy(&sig_outoffs[q]); }
     }
 };
 
@@ -1090,10 +1096,8 @@ hipError_t ensure_streams(Workspace* ws) {
     if (!ws->st_compute) r = hipStreamCreate(&ws->st_compute);
     if (r == hipSuccess && !ws->st_in) r = hipStreamCreate(&ws->st_in);
     if (r == hipSuccess && !ws->st_out) r = hipStreamCreate(&ws->st_out);
-    for (int q = 0; q < 2 && r == hipSuccess; ++q) {
-        if (!ws->ev_in[q]) r = hipEventCreate(&ws->ev_in[q]);
-        if (r == hipSuccess && !ws->ev_out[q]) r = hipEventCreate(&ws->ev_out[q]);
-    }
+    for (int q = 0; q < 2 && r == hipSuccess; ++q) if (!ws->ev_in[q]) r = hipEventCreate(&ws->ev_in[q]);
+    for (int q = 0; q < 3 && r == hipSuccess; ++q) if (!ws->ev_out[q]) r = hipEventCreate(&ws->ev_out[q]);
     return r;
 }
 
@@ -1112,12 +1116,13 @@ bool pinned_host(const void* p, void** dev) {
 // host buffers -> staging -> device path -> back, for documents given as UTF-8 bytes (`bytes`) or as UTF-16 code units (`units`: uploaded as they are,
 // Encoding.UTF8.GetBytes -- TikTokenizer.cs:261 -- runs on the device; offsets in units then).
 //  * at most 128 KiB of UTF-8: the single-launch kernel (encode_small);
-//  * a batch whose upload is below 1.5 chunks (a chunk: 32 MB): one launch sequence.  From page-locked caller buffers the inputs are copied
-//    asynchronously and -- up to 8 MB of text -- the ids and offsets are written by the kernels STRAIGHT into the caller's memory (k_place / k_docoffs
-//    store whole lines over PCIe): no download commands, one synchronisation;
-//  * larger: document ranges of ~32 MB of upload, pipelined on three streams -- the upload of chunk k+1 (and, for UTF-16, its length pass), the kernels
-//    of chunk k and the download of chunk k-1 run at the same time; PCIe is full duplex and the kernels need a fraction of a transfer's time.
-//    (48 MB chunks from 96 MB up until round 5: a 64 MB batch was one chunk, upload, kernels and download one after the other.)
+//  * a batch whose upload is below 1.5 chunks (a chunk: 16 MB from page-locked buffers, 32 MB from pageable ones; at least 8 MB): one launch sequence.  From
+//    page-locked caller buffers the inputs are copied asynchronously and -- up to 8 MB of text -- the ids and offsets are written by the kernels STRAIGHT into
+//    the caller's memory (k_place / k_docoffs store whole lines over PCIe): no download commands, one synchronisation;
+//  * larger: document ranges of a chunk each, pipelined -- the upload of chunk k+2 (and, for UTF-16, its length pass), the launch sequences of chunks k+1 and
+//    k+2 (enqueued ahead, on two workspaces) and the download of chunk k (page-locked results: on a copy engine of its own, tkz_sdma.h) run at the same time.
+//    512 MB of page-locked text: 22 -> 37 GB/s, 64 MB: 22 -> 29.5 (profiles/r06/host_batches_ab.txt); what bounds it now is the download of the ids at the
+//    link's duplex rate.
 tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* units, const int64_t* offs, int64_t n_docs, int32_t* out_ids,
                        int64_t out_cap, int64_t* out_offsets, int64_t* needed, bool pretok, uint64_t* bitmap) {
     using namespace tkz;
@@ -1139,14 +1144,25 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
     int64_t* acc = &ws->bytes_allocated;
     const int64_t unit = u16 ? 2 : 1;
     // ($TKZ_HOST_CHUNK_BYTES: test knob, so that the CPU-emulated tests can exercise the pipeline on kilobytes)
-    // (32 MB of upload a chunk: the launch sequence of a chunk has a floor of ~0.4 ms whatever its size, a 16 MB chunk's transfer is 0.3 ms -- measured,
-    //  round 5: 16 MB chunks ran a 512 MB batch at 26 GB/s where 48 MB chunks had run it at 42)
-    static const int64_t kChunkBytes = [] { const char* v = getenv("TKZ_HOST_CHUNK_BYTES"); const long long n = v ? atoll(v) : 0; return n > 0 ? (int64_t)n : (int64_t(32) << 20); }();
+    // (the single-launch path first: at most 128 KiB, a fraction of a chunk -- and none of the questions below are asked of a 64-byte prompt)
+    if (!u16 && pretok && !bitmap && small_eligible(e, offs, n_docs, total)) {
+        bool handled = false;
+        st = encode_small(e, ws, bytes, offs, n_docs, total, out_ids, out_cap, out_offsets, needed, &handled);
+        if (st != TKZ_OK || handled) return st;
+    }
+    // page-locked caller buffers?  (a single chunk then needs no staging for its results; the copies of every path are asynchronous)
+    void *dv_in = nullptr, *dv_offs = nullptr, *dv_ids = nullptr, *dv_ooffs = nullptr;
+    const bool pin_in = pinned_host(u16 ? (const void*)units : (const void*)bytes, &dv_in) && pinned_host(offs, &dv_offs);
+    const bool pin_out = !bitmap && pinned_host(out_offsets, &dv_ooffs) && (out_cap == 0 || pinned_host(out_ids, &dv_ids));
+    // (16 MB of upload a chunk.  Until round 6 a chunk's kernels were launched when the chunk before had drained, every chunk paid its launch sequence's
+    //  floor of ~0.4 ms and 32 MB chunks were the optimum; with two launch sequences enqueued ahead and the downloads on a copy engine of their own the
+    //  floor is hidden: profiles/r06/host_batches_ab.txt.  Pageable buffers keep 32 MB: the runtime stages their copies itself, synchronously, a cost per copy)
+    static const int64_t kChunkEnv = [] { const char* v = getenv("TKZ_HOST_CHUNK_BYTES"); const long long n = v ? atoll(v) : 0; return n > 0 ? (int64_t)n : (int64_t)0; }();
+    const int64_t kChunkBytes = kChunkEnv ? kChunkEnv : (pin_in && pin_out ? int64_t(16) << 20 : int64_t(32) << 20);
+    static const int64_t kChunkMin = [] { const char* v = getenv("TKZ_HOST_CHUNK_MIN"); const long long n = v ? atoll(v) : 0; return n > 0 ? (int64_t)n : (int64_t(8) << 20); }();
     const int64_t up_bytes = total * unit;
-    // (from 12 MB up a batch is two chunks at least, of 8 MB or more: the second chunk's upload runs beside the first one's kernels -- 16 MB: 1.00 -> 0.89 ms.
-    //  More, smaller chunks do not pay: a chunk's kernels wait for the download of the chunk before -- the comment at the download below -- so every chunk adds
-    //  its launch sequence's floor: 64 MB as 4 x 16 MB 2.83 ms, as 2 x 32 MB 2.71)
-    const int64_t chunk_bytes = std::min(kChunkBytes, std::max(std::min(kChunkBytes, int64_t(8) << 20), up_bytes / 2));
+    // (from 12 MB up a batch is two chunks at least, of 8 MB or more: the second chunk's upload runs beside the first one's kernels)
+    const int64_t chunk_bytes = std::min(kChunkBytes, std::max(std::min(kChunkBytes, kChunkMin), up_bytes / 2));
     int64_t nchunks = (bitmap || !pretok || 2 * up_bytes < 3 * chunk_bytes) ? 1 : std::min<int64_t>(1024, std::max<int64_t>(2, (up_bytes + chunk_bytes / 2) / chunk_bytes));
     // chunk boundaries on documents: chunk k = documents [cut[k], cut[k+1]).  Offsets that are not monotone cannot be cut: the
     // whole batch then goes as one chunk and the device reports them (k_docmark)
@@ -1158,15 +1174,6 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
         if (cut[(size_t)k] < cut[(size_t)k - 1] || offs[cut[(size_t)k]] < offs[cut[(size_t)k - 1]]) { nchunks = 1; break; }
     }
     if (nchunks == 1) { cut.assign(2, 0); cut[1] = n_docs; }
-    if (!u16 && nchunks == 1 && pretok && !bitmap && small_eligible(e, offs, n_docs, total)) {
-        bool handled = false;
-        st = encode_small(e, ws, bytes, offs, n_docs, total, out_ids, out_cap, out_offsets, needed, &handled);
-        if (st != TKZ_OK || handled) return st;
-    }
-    // page-locked caller buffers?  (a single chunk then needs no staging for its results; the copies of every path are asynchronous)
-    void *dv_in = nullptr, *dv_offs = nullptr, *dv_ids = nullptr, *dv_ooffs = nullptr;
-    const bool pin_in = pinned_host(u16 ? (const void*)units : (const void*)bytes, &dv_in) && pinned_host(offs, &dv_offs);
-    const bool pin_out = !bitmap && pinned_host(out_offsets, &dv_ooffs) && (out_cap == 0 || pinned_host(out_ids, &dv_ids));
     if (!u16 && nchunks == 1 && !(pin_in && pin_out && pretok && !bitmap && total > 0)) {
         // ---- one chunk, ordinary (pageable) buffers: blocking copies either side of the launch sequence ----
         HIP_TRY(ws->s_bytes[0].ensure((size_t)total + 64, acc));
@@ -1198,6 +1205,19 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
     // the kernels write the caller's page-locked ids and offsets themselves -- up to 8 MB of text: beyond that a DMA download beats k_place's stores over PCIe
     // (measured, round 5: 16 MB 1.08 ms direct, 1.00 ms staged)
     const bool direct_out = nchunks == 1 && pin_out && up_bytes <= (int64_t(8) << 20) * unit;
+    // TWO chunks' launch sequences are enqueued ahead (round 6).  Until then a chunk's kernels were launched when the chunk before had drained -- the host
+    // needs its token count to place the download --, so the device idled for the ~25 launches of every chunk (tools/gpu_job_sdma.sh: 64 MB as 8 chunks took
+    // 1.5 ms longer than as 2, ~250 us a chunk, whatever the download did).  Now chunk k + 2 is begun (encode_device, kCallBegin: enqueue and return) the
+    // moment chunk k has ended (kCallEnd: wait, evaluate, retry if a list has to grow), on the workspace and the stream chunk k has just left: odd and even chunks
+    // alternate between two leased workspaces, two input staging sets and -- since the download of chunk k is only ISSUED when k has ended -- three output sets.
+    std::unique_ptr<Lease> lease_b;
+    Workspace* W[2] = {ws, ws};
+    if (nchunks > 1) {
+        lease_b.reset(new Lease(e));
+        W[1] = lease_b->ws;
+        if (!W[1]->st_compute) HIP_TRY(hipStreamCreate(&W[1]->st_compute));
+    }
+    const int nout = nchunks > 2 ? 3 : (int)nchunks;
     int64_t max_units = 0, max_docs = 0;
     for (int64_t k = 0; k < nchunks; ++k) {
         max_units = std::max(max_units, offs[cut[(size_t)k + 1]] - offs[cut[(size_t)k]]);
@@ -1221,10 +1241,10 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
             HIP_TRY(ws->s_bytes[q].ensure((size_t)max_units + 64, acc));
             HIP_TRY(ws->s_offs[q].ensure((size_t)(max_docs + 1) * 8, acc));
         }
-        if (!direct_out) {
-            HIP_TRY(ws->s_out[q].ensure((size_t)std::max<int64_t>(std::min<int64_t>(out_cap, (u16 ? 3 : 1) * max_units), 1) * 4, acc));      // (a token is at least one byte, a code unit at most three)
-            HIP_TRY(ws->s_outoffs[q].ensure((size_t)(max_docs + 1) * 8, acc));
-        }
+    }
+    if (!direct_out) for (int o = 0; o < nout; ++o) {
+        HIP_TRY(ws->s_out[o].ensure((size_t)std::max<int64_t>(std::min<int64_t>(out_cap, (u16 ? 3 : 1) * max_units), 1) * 4, acc));      // (a token is at least one byte, a code unit at most three)
+        HIP_TRY(ws->s_outoffs[o].ensure((size_t)(max_docs + 1) * 8, acc));
     }
     // the input of chunk k, on its way to the device (stream st_in); for UTF-16 also its document marks, the UTF-8 length of every unit and their scan
     auto stage_in = [&](int64_t k) -> tkz_status {
@@ -1253,61 +1273,156 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
     };
     std::vector<int64_t> tok_base((size_t)nchunks + 1, 0);
     bool over = false;                                       // out_cap exceeded: the remaining chunks are only counted
+    // downloads by copy engine: page-locked results whose device-side address is their host address (hipHostMalloc, tkz_host_alloc, torch's pinned tensors --
+    // not memory registered after the fact, which the HSA runtime knows under another address)
+    if (ws->sdma_state == 0) {
+        bool ok = sdma_available(e->device);
+        for (int o = 0; o < 3 && ok; ++o) ok = sdma_signal_create(&ws->sig_out[o]) && sdma_signal_create(&ws->sig_outoffs[o]);
+        ws->sdma_state = ok ? 1 : -1;
+    }
+    bool sdma_out = ws->sdma_state == 1 && !direct_out && pin_out && dv_ooffs == (void*)out_offsets && (out_cap == 0 || dv_ids == (void*)out_ids);
+    bool sig_pending[3] = {false, false, false}, sigo_pending[3] = {false, false, false}, ev_pending[3] = {false, false, false};
+    auto wait_engine = [&](int o) {          // the copies of output set o that went by engine have arrived
+        bool ok = true;
+        if (sig_pending[o]) { sig_pending[o] = false; ok = sdma_signal_wait(ws->sig_out[o]) && ok; }
+        if (sigo_pending[o]) { sigo_pending[o] = false; ok = sdma_signal_wait(ws->sig_outoffs[o]) && ok; }
+        return ok;
+    };
     tkz_status first_err = TKZ_OK;
     std::string first_msg;
+    auto note = [&](tkz_status s) { if (first_err == TKZ_OK) { first_err = s; first_msg = g_err; } return s; };
     // (one small chunk on page-locked buffers: no upload stream at all -- the launch sequence starts with k_ingest, which fetches the text itself)
     const bool ingest_in = direct_out && !u16 && pin_in && total > 0 && (reinterpret_cast<uintptr_t>(dv_in) & 15) == 0;
     const IngestSrc ingest_src{static_cast<const uint8_t*>(dv_in), static_cast<const int64_t*>(dv_offs)};
-    if (!ingest_in) {
-        st = stage_in(0);
-        if (st != TKZ_OK) return st;
-    }
-    // (inside the loop a failed runtime call is RECORDED and the loop left -- never returned from: the upload of chunk k + 1 may still be reading the caller's text
-    //  and the download of chunk k - 1 writing the caller's ids, and the caller is free to release both the moment it sees the error; the two stream
-    //  synchronisations behind the loop always run first -- the round-5 advisor)
-#define LOOP_TRY(expr) { const hipError_t e_ = (expr); if (e_ != hipSuccess) { first_err = fail(TKZ_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); first_msg = g_err; break; } }
-    for (int64_t k = 0; k < nchunks; ++k) {
-        const int q = (int)(k & 1);
+    // what encode_device was given for the chunk in flight on W[q] (kCallEnd is handed the same)
+    struct InFlight { const uint8_t* cb; const int64_t* co; int64_t cbytes, nd, cap; int32_t* dst_ids; int64_t* dst_offs; } fl[2] = {};
+    // (inside the lambdas a failed runtime call is RECORDED, never returned from the function: the upload of a later chunk may still be reading the caller's text and the
+    //  download of an earlier one writing the caller's ids, and the caller is free to release both the moment it sees the error; the drain behind the loop always runs first)
+#define CHUNK_TRY(expr) { const hipError_t e_ = (expr); if (e_ != hipSuccess) return note(fail(TKZ_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_))); }
+    // enqueue chunk k's launch sequence behind its upload (one chunk: run it whole -- phase kCallWhole)
+    auto begin_chunk = [&](int64_t k, int phase, int64_t* tokens) -> tkz_status {
+        const int q = (int)(k & 1), o = (int)(k % nout);
+        Workspace* w = W[q];
         const int64_t d0 = cut[(size_t)k], d1 = cut[(size_t)k + 1], nu = offs[d1] - offs[d0], nd = d1 - d0;
-        if (k + 1 < nchunks) { st = stage_in(k + 1); if (st != TKZ_OK) { first_err = st; first_msg = g_err; break; } }     // (its staging set was last read by the kernels of chunk k-1: done)
-        const uint8_t* cb; const int64_t* co; int64_t cbytes;
+        InFlight& F = fl[q];
+        F.nd = nd;
         if (u16) {
             // the UTF-8 size of the chunk is known once its length pass is through (the host needs it: the launch shapes of the encode path)
             Workspace::U16Stage& U = ws->u16[q];
-            LOOP_TRY(hipEventSynchronize(ws->ev_in[q]));
-            if (U.h->err & kErrOffsets) { first_err = fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count"); first_msg = g_err; break; }
-            cbytes = U.h->grand;
-            LOOP_TRY(ws->u_bytes.ensure((size_t)cbytes + 64, acc));
-            Launch L{ws->st_compute, nullptr, ws};
-            launch_u16_write(L, U.units.as<uint16_t>(), nu, U.docbits.as<uint64_t>(), u16_tiles(nu), U.tbase.as<int64_t>(), ws->u_bytes.as<uint8_t>(),
+            CHUNK_TRY(hipEventSynchronize(ws->ev_in[q]));
+            if (U.h->err & kErrOffsets) return note(fail(TKZ_E_ARG, "document offsets must start at 0, be non-decreasing and end at the unit count"));
+            F.cbytes = U.h->grand;
+            CHUNK_TRY(ws->u_bytes[q].ensure((size_t)F.cbytes + 64, acc));
+            Launch L{w->st_compute, nullptr, w};
+            launch_u16_write(L, U.units.as<uint16_t>(), nu, U.docbits.as<uint64_t>(), u16_tiles(nu), U.tbase.as<int64_t>(), ws->u_bytes[q].as<uint8_t>(),
                              U.offs.as<int64_t>(), nd, U.grp.as<int32_t>(), reinterpret_cast<int64_t*>(U.counters.as<char>() + 8), U.boffs.as<int64_t>());
-            cb = ws->u_bytes.as<uint8_t>(); co = U.boffs.as<int64_t>();
+            F.cb = ws->u_bytes[q].as<uint8_t>(); F.co = U.boffs.as<int64_t>();
         } else {
-            if (!ingest_in) LOOP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_in[q], 0));
-            cb = ws->s_bytes[q].as<uint8_t>(); co = ws->s_offs[q].as<int64_t>(); cbytes = nu;
+            if (!ingest_in) CHUNK_TRY(hipStreamWaitEvent(w->st_compute, ws->ev_in[q], 0));
+            F.cb = ws->s_bytes[q].as<uint8_t>(); F.co = ws->s_offs[q].as<int64_t>(); F.cbytes = nu;
         }
-        if (k >= 2) LOOP_TRY(hipStreamWaitEvent(ws->st_compute, ws->ev_out[q], 0));   // the download of chunk k-2 has left this set's output buffers
-        int32_t* dst_ids = direct_out ? static_cast<int32_t*>(dv_ids) : ws->s_out[q].as<int32_t>();
-        int64_t* dst_offs = direct_out ? static_cast<int64_t*>(dv_ooffs) : ws->s_outoffs[q].as<int64_t>();
-        const int64_t cap = over ? 0 : (direct_out ? std::min<int64_t>(out_cap, cbytes) : std::min<int64_t>(out_cap - tok_base[(size_t)k], cbytes));
-        int64_t tokens = 0;
-        st = encode_device(e, ws, cb, co, nd, cbytes, dst_ids, cap, dst_offs, ws->st_compute, true, nullptr, &tokens, nullptr, kCallWhole, nullptr,
-                           ingest_in ? &ingest_src : nullptr);      // (returns when st_compute has drained)
+        // the download of chunk k - nout has left this chunk's output set
+        if (!wait_engine(o)) return note(fail(TKZ_E_DEVICE, "a copy engine reported an error for a download"));
+        if (ev_pending[o]) { ev_pending[o] = false; CHUNK_TRY(hipStreamWaitEvent(w->st_compute, ws->ev_out[o], 0)); }
+        F.dst_ids = direct_out ? static_cast<int32_t*>(dv_ids) : ws->s_out[o].as<int32_t>();
+        F.dst_offs = direct_out ? static_cast<int64_t*>(dv_ooffs) : ws->s_outoffs[o].as<int64_t>();
+        // (how much of out_cap the chunks before leave is not known yet when a chunk is begun: the staging set holds a chunk's ids whatever their number, and the
+        //  sum is checked when the chunk ends)
+        F.cap = over ? 0 : std::min<int64_t>(out_cap, F.cbytes);
+        return encode_device(e, w, F.cb, F.co, F.nd, F.cbytes, F.dst_ids, F.cap, F.dst_offs, w->st_compute, true, nullptr, tokens, nullptr, phase, nullptr,
+                             ingest_in ? &ingest_src : nullptr);
+    };
+    auto end_chunk = [&](int64_t k, int64_t* tokens) -> tkz_status {          // (returns when the chunk's stream has drained)
+        const InFlight& F = fl[k & 1];
+        Workspace* w = W[k & 1];
+        return encode_device(e, w, F.cb, F.co, F.nd, F.cbytes, F.dst_ids, F.cap, F.dst_offs, w->st_compute, true, nullptr, tokens, nullptr, kCallEnd, nullptr, nullptr);
+    };
+    // The download of chunk k.  The runtime's D2H copy of page-locked memory is a blit KERNEL and other kernels make no progress beside it (traced, round 5; a
+    // small-grid download kernel of our own stalled their first stores until its PCIe writes had drained).  Page-locked results therefore leave on a COPY ENGINE
+    // of their own, named through the HSA runtime (tkz_sdma.h; tools/sdma_probe.hip: 56 GB/s beside a store-heavy kernel, and beside the runtime's upload
+    // when the engines differ).  The kernels of the chunk have completed (end_chunk returned), which is all such a copy waits for.
+    auto download = [&](int64_t k, int64_t tokens) -> tkz_status {
+        const int o = (int)(k % nout);
+        const int64_t d0 = cut[(size_t)k], nd = cut[(size_t)k + 1] - d0;
+        bool ids_sent = tokens == 0, offs_sent = false;
+        const size_t nb_ids = (size_t)tokens * 4, nb_offs = (size_t)(nd + 1) * 8;
+        // (an engine that refuses a copy is not asked again: that copy and the rest of the call go through the runtime)
+        auto by_engine = [&](void* dst, const void* src, size_t nb, SdmaSignal sg, bool* pending) {
+            if (!sdma_out) return false;
+            sdma_signal_arm(sg, 1);
+            if (sdma_copy_d2h(e->device, dst, src, nb, sg)) { *pending = true; return true; }
+            sdma_signal_arm(sg, 0); sdma_out = false; ws->sdma_state = -1;
+            return false;
+        };
+        if (tokens) ids_sent = by_engine(out_ids + tok_base[(size_t)k], ws->s_out[o].p, nb_ids, ws->sig_out[o], &sig_pending[o]);
+        offs_sent = by_engine(out_offsets + d0, ws->s_outoffs[o].p, nb_offs, ws->sig_outoffs[o], &sigo_pending[o]);
+        if (!ids_sent || !offs_sent) {
+            if (!ids_sent) CHUNK_TRY(hipMemcpyAsync(out_ids + tok_base[(size_t)k], ws->s_out[o].p, nb_ids, hipMemcpyDeviceToHost, ws->st_out));
+            if (!offs_sent) CHUNK_TRY(hipMemcpyAsync(out_offsets + d0, ws->s_outoffs[o].p, nb_offs, hipMemcpyDeviceToHost, ws->st_out));
+            CHUNK_TRY(hipEventRecord(ws->ev_out[o], ws->st_out));
+            ev_pending[o] = true;
+        }
+        return TKZ_OK;
+    };
+    int64_t begun = 0, ended = 0;            // chunks [ended, begun) are in flight
+    // ($TKZ_TRACE_HOST: the host's side of the pipeline on stderr -- microseconds since the call began at which each step RETURNED; development)
+    static const bool kTraceHost = getenv("TKZ_TRACE_HOST") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    std::vector<std::pair<std::string, double>> stamps;
+    auto stamp = [&](const char* what, int64_t k) {
+        if (kTraceHost) stamps.emplace_back(std::string(what) + " " + std::to_string(k), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count());
+    };
+    auto finish = [&](int64_t k, tkz_status cs, int64_t tokens) -> bool {      // chunk k has ended with status cs: its place in the output, its download; false: stop
         tok_base[(size_t)k + 1] = tok_base[(size_t)k] + tokens;
-        if (st == TKZ_E_CAPACITY) { over = true; continue; }
-        if (st != TKZ_OK) { first_err = st; first_msg = g_err; break; }
-        if (!over && !direct_out) {
-            // (the runtime's D2H copy of page-locked memory is a blit kernel and the next chunk's kernels make no progress beside it -- traced: chunk k+1 starts
-            //  the moment chunk k's download ends.  A small-grid download kernel of our own was tried: the next chunk's kernels then start at once but stall in
-            //  their first stores until the PCIe writes have drained, and the kernel is slower than the blit -- 16 MB 0.89 -> 1.05 ms.  DESIGN.md 6)
-            if (tokens) LOOP_TRY(hipMemcpyAsync(out_ids + tok_base[(size_t)k], ws->s_out[q].p, (size_t)tokens * 4, hipMemcpyDeviceToHost, ws->st_out));
-            LOOP_TRY(hipMemcpyAsync(out_offsets + d0, ws->s_outoffs[q].p, (size_t)(nd + 1) * 8, hipMemcpyDeviceToHost, ws->st_out));
-            LOOP_TRY(hipEventRecord(ws->ev_out[q], ws->st_out));
+        if (cs == TKZ_E_CAPACITY || (cs == TKZ_OK && tok_base[(size_t)k + 1] > out_cap)) { over = true; return true; }
+        if (cs != TKZ_OK) { note(cs); return false; }
+        if (!over && !direct_out && download(k, tokens) != TKZ_OK) return false;
+        return true;
+    };
+    if (nchunks == 1) {
+        int64_t tokens = 0;
+        const tkz_status ss = ingest_in ? TKZ_OK : stage_in(0);
+        if (ss == TKZ_OK) { const tkz_status cs = begin_chunk(0, kCallWhole, &tokens); if (first_err == TKZ_OK) (void)finish(0, cs, tokens); }
+        else note(ss);
+    } else {
+        // (upload 1 is issued BEHIND launch sequence 0, although that starts it ~130 us late: an upload stream's k_rebase kernel waits in a hardware queue for its copy, and
+        //  the launch sequence of chunk 0 enqueued behind it -- the runtime maps its streams onto a few hardware queues -- waited with it: 16 MB 884 -> 1,040 us)
+        for (int64_t k = 0; k < 2 && first_err == TKZ_OK; ++k) {
+            { const tkz_status ss = stage_in(k); if (ss != TKZ_OK) { note(ss); break; } }
+            const tkz_status bs = begin_chunk(k, kCallBegin, nullptr);
+            if (bs != TKZ_OK) { note(bs); break; }
+            ++begun;
+            stamp("begun", k);
         }
+        for (int64_t k = 0; k < nchunks && first_err == TKZ_OK; ++k) {
+            int64_t tokens = 0;
+            const tkz_status cs = end_chunk(k, &tokens);
+            ++ended;
+            stamp("ended", k);
+            if (!finish(k, cs, tokens)) break;
+            stamp("download issued", k);
+            if (k + 2 < nchunks) {         // (its input set and its workspace are chunk k's: free now)
+                tkz_status bs = stage_in(k + 2);
+                if (bs == TKZ_OK) bs = begin_chunk(k + 2, kCallBegin, nullptr);
+                if (bs != TKZ_OK) { note(bs); break; }
+                ++begun;
+                stamp("begun", k + 2);
+            }
+        }
+        // (a chunk that was begun is always ended: its workspace may hold the encoder's learning slot, and its kernels write the staging sets)
+        for (; ended < begun; ++ended) { const std::string keep = g_err; int64_t t = 0; (void)end_chunk(ended, &t); g_err = keep; }
     }
-#undef LOOP_TRY
+#undef CHUNK_TRY
     (void)hipStreamSynchronize(ws->st_in);      // (an error of the runtime here is an error of the copies above: reported by them or by the next call)
     (void)hipStreamSynchronize(ws->st_out);
+    for (int o = 0; o < 3; ++o)
+        if (!wait_engine(o)) note(fail(TKZ_E_DEVICE, "a copy engine reported an error for a download"));
+    if (kTraceHost && nchunks > 1) {
+        stamp("downloads arrived", nchunks);
+        std::string line = "[tkz host trace] " + std::to_string(nchunks) + " chunks:";
+        for (const auto& sp : stamps) { char b[96]; snprintf(b, sizeof b, " %s @%.0f", sp.first.c_str(), sp.second); line += b; }
+        fprintf(stderr, "%s\n", line.c_str());
+    }
     if (first_err != TKZ_OK) return fail(first_err, first_msg);
     if (needed) *needed = tok_base[(size_t)nchunks];
     if (over) return fail(TKZ_E_CAPACITY, "output capacity too small");
