@@ -976,8 +976,8 @@ TKZ_HD int tkz_result_cnt(uint32_t r) { return (int)((r >> kMrCntShift) & 1023u)
 TKZ_HD int tkz_result_off(uint32_t r) { return (int)(r & kMrOffMask); }
 
 // largest q in [0, N) with pre[q] <= g  (pre: non-decreasing exclusive prefix sums in LDS, g below the total): the list a position belongs to
-template <int N>
-TKZ_DEV int tkz_find_list(const int* pre, int g) {
+template <int N, class Pre>
+TKZ_DEV int tkz_find_list(const Pre* pre, int g) {
     int q = 0;
 #pragma unroll
     for (int step = N / 2; step >= 1; step >>= 1) if (pre[q + step] <= g) q += step;
@@ -992,20 +992,31 @@ TKZ_DEV int tkz_find_list(const int* pre, int g) {
 // dependent round trips, a memo lookup 4 and one.  Every entry is answered in place (tkz_result_entry); the records are never read.
 // (LDS: 4 x 9.25 KB of merge state + 2.3 KB = 40 KB per workgroup, and <= 128 VGPRs: four workgroups = 16 wavefronts per CU)
 constexpr int kMsStride = TkzBpeGeom<16>::kStride, kMsIdStride = TkzBpeGeom<16>::kIdStride;
+#ifndef TKZ_MS_SHORT_LEN
+#define TKZ_MS_SHORT_LEN 8
+#endif
+#ifndef TKZ_MS_TWO_MIN
+#define TKZ_MS_TWO_MIN 320
+#endif
+constexpr int kMsTwoListsMin = TKZ_MS_TWO_MIN;         // ... when the group's lists hold at least this many entries
+constexpr int kMsShortLen = TKZ_MS_SHORT_LEN;          // k_merge_short's two lists: pieces of up to this many bytes | longer ones
 // LDS of one wavefront of k_merge_short (+ the byte-id table shared by the workgroup)
-struct MsLds { uint4* pr; uint32_t* ids; uint16_t* rec; uint16_t* idx; int* extra; int* pre; const uint16_t* brank16; };
-constexpr int kMsLdsBytes = kMsStride * 64 * 4 + kMsIdStride * 64 * 4 + 2 * 64 + 2 * 64 + 4 * kGroup + 4 * (kGroup + 1) + 12;   // per wavefront, rounded to 16 below
+struct MsLds { uint4* pr; uint32_t* ids; uint16_t* rec; uint16_t* idx; int* extra; uint16_t* pre; const uint16_t* brank16; };
+// (four workgroups of four wavefronts a CU: 40,960 bytes a workgroup with the 512 of the byte-id table -- 10,112 a wavefront at most)
+constexpr int kMsLdsBytes = kMsStride * 64 * 4 + kMsIdStride * 64 * 4 + 2 * (2 * 64 + 2 * 64) + 4 * kGroup + 2 * (kGroup + 1);   // per wavefront, rounded to 16 below
 constexpr int kMsLdsQuads = (kMsLdsBytes + 15) / 16;
+static_assert((kMsThreads / 64) * kMsLdsQuads * 16 + 512 <= 40960, "k_merge_short: four workgroups a CU (160 KB of LDS, allocated in units of 1,280 bytes)");
 TKZ_DEV MsLds tkz_ms_lds(uint4* wave_quads, const uint16_t* brank16) {
     MsLds L;
     uint8_t* b = reinterpret_cast<uint8_t*>(wave_quads);
     L.pr = reinterpret_cast<uint4*>(b); b += kMsStride * 64 * 4;              // per lane pr[16] at a conflict-free stride for 16-byte reads
     L.ids = reinterpret_cast<uint32_t*>(b); b += kMsIdStride * 64 * 4;        // per lane ids[16]
     L.extra = reinterpret_cast<int*>(b); b += 4 * kGroup;                     // tokens the merges added to every sub-tile of the group
-    L.pre = reinterpret_cast<int*>(b); b += 4 * (kGroup + 1);                 // exclusive prefix of the lists' lengths
-    // the wave's list: relpos | (len-1) << 10 | looked-up-in-the-memo << 15, and (sub-tile of the group) << 10 | index in its miss list
-    L.rec = reinterpret_cast<uint16_t*>(b); b += 2 * 64;
-    L.idx = reinterpret_cast<uint16_t*>(b);
+    // the wave's TWO lists of pieces that missed the memo (up to 8 bytes | 9..16 bytes), 64 entries each: relpos | (len-1) << 10, and
+    // (sub-tile of the group) << 10 | index in its miss list
+    L.rec = reinterpret_cast<uint16_t*>(b); b += 2 * 2 * 64;
+    L.idx = reinterpret_cast<uint16_t*>(b); b += 2 * 2 * 64;
+    L.pre = reinterpret_cast<uint16_t*>(b);                                   // exclusive prefix of the lists' lengths (16 lists of at most 1,024 entries)
     L.brank16 = brank16;
     return L;
 }
@@ -1033,7 +1044,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     uint16_t* s_rec = LD.rec;
     uint16_t* s_idx = LD.idx;
     int* s_extra = LD.extra;
-    int* s_pre = LD.pre;
+    uint16_t* s_pre = LD.pre;
     uint32_t* ids = LD.ids + lane * IDSTRIDE;
     uint32_t* pr = reinterpret_cast<uint32_t*>(LD.pr) + lane * STRIDE;
     // lane q < kGroup looks after sub-tile q of the group: how many pieces start there, how long its short-miss list is
@@ -1042,10 +1053,11 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     // (a list longer than mcap was cut by k_probe, which has reported it: the batch is redone; keep to what was written)
     { const int nl_ = lane < kGroup && sub0 + lane < P.nsub ? (int)(P.mcount[sub0 + lane] >> 16) : 0; if (my_ns + nl_ > P.mcap) my_ns = 0; }
     int ntotal;
-    { const int pre = tkz_wave_scan_sum(my_ns, &ntotal); if (lane <= kGroup) s_pre[lane] = pre; }
+    { const int pre = tkz_wave_scan_sum(my_ns, &ntotal); if (lane <= kGroup) s_pre[lane] = (uint16_t)pre; }
     if (lane < kGroup) s_extra[lane] = 0;
     uint32_t* const ml0 = P.mlist + sub0 * (int64_t)P.mcap;
-    int err = 0, nlist = 0, nchk = 0, dused = 0, done = 0;      // list entries [0, nchk) have been through the memo, [nchk, nlist) not yet
+    int err = 0, dused = 0, done = 0;
+    int nl0 = 0, nl1 = 0;                                       // entries in the wave's two lists (pieces of up to kMsShortLen bytes | longer ones): all have missed the memo
     int st_look = 0, st_hit = 0;                                // TKZ_OPT_PIECE_STATS: memo lookups and hits of this group (one pair of atomics at its end)
     int32_t* const dense = P.dense + grp * kDenseCap;
     const bool memo = T.memo_n != 0;
@@ -1091,13 +1103,11 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
     // (an entry never changes once valid), so whatever mixture of old and new words a reader may be handed -- the key and the value are
     // two loads, and a slot can be claimed between them -- a key without zero bytes inside its length can only ever equal a COMPLETE key of the
     // same length, and then the value it is paired with is either that key's (valid) or not valid at all.
-    // (fr16 / fix / fkq: the entry and the quad of the lanes that hold a NEW entry -- list positions [nchk, nlist) --, fetched together by
-    //  those very lanes: the memo slot is the only round trip between taking an entry and answering it)
-    auto memo_phase = [&](uint32_t fr16, uint32_t fix, uint4 fkq) {
+    // (r16 / ix / fkq: the entry and the quad of the `take` lanes that hold a NEW entry, fetched together by those very lanes: the memo slot is the only
+    //  round trip between taking an entry and answering it.)  Returns, per lane, whether its piece has to be merged; the caller lists it.
+    auto memo_phase = [&](int take, uint32_t r16, uint32_t ix, uint4 fkq) -> bool {
         (void)simt::ballot(true);
-        const bool mine = lane >= nchk && lane < nlist;
-        uint32_t r16 = fr16, ix = fix;
-        if (lane < nchk) { r16 = s_rec[lane]; ix = s_idx[lane]; }
+        const bool mine = lane < take;
         const int si = (int)(ix >> 10), j = (int)(ix & 1023u), rel = (int)(r16 & 1023u), len = (int)((r16 >> 10) & 15u) + 1;
         bool hit = false;
         uint32_t hit_slot = 0;
@@ -1124,7 +1134,7 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
         // microsecond each (the first batch under synth100k took 2.4 s instead of 25 ms when every hit of every eighth group was counted).  A counter
         // also stops at kMemoHitsSat (read with an agent-scope atomic load: the line in this XCD's L2 may be stale): such a slot is promoted anyway.
         if (count_hits) {
-            if (hit && (!sparse || lane == ((done * 5 + nlist) & 63)) && tkz_atomic_load_agent(&T.memo_hits[hit_slot]) < kMemoHitsSat)
+            if (hit && (!sparse || lane == ((done * 5 + nl0 + nl1) & 63)) && tkz_atomic_load_agent(&T.memo_hits[hit_slot]) < kMemoHitsSat)
                 simt::atomic_add(reinterpret_cast<int*>(&T.memo_hits[hit_slot]), 1);
         }
         if (P.stats) { st_look += tkz_popc64(simt::ballot(mine && memo)); st_hit += tkz_popc64(simt::ballot(hit)); }   // (statistics run only: wave-uniform, null in the timed runs)
@@ -1134,21 +1144,18 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
             uint4 tq; tq.x = vv.x & 0x07FFFFFFu; tq.y = vv.y & 0x07FFFFFFu; tq.z = vv.z & 0x07FFFFFFu; tq.w = vv.w & 0x07FFFFFFu;
             mq0[si * (int64_t)P.mcap + j] = tq;
         }
-        const bool keep = lane < nchk || (mine && !hit);
-        const uint64_t km = simt::ballot(keep);
-        if (keep) { const int o = tkz_popc64(km & tkz_lowmask(lane)); s_rec[o] = (uint16_t)(r16 | 0x8000u); s_idx[o] = (uint16_t)ix; }
-        nlist = nchk = tkz_popc64(km);
         (void)simt::ballot(true);
+        return mine && !hit;
     };
-    // one batch: lane i < n merges the piece of list entry i (all of them have missed the memo)
-    auto run_batch = [&](int n) {
+    // one batch: lane i < n merges the piece of entry i of list c
+    auto run_batch = [&](int c, int n) {
         (void)simt::ballot(true);
         int cnt = 0, si = 0, j = 0, rel = 0, e1 = 0, len = 1;
         bool nul = false;
         uint32_t alive = 1;
         uint32_t kw[4] = {0, 0, 0, 0};
         if (lane < n) {
-            const uint32_t r16 = s_rec[lane], ix = s_idx[lane];
+            const uint32_t r16 = s_rec[64 * c + lane], ix = s_idx[64 * c + lane];
             si = (int)(ix >> 10); j = (int)(ix & 1023u); rel = (int)(r16 & 1023u); len = (int)((r16 >> 10) & 15u) + 1;
             key_of(tkz_load16(&mq0[si * (int64_t)P.mcap + j]), len, kw, &nul);
             cnt = tkz_bpe_lane_f<NMAX>(T, kw, len, ids, pr, byte_id, pair_rank, &alive, &e1);
@@ -1191,36 +1198,56 @@ TKZ_DEV void tkz_merge_short_group(const TkzTables& T, const EncodeParams& P, in
         (void)simt::ballot(true);
     };
     (void)simt::ballot(true);
-    // Entry g of the group's concatenated lists is entry g - pre[q] of sub-tile q.  Lane i always has entries done + i of the lists in flight
-    // (entry, quad: two independent loads), requested while the entries before them are looked up in the memo; when the wave's list has
-    // room for `take` more, list position nlist + e gets what lane e holds (a shuffle).
+    // Entry g of the group's concatenated lists is entry g - pre[q] of sub-tile q.  Lane i always has entry done + i of the lists in flight
+    // (entry, quad: two independent loads), requested while the entries before them are looked up in the memo.
     auto request = [&](int g, uint32_t* r16, uint32_t* ix, uint4* kq) {
         *r16 = 0; *ix = 0; kq->x = kq->y = kq->z = kq->w = 0;
         if (g < ntotal) {
-            const int q = tkz_find_list<kGroup>(s_pre, g), j = g - s_pre[q];
+            const int q = tkz_find_list<kGroup>(s_pre, g), j = g - (int)s_pre[q];
             const uint32_t ent = tkz_load_nt(&ml0[q * (int64_t)P.mcap + j]);
             *kq = tkz_load16(&mq0[q * (int64_t)P.mcap + j]);
             *r16 = (ent & 1023u) | (((ent >> kMrLenShift) & 15u) << 10);
             *ix = (uint32_t)((q << 10) | j);
         }
     };
+    // The pieces that have to be merged wait in TWO lists, by length (round 6): a batch lasts as long as its longest piece -- a merge a step, a round trip a
+    // merge --, and with lengths 1..16 in one batch the lanes of the short pieces idled for half of it (lane use 0.4).  A list that reaches 64 entries is
+    // merged; what is left of both at the end goes as ONE batch if it fits one (the bench text: ~40 survivors a group), else as one batch a list.
+    // (Two lists only for a group with many misses -- kMsTwoListsMin entries, 20 a sub-tile: source text has ~860 a group and gains (k_merge_short 1.66 -> 1.10 ms on
+    //  436 MB), the bench text has ~160, ends with ONE batch of ~40 pieces either way and only paid for the second list: 2.39 -> 2.55 ms.  profiles/r06/variants_merge_short2.txt)
+    const bool two = ntotal >= kMsTwoListsMin;
     uint32_t a_r16, a_ix;
     uint4 a_kq;
     request(lane, &a_r16, &a_ix, &a_kq);
     while (done < ntotal) {
-        const int take = ntotal - done < 64 - nlist ? ntotal - done : 64 - nlist;
-        // list position p in [nlist, nlist + take) <- what lane p - nlist holds
-        const int src = (lane - nlist) & 63;
-        const uint32_t f_r16 = simt::shflu(a_r16, src), f_ix = simt::shflu(a_ix, src);
-        uint4 f_kq;
-        f_kq.x = simt::shflu(a_kq.x, src); f_kq.y = simt::shflu(a_kq.y, src); f_kq.z = simt::shflu(a_kq.z, src); f_kq.w = simt::shflu(a_kq.w, src);
-        if (lane >= nlist && lane < nlist + take) { s_rec[lane] = (uint16_t)f_r16; s_idx[lane] = (uint16_t)f_ix; }
-        nlist += take; done += take;
+        const int take = ntotal - done < 64 ? ntotal - done : 64;
+        const uint32_t f_r16 = a_r16, f_ix = a_ix;
+        const uint4 f_kq = a_kq;
+        done += take;
         request(done + lane, &a_r16, &a_ix, &a_kq);            // (the entries behind these: in flight during the memo lookups)
-        memo_phase(f_r16, f_ix, f_kq);
-        if (nlist == 64) { run_batch(64); nlist = nchk = 0; }
+        const bool merge_it = memo_phase(take, f_r16, f_ix, f_kq);
+        const int cls = two && ((f_r16 >> 10) & 15u) >= (uint32_t)kMsShortLen ? 1 : 0;       // (the field holds len - 1)
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            const uint64_t m = simt::ballot(merge_it && cls == c);
+            const int had = c ? nl1 : nl0;
+            const int pos = had + tkz_popc64(m & tkz_lowmask(lane)), tot = had + tkz_popc64(m);
+            const bool here = merge_it && cls == c;
+            if (here && pos < 64) { s_rec[64 * c + pos] = (uint16_t)f_r16; s_idx[64 * c + pos] = (uint16_t)f_ix; }
+            if (tot >= 64) {                                   // the list is full: its batch, then the entries that did not fit
+                run_batch(c, 64);
+                if (here && pos >= 64) { s_rec[64 * c + pos - 64] = (uint16_t)f_r16; s_idx[64 * c + pos - 64] = (uint16_t)f_ix; }
+                if (c) nl1 = tot - 64; else nl0 = tot - 64;
+            } else if (c) nl1 = tot; else nl0 = tot;
+        }
     }
-    if (nlist > 0) run_batch(nlist);
+    if (nl0 + nl1 <= 64 && nl1 > 0) {                           // (one batch for both lists' leftovers)
+        (void)simt::ballot(true);
+        if (lane < nl1) { s_rec[nl0 + lane] = s_rec[64 + lane]; s_idx[nl0 + lane] = s_idx[64 + lane]; }
+        nl0 += nl1; nl1 = 0;
+    }
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) { const int n = c ? nl1 : nl0; if (n > 0) run_batch(c, n); }
     (void)simt::ballot(true);
     // tokens of every sub-tile of the group: one per piece, plus what the merges added (k_merge_long adds its own later)
     if (lane < kGroup && sub0 + lane < P.nsub) {
