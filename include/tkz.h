@@ -366,6 +366,10 @@ int64_t tkz_encoder_workspace_bytes(const tkz_encoder* e);
 /* Informational: batches whose kernels of the long missed pieces (k_merge_long_q, k_merge_coop) ran BESIDE k_merge_short on streams of their own instead of behind it --
  * a batch above TKZ_OPT_LATENCY_BYTES on a workspace whose previous such batch left at most 2^20 long misses (the launch sequence of a large batch). */
 int64_t tkz_encoder_side_by_side_batches(const tkz_encoder* e);
+/* Informational: copies of results (ids, offsets) of host-buffer calls that left the device on a copy engine of their own, named through the HSA runtime
+ * (csrc/tkz_sdma.h) -- the chunks of a batch of 12 MB or more whose result buffers are page-locked (tkz_host_alloc, hipHostMalloc).  0 when the runtime
+ * library or its entry points are missing, or TKZ_D2H_ENGINE=-1: such downloads go through hipMemcpyAsync. */
+int64_t tkz_encoder_engine_downloads(const tkz_encoder* e);
 const char* tkz_kernel_name(int32_t k);
 
 /* Synthetic corpus of BASELINE.json's configs, generated ON DEVICE by a counter-based generator

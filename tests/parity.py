@@ -869,7 +869,10 @@ def check_miss_lists(lib, O, vocab, ovocab, pattern=N.CL100K, seed=41):
                 gib(3000, 17, 30).encode(),                                                           # long misses only
                 ("a\nb\nc\nd\n" * 600).encode(),                                                      # 1024 pieces per sub-tile, all hits
                 "".join(rng.choice(cons) + "\n" for _ in range(2000)).encode(),
-                gib(700, 2, 3).encode() + ("x" * 1500).encode() + gib(700, 2, 16).encode()]           # a giant piece between crowded sub-tiles
+                gib(700, 2, 3).encode() + ("x" * 1500).encode() + gib(700, 2, 16).encode(),           # a giant piece between crowded sub-tiles
+                # (round 6) a group of 16 sub-tiles with ~2,000 short misses of EVERY length 1..16: k_merge_short keeps the pieces the memo does not answer in two
+                # lists by length (<= 8 bytes | 9..16) from 320 misses a group on -- both fill, overflow mid-round and leave leftovers that share the last batch
+                gib(20000, 1, 16).encode(), (gib(9000, 1, 8) + gib(9000, 9, 16)).encode()]
     # k_place's two paths: sub-tiles whose lists straddle what it keeps in LDS (32 of each kind), whose token runs straddle kPlaceBig (8),
     # with more than 256 pieces, and batches of tiny documents (up to four document starts in the four records a lane holds)
     words = "the of and to in is that for it with as was on be at by this had not are but from or have an they which one you were her all".split()

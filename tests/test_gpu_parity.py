@@ -473,6 +473,9 @@ def test_host_path_chunked_and_threads(lib, vocabs, oracle_mod):
     dt = time.perf_counter() - t0
     assert np.array_equal(ids, want_ids) and np.array_equal(ooff, want_offs)
     print("host path, page-locked buffers: %.1f GB/s" % (len(h_bytes) / dt / 1e9))
+    # the chunks' results left on a copy engine of their own (csrc/tkz_sdma.cpp): ids + offsets of every chunk -- unless the run switched that off
+    if os.environ.get("TKZ_D2H_ENGINE") != "-1":
+        assert enc.engine_downloads >= 2 * (len(h_bytes) // (24 << 20)), enc.engine_downloads
     # mid-size page-locked batches: 20 MB (chunks of a quarter of the batch), 3 MB (one chunk, fetched by k_ingest, ids
     # written by k_place itself) -- twice each: a fresh workspace, then a sized one
     for nd in (40_000, 6_000):

@@ -131,6 +131,8 @@ class Library:
         L.tkz_encoder_workspace_bytes.restype = i64
         L.tkz_encoder_side_by_side_batches.argtypes = [vp]
         L.tkz_encoder_side_by_side_batches.restype = i64
+        L.tkz_encoder_engine_downloads.argtypes = [vp]
+        L.tkz_encoder_engine_downloads.restype = i64
         L.tkz_kernel_name.argtypes = [i32]
         L.tkz_kernel_name.restype = C.c_char_p
         L.tkz_corpus_generate_device.argtypes = [i32, i32, C.c_uint64, i64, i64, i32, i32, vp, vp, i64, vp, pi64]
@@ -318,6 +320,11 @@ class Encoder:
     @property
     def workspace_bytes(self):
         return self.lib.L.tkz_encoder_workspace_bytes(self._h)
+
+    @property
+    def engine_downloads(self):
+        """Copies of host-call results that left the device on a copy engine of their own (tkz_encoder_engine_downloads)."""
+        return self.lib.L.tkz_encoder_engine_downloads(self._h)
 
     @property
     def side_by_side_batches(self):

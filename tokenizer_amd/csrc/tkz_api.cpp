@@ -153,6 +153,7 @@ struct Workspace {
     hipEvent_t ev_in[2] = {}, ev_done[2] = {}, ev_out[3] = {};
     tkz::SdmaSignal sig_out[3], sig_outoffs[3];   // downloads on a copy engine of their own (tkz_sdma.h): the completion signal of each staging set
     int sdma_state = 0;                    // 0 not looked at, 1 in use, -1 not available: the runtime's hipMemcpyAsync
+    std::atomic<int64_t> engine_downloads{0};      // copies of results that went by copy engine (tkz_encoder_engine_downloads)
     int64_t bytes_allocated = 0;
     bool busy = false;
     // profiling
@@ -1350,7 +1351,7 @@ tkz_status encode_host(tkz_encoder* e, const uint8_t* bytes, const uint16_t* uni
         auto by_engine = [&](void* dst, const void* src, size_t nb, SdmaSignal sg, bool* pending) {
             if (!sdma_out) return false;
             sdma_signal_arm(sg, 1);
-            if (sdma_copy_d2h(e->device, dst, src, nb, sg)) { *pending = true; return true; }
+            if (sdma_copy_d2h(e->device, dst, src, nb, sg)) { *pending = true; ws->engine_downloads.fetch_add(1, std::memory_order_relaxed); return true; }
             sdma_signal_arm(sg, 0); sdma_out = false; ws->sdma_state = -1;
             return false;
         };
@@ -2159,6 +2160,14 @@ int64_t tkz_encoder_side_by_side_batches(const tkz_encoder* e) {
     std::lock_guard<std::mutex> lock(m->mu);
     int64_t n = 0;
     for (Workspace* w : e->pool) n += w->forked_batches;
+    return n;
+}
+int64_t tkz_encoder_engine_downloads(const tkz_encoder* e) {
+    if (!e) return 0;
+    tkz_encoder* m = const_cast<tkz_encoder*>(e);
+    std::lock_guard<std::mutex> lock(m->mu);
+    int64_t n = 0;
+    for (Workspace* w : e->pool) n += w->engine_downloads.load(std::memory_order_relaxed);
     return n;
 }
 const char* tkz_kernel_name(int32_t k) {
