@@ -1495,6 +1495,20 @@ def check_host_chunks(lib, O, vocab, ovocab, pattern=N.CL100K, seed=21):
     with pytest.raises(N.TkzError) as ei:
         enc.encode_batch(np.frombuffer(b"x" * 40000, np.uint8), np.array([0, 30000, 20000, 40000]))
     assert ei.value.code == N.E_ARG
+    # an error in a LATER chunk while the chunks behind it are already enqueued (round 6: two launch sequences ahead): the call reports it, every chunk
+    # that was begun is ended, and the encoder serves the next call as if nothing had happened -- on both workspaces of the pipeline
+    good = [gen_text(rng, "mix", 3000, alpha).encode("utf-8") for _ in range(12)]
+    for bad_at in (0, 3, 7, 11):
+        docs = list(good)
+        docs[bad_at] = docs[bad_at][:1500] + b"\xC3(" + docs[bad_at][1500:]            # a lead byte without its continuation
+        data, offs = pack(docs)
+        with pytest.raises(N.TkzError) as ei:
+            enc.encode_batch(data, offs)
+        assert ei.value.code == N.E_INVALID_UTF8, (bad_at, ei.value.code)
+        data, offs = pack(good)
+        ids, ooff = enc.encode_batch(data, offs)
+        exp, eoff = oracle_encode_docs(oenc, good)
+        assert ids.tolist() == exp and ooff.tolist() == eoff, bad_at
     # UTF-16 batches through the chunks (round 6: the chunk loop serves that entry too): a document that spans a chunk cut -- or several -- leaves chunks
     # WITHOUT any document or unit: no kernel may be launched on nothing (a grid of 0 workgroups is an invalid configuration on HIP; the emulator aborts on it)
     for shape in ("one", "last", "first", "empties"):

@@ -2126,11 +2126,14 @@ tkz_status tkz_encoder_reserve(tkz_encoder* e, int64_t max_bytes, int64_t max_do
     HIP_TRY(ws->w_xq.ensure((size_t)(nwords / kRowsPerWave + 4) * 16, acc));                      // (the o200k scanners' queues)
     if (!ws->h_counters) HIP_TRY(hipHostMalloc((void**)&ws->h_counters, sizeof(CounterBlock), 0));
     HIP_TRY(ensure_streams(ws));
-    {   // what the host-buffer entry points stage a chunk in (two sets: tkz_encode_batch_utf8 cuts a large batch into chunks of 32 MB)
+    {   // what the host-buffer entry points stage a chunk in (two input sets, three output sets: encode_host cuts a large batch into chunks of at most 32 MB; the
+        // second workspace its pipeline leases for every other chunk is a chunk's size and sizes itself on its first use)
         const int64_t chunk = std::min<int64_t>(max_bytes, int64_t(32) << 20), cdocs = std::min<int64_t>(max_docs, std::max<int64_t>(1, chunk / 16));
-        for (int q = 0; q < 2; ++q) {
-            HIP_TRY(ws->s_bytes[q].ensure((size_t)chunk + 64, acc));
-            HIP_TRY(ws->s_offs[q].ensure((size_t)(cdocs + 1) * 8, acc));
+        for (int q = 0; q < 3; ++q) {
+            if (q < 2) {
+                HIP_TRY(ws->s_bytes[q].ensure((size_t)chunk + 64, acc));
+                HIP_TRY(ws->s_offs[q].ensure((size_t)(cdocs + 1) * 8, acc));
+            }
             HIP_TRY(ws->s_out[q].ensure((size_t)std::max<int64_t>(chunk, 1) * 4, acc));
             HIP_TRY(ws->s_outoffs[q].ensure((size_t)(cdocs + 1) * 8, acc));
         }
