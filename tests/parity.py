@@ -482,6 +482,32 @@ def check_adaptation(lib, O, vocab, ovocab, monkeypatch, pattern=N.CL100K, seed=
     run(batch(lex_a, rr))
     assert enc.adapt_stats()["retired_images"] == 0       # freed when the call that followed the swap returned
     assert enc.workspace_bytes <= mem0 + (4 << 20), (mem0, enc.workspace_bytes)
+    # a change of text that falls BETWEEN two installs (round 6): the second round's promotion lands on the change, so the miss share has no settled level to leave --
+    # it settles again on text B, ABOVE the level before that install although a round only adds pieces: a drift all the same ($TKZ_ADAPT_ROUND_BYTES: the rounds'
+    # spacing, a gigabyte by default)
+    monkeypatch.setenv("TKZ_ADAPT_ROUND_BYTES", "600000")
+    enc4 = N.Encoder(vocab, pattern)
+    enc4.set_option(N.OPT_PROMOTE_MIN_BYTES, 100_000)
+    r4 = random.Random(seed + 21)
+
+    def run4(lex):
+        docs = batch(lex, r4)
+        data, offs = pack(docs)
+        ids, ooff = enc4.encode_batch(data, offs)
+        e, eo = oracle_encode_docs(oenc, docs)
+        assert ids.tolist() == e and ooff.tolist() == eo
+        return enc4.adapt_stats()
+    st = run4(lex_a)
+    while st["promotions"] < 2:                           # (batches of ~160 KB: the first window, the settled level, then the second round 600 KB after the first began)
+        assert st["relearns"] == 0 and enc4.adapt_stats()["promotions"] >= 1, st
+        st = run4(lex_a)
+    # (the second install has just landed -- on its thread: as a rule no level has settled yet, st["settled_miss_share"] is None -- and the text changes here)
+    for i in range(6):
+        st = run4(lex_b)
+        if st["relearns"]:
+            break
+    assert st["relearns"] == 1 and i <= 3, (i, st)
+    monkeypatch.delenv("TKZ_ADAPT_ROUND_BYTES")
     # small batches add up to a learning window (the single-launch path -- up to 128 KiB -- keeps no statistics: these are just above it)
     enc2 = N.Encoder(vocab, pattern)
     enc2.set_option(N.OPT_PROMOTE_MIN_BYTES, 600_000)

@@ -231,9 +231,12 @@ struct tkz_encoder {
     // (how much text the miss share is averaged over / has to settle for after a promotion, and how soon after one the encoder may learn again; the
     //  environment variables are the tests' handle on them: their batches are kilobytes)
     int64_t adapt_settle_bytes = [] { const char* v = getenv("TKZ_ADAPT_SETTLE_BYTES"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : int64_t(64) << 20; }();
+    int64_t adapt_round_bytes = [] { const char* v = getenv("TKZ_ADAPT_ROUND_BYTES"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : int64_t(1) << 30; }();     // (the tests' handle on the rounds' spacing)
     int64_t adapt_min_bytes = [] { const char* v = getenv("TKZ_ADAPT_MIN_BYTES"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : int64_t(256) << 20; }();
     double ew_miss = 0, base_miss = 0;     // miss share of the recent batches (weighted by their bytes, 64 MB time constant); ... as it settled after the last promotion
     bool ew_valid = false, base_valid = false;
+    double prev_base = 0;                  // the level the miss share had settled at BEFORE the last install (an additive round only lowers it on unchanged text)
+    bool prev_base_valid = false;
     int64_t bytes_at_install = 0;          // bytes_seen when the key tables were last replaced
     int64_t learn_bytes = 0;               // bytes of the learning window so far (batches smaller than promo_min_bytes add up to one)
     bool memo_clear_pending = false;       // the memo is emptied before the next learning window starts (only while no other call is in flight)
@@ -548,7 +551,16 @@ bool adapt_after_batch(tkz_encoder* e, int64_t total, double misses, double piec
     if (e->learning || e->promo_rounds < 1) return false;
     const int64_t since = e->bytes_seen - e->bytes_at_install;
     if (!e->base_valid) {
-        if (since >= kAdaptSettleBytes) { e->base_miss = e->ew_miss; e->base_valid = true; }
+        if (since >= kAdaptSettleBytes) {
+            e->base_miss = e->ew_miss; e->base_valid = true;
+            // A change of text that falls BETWEEN two installs has no settled level to leave: the level is re-established on the new text.  But a round only ever ADDS
+            // pieces, so on unchanged text the new level is at or below the one before the install -- one that is a quarter (and a percentage point) ABOVE it is a drift.
+            // (tools/adapt_probe.py, synthetic -> real text with the second round's install landing on the change: the encoder kept 25 k synthetic pieces and a memo
+            //  full of them, found 2 k new ones a round and ran at 95 GB/s where a fresh encoder runs at 118.)
+            const bool drifted = e->prev_base_valid && e->base_miss > e->prev_base * 1.25 + 0.01;
+            e->prev_base = e->base_miss; e->prev_base_valid = !drifted;
+            if (drifted) return true;
+        }
         return false;
     }
     if (since < kAdaptMinBytes) return false;
@@ -704,7 +716,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             // (TKZ_OPT_ADAPT: the rounds go on -- a gigabyte after the first window began, then two, four, eight ... gigabytes after the one before: text that
             //  changed without moving the miss share, or right behind a promotion, is still learnt, a round costs one batch that counts hits and ~50 ms of a
             //  host thread; pieces are only ever ADDED by a round -- what empties the list is a drift, or the list reaching its cap: adapt_after_batch)
-            const int64_t round_gap = kPromoSecondBytes << std::min(std::max(e->promo_rounds - 1, 0), 20);
+            const int64_t round_gap = e->adapt_round_bytes << std::min(std::max(e->promo_rounds - 1, 0), 20);
             if (attempt == 0 && !ws->learning && pretok && !d_bitmap_only && e->promo_mode == 1 && !e->learning && (e->adapt || e->promo_rounds < kPromoAutoRounds) &&
                 e->T.memo_n != 0 && e->T.max_rank < (int32_t)kPromoFlag && (e->adapt || total >= e->promo_min_bytes) && e->promo_items.size() < e->promo_cap &&
                 (e->promo_rounds == 0 || e->bytes_seen - e->bytes_at_promo >= round_gap)) {
@@ -983,15 +995,23 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                     DeviceScope scope;
                     const bool dev = scope.enter(e->device) == hipSuccess;
                     if (promote) {
-                        if (dev) (void)promote_from_memo(e, true, true, nullptr);   // (a failure leaves the tables as they were)
+                        int64_t added = 0;
+                        size_t held;
+                        { std::lock_guard<std::mutex> lock(e->mu); held = e->promo_items.size(); }
+                        if (dev) (void)promote_from_memo(e, true, true, &added);   // (a failure leaves the tables as they were)
                         std::lock_guard<std::mutex> lock(e->mu);
                         e->learning = false; ++e->promo_rounds; ++e->n_promotions;
+                        // A round that found much it did not know -- more than a tenth of what the list held -- is a young encoder, or text that CHANGED without the miss
+                        // share having had a settled level to leave (the change fell between two installs): the next round then follows a gigabyte later, not
+                        // 2^rounds gigabytes.  (bench.py's drift leg, synthetic -> real text: the steps beyond 2 GB ran at 0.81 of an encoder that only ever saw
+                        // the real text, whose second round comes after 1 GB while this one's was 4 GB away.)
+                        if (e->adapt && e->promo_rounds > 1 && (size_t)added * 10 > held) e->promo_rounds = 1;
                         e->bytes_at_install = e->bytes_seen; e->ew_valid = e->base_valid = false;
                     } else {
                         if (dev) (void)drop_promotions(e, true);
                         std::lock_guard<std::mutex> lock(e->mu);
                         e->learning = false; e->promo_rounds = 0; e->learn_bytes = 0; e->memo_clear_pending = true; ++e->n_relearns;
-                        e->bytes_at_install = e->bytes_at_promo = e->bytes_seen; e->ew_valid = e->base_valid = false;
+                        e->bytes_at_install = e->bytes_at_promo = e->bytes_seen; e->ew_valid = e->base_valid = e->prev_base_valid = false;
                     }
                 };
                 bool started = false;
@@ -2004,7 +2024,7 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
         if (value == 2) return promote_from_memo(e, false, true, nullptr);
         {
             std::lock_guard<std::mutex> lock(e->mu);
-            e->promo_rounds = 0; e->learn_bytes = 0; e->bytes_at_promo = e->bytes_at_install = e->bytes_seen; e->ew_valid = e->base_valid = false;
+            e->promo_rounds = 0; e->learn_bytes = 0; e->bytes_at_promo = e->bytes_at_install = e->bytes_seen; e->ew_valid = e->base_valid = e->prev_base_valid = false;
         }
         {
             bool none;

@@ -38,6 +38,12 @@ def run(which):
     print(json.dumps({"text": which, "GBps": round(tot / dt / 1e9, 1), "ms": round(dt * 1e3, 2), **{k: s[k] for k in ("promotions", "relearns", "promoted_pieces", "settled_miss_share", "recent_miss_share")}}), flush=True)
 
 
-for which, n in (("syn", 5), ("real", 12), ("syn", 6)):
+for which, n in (("syn", 3), ("real", 16), ("syn", 6)):
     for _ in range(n):
         run(which)
+# ... and an encoder that only ever sees the real text, step for step
+enc = N.Encoder(N.Vocab(raw), pattern)
+enc.set_option(N.OPT_ADAPT, adapt)
+print(json.dumps({"text": "a fresh encoder on the real text"}), flush=True)
+for _ in range(16):
+    run("real")
