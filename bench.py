@@ -1046,7 +1046,8 @@ def main():
                         rates.append(round(best_rate, 1))
                         host_same = host_same and int(r_ooffs[-1]) == int(d_ooffs[nh].item()) and np.array_equal(r_ids[:len(h_ids)], h_ids[:len(r_ids)])
                     host_path = {"value": rates[0], "value_pinned_buffers": rates[1], "unit": "MB/s", "docs": nh, "same_ids_as_device_path": bool(host_same),
-                                 "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text, kernels and D2H of ids and offsets, chunked and overlapped on three streams; the better of two calls"}
+                                 "engine_downloads": int(enc.engine_downloads) if hasattr(enc, "engine_downloads") else None,
+                                 "note": "tkz_encode_batch_utf8 on host buffers: H2D of the text, kernels and D2H of ids and offsets; chunks of 16 MB (page-locked) / 32 MB, two launch sequences enqueued ahead, page-locked results downloaded by a copy engine of their own (engine_downloads: how many such copies this encoder has made); the better of two calls"}
                 except Exception as ex:                      # an auxiliary figure must never cost the bench line
                     host_path = {"error": "%s: %s" % (type(ex).__name__, ex)}
                 # The ITokenizer-shaped surface: tkz::TikTokenizer::EncodeBatchFlat(std::vector<std::string>) of include/tkz_tokenizer.hpp on the
