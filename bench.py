@@ -683,7 +683,13 @@ def main():
                         for name, first, first_b, second, second_b in (("synthetic_then_real", syn, sl_total, real, r_total), ("real_then_synthetic", real, r_total, syn, sl_total)):
                             e_d = N.Encoder(N.Vocab(raw_v), pat, device=local_rank)        # default options: promotions automatic, TKZ_OPT_ADAPT on
                             for _ in range(max(3, int((3 << 30) // max(1, first_b)))):
-                                first(e_d)                                                 # ~3 GB of the first text: learnt, promoted, settled
+                                first(e_d)                                                 # ~3 GB of the first text: learnt, promoted ...
+                            # ... and SETTLED: a promotion is built on a host thread (tens of milliseconds -- these batches take 3..7 ms each), so the text goes on
+                            # until what was learnt from it is in the tables and the miss share has a level (an encoder that has LEARNT the first text meets the second:
+                            # a change that falls into the build itself is the case tools/adapt_probe.py's `fast` mode shows)
+                            extra_first = 0
+                            while e_d.adapt_stats()["settled_miss_share"] is None and extra_first < 40:
+                                first(e_d); device_sync(); time.sleep(0.005); extra_first += 1
                             before = e_d.adapt_stats()
                             n2 = max(7, int((3 << 30) // max(1, second_b)))
                             series = rate_steps(e_d, second, second_b, n2)
@@ -697,7 +703,7 @@ def main():
                             med_d, med_f = tail_d[len(tail_d) // 2], tail_f[len(tail_f) // 2]
                             drift[name] = {"mbps_by_step_after_the_change": series, "mbps_by_step_fresh_encoder": fresh,
                                            "value_after_drift": med_d, "value_fresh": med_f,
-                                           "ratio": round(med_d / med_f, 3), "steps_within_2GB": k2gb,
+                                           "ratio": round(med_d / med_f, 3), "steps_within_2GB": k2gb, "first_text_batches_until_settled": extra_first,
                                            "relearns": after["relearns"] - before["relearns"], "promoted_before": before["promoted_pieces"], "promoted_after": after["promoted_pieces"],
                                            "miss_share_settled_before": before["settled_miss_share"], "miss_share_recent_after": after["recent_miss_share"]}
                             del e_d, e_f

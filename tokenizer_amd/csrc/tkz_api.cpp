@@ -144,6 +144,7 @@ struct Workspace {
     uint8_t* h_small = nullptr;
     bool fork_token = false;               // this workspace's call holds the process's one permission to use the side streams (g_fork_in_flight)
     int64_t forked_batches = 0;            // batches that ran the long pieces' kernels beside k_merge_short (tkz_encoder_side_by_side_batches)
+    int64_t last_coop = 0;                 // ... and how many of its long misses were pieces of more than 128 bytes (a wavefront each: k_merge_coop)
     int64_t last_lq_total = -1;            // entries of the class queue of the long misses in the workspace's last batch on the batch path (-1: none yet)
     hipStream_t st_side = nullptr, st_side2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;   // large batches: k_merge_long_q and k_merge_coop run beside k_merge_short (launch_encode)
     hipStream_t st_small = nullptr;        // (non-blocking: a small call never waits for another thread's batch on the legacy default stream)
@@ -235,8 +236,11 @@ struct tkz_encoder {
     int64_t adapt_min_bytes = [] { const char* v = getenv("TKZ_ADAPT_MIN_BYTES"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : int64_t(256) << 20; }();
     double ew_miss = 0, base_miss = 0;     // miss share of the recent batches (weighted by their bytes, 64 MB time constant); ... as it settled after the last promotion
     bool ew_valid = false, base_valid = false;
-    double prev_base = 0;                  // the level the miss share had settled at BEFORE the last install (an additive round only lowers it on unchanged text)
-    bool prev_base_valid = false;
+    double win_miss = 0, win_pieces = 0;   // misses and pieces of the learning window so far ...
+    double window_miss = 0;                // ... and the miss share of the window the LAST install was learnt in (promotions only lower it on unchanged text)
+    bool window_valid = false;
+    double last_window_miss = 0;           // the same, kept for the NEXT window to be compared with
+    bool last_window_valid = false;
     int64_t bytes_at_install = 0;          // bytes_seen when the key tables were last replaced
     int64_t learn_bytes = 0;               // bytes of the learning window so far (batches smaller than promo_min_bytes add up to one)
     bool memo_clear_pending = false;       // the memo is emptied before the next learning window starts (only while no other call is in flight)
@@ -553,12 +557,13 @@ bool adapt_after_batch(tkz_encoder* e, int64_t total, double misses, double piec
     if (!e->base_valid) {
         if (since >= kAdaptSettleBytes) {
             e->base_miss = e->ew_miss; e->base_valid = true;
-            // A change of text that falls BETWEEN two installs has no settled level to leave: the level is re-established on the new text.  But a round only ever ADDS
-            // pieces, so on unchanged text the new level is at or below the one before the install -- one that is a quarter (and a percentage point) ABOVE it is a drift.
-            // (tools/adapt_probe.py, synthetic -> real text with the second round's install landing on the change: the encoder kept 25 k synthetic pieces and a memo
-            //  full of them, found 2 k new ones a round and ran at 95 GB/s where a fresh encoder runs at 118.)
-            const bool drifted = e->prev_base_valid && e->base_miss > e->prev_base * 1.25 + 0.01;
-            e->prev_base = e->base_miss; e->prev_base_valid = !drifted;
+            // A change of text that falls between a learning window and the install of what it learnt -- a promotion is built on a host thread, tens of
+            // milliseconds, gigabytes of text at this rate -- has no settled level to leave: the level settles on the new text.  But an install only ever ADDS
+            // pieces, so on the text it was learnt from the level it leaves is at or below the WINDOW's own miss share; one that is a quarter (and a percentage
+            // point) ABOVE it means those promotions answer another text: a drift.  (bench.py's drift leg, 3 GB of synthetic text in 15 ms and real text
+            //  behind it: the first install landed ten real batches later, no drift was ever seen, and the encoder ran at 0.77 of a fresh one.)
+            const bool drifted = e->window_valid && e->base_miss > e->window_miss * 1.25 + 0.01;
+            e->window_valid = false;
             if (drifted) return true;
         }
         return false;
@@ -695,7 +700,15 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         // each of the 4,096 wavefronts the chip holds --; with a long queue (mixed text: 17 M entries in 1 GB) the queue kernel is the step's largest and needs the whole chip
         // (measured with the tail grids: 17.0 -> 19.8 ms), and on the bench text (1.3 M) the two forms are equal (20.6 / 20.8 ms).
         static const int64_t kForkMaxLong = [] { const char* v = getenv("TKZ_FORK_MAX_LONG"); return v ? (int64_t)atoll(v) : int64_t(1) << 20; }();
-        if (total > e->latency_bytes && !kNoFork && ws->last_lq_total >= 0 && ws->last_lq_total <= kForkMaxLong) {
+        // (round 6, last session) ... or up to twice that many when one in 2,048 of them is a piece of more than 128 bytes: such a queue ends in a tail of slow wavefronts
+        // whatever its length.  436 MB of source text (1.18 M long misses, 1,467 of them of 129+ bytes): 94.5 -> 104.3 GB/s side by side; the bench text (1.31-1.43 M, none
+        // above 128 bytes) loses 0.1-0.3 ms that way and stays serial.  profiles/r06/variants_side_by_side2.txt
+        static const int64_t kForkMaxLongTail = [] { const char* v = getenv("TKZ_FORK_MAX_LONG_TAIL"); return v ? (int64_t)atoll(v) : int64_t(1) << 21; }();
+        static const int64_t kForkTailShare = [] { const char* v = getenv("TKZ_FORK_TAIL_SHARE"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : int64_t(2048); }();
+        static const bool kTraceFork = getenv("TKZ_TRACE_FORK") != nullptr;
+        if (kTraceFork && attempt == 0 && total > e->latency_bytes) fprintf(stderr, "[tkz fork] bytes %lld: the batch before left %lld long misses, %lld of more than 128 bytes\n", (long long)total, (long long)ws->last_lq_total, (long long)ws->last_coop);
+        const bool short_queue = ws->last_lq_total >= 0 && (ws->last_lq_total <= kForkMaxLong || (ws->last_lq_total <= kForkMaxLongTail && ws->last_coop * kForkTailShare >= ws->last_lq_total));
+        if (total > e->latency_bytes && !kNoFork && short_queue) {
             if (!ws->fork_token) { int none = 0; ws->fork_token = g_fork_in_flight.compare_exchange_strong(none, 1); }      // (given back when the call ends: ~Lease)
             bool ok = ws->fork_token;
             for (hipStream_t* st : {&ws->st_side, &ws->st_side2}) if (!*st && hipStreamCreateWithFlags(st, hipStreamNonBlocking) != hipSuccess) { *st = nullptr; ok = false; }
@@ -896,6 +909,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
         if (err & kErrTooLong) return fail(TKZ_E_UNSUPPORTED, "a single piece longer than 2^30 bytes");
         marks_ready = true;                // (what is wrong from here on is the size of a buffer)
         if (!d_bitmap_only) ws->sized = true;
+        if (!d_bitmap_only && !sizing && total > e->latency_bytes) ws->last_coop = (int64_t)ws->h_counters->coop_count;
         if (!d_bitmap_only && !sizing && total > e->latency_bytes) ws->last_lq_total = ws->h_counters->lq_total;      // (the next batch's form of the long pieces' kernels: above)
         if (sizing) {
             // k_place's form for THIS batch from the sample (it is otherwise chosen from the batch before: a fresh encoder's first miss-heavy batch ran
@@ -981,13 +995,27 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                 e->bytes_seen += total;
                 if (ws->learning) {
                     e->learn_bytes += total;
+                    e->win_miss += (double)(ws->h_counters->miss_short + ws->h_counters->miss_long); e->win_pieces += (double)ws->h_counters->npieces;
                     promote = !e->adapt || e->learn_bytes >= e->promo_min_bytes;
                     if (!promote) { ws->learning = false; e->learning = false; }      // (the window goes on with the next batch)
+                    else if (e->adapt && e->last_window_valid && e->win_pieces >= 1 && e->win_miss / e->win_pieces > e->last_window_miss * 1.25 + 0.01) {
+                        // A window whose miss share is a quarter (and a point) ABOVE the window's before it -- although that one's promotions have been installed since,
+                        // and promotions only lower the share on unchanged text -- was counted on ANOTHER text, with a memo full of the old one's pieces (it takes no
+                        // new entry into a full bucket): what it found is a fraction of what a fresh encoder finds (2 k against 9 k pieces on the source text behind 3 GB
+                        // of synthetic text).  A drift: start over -- this window's counts are dropped with the promotions, the memo is emptied, the next batch begins a window.
+                        promote = false; relearn = true; ws->learning = false;
+                        e->learn_bytes = 0; e->win_miss = e->win_pieces = 0;
+                    }
                 } else relearn = adapt_after_batch(e, total, (double)(ws->h_counters->miss_short + ws->h_counters->miss_long), (double)ws->h_counters->npieces);
                 if (relearn) e->learning = true;                                     // (nothing learns while the promotions are being dropped)
             }
             if (promote || relearn) {
-                if (promote) { std::lock_guard<std::mutex> lock(e->mu); ws->learning = false; e->learn_bytes = 0; }
+                if (promote) {
+                    std::lock_guard<std::mutex> lock(e->mu);
+                    ws->learning = false; e->learn_bytes = 0;
+                    e->window_valid = e->win_pieces >= 1; e->window_miss = e->window_valid ? e->win_miss / e->win_pieces : 0; e->win_miss = e->win_pieces = 0;
+                    e->last_window_valid = e->window_valid; e->last_window_miss = e->window_miss;
+                }
                 // (the workspace is this call's no longer once it returns; the counters, the log and the memo are the encoder's, and no other batch writes the
                 //  first two while e->learning is set)
                 join_promotion(e);                 // (the previous one ended before this batch could be armed: this only reaps the thread)
@@ -1011,7 +1039,7 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
                         if (dev) (void)drop_promotions(e, true);
                         std::lock_guard<std::mutex> lock(e->mu);
                         e->learning = false; e->promo_rounds = 0; e->learn_bytes = 0; e->memo_clear_pending = true; ++e->n_relearns;
-                        e->bytes_at_install = e->bytes_at_promo = e->bytes_seen; e->ew_valid = e->base_valid = e->prev_base_valid = false;
+                        e->bytes_at_install = e->bytes_at_promo = e->bytes_seen; e->ew_valid = e->base_valid = e->window_valid = e->last_window_valid = false; e->win_miss = e->win_pieces = 0;
                     }
                 };
                 bool started = false;
@@ -2024,7 +2052,7 @@ tkz_status tkz_encoder_set_option(tkz_encoder* e, int32_t option, int64_t value)
         if (value == 2) return promote_from_memo(e, false, true, nullptr);
         {
             std::lock_guard<std::mutex> lock(e->mu);
-            e->promo_rounds = 0; e->learn_bytes = 0; e->bytes_at_promo = e->bytes_at_install = e->bytes_seen; e->ew_valid = e->base_valid = e->prev_base_valid = false;
+            e->promo_rounds = 0; e->learn_bytes = 0; e->bytes_at_promo = e->bytes_at_install = e->bytes_seen; e->ew_valid = e->base_valid = e->window_valid = e->last_window_valid = false; e->win_miss = e->win_pieces = 0;
         }
         {
             bool none;

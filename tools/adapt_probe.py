@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """TKZ_OPT_ADAPT under a text that changes: per-step rate and the encoder's bookkeeping (tkz_encoder_adapt_stats) while ONE encoder goes from the
-synthetic corpus to the box's real text and back.  usage: adapt_probe.py [vocab=gpt2] [pattern=1] [adapt=1]   -> JSON lines"""
+synthetic corpus to the box's real text and back.  usage: adapt_probe.py [vocab=gpt2] [pattern=1] [adapt=1] [fast=0]   -> JSON lines"""
 import gzip, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -38,7 +38,11 @@ def run(which):
     print(json.dumps({"text": which, "GBps": round(tot / dt / 1e9, 1), "ms": round(dt * 1e3, 2), **{k: s[k] for k in ("promotions", "relearns", "promoted_pieces", "settled_miss_share", "recent_miss_share")}}), flush=True)
 
 
-for which, n in (("syn", 3), ("real", 16), ("syn", 6)):
+fast = int(sys.argv[4]) if len(sys.argv) > 4 else 0       # 1: the three synthetic batches back to back, as bench.py's drift leg feeds them (15 ms: the first promotion is still being built when the text changes)
+if fast:
+    for _ in range(3):
+        enc.encode_batch_device(d_bytes.data_ptr(), d_offs.data_ptr(), n_docs, total, d_ids.data_ptr(), total, d_oo.data_ptr(), st)
+for which, n in ((("real", 24), ("syn", 6)) if fast else (("syn", 3), ("real", 16), ("syn", 6))):
     for _ in range(n):
         run(which)
 # ... and an encoder that only ever sees the real text, step for step
