@@ -113,8 +113,10 @@ tkz_status tkz_encoder_unicode_classes(tkz_encoder* e, uint32_t first, int32_t n
 tkz_status tkz_encoder_set_unicode_classes(tkz_encoder* e, const uint8_t* classes, int64_t n_code_points);
 
 /* Page-locked host memory for the buffers a host hands to the host-buffer entry points: copies from and to it run asynchronously at
- * the PCIe rate (tkz_encode_batch_utf8 overlaps the upload of one document range with the kernels of the previous one and the download
- * of the one before; from pageable memory every copy is staged by the runtime first: about half the rate).  A host without a HIP
+ * the PCIe rate (tkz_encode_batch_utf8 cuts a batch of 12 MB or more into document ranges of 16 MB, keeps two launch sequences enqueued ahead and
+ * overlaps the upload of a range with the kernels of the two before it and the download of the one before those -- results in memory from this
+ * function leave on a copy engine of their own, tkz_encoder_engine_downloads; from pageable memory every copy is staged by the runtime first:
+ * about half the rate).  A host without a HIP
  * binding of its own (C#, a plain C++ program) gets such memory here.  The memory is page-locked for every HIP device of the process
  * (hipHostMallocPortable), whichever device is current at the call.  tkz_host_free(NULL) is a no-op. */
 tkz_status tkz_host_alloc(size_t bytes, void** out);
