@@ -487,11 +487,13 @@ tkz_status promote_from_memo(tkz_encoder* e, bool use_hits, bool retire, int64_t
     }
     struct Cand { uint32_t hits, slot; };
     std::vector<Cand> cand;
+    uint32_t n_valid = 0;
     for (uint32_t i = 0; i < e->memo_slots; ++i) {
         const uint32_t* v = memo[i].v;
         // the kernels' validity rule: the valid tag in every value word, not the BUSY mark; and a complete key: no zero byte inside its length, nothing
         // but zero bytes beyond it (other calls may be inserting while this copy was taken)
         if (!((v[0] & v[1] & v[2] & v[3]) & kMemoValid) || v[0] == kMemoBusy) continue;
+        ++n_valid;
         if (use_hits && hits[i] == 0) continue;
         const uint32_t len = ((v[1] >> 27) & 15u) + 1u;
         bool ok = true;
@@ -499,6 +501,12 @@ tkz_status promote_from_memo(tkz_encoder* e, bool use_hits, bool retire, int64_t
         if (!ok) continue;
         cand.push_back(Cand{use_hits ? hits[i] : 1u, i});
     }
+    // A memo three quarters full takes hardly any new piece (an entry is never replaced; a bucket has two ways): text with many one-off pieces fills it within a
+    // gigabyte, and whatever the text turns into afterwards finds it closed -- the reference's LRUCache would have evicted (LRUCache.cs:79-88).  The next learning
+    // window therefore starts on an EMPTY memo (memo_clear_pending: cleared under the lock while no other call is in flight, as after a drift): the hot pieces are
+    // back within the first megabytes of that batch, the one-off ones are gone.  (tools/adapt_probe.py ... 1: source text behind 3 GB of synthetic text, the change
+    // inside the first promotion's build: 95 GB/s and 2 k new pieces a round with the full memo, against a fresh encoder's 118 and 9 k.)
+    if (use_hits && e->adapt && (uint64_t)n_valid * 4 >= (uint64_t)e->memo_slots * 3) e->memo_clear_pending = true;
     std::stable_sort(cand.begin(), cand.end(), [](const Cand& a, const Cand& b) { return a.hits > b.hits; });
     for (const Cand& c : cand) {
         if (e->promo_items.size() >= cap) break;
