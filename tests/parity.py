@@ -528,6 +528,61 @@ def check_adaptation(lib, O, vocab, ovocab, monkeypatch, pattern=N.CL100K, seed=
     assert enc3.adapt_stats()["promotions"] == 0 and enc3.adapt_stats()["promoted_pieces"] == 0
 
 
+def check_memo_refresh(lib, O, vocab, ovocab, monkeypatch, pattern=N.CL100K, seed=77):
+    """The memo does not evict -- an entry is never replaced --, so text with many one-off pieces fills it and whatever the text turns into finds it closed.
+    TKZ_OPT_ADAPT (round 6): a learning round that reads the memo back three quarters full has it emptied at the start of the next learning window (the
+    reference's LRUCache evicts, LRUCache.cs:79-88).  A memo of 4,096 slots, text A with 6,000 different missed pieces, then text B with 250 that repeat: with
+    the rule B's pieces are answered by the memo (or promoted), without it (TKZ_OPT_ADAPT 0) nearly every occurrence is merged again.  Ids = the oracle's throughout."""
+    monkeypatch.setenv("TKZ_MEMO_SLOTS_LOG2", "12")
+    monkeypatch.setenv("TKZ_ADAPT_ROUND_BYTES", "300000")
+    monkeypatch.setenv("TKZ_ADAPT_SETTLE_BYTES", "100000")
+    monkeypatch.setenv("TKZ_ADAPT_MIN_BYTES", "300000")
+    cons, vow = "bcdfghjklmnpqrstvwxz", "aeiou"
+    r0 = random.Random(seed)
+
+    def word(r):
+        return "".join(r.choice(cons) + r.choice(vow) for _ in range(r.randint(3, 5))) + r.choice(["", "s", "ed"])
+    one_off = [word(r0) for _ in range(6000)]
+    lex_b = [word(random.Random(seed + 1)) + "q" for _ in range(250)]
+    oenc = O.Encoder(ovocab, pattern)
+
+    def batch(lex, r, nbytes=170_000):
+        docs, size = [], 0
+        while size < nbytes:
+            words, n = [], r.choice([2000, 9000])
+            while sum(map(len, words)) < n:
+                words.append(r.choice([" ", " ", "\n"]) + (r.choice(["the", "and", "with"]) if r.random() < 0.3 else r.choice(lex)))
+            docs.append("".join(words).encode("utf-8"))
+            size += len(docs[-1])
+        return docs
+    merged = {}
+    for adapt in (1, 0):
+        enc = N.Encoder(vocab, pattern)
+        assert enc.memo_slots == 4096
+        enc.set_option(N.OPT_PROMOTE_MIN_BYTES, 100_000)
+        enc.set_option(N.OPT_ADAPT, adapt)
+        rr = random.Random(seed + 5)
+
+        def run(docs):
+            data, offs = pack(docs)
+            ids, ooff = enc.encode_batch(data, offs)
+            e, eo = oracle_encode_docs(oenc, docs)
+            assert ids.tolist() == e and ooff.tolist() == eo
+            return enc.adapt_stats()
+        for _ in range(6):                                 # text A: the memo fills in the first batch; two rounds (the second one starts on an emptied memo and fills it again)
+            st = run(batch(one_off, rr))
+        assert st["promotions"] >= (2 if adapt else 1), st
+        for _ in range(10):                                # text B: with TKZ_OPT_ADAPT its next window empties the memo once more -- and B's pieces get in
+            st = run(batch(lex_b, rr))
+        enc.set_option(N.OPT_PROMOTE, 0)
+        enc.set_option(N.OPT_PIECE_STATS, 1)
+        enc.piece_stats(reset=True)
+        run(batch(lex_b, random.Random(seed + 9)))
+        merged[adapt] = enc.piece_stats(reset=True)["merged_short"]
+    print("merged_short with / without the rule:", merged)
+    assert merged[1] * 2 < merged[0], merged
+
+
 def check_piece_memo(lib, O, vocab, ovocab, pattern=N.CL100K, seed=23):
     """The piece memo (TKZ_OPT_PIECE_MEMO): the same ids with the memo off, empty, filled by an earlier batch of the same text (every
     short miss a hit), and filled by OTHER text (hits and misses mixed, slots already taken by other pieces)."""

@@ -154,6 +154,11 @@ def test_cache_adapts_to_drift(lib, vocabs, oracle_mod, monkeypatch):
     parity.check_adaptation(lib, oracle_mod, v, ov, monkeypatch)
 
 
+def test_memo_is_refreshed_when_full(lib, vocabs, oracle_mod, monkeypatch):
+    v, ov = vocabs("gpt2")
+    parity.check_memo_refresh(lib, oracle_mod, v, ov, monkeypatch)
+
+
 def test_host_runtime_defines_the_split(lib, vocabs, oracle_mod):
     v, ov = vocabs("gpt2")
     parity.check_runtime_overrides(lib, oracle_mod, v, ov)

@@ -1658,7 +1658,9 @@ tkz_status tkz_encoder_create(const tkz_vocab* v, int32_t pattern, int32_t devic
 #ifndef TKZ_MEMO_SLOTS_LOG2
 #define TKZ_MEMO_SLOTS_LOG2 19
 #endif
-        constexpr uint32_t kMemoSlots = 1u << TKZ_MEMO_SLOTS_LOG2;
+        // ($TKZ_MEMO_SLOTS_LOG2 in the environment, 10..22: the tests' handle on it -- a memo that a few thousand pieces fill)
+        uint32_t kMemoSlots = 1u << TKZ_MEMO_SLOTS_LOG2;
+        { const char* v = getenv("TKZ_MEMO_SLOTS_LOG2"); const int n = v ? atoi(v) : 0; if (n >= 10 && n <= 22) kMemoSlots = 1u << n; }
         h = e->t_memo.ensure(size_t(kMemoSlots) * sizeof(TkzMemoSlot), acc);
         if (h == hipSuccess) h = hipMemset(e->t_memo.p, 0, size_t(kMemoSlots) * sizeof(TkzMemoSlot));
         if (h != hipSuccess) { tkz_encoder_destroy(e); return fail(TKZ_E_OUT_OF_MEMORY, std::string("piece memo: ") + hipGetErrorString(h)); }
