@@ -186,6 +186,8 @@ struct Workspace {
     }
 };
 
+constexpr int64_t kPromoSecondBytes = int64_t(1) << 30;      // the second learning round follows the first window by this much text (then 2, 4, 8 ... times: encode_device)
+
 struct tkz_encoder {
     int device = 0;
     int pattern = 0;
@@ -232,7 +234,7 @@ struct tkz_encoder {
     // (how much text the miss share is averaged over / has to settle for after a promotion, and how soon after one the encoder may learn again; the
     //  environment variables are the tests' handle on them: their batches are kilobytes)
     int64_t adapt_settle_bytes = [] { const char* v = getenv("TKZ_ADAPT_SETTLE_BYTES"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : int64_t(64) << 20; }();
-    int64_t adapt_round_bytes = [] { const char* v = getenv("TKZ_ADAPT_ROUND_BYTES"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : int64_t(1) << 30; }();     // (the tests' handle on the rounds' spacing)
+    int64_t adapt_round_bytes = [] { const char* v = getenv("TKZ_ADAPT_ROUND_BYTES"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : kPromoSecondBytes; }();     // (the tests' handle on the rounds' spacing)
     int64_t adapt_min_bytes = [] { const char* v = getenv("TKZ_ADAPT_MIN_BYTES"); return v && atoll(v) > 0 ? (int64_t)atoll(v) : int64_t(256) << 20; }();
     double ew_miss = 0, base_miss = 0;     // miss share of the recent batches (weighted by their bytes, 64 MB time constant); ... as it settled after the last promotion
     bool ew_valid = false, base_valid = false;
@@ -369,7 +371,6 @@ tkz_status build_decode_table(tkz_encoder* e) {
 // slot is read back under the same validity rule the kernels use); the tests compare a promoted encoder with the oracle.
 constexpr int64_t kLongLogCap = 65536;             // records of merged 17..28-byte pieces a learning batch may log (EncodeParams::long_log)
 constexpr int kPromoAutoRounds = 2;                // automatic promotions: the first batch of >= kPromoMinBytes, and one more after kPromoSecondBytes more
-constexpr int64_t kPromoSecondBytes = int64_t(1) << 30;
 
 // (re)builds the SHORT / MID images from the vocabulary's keys + the promoted pieces and publishes them; `retire`: other calls may be probing the
 // current images (they are kept until the encoder is destroyed), else they are freed
