@@ -19,7 +19,7 @@ for spec in ${SPECS:-"-1:0:0" "-2:0:0" "-2:32:0" "-2:8:4" "-2:16:4"}; do
   if [ -z "${NO_PCIE:-}" ]; then timeout 300 python tools/pcie_probe.py > $O/pcie_$T.txt 2>&1; grep -E "pinned call|pageable call" $O/pcie_$T.txt | tail -4 | tr '\n' ';'; echo; fi
 done
 if [ -n "${TRACE_MB:-}" ]; then
-  # (under rocprofv3 the downloads fall back to the runtime's copies: the trace shows the kernels and uploads; TKZ_TRACE_HOST shows the host's side)
+  # (under rocprofv3 the downloads have been seen to fall back to the runtime's copies -- profiles/r06/sdma_engines.txt is the untraced timing; TKZ_TRACE_HOST shows the host's side)
   for mb in $TRACE_MB; do
     ( cd /tmp && export TMPDIR=/tmp TKZ_TRACE_HOST=1 && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $REPO/$O/midtrace_${mb} -- python $REPO/tools/midsize_trace.py run $mb 12 ) > $O/midtrace_${mb}.json 2> $O/midtrace_${mb}.err
     tail -1 $O/midtrace_${mb}.json; tail -1 $O/midtrace_${mb}.err; python tools/midsize_trace.py show $O/midtrace_${mb} > $O/midtrace_${mb}.txt; find $O/midtrace_${mb} -name "*.csv" -size +2M -delete
