@@ -479,7 +479,13 @@ def test_host_path_chunked_and_threads(lib, vocabs, oracle_mod):
     assert np.array_equal(ids, want_ids) and np.array_equal(ooff, want_offs)
     print("host path, page-locked buffers: %.1f GB/s" % (len(h_bytes) / dt / 1e9))
     # the chunks' results left on a copy engine of their own (csrc/tkz_sdma.cpp): ids + offsets of every chunk -- unless the run switched that off
-    if os.environ.get("TKZ_D2H_ENGINE") != "-1":
+    # (where the HSA runtime under HIP has the entry point at all: the path is optional by design, csrc/tkz_sdma.h)
+    import ctypes
+    try:
+        has_engine_copy = hasattr(ctypes.CDLL("libhsa-runtime64.so.1"), "hsa_amd_memory_async_copy_on_engine")
+    except OSError:
+        has_engine_copy = False
+    if os.environ.get("TKZ_D2H_ENGINE") != "-1" and has_engine_copy:
         assert enc.engine_downloads >= 2 * (len(h_bytes) // (24 << 20)), enc.engine_downloads
     # mid-size page-locked batches: 20 MB (chunks of a quarter of the batch), 3 MB (one chunk, fetched by k_ingest, ids
     # written by k_place itself) -- twice each: a fresh workspace, then a sized one
