@@ -816,7 +816,9 @@ tkz_status encode_device(tkz_encoder* e, Workspace* ws, const uint8_t* d_bytes, 
             //  pieces of 33..128 bytes to k_merge_coop as well was tried: 115 us in that kernel for what the lanes do in 6 -- a wavefront takes ~30 us a piece)
             P.lane_piece = kLanePiece;
             P.latency = total <= e->latency_bytes ? 1 : 0;
-            P.tc_atomic = L.side ? 1 : 0;
+            // (... and in a small batch, whose three merge stages run as ONE launch: k_merge_latency.  $TKZ_NO_LATENCY_FUSE: the three launches, development A/B)
+            static const bool kNoLatencyFuse = getenv("TKZ_NO_LATENCY_FUSE") != nullptr;
+            P.tc_atomic = (L.side || (P.latency && !kNoLatencyFuse)) ? 1 : 0;
             if (L.side && !sizing) ++ws->forked_batches;
             P.coop_cap = total / P.lane_piece + 64;
             HIP_TRY(ws->w_coopq.ensure((size_t)P.coop_cap * 8, acc));

@@ -1793,9 +1793,9 @@ constexpr int kCoopGrid = 4;          // (the CPU emulator pays for every idle w
 #else
 constexpr int kCoopGrid = 2048;
 #endif
-TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
-    if (tkz_attempt_failed(P)) return;
-    TKZ_SHARED uint4 s_lds[(kCoopLdsBytes + 15) / 16];
+constexpr int kCoopLdsQuads = (kCoopLdsBytes + 15) / 16;
+// one wavefront, number `bid` of `nblocks`, over the queue (the body of k_merge_coop; k_merge_latency runs it beside the other two merge stages)
+TKZ_DEV void tkz_merge_coop_queue(const TkzTables& T, const EncodeParams& P, uint4* s_lds, unsigned long long bid, unsigned long long nblocks) {
     int32_t* ids = reinterpret_cast<int32_t*>(s_lds);
     int32_t* pr = ids + kArenaPiece;
     uint32_t* alive = reinterpret_cast<uint32_t*>(pr + kArenaPiece);
@@ -1810,9 +1810,9 @@ TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
     const unsigned long long count = *P.coop_count < (unsigned long long)P.coop_cap ? *P.coop_count : (unsigned long long)P.coop_cap;
     bool first = true;
     for (;;) {
-        unsigned long long tk = (unsigned long long)simt::bid();
+        unsigned long long tk = bid;
         if (!first) {
-            if (lane == 0) tk = (unsigned long long)simt::nblocks() + simt::atomic_add64(P.coop_ticket, 1ull);
+            if (lane == 0) tk = nblocks + simt::atomic_add64(P.coop_ticket, 1ull);
             tk = ((unsigned long long)simt::shflu((uint32_t)(tk >> 32), 0) << 32) | simt::shflu((uint32_t)tk, 0);
         }
         first = false;
@@ -1840,6 +1840,36 @@ TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
         simt::sync();
     }
     if (err) simt::atomic_or((unsigned*)&P.counters[0], (unsigned)err);
+}
+TKZ_KERNEL(64) void k_merge_coop(TkzTables T, EncodeParams P) {
+    if (tkz_attempt_failed(P)) return;
+    TKZ_SHARED uint4 s_lds[kCoopLdsQuads];
+    tkz_merge_coop_queue(T, P, s_lds, (unsigned long long)simt::bid(), (unsigned long long)simt::nblocks());
+}
+
+// A SMALL batch (TKZ_OPT_LATENCY_BYTES) waits for the slowest wavefront of every kernel and for every dispatch: its two large merge stages -- the short misses, the
+// long ones in the chunk form -- touch different list entries and add their tokens to the sub-tiles' counts with atomics (EncodeParams::tc_atomic: k_probe has
+// zeroed them), so they run as ONE launch: workgroups [0, nb_short) are k_merge_short's, block for block (four groups of 16 sub-tiles each, the same XCD order:
+// the piece memo is shared through an XCD's L2 -- a wavefront a workgroup, spread over the eight XCDs, cut a 160 KB batch's memo hits from most lookups to 6 %),
+// workgroups [nb_short, nb_short + nb_long) take the units of the long lists, a wavefront each.  A 1 MB call: k_merge_short 33 us + k_merge_long 45 us one after
+// the other, each behind its own dispatch; 240 -> 210 us a call.
+constexpr int kMergeLatWaveQuads = kMsLdsQuads > kLongLdsQuads ? kMsLdsQuads : kLongLdsQuads;
+template <bool COMPACT>
+TKZ_KERNEL_OCC(kMsThreads, 3) void k_merge_latency(TkzTables T, EncodeParams P, int nb_short, int nb_long) {
+    if (tkz_attempt_failed(P)) return;
+    TKZ_SHARED uint4 s_wave[kMsThreads / 64][kMergeLatWaveQuads];
+    TKZ_SHARED uint16_t s_brank16[256];
+    const int b = (int)simt::bid();
+    if (b < nb_short) {                                     // (wave-uniform, block-uniform: the barrier below is reached by the whole workgroup or not at all)
+        tkz_ms_brank_init(T, s_brank16);
+        simt::sync();
+        const int64_t grp = tkz_xcd_block(b, nb_short) * (kMsThreads / 64) + simt::wave();
+        tkz_merge_short_group(T, P, grp, tkz_ms_lds(s_wave[simt::wave()], s_brank16));
+    } else {
+        const LongLds LD = tkz_long_lds(s_wave[simt::wave()]);
+        tkz_long_brank_init(T, LD.brank);
+        tkz_merge_long_chunks<COMPACT, kLongPartsLatency, -1>(T, P, (int64_t)(b - nb_short) * (kMsThreads / 64) + simt::wave(), (int64_t)nb_long * (kMsThreads / 64), LD, P.lane_piece);
+    }
 }
 
 // ids at their final position: count per record -> prefix -> the sub-tile's ids staged in LDS -> stored as whole 16-byte quads (one
@@ -3112,6 +3142,23 @@ void launch_encode(const Launch& L, const TkzTables& T, const EncodeParams& P, i
         const int64_t cgrid = latency ? 512 : cdiv(nsub, 64);
         TKZ_LAUNCH(k_merge_coop, cgrid < cap ? cgrid : cap, 64, st, T, P);
     };
+    // (a small batch whose token counts are summed with atomics: the three merge stages as one launch, behind the giant pieces -- k_merge_latency)
+    const bool fused = !fork && P.latency != 0 && P.tc_atomic != 0 && P.lq != nullptr;
+    if (fused) {
+        hook(L, K_HEAVY, 0);
+        TKZ_LAUNCH(k_giant_order, 1, 1024, L.stream, P);
+        TKZ_LAUNCH(k_giant_merge, kGiantGrid, 1024, L.stream, T, P);
+        hook(L, K_HEAVY, 1);
+        const int64_t nb_short = xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), chunks = cdiv(nsub, 64) * kLongPartsLatency, nb_long = cdiv(chunks < 65536 ? chunks : 65536, kMsThreads / 64);
+        hook(L, K_MERGE_SHORT, 0);
+        if (T.max_rank <= kVarCompactMaxRank) TKZ_LAUNCH((k_merge_latency<true>), nb_short + nb_long, kMsThreads, L.stream, T, P, (int)nb_short, (int)nb_long);
+        else TKZ_LAUNCH((k_merge_latency<false>), nb_short + nb_long, kMsThreads, L.stream, T, P, (int)nb_short, (int)nb_long);
+        // (the queue of the 129+-byte pieces stays a launch of its own BEHIND the chunk form of the long lists, as it always was: inside the same launch its pieces came
+        //  out wrong on the GPU -- test_pieces_vs_oracle_bpe, test_mid_pieces_share_the_arena -- while the emulator, whose workgroups take turns, saw nothing)
+        coop(L.stream, kCoopGrid);
+        hook(L, K_MERGE_SHORT, 1);
+        return;
+    }
     if (!fork) {                   // (the serial form keeps k_merge_short in front, as it always was)
         hook(L, K_MERGE_SHORT, 0);
         TKZ_LAUNCH(k_merge_short, xcd_grid(cdiv(nsub, (kMsThreads / 64) * kGroup)), kMsThreads, L.stream, T, P);
