@@ -328,7 +328,8 @@ enum { TKZ_K_DOCMARK = 0, TKZ_K_PRETOK = 1, TKZ_K_PROBE = 2 /* k_probe alone */,
  * k_doccount2 and the scan of its counts, k_list_stats (which also finds the giant pieces and fills k_merge_coop's queue).
  * A batch that runs the long pieces' kernels beside k_merge_short (tkz_encoder_side_by_side_batches) has k_merge_long_q and k_merge_coop INSIDE the
  * TKZ_K_MERGE_SHORT bracket -- the three side by side, from the fork to the join -- and only what runs in front of them (the giant pieces, the class
- * queue's counting, scan and scatter) in TKZ_K_MERGE_LONG. */
+ * queue's counting, scan and scatter) in TKZ_K_MERGE_LONG.  A batch of at most TKZ_OPT_LATENCY_BYTES likewise: its TKZ_K_MERGE_SHORT bracket is k_merge_latency
+ * (k_merge_short's workgroups and the chunk form of k_merge_long in one launch) + k_merge_coop, its TKZ_K_MERGE_LONG bracket the giant pieces' two kernels. */
 tkz_status tkz_encoder_set_profiling(tkz_encoder* e, int32_t enabled);
 tkz_status tkz_encoder_kernel_ms(tkz_encoder* e, double* ms, int64_t* launches, int32_t reset);
 /* o200k only, informational: of the 4 KiB blocks of the last batch, how many the ASCII block scanner handed on (blocks with multi-byte
